@@ -1,0 +1,184 @@
+"""Pin the CPU oracle (oracle/rnad_oracle.c) against fixtures captured from the imported reference.
+
+CPU-only.  Integer/index results must be bit-exact; float results are compared bitwise where the
+oracle replays the reference's op order (observe, transition rewards, process_policy, v_trace) and
+to 1e-5 elsewhere (anything through exp/log or a long reduction).
+"""
+import json
+
+import numpy as np
+import pytest
+
+from _util import TREES, assert_bits_equal, load, load_tree, mlp_weights
+from oracle import oracle
+
+TOL = 1e-5
+
+
+@pytest.mark.parametrize("name", TREES)
+def test_observe_and_masks(name):
+    tree, ro = load_tree(name), load("rollout_" + name)
+    T = int(ro["t_eff"]) + 1
+    for t in range(T):
+        obs, mask = oracle.observe(tree["expected_value"], tree["legal"], ro["indices"][t], ro["turns"][t])
+        assert_bits_equal(obs, ro["observations"][t], f"obs t={t}")  # includes the -0.0 of the column view
+        assert_bits_equal(mask, ro["masks"][t], f"mask t={t}")
+
+
+@pytest.mark.parametrize("name", TREES)
+def test_sampler_and_transition_bit_exact(name):
+    tree, ro = load_tree(name), load("rollout_" + name)
+    T = int(ro["t_eff"]) + 1
+    act = ro["actions"].argmax(-1)
+    assert (ro["actions"].sum(-1) == 1).all()
+    for t in range(T):
+        a = oracle.sample(ro["policy"][t], ro["noise_action"][t])
+        np.testing.assert_array_equal(a, act[t])
+        if t % 2 == 1:
+            nxt, rew = oracle.transition(tree["index"], tree["chance"], tree["value"], ro["indices"][t], act[t - 1],
+                                         act[t], ro["noise_chance"][t])
+            if t + 1 < T:
+                np.testing.assert_array_equal(nxt, ro["indices"][t + 1])
+            else:
+                assert (nxt == 0).all()
+            assert_bits_equal(rew, ro["rewards"][t], f"reward t={t}")
+        else:
+            assert (ro["rewards"][t] == 0).all()
+            if t + 1 < T:
+                np.testing.assert_array_equal(ro["indices"][t + 1], ro["indices"][t])
+
+
+@pytest.mark.parametrize("name", TREES)
+def test_mlp_and_policy_head(name):
+    tree, ro = load_tree(name), load("rollout_" + name)
+    A = tree["index"].shape[-1]
+    T = int(ro["t_eff"]) + 1
+    w = mlp_weights(ro)
+    for t in range(T):
+        logits, value = oracle.mlp_forward(w, ro["observations"][t], A)
+        np.testing.assert_allclose(logits, ro["logits"][t], rtol=TOL, atol=TOL)
+        np.testing.assert_allclose(value, ro["values"][t], rtol=TOL, atol=TOL)
+        pol, _ = oracle.policy_head(ro["logits"][t], ro["masks"][t])
+        np.testing.assert_allclose(pol, ro["policy"][t], rtol=TOL, atol=1e-7)
+        assert ((pol == 0) == (ro["masks"][t] == 0)).all()
+
+
+def test_process_policy_edge_cases():
+    g = load("process_policy")
+    for key in g:
+        if not key.startswith("out_"):
+            continue
+        n_disc, eps = key[5:].split("_e")
+        out = oracle.process_policy(g["policy"], g["mask"], int(n_disc), float(eps))
+        assert_bits_equal(out, g[key], key)
+
+
+LEARN = ("c1_eta0.2", "small_eta0", "small_eta0.2", "ragged_eta0.5", "a5_eta0.2")
+
+
+def _learn_inputs(name):
+    g = load("learn_" + name)
+    ro = load("rollout_" + name.split("_")[0])
+    hp = dict(eta=float(g["eta"]), lambda_=1.0, c=float(g.get("hp_c_bar", 1.0)), rho=float(g.get("hp_roh_bar", 1.0)),
+              gamma=float(g.get("hp_vtrace_gamma", 1.0)))
+    clip = float(g.get("hp_neurd_clip", 1e3))
+    thr = float(g.get("hp_beta", 2.0))
+    return g, ro, hp, clip, thr
+
+
+@pytest.mark.parametrize("name", LEARN)
+def test_learn_policy_head_and_process_policy(name):
+    g, ro, *_ = _learn_inputs(name)
+    pol, logp = oracle.policy_head(g["logit"], ro["masks"])
+    np.testing.assert_allclose(pol, g["pi"], rtol=TOL, atol=1e-7)
+    np.testing.assert_allclose(logp, g["log_pi"], rtol=TOL, atol=TOL)
+    # process_policy is discontinuous: feed it the reference's own pi bits
+    assert_bits_equal(oracle.process_policy(g["pi"], ro["masks"], 32, 0.03), g["pi_processed"], "pi_processed")
+
+
+@pytest.mark.parametrize("name", LEARN)
+def test_vtrace_matches_reference(name):
+    g, ro, hp, _, _ = _learn_inputs(name)
+    for p in range(2):
+        reward = ro["rewards"] if p == 0 else -ro["rewards"]
+        vt, has, q = oracle.vtrace(g["v_target_net"], g["valid"], ro["turns"], ro["policy"], g["pi_processed"],
+                                   g["log_policy_reg"], ro["actions"], reward, p, **hp)
+        np.testing.assert_array_equal(has, g[f"has_played_p{p}"])
+        np.testing.assert_allclose(vt, g[f"v_target_p{p}"], rtol=TOL, atol=TOL)
+        np.testing.assert_allclose(q, g[f"q_p{p}"], rtol=TOL, atol=TOL)
+
+
+def test_vtrace_is_bitwise_on_three_actions():
+    """With A == 3 torch's inner-dim sums run in index order, so the straight loop is bit-exact."""
+    for name in ("small_eta0.2", "c1_eta0.2"):
+        g, ro, hp, _, _ = _learn_inputs(name)
+        for p in range(2):
+            reward = ro["rewards"] if p == 0 else -ro["rewards"]
+            vt, _, q = oracle.vtrace(g["v_target_net"], g["valid"], ro["turns"], ro["policy"], g["pi_processed"],
+                                     g["log_policy_reg"], ro["actions"], reward, p, **hp)
+            assert_bits_equal(vt, g[f"v_target_p{p}"], f"{name} v_target p{p}")
+            assert_bits_equal(q, g[f"q_p{p}"], f"{name} q p{p}")
+
+
+@pytest.mark.parametrize("name", LEARN)
+def test_losses_and_closed_form_grads(name):
+    g, ro, hp, clip, thr = _learn_inputs(name)
+    lv, dv = oracle.loss_v(g["v"], g["v_target_p0"], g["v_target_p1"], g["has_played_p0"], g["has_played_p1"])
+    ln, dl = oracle.loss_nerd(g["logit"], g["pi_processed"], g["q_p0"], g["q_p1"], g["valid"], ro["turns"],
+                              ro["masks"], clip, thr)
+    np.testing.assert_allclose(lv, g["loss_v"], rtol=TOL)
+    np.testing.assert_allclose(ln, g["loss_nerd"], rtol=TOL, atol=1e-7)
+    np.testing.assert_allclose(dv, g["dv"], rtol=TOL, atol=1e-8)
+    np.testing.assert_allclose(dl, g["dlogit"], rtol=TOL, atol=1e-8)
+
+
+def test_vtrace_offpolicy_synthetic():
+    g = load("vtrace_synth")
+    a_oh = np.eye(g["mu"].shape[-1], dtype=np.float32)[g["actions"]]
+    for tag in ("a", "b"):
+        hp = json.loads(str(g[f"{tag}_hp"]))
+        for p in range(2):
+            reward = g["reward"] if p == 0 else -g["reward"]
+            vt, has, q = oracle.vtrace(g["v"], g["valid"], g["player_id"], g["mu"], g["pi"], g["logpi_reg"], a_oh,
+                                       reward, p, **hp)
+            np.testing.assert_array_equal(has, g[f"{tag}_has_played_p{p}"])
+            assert_bits_equal(vt, g[f"{tag}_v_target_p{p}"], f"{tag} vt p{p}")
+            assert_bits_equal(q, g[f"{tag}_q_p{p}"], f"{tag} q p{p}")
+    lv, dv = oracle.loss_v(g["v"], g["b_v_target_p0"], g["b_v_target_p1"], g["b_has_played_p0"], g["b_has_played_p1"])
+    ln, dl = oracle.loss_nerd(g["logit"], g["pi"], g["b_q_p0"], g["b_q_p1"], g["valid"], g["player_id"], g["mask"],
+                              float(g["nerd_clip"]), float(g["nerd_threshold"]))
+    np.testing.assert_allclose(lv, g["loss_v"], rtol=TOL)
+    np.testing.assert_allclose(ln, g["loss_nerd"], rtol=TOL)
+    np.testing.assert_allclose(dv, g["dv"], rtol=TOL, atol=1e-8)
+    np.testing.assert_allclose(dl, g["dlogit"], rtol=TOL, atol=1e-8)
+
+
+@pytest.mark.parametrize("name", TREES)
+def test_nashconv(name):
+    tree, g = load_tree(name), load("nashconv_" + name)
+    jp = g["joint_policy"]
+    rb, cb, reach, depth = oracle.nashconv(tree["index"], tree["value"], tree["chance"], tree["legal"], jp[1], jp)
+    np.testing.assert_array_equal(depth, g["depth"])
+    np.testing.assert_allclose(rb, g["row_best"], rtol=TOL, atol=TOL)
+    np.testing.assert_allclose(cb, g["col_best"], rtol=TOL, atol=TOL)
+    np.testing.assert_allclose(reach, g["reach_probability"], rtol=TOL, atol=1e-9)
+    np.testing.assert_allclose(rb[1] + cb[1], g["nashconv"], rtol=TOL, atol=TOL)
+    # the tree's own solution is a Nash equilibrium: NashConv ~ 0 and row_best[root] == root value
+    sol = tree["solution"]
+    rb, cb, reach, depth = oracle.nashconv(tree["index"], tree["value"], tree["chance"], tree["legal"], sol[1], sol)
+    np.testing.assert_allclose(rb, g["sol_row_best"], rtol=TOL, atol=TOL)
+    np.testing.assert_allclose(cb, g["sol_col_best"], rtol=TOL, atol=TOL)
+    assert abs(rb[1] + cb[1]) < 1e-5
+    np.testing.assert_allclose(rb[1], tree["root_value"][1, 0], atol=1e-5)
+
+
+def test_nashconv_reference_test_semantics():
+    """reference tests/test_nashconv.py: get_nashconv(tree, solution) with data.joint_policy still zero
+    recurses with the zero table (util/metric.py:148-151), giving exactly 0 and total reach 2."""
+    for name in ("c1",):
+        tree = load_tree(name)
+        zeros = np.zeros_like(tree["solution"])
+        rb, cb, reach, _ = oracle.nashconv(tree["index"], tree["value"], tree["chance"], tree["legal"],
+                                           tree["solution"][1], zeros)
+        assert rb[1] + cb[1] == 0
+        assert reach.sum() == 2
