@@ -1,0 +1,244 @@
+/*
+ * rnad_hip.h -- C-ABI of librnad_hip.so: the MI355X (gfx950) implementation of the baskuit/R-NaD
+ * vectorised self-play hot path.
+ *
+ * The reference is pure Python/PyTorch and has NO FFI/operator boundary of its own (SURVEY.md
+ * section 8b); the drop-in boundary is its Python class/function API, which r-nad_amd/ mirrors.
+ * This header is the native boundary underneath: each entry point names the reference code
+ * (file:line in baskuit/R-NaD) whose tensor program it replaces.  INTEGRATION.md shows the
+ * ctypes stub a reference maintainer would add per call site.
+ *
+ * Conventions
+ *   - plain C, no torch types: caller-owned DEVICE pointers (tensor.data_ptr()), explicit sizes;
+ *     `stream` is a hipStream_t passed as void* (NULL = the null stream).  Calls only enqueue
+ *     work and never synchronise unless stated.
+ *   - every function returns 0 on success, non-zero on failure; rnad_last_error() then returns a
+ *     message (thread-local).  Nothing here falls back to a CPU path.
+ *   - B = episodes ("lanes") in the batch, T = env steps, A = max_actions, C = max_transitions,
+ *     S = states in the tree.  Trajectory tensors are [T, B, ...] row-major like the reference's
+ *     torch.stack'ed lists (environment/episode.py:218-225).
+ *   - dtypes differ from the reference only where noted: state indices and actions are int32
+ *     (reference int64), `turns` is implicit (t & 1, see episode.py:96-98), legal masks travel as
+ *     one byte of bits per (t, b) next to the fp32 observation.
+ *   - fp32 arithmetic follows the reference's operation order and is compiled with
+ *     -ffp-contract=off; integer results are bit-exact, fp32 results within 1e-5 (exp/log use the
+ *     device libm).
+ *   - one host thread per GPU; handles are not thread-safe.
+ */
+#ifndef RNAD_HIP_H
+#define RNAD_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+#pragma GCC visibility push(default) /* the library is built with -fvisibility=hidden */
+
+#define RNAD_MAX_ACTIONS 8
+#define RNAD_MAX_TRANSITIONS 8
+
+const char *rnad_last_error(void);
+int rnad_version(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * Tree tables.  Replaces the seven per-state tensors of environment/tree.py:115-146 as the thing
+ * the kernels read.  Inputs are HOST pointers in the reference layout
+ *   index int64 [S,C,A,A], value/chance f32 [S,C,A,A], expected_value/legal f32 [S,1,A,A]
+ * and are re-packed for the GPU (DESIGN.md "HBM layout"):
+ *   node  [S][NS]        f32: expected_value[A*A], legal bitmask (bit i*A+j), pad to 16 B
+ *   trans [S][A][A][C]   {int32 next, f32 chance, f32 value}   (12*C contiguous bytes per joint action)
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct rnad_tree rnad_tree_t;
+
+int rnad_tree_create(rnad_tree_t **out, int64_t S, int C, int A, const int64_t *index, const float *value,
+                     const float *chance, const float *expected_value, const float *legal, int device);
+void rnad_tree_destroy(rnad_tree_t *tree);
+/* size queries: which = 0:S 1:C 2:A 3:max game depth (longest root->terminal chain of transitions)
+ * 4:node stride in floats 5:bytes of device tables */
+int64_t rnad_tree_info(const rnad_tree_t *tree, int which);
+
+/* ------------------------------------------------------------------------------------------------
+ * K1  observe  --  environment/episode.py:62-68 (States.observations) + :208 (masks).
+ *   obs[b,0,i,j] = player ?  -ev[s,j,i] : ev[s,i,j]      obs[b,1,i,j] = player ? legal[s,j,i] : legal[s,i,j]
+ * `player` is uniform over the batch (episode.py:96-98).  obs is fp32 [B,2,A,A] (obs_half != 0:
+ * fp16).  mask_bits (u8 [B], bit i = row i legal for the mover) and mask (f32 [B,A]) are optional.
+ * ---------------------------------------------------------------------------------------------- */
+int rnad_observe(const rnad_tree_t *tree, int64_t B, const int32_t *idx, int player, void *obs, int obs_half,
+                 uint8_t *mask_bits, float *mask, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Policy head  --  nn/net.py:45-46 (forward) and :74-77 (forward_batch):
+ *   policy = where(legal, exp(logits), 0) / max(sum, 1e-12);  log_policy = where(legal, logits - log(sum), 0)
+ * legality comes from mask_bits (u8 [N]) or, if that is NULL, from mask (f32 [N,A], non-zero = legal).
+ * ---------------------------------------------------------------------------------------------- */
+int rnad_policy_head(int64_t N, int A, const float *logits, const uint8_t *mask_bits, const float *mask,
+                     float *policy, float *log_policy, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * K3  sample  --  torch.multinomial(policy, 1) at nn/net.py:49, i.e. argmax_a(policy[a] / q[a]) with
+ * q ~ Exp(1), first maximum wins.  q is `noise` (f32 [B,n]) when given, otherwise the seeded
+ * stream of include/rnad_rng.h at (seed, lane0 + b, step, stream).
+ * ---------------------------------------------------------------------------------------------- */
+int rnad_sample(int64_t B, int n, const float *probs, const float *noise, uint64_t seed, int64_t lane0, int step,
+                int stream_id, int32_t *out, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * K2  transition  --  environment/episode.py:102-123 (States.step, column branch):
+ *   t ~ multinomial(chance[s,:,r,c]);  s' = index[s,t,r,c];  reward = value[s,t,r,c] * (s' == 0)
+ * noise: f32 [B,C] or NULL (seeded, stream 1).  alive (optional, int32[1]) is incremented by the
+ * number of lanes with s' != 0 (replaces the host sync of episode.py:124).
+ * ---------------------------------------------------------------------------------------------- */
+int rnad_transition(const rnad_tree_t *tree, int64_t B, const int32_t *idx, const int32_t *row_actions,
+                    const int32_t *col_actions, const float *noise, uint64_t seed, int64_t lane0, int step,
+                    int32_t *idx_out, float *reward, int32_t *alive, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Rollout driver  --  environment/episode.py:175-230 (Episodes.generate) without the per-step
+ * clones, list appends and host syncs.  The caller owns preallocated [T_cap, B, ...] buffers:
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct rnad_traj {
+    int32_t T_cap;        /* capacity in env steps (>= 2 * max depth)                               */
+    int32_t obs_half;     /* 0: observations fp32, 1: fp16                                          */
+    int64_t B;            /* lanes                                                                   */
+    int32_t *indices;     /* [T_cap + 1, B]  state id at the START of step t (row T_cap: after last) */
+    void *observations;   /* [T_cap, B, 2, A, A]                                                     */
+    uint8_t *mask_bits;   /* [T_cap, B]                                                              */
+    float *policy;        /* [T_cap, B, A]   acting policy mu                                        */
+    int32_t *actions;     /* [T_cap, B]      sampled action id                                       */
+    float *rewards;       /* [T_cap, B]      row-player reward (episode.py:120-121)                  */
+    float *values;        /* [T_cap, B]      actor value head (episode.py:207)                       */
+    int32_t *alive;       /* [T_cap + 1]     #lanes with indices[t] != 0                             */
+} rnad_traj_t;
+
+/* indices[0,:] = 1 (root, episode.py:22), alive[:] = 0, alive[0] = B, then K1 for t = 0. */
+int rnad_rollout_begin(const rnad_tree_t *tree, const rnad_traj_t *traj, void *stream);
+
+/* One env step t given the net outputs for observations[t] (nn/net.py:37-51):
+ *   mode 0: `logits` [B,A] given      -> policy head, sample, record            (fast path)
+ *   mode 1: `policy_in` [B,A] given   -> sample, record
+ *   mode 2: `policy_in` and `actions_in` (int32 [B]) given -> record only       (generic nets that
+ *           sample for themselves, net.py:49)
+ * then (odd t) the transition of K2 with row action actions[t-1] and column action actions[t],
+ * (even t) indices[t+1] = indices[t], rewards[t] = 0 (episode.py:99-101); alive[t+1]; and, if
+ * t + 1 < T_cap, K1 for step t + 1 as a second launch.
+ * noise_action [B,A] / noise_chance [B,C]: explicit Exp(1) noise or NULL for the seeded stream. */
+int rnad_rollout_step(const rnad_tree_t *tree, const rnad_traj_t *traj, int t, int mode, const float *logits,
+                      const float *policy_in, const int32_t *actions_in, const float *value,
+                      const float *noise_action, const float *noise_chance, uint64_t seed, int64_t lane0,
+                      void *stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * K4  process_policy  --  learn/vtrace.py:24-55.   policy, mask f32 [N,A] -> out f32 [N,A].
+ * ---------------------------------------------------------------------------------------------- */
+int rnad_process_policy(int64_t N, int A, const float *policy, const float *mask, int n_disc, float eps,
+                        float *out, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * K5  v_trace  --  learn/vtrace.py:207-352 for `player`, incl. _has_played (:141-177),
+ * _policy_ratio (:180-204), _player_others (:70-87).  One lane per episode, backward in time.
+ *   v, valid, reward f32 [T,B]; player_id int32 [T,B] or NULL (= t & 1); mu (acting), pi (merged),
+ *   logpi (merged log policy) f32 [T,B,A]; actions: one-hot f32 [T,B,A] (actions_onehot != 0) or
+ *   int32 [T,B].  Outputs v_target f32 [T,B], q (= learning_output) f32 [T,B,A], has_played int32 [T,B]
+ *   (optional).
+ * ---------------------------------------------------------------------------------------------- */
+int rnad_vtrace(int T, int64_t B, int A, const float *v, const float *valid, const int32_t *player_id,
+                const float *mu, const float *pi, const float *logpi, const void *actions, int actions_onehot,
+                const float *reward, int player, float eta, float lambda_, float c, float rho, float gamma,
+                float *v_target, int32_t *has_played, float *q, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * K6  losses + closed-form gradients, one list entry (player) per call like the reference's loops
+ * --  learn/vtrace.py:377-393 (get_loss_v) and :396-431 (get_loss_nerd with
+ * apply_force_with_threshold :355-367 and renormalize :370-374).
+ *   rnad_mask_sum: out[0] (device f64) = sum(mask), the `normalization` of :373/:388.  A
+ *   data-parallel caller all-reduces it over ranks before passing it on as `norm`.
+ *   rnad_loss_v:   L = sum(mask * (v - v_target)^2) / max(norm, 1);  dv = weight * 2 mask (v - v_target) / norm
+ *   rnad_loss_nerd: adv = clip(q - sum_a(pi q)); l = logit - mean_a(logit * legal);
+ *                   f = (l > -thr) min(adv, 0) + (l < thr) max(adv, 0);  L = -sum(mask * sum_a legal l f) / norm;
+ *                   dlogit = -weight * mask (w - legal * sum_a(w) / A) / norm,  w = legal * f  (f is detached)
+ *   v, v_target, mask f32 [N]; logit, pi, q, legal f32 [N,A]; norm device f64[1].
+ *   loss (device f64[1], optional) receives += weight-free LOCAL sum / norm.  accumulate == 0:
+ *   gradients are written, != 0: added to (second player of the list).
+ * ---------------------------------------------------------------------------------------------- */
+int rnad_mask_sum(int64_t N, const float *mask, double *out, void *stream);
+int rnad_loss_v(int64_t N, const float *v, const float *v_target, const float *mask, const double *norm, float weight,
+                double *loss, float *dv, int accumulate, void *stream);
+int rnad_loss_nerd(int64_t N, int A, const float *logit, const float *pi, const float *q, const float *mask,
+                   const float *legal, const double *norm, float clip, float threshold, float weight, double *loss,
+                   float *dlogit, int accumulate, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Fused learner post-processing  --  the tensor program of RNaD.__learn, learn/rnad.py:365-425,
+ * between the four forward_batch calls and loss.backward(): policy heads of the learner and the
+ * two regularisation nets, log_policy_reg (:382), process_policy (:374), both players' v_trace
+ * (:384-406) and the loss gradients (:407-425), in ONE backward-in-time pass per lane.  Nothing
+ * but dlogit/dv (and optional logging tensors) is written to HBM.
+ *   inputs [T,B(,A)]: indices (valid = != 0, :369), mask_bits, actions, rewards, mu = acting policy,
+ *   logit / v of the learner, v_target_net of the target net, logit_reg / logit_reg_ of the
+ *   regularisation nets; alpha (:497); norm = device f64[2], #(valid & t&1 == P) for P = 0, 1
+ *   (all-reduced over ranks by a data-parallel caller).
+ *   outputs: dlogit [T,B,A], dv [T,B]; losses f64[2] partial sums / norm; optional
+ *   pi_out, v_target_out [2,T,B], q_out [2,T,B,A] for logging and tests (may be NULL).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct rnad_learn_params {
+    float alpha, one_minus_alpha;               /* rnad.py:382,:497; 1 - alpha is rounded from the double */
+    float eta, lambda_, c, rho, gamma;          /* rnad.py:397-401 */
+    float clip, threshold;                      /* neurd_clip, logit_clip (beta), rnad.py:420-421 */
+    float w_v, w_n;                             /* value_loss_weight, neurd_loss_weight, rnad.py:424 */
+    float eps_threshold;                        /* process_policy epsilon, rnad.py:374 */
+    int32_t n_disc;
+} rnad_learn_params_t;
+
+int rnad_learn_fused(int T, int64_t B, int A, const int32_t *indices, const uint8_t *mask_bits,
+                     const int32_t *actions, const float *rewards, const float *mu, const float *logit,
+                     const float *v, const float *v_target_net, const float *logit_reg, const float *logit_reg_,
+                     const double *norm, const rnad_learn_params_t *hp, double *losses, float *dlogit, float *dv,
+                     float *pi_out, float *v_target_out, float *q_out, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * NashConv  --  util/metric.py:93-175 (NashConvData.get_nashconv), level-batched on the GPU
+ * instead of one Python frame per state.  joint_policy f32 [S,2A] (device) for every state below
+ * `state_index`; root_policy f32 [2A] (device) is the row used AT state_index (the reference
+ * recursion passes self.joint_policy to descendants, :148-151).  Outputs f32/int32 [S] (device):
+ * only states reachable from state_index are written.
+ * ---------------------------------------------------------------------------------------------- */
+int rnad_nashconv(const rnad_tree_t *tree, const float *joint_policy, const float *root_policy,
+                  int64_t state_index, float reach, float *row_best, float *col_best, float *reach_out,
+                  int32_t *depth_out, void *stream);
+/* Observations of EVERY state for both players (metric.py:66-81): obs_row, obs_col f32 [S,2,A,A]. */
+int rnad_observe_all(const rnad_tree_t *tree, float *obs_row, float *obs_col, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Native tree generator (HOST code)  --  environment/tree.py:164-366 (generate, _transition_probs,
+ * _solve) for trees too large for the Python recursion (66 431 states take > 100 s there).
+ * Regular shape only: every state has A x A legal actions and depth_bound - 1 below it; chance
+ * profiles are Dirichlet(1/C) thresholded and renormalised (tree.py:182-197); terminal payoffs are
+ * drawn uniformly from terminal_values (tree.py:271-275); each state's matrix game is solved
+ * exactly (Shapley-Snow enumeration, same sub-matrix order as tests/golden/_pygambit_stub.py);
+ * ids are the reference's DFS pre-order with the absorbing state 0 prepended (tree.py:311-366).
+ * prune_num/prune_den: each child's depth_bound is additionally lowered by 2 with probability
+ * prune_num/prune_den (reference main.py:37).  Randomness: splitmix64(seed), NOT numpy's.
+ * Call with outputs NULL to get the state count, then with buffers of that size.
+ * ---------------------------------------------------------------------------------------------- */
+int64_t rnad_tree_generate(int A, int C, int depth_bound, float transition_threshold, const float *terminal_values,
+                           int n_terminal_values, int prune_num, int prune_den, uint64_t seed, int64_t capacity,
+                           int64_t *index, float *value, float *chance, float *expected_value, float *legal,
+                           float *root_value, float *solution);
+/* tree.py:199-234: one zero-sum matrix game M [ra,ca] (row-major, row player maximises) ->
+ * solution f32 [2*max_actions] (row strategy | column strategy), returns the game value via *value. */
+int rnad_solve_matrix(const float *M, int ra, int ca, int max_actions, float *solution, float *value);
+
+/* ------------------------------------------------------------------------------------------------
+ * Kernel timing (bench.py's roofline leg): when enabled, every launch of kernel `which`
+ * (0 = observe, 1 = act/transition, 2 = learn_fused) is bracketed by hipEvents on its own stream.
+ * rnad_prof_read synchronises the device and returns launches and total milliseconds since reset.
+ * ---------------------------------------------------------------------------------------------- */
+int rnad_prof_enable(int on);
+int rnad_prof_read(int which, int64_t *launches, double *total_ms);
+
+#pragma GCC visibility pop
+#ifdef __cplusplus
+}
+#endif
+#endif /* RNAD_HIP_H */

@@ -1,0 +1,85 @@
+// common.hpp -- shared host/device plumbing of librnad_hip.so (gfx950 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <string>
+#include <vector>
+
+#include "rnad_hip.h"
+#include "rnad_rng.h"
+
+namespace rnad {
+
+void set_error(const char *fmt, ...);
+
+#define RNAD_HIP_OK(expr)                                                                            \
+    do {                                                                                             \
+        hipError_t e_ = (expr);                                                                      \
+        if (e_ != hipSuccess) {                                                                      \
+            rnad::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+            return 1;                                                                                \
+        }                                                                                            \
+    } while (0)
+
+#define RNAD_REQUIRE(cond, ...)           \
+    do {                                  \
+        if (!(cond)) {                    \
+            rnad::set_error(__VA_ARGS__); \
+            return 2;                     \
+        }                                 \
+    } while (0)
+
+// One (int32 next, f32 chance, f32 value) per chance outcome; C of them are contiguous per joint action.
+struct Trans {
+    int32_t next;
+    float chance;
+    float value;
+};
+
+// node row: expected_value[A*A] | legal bits lo | legal bits hi | pad to a multiple of 4 floats (16 B)
+inline int node_stride_floats(int A) { return (A * A + 2 + 3) & ~3; }
+
+// Event bracketing for bench.py's roofline leg.
+enum ProfKernel { PROF_OBSERVE = 0, PROF_ACT = 1, PROF_LEARN = 2, PROF_COUNT = 3 };
+struct ProfScope {
+    int which;
+    hipStream_t stream;
+    hipEvent_t start = nullptr;
+    ProfScope(int which, hipStream_t stream);
+    ~ProfScope();
+};
+
+}  // namespace rnad
+
+struct rnad_tree {
+    int64_t S = 0;
+    int C = 0, A = 0, NS = 0, device = 0, max_depth = 0;
+    float *node = nullptr;        // [S][NS]
+    rnad::Trans *trans = nullptr; // [S][A][A][C]
+    // NashConv support: states grouped by depth below the root (level 0 = {1}); ids of one level are contiguous
+    // in level_order, parent/child relation is in `trans`.
+    int n_levels = 0;
+    int32_t *level_order = nullptr;      // device [S]
+    std::vector<int64_t> level_offsets;  // host [n_levels + 1]
+    std::vector<int32_t> level_of;       // host [S] (-1: unreachable)
+    size_t bytes = 0;
+};
+
+// Dispatch a functor templated on A (1..RNAD_MAX_ACTIONS).
+#define RNAD_DISPATCH_A(A_, ...)                                            \
+    switch (A_) {                                                           \
+        case 1: { constexpr int kA = 1; __VA_ARGS__; } break;               \
+        case 2: { constexpr int kA = 2; __VA_ARGS__; } break;               \
+        case 3: { constexpr int kA = 3; __VA_ARGS__; } break;               \
+        case 4: { constexpr int kA = 4; __VA_ARGS__; } break;               \
+        case 5: { constexpr int kA = 5; __VA_ARGS__; } break;               \
+        case 6: { constexpr int kA = 6; __VA_ARGS__; } break;               \
+        case 7: { constexpr int kA = 7; __VA_ARGS__; } break;               \
+        case 8: { constexpr int kA = 8; __VA_ARGS__; } break;               \
+        default: rnad::set_error("max_actions %d out of range [1,%d]", A_, RNAD_MAX_ACTIONS); return 2; \
+    }

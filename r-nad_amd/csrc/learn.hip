@@ -1,0 +1,504 @@
+// learn.hip -- the R-NaD / NeuRD update with two-player V-trace (gfx950).
+//
+// Replaces: learn/vtrace.py:24-55 (process_policy, K4), :141-352 (v_trace and helpers, K5), :355-431 (losses, K6) and the
+// tensor program of learn/rnad.py:365-425 between the four forward_batch calls and loss.backward() (fused kernel).
+// Citations are baskuit/R-NaD file:line.
+//
+// Mapping: one lane (thread) per episode, sequential over the T <= 32 timesteps.  With the reference's [T, B, ...]
+// layout every per-step load is a full-width coalesced access across the 64 lanes of a wave; the scan carry lives in
+// registers.  The V-trace recurrence is not an associative scan -- the carry goes through min(cs * is, rho) and a
+// three-way select per step -- and B >> 256 CUs x 2048 lanes, so parallelism comes from the batch, not from T.
+// All fp32 expressions keep the reference's association order; the file is built with -ffp-contract=off.
+#include "common.hpp"
+
+#include <algorithm>
+
+using namespace rnad;
+
+namespace {
+
+constexpr int kThreads = 256;
+inline unsigned blocks_for(int64_t n) { return (unsigned)((n + kThreads - 1) / kThreads); }
+
+// ---------------------------------------------------------------------------------------- device helpers
+// nn/net.py:45-46,76-77 (same function as in rollout.hip, kept local so each kernel file stands alone)
+template <int A>
+__device__ __forceinline__ void policy_head(const float (&logit)[A], uint32_t legal_bits, float (&policy)[A], float (&log_policy)[A]) {
+    float ex[A];
+    float s = 0.0f, s2 = 0.0f;
+#pragma unroll
+    for (int a = 0; a < A; ++a) {
+        ex[a] = ((legal_bits >> a) & 1) ? expf(logit[a]) : 0.0f;
+        s += fabsf(ex[a]);
+        s2 += ex[a];
+    }
+    const float d = fmaxf(s, 1e-12f);
+    const float ls = logf(s2);
+#pragma unroll
+    for (int a = 0; a < A; ++a) {
+        policy[a] = ex[a] / d;
+        log_policy[a] = ((legal_bits >> a) & 1) ? logit[a] - ls : 0.0f;
+    }
+}
+
+template <int A>
+__device__ __forceinline__ void log_policy_only(const float (&logit)[A], uint32_t legal_bits, float (&log_policy)[A]) {
+    float s2 = 0.0f;
+#pragma unroll
+    for (int a = 0; a < A; ++a) s2 += ((legal_bits >> a) & 1) ? expf(logit[a]) : 0.0f;
+    const float ls = logf(s2);
+#pragma unroll
+    for (int a = 0; a < A; ++a) log_policy[a] = ((legal_bits >> a) & 1) ? logit[a] - ls : 0.0f;
+}
+
+// learn/vtrace.py:24-55 for one row.  `mask` holds the caller's mask VALUES (0/1 in practice).
+template <int A>
+__device__ __forceinline__ void process_policy_row(const float (&pi)[A], const float (&mask)[A], int n_disc, float eps,
+                                                   float (&out)[A]) {
+    float mx = pi[0];
+#pragma unroll
+    for (int a = 1; a < A; ++a) mx = pi[a] > mx ? pi[a] : mx;
+    const bool all_below = mx < eps;  // :37 "prevent degen case where all < eps"
+    float m[A], p[A];
+    float s = 0.0f;
+#pragma unroll
+    for (int a = 0; a < A; ++a) {
+        m[a] = mask[a] * ((pi[a] >= eps) || all_below ? 1.0f : 0.0f);  // :34-39
+        s += m[a] * pi[a];
+    }
+#pragma unroll
+    for (int a = 0; a < A; ++a) {
+        p[a] = m[a] * pi[a] / s;  // :40
+        out[a] = 0.0f;
+    }
+    // argsort(descending) with ties in index order == rank by (#greater) + (#equal with lower index)  (:46)
+    int rank[A];
+#pragma unroll
+    for (int a = 0; a < A; ++a) {
+        int r = 0;
+#pragma unroll
+        for (int j = 0; j < A; ++j) r += (p[j] > p[a]) || (p[j] == p[a] && j < a);
+        rank[a] = r;
+    }
+    float leftover = (float)n_disc;
+    const float nf = (float)n_disc;
+#pragma unroll
+    for (int i = 0; i < A; ++i) {  // :47-51
+#pragma unroll
+        for (int a = 0; a < A; ++a) {
+            if (rank[a] == i) {
+                const float block = (float)(int32_t)ceilf(nf * p[a]);
+                const float x = fminf(leftover, block);
+                leftover -= x;
+                out[a] += x;
+            }
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < A; ++a) out[a] /= nf;  // :52
+}
+
+__device__ __forceinline__ float clamp_max(float x, float hi) { return x != x ? x : (x < hi ? x : hi); }  // torch.clamp(max=)
+
+// Carry of the reverse scan, learn/vtrace.py:58-67 and :241-247.
+struct Carry {
+    float r = 0.0f, ru = 0.0f, nv = 0.0f, nvt = 0.0f, is = 1.0f;
+};
+
+struct VtHp {
+    float neg_eta, lambda_, c, rho, gamma;
+};
+
+// One timestep of _loop_v_trace (learn/vtrace.py:249-333) for one lane and one `player`.
+//   ours: valid && player_id == player.  oh[a] is the action one-hot VALUE (literal multiply as in :291).
+// Writes vt / q[] (zeros unless ours) and advances the carry.
+template <int A>
+__device__ __forceinline__ void vtrace_step(Carry &cy, const VtHp &hp, bool valid, bool ours, float valid_f, float vv, float rew,
+                                            const float (&mu)[A], const float (&pi)[A], const float (&logpi)[A],
+                                            const float (&oh)[A], float &vt_out, float (&q_out)[A]) {
+    // _policy_ratio (:199-204): sum(a_oh * pi) * valid + (1 - valid)
+    float s_pi = 0.0f, s_mu = 0.0f, s_one = 0.0f, ent = 0.0f;
+#pragma unroll
+    for (int a = 0; a < A; ++a) {
+        s_pi += oh[a] * pi[a];
+        s_mu += oh[a] * mu[a];
+        s_one += oh[a] * 1.0f;
+        ent += pi[a] * logpi[a];
+    }
+    const float inv = 1.0f - valid_f;
+    const float sel_mu = s_mu * valid_f + inv;
+    const float cs = (s_pi * valid_f + inv) / sel_mu;
+    const float inv_mu = (s_one * valid_f + inv) / sel_mu;
+    const float po = (ours ? 1.0f : -1.0f) * valid_f;  // _player_others (:83-87)
+    const float ere = hp.neg_eta * ent * po;           // eta_reg_entropy (:234-238)
+
+    const float ru = rew + hp.gamma * cy.ru + ere;  // reward_uncorrected (:262)
+    const float dr = rew + hp.gamma * cy.r;         // discounted_reward (:263)
+    const float w = cs * cy.is;
+    if (valid && ours) {
+        // our_v_target (:266-282)
+        const float vt = vv + clamp_max(w, hp.rho) * (ru + hp.gamma * cy.nv - vv) +
+                         hp.lambda_ * clamp_max(w, hp.c) * hp.gamma * (cy.nvt - cy.nv);
+        const float tail = dr + hp.gamma * cy.is * cy.nvt - vv;
+#pragma unroll
+        for (int a = 0; a < A; ++a) {
+            const float elp = hp.neg_eta * logpi[a] * po;  // eta_log_policy (:239)
+            q_out[a] = vv + elp + oh[a] * inv_mu * tail;   // our_learning_output (:288-300)
+        }
+        vt_out = vt;
+        cy.r = 0.0f; cy.ru = 0.0f; cy.nv = vv; cy.nvt = vt; cy.is = 1.0f;  // our_carry (:306-312)
+    } else {
+        vt_out = 0.0f;
+#pragma unroll
+        for (int a = 0; a < A; ++a) q_out[a] = 0.0f;
+        if (valid) {  // opp_carry (:313-319)
+            cy.r = ere + cs * dr; cy.ru = ru; cy.nv = hp.gamma * cy.nv; cy.nvt = hp.gamma * cy.nvt; cy.is = w;
+        } else {  // reset_carry (:320)
+            cy = Carry{};
+        }
+    }
+}
+
+// get_loss_nerd for one row and one player (learn/vtrace.py:410-429), with the closed-form gradient
+//   d/dlogit sum_a legal*l*f = w - legal * sum(w) / A,  w = legal * f   (f detached, :367,:418)
+template <int A>
+__device__ __forceinline__ float nerd_row(const float (&logit)[A], const float (&pi)[A], const float (&q)[A], const float (&legal)[A],
+                                          float clip, float thr, float (&grad)[A]) {
+    float base = 0.0f, mean = 0.0f;
+#pragma unroll
+    for (int a = 0; a < A; ++a) {
+        base += pi[a] * q[a];
+        mean += logit[a] * legal[a];
+    }
+    mean = mean / (float)A;  // torch.mean over ALL A (:420)
+    float w[A], wsum = 0.0f, nerd = 0.0f;
+#pragma unroll
+    for (int a = 0; a < A; ++a) {
+        float adv = q[a] - base;                                   // :415 (is_c == 1, :416)
+        adv = adv != adv ? adv : fminf(fmaxf(adv, -clip), clip);   // :417
+        const float l = logit[a] - mean;
+        const float f = (l > -thr ? 1.0f : 0.0f) * fminf(adv, 0.0f) + (l < thr ? 1.0f : 0.0f) * fmaxf(adv, 0.0f);  // :362-366
+        nerd += legal[a] * (l * f);                                // :424-428
+        w[a] = legal[a] * f;
+        wsum += w[a];
+    }
+#pragma unroll
+    for (int a = 0; a < A; ++a) grad[a] = w[a] - legal[a] * wsum / (float)A;
+    return nerd;
+}
+
+// Sum `x` over the block in double and add it to *dst with one atomic.
+__device__ __forceinline__ void block_atomic_add(double x, double *dst) {
+    __shared__ double part[kThreads / 64];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = x;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double s = 0.0;
+#pragma unroll
+        for (int i = 0; i < kThreads / 64; ++i) s += part[i];
+        if (s != 0.0) atomicAdd(dst, s);
+    }
+}
+
+// ---------------------------------------------------------------------------------------- kernels
+template <int A>
+__global__ __launch_bounds__(kThreads) void k_process_policy(int64_t N, const float *__restrict__ policy, const float *__restrict__ mask,
+                                                             int n_disc, float eps, float *__restrict__ out) {
+    const int64_t n = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    if (n >= N) return;
+    float pi[A], m[A], o[A];
+#pragma unroll
+    for (int a = 0; a < A; ++a) {
+        pi[a] = policy[n * A + a];
+        m[a] = mask[n * A + a];
+    }
+    process_policy_row<A>(pi, m, n_disc, eps, o);
+#pragma unroll
+    for (int a = 0; a < A; ++a) out[n * A + a] = o[a];
+}
+
+template <int A, bool ONEHOT>
+__global__ __launch_bounds__(kThreads) void k_vtrace(int T, int64_t B, const float *__restrict__ v, const float *__restrict__ valid,
+                                                     const int32_t *__restrict__ player_id, const float *__restrict__ mu,
+                                                     const float *__restrict__ pi, const float *__restrict__ logpi,
+                                                     const void *__restrict__ actions, const float *__restrict__ reward, int player,
+                                                     VtHp hp, float *__restrict__ v_target, int32_t *__restrict__ has_played,
+                                                     float *__restrict__ q) {
+    const int64_t b = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    if (b >= B) return;
+    Carry cy;
+    for (int t = T - 1; t >= 0; --t) {
+        const int64_t i = (int64_t)t * B + b;
+        const float val = valid[i];
+        const bool ours = (player_id ? player_id[i] : (t & 1)) == player;
+        float m[A], p[A], lp[A], oh[A], qo[A];
+        int act = 0;
+        if (!ONEHOT) act = ((const int32_t *)actions)[i];
+#pragma unroll
+        for (int a = 0; a < A; ++a) {
+            m[a] = mu[i * A + a];
+            p[a] = pi[i * A + a];
+            lp[a] = logpi[i * A + a];
+            oh[a] = ONEHOT ? ((const float *)actions)[i * A + a] : (act == a ? 1.0f : 0.0f);
+        }
+        float vt;
+        vtrace_step<A>(cy, hp, val != 0.0f, ours, val, v[i], reward[i], m, p, lp, oh, vt, qo);
+        v_target[i] = vt;
+        if (has_played) has_played[i] = (val != 0.0f && ours) ? 1 : 0;  // _has_played (:141-177): its carry is never set
+#pragma unroll
+        for (int a = 0; a < A; ++a) q[i * A + a] = qo[a];
+    }
+}
+
+__global__ __launch_bounds__(kThreads) void k_mask_sum(int64_t N, const float *__restrict__ mask, double *__restrict__ out) {
+    double s = 0.0;
+    for (int64_t n = (int64_t)blockIdx.x * kThreads + threadIdx.x; n < N; n += (int64_t)gridDim.x * kThreads) s += (double)mask[n];
+    block_atomic_add(s, out);
+}
+
+__device__ __forceinline__ float norm_of(const double *norm) {
+    const float n = (float)norm[0];
+    return n + (n == 0.0f ? 1.0f : 0.0f);  // normalization + (normalization == 0.0)  (:374,:389)
+}
+
+template <bool ACC>
+__global__ __launch_bounds__(kThreads) void k_loss_v(int64_t N, const float *__restrict__ v, const float *__restrict__ vt,
+                                                     const float *__restrict__ mask, const double *__restrict__ norm, float weight,
+                                                     double *__restrict__ loss, float *__restrict__ dv) {
+    const int64_t n = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    const float nf = norm_of(norm);
+    double part = 0.0;
+    if (n < N) {
+        const float m = mask[n];
+        const float d = v[n] - vt[n];
+        part = (double)(m * (d * d));  // :387
+        if (dv) {
+            const float g = weight * (2.0f * m * d / nf);
+            dv[n] = ACC ? dv[n] + g : g;
+        }
+    }
+    if (loss) block_atomic_add(part / (double)nf, loss);
+}
+
+template <int A, bool ACC>
+__global__ __launch_bounds__(kThreads) void k_loss_nerd(int64_t N, const float *__restrict__ logit, const float *__restrict__ pi,
+                                                        const float *__restrict__ q, const float *__restrict__ mask,
+                                                        const float *__restrict__ legal, const double *__restrict__ norm, float clip,
+                                                        float thr, float weight, double *__restrict__ loss,
+                                                        float *__restrict__ dlogit) {
+    const int64_t n = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    const float nf = norm_of(norm);
+    double part = 0.0;
+    if (n < N) {
+        float l[A], p[A], qq[A], lg[A], g[A];
+#pragma unroll
+        for (int a = 0; a < A; ++a) {
+            l[a] = logit[n * A + a];
+            p[a] = pi[n * A + a];
+            qq[a] = q[n * A + a];
+            lg[a] = legal[n * A + a];
+        }
+        const float m = mask[n];
+        const float nerd = nerd_row<A>(l, p, qq, lg, clip, thr, g);
+        part = -(double)(nerd * m);  // :429
+        if (dlogit) {
+#pragma unroll
+            for (int a = 0; a < A; ++a) {
+                const float gg = weight * (-(m * g[a]) / nf);
+                dlogit[n * A + a] = ACC ? dlogit[n * A + a] + gg : gg;
+            }
+        }
+    }
+    if (loss) block_atomic_add(part / (double)nf, loss);
+}
+
+// The fused learner pass (header comment of rnad_learn_fused).  Per (t, b): 69 B read, 16 B written (A = 3).
+template <int A>
+__global__ __launch_bounds__(kThreads) void k_learn_fused(int T, int64_t B, const int32_t *__restrict__ indices,
+                                                          const uint8_t *__restrict__ mbits, const int32_t *__restrict__ actions,
+                                                          const float *__restrict__ rewards, const float *__restrict__ mu_,
+                                                          const float *__restrict__ logit_, const float *__restrict__ v_,
+                                                          const float *__restrict__ vtn_, const float *__restrict__ lreg_,
+                                                          const float *__restrict__ lreg2_, const double *__restrict__ norm,
+                                                          rnad_learn_params_t hp, double *__restrict__ losses,
+                                                          float *__restrict__ dlogit, float *__restrict__ dv,
+                                                          float *__restrict__ pi_out, float *__restrict__ vt_out,
+                                                          float *__restrict__ q_out) {
+    const int64_t b = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    double part_v = 0.0, part_n = 0.0;
+    if (b < B) {
+        const float nf0 = norm_of(norm), nf1 = norm_of(norm + 1);
+        const VtHp vh{-hp.eta, hp.lambda_, hp.c, hp.rho, hp.gamma};
+        Carry cy[2];
+        for (int t = T - 1; t >= 0; --t) {
+            const int64_t i = (int64_t)t * B + b;
+            const bool valid = indices[i] != 0;  // rnad.py:369
+            const float valid_f = valid ? 1.0f : 0.0f;
+            const int P = t & 1;  // turns[t, :] (episode.py:96-98)
+            const uint32_t bits = mbits[i];
+            const int act = actions[i];
+            float mu[A], lg[A], lr[A], lr2[A], legal[A], oh[A];
+#pragma unroll
+            for (int a = 0; a < A; ++a) {
+                mu[a] = mu_[i * A + a];
+                lg[a] = logit_[i * A + a];
+                lr[a] = lreg_[i * A + a];
+                lr2[a] = lreg2_[i * A + a];
+                legal[a] = (float)((bits >> a) & 1);
+                oh[a] = act == a ? 1.0f : 0.0f;
+            }
+            float pi[A], lp[A], lpr[A], lpr2[A], pip[A], lpol[A];
+            policy_head<A>(lg, bits, pi, lp);             // net.forward_batch of the learner (rnad.py:373)
+            log_policy_only<A>(lr, bits, lpr);            // net_reg (rnad.py:379)
+            log_policy_only<A>(lr2, bits, lpr2);          // net_reg_ (rnad.py:380)
+            process_policy_row<A>(pi, legal, hp.n_disc, hp.eps_threshold, pip);  // rnad.py:374
+#pragma unroll
+            for (int a = 0; a < A; ++a) lpol[a] = lp[a] - (hp.alpha * lpr[a] + hp.one_minus_alpha * lpr2[a]);  // rnad.py:382
+            const float rew = rewards[i];
+            const float vtn = vtn_[i];
+            float vt[2], q[2][A];
+            vtrace_step<A>(cy[0], vh, valid, P == 0, valid_f, vtn, rew, mu, pip, lpol, oh, vt[0], q[0]);   // player 0 (rnad.py:384-406)
+            vtrace_step<A>(cy[1], vh, valid, P == 1, valid_f, vtn, -rew, mu, pip, lpol, oh, vt[1], q[1]);  // player 1: rewards = -r (:368)
+            // losses: only player P has a non-zero mask at this step (has_played_P = valid && turn == P)
+            float g_v = 0.0f, g_l[A];
+#pragma unroll
+            for (int a = 0; a < A; ++a) g_l[a] = 0.0f;
+            if (valid) {
+                const float nfp = P ? nf1 : nf0;
+                const float vv = v_[i];
+                const float vtp = P ? vt[1] : vt[0];
+                const float d = vv - vtp;
+                part_v += (double)(d * d) / (double)nfp;
+                g_v = hp.w_v * (2.0f * d / nfp);
+                float qp[A], g[A];
+#pragma unroll
+                for (int a = 0; a < A; ++a) qp[a] = P ? q[1][a] : q[0][a];
+                const float nerd = nerd_row<A>(lg, pip, qp, legal, hp.clip, hp.threshold, g);
+                part_n += -(double)nerd / (double)nfp;
+#pragma unroll
+                for (int a = 0; a < A; ++a) g_l[a] = hp.w_n * (-g[a] / nfp);
+            }
+            dv[i] = g_v;
+#pragma unroll
+            for (int a = 0; a < A; ++a) dlogit[i * A + a] = g_l[a];
+            if (pi_out) {
+#pragma unroll
+                for (int a = 0; a < A; ++a) pi_out[i * A + a] = pi[a];
+            }
+            if (vt_out) {
+                vt_out[i] = vt[0];
+                vt_out[(int64_t)T * B + i] = vt[1];
+            }
+            if (q_out) {
+#pragma unroll
+                for (int a = 0; a < A; ++a) {
+                    q_out[i * A + a] = q[0][a];
+                    q_out[((int64_t)T * B + i) * A + a] = q[1][a];
+                }
+            }
+        }
+    }
+    if (losses) {
+        block_atomic_add(part_v, losses);
+        __syncthreads();
+        block_atomic_add(part_n, losses + 1);
+    }
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------- entry points
+extern "C" int rnad_process_policy(int64_t N, int A, const float *policy, const float *mask, int n_disc, float eps, float *out,
+                                   void *stream) {
+    RNAD_REQUIRE(policy && mask && out, "rnad_process_policy: null argument");
+    RNAD_REQUIRE(n_disc >= 1, "rnad_process_policy: n_disc must be positive");
+    if (N == 0) return 0;
+    RNAD_DISPATCH_A(A, hipLaunchKernelGGL((k_process_policy<kA>), dim3(blocks_for(N)), dim3(kThreads), 0, (hipStream_t)stream, N, policy,
+                                          mask, n_disc, eps, out));
+    RNAD_HIP_OK(hipGetLastError());
+    return 0;
+}
+
+extern "C" int rnad_vtrace(int T, int64_t B, int A, const float *v, const float *valid, const int32_t *player_id, const float *mu,
+                           const float *pi, const float *logpi, const void *actions, int actions_onehot, const float *reward,
+                           int player, float eta, float lambda_, float c, float rho, float gamma, float *v_target,
+                           int32_t *has_played, float *q, void *stream) {
+    RNAD_REQUIRE(v && valid && mu && pi && logpi && actions && reward && v_target && q, "rnad_vtrace: null argument");
+    RNAD_REQUIRE(T >= 0 && B >= 0, "rnad_vtrace: negative shape");
+    if (T == 0 || B == 0) return 0;
+    const VtHp hp{-eta, lambda_, c, rho, gamma};
+    RNAD_DISPATCH_A(A, {
+        if (actions_onehot)
+            hipLaunchKernelGGL((k_vtrace<kA, true>), dim3(blocks_for(B)), dim3(kThreads), 0, (hipStream_t)stream, T, B, v, valid, player_id,
+                               mu, pi, logpi, actions, reward, player, hp, v_target, has_played, q);
+        else
+            hipLaunchKernelGGL((k_vtrace<kA, false>), dim3(blocks_for(B)), dim3(kThreads), 0, (hipStream_t)stream, T, B, v, valid, player_id,
+                               mu, pi, logpi, actions, reward, player, hp, v_target, has_played, q);
+    });
+    RNAD_HIP_OK(hipGetLastError());
+    return 0;
+}
+
+extern "C" int rnad_mask_sum(int64_t N, const float *mask, double *out, void *stream) {
+    RNAD_REQUIRE(mask && out, "rnad_mask_sum: null argument");
+    RNAD_HIP_OK(hipMemsetAsync(out, 0, sizeof(double), (hipStream_t)stream));
+    if (N == 0) return 0;
+    const unsigned grid = (unsigned)std::min<int64_t>(blocks_for(N), 2048);
+    hipLaunchKernelGGL(k_mask_sum, dim3(grid), dim3(kThreads), 0, (hipStream_t)stream, N, mask, out);
+    RNAD_HIP_OK(hipGetLastError());
+    return 0;
+}
+
+extern "C" int rnad_loss_v(int64_t N, const float *v, const float *v_target, const float *mask, const double *norm, float weight,
+                           double *loss, float *dv, int accumulate, void *stream) {
+    RNAD_REQUIRE(v && v_target && mask && norm, "rnad_loss_v: null argument");
+    if (N == 0) return 0;
+    if (accumulate)
+        hipLaunchKernelGGL((k_loss_v<true>), dim3(blocks_for(N)), dim3(kThreads), 0, (hipStream_t)stream, N, v, v_target, mask, norm, weight,
+                           loss, dv);
+    else
+        hipLaunchKernelGGL((k_loss_v<false>), dim3(blocks_for(N)), dim3(kThreads), 0, (hipStream_t)stream, N, v, v_target, mask, norm, weight,
+                           loss, dv);
+    RNAD_HIP_OK(hipGetLastError());
+    return 0;
+}
+
+extern "C" int rnad_loss_nerd(int64_t N, int A, const float *logit, const float *pi, const float *q, const float *mask,
+                              const float *legal, const double *norm, float clip, float threshold, float weight, double *loss,
+                              float *dlogit, int accumulate, void *stream) {
+    RNAD_REQUIRE(logit && pi && q && mask && legal && norm, "rnad_loss_nerd: null argument");
+    if (N == 0) return 0;
+    RNAD_DISPATCH_A(A, {
+        if (accumulate)
+            hipLaunchKernelGGL((k_loss_nerd<kA, true>), dim3(blocks_for(N)), dim3(kThreads), 0, (hipStream_t)stream, N, logit, pi, q, mask,
+                               legal, norm, clip, threshold, weight, loss, dlogit);
+        else
+            hipLaunchKernelGGL((k_loss_nerd<kA, false>), dim3(blocks_for(N)), dim3(kThreads), 0, (hipStream_t)stream, N, logit, pi, q, mask,
+                               legal, norm, clip, threshold, weight, loss, dlogit);
+    });
+    RNAD_HIP_OK(hipGetLastError());
+    return 0;
+}
+
+extern "C" int rnad_learn_fused(int T, int64_t B, int A, const int32_t *indices, const uint8_t *mask_bits, const int32_t *actions,
+                                const float *rewards, const float *mu, const float *logit, const float *v, const float *v_target_net,
+                                const float *logit_reg, const float *logit_reg_, const double *norm, const rnad_learn_params_t *hp,
+                                double *losses, float *dlogit, float *dv, float *pi_out, float *v_target_out, float *q_out,
+                                void *stream_) {
+    RNAD_REQUIRE(indices && mask_bits && actions && rewards && mu && logit && v && v_target_net && logit_reg && logit_reg_ && norm &&
+                     hp && dlogit && dv,
+                 "rnad_learn_fused: null argument");
+    RNAD_REQUIRE(T >= 0 && B >= 0, "rnad_learn_fused: negative shape");
+    RNAD_REQUIRE(hp->n_disc >= 1, "rnad_learn_fused: n_disc must be positive");
+    hipStream_t stream = (hipStream_t)stream_;
+    if (losses) RNAD_HIP_OK(hipMemsetAsync(losses, 0, 2 * sizeof(double), stream));
+    if (T == 0 || B == 0) return 0;
+    ProfScope prof(PROF_LEARN, stream);
+    RNAD_DISPATCH_A(A, hipLaunchKernelGGL((k_learn_fused<kA>), dim3(blocks_for(B)), dim3(kThreads), 0, stream, T, B, indices, mask_bits,
+                                          actions, rewards, mu, logit, v, v_target_net, logit_reg, logit_reg_, norm, *hp, losses, dlogit,
+                                          dv, pi_out, v_target_out, q_out));
+    RNAD_HIP_OK(hipGetLastError());
+    return 0;
+}

@@ -1,0 +1,344 @@
+// rollout.hip -- policy head, sampler (K3), transition (K2) and the rollout driver (gfx950).
+//
+// Replaces: nn/net.py:45-49,74-77 (masked exp-normalise, log-policy, multinomial), environment/episode.py:96-125
+// (States.step) and :175-230 (Episodes.generate).  Citations are baskuit/R-NaD file:line.
+#include "common.hpp"
+
+using namespace rnad;
+
+namespace rnad {
+int launch_observe(const rnad_tree_t *tree, int64_t B, const int32_t *idx, int player, void *obs, int obs_half, uint8_t *mbits,
+                   float *maskf, hipStream_t stream);
+}
+
+namespace {
+
+constexpr int kThreads = 256;
+
+// nn/net.py:45-46: exp_logits = where(legal, exp(logits), 0); policy = normalize(exp_logits, p=1) (eps 1e-12).
+// :76-77: log_policy = where(legal, logits - log(sum(exp_logits)), 0).
+template <int A>
+__device__ __forceinline__ void policy_head(const float *logit, uint32_t legal_bits, float *policy, float *log_policy) {
+    float ex[A];
+    float s = 0.0f;
+#pragma unroll
+    for (int a = 0; a < A; ++a) {
+        ex[a] = ((legal_bits >> a) & 1) ? expf(logit[a]) : 0.0f;
+        s += fabsf(ex[a]);
+    }
+    const float d = fmaxf(s, 1e-12f);
+#pragma unroll
+    for (int a = 0; a < A; ++a) policy[a] = ex[a] / d;
+    if (log_policy) {
+        float s2 = 0.0f;
+#pragma unroll
+        for (int a = 0; a < A; ++a) s2 += ex[a];
+        const float ls = logf(s2);
+#pragma unroll
+        for (int a = 0; a < A; ++a) log_policy[a] = ((legal_bits >> a) & 1) ? logit[a] - ls : 0.0f;
+    }
+}
+
+// torch CPU multinomial(p, 1) == argmax(p / q), q ~ Exp(1), first maximum wins (Distributions.cpp, n_sample == 1).
+template <int N>
+__device__ __forceinline__ int race_argmax(const float *p, const float *q) {
+    int best = 0;
+    float bv = p[0] / q[0];
+#pragma unroll
+    for (int a = 1; a < N; ++a) {
+        const float r = p[a] / q[a];
+        if (r > bv) {
+            bv = r;
+            best = a;
+        }
+    }
+    return best;
+}
+
+// Runtime category count n <= NMAX without runtime-indexed arrays (those would live in scratch): fully
+// unrolled, predicated on k < n.
+template <int NMAX>
+__device__ __forceinline__ void exp_noise_n(uint64_t seed, uint64_t lane, uint32_t step, uint32_t stream, int n,
+                                            float (&q)[NMAX]) {
+#pragma unroll
+    for (int j = 0; j < NMAX; j += 4) {
+        if (j < n) {
+            uint32_t c[4] = {(uint32_t)lane, (uint32_t)(lane >> 32), step | (stream << 24), (uint32_t)(j >> 2)};
+            rnad_philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (j + i < NMAX) q[j + i] = rnad_neg_log_u(c[i]);
+        }
+    }
+}
+
+template <int NMAX>
+__device__ __forceinline__ void load_n(const float *__restrict__ src, int n, float (&dst)[NMAX]) {
+#pragma unroll
+    for (int k = 0; k < NMAX; ++k)
+        if (k < n) dst[k] = src[k];
+}
+
+template <int NMAX>
+__device__ __forceinline__ int race_argmax_n(int n, const float (&p)[NMAX], const float (&q)[NMAX]) {
+    int best = 0;
+    float bv = p[0] / q[0];
+#pragma unroll
+    for (int a = 1; a < NMAX; ++a) {
+        if (a < n) {
+            const float r = p[a] / q[a];
+            if (r > bv) {
+                bv = r;
+                best = a;
+            }
+        }
+    }
+    return best;
+}
+
+template <int A>
+__global__ __launch_bounds__(kThreads) void k_policy_head(int64_t N, const float *__restrict__ logits,
+                                                          const uint8_t *__restrict__ mbits, const float *__restrict__ maskf,
+                                                          float *__restrict__ policy, float *__restrict__ log_policy) {
+    const int64_t n = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    if (n >= N) return;
+    float l[A], p[A], lp[A];
+    uint32_t bits = 0;
+#pragma unroll
+    for (int a = 0; a < A; ++a) {
+        l[a] = logits[n * A + a];
+        if (!mbits) bits |= (maskf[n * A + a] != 0.0f ? 1u : 0u) << a;
+    }
+    if (mbits) bits = mbits[n];
+    policy_head<A>(l, bits, p, log_policy ? lp : nullptr);
+#pragma unroll
+    for (int a = 0; a < A; ++a) {
+        policy[n * A + a] = p[a];
+        if (log_policy) log_policy[n * A + a] = lp[a];
+    }
+}
+
+__global__ __launch_bounds__(kThreads) void k_sample(int64_t B, int n, const float *__restrict__ probs,
+                                                     const float *__restrict__ noise, uint64_t seed, int64_t lane0, int step,
+                                                     int stream_id, int32_t *__restrict__ out) {
+    const int64_t b = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    if (b >= B) return;
+    float p[RNAD_MAX_ACTIONS], q[RNAD_MAX_ACTIONS];
+    load_n<RNAD_MAX_ACTIONS>(probs + b * n, n, p);
+    if (noise)
+        load_n<RNAD_MAX_ACTIONS>(noise + b * n, n, q);
+    else
+        exp_noise_n<RNAD_MAX_ACTIONS>(seed, (uint64_t)(lane0 + b), (uint32_t)step, (uint32_t)stream_id, n, q);
+    out[b] = race_argmax_n<RNAD_MAX_ACTIONS>(n, p, q);
+}
+
+// environment/episode.py:106-121 for one lane: the C chance outcomes of joint action (r, c) are 12*C contiguous bytes.
+template <int A>
+__device__ __forceinline__ void transition_lane(const Trans *__restrict__ trans, int C, int s, int r, int c,
+                                                const float *__restrict__ noise_c, uint64_t seed, uint64_t lane, uint32_t step,
+                                                int &next, float &reward) {
+    const Trans *e = trans + (((int64_t)s * A + r) * A + c) * C;
+    float q[RNAD_MAX_TRANSITIONS];
+    if (noise_c)
+        load_n<RNAD_MAX_TRANSITIONS>(noise_c, C, q);
+    else
+        exp_noise_n<RNAD_MAX_TRANSITIONS>(seed, lane, step, 1u, C, q);
+    Trans best = e[0];
+    float bv = best.chance / q[0];
+#pragma unroll
+    for (int t = 1; t < RNAD_MAX_TRANSITIONS; ++t) {
+        if (t < C) {
+            const Trans et = e[t];
+            const float rr = et.chance / q[t];
+            if (rr > bv) {
+                bv = rr;
+                best = et;
+            }
+        }
+    }
+    next = best.next;
+    reward = best.value * (next == 0 ? 1.0f : 0.0f);  // rewards *= (indices == 0): keeps -0.0
+}
+
+template <int A>
+__global__ __launch_bounds__(kThreads) void k_transition(const Trans *__restrict__ trans, int C, int64_t B,
+                                                         const int32_t *__restrict__ idx, const int32_t *__restrict__ row_a,
+                                                         const int32_t *__restrict__ col_a, const float *__restrict__ noise,
+                                                         uint64_t seed, int64_t lane0, int step, int32_t *__restrict__ idx_out,
+                                                         float *__restrict__ reward, int32_t *__restrict__ alive) {
+    const int64_t b = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    bool live = false;
+    if (b < B) {
+        int next;
+        float rew;
+        transition_lane<A>(trans, C, idx[b], row_a[b], col_a[b], noise ? noise + b * C : nullptr, seed, (uint64_t)(lane0 + b),
+                           (uint32_t)step, next, rew);
+        idx_out[b] = next;
+        reward[b] = rew;
+        live = next != 0;
+    }
+    if (alive) {
+        const unsigned long long m = __ballot(live);
+        if ((threadIdx.x & 63) == 0 && m) atomicAdd(alive, (int)__popcll(m));
+    }
+}
+
+// One env step of Episodes.generate for one lane (episode.py:196-212), everything except the net forward and
+// the observation of the next step.  MODE 0: logits -> policy head -> sample; 1: policy given -> sample;
+// 2: policy and action given (a net that samples for itself, net.py:49).
+template <int A, int MODE>
+__global__ __launch_bounds__(kThreads) void k_act(const Trans *__restrict__ trans, int C, int64_t B, int t,
+                                                  const float *__restrict__ net_out, const int32_t *__restrict__ actions_in,
+                                                  const float *__restrict__ value, const float *__restrict__ noise_a,
+                                                  const float *__restrict__ noise_c, uint64_t seed, int64_t lane0,
+                                                  const int32_t *__restrict__ idx_t, const uint8_t *__restrict__ mbits_t,
+                                                  const int32_t *__restrict__ act_prev, float *__restrict__ policy_t,
+                                                  int32_t *__restrict__ act_t, float *__restrict__ rewards_t,
+                                                  float *__restrict__ values_t, int32_t *__restrict__ idx_next,
+                                                  int32_t *__restrict__ alive_next) {
+    const int64_t b = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    bool live = false;
+    if (b < B) {
+        float in[A], pol[A];
+#pragma unroll
+        for (int a = 0; a < A; ++a) in[a] = net_out[b * A + a];
+        if (MODE == 0) {
+            policy_head<A>(in, mbits_t[b], pol, nullptr);
+        } else {
+#pragma unroll
+            for (int a = 0; a < A; ++a) pol[a] = in[a];
+        }
+        int action;
+        if (MODE == 2) {
+            action = actions_in[b];
+        } else {
+            float q[A];
+            if (noise_a) {
+#pragma unroll
+                for (int a = 0; a < A; ++a) q[a] = noise_a[b * A + a];
+            } else {
+                rnad_exp_noise(seed, (uint64_t)(lane0 + b), (uint32_t)t, 0u, A, q);
+            }
+            action = race_argmax<A>(pol, q);
+        }
+#pragma unroll
+        for (int a = 0; a < A; ++a) policy_t[b * A + a] = pol[a];
+        act_t[b] = action;
+        values_t[b] = value[b];
+        const int s = idx_t[b];
+        int next = s;
+        float rew = 0.0f;  // row turn: torch.zeros (episode.py:101)
+        if (t & 1)
+            transition_lane<A>(trans, C, s, act_prev[b], action, noise_c ? noise_c + b * C : nullptr, seed,
+                               (uint64_t)(lane0 + b), (uint32_t)t, next, rew);
+        idx_next[b] = next;
+        rewards_t[b] = rew;
+        live = next != 0;
+    }
+    const unsigned long long m = __ballot(live);
+    if ((threadIdx.x & 63) == 0 && m) atomicAdd(alive_next, (int)__popcll(m));
+}
+
+__global__ void k_fill_i32(int64_t n, int32_t *p, int32_t v) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+
+inline unsigned blocks_for(int64_t n) { return (unsigned)((n + kThreads - 1) / kThreads); }
+
+}  // namespace
+
+extern "C" int rnad_policy_head(int64_t N, int A, const float *logits, const uint8_t *mask_bits, const float *mask,
+                                float *policy, float *log_policy, void *stream) {
+    RNAD_REQUIRE(logits && policy && (mask_bits || mask), "rnad_policy_head: null argument");
+    if (N == 0) return 0;
+    RNAD_DISPATCH_A(A, hipLaunchKernelGGL((k_policy_head<kA>), dim3(blocks_for(N)), dim3(kThreads), 0, (hipStream_t)stream, N,
+                                          logits, mask_bits, mask, policy, log_policy));
+    RNAD_HIP_OK(hipGetLastError());
+    return 0;
+}
+
+extern "C" int rnad_sample(int64_t B, int n, const float *probs, const float *noise, uint64_t seed, int64_t lane0, int step,
+                           int stream_id, int32_t *out, void *stream) {
+    RNAD_REQUIRE(probs && out, "rnad_sample: null argument");
+    RNAD_REQUIRE(n >= 1 && n <= RNAD_MAX_ACTIONS, "rnad_sample: %d categories out of range [1,%d]", n, RNAD_MAX_ACTIONS);
+    if (B == 0) return 0;
+    hipLaunchKernelGGL(k_sample, dim3(blocks_for(B)), dim3(kThreads), 0, (hipStream_t)stream, B, n, probs, noise, seed, lane0,
+                       step, stream_id, out);
+    RNAD_HIP_OK(hipGetLastError());
+    return 0;
+}
+
+extern "C" int rnad_transition(const rnad_tree_t *tree, int64_t B, const int32_t *idx, const int32_t *row_actions,
+                               const int32_t *col_actions, const float *noise, uint64_t seed, int64_t lane0, int step,
+                               int32_t *idx_out, float *reward, int32_t *alive, void *stream) {
+    RNAD_REQUIRE(tree && idx && row_actions && col_actions && idx_out && reward, "rnad_transition: null argument");
+    if (B == 0) return 0;
+    RNAD_DISPATCH_A(tree->A, hipLaunchKernelGGL((k_transition<kA>), dim3(blocks_for(B)), dim3(kThreads), 0, (hipStream_t)stream,
+                                                tree->trans, tree->C, B, idx, row_actions, col_actions, noise, seed, lane0,
+                                                step, idx_out, reward, alive));
+    RNAD_HIP_OK(hipGetLastError());
+    return 0;
+}
+
+static int check_traj(const rnad_tree_t *tree, const rnad_traj_t *tr, const char *who) {
+    RNAD_REQUIRE(tree && tr, "%s: null argument", who);
+    RNAD_REQUIRE(tr->indices && tr->observations && tr->mask_bits && tr->policy && tr->actions && tr->rewards && tr->values &&
+                     tr->alive,
+                 "%s: trajectory has a null buffer", who);
+    RNAD_REQUIRE(tr->T_cap >= 1 && tr->B >= 1, "%s: bad trajectory shape T_cap=%d B=%lld", who, tr->T_cap, (long long)tr->B);
+    return 0;
+}
+
+extern "C" int rnad_rollout_begin(const rnad_tree_t *tree, const rnad_traj_t *tr, void *stream_) {
+    if (int rc = check_traj(tree, tr, "rnad_rollout_begin")) return rc;
+    hipStream_t stream = (hipStream_t)stream_;
+    RNAD_HIP_OK(hipMemsetAsync(tr->alive, 0, sizeof(int32_t) * (tr->T_cap + 1), stream));
+    hipLaunchKernelGGL(k_fill_i32, dim3(blocks_for(tr->B)), dim3(kThreads), 0, stream, tr->B, tr->indices, 1);  // root, episode.py:22
+    const int32_t b32 = (int32_t)tr->B;
+    RNAD_REQUIRE(tr->B < ((int64_t)1 << 31), "rnad_rollout_begin: batch %lld too large", (long long)tr->B);
+    hipLaunchKernelGGL(k_fill_i32, dim3(1), dim3(1), 0, stream, (int64_t)1, tr->alive, b32);
+    RNAD_HIP_OK(hipGetLastError());
+    return launch_observe(tree, tr->B, tr->indices, 0, tr->observations, tr->obs_half, tr->mask_bits, nullptr, stream);
+}
+
+extern "C" int rnad_rollout_step(const rnad_tree_t *tree, const rnad_traj_t *tr, int t, int mode, const float *logits,
+                                 const float *policy_in, const int32_t *actions_in, const float *value,
+                                 const float *noise_action, const float *noise_chance, uint64_t seed, int64_t lane0,
+                                 void *stream_) {
+    if (int rc = check_traj(tree, tr, "rnad_rollout_step")) return rc;
+    RNAD_REQUIRE(t >= 0 && t < tr->T_cap, "rnad_rollout_step: step %d outside [0,%d)", t, tr->T_cap);
+    RNAD_REQUIRE(mode >= 0 && mode <= 2, "rnad_rollout_step: mode %d", mode);
+    RNAD_REQUIRE(value, "rnad_rollout_step: value is null");
+    RNAD_REQUIRE(mode != 0 || logits, "rnad_rollout_step: mode 0 needs logits");
+    RNAD_REQUIRE(mode == 0 || policy_in, "rnad_rollout_step: mode %d needs policy_in", mode);
+    RNAD_REQUIRE(mode != 2 || actions_in, "rnad_rollout_step: mode 2 needs actions_in");
+    hipStream_t stream = (hipStream_t)stream_;
+    const int64_t B = tr->B;
+    const int A = tree->A;
+    const float *net_out = mode == 0 ? logits : policy_in;
+    const int32_t *idx_t = tr->indices + (int64_t)t * B;
+    const int32_t *act_prev = t > 0 ? tr->actions + (int64_t)(t - 1) * B : tr->actions;
+    {
+        ProfScope prof(PROF_ACT, stream);
+#define RNAD_ACT(MODE_)                                                                                                       \
+    hipLaunchKernelGGL((k_act<kA, MODE_>), dim3(blocks_for(B)), dim3(kThreads), 0, stream, tree->trans, tree->C, B, t, net_out, \
+                       actions_in, value, noise_action, noise_chance, seed, lane0, idx_t, tr->mask_bits + (int64_t)t * B,      \
+                       act_prev, tr->policy + (int64_t)t * B * A, tr->actions + (int64_t)t * B, tr->rewards + (int64_t)t * B,  \
+                       tr->values + (int64_t)t * B, tr->indices + (int64_t)(t + 1) * B, tr->alive + t + 1)
+        RNAD_DISPATCH_A(A, {
+            if (mode == 0) RNAD_ACT(0);
+            else if (mode == 1) RNAD_ACT(1);
+            else RNAD_ACT(2);
+        });
+#undef RNAD_ACT
+        RNAD_HIP_OK(hipGetLastError());
+    }
+    if (t + 1 < tr->T_cap) {
+        const size_t esz = tr->obs_half ? 2 : 4;
+        void *obs_next = (char *)tr->observations + (size_t)(t + 1) * B * 2 * A * A * esz;
+        return launch_observe(tree, B, tr->indices + (int64_t)(t + 1) * B, (t + 1) & 1, obs_next, tr->obs_half,
+                              tr->mask_bits + (int64_t)(t + 1) * B, nullptr, stream);
+    }
+    return 0;
+}

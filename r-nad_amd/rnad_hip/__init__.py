@@ -1,0 +1,334 @@
+"""ctypes binding of librnad_hip.so (include/rnad_hip.h) for torch device tensors.
+
+Thin plumbing only: every function checks dtype/device/contiguity, passes `tensor.data_ptr()` and
+torch's CURRENT stream to the C-ABI and raises `RnadHipError` on a non-zero status.  There is no
+CPU fallback: if the library is missing or a tensor is not on a GPU the call fails loudly.
+"""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.realpath(__file__))
+SO_PATH = os.path.join(_HERE, "..", "csrc", "librnad_hip.so")
+
+MAX_ACTIONS = 8
+MAX_TRANSITIONS = 8
+
+
+class RnadHipError(RuntimeError):
+    pass
+
+
+class Traj(C.Structure):
+    """struct rnad_traj (include/rnad_hip.h)."""
+
+    _fields_ = [
+        ("T_cap", C.c_int32), ("obs_half", C.c_int32), ("B", C.c_int64),
+        ("indices", C.c_void_p), ("observations", C.c_void_p), ("mask_bits", C.c_void_p),
+        ("policy", C.c_void_p), ("actions", C.c_void_p), ("rewards", C.c_void_p),
+        ("values", C.c_void_p), ("alive", C.c_void_p),
+    ]
+
+
+class LearnParams(C.Structure):
+    """struct rnad_learn_params (include/rnad_hip.h)."""
+
+    _fields_ = [
+        ("alpha", C.c_float), ("one_minus_alpha", C.c_float),
+        ("eta", C.c_float), ("lambda_", C.c_float), ("c", C.c_float), ("rho", C.c_float), ("gamma", C.c_float),
+        ("clip", C.c_float), ("threshold", C.c_float), ("w_v", C.c_float), ("w_n", C.c_float),
+        ("eps_threshold", C.c_float), ("n_disc", C.c_int32),
+    ]
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(SO_PATH):
+            raise RnadHipError(
+                f"{os.path.normpath(SO_PATH)} is missing: build it with `make -C r-nad_amd/csrc` "
+                "(or __graft_entry__.build()).  There is no CPU fallback for the R-NaD hot path."
+            )
+        _lib = C.CDLL(SO_PATH)
+        _lib.rnad_last_error.restype = C.c_char_p
+        _lib.rnad_tree_info.restype = C.c_int64
+        _lib.rnad_tree_generate.restype = C.c_int64
+        _lib.rnad_tree_destroy.restype = None
+    return _lib
+
+
+def _check(rc):
+    if rc != 0:
+        raise RnadHipError(lib().rnad_last_error().decode() or f"librnad_hip status {rc}")
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _dp(t, dtype, name, optional=False):
+    """Device pointer of a contiguous CUDA tensor of the given dtype."""
+    if t is None:
+        if optional:
+            return None
+        raise RnadHipError(f"{name}: tensor required")
+    if not t.is_cuda:
+        raise RnadHipError(f"{name}: expected a GPU tensor, got device {t.device} (no CPU path)")
+    if t.dtype != dtype:
+        raise RnadHipError(f"{name}: expected dtype {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise RnadHipError(f"{name}: tensor must be contiguous")
+    return C.c_void_p(t.data_ptr())
+
+
+F32, F64, I32, U8, F16 = torch.float32, torch.float64, torch.int32, torch.uint8, torch.float16
+
+
+# --------------------------------------------------------------------------------------- tree
+class TreeHandle:
+    """Owns an `rnad_tree_t*`: the packed node / transition tables on one GPU."""
+
+    def __init__(self, index, value, chance, expected_value, legal, device):
+        dev = torch.device(device)
+        if dev.type != "cuda":
+            raise RnadHipError(f"tree tables can only be uploaded to a GPU, got device {dev}")
+        host = lambda t, dt: t.detach().to("cpu", dt).contiguous()  # noqa: E731
+        index, value, chance = host(index, torch.int64), host(value, F32), host(chance, F32)
+        expected_value, legal = host(expected_value, F32), host(legal, F32)
+        S, Cc, A, A2 = index.shape
+        assert A == A2 and value.shape == index.shape and chance.shape == index.shape
+        assert expected_value.shape == (S, 1, A, A) and legal.shape == (S, 1, A, A)
+        self.S, self.C, self.A = S, Cc, A
+        self.device = dev
+        self._h = C.c_void_p()
+        idx = dev.index if dev.index is not None else torch.cuda.current_device()
+        _check(lib().rnad_tree_create(C.byref(self._h), C.c_int64(S), Cc, A, C.c_void_p(index.data_ptr()),
+                                      C.c_void_p(value.data_ptr()), C.c_void_p(chance.data_ptr()),
+                                      C.c_void_p(expected_value.data_ptr()), C.c_void_p(legal.data_ptr()), idx))
+        self.max_depth = int(lib().rnad_tree_info(self._h, 3))
+        self.table_bytes = int(lib().rnad_tree_info(self._h, 5))
+
+    @property
+    def ptr(self):
+        return self._h
+
+    def __del__(self):
+        try:
+            if self._h:
+                lib().rnad_tree_destroy(self._h)
+                self._h = C.c_void_p()
+        except Exception:
+            pass
+
+
+def observe(tree, idx, player, obs=None, half=False, mask_bits=None, mask=None):
+    """K1.  idx int32 [B] -> obs [B,2,A,A] (fp32 or fp16), optional mask_bits u8 [B], mask f32 [B,A]."""
+    B, A = idx.shape[0], tree.A
+    if obs is None:
+        obs = torch.empty((B, 2, A, A), dtype=F16 if half else F32, device=idx.device)
+    _check(lib().rnad_observe(tree.ptr, C.c_int64(B), _dp(idx, I32, "idx"), int(player), _dp(obs, F16 if half else F32, "obs"),
+                              int(half), _dp(mask_bits, U8, "mask_bits", True), _dp(mask, F32, "mask", True), _stream()))
+    return obs
+
+
+def observe_all(tree, device):
+    S, A = tree.S, tree.A
+    row = torch.empty((S, 2, A, A), dtype=F32, device=device)
+    col = torch.empty_like(row)
+    _check(lib().rnad_observe_all(tree.ptr, _dp(row, F32, "obs_row"), _dp(col, F32, "obs_col"), _stream()))
+    return row, col
+
+
+# --------------------------------------------------------------------------------------- policy head / sampler / transition
+def policy_head(logits, mask_bits=None, mask=None, want_log=False):
+    A = logits.shape[-1]
+    N = logits.numel() // A
+    policy = torch.empty_like(logits)
+    log_policy = torch.empty_like(logits) if want_log else None
+    _check(lib().rnad_policy_head(C.c_int64(N), A, _dp(logits, F32, "logits"), _dp(mask_bits, U8, "mask_bits", True),
+                                  _dp(mask, F32, "mask", True), _dp(policy, F32, "policy"),
+                                  _dp(log_policy, F32, "log_policy", True), _stream()))
+    return (policy, log_policy) if want_log else policy
+
+
+def sample(probs, noise=None, seed=0, lane0=0, step=0, stream_id=0):
+    B, n = probs.shape
+    out = torch.empty((B,), dtype=I32, device=probs.device)
+    _check(lib().rnad_sample(C.c_int64(B), n, _dp(probs, F32, "probs"), _dp(noise, F32, "noise", True), C.c_uint64(seed),
+                             C.c_int64(lane0), int(step), int(stream_id), _dp(out, I32, "out"), _stream()))
+    return out
+
+
+def transition(tree, idx, row_actions, col_actions, noise=None, seed=0, lane0=0, step=1, alive=None):
+    B = idx.shape[0]
+    idx_out = torch.empty_like(idx)
+    reward = torch.empty((B,), dtype=F32, device=idx.device)
+    _check(lib().rnad_transition(tree.ptr, C.c_int64(B), _dp(idx, I32, "idx"), _dp(row_actions, I32, "row_actions"),
+                                 _dp(col_actions, I32, "col_actions"), _dp(noise, F32, "noise", True), C.c_uint64(seed),
+                                 C.c_int64(lane0), int(step), _dp(idx_out, I32, "idx_out"), _dp(reward, F32, "reward"),
+                                 _dp(alive, I32, "alive", True), _stream()))
+    return idx_out, reward
+
+
+# --------------------------------------------------------------------------------------- rollout driver
+class Trajectory:
+    """Preallocated [T_cap, B, ...] device buffers of one batch of episodes (struct rnad_traj)."""
+
+    def __init__(self, tree, B, T_cap, device, half=False):
+        A = tree.A
+        self.T_cap, self.B, self.A, self.half = T_cap, B, A, half
+        self.indices = torch.empty((T_cap + 1, B), dtype=I32, device=device)
+        self.observations = torch.empty((T_cap, B, 2, A, A), dtype=F16 if half else F32, device=device)
+        self.mask_bits = torch.empty((T_cap, B), dtype=U8, device=device)
+        self.policy = torch.empty((T_cap, B, A), dtype=F32, device=device)
+        self.actions = torch.empty((T_cap, B), dtype=I32, device=device)
+        self.rewards = torch.empty((T_cap, B), dtype=F32, device=device)
+        self.values = torch.empty((T_cap, B), dtype=F32, device=device)
+        self.alive = torch.empty((T_cap + 1,), dtype=I32, device=device)
+        self.c = Traj(T_cap, int(half), B, self.indices.data_ptr(), self.observations.data_ptr(), self.mask_bits.data_ptr(),
+                      self.policy.data_ptr(), self.actions.data_ptr(), self.rewards.data_ptr(), self.values.data_ptr(),
+                      self.alive.data_ptr())
+
+
+def rollout_begin(tree, traj):
+    _check(lib().rnad_rollout_begin(tree.ptr, C.byref(traj.c), _stream()))
+
+
+def rollout_step(tree, traj, t, value, logits=None, policy=None, actions=None, noise_action=None, noise_chance=None,
+                 seed=0, lane0=0):
+    mode = 0 if logits is not None else (1 if actions is None else 2)
+    _check(lib().rnad_rollout_step(tree.ptr, C.byref(traj.c), int(t), mode, _dp(logits, F32, "logits", True),
+                                   _dp(policy, F32, "policy", True), _dp(actions, I32, "actions", True),
+                                   _dp(value, F32, "value"), _dp(noise_action, F32, "noise_action", True),
+                                   _dp(noise_chance, F32, "noise_chance", True), C.c_uint64(seed), C.c_int64(lane0), _stream()))
+
+
+# --------------------------------------------------------------------------------------- learner kernels
+def process_policy(policy, mask, n_disc, eps):
+    A = policy.shape[-1]
+    out = torch.empty_like(policy)
+    _check(lib().rnad_process_policy(C.c_int64(policy.numel() // A), A, _dp(policy, F32, "policy"), _dp(mask, F32, "mask"),
+                                     int(n_disc), C.c_float(eps), _dp(out, F32, "out"), _stream()))
+    return out
+
+
+def vtrace(v, valid, player_id, mu, pi, logpi, actions, reward, player, eta, lambda_, c, rho, gamma, want_has_played=True):
+    """actions: one-hot f32 [T,B,A] or int32 [T,B]; player_id: int32 [T,B] or None (= t & 1)."""
+    T, B, A = mu.shape
+    onehot = actions.dtype == F32
+    v_target = torch.empty((T, B), dtype=F32, device=mu.device)
+    q = torch.empty((T, B, A), dtype=F32, device=mu.device)
+    has_played = torch.empty((T, B), dtype=I32, device=mu.device) if want_has_played else None
+    _check(lib().rnad_vtrace(T, C.c_int64(B), A, _dp(v, F32, "v"), _dp(valid, F32, "valid"), _dp(player_id, I32, "player_id", True),
+                             _dp(mu, F32, "mu"), _dp(pi, F32, "pi"), _dp(logpi, F32, "logpi"),
+                             _dp(actions, F32 if onehot else I32, "actions"), int(onehot), _dp(reward, F32, "reward"), int(player),
+                             C.c_float(eta), C.c_float(lambda_), C.c_float(c), C.c_float(rho), C.c_float(gamma),
+                             _dp(v_target, F32, "v_target"), _dp(has_played, I32, "has_played", True), _dp(q, F32, "q"), _stream()))
+    return v_target, has_played, q
+
+
+def mask_sum(mask):
+    out = torch.empty((1,), dtype=F64, device=mask.device)
+    _check(lib().rnad_mask_sum(C.c_int64(mask.numel()), _dp(mask, F32, "mask"), _dp(out, F64, "out"), _stream()))
+    return out
+
+
+def loss_v(v, v_target, mask, norm, weight, loss, dv, accumulate):
+    _check(lib().rnad_loss_v(C.c_int64(v.numel()), _dp(v, F32, "v"), _dp(v_target, F32, "v_target"), _dp(mask, F32, "mask"),
+                             _dp(norm, F64, "norm"), C.c_float(weight), _dp(loss, F64, "loss", True), _dp(dv, F32, "dv", True),
+                             int(accumulate), _stream()))
+
+
+def loss_nerd(logit, pi, q, mask, legal, norm, clip, threshold, weight, loss, dlogit, accumulate):
+    A = logit.shape[-1]
+    _check(lib().rnad_loss_nerd(C.c_int64(logit.numel() // A), A, _dp(logit, F32, "logit"), _dp(pi, F32, "pi"), _dp(q, F32, "q"),
+                                _dp(mask, F32, "mask"), _dp(legal, F32, "legal"), _dp(norm, F64, "norm"), C.c_float(clip),
+                                C.c_float(threshold), C.c_float(weight), _dp(loss, F64, "loss", True),
+                                _dp(dlogit, F32, "dlogit", True), int(accumulate), _stream()))
+
+
+def learn_fused(indices, mask_bits, actions, rewards, mu, logit, v, v_target_net, logit_reg, logit_reg_, norm, hp,
+                want_aux=False):
+    """One pass over a [T,B] trajectory: returns dlogit [T,B,A], dv [T,B], losses f64[2] and (optionally) pi, v_target, q."""
+    T, B, A = mu.shape
+    dev = mu.device
+    dlogit = torch.empty((T, B, A), dtype=F32, device=dev)
+    dv = torch.empty((T, B), dtype=F32, device=dev)
+    losses = torch.empty((2,), dtype=F64, device=dev)
+    pi = torch.empty((T, B, A), dtype=F32, device=dev) if want_aux else None
+    vt = torch.empty((2, T, B), dtype=F32, device=dev) if want_aux else None
+    q = torch.empty((2, T, B, A), dtype=F32, device=dev) if want_aux else None
+    _check(lib().rnad_learn_fused(T, C.c_int64(B), A, _dp(indices, I32, "indices"), _dp(mask_bits, U8, "mask_bits"),
+                                  _dp(actions, I32, "actions"), _dp(rewards, F32, "rewards"), _dp(mu, F32, "mu"),
+                                  _dp(logit, F32, "logit"), _dp(v, F32, "v"), _dp(v_target_net, F32, "v_target_net"),
+                                  _dp(logit_reg, F32, "logit_reg"), _dp(logit_reg_, F32, "logit_reg_"), _dp(norm, F64, "norm"),
+                                  C.byref(hp), _dp(losses, F64, "losses"), _dp(dlogit, F32, "dlogit"), _dp(dv, F32, "dv"),
+                                  _dp(pi, F32, "pi", True), _dp(vt, F32, "vt", True), _dp(q, F32, "q", True), _stream()))
+    return dlogit, dv, losses, pi, vt, q
+
+
+def make_learn_params(alpha, eta, lambda_=1.0, c=1.0, rho=1.0, gamma=1.0, clip=1e3, threshold=2.0, w_v=1.0, w_n=1.0,
+                      eps_threshold=0.03, n_disc=32):
+    # 1 - alpha is taken in double like the reference's python scalar (rnad.py:382), then rounded to fp32
+    return LearnParams(float(alpha), 1.0 - float(alpha), float(eta), float(lambda_), float(c), float(rho), float(gamma),
+                       float(clip), float(threshold), float(w_v), float(w_n), float(eps_threshold), int(n_disc))
+
+
+# --------------------------------------------------------------------------------------- NashConv
+def nashconv(tree, joint_policy, root_policy, state_index, reach, row_best, col_best, reach_out, depth_out):
+    _check(lib().rnad_nashconv(tree.ptr, _dp(joint_policy, F32, "joint_policy"), _dp(root_policy, F32, "root_policy"),
+                               C.c_int64(state_index), C.c_float(reach), _dp(row_best, F32, "row_best"),
+                               _dp(col_best, F32, "col_best"), _dp(reach_out, F32, "reach_probability"),
+                               _dp(depth_out, I32, "depth"), _stream()))
+
+
+# --------------------------------------------------------------------------------------- host-side: generator / solver
+def solve_matrix(M, max_actions):
+    """tree.py:199-234 for one fp32 matrix (CPU tensor [ra, ca]) -> (solution [2*max_actions], value)."""
+    M = M.detach().to("cpu", F32).contiguous()
+    ra, ca = M.shape
+    sol = torch.zeros((2 * max_actions,), dtype=F32)
+    val = C.c_float()
+    _check(lib().rnad_solve_matrix(C.c_void_p(M.data_ptr()), ra, ca, max_actions, C.c_void_p(sol.data_ptr()), C.byref(val)))
+    return sol, val.value
+
+
+def tree_generate(A, Cc, depth_bound, transition_threshold=0.0, terminal_values=(-1.0, 1.0), prune=(0, 0), seed=0):
+    """Native regular-tree generator (rnad_tree_generate).  Returns a dict of CPU tensors in the reference layout."""
+    tv = torch.tensor(list(terminal_values), dtype=F32)
+    args = (A, Cc, int(depth_bound), C.c_float(transition_threshold), C.c_void_p(tv.data_ptr()), tv.numel(), int(prune[0]),
+            int(prune[1]), C.c_uint64(seed))
+    null = C.c_void_p()
+    S = lib().rnad_tree_generate(*args, C.c_int64(0), null, null, null, null, null, null, null)
+    if S < 0:
+        _check(1)
+    out = dict(
+        index=torch.zeros((S, Cc, A, A), dtype=torch.int64), value=torch.zeros((S, Cc, A, A), dtype=F32),
+        chance=torch.zeros((S, Cc, A, A), dtype=F32), expected_value=torch.zeros((S, 1, A, A), dtype=F32),
+        legal=torch.zeros((S, 1, A, A), dtype=F32), root_value=torch.zeros((S, 1), dtype=F32),
+        solution=torch.zeros((S, 2 * A), dtype=F32),
+    )
+    S2 = lib().rnad_tree_generate(*args, C.c_int64(S), *[C.c_void_p(out[k].data_ptr()) for k in
+                                                         ("index", "value", "chance", "expected_value", "legal", "root_value", "solution")])
+    if S2 != S:
+        _check(1 if S2 < 0 else 0)
+        raise RnadHipError(f"rnad_tree_generate is not deterministic: {S} then {S2} states")
+    return out
+
+
+# --------------------------------------------------------------------------------------- profiling hooks
+PROF_OBSERVE, PROF_ACT, PROF_LEARN = 0, 1, 2
+
+
+def prof_enable(on):
+    _check(lib().rnad_prof_enable(int(bool(on))))
+
+
+def prof_read(which):
+    n, ms = C.c_int64(), C.c_double()
+    _check(lib().rnad_prof_read(int(which), C.byref(n), C.byref(ms)))
+    return n.value, ms.value
