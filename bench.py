@@ -1,0 +1,202 @@
+#!/usr/bin/env python3
+"""bench.py -- the R-NaD self-play hot path on MI355X: env-steps/s and updates/s at batch 2^20.
+
+    python bench.py --gpus 1 --steps 5 --warmup 2
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \\
+        bench.py --gpus N --steps K --warmup W
+
+One "step" = one iteration of the reference's training loop (learn/rnad.py:495-526): roll out a batch of episodes with
+the learner net (Episodes.generate), sample the buffer, RNaD.__learn (4 MLP forwards, fused V-trace/NeuRD kernel,
+backward), Adam, EMA target.  Workload = BASELINE.json configs[1]: depth-6 ternary (3x3) tree, C = 1, 66 431 states,
+GLOBAL batch 2^20 episodes x 12 env steps, MLP width 256, fp32.  N > 1 shards the episodes over the ranks (strong
+scaling, BASELINE north_star) with one RCCL all-reduce of the 2 loss normalisers and one of the 43 KB gradient bucket.
+
+Prints ONE JSON line on rank 0.  `value` = env steps of all ranks / wall time of the K timed steps (inputs resident in HBM;
+the tree is generated and uploaded before the timed region).  `roofline` is for K1, the episode-gather kernel
+(rnad_observe): algorithmic bytes per launch (160 B per env step at A = 3 fp32) / mean launch duration
+measured with hipEvents on the launching stream inside the timed region.  `cpu_baseline` times the CPU port
+(oracle/port.py: C oracle + PyTorch-CPU MLP) of the same step on a bounded sample, rank 0, N = 1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.realpath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "r-nad_amd"))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch-log2", type=int, default=20, help="log2 of the GLOBAL episode batch")
+    ap.add_argument("--depth", type=int, default=6)
+    ap.add_argument("--actions", type=int, default=3)
+    ap.add_argument("--transitions", type=int, default=1)
+    ap.add_argument("--width", type=int, default=256)
+    ap.add_argument("--obs-half", action="store_true", help="fp16 observations (BASELINE configs[4])")
+    ap.add_argument("--cpu-lanes-log2", type=int, default=15, help="episodes in the CPU-baseline sample")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)
+
+    import rnad_hip
+    from environment.episode import Buffer
+    from environment.tree import Tree
+    from learn.rnad import RNaD
+
+    A, C, depth = args.actions, args.transitions, args.depth
+    global_batch = 1 << args.batch_log2
+    assert global_batch % world == 0
+    local_batch = global_batch // world
+
+    # ---- setup (untimed): tree tables into HBM, nets, optimizer
+    t0 = time.perf_counter()
+    tree = Tree(device=device, max_actions=A, max_transitions=C, depth_bound=depth, transition_threshold=0.0 if C == 1 else 0.5 / C)
+    tree.generate_native(seed=0)
+    tree.handle()
+    setup_tree_s = time.perf_counter() - t0
+    os.environ["RNAD_SAVE_DIR"] = tempfile.mkdtemp(prefix="rnad_bench_")
+    torch.manual_seed(0)
+    rn = RNaD(tree=tree, device=device, directory_name=f"bench-r{rank}", batch_size=global_batch, eta=0.2, b1_adam=0.0,
+              net_params={"type": "MLP", "max_actions": A, "width": args.width})
+    rn.initialize()
+    buffer = Buffer(rn.n_batches_per_buffer)
+    delta_m = 10_000
+
+    def one_step(i):
+        alpha = 1 if i > delta_m / 2 else i * 2 / delta_m
+        rn.train_step(buffer, alpha)
+        rn.total_steps += 1
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        one_step(i)
+    fence()
+    rnad_hip.prof_enable(True)
+    rollout_s = 0.0
+    t_start = time.perf_counter()
+    for i in range(args.steps):
+        one_step(args.warmup + i)
+        rollout_s += rn.last_episodes.generation_time
+    fence()
+    elapsed = time.perf_counter() - t_start
+    n_obs, obs_ms = rnad_hip.prof_read(rnad_hip.PROF_OBSERVE)
+    n_act, act_ms = rnad_hip.prof_read(rnad_hip.PROF_ACT)
+    n_learn, learn_ms = rnad_hip.prof_read(rnad_hip.PROF_LEARN)
+    rnad_hip.prof_enable(False)
+    T = rn.last_episodes.t_eff + 1
+    if world > 1:
+        t = torch.tensor([elapsed, rollout_s], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed, rollout_s = t.tolist()
+
+    if rank == 0:
+        env_steps = global_batch * T * args.steps
+        obs_elem = 2 if args.obs_half else 4
+        k1_bytes_per_step = 4 + 8 * A * A + 2 * A * A * obs_elem + 4 * A  # idx + ev row + legal row + obs + mask
+        k1_bytes_per_launch = k1_bytes_per_step * local_batch
+        k1_avg_s = obs_ms / 1e3 / max(n_obs, 1)
+        achieved = k1_bytes_per_launch / k1_avg_s / 1e9 if n_obs else 0.0
+        learn_bytes = (69 + 16) * local_batch * T if A == 3 else None
+        out = {
+            "metric": "env_steps_per_sec (rollout + R-NaD update, one iteration of learn/rnad.py:495-526 per step)",
+            "value": env_steps / elapsed,
+            "unit": "env-steps/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f32" if not args.obs_half else "f32 (fp16 observations)",
+            "data": "synthetic",
+            "config": {
+                "workload": f"depth-{depth} {A}x{A} matrix tree, C={C}, S={tree.index_tensor.shape[0]}, global batch 2^{args.batch_log2}"
+                            f" episodes x T={T} env steps, MLP width {args.width}, BASELINE.json configs[1]",
+                "global_batch": global_batch, "per_gpu_batch": local_batch, "T": T,
+                "parallelism": f"dp{world} (episodes sharded, RCCL all-reduce of 2 normalisers + 43 KB grads)",
+            },
+            "updates_per_sec": args.steps / elapsed,
+            "rollout_env_steps_per_sec": env_steps / rollout_s,
+            "rollout_ms_per_step": rollout_s / args.steps * 1e3,
+            "roofline": {
+                "kernel": "k_observe (K1 episode gather, rnad_observe)",
+                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                "traffic": None,
+                "bytes_per_launch": k1_bytes_per_launch, "avg_launch_us": k1_avg_s * 1e6, "launches": n_obs,
+            },
+            "other_kernels": {
+                "k_act": {"launches": n_act, "avg_launch_us": act_ms * 1e3 / max(n_act, 1)},
+                "k_learn_fused": {"launches": n_learn, "avg_launch_us": learn_ms * 1e3 / max(n_learn, 1),
+                                  "achieved_GBps": (learn_bytes / (learn_ms / 1e3 / max(n_learn, 1)) / 1e9) if learn_bytes and n_learn else None},
+            },
+            "setup": {"tree_generate_and_upload_s": setup_tree_s, "tree_table_bytes": tree.handle().table_bytes},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(tree, args, T)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(tree, args, T):
+    """The same step on the host cores: C oracle + PyTorch-CPU MLP (oracle/port.py), bounded sample."""
+    from oracle.port import CpuTrainer
+
+    arrs = dict(index=tree.index_tensor.cpu().numpy(), value=tree.value_tensor.cpu().numpy(), chance=tree.chance_tensor.cpu().numpy(),
+                expected_value=tree.expected_value_tensor.cpu().numpy(), legal=tree.legal_tensor.cpu().numpy(),
+                depth_bound=tree.depth_bound)
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    os.environ.setdefault("OMP_NUM_THREADS", str(cores))
+    ct = CpuTrainer(arrs, width=args.width)
+    lanes = 1 << args.cpu_lanes_log2
+    ct.step(min(lanes, 4096), seed=0)  # warm-up (thread pools, page faults)
+    t0 = time.perf_counter()
+    n, roll, upd = 0, 0.0, 0.0
+    while n < 2 or (time.perf_counter() - t0 < 12 and n < 6):
+        Tc, r, u = ct.step(lanes, seed=1 + n)
+        roll += r
+        upd += u
+        n += 1
+    dt = time.perf_counter() - t0
+    return {
+        "value": lanes * Tc * n / dt, "unit": "env-steps/s", "cores": cores, "kind": "port",
+        "sample": f"{n} full steps (rollout + update) of 2^{args.cpu_lanes_log2} episodes x T={Tc} on the same tree; "
+                  f"C oracle (OpenMP) + PyTorch-CPU MLP, {cores} threads",
+        "rollout_env_steps_per_sec": lanes * Tc * n / roll, "updates_per_sec_at_sample_batch": n / dt,
+    }
+
+
+if __name__ == "__main__":
+    main()

@@ -35,6 +35,7 @@
 EXPORT void oracle_observe(int64_t B, int A, const float *ev, const float *legal, const int64_t *idx,
                            const int64_t *player, float *obs, float *mask) {
     const int AA = A * A;
+#pragma omp parallel for schedule(static)
     for (int64_t b = 0; b < B; ++b) {
         const float *e = ev + idx[b] * AA;
         const float *l = legal + idx[b] * AA;
@@ -74,12 +75,14 @@ static inline int race_argmax(int n, const float *p, const float *q) {
 }
 
 EXPORT void oracle_sample(int64_t B, int A, const float *policy, const float *noise, int64_t *actions) {
+#pragma omp parallel for schedule(static)
     for (int64_t b = 0; b < B; ++b) actions[b] = race_argmax(A, policy + b * A, noise + b * A);
 }
 
 /* Seeded variant: the Exp(1) noise for lane `lane`, step `t`, stream `stream` comes from the
  * counter-based generator in rnad_rng.h (shared, bit for bit, with the HIP kernels). */
 EXPORT void oracle_noise(int64_t B, int n, uint64_t seed, int64_t lane0, int t, int stream, float *noise) {
+#pragma omp parallel for schedule(static)
     for (int64_t b = 0; b < B; ++b) rnad_exp_noise(seed, (uint64_t)(lane0 + b), (uint32_t)t, (uint32_t)stream, n, noise + b * n);
 }
 
@@ -92,8 +95,9 @@ EXPORT void oracle_transition(int64_t B, int A, int C, const int64_t *index_t, c
                               const float *value, const int64_t *idx, const int64_t *row_a,
                               const int64_t *col_a, const float *noise, int64_t *idx_out, float *reward) {
     const int AA = A * A;
-    float p[64];
+#pragma omp parallel for schedule(static)
     for (int64_t b = 0; b < B; ++b) {
+        float p[64];
         const int64_t base = idx[b] * C * AA + row_a[b] * A + col_a[b];
         for (int t = 0; t < C; ++t) p[t] = chance[base + (int64_t)t * AA];
         const int t = race_argmax(C, p, noise + b * C);
@@ -110,8 +114,9 @@ EXPORT void oracle_transition(int64_t B, int A, int C, const int64_t *index_t, c
  * ---------------------------------------------------------------------------------------------- */
 EXPORT void oracle_policy_head(int64_t N, int A, const float *logits, const float *mask, float *policy,
                                float *log_policy) {
-    float ex[64];
+#pragma omp parallel for schedule(static)
     for (int64_t n = 0; n < N; ++n) {
+        float ex[64];
         float s = 0.0f;
         for (int a = 0; a < A; ++a) {
             ex[a] = mask[n * A + a] != 0.0f ? expf(logits[n * A + a]) : 0.0f;
@@ -167,9 +172,10 @@ EXPORT void oracle_mlp_forward(int64_t N, int A, int W, const float *vw0, const 
  * ---------------------------------------------------------------------------------------------- */
 EXPORT void oracle_process_policy(int64_t N, int A, const float *policy, const float *mask, int n_disc,
                                   float eps, float *out) {
-    float p[64], m[64];
-    int order[64];
+#pragma omp parallel for schedule(static)
     for (int64_t n = 0; n < N; ++n) {
+        float p[64], m[64];
+        int order[64];
         const float *pi = policy + n * A;
         float mx = pi[0];
         for (int a = 1; a < A; ++a) mx = pi[a] > mx ? pi[a] : mx;

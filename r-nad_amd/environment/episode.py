@@ -1,0 +1,285 @@
+"""States / Episodes / Buffer -- drop-in for reference environment/episode.py, running on librnad_hip.so.
+
+API kept (names, argument order, attribute names, shapes): `States(tree, B).observations() / .step(actions) /
+.indices / .player_to_move / .terminal`; `Episodes(tree, B).generate(net) / .sample(n) / Episodes.collate(list)`
+with attributes `t_eff, turns, indices, observations, policy, actions, rewards, values, masks, q_estimates,
+v_estimates, generation_time, finished`; `Buffer(max_size).sample / append / clear`.
+
+What differs from the reference (all documented in INTEGRATION.md):
+  * state ids and action ids are int32 on the device (reference: int64); `indices` is `[T, B]` int32;
+  * `Episodes.generate` writes straight into preallocated `[T_cap, B, ...]` buffers (no per-step clones, list
+    appends or torch.stack, episode.py:196-227), runs `T_cap = 2 * tree depth` steps without any host sync and reads
+    the per-step alive counters ONCE at the end to trim to the reference's T (episode.py:194 loops until every lane is
+    absorbed);
+  * `turns`, `actions` (one-hot), `masks`, `q_estimates`, `v_estimates` are materialised lazily from the compact
+    primaries (`t & 1`, `action_idx` int32, `mask_bits` u8 / a strided view of `observations`);
+  * randomness: the sampler is the reference's (`argmax(p / q)`, q ~ Exp(1) == torch CPU multinomial) but q comes from
+    the counter-based stream of include/rnad_rng.h keyed by (seed, global lane, step) instead of torch's global
+    generator.  `seed` defaults to a draw from torch's generator, so `torch.manual_seed` still makes runs repeatable.
+"""
+import random
+import time
+from collections import deque
+
+import numpy
+import torch
+
+import rnad_hip
+from environment.tree import Tree
+
+
+def _draw_seed():
+    return int(torch.randint(0, 2**62, (1,)).item())
+
+
+class States:
+    """A parallel collection of states of one Tree (reference episode.py:18-125)."""
+
+    def __init__(self, tree: Tree, batch_size, seed=None, lane_offset=0):
+        self.tree = tree
+        self.batch_size = batch_size
+        dev = tree.device
+        self.indices = torch.ones((batch_size,), dtype=torch.int32, device=dev)
+        self.player_to_move = torch.zeros((batch_size,), dtype=torch.long, device=dev)
+        self.row_actions = None
+        self.col_actions = None
+        self._player = 0  # host copy: the reference itself only ever looks at player_to_move[0] (episode.py:96-98)
+        self._step = 0
+        self._terminal = False
+        self._terminal_stale = False
+        self.seed = _draw_seed() if seed is None else int(seed)
+        self.lane_offset = int(lane_offset)
+
+    @property
+    def terminal(self):
+        """True when every lane sits in the absorbing state 0 (episode.py:124); synchronises when read."""
+        if self._terminal_stale:
+            self._terminal = bool((self.indices == 0).all().item())
+            self._terminal_stale = False
+        return self._terminal
+
+    @terminal.setter
+    def terminal(self, value):
+        self._terminal, self._terminal_stale = bool(value), False
+
+    def observations(self, half=False) -> torch.Tensor:
+        """[B, 2, A, A]: expected-value matrix + legal mask from the mover's point of view (episode.py:62-68)."""
+        return rnad_hip.observe(self.tree.handle(), self.indices, self._player, half=half)
+
+    def observations_noisy(self):
+        return None  # reference placeholder (episode.py:70-82)
+
+    def step(self, actions: torch.Tensor, noise=None) -> torch.Tensor:
+        """Commit the mover's actions; on the column player's turn sample chance and transition (episode.py:84-125).
+        `noise` (f32 [B, C], Exp(1)) replaces the seeded chance noise; tests use it to replay the reference."""
+        actions = actions.to(device=self.indices.device, dtype=torch.int32).contiguous().view(-1)
+        if self._player == 0:
+            self.row_actions = actions
+            rewards = torch.zeros((self.batch_size,), device=self.indices.device)
+        else:
+            self.col_actions = actions
+            self.indices, rewards = rnad_hip.transition(
+                self.tree.handle(), self.indices, self.row_actions, self.col_actions, noise=noise, seed=self.seed,
+                lane0=self.lane_offset, step=self._step)
+            self.row_actions = None
+            self.col_actions = None
+        self._player = 1 - self._player
+        self.player_to_move = 1 - self.player_to_move
+        self._step += 1
+        self._terminal_stale = True
+        return rewards
+
+
+class Episodes:
+    """A parallel batch of rollout trajectories from the root (reference episode.py:131-290)."""
+
+    _PRIMARY = ("indices", "observations", "mask_bits", "policy", "action_idx", "rewards", "values")
+
+    def __init__(self, tree: Tree, batch_size, seed=None, lane_offset=0, obs_half=False):
+        self.tree: Tree = tree
+        self.batch_size: int = batch_size
+        self.states: States = States(tree, batch_size, seed=seed, lane_offset=lane_offset)
+        self.seed = self.states.seed
+        self.lane_offset = int(lane_offset)
+        self.obs_half = bool(obs_half)
+        self.finished: bool = False
+        self.generation_time: float = 0
+        self.estimation_time: float = 0
+        self.t_eff: int = -1
+        self.indices = self.observations = self.mask_bits = self.policy = None
+        self.action_idx = self.rewards = self.values = None
+        self.alive = None  # int32 [T + 1] on the device: lanes with indices[t] != 0
+        self._lazy = {}
+
+    # ---------------------------------------------------------------- lazily materialised reference attributes
+    def _get(self, key, make):
+        if key not in self._lazy:
+            self._lazy[key] = make()
+        return self._lazy[key]
+
+    @property
+    def turns(self):
+        """[T, B] int64, == t mod 2 for every lane (episode.py:197); an expanded view, no memory."""
+        T = self.t_eff + 1
+        return self._get("turns", lambda: (torch.arange(T, device=self.indices.device) % 2).view(T, 1).expand(T, self.batch_size))
+
+    @property
+    def actions(self):
+        """[T, B, A] one-hot float of the sampled actions (episode.py:205-206)."""
+        return self._get("actions", lambda: torch.nn.functional.one_hot(self.action_idx.long(), self.tree.max_actions).to(torch.float))
+
+    @property
+    def masks(self):
+        """[T, B, A] legal actions of the mover == observations[:, :, 1, :, 0] (episode.py:208); a strided view."""
+        return self._get("masks", lambda: self.observations[:, :, 1, :, 0].to(torch.float))
+
+    @property
+    def q_estimates(self):
+        return self._get("q_estimates", lambda: torch.zeros_like(self.policy))  # episode.py:226 (unused)
+
+    @property
+    def v_estimates(self):
+        return self._get("v_estimates", lambda: torch.zeros_like(self.rewards))  # episode.py:227 (unused)
+
+    @property
+    def valid_counts(self):
+        """f64 [2] on the device: number of valid steps of player 0 / player 1 (= N_P of the losses)."""
+        T = self.t_eff + 1
+        a = self.alive[:T].to(torch.float64)
+        return torch.stack([a[0::2].sum(), a[1::2].sum()])
+
+    # ---------------------------------------------------------------- episode.py:175-230
+    def generate(self, net: torch.nn.Module, noise_action=None, noise_chance=None, max_steps=None):
+        """Play the batch to the end with `net` as the actor.
+
+        Nets exposing `forward_logits(obs) -> (logits [B,A], value [B,1])` (the MLP here) take the fast path: policy head,
+        sampling, transition and the next observation are HIP kernels.  Any other module honouring the reference
+        contract `forward(obs) -> (logits, policy, value, actions)` (nn/net.py:37-51) is driven through that instead and
+        samples for itself.  noise_action [T,B,A] / noise_chance [T,B,C]: explicit Exp(1) noise (tests).
+        """
+        tree, B = self.tree, self.batch_size
+        handle = tree.handle()
+        T_cap = 2 * handle.max_depth if max_steps is None else int(max_steps)
+        dev = self.states.indices.device
+        traj = rnad_hip.Trajectory(handle, B, T_cap, dev, half=self.obs_half)
+        fast = hasattr(net, "forward_logits")
+        net.eval()
+        time_start = time.perf_counter()
+        rnad_hip.rollout_begin(handle, traj)
+        with torch.no_grad():
+            for t in range(T_cap):
+                obs_t = traj.observations[t]
+                na = None if noise_action is None else noise_action[t]
+                nc = None if noise_chance is None else noise_chance[t]
+                if fast:
+                    logits, value = net.forward_logits(obs_t)
+                    rnad_hip.rollout_step(handle, traj, t, value.reshape(-1), logits=logits, noise_action=na, noise_chance=nc,
+                                          seed=self.seed, lane0=self.lane_offset)
+                else:
+                    _, policy, value, actions = net.forward(obs_t)
+                    rnad_hip.rollout_step(handle, traj, t, value.reshape(-1).contiguous(), policy=policy.contiguous(),
+                                          actions=actions.to(torch.int32).contiguous().view(-1), noise_chance=nc,
+                                          seed=self.seed, lane0=self.lane_offset)
+        alive = traj.alive.cpu()  # the only host sync of the rollout
+        T = int((alive[:T_cap] > 0).sum().item())
+        time_end = time.perf_counter()
+        self.generation_time = time_end - time_start
+        self._traj = traj
+        self.t_eff = T - 1
+        self.indices = traj.indices[:T]
+        self.observations = traj.observations[:T]
+        self.mask_bits = traj.mask_bits[:T]
+        self.policy = traj.policy[:T]
+        self.action_idx = traj.actions[:T]
+        self.rewards = traj.rewards[:T]
+        self.values = traj.values[:T]
+        self.alive = traj.alive[: T + 1]
+        self._lazy = {}
+        self.states.indices = traj.indices[T]
+        self.states.terminal = True
+        self.finished = True
+        net.train()
+
+    def __repr__(self):
+        result = ""
+        for key in ("batch_size", "t_eff", "finished", "generation_time") + self._PRIMARY:
+            value = getattr(self, key)
+            if torch.is_tensor(value) and torch.numel(value) > 20:
+                value = value.shape
+            result += f"{key}: {value}\n"
+        return result
+
+    # ---------------------------------------------------------------- episode.py:243-256
+    def _like(self, batch_size):
+        result = Episodes(self.tree, batch_size, seed=self.seed, lane_offset=self.lane_offset, obs_half=self.obs_half)
+        result.finished = True
+        return result
+
+    def sample(self, batch_size):
+        """A uniformly random subset of `batch_size` lanes in random order (the reference permutes with python's `random`;
+        here python's `random` seeds a device permutation)."""
+        assert self.finished
+        batch_size = min(batch_size, self.batch_size)
+        dev = self.indices.device
+        g = torch.Generator(device=dev)
+        g.manual_seed(random.getrandbits(62))
+        selected = torch.randperm(self.batch_size, generator=g, device=dev)[:batch_size]
+        result = self._like(batch_size)
+        for key in self._PRIMARY:
+            setattr(result, key, torch.index_select(getattr(self, key), dim=1, index=selected))
+        result.t_eff = self.t_eff
+        if batch_size == self.batch_size:
+            result.alive = self.alive  # a permutation keeps the per-step counts
+        else:
+            alive = torch.zeros_like(self.alive)
+            alive[: self.t_eff + 1] = (result.indices != 0).sum(dim=1).to(torch.int32)
+            result.alive = alive
+        return result
+
+    # ---------------------------------------------------------------- episode.py:258-290
+    @classmethod
+    def collate(cls, lst: list["Episodes"]):
+        """Pad each member along time with zeros (index 0 == invalid) and concatenate along the batch."""
+        t_eff = max(e.t_eff for e in lst)
+        tree = lst[0].tree
+        batch_size = sum(e.batch_size for e in lst)
+        assert all(e.tree == tree for e in lst)
+        assert all(e.finished for e in lst)
+        result = lst[0]._like(batch_size)
+        T = t_eff + 1
+        for key in cls._PRIMARY:
+            parts = []
+            for e in lst:
+                x = getattr(e, key)
+                if x.shape[0] < T:
+                    pad = torch.zeros((T - x.shape[0],) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
+                    x = torch.cat([x, pad], dim=0)
+                parts.append(x)
+            setattr(result, key, parts[0] if len(parts) == 1 else torch.cat(parts, dim=1))
+        alive = torch.zeros((T + 1,), dtype=torch.int32, device=result.indices.device)
+        alive[:T] = (result.indices != 0).sum(dim=1).to(torch.int32)
+        result.alive = alive
+        result.t_eff = t_eff
+        return result
+
+
+class Buffer:
+    """Replay buffer of Episodes played with older actor nets (reference episode.py:292-333)."""
+
+    def __init__(self, max_size) -> None:
+        self.max_size = max_size
+        self.episodes_buffer = deque(maxlen=max_size)
+
+    def sample(self, batch_size):
+        n = len(self.episodes_buffer)
+        bucket_sizes = numpy.random.multinomial(batch_size, [1 / n] * n)
+        assert sum(bucket_sizes) == batch_size
+        return Episodes.collate([self.episodes_buffer[_].sample(int(bucket_sizes[_])) for _ in range(n)])
+
+    def append(self, episodes: Episodes):
+        self.episodes_buffer.append(episodes)
+        while len(self.episodes_buffer) > self.max_size:
+            self.episodes_buffer.popleft()
+
+    def clear(self):
+        self.episodes_buffer.clear()

@@ -1,0 +1,412 @@
+"""RNaD trainer -- drop-in for reference learn/rnad.py (same constructor kwargs, `run()`, schedule and checkpoints).
+
+The host loop is the reference's (`__resume`, learn/rnad.py:458-531): (m, n) schedule, alpha ramp, rollout cadence, Adam,
+EMA target, regularisation-net rotation.  What changed is what one iteration executes:
+
+  rollout   Episodes.generate -> HIP kernels K1/K2/K3 around the PyTorch-ROCm MLP forward (environment/episode.py)
+  update    4 flattened MLP forwards (PyTorch-ROCm) -> ONE fused HIP kernel (policy heads, process_policy, both players'
+            V-trace, NeuRD + value loss gradients, learn/rnad.py:365-425) -> autograd.backward through the MLP with the
+            closed-form dL/dlogit, dL/dv -> clip -> Adam -> EMA.
+
+Data parallel: when torch.distributed is initialised (one process per GPU, backend "nccl" == RCCL over xGMI), every rank
+plays `batch_size // world_size` lanes of the SAME seeded noise stream (global lane ids), the two loss normalisers are
+all-reduced before the fused kernel scales gradients (they are batch-global, learn/vtrace.py:373,388), and the 10 756
+parameter gradients are all-reduced (sum) in one flat bucket before clipping.  No other communication.
+"""
+import logging
+import os
+import time
+from typing import Dict
+
+import torch
+import torch.nn as nn
+import torch.distributed as dist
+
+import environment.episode as episode
+import environment.tree as tree
+import nn.net as net
+import util.metric as metric
+import rnad_hip
+
+
+def _save_root():
+    return os.environ.get("RNAD_SAVE_DIR") or os.path.join(os.path.dirname(os.path.realpath(__file__)), "..")
+
+
+def _dist_on():
+    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+
+
+class RNaD:
+    def __init__(
+        self,
+        tree: tree.Tree,
+        device=torch.device("cuda"),
+        directory_name=None,
+        batch_size=3 * 2**8,
+        eta=0.2,
+        bounds=[100, 165, 200],
+        delta_m=[10_000, 100_000, 35_000],
+        lr=5 * 10**-5,
+        logit_clip=2,
+        neurd_clip=10**3,
+        grad_clip=10**3,
+        b1_adam=0,
+        b2_adam=0.999,
+        epsilon_adam=10**-8,
+        gamma_averaging=0.001,
+        roh_bar=1,
+        c_bar=1,
+        epsilon_threshold=0.03,
+        n_discrete=32,
+        # parameters from https://arxiv.org/abs/2206.15378 (reference learn/rnad.py:40-64)
+        n_batches_per_buffer=1,
+        buffer_mod=1,
+        net_params=None,
+        vtrace_gamma=1,
+        value_loss_weight=1,
+        neurd_loss_weight=1,
+        wandb=False,
+        use_same_init_net_as=False,
+    ):
+        self.tree = tree
+        self.tree_hash = 0
+        self.device = device
+
+        self.eta = eta
+        self.bounds = bounds
+        self.delta_m = delta_m
+        self.n_batches_per_buffer = n_batches_per_buffer
+        self.buffer_mod = buffer_mod
+        self.lr = lr
+        self.beta = logit_clip
+        self.neurd_clip = neurd_clip
+        self.grad_clip = grad_clip
+        self.b1_adam = b1_adam
+        self.b2_adam = b2_adam
+        self.epsilon_adam = epsilon_adam
+        self.gamma_averaging = gamma_averaging
+        self.roh_bar = roh_bar
+        self.c_bar = c_bar
+        self.batch_size = batch_size
+        self.epsilon_threshold = epsilon_threshold
+        self.n_discrete = n_discrete
+        self.vtrace_gamma = vtrace_gamma
+        self.neurd_weight = neurd_loss_weight
+        self.value_weight = value_loss_weight
+        self.wandb = wandb
+
+        if directory_name is None:
+            directory_name = str(int(time.perf_counter()))
+        self.directory_name = directory_name
+
+        if net_params is None:
+            net_params = {"type": "MLP", "max_actions": self.tree.max_actions, "width": 2**8}
+        self.net_params = net_params
+
+        self.saved_keys = [key for key in self.__dict__.keys() if key != "tree"]
+        # only the above members are saved in and reloaded from the 'params' object (reference learn/rnad.py:153)
+
+        self.directory = os.path.join(_save_root(), "saved_runs", directory_name)
+        self.use_same_init_net_as = use_same_init_net_as
+
+        self.m = 0
+        self.n = 0
+        self.total_steps = 0
+        self.net = None
+        self.net_target = None
+        self.net_reg = None
+        self.net_reg_ = None
+        self.last_log = None  # scalars of the most recent logged step (the reference sends them to wandb)
+        self.nashconv_history = []  # (m, total_steps, nashconv)
+
+    # ------------------------------------------------------------------ data-parallel helpers
+    @property
+    def _rank(self):
+        return dist.get_rank() if _dist_on() else 0
+
+    @property
+    def _world(self):
+        return dist.get_world_size() if _dist_on() else 1
+
+    def _sync_from_rank0(self, module):
+        if _dist_on():
+            for t in list(module.parameters()) + list(module.buffers()):
+                dist.broadcast(t.data, src=0)
+
+    def _new_seed(self):
+        s = torch.randint(0, 2**62, (1,), dtype=torch.int64)
+        if _dist_on():
+            s = s.to(self.device)
+            dist.broadcast(s, src=0)
+        return int(s.item())
+
+    # ------------------------------------------------------------------ reference learn/rnad.py:174-188
+    def __new_net(self) -> nn.Module:
+        types = {"MLP": net.MLP}
+        if hasattr(net, "ConvNet"):
+            types["ConvNet"] = net.ConvNet
+        t = types[self.net_params["type"]]
+        net_params = {k: v for k, v in self.net_params.items() if k != "type"}
+        net_params["device"] = self.device
+        new_net = t(**net_params)
+        new_net.eval()
+        return new_net
+
+    def __new_optimizer(self):
+        return torch.optim.Adam(self.net.parameters(), lr=self.lr, betas=(float(self.b1_adam), float(self.b2_adam)),
+                                eps=self.epsilon_adam)
+
+    # ------------------------------------------------------------------ reference learn/rnad.py:190-280
+    def __initialize(self):
+        logging.info("Initializing R-NaD run: {}".format(self.directory_name))
+        if self._rank == 0:
+            os.makedirs(self.directory, exist_ok=True)
+        if _dist_on():
+            dist.barrier()
+        saved_updates = [int(os.path.relpath(f.path, self.directory)) for f in os.scandir(self.directory) if f.is_dir()] \
+            if os.path.isdir(self.directory) else []
+        if not saved_updates:
+            self.tree_hash = self.tree.hash
+            if self._rank == 0:
+                params_dict = {key: self.__dict__[key] for key in self.saved_keys}
+                torch.save(params_dict, os.path.join(self.directory, "params"))
+                os.makedirs(os.path.join(self.directory, "0"), exist_ok=True)
+            self.net = self.__new_net()
+            if self.use_same_init_net_as:
+                net_dir = os.path.join(_save_root(), "saved_runs", self.use_same_init_net_as, "0", "0")
+                checkpoint = torch.load(net_dir, map_location=self.device, weights_only=False)
+                self.net.load_state_dict(checkpoint["net"])
+                logging.info("Loading init net from {}".format(self.use_same_init_net_as))
+            self._sync_from_rank0(self.net)
+            self.net.train()
+            self.net_target = self.__new_net()
+            self.net_target.load_state_dict(self.net.state_dict())
+            self.net_reg = self.__new_net()
+            self.net_reg.load_state_dict(self.net.state_dict())
+            self.net_reg_ = self.__new_net()
+            self.net_reg_.load_state_dict(self.net.state_dict())
+            self.optimizer = self.__new_optimizer()
+            self.m = 0
+            self.n = 0
+            self.__save_checkpoint()
+        else:
+            params_dict = torch.load(os.path.join(self.directory, "params"), weights_only=False)
+            for key, value in params_dict.items():
+                if key == "directory_name":
+                    params_dict[key] = self.directory_name
+                    continue
+                if key == "device":
+                    continue
+                if torch.is_tensor(value):
+                    params_dict[key] = params_dict[key].to(self.device)
+                if key == "tree_hash":
+                    assert params_dict["tree_hash"] == self.tree.hash  # resuming fails if the trees differ
+                self.__dict__[key] = value
+            if self._rank == 0:
+                torch.save(params_dict, os.path.join(self.directory, "params"))
+            self.m = max(saved_updates)
+            last_update = os.path.join(self.directory, str(self.m))
+            checkpoints = [int(os.path.relpath(f.path, last_update)) for f in os.scandir(last_update) if not f.is_dir()]
+            self.n = max(checkpoints)
+            self.__load_checkpoint(self.m, self.n)
+
+        if self.wandb:
+            import wandb
+
+            wandb.init(resume=bool(saved_updates), project="RNaD", config={key: self.__dict__[key] for key in self.saved_keys})
+            wandb.run.name = self.directory_name
+
+    # ------------------------------------------------------------------ reference learn/rnad.py:282-319
+    def __load_checkpoint(self, m, n):
+        saved_dict = torch.load(os.path.join(self.directory, str(m), str(n)), map_location=self.device, weights_only=False)
+        self.total_steps = saved_dict["total_steps"]
+        self.net_params = saved_dict["net_params"]
+        self.net = self.__new_net()
+        self.net.load_state_dict(saved_dict["net"])
+        self.net_target = self.__new_net()
+        self.net_target.load_state_dict(saved_dict["net_target"])
+        self.net_reg = self.__new_net()
+        self.net_reg.load_state_dict(saved_dict["net_reg"])
+        self.net_reg_ = self.__new_net()
+        self.net_reg_.load_state_dict(saved_dict["net_reg_"])
+        self.optimizer = self.__new_optimizer()
+        self.optimizer.load_state_dict(saved_dict["optimizer"])
+
+    def __save_checkpoint(self):
+        if self._rank != 0:
+            return
+        saved_dict = {
+            "total_steps": self.total_steps,
+            "net_params": self.net_params,
+            "net": self.net.state_dict(),
+            "net_target": self.net_target.state_dict(),
+            "net_reg": self.net_reg.state_dict(),
+            "net_reg_": self.net_reg_.state_dict(),
+            "optimizer": self.optimizer.state_dict(),
+        }
+        os.makedirs(os.path.join(self.directory, str(self.m)), exist_ok=True)
+        torch.save(saved_dict, os.path.join(self.directory, str(self.m), str(self.n)))
+
+    # ------------------------------------------------------------------ reference learn/rnad.py:321-332
+    def __get_update_info(self):
+        bounding_indices = [i for i, bound in enumerate(self.bounds) if bound > self.m]
+        if not bounding_indices:
+            return False, 0
+        return True, self.delta_m[min(bounding_indices)]
+
+    # ------------------------------------------------------------------ reference learn/rnad.py:334-351
+    def __nashconv(self) -> float:
+        logging.info("NashConv at m: {}, n: {}, step {}".format(self.m, self.n, self.total_steps))
+        nashconv_data = metric.NashConvData(self.tree)
+        nashconv_data.get_nashconv_from_net(self.tree, self.net_target)
+        mean_nashconv: Dict[int, float] = nashconv_data.mean_nashconv_by_depth()
+        for depth, nashconv in mean_nashconv.items():
+            logging.info("depth:{}, nash_conv:{}".format(depth, nashconv))
+        return (nashconv_data.row_best[1] + nashconv_data.col_best[1]).item()
+
+    # ------------------------------------------------------------------ reference learn/rnad.py:353-456
+    @staticmethod
+    def _logits_of(module, episodes, want_value=True):
+        """Raw policy logits [T*B, A] (and value [T*B, 1]) of `module` on a trajectory."""
+        T = episodes.t_eff + 1
+        if hasattr(module, "forward_logits"):
+            return module.forward_logits(episodes.observations[:T])
+        logit, _, _, v = module.forward_batch(episodes)  # any module honouring the reference contract (nn/net.py:64-85)
+        A = logit.shape[-1]
+        return logit.reshape(-1, A), v.reshape(-1, 1)
+
+    def __learn(self, episodes: episode.Episodes, alpha: float, log: dict = None):
+        """Gradients of the learner net from a batch of trajectories (reward transform + V-trace + NeuRD)."""
+        T, B, A = episodes.t_eff + 1, episodes.batch_size, self.tree.max_actions
+
+        logit, v = self._logits_of(self.net, episodes)  # rnad.py:373, with grad
+        with torch.no_grad():
+            logit_target, v_target = self._logits_of(self.net_target, episodes)  # :378
+            logit_reg, _ = self._logits_of(self.net_reg, episodes)  # :379
+            logit_reg_, _ = self._logits_of(self.net_reg_, episodes)  # :380
+
+        norm = episodes.valid_counts  # N_P = #(valid & turn == P): batch-global normalisers (vtrace.py:373,388)
+        if _dist_on():
+            dist.all_reduce(norm)
+        hp = rnad_hip.make_learn_params(
+            alpha=alpha, eta=self.eta, lambda_=1.0, c=self.c_bar, rho=self.roh_bar, gamma=self.vtrace_gamma,
+            clip=self.neurd_clip, threshold=self.beta, w_v=self.value_weight, w_n=self.neurd_weight,
+            eps_threshold=self.epsilon_threshold, n_disc=self.n_discrete)
+        dlogit, dv, losses, pi, _, _ = rnad_hip.learn_fused(
+            episodes.indices[:T], episodes.mask_bits[:T], episodes.action_idx[:T], episodes.rewards[:T], episodes.policy[:T],
+            logit.detach().contiguous(), v.detach().reshape(T, B).contiguous(), v_target.reshape(T, B).contiguous(),
+            logit_reg.contiguous(), logit_reg_.contiguous(), norm, hp, want_aux=log is not None)
+        # loss.backward() (rnad.py:424-425) with the closed-form dL/dlogit, dL/dv
+        torch.autograd.backward([logit, v], [dlogit.view(-1, A), dv.view(-1, 1)])
+
+        if _dist_on():
+            grads = [p.grad for p in self.net.parameters()]
+            flat = torch.cat([g.reshape(-1) for g in grads])
+            dist.all_reduce(flat)  # one 43 KB bucket over RCCL
+            off = 0
+            for g in grads:
+                g.copy_(flat[off: off + g.numel()].view_as(g))
+                off += g.numel()
+            dist.all_reduce(losses)
+
+        if log is not None:
+            total_norm = 0
+            for p in self.net.parameters():
+                total_norm += p.grad.detach().data.norm(2).item() ** 2
+            total_norm = total_norm**0.5
+            valid = (episodes.indices[:T] != 0).to(torch.float)
+            masks = episodes.masks[:T]
+            logit_mean = logit.mean().item()
+            pi_target = rnad_hip.policy_head(logit_target.contiguous(), mask_bits=episodes.mask_bits[:T].reshape(-1)).view(T, B, A)
+            uniform_policy = torch.nn.functional.normalize(masks, p=1, dim=-1)
+            log.update({
+                "loss_v": losses[0].item(),
+                "loss_nerd": losses[1].item(),
+                "traj_len": valid.sum(0).mean(-1).item(),
+                "gradient_norm": total_norm,
+                "logit_mean": logit_mean,
+                "logit_max": torch.max(torch.abs(logit - logit_mean)).item(),
+                "entropy": metric.kld(pi, uniform_policy, valid, legal_actions=masks),
+                "entropy_target": metric.kld(pi_target, uniform_policy, valid, legal_actions=masks),
+                "actor_learner_kld": metric.kld(pi, episodes.policy[:T], valid, legal_actions=masks),
+            })
+
+        nn.utils.clip_grad_norm_(self.net.parameters(), self.grad_clip)  # rnad.py:456
+
+    # ------------------------------------------------------------------ reference learn/rnad.py:502-523
+    def train_step(self, buffer, alpha, log=None):
+        """One iteration of the reference's inner loop: rollout (every buffer_mod steps) -> buffer sample -> __learn ->
+        Adam -> EMA target.  Also what bench.py times as one "step"."""
+        world, rank = self._world, self._rank
+        local_batch = self.batch_size // world
+        if self.total_steps % self.buffer_mod == 0:
+            episodes = episode.Episodes(self.tree, local_batch, seed=self._new_seed(), lane_offset=rank * local_batch)
+            episodes.generate(self.net)
+            buffer.append(episodes)
+            self.last_episodes = episodes
+        episodes_sample = buffer.sample(local_batch)
+        self.__learn(episodes_sample, alpha, log=log)
+        self.optimizer.step()
+        self.optimizer.zero_grad()
+        params1: Dict[str, torch.Tensor] = self.net.state_dict()
+        params2: Dict[str, torch.Tensor] = self.net_target.state_dict()
+        for name1, param1 in params1.items():  # EMA target (rnad.py:516-523)
+            params2[name1].data.copy_(self.gamma_averaging * param1.data + (1 - self.gamma_averaging) * params2[name1].data)
+        self.net_target.load_state_dict(params2)
+
+    def initialize(self):
+        """Public alias of the reference's private __initialize (nets, optimizer, checkpoint 0/0)."""
+        self.__initialize()
+
+    # ------------------------------------------------------------------ reference learn/rnad.py:458-531
+    def __resume(self, max_updates=10**6, checkpoint_mod=1000, expl_mod=1, log_mod=20) -> None:
+        buffer = episode.Buffer(self.n_batches_per_buffer)
+        rank = self._rank
+        assert self.batch_size % self._world == 0, "batch_size must be divisible by the number of GPUs"
+        for _ in range(max_updates):
+            may_resume, delta_m = self.__get_update_info()
+            if not may_resume:
+                return
+            logging.info("m: {}, delta_m: {}".format(self.m, delta_m))
+            buffer.max_size = self.n_batches_per_buffer
+
+            if self.m % expl_mod == 0 and self.n == 0 and self.m != 0:
+                if rank == 0:
+                    nashconv = self.__nashconv()
+                    self.nashconv_history.append((self.m, self.total_steps, nashconv))
+                    if self.wandb:
+                        import wandb
+
+                        wandb.log({"nashconv": nashconv}, step=self.total_steps)
+                if _dist_on():
+                    dist.barrier()
+
+            while self.n < delta_m:
+                alpha = 1 if self.n > delta_m / 2 else self.n * 2 / delta_m  # rnad.py:497
+                if self.n % checkpoint_mod == 0:
+                    self.__save_checkpoint()
+                log = {} if (self.n % log_mod == 0 and (self.wandb or log_mod < 10**8)) else None
+                self.train_step(buffer, alpha, log=log)
+                if log:
+                    self.last_log = dict(log, m=self.m, n=self.n, total_steps=self.total_steps)
+                    if self.wandb:
+                        import wandb
+
+                        wandb.log(log, step=self.total_steps)
+                self.n += 1
+                self.total_steps += 1
+
+            self.n = 0
+            self.m += 1
+            self.net_reg_.load_state_dict(self.net_reg.state_dict())  # rnad.py:530-531
+            self.net_reg.load_state_dict(self.net_target.state_dict())
+
+    def run(self, max_updates=10**6, checkpoint_mod=1000, expl_mod=1, log_mod=20):
+        """Either starts or resumes a run (reference learn/rnad.py:533-547)."""
+        self.__initialize()
+        self.__resume(max_updates=max_updates, checkpoint_mod=checkpoint_mod, expl_mod=expl_mod, log_mod=log_mod)
+        if self.wandb:
+            import wandb
+
+            wandb.finish()

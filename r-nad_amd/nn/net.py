@@ -1,0 +1,71 @@
+"""MLP policy/value net -- drop-in for reference nn/net.py:18-85 (interface + parameter names kept).
+
+Per BASELINE.json's north_star the tiny MLP itself (two parallel 2-layer perceptrons, 10 756 parameters at A = 3,
+width 256) stays in PyTorch-ROCm: its contraction depth is 2*A^2 = 18, nowhere near an MFMA-shaped GEMM.  What moves
+to HIP is everything around the GEMMs: the masked exp-normalise policy head (net.py:45-46, :74-77) and the multinomial
+sampler (net.py:49).  `forward_batch` runs the four Linear layers ONCE over the flattened `[T*B, 2A^2]` trajectory
+instead of a Python loop over t (net.py:67).
+
+State-dict keys (`value_fc0.weight`, ...) are the reference's, so its checkpoints load unchanged.
+"""
+import torch
+import torch.nn as nn
+
+import rnad_hip
+
+
+class MLP(nn.Module):
+    def __init__(self, max_actions, width, device=torch.device("cpu:0"), dtype=torch.float):
+        super().__init__()
+        self.device = device
+        self.value_fc0 = nn.Linear(2 * max_actions**2, width, device=device, dtype=dtype)
+        self.value_fc1 = nn.Linear(width, 1, device=device, dtype=dtype)
+        self.policy_fc0 = nn.Linear(2 * max_actions**2, width, device=device, dtype=dtype)
+        self.policy_fc1 = nn.Linear(width, max_actions, device=device, dtype=dtype)
+        self.max_actions = max_actions
+        self.width = width
+        self._seed = int(torch.randint(0, 2**62, (1,)).item())  # sampler stream of forward(); torch.manual_seed controls it
+        self._calls = 0
+
+    # ---------------------------------------------------------------- the GEMMs (PyTorch-ROCm)
+    def forward_logits(self, input_batch):
+        """obs [N, 2, A, A] (fp32 or fp16) -> logits [N, A], value [N, 1]   (net.py:40-43)."""
+        x = input_batch.reshape(-1, 2 * self.max_actions**2)
+        if x.dtype != self.value_fc0.weight.dtype:
+            x = x.to(self.value_fc0.weight.dtype)
+        value = self.value_fc1(torch.relu(self.value_fc0(x)))
+        logits = self.policy_fc1(torch.relu(self.policy_fc0(x)))
+        return logits, value
+
+    @staticmethod
+    def _mask(input_batch):
+        return input_batch[:, 1, :, 0].to(torch.float).contiguous()  # filter_row (net.py:38)
+
+    # ---------------------------------------------------------------- net.py:37-51
+    def forward(self, input_batch):
+        logits, value = self.forward_logits(input_batch)
+        policy = rnad_hip.policy_head(logits.detach().contiguous(), mask=self._mask(input_batch))
+        actions = rnad_hip.sample(policy, seed=self._seed, step=self._calls & 0xFFFFFF, stream_id=2).long()
+        self._calls += 1
+        return logits, policy, value, actions
+
+    # ---------------------------------------------------------------- net.py:53-62
+    def forward_policy(self, input_batch: torch.Tensor) -> torch.Tensor:
+        x = input_batch.reshape(-1, 2 * self.max_actions**2)
+        logits = self.policy_fc1(torch.relu(self.policy_fc0(x)))
+        return rnad_hip.policy_head(logits.detach().contiguous(), mask=self._mask(input_batch))
+
+    # ---------------------------------------------------------------- net.py:64-85
+    def forward_batch(self, episodes):
+        """-> [logit, log_policy, policy, value], shapes [T,B,A] x3 and [T,B,1].  `logit` and `value` carry autograd;
+        policy / log_policy come out of the HIP policy head and are constants (the reference's loss never
+        differentiates through them: learn/vtrace.py:418, learn/rnad.py:377-382)."""
+        T, B = episodes.t_eff + 1, episodes.batch_size
+        A = self.max_actions
+        logits, value = self.forward_logits(episodes.observations[:T])
+        mask_bits = getattr(episodes, "mask_bits", None)
+        if mask_bits is not None:
+            policy, log_policy = rnad_hip.policy_head(logits.detach(), mask_bits=mask_bits[:T].reshape(-1), want_log=True)
+        else:
+            policy, log_policy = rnad_hip.policy_head(logits.detach(), mask=episodes.masks[:T].reshape(-1, A).contiguous(), want_log=True)
+        return [logits.view(T, B, A), log_policy.view(T, B, A), policy.view(T, B, A), value.view(T, B, 1)]
