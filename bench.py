@@ -24,6 +24,11 @@ import sys
 import tempfile
 import time
 
+# host threads of the CPU-baseline leg: fixed BEFORE torch / libgomp start (256 spinning threads on the GPU box's host
+# are 8x slower than 32).  The GPU path does not use them.
+CPU_THREADS = int(os.environ.get("RNAD_CPU_THREADS", min(os.cpu_count() or 1, 32)))
+os.environ.setdefault("OMP_NUM_THREADS", str(CPU_THREADS))
+
 ROOT = os.path.dirname(os.path.realpath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "r-nad_amd"))
 sys.path.insert(0, ROOT)
@@ -176,9 +181,8 @@ def cpu_baseline(tree, args, T):
     arrs = dict(index=tree.index_tensor.cpu().numpy(), value=tree.value_tensor.cpu().numpy(), chance=tree.chance_tensor.cpu().numpy(),
                 expected_value=tree.expected_value_tensor.cpu().numpy(), legal=tree.legal_tensor.cpu().numpy(),
                 depth_bound=tree.depth_bound)
-    cores = os.cpu_count() or 1
+    cores = CPU_THREADS
     torch.set_num_threads(cores)
-    os.environ.setdefault("OMP_NUM_THREADS", str(cores))
     ct = CpuTrainer(arrs, width=args.width)
     lanes = 1 << args.cpu_lanes_log2
     ct.step(min(lanes, 4096), seed=0)  # warm-up (thread pools, page faults)

@@ -111,7 +111,7 @@ typedef struct rnad_traj {
     int32_t *alive;       /* [T_cap + 1]     #lanes with indices[t] != 0                             */
 } rnad_traj_t;
 
-/* indices[0,:] = 1 (root, episode.py:22), alive[:] = 0, alive[0] = B, then K1 for t = 0. */
+/* indices[0,:] = 1 (root, episode.py:22), then K1 for t = 0. */
 int rnad_rollout_begin(const rnad_tree_t *tree, const rnad_traj_t *traj, void *stream);
 
 /* One env step t given the net outputs for observations[t] (nn/net.py:37-51):
@@ -120,13 +120,19 @@ int rnad_rollout_begin(const rnad_tree_t *tree, const rnad_traj_t *traj, void *s
  *   mode 2: `policy_in` and `actions_in` (int32 [B]) given -> record only       (generic nets that
  *           sample for themselves, net.py:49)
  * then (odd t) the transition of K2 with row action actions[t-1] and column action actions[t],
- * (even t) indices[t+1] = indices[t], rewards[t] = 0 (episode.py:99-101); alive[t+1]; and, if
- * t + 1 < T_cap, K1 for step t + 1 as a second launch.
+ * (even t) indices[t+1] = indices[t], rewards[t] = 0 (episode.py:99-101); and, if t + 1 < T_cap, K1 for
+ * step t + 1 as a second launch.  The alive counters are NOT touched per step (one contended atomic word
+ * caps at ~90 updates/us on gfx950): rnad_rollout_end counts them once.
  * noise_action [B,A] / noise_chance [B,C]: explicit Exp(1) noise or NULL for the seeded stream. */
 int rnad_rollout_step(const rnad_tree_t *tree, const rnad_traj_t *traj, int t, int mode, const float *logits,
                       const float *policy_in, const int32_t *actions_in, const float *value,
                       const float *noise_action, const float *noise_chance, uint64_t seed, int64_t lane0,
                       void *stream);
+
+/* alive[t] = #lanes with indices[t, :] != 0 for t in [0, T_cap]: one pass over the index buffer after the last
+ * step.  The host reads it once to trim the trajectory to the reference's T (episode.py:194 stops when every lane
+ * is absorbed) and to get the loss normalisers N_P = sum over t == P (mod 2) of alive[t]. */
+int rnad_rollout_end(const rnad_tree_t *tree, const rnad_traj_t *traj, void *stream);
 
 /* ------------------------------------------------------------------------------------------------
  * K4  process_policy  --  learn/vtrace.py:24-55.   policy, mask f32 [N,A] -> out f32 [N,A].

@@ -4,6 +4,8 @@
 // (States.step) and :175-230 (Episodes.generate).  Citations are baskuit/R-NaD file:line.
 #include "common.hpp"
 
+#include <algorithm>
+
 using namespace rnad;
 
 namespace rnad {
@@ -177,9 +179,17 @@ __global__ __launch_bounds__(kThreads) void k_transition(const Trans *__restrict
         reward[b] = rew;
         live = next != 0;
     }
-    if (alive) {
+    if (alive) {  // one atomic per block
+        __shared__ int part[kThreads / 64];
         const unsigned long long m = __ballot(live);
-        if ((threadIdx.x & 63) == 0 && m) atomicAdd(alive, (int)__popcll(m));
+        if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = (int)__popcll(m);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            int s = 0;
+#pragma unroll
+            for (int i = 0; i < kThreads / 64; ++i) s += part[i];
+            if (s) atomicAdd(alive, s);
+        }
     }
 }
 
@@ -194,10 +204,8 @@ __global__ __launch_bounds__(kThreads) void k_act(const Trans *__restrict__ tran
                                                   const int32_t *__restrict__ idx_t, const uint8_t *__restrict__ mbits_t,
                                                   const int32_t *__restrict__ act_prev, float *__restrict__ policy_t,
                                                   int32_t *__restrict__ act_t, float *__restrict__ rewards_t,
-                                                  float *__restrict__ values_t, int32_t *__restrict__ idx_next,
-                                                  int32_t *__restrict__ alive_next) {
+                                                  float *__restrict__ values_t, int32_t *__restrict__ idx_next) {
     const int64_t b = (int64_t)blockIdx.x * kThreads + threadIdx.x;
-    bool live = false;
     if (b < B) {
         float in[A], pol[A];
 #pragma unroll
@@ -233,10 +241,27 @@ __global__ __launch_bounds__(kThreads) void k_act(const Trans *__restrict__ tran
                                (uint64_t)(lane0 + b), (uint32_t)t, next, rew);
         idx_next[b] = next;
         rewards_t[b] = rew;
-        live = next != 0;
     }
-    const unsigned long long m = __ballot(live);
-    if ((threadIdx.x & 63) == 0 && m) atomicAdd(alive_next, (int)__popcll(m));
+}
+
+// alive[t] = #lanes with indices[t, :] != 0.  grid = (chunks, T_cap + 1): each block counts one chunk of one row and
+// issues ONE atomic, so a counter word sees at most `chunks` (<= 64) updates.
+__global__ __launch_bounds__(kThreads) void k_count_alive(int64_t B, const int32_t *__restrict__ indices, int32_t *__restrict__ alive) {
+    const int t = blockIdx.y;
+    const int32_t *row = indices + (int64_t)t * B;
+    int cnt = 0;
+    for (int64_t b = (int64_t)blockIdx.x * kThreads + threadIdx.x; b < B; b += (int64_t)gridDim.x * kThreads) cnt += row[b] != 0;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) cnt += __shfl_down(cnt, off, 64);
+    __shared__ int part[kThreads / 64];
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = cnt;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int s = 0;
+#pragma unroll
+        for (int i = 0; i < kThreads / 64; ++i) s += part[i];
+        if (s) atomicAdd(alive + t, s);
+    }
 }
 
 __global__ void k_fill_i32(int64_t n, int32_t *p, int32_t v) {
@@ -293,11 +318,8 @@ static int check_traj(const rnad_tree_t *tree, const rnad_traj_t *tr, const char
 extern "C" int rnad_rollout_begin(const rnad_tree_t *tree, const rnad_traj_t *tr, void *stream_) {
     if (int rc = check_traj(tree, tr, "rnad_rollout_begin")) return rc;
     hipStream_t stream = (hipStream_t)stream_;
-    RNAD_HIP_OK(hipMemsetAsync(tr->alive, 0, sizeof(int32_t) * (tr->T_cap + 1), stream));
-    hipLaunchKernelGGL(k_fill_i32, dim3(blocks_for(tr->B)), dim3(kThreads), 0, stream, tr->B, tr->indices, 1);  // root, episode.py:22
-    const int32_t b32 = (int32_t)tr->B;
     RNAD_REQUIRE(tr->B < ((int64_t)1 << 31), "rnad_rollout_begin: batch %lld too large", (long long)tr->B);
-    hipLaunchKernelGGL(k_fill_i32, dim3(1), dim3(1), 0, stream, (int64_t)1, tr->alive, b32);
+    hipLaunchKernelGGL(k_fill_i32, dim3(blocks_for(tr->B)), dim3(kThreads), 0, stream, tr->B, tr->indices, 1);  // root, episode.py:22
     RNAD_HIP_OK(hipGetLastError());
     return launch_observe(tree, tr->B, tr->indices, 0, tr->observations, tr->obs_half, tr->mask_bits, nullptr, stream);
 }
@@ -325,7 +347,7 @@ extern "C" int rnad_rollout_step(const rnad_tree_t *tree, const rnad_traj_t *tr,
     hipLaunchKernelGGL((k_act<kA, MODE_>), dim3(blocks_for(B)), dim3(kThreads), 0, stream, tree->trans, tree->C, B, t, net_out, \
                        actions_in, value, noise_action, noise_chance, seed, lane0, idx_t, tr->mask_bits + (int64_t)t * B,      \
                        act_prev, tr->policy + (int64_t)t * B * A, tr->actions + (int64_t)t * B, tr->rewards + (int64_t)t * B,  \
-                       tr->values + (int64_t)t * B, tr->indices + (int64_t)(t + 1) * B, tr->alive + t + 1)
+                       tr->values + (int64_t)t * B, tr->indices + (int64_t)(t + 1) * B)
         RNAD_DISPATCH_A(A, {
             if (mode == 0) RNAD_ACT(0);
             else if (mode == 1) RNAD_ACT(1);
@@ -340,5 +362,15 @@ extern "C" int rnad_rollout_step(const rnad_tree_t *tree, const rnad_traj_t *tr,
         return launch_observe(tree, B, tr->indices + (int64_t)(t + 1) * B, (t + 1) & 1, obs_next, tr->obs_half,
                               tr->mask_bits + (int64_t)(t + 1) * B, nullptr, stream);
     }
+    return 0;
+}
+
+extern "C" int rnad_rollout_end(const rnad_tree_t *tree, const rnad_traj_t *tr, void *stream_) {
+    if (int rc = check_traj(tree, tr, "rnad_rollout_end")) return rc;
+    hipStream_t stream = (hipStream_t)stream_;
+    RNAD_HIP_OK(hipMemsetAsync(tr->alive, 0, sizeof(int32_t) * (tr->T_cap + 1), stream));
+    const unsigned chunks = (unsigned)std::min<int64_t>(64, blocks_for(tr->B));
+    hipLaunchKernelGGL(k_count_alive, dim3(chunks, tr->T_cap + 1), dim3(kThreads), 0, stream, tr->B, tr->indices, tr->alive);
+    RNAD_HIP_OK(hipGetLastError());
     return 0;
 }

@@ -180,6 +180,7 @@ class Episodes:
                     rnad_hip.rollout_step(handle, traj, t, value.reshape(-1).contiguous(), policy=policy.contiguous(),
                                           actions=actions.to(torch.int32).contiguous().view(-1), noise_chance=nc,
                                           seed=self.seed, lane0=self.lane_offset)
+        rnad_hip.rollout_end(handle, traj)
         alive = traj.alive.cpu()  # the only host sync of the rollout
         T = int((alive[:T_cap] > 0).sum().item())
         time_end = time.perf_counter()

@@ -130,6 +130,8 @@ def observe(tree, idx, player, obs=None, half=False, mask_bits=None, mask=None):
     B, A = idx.shape[0], tree.A
     if obs is None:
         obs = torch.empty((B, 2, A, A), dtype=F16 if half else F32, device=idx.device)
+    if B == 0:
+        return obs
     _check(lib().rnad_observe(tree.ptr, C.c_int64(B), _dp(idx, I32, "idx"), int(player), _dp(obs, F16 if half else F32, "obs"),
                               int(half), _dp(mask_bits, U8, "mask_bits", True), _dp(mask, F32, "mask", True), _stream()))
     return obs
@@ -196,6 +198,10 @@ class Trajectory:
 
 def rollout_begin(tree, traj):
     _check(lib().rnad_rollout_begin(tree.ptr, C.byref(traj.c), _stream()))
+
+
+def rollout_end(tree, traj):
+    _check(lib().rnad_rollout_end(tree.ptr, C.byref(traj.c), _stream()))
 
 
 def rollout_step(tree, traj, t, value, logits=None, policy=None, actions=None, noise_action=None, noise_chance=None,

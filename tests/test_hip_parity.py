@@ -169,6 +169,7 @@ def test_rollout_steps_replay_reference_episode(G, hip, name, mode):
         kw = dict(policy=G.gpu(ro["policy"][t])) if mode == "policy" else dict(logits=G.gpu(ro["logits"][t]))
         hip.rollout_step(tree.handle(), traj, t, G.gpu(ro["values"][t]), noise_action=G.gpu(ro["noise_action"][t]),
                          noise_chance=G.gpu(ro["noise_chance"][t]), **kw)
+    hip.rollout_end(tree.handle(), traj)
     _check_traj(G, traj, ro, T, exact_policy=mode == "policy")
 
 
