@@ -25,8 +25,8 @@ import tempfile
 import time
 
 # host threads of the CPU-baseline leg: fixed BEFORE torch / libgomp start (256 spinning threads on the GPU box's host
-# are 8x slower than 32).  The GPU path does not use them.
-CPU_THREADS = int(os.environ.get("RNAD_CPU_THREADS", min(os.cpu_count() or 1, 32)))
+# are 8x slower than 16).  The GPU path does not use them.
+CPU_THREADS = int(os.environ.get("RNAD_CPU_THREADS", min(os.cpu_count() or 1, 16)))
 os.environ.setdefault("OMP_NUM_THREADS", str(CPU_THREADS))
 
 ROOT = os.path.dirname(os.path.realpath(__file__))
