@@ -106,18 +106,26 @@ def main():
         one_step(i)
     fence()
     rnad_hip.prof_enable(True)
-    rollout_s = 0.0
     t_start = time.perf_counter()
     for i in range(args.steps):
         one_step(args.warmup + i)
-        rollout_s += rn.last_episodes.generation_time
     fence()
     elapsed = time.perf_counter() - t_start
     n_obs, obs_ms = rnad_hip.prof_read(rnad_hip.PROF_OBSERVE)
     n_act, act_ms = rnad_hip.prof_read(rnad_hip.PROF_ACT)
     n_learn, learn_ms = rnad_hip.prof_read(rnad_hip.PROF_LEARN)
+    n_mlp, mlp_ms = rnad_hip.prof_read(rnad_hip.PROF_MLP)
+    n_bwd, bwd_ms = rnad_hip.prof_read(rnad_hip.PROF_MLP_BWD)
     rnad_hip.prof_enable(False)
     T = rn.last_episodes.t_eff + 1
+    # rollout alone (Episodes.generate, reference episode.py:175-230), outside the headline timed region
+    from environment.episode import Episodes
+    fence()
+    t_r = time.perf_counter()
+    for i in range(args.steps):
+        Episodes(tree, local_batch, seed=1000 + i, lane_offset=rank * local_batch).generate(rn.net)
+    fence()
+    rollout_s = time.perf_counter() - t_r
     if world > 1:
         t = torch.tensor([elapsed, rollout_s], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -161,6 +169,9 @@ def main():
             },
             "other_kernels": {
                 "k_act": {"launches": n_act, "avg_launch_us": act_ms * 1e3 / max(n_act, 1)},
+                "k_mlp_forward": {"launches": n_mlp, "total_ms_per_step": mlp_ms / args.steps,
+                                  "note": "fp32 MFMA; rollout + target/reg nets"},
+                "k_mlp_backward": {"launches": n_bwd, "total_ms_per_step": bwd_ms / args.steps},
                 "k_learn_fused": {"launches": n_learn, "avg_launch_us": learn_ms * 1e3 / max(n_learn, 1),
                                   "achieved_GBps": (learn_bytes / (learn_ms / 1e3 / max(n_learn, 1)) / 1e9) if learn_bytes and n_learn else None},
             },

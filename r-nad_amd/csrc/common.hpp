@@ -45,7 +45,7 @@ struct Trans {
 inline int node_stride_floats(int A) { return (A * A + 2 + 3) & ~3; }
 
 // Event bracketing for bench.py's roofline leg.
-enum ProfKernel { PROF_OBSERVE = 0, PROF_ACT = 1, PROF_LEARN = 2, PROF_COUNT = 3 };
+enum ProfKernel { PROF_OBSERVE = 0, PROF_ACT = 1, PROF_LEARN = 2, PROF_MLP = 3, PROF_MLP_BWD = 4, PROF_COUNT = 5 };
 struct ProfScope {
     int which;
     hipStream_t stream;

@@ -1,0 +1,450 @@
+// mlp.hip -- fused policy/value MLP forward on the fp32 matrix cores (gfx950).
+//
+// Replaces the tensor program of nn/net.py:40-43 (and :70-73 in forward_batch):
+//     value  = value_fc1 (relu(value_fc0 (x)))        x = observation flattened to 2*A*A floats
+//     logits = policy_fc1(relu(policy_fc0(x)))
+// Citations are baskuit/R-NaD file:line.
+//
+// Why a kernel: rocprof of the PyTorch-ROCm version (profiles/r01a_*) shows the two hidden activations [N, 256] fp32
+// going to HBM and back four times per head (GEMM out, relu in/out, GEMM in): 99.5 % of a training step.  Here the hidden
+// layer never leaves the register file.
+//
+// Mapping (wave64, v_mfma_f32_32x32x2_f32, exact fp32 == an fmaf chain):
+//   C[hidden, sample] = W0aug[hidden, k] * Xaug[k, sample]     M = 32 hidden units, N = 32 samples, K = 2 per MFMA
+//   A operand  lane l: W0aug[tile*32 + (l & 31)][2*ks + (l >> 5)]   from LDS ([k][2W] layout: conflict-free)
+//   B operand  lane l: x[sample0 + (l & 31)][2*ks + (l >> 5)]       one VGPR per k-step, loaded once per 32 samples
+//   the bias rides along as feature k = K (x = 1), feature K + 1 is zero padding -> (K + 2) / 2 MFMAs per tile
+//   C layout   lane l holds sample (l & 31) and hidden rows (r & 3) + 8 (r >> 2) + 4 (l >> 5), r in [0, 16):
+//              four consecutive hidden units per register quad -> relu, then the second layer as VALU FMAs against
+//              float4 reads of W1 from LDS; the two half-waves hold complementary rows and are summed with one DPP add.
+// Both heads share the B operand; a wave walks 2 * W / 32 hidden tiles per 32 samples.  Matrix-pipe time per sample
+// tile = 2 * (W / 32) * (K / 2 + 1) * 64 cycles; 3 waves per SIMD hide the epilogue VALU work under other waves' MFMAs.
+#include "common.hpp"
+
+#include <algorithm>
+
+using namespace rnad;
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int kThreads = 256;
+constexpr int kTile = 32;  // samples per wave-tile and hidden units per MFMA tile
+
+template <typename T>
+__device__ __forceinline__ float load_obs(const T *p);
+template <>
+__device__ __forceinline__ float load_obs<float>(const float *p) { return *p; }
+template <>
+__device__ __forceinline__ float load_obs<__half>(const __half *p) { return __half2float(*p); }
+
+// LDS image (floats):  w0[(K + 2)][2W]  |  w1v[W]  |  w1p[A][W]
+template <int A, typename ObsT>
+__global__ __launch_bounds__(kThreads) void k_mlp_forward(int64_t N, int W, const float *__restrict__ vw0, const float *__restrict__ vb0,
+                                                          const float *__restrict__ vw1, const float *__restrict__ vb1,
+                                                          const float *__restrict__ pw0, const float *__restrict__ pb0,
+                                                          const float *__restrict__ pw1, const float *__restrict__ pb1,
+                                                          const ObsT *__restrict__ obs, float *__restrict__ logits,
+                                                          float *__restrict__ value) {
+    constexpr int K = 2 * A * A, KS = K / 2 + 1;  // k-steps incl. the bias step
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int W2 = 2 * W;
+    float *w0 = lds;                    // [(K + 2)][2W]
+    float *w1v = lds + (K + 2) * W2;    // [W]
+    float *w1p = w1v + W;               // [A][W]
+    for (int i = threadIdx.x; i < W2 * (K + 2); i += kThreads) {
+        const int k = i / W2, h = i % W2;
+        float x;
+        if (k < K)
+            x = h < W ? vw0[h * K + k] : pw0[(h - W) * K + k];
+        else if (k == K)
+            x = h < W ? vb0[h] : pb0[h - W];
+        else
+            x = 0.0f;
+        w0[i] = x;
+    }
+    for (int i = threadIdx.x; i < W; i += kThreads) w1v[i] = vw1[i];
+    for (int i = threadIdx.x; i < A * W; i += kThreads) w1p[i] = pw1[i];
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int col = lane & 31, half = lane >> 5;
+    const int tiles_per_head = W / kTile;
+    const float bv = vb1[0];
+    float bp[A];
+#pragma unroll
+    for (int a = 0; a < A; ++a) bp[a] = pb1[a];
+
+    const int64_t n_tiles = (N + kTile - 1) / kTile;
+    for (int64_t tile = (int64_t)blockIdx.x * (kThreads / 64) + wave; tile < n_tiles; tile += (int64_t)gridDim.x * (kThreads / 64)) {
+        const int64_t sample = tile * kTile + col;
+        const bool live = sample < N;
+        float xk[KS];
+#pragma unroll
+        for (int ks = 0; ks < KS - 1; ++ks) xk[ks] = live ? load_obs<ObsT>(obs + sample * K + 2 * ks + half) : 0.0f;
+        xk[KS - 1] = half == 0 ? 1.0f : 0.0f;  // bias feature, zero pad
+
+        float acc_v = 0.0f, acc_p[A];
+#pragma unroll
+        for (int a = 0; a < A; ++a) acc_p[a] = 0.0f;
+
+        // a NULL output skips that head's hidden tiles entirely (regularisation nets need logits only, the target net value only)
+        const int ht_begin = value ? 0 : tiles_per_head, ht_end = logits ? 2 * tiles_per_head : tiles_per_head;
+        for (int ht = ht_begin; ht < ht_end; ++ht) {
+            const float *wa = w0 + ht * kTile + col;
+            f32x16 c = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) c = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[(2 * ks + half) * W2], xk[ks], c, 0, 0, 0);
+            if (ht < tiles_per_head) {  // value head: one output
+                const float *w1 = w1v + ht * kTile + 4 * half;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const float4 w = *reinterpret_cast<const float4 *>(w1 + 8 * g);
+                    acc_v += w.x * fmaxf(c[4 * g + 0], 0.0f);
+                    acc_v += w.y * fmaxf(c[4 * g + 1], 0.0f);
+                    acc_v += w.z * fmaxf(c[4 * g + 2], 0.0f);
+                    acc_v += w.w * fmaxf(c[4 * g + 3], 0.0f);
+                }
+            } else {  // policy head: A outputs
+                const float *w1 = w1p + (ht - tiles_per_head) * kTile + 4 * half;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const float h0 = fmaxf(c[4 * g + 0], 0.0f), h1 = fmaxf(c[4 * g + 1], 0.0f);
+                    const float h2 = fmaxf(c[4 * g + 2], 0.0f), h3 = fmaxf(c[4 * g + 3], 0.0f);
+#pragma unroll
+                    for (int a = 0; a < A; ++a) {
+                        const float4 w = *reinterpret_cast<const float4 *>(w1 + a * W + 8 * g);
+                        acc_p[a] += w.x * h0;
+                        acc_p[a] += w.y * h1;
+                        acc_p[a] += w.z * h2;
+                        acc_p[a] += w.w * h3;
+                    }
+                }
+            }
+        }
+        // the two half-waves hold complementary hidden rows of the same 32 samples
+        acc_v += __shfl_xor(acc_v, 32, 64);
+#pragma unroll
+        for (int a = 0; a < A; ++a) acc_p[a] += __shfl_xor(acc_p[a], 32, 64);
+        if (live && half == 0) {
+            if (value) value[sample] = acc_v + bv;
+            if (logits) {
+#pragma unroll
+                for (int a = 0; a < A; ++a) logits[sample * A + a] = acc_p[a] + bp[a];
+            }
+        }
+    }
+}
+
+
+// ------------------------------------------------------------------------------------------------ backward
+// Gradients of the 8 Linear tensors given dL/dlogits [N, A] and dL/dvalue [N] -- what autograd computes for
+// nn/net.py:40-43 -- in ONE pass over the samples with the hidden layer recomputed on chip:
+//     z = W0aug x (MFMA, as in the forward)          h = relu(z)
+//     dW1[o, j] += dout[o] * h[j]                     (VALU, per-lane partial sums over this lane's samples)
+//     dz[j] = (z[j] > 0) * sum_o W1[o, j] * dout[o]
+//     dW0aug[j, k] += dz[j] * xaug[k]                 (MFMA with the 32 SAMPLES of the tile as the contraction dimension:
+//                                                      A = dz^T via a per-wave 32x33 LDS transpose, B = x rows; the
+//                                                      bias gradient is the k = K column because xaug[K] = 1)
+// Block = W/32 waves; wave w owns hidden tile w of BOTH heads for every sample tile the block visits, so its two
+// 32x32 dW0aug accumulators (32 registers) and its dW1 partials (16 + 16 A registers) stay resident for the whole
+// launch.  Blocks write their partial gradients to `partial`; k_mlp_reduce sums them in a fixed order (deterministic).
+template <int A, typename ObsT>
+__global__ __launch_bounds__(512) void k_mlp_backward(int64_t N, int W, const float *__restrict__ vw0, const float *__restrict__ vb0,
+                                                      const float *__restrict__ vw1, const float *__restrict__ pw0,
+                                                      const float *__restrict__ pb0, const float *__restrict__ pw1,
+                                                      const ObsT *__restrict__ obs, const float *__restrict__ dlogit,
+                                                      const float *__restrict__ dv, float *__restrict__ partial, int P) {
+    constexpr int K = 2 * A * A, KS = K / 2 + 1;
+    static_assert(K + 1 <= kTile, "feature tile");
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int W2 = 2 * W, nthreads = blockDim.x;
+    float *w0 = lds;
+    float *w1v = lds + (K + 2) * W2;
+    float *w1p = w1v + W;
+    float *scratch = w1p + A * W;  // [waves][32][33]
+    for (int i = threadIdx.x; i < W2 * (K + 2); i += nthreads) {
+        const int k = i / W2, h = i % W2;
+        float x;
+        if (k < K)
+            x = h < W ? vw0[h * K + k] : pw0[(h - W) * K + k];
+        else if (k == K)
+            x = h < W ? vb0[h] : pb0[h - W];
+        else
+            x = 0.0f;
+        w0[i] = x;
+    }
+    for (int i = threadIdx.x; i < W; i += nthreads) w1v[i] = vw1[i];
+    for (int i = threadIdx.x; i < A * W; i += nthreads) w1p[i] = pw1[i];
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int col = lane & 31, half = lane >> 5;
+    float *tr = scratch + wave * (kTile * 33);
+    const int tile_v = wave, tile_p = W / kTile + wave;
+
+    f32x16 gW0v = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, gW0p = gW0v;
+    float gW1v[16], gW1p[A][16], gb1v = 0.0f, gb1p[A];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        gW1v[r] = 0.0f;
+#pragma unroll
+        for (int a = 0; a < A; ++a) gW1p[a][r] = 0.0f;
+    }
+#pragma unroll
+    for (int a = 0; a < A; ++a) gb1p[a] = 0.0f;
+
+    const int64_t n_tiles = (N + kTile - 1) / kTile;
+    for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const int64_t s0 = tile * kTile;
+        const int64_t sample = s0 + col;
+        const bool live = sample < N;
+        float xk[KS];   // B operand of the forward product: x[sample = col][2 ks + half]
+#pragma unroll
+        for (int ks = 0; ks < KS - 1; ++ks) xk[ks] = live ? load_obs<ObsT>(obs + sample * K + 2 * ks + half) : 0.0f;
+        xk[KS - 1] = half == 0 ? 1.0f : 0.0f;
+        float xt[16];   // B operand of the weight-gradient product: xaug[sample = 2 ks + half][feature = col]
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) {
+            const int64_t sk = s0 + 2 * ks + half;
+            float x = 0.0f;
+            if (sk < N) x = col < K ? load_obs<ObsT>(obs + sk * K + col) : (col == K ? 1.0f : 0.0f);
+            xt[ks] = x;
+        }
+        const float dvs = live ? dv[sample] : 0.0f;
+        float dl[A];
+#pragma unroll
+        for (int a = 0; a < A; ++a) dl[a] = live ? dlogit[sample * A + a] : 0.0f;
+        gb1v += dvs;
+#pragma unroll
+        for (int a = 0; a < A; ++a) gb1p[a] += dl[a];
+
+        // ---------------- value head, hidden tile `tile_v`
+        {
+            const float *wa = w0 + tile_v * kTile + col;
+            f32x16 c = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) c = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[(2 * ks + half) * W2], xk[ks], c, 0, 0, 0);
+            const float *w1 = w1v + tile_v * kTile + 4 * half;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float4 w = *reinterpret_cast<const float4 *>(w1 + 8 * g);
+                const float wv[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int r = 4 * g + j;
+                    const float z = c[r];
+                    gW1v[r] += dvs * fmaxf(z, 0.0f);
+                    tr[(j + 8 * g + 4 * half) * 33 + col] = z > 0.0f ? wv[j] * dvs : 0.0f;  // dz, stored [hidden][sample]
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int ks = 0; ks < 16; ++ks) gW0v = __builtin_amdgcn_mfma_f32_32x32x2f32(tr[col * 33 + 2 * ks + half], xt[ks], gW0v, 0, 0, 0);
+            __builtin_amdgcn_wave_barrier();
+        }
+        // ---------------- policy head, hidden tile `tile_p`
+        {
+            const float *wa = w0 + tile_p * kTile + col;
+            f32x16 c = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) c = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[(2 * ks + half) * W2], xk[ks], c, 0, 0, 0);
+            const float *w1 = w1p + wave * kTile + 4 * half;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                float dh[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+                for (int a = 0; a < A; ++a) {
+                    const float4 w = *reinterpret_cast<const float4 *>(w1 + a * W + 8 * g);
+                    dh[0] += w.x * dl[a]; dh[1] += w.y * dl[a]; dh[2] += w.z * dl[a]; dh[3] += w.w * dl[a];
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int r = 4 * g + j;
+                    const float z = c[r];
+                    const float h = fmaxf(z, 0.0f);
+#pragma unroll
+                    for (int a = 0; a < A; ++a) gW1p[a][r] += dl[a] * h;
+                    tr[(j + 8 * g + 4 * half) * 33 + col] = z > 0.0f ? dh[j] : 0.0f;
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int ks = 0; ks < 16; ++ks) gW0p = __builtin_amdgcn_mfma_f32_32x32x2f32(tr[col * 33 + 2 * ks + half], xt[ks], gW0p, 0, 0, 0);
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+
+    // ---------------- write this block's partial gradients
+    // layout: dW0aug [2W][32] | dW1v [W] | dW1p [A][W] | db1v | db1p [A]
+    float *out = partial + (int64_t)blockIdx.x * P;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+        out[(tile_v * kTile + row) * kTile + col] = gW0v[r];
+        out[(tile_p * kTile + row) * kTile + col] = gW0p[r];
+    }
+    float *o1 = out + W2 * kTile;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        float v = gW1v[r];
+#pragma unroll
+        for (int off = 16; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);  // over the 32 sample lanes of this half-wave
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (col == 0) o1[tile_v * kTile + row] = v;
+#pragma unroll
+        for (int a = 0; a < A; ++a) {
+            float p = gW1p[a][r];
+#pragma unroll
+            for (int off = 16; off > 0; off >>= 1) p += __shfl_xor(p, off, 64);
+            if (col == 0) o1[W + a * W + wave * kTile + row] = p;
+        }
+    }
+    if (wave == 0) {  // every wave saw the same samples: one of them reports the output-bias gradients
+#pragma unroll
+        for (int off = 16; off > 0; off >>= 1) gb1v += __shfl_xor(gb1v, off, 64);
+        if (lane == 0) o1[W + A * W] = gb1v;
+#pragma unroll
+        for (int a = 0; a < A; ++a) {
+            float p = gb1p[a];
+#pragma unroll
+            for (int off = 16; off > 0; off >>= 1) p += __shfl_xor(p, off, 64);
+            if (lane == 0) o1[W + A * W + 1 + a] = p;
+        }
+    }
+}
+
+// Sum the per-block partials (fixed order, fp64 accumulate) into the eight gradient tensors (torch Linear layouts).
+template <int A>
+__global__ __launch_bounds__(kThreads) void k_mlp_reduce(int nblocks, int W, int P, const float *__restrict__ partial,
+                                                         float *__restrict__ g_vw0, float *__restrict__ g_vb0, float *__restrict__ g_vw1,
+                                                         float *__restrict__ g_vb1, float *__restrict__ g_pw0, float *__restrict__ g_pb0,
+                                                         float *__restrict__ g_pw1, float *__restrict__ g_pb1) {
+    constexpr int K = 2 * A * A;
+    const int e = blockIdx.x * kThreads + threadIdx.x;
+    const int total = 2 * W * kTile + W + A * W + 1 + A;
+    if (e >= total) return;
+    double s = 0.0;
+    for (int b = 0; b < nblocks; ++b) s += (double)partial[(int64_t)b * P + e];
+    const float v = (float)s;
+    const int n0 = 2 * W * kTile;
+    if (e < n0) {
+        const int h = e / kTile, k = e % kTile;
+        float *gw = h < W ? g_vw0 : g_pw0, *gb = h < W ? g_vb0 : g_pb0;
+        const int hh = h < W ? h : h - W;
+        if (k < K) gw[hh * K + k] = v;
+        else if (k == K) gb[hh] = v;
+    } else if (e < n0 + W) {
+        g_vw1[e - n0] = v;
+    } else if (e < n0 + W + A * W) {
+        g_pw1[e - n0 - W] = v;
+    } else if (e == n0 + W + A * W) {
+        g_vb1[0] = v;
+    } else {
+        g_pb1[e - n0 - W - A * W - 1] = v;
+    }
+}
+
+}  // namespace
+
+extern "C" int rnad_mlp_forward(int64_t N, int A, int W, const float *vw0, const float *vb0, const float *vw1, const float *vb1,
+                                const float *pw0, const float *pb0, const float *pw1, const float *pb1, const void *obs, int obs_half,
+                                float *logits, float *value, void *stream_) {
+    RNAD_REQUIRE(vw0 && vb0 && vw1 && vb1 && pw0 && pb0 && pw1 && pb1 && obs && (logits || value), "rnad_mlp_forward: null argument");
+    RNAD_REQUIRE(W >= kTile && W % kTile == 0, "rnad_mlp_forward: width %d must be a positive multiple of %d", W, kTile);
+    RNAD_REQUIRE(N >= 0, "rnad_mlp_forward: negative batch");
+    if (N == 0) return 0;
+    hipStream_t stream = (hipStream_t)stream_;
+    const int K = 2 * A * A;
+    const size_t lds_bytes = ((size_t)(K + 2) * 2 * W + (size_t)(1 + A) * W) * sizeof(float);
+    RNAD_REQUIRE(lds_bytes <= 160 * 1024, "rnad_mlp_forward: weights (%zu B) do not fit the 160 KiB LDS (A=%d, width=%d)", lds_bytes, A, W);
+    int dev = 0, cus = 256;
+    RNAD_HIP_OK(hipGetDevice(&dev));
+    RNAD_HIP_OK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    const int blocks_per_cu = std::max(1, std::min(3, (int)(160 * 1024 / lds_bytes)));
+    const int64_t n_tiles = (N + kTile - 1) / kTile;
+    const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>((n_tiles + 3) / 4, (int64_t)cus * blocks_per_cu));
+    ProfScope prof(PROF_MLP, stream);
+#define RNAD_MLP_LAUNCH(T_)                                                                                                        \
+    do {                                                                                                                           \
+        auto kern = k_mlp_forward<kA, T_>;                                                                                         \
+        if (lds_bytes > 64 * 1024)                                                                                                 \
+            RNAD_HIP_OK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));      \
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(kThreads), lds_bytes, stream, N, W, vw0, vb0, vw1, vb1, pw0, pb0, pw1, pb1,      \
+                           (const T_ *)obs, logits, value);                                                                        \
+    } while (0)
+    RNAD_DISPATCH_A(A, {
+        if (obs_half)
+            RNAD_MLP_LAUNCH(__half);
+        else
+            RNAD_MLP_LAUNCH(float);
+    });
+#undef RNAD_MLP_LAUNCH
+    RNAD_HIP_OK(hipGetLastError());
+    return 0;
+}
+
+static int mlp_backward_grid(int64_t N, int W, int A, size_t *lds_bytes, int *P) {
+    const int K = 2 * A * A;
+    *lds_bytes = ((size_t)(K + 2) * 2 * W + (size_t)(1 + A) * W + (size_t)(W / kTile) * kTile * 33) * sizeof(float);
+    *P = (2 * W * kTile + W + A * W + 1 + A + 3) & ~3;
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    const int blocks_per_cu = std::max(1, std::min(2, (int)(160 * 1024 / *lds_bytes)));
+    const int64_t n_tiles = (N + kTile - 1) / kTile;
+    return (int)std::max<int64_t>(1, std::min<int64_t>(n_tiles, (int64_t)cus * blocks_per_cu));
+}
+
+extern "C" int64_t rnad_mlp_backward_workspace(int64_t N, int A, int W) {
+    size_t lds;
+    int P;
+    const int grid = mlp_backward_grid(N, W, A, &lds, &P);
+    return (int64_t)grid * P * (int64_t)sizeof(float);
+}
+
+extern "C" int rnad_mlp_backward(int64_t N, int A, int W, const float *vw0, const float *vb0, const float *vw1, const float *pw0,
+                                 const float *pb0, const float *pw1, const void *obs, int obs_half, const float *dlogits,
+                                 const float *dvalue, float *g_vw0, float *g_vb0, float *g_vw1, float *g_vb1, float *g_pw0,
+                                 float *g_pb0, float *g_pw1, float *g_pb1, float *workspace, void *stream_) {
+    RNAD_REQUIRE(vw0 && vb0 && vw1 && pw0 && pb0 && pw1 && obs && dlogits && dvalue && g_vw0 && g_vb0 && g_vw1 && g_vb1 && g_pw0 &&
+                     g_pb0 && g_pw1 && g_pb1 && workspace,
+                 "rnad_mlp_backward: null argument");
+    RNAD_REQUIRE(W >= kTile && W % kTile == 0 && W <= 256, "rnad_mlp_backward: width %d must be a multiple of %d, at most 256", W, kTile);
+    RNAD_REQUIRE(2 * A * A + 1 <= kTile, "rnad_mlp_backward: max_actions %d needs more than %d input features", A, kTile);
+    RNAD_REQUIRE(N >= 1, "rnad_mlp_backward: empty batch");
+    hipStream_t stream = (hipStream_t)stream_;
+    size_t lds_bytes;
+    int P;
+    const int grid = mlp_backward_grid(N, W, A, &lds_bytes, &P);
+    RNAD_REQUIRE(lds_bytes <= 160 * 1024, "rnad_mlp_backward: weights do not fit the LDS (A=%d, width=%d)", A, W);
+    const int threads = 64 * (W / kTile);
+    {
+        ProfScope prof(PROF_MLP_BWD, stream);
+#define RNAD_MLPB_LAUNCH(T_)                                                                                                       \
+    do {                                                                                                                           \
+        auto kern = k_mlp_backward<kA, T_>;                                                                                        \
+        if (lds_bytes > 64 * 1024)                                                                                                 \
+            RNAD_HIP_OK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));      \
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), lds_bytes, stream, N, W, vw0, vb0, vw1, pw0, pb0, pw1, (const T_ *)obs, \
+                           dlogits, dvalue, workspace, P);                                                                         \
+    } while (0)
+        switch (A) {
+            case 1: { constexpr int kA = 1; if (obs_half) RNAD_MLPB_LAUNCH(__half); else RNAD_MLPB_LAUNCH(float); } break;
+            case 2: { constexpr int kA = 2; if (obs_half) RNAD_MLPB_LAUNCH(__half); else RNAD_MLPB_LAUNCH(float); } break;
+            case 3: { constexpr int kA = 3; if (obs_half) RNAD_MLPB_LAUNCH(__half); else RNAD_MLPB_LAUNCH(float); } break;
+            default: rnad::set_error("rnad_mlp_backward: max_actions %d not supported (1..3)", A); return 2;
+        }
+#undef RNAD_MLPB_LAUNCH
+        RNAD_HIP_OK(hipGetLastError());
+    }
+    const int total = 2 * W * kTile + W + A * W + 1 + A;
+    const unsigned rgrid = (unsigned)((total + kThreads - 1) / kThreads);
+    switch (A) {
+        case 1: hipLaunchKernelGGL((k_mlp_reduce<1>), dim3(rgrid), dim3(kThreads), 0, stream, grid, W, P, workspace, g_vw0, g_vb0, g_vw1, g_vb1, g_pw0, g_pb0, g_pw1, g_pb1); break;
+        case 2: hipLaunchKernelGGL((k_mlp_reduce<2>), dim3(rgrid), dim3(kThreads), 0, stream, grid, W, P, workspace, g_vw0, g_vb0, g_vw1, g_vb1, g_pw0, g_pb0, g_pw1, g_pb1); break;
+        default: hipLaunchKernelGGL((k_mlp_reduce<3>), dim3(rgrid), dim3(kThreads), 0, stream, grid, W, P, workspace, g_vw0, g_vb0, g_vw1, g_vb1, g_pw0, g_pb0, g_pw1, g_pb1); break;
+    }
+    RNAD_HIP_OK(hipGetLastError());
+    return 0;
+}

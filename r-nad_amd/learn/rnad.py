@@ -267,11 +267,11 @@ class RNaD:
 
     # ------------------------------------------------------------------ reference learn/rnad.py:353-456
     @staticmethod
-    def _logits_of(module, episodes, want_value=True):
-        """Raw policy logits [T*B, A] (and value [T*B, 1]) of `module` on a trajectory."""
+    def _logits_of(module, episodes, want_logits=True, want_value=True):
+        """Raw policy logits [T*B, A] and value [T*B, 1] of `module` on a trajectory (a head that is not wanted may be None)."""
         T = episodes.t_eff + 1
         if hasattr(module, "forward_logits"):
-            return module.forward_logits(episodes.observations[:T])
+            return module.forward_logits(episodes.observations[:T], want_logits=want_logits, want_value=want_value)
         logit, _, _, v = module.forward_batch(episodes)  # any module honouring the reference contract (nn/net.py:64-85)
         A = logit.shape[-1]
         return logit.reshape(-1, A), v.reshape(-1, 1)
@@ -282,9 +282,10 @@ class RNaD:
 
         logit, v = self._logits_of(self.net, episodes)  # rnad.py:373, with grad
         with torch.no_grad():
-            logit_target, v_target = self._logits_of(self.net_target, episodes)  # :378
-            logit_reg, _ = self._logits_of(self.net_reg, episodes)  # :379
-            logit_reg_, _ = self._logits_of(self.net_reg_, episodes)  # :380
+            # the reference runs all four full nets (:378-380); only these heads are ever read (:382-406)
+            logit_target, v_target = self._logits_of(self.net_target, episodes, want_logits=log is not None)  # :378
+            logit_reg, _ = self._logits_of(self.net_reg, episodes, want_value=False)  # :379
+            logit_reg_, _ = self._logits_of(self.net_reg_, episodes, want_value=False)  # :380
 
         norm = episodes.valid_counts  # N_P = #(valid & turn == P): batch-global normalisers (vtrace.py:373,388)
         if _dist_on():

@@ -27,14 +27,28 @@ class MLP(nn.Module):
         self._seed = int(torch.randint(0, 2**62, (1,)).item())  # sampler stream of forward(); torch.manual_seed controls it
         self._calls = 0
 
-    # ---------------------------------------------------------------- the GEMMs (PyTorch-ROCm)
-    def forward_logits(self, input_batch):
-        """obs [N, 2, A, A] (fp32 or fp16) -> logits [N, A], value [N, 1]   (net.py:40-43)."""
+    # ---------------------------------------------------------------- the two perceptrons
+    def _weights(self):
+        return [self.value_fc0.weight, self.value_fc0.bias, self.value_fc1.weight, self.value_fc1.bias,
+                self.policy_fc0.weight, self.policy_fc0.bias, self.policy_fc1.weight, self.policy_fc1.bias]
+
+    def forward_logits(self, input_batch, want_logits=True, want_value=True):
+        """obs [N, 2, A, A] (fp32 or fp16) -> logits [N, A], value [N, 1]   (net.py:40-43).
+
+        ONE fused HIP kernel that keeps the hidden layer in registers (rnad_mlp_forward); under autograd it is an
+        autograd node whose backward is rnad_mlp_backward (hidden layer recomputed on chip).  Shapes the kernels do not
+        cover (A > 3 for the backward, width not a multiple of 32, non-fp32 weights) use four PyTorch-ROCm Linear calls."""
+        A = self.max_actions
+        if input_batch.is_cuda and self.value_fc0.weight.dtype == torch.float32 and self.width % 32 == 0:
+            if not torch.is_grad_enabled():
+                return rnad_hip.mlp_forward(self._weights(), input_batch.contiguous(), A, want_logits, want_value)
+            if rnad_hip.mlp_backward_supported(A, self.width) and not input_batch.requires_grad:
+                return rnad_hip.FusedMLP.apply(input_batch.contiguous(), A, *self._weights())
         x = input_batch.reshape(-1, 2 * self.max_actions**2)
         if x.dtype != self.value_fc0.weight.dtype:
             x = x.to(self.value_fc0.weight.dtype)
-        value = self.value_fc1(torch.relu(self.value_fc0(x)))
-        logits = self.policy_fc1(torch.relu(self.policy_fc0(x)))
+        value = self.value_fc1(torch.relu(self.value_fc0(x))) if want_value else None
+        logits = self.policy_fc1(torch.relu(self.policy_fc0(x))) if want_logits else None
         return logits, value
 
     @staticmethod
@@ -51,9 +65,9 @@ class MLP(nn.Module):
 
     # ---------------------------------------------------------------- net.py:53-62
     def forward_policy(self, input_batch: torch.Tensor) -> torch.Tensor:
-        x = input_batch.reshape(-1, 2 * self.max_actions**2)
-        logits = self.policy_fc1(torch.relu(self.policy_fc0(x)))
-        return rnad_hip.policy_head(logits.detach().contiguous(), mask=self._mask(input_batch))
+        with torch.no_grad():
+            logits, _ = self.forward_logits(input_batch, want_value=False)
+        return rnad_hip.policy_head(logits.contiguous(), mask=self._mask(input_batch))
 
     # ---------------------------------------------------------------- net.py:64-85
     def forward_batch(self, episodes):

@@ -58,6 +58,7 @@ def lib():
         _lib.rnad_tree_info.restype = C.c_int64
         _lib.rnad_tree_generate.restype = C.c_int64
         _lib.rnad_tree_destroy.restype = None
+        _lib.rnad_mlp_backward_workspace.restype = C.c_int64
     return _lib
 
 
@@ -174,6 +175,59 @@ def transition(tree, idx, row_actions, col_actions, noise=None, seed=0, lane0=0,
                                  C.c_int64(lane0), int(step), _dp(idx_out, I32, "idx_out"), _dp(reward, F32, "reward"),
                                  _dp(alive, I32, "alive", True), _stream()))
     return idx_out, reward
+
+
+# --------------------------------------------------------------------------------------- fused MLP
+MLP_KEYS = ("value_fc0.weight", "value_fc0.bias", "value_fc1.weight", "value_fc1.bias",
+            "policy_fc0.weight", "policy_fc0.bias", "policy_fc1.weight", "policy_fc1.bias")
+
+
+def mlp_forward(weights, obs, A, want_logits=True, want_value=True):
+    """weights: the 8 Linear tensors in MLP_KEYS order (fp32, device); obs [N, 2, A, A] fp32/fp16 -> logits [N, A], value [N, 1].
+    A head that is not wanted is not computed (returns None for it)."""
+    N = obs.numel() // (2 * A * A)
+    W = weights[0].shape[0]
+    half = obs.dtype == F16
+    logits = torch.empty((N, A), dtype=F32, device=obs.device) if want_logits else None
+    value = torch.empty((N, 1), dtype=F32, device=obs.device) if want_value else None
+    _check(lib().rnad_mlp_forward(C.c_int64(N), A, W, *[_dp(w.detach(), F32, "weight") for w in weights],
+                                  _dp(obs, F16 if half else F32, "obs"), int(half), _dp(logits, F32, "logits", True),
+                                  _dp(value, F32, "value", True), _stream()))
+    return logits, value
+
+
+def mlp_backward_supported(A, W):
+    return 2 * A * A + 1 <= 32 and W % 32 == 0 and W <= 256
+
+
+def mlp_backward(weights, obs, A, dlogits, dvalue):
+    """Gradients of the 8 Linear tensors (MLP_KEYS order) for dL/dlogits [N, A], dL/dvalue [N(,1)]."""
+    N = obs.numel() // (2 * A * A)
+    W = weights[0].shape[0]
+    half = obs.dtype == F16
+    grads = [torch.empty_like(w) for w in weights]
+    ws = torch.empty((lib().rnad_mlp_backward_workspace(C.c_int64(N), A, W) // 4,), dtype=F32, device=obs.device)
+    w = [_dp(x.detach(), F32, "weight") for x in weights]
+    _check(lib().rnad_mlp_backward(C.c_int64(N), A, W, w[0], w[1], w[2], w[4], w[5], w[6], _dp(obs, F16 if half else F32, "obs"), int(half),
+                                   _dp(dlogits, F32, "dlogits"), _dp(dvalue, F32, "dvalue"), *[_dp(g, F32, "grad") for g in grads],
+                                   _dp(ws, F32, "workspace"), _stream()))
+    return grads
+
+
+class FusedMLP(torch.autograd.Function):
+    """logits, value = FusedMLP.apply(obs, A, *weights): rnad_mlp_forward / rnad_mlp_backward as one autograd node."""
+
+    @staticmethod
+    def forward(ctx, obs, A, *weights):
+        ctx.A = A
+        ctx.save_for_backward(obs, *weights)
+        return mlp_forward(weights, obs, A)
+
+    @staticmethod
+    def backward(ctx, dlogits, dvalue):
+        obs, *weights = ctx.saved_tensors
+        grads = mlp_backward(weights, obs, ctx.A, dlogits.contiguous(), dvalue.contiguous())
+        return (None, None, *grads)
 
 
 # --------------------------------------------------------------------------------------- rollout driver
@@ -327,7 +381,7 @@ def tree_generate(A, Cc, depth_bound, transition_threshold=0.0, terminal_values=
 
 
 # --------------------------------------------------------------------------------------- profiling hooks
-PROF_OBSERVE, PROF_ACT, PROF_LEARN = 0, 1, 2
+PROF_OBSERVE, PROF_ACT, PROF_LEARN, PROF_MLP, PROF_MLP_BWD = 0, 1, 2, 3, 4
 
 
 def prof_enable(on):
