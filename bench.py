@@ -164,7 +164,7 @@ def main():
             "roofline": {
                 "kernel": "k_observe (K1 episode gather, rnad_observe)",
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                "traffic": None,
+                "traffic": k1_traffic(A, args),
                 "bytes_per_launch": k1_bytes_per_launch, "avg_launch_us": k1_avg_s * 1e6, "launches": n_obs,
             },
             "other_kernels": {
@@ -183,6 +183,16 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def k1_traffic(A, args):
+    """HBM bytes per K1 launch from the separate rocprofv3 PMC passes (profiles/r01_k1_pmc.json: FETCH_SIZE doubled per the
+    gfx950 correction + WRITE_SIZE), valid for the default workload only; None otherwise."""
+    path = os.path.join(ROOT, "profiles", "r01_k1_pmc.json")
+    if A != 3 or args.batch_log2 != 20 or args.gpus != 1 or args.obs_half or not os.path.exists(path):
+        return None
+    with open(path) as f:
+        return json.load(f)["traffic_bytes_per_launch"]
 
 
 def cpu_baseline(tree, args, T):

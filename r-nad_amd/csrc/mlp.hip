@@ -40,7 +40,58 @@ template <>
 __device__ __forceinline__ float load_obs<__half>(const __half *p) { return __half2float(*p); }
 
 // LDS image (floats):  w0[(K + 2)][2W]  |  w1v[W]  |  w1p[A][W]
-template <int A, typename ObsT>
+//
+// HEADS: 1 = value only, 2 = policy only, 3 = both.  A wave keeps TWO hidden tiles in flight (two independent
+// accumulator chains) and is software-pipelined by hand: the MFMA chains of the next tile pair are issued before the
+// relu / second-layer VALU epilogue of the current pair.  (Measured on gfx950: fp32 MFMA and fp32 VALU work do NOT
+// overlap -- kernel time is the sum of the two -- so what counts is the VALU instruction count of the epilogue: built
+// with -mllvm -amdgpu-mfma-vgpr-form (no v_accvgpr_read) and -fno-honor-nans (no canonicalising v_max before relu).)
+template <int A, int KS>
+__device__ __forceinline__ f32x16 mfma_chain(const float *__restrict__ wa, int W2, int half, const float (&xk)[KS]) {
+    f32x16 c = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) c = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[(2 * ks + half) * W2], xk[ks], c, 0, 0, 0);
+    return c;
+}
+
+// Second layer for one 32x32 hidden tile.  Four independent partial sums per output keep the fma chains short;
+// explicit fmaf: the summation order here is this kernel's own (nothing in the reference fixes it).
+__device__ __forceinline__ void epilogue_value(const f32x16 &c, const float *__restrict__ w1, float &acc) {
+    float p[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const float4 w = *reinterpret_cast<const float4 *>(w1 + 8 * g);
+        p[0] = fmaf(w.x, fmaxf(c[4 * g + 0], 0.0f), p[0]);
+        p[1] = fmaf(w.y, fmaxf(c[4 * g + 1], 0.0f), p[1]);
+        p[2] = fmaf(w.z, fmaxf(c[4 * g + 2], 0.0f), p[2]);
+        p[3] = fmaf(w.w, fmaxf(c[4 * g + 3], 0.0f), p[3]);
+    }
+    acc += (p[0] + p[1]) + (p[2] + p[3]);
+}
+
+template <int A>
+__device__ __forceinline__ void epilogue_policy(const f32x16 &c, const float *__restrict__ w1, int W, float (&acc)[A]) {
+    float p[A][4];
+#pragma unroll
+    for (int a = 0; a < A; ++a) p[a][0] = p[a][1] = p[a][2] = p[a][3] = 0.0f;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const float h0 = fmaxf(c[4 * g + 0], 0.0f), h1 = fmaxf(c[4 * g + 1], 0.0f);
+        const float h2 = fmaxf(c[4 * g + 2], 0.0f), h3 = fmaxf(c[4 * g + 3], 0.0f);
+#pragma unroll
+        for (int a = 0; a < A; ++a) {
+            const float4 w = *reinterpret_cast<const float4 *>(w1 + a * W + 8 * g);
+            p[a][0] = fmaf(w.x, h0, p[a][0]);
+            p[a][1] = fmaf(w.y, h1, p[a][1]);
+            p[a][2] = fmaf(w.z, h2, p[a][2]);
+            p[a][3] = fmaf(w.w, h3, p[a][3]);
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < A; ++a) acc[a] += (p[a][0] + p[a][1]) + (p[a][2] + p[a][3]);
+}
+
+template <int A, typename ObsT, int HEADS>
 __global__ __launch_bounds__(kThreads) void k_mlp_forward(int64_t N, int W, const float *__restrict__ vw0, const float *__restrict__ vb0,
                                                           const float *__restrict__ vw1, const float *__restrict__ vb1,
                                                           const float *__restrict__ pw0, const float *__restrict__ pb0,
@@ -70,11 +121,16 @@ __global__ __launch_bounds__(kThreads) void k_mlp_forward(int64_t N, int W, cons
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int col = lane & 31, half = lane >> 5;
-    const int tiles_per_head = W / kTile;
-    const float bv = vb1[0];
+    const int T = W / kTile;  // hidden tiles per head
+    const float bv = HEADS & 1 ? vb1[0] : 0.0f;
+    (void)wave;
     float bp[A];
 #pragma unroll
-    for (int a = 0; a < A; ++a) bp[a] = pb1[a];
+    for (int a = 0; a < A; ++a) bp[a] = HEADS & 2 ? pb1[a] : 0.0f;
+    // tile pair p of this launch: both heads -> (value tile p, policy tile p); one head -> its tiles (2p, 2p + 1)
+    const int n_pairs = HEADS == 3 ? T : T / 2;  // single-head launches need an even tile count (the launcher sees to it)
+    const int first = HEADS == 2 ? T : 0;
+    const int stride0 = HEADS == 3 ? 1 : 2, off1 = HEADS == 3 ? T : 1;
 
     const int64_t n_tiles = (N + kTile - 1) / kTile;
     for (int64_t tile = (int64_t)blockIdx.x * (kThreads / 64) + wave; tile < n_tiles; tile += (int64_t)gridDim.x * (kThreads / 64)) {
@@ -89,47 +145,50 @@ __global__ __launch_bounds__(kThreads) void k_mlp_forward(int64_t N, int W, cons
 #pragma unroll
         for (int a = 0; a < A; ++a) acc_p[a] = 0.0f;
 
-        // a NULL output skips that head's hidden tiles entirely (regularisation nets need logits only, the target net value only)
-        const int ht_begin = value ? 0 : tiles_per_head, ht_end = logits ? 2 * tiles_per_head : tiles_per_head;
-        for (int ht = ht_begin; ht < ht_end; ++ht) {
-            const float *wa = w0 + ht * kTile + col;
-            f32x16 c = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks) c = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[(2 * ks + half) * W2], xk[ks], c, 0, 0, 0);
-            if (ht < tiles_per_head) {  // value head: one output
-                const float *w1 = w1v + ht * kTile + 4 * half;
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const float4 w = *reinterpret_cast<const float4 *>(w1 + 8 * g);
-                    acc_v += w.x * fmaxf(c[4 * g + 0], 0.0f);
-                    acc_v += w.y * fmaxf(c[4 * g + 1], 0.0f);
-                    acc_v += w.z * fmaxf(c[4 * g + 2], 0.0f);
-                    acc_v += w.w * fmaxf(c[4 * g + 3], 0.0f);
-                }
-            } else {  // policy head: A outputs
-                const float *w1 = w1p + (ht - tiles_per_head) * kTile + 4 * half;
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const float h0 = fmaxf(c[4 * g + 0], 0.0f), h1 = fmaxf(c[4 * g + 1], 0.0f);
-                    const float h2 = fmaxf(c[4 * g + 2], 0.0f), h3 = fmaxf(c[4 * g + 3], 0.0f);
-#pragma unroll
-                    for (int a = 0; a < A; ++a) {
-                        const float4 w = *reinterpret_cast<const float4 *>(w1 + a * W + 8 * g);
-                        acc_p[a] += w.x * h0;
-                        acc_p[a] += w.y * h1;
-                        acc_p[a] += w.z * h2;
-                        acc_p[a] += w.w * h3;
-                    }
-                }
+        int t0 = first, t1 = first + off1;
+        f32x16 c0 = mfma_chain<A, KS>(w0 + t0 * kTile + col, W2, half, xk);
+        f32x16 c1 = mfma_chain<A, KS>(w0 + t1 * kTile + col, W2, half, xk);
+        for (int p = 0; p + 1 < n_pairs; ++p) {
+            const int e0 = t0, e1 = t1;
+            const f32x16 d0 = c0, d1 = c1;
+            t0 += stride0;
+            t1 += stride0;
+            // next pair's matrix work and this pair's epilogue in ONE scheduling region, interleaved below
+            c0 = mfma_chain<A, KS>(w0 + t0 * kTile + col, W2, half, xk);
+            c1 = mfma_chain<A, KS>(w0 + t1 * kTile + col, W2, half, xk);
+            if (HEADS == 1) {
+                epilogue_value(d0, w1v + e0 * kTile + 4 * half, acc_v);
+                epilogue_value(d1, w1v + e1 * kTile + 4 * half, acc_v);
+            } else if (HEADS == 2) {
+                epilogue_policy<A>(d0, w1p + (e0 - T) * kTile + 4 * half, W, acc_p);
+                epilogue_policy<A>(d1, w1p + (e1 - T) * kTile + 4 * half, W, acc_p);
+            } else {
+                epilogue_value(d0, w1v + e0 * kTile + 4 * half, acc_v);
+                epilogue_policy<A>(d1, w1p + (e1 - T) * kTile + 4 * half, W, acc_p);
+            }
+        }
+        {
+            const int e0 = t0, e1 = t1;
+            if (HEADS == 1) {
+                epilogue_value(c0, w1v + e0 * kTile + 4 * half, acc_v);
+                epilogue_value(c1, w1v + e1 * kTile + 4 * half, acc_v);
+            } else if (HEADS == 2) {
+                epilogue_policy<A>(c0, w1p + (e0 - T) * kTile + 4 * half, W, acc_p);
+                epilogue_policy<A>(c1, w1p + (e1 - T) * kTile + 4 * half, W, acc_p);
+            } else {
+                epilogue_value(c0, w1v + e0 * kTile + 4 * half, acc_v);
+                epilogue_policy<A>(c1, w1p + (e1 - T) * kTile + 4 * half, W, acc_p);
             }
         }
         // the two half-waves hold complementary hidden rows of the same 32 samples
-        acc_v += __shfl_xor(acc_v, 32, 64);
+        if (HEADS & 1) acc_v += __shfl_xor(acc_v, 32, 64);
+        if (HEADS & 2) {
 #pragma unroll
-        for (int a = 0; a < A; ++a) acc_p[a] += __shfl_xor(acc_p[a], 32, 64);
+            for (int a = 0; a < A; ++a) acc_p[a] += __shfl_xor(acc_p[a], 32, 64);
+        }
         if (live && half == 0) {
-            if (value) value[sample] = acc_v + bv;
-            if (logits) {
+            if ((HEADS & 1) && value) value[sample] = acc_v + bv;
+            if ((HEADS & 2) && logits) {
 #pragma unroll
                 for (int a = 0; a < A; ++a) logits[sample * A + a] = acc_p[a] + bp[a];
             }
@@ -365,14 +424,22 @@ extern "C" int rnad_mlp_forward(int64_t N, int A, int W, const float *vw0, const
     const int blocks_per_cu = std::max(1, std::min(3, (int)(160 * 1024 / lds_bytes)));
     const int64_t n_tiles = (N + kTile - 1) / kTile;
     const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>((n_tiles + 3) / 4, (int64_t)cus * blocks_per_cu));
+    int heads = (value ? 1 : 0) | (logits ? 2 : 0);
+    if ((W / kTile) % 2) heads = 3;  // odd tile count: the paired single-head kernels do not apply; compute both, store the wanted one
     ProfScope prof(PROF_MLP, stream);
-#define RNAD_MLP_LAUNCH(T_)                                                                                                        \
+#define RNAD_MLP_LAUNCH2(T_, H_)                                                                                                  \
     do {                                                                                                                           \
-        auto kern = k_mlp_forward<kA, T_>;                                                                                         \
+        auto kern = k_mlp_forward<kA, T_, H_>;                                                                                     \
         if (lds_bytes > 64 * 1024)                                                                                                 \
             RNAD_HIP_OK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));      \
         hipLaunchKernelGGL(kern, dim3(grid), dim3(kThreads), lds_bytes, stream, N, W, vw0, vb0, vw1, vb1, pw0, pb0, pw1, pb1,      \
                            (const T_ *)obs, logits, value);                                                                        \
+    } while (0)
+#define RNAD_MLP_LAUNCH(T_)                                   \
+    do {                                                      \
+        if (heads == 1) RNAD_MLP_LAUNCH2(T_, 1);              \
+        else if (heads == 2) RNAD_MLP_LAUNCH2(T_, 2);         \
+        else RNAD_MLP_LAUNCH2(T_, 3);                         \
     } while (0)
     RNAD_DISPATCH_A(A, {
         if (obs_half)
@@ -380,6 +447,7 @@ extern "C" int rnad_mlp_forward(int64_t N, int A, int W, const float *vw0, const
         else
             RNAD_MLP_LAUNCH(float);
     });
+#undef RNAD_MLP_LAUNCH2
 #undef RNAD_MLP_LAUNCH
     RNAD_HIP_OK(hipGetLastError());
     return 0;

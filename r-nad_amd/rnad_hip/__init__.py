@@ -10,7 +10,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.realpath(__file__))
-SO_PATH = os.path.join(_HERE, "..", "csrc", "librnad_hip.so")
+SO_PATH = os.environ.get("RNAD_HIP_SO") or os.path.join(_HERE, "..", "csrc", "librnad_hip.so")  # override: kernel A/B experiments
 
 MAX_ACTIONS = 8
 MAX_TRANSITIONS = 8
