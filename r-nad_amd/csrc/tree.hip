@@ -201,11 +201,16 @@ extern "C" int64_t rnad_tree_info(const rnad_tree_t *tree, int which) {
 // Algorithmic bytes per env step: 4 (idx) + 8A^2 (ev + legal rows) + 2A^2*sizeof(obs) + 4A (mask).
 template <typename OutT>
 struct Pack16;
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef unsigned v4u __attribute__((ext_vector_type(4)));
 template <>
 struct Pack16<float> {
     static constexpr int N = 4;
     static __device__ __forceinline__ void store(float *dst, const float *v) {
-        *reinterpret_cast<float4 *>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+        const v4f x = {v[0], v[1], v[2], v[3]};
+        // streaming output, never re-read by this kernel: non-temporal keeps the node table resident in L2 (measured
+        // 18.8 -> 17.8 us per launch inside the rollout)
+        __builtin_nontemporal_store(x, reinterpret_cast<v4f *>(dst));
     }
     static __device__ __forceinline__ float cvt(float x) { return x; }
 };
@@ -219,7 +224,8 @@ struct Pack16<__half> {
         } p;
 #pragma unroll
         for (int i = 0; i < 8; ++i) p.h[i] = __float2half(v[i]);
-        *reinterpret_cast<uint4 *>(dst) = p.u;
+        const v4u x = {p.u.x, p.u.y, p.u.z, p.u.w};
+        __builtin_nontemporal_store(x, reinterpret_cast<v4u *>(dst));
     }
     static __device__ __forceinline__ __half cvt(float x) { return __float2half(x); }
 };
