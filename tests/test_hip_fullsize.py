@@ -1,0 +1,243 @@
+"""BASELINE.json-sized runs on the GPU, checked through size-independent properties and against the oracle on sub-sampled
+lanes (episodes are independent, so any subset of lanes must reproduce exactly)."""
+import numpy as np
+import pytest
+import torch
+
+from _util import assert_bits_equal, load
+
+pytestmark = pytest.mark.gpu
+
+
+def _arrays(tree):
+    return dict(index=tree.index_tensor.cpu().numpy(), value=tree.value_tensor.cpu().numpy(), chance=tree.chance_tensor.cpu().numpy(),
+                expected_value=tree.expected_value_tensor.cpu().numpy(), legal=tree.legal_tensor.cpu().numpy())
+
+
+def _check_lanes_against_oracle(ep, arrs, lanes, seed, C, half=False):
+    """Given the policy bits the GPU produced and the seeded noise, every recorded step of `lanes` must be what the oracle computes."""
+    from oracle import oracle
+
+    T = ep.t_eff + 1
+    lanes_t = torch.as_tensor(lanes, device=ep.indices.device)
+    idx = ep.indices[:, lanes_t].cpu().numpy().astype(np.int64)
+    act = ep.action_idx[:, lanes_t].cpu().numpy().astype(np.int64)
+    pol = ep.policy[:, lanes_t].cpu().numpy()
+    obs = ep.observations[:, lanes_t].cpu().numpy()
+    rew = ep.rewards[:, lanes_t].cpu().numpy()
+    nxt_last = ep.states.indices[lanes_t].cpu().numpy()
+    A = pol.shape[-1]
+    n = len(lanes)
+    for t in range(T):
+        want_obs, want_mask = oracle.observe(arrs["expected_value"], arrs["legal"], idx[t], np.full(n, t & 1))
+        assert_bits_equal(obs[t], want_obs.astype(np.float16) if half else want_obs, f"observe t={t}")
+        noise = np.stack([oracle.noise(1, A, seed, int(b), t, 0)[0] for b in lanes])
+        np.testing.assert_array_equal(oracle.sample(pol[t], noise), act[t], err_msg=f"sample t={t}")
+        assert ((pol[t] > 0) == (want_mask > 0)).all()
+        if t & 1:
+            noise_c = np.stack([oracle.noise(1, C, seed, int(b), t, 1)[0] for b in lanes])
+            nxt, r = oracle.transition(arrs["index"], arrs["chance"], arrs["value"], idx[t], act[t - 1], act[t], noise_c)
+            np.testing.assert_array_equal(nxt, idx[t + 1] if t + 1 < T else nxt_last)
+            assert_bits_equal(rew[t], r, f"reward t={t}")
+        else:
+            assert (rew[t] == 0).all()
+            if t + 1 < T:
+                np.testing.assert_array_equal(idx[t + 1], idx[t])
+
+
+@pytest.fixture(scope="module")
+def c2():
+    """BASELINE.json configs[1]: depth-6 ternary tree, batch 2^20, MLP width 256."""
+    from environment.episode import Episodes
+    from environment.tree import Tree
+    from nn.net import MLP
+
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    tree = Tree(device=dev, max_actions=3, max_transitions=1, depth_bound=6)
+    tree.generate_native(seed=0)
+    net = MLP(3, 256, device=dev)
+    ep = Episodes(tree, 1 << 20, seed=99)
+    ep.generate(net)
+    return tree, net, ep
+
+
+def test_c2_rollout_properties_and_sampled_lanes(c2):
+    tree, net, ep = c2
+    B = 1 << 20
+    assert tree.index_tensor.shape[0] == 66431 and ep.t_eff + 1 == 12
+    alive = ep.alive.cpu().numpy()
+    assert (alive[:12] == B).all() and alive[12] == 0  # regular tree: every episode lasts exactly 2 * depth steps
+    assert (ep.rewards[:11] == 0).all() and (ep.rewards[11].abs() == 1).all()  # +-1 terminal payoffs on the last column step
+    assert (ep.indices[0] == 1).all() and (ep.states.indices == 0).all()
+    depth_of = lambda idx: idx  # noqa: E731
+    s = ep.policy.sum(-1)
+    assert torch.allclose(s, torch.ones_like(s), atol=1e-5)
+    assert (ep.mask_bits == 7).all()
+    lanes = np.random.default_rng(0).choice(B, size=2048, replace=False)
+    lanes[:4] = (0, 1, B - 1, B // 2)
+    _check_lanes_against_oracle(ep, _arrays(tree), lanes, seed=99, C=1)
+    # rollouts are reproducible and lane-addressed: a 2-way split with lane offsets replays the same episodes
+    from environment.episode import Episodes
+
+    half = B // 2
+    shard = Episodes(tree, half, seed=99, lane_offset=half)
+    shard.generate(net)
+    assert torch.equal(shard.indices, ep.indices[:, half:]) and torch.equal(shard.action_idx, ep.action_idx[:, half:])
+    assert torch.equal(shard.rewards, ep.rewards[:, half:])
+
+
+def test_c2_learner_is_lane_independent_and_matches_oracle_on_a_subset(c2):
+    """rnad_learn_fused at 12.6 M (t, b): any subset of lanes run on its own gives the same bits; the oracle composition
+    (policy head -> process_policy -> v_trace x2 -> losses) agrees on that subset."""
+    import rnad_hip
+    from nn.net import MLP
+    from oracle import oracle
+
+    tree, net, ep = c2
+    dev = ep.indices.device
+    T, B, A = 12, 1 << 20, 3
+    torch.manual_seed(1)
+    nets = [net] + [MLP(3, 256, device=dev) for _ in range(3)]
+    with torch.no_grad():
+        logit, v = nets[0].forward_logits(ep.observations)
+        _, vt = nets[1].forward_logits(ep.observations, want_logits=False)
+        lr, _ = nets[2].forward_logits(ep.observations, want_value=False)
+        lr_, _ = nets[3].forward_logits(ep.observations, want_value=False)
+    norm = ep.valid_counts
+    assert norm.tolist() == [6.0 * B, 6.0 * B]
+    hp = rnad_hip.make_learn_params(alpha=0.3, eta=0.2)
+    full = rnad_hip.learn_fused(ep.indices, ep.mask_bits, ep.action_idx, ep.rewards, ep.policy, logit, v.view(T, B), vt.view(T, B), lr, lr_, norm, hp)
+    lanes = torch.as_tensor(np.random.default_rng(1).choice(B, size=4096, replace=False), device=dev)
+    sub = lambda x: x.view(T, B, -1)[:, lanes].contiguous()  # noqa: E731
+    sub2 = lambda x: x.view(T, B)[:, lanes].contiguous()  # noqa: E731
+    part = rnad_hip.learn_fused(sub2(ep.indices), sub2(ep.mask_bits), sub2(ep.action_idx), sub2(ep.rewards), sub(ep.policy), sub(logit),
+                                sub2(v), sub2(vt), sub(lr), sub(lr_), norm, hp, want_aux=True)
+    assert torch.equal(part[0], full[0][:, lanes]) and torch.equal(part[1], full[1][:, lanes])
+    # oracle composition on the subset, fed with the GPU's own pi bits where the reference's functions are discontinuous
+    n = lambda t: t.cpu().numpy()  # noqa: E731
+    masks = np.ones((T, 4096, A), np.float32)
+    pi = n(part[3])
+    pip = oracle.process_policy(pi, masks, 32, 0.03)
+    _, log_pi = oracle.policy_head(n(sub(logit)), masks)
+    _, log_r = oracle.policy_head(n(sub(lr)), masks)
+    _, log_r_ = oracle.policy_head(n(sub(lr_)), masks)
+    lpol = log_pi - (np.float32(0.3) * log_r + np.float32(1 - 0.3) * log_r_)
+    valid = (n(sub2(ep.indices)) != 0).astype(np.float32)
+    turns = np.broadcast_to((np.arange(T) % 2)[:, None], (T, 4096)).astype(np.int64)
+    a_oh = np.eye(A, dtype=np.float32)[n(sub2(ep.action_idx))]
+    for p in range(2):
+        rew = n(sub2(ep.rewards)) * (1 if p == 0 else -1)
+        vt_p, _, q_p = oracle.vtrace(n(sub2(vt))[..., None], valid, turns, n(sub(ep.policy)), pip, lpol, a_oh, rew, p, 0.2, 1.0, 1.0, 1.0, 1.0)
+        np.testing.assert_allclose(n(part[4][p]), vt_p[..., 0], rtol=1e-4, atol=2e-5)
+        np.testing.assert_allclose(n(part[5][p]), q_p, rtol=1e-4, atol=2e-5)
+
+
+def test_c2_update_step_runs_and_is_finite(c2):
+    import os
+    import tempfile
+
+    from environment.episode import Buffer
+    from learn.rnad import RNaD
+
+    tree, _, _ = c2
+    os.environ["RNAD_SAVE_DIR"] = tempfile.mkdtemp(prefix="rnad_test_")
+    rn = RNaD(tree=tree, device=tree.device, directory_name="full", batch_size=1 << 20, eta=0.2, b1_adam=0.0, lr=1e-3)
+    rn.initialize()
+    before = [p.detach().clone() for p in rn.net.parameters()]
+    log = {}
+    rn.train_step(Buffer(1), alpha=0.5, log=log)
+    assert all(torch.isfinite(p).all() for p in rn.net.parameters())
+    assert any(not torch.equal(a, b) for a, b in zip(before, rn.net.parameters()))
+    assert np.isfinite(log["loss_v"]) and np.isfinite(log["loss_nerd"]) and log["traj_len"] == 12
+    # target net moved by gamma_averaging * (net - target)
+    for pt, pn, p0 in zip(rn.net_target.parameters(), rn.net.parameters(), before):
+        np.testing.assert_allclose(pt.detach().cpu().numpy(), (0.001 * pn + 0.999 * p0).detach().cpu().numpy(), rtol=1e-5, atol=1e-7)
+
+
+@pytest.mark.parametrize("half", (False, True))
+def test_c4_like_tree_five_actions_four_chance_outcomes(half):
+    """BASELINE.json configs[3] shape (5x5 actions, chance branching 4, pruned) at a size the oracle finishes in seconds;
+    half=True is configs[4]'s fp16 observation buffer."""
+    from environment.episode import Buffer, Episodes
+    from environment.tree import Tree
+    from learn.rnad import RNaD
+    from nn.net import MLP
+
+    dev = torch.device("cuda:0")
+    torch.manual_seed(3)
+    tree = Tree(device=dev, max_actions=5, max_transitions=4, depth_bound=4, transition_threshold=0.2)
+    tree.generate_native(seed=11, prune=(1, 2))
+    tree.assert_index_is_tree()
+    S = tree.index_tensor.shape[0]
+    assert S > 2000
+    B, seed = 1 << 15, 5
+    net = MLP(5, 128, device=dev)
+    ep = Episodes(tree, B, seed=seed, obs_half=half)
+    ep.generate(net)
+    T = ep.t_eff + 1
+    assert 2 <= T <= 8 and T % 2 == 0
+    alive = ep.alive.cpu().numpy()
+    assert alive[0] == B and (np.diff(alive) <= 0).all() and alive[T] == 0
+    np.testing.assert_array_equal(alive[:T], (ep.indices != 0).sum(1).cpu().numpy())
+    lanes = np.random.default_rng(2).choice(B, size=1024, replace=False)
+    _check_lanes_against_oracle(ep, _arrays(tree), lanes, seed=seed, C=4, half=half)
+    if not half:
+        import os
+        import tempfile
+
+        os.environ["RNAD_SAVE_DIR"] = tempfile.mkdtemp(prefix="rnad_test_")
+        rn = RNaD(tree=tree, device=dev, directory_name="c4", batch_size=B, eta=0.2, b1_adam=0.0, lr=1e-3,
+                  net_params={"type": "MLP", "max_actions": 5, "width": 128})
+        rn.initialize()
+        rn.train_step(Buffer(1), alpha=1.0, log={})  # A = 5: the MLP backward falls back to PyTorch-ROCm autograd
+        assert all(torch.isfinite(p).all() for p in rn.net.parameters())
+
+
+def test_short_run_follows_the_reference_schedule(tmp_path, monkeypatch):
+    """RNaD.run() with the fixture's settings (2 regularisation updates x 3 steps on the c1 tree): same (m, n, alpha)
+    sequence, same net_reg / net_reg_ rotation and EMA bookkeeping as the reference's recorded run."""
+    from _gpu import DEV, golden_tree
+    from learn.rnad import RNaD
+
+    g = load("run_c1")
+    tree, _ = golden_tree("c1")
+    monkeypatch.setenv("RNAD_SAVE_DIR", str(tmp_path))
+    torch.manual_seed(21)
+    rn = RNaD(tree=tree, device=DEV, directory_name="golden", batch_size=int(g["batch"]), eta=0.2, bounds=[2], delta_m=[3], lr=1e-2,
+              gamma_averaging=0.1, b1_adam=0.0, net_params={"type": "MLP", "max_actions": 2, "width": 16})
+    seen = []
+    step = rn.train_step
+
+    def spy(buffer, alpha, log=None):
+        nets = {k: [p.detach().clone() for p in getattr(rn, k).parameters()] for k in ("net", "net_target", "net_reg", "net_reg_")}
+        step(buffer, alpha, log=log)
+        seen.append(dict(m=rn.m, n=rn.n, alpha=alpha, before=nets,
+                         after={k: [p.detach().clone() for p in getattr(rn, k).parameters()] for k in nets}))
+
+    rn.train_step = spy
+    rn.run(checkpoint_mod=1, expl_mod=1, log_mod=10**9)
+    assert len(seen) == int(g["n_steps"]) == 6
+    for i, st in enumerate(seen):
+        assert (st["m"], st["n"]) == tuple(g[f"s{i}_mn"]) and st["alpha"] == pytest.approx(float(g[f"s{i}_alpha"]))
+        for pt, pn, p0 in zip(st["after"]["net_target"], st["after"]["net"], st["before"]["net_target"]):  # rnad.py:516-523
+            assert torch.allclose(pt, 0.1 * pn + 0.9 * p0, rtol=1e-5, atol=1e-7)
+        for a, b in zip(st["before"]["net_reg"], st["after"]["net_reg"]):  # regularisation nets only move between updates
+            assert torch.equal(a, b)
+    # rotation at the end of m = 0 (rnad.py:528-531): net_reg_ <- net_reg (still the initial net), net_reg <- net_target
+    for a, b in zip(seen[3]["before"]["net_reg_"], seen[0]["before"]["net_reg"]):
+        assert torch.equal(a, b)
+    for a, b in zip(seen[3]["before"]["net_reg"], seen[2]["after"]["net_target"]):
+        assert torch.equal(a, b)
+    assert rn.m == 2 and rn.n == 0 and rn.total_steps == 6
+    assert len(rn.nashconv_history) == 1 and 0 <= rn.nashconv_history[0][2] <= 2.0  # NashConv logged at m = 1 (rnad.py:490)
+    # checkpoints in the reference's layout: saved_runs/<dir>/params and <m>/<n>
+    assert (tmp_path / "saved_runs" / "golden" / "params").exists()
+    assert sorted(p.name for p in (tmp_path / "saved_runs" / "golden" / "1").iterdir()) == ["0", "1", "2"]
+    ck = torch.load(tmp_path / "saved_runs" / "golden" / "1" / "2", weights_only=False)
+    assert sorted(ck) == ["net", "net_params", "net_reg", "net_reg_", "net_target", "optimizer", "total_steps"]
+    # resuming picks up where the run stopped (rnad.py:243-272)
+    rn2 = RNaD(tree=tree, device=DEV, directory_name="golden", batch_size=int(g["batch"]), bounds=[3], delta_m=[3], b1_adam=0.0,
+               net_params={"type": "MLP", "max_actions": 2, "width": 16})
+    rn2.initialize()
+    assert (rn2.m, rn2.n) == (1, 2) and rn2.eta == 0.2 and rn2.lr == 1e-2
