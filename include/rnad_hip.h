@@ -76,27 +76,30 @@ int rnad_policy_head(int64_t N, int A, const float *logits, const uint8_t *mask_
                      float *policy, float *log_policy, void *stream);
 
 /* ------------------------------------------------------------------------------------------------
- * Fused MLP forward  --  nn/net.py:40-43 (and :70-73): value = value_fc1(relu(value_fc0 x)),
+ * Fused MLP  --  nn/net.py:40-43 (and :70-73): value = value_fc1(relu(value_fc0 x)),
  * logits = policy_fc1(relu(policy_fc0 x)), x = obs flattened to 2*A*A floats (fp32, or fp16 when
- * obs_half != 0).  Weights are the torch Linear tensors as they are ([out, in] row-major, fp32):
- * vw0 [W,2A^2], vb0 [W], vw1 [1,W], vb1 [1], pw0 [W,2A^2], pb0 [W], pw1 [A,W], pb1 [A].
- * The hidden layer stays in registers (fp32 MFMA, exact fp32 products and sums; the summation order
- * differs from a BLAS GEMM, results agree to ~1e-6 relative).  W must be a multiple of 32.
- * `logits` or `value` may be NULL: that head is then not computed at all.
+ * obs_half != 0).  The hidden layer stays in registers (fp32 MFMA: exact fp32 products and sums;
+ * the summation order differs from a BLAS GEMM, results agree to ~1e-6 relative).
+ *
+ * rnad_mlp_pack lays the eight torch Linear tensors ([out, in] row-major fp32: vw0 [W,2A^2], vb0 [W],
+ * vw1 [1,W], vb1 [1], pw0 [W,2A^2], pb0 [W], pw1 [A,W], pb1 [A]) out as the `packed` image of
+ * rnad_mlp_packed_size(A, W) floats that the kernels copy into LDS with one coalesced pass; pack once
+ * per weight update, reuse for every forward/backward with those weights.  W: multiple of 32.
+ *
+ * rnad_mlp_forward: logits [N,A] and/or value [N]; a NULL output means that head is not computed.
+ * rnad_mlp_backward: gradients of the eight tensors given dL/dlogits [N,A] and dL/dvalue [N] (what
+ * loss.backward() computes for the learner net, learn/rnad.py:425), hidden layer recomputed on chip,
+ * weight gradients contracted over samples on the matrix cores.  g_* are written (not accumulated),
+ * torch Linear layouts.  workspace: rnad_mlp_backward_workspace(N, A, W) bytes (per-block partials,
+ * summed in a fixed order).  Supported: 2*A*A + 1 <= 32 (A <= 3), W a multiple of 32 up to 256.
  * ---------------------------------------------------------------------------------------------- */
-int rnad_mlp_forward(int64_t N, int A, int W, const float *vw0, const float *vb0, const float *vw1, const float *vb1,
-                     const float *pw0, const float *pb0, const float *pw1, const float *pb1, const void *obs,
-                     int obs_half, float *logits, float *value, void *stream);
-
-/* Backward of rnad_mlp_forward: gradients of the eight Linear tensors given dL/dlogits [N,A] and
- * dL/dvalue [N] (what loss.backward() computes for the learner net, learn/rnad.py:425), with the
- * hidden layer recomputed on chip and the weight gradients contracted over samples on the matrix
- * cores.  g_* are written (not accumulated), torch Linear layouts.  workspace: device buffer of
- * rnad_mlp_backward_workspace(N, A, W) bytes (per-block partials, summed in a fixed order).
- * Supported: 2*A*A + 1 <= 32 (A <= 3), W a multiple of 32 up to 256 (one wave per 32 hidden units). */
+int64_t rnad_mlp_packed_size(int A, int W);
+int rnad_mlp_pack(int A, int W, const float *vw0, const float *vb0, const float *vw1, const float *vb1, const float *pw0,
+                  const float *pb0, const float *pw1, const float *pb1, float *packed, void *stream);
+int rnad_mlp_forward(int64_t N, int A, int W, const float *packed, const void *obs, int obs_half, float *logits,
+                     float *value, void *stream);
 int64_t rnad_mlp_backward_workspace(int64_t N, int A, int W);
-int rnad_mlp_backward(int64_t N, int A, int W, const float *vw0, const float *vb0, const float *vw1, const float *pw0,
-                      const float *pb0, const float *pw1, const void *obs, int obs_half, const float *dlogits,
+int rnad_mlp_backward(int64_t N, int A, int W, const float *packed, const void *obs, int obs_half, const float *dlogits,
                       const float *dvalue, float *g_vw0, float *g_vb0, float *g_vw1, float *g_vb1, float *g_pw0,
                       float *g_pb0, float *g_pw1, float *g_pb1, float *workspace, void *stream);
 

@@ -31,6 +31,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int kThreads = 256;
 constexpr int kTile = 32;  // samples per wave-tile and hidden units per MFMA tile
+constexpr int kB1Pad = 12;  // floats reserved for the 1 + A output biases at the end of the packed image (multiple of 4)
 
 template <typename T>
 __device__ __forceinline__ float load_obs(const T *p);
@@ -39,7 +40,7 @@ __device__ __forceinline__ float load_obs<float>(const float *p) { return *p; }
 template <>
 __device__ __forceinline__ float load_obs<__half>(const __half *p) { return __half2float(*p); }
 
-// LDS image (floats):  w0[(K + 2)][2W]  |  w1v[W]  |  w1p[A][W]
+// LDS image (floats) = the packed weight image:  w0[(K + 2)][2W]  |  w1v[W]  |  w1p[A][W]  |  b1[1 + A] (padded to 12)
 //
 // HEADS: 1 = value only, 2 = policy only, 3 = both.  A wave keeps TWO hidden tiles in flight (two independent
 // accumulator chains) and is software-pipelined by hand: the MFMA chains of the next tile pair are issued before the
@@ -92,10 +93,7 @@ __device__ __forceinline__ void epilogue_policy(const f32x16 &c, const float *__
 }
 
 template <int A, typename ObsT, int HEADS>
-__global__ __launch_bounds__(kThreads) void k_mlp_forward(int64_t N, int W, const float *__restrict__ vw0, const float *__restrict__ vb0,
-                                                          const float *__restrict__ vw1, const float *__restrict__ vb1,
-                                                          const float *__restrict__ pw0, const float *__restrict__ pb0,
-                                                          const float *__restrict__ pw1, const float *__restrict__ pb1,
+__global__ __launch_bounds__(kThreads) void k_mlp_forward(int64_t N, int W, const float *__restrict__ packed,
                                                           const ObsT *__restrict__ obs, float *__restrict__ logits,
                                                           float *__restrict__ value) {
     constexpr int K = 2 * A * A, KS = K / 2 + 1;  // k-steps incl. the bias step
@@ -104,29 +102,22 @@ __global__ __launch_bounds__(kThreads) void k_mlp_forward(int64_t N, int W, cons
     float *w0 = lds;                    // [(K + 2)][2W]
     float *w1v = lds + (K + 2) * W2;    // [W]
     float *w1p = w1v + W;               // [A][W]
-    for (int i = threadIdx.x; i < W2 * (K + 2); i += kThreads) {
-        const int k = i / W2, h = i % W2;
-        float x;
-        if (k < K)
-            x = h < W ? vw0[h * K + k] : pw0[(h - W) * K + k];
-        else if (k == K)
-            x = h < W ? vb0[h] : pb0[h - W];
-        else
-            x = 0.0f;
-        w0[i] = x;
+    {   // weights: one coalesced 16-byte copy of the image rnad_mlp_pack laid out (w0 | w1v | w1p | b1)
+        const int n4 = ((K + 2) * W2 + (1 + A) * W + kB1Pad) / 4;
+        const float4 *src = reinterpret_cast<const float4 *>(packed);
+        float4 *dst = reinterpret_cast<float4 *>(lds);
+        for (int i = threadIdx.x; i < n4; i += kThreads) dst[i] = src[i];
     }
-    for (int i = threadIdx.x; i < W; i += kThreads) w1v[i] = vw1[i];
-    for (int i = threadIdx.x; i < A * W; i += kThreads) w1p[i] = pw1[i];
     __syncthreads();
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int col = lane & 31, half = lane >> 5;
     const int T = W / kTile;  // hidden tiles per head
-    const float bv = HEADS & 1 ? vb1[0] : 0.0f;
-    (void)wave;
+    const float *b1 = w1p + A * W;  // [1 + A]: value_fc1.bias, policy_fc1.bias
+    const float bv = b1[0];
     float bp[A];
 #pragma unroll
-    for (int a = 0; a < A; ++a) bp[a] = HEADS & 2 ? pb1[a] : 0.0f;
+    for (int a = 0; a < A; ++a) bp[a] = b1[1 + a];
     // tile pair p of this launch: both heads -> (value tile p, policy tile p); one head -> its tiles (2p, 2p + 1)
     const int n_pairs = HEADS == 3 ? T : T / 2;  // single-head launches need an even tile count (the launcher sees to it)
     const int first = HEADS == 2 ? T : 0;
@@ -210,9 +201,7 @@ __global__ __launch_bounds__(kThreads) void k_mlp_forward(int64_t N, int W, cons
 // 32x32 dW0aug accumulators (32 registers) and its dW1 partials (16 + 16 A registers) stay resident for the whole
 // launch.  Blocks write their partial gradients to `partial`; k_mlp_reduce sums them in a fixed order (deterministic).
 template <int A, typename ObsT>
-__global__ __launch_bounds__(512) void k_mlp_backward(int64_t N, int W, const float *__restrict__ vw0, const float *__restrict__ vb0,
-                                                      const float *__restrict__ vw1, const float *__restrict__ pw0,
-                                                      const float *__restrict__ pb0, const float *__restrict__ pw1,
+__global__ __launch_bounds__(512) void k_mlp_backward(int64_t N, int W, const float *__restrict__ packed,
                                                       const ObsT *__restrict__ obs, const float *__restrict__ dlogit,
                                                       const float *__restrict__ dv, float *__restrict__ partial, int P) {
     constexpr int K = 2 * A * A, KS = K / 2 + 1;
@@ -222,20 +211,13 @@ __global__ __launch_bounds__(512) void k_mlp_backward(int64_t N, int W, const fl
     float *w0 = lds;
     float *w1v = lds + (K + 2) * W2;
     float *w1p = w1v + W;
-    float *scratch = w1p + A * W;  // [waves][32][33]
-    for (int i = threadIdx.x; i < W2 * (K + 2); i += nthreads) {
-        const int k = i / W2, h = i % W2;
-        float x;
-        if (k < K)
-            x = h < W ? vw0[h * K + k] : pw0[(h - W) * K + k];
-        else if (k == K)
-            x = h < W ? vb0[h] : pb0[h - W];
-        else
-            x = 0.0f;
-        w0[i] = x;
+    float *scratch = w1p + A * W + kB1Pad;  // after b1: [waves][32][33]
+    {
+        const int n4 = ((K + 2) * W2 + (1 + A) * W + kB1Pad) / 4;
+        const float4 *src = reinterpret_cast<const float4 *>(packed);
+        float4 *dst = reinterpret_cast<float4 *>(lds);
+        for (int i = threadIdx.x; i < n4; i += nthreads) dst[i] = src[i];
     }
-    for (int i = threadIdx.x; i < W; i += nthreads) w1v[i] = vw1[i];
-    for (int i = threadIdx.x; i < A * W; i += nthreads) w1p[i] = pw1[i];
     __syncthreads();
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -405,18 +387,61 @@ __global__ __launch_bounds__(kThreads) void k_mlp_reduce(int nblocks, int W, int
     }
 }
 
+// Lay the eight torch Linear tensors out as the LDS image the kernels copy in one go:
+//   w0[(K + 2)][2W] (k-major; row K = first-layer biases, row K + 1 = 0)  |  w1v[W]  |  w1p[A][W]  |  b1[1 + A], padded to 12
+__global__ __launch_bounds__(kThreads) void k_mlp_pack(int A, int W, const float *__restrict__ vw0, const float *__restrict__ vb0,
+                                                       const float *__restrict__ vw1, const float *__restrict__ vb1,
+                                                       const float *__restrict__ pw0, const float *__restrict__ pb0,
+                                                       const float *__restrict__ pw1, const float *__restrict__ pb1,
+                                                       float *__restrict__ packed, int total) {
+    const int K = 2 * A * A, W2 = 2 * W;
+    const int i = blockIdx.x * kThreads + threadIdx.x;
+    if (i >= total) return;
+    const int n0 = (K + 2) * W2;
+    float x = 0.0f;
+    if (i < n0) {
+        const int k = i / W2, h = i % W2;
+        if (k < K) x = h < W ? vw0[h * K + k] : pw0[(h - W) * K + k];
+        else if (k == K) x = h < W ? vb0[h] : pb0[h - W];
+    } else if (i < n0 + W) {
+        x = vw1[i - n0];
+    } else if (i < n0 + W + A * W) {
+        x = pw1[i - n0 - W];
+    } else if (i == n0 + W + A * W) {
+        x = vb1[0];
+    } else if (i < n0 + W + A * W + 1 + A) {
+        x = pb1[i - n0 - W - A * W - 1];
+    }
+    packed[i] = x;
+}
+
 }  // namespace
 
-extern "C" int rnad_mlp_forward(int64_t N, int A, int W, const float *vw0, const float *vb0, const float *vw1, const float *vb1,
-                                const float *pw0, const float *pb0, const float *pw1, const float *pb1, const void *obs, int obs_half,
-                                float *logits, float *value, void *stream_) {
-    RNAD_REQUIRE(vw0 && vb0 && vw1 && vb1 && pw0 && pb0 && pw1 && pb1 && obs && (logits || value), "rnad_mlp_forward: null argument");
+static inline int mlp_packed_floats(int A, int W) { return (2 * A * A + 2) * 2 * W + (1 + A) * W + kB1Pad; }
+
+extern "C" int64_t rnad_mlp_packed_size(int A, int W) { return mlp_packed_floats(A, W); }
+
+extern "C" int rnad_mlp_pack(int A, int W, const float *vw0, const float *vb0, const float *vw1, const float *vb1, const float *pw0,
+                             const float *pb0, const float *pw1, const float *pb1, float *packed, void *stream) {
+    RNAD_REQUIRE(vw0 && vb0 && vw1 && vb1 && pw0 && pb0 && pw1 && pb1 && packed, "rnad_mlp_pack: null argument");
+    RNAD_REQUIRE(A >= 1 && A <= RNAD_MAX_ACTIONS && W >= kTile && W % kTile == 0, "rnad_mlp_pack: bad shape (A=%d, width=%d)", A, W);
+    const int total = mlp_packed_floats(A, W);
+    hipLaunchKernelGGL(k_mlp_pack, dim3((total + kThreads - 1) / kThreads), dim3(kThreads), 0, (hipStream_t)stream, A, W, vw0, vb0, vw1,
+                       vb1, pw0, pb0, pw1, pb1, packed, total);
+    RNAD_HIP_OK(hipGetLastError());
+    return 0;
+}
+
+extern "C" int rnad_mlp_forward(int64_t N, int A, int W, const float *packed, const void *obs, int obs_half, float *logits, float *value,
+                                void *stream_) {
+    RNAD_REQUIRE(packed && obs && (logits || value), "rnad_mlp_forward: null argument");
     RNAD_REQUIRE(W >= kTile && W % kTile == 0, "rnad_mlp_forward: width %d must be a positive multiple of %d", W, kTile);
     RNAD_REQUIRE(N >= 0, "rnad_mlp_forward: negative batch");
     if (N == 0) return 0;
     hipStream_t stream = (hipStream_t)stream_;
     const int K = 2 * A * A;
-    const size_t lds_bytes = ((size_t)(K + 2) * 2 * W + (size_t)(1 + A) * W) * sizeof(float);
+    (void)K;
+    const size_t lds_bytes = (size_t)mlp_packed_floats(A, W) * sizeof(float);
     RNAD_REQUIRE(lds_bytes <= 160 * 1024, "rnad_mlp_forward: weights (%zu B) do not fit the 160 KiB LDS (A=%d, width=%d)", lds_bytes, A, W);
     int dev = 0, cus = 256;
     RNAD_HIP_OK(hipGetDevice(&dev));
@@ -432,8 +457,8 @@ extern "C" int rnad_mlp_forward(int64_t N, int A, int W, const float *vw0, const
         auto kern = k_mlp_forward<kA, T_, H_>;                                                                                     \
         if (lds_bytes > 64 * 1024)                                                                                                 \
             RNAD_HIP_OK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));      \
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(kThreads), lds_bytes, stream, N, W, vw0, vb0, vw1, vb1, pw0, pb0, pw1, pb1,      \
-                           (const T_ *)obs, logits, value);                                                                        \
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(kThreads), lds_bytes, stream, N, W, packed, (const T_ *)obs, logits, value);            \
+                                                                        \
     } while (0)
 #define RNAD_MLP_LAUNCH(T_)                                   \
     do {                                                      \
@@ -455,7 +480,8 @@ extern "C" int rnad_mlp_forward(int64_t N, int A, int W, const float *vw0, const
 
 static int mlp_backward_grid(int64_t N, int W, int A, size_t *lds_bytes, int *P) {
     const int K = 2 * A * A;
-    *lds_bytes = ((size_t)(K + 2) * 2 * W + (size_t)(1 + A) * W + (size_t)(W / kTile) * kTile * 33) * sizeof(float);
+    (void)K;
+    *lds_bytes = ((size_t)mlp_packed_floats(A, W) + (size_t)(W / kTile) * kTile * 33) * sizeof(float);
     *P = (2 * W * kTile + W + A * W + 1 + A + 3) & ~3;
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
@@ -471,12 +497,10 @@ extern "C" int64_t rnad_mlp_backward_workspace(int64_t N, int A, int W) {
     return (int64_t)grid * P * (int64_t)sizeof(float);
 }
 
-extern "C" int rnad_mlp_backward(int64_t N, int A, int W, const float *vw0, const float *vb0, const float *vw1, const float *pw0,
-                                 const float *pb0, const float *pw1, const void *obs, int obs_half, const float *dlogits,
+extern "C" int rnad_mlp_backward(int64_t N, int A, int W, const float *packed, const void *obs, int obs_half, const float *dlogits,
                                  const float *dvalue, float *g_vw0, float *g_vb0, float *g_vw1, float *g_vb1, float *g_pw0,
                                  float *g_pb0, float *g_pw1, float *g_pb1, float *workspace, void *stream_) {
-    RNAD_REQUIRE(vw0 && vb0 && vw1 && pw0 && pb0 && pw1 && obs && dlogits && dvalue && g_vw0 && g_vb0 && g_vw1 && g_vb1 && g_pw0 &&
-                     g_pb0 && g_pw1 && g_pb1 && workspace,
+    RNAD_REQUIRE(packed && obs && dlogits && dvalue && g_vw0 && g_vb0 && g_vw1 && g_vb1 && g_pw0 && g_pb0 && g_pw1 && g_pb1 && workspace,
                  "rnad_mlp_backward: null argument");
     RNAD_REQUIRE(W >= kTile && W % kTile == 0 && W <= 256, "rnad_mlp_backward: width %d must be a multiple of %d, at most 256", W, kTile);
     RNAD_REQUIRE(2 * A * A + 1 <= kTile, "rnad_mlp_backward: max_actions %d needs more than %d input features", A, kTile);
@@ -494,8 +518,8 @@ extern "C" int rnad_mlp_backward(int64_t N, int A, int W, const float *vw0, cons
         auto kern = k_mlp_backward<kA, T_>;                                                                                        \
         if (lds_bytes > 64 * 1024)                                                                                                 \
             RNAD_HIP_OK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));      \
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), lds_bytes, stream, N, W, vw0, vb0, vw1, pw0, pb0, pw1, (const T_ *)obs, \
-                           dlogits, dvalue, workspace, P);                                                                         \
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), lds_bytes, stream, N, W, packed, (const T_ *)obs, dlogits, dvalue,           \
+                           workspace, P);                                                                         \
     } while (0)
         switch (A) {
             case 1: { constexpr int kA = 1; if (obs_half) RNAD_MLPB_LAUNCH(__half); else RNAD_MLPB_LAUNCH(float); } break;

@@ -149,13 +149,18 @@ class Episodes:
         return torch.stack([a[0::2].sum(), a[1::2].sum()])
 
     # ---------------------------------------------------------------- episode.py:175-230
-    def generate(self, net: torch.nn.Module, noise_action=None, noise_chance=None, max_steps=None):
+    def generate(self, net: torch.nn.Module, noise_action=None, noise_chance=None, max_steps=None, trim=True):
         """Play the batch to the end with `net` as the actor.
 
         Nets exposing `forward_logits(obs) -> (logits [B,A], value [B,1])` (the MLP here) take the fast path: policy head,
         sampling, transition and the next observation are HIP kernels.  Any other module honouring the reference
         contract `forward(obs) -> (logits, policy, value, actions)` (nn/net.py:37-51) is driven through that instead and
         samples for itself.  noise_action [T,B,A] / noise_chance [T,B,C]: explicit Exp(1) noise (tests).
+
+        trim=True reads the alive counters back (the rollout's only host sync) and cuts the trajectory to the reference's
+        length T (episode.py:194 stops once every lane is absorbed).  trim=False keeps all T_cap = 2 * depth steps and
+        never synchronises: trailing steps where every lane sits in state 0 are invalid (`indices == 0`) and contribute
+        nothing to V-trace or the losses, so learning is unchanged; RNaD uses this.
         """
         tree, B = self.tree, self.batch_size
         handle = tree.handle()
@@ -163,6 +168,7 @@ class Episodes:
         dev = self.states.indices.device
         traj = rnad_hip.Trajectory(handle, B, T_cap, dev, half=self.obs_half)
         fast = hasattr(net, "forward_logits")
+        packed = net.pack() if fast and hasattr(net, "pack") else None  # weights are fixed for the whole rollout
         net.eval()
         time_start = time.perf_counter()
         rnad_hip.rollout_begin(handle, traj)
@@ -172,7 +178,7 @@ class Episodes:
                 na = None if noise_action is None else noise_action[t]
                 nc = None if noise_chance is None else noise_chance[t]
                 if fast:
-                    logits, value = net.forward_logits(obs_t)
+                    logits, value = net.forward_logits(obs_t, packed=packed) if packed is not None else net.forward_logits(obs_t)
                     rnad_hip.rollout_step(handle, traj, t, value.reshape(-1), logits=logits, noise_action=na, noise_chance=nc,
                                           seed=self.seed, lane0=self.lane_offset)
                 else:
@@ -181,8 +187,11 @@ class Episodes:
                                           actions=actions.to(torch.int32).contiguous().view(-1), noise_chance=nc,
                                           seed=self.seed, lane0=self.lane_offset)
         rnad_hip.rollout_end(handle, traj)
-        alive = traj.alive.cpu()  # the only host sync of the rollout
-        T = int((alive[:T_cap] > 0).sum().item())
+        if trim:
+            alive = traj.alive.cpu()  # the only host sync of the rollout
+            T = int((alive[:T_cap] > 0).sum().item())
+        else:
+            T = T_cap
         time_end = time.perf_counter()
         self.generation_time = time_end - time_start
         self._traj = traj
@@ -197,7 +206,7 @@ class Episodes:
         self.alive = traj.alive[: T + 1]
         self._lazy = {}
         self.states.indices = traj.indices[T]
-        self.states.terminal = True
+        self.states.terminal = True  # by construction after 2 * depth steps
         self.finished = True
         net.train()
 
@@ -216,11 +225,17 @@ class Episodes:
         result.finished = True
         return result
 
-    def sample(self, batch_size):
-        """A uniformly random subset of `batch_size` lanes in random order (the reference permutes with python's `random`;
-        here python's `random` seeds a device permutation)."""
+    def sample(self, batch_size, shuffle=False):
+        """A uniformly random subset of `batch_size` lanes (reference: `random.sample` + index_select on every tensor).
+
+        Asking for the whole batch -- what RNaD does every step with the default one-batch buffer (rnad.py:507) -- is a
+        pure permutation of lanes in the reference, and no loss term depends on the lane order, so it returns `self`
+        without copying 1.7 GB per step; pass shuffle=True to get the permuted copy anyway.  Proper subsets are drawn with
+        a device permutation seeded from python's `random`."""
         assert self.finished
         batch_size = min(batch_size, self.batch_size)
+        if batch_size == self.batch_size and not shuffle:
+            return self
         dev = self.indices.device
         g = torch.Generator(device=dev)
         g.manual_seed(random.getrandbits(62))
@@ -241,6 +256,8 @@ class Episodes:
     @classmethod
     def collate(cls, lst: list["Episodes"]):
         """Pad each member along time with zeros (index 0 == invalid) and concatenate along the batch."""
+        if len(lst) == 1:
+            return lst[0]  # nothing to pad or concatenate
         t_eff = max(e.t_eff for e in lst)
         tree = lst[0].tree
         batch_size = sum(e.batch_size for e in lst)

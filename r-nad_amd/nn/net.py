@@ -32,18 +32,30 @@ class MLP(nn.Module):
         return [self.value_fc0.weight, self.value_fc0.bias, self.value_fc1.weight, self.value_fc1.bias,
                 self.policy_fc0.weight, self.policy_fc0.bias, self.policy_fc1.weight, self.policy_fc1.bias]
 
-    def forward_logits(self, input_batch, want_logits=True, want_value=True):
+    def pack(self):
+        """The weight image the fused kernels read (rnad_mlp_pack).  Pack once per net and weight version and hand it to
+        every `forward_logits(..., packed=...)` of a rollout; it is NOT cached here (in-place optimizers such as fused
+        Adam do not bump tensor versions, so a cache could go stale silently)."""
+        if not self._fusable():
+            return None
+        return rnad_hip.mlp_pack(self._weights(), self.max_actions)
+
+    def _fusable(self):
+        w = self.value_fc0.weight
+        return w.is_cuda and w.dtype == torch.float32 and self.width % 32 == 0
+
+    def forward_logits(self, input_batch, want_logits=True, want_value=True, packed=None):
         """obs [N, 2, A, A] (fp32 or fp16) -> logits [N, A], value [N, 1]   (net.py:40-43).
 
         ONE fused HIP kernel that keeps the hidden layer in registers (rnad_mlp_forward); under autograd it is an
         autograd node whose backward is rnad_mlp_backward (hidden layer recomputed on chip).  Shapes the kernels do not
         cover (A > 3 for the backward, width not a multiple of 32, non-fp32 weights) use four PyTorch-ROCm Linear calls."""
         A = self.max_actions
-        if input_batch.is_cuda and self.value_fc0.weight.dtype == torch.float32 and self.width % 32 == 0:
+        if input_batch.is_cuda and self._fusable():
             if not torch.is_grad_enabled():
-                return rnad_hip.mlp_forward(self._weights(), input_batch.contiguous(), A, want_logits, want_value)
+                return rnad_hip.mlp_forward(packed if packed is not None else self.pack(), self.width, input_batch.contiguous(), A, want_logits, want_value)
             if rnad_hip.mlp_backward_supported(A, self.width) and not input_batch.requires_grad:
-                return rnad_hip.FusedMLP.apply(input_batch.contiguous(), A, *self._weights())
+                return rnad_hip.FusedMLP.apply(input_batch.contiguous(), A, packed if packed is not None else self.pack(), *self._weights())
         x = input_batch.reshape(-1, 2 * self.max_actions**2)
         if x.dtype != self.value_fc0.weight.dtype:
             x = x.to(self.value_fc0.weight.dtype)

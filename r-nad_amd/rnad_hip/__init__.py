@@ -59,6 +59,7 @@ def lib():
         _lib.rnad_tree_generate.restype = C.c_int64
         _lib.rnad_tree_destroy.restype = None
         _lib.rnad_mlp_backward_workspace.restype = C.c_int64
+        _lib.rnad_mlp_packed_size.restype = C.c_int64
     return _lib
 
 
@@ -182,17 +183,23 @@ MLP_KEYS = ("value_fc0.weight", "value_fc0.bias", "value_fc1.weight", "value_fc1
             "policy_fc0.weight", "policy_fc0.bias", "policy_fc1.weight", "policy_fc1.bias")
 
 
-def mlp_forward(weights, obs, A, want_logits=True, want_value=True):
-    """weights: the 8 Linear tensors in MLP_KEYS order (fp32, device); obs [N, 2, A, A] fp32/fp16 -> logits [N, A], value [N, 1].
+def mlp_pack(weights, A):
+    """The eight Linear tensors (MLP_KEYS order, fp32, device) -> the packed LDS image the MLP kernels read."""
+    W = weights[0].shape[0]
+    packed = torch.empty((lib().rnad_mlp_packed_size(A, W),), dtype=F32, device=weights[0].device)
+    _check(lib().rnad_mlp_pack(A, W, *[_dp(w.detach(), F32, "weight") for w in weights], _dp(packed, F32, "packed"), _stream()))
+    return packed
+
+
+def mlp_forward(packed, W, obs, A, want_logits=True, want_value=True):
+    """packed: mlp_pack(weights, A); obs [N, 2, A, A] fp32/fp16 -> logits [N, A], value [N, 1].
     A head that is not wanted is not computed (returns None for it)."""
     N = obs.numel() // (2 * A * A)
-    W = weights[0].shape[0]
     half = obs.dtype == F16
     logits = torch.empty((N, A), dtype=F32, device=obs.device) if want_logits else None
     value = torch.empty((N, 1), dtype=F32, device=obs.device) if want_value else None
-    _check(lib().rnad_mlp_forward(C.c_int64(N), A, W, *[_dp(w.detach(), F32, "weight") for w in weights],
-                                  _dp(obs, F16 if half else F32, "obs"), int(half), _dp(logits, F32, "logits", True),
-                                  _dp(value, F32, "value", True), _stream()))
+    _check(lib().rnad_mlp_forward(C.c_int64(N), A, W, _dp(packed, F32, "packed"), _dp(obs, F16 if half else F32, "obs"), int(half),
+                                  _dp(logits, F32, "logits", True), _dp(value, F32, "value", True), _stream()))
     return logits, value
 
 
@@ -200,34 +207,34 @@ def mlp_backward_supported(A, W):
     return 2 * A * A + 1 <= 32 and W % 32 == 0 and W <= 256
 
 
-def mlp_backward(weights, obs, A, dlogits, dvalue):
+def mlp_backward(packed, weights, obs, A, dlogits, dvalue):
     """Gradients of the 8 Linear tensors (MLP_KEYS order) for dL/dlogits [N, A], dL/dvalue [N(,1)]."""
     N = obs.numel() // (2 * A * A)
     W = weights[0].shape[0]
     half = obs.dtype == F16
     grads = [torch.empty_like(w) for w in weights]
     ws = torch.empty((lib().rnad_mlp_backward_workspace(C.c_int64(N), A, W) // 4,), dtype=F32, device=obs.device)
-    w = [_dp(x.detach(), F32, "weight") for x in weights]
-    _check(lib().rnad_mlp_backward(C.c_int64(N), A, W, w[0], w[1], w[2], w[4], w[5], w[6], _dp(obs, F16 if half else F32, "obs"), int(half),
+    _check(lib().rnad_mlp_backward(C.c_int64(N), A, W, _dp(packed, F32, "packed"), _dp(obs, F16 if half else F32, "obs"), int(half),
                                    _dp(dlogits, F32, "dlogits"), _dp(dvalue, F32, "dvalue"), *[_dp(g, F32, "grad") for g in grads],
                                    _dp(ws, F32, "workspace"), _stream()))
     return grads
 
 
 class FusedMLP(torch.autograd.Function):
-    """logits, value = FusedMLP.apply(obs, A, *weights): rnad_mlp_forward / rnad_mlp_backward as one autograd node."""
+    """logits, value = FusedMLP.apply(obs, A, packed, *weights): rnad_mlp_forward / rnad_mlp_backward as one autograd node
+    (`packed` = mlp_pack(weights, A); the weights themselves are only needed to route the gradients)."""
 
     @staticmethod
-    def forward(ctx, obs, A, *weights):
+    def forward(ctx, obs, A, packed, *weights):
         ctx.A = A
-        ctx.save_for_backward(obs, *weights)
-        return mlp_forward(weights, obs, A)
+        ctx.save_for_backward(obs, packed, *weights)
+        return mlp_forward(packed, weights[0].shape[0], obs, A)
 
     @staticmethod
     def backward(ctx, dlogits, dvalue):
-        obs, *weights = ctx.saved_tensors
-        grads = mlp_backward(weights, obs, ctx.A, dlogits.contiguous(), dvalue.contiguous())
-        return (None, None, *grads)
+        obs, packed, *weights = ctx.saved_tensors
+        grads = mlp_backward(packed, weights, obs, ctx.A, dlogits.contiguous(), dvalue.contiguous())
+        return (None, None, None, *grads)
 
 
 # --------------------------------------------------------------------------------------- rollout driver

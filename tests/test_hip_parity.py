@@ -146,7 +146,7 @@ def test_mlp_forward_vs_reference(G, hip, name):
     A = tree.max_actions
     w = [G.gpu(x) for x in mlp_weights(ro)]
     T, B = ro["logits"].shape[:2]
-    logits, value = hip.mlp_forward(w, G.gpu(ro["observations"]), A)
+    logits, value = hip.mlp_forward(hip.mlp_pack(w, A), w[0].shape[0], G.gpu(ro["observations"]), A)
     np.testing.assert_allclose(G.cpu(logits).reshape(T, B, A), ro["logits"], rtol=TOL, atol=TOL)
     np.testing.assert_allclose(G.cpu(value).reshape(T, B), ro["values"], rtol=TOL, atol=TOL)
 
@@ -162,13 +162,14 @@ def test_mlp_forward_shapes_vs_oracle_and_torch(G, hip, A, W, N):
     x = rng.standard_normal((N, 2, A, A)).astype(np.float32)
     want_l, want_v = oracle.mlp_forward(w, x, A)
     wg = [G.gpu(a) for a in w]
-    logits, value = hip.mlp_forward(wg, G.gpu(x), A)
+    packed = hip.mlp_pack(wg, A)
+    logits, value = hip.mlp_forward(packed, W, G.gpu(x), A)
     np.testing.assert_allclose(G.cpu(logits), want_l, rtol=TOL, atol=TOL)
     np.testing.assert_allclose(G.cpu(value)[:, 0], want_v, rtol=TOL, atol=TOL)
     xt = G.gpu(x).view(N, K)
     tl = torch.relu(xt @ wg[4].T + wg[5]) @ wg[6].T + wg[7]
     np.testing.assert_allclose(G.cpu(logits), G.cpu(tl), rtol=TOL, atol=TOL)
-    lh, vh = hip.mlp_forward(wg, G.gpu(x).half(), A)  # fp16 observations, fp32 arithmetic
+    lh, vh = hip.mlp_forward(packed, W, G.gpu(x).half(), A)  # fp16 observations, fp32 arithmetic
     want_lh, want_vh = oracle.mlp_forward(w, x.astype(np.float16).astype(np.float32), A)
     np.testing.assert_allclose(G.cpu(lh), want_lh, rtol=TOL, atol=TOL)
     np.testing.assert_allclose(G.cpu(vh)[:, 0], want_vh, rtol=TOL, atol=TOL)
@@ -190,7 +191,8 @@ def test_mlp_backward_vs_torch_autograd(G, hip, A, W, N):
     logits = torch.relu(xt @ wt[4].T + wt[5]) @ wt[6].T + wt[7]
     torch.autograd.backward([logits, value], [torch.tensor(dl, dtype=torch.float64), torch.tensor(dv, dtype=torch.float64)])
     wg = [G.gpu(a).requires_grad_(True) for a in w]
-    lg, vg = hip.FusedMLP.apply(G.gpu(x), A, *wg)
+    packed = hip.mlp_pack(wg, A)
+    lg, vg = hip.FusedMLP.apply(G.gpu(x), A, packed, *wg)
     np.testing.assert_allclose(G.cpu(lg), logits.detach().numpy(), rtol=TOL, atol=TOL)
     torch.autograd.backward([lg, vg], [G.gpu(dl), G.gpu(dv)])
     # a hidden unit whose pre-activation is within fp32 rounding of 0 for some sample has an ambiguous relu gate there:
@@ -206,11 +208,11 @@ def test_mlp_backward_vs_torch_autograd(G, hip, A, W, N):
             ref, g = ref[rows[i]], g[rows[i]]
         scale = np.abs(ref).max() + 1e-12
         np.testing.assert_allclose(g, ref, rtol=1e-4, atol=1e-5 * scale, err_msg=str(shape))
-    lo, vo = hip.mlp_forward([x_.detach() for x_ in wg], G.gpu(x), A, want_value=False)  # single heads
+    lo, vo = hip.mlp_forward(packed, W, G.gpu(x), A, want_value=False)  # single heads
     assert vo is None and torch.equal(lo, lg.detach())
-    lo, vo = hip.mlp_forward([x_.detach() for x_ in wg], G.gpu(x), A, want_logits=False)
+    lo, vo = hip.mlp_forward(packed, W, G.gpu(x), A, want_logits=False)
     assert lo is None and torch.equal(vo, vg.detach())
-    lh, vh = hip.FusedMLP.apply(G.gpu(x).half(), A, *[g.detach().requires_grad_(True) for g in wg])  # fp16 observations
+    lh, vh = hip.FusedMLP.apply(G.gpu(x).half(), A, packed, *[g.detach().requires_grad_(True) for g in wg])  # fp16 observations
     assert lh.shape == (N, A) and vh.shape == (N, 1)
 
 
@@ -577,10 +579,14 @@ def test_reference_test_nashconv_semantics(G, A):
     from environment.tree import Tree
     from util.metric import NashConvData
 
+    import random
+
     np.random.seed(A)
+    random.seed(A)
     tree = Tree(device=G.DEV, max_actions=A, max_transitions=1, depth_bound=3)
     tree.generate()
     data = NashConvData(tree)
     data.get_nashconv(tree, tree.solution_tensor)
     assert (data.row_best[1] + data.col_best[1]).item() == 0
-    assert torch.sum(data.reach_probability).item() == 2
+    # the reference asserts == 2 exactly; mixed solutions such as (1/3, 1/3, 1/3) sum to 2 only up to fp32 rounding
+    assert abs(torch.sum(data.reach_probability).item() - 2) < 1e-6

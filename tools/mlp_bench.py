@@ -35,9 +35,10 @@ def timeit(fn):
 
 fwd_flop = 2.0 * N * (K + 2) * 2 * W  # executed MFMA flops (bias k-step included)
 bwd_flop = fwd_flop + 2.0 * N * 32 * 2 * W  # recompute + dW0 with the feature tile padded to 32
-ms = timeit(lambda: rnad_hip.mlp_forward(w, x, A))
+packed = rnad_hip.mlp_pack(w, A)
+ms = timeit(lambda: rnad_hip.mlp_forward(packed, W, x, A))
 print(f"forward  both heads: {ms:7.3f} ms  {fwd_flop / ms / 1e9:6.1f} TFLOP/s (MFMA-executed)")
-ms = timeit(lambda: rnad_hip.mlp_forward(w, x, A, want_value=False))
+ms = timeit(lambda: rnad_hip.mlp_forward(packed, W, x, A, want_value=False))
 print(f"forward  policy only: {ms:7.3f} ms  {fwd_flop / 2 / ms / 1e9:6.1f} TFLOP/s")
-ms = timeit(lambda: rnad_hip.mlp_backward(w, x, A, dl, dv))
+ms = timeit(lambda: rnad_hip.mlp_backward(packed, w, x, A, dl, dv))
 print(f"backward           : {ms:7.3f} ms  {bwd_flop / ms / 1e9:6.1f} TFLOP/s")
