@@ -139,6 +139,12 @@ def main():
         k1_avg_s = obs_ms / 1e3 / max(n_obs, 1)
         achieved = k1_bytes_per_launch / k1_avg_s / 1e9 if n_obs else 0.0
         learn_bytes = (69 + 16) * local_batch * T if A == 3 else None
+        # fused MLP: flops the matrix cores execute per sample (first layer incl. the bias k-step, both heads)
+        K = 2 * A * A
+        mlp_flops_per_sample = 2.0 * (K + 2) * 2 * args.width
+        # per step: T rollout forwards of B + learner fwd (1) + target value head (.5) + 2 reg policy heads (1) of T*B samples
+        mlp_fwd_flops_per_step = mlp_flops_per_sample * local_batch * T * (1 + 1 + 0.5 + 1)
+        mlp_tflops = mlp_fwd_flops_per_step / (mlp_ms / args.steps / 1e3) / 1e12 if n_mlp else None
         out = {
             "metric": "env_steps_per_sec (rollout + R-NaD update, one iteration of learn/rnad.py:495-526 per step)",
             "value": env_steps / elapsed,
@@ -169,8 +175,10 @@ def main():
             },
             "other_kernels": {
                 "k_act": {"launches": n_act, "avg_launch_us": act_ms * 1e3 / max(n_act, 1)},
-                "k_mlp_forward": {"launches": n_mlp, "total_ms_per_step": mlp_ms / args.steps,
-                                  "note": "fp32 MFMA; rollout + target/reg nets"},
+                "k_mlp_forward": {"launches": n_mlp, "total_ms_per_step": mlp_ms / args.steps, "bound": "mfma", "achieved": mlp_tflops,
+                                  "peak": 157.3, "unit": "TFLOP/s (fp32 MFMA, v_mfma_f32_32x32x2_f32)",
+                                  "frac": mlp_tflops / 157.3 if mlp_tflops else None,
+                                  "note": "dominant kernel by time; rollout actor + learner/target/reg forwards"},
                 "k_mlp_backward": {"launches": n_bwd, "total_ms_per_step": bwd_ms / args.steps},
                 "k_learn_fused": {"launches": n_learn, "avg_launch_us": learn_ms * 1e3 / max(n_learn, 1),
                                   "achieved_GBps": (learn_bytes / (learn_ms / 1e3 / max(n_learn, 1)) / 1e9) if learn_bytes and n_learn else None},

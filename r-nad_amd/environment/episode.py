@@ -26,6 +26,7 @@ import torch
 
 import rnad_hip
 from environment.tree import Tree
+from nn.net import MLP as _MLP
 
 
 def _draw_seed():
@@ -171,22 +172,26 @@ class Episodes:
         packed = net.pack() if fast and hasattr(net, "pack") else None  # weights are fixed for the whole rollout
         net.eval()
         time_start = time.perf_counter()
-        rnad_hip.rollout_begin(handle, traj)
-        with torch.no_grad():
-            for t in range(T_cap):
-                obs_t = traj.observations[t]
-                na = None if noise_action is None else noise_action[t]
-                nc = None if noise_chance is None else noise_chance[t]
-                if fast:
-                    logits, value = net.forward_logits(obs_t, packed=packed) if packed is not None else net.forward_logits(obs_t)
-                    rnad_hip.rollout_step(handle, traj, t, value.reshape(-1), logits=logits, noise_action=na, noise_chance=nc,
-                                          seed=self.seed, lane0=self.lane_offset)
-                else:
-                    _, policy, value, actions = net.forward(obs_t)
-                    rnad_hip.rollout_step(handle, traj, t, value.reshape(-1).contiguous(), policy=policy.contiguous(),
-                                          actions=actions.to(torch.int32).contiguous().view(-1), noise_chance=nc,
-                                          seed=self.seed, lane0=self.lane_offset)
-        rnad_hip.rollout_end(handle, traj)
+        if packed is not None and noise_action is None and noise_chance is None and type(net).forward_logits is _MLP.forward_logits:
+            # the actor is this package's MLP: the whole loop is enqueued natively (rnad_rollout_run)
+            rnad_hip.rollout_run(handle, traj, net.width, packed, seed=self.seed, lane0=self.lane_offset)
+        else:
+            rnad_hip.rollout_begin(handle, traj)
+            with torch.no_grad():
+                for t in range(T_cap):
+                    obs_t = traj.observations[t]
+                    na = None if noise_action is None else noise_action[t]
+                    nc = None if noise_chance is None else noise_chance[t]
+                    if fast:
+                        logits, value = net.forward_logits(obs_t, packed=packed) if packed is not None else net.forward_logits(obs_t)
+                        rnad_hip.rollout_step(handle, traj, t, value.reshape(-1), logits=logits, noise_action=na, noise_chance=nc,
+                                              seed=self.seed, lane0=self.lane_offset)
+                    else:
+                        _, policy, value, actions = net.forward(obs_t)
+                        rnad_hip.rollout_step(handle, traj, t, value.reshape(-1).contiguous(), policy=policy.contiguous(),
+                                              actions=actions.to(torch.int32).contiguous().view(-1), noise_chance=nc,
+                                              seed=self.seed, lane0=self.lane_offset)
+            rnad_hip.rollout_end(handle, traj)
         if trim:
             alive = traj.alive.cpu()  # the only host sync of the rollout
             T = int((alive[:T_cap] > 0).sum().item())

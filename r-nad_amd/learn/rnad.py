@@ -310,7 +310,8 @@ class RNaD:
             for g in grads:
                 g.copy_(flat[off: off + g.numel()].view_as(g))
                 off += g.numel()
-            dist.all_reduce(losses)
+            if log is not None:
+                dist.all_reduce(losses)
 
         if log is not None:
             total_norm = 0

@@ -261,6 +261,15 @@ def rollout_begin(tree, traj):
     _check(lib().rnad_rollout_begin(tree.ptr, C.byref(traj.c), _stream()))
 
 
+def rollout_run(tree, traj, W, packed, seed=0, lane0=0):
+    """All T_cap steps of a rollout with the fused MLP as the actor, enqueued by one native call."""
+    dev = traj.indices.device
+    logits = torch.empty((traj.B, tree.A), dtype=F32, device=dev)
+    value = torch.empty((traj.B,), dtype=F32, device=dev)
+    _check(lib().rnad_rollout_run(tree.ptr, C.byref(traj.c), int(W), _dp(packed, F32, "packed"), _dp(logits, F32, "logits"),
+                                  _dp(value, F32, "value"), C.c_uint64(seed), C.c_int64(lane0), _stream()))
+
+
 def rollout_end(tree, traj):
     _check(lib().rnad_rollout_end(tree.ptr, C.byref(traj.c), _stream()))
 

@@ -1,0 +1,62 @@
+"""The data-parallel update on REAL kernels: two ranks (sharing the one GPU of the test box, gloo transport) each roll out
+half of the lanes and all-reduce normalisers + gradients; the result must equal the single-process full-batch step."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+B, SEED = 4096, 77
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _one_step(tmp, tag):
+    from environment.episode import Buffer
+    from environment.tree import Tree
+    from learn.rnad import RNaD
+
+    dev = torch.device("cuda:0")
+    os.environ["RNAD_SAVE_DIR"] = os.path.join(tmp, tag)
+    tree = Tree(device=dev, max_actions=3, max_transitions=2, depth_bound=3, transition_threshold=0.2)
+    tree.generate_native(seed=4, prune=(1, 3))
+    torch.manual_seed(SEED)  # same initial nets and the same rollout seed everywhere
+    rn = RNaD(tree=tree, device=dev, directory_name="dp", batch_size=B, eta=0.2, b1_adam=0.0, lr=1e-3,
+              net_params={"type": "MLP", "max_actions": 3, "width": 64})
+    rn.initialize()
+    log = {}
+    rn.train_step(Buffer(1), alpha=0.4, log=log)
+    torch.cuda.synchronize()
+    return {k: v.detach().cpu().numpy() for k, v in rn.net.state_dict().items()}, log
+
+
+def _worker(rank, world, port, tmp):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        params, log = _one_step(tmp, f"rank{rank}")
+        np.savez(os.path.join(tmp, f"dp_{rank}.npz"), loss_v=log["loss_v"], loss_nerd=log["loss_nerd"], **params)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_two_ranks_equal_one_process(tmp_path):
+    single, log = _one_step(str(tmp_path), "single")
+    mp.spawn(_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = (np.load(tmp_path / f"dp_{r}.npz") for r in range(2))
+    for k, want in single.items():
+        np.testing.assert_array_equal(r0[k], r1[k])  # ranks stay in lock step
+        np.testing.assert_allclose(r0[k], want, rtol=2e-4, atol=2e-6, err_msg=k)  # Adam normalises: compare loosely
+    np.testing.assert_allclose(r0["loss_v"], log["loss_v"], rtol=1e-5)
+    np.testing.assert_allclose(r0["loss_nerd"], log["loss_nerd"], rtol=1e-4, atol=1e-7)
