@@ -41,8 +41,11 @@ class MLP(nn.Module):
         return rnad_hip.mlp_pack(self._weights(), self.max_actions)
 
     def _fusable(self):
+        """The fused kernels keep ALL weights in the 160 KiB LDS of a CU and tile the hidden layer by 32."""
         w = self.value_fc0.weight
-        return w.is_cuda and w.dtype == torch.float32 and self.width % 32 == 0
+        A, W = self.max_actions, self.width
+        image_floats = (2 * A * A + 2) * 2 * W + (1 + A) * W + 12
+        return w.is_cuda and w.dtype == torch.float32 and W % 32 == 0 and image_floats * 4 <= 160 * 1024
 
     def forward_logits(self, input_batch, want_logits=True, want_value=True, packed=None):
         """obs [N, 2, A, A] (fp32 or fp16) -> logits [N, A], value [N, 1]   (net.py:40-43).
