@@ -91,7 +91,7 @@ int rnad_policy_head(int64_t N, int A, const float *logits, const uint8_t *mask_
  * loss.backward() computes for the learner net, learn/rnad.py:425), hidden layer recomputed on chip,
  * weight gradients contracted over samples on the matrix cores.  g_* are written (not accumulated),
  * torch Linear layouts.  workspace: rnad_mlp_backward_workspace(N, A, W) bytes (per-block partials,
- * summed in a fixed order).  Supported: 2*A*A + 1 <= 32 (A <= 3), W a multiple of 32 up to 256.
+ * summed in a fixed order; -1 if the weight image does not fit the 160 KiB LDS).
  * ---------------------------------------------------------------------------------------------- */
 int64_t rnad_mlp_packed_size(int A, int W);
 int rnad_mlp_pack(int A, int W, const float *vw0, const float *vb0, const float *vw1, const float *vb1, const float *pw0,

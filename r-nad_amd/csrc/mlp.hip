@@ -202,12 +202,12 @@ __global__ __launch_bounds__(kThreads) void k_mlp_forward(int64_t N, int W, cons
 // Block = W/32 waves; wave w owns hidden tile w of BOTH heads for every sample tile the block visits, so its two
 // 32x32 dW0aug accumulators (32 registers) and its dW1 partials (16 + 16 A registers) stay resident for the whole
 // launch.  Blocks write their partial gradients to `partial`; k_mlp_reduce sums them in a fixed order (deterministic).
-template <int A, typename ObsT>
-__global__ __launch_bounds__(512) void k_mlp_backward(int64_t N, int W, const float *__restrict__ packed,
-                                                      const ObsT *__restrict__ obs, const float *__restrict__ dlogit,
-                                                      const float *__restrict__ dv, float *__restrict__ partial, int P) {
+template <int A, typename ObsT, int MAXT>
+__global__ __launch_bounds__(MAXT) void k_mlp_backward(int64_t N, int W, const float *__restrict__ packed,
+                                                       const ObsT *__restrict__ obs, const float *__restrict__ dlogit,
+                                                       const float *__restrict__ dv, float *__restrict__ partial, int P) {
     constexpr int K = 2 * A * A, KS = K / 2 + 1;
-    static_assert(K + 1 <= kTile, "feature tile");
+    constexpr int FT = (K + 1 + kTile - 1) / kTile;  // 32-wide feature tiles of the augmented input (x | 1)
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int W2 = 2 * W, nthreads = blockDim.x;
     float *w0 = lds;
@@ -225,9 +225,16 @@ __global__ __launch_bounds__(512) void k_mlp_backward(int64_t N, int W, const fl
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int col = lane & 31, half = lane >> 5;
     float *tr = scratch + wave * (kTile * 33);
-    const int tile_v = wave, tile_p = W / kTile + wave;
+    // blockIdx.y selects a group of (blockDim.x / 64) hidden tiles; this wave owns one of them, in both heads
+    const int own = blockIdx.y * (nthreads >> 6) + wave;
+    const int tile_v = own, tile_p = W / kTile + own;
 
-    f32x16 gW0v = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, gW0p = gW0v;
+    f32x16 gW0v[FT], gW0p[FT];
+#pragma unroll
+    for (int ft = 0; ft < FT; ++ft) {
+        gW0v[ft] = f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        gW0p[ft] = gW0v[ft];
+    }
     float gW1v[16], gW1p[A][16], gb1v = 0.0f, gb1p[A];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -247,13 +254,17 @@ __global__ __launch_bounds__(512) void k_mlp_backward(int64_t N, int W, const fl
 #pragma unroll
         for (int ks = 0; ks < KS - 1; ++ks) xk[ks] = live ? load_obs<ObsT>(obs + sample * K + 2 * ks + half) : 0.0f;
         xk[KS - 1] = half == 0 ? 1.0f : 0.0f;
-        float xt[16];   // B operand of the weight-gradient product: xaug[sample = 2 ks + half][feature = col]
+        float xt[FT][16];   // B operand of the weight-gradient product: xaug[sample = 2 ks + half][feature = 32 ft + col]
 #pragma unroll
-        for (int ks = 0; ks < 16; ++ks) {
-            const int64_t sk = s0 + 2 * ks + half;
-            float x = 0.0f;
-            if (sk < N) x = col < K ? load_obs<ObsT>(obs + sk * K + col) : (col == K ? 1.0f : 0.0f);
-            xt[ks] = x;
+        for (int ft = 0; ft < FT; ++ft) {
+            const int f = ft * kTile + col;
+#pragma unroll
+            for (int ks = 0; ks < 16; ++ks) {
+                const int64_t sk = s0 + 2 * ks + half;
+                float x = 0.0f;
+                if (sk < N) x = f < K ? load_obs<ObsT>(obs + sk * K + f) : (f == K ? 1.0f : 0.0f);
+                xt[ft][ks] = x;
+            }
         }
         const float dvs = live ? dv[sample] : 0.0f;
         float dl[A];
@@ -265,10 +276,7 @@ __global__ __launch_bounds__(512) void k_mlp_backward(int64_t N, int W, const fl
 
         // ---------------- value head, hidden tile `tile_v`
         {
-            const float *wa = w0 + tile_v * kTile + col;
-            f32x16 c = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks) c = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[(2 * ks + half) * W2], xk[ks], c, 0, 0, 0);
+            const f32x16 c = mfma_chain<A, KS>(w0 + tile_v * kTile + col, W2, half, xk);
             const float *w1 = w1v + tile_v * kTile + 4 * half;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
@@ -278,29 +286,31 @@ __global__ __launch_bounds__(512) void k_mlp_backward(int64_t N, int W, const fl
                 for (int j = 0; j < 4; ++j) {
                     const int r = 4 * g + j;
                     const float z = c[r];
-                    gW1v[r] += dvs * fmaxf(z, 0.0f);
+                    gW1v[r] = fmaf(dvs, fmaxf(z, 0.0f), gW1v[r]);
                     tr[(j + 8 * g + 4 * half) * 33 + col] = z > 0.0f ? wv[j] * dvs : 0.0f;  // dz, stored [hidden][sample]
                 }
             }
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
-            for (int ks = 0; ks < 16; ++ks) gW0v = __builtin_amdgcn_mfma_f32_32x32x2f32(tr[col * 33 + 2 * ks + half], xt[ks], gW0v, 0, 0, 0);
+            for (int ks = 0; ks < 16; ++ks) {
+                const float at = tr[col * 33 + 2 * ks + half];
+#pragma unroll
+                for (int ft = 0; ft < FT; ++ft) gW0v[ft] = __builtin_amdgcn_mfma_f32_32x32x2f32(at, xt[ft][ks], gW0v[ft], 0, 0, 0);
+            }
             __builtin_amdgcn_wave_barrier();
         }
         // ---------------- policy head, hidden tile `tile_p`
         {
-            const float *wa = w0 + tile_p * kTile + col;
-            f32x16 c = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks) c = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[(2 * ks + half) * W2], xk[ks], c, 0, 0, 0);
-            const float *w1 = w1p + wave * kTile + 4 * half;
+            const f32x16 c = mfma_chain<A, KS>(w0 + tile_p * kTile + col, W2, half, xk);
+            const float *w1 = w1p + own * kTile + 4 * half;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 float dh[4] = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
                 for (int a = 0; a < A; ++a) {
                     const float4 w = *reinterpret_cast<const float4 *>(w1 + a * W + 8 * g);
-                    dh[0] += w.x * dl[a]; dh[1] += w.y * dl[a]; dh[2] += w.z * dl[a]; dh[3] += w.w * dl[a];
+                    dh[0] = fmaf(w.x, dl[a], dh[0]); dh[1] = fmaf(w.y, dl[a], dh[1]);
+                    dh[2] = fmaf(w.z, dl[a], dh[2]); dh[3] = fmaf(w.w, dl[a], dh[3]);
                 }
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
@@ -308,27 +318,35 @@ __global__ __launch_bounds__(512) void k_mlp_backward(int64_t N, int W, const fl
                     const float z = c[r];
                     const float h = fmaxf(z, 0.0f);
 #pragma unroll
-                    for (int a = 0; a < A; ++a) gW1p[a][r] += dl[a] * h;
+                    for (int a = 0; a < A; ++a) gW1p[a][r] = fmaf(dl[a], h, gW1p[a][r]);
                     tr[(j + 8 * g + 4 * half) * 33 + col] = z > 0.0f ? dh[j] : 0.0f;
                 }
             }
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
-            for (int ks = 0; ks < 16; ++ks) gW0p = __builtin_amdgcn_mfma_f32_32x32x2f32(tr[col * 33 + 2 * ks + half], xt[ks], gW0p, 0, 0, 0);
+            for (int ks = 0; ks < 16; ++ks) {
+                const float at = tr[col * 33 + 2 * ks + half];
+#pragma unroll
+                for (int ft = 0; ft < FT; ++ft) gW0p[ft] = __builtin_amdgcn_mfma_f32_32x32x2f32(at, xt[ft][ks], gW0p[ft], 0, 0, 0);
+            }
             __builtin_amdgcn_wave_barrier();
         }
     }
 
     // ---------------- write this block's partial gradients
-    // layout: dW0aug [2W][32] | dW1v [W] | dW1p [A][W] | db1v | db1p [A]
+    // layout: dW0aug [2W][32 FT] | dW1v [W] | dW1p [A][W] | db1v | db1p [A]
+    constexpr int FW = FT * kTile;
     float *out = partial + (int64_t)blockIdx.x * P;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
-        out[(tile_v * kTile + row) * kTile + col] = gW0v[r];
-        out[(tile_p * kTile + row) * kTile + col] = gW0p[r];
+#pragma unroll
+        for (int ft = 0; ft < FT; ++ft) {
+            out[(tile_v * kTile + row) * FW + ft * kTile + col] = gW0v[ft][r];
+            out[(tile_p * kTile + row) * FW + ft * kTile + col] = gW0p[ft][r];
+        }
     }
-    float *o1 = out + W2 * kTile;
+    float *o1 = out + W2 * FW;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         float v = gW1v[r];
@@ -341,10 +359,10 @@ __global__ __launch_bounds__(512) void k_mlp_backward(int64_t N, int W, const fl
             float p = gW1p[a][r];
 #pragma unroll
             for (int off = 16; off > 0; off >>= 1) p += __shfl_xor(p, off, 64);
-            if (col == 0) o1[W + a * W + wave * kTile + row] = p;
+            if (col == 0) o1[W + a * W + own * kTile + row] = p;
         }
     }
-    if (wave == 0) {  // every wave saw the same samples: one of them reports the output-bias gradients
+    if (own == 0) {  // every wave saw the same samples: one of them reports the output-bias gradients
 #pragma unroll
         for (int off = 16; off > 0; off >>= 1) gb1v += __shfl_xor(gb1v, off, 64);
         if (lane == 0) o1[W + A * W] = gb1v;
@@ -364,16 +382,16 @@ __global__ __launch_bounds__(kThreads) void k_mlp_reduce(int nblocks, int W, int
                                                          float *__restrict__ g_vw0, float *__restrict__ g_vb0, float *__restrict__ g_vw1,
                                                          float *__restrict__ g_vb1, float *__restrict__ g_pw0, float *__restrict__ g_pb0,
                                                          float *__restrict__ g_pw1, float *__restrict__ g_pb1) {
-    constexpr int K = 2 * A * A;
+    constexpr int K = 2 * A * A, FW = ((K + 1 + kTile - 1) / kTile) * kTile;
     const int e = blockIdx.x * kThreads + threadIdx.x;
-    const int total = 2 * W * kTile + W + A * W + 1 + A;
+    const int total = 2 * W * FW + W + A * W + 1 + A;
     if (e >= total) return;
     double s = 0.0;
     for (int b = 0; b < nblocks; ++b) s += (double)partial[(int64_t)b * P + e];
     const float v = (float)s;
-    const int n0 = 2 * W * kTile;
+    const int n0 = 2 * W * FW;
     if (e < n0) {
-        const int h = e / kTile, k = e % kTile;
+        const int h = e / FW, k = e % FW;
         float *gw = h < W ? g_vw0 : g_pw0, *gb = h < W ? g_vb0 : g_pb0;
         const int hh = h < W ? h : h - W;
         if (k < K) gw[hh * K + k] = v;
@@ -482,23 +500,34 @@ extern "C" int rnad_mlp_forward(int64_t N, int A, int W, const float *packed, co
     return 0;
 }
 
-static int mlp_backward_grid(int64_t N, int W, int A, size_t *lds_bytes, int *P) {
-    const int K = 2 * A * A;
-    (void)K;
-    *lds_bytes = ((size_t)mlp_packed_floats(A, W) + (size_t)(W / kTile) * kTile * 33) * sizeof(float);
-    *P = (2 * W * kTile + W + A * W + 1 + A + 3) & ~3;
+struct BwdPlan {
+    int waves, groups, grid_x, P, total;
+    size_t lds_bytes;
+};
+
+// One wave per hidden tile (of both heads).  With one feature tile (A <= 3) a wave needs ~230 VGPRs: 8 waves per block, two
+// per SIMD.  With more feature tiles it needs up to ~400: 4 waves per block, one per SIMD, and blockIdx.y walks the tile groups.
+static bool mlp_backward_plan(int64_t N, int W, int A, BwdPlan *p) {
+    const int K = 2 * A * A, T = W / kTile, FT = (K + 1 + kTile - 1) / kTile;
+    int waves = FT == 1 ? 8 : 4;
+    while (waves > 1 && T % waves) waves >>= 1;
+    p->waves = waves;
+    p->groups = T / waves;
+    p->lds_bytes = ((size_t)mlp_packed_floats(A, W) + (size_t)waves * kTile * 33) * sizeof(float);
+    p->total = 2 * W * FT * kTile + W + A * W + 1 + A;
+    p->P = (p->total + 3) & ~3;
+    if (p->lds_bytes > 160 * 1024) return false;
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    const int blocks_per_cu = std::max(1, std::min(2, (int)(160 * 1024 / *lds_bytes)));
     const int64_t n_tiles = (N + kTile - 1) / kTile;
-    return (int)std::max<int64_t>(1, std::min<int64_t>(n_tiles, (int64_t)cus * blocks_per_cu));
+    p->grid_x = (int)std::max<int64_t>(1, std::min<int64_t>(n_tiles, std::max(1, cus / p->groups)));
+    return true;
 }
 
 extern "C" int64_t rnad_mlp_backward_workspace(int64_t N, int A, int W) {
-    size_t lds;
-    int P;
-    const int grid = mlp_backward_grid(N, W, A, &lds, &P);
-    return (int64_t)grid * P * (int64_t)sizeof(float);
+    BwdPlan p;
+    if (A < 1 || A > RNAD_MAX_ACTIONS || W < kTile || W % kTile || !mlp_backward_plan(N, W, A, &p)) return -1;
+    return (int64_t)p.grid_x * p.P * (int64_t)sizeof(float);
 }
 
 extern "C" int rnad_mlp_backward(int64_t N, int A, int W, const float *packed, const void *obs, int obs_half, const float *dlogits,
@@ -506,41 +535,37 @@ extern "C" int rnad_mlp_backward(int64_t N, int A, int W, const float *packed, c
                                  float *g_pb0, float *g_pw1, float *g_pb1, float *workspace, void *stream_) {
     RNAD_REQUIRE(packed && obs && dlogits && dvalue && g_vw0 && g_vb0 && g_vw1 && g_vb1 && g_pw0 && g_pb0 && g_pw1 && g_pb1 && workspace,
                  "rnad_mlp_backward: null argument");
-    RNAD_REQUIRE(W >= kTile && W % kTile == 0 && W <= 256, "rnad_mlp_backward: width %d must be a multiple of %d, at most 256", W, kTile);
-    RNAD_REQUIRE(2 * A * A + 1 <= kTile, "rnad_mlp_backward: max_actions %d needs more than %d input features", A, kTile);
+    RNAD_REQUIRE(W >= kTile && W % kTile == 0, "rnad_mlp_backward: width %d must be a positive multiple of %d", W, kTile);
     RNAD_REQUIRE(N >= 1, "rnad_mlp_backward: empty batch");
     hipStream_t stream = (hipStream_t)stream_;
-    size_t lds_bytes;
-    int P;
-    const int grid = mlp_backward_grid(N, W, A, &lds_bytes, &P);
-    RNAD_REQUIRE(lds_bytes <= 160 * 1024, "rnad_mlp_backward: weights do not fit the LDS (A=%d, width=%d)", A, W);
-    const int threads = 64 * (W / kTile);
+    BwdPlan plan;
+    RNAD_REQUIRE(A >= 1 && A <= RNAD_MAX_ACTIONS && mlp_backward_plan(N, W, A, &plan),
+                 "rnad_mlp_backward: weights do not fit the LDS (A=%d, width=%d)", A, W);
+    const int grid = plan.grid_x, P = plan.P;
+    const size_t lds_bytes = plan.lds_bytes;
+    const int threads = 64 * plan.waves;
     {
         ProfScope prof(PROF_MLP_BWD, stream);
-#define RNAD_MLPB_LAUNCH(T_)                                                                                                       \
+#define RNAD_MLPB_LAUNCH(T_, MAXT_)                                                                                                \
     do {                                                                                                                           \
-        auto kern = k_mlp_backward<kA, T_>;                                                                                        \
+        auto kern = k_mlp_backward<kA, T_, MAXT_>;                                                                                 \
         if (lds_bytes > 64 * 1024)                                                                                                 \
             RNAD_HIP_OK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));      \
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), lds_bytes, stream, N, W, packed, (const T_ *)obs, dlogits, dvalue,           \
-                           workspace, P);                                                                         \
+        hipLaunchKernelGGL(kern, dim3(grid, plan.groups), dim3(threads), lds_bytes, stream, N, W, packed, (const T_ *)obs, dlogits, \
+                           dvalue, workspace, P);                                                                                  \
     } while (0)
-        switch (A) {
-            case 1: { constexpr int kA = 1; if (obs_half) RNAD_MLPB_LAUNCH(__half); else RNAD_MLPB_LAUNCH(float); } break;
-            case 2: { constexpr int kA = 2; if (obs_half) RNAD_MLPB_LAUNCH(__half); else RNAD_MLPB_LAUNCH(float); } break;
-            case 3: { constexpr int kA = 3; if (obs_half) RNAD_MLPB_LAUNCH(__half); else RNAD_MLPB_LAUNCH(float); } break;
-            default: rnad::set_error("rnad_mlp_backward: max_actions %d not supported (1..3)", A); return 2;
-        }
+        RNAD_DISPATCH_A(A, {
+            constexpr int kMaxT = (2 * kA * kA + 1 <= kTile) ? 512 : 256;
+            if (obs_half) RNAD_MLPB_LAUNCH(__half, kMaxT);
+            else RNAD_MLPB_LAUNCH(float, kMaxT);
+        });
 #undef RNAD_MLPB_LAUNCH
         RNAD_HIP_OK(hipGetLastError());
     }
-    const int total = 2 * W * kTile + W + A * W + 1 + A;
+    const int total = plan.total;
     const unsigned rgrid = (unsigned)((total + kThreads - 1) / kThreads);
-    switch (A) {
-        case 1: hipLaunchKernelGGL((k_mlp_reduce<1>), dim3(rgrid), dim3(kThreads), 0, stream, grid, W, P, workspace, g_vw0, g_vb0, g_vw1, g_vb1, g_pw0, g_pb0, g_pw1, g_pb1); break;
-        case 2: hipLaunchKernelGGL((k_mlp_reduce<2>), dim3(rgrid), dim3(kThreads), 0, stream, grid, W, P, workspace, g_vw0, g_vb0, g_vw1, g_vb1, g_pw0, g_pb0, g_pw1, g_pb1); break;
-        default: hipLaunchKernelGGL((k_mlp_reduce<3>), dim3(rgrid), dim3(kThreads), 0, stream, grid, W, P, workspace, g_vw0, g_vb0, g_vw1, g_vb1, g_pw0, g_pb0, g_pw1, g_pb1); break;
-    }
+    RNAD_DISPATCH_A(A, hipLaunchKernelGGL((k_mlp_reduce<kA>), dim3(rgrid), dim3(kThreads), 0, stream, grid, W, P, workspace, g_vw0, g_vb0,
+                                          g_vw1, g_vb1, g_pw0, g_pb0, g_pw1, g_pb1));
     RNAD_HIP_OK(hipGetLastError());
     return 0;
 }

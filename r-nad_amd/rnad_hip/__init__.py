@@ -204,7 +204,7 @@ def mlp_forward(packed, W, obs, A, want_logits=True, want_value=True):
 
 
 def mlp_backward_supported(A, W):
-    return 2 * A * A + 1 <= 32 and W % 32 == 0 and W <= 256
+    return W % 32 == 0 and lib().rnad_mlp_backward_workspace(C.c_int64(32), A, W) > 0
 
 
 def mlp_backward(packed, weights, obs, A, dlogits, dvalue):

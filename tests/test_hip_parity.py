@@ -175,7 +175,8 @@ def test_mlp_forward_shapes_vs_oracle_and_torch(G, hip, A, W, N):
     np.testing.assert_allclose(G.cpu(vh)[:, 0], want_vh, rtol=TOL, atol=TOL)
 
 
-@pytest.mark.parametrize("A,W,N", [(3, 256, 50_001), (2, 64, 333), (3, 32, 5), (1, 32, 1000), (3, 128, 20_000)])
+@pytest.mark.parametrize("A,W,N", [(3, 256, 50_001), (2, 64, 333), (3, 32, 5), (1, 32, 1000), (3, 128, 20_000), (3, 512, 9_000), (4, 64, 3_000),
+                                   (5, 128, 12_345), (5, 256, 4_000), (6, 96, 777)])
 def test_mlp_backward_vs_torch_autograd(G, hip, A, W, N):
     """rnad_mlp_backward == autograd through the four Linear layers (fp64 reference on the host for the tolerance)."""
     rng = np.random.default_rng(A * 100 + W + N)
