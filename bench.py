@@ -118,6 +118,17 @@ def main():
     n_bwd, bwd_ms = rnad_hip.prof_read(rnad_hip.PROF_MLP_BWD)
     rnad_hip.prof_enable(False)
     T = rn.last_episodes.t_eff + 1
+    # the same step with the on-policy shortcut (RNaD.reuse_actor_outputs: the rollout's logits / values stand in for the
+    # learner's forward_batch, bit-identical when the buffer holds only the current batch); reported separately, NOT `value`
+    rn.reuse_actor_outputs = True
+    one_step(args.warmup + args.steps)
+    fence()
+    t_s = time.perf_counter()
+    for i in range(args.steps):
+        one_step(args.warmup + args.steps + 1 + i)
+    fence()
+    elapsed_reuse = time.perf_counter() - t_s
+    rn.reuse_actor_outputs = False
     # rollout alone (Episodes.generate, reference episode.py:175-230), outside the headline timed region
     from environment.episode import Episodes
     fence()
@@ -127,9 +138,9 @@ def main():
     fence()
     rollout_s = time.perf_counter() - t_r
     if world > 1:
-        t = torch.tensor([elapsed, rollout_s], device=device, dtype=torch.float64)
+        t = torch.tensor([elapsed, rollout_s, elapsed_reuse], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed, rollout_s = t.tolist()
+        elapsed, rollout_s, elapsed_reuse = t.tolist()
 
     if rank == 0:
         env_steps = global_batch * T * args.steps
@@ -165,6 +176,9 @@ def main():
                 "parallelism": f"dp{world} (episodes sharded, RCCL all-reduce of 2 normalisers + 43 KB grads)",
             },
             "updates_per_sec": args.steps / elapsed,
+            "on_policy_shortcut": {"env_steps_per_sec": env_steps / elapsed_reuse, "updates_per_sec": args.steps / elapsed_reuse,
+                                   "ms_per_step": elapsed_reuse / args.steps * 1e3,
+                                   "what": "RNaD.reuse_actor_outputs=True: learner forward replaced by the rollout's own (bit-identical) logits/values"},
             "rollout_env_steps_per_sec": env_steps / rollout_s,
             "rollout_ms_per_step": rollout_s / args.steps * 1e3,
             "roofline": {

@@ -159,10 +159,11 @@ int rnad_rollout_step(const rnad_tree_t *tree, const rnad_traj_t *traj, int t, i
 
 /* The whole loop of Episodes.generate for a net that is the fused MLP of this library (nn/net.py:18-51): begin, then
  * for every t: rnad_mlp_forward(observations[t]) -> rnad_rollout_step(mode 0), then rnad_rollout_end -- enqueued from ONE
- * call (3 * T_cap + 2 launches, no host work in between).  packed: rnad_mlp_pack image; logits_ws [B,A], value_ws [B]:
- * scratch buffers.  Seeded noise only. */
+ * call (3 * T_cap + 2 launches, no host work in between).  packed: rnad_mlp_pack image; value_ws [B] scratch;
+ * logits_ws: [B,A] scratch with logits_step_stride = 0, or a [T_cap,B,A] buffer with logits_step_stride = B*A that
+ * keeps the actor's raw logits of every step.  Seeded noise only. */
 int rnad_rollout_run(const rnad_tree_t *tree, const rnad_traj_t *traj, int W, const float *packed, float *logits_ws,
-                     float *value_ws, uint64_t seed, int64_t lane0, void *stream);
+                     int64_t logits_step_stride, float *value_ws, uint64_t seed, int64_t lane0, void *stream);
 
 /* alive[t] = #lanes with indices[t, :] != 0 for t in [0, T_cap]: one pass over the index buffer after the last
  * step.  The host reads it once to trim the trajectory to the reference's T (episode.py:194 stops when every lane

@@ -377,7 +377,7 @@ extern "C" int rnad_rollout_end(const rnad_tree_t *tree, const rnad_traj_t *tr, 
 
 // Episodes.generate (episode.py:194-212) for a net that IS the fused MLP: all T_cap steps enqueued from one call.
 extern "C" int rnad_rollout_run(const rnad_tree_t *tree, const rnad_traj_t *tr, int W, const float *packed, float *logits_ws,
-                                float *value_ws, uint64_t seed, int64_t lane0, void *stream) {
+                                int64_t logits_step_stride, float *value_ws, uint64_t seed, int64_t lane0, void *stream) {
     if (int rc = check_traj(tree, tr, "rnad_rollout_run")) return rc;
     RNAD_REQUIRE(packed && logits_ws && value_ws, "rnad_rollout_run: null argument");
     if (int rc = rnad_rollout_begin(tree, tr, stream)) return rc;
@@ -385,8 +385,9 @@ extern "C" int rnad_rollout_run(const rnad_tree_t *tree, const rnad_traj_t *tr, 
     const size_t step_bytes = (size_t)tr->B * 2 * tree->A * tree->A * esz;
     for (int t = 0; t < tr->T_cap; ++t) {
         const void *obs_t = (const char *)tr->observations + (size_t)t * step_bytes;
-        if (int rc = rnad_mlp_forward(tr->B, tree->A, W, packed, obs_t, tr->obs_half, logits_ws, value_ws, stream)) return rc;
-        if (int rc = rnad_rollout_step(tree, tr, t, 0, logits_ws, nullptr, nullptr, value_ws, nullptr, nullptr, seed, lane0, stream)) return rc;
+        float *logits_t = logits_ws + (int64_t)t * logits_step_stride;  // stride 0: one scratch row; B*A: keep every step's logits
+        if (int rc = rnad_mlp_forward(tr->B, tree->A, W, packed, obs_t, tr->obs_half, logits_t, value_ws, stream)) return rc;
+        if (int rc = rnad_rollout_step(tree, tr, t, 0, logits_t, nullptr, nullptr, value_ws, nullptr, nullptr, seed, lane0, stream)) return rc;
     }
     return rnad_rollout_end(tree, tr, stream);
 }

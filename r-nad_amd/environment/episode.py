@@ -110,6 +110,7 @@ class Episodes:
         self.indices = self.observations = self.mask_bits = self.policy = None
         self.action_idx = self.rewards = self.values = None
         self.alive = None  # int32 [T + 1] on the device: lanes with indices[t] != 0
+        self.actor_logits = None  # [T, B, A] raw logits of the actor (generate(keep_logits=True), native rollout only)
         self._lazy = {}
 
     # ---------------------------------------------------------------- lazily materialised reference attributes
@@ -150,7 +151,7 @@ class Episodes:
         return torch.stack([a[0::2].sum(), a[1::2].sum()])
 
     # ---------------------------------------------------------------- episode.py:175-230
-    def generate(self, net: torch.nn.Module, noise_action=None, noise_chance=None, max_steps=None, trim=True):
+    def generate(self, net: torch.nn.Module, noise_action=None, noise_chance=None, max_steps=None, trim=True, keep_logits=False):
         """Play the batch to the end with `net` as the actor.
 
         Nets exposing `forward_logits(obs) -> (logits [B,A], value [B,1])` (the MLP here) take the fast path: policy head,
@@ -174,7 +175,8 @@ class Episodes:
         time_start = time.perf_counter()
         if packed is not None and noise_action is None and noise_chance is None and type(net).forward_logits is _MLP.forward_logits:
             # the actor is this package's MLP: the whole loop is enqueued natively (rnad_rollout_run)
-            rnad_hip.rollout_run(handle, traj, net.width, packed, seed=self.seed, lane0=self.lane_offset)
+            self.actor_logits = rnad_hip.rollout_run(handle, traj, net.width, packed, seed=self.seed, lane0=self.lane_offset,
+                                                     keep_logits=keep_logits)
         else:
             rnad_hip.rollout_begin(handle, traj)
             with torch.no_grad():
@@ -209,6 +211,8 @@ class Episodes:
         self.rewards = traj.rewards[:T]
         self.values = traj.values[:T]
         self.alive = traj.alive[: T + 1]
+        if self.actor_logits is not None:
+            self.actor_logits = self.actor_logits[:T]
         self._lazy = {}
         self.states.indices = traj.indices[T]
         self.states.terminal = True  # by construction after 2 * depth steps

@@ -118,6 +118,10 @@ class RNaD:
         self.net_reg = None
         self.net_reg_ = None
         self.last_log = None  # scalars of the most recent logged step (the reference sends them to wandb)
+        # On-policy shortcut (off by default): with the default one-batch buffer the learner net of __learn IS the actor of the
+        # rollout that just finished, with unchanged weights, so forward_batch(net) (rnad.py:373) recomputes bit-identical
+        # logits / values; when True they are taken from the rollout and only the backward runs.
+        self.reuse_actor_outputs = False
         self.nashconv_history = []  # (m, total_steps, nashconv)
 
     # ------------------------------------------------------------------ data-parallel helpers
@@ -281,7 +285,13 @@ class RNaD:
         """Gradients of the learner net from a batch of trajectories (reward transform + V-trace + NeuRD)."""
         T, B, A = episodes.t_eff + 1, episodes.batch_size, self.tree.max_actions
 
-        logit, v = self._logits_of(self.net, episodes)  # rnad.py:373, with grad
+        reuse = (getattr(self, "reuse_actor_outputs", False) and getattr(episodes, "actor_logits", None) is not None
+                 and getattr(episodes, "_actor_tag", None) == (id(self.net), self.total_steps)
+                 and rnad_hip.mlp_backward_supported(A, getattr(self.net, "width", 0)))
+        if reuse:  # the rollout's own outputs: same weights, same observations, same kernel -> same bits as rnad.py:373
+            logit, v = episodes.actor_logits.reshape(-1, A), episodes.values[:T].reshape(-1, 1)
+        else:
+            logit, v = self._logits_of(self.net, episodes)  # rnad.py:373, with grad
         with torch.no_grad():
             # the reference runs all four full nets (:378-380); only these heads are ever read (:382-406)
             logit_target, v_target = self._logits_of(self.net_target, episodes, want_logits=log is not None)  # :378
@@ -300,7 +310,13 @@ class RNaD:
             logit.detach().contiguous(), v.detach().reshape(T, B).contiguous(), v_target.reshape(T, B).contiguous(),
             logit_reg.contiguous(), logit_reg_.contiguous(), norm, hp, want_aux=log is not None)
         # loss.backward() (rnad.py:424-425) with the closed-form dL/dlogit, dL/dv
-        torch.autograd.backward([logit, v], [dlogit.view(-1, A), dv.view(-1, 1)])
+        if reuse:
+            grads = rnad_hip.mlp_backward(self.net.pack(), self.net._weights(), episodes.observations[:T], A, dlogit.view(-1, A),
+                                          dv.view(-1, 1))
+            for p_, g_ in zip(self.net._weights(), grads):
+                p_.grad = g_ if p_.grad is None else p_.grad + g_
+        else:
+            torch.autograd.backward([logit, v], [dlogit.view(-1, A), dv.view(-1, 1)])
 
         if _dist_on():
             grads = [p.grad for p in self.net.parameters()]
@@ -345,7 +361,9 @@ class RNaD:
         local_batch = self.batch_size // world
         if self.total_steps % self.buffer_mod == 0:
             episodes = episode.Episodes(self.tree, local_batch, seed=self._new_seed(), lane_offset=rank * local_batch)
-            episodes.generate(self.net, trim=False)  # no host sync: trailing all-absorbed steps are masked by `valid`
+            # no host sync: trailing all-absorbed steps are masked by `valid`
+            episodes.generate(self.net, trim=False, keep_logits=self.reuse_actor_outputs)
+            episodes._actor_tag = (id(self.net), self.total_steps)
             buffer.append(episodes)
             self.last_episodes = episodes
         episodes_sample = buffer.sample(local_batch)

@@ -261,13 +261,16 @@ def rollout_begin(tree, traj):
     _check(lib().rnad_rollout_begin(tree.ptr, C.byref(traj.c), _stream()))
 
 
-def rollout_run(tree, traj, W, packed, seed=0, lane0=0):
-    """All T_cap steps of a rollout with the fused MLP as the actor, enqueued by one native call."""
+def rollout_run(tree, traj, W, packed, seed=0, lane0=0, keep_logits=False):
+    """All T_cap steps of a rollout with the fused MLP as the actor, enqueued by one native call.
+    keep_logits: return the actor's raw logits of every step as a [T_cap, B, A] tensor (else None)."""
     dev = traj.indices.device
-    logits = torch.empty((traj.B, tree.A), dtype=F32, device=dev)
+    logits = torch.empty((traj.T_cap if keep_logits else 1, traj.B, tree.A), dtype=F32, device=dev)
     value = torch.empty((traj.B,), dtype=F32, device=dev)
     _check(lib().rnad_rollout_run(tree.ptr, C.byref(traj.c), int(W), _dp(packed, F32, "packed"), _dp(logits, F32, "logits"),
-                                  _dp(value, F32, "value"), C.c_uint64(seed), C.c_int64(lane0), _stream()))
+                                  C.c_int64(traj.B * tree.A if keep_logits else 0), _dp(value, F32, "value"), C.c_uint64(seed),
+                                  C.c_int64(lane0), _stream()))
+    return logits if keep_logits else None
 
 
 def rollout_end(tree, traj):

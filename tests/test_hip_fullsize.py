@@ -241,3 +241,30 @@ def test_short_run_follows_the_reference_schedule(tmp_path, monkeypatch):
                net_params={"type": "MLP", "max_actions": 2, "width": 16})
     rn2.initialize()
     assert (rn2.m, rn2.n) == (1, 2) and rn2.eta == 0.2 and rn2.lr == 1e-2
+
+
+def test_on_policy_shortcut_gives_the_same_update(tmp_path, monkeypatch):
+    """RNaD.reuse_actor_outputs: the rollout's logits / values ARE the learner's forward outputs -> identical parameters."""
+    from environment.episode import Buffer
+    from environment.tree import Tree
+    from learn.rnad import RNaD
+
+    dev = torch.device("cuda:0")
+    monkeypatch.setenv("RNAD_SAVE_DIR", str(tmp_path))
+    tree = Tree(device=dev, max_actions=3, max_transitions=2, depth_bound=3, transition_threshold=0.2)
+    tree.generate_native(seed=8)
+    out = []
+    for reuse in (False, True):
+        torch.manual_seed(5)
+        rn = RNaD(tree=tree, device=dev, directory_name=f"reuse{int(reuse)}", batch_size=8192, eta=0.2, b1_adam=0.0, lr=1e-3,
+                  net_params={"type": "MLP", "max_actions": 3, "width": 64})
+        rn.initialize()
+        rn.reuse_actor_outputs = reuse
+        buf = Buffer(1)
+        for i in range(3):
+            rn.train_step(buf, alpha=0.3 * i)
+            rn.total_steps += 1
+        assert (rn.last_episodes.actor_logits is not None) == reuse
+        out.append([p.detach().clone() for p in rn.net.parameters()] + [p.detach().clone() for p in rn.net_target.parameters()])
+    for a, b in zip(*out):
+        assert torch.equal(a, b)
