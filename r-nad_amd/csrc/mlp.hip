@@ -13,12 +13,12 @@
 //   C[hidden, sample] = W0aug[hidden, k] * Xaug[k, sample]     M = 32 hidden units, N = 32 samples, K = 2 per MFMA
 //   A operand  lane l: W0aug[tile*32 + (l & 31)][2*ks + (l >> 5)]   from LDS ([k][2W] layout: conflict-free)
 //   B operand  lane l: x[sample0 + (l & 31)][2*ks + (l >> 5)]       one VGPR per k-step, loaded once per 32 samples
-//   the bias rides along as feature k = K (x = 1), feature K + 1 is zero padding -> (K + 2) / 2 MFMAs per tile
+//   the first-layer bias is the accumulator's initial value (row K of the LDS image) -> K / 2 MFMAs per tile
 //   C layout   lane l holds sample (l & 31) and hidden rows (r & 3) + 8 (r >> 2) + 4 (l >> 5), r in [0, 16):
 //              four consecutive hidden units per register quad -> relu, then the second layer as VALU FMAs against
 //              float4 reads of W1 from LDS; the two half-waves hold complementary rows and are summed with one DPP add.
 // Both heads share the B operand; a wave walks 2 * W / 32 hidden tiles per 32 samples.  Matrix-pipe time per sample
-// tile = 2 * (W / 32) * (K / 2 + 1) * 64 cycles; 3 waves per SIMD hide the epilogue VALU work under other waves' MFMAs.
+// tile = 2 * (W / 32) * (K / 2) * 64 cycles.
 #include "common.hpp"
 
 #include <algorithm>
@@ -30,6 +30,10 @@ namespace {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int kThreads = 256;
+#ifndef RNAD_MLP_FWD_THREADS
+#define RNAD_MLP_FWD_THREADS 256
+#endif
+constexpr int kFwdThreads = RNAD_MLP_FWD_THREADS;  // forward block size: waves of one block share one LDS weight image
 constexpr int kTile = 32;  // samples per wave-tile and hidden units per MFMA tile
 constexpr int kB1Pad = 12;  // floats reserved for the 1 + A output biases at the end of the packed image (multiple of 4)
 
@@ -47,11 +51,22 @@ __device__ __forceinline__ float load_obs<__half>(const __half *p) { return __ha
 // relu / second-layer VALU epilogue of the current pair.  (Measured on gfx950: fp32 MFMA and fp32 VALU work do NOT
 // overlap -- kernel time is the sum of the two -- so what counts is the VALU instruction count of the epilogue: built
 // with -mllvm -amdgpu-mfma-vgpr-form (no v_accvgpr_read) and -fno-honor-nans (no canonicalising v_max before relu).)
-template <int A, int KS>
-__device__ __forceinline__ f32x16 mfma_chain(const float *__restrict__ wa, int W2, int half, const float (&xk)[KS]) {
-    f32x16 c = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+// z tile = b0 + W0 x.  The accumulator starts as the first-layer bias of this lane's 16 hidden rows -- four broadcast float4
+// reads of the bias row (row K) of the LDS image, no VALU work -- then K / 2 MFMAs walk the input features: one MFMA fewer
+// per tile than carrying the bias as an extra k-step.  `wt` points at column 0 of the hidden tile in w0.
+template <int A>
+__device__ __forceinline__ f32x16 mfma_chain(const float *__restrict__ wt, int W2, int col, int half, const float (&xk)[A * A]) {
+    constexpr int K = 2 * A * A;
+    const float *brow = wt + K * W2 + 4 * half;
+    f32x16 c;
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) c = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[(2 * ks + half) * W2], xk[ks], c, 0, 0, 0);
+    for (int g = 0; g < 4; ++g) {
+        const float4 b = *reinterpret_cast<const float4 *>(brow + 8 * g);
+        c[4 * g + 0] = b.x; c[4 * g + 1] = b.y; c[4 * g + 2] = b.z; c[4 * g + 3] = b.w;
+    }
+    const float *wa = wt + col;
+#pragma unroll
+    for (int ks = 0; ks < A * A; ++ks) c = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[(2 * ks + half) * W2], xk[ks], c, 0, 0, 0);
     return c;
 }
 
@@ -92,11 +107,11 @@ __device__ __forceinline__ void epilogue_policy(const f32x16 &c, const float *__
     for (int a = 0; a < A; ++a) acc[a] += (p[a][0] + p[a][1]) + (p[a][2] + p[a][3]);
 }
 
-template <int A, typename ObsT, int HEADS, bool PINGPONG>
-__global__ __launch_bounds__(kThreads) void k_mlp_forward(int64_t N, int W, const float *__restrict__ packed,
+template <int A, typename ObsT, int HEADS>
+__global__ __launch_bounds__(kFwdThreads) void k_mlp_forward(int64_t N, int W, const float *__restrict__ packed,
                                                           const ObsT *__restrict__ obs, float *__restrict__ logits,
                                                           float *__restrict__ value) {
-    constexpr int K = 2 * A * A, KS = K / 2 + 1;  // k-steps incl. the bias step
+    constexpr int K = 2 * A * A, KS = K / 2;  // MFMA k-steps per hidden tile
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int W2 = 2 * W;
     float *w0 = lds;                    // [(K + 2)][2W]
@@ -106,7 +121,7 @@ __global__ __launch_bounds__(kThreads) void k_mlp_forward(int64_t N, int W, cons
         const int n4 = ((K + 2) * W2 + (1 + A) * W + kB1Pad) / 4;
         const float4 *src = reinterpret_cast<const float4 *>(packed);
         float4 *dst = reinterpret_cast<float4 *>(lds);
-        for (int i = threadIdx.x; i < n4; i += kThreads) dst[i] = src[i];
+        for (int i = threadIdx.x; i < n4; i += kFwdThreads) dst[i] = src[i];
     }
     __syncthreads();
 
@@ -124,13 +139,12 @@ __global__ __launch_bounds__(kThreads) void k_mlp_forward(int64_t N, int W, cons
     const int stride0 = HEADS == 3 ? 1 : 2, off1 = HEADS == 3 ? T : 1;
 
     const int64_t n_tiles = (N + kTile - 1) / kTile;
-    for (int64_t tile = (int64_t)blockIdx.x * (kThreads / 64) + wave; tile < n_tiles; tile += (int64_t)gridDim.x * (kThreads / 64)) {
+    for (int64_t tile = (int64_t)blockIdx.x * (kFwdThreads / 64) + wave; tile < n_tiles; tile += (int64_t)gridDim.x * (kFwdThreads / 64)) {
         const int64_t sample = tile * kTile + col;
         const bool live = sample < N;
         float xk[KS];
 #pragma unroll
-        for (int ks = 0; ks < KS - 1; ++ks) xk[ks] = live ? load_obs<ObsT>(obs + sample * K + 2 * ks + half) : 0.0f;
-        xk[KS - 1] = half == 0 ? 1.0f : 0.0f;  // bias feature, zero pad
+        for (int ks = 0; ks < KS; ++ks) xk[ks] = live ? load_obs<ObsT>(obs + sample * K + 2 * ks + half) : 0.0f;
 
         float acc_v = 0.0f, acc_p[A];
 #pragma unroll
@@ -150,28 +164,12 @@ __global__ __launch_bounds__(kThreads) void k_mlp_forward(int64_t N, int W, cons
                 epilogue_policy<A>(d1, w1p + (e1 - T) * kTile + 4 * half, W, acc_p);
             }
         };
-        auto chain = [&](int t) { return mfma_chain<A, KS>(w0 + t * kTile + col, W2, half, xk); };
+        auto chain = [&](int t) { return mfma_chain<A>(w0 + t * kTile, W2, col, half, xk); };
         int t0 = first;
-        if (PINGPONG) {
-            // n_pairs is even: two accumulator sets alternate, so the matrix work of pair p + 1 is issued before the VALU
-            // epilogue of pair p without any register copies
-            f32x16 a0 = chain(t0), a1 = chain(t0 + off1);
-            for (int p = 0; p < n_pairs; p += 2) {
-                const f32x16 b0 = chain(t0 + stride0), b1 = chain(t0 + stride0 + off1);
-                finish(a0, a1, t0);
-                if (p + 2 < n_pairs) {
-                    a0 = chain(t0 + 2 * stride0);
-                    a1 = chain(t0 + 2 * stride0 + off1);
-                }
-                finish(b0, b1, t0 + stride0);
-                t0 += 2 * stride0;
-            }
-        } else {
-            for (int p = 0; p < n_pairs; ++p) {
-                const f32x16 c0 = chain(t0), c1 = chain(t0 + off1);
-                finish(c0, c1, t0);
-                t0 += stride0;
-            }
+        for (int p = 0; p < n_pairs; ++p) {
+            const f32x16 c0 = chain(t0), c1 = chain(t0 + off1);
+            finish(c0, c1, t0);
+            t0 += stride0;
         }
         // the two half-waves hold complementary hidden rows of the same 32 samples
         if (HEADS & 1) acc_v += __shfl_xor(acc_v, 32, 64);
@@ -206,7 +204,7 @@ template <int A, typename ObsT, int MAXT>
 __global__ __launch_bounds__(MAXT) void k_mlp_backward(int64_t N, int W, const float *__restrict__ packed,
                                                        const ObsT *__restrict__ obs, const float *__restrict__ dlogit,
                                                        const float *__restrict__ dv, float *__restrict__ partial, int P) {
-    constexpr int K = 2 * A * A, KS = K / 2 + 1;
+    constexpr int K = 2 * A * A, KS = K / 2;
     constexpr int FT = (K + 1 + kTile - 1) / kTile;  // 32-wide feature tiles of the augmented input (x | 1)
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int W2 = 2 * W, nthreads = blockDim.x;
@@ -252,8 +250,7 @@ __global__ __launch_bounds__(MAXT) void k_mlp_backward(int64_t N, int W, const f
         const bool live = sample < N;
         float xk[KS];   // B operand of the forward product: x[sample = col][2 ks + half]
 #pragma unroll
-        for (int ks = 0; ks < KS - 1; ++ks) xk[ks] = live ? load_obs<ObsT>(obs + sample * K + 2 * ks + half) : 0.0f;
-        xk[KS - 1] = half == 0 ? 1.0f : 0.0f;
+        for (int ks = 0; ks < KS; ++ks) xk[ks] = live ? load_obs<ObsT>(obs + sample * K + 2 * ks + half) : 0.0f;
         float xt[FT][16];   // B operand of the weight-gradient product: xaug[sample = 2 ks + half][feature = 32 ft + col]
 #pragma unroll
         for (int ft = 0; ft < FT; ++ft) {
@@ -276,7 +273,7 @@ __global__ __launch_bounds__(MAXT) void k_mlp_backward(int64_t N, int W, const f
 
         // ---------------- value head, hidden tile `tile_v`
         {
-            const f32x16 c = mfma_chain<A, KS>(w0 + tile_v * kTile + col, W2, half, xk);
+            const f32x16 c = mfma_chain<A>(w0 + tile_v * kTile, W2, col, half, xk);
             const float *w1 = w1v + tile_v * kTile + 4 * half;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
@@ -301,7 +298,7 @@ __global__ __launch_bounds__(MAXT) void k_mlp_backward(int64_t N, int W, const f
         }
         // ---------------- policy head, hidden tile `tile_p`
         {
-            const f32x16 c = mfma_chain<A, KS>(w0 + tile_p * kTile + col, W2, half, xk);
+            const f32x16 c = mfma_chain<A>(w0 + tile_p * kTile, W2, col, half, xk);
             const float *w1 = w1p + own * kTile + 4 * half;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
@@ -466,20 +463,19 @@ extern "C" int rnad_mlp_forward(int64_t N, int A, int W, const float *packed, co
     int dev = 0, cus = 256;
     RNAD_HIP_OK(hipGetDevice(&dev));
     RNAD_HIP_OK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-    const int blocks_per_cu = std::max(1, std::min(3, (int)(160 * 1024 / lds_bytes)));
+    constexpr int kWaves = kFwdThreads / 64;
+    const int blocks_per_cu = std::max(1, std::min(12 / kWaves, (int)(160 * 1024 / lds_bytes)));
     const int64_t n_tiles = (N + kTile - 1) / kTile;
-    const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>((n_tiles + 3) / 4, (int64_t)cus * blocks_per_cu));
+    const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>((n_tiles + kWaves - 1) / kWaves, (int64_t)cus * blocks_per_cu));
     int heads = (value ? 1 : 0) | (logits ? 2 : 0);
     if ((W / kTile) % 2) heads = 3;  // odd tile count: the paired single-head kernels do not apply; compute both, store the wanted one
-    const int n_pairs = heads == 3 ? W / kTile : W / kTile / 2;
-    const bool pingpong = heads == 3 && n_pairs % 2 == 0;  // measured: +3.5 % for the two-head launch, -20 % for single-head ones
     ProfScope prof(PROF_MLP, stream);
 #define RNAD_MLP_LAUNCH2(T_, H_)                                                                                                  \
     do {                                                                                                                           \
-        auto kern = pingpong ? k_mlp_forward<kA, T_, H_, true> : k_mlp_forward<kA, T_, H_, false>;                                 \
+        auto kern = k_mlp_forward<kA, T_, H_>;                                                                                     \
         if (lds_bytes > 64 * 1024)                                                                                                 \
             RNAD_HIP_OK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));      \
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(kThreads), lds_bytes, stream, N, W, packed, (const T_ *)obs, logits, value);            \
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(kFwdThreads), lds_bytes, stream, N, W, packed, (const T_ *)obs, logits, value);            \
                                                                         \
     } while (0)
 #define RNAD_MLP_LAUNCH(T_)                                   \

@@ -33,7 +33,7 @@ def timeit(fn):
     return (time.perf_counter() - t) / reps * 1e3
 
 
-fwd_flop = 2.0 * N * (K + 2) * 2 * W  # executed MFMA flops (bias k-step included)
+fwd_flop = 2.0 * N * K * 2 * W  # executed MFMA flops of the first layer, both heads
 bwd_flop = fwd_flop + 2.0 * N * 32 * 2 * W  # recompute + dW0 with the feature tile padded to 32
 packed = rnad_hip.mlp_pack(w, A)
 ms = timeit(lambda: rnad_hip.mlp_forward(packed, W, x, A))
