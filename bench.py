@@ -150,9 +150,9 @@ def main():
         k1_avg_s = obs_ms / 1e3 / max(n_obs, 1)
         achieved = k1_bytes_per_launch / k1_avg_s / 1e9 if n_obs else 0.0
         learn_bytes = (69 + 16) * local_batch * T if A == 3 else None
-        # fused MLP: flops the matrix cores execute per sample (first layer incl. the bias k-step, both heads)
+        # fused MLP: flops the matrix cores execute per sample (first layer, both heads; relu + second layer run on the VALU)
         K = 2 * A * A
-        mlp_flops_per_sample = 2.0 * (K + 2) * 2 * args.width
+        mlp_flops_per_sample = 2.0 * K * 2 * args.width
         # per step: T rollout forwards of B + learner fwd (1) + target value head (.5) + 2 reg policy heads (1) of T*B samples
         mlp_fwd_flops_per_step = mlp_flops_per_sample * local_batch * T * (1 + 1 + 0.5 + 1)
         mlp_tflops = mlp_fwd_flops_per_step / (mlp_ms / args.steps / 1e3) / 1e12 if n_mlp else None

@@ -268,3 +268,57 @@ def test_on_policy_shortcut_gives_the_same_update(tmp_path, monkeypatch):
         out.append([p.detach().clone() for p in rn.net.parameters()] + [p.detach().clone() for p in rn.net_target.parameters()])
     for a, b in zip(*out):
         assert torch.equal(a, b)
+
+
+def test_run_replays_the_reference_run_given_its_noise(tmp_path, monkeypatch):
+    """The reference's recorded 6-step RNaD.run (tests/golden/run_c1.npz): same initial weights + the Exp(1) noise it consumed
+    -> the same rollouts, the same gradients and the same nets after Adam / EMA / rotation, step by step."""
+    import environment.episode as episode
+    from _gpu import DEV, golden_tree, gpu
+    from learn.rnad import RNaD
+
+    g = load("run_c1")
+    tree, _ = golden_tree("c1")
+    monkeypatch.setenv("RNAD_SAVE_DIR", str(tmp_path))
+    keys = ("value_fc0.weight", "value_fc0.bias", "value_fc1.weight", "value_fc1.bias", "policy_fc0.weight", "policy_fc0.bias",
+            "policy_fc1.weight", "policy_fc1.bias")
+    sd = lambda prefix: {k: gpu(g[prefix + k.replace(".", "_")]) for k in keys}  # noqa: E731
+    rn = RNaD(tree=tree, device=DEV, directory_name="replay", batch_size=int(g["batch"]), eta=0.2, bounds=[2], delta_m=[3], lr=1e-2,
+              gamma_averaging=0.1, b1_adam=0.0, net_params={"type": "MLP", "max_actions": 2, "width": 16})
+    rn.initialize()
+    for n in (rn.net, rn.net_target, rn.net_reg, rn.net_reg_):  # the reference's initial net (all four start equal, rnad.py:226-231)
+        n.load_state_dict(sd("w0_"))
+    step = {"i": 0}
+    real_generate = episode.Episodes.generate
+
+    def generate_with_reference_noise(self, net, **kw):
+        i = step["i"]
+        real_generate(self, net, noise_action=gpu(g[f"s{i}_noise_action"]), noise_chance=gpu(g[f"s{i}_noise_chance"]), trim=False)
+        T = g[f"s{i}_indices"].shape[0]
+        same = (self.indices[:T].cpu().numpy() == g[f"s{i}_indices"]).all(0) & (self.action_idx[:T].cpu().numpy() == g[f"s{i}_actions"].argmax(-1)).all(0)
+        step.setdefault("same", []).append(same.mean())
+        if i == 0:  # identical weights in -> the identical episode batch out
+            assert same.all()
+            assert_bits_equal(self.rewards[:T].cpu().numpy(), g["s0_rewards"], "rewards")
+
+    monkeypatch.setattr(episode.Episodes, "generate", generate_with_reference_noise)
+    real_step = rn.train_step
+
+    def checked_step(buffer, alpha, log=None):
+        i = step["i"]
+        assert (rn.m, rn.n) == tuple(g[f"s{i}_mn"]) and alpha == pytest.approx(float(g[f"s{i}_alpha"]))
+        real_step(buffer, alpha, log=log)
+        for tag, net in (("net", rn.net), ("net_target", rn.net_target), ("net_reg", rn.net_reg), ("net_reg_", rn.net_reg_)):
+            for k, p in net.state_dict().items():
+                want = g[f"s{i}_{tag}_" + k.replace(".", "_")]
+                close = np.isclose(p.detach().cpu().numpy(), want, rtol=1e-4, atol=2e-5)
+                assert close.mean() >= (1.0 if i == 0 else 0.97), (i, tag, k, close.mean())
+        step["i"] += 1
+
+    rn.train_step = checked_step
+    rn._RNaD__resume(checkpoint_mod=10**9, expl_mod=10**9, log_mod=10**9)
+    assert step["i"] == 6 and min(step["same"]) > 0.9
+    for tag, net in (("net", rn.net), ("target", rn.net_target), ("reg", rn.net_reg), ("reg_", rn.net_reg_)):  # after the last rotation
+        for k, p in net.state_dict().items():
+            close = np.isclose(p.detach().cpu().numpy(), g[f"final_{tag}_" + k.replace(".", "_")], rtol=1e-4, atol=2e-5)
+            assert close.mean() >= 0.97, (tag, k, close.mean())
