@@ -272,11 +272,13 @@ int64_t rnad_tree_generate(int A, int C, int depth_bound, float transition_thres
 int rnad_solve_matrix(const float *M, int ra, int ca, int max_actions, float *solution, float *value);
 
 /* ------------------------------------------------------------------------------------------------
- * Kernel timing (bench.py's roofline leg): when enabled, every launch of kernel `which`
- * (0 = observe, 1 = act/transition, 2 = learn_fused, 3 = mlp_forward, 4 = mlp_backward) is bracketed by hipEvents on its own stream.
- * rnad_prof_read synchronises the device and returns launches and total milliseconds since reset.
+ * Kernel timing (bench.py's roofline leg): rnad_prof_enable(mask) brackets every launch of kernel k with a pair of
+ * hipEvents on the launching stream when bit (1 << k) of `mask` is set (k: 0 = observe, 1 = act/transition,
+ * 2 = learn_fused, 3 = mlp_forward, 4 = mlp_backward; -1 = all, 0 = off) and drops earlier measurements.  Each
+ * bracket costs a few microseconds of dispatch latency, so bracket only what is being measured.
+ * rnad_prof_read synchronises the device and returns launches and total milliseconds since the last enable.
  * ---------------------------------------------------------------------------------------------- */
-int rnad_prof_enable(int on);
+int rnad_prof_enable(int mask);
 int rnad_prof_read(int which, int64_t *launches, double *total_ms);
 
 #pragma GCC visibility pop

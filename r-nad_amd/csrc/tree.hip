@@ -22,14 +22,14 @@ void set_error(const char *fmt, ...) {
 }
 
 // ---------------------------------------------------------------------------------------- profiling
-static bool g_prof_on = false;
+static unsigned g_prof_mask = 0;  // bit k: bracket launches of kernel k with events
 struct ProfPair {
     hipEvent_t a, b;
 };
 static std::vector<ProfPair> g_prof[PROF_COUNT];
 
 ProfScope::ProfScope(int which_, hipStream_t stream_) : which(which_), stream(stream_) {
-    if (!g_prof_on) return;
+    if (!((g_prof_mask >> which_) & 1u)) return;
     if (hipEventCreate(&start) != hipSuccess) {
         start = nullptr;
         return;
@@ -52,7 +52,7 @@ using namespace rnad;
 extern "C" const char *rnad_last_error(void) { return g_error.c_str(); }
 extern "C" int rnad_version(void) { return 1; }
 
-extern "C" int rnad_prof_enable(int on) {
+extern "C" int rnad_prof_enable(int on /* bit mask, -1 = all */) {
     for (auto &v : g_prof) {
         for (auto &p : v) {
             (void)hipEventDestroy(p.a);
@@ -60,7 +60,7 @@ extern "C" int rnad_prof_enable(int on) {
         }
         v.clear();
     }
-    g_prof_on = on != 0;
+    g_prof_mask = (unsigned)on;
     return 0;
 }
 

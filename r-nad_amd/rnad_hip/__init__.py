@@ -404,7 +404,14 @@ PROF_OBSERVE, PROF_ACT, PROF_LEARN, PROF_MLP, PROF_MLP_BWD = 0, 1, 2, 3, 4
 
 
 def prof_enable(on):
-    _check(lib().rnad_prof_enable(int(bool(on))))
+    """True: bracket every kernel; False: off; or an iterable of PROF_* ids to bracket only those."""
+    if on is True:
+        mask = -1
+    elif not on:
+        mask = 0
+    else:
+        mask = sum(1 << int(k) for k in on)
+    _check(lib().rnad_prof_enable(mask))
 
 
 def prof_read(which):
