@@ -322,3 +322,21 @@ def test_run_replays_the_reference_run_given_its_noise(tmp_path, monkeypatch):
         for k, p in net.state_dict().items():
             close = np.isclose(p.detach().cpu().numpy(), g[f"final_{tag}_" + k.replace(".", "_")], rtol=1e-4, atol=2e-5)
             assert close.mean() >= 0.97, (tag, k, close.mean())
+
+
+def test_main_script_runs_like_the_reference_driver(tmp_path):
+    """r-nad_amd/main.py == reference main.py's call pattern (Tree(...).generate/save, RNaD(...).run for several etas)."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.realpath(__file__)))
+    env = dict(os.environ, RNAD_SAVE_DIR=str(tmp_path))
+    out = subprocess.run([sys.executable, os.path.join(root, "r-nad_amd", "main.py"), "--updates", "3", "--steps", "20", "--etas", "0", "0.2"],
+                         env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("eta=")]
+    assert len(lines) == 2 and all("NashConv by update" in ln for ln in lines)
+    assert (tmp_path / "saved_trees" / "small_tree" / "tree.tar").exists()
+    runs = sorted(p.name for p in (tmp_path / "saved_runs").iterdir())
+    assert len(runs) == 2 and runs[0].endswith("eta=0.0") or runs[0].endswith("eta=0")
