@@ -88,6 +88,7 @@ def main():
     rn = RNaD(tree=tree, device=device, directory_name=f"bench-r{rank}", batch_size=global_batch, eta=0.2, b1_adam=0.0,
               net_params={"type": "MLP", "max_actions": A, "width": args.width})
     rn.initialize()
+    rn.obs_half = args.obs_half
     buffer = Buffer(rn.n_batches_per_buffer)
     delta_m = 10_000
 
@@ -140,7 +141,7 @@ def main():
     fence()
     t_r = time.perf_counter()
     for i in range(args.steps):
-        Episodes(tree, local_batch, seed=1000 + i, lane_offset=rank * local_batch).generate(rn.net)
+        Episodes(tree, local_batch, seed=1000 + i, lane_offset=rank * local_batch, obs_half=args.obs_half).generate(rn.net)
     fence()
     rollout_s = time.perf_counter() - t_r
     if world > 1:

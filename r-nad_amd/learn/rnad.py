@@ -122,6 +122,7 @@ class RNaD:
         # rollout that just finished, with unchanged weights, so forward_batch(net) (rnad.py:373) recomputes bit-identical
         # logits / values; when True they are taken from the rollout and only the backward runs.
         self.reuse_actor_outputs = False
+        self.obs_half = False  # store observations as fp16 (BASELINE.json configs[4]); arithmetic stays fp32
         self.nashconv_history = []  # (m, total_steps, nashconv)
 
     # ------------------------------------------------------------------ data-parallel helpers
@@ -360,7 +361,8 @@ class RNaD:
         world, rank = self._world, self._rank
         local_batch = self.batch_size // world
         if self.total_steps % self.buffer_mod == 0:
-            episodes = episode.Episodes(self.tree, local_batch, seed=self._new_seed(), lane_offset=rank * local_batch)
+            episodes = episode.Episodes(self.tree, local_batch, seed=self._new_seed(), lane_offset=rank * local_batch,
+                                        obs_half=getattr(self, "obs_half", False))
             # no host sync: trailing all-absorbed steps are masked by `valid`
             episodes.generate(self.net, trim=False, keep_logits=self.reuse_actor_outputs)
             episodes._actor_tag = (id(self.net), self.total_steps)
