@@ -139,6 +139,10 @@ def make_tree(name):
     meta = dict(seed=spec["seed"], kw=spec["kw"], depth_lambda=spec.get("depth_lambda"),
                 row_lambda=spec.get("row_lambda"), col_lambda=spec.get("col_lambda"),
                 hash=tree.hash, size=int(tree.value_tensor.shape[0]))
+    if name == "c1":
+        # the reference's own on-disk format (Tree.save, tree.py:385-415): kept as a data fixture for the loader test
+        tree.save("golden_c1")
+        shutil.copy(os.path.join(REF, "saved_trees", "golden_c1", "tree.tar"), os.path.join(HERE, "ref_tree_c1.tar"))
     save(
         "tree_" + name,
         index=tree.index_tensor, value=tree.value_tensor, chance=tree.chance_tensor,
@@ -472,10 +476,14 @@ def make_run(tree):
 
     rn._RNaD__initialize = init_then_hook
     try:
-        rn.run(checkpoint_mod=10**9, expl_mod=10**9, log_mod=10**9)
+        rn.run(checkpoint_mod=3, expl_mod=10**9, log_mod=10**9)
     finally:
         ref_episode.Episodes.generate = gen
         ref_episode.Episodes.sample = samp
+    # the reference's checkpoint files of this run (rnad.py:208-209, :307-319) as data fixtures for the resume test
+    run_dir = os.path.join(REF, "saved_runs", "golden")
+    shutil.copy(os.path.join(run_dir, "params"), os.path.join(HERE, "ref_run_params"))
+    shutil.copy(os.path.join(run_dir, "1", "0"), os.path.join(HERE, "ref_run_ckpt_1_0"))
     final = {f"final_{tag}_{k.replace('.', '_')}": v.detach().numpy().copy()
              for tag, net in (("net", rn.net), ("target", rn.net_target), ("reg", rn.net_reg), ("reg_", rn.net_reg_))
              for k, v in net.state_dict().items()}

@@ -122,3 +122,56 @@ def test_native_generator_solution_is_a_nash_equilibrium():
                                            t.legal_tensor.numpy(), sol[1], sol)
     assert abs(rb[1] + cb[1]) < 1e-5
     assert abs(rb[1] - t.root_value_tensor[1, 0].item()) < 1e-5
+
+
+def test_loads_a_tree_file_written_by_the_reference(tmp_path, monkeypatch):
+    """tests/golden/ref_tree_c1.tar is `Tree.save()` of the reference itself (tree.py:385-415): same format, loads directly."""
+    import os
+    import shutil
+
+    from _util import GOLDEN
+
+    monkeypatch.setenv("RNAD_SAVE_DIR", str(tmp_path))
+    os.makedirs(tmp_path / "saved_trees" / "from_reference")
+    shutil.copy(os.path.join(GOLDEN, "ref_tree_c1.tar"), tmp_path / "saved_trees" / "from_reference" / "tree.tar")
+    g = load_tree("c1")
+    t = Tree(max_actions=3, depth_bound=1)  # deliberately a different shape: load() overwrites everything (tree.py:430-432)
+    t.load("from_reference")
+    assert (t.max_actions, t.max_transitions, t.depth_bound, t.hash) == (2, 1, 3, g["meta"]["hash"])
+    for key, tensor in (("index", t.index_tensor), ("value", t.value_tensor), ("chance", t.chance_tensor), ("legal", t.legal_tensor),
+                        ("expected_value", t.expected_value_tensor), ("root_value", t.root_value_tensor), ("solution", t.solution_tensor)):
+        assert_bits_equal(tensor.numpy(), g[key], key)
+    t.assert_index_is_tree()
+
+
+def test_resumes_from_a_checkpoint_written_by_the_reference(tmp_path, monkeypatch):
+    """saved_runs/<dir>/{params, <m>/<n>} as the reference writes them (rnad.py:208-209, :307-319): resuming picks the
+    latest (m, n), restores hyper-parameters, the four nets and the optimizer (rnad.py:243-272)."""
+    import os
+    import shutil
+
+    from _util import GOLDEN, load
+    from learn.rnad import RNaD
+
+    monkeypatch.setenv("RNAD_SAVE_DIR", str(tmp_path))
+    run = tmp_path / "saved_runs" / "from_reference"
+    os.makedirs(run / "1")
+    shutil.copy(os.path.join(GOLDEN, "ref_run_params"), run / "params")
+    shutil.copy(os.path.join(GOLDEN, "ref_run_ckpt_1_0"), run / "1" / "0")
+    tree, tg = build_like_reference("c1")
+    rn = RNaD(tree=tree, device=torch.device("cpu"), directory_name="from_reference", b1_adam=0.0)
+    rn.initialize()
+    g = load("run_c1")
+    assert (rn.m, rn.n, rn.total_steps) == (1, 0, 3)
+    assert (rn.eta, rn.lr, rn.gamma_averaging, rn.batch_size, rn.bounds, rn.delta_m) == (0.2, 1e-2, 0.1, 64, [2], [3])
+    assert rn.net_params == {"type": "MLP", "max_actions": 2, "width": 16} and rn.tree_hash == tree.hash
+    # the checkpoint at (m, n) = (1, 0) holds the nets after step 2 and the rotation at the end of m = 0 (rnad.py:528-531)
+    for tag, net, key in (("net", rn.net, "s2_net_"), ("target", rn.net_target, "s2_net_target_"), ("reg", rn.net_reg, "s2_net_target_"),
+                          ("reg_", rn.net_reg_, "s2_net_reg_")):
+        for k, p in net.state_dict().items():
+            assert_bits_equal(p.numpy(), g[key + k.replace(".", "_")], f"{tag} {k}")
+    assert len(rn.optimizer.state_dict()["state"]) == 8 and rn.optimizer.state_dict()["param_groups"][0]["lr"] == 1e-2
+    # a tree with another hash is refused (rnad.py:256-258)
+    tree.hash += 1
+    with pytest.raises(AssertionError):
+        RNaD(tree=tree, device=torch.device("cpu"), directory_name="from_reference", b1_adam=0.0).initialize()
