@@ -340,3 +340,23 @@ def test_main_script_runs_like_the_reference_driver(tmp_path):
     assert (tmp_path / "saved_trees" / "small_tree" / "tree.tar").exists()
     runs = sorted(p.name for p in (tmp_path / "saved_runs").iterdir())
     assert len(runs) == 2 and runs[0].endswith("eta=0.0") or runs[0].endswith("eta=0")
+
+
+def test_off_policy_replay_buffer_path(tmp_path, monkeypatch):
+    """n_batches_per_buffer = 2, buffer_mod = 2 (reference rnad.py:66-67, :502-507): the learner sees collated samples of older
+    rollouts, so the V-trace importance ratios differ from 1; the update must run and stay finite."""
+    from environment.tree import Tree
+    from learn.rnad import RNaD
+
+    dev = torch.device("cuda:0")
+    monkeypatch.setenv("RNAD_SAVE_DIR", str(tmp_path))
+    tree = Tree(device=dev, max_actions=3, max_transitions=2, depth_bound=3, transition_threshold=0.2)
+    tree.generate_native(seed=9, prune=(1, 3))
+    torch.manual_seed(1)
+    np.random.seed(1)
+    rn = RNaD(tree=tree, device=dev, directory_name="offpolicy", batch_size=2048, eta=0.2, b1_adam=0.0, lr=1e-3, bounds=[1], delta_m=[6],
+              n_batches_per_buffer=2, buffer_mod=2, net_params={"type": "MLP", "max_actions": 3, "width": 64})
+    rn.run(checkpoint_mod=10**9, expl_mod=1, log_mod=1)
+    assert rn.total_steps == 6 and rn.m == 1
+    assert all(torch.isfinite(p).all() for p in rn.net.parameters())
+    assert rn.last_log is not None and np.isfinite(rn.last_log["loss_v"]) and rn.last_log["actor_learner_kld"] >= 0
