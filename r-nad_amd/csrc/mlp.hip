@@ -22,6 +22,7 @@
 #include "common.hpp"
 
 #include <algorithm>
+#include <cstdlib>
 
 using namespace rnad;
 
@@ -37,6 +38,22 @@ constexpr int kFwdThreads = RNAD_MLP_FWD_THREADS;  // forward block size: waves 
 constexpr int kTile = 32;  // samples per wave-tile and hidden units per MFMA tile
 constexpr int kB1Pad = 12;  // floats reserved for the 1 + A output biases at the end of the packed image (multiple of 4)
 
+// Packed weight image (floats), copied verbatim into LDS by every block:
+//   w0t [2T][K/2][2][32]   first-layer weights, hidden tile major: element ((tile * K/2 + ks) * 2 + half) * 32 + col is
+//                          W0[hidden = 32 tile + col][k = 2 ks + half] -- exactly the A operand of MFMA k-step ks for lane
+//                          (col, half), so one base address + immediate offsets ks * 256 B serve a whole chain
+//   b0  [2W]               first-layer biases (value head | policy head)
+//   w1v [W], w1p [A][W]    second-layer weights
+//   b1  [1 + A] (pad 12)   second-layer biases
+// T = W / 32 hidden tiles per head; tiles 0..T-1 = value head, T..2T-1 = policy head.
+__host__ __device__ constexpr int img_b0(int K, int W) { return 2 * W * K; }
+__host__ __device__ constexpr int img_w1v(int K, int W) { return img_b0(K, W) + 2 * W; }
+__host__ __device__ constexpr int img_w1p(int K, int W) { return img_w1v(K, W) + W; }
+__host__ __device__ constexpr int img_b1(int K, int W, int A) { return img_w1p(K, W) + A * W; }
+__host__ __device__ constexpr int img_floats(int K, int W, int A) { return img_b1(K, W, A) + kB1Pad; }
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
 template <typename T>
 __device__ __forceinline__ float load_obs(const T *p);
 template <>
@@ -51,84 +68,76 @@ __device__ __forceinline__ float load_obs<__half>(const __half *p) { return __ha
 // relu / second-layer VALU epilogue of the current pair.  (Measured on gfx950: fp32 MFMA and fp32 VALU work do NOT
 // overlap -- kernel time is the sum of the two -- so what counts is the VALU instruction count of the epilogue: built
 // with -mllvm -amdgpu-mfma-vgpr-form (no v_accvgpr_read) and -fno-honor-nans (no canonicalising v_max before relu).)
-// z tile = b0 + W0 x.  The accumulator starts as the first-layer bias of this lane's 16 hidden rows -- four broadcast float4
-// reads of the bias row (row K) of the LDS image, no VALU work -- then K / 2 MFMAs walk the input features: one MFMA fewer
-// per tile than carrying the bias as an extra k-step.  `wt` points at column 0 of the hidden tile in w0.
+// z tile = b0 + W0 x.  The accumulator starts as the first-layer bias of this lane's 16 hidden rows (four broadcast float4
+// reads, no VALU work), then K / 2 MFMAs walk the input features; their A operands are loaded up front from one base
+// address with immediate offsets.
 template <int A>
-__device__ __forceinline__ f32x16 mfma_chain(const float *__restrict__ wt, int W2, int col, int half, const float (&xk)[A * A]) {
-    constexpr int K = 2 * A * A;
-    const float *brow = wt + K * W2 + 4 * half;
+__device__ __forceinline__ f32x16 mfma_chain(const float *__restrict__ lds, int W, int tile, int col, int half, const float (&xk)[A * A]) {
+    constexpr int K = 2 * A * A, KS = A * A;
+    const float *wa = lds + tile * (KS * 64) + half * 32 + col;
+    const float *brow = lds + img_b0(K, W) + tile * kTile + 4 * half;
+    float a[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) a[ks] = wa[ks * 64];
     f32x16 c;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
         const float4 b = *reinterpret_cast<const float4 *>(brow + 8 * g);
         c[4 * g + 0] = b.x; c[4 * g + 1] = b.y; c[4 * g + 2] = b.z; c[4 * g + 3] = b.w;
     }
-    const float *wa = wt + col;
 #pragma unroll
-    for (int ks = 0; ks < A * A; ++ks) c = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[(2 * ks + half) * W2], xk[ks], c, 0, 0, 0);
+    for (int ks = 0; ks < KS; ++ks) c = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ks], xk[ks], c, 0, 0, 0);
     return c;
 }
 
-// Second layer for one 32x32 hidden tile.  Four independent partial sums per output keep the fma chains short;
-// explicit fmaf: the summation order here is this kernel's own (nothing in the reference fixes it).
-__device__ __forceinline__ void epilogue_value(const f32x16 &c, const float *__restrict__ w1, float &acc) {
-    float p[4] = {0.f, 0.f, 0.f, 0.f};
+__device__ __forceinline__ f32x2 relu2(float a, float b) { return f32x2{fmaxf(a, 0.0f), fmaxf(b, 0.0f)}; }
+
+// Second layer for one 32x32 hidden tile, written on float pairs so that it compiles to v_pk_fma_f32 without register
+// shuffles (fp32 MFMA and VALU work do not overlap on gfx950: every VALU instruction here is kernel time).  The summation
+// order is this kernel's own; nothing in the reference fixes it.
+__device__ __forceinline__ void epilogue_value(const f32x16 &c, const float *__restrict__ w1, f32x2 (&acc)[2]) {
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
         const float4 w = *reinterpret_cast<const float4 *>(w1 + 8 * g);
-        p[0] = fmaf(w.x, fmaxf(c[4 * g + 0], 0.0f), p[0]);
-        p[1] = fmaf(w.y, fmaxf(c[4 * g + 1], 0.0f), p[1]);
-        p[2] = fmaf(w.z, fmaxf(c[4 * g + 2], 0.0f), p[2]);
-        p[3] = fmaf(w.w, fmaxf(c[4 * g + 3], 0.0f), p[3]);
+        acc[0] = __builtin_elementwise_fma(f32x2{w.x, w.y}, relu2(c[4 * g + 0], c[4 * g + 1]), acc[0]);
+        acc[1] = __builtin_elementwise_fma(f32x2{w.z, w.w}, relu2(c[4 * g + 2], c[4 * g + 3]), acc[1]);
     }
-    acc += (p[0] + p[1]) + (p[2] + p[3]);
 }
 
 template <int A>
-__device__ __forceinline__ void epilogue_policy(const f32x16 &c, const float *__restrict__ w1, int W, float (&acc)[A]) {
-    float p[A][4];
-#pragma unroll
-    for (int a = 0; a < A; ++a) p[a][0] = p[a][1] = p[a][2] = p[a][3] = 0.0f;
+__device__ __forceinline__ void epilogue_policy(const f32x16 &c, const float *__restrict__ w1, int W, f32x2 (&acc)[A][2]) {
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-        const float h0 = fmaxf(c[4 * g + 0], 0.0f), h1 = fmaxf(c[4 * g + 1], 0.0f);
-        const float h2 = fmaxf(c[4 * g + 2], 0.0f), h3 = fmaxf(c[4 * g + 3], 0.0f);
+        const f32x2 h01 = relu2(c[4 * g + 0], c[4 * g + 1]), h23 = relu2(c[4 * g + 2], c[4 * g + 3]);
 #pragma unroll
         for (int a = 0; a < A; ++a) {
             const float4 w = *reinterpret_cast<const float4 *>(w1 + a * W + 8 * g);
-            p[a][0] = fmaf(w.x, h0, p[a][0]);
-            p[a][1] = fmaf(w.y, h1, p[a][1]);
-            p[a][2] = fmaf(w.z, h2, p[a][2]);
-            p[a][3] = fmaf(w.w, h3, p[a][3]);
+            acc[a][0] = __builtin_elementwise_fma(f32x2{w.x, w.y}, h01, acc[a][0]);
+            acc[a][1] = __builtin_elementwise_fma(f32x2{w.z, w.w}, h23, acc[a][1]);
         }
     }
-#pragma unroll
-    for (int a = 0; a < A; ++a) acc[a] += (p[a][0] + p[a][1]) + (p[a][2] + p[a][3]);
 }
 
 template <int A, typename ObsT, int HEADS>
 __global__ __launch_bounds__(kFwdThreads) void k_mlp_forward(int64_t N, int W, const float *__restrict__ packed,
-                                                          const ObsT *__restrict__ obs, float *__restrict__ logits,
-                                                          float *__restrict__ value) {
+                                                             const ObsT *__restrict__ obs, float *__restrict__ logits,
+                                                             float *__restrict__ value) {
     constexpr int K = 2 * A * A, KS = K / 2;  // MFMA k-steps per hidden tile
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int W2 = 2 * W;
-    float *w0 = lds;                    // [(K + 2)][2W]
-    float *w1v = lds + (K + 2) * W2;    // [W]
-    float *w1p = w1v + W;               // [A][W]
-    {   // weights: one coalesced 16-byte copy of the image rnad_mlp_pack laid out (w0 | w1v | w1p | b1)
-        const int n4 = ((K + 2) * W2 + (1 + A) * W + kB1Pad) / 4;
+    {   // weights: one coalesced 16-byte copy of the image rnad_mlp_pack laid out
+        const int n4 = img_floats(K, W, A) / 4;
         const float4 *src = reinterpret_cast<const float4 *>(packed);
         float4 *dst = reinterpret_cast<float4 *>(lds);
         for (int i = threadIdx.x; i < n4; i += kFwdThreads) dst[i] = src[i];
     }
     __syncthreads();
+    const float *w1v = lds + img_w1v(K, W);
+    const float *w1p = lds + img_w1p(K, W);
+    const float *b1 = lds + img_b1(K, W, A);  // [1 + A]: value_fc1.bias, policy_fc1.bias
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int col = lane & 31, half = lane >> 5;
     const int T = W / kTile;  // hidden tiles per head
-    const float *b1 = w1p + A * W;  // [1 + A]: value_fc1.bias, policy_fc1.bias
     const float bv = b1[0];
     float bp[A];
 #pragma unroll
@@ -146,42 +155,41 @@ __global__ __launch_bounds__(kFwdThreads) void k_mlp_forward(int64_t N, int W, c
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) xk[ks] = live ? load_obs<ObsT>(obs + sample * K + 2 * ks + half) : 0.0f;
 
-        float acc_v = 0.0f, acc_p[A];
+        f32x2 acc_v[2] = {f32x2{0.f, 0.f}, f32x2{0.f, 0.f}}, acc_p[A][2];
 #pragma unroll
-        for (int a = 0; a < A; ++a) acc_p[a] = 0.0f;
+        for (int a = 0; a < A; ++a) acc_p[a][0] = acc_p[a][1] = f32x2{0.f, 0.f};
 
-        // epilogue of the tile pair whose first tile is `e0` (second: e0 + off1)
-        auto finish = [&](const f32x16 &d0, const f32x16 &d1, int e0) {
-            const int e1 = e0 + off1;
-            if (HEADS == 1) {
-                epilogue_value(d0, w1v + e0 * kTile + 4 * half, acc_v);
-                epilogue_value(d1, w1v + e1 * kTile + 4 * half, acc_v);
-            } else if (HEADS == 2) {
-                epilogue_policy<A>(d0, w1p + (e0 - T) * kTile + 4 * half, W, acc_p);
-                epilogue_policy<A>(d1, w1p + (e1 - T) * kTile + 4 * half, W, acc_p);
-            } else {
-                epilogue_value(d0, w1v + e0 * kTile + 4 * half, acc_v);
-                epilogue_policy<A>(d1, w1p + (e1 - T) * kTile + 4 * half, W, acc_p);
-            }
-        };
-        auto chain = [&](int t) { return mfma_chain<A>(w0 + t * kTile, W2, col, half, xk); };
         int t0 = first;
         for (int p = 0; p < n_pairs; ++p) {
-            const f32x16 c0 = chain(t0), c1 = chain(t0 + off1);
-            finish(c0, c1, t0);
+            const int t1 = t0 + off1;
+            const f32x16 c0 = mfma_chain<A>(lds, W, t0, col, half, xk);
+            const f32x16 c1 = mfma_chain<A>(lds, W, t1, col, half, xk);
+            if (HEADS == 1) {
+                epilogue_value(c0, w1v + t0 * kTile + 4 * half, acc_v);
+                epilogue_value(c1, w1v + t1 * kTile + 4 * half, acc_v);
+            } else if (HEADS == 2) {
+                epilogue_policy<A>(c0, w1p + (t0 - T) * kTile + 4 * half, W, acc_p);
+                epilogue_policy<A>(c1, w1p + (t1 - T) * kTile + 4 * half, W, acc_p);
+            } else {
+                epilogue_value(c0, w1v + t0 * kTile + 4 * half, acc_v);
+                epilogue_policy<A>(c1, w1p + (t1 - T) * kTile + 4 * half, W, acc_p);
+            }
             t0 += stride0;
         }
-        // the two half-waves hold complementary hidden rows of the same 32 samples
-        if (HEADS & 1) acc_v += __shfl_xor(acc_v, 32, 64);
+        // lane-local sums, then the two half-waves (complementary hidden rows of the same 32 samples)
+        float out_v = (acc_v[0].x + acc_v[0].y) + (acc_v[1].x + acc_v[1].y), out_p[A];
+#pragma unroll
+        for (int a = 0; a < A; ++a) out_p[a] = (acc_p[a][0].x + acc_p[a][0].y) + (acc_p[a][1].x + acc_p[a][1].y);
+        if (HEADS & 1) out_v += __shfl_xor(out_v, 32, 64);
         if (HEADS & 2) {
 #pragma unroll
-            for (int a = 0; a < A; ++a) acc_p[a] += __shfl_xor(acc_p[a], 32, 64);
+            for (int a = 0; a < A; ++a) out_p[a] += __shfl_xor(out_p[a], 32, 64);
         }
         if (live && half == 0) {
-            if ((HEADS & 1) && value) value[sample] = acc_v + bv;
+            if ((HEADS & 1) && value) value[sample] = out_v + bv;
             if ((HEADS & 2) && logits) {
 #pragma unroll
-                for (int a = 0; a < A; ++a) logits[sample * A + a] = acc_p[a] + bp[a];
+                for (int a = 0; a < A; ++a) logits[sample * A + a] = out_p[a] + bp[a];
             }
         }
     }
@@ -208,12 +216,11 @@ __global__ __launch_bounds__(MAXT) void k_mlp_backward(int64_t N, int W, const f
     constexpr int FT = (K + 1 + kTile - 1) / kTile;  // 32-wide feature tiles of the augmented input (x | 1)
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int W2 = 2 * W, nthreads = blockDim.x;
-    float *w0 = lds;
-    float *w1v = lds + (K + 2) * W2;
-    float *w1p = w1v + W;
-    float *scratch = w1p + A * W + kB1Pad;  // after b1: [waves][32][33]
+    const float *w1v = lds + img_w1v(K, W);
+    const float *w1p = lds + img_w1p(K, W);
+    float *scratch = lds + img_floats(K, W, A);  // after the image: [waves][32][33]
     {
-        const int n4 = ((K + 2) * W2 + (1 + A) * W + kB1Pad) / 4;
+        const int n4 = img_floats(K, W, A) / 4;
         const float4 *src = reinterpret_cast<const float4 *>(packed);
         float4 *dst = reinterpret_cast<float4 *>(lds);
         for (int i = threadIdx.x; i < n4; i += nthreads) dst[i] = src[i];
@@ -233,12 +240,13 @@ __global__ __launch_bounds__(MAXT) void k_mlp_backward(int64_t N, int W, const f
         gW0v[ft] = f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
         gW0p[ft] = gW0v[ft];
     }
-    float gW1v[16], gW1p[A][16], gb1v = 0.0f, gb1p[A];
+    f32x2 gW1v[8], gW1p[A][8];  // second-layer weight-gradient partials of this lane's 16 hidden rows, as register pairs
+    float gb1v = 0.0f, gb1p[A];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        gW1v[r] = 0.0f;
+    for (int r = 0; r < 8; ++r) {
+        gW1v[r] = f32x2{0.f, 0.f};
 #pragma unroll
-        for (int a = 0; a < A; ++a) gW1p[a][r] = 0.0f;
+        for (int a = 0; a < A; ++a) gW1p[a][r] = f32x2{0.f, 0.f};
     }
 #pragma unroll
     for (int a = 0; a < A; ++a) gb1p[a] = 0.0f;
@@ -273,18 +281,21 @@ __global__ __launch_bounds__(MAXT) void k_mlp_backward(int64_t N, int W, const f
 
         // ---------------- value head, hidden tile `tile_v`
         {
-            const f32x16 c = mfma_chain<A>(w0 + tile_v * kTile, W2, col, half, xk);
+            const f32x16 c = mfma_chain<A>(lds, W, tile_v, col, half, xk);
             const float *w1 = w1v + tile_v * kTile + 4 * half;
+            const f32x2 dv2 = {dvs, dvs};
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const float4 w = *reinterpret_cast<const float4 *>(w1 + 8 * g);
-                const float wv[4] = {w.x, w.y, w.z, w.w};
+                const f32x2 wq[2] = {f32x2{w.x, w.y}, f32x2{w.z, w.w}};
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int r = 4 * g + j;
-                    const float z = c[r];
-                    gW1v[r] = fmaf(dvs, fmaxf(z, 0.0f), gW1v[r]);
-                    tr[(j + 8 * g + 4 * half) * 33 + col] = z > 0.0f ? wv[j] * dvs : 0.0f;  // dz, stored [hidden][sample]
+                for (int j = 0; j < 2; ++j) {
+                    const float z0 = c[4 * g + 2 * j], z1 = c[4 * g + 2 * j + 1];
+                    gW1v[2 * g + j] = __builtin_elementwise_fma(dv2, relu2(z0, z1), gW1v[2 * g + j]);
+                    const f32x2 dz = wq[j] * dv2;  // dL/dz where the unit is active
+                    float *t = tr + (2 * j + 8 * g + 4 * half) * 33 + col;  // stored [hidden][sample]
+                    t[0] = z0 > 0.0f ? dz.x : 0.0f;
+                    t[33] = z1 > 0.0f ? dz.y : 0.0f;
                 }
             }
             __builtin_amdgcn_wave_barrier();
@@ -298,25 +309,29 @@ __global__ __launch_bounds__(MAXT) void k_mlp_backward(int64_t N, int W, const f
         }
         // ---------------- policy head, hidden tile `tile_p`
         {
-            const f32x16 c = mfma_chain<A>(w0 + tile_p * kTile, W2, col, half, xk);
+            const f32x16 c = mfma_chain<A>(lds, W, tile_p, col, half, xk);
             const float *w1 = w1p + own * kTile + 4 * half;
+            f32x2 dl2[A];
+#pragma unroll
+            for (int a = 0; a < A; ++a) dl2[a] = f32x2{dl[a], dl[a]};
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                float dh[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+                f32x2 dh[2] = {f32x2{0.f, 0.f}, f32x2{0.f, 0.f}};
 #pragma unroll
                 for (int a = 0; a < A; ++a) {
                     const float4 w = *reinterpret_cast<const float4 *>(w1 + a * W + 8 * g);
-                    dh[0] = fmaf(w.x, dl[a], dh[0]); dh[1] = fmaf(w.y, dl[a], dh[1]);
-                    dh[2] = fmaf(w.z, dl[a], dh[2]); dh[3] = fmaf(w.w, dl[a], dh[3]);
+                    dh[0] = __builtin_elementwise_fma(f32x2{w.x, w.y}, dl2[a], dh[0]);
+                    dh[1] = __builtin_elementwise_fma(f32x2{w.z, w.w}, dl2[a], dh[1]);
                 }
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int r = 4 * g + j;
-                    const float z = c[r];
-                    const float h = fmaxf(z, 0.0f);
+                for (int j = 0; j < 2; ++j) {
+                    const float z0 = c[4 * g + 2 * j], z1 = c[4 * g + 2 * j + 1];
+                    const f32x2 h = relu2(z0, z1);
 #pragma unroll
-                    for (int a = 0; a < A; ++a) gW1p[a][r] = fmaf(dl[a], h, gW1p[a][r]);
-                    tr[(j + 8 * g + 4 * half) * 33 + col] = z > 0.0f ? dh[j] : 0.0f;
+                    for (int a = 0; a < A; ++a) gW1p[a][2 * g + j] = __builtin_elementwise_fma(dl2[a], h, gW1p[a][2 * g + j]);
+                    float *t = tr + (2 * j + 8 * g + 4 * half) * 33 + col;
+                    t[0] = z0 > 0.0f ? dh[j].x : 0.0f;
+                    t[33] = z1 > 0.0f ? dh[j].y : 0.0f;
                 }
             }
             __builtin_amdgcn_wave_barrier();
@@ -346,14 +361,14 @@ __global__ __launch_bounds__(MAXT) void k_mlp_backward(int64_t N, int W, const f
     float *o1 = out + W2 * FW;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-        float v = gW1v[r];
+        float v = gW1v[r >> 1][r & 1];
 #pragma unroll
         for (int off = 16; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);  // over the 32 sample lanes of this half-wave
         const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
         if (col == 0) o1[tile_v * kTile + row] = v;
 #pragma unroll
         for (int a = 0; a < A; ++a) {
-            float p = gW1p[a][r];
+            float p = gW1p[a][r >> 1][r & 1];
 #pragma unroll
             for (int off = 16; off > 0; off >>= 1) p += __shfl_xor(p, off, 64);
             if (col == 0) o1[W + a * W + own * kTile + row] = p;
@@ -404,37 +419,39 @@ __global__ __launch_bounds__(kThreads) void k_mlp_reduce(int nblocks, int W, int
     }
 }
 
-// Lay the eight torch Linear tensors out as the LDS image the kernels copy in one go:
-//   w0[(K + 2)][2W] (k-major; row K = first-layer biases, row K + 1 = 0)  |  w1v[W]  |  w1p[A][W]  |  b1[1 + A], padded to 12
+// Lay the eight torch Linear tensors out as the LDS image described at the top of this file.
 __global__ __launch_bounds__(kThreads) void k_mlp_pack(int A, int W, const float *__restrict__ vw0, const float *__restrict__ vb0,
                                                        const float *__restrict__ vw1, const float *__restrict__ vb1,
                                                        const float *__restrict__ pw0, const float *__restrict__ pb0,
                                                        const float *__restrict__ pw1, const float *__restrict__ pb1,
                                                        float *__restrict__ packed, int total) {
-    const int K = 2 * A * A, W2 = 2 * W;
+    const int K = 2 * A * A, KS = A * A;
     const int i = blockIdx.x * kThreads + threadIdx.x;
     if (i >= total) return;
-    const int n0 = (K + 2) * W2;
     float x = 0.0f;
-    if (i < n0) {
-        const int k = i / W2, h = i % W2;
-        if (k < K) x = h < W ? vw0[h * K + k] : pw0[(h - W) * K + k];
-        else if (k == K) x = h < W ? vb0[h] : pb0[h - W];
-    } else if (i < n0 + W) {
-        x = vw1[i - n0];
-    } else if (i < n0 + W + A * W) {
-        x = pw1[i - n0 - W];
-    } else if (i == n0 + W + A * W) {
+    if (i < img_b0(K, W)) {
+        const int tile = i / (KS * 64), rem = i % (KS * 64);
+        const int ks = rem / 64, half = (rem % 64) / 32, col = rem % 32;
+        const int h = tile * kTile + col, k = 2 * ks + half;
+        x = h < W ? vw0[h * K + k] : pw0[(h - W) * K + k];
+    } else if (i < img_w1v(K, W)) {
+        const int h = i - img_b0(K, W);
+        x = h < W ? vb0[h] : pb0[h - W];
+    } else if (i < img_w1p(K, W)) {
+        x = vw1[i - img_w1v(K, W)];
+    } else if (i < img_b1(K, W, A)) {
+        x = pw1[i - img_w1p(K, W)];
+    } else if (i == img_b1(K, W, A)) {
         x = vb1[0];
-    } else if (i < n0 + W + A * W + 1 + A) {
-        x = pb1[i - n0 - W - A * W - 1];
+    } else if (i < img_b1(K, W, A) + 1 + A) {
+        x = pb1[i - img_b1(K, W, A) - 1];
     }
     packed[i] = x;
 }
 
 }  // namespace
 
-static inline int mlp_packed_floats(int A, int W) { return (2 * A * A + 2) * 2 * W + (1 + A) * W + kB1Pad; }
+static inline int mlp_packed_floats(int A, int W) { return img_floats(2 * A * A, W, A); }
 
 extern "C" int64_t rnad_mlp_packed_size(int A, int W) { return mlp_packed_floats(A, W); }
 
@@ -463,8 +480,10 @@ extern "C" int rnad_mlp_forward(int64_t N, int A, int W, const float *packed, co
     int dev = 0, cus = 256;
     RNAD_HIP_OK(hipGetDevice(&dev));
     RNAD_HIP_OK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    size_t lds_pad = 0;
+    if (const char *e = getenv("RNAD_MLP_LDS_PAD")) lds_pad = (size_t)atoi(e);  // experiment knob: fewer blocks per CU
     constexpr int kWaves = kFwdThreads / 64;
-    const int blocks_per_cu = std::max(1, std::min(12 / kWaves, (int)(160 * 1024 / lds_bytes)));
+    const int blocks_per_cu = std::max(1, std::min(12 / kWaves, (int)(160 * 1024 / (lds_bytes + lds_pad))));
     const int64_t n_tiles = (N + kTile - 1) / kTile;
     const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>((n_tiles + kWaves - 1) / kWaves, (int64_t)cus * blocks_per_cu));
     int heads = (value ? 1 : 0) | (logits ? 2 : 0);
@@ -473,9 +492,9 @@ extern "C" int rnad_mlp_forward(int64_t N, int A, int W, const float *packed, co
 #define RNAD_MLP_LAUNCH2(T_, H_)                                                                                                  \
     do {                                                                                                                           \
         auto kern = k_mlp_forward<kA, T_, H_>;                                                                                     \
-        if (lds_bytes > 64 * 1024)                                                                                                 \
-            RNAD_HIP_OK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));      \
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(kFwdThreads), lds_bytes, stream, N, W, packed, (const T_ *)obs, logits, value);            \
+        if (lds_bytes + lds_pad > 64 * 1024)                                                                                       \
+            RNAD_HIP_OK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds_bytes + lds_pad))); \
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(kFwdThreads), lds_bytes + lds_pad, stream, N, W, packed, (const T_ *)obs, logits, value);            \
                                                                         \
     } while (0)
 #define RNAD_MLP_LAUNCH(T_)                                   \

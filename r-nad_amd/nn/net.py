@@ -44,7 +44,7 @@ class MLP(nn.Module):
         """The fused kernels keep ALL weights in the 160 KiB LDS of a CU and tile the hidden layer by 32."""
         w = self.value_fc0.weight
         A, W = self.max_actions, self.width
-        image_floats = (2 * A * A + 2) * 2 * W + (1 + A) * W + 12
+        image_floats = (2 * A * A + 1) * 2 * W + (1 + A) * W + 12
         return w.is_cuda and w.dtype == torch.float32 and W % 32 == 0 and image_floats * 4 <= 160 * 1024
 
     def forward_logits(self, input_batch, want_logits=True, want_value=True, packed=None):
