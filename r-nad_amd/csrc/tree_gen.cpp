@@ -131,6 +131,10 @@ void extreme_strategies(const double *M, int ra, int ca, std::vector<Strat> &xs,
                 add_unique(ys, y, ca);
             } while (next_comb(cols, k, ca));
         } while (next_comb(rows, k, ra));
+        // A saddle point gives a (pure, pure) pair, the lowest purity key there is (tree.py:227-231), and the stable sort keeps
+        // the FIRST such pair in enumeration order -- which is made of the first pure x and the first pure y found at k = 1.
+        // Larger supports cannot change the selection any more, so the enumeration stops here.
+        if (k == 1 && !xs.empty() && !ys.empty()) return;
     }
 }
 
