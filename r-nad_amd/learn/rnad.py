@@ -286,6 +286,11 @@ class RNaD:
         """Gradients of the learner net from a batch of trajectories (reward transform + V-trace + NeuRD)."""
         T, B, A = episodes.t_eff + 1, episodes.batch_size, self.tree.max_actions
 
+        # N_P = #(valid & turn == P): batch-global loss normalisers (vtrace.py:373,388).  Their all-reduce over the ranks is
+        # issued first and overlaps the MLP forwards below (RCCL runs it on its own stream).
+        norm = episodes.valid_counts
+        norm_work = dist.all_reduce(norm, async_op=True) if _dist_on() else None
+
         reuse = (getattr(self, "reuse_actor_outputs", False) and getattr(episodes, "actor_logits", None) is not None
                  and getattr(episodes, "_actor_tag", None) == (id(self.net), self.total_steps)
                  and rnad_hip.mlp_backward_supported(A, getattr(self.net, "width", 0)))
@@ -299,9 +304,8 @@ class RNaD:
             logit_reg, _ = self._logits_of(self.net_reg, episodes, want_value=False)  # :379
             logit_reg_, _ = self._logits_of(self.net_reg_, episodes, want_value=False)  # :380
 
-        norm = episodes.valid_counts  # N_P = #(valid & turn == P): batch-global normalisers (vtrace.py:373,388)
-        if _dist_on():
-            dist.all_reduce(norm)
+        if norm_work is not None:
+            norm_work.wait()
         hp = rnad_hip.make_learn_params(
             alpha=alpha, eta=self.eta, lambda_=1.0, c=self.c_bar, rho=self.roh_bar, gamma=self.vtrace_gamma,
             clip=self.neurd_clip, threshold=self.beta, w_v=self.value_weight, w_n=self.neurd_weight,
