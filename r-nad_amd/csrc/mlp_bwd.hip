@@ -1,0 +1,352 @@
+// mlp_bwd.hip -- backward of the fused policy/value MLP (see mlp_fwd.hip for the forward and the mapping).
+// Built WITHOUT -mllvm -amdgpu-mfma-vgpr-form: that pass crashes hipcc (ROCm 7.2) on this kernel; the backward gained < 3 % from it.
+#include "mlp_common.hpp"
+
+using namespace rnad;
+using namespace rnad_mlp;
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------ backward
+// Gradients of the 8 Linear tensors given dL/dlogits [N, A] and dL/dvalue [N] -- what autograd computes for
+// nn/net.py:40-43 -- in ONE pass over the samples with the hidden layer recomputed on chip:
+//     z = W0aug x (MFMA, as in the forward)          h = relu(z)
+//     dW1[o, j] += dout[o] * h[j]                     (VALU, per-lane partial sums over this lane's samples)
+//     dz[j] = (z[j] > 0) * sum_o W1[o, j] * dout[o]
+//     dW0aug[j, k] += dz[j] * xaug[k]                 (MFMA with the 32 SAMPLES of the tile as the contraction dimension:
+//                                                      A = dz^T via a per-wave 32x33 LDS transpose, B = x rows; the
+//                                                      bias gradient is the k = K column because xaug[K] = 1)
+// Block = W/32 waves; wave w owns hidden tile w of BOTH heads for every sample tile the block visits, so its two
+// 32x32 dW0aug accumulators (32 registers) and its dW1 partials (16 + 16 A registers) stay resident for the whole
+// launch.  Blocks write their partial gradients to `partial`; k_mlp_reduce sums them in a fixed order (deterministic).
+template <int A, typename ObsT, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void k_mlp_backward(int64_t N, int W, const float *__restrict__ packed,
+                                                       const ObsT *__restrict__ obs, const float *__restrict__ dlogit,
+                                                       const float *__restrict__ dv, float *__restrict__ partial, int P) {
+    constexpr int K = 2 * A * A, KS = K / 2;
+    constexpr int FT = (K + 1 + kTile - 1) / kTile;  // 32-wide feature tiles of the augmented input (x | 1)
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int nthreads = 64 * WAVES;
+    const int W2 = 2 * W;
+    const float *w1v = lds + img_w1v(K, W);
+    const float *w1p = lds + img_w1p(K, W);
+    float *scratch = lds + img_floats(K, W, A);  // after the image: [waves][32][33]
+    {
+        const int n4 = img_floats(K, W, A) / 4;
+        const float4 *src = reinterpret_cast<const float4 *>(packed);
+        float4 *dst = reinterpret_cast<float4 *>(lds);
+        for (int i = threadIdx.x; i < n4; i += nthreads) dst[i] = src[i];
+    }
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int col = lane & 31, half = lane >> 5;
+    float *tr = scratch + wave * (kTile * 33);
+    // blockIdx.y selects a group of (blockDim.x / 64) hidden tiles; this wave owns one of them, in both heads
+    const int own = blockIdx.y * WAVES + wave;
+    const int tile_v = own, tile_p = W / kTile + own;
+
+    f32x16 gW0v[FT], gW0p[FT];
+#pragma unroll
+    for (int ft = 0; ft < FT; ++ft) {
+        gW0v[ft] = f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        gW0p[ft] = gW0v[ft];
+    }
+    f32x2 gW1v[8], gW1p[A][8];  // second-layer weight-gradient partials of this lane's 16 hidden rows, as register pairs
+    float gb1v = 0.0f, gb1p[A];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        gW1v[r] = f32x2{0.f, 0.f};
+#pragma unroll
+        for (int a = 0; a < A; ++a) gW1p[a][r] = f32x2{0.f, 0.f};
+    }
+#pragma unroll
+    for (int a = 0; a < A; ++a) gb1p[a] = 0.0f;
+
+    // The 32 samples of a tile (x, dL/dvalue, dL/dlogits: 32 (K + 1 + A) floats) are shared by every wave of the block: they
+    // are fetched once with coalesced loads, one tile ahead, and handed over through a double-buffered LDS stage (one barrier
+    // per tile).  Per-wave global loads of the same tile cost 13 % of the kernel (measured).
+    constexpr int XN = kTile * K, STG = XN + kTile + kTile * A;  // floats per stage: x | dv | dlogits
+    float *stage = scratch + WAVES * (kTile * 33);               // [2][STG]
+    const int64_t n_tiles = (N + kTile - 1) / kTile;
+    const int64_t NK = N * K;
+    constexpr int XU = (XN + nthreads - 1) / nthreads, DU = (kTile * A + nthreads - 1) / nthreads;  // prefetch registers per thread
+    float pre_x[XU], pre_dv = 0.0f, pre_dl[DU];
+    auto fetch = [&](int64_t tile) {  // global -> registers
+        const int64_t s0 = tile * kTile;
+#pragma unroll
+        for (int u = 0; u < XU; ++u) {
+            const int i = threadIdx.x + u * nthreads;
+            const int64_t gi = s0 * K + i;
+            pre_x[u] = (i < XN && gi < NK) ? load_obs<ObsT>(obs + gi) : 0.0f;
+        }
+        pre_dv = (threadIdx.x < kTile && s0 + threadIdx.x < N) ? dv[s0 + threadIdx.x] : 0.0f;
+#pragma unroll
+        for (int u = 0; u < DU; ++u) {
+            const int i = threadIdx.x + u * nthreads;
+            pre_dl[u] = (i < kTile * A && s0 * A + i < N * A) ? dlogit[s0 * A + i] : 0.0f;
+        }
+    };
+    auto park = [&](float *dst) {  // registers -> LDS stage
+#pragma unroll
+        for (int u = 0; u < XU; ++u) {
+            const int i = threadIdx.x + u * nthreads;
+            if (i < XN) dst[i] = pre_x[u];
+        }
+        if (threadIdx.x < kTile) dst[XN + threadIdx.x] = pre_dv;
+#pragma unroll
+        for (int u = 0; u < DU; ++u) {
+            const int i = threadIdx.x + u * nthreads;
+            if (i < kTile * A) dst[XN + kTile + i] = pre_dl[u];
+        }
+    };
+    int cur = 0;
+    if ((int64_t)blockIdx.x < n_tiles) {
+        fetch(blockIdx.x);
+        park(stage);
+    }
+    __syncthreads();
+    for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const bool more = tile + gridDim.x < n_tiles;
+        if (more) fetch(tile + gridDim.x);  // next tile's loads are in flight during this tile's matrix work
+        const float *xs = stage + cur * STG;
+        float xk[KS];   // B operand of the forward product: x[sample = col][2 ks + half]
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) xk[ks] = xs[col * K + 2 * ks + half];
+        float xt[FT][16];   // B operand of the weight-gradient product: xaug[sample = 2 ks + half][feature = 32 ft + col]
+#pragma unroll
+        for (int ft = 0; ft < FT; ++ft) {
+            const int f = ft * kTile + col;
+#pragma unroll
+            for (int ks = 0; ks < 16; ++ks) xt[ft][ks] = f < K ? xs[(2 * ks + half) * K + f] : (f == K ? 1.0f : 0.0f);
+        }
+        const float dvs = xs[XN + col];  // zero for samples past N, so padded lanes contribute nothing
+        float dl[A];
+#pragma unroll
+        for (int a = 0; a < A; ++a) dl[a] = xs[XN + kTile + col * A + a];
+        gb1v += dvs;
+#pragma unroll
+        for (int a = 0; a < A; ++a) gb1p[a] += dl[a];
+
+        // ---------------- value head, hidden tile `tile_v`
+        {
+            const f32x16 c = mfma_chain<A>(lds, W, tile_v, col, half, xk);
+            const float *w1 = w1v + tile_v * kTile + 4 * half;
+            const f32x2 dv2 = {dvs, dvs};
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float4 w = *reinterpret_cast<const float4 *>(w1 + 8 * g);
+                const f32x2 wq[2] = {f32x2{w.x, w.y}, f32x2{w.z, w.w}};
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const float z0 = c[4 * g + 2 * j], z1 = c[4 * g + 2 * j + 1];
+                    gW1v[2 * g + j] = __builtin_elementwise_fma(dv2, relu2(z0, z1), gW1v[2 * g + j]);
+                    const f32x2 dz = wq[j] * dv2;  // dL/dz where the unit is active
+                    float *t = tr + (2 * j + 8 * g + 4 * half) * 33 + col;  // stored [hidden][sample]
+                    t[0] = z0 > 0.0f ? dz.x : 0.0f;
+                    t[33] = z1 > 0.0f ? dz.y : 0.0f;
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int ks = 0; ks < 16; ++ks) {
+                const float at = tr[col * 33 + 2 * ks + half];
+#pragma unroll
+                for (int ft = 0; ft < FT; ++ft) gW0v[ft] = __builtin_amdgcn_mfma_f32_32x32x2f32(at, xt[ft][ks], gW0v[ft], 0, 0, 0);
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        // ---------------- policy head, hidden tile `tile_p`
+        {
+            const f32x16 c = mfma_chain<A>(lds, W, tile_p, col, half, xk);
+            const float *w1 = w1p + own * kTile + 4 * half;
+            f32x2 dl2[A];
+#pragma unroll
+            for (int a = 0; a < A; ++a) dl2[a] = f32x2{dl[a], dl[a]};
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f32x2 dh[2] = {f32x2{0.f, 0.f}, f32x2{0.f, 0.f}};
+#pragma unroll
+                for (int a = 0; a < A; ++a) {
+                    const float4 w = *reinterpret_cast<const float4 *>(w1 + a * W + 8 * g);
+                    dh[0] = __builtin_elementwise_fma(f32x2{w.x, w.y}, dl2[a], dh[0]);
+                    dh[1] = __builtin_elementwise_fma(f32x2{w.z, w.w}, dl2[a], dh[1]);
+                }
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const float z0 = c[4 * g + 2 * j], z1 = c[4 * g + 2 * j + 1];
+                    const f32x2 h = relu2(z0, z1);
+#pragma unroll
+                    for (int a = 0; a < A; ++a) gW1p[a][2 * g + j] = __builtin_elementwise_fma(dl2[a], h, gW1p[a][2 * g + j]);
+                    float *t = tr + (2 * j + 8 * g + 4 * half) * 33 + col;
+                    t[0] = z0 > 0.0f ? dh[j].x : 0.0f;
+                    t[33] = z1 > 0.0f ? dh[j].y : 0.0f;
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int ks = 0; ks < 16; ++ks) {
+                const float at = tr[col * 33 + 2 * ks + half];
+#pragma unroll
+                for (int ft = 0; ft < FT; ++ft) gW0p[ft] = __builtin_amdgcn_mfma_f32_32x32x2f32(at, xt[ft][ks], gW0p[ft], 0, 0, 0);
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        if (more) park(stage + (cur ^ 1) * STG);  // nobody reads that stage any more: every wave passed the last barrier
+        __syncthreads();
+        cur ^= 1;
+    }
+
+    // ---------------- write this block's partial gradients
+    // layout: dW0aug [2W][32 FT] | dW1v [W] | dW1p [A][W] | db1v | db1p [A]
+    constexpr int FW = FT * kTile;
+    float *out = partial + (int64_t)blockIdx.x * P;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+#pragma unroll
+        for (int ft = 0; ft < FT; ++ft) {
+            out[(tile_v * kTile + row) * FW + ft * kTile + col] = gW0v[ft][r];
+            out[(tile_p * kTile + row) * FW + ft * kTile + col] = gW0p[ft][r];
+        }
+    }
+    float *o1 = out + W2 * FW;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        float v = gW1v[r >> 1][r & 1];
+#pragma unroll
+        for (int off = 16; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);  // over the 32 sample lanes of this half-wave
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (col == 0) o1[tile_v * kTile + row] = v;
+#pragma unroll
+        for (int a = 0; a < A; ++a) {
+            float p = gW1p[a][r >> 1][r & 1];
+#pragma unroll
+            for (int off = 16; off > 0; off >>= 1) p += __shfl_xor(p, off, 64);
+            if (col == 0) o1[W + a * W + own * kTile + row] = p;
+        }
+    }
+    if (own == 0) {  // every wave saw the same samples: one of them reports the output-bias gradients
+#pragma unroll
+        for (int off = 16; off > 0; off >>= 1) gb1v += __shfl_xor(gb1v, off, 64);
+        if (lane == 0) o1[W + A * W] = gb1v;
+#pragma unroll
+        for (int a = 0; a < A; ++a) {
+            float p = gb1p[a];
+#pragma unroll
+            for (int off = 16; off > 0; off >>= 1) p += __shfl_xor(p, off, 64);
+            if (lane == 0) o1[W + A * W + 1 + a] = p;
+        }
+    }
+}
+
+// Sum the per-block partials (fixed order, fp64 accumulate) into the eight gradient tensors (torch Linear layouts).
+template <int A>
+__global__ __launch_bounds__(kThreads) void k_mlp_reduce(int nblocks, int W, int P, const float *__restrict__ partial,
+                                                         float *__restrict__ g_vw0, float *__restrict__ g_vb0, float *__restrict__ g_vw1,
+                                                         float *__restrict__ g_vb1, float *__restrict__ g_pw0, float *__restrict__ g_pb0,
+                                                         float *__restrict__ g_pw1, float *__restrict__ g_pb1) {
+    constexpr int K = 2 * A * A, FW = ((K + 1 + kTile - 1) / kTile) * kTile;
+    const int e = blockIdx.x * kThreads + threadIdx.x;
+    const int total = 2 * W * FW + W + A * W + 1 + A;
+    if (e >= total) return;
+    double s = 0.0;
+    for (int b = 0; b < nblocks; ++b) s += (double)partial[(int64_t)b * P + e];
+    const float v = (float)s;
+    const int n0 = 2 * W * FW;
+    if (e < n0) {
+        const int h = e / FW, k = e % FW;
+        float *gw = h < W ? g_vw0 : g_pw0, *gb = h < W ? g_vb0 : g_pb0;
+        const int hh = h < W ? h : h - W;
+        if (k < K) gw[hh * K + k] = v;
+        else if (k == K) gb[hh] = v;
+    } else if (e < n0 + W) {
+        g_vw1[e - n0] = v;
+    } else if (e < n0 + W + A * W) {
+        g_pw1[e - n0 - W] = v;
+    } else if (e == n0 + W + A * W) {
+        g_vb1[0] = v;
+    } else {
+        g_pb1[e - n0 - W - A * W - 1] = v;
+    }
+}
+
+}  // namespace
+
+struct BwdPlan {
+    int waves, groups, grid_x, P, total;
+    size_t lds_bytes;
+};
+
+// One wave per hidden tile (of both heads).  With one feature tile (A <= 3) a wave needs ~230 VGPRs: 8 waves per block, two
+// per SIMD.  With more feature tiles it needs up to ~400: 4 waves per block, one per SIMD, and blockIdx.y walks the tile groups.
+static bool mlp_backward_plan(int64_t N, int W, int A, BwdPlan *p) {
+    const int K = 2 * A * A, T = W / kTile, FT = (K + 1 + kTile - 1) / kTile;
+    int waves = FT == 1 ? 8 : 4;
+    while (waves > 1 && T % waves) waves >>= 1;
+    p->waves = waves;
+    p->groups = T / waves;
+    p->lds_bytes = ((size_t)mlp_packed_floats(A, W) + (size_t)waves * kTile * 33 + 2 * (size_t)kTile * (K + 1 + A)) * sizeof(float);
+    p->total = 2 * W * FT * kTile + W + A * W + 1 + A;
+    p->P = (p->total + 3) & ~3;
+    if (p->lds_bytes > 160 * 1024) return false;
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    const int64_t n_tiles = (N + kTile - 1) / kTile;
+    p->grid_x = (int)std::max<int64_t>(1, std::min<int64_t>(n_tiles, std::max(1, cus / p->groups)));
+    return true;
+}
+
+extern "C" int64_t rnad_mlp_backward_workspace(int64_t N, int A, int W) {
+    BwdPlan p;
+    if (A < 1 || A > RNAD_MAX_ACTIONS || W < kTile || W % kTile || !mlp_backward_plan(N, W, A, &p)) return -1;
+    return (int64_t)p.grid_x * p.P * (int64_t)sizeof(float);
+}
+
+extern "C" int rnad_mlp_backward(int64_t N, int A, int W, const float *packed, const void *obs, int obs_half, const float *dlogits,
+                                 const float *dvalue, float *g_vw0, float *g_vb0, float *g_vw1, float *g_vb1, float *g_pw0,
+                                 float *g_pb0, float *g_pw1, float *g_pb1, float *workspace, void *stream_) {
+    RNAD_REQUIRE(packed && obs && dlogits && dvalue && g_vw0 && g_vb0 && g_vw1 && g_vb1 && g_pw0 && g_pb0 && g_pw1 && g_pb1 && workspace,
+                 "rnad_mlp_backward: null argument");
+    RNAD_REQUIRE(W >= kTile && W % kTile == 0, "rnad_mlp_backward: width %d must be a positive multiple of %d", W, kTile);
+    RNAD_REQUIRE(N >= 1, "rnad_mlp_backward: empty batch");
+    hipStream_t stream = (hipStream_t)stream_;
+    BwdPlan plan;
+    RNAD_REQUIRE(A >= 1 && A <= RNAD_MAX_ACTIONS && mlp_backward_plan(N, W, A, &plan),
+                 "rnad_mlp_backward: weights do not fit the LDS (A=%d, width=%d)", A, W);
+    const int grid = plan.grid_x, P = plan.P;
+    const size_t lds_bytes = plan.lds_bytes;
+    const int threads = 64 * plan.waves;
+    {
+        ProfScope prof(PROF_MLP_BWD, stream);
+#define RNAD_MLPB_LAUNCH(T_, WV_)                                                                                                 \
+    do {                                                                                                                           \
+        auto kern = k_mlp_backward<kA, T_, WV_>;                                                                                   \
+        if (lds_bytes > 64 * 1024)                                                                                                 \
+            RNAD_HIP_OK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));      \
+        hipLaunchKernelGGL(kern, dim3(grid, plan.groups), dim3(threads), lds_bytes, stream, N, W, packed, (const T_ *)obs, dlogits, \
+                           dvalue, workspace, P);                                                                                  \
+    } while (0)
+#define RNAD_MLPB_WAVES(T_)                                                      \
+    do {                                                                         \
+        if (plan.waves == 8) { if constexpr (kOneFt) RNAD_MLPB_LAUNCH(T_, 8); }  \
+        else if (plan.waves == 4) RNAD_MLPB_LAUNCH(T_, 4);                       \
+        else if (plan.waves == 2) RNAD_MLPB_LAUNCH(T_, 2);                       \
+        else RNAD_MLPB_LAUNCH(T_, 1);                                            \
+    } while (0)
+        RNAD_DISPATCH_A(A, {
+            constexpr bool kOneFt = 2 * kA * kA + 1 <= kTile;
+            if (obs_half) RNAD_MLPB_WAVES(__half);
+            else RNAD_MLPB_WAVES(float);
+        });
+#undef RNAD_MLPB_WAVES
+#undef RNAD_MLPB_LAUNCH
+        RNAD_HIP_OK(hipGetLastError());
+    }
+    const int total = plan.total;
+    const unsigned rgrid = (unsigned)((total + kThreads - 1) / kThreads);
+    RNAD_DISPATCH_A(A, hipLaunchKernelGGL((k_mlp_reduce<kA>), dim3(rgrid), dim3(kThreads), 0, stream, grid, W, P, workspace, g_vw0, g_vb0,
+                                          g_vw1, g_vb1, g_pw0, g_pb0, g_pw1, g_pb1));
+    RNAD_HIP_OK(hipGetLastError());
+    return 0;
+}

@@ -1,0 +1,226 @@
+// mlp.hip -- fused policy/value MLP forward on the fp32 matrix cores (gfx950).
+//
+// Replaces the tensor program of nn/net.py:40-43 (and :70-73 in forward_batch):
+//     value  = value_fc1 (relu(value_fc0 (x)))        x = observation flattened to 2*A*A floats
+//     logits = policy_fc1(relu(policy_fc0(x)))
+// Citations are baskuit/R-NaD file:line.
+//
+// Why a kernel: rocprof of the PyTorch-ROCm version (profiles/r01a_*) shows the two hidden activations [N, 256] fp32
+// going to HBM and back four times per head (GEMM out, relu in/out, GEMM in): 99.5 % of a training step.  Here the hidden
+// layer never leaves the register file.
+//
+// Mapping (wave64, v_mfma_f32_32x32x2_f32, exact fp32 == an fmaf chain):
+//   C[hidden, sample] = W0aug[hidden, k] * Xaug[k, sample]     M = 32 hidden units, N = 32 samples, K = 2 per MFMA
+//   A operand  lane l: W0aug[tile*32 + (l & 31)][2*ks + (l >> 5)]   from LDS ([k][2W] layout: conflict-free)
+//   B operand  lane l: x[sample0 + (l & 31)][2*ks + (l >> 5)]       one VGPR per k-step, loaded once per 32 samples
+//   the first-layer bias is the accumulator's initial value (row K of the LDS image) -> K / 2 MFMAs per tile
+//   C layout   lane l holds sample (l & 31) and hidden rows (r & 3) + 8 (r >> 2) + 4 (l >> 5), r in [0, 16):
+//              four consecutive hidden units per register quad -> relu, then the second layer as VALU FMAs against
+//              float4 reads of W1 from LDS; the two half-waves hold complementary rows and are summed with one DPP add.
+// Both heads share the B operand; a wave walks 2 * W / 32 hidden tiles per 32 samples.  Matrix-pipe time per sample
+// tile = 2 * (W / 32) * (K / 2) * 64 cycles.
+#include "mlp_common.hpp"
+
+using namespace rnad;
+using namespace rnad_mlp;
+
+namespace {
+
+// Second layer for one 32x32 hidden tile, written on float pairs so that it compiles to v_pk_fma_f32 without register
+// shuffles (fp32 MFMA and VALU work do not overlap on gfx950: every VALU instruction here is kernel time).  The summation
+// order is this kernel's own; nothing in the reference fixes it.
+__device__ __forceinline__ void epilogue_value(const f32x16 &c, const float *__restrict__ w1, f32x2 (&acc)[2]) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const float4 w = *reinterpret_cast<const float4 *>(w1 + 8 * g);
+        acc[0] = __builtin_elementwise_fma(f32x2{w.x, w.y}, relu2(c[4 * g + 0], c[4 * g + 1]), acc[0]);
+        acc[1] = __builtin_elementwise_fma(f32x2{w.z, w.w}, relu2(c[4 * g + 2], c[4 * g + 3]), acc[1]);
+    }
+}
+
+template <int A>
+__device__ __forceinline__ void epilogue_policy(const f32x16 &c, const float *__restrict__ w1, int W, f32x2 (&acc)[A][2]) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const f32x2 h01 = relu2(c[4 * g + 0], c[4 * g + 1]), h23 = relu2(c[4 * g + 2], c[4 * g + 3]);
+#pragma unroll
+        for (int a = 0; a < A; ++a) {
+            const float4 w = *reinterpret_cast<const float4 *>(w1 + a * W + 8 * g);
+            acc[a][0] = __builtin_elementwise_fma(f32x2{w.x, w.y}, h01, acc[a][0]);
+            acc[a][1] = __builtin_elementwise_fma(f32x2{w.z, w.w}, h23, acc[a][1]);
+        }
+    }
+}
+
+template <int A, typename ObsT, int HEADS>
+__global__ __launch_bounds__(kFwdThreads) void k_mlp_forward(int64_t N, int W, const float *__restrict__ packed,
+                                                             const ObsT *__restrict__ obs, float *__restrict__ logits,
+                                                             float *__restrict__ value) {
+    constexpr int K = 2 * A * A, KS = K / 2;  // MFMA k-steps per hidden tile
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    {   // weights: one coalesced 16-byte copy of the image rnad_mlp_pack laid out
+        const int n4 = img_floats(K, W, A) / 4;
+        const float4 *src = reinterpret_cast<const float4 *>(packed);
+        float4 *dst = reinterpret_cast<float4 *>(lds);
+        for (int i = threadIdx.x; i < n4; i += kFwdThreads) dst[i] = src[i];
+    }
+    __syncthreads();
+    const float *w1v = lds + img_w1v(K, W);
+    const float *w1p = lds + img_w1p(K, W);
+    const float *b1 = lds + img_b1(K, W, A);  // [1 + A]: value_fc1.bias, policy_fc1.bias
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int col = lane & 31, half = lane >> 5;
+    const int T = W / kTile;  // hidden tiles per head
+    const float bv = b1[0];
+    float bp[A];
+#pragma unroll
+    for (int a = 0; a < A; ++a) bp[a] = b1[1 + a];
+    // tile pair p of this launch: both heads -> (value tile p, policy tile p); one head -> its tiles (2p, 2p + 1)
+    const int n_pairs = HEADS == 3 ? T : T / 2;  // single-head launches need an even tile count (the launcher sees to it)
+    const int first = HEADS == 2 ? T : 0;
+    const int stride0 = HEADS == 3 ? 1 : 2, off1 = HEADS == 3 ? T : 1;
+
+    const int64_t n_tiles = (N + kTile - 1) / kTile;
+    for (int64_t tile = (int64_t)blockIdx.x * (kFwdThreads / 64) + wave; tile < n_tiles; tile += (int64_t)gridDim.x * (kFwdThreads / 64)) {
+        const int64_t sample = tile * kTile + col;
+        const bool live = sample < N;
+        float xk[KS];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) xk[ks] = live ? load_obs<ObsT>(obs + sample * K + 2 * ks + half) : 0.0f;
+
+        f32x2 acc_v[2] = {f32x2{0.f, 0.f}, f32x2{0.f, 0.f}}, acc_p[A][2];
+#pragma unroll
+        for (int a = 0; a < A; ++a) acc_p[a][0] = acc_p[a][1] = f32x2{0.f, 0.f};
+
+        int t0 = first;
+        for (int p = 0; p < n_pairs; ++p) {
+            const int t1 = t0 + off1;
+            const f32x16 c0 = mfma_chain<A>(lds, W, t0, col, half, xk);
+            const f32x16 c1 = mfma_chain<A>(lds, W, t1, col, half, xk);
+            if (HEADS == 1) {
+                epilogue_value(c0, w1v + t0 * kTile + 4 * half, acc_v);
+                epilogue_value(c1, w1v + t1 * kTile + 4 * half, acc_v);
+            } else if (HEADS == 2) {
+                epilogue_policy<A>(c0, w1p + (t0 - T) * kTile + 4 * half, W, acc_p);
+                epilogue_policy<A>(c1, w1p + (t1 - T) * kTile + 4 * half, W, acc_p);
+            } else {
+                epilogue_value(c0, w1v + t0 * kTile + 4 * half, acc_v);
+                epilogue_policy<A>(c1, w1p + (t1 - T) * kTile + 4 * half, W, acc_p);
+            }
+            t0 += stride0;
+        }
+        // lane-local sums, then the two half-waves (complementary hidden rows of the same 32 samples)
+        float out_v = (acc_v[0].x + acc_v[0].y) + (acc_v[1].x + acc_v[1].y), out_p[A];
+#pragma unroll
+        for (int a = 0; a < A; ++a) out_p[a] = (acc_p[a][0].x + acc_p[a][0].y) + (acc_p[a][1].x + acc_p[a][1].y);
+        if (HEADS & 1) out_v += __shfl_xor(out_v, 32, 64);
+        if (HEADS & 2) {
+#pragma unroll
+            for (int a = 0; a < A; ++a) out_p[a] += __shfl_xor(out_p[a], 32, 64);
+        }
+        if (live && half == 0) {
+            if ((HEADS & 1) && value) value[sample] = out_v + bv;
+            if ((HEADS & 2) && logits) {
+#pragma unroll
+                for (int a = 0; a < A; ++a) logits[sample * A + a] = out_p[a] + bp[a];
+            }
+        }
+    }
+}
+
+
+// Lay the eight torch Linear tensors out as the LDS image described at the top of this file.
+__global__ __launch_bounds__(kThreads) void k_mlp_pack(int A, int W, const float *__restrict__ vw0, const float *__restrict__ vb0,
+                                                       const float *__restrict__ vw1, const float *__restrict__ vb1,
+                                                       const float *__restrict__ pw0, const float *__restrict__ pb0,
+                                                       const float *__restrict__ pw1, const float *__restrict__ pb1,
+                                                       float *__restrict__ packed, int total) {
+    const int K = 2 * A * A, KS = A * A;
+    const int i = blockIdx.x * kThreads + threadIdx.x;
+    if (i >= total) return;
+    float x = 0.0f;
+    if (i < img_b0(K, W)) {
+        const int tile = i / (KS * 64), rem = i % (KS * 64);
+        const int ks = rem / 64, half = (rem % 64) / 32, col = rem % 32;
+        const int h = tile * kTile + col, k = 2 * ks + half;
+        x = h < W ? vw0[h * K + k] : pw0[(h - W) * K + k];
+    } else if (i < img_w1v(K, W)) {
+        const int h = i - img_b0(K, W);
+        x = h < W ? vb0[h] : pb0[h - W];
+    } else if (i < img_w1p(K, W)) {
+        x = vw1[i - img_w1v(K, W)];
+    } else if (i < img_b1(K, W, A)) {
+        x = pw1[i - img_w1p(K, W)];
+    } else if (i == img_b1(K, W, A)) {
+        x = vb1[0];
+    } else if (i < img_b1(K, W, A) + 1 + A) {
+        x = pb1[i - img_b1(K, W, A) - 1];
+    }
+    packed[i] = x;
+}
+
+}  // namespace
+
+extern "C" int64_t rnad_mlp_packed_size(int A, int W) { return mlp_packed_floats(A, W); }
+
+extern "C" int rnad_mlp_pack(int A, int W, const float *vw0, const float *vb0, const float *vw1, const float *vb1, const float *pw0,
+                             const float *pb0, const float *pw1, const float *pb1, float *packed, void *stream) {
+    RNAD_REQUIRE(vw0 && vb0 && vw1 && vb1 && pw0 && pb0 && pw1 && pb1 && packed, "rnad_mlp_pack: null argument");
+    RNAD_REQUIRE(A >= 1 && A <= RNAD_MAX_ACTIONS && W >= kTile && W % kTile == 0, "rnad_mlp_pack: bad shape (A=%d, width=%d)", A, W);
+    const int total = mlp_packed_floats(A, W);
+    hipLaunchKernelGGL(k_mlp_pack, dim3((total + kThreads - 1) / kThreads), dim3(kThreads), 0, (hipStream_t)stream, A, W, vw0, vb0, vw1,
+                       vb1, pw0, pb0, pw1, pb1, packed, total);
+    RNAD_HIP_OK(hipGetLastError());
+    return 0;
+}
+
+extern "C" int rnad_mlp_forward(int64_t N, int A, int W, const float *packed, const void *obs, int obs_half, float *logits, float *value,
+                                void *stream_) {
+    RNAD_REQUIRE(packed && obs && (logits || value), "rnad_mlp_forward: null argument");
+    RNAD_REQUIRE(W >= kTile && W % kTile == 0, "rnad_mlp_forward: width %d must be a positive multiple of %d", W, kTile);
+    RNAD_REQUIRE(N >= 0, "rnad_mlp_forward: negative batch");
+    if (N == 0) return 0;
+    hipStream_t stream = (hipStream_t)stream_;
+    const int K = 2 * A * A;
+    (void)K;
+    const size_t lds_bytes = (size_t)mlp_packed_floats(A, W) * sizeof(float);
+    RNAD_REQUIRE(lds_bytes <= 160 * 1024, "rnad_mlp_forward: weights (%zu B) do not fit the 160 KiB LDS (A=%d, width=%d)", lds_bytes, A, W);
+    int dev = 0, cus = 256;
+    RNAD_HIP_OK(hipGetDevice(&dev));
+    RNAD_HIP_OK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    size_t lds_pad = 0;
+    if (const char *e = getenv("RNAD_MLP_LDS_PAD")) lds_pad = (size_t)atoi(e);  // experiment knob: fewer blocks per CU
+    constexpr int kWaves = kFwdThreads / 64;
+    const int blocks_per_cu = std::max(1, std::min(12 / kWaves, (int)(160 * 1024 / (lds_bytes + lds_pad))));
+    const int64_t n_tiles = (N + kTile - 1) / kTile;
+    const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>((n_tiles + kWaves - 1) / kWaves, (int64_t)cus * blocks_per_cu));
+    int heads = (value ? 1 : 0) | (logits ? 2 : 0);
+    if ((W / kTile) % 2) heads = 3;  // odd tile count: the paired single-head kernels do not apply; compute both, store the wanted one
+    ProfScope prof(PROF_MLP, stream);
+#define RNAD_MLP_LAUNCH2(T_, H_)                                                                                                  \
+    do {                                                                                                                           \
+        auto kern = k_mlp_forward<kA, T_, H_>;                                                                                     \
+        if (lds_bytes + lds_pad > 64 * 1024)                                                                                       \
+            RNAD_HIP_OK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds_bytes + lds_pad))); \
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(kFwdThreads), lds_bytes + lds_pad, stream, N, W, packed, (const T_ *)obs, logits, value);            \
+                                                                        \
+    } while (0)
+#define RNAD_MLP_LAUNCH(T_)                                   \
+    do {                                                      \
+        if (heads == 1) RNAD_MLP_LAUNCH2(T_, 1);              \
+        else if (heads == 2) RNAD_MLP_LAUNCH2(T_, 2);         \
+        else RNAD_MLP_LAUNCH2(T_, 3);                         \
+    } while (0)
+    RNAD_DISPATCH_A(A, {
+        if (obs_half)
+            RNAD_MLP_LAUNCH(__half);
+        else
+            RNAD_MLP_LAUNCH(float);
+    });
+#undef RNAD_MLP_LAUNCH2
+#undef RNAD_MLP_LAUNCH
+    RNAD_HIP_OK(hipGetLastError());
+    return 0;
+}
+
