@@ -1,4 +1,4 @@
-// mlp.hip -- fused policy/value MLP forward on the fp32 matrix cores (gfx950).
+// mlp_fwd.hip -- fused policy/value MLP forward on the fp32 matrix cores (gfx950).
 //
 // Replaces the tensor program of nn/net.py:40-43 (and :70-73 in forward_batch):
 //     value  = value_fc1 (relu(value_fc0 (x)))        x = observation flattened to 2*A*A floats
@@ -17,8 +17,15 @@
 //   C layout   lane l holds sample (l & 31) and hidden rows (r & 3) + 8 (r >> 2) + 4 (l >> 5), r in [0, 16):
 //              four consecutive hidden units per register quad -> relu, then the second layer as VALU FMAs against
 //              float4 reads of W1 from LDS; the two half-waves hold complementary rows and are summed with one DPP add.
-// Both heads share the B operand; a wave walks 2 * W / 32 hidden tiles per 32 samples.  Matrix-pipe time per sample
-// tile = 2 * (W / 32) * (K / 2) * 64 cycles.
+// Both heads share the B operand; a wave walks 2 * W / 32 hidden tiles per 64 samples (two MFMA sample tiles per LDS read).
+// Matrix-pipe time per sample tile = 2 * (W / 32) * (K / 2) * 64 cycles.
+//
+// Where the time goes (profiles/r01e_mlp_pmc.md): fp32 MFMA and fp32 VALU share the ALUs on gfx950, so a hidden tile pair
+// costs 18 * 64 MFMA cycles + 32 v_max (4.7 cycles each) + the second-layer packed FMAs (6.4 each); that sum is 72 % matrix
+// pipe, and the kernel measures 72 % of the fp32 MFMA peak AT THE CLOCK IT RUNS AT -- 2.04 GHz under this load, not 2.4
+// (GRBM_GUI_ACTIVE / wall time; a bare MFMA loop holds 2.39 GHz).  LDS traffic, LDS latency and the input loads were each
+// removed in turn (two sample tiles per weight read, software-pipelined operand reads, prefetched inputs) without moving the
+// wall time: the kernel is ALU- and power-bound, not memory- or latency-bound.
 #include "mlp_common.hpp"
 
 using namespace rnad;
@@ -52,6 +59,39 @@ __device__ __forceinline__ void epilogue_policy(const f32x16 &c, const float *__
     }
 }
 
+// First layer for ONE hidden tile and TWO 32-sample tiles: the A operand (weights) and the bias tile are read from LDS once
+// and feed two independent accumulator chains.  The first-layer bias enters as the C operand of each chain's first MFMA
+// (destination != source, so no register copies and no tenth MFMA).
+template <int A>
+__device__ __forceinline__ void mfma_chain2(const float *__restrict__ lds, int W, int tile, int col, int half, const float (&x0)[A * A],
+                                            const float (&x1)[A * A], f32x16 &c0, f32x16 &c1) {
+    constexpr int K = 2 * A * A, KS = A * A;
+    const float *wa = lds + tile * (KS * 64) + half * 32 + col;
+    const float *brow = lds + img_b0(K, W) + tile * kTile + 4 * half;
+    float a[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) a[ks] = wa[ks * 64];
+    f32x16 bias;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const float4 b = *reinterpret_cast<const float4 *>(brow + 8 * g);
+        bias[4 * g + 0] = b.x; bias[4 * g + 1] = b.y; bias[4 * g + 2] = b.z; bias[4 * g + 3] = b.w;
+    }
+    c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0], x0[0], bias, 0, 0, 0);
+    c1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0], x1[0], bias, 0, 0, 0);
+#pragma unroll
+    for (int ks = 1; ks < KS; ++ks) {
+        c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ks], x0[ks], c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ks], x1[ks], c1, 0, 0, 0);
+    }
+}
+
+// HEADS: 1 = value only, 2 = policy only, 3 = both.  A wave owns 64 consecutive samples (two MFMA sample tiles) and walks the
+// hidden tiles of the wanted heads one at a time: every LDS read (first-layer weights, second-layer weights) serves both
+// sample tiles, which keeps the LDS pipe (shared by the four SIMDs) well below saturation.  The next 64 samples' inputs are
+// loaded while the current ones are in the matrix pipe.  (Measured on gfx950: fp32 MFMA and fp32 VALU share the ALUs --
+// tools/micro/mfma_peak.hip: every v_pk_fma_f32 adds 6.4 cycles to a 64-cycle MFMA -- so the VALU epilogue is kernel time and
+// is kept to relu + the second-layer FMAs.)
 template <int A, typename ObsT, int HEADS>
 __global__ __launch_bounds__(kFwdThreads) void k_mlp_forward(int64_t N, int W, const float *__restrict__ packed,
                                                              const ObsT *__restrict__ obs, float *__restrict__ logits,
@@ -76,54 +116,67 @@ __global__ __launch_bounds__(kFwdThreads) void k_mlp_forward(int64_t N, int W, c
     float bp[A];
 #pragma unroll
     for (int a = 0; a < A; ++a) bp[a] = b1[1 + a];
-    // tile pair p of this launch: both heads -> (value tile p, policy tile p); one head -> its tiles (2p, 2p + 1)
-    const int n_pairs = HEADS == 3 ? T : T / 2;  // single-head launches need an even tile count (the launcher sees to it)
-    const int first = HEADS == 2 ? T : 0;
-    const int stride0 = HEADS == 3 ? 1 : 2, off1 = HEADS == 3 ? T : 1;
 
-    const int64_t n_tiles = (N + kTile - 1) / kTile;
-    for (int64_t tile = (int64_t)blockIdx.x * (kFwdThreads / 64) + wave; tile < n_tiles; tile += (int64_t)gridDim.x * (kFwdThreads / 64)) {
-        const int64_t sample = tile * kTile + col;
-        const bool live = sample < N;
-        float xk[KS];
+    constexpr int kSpan = 2 * kTile;  // samples per wave iteration
+    const int64_t n_spans = (N + kSpan - 1) / kSpan;
+    const int64_t span0 = (int64_t)blockIdx.x * (kFwdThreads / 64) + wave, dspan = (int64_t)gridDim.x * (kFwdThreads / 64);
+    float xn[2][KS];  // inputs of the next span, in flight during the current one
+    auto fetch = [&](int64_t span) {
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) xk[ks] = live ? load_obs<ObsT>(obs + sample * K + 2 * ks + half) : 0.0f;
-
-        f32x2 acc_v[2] = {f32x2{0.f, 0.f}, f32x2{0.f, 0.f}}, acc_p[A][2];
+        for (int s = 0; s < 2; ++s) {
+            const int64_t sample = span * kSpan + s * kTile + col;
 #pragma unroll
-        for (int a = 0; a < A; ++a) acc_p[a][0] = acc_p[a][1] = f32x2{0.f, 0.f};
+            for (int ks = 0; ks < KS; ++ks) xn[s][ks] = sample < N ? load_obs<ObsT>(obs + sample * K + 2 * ks + half) : 0.0f;
+        }
+    };
+    if (span0 < n_spans) fetch(span0);
+    for (int64_t span = span0; span < n_spans; span += dspan) {
+        float x0[KS], x1[KS];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) { x0[ks] = xn[0][ks]; x1[ks] = xn[1][ks]; }
+        if (span + dspan < n_spans) fetch(span + dspan);
 
-        int t0 = first;
-        for (int p = 0; p < n_pairs; ++p) {
-            const int t1 = t0 + off1;
-            const f32x16 c0 = mfma_chain<A>(lds, W, t0, col, half, xk);
-            const f32x16 c1 = mfma_chain<A>(lds, W, t1, col, half, xk);
-            if (HEADS == 1) {
-                epilogue_value(c0, w1v + t0 * kTile + 4 * half, acc_v);
-                epilogue_value(c1, w1v + t1 * kTile + 4 * half, acc_v);
-            } else if (HEADS == 2) {
-                epilogue_policy<A>(c0, w1p + (t0 - T) * kTile + 4 * half, W, acc_p);
-                epilogue_policy<A>(c1, w1p + (t1 - T) * kTile + 4 * half, W, acc_p);
-            } else {
-                epilogue_value(c0, w1v + t0 * kTile + 4 * half, acc_v);
-                epilogue_policy<A>(c1, w1p + (t1 - T) * kTile + 4 * half, W, acc_p);
+        f32x2 acc_v[2][2], acc_p[2][A][2];
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            acc_v[s][0] = acc_v[s][1] = f32x2{0.f, 0.f};
+#pragma unroll
+            for (int a = 0; a < A; ++a) acc_p[s][a][0] = acc_p[s][a][1] = f32x2{0.f, 0.f};
+        }
+        if (HEADS & 1) {
+            for (int t = 0; t < T; ++t) {
+                f32x16 c0, c1;
+                mfma_chain2<A>(lds, W, t, col, half, x0, x1, c0, c1);
+                epilogue_value(c0, w1v + t * kTile + 4 * half, acc_v[0]);
+                epilogue_value(c1, w1v + t * kTile + 4 * half, acc_v[1]);
             }
-            t0 += stride0;
+        }
+        if (HEADS & 2) {
+            for (int t = 0; t < T; ++t) {
+                f32x16 c0, c1;
+                mfma_chain2<A>(lds, W, T + t, col, half, x0, x1, c0, c1);
+                epilogue_policy<A>(c0, w1p + t * kTile + 4 * half, W, acc_p[0]);
+                epilogue_policy<A>(c1, w1p + t * kTile + 4 * half, W, acc_p[1]);
+            }
         }
         // lane-local sums, then the two half-waves (complementary hidden rows of the same 32 samples)
-        float out_v = (acc_v[0].x + acc_v[0].y) + (acc_v[1].x + acc_v[1].y), out_p[A];
 #pragma unroll
-        for (int a = 0; a < A; ++a) out_p[a] = (acc_p[a][0].x + acc_p[a][0].y) + (acc_p[a][1].x + acc_p[a][1].y);
-        if (HEADS & 1) out_v += __shfl_xor(out_v, 32, 64);
-        if (HEADS & 2) {
+        for (int s = 0; s < 2; ++s) {
+            const int64_t sample = span * kSpan + s * kTile + col;
+            float out_v = (acc_v[s][0].x + acc_v[s][0].y) + (acc_v[s][1].x + acc_v[s][1].y), out_p[A];
 #pragma unroll
-            for (int a = 0; a < A; ++a) out_p[a] += __shfl_xor(out_p[a], 32, 64);
-        }
-        if (live && half == 0) {
-            if ((HEADS & 1) && value) value[sample] = out_v + bv;
-            if ((HEADS & 2) && logits) {
+            for (int a = 0; a < A; ++a) out_p[a] = (acc_p[s][a][0].x + acc_p[s][a][0].y) + (acc_p[s][a][1].x + acc_p[s][a][1].y);
+            if (HEADS & 1) out_v += __shfl_xor(out_v, 32, 64);
+            if (HEADS & 2) {
 #pragma unroll
-                for (int a = 0; a < A; ++a) logits[sample * A + a] = out_p[a] + bp[a];
+                for (int a = 0; a < A; ++a) out_p[a] += __shfl_xor(out_p[a], 32, 64);
+            }
+            if (sample < N && half == 0) {
+                if ((HEADS & 1) && value) value[sample] = out_v + bv;
+                if ((HEADS & 2) && logits) {
+#pragma unroll
+                    for (int a = 0; a < A; ++a) logits[sample * A + a] = out_p[a] + bp[a];
+                }
             }
         }
     }
@@ -189,21 +242,18 @@ extern "C" int rnad_mlp_forward(int64_t N, int A, int W, const float *packed, co
     int dev = 0, cus = 256;
     RNAD_HIP_OK(hipGetDevice(&dev));
     RNAD_HIP_OK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-    size_t lds_pad = 0;
-    if (const char *e = getenv("RNAD_MLP_LDS_PAD")) lds_pad = (size_t)atoi(e);  // experiment knob: fewer blocks per CU
     constexpr int kWaves = kFwdThreads / 64;
-    const int blocks_per_cu = std::max(1, std::min(12 / kWaves, (int)(160 * 1024 / (lds_bytes + lds_pad))));
-    const int64_t n_tiles = (N + kTile - 1) / kTile;
-    const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>((n_tiles + kWaves - 1) / kWaves, (int64_t)cus * blocks_per_cu));
-    int heads = (value ? 1 : 0) | (logits ? 2 : 0);
-    if ((W / kTile) % 2) heads = 3;  // odd tile count: the paired single-head kernels do not apply; compute both, store the wanted one
+    const int blocks_per_cu = std::max(1, std::min(12 / kWaves, (int)(160 * 1024 / lds_bytes)));
+    const int64_t n_spans = (N + 2 * kTile - 1) / (2 * kTile);  // a wave iteration covers 64 samples
+    const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>((n_spans + kWaves - 1) / kWaves, (int64_t)cus * blocks_per_cu));
+    const int heads = (value ? 1 : 0) | (logits ? 2 : 0);
     ProfScope prof(PROF_MLP, stream);
 #define RNAD_MLP_LAUNCH2(T_, H_)                                                                                                  \
     do {                                                                                                                           \
         auto kern = k_mlp_forward<kA, T_, H_>;                                                                                     \
-        if (lds_bytes + lds_pad > 64 * 1024)                                                                                       \
-            RNAD_HIP_OK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds_bytes + lds_pad))); \
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(kFwdThreads), lds_bytes + lds_pad, stream, N, W, packed, (const T_ *)obs, logits, value);            \
+        if (lds_bytes > 64 * 1024)                                                                                       \
+            RNAD_HIP_OK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes)); \
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(kFwdThreads), lds_bytes, stream, N, W, packed, (const T_ *)obs, logits, value);            \
                                                                         \
     } while (0)
 #define RNAD_MLP_LAUNCH(T_)                                   \
