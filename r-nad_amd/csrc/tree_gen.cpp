@@ -9,6 +9,8 @@
 #include <cmath>
 #include <cstdint>
 #include <cstring>
+#include <thread>
+#include <atomic>
 #include <vector>
 
 #include "rnad_hip.h"
@@ -236,61 +238,103 @@ struct Gen {
         for (int t = 0; t < C; ++t) p[t] = f[t] / d;
     }
 
-    // Returns the state's NE payoff; `id` is its DFS pre-order id (root = 1).
-    float build(int depth_bound) {
+    // Structure pass for one state (DFS pre-order id, root = 1): chance profiles, pruning, terminal payoffs, child ids --
+    // everything that consumes random numbers, in the reference's order.  Matrix games are NOT solved here: a state's payoff
+    // matrix needs its children's equilibrium payoffs, so the solves run afterwards, bottom-up by level and in parallel
+    // (solve_levels).  The counting pass (no output buffers) stops at the structure.
+    void build(int depth_bound, int level, int64_t parent_slot) {
         const int AA = A * A;
         const int64_t id = ++count;  // pre-order: the parent takes its id before its children (tree.py:311-330)
-        std::vector<float> ch((size_t)C * AA), val((size_t)C * AA, 0.0f), evm((size_t)AA, 0.0f);
-        std::vector<int64_t> idx((size_t)C * AA, 0);
+        if (writing() && id >= capacity) {
+            failed = true;
+            return;
+        }
+        std::vector<float> ch((size_t)C * AA);
         for (int rc = 0; rc < AA; ++rc) {  // the child-less ctor draws the whole [A, A, C] profile first (tree.py:134-136)
             float p[RNAD_MAX_TRANSITIONS];
             chance_profile(p);
             for (int t = 0; t < C; ++t) ch[(size_t)t * AA + rc] = p[t];
         }
+        if (writing()) {
+            for (int k = 0; k < C * AA; ++k) {
+                index[id * C * AA + k] = 0;
+                value[id * C * AA + k] = 0.0f;
+                chance[id * C * AA + k] = ch[k];
+            }
+            for (int k = 0; k < AA; ++k) legal[id * AA + k] = 1.0f;
+            level_of[(size_t)id] = level;
+            parent_of[(size_t)id] = parent_slot;
+            max_level = std::max(max_level, level);
+        }
         for (int r = 0; r < A; ++r)
             for (int c = 0; c < A; ++c) {
                 const int rc = r * A + c;
-                float e = 0.0f;
                 for (int t = 0; t < C; ++t) {  // tree.py:253-277
-                    const float tp = ch[(size_t)t * AA + rc];
-                    if (tp > 0.0f) {
-                        int child_depth = depth_bound - 1;
-                        if (prune_den > 0 && (int)rng.below((uint64_t)prune_den) < prune_num) child_depth -= 2;  // main.py:37
-                        child_depth = std::max(0, child_depth);
-                        float payoff;
-                        if (child_depth > 0) {
-                            idx[(size_t)t * AA + rc] = count + 1;  // the id the child is about to take
-                            payoff = build(child_depth);
-                        } else {
-                            payoff = tv[rng.below((uint64_t)ntv)];  // random.choice(terminal_values) (tree.py:273-275)
-                        }
-                        val[(size_t)t * AA + rc] = payoff;
+                    if (!(ch[(size_t)t * AA + rc] > 0.0f)) continue;
+                    int child_depth = depth_bound - 1;
+                    if (prune_den > 0 && (int)rng.below((uint64_t)prune_den) < prune_num) child_depth -= 2;  // main.py:37
+                    child_depth = std::max(0, child_depth);
+                    const int64_t slot = id * C * AA + (int64_t)t * AA + rc;
+                    if (child_depth > 0) {
+                        if (writing()) index[slot] = count + 1;  // the id the child is about to take
+                        build(child_depth, level + 1, slot);
+                        if (failed) return;
+                    } else {
+                        const float payoff = tv[rng.below((uint64_t)ntv)];  // random.choice(terminal_values) (tree.py:273-275)
+                        if (writing()) value[slot] = payoff;
                     }
-                    e += val[(size_t)t * AA + rc] * tp;  // tree.py:280-282
                 }
-                evm[rc] = e;
             }
-        float sol[2 * MAXA], rv = 0.0f;
-        if (!solve_matrix(evm.data(), A, A, A, sol, &rv)) failed = true;
-        if (writing()) {
-            if (id >= capacity) {
-                failed = true;
-                return rv;
-            }
-            for (int k = 0; k < C * AA; ++k) {
-                index[id * C * AA + k] = idx[k];
-                value[id * C * AA + k] = val[k];
-                chance[id * C * AA + k] = ch[k];
-            }
-            for (int k = 0; k < AA; ++k) {
-                ev[id * AA + k] = evm[k];
-                legal[id * AA + k] = 1.0f;
-            }
-            root_value[id] = rv;
-            for (int k = 0; k < 2 * A; ++k) solution[id * 2 * A + k] = sol[k];
-        }
-        return rv;
     }
+
+    // tree.py:280-300 for one state whose children are done: expected_value = sum_t value * chance, the matrix game, and the
+    // state's own payoff handed up into its parent's value slot.
+    bool solve_state(int64_t id) {
+        const int AA = A * A;
+        float evm[MAXA * MAXA];
+        for (int rc = 0; rc < AA; ++rc) {
+            float e = 0.0f;
+            for (int t = 0; t < C; ++t) e += value[id * C * AA + (int64_t)t * AA + rc] * chance[id * C * AA + (int64_t)t * AA + rc];
+            evm[rc] = e;
+            ev[id * AA + rc] = e;
+        }
+        float sol[2 * MAXA], rv = 0.0f;
+        if (!solve_matrix(evm, A, A, A, sol, &rv)) return false;
+        root_value[id] = rv;
+        for (int k = 0; k < 2 * A; ++k) solution[id * 2 * A + k] = sol[k];
+        if (parent_of[(size_t)id] >= 0) value[parent_of[(size_t)id]] = rv;
+        return true;
+    }
+
+    // Deepest level first; the states of one level are independent (each writes its own rows and one slot of its parent).
+    void solve_levels() {
+        std::vector<std::vector<int64_t>> by_level((size_t)max_level + 1);
+        for (int64_t id = 1; id <= count; ++id) by_level[(size_t)level_of[(size_t)id]].push_back(id);
+        unsigned hw = std::thread::hardware_concurrency();
+        const unsigned max_threads = std::max(1u, std::min(hw ? hw : 1u, 32u));
+        std::atomic<bool> bad{false};
+        for (int lv = max_level; lv >= 0; --lv) {
+            const std::vector<int64_t> &ids = by_level[(size_t)lv];
+            const size_t n = ids.size();
+            const unsigned nt = (unsigned)std::min<size_t>(max_threads, (n + 255) / 256);  // >= 256 states per thread
+            auto work = [&](size_t lo, size_t hi) {
+                for (size_t i = lo; i < hi; ++i)
+                    if (!solve_state(ids[i])) bad = true;
+            };
+            if (nt <= 1) {
+                work(0, n);
+            } else {
+                std::vector<std::thread> pool;
+                for (unsigned w = 0; w < nt; ++w) pool.emplace_back(work, n * w / nt, n * (w + 1) / nt);
+                for (std::thread &t : pool) t.join();
+            }
+        }
+        if (bad) failed = true;
+    }
+
+    std::vector<int> level_of;        // [capacity] depth below the root
+    std::vector<int64_t> parent_of;   // [capacity] flat index of the parent's value slot, -1 for the root
+    int max_level = 0;
 };
 
 }  // namespace
@@ -345,7 +389,12 @@ extern "C" int64_t rnad_tree_generate(int A, int C, int depth_bound, float trans
         legal[0] = 1.0f;
         root_value[0] = 0.0f;
     }
-    g.build(depth_bound);
+    if (writing) {
+        g.level_of.assign((size_t)capacity, 0);
+        g.parent_of.assign((size_t)capacity, -1);
+    }
+    g.build(depth_bound, 0, -1);
+    if (writing && !g.failed) g.solve_levels();
     if (g.failed) {
         rnad::set_error(writing ? "rnad_tree_generate: capacity %lld too small or a matrix was not solved"
                                 : "rnad_tree_generate: a matrix game was not solved",
