@@ -49,6 +49,10 @@ def main():
     ap.add_argument("--actions", type=int, default=3)
     ap.add_argument("--transitions", type=int, default=1)
     ap.add_argument("--width", type=int, default=256)
+    ap.add_argument("--prune", type=int, nargs=2, default=(0, 0), metavar=("NUM", "DEN"),
+                    help="each child's depth drops by 2 more with probability NUM/DEN (reference main.py:37); configs[3] uses a pruned tree")
+    ap.add_argument("--threshold", type=float, default=None, help="transition_threshold (default 0 for C=1, 0.5/C otherwise)")
+    ap.add_argument("--tree-seed", type=int, default=0)
     ap.add_argument("--obs-half", action="store_true", help="fp16 observations (BASELINE configs[4])")
     ap.add_argument("--cpu-lanes-log2", type=int, default=15, help="episodes in the CPU-baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -79,8 +83,9 @@ def main():
 
     # ---- setup (untimed): tree tables into HBM, nets, optimizer
     t0 = time.perf_counter()
-    tree = Tree(device=device, max_actions=A, max_transitions=C, depth_bound=depth, transition_threshold=0.0 if C == 1 else 0.5 / C)
-    tree.generate_native(seed=0)
+    threshold = args.threshold if args.threshold is not None else (0.0 if C == 1 else 0.5 / C)
+    tree = Tree(device=device, max_actions=A, max_transitions=C, depth_bound=depth, transition_threshold=threshold)
+    tree.generate_native(seed=args.tree_seed, prune=tuple(args.prune))
     tree.handle()
     setup_tree_s = time.perf_counter() - t0
     os.environ["RNAD_SAVE_DIR"] = tempfile.mkdtemp(prefix="rnad_bench_")
@@ -141,7 +146,8 @@ def main():
     fence()
     t_r = time.perf_counter()
     for i in range(args.steps):
-        Episodes(tree, local_batch, seed=1000 + i, lane_offset=rank * local_batch, obs_half=args.obs_half).generate(rn.net)
+        Episodes(tree, local_batch, seed=1000 + i, lane_offset=rank * local_batch, obs_half=args.obs_half).generate(
+            rn.net, trim=False, skip_absorbed=True)  # as RNaD.train_step calls it
     fence()
     rollout_s = time.perf_counter() - t_r
     if world > 1:
@@ -150,7 +156,12 @@ def main():
         elapsed, rollout_s, elapsed_reuse = t.tolist()
 
     if rank == 0:
-        env_steps = global_batch * T * args.steps
+        # the reference's loop (episode.py:194) runs until every lane is absorbed and counts all B lanes in each of those steps;
+        # on the regular c2 tree that is all T = 2 * depth steps, on pruned trees the trailing all-absorbed steps are not counted
+        alive = rn.last_episodes.alive.cpu().numpy()[:T]
+        T_ref = int((alive > 0).sum())
+        env_steps = global_batch * T_ref * args.steps
+        default_workload = (A, C, depth, tuple(args.prune), args.batch_log2, args.width) == (3, 1, 6, (0, 0), 20, 256)
         obs_elem = 2 if args.obs_half else 4
         k1_bytes_per_step = 4 + 8 * A * A + 2 * A * A * obs_elem + 4 * A  # idx + ev row + legal row + obs + mask
         k1_bytes_per_launch = k1_bytes_per_step * local_batch
@@ -178,8 +189,11 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": f"depth-{depth} {A}x{A} matrix tree, C={C}, S={tree.index_tensor.shape[0]}, global batch 2^{args.batch_log2}"
-                            f" episodes x T={T} env steps, MLP width {args.width}, BASELINE.json configs[1]",
-                "global_batch": global_batch, "per_gpu_batch": local_batch, "T": T,
+                            f" episodes x T={T_ref} env steps, MLP width {args.width}"
+                            + (", BASELINE.json configs[1]" if default_workload else
+                               f", prune {args.prune[0]}/{args.prune[1]}, threshold {threshold:g} (a BASELINE.json configs[3]/[4]-style variant)"),
+                "global_batch": global_batch, "per_gpu_batch": local_batch, "T": T_ref, "T_buffer": T,
+                "valid_env_steps_per_step": int(alive.sum()) * world,
                 "parallelism": f"dp{world} (episodes sharded, RCCL all-reduce of 2 normalisers + 43 KB grads)",
             },
             "updates_per_sec": args.steps / elapsed,

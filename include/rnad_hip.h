@@ -55,7 +55,8 @@ int rnad_tree_create(rnad_tree_t **out, int64_t S, int C, int A, const int64_t *
                      const float *chance, const float *expected_value, const float *legal, int device);
 void rnad_tree_destroy(rnad_tree_t *tree);
 /* size queries: which = 0:S 1:C 2:A 3:max game depth (longest root->terminal chain of transitions)
- * 4:node stride in floats 5:bytes of device tables */
+ * 4:node stride in floats 5:bytes of device tables 6:1 if every episode has the same length (the tree is left only from
+ * its deepest level: nothing for the live-row lists below to skip) */
 int64_t rnad_tree_info(const rnad_tree_t *tree, int which);
 
 /* ------------------------------------------------------------------------------------------------
@@ -102,6 +103,22 @@ int64_t rnad_mlp_backward_workspace(int64_t N, int A, int W);
 int rnad_mlp_backward(int64_t N, int A, int W, const float *packed, const void *obs, int obs_half, const float *dlogits,
                       const float *dvalue, float *g_vw0, float *g_vb0, float *g_vw1, float *g_vb1, float *g_pw0,
                       float *g_pb0, float *g_pw1, float *g_pb1, float *workspace, void *stream);
+
+/* Ragged trees: once an episode is absorbed (state 0) the reference keeps evaluating the nets on it (episode.py:194-212,
+ * net.py:64-85 run on all of [T, B]) and masks the results (`valid`, rnad.py:369).  The *_rows variants evaluate only the
+ * rows listed: sample s of the launch is row rows[s] of obs / logits / value / dlogits / dvalue; rows that are not listed
+ * are neither read nor written.  The row count is read from device memory (*n_rows <= max_rows), so the list can be built
+ * on the same stream with no host round trip.
+ * rnad_compact_valid: rows = the positions r in [0, N) with indices[r] != 0, ascending, *n_rows = how many;
+ * block_counts: scratch of rnad_compact_workspace(N) int32. */
+int64_t rnad_compact_workspace(int64_t N);
+int rnad_compact_valid(int64_t N, const int32_t *indices, int32_t *rows, int64_t *n_rows, int32_t *block_counts, void *stream);
+int rnad_mlp_forward_rows(int64_t max_rows, const int32_t *rows, const int64_t *n_rows, int A, int W, const float *packed,
+                          const void *obs, int obs_half, float *logits, float *value, void *stream);
+int rnad_mlp_backward_rows(int64_t max_rows, const int32_t *rows, const int64_t *n_rows, int A, int W, const float *packed,
+                           const void *obs, int obs_half, const float *dlogits, const float *dvalue, float *g_vw0,
+                           float *g_vb0, float *g_vw1, float *g_vb1, float *g_pw0, float *g_pb0, float *g_pw1, float *g_pb1,
+                           float *workspace, void *stream);
 
 /* ------------------------------------------------------------------------------------------------
  * K3  sample  --  torch.multinomial(policy, 1) at nn/net.py:49, i.e. argmax_a(policy[a] / q[a]) with
@@ -161,9 +178,14 @@ int rnad_rollout_step(const rnad_tree_t *tree, const rnad_traj_t *traj, int t, i
  * for every t: rnad_mlp_forward(observations[t]) -> rnad_rollout_step(mode 0), then rnad_rollout_end -- enqueued from ONE
  * call (3 * T_cap + 2 launches, no host work in between).  packed: rnad_mlp_pack image; value_ws [B] scratch;
  * logits_ws: [B,A] scratch with logits_step_stride = 0, or a [T_cap,B,A] buffer with logits_step_stride = B*A that
- * keeps the actor's raw logits of every step.  Seeded noise only. */
+ * keeps the actor's raw logits of every step.  Seeded noise only.
+ * live_rows [B] int32 / n_live [1] / block_counts [rnad_compact_workspace(B)]: all NULL = the actor runs on every lane at
+ * every step, as the reference does; all given (logits_step_stride must be 0) = from step 1 on it runs only on the lanes
+ * still in the tree (rnad_compact_valid + rnad_mlp_forward_rows); absorbed lanes then carry the logits / value of their
+ * last live step instead of the net's output on state 0 -- masked everywhere downstream. */
 int rnad_rollout_run(const rnad_tree_t *tree, const rnad_traj_t *traj, int W, const float *packed, float *logits_ws,
-                     int64_t logits_step_stride, float *value_ws, uint64_t seed, int64_t lane0, void *stream);
+                     int64_t logits_step_stride, float *value_ws, uint64_t seed, int64_t lane0, int32_t *live_rows,
+                     int64_t *n_live, int32_t *block_counts, void *stream);
 
 /* alive[t] = #lanes with indices[t, :] != 0 for t in [0, T_cap]: one pass over the index buffer after the last
  * step.  The host reads it once to trim the trajectory to the reference's T (episode.py:194 stops when every lane

@@ -59,6 +59,7 @@ struct ProfScope {
 struct rnad_tree {
     int64_t S = 0;
     int C = 0, A = 0, NS = 0, device = 0, max_depth = 0;
+    bool uniform_length = false;  // every episode takes exactly max_depth transitions (no early terminal, nothing pruned)
     float *node = nullptr;        // [S][NS]
     rnad::Trans *trans = nullptr; // [S][A][A][C]
     // NashConv support: states grouped by depth below the root (level 0 = {1}); ids of one level are contiguous

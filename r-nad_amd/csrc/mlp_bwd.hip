@@ -22,7 +22,9 @@ namespace {
 template <int A, typename ObsT, int WAVES>
 __global__ __launch_bounds__(64 * WAVES) void k_mlp_backward(int64_t N, int W, const float *__restrict__ packed,
                                                        const ObsT *__restrict__ obs, const float *__restrict__ dlogit,
-                                                       const float *__restrict__ dv, float *__restrict__ partial, int P) {
+                                                       const float *__restrict__ dv, float *__restrict__ partial, int P,
+                                                       const int32_t *__restrict__ rows, const int64_t *__restrict__ n_rows) {
+    if (n_rows) N = *n_rows;  // row-list launch (see k_mlp_forward): sample s is row rows[s]; the count lives in device memory
     constexpr int K = 2 * A * A, KS = K / 2;
     constexpr int FT = (K + 1 + kTile - 1) / kTile;  // 32-wide feature tiles of the augmented input (x | 1)
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -69,46 +71,55 @@ __global__ __launch_bounds__(64 * WAVES) void k_mlp_backward(int64_t N, int W, c
     constexpr int XN = kTile * K, STG = XN + kTile + kTile * A;  // floats per stage: x | dv | dlogits
     float *stage = scratch + WAVES * (kTile * 33);               // [2][STG]
     const int64_t n_tiles = (N + kTile - 1) / kTile;
-    const int64_t NK = N * K;
-    constexpr int XU = (XN + nthreads - 1) / nthreads, DU = (kTile * A + nthreads - 1) / nthreads;  // prefetch registers per thread
+    // TPS threads share one sample of the tile: thread (smp, part) loads elements part, part + TPS, ... of that sample's row.
+    // One row id per thread and tile, itself prefetched a further tile ahead (row-list launches: a lookup that the x loads
+    // would otherwise have to wait for, exposed, at the top of every tile).
+    constexpr int TPS = nthreads / kTile, XU = (K + TPS - 1) / TPS, DU = (A + TPS - 1) / TPS;
+    const int smp = threadIdx.x / TPS, part = threadIdx.x % TPS;
     float pre_x[XU], pre_dv = 0.0f, pre_dl[DU];
-    auto fetch = [&](int64_t tile) {  // global -> registers
-        const int64_t s0 = tile * kTile;
+    auto row_of = [&](int64_t tile) -> int64_t {  // -1: past the end
+        const int64_t sample = tile * kTile + smp;
+        if (tile >= n_tiles || sample >= N) return -1;
+        return rows ? (int64_t)rows[sample] : sample;
+    };
+    auto fetch = [&](int64_t row) {  // global -> registers
+        const bool in = row >= 0;
 #pragma unroll
         for (int u = 0; u < XU; ++u) {
-            const int i = threadIdx.x + u * nthreads;
-            const int64_t gi = s0 * K + i;
-            pre_x[u] = (i < XN && gi < NK) ? load_obs<ObsT>(obs + gi) : 0.0f;
+            const int k = part + u * TPS;
+            pre_x[u] = (in && k < K) ? load_obs<ObsT>(obs + row * K + k) : 0.0f;
         }
-        pre_dv = (threadIdx.x < kTile && s0 + threadIdx.x < N) ? dv[s0 + threadIdx.x] : 0.0f;
+        pre_dv = (in && part == 0) ? dv[row] : 0.0f;
 #pragma unroll
         for (int u = 0; u < DU; ++u) {
-            const int i = threadIdx.x + u * nthreads;
-            pre_dl[u] = (i < kTile * A && s0 * A + i < N * A) ? dlogit[s0 * A + i] : 0.0f;
+            const int a = part + u * TPS;
+            pre_dl[u] = (in && a < A) ? dlogit[row * A + a] : 0.0f;
         }
     };
     auto park = [&](float *dst) {  // registers -> LDS stage
 #pragma unroll
         for (int u = 0; u < XU; ++u) {
-            const int i = threadIdx.x + u * nthreads;
-            if (i < XN) dst[i] = pre_x[u];
+            const int k = part + u * TPS;
+            if (k < K) dst[smp * K + k] = pre_x[u];
         }
-        if (threadIdx.x < kTile) dst[XN + threadIdx.x] = pre_dv;
+        if (part == 0) dst[XN + smp] = pre_dv;
 #pragma unroll
         for (int u = 0; u < DU; ++u) {
-            const int i = threadIdx.x + u * nthreads;
-            if (i < kTile * A) dst[XN + kTile + i] = pre_dl[u];
+            const int a = part + u * TPS;
+            if (a < A) dst[XN + kTile + smp * A + a] = pre_dl[u];
         }
     };
     int cur = 0;
     if ((int64_t)blockIdx.x < n_tiles) {
-        fetch(blockIdx.x);
+        fetch(row_of(blockIdx.x));
         park(stage);
     }
+    int64_t row_next = row_of((int64_t)blockIdx.x + gridDim.x);
     __syncthreads();
     for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         const bool more = tile + gridDim.x < n_tiles;
-        if (more) fetch(tile + gridDim.x);  // next tile's loads are in flight during this tile's matrix work
+        if (more) fetch(row_next);  // next tile's loads are in flight during this tile's matrix work
+        row_next = row_of(tile + 2 * (int64_t)gridDim.x);
         const float *xs = stage + cur * STG;
         float xk[KS];   // B operand of the forward product: x[sample = col][2 ks + half]
 #pragma unroll
@@ -303,9 +314,9 @@ extern "C" int64_t rnad_mlp_backward_workspace(int64_t N, int A, int W) {
     return (int64_t)p.grid_x * p.P * (int64_t)sizeof(float);
 }
 
-extern "C" int rnad_mlp_backward(int64_t N, int A, int W, const float *packed, const void *obs, int obs_half, const float *dlogits,
-                                 const float *dvalue, float *g_vw0, float *g_vb0, float *g_vw1, float *g_vb1, float *g_pw0,
-                                 float *g_pb0, float *g_pw1, float *g_pb1, float *workspace, void *stream_) {
+static int mlp_backward_launch(int64_t N, const int32_t *rows, const int64_t *n_rows, int A, int W, const float *packed, const void *obs,
+                               int obs_half, const float *dlogits, const float *dvalue, float *g_vw0, float *g_vb0, float *g_vw1,
+                               float *g_vb1, float *g_pw0, float *g_pb0, float *g_pw1, float *g_pb1, float *workspace, void *stream_) {
     RNAD_REQUIRE(packed && obs && dlogits && dvalue && g_vw0 && g_vb0 && g_vw1 && g_vb1 && g_pw0 && g_pb0 && g_pw1 && g_pb1 && workspace,
                  "rnad_mlp_backward: null argument");
     RNAD_REQUIRE(W >= kTile && W % kTile == 0, "rnad_mlp_backward: width %d must be a positive multiple of %d", W, kTile);
@@ -325,7 +336,7 @@ extern "C" int rnad_mlp_backward(int64_t N, int A, int W, const float *packed, c
         if (lds_bytes > 64 * 1024)                                                                                                 \
             RNAD_HIP_OK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));      \
         hipLaunchKernelGGL(kern, dim3(grid, plan.groups), dim3(threads), lds_bytes, stream, N, W, packed, (const T_ *)obs, dlogits, \
-                           dvalue, workspace, P);                                                                                  \
+                           dvalue, workspace, P, rows, n_rows);                                                                                  \
     } while (0)
 #define RNAD_MLPB_WAVES(T_)                                                      \
     do {                                                                         \
@@ -349,4 +360,20 @@ extern "C" int rnad_mlp_backward(int64_t N, int A, int W, const float *packed, c
                                           g_vw1, g_vb1, g_pw0, g_pb0, g_pw1, g_pb1));
     RNAD_HIP_OK(hipGetLastError());
     return 0;
+}
+
+extern "C" int rnad_mlp_backward(int64_t N, int A, int W, const float *packed, const void *obs, int obs_half, const float *dlogits,
+                                 const float *dvalue, float *g_vw0, float *g_vb0, float *g_vw1, float *g_vb1, float *g_pw0,
+                                 float *g_pb0, float *g_pw1, float *g_pb1, float *workspace, void *stream) {
+    return mlp_backward_launch(N, nullptr, nullptr, A, W, packed, obs, obs_half, dlogits, dvalue, g_vw0, g_vb0, g_vw1, g_vb1, g_pw0, g_pb0,
+                               g_pw1, g_pb1, workspace, stream);
+}
+
+extern "C" int rnad_mlp_backward_rows(int64_t max_rows, const int32_t *rows, const int64_t *n_rows, int A, int W, const float *packed,
+                                      const void *obs, int obs_half, const float *dlogits, const float *dvalue, float *g_vw0,
+                                      float *g_vb0, float *g_vw1, float *g_vb1, float *g_pw0, float *g_pb0, float *g_pw1, float *g_pb1,
+                                      float *workspace, void *stream) {
+    RNAD_REQUIRE(rows && n_rows, "rnad_mlp_backward_rows: null row list");
+    return mlp_backward_launch(max_rows, rows, n_rows, A, W, packed, obs, obs_half, dlogits, dvalue, g_vw0, g_vb0, g_vw1, g_vb1, g_pw0,
+                               g_pb0, g_pw1, g_pb1, workspace, stream);
 }

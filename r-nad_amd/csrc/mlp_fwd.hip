@@ -95,7 +95,11 @@ __device__ __forceinline__ void mfma_chain2(const float *__restrict__ lds, int W
 template <int A, typename ObsT, int HEADS>
 __global__ __launch_bounds__(kFwdThreads) void k_mlp_forward(int64_t N, int W, const float *__restrict__ packed,
                                                              const ObsT *__restrict__ obs, float *__restrict__ logits,
-                                                             float *__restrict__ value) {
+                                                             float *__restrict__ value, const int32_t *__restrict__ rows,
+                                                             const int64_t *__restrict__ n_rows) {
+    // rows != null: sample s of this launch is row rows[s] of obs / logits / value, and the sample count comes from device
+    // memory (rnad_compact_valid's output: no host round trip between the compaction and this launch)
+    if (n_rows) N = *n_rows;
     constexpr int K = 2 * A * A, KS = K / 2;  // MFMA k-steps per hidden tile
     extern __shared__ __attribute__((aligned(16))) float lds[];
     {   // weights: one coalesced 16-byte copy of the image rnad_mlp_pack laid out
@@ -125,8 +129,9 @@ __global__ __launch_bounds__(kFwdThreads) void k_mlp_forward(int64_t N, int W, c
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             const int64_t sample = span * kSpan + s * kTile + col;
+            const int64_t row = (rows && sample < N) ? (int64_t)rows[sample] : sample;
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks) xn[s][ks] = sample < N ? load_obs<ObsT>(obs + sample * K + 2 * ks + half) : 0.0f;
+            for (int ks = 0; ks < KS; ++ks) xn[s][ks] = sample < N ? load_obs<ObsT>(obs + row * K + 2 * ks + half) : 0.0f;
         }
     };
     if (span0 < n_spans) fetch(span0);
@@ -172,10 +177,11 @@ __global__ __launch_bounds__(kFwdThreads) void k_mlp_forward(int64_t N, int W, c
                 for (int a = 0; a < A; ++a) out_p[a] += __shfl_xor(out_p[a], 32, 64);
             }
             if (sample < N && half == 0) {
-                if ((HEADS & 1) && value) value[sample] = out_v + bv;
+                const int64_t row = rows ? (int64_t)rows[sample] : sample;
+                if ((HEADS & 1) && value) value[row] = out_v + bv;
                 if ((HEADS & 2) && logits) {
 #pragma unroll
-                    for (int a = 0; a < A; ++a) logits[sample * A + a] = out_p[a] + bp[a];
+                    for (int a = 0; a < A; ++a) logits[row * A + a] = out_p[a] + bp[a];
                 }
             }
         }
@@ -228,8 +234,8 @@ extern "C" int rnad_mlp_pack(int A, int W, const float *vw0, const float *vb0, c
     return 0;
 }
 
-extern "C" int rnad_mlp_forward(int64_t N, int A, int W, const float *packed, const void *obs, int obs_half, float *logits, float *value,
-                                void *stream_) {
+static int mlp_forward_launch(int64_t N, const int32_t *rows, const int64_t *n_rows, int A, int W, const float *packed, const void *obs,
+                              int obs_half, float *logits, float *value, void *stream_) {
     RNAD_REQUIRE(packed && obs && (logits || value), "rnad_mlp_forward: null argument");
     RNAD_REQUIRE(W >= kTile && W % kTile == 0, "rnad_mlp_forward: width %d must be a positive multiple of %d", W, kTile);
     RNAD_REQUIRE(N >= 0, "rnad_mlp_forward: negative batch");
@@ -253,7 +259,7 @@ extern "C" int rnad_mlp_forward(int64_t N, int A, int W, const float *packed, co
         auto kern = k_mlp_forward<kA, T_, H_>;                                                                                     \
         if (lds_bytes > 64 * 1024)                                                                                       \
             RNAD_HIP_OK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes)); \
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(kFwdThreads), lds_bytes, stream, N, W, packed, (const T_ *)obs, logits, value);            \
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(kFwdThreads), lds_bytes, stream, N, W, packed, (const T_ *)obs, logits, value, rows, n_rows);            \
                                                                         \
     } while (0)
 #define RNAD_MLP_LAUNCH(T_)                                   \
@@ -274,3 +280,13 @@ extern "C" int rnad_mlp_forward(int64_t N, int A, int W, const float *packed, co
     return 0;
 }
 
+extern "C" int rnad_mlp_forward(int64_t N, int A, int W, const float *packed, const void *obs, int obs_half, float *logits, float *value,
+                                void *stream) {
+    return mlp_forward_launch(N, nullptr, nullptr, A, W, packed, obs, obs_half, logits, value, stream);
+}
+
+extern "C" int rnad_mlp_forward_rows(int64_t max_rows, const int32_t *rows, const int64_t *n_rows, int A, int W, const float *packed,
+                                     const void *obs, int obs_half, float *logits, float *value, void *stream) {
+    RNAD_REQUIRE(rows && n_rows, "rnad_mlp_forward_rows: null row list");
+    return mlp_forward_launch(max_rows, rows, n_rows, A, W, packed, obs, obs_half, logits, value, stream);
+}

@@ -264,6 +264,94 @@ __global__ __launch_bounds__(kThreads) void k_count_alive(int64_t B, const int32
     }
 }
 
+// ---------------------------------------------------------------------------------------- live-row lists
+// rows[] = the positions r with indices[r] != 0, in increasing order, and their count -- so that the MLP kernels can skip the
+// (t, b) slots of absorbed episodes (ragged trees: rnad_mlp_forward_rows / rnad_mlp_backward_rows).  Three small launches:
+// per-chunk counts, one-block exclusive scan of the counts, ordered write.  The order is fixed (not an atomic append), which
+// keeps the weight-gradient sums of the backward pass reproducible.
+constexpr int kCompactRows = 8;                           // rows of kThreads elements per block
+constexpr int kCompactChunk = kCompactRows * kThreads;    // 2048 positions per block
+
+__device__ __forceinline__ int wave_rank(bool flag, int &wave_total) {
+    const uint64_t m = __ballot(flag);
+    wave_total = __popcll(m);
+    return __popcll(m & ((1ull << (threadIdx.x & 63)) - 1ull));
+}
+
+__global__ __launch_bounds__(kThreads) void k_compact_count(int64_t N, const int32_t *__restrict__ indices, int32_t *__restrict__ counts) {
+    const int64_t base = (int64_t)blockIdx.x * kCompactChunk;
+    int cnt = 0;
+#pragma unroll
+    for (int j = 0; j < kCompactRows; ++j) {
+        const int64_t r = base + j * kThreads + threadIdx.x;
+        cnt += (r < N && indices[r] != 0) ? 1 : 0;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) cnt += __shfl_down(cnt, off, 64);
+    __shared__ int part[kThreads / 64];
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = cnt;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int s = 0;
+#pragma unroll
+        for (int i = 0; i < kThreads / 64; ++i) s += part[i];
+        counts[blockIdx.x] = s;
+    }
+}
+
+// counts[nb] -> exclusive prefix sums in place, total -> *n_rows.  One block; nb is N / 2048 (8192 for 2^24 positions).
+__global__ __launch_bounds__(1024) void k_compact_scan(int nb, int32_t *__restrict__ counts, int64_t *__restrict__ n_rows) {
+    __shared__ int64_t wave_sum[16];
+    __shared__ int64_t carry_s;
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    for (int base = 0; base < nb; base += 1024) {
+        const int i = base + threadIdx.x;
+        const int v = i < nb ? counts[i] : 0;
+        int incl = v;  // inclusive scan within the wave
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int o = __shfl_up(incl, off, 64);
+            if ((threadIdx.x & 63) >= off) incl += o;
+        }
+        if ((threadIdx.x & 63) == 63) wave_sum[threadIdx.x >> 6] = incl;
+        __syncthreads();
+        int64_t before = carry_s;
+        for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) before += wave_sum[w];
+        if (i < nb) counts[i] = (int32_t)(before + incl - v);
+        __syncthreads();
+        if (threadIdx.x == 1023) carry_s = before + incl;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *n_rows = carry_s;
+}
+
+__global__ __launch_bounds__(kThreads) void k_compact_write(int64_t N, const int32_t *__restrict__ indices,
+                                                            const int32_t *__restrict__ offsets, int32_t *__restrict__ rows) {
+    __shared__ int totals[kCompactRows][kThreads / 64];
+    const int64_t base = (int64_t)blockIdx.x * kCompactChunk;
+    bool flag[kCompactRows];
+    int rank[kCompactRows];
+#pragma unroll
+    for (int j = 0; j < kCompactRows; ++j) {
+        const int64_t r = base + j * kThreads + threadIdx.x;
+        flag[j] = r < N && indices[r] != 0;
+        int tot;
+        rank[j] = wave_rank(flag[j], tot);
+        if ((threadIdx.x & 63) == 0) totals[j][threadIdx.x >> 6] = tot;
+    }
+    __syncthreads();
+    int before = offsets[blockIdx.x];
+#pragma unroll
+    for (int j = 0; j < kCompactRows; ++j) {
+#pragma unroll
+        for (int w = 0; w < kThreads / 64; ++w) {
+            if (w == (int)(threadIdx.x >> 6) && flag[j]) rows[before + rank[j]] = (int32_t)(base + j * kThreads + threadIdx.x);
+            before += totals[j][w];
+        }
+    }
+}
+
 __global__ void k_fill_i32(int64_t n, int32_t *p, int32_t v) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) p[i] = v;
@@ -376,18 +464,50 @@ extern "C" int rnad_rollout_end(const rnad_tree_t *tree, const rnad_traj_t *tr, 
 }
 
 // Episodes.generate (episode.py:194-212) for a net that IS the fused MLP: all T_cap steps enqueued from one call.
+// live_rows / n_live / block_counts (all three or none): from step 1 on the actor runs on the lanes that are still in the tree
+// only (rnad_compact_valid of indices[t], then rnad_mlp_forward_rows).  Absorbed lanes keep the logits / value of their last
+// live step: finite, and every consumer masks them (they sit in state 0, whose only transition is back to state 0).
 extern "C" int rnad_rollout_run(const rnad_tree_t *tree, const rnad_traj_t *tr, int W, const float *packed, float *logits_ws,
-                                int64_t logits_step_stride, float *value_ws, uint64_t seed, int64_t lane0, void *stream) {
+                                int64_t logits_step_stride, float *value_ws, uint64_t seed, int64_t lane0, int32_t *live_rows,
+                                int64_t *n_live, int32_t *block_counts, void *stream) {
     if (int rc = check_traj(tree, tr, "rnad_rollout_run")) return rc;
     RNAD_REQUIRE(packed && logits_ws && value_ws, "rnad_rollout_run: null argument");
+    const bool skip = live_rows != nullptr;
+    RNAD_REQUIRE(skip == (n_live != nullptr) && skip == (block_counts != nullptr), "rnad_rollout_run: incomplete live-row workspace");
+    RNAD_REQUIRE(!skip || logits_step_stride == 0, "rnad_rollout_run: keeping every step's logits needs the dense actor");
     if (int rc = rnad_rollout_begin(tree, tr, stream)) return rc;
     const size_t esz = tr->obs_half ? 2 : 4;
     const size_t step_bytes = (size_t)tr->B * 2 * tree->A * tree->A * esz;
     for (int t = 0; t < tr->T_cap; ++t) {
         const void *obs_t = (const char *)tr->observations + (size_t)t * step_bytes;
         float *logits_t = logits_ws + (int64_t)t * logits_step_stride;  // stride 0: one scratch row; B*A: keep every step's logits
-        if (int rc = rnad_mlp_forward(tr->B, tree->A, W, packed, obs_t, tr->obs_half, logits_t, value_ws, stream)) return rc;
+        if (skip && t > 0) {
+            if (int rc = rnad_compact_valid(tr->B, tr->indices + (int64_t)t * tr->B, live_rows, n_live, block_counts, stream)) return rc;
+            if (int rc = rnad_mlp_forward_rows(tr->B, live_rows, n_live, tree->A, W, packed, obs_t, tr->obs_half, logits_t, value_ws, stream))
+                return rc;
+        } else {
+            if (int rc = rnad_mlp_forward(tr->B, tree->A, W, packed, obs_t, tr->obs_half, logits_t, value_ws, stream)) return rc;
+        }
         if (int rc = rnad_rollout_step(tree, tr, t, 0, logits_t, nullptr, nullptr, value_ws, nullptr, nullptr, seed, lane0, stream)) return rc;
     }
     return rnad_rollout_end(tree, tr, stream);
+}
+
+// ---------------------------------------------------------------------------------------- rnad_compact_valid
+extern "C" int64_t rnad_compact_workspace(int64_t N) { return N < 0 ? -1 : (N + kCompactChunk - 1) / kCompactChunk + 1; }
+
+extern "C" int rnad_compact_valid(int64_t N, const int32_t *indices, int32_t *rows, int64_t *n_rows, int32_t *block_counts, void *stream_) {
+    RNAD_REQUIRE(N >= 0 && N < ((int64_t)1 << 31), "rnad_compact_valid: %lld positions do not fit an int32 row list", (long long)N);
+    RNAD_REQUIRE(n_rows && (N == 0 || (indices && rows && block_counts)), "rnad_compact_valid: null argument");
+    hipStream_t stream = (hipStream_t)stream_;
+    if (N == 0) {
+        RNAD_HIP_OK(hipMemsetAsync(n_rows, 0, sizeof(int64_t), stream));
+        return 0;
+    }
+    const int nb = (int)((N + kCompactChunk - 1) / kCompactChunk);
+    hipLaunchKernelGGL(k_compact_count, dim3(nb), dim3(kThreads), 0, stream, N, indices, block_counts);
+    hipLaunchKernelGGL(k_compact_scan, dim3(1), dim3(1024), 0, stream, nb, block_counts, n_rows);
+    hipLaunchKernelGGL(k_compact_write, dim3(nb), dim3(kThreads), 0, stream, N, indices, block_counts, rows);
+    RNAD_HIP_OK(hipGetLastError());
+    return 0;
 }

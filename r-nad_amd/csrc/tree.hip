@@ -133,6 +133,17 @@ extern "C" int rnad_tree_create(rnad_tree_t **out, int64_t S, int C, int A, cons
     }
     tree->n_levels = max_level + 1;
     tree->max_depth = max_level + 1;
+    // uniform_length: the only way out of the tree is from its deepest level.  Then every lane is live for exactly
+    // 2 * max_depth env steps and there is nothing for the live-row lists to skip.
+    tree->uniform_length = true;
+    for (int64_t s = 1; s < S && tree->uniform_length; ++s) {
+        const int lv = tree->level_of[s];
+        if (lv < 0) continue;
+        for (int k = 0; k < AA * C; ++k) {
+            const Trans &e = trans[(size_t)s * AA * C + k];
+            if (e.chance > 0.0f && (e.next == 0) != (lv == max_level)) { tree->uniform_length = false; break; }
+        }
+    }
     std::vector<int64_t> count(tree->n_levels + 1, 0);
     for (int64_t s = 1; s < S; ++s)
         if (tree->level_of[s] >= 0) count[tree->level_of[s] + 1]++;
@@ -184,6 +195,7 @@ extern "C" int64_t rnad_tree_info(const rnad_tree_t *tree, int which) {
         case 3: return tree->max_depth;
         case 4: return tree->NS;
         case 5: return (int64_t)tree->bytes;
+        case 6: return tree->uniform_length ? 1 : 0;
         default: return -1;
     }
 }

@@ -151,7 +151,8 @@ class Episodes:
         return torch.stack([a[0::2].sum(), a[1::2].sum()])
 
     # ---------------------------------------------------------------- episode.py:175-230
-    def generate(self, net: torch.nn.Module, noise_action=None, noise_chance=None, max_steps=None, trim=True, keep_logits=False):
+    def generate(self, net: torch.nn.Module, noise_action=None, noise_chance=None, max_steps=None, trim=True, keep_logits=False,
+                 skip_absorbed=False):
         """Play the batch to the end with `net` as the actor.
 
         Nets exposing `forward_logits(obs) -> (logits [B,A], value [B,1])` (the MLP here) take the fast path: policy head,
@@ -163,6 +164,11 @@ class Episodes:
         length T (episode.py:194 stops once every lane is absorbed).  trim=False keeps all T_cap = 2 * depth steps and
         never synchronises: trailing steps where every lane sits in state 0 are invalid (`indices == 0`) and contribute
         nothing to V-trace or the losses, so learning is unchanged; RNaD uses this.
+
+        skip_absorbed=True (native MLP actor on a ragged tree only): from step 1 on the actor is evaluated on the lanes that
+        are still in the tree; an absorbed lane keeps the logits / value of its last live step, where the reference stores the
+        net's output on state 0's observation (episode.py:203-212).  Those slots are invalid (`indices == 0`) for every
+        consumer, so RNaD uses this too; leave it off to reproduce the reference's buffers slot for slot.
         """
         tree, B = self.tree, self.batch_size
         handle = tree.handle()
@@ -176,7 +182,8 @@ class Episodes:
         if packed is not None and noise_action is None and noise_chance is None and type(net).forward_logits is _MLP.forward_logits:
             # the actor is this package's MLP: the whole loop is enqueued natively (rnad_rollout_run)
             self.actor_logits = rnad_hip.rollout_run(handle, traj, net.width, packed, seed=self.seed, lane0=self.lane_offset,
-                                                     keep_logits=keep_logits)
+                                                     keep_logits=keep_logits,
+                                                     skip_absorbed=skip_absorbed and not keep_logits and not handle.uniform_length)
         else:
             rnad_hip.rollout_begin(handle, traj)
             with torch.no_grad():

@@ -273,11 +273,13 @@ class RNaD:
 
     # ------------------------------------------------------------------ reference learn/rnad.py:353-456
     @staticmethod
-    def _logits_of(module, episodes, want_logits=True, want_value=True):
-        """Raw policy logits [T*B, A] and value [T*B, 1] of `module` on a trajectory (a head that is not wanted may be None)."""
+    def _logits_of(module, episodes, want_logits=True, want_value=True, live=None):
+        """Raw policy logits [T*B, A] and value [T*B, 1] of `module` on a trajectory (a head that is not wanted may be None).
+        live: evaluate only the (t, b) slots of that rnad_hip.LiveRows list (zeros elsewhere)."""
         T = episodes.t_eff + 1
         if hasattr(module, "forward_logits"):
-            return module.forward_logits(episodes.observations[:T], want_logits=want_logits, want_value=want_value)
+            kw = {"live": live} if live is not None else {}
+            return module.forward_logits(episodes.observations[:T], want_logits=want_logits, want_value=want_value, **kw)
         logit, _, _, v = module.forward_batch(episodes)  # any module honouring the reference contract (nn/net.py:64-85)
         A = logit.shape[-1]
         return logit.reshape(-1, A), v.reshape(-1, 1)
@@ -294,15 +296,23 @@ class RNaD:
         reuse = (getattr(self, "reuse_actor_outputs", False) and getattr(episodes, "actor_logits", None) is not None
                  and getattr(episodes, "_actor_tag", None) == (id(self.net), self.total_steps)
                  and rnad_hip.mlp_backward_supported(A, getattr(self.net, "width", 0)))
+        # Ragged trajectories (pruned trees, padded replay batches): the reference evaluates all four nets on every (t, b) slot
+        # and masks the absorbed ones afterwards (valid, :369).  Here the nets run on the live slots only; the others hold
+        # zeros, which the same masks discard -- losses and gradients are unchanged.  Logging steps stay dense, because
+        # logit_mean / logit_max (:427-452) are taken over ALL slots.
+        live = None
+        if (getattr(self, "skip_absorbed", True) and log is None and isinstance(self.net, net.MLP) and self.net._fusable()
+                and rnad_hip.mlp_backward_supported(A, self.net.width) and not self.tree.handle().uniform_length):
+            live = rnad_hip.compact_valid(episodes.indices[:T])
         if reuse:  # the rollout's own outputs: same weights, same observations, same kernel -> same bits as rnad.py:373
             logit, v = episodes.actor_logits.reshape(-1, A), episodes.values[:T].reshape(-1, 1)
         else:
-            logit, v = self._logits_of(self.net, episodes)  # rnad.py:373, with grad
+            logit, v = self._logits_of(self.net, episodes, live=live)  # rnad.py:373, with grad
         with torch.no_grad():
             # the reference runs all four full nets (:378-380); only these heads are ever read (:382-406)
-            logit_target, v_target = self._logits_of(self.net_target, episodes, want_logits=log is not None)  # :378
-            logit_reg, _ = self._logits_of(self.net_reg, episodes, want_value=False)  # :379
-            logit_reg_, _ = self._logits_of(self.net_reg_, episodes, want_value=False)  # :380
+            logit_target, v_target = self._logits_of(self.net_target, episodes, want_logits=log is not None, live=live)  # :378
+            logit_reg, _ = self._logits_of(self.net_reg, episodes, want_value=False, live=live)  # :379
+            logit_reg_, _ = self._logits_of(self.net_reg_, episodes, want_value=False, live=live)  # :380
 
         if norm_work is not None:
             norm_work.wait()
@@ -317,7 +327,7 @@ class RNaD:
         # loss.backward() (rnad.py:424-425) with the closed-form dL/dlogit, dL/dv
         if reuse:
             grads = rnad_hip.mlp_backward(self.net.pack(), self.net._weights(), episodes.observations[:T], A, dlogit.view(-1, A),
-                                          dv.view(-1, 1))
+                                          dv.view(-1, 1), live=live)
             for p_, g_ in zip(self.net._weights(), grads):
                 p_.grad = g_ if p_.grad is None else p_.grad + g_
         else:
@@ -368,7 +378,8 @@ class RNaD:
             episodes = episode.Episodes(self.tree, local_batch, seed=self._new_seed(), lane_offset=rank * local_batch,
                                         obs_half=getattr(self, "obs_half", False))
             # no host sync: trailing all-absorbed steps are masked by `valid`
-            episodes.generate(self.net, trim=False, keep_logits=self.reuse_actor_outputs)
+            episodes.generate(self.net, trim=False, keep_logits=self.reuse_actor_outputs,
+                              skip_absorbed=getattr(self, "skip_absorbed", True) and not self.reuse_actor_outputs)
             episodes._actor_tag = (id(self.net), self.total_steps)
             buffer.append(episodes)
             self.last_episodes = episodes

@@ -47,18 +47,25 @@ class MLP(nn.Module):
         image_floats = (2 * A * A + 1) * 2 * W + (1 + A) * W + 12
         return w.is_cuda and w.dtype == torch.float32 and W % 32 == 0 and image_floats * 4 <= 160 * 1024
 
-    def forward_logits(self, input_batch, want_logits=True, want_value=True, packed=None):
+    def forward_logits(self, input_batch, want_logits=True, want_value=True, packed=None, live=None):
         """obs [N, 2, A, A] (fp32 or fp16) -> logits [N, A], value [N, 1]   (net.py:40-43).
 
         ONE fused HIP kernel that keeps the hidden layer in registers (rnad_mlp_forward); under autograd it is an
         autograd node whose backward is rnad_mlp_backward (hidden layer recomputed on chip).  Shapes the kernels do not
-        cover (A > 3 for the backward, width not a multiple of 32, non-fp32 weights) use four PyTorch-ROCm Linear calls."""
+        cover (width not a multiple of 32, non-fp32 weights, a weight image larger than the LDS) use four PyTorch-ROCm Linear calls.
+
+        live: an rnad_hip.LiveRows over the N samples (ragged trajectories) -- the fused kernels then evaluate those rows only
+        and return zeros elsewhere; the PyTorch fallback ignores it and evaluates everything."""
         A = self.max_actions
         if input_batch.is_cuda and self._fusable():
             if not torch.is_grad_enabled():
-                return rnad_hip.mlp_forward(packed if packed is not None else self.pack(), self.width, input_batch.contiguous(), A, want_logits, want_value)
+                return rnad_hip.mlp_forward(packed if packed is not None else self.pack(), self.width, input_batch.contiguous(), A, want_logits,
+                                            want_value, live=live)
             if rnad_hip.mlp_backward_supported(A, self.width) and not input_batch.requires_grad:
-                return rnad_hip.FusedMLP.apply(input_batch.contiguous(), A, packed if packed is not None else self.pack(), *self._weights())
+                packed = packed if packed is not None else self.pack()
+                if live is not None:
+                    return rnad_hip.FusedMLPRows.apply(input_batch.contiguous(), A, packed, live, *self._weights())
+                return rnad_hip.FusedMLP.apply(input_batch.contiguous(), A, packed, *self._weights())
         x = input_batch.reshape(-1, 2 * self.max_actions**2)
         if x.dtype != self.value_fc0.weight.dtype:
             x = x.to(self.value_fc0.weight.dtype)

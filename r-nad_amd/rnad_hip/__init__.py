@@ -60,6 +60,7 @@ def lib():
         _lib.rnad_tree_destroy.restype = None
         _lib.rnad_mlp_backward_workspace.restype = C.c_int64
         _lib.rnad_mlp_packed_size.restype = C.c_int64
+        _lib.rnad_compact_workspace.restype = C.c_int64
     return _lib
 
 
@@ -113,6 +114,7 @@ class TreeHandle:
                                       C.c_void_p(expected_value.data_ptr()), C.c_void_p(legal.data_ptr()), idx))
         self.max_depth = int(lib().rnad_tree_info(self._h, 3))
         self.table_bytes = int(lib().rnad_tree_info(self._h, 5))
+        self.uniform_length = bool(lib().rnad_tree_info(self._h, 6))  # every episode 2 * max_depth env steps long
 
     @property
     def ptr(self):
@@ -191,15 +193,44 @@ def mlp_pack(weights, A):
     return packed
 
 
-def mlp_forward(packed, W, obs, A, want_logits=True, want_value=True):
+class LiveRows:
+    """Ascending list of the positions with indices != 0 (rnad_compact_valid): `rows` int32 [N] of which the first `count`
+    (a device int64) are meaningful.  Built and consumed on the stream, never read by the host."""
+
+    def __init__(self, indices):
+        flat = indices.reshape(-1)
+        N = flat.numel()
+        dev = flat.device
+        self.N = N
+        self.rows = torch.empty((N,), dtype=I32, device=dev)
+        self.count = torch.empty((1,), dtype=torch.int64, device=dev)
+        self._scratch = torch.empty((max(int(lib().rnad_compact_workspace(C.c_int64(N))), 1),), dtype=I32, device=dev)
+        _check(lib().rnad_compact_valid(C.c_int64(N), _dp(flat, I32, "indices"), _dp(self.rows, I32, "rows"),
+                                        C.c_void_p(self.count.data_ptr()), _dp(self._scratch, I32, "block_counts"), _stream()))
+
+
+def compact_valid(indices):
+    """indices int32 [...] -> LiveRows of the flattened positions that are not in the absorbing state."""
+    return LiveRows(indices)
+
+
+def mlp_forward(packed, W, obs, A, want_logits=True, want_value=True, live=None):
     """packed: mlp_pack(weights, A); obs [N, 2, A, A] fp32/fp16 -> logits [N, A], value [N, 1].
-    A head that is not wanted is not computed (returns None for it)."""
+    A head that is not wanted is not computed (returns None for it).
+    live: a LiveRows over the N samples -- only those rows are evaluated, the others come back as zeros."""
     N = obs.numel() // (2 * A * A)
     half = obs.dtype == F16
-    logits = torch.empty((N, A), dtype=F32, device=obs.device) if want_logits else None
-    value = torch.empty((N, 1), dtype=F32, device=obs.device) if want_value else None
-    _check(lib().rnad_mlp_forward(C.c_int64(N), A, W, _dp(packed, F32, "packed"), _dp(obs, F16 if half else F32, "obs"), int(half),
-                                  _dp(logits, F32, "logits", True), _dp(value, F32, "value", True), _stream()))
+    alloc = torch.zeros if live is not None else torch.empty
+    logits = alloc((N, A), dtype=F32, device=obs.device) if want_logits else None
+    value = alloc((N, 1), dtype=F32, device=obs.device) if want_value else None
+    if live is None:
+        _check(lib().rnad_mlp_forward(C.c_int64(N), A, W, _dp(packed, F32, "packed"), _dp(obs, F16 if half else F32, "obs"), int(half),
+                                      _dp(logits, F32, "logits", True), _dp(value, F32, "value", True), _stream()))
+    else:
+        assert live.N == N, "live-row list built for a different batch"
+        _check(lib().rnad_mlp_forward_rows(C.c_int64(N), _dp(live.rows, I32, "rows"), C.c_void_p(live.count.data_ptr()), A, W,
+                                           _dp(packed, F32, "packed"), _dp(obs, F16 if half else F32, "obs"), int(half),
+                                           _dp(logits, F32, "logits", True), _dp(value, F32, "value", True), _stream()))
     return logits, value
 
 
@@ -207,16 +238,21 @@ def mlp_backward_supported(A, W):
     return W % 32 == 0 and lib().rnad_mlp_backward_workspace(C.c_int64(32), A, W) > 0
 
 
-def mlp_backward(packed, weights, obs, A, dlogits, dvalue):
-    """Gradients of the 8 Linear tensors (MLP_KEYS order) for dL/dlogits [N, A], dL/dvalue [N(,1)]."""
+def mlp_backward(packed, weights, obs, A, dlogits, dvalue, live=None):
+    """Gradients of the 8 Linear tensors (MLP_KEYS order) for dL/dlogits [N, A], dL/dvalue [N(,1)].
+    live: a LiveRows -- only those rows contribute (the caller guarantees the others carry zero gradients)."""
     N = obs.numel() // (2 * A * A)
     W = weights[0].shape[0]
     half = obs.dtype == F16
     grads = [torch.empty_like(w) for w in weights]
     ws = torch.empty((lib().rnad_mlp_backward_workspace(C.c_int64(N), A, W) // 4,), dtype=F32, device=obs.device)
-    _check(lib().rnad_mlp_backward(C.c_int64(N), A, W, _dp(packed, F32, "packed"), _dp(obs, F16 if half else F32, "obs"), int(half),
-                                   _dp(dlogits, F32, "dlogits"), _dp(dvalue, F32, "dvalue"), *[_dp(g, F32, "grad") for g in grads],
-                                   _dp(ws, F32, "workspace"), _stream()))
+    common = (A, W, _dp(packed, F32, "packed"), _dp(obs, F16 if half else F32, "obs"), int(half), _dp(dlogits, F32, "dlogits"),
+              _dp(dvalue, F32, "dvalue"), *[_dp(g, F32, "grad") for g in grads], _dp(ws, F32, "workspace"), _stream())
+    if live is None:
+        _check(lib().rnad_mlp_backward(C.c_int64(N), *common))
+    else:
+        assert live.N == N, "live-row list built for a different batch"
+        _check(lib().rnad_mlp_backward_rows(C.c_int64(N), _dp(live.rows, I32, "rows"), C.c_void_p(live.count.data_ptr()), *common))
     return grads
 
 
@@ -235,6 +271,23 @@ class FusedMLP(torch.autograd.Function):
         obs, packed, *weights = ctx.saved_tensors
         grads = mlp_backward(packed, weights, obs, ctx.A, dlogits.contiguous(), dvalue.contiguous())
         return (None, None, None, *grads)
+
+
+class FusedMLPRows(torch.autograd.Function):
+    """FusedMLP restricted to a LiveRows list: logits, value = FusedMLPRows.apply(obs, A, packed, live, *weights).  Rows that
+    are not listed come back as zeros and must receive zero gradients (they are not read in backward)."""
+
+    @staticmethod
+    def forward(ctx, obs, A, packed, live, *weights):
+        ctx.A, ctx.live = A, live
+        ctx.save_for_backward(obs, packed, *weights)
+        return mlp_forward(packed, weights[0].shape[0], obs, A, live=live)
+
+    @staticmethod
+    def backward(ctx, dlogits, dvalue):
+        obs, packed, *weights = ctx.saved_tensors
+        grads = mlp_backward(packed, weights, obs, ctx.A, dlogits.contiguous(), dvalue.contiguous(), live=ctx.live)
+        return (None, None, None, None, *grads)
 
 
 # --------------------------------------------------------------------------------------- rollout driver
@@ -261,15 +314,25 @@ def rollout_begin(tree, traj):
     _check(lib().rnad_rollout_begin(tree.ptr, C.byref(traj.c), _stream()))
 
 
-def rollout_run(tree, traj, W, packed, seed=0, lane0=0, keep_logits=False):
+def rollout_run(tree, traj, W, packed, seed=0, lane0=0, keep_logits=False, skip_absorbed=False):
     """All T_cap steps of a rollout with the fused MLP as the actor, enqueued by one native call.
-    keep_logits: return the actor's raw logits of every step as a [T_cap, B, A] tensor (else None)."""
+    keep_logits: return the actor's raw logits of every step as a [T_cap, B, A] tensor (else None).
+    skip_absorbed: from step 1 on evaluate the actor only on lanes still in the tree (not with keep_logits)."""
     dev = traj.indices.device
-    logits = torch.empty((traj.T_cap if keep_logits else 1, traj.B, tree.A), dtype=F32, device=dev)
-    value = torch.empty((traj.B,), dtype=F32, device=dev)
+    logits = torch.zeros((traj.T_cap if keep_logits else 1, traj.B, tree.A), dtype=F32, device=dev)
+    value = torch.zeros((traj.B,), dtype=F32, device=dev)
+    null = C.c_void_p()
+    rows = count = scratch = None
+    if skip_absorbed:
+        assert not keep_logits, "keep_logits needs the dense actor"
+        rows = torch.empty((traj.B,), dtype=I32, device=dev)
+        count = torch.empty((1,), dtype=torch.int64, device=dev)
+        scratch = torch.empty((int(lib().rnad_compact_workspace(C.c_int64(traj.B))),), dtype=I32, device=dev)
     _check(lib().rnad_rollout_run(tree.ptr, C.byref(traj.c), int(W), _dp(packed, F32, "packed"), _dp(logits, F32, "logits"),
                                   C.c_int64(traj.B * tree.A if keep_logits else 0), _dp(value, F32, "value"), C.c_uint64(seed),
-                                  C.c_int64(lane0), _stream()))
+                                  C.c_int64(lane0), _dp(rows, I32, "live_rows", True),
+                                  C.c_void_p(count.data_ptr()) if count is not None else null,
+                                  _dp(scratch, I32, "block_counts", True), _stream()))
     return logits if keep_logits else None
 
 

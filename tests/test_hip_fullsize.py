@@ -190,7 +190,7 @@ def test_c4_like_tree_five_actions_four_chance_outcomes(half):
         rn = RNaD(tree=tree, device=dev, directory_name="c4", batch_size=B, eta=0.2, b1_adam=0.0, lr=1e-3,
                   net_params={"type": "MLP", "max_actions": 5, "width": 128})
         rn.initialize()
-        rn.train_step(Buffer(1), alpha=1.0, log={})  # A = 5: the MLP backward falls back to PyTorch-ROCm autograd
+        rn.train_step(Buffer(1), alpha=1.0, log={})
         assert all(torch.isfinite(p).all() for p in rn.net.parameters())
 
 

@@ -1,0 +1,145 @@
+"""Ragged trajectories: the live-row lists (rnad_compact_valid) and the *_rows MLP kernels that skip absorbed (t, b) slots.
+
+What must hold: the list is exactly the ascending positions with indices != 0; listed rows get the dense kernels' results bit
+for bit (the per-sample arithmetic is the same), unlisted rows are left alone; weight gradients equal the dense ones with the
+masked rows' upstream gradients zeroed (different summation grouping: compared at 1e-5); a rollout / an update that skips
+absorbed slots gives the same valid trajectory bits and the same update as the dense one."""
+import os
+import tempfile
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device("cuda:0")
+
+
+@pytest.mark.parametrize("N,p", [(0, 0.5), (1, 1.0), (1, 0.0), (63, 0.5), (2047, 0.3), (2048, 0.9), (2049, 0.5), (5000, 0.0), (5000, 1.0),
+                                 (1_000_003, 0.4), (3 * 2048 * 1024 + 17, 0.05)])
+def test_compact_valid_is_the_ascending_nonzero_list(N, p):
+    import rnad_hip
+
+    rng = np.random.default_rng(N + int(100 * p))
+    flags = rng.random(N) < p
+    idx = np.where(flags, rng.integers(1, 1000, size=N), 0).astype(np.int32)
+    live = rnad_hip.compact_valid(torch.from_numpy(idx).to(DEV))
+    n = int(live.count.item())
+    want = np.flatnonzero(idx)
+    assert n == want.size
+    np.testing.assert_array_equal(live.rows[:n].cpu().numpy(), want)
+
+
+@pytest.mark.parametrize("A,W,N", [(3, 256, 10_000), (2, 64, 77), (5, 128, 4097), (3, 32, 64), (7, 64, 1000)])
+@pytest.mark.parametrize("half", (False, True))
+def test_mlp_rows_match_the_dense_kernels_on_listed_rows(A, W, N, half):
+    import rnad_hip
+
+    g = torch.Generator().manual_seed(A * 1000 + W + N)
+    K = 2 * A * A
+    shapes = [(W, K), (W,), (1, W), (1,), (W, K), (W,), (A, W), (A,)]
+    w = [(torch.randn(s, generator=g) / s[-1] ** 0.5).to(DEV) for s in shapes]
+    x = torch.randn((N, 2, A, A), generator=g).to(DEV)
+    if half:
+        x = x.half()
+    flags = torch.rand((N,), generator=g) < 0.4
+    idx = torch.where(flags, torch.ones(N, dtype=torch.int32), torch.zeros(N, dtype=torch.int32)).to(DEV)
+    live = rnad_hip.compact_valid(idx)
+    packed = rnad_hip.mlp_pack(w, A)
+    ld, vd = rnad_hip.mlp_forward(packed, W, x, A)
+    ll, vl = rnad_hip.mlp_forward(packed, W, x, A, live=live)
+    m = flags.to(DEV)
+    assert torch.equal(ll[m], ld[m]) and torch.equal(vl[m], vd[m])  # same arithmetic per sample: same bits
+    assert (ll[~m] == 0).all() and (vl[~m] == 0).all()                # rows that are not listed are not written
+    lp, none = rnad_hip.mlp_forward(packed, W, x, A, want_value=False, live=live)
+    assert none is None and torch.equal(lp, ll)
+    if not rnad_hip.mlp_backward_supported(A, W):
+        return
+    dl = torch.randn((N, A), generator=g).to(DEV)
+    dv = torch.randn((N, 1), generator=g).to(DEV)
+    garbage = torch.full_like(dl, float("nan"))  # rows that are not listed must not even be read
+    got = rnad_hip.mlp_backward(packed, w, x, A, torch.where(m[:, None], dl, garbage), torch.where(m[:, None], dv, garbage[:, :1]), live=live)
+    want = rnad_hip.mlp_backward(packed, w, x, A, dl * m[:, None], dv * m[:, None])
+    for a, b in zip(got, want):
+        scale = float(b.abs().max()) + 1e-6
+        assert torch.isfinite(a).all()
+        np.testing.assert_allclose(a.cpu().numpy() / scale, b.cpu().numpy() / scale, rtol=0, atol=1e-5)
+
+
+def _ragged_tree(A=3, C=2, depth=5, seed=4):
+    from environment.tree import Tree
+
+    tree = Tree(device=DEV, max_actions=A, max_transitions=C, depth_bound=depth, transition_threshold=0.2)
+    tree.generate_native(seed=seed, prune=(1, 2))
+    assert not tree.handle().uniform_length
+    return tree
+
+
+def test_uniform_length_flag():
+    from environment.tree import Tree
+
+    tree = Tree(device=DEV, max_actions=3, max_transitions=1, depth_bound=4)
+    tree.generate_native(seed=0)
+    assert tree.handle().uniform_length
+    assert not _ragged_tree().handle().uniform_length
+
+
+@pytest.mark.parametrize("half", (False, True))
+def test_rollout_that_skips_absorbed_lanes_keeps_every_valid_slot(half):
+    from environment.episode import Episodes
+    from nn.net import MLP
+
+    torch.manual_seed(1)
+    tree = _ragged_tree()
+    net = MLP(3, 64, device=DEV)
+    B = 20_000
+    dense = Episodes(tree, B, seed=9, obs_half=half)
+    dense.generate(net, trim=False)
+    skip = Episodes(tree, B, seed=9, obs_half=half)
+    skip.generate(net, trim=False, skip_absorbed=True)
+    T = dense.t_eff + 1
+    assert skip.t_eff == dense.t_eff
+    valid = dense.indices[:T] != 0
+    assert 0.05 < valid.float().mean().item() < 0.95  # really ragged
+    assert torch.equal(skip.indices[:T], dense.indices[:T])
+    assert torch.equal(skip.alive, dense.alive)
+    assert torch.equal(skip.rewards[:T], dense.rewards[:T])  # rewards of absorbed lanes are 0 either way
+    assert torch.equal(skip.observations[:T], dense.observations[:T]) and torch.equal(skip.mask_bits[:T], dense.mask_bits[:T])
+    for name in ("action_idx", "values"):
+        a, b = getattr(skip, name)[:T], getattr(dense, name)[:T]
+        assert torch.equal(a[valid], b[valid]), name
+    assert torch.equal(skip.policy[:T][valid], dense.policy[:T][valid])
+    assert torch.isfinite(skip.policy[:T]).all() and torch.isfinite(skip.values[:T]).all()
+
+
+@pytest.mark.parametrize("reuse", (False, True))
+def test_update_that_skips_absorbed_slots_is_the_dense_update(reuse):
+    """Same learner, same nets: gradients from (dense rollout, dense update) vs (rollout and update that skip absorbed slots)."""
+    from environment.episode import Episodes
+    from learn.rnad import RNaD
+
+    tree = _ragged_tree()
+    os.environ["RNAD_SAVE_DIR"] = tempfile.mkdtemp(prefix="rnad_test_")
+    B = 1 << 14
+    torch.manual_seed(5)
+    rn = RNaD(tree=tree, device=DEV, directory_name=f"ragged{int(reuse)}", batch_size=B, eta=0.2, b1_adam=0.0, lr=1e-3,
+              net_params={"type": "MLP", "max_actions": 3, "width": 64})
+    rn.initialize()
+    with torch.no_grad():  # make the four nets differ, as they do after the first outer iteration
+        for i, m in enumerate((rn.net_target, rn.net_reg, rn.net_reg_)):
+            for p_ in m.parameters():
+                p_.add_(0.05 * (i + 1) * torch.randn_like(p_))
+    rn.reuse_actor_outputs = reuse
+    grads, losses = [], []
+    for skip in (False, True):
+        ep = Episodes(tree, B, seed=3)
+        ep.generate(rn.net, trim=False, keep_logits=reuse, skip_absorbed=skip and not reuse)
+        ep._actor_tag = (id(rn.net), rn.total_steps)
+        rn.skip_absorbed = skip
+        rn.optimizer.zero_grad()
+        rn._RNaD__learn(ep, 0.4)
+        grads.append([p_.grad.detach().clone() for p_ in rn.net.parameters()])
+    for a, b in zip(*grads):
+        scale = float(b.abs().max()) + 1e-12
+        assert torch.isfinite(a).all() and float(b.abs().max()) > 0
+        np.testing.assert_allclose(a.cpu().numpy() / scale, b.cpu().numpy() / scale, rtol=0, atol=1e-5)

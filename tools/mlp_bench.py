@@ -10,7 +10,8 @@ import torch  # noqa: E402
 
 import rnad_hip  # noqa: E402
 
-A, W = 3, 256
+A = int(os.environ.get("MLP_BENCH_A", 3))
+W = 256
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 12 * 2**20
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
 dev = torch.device("cuda:0")
@@ -42,3 +43,15 @@ ms = timeit(lambda: rnad_hip.mlp_forward(packed, W, x, A, want_value=False))
 print(f"forward  policy only: {ms:7.3f} ms  {fwd_flop / 2 / ms / 1e9:6.1f} TFLOP/s")
 ms = timeit(lambda: rnad_hip.mlp_backward(packed, w, x, A, dl, dv))
 print(f"backward           : {ms:7.3f} ms  {bwd_flop / ms / 1e9:6.1f} TFLOP/s")
+
+# the same kernels through a live-row list (ragged trajectories): every row listed, then a random 43 %
+for frac in (1.0, 0.43):
+    flags = (torch.rand((N,), device=dev) < frac).to(torch.int32)
+    live = rnad_hip.compact_valid(flags)
+    n = int(live.count.item())
+    ms = timeit(lambda: rnad_hip.mlp_forward(packed, W, x, A, live=live))
+    print(f"rows {frac:4.2f} forward both heads: {ms:7.3f} ms  {fwd_flop * n / N / ms / 1e9:6.1f} TFLOP/s on the listed rows")
+    ms = timeit(lambda: rnad_hip.mlp_backward(packed, w, x, A, dl, dv, live=live))
+    print(f"rows {frac:4.2f} backward          : {ms:7.3f} ms  {bwd_flop * n / N / ms / 1e9:6.1f} TFLOP/s on the listed rows")
+ms = timeit(lambda: rnad_hip.compact_valid(flags))
+print(f"compact_valid of {N} positions: {ms * 1e3:7.1f} us")
