@@ -94,6 +94,12 @@ def main():
               net_params={"type": "MLP", "max_actions": A, "width": args.width})
     rn.initialize()
     rn.obs_half = args.obs_half
+    with torch.no_grad():
+        # the general case of rnad.py:382: two DISTINCT regularisation nets and 0 < alpha < 1 (four net evaluations per update).
+        # During m == 0 the two coincide and for alpha == 1 one of them has weight 0; RNaD then evaluates one net less --
+        # that is not what is timed here.
+        for p in rn.net_reg_.parameters():
+            p.mul_(1.001)
     buffer = Buffer(rn.n_batches_per_buffer)
     delta_m = 10_000
 

@@ -271,6 +271,16 @@ class RNaD:
             logging.info("depth:{}, nash_conv:{}".format(depth, nashconv))
         return (nashconv_data.row_best[1] + nashconv_data.col_best[1]).item()
 
+    def _reg_nets_identical(self):
+        """True while net_reg and net_reg_ hold the same weights (all of m == 0).  Checked once per outer iteration."""
+        key = (getattr(self, "m", None), id(self.net_reg), id(self.net_reg_),
+               sum(p._version for p in self.net_reg.parameters()), sum(p._version for p in self.net_reg_.parameters()))
+        if getattr(self, "_reg_identical_key", None) != key:
+            a, b = self.net_reg.state_dict(), self.net_reg_.state_dict()
+            self._reg_identical = a.keys() == b.keys() and all(torch.equal(a[k], b[k]) for k in a)
+            self._reg_identical_key = key
+        return self._reg_identical
+
     # ------------------------------------------------------------------ reference learn/rnad.py:353-456
     @staticmethod
     def _logits_of(module, episodes, want_logits=True, want_value=True, live=None):
@@ -311,8 +321,19 @@ class RNaD:
         with torch.no_grad():
             # the reference runs all four full nets (:378-380); only these heads are ever read (:382-406)
             logit_target, v_target = self._logits_of(self.net_target, episodes, want_logits=log is not None, live=live)  # :378
-            logit_reg, _ = self._logits_of(self.net_reg, episodes, want_value=False, live=live)  # :379
-            logit_reg_, _ = self._logits_of(self.net_reg_, episodes, want_value=False, live=live)  # :380
+            # log_policy_reg = log_pi - (alpha * log_pi_reg + (1 - alpha) * log_pi_reg_) (:382).  A term whose weight is exactly 0
+            # adds exactly 0 (log-policies are finite), and two nets with the same weights give the same bits: in the second half
+            # of every outer iteration (alpha == 1, :497) and during all of m == 0 (both reg nets are copies of the initial net,
+            # :183-186) one evaluation serves both operands.
+            if alpha == 0:
+                logit_reg_, _ = self._logits_of(self.net_reg_, episodes, want_value=False, live=live)  # :380
+                logit_reg = logit_reg_
+            else:
+                logit_reg, _ = self._logits_of(self.net_reg, episodes, want_value=False, live=live)  # :379
+                if alpha == 1 or self._reg_nets_identical():
+                    logit_reg_ = logit_reg
+                else:
+                    logit_reg_, _ = self._logits_of(self.net_reg_, episodes, want_value=False, live=live)  # :380
 
         if norm_work is not None:
             norm_work.wait()

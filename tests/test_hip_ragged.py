@@ -143,3 +143,49 @@ def test_update_that_skips_absorbed_slots_is_the_dense_update(reuse):
         scale = float(b.abs().max()) + 1e-12
         assert torch.isfinite(a).all() and float(b.abs().max()) > 0
         np.testing.assert_allclose(a.cpu().numpy() / scale, b.cpu().numpy() / scale, rtol=0, atol=1e-5)
+
+
+def test_one_reg_net_evaluation_when_the_other_cannot_matter(monkeypatch):
+    """rnad.py:382 with alpha == 1 (weight 0 on net_reg_), alpha == 0 (weight 0 on net_reg) or identical reg nets: evaluating
+    one net for both operands gives the same gradient bits as evaluating both."""
+    from environment.episode import Episodes
+    from learn.rnad import RNaD
+
+    tree = _ragged_tree()
+    os.environ["RNAD_SAVE_DIR"] = tempfile.mkdtemp(prefix="rnad_test_")
+    B = 1 << 12
+    torch.manual_seed(7)
+    rn = RNaD(tree=tree, device=DEV, directory_name="alias", batch_size=B, eta=0.2, b1_adam=0.0,
+              net_params={"type": "MLP", "max_actions": 3, "width": 64})
+    rn.initialize()
+    ep = Episodes(tree, B, seed=3)
+    ep.generate(rn.net, trim=False)
+
+    def grads(alpha):
+        rn.optimizer.zero_grad()
+        rn._RNaD__learn(ep, alpha)
+        return [p_.grad.detach().clone() for p_ in rn.net.parameters()]
+
+    assert rn._reg_nets_identical()
+    one = grads(0.3)                                                   # identical nets: one evaluation
+    monkeypatch.setattr(RNaD, "_reg_nets_identical", lambda self: False)
+    two = grads(0.3)                                                   # forced: both evaluated
+    assert all(torch.equal(a, b) for a, b in zip(one, two))
+    monkeypatch.undo()
+    with torch.no_grad():
+        for p_ in rn.net_reg_.parameters():
+            p_.add_(0.1 * torch.randn_like(p_))
+    assert not rn._reg_nets_identical()                                # the version-keyed cache noticed
+    g1 = grads(1)
+    with torch.no_grad():
+        for p_ in rn.net_reg_.parameters():
+            p_.add_(0.1 * torch.randn_like(p_))
+    g1b = grads(1)                                                     # alpha == 1: net_reg_ must not matter
+    assert all(torch.equal(a, b) for a, b in zip(g1, g1b))
+    g0 = grads(0)
+    with torch.no_grad():
+        for p_ in rn.net_reg.parameters():
+            p_.add_(0.1 * torch.randn_like(p_))
+    g0b = grads(0)                                                     # alpha == 0: net_reg must not matter
+    assert all(torch.equal(a, b) for a, b in zip(g0, g0b))
+    assert not all(torch.equal(a, b) for a, b in zip(g0, g1))
