@@ -153,7 +153,7 @@ def main():
     t_r = time.perf_counter()
     for i in range(args.steps):
         Episodes(tree, local_batch, seed=1000 + i, lane_offset=rank * local_batch, obs_half=args.obs_half).generate(
-            rn.net, trim=False, skip_absorbed=True)  # as RNaD.train_step calls it
+            rn.net, trim=False, skip_absorbed=True, store_values=False)  # as RNaD.train_step calls it
     fence()
     rollout_s = time.perf_counter() - t_r
     if world > 1:

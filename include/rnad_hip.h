@@ -176,7 +176,9 @@ int rnad_rollout_step(const rnad_tree_t *tree, const rnad_traj_t *traj, int t, i
 
 /* The whole loop of Episodes.generate for a net that is the fused MLP of this library (nn/net.py:18-51): begin, then
  * for every t: rnad_mlp_forward(observations[t]) -> rnad_rollout_step(mode 0), then rnad_rollout_end -- enqueued from ONE
- * call (3 * T_cap + 2 launches, no host work in between).  packed: rnad_mlp_pack image; value_ws [B] scratch;
+ * call (3 * T_cap + 2 launches, no host work in between).  packed: rnad_mlp_pack image; value_ws [B] scratch, or NULL:
+ * the actor's value head is then not evaluated and traj->values is filled with zeros (the reference stores the actor's
+ * values, episode.py:206,218, and never reads them: learn/rnad.py:373 recomputes v from the learner net);
  * logits_ws: [B,A] scratch with logits_step_stride = 0, or a [T_cap,B,A] buffer with logits_step_stride = B*A that
  * keeps the actor's raw logits of every step.  Seeded noise only.
  * live_rows [B] int32 / n_live [1] / block_counts [rnad_compact_workspace(B)]: all NULL = the actor runs on every lane at

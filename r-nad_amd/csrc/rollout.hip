@@ -232,7 +232,7 @@ __global__ __launch_bounds__(kThreads) void k_act(const Trans *__restrict__ tran
 #pragma unroll
         for (int a = 0; a < A; ++a) policy_t[b * A + a] = pol[a];
         act_t[b] = action;
-        values_t[b] = value[b];
+        values_t[b] = value ? value[b] : 0.0f;  // no value head in this rollout: the slot is defined, and unread (rnad.py never reads it)
         const int s = idx_t[b];
         int next = s;
         float rew = 0.0f;  // row turn: torch.zeros (episode.py:101)
@@ -419,7 +419,6 @@ extern "C" int rnad_rollout_step(const rnad_tree_t *tree, const rnad_traj_t *tr,
     if (int rc = check_traj(tree, tr, "rnad_rollout_step")) return rc;
     RNAD_REQUIRE(t >= 0 && t < tr->T_cap, "rnad_rollout_step: step %d outside [0,%d)", t, tr->T_cap);
     RNAD_REQUIRE(mode >= 0 && mode <= 2, "rnad_rollout_step: mode %d", mode);
-    RNAD_REQUIRE(value, "rnad_rollout_step: value is null");
     RNAD_REQUIRE(mode != 0 || logits, "rnad_rollout_step: mode 0 needs logits");
     RNAD_REQUIRE(mode == 0 || policy_in, "rnad_rollout_step: mode %d needs policy_in", mode);
     RNAD_REQUIRE(mode != 2 || actions_in, "rnad_rollout_step: mode 2 needs actions_in");
@@ -471,7 +470,7 @@ extern "C" int rnad_rollout_run(const rnad_tree_t *tree, const rnad_traj_t *tr, 
                                 int64_t logits_step_stride, float *value_ws, uint64_t seed, int64_t lane0, int32_t *live_rows,
                                 int64_t *n_live, int32_t *block_counts, void *stream) {
     if (int rc = check_traj(tree, tr, "rnad_rollout_run")) return rc;
-    RNAD_REQUIRE(packed && logits_ws && value_ws, "rnad_rollout_run: null argument");
+    RNAD_REQUIRE(packed && logits_ws, "rnad_rollout_run: null argument");
     const bool skip = live_rows != nullptr;
     RNAD_REQUIRE(skip == (n_live != nullptr) && skip == (block_counts != nullptr), "rnad_rollout_run: incomplete live-row workspace");
     RNAD_REQUIRE(!skip || logits_step_stride == 0, "rnad_rollout_run: keeping every step's logits needs the dense actor");

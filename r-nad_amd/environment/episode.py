@@ -152,7 +152,7 @@ class Episodes:
 
     # ---------------------------------------------------------------- episode.py:175-230
     def generate(self, net: torch.nn.Module, noise_action=None, noise_chance=None, max_steps=None, trim=True, keep_logits=False,
-                 skip_absorbed=False):
+                 skip_absorbed=False, store_values=True):
         """Play the batch to the end with `net` as the actor.
 
         Nets exposing `forward_logits(obs) -> (logits [B,A], value [B,1])` (the MLP here) take the fast path: policy head,
@@ -169,6 +169,10 @@ class Episodes:
         are still in the tree; an absorbed lane keeps the logits / value of its last live step, where the reference stores the
         net's output on state 0's observation (episode.py:203-212).  Those slots are invalid (`indices == 0`) for every
         consumer, so RNaD uses this too; leave it off to reproduce the reference's buffers slot for slot.
+
+        store_values=False (native MLP actor only): the actor's value head is not evaluated and `values` is zeros.  The
+        reference stores the actor's values (episode.py:206,218) but nothing ever reads them (learn/rnad.py:373 recomputes v
+        with the learner net), so RNaD's own rollouts do without, unless `reuse_actor_outputs` needs them.
         """
         tree, B = self.tree, self.batch_size
         handle = tree.handle()
@@ -183,7 +187,8 @@ class Episodes:
             # the actor is this package's MLP: the whole loop is enqueued natively (rnad_rollout_run)
             self.actor_logits = rnad_hip.rollout_run(handle, traj, net.width, packed, seed=self.seed, lane0=self.lane_offset,
                                                      keep_logits=keep_logits,
-                                                     skip_absorbed=skip_absorbed and not keep_logits and not handle.uniform_length)
+                                                     skip_absorbed=skip_absorbed and not keep_logits and not handle.uniform_length,
+                                                     store_values=store_values)
         else:
             rnad_hip.rollout_begin(handle, traj)
             with torch.no_grad():

@@ -400,7 +400,8 @@ class RNaD:
                                         obs_half=getattr(self, "obs_half", False))
             # no host sync: trailing all-absorbed steps are masked by `valid`
             episodes.generate(self.net, trim=False, keep_logits=self.reuse_actor_outputs,
-                              skip_absorbed=getattr(self, "skip_absorbed", True) and not self.reuse_actor_outputs)
+                              skip_absorbed=getattr(self, "skip_absorbed", True) and not self.reuse_actor_outputs,
+                              store_values=self.reuse_actor_outputs or getattr(self, "store_actor_values", False))
             episodes._actor_tag = (id(self.net), self.total_steps)
             buffer.append(episodes)
             self.last_episodes = episodes

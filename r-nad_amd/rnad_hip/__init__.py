@@ -314,13 +314,14 @@ def rollout_begin(tree, traj):
     _check(lib().rnad_rollout_begin(tree.ptr, C.byref(traj.c), _stream()))
 
 
-def rollout_run(tree, traj, W, packed, seed=0, lane0=0, keep_logits=False, skip_absorbed=False):
+def rollout_run(tree, traj, W, packed, seed=0, lane0=0, keep_logits=False, skip_absorbed=False, store_values=True):
     """All T_cap steps of a rollout with the fused MLP as the actor, enqueued by one native call.
     keep_logits: return the actor's raw logits of every step as a [T_cap, B, A] tensor (else None).
-    skip_absorbed: from step 1 on evaluate the actor only on lanes still in the tree (not with keep_logits)."""
+    skip_absorbed: from step 1 on evaluate the actor only on lanes still in the tree (not with keep_logits).
+    store_values=False: the actor's value head is not evaluated; traj.values is zeros."""
     dev = traj.indices.device
     logits = torch.zeros((traj.T_cap if keep_logits else 1, traj.B, tree.A), dtype=F32, device=dev)
-    value = torch.zeros((traj.B,), dtype=F32, device=dev)
+    value = torch.zeros((traj.B,), dtype=F32, device=dev) if store_values else None
     null = C.c_void_p()
     rows = count = scratch = None
     if skip_absorbed:
@@ -329,7 +330,7 @@ def rollout_run(tree, traj, W, packed, seed=0, lane0=0, keep_logits=False, skip_
         count = torch.empty((1,), dtype=torch.int64, device=dev)
         scratch = torch.empty((int(lib().rnad_compact_workspace(C.c_int64(traj.B))),), dtype=I32, device=dev)
     _check(lib().rnad_rollout_run(tree.ptr, C.byref(traj.c), int(W), _dp(packed, F32, "packed"), _dp(logits, F32, "logits"),
-                                  C.c_int64(traj.B * tree.A if keep_logits else 0), _dp(value, F32, "value"), C.c_uint64(seed),
+                                  C.c_int64(traj.B * tree.A if keep_logits else 0), _dp(value, F32, "value", True), C.c_uint64(seed),
                                   C.c_int64(lane0), _dp(rows, I32, "live_rows", True),
                                   C.c_void_p(count.data_ptr()) if count is not None else null,
                                   _dp(scratch, I32, "block_counts", True), _stream()))

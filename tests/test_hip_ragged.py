@@ -112,6 +112,23 @@ def test_rollout_that_skips_absorbed_lanes_keeps_every_valid_slot(half):
     assert torch.isfinite(skip.policy[:T]).all() and torch.isfinite(skip.values[:T]).all()
 
 
+def test_rollout_without_the_actor_value_head_changes_nothing_else():
+    from environment.episode import Episodes
+    from nn.net import MLP
+
+    torch.manual_seed(2)
+    tree = _ragged_tree()
+    net = MLP(3, 64, device=DEV)
+    full = Episodes(tree, 5000, seed=4)
+    full.generate(net)
+    lean = Episodes(tree, 5000, seed=4)
+    lean.generate(net, store_values=False)
+    assert lean.t_eff == full.t_eff
+    for name in ("indices", "observations", "mask_bits", "policy", "action_idx", "rewards", "alive"):
+        assert torch.equal(getattr(lean, name), getattr(full, name)), name
+    assert (lean.values == 0).all() and (full.values != 0).any()
+
+
 @pytest.mark.parametrize("reuse", (False, True))
 def test_update_that_skips_absorbed_slots_is_the_dense_update(reuse):
     """Same learner, same nets: gradients from (dense rollout, dense update) vs (rollout and update that skip absorbed slots)."""
