@@ -140,11 +140,21 @@ class RNaD:
                 dist.broadcast(t.data, src=0)
 
     def _new_seed(self):
-        s = torch.randint(0, 2**62, (1,), dtype=torch.int64)
-        if _dist_on():
-            s = s.to(self.device)
-            dist.broadcast(s, src=0)
-        return int(s.item())
+        """Noise seed of the next rollout.  The first one is drawn from torch's generator (so torch.manual_seed makes runs
+        repeatable) and, under torch.distributed, broadcast from rank 0 -- once: the following seeds are a counter hashed with
+        it on the host, so the ranks stay in lock step without a broadcast + host sync in every step."""
+        if getattr(self, "_seed_base", None) is None:
+            s = torch.randint(0, 2**62, (1,), dtype=torch.int64)
+            if _dist_on():
+                s = s.to(self.device)
+                dist.broadcast(s, src=0)
+            self._seed_base, self._seed_count = int(s.item()), 0
+            return self._seed_base
+        self._seed_count += 1
+        z = (self._seed_base + self._seed_count * 0x9E3779B97F4A7C15) & 0xFFFFFFFFFFFFFFFF  # splitmix64
+        z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & 0xFFFFFFFFFFFFFFFF
+        z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & 0xFFFFFFFFFFFFFFFF
+        return (z ^ (z >> 31)) & (2**62 - 1)
 
     # ------------------------------------------------------------------ reference learn/rnad.py:174-188
     def __new_net(self) -> nn.Module:
