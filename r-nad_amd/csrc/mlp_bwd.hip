@@ -33,12 +33,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_mlp_backward(int64_t N, int W, c
     const float *w1v = lds + img_w1v(K, W);
     const float *w1p = lds + img_w1p(K, W);
     float *scratch = lds + img_floats(K, W, A);  // after the image: [waves][32][33]
-    {
-        const int n4 = img_floats(K, W, A) / 4;
-        const float4 *src = reinterpret_cast<const float4 *>(packed);
-        float4 *dst = reinterpret_cast<float4 *>(lds);
-        for (int i = threadIdx.x; i < n4; i += nthreads) dst[i] = src[i];
-    }
+    load_image<nthreads>(packed, lds, img_floats(K, W, A) / 4);
     __syncthreads();
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -252,17 +247,27 @@ __global__ __launch_bounds__(64 * WAVES) void k_mlp_backward(int64_t N, int W, c
 }
 
 // Sum the per-block partials (fixed order, fp64 accumulate) into the eight gradient tensors (torch Linear layouts).
+// blockDim = (64 outputs, kReduceSlices): slice s adds blocks s, s + kReduceSlices, ... of its output, then the slices are
+// added in order -- the same grouping on every run, 1 / kReduceSlices of the dependent-load chain of one thread per output.
+constexpr int kReduceSlices = 8;
 template <int A>
-__global__ __launch_bounds__(kThreads) void k_mlp_reduce(int nblocks, int W, int P, const float *__restrict__ partial,
-                                                         float *__restrict__ g_vw0, float *__restrict__ g_vb0, float *__restrict__ g_vw1,
-                                                         float *__restrict__ g_vb1, float *__restrict__ g_pw0, float *__restrict__ g_pb0,
-                                                         float *__restrict__ g_pw1, float *__restrict__ g_pb1) {
+__global__ __launch_bounds__(64 * kReduceSlices) void k_mlp_reduce(int nblocks, int W, int P, const float *__restrict__ partial,
+                                                                   float *__restrict__ g_vw0, float *__restrict__ g_vb0,
+                                                                   float *__restrict__ g_vw1, float *__restrict__ g_vb1,
+                                                                   float *__restrict__ g_pw0, float *__restrict__ g_pb0,
+                                                                   float *__restrict__ g_pw1, float *__restrict__ g_pb1) {
     constexpr int K = 2 * A * A, FW = ((K + 1 + kTile - 1) / kTile) * kTile;
-    const int e = blockIdx.x * kThreads + threadIdx.x;
+    __shared__ double part[kReduceSlices][64];
+    const int e = blockIdx.x * 64 + threadIdx.x;
     const int total = 2 * W * FW + W + A * W + 1 + A;
-    if (e >= total) return;
     double s = 0.0;
-    for (int b = 0; b < nblocks; ++b) s += (double)partial[(int64_t)b * P + e];
+    if (e < total)
+        for (int b = threadIdx.y; b < nblocks; b += kReduceSlices) s += (double)partial[(int64_t)b * P + e];
+    part[threadIdx.y][threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.y != 0 || e >= total) return;
+#pragma unroll
+    for (int i = 1; i < kReduceSlices; ++i) s += part[i][threadIdx.x];
     const float v = (float)s;
     const int n0 = 2 * W * FW;
     if (e < n0) {
@@ -355,8 +360,8 @@ static int mlp_backward_launch(int64_t N, const int32_t *rows, const int64_t *n_
         RNAD_HIP_OK(hipGetLastError());
     }
     const int total = plan.total;
-    const unsigned rgrid = (unsigned)((total + kThreads - 1) / kThreads);
-    RNAD_DISPATCH_A(A, hipLaunchKernelGGL((k_mlp_reduce<kA>), dim3(rgrid), dim3(kThreads), 0, stream, grid, W, P, workspace, g_vw0, g_vb0,
+    const unsigned rgrid = (unsigned)((total + 63) / 64);
+    RNAD_DISPATCH_A(A, hipLaunchKernelGGL((k_mlp_reduce<kA>), dim3(rgrid), dim3(64, kReduceSlices), 0, stream, grid, W, P, workspace, g_vw0, g_vb0,
                                           g_vw1, g_vb1, g_pw0, g_pb0, g_pw1, g_pb1));
     RNAD_HIP_OK(hipGetLastError());
     return 0;

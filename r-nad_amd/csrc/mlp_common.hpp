@@ -36,6 +36,25 @@ __host__ __device__ constexpr int img_floats(int K, int W, int A) { return img_b
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
+// Weight image -> LDS, 16 bytes per lane and request.  Eight requests are in flight per lane before the first LDS write: a
+// plain copy loop waits for every global load in turn (an L2 round trip per 4 KiB), which is most of a rollout-step launch
+// at 2^17 samples.
+template <int NT>
+__device__ __forceinline__ void load_image(const float *__restrict__ packed, float *__restrict__ lds, int n4) {
+    const float4 *src = reinterpret_cast<const float4 *>(packed);
+    float4 *dst = reinterpret_cast<float4 *>(lds);
+    constexpr int U = 8;
+    int i = threadIdx.x;
+    for (; i + (U - 1) * NT < n4; i += U * NT) {
+        float4 v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) v[u] = src[i + u * NT];
+#pragma unroll
+        for (int u = 0; u < U; ++u) dst[i + u * NT] = v[u];
+    }
+    for (; i < n4; i += NT) dst[i] = src[i];
+}
+
 template <typename T>
 __device__ __forceinline__ float load_obs(const T *p);
 template <>

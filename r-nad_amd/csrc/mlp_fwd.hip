@@ -102,12 +102,7 @@ __global__ __launch_bounds__(kFwdThreads) void k_mlp_forward(int64_t N, int W, c
     if (n_rows) N = *n_rows;
     constexpr int K = 2 * A * A, KS = K / 2;  // MFMA k-steps per hidden tile
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    {   // weights: one coalesced 16-byte copy of the image rnad_mlp_pack laid out
-        const int n4 = img_floats(K, W, A) / 4;
-        const float4 *src = reinterpret_cast<const float4 *>(packed);
-        float4 *dst = reinterpret_cast<float4 *>(lds);
-        for (int i = threadIdx.x; i < n4; i += kFwdThreads) dst[i] = src[i];
-    }
+    load_image<kFwdThreads>(packed, lds, img_floats(K, W, A) / 4);  // the image rnad_mlp_pack laid out, copied as is
     __syncthreads();
     const float *w1v = lds + img_w1v(K, W);
     const float *w1p = lds + img_w1p(K, W);

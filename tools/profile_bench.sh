@@ -6,7 +6,7 @@ tag=$1; shift
 out=$R/gpurun_out/prof_$tag
 mkdir -p $out
 rocprofv3 --kernel-trace --stats --output-format csv -d $out -- python $R/bench.py --no-cpu-baseline "$@" > $out/bench.log 2>&1
-tail -1 $out/bench.log > $R/gpurun_out/${tag}_bench_profiled.json.log
+grep "^{" $out/bench.log | tail -1 > $R/gpurun_out/${tag}_bench_profiled.json.log
 f=$(find $out -name '*kernel_stats.csv' | head -1)
 cp "$f" $R/gpurun_out/${tag}_bench_kernel_stats.csv
 head -12 $R/gpurun_out/${tag}_bench_kernel_stats.csv | cut -c1-200
