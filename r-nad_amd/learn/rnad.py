@@ -281,6 +281,16 @@ class RNaD:
             logging.info("depth:{}, nash_conv:{}".format(depth, nashconv))
         return (nashconv_data.row_best[1] + nashconv_data.col_best[1]).item()
 
+    def _grad_bucket(self, weights):
+        """One flat fp32 buffer holding the learner's gradients back to back (the RCCL bucket) and per-tensor views of it."""
+        n = sum(w.numel() for w in weights)
+        flat = torch.empty((n,), dtype=torch.float32, device=weights[0].device)  # fresh each step: .grad of the last step may
+        views, off = [], 0                                                        # still be referenced by the caller
+        for w in weights:
+            views.append(flat[off: off + w.numel()].view_as(w))
+            off += w.numel()
+        return flat, views
+
     def _reg_nets_identical(self):
         """True while net_reg and net_reg_ hold the same weights (all of m == 0).  Checked once per outer iteration."""
         key = (getattr(self, "m", None), id(self.net_reg), id(self.net_reg_),
@@ -324,8 +334,14 @@ class RNaD:
         if (getattr(self, "skip_absorbed", True) and log is None and isinstance(self.net, net.MLP) and self.net._fusable()
                 and rnad_hip.mlp_backward_supported(A, self.net.width) and not self.tree.handle().uniform_length):
             live = rnad_hip.compact_valid(episodes.indices[:T])
+        # The fused MLP is differentiated by hand (rnad_mlp_backward), so the learner's forward needs no autograd graph and its
+        # gradients can be written straight into one flat bucket (the all-reduce buffer).  Any other net goes through autograd.
+        direct = isinstance(self.net, net.MLP) and self.net._fusable() and rnad_hip.mlp_backward_supported(A, self.net.width)
         if reuse:  # the rollout's own outputs: same weights, same observations, same kernel -> same bits as rnad.py:373
             logit, v = episodes.actor_logits.reshape(-1, A), episodes.values[:T].reshape(-1, 1)
+        elif direct:
+            with torch.no_grad():
+                logit, v = self._logits_of(self.net, episodes, live=live)  # rnad.py:373
         else:
             logit, v = self._logits_of(self.net, episodes, live=live)  # rnad.py:373, with grad
         with torch.no_grad():
@@ -356,22 +372,33 @@ class RNaD:
             logit.detach().contiguous(), v.detach().reshape(T, B).contiguous(), v_target.reshape(T, B).contiguous(),
             logit_reg.contiguous(), logit_reg_.contiguous(), norm, hp, want_aux=log is not None)
         # loss.backward() (rnad.py:424-425) with the closed-form dL/dlogit, dL/dv
-        if reuse:
-            grads = rnad_hip.mlp_backward(self.net.pack(), self.net._weights(), episodes.observations[:T], A, dlogit.view(-1, A),
-                                          dv.view(-1, 1), live=live)
-            for p_, g_ in zip(self.net._weights(), grads):
-                p_.grad = g_ if p_.grad is None else p_.grad + g_
+        flat = None
+        if reuse or direct:
+            weights = self.net._weights()
+            flat, views = self._grad_bucket(weights)
+            rnad_hip.mlp_backward(self.net.pack(), weights, episodes.observations[:T], A, dlogit.view(-1, A), dv.view(-1, 1), live=live,
+                                  out=views)
+            if all(p_.grad is None for p_ in weights):
+                for p_, g_ in zip(weights, views):
+                    p_.grad = g_
+            else:  # gradient accumulation across calls, as loss.backward() would
+                for p_, g_ in zip(weights, views):
+                    p_.grad = g_.clone() if p_.grad is None else p_.grad + g_
+                flat = None
         else:
             torch.autograd.backward([logit, v], [dlogit.view(-1, A), dv.view(-1, 1)])
 
         if _dist_on():
-            grads = [p.grad for p in self.net.parameters()]
-            flat = torch.cat([g.reshape(-1) for g in grads])
-            dist.all_reduce(flat)  # one 43 KB bucket over RCCL
-            off = 0
-            for g in grads:
-                g.copy_(flat[off: off + g.numel()].view_as(g))
-                off += g.numel()
+            if flat is not None:
+                dist.all_reduce(flat)  # one 43 KB bucket over RCCL, in place: the .grad tensors are views of it
+            else:
+                grads = [p.grad for p in self.net.parameters()]
+                flat = torch.cat([g.reshape(-1) for g in grads])
+                dist.all_reduce(flat)
+                off = 0
+                for g in grads:
+                    g.copy_(flat[off: off + g.numel()].view_as(g))
+                    off += g.numel()
             if log is not None:
                 dist.all_reduce(losses)
 

@@ -238,13 +238,15 @@ def mlp_backward_supported(A, W):
     return W % 32 == 0 and lib().rnad_mlp_backward_workspace(C.c_int64(32), A, W) > 0
 
 
-def mlp_backward(packed, weights, obs, A, dlogits, dvalue, live=None):
+def mlp_backward(packed, weights, obs, A, dlogits, dvalue, live=None, out=None):
     """Gradients of the 8 Linear tensors (MLP_KEYS order) for dL/dlogits [N, A], dL/dvalue [N(,1)].
-    live: a LiveRows -- only those rows contribute (the caller guarantees the others carry zero gradients)."""
+    live: a LiveRows -- only those rows contribute (the caller guarantees the others carry zero gradients).
+    out: eight preallocated tensors shaped like the weights (e.g. views of one flat all-reduce bucket) to write into."""
     N = obs.numel() // (2 * A * A)
     W = weights[0].shape[0]
     half = obs.dtype == F16
-    grads = [torch.empty_like(w) for w in weights]
+    grads = [torch.empty_like(w) for w in weights] if out is None else list(out)
+    assert len(grads) == len(weights) and all(g.shape == w.shape for g, w in zip(grads, weights))
     ws = torch.empty((lib().rnad_mlp_backward_workspace(C.c_int64(N), A, W) // 4,), dtype=F32, device=obs.device)
     common = (A, W, _dp(packed, F32, "packed"), _dp(obs, F16 if half else F32, "obs"), int(half), _dp(dlogits, F32, "dlogits"),
               _dp(dvalue, F32, "dvalue"), *[_dp(g, F32, "grad") for g in grads], _dp(ws, F32, "workspace"), _stream())
