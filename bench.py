@@ -147,6 +147,19 @@ def main():
     fence()
     elapsed_reuse = time.perf_counter() - t_s
     rn.reuse_actor_outputs = False
+    # the same step with tabular net evaluation (RNaD.tabular: nets evaluated once per (player, state) -- 2S rows -- instead of
+    # once per (t, b) slot; identical rollouts and losses, gradients equal up to fp32 summation order); reported separately
+    elapsed_tab = None
+    if 8 * tree.handle().S <= T * local_batch:
+        rn.tabular = True
+        one_step(args.warmup + 3 * args.steps + 1)
+        fence()
+        t_s = time.perf_counter()
+        for i in range(args.steps):
+            one_step(args.warmup + 3 * args.steps + 2 + i)
+        fence()
+        elapsed_tab = time.perf_counter() - t_s
+        rn.tabular = False
     # rollout alone (Episodes.generate, reference episode.py:175-230), outside the headline timed region
     from environment.episode import Episodes
     fence()
@@ -157,9 +170,10 @@ def main():
     fence()
     rollout_s = time.perf_counter() - t_r
     if world > 1:
-        t = torch.tensor([elapsed, rollout_s, elapsed_reuse], device=device, dtype=torch.float64)
+        t = torch.tensor([elapsed, rollout_s, elapsed_reuse, elapsed_tab or 0.0], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed, rollout_s, elapsed_reuse = t.tolist()
+        elapsed, rollout_s, elapsed_reuse, et = t.tolist()
+        elapsed_tab = et if elapsed_tab is not None else None
 
     if rank == 0:
         # the reference's loop (episode.py:194) runs until every lane is absorbed and counts all B lanes in each of those steps;
@@ -206,6 +220,12 @@ def main():
             "on_policy_shortcut": {"env_steps_per_sec": env_steps / elapsed_reuse, "updates_per_sec": args.steps / elapsed_reuse,
                                    "ms_per_step": elapsed_reuse / args.steps * 1e3,
                                    "what": "RNaD.reuse_actor_outputs=True: learner forward replaced by the rollout's own (bit-identical) logits/values"},
+            "tabular_nets": None if elapsed_tab is None else {
+                "env_steps_per_sec": env_steps / elapsed_tab, "updates_per_sec": args.steps / elapsed_tab,
+                "ms_per_step": elapsed_tab / args.steps * 1e3,
+                "what": f"RNaD.tabular=True (opt-in): each net evaluated on the 2S = {2 * tree.handle().S} distinct observations of the tree and "
+                        f"gathered per slot, instead of on the T*B = {T * local_batch} slots; same rollouts and losses bit for bit, weight "
+                        "gradients equal up to fp32 summation order (tests/test_hip_ragged.py)"},
             "rollout_env_steps_per_sec": env_steps / rollout_s,
             "rollout_ms_per_step": rollout_s / args.steps * 1e3,
             "roofline": {

@@ -189,6 +189,13 @@ int rnad_rollout_run(const rnad_tree_t *tree, const rnad_traj_t *traj, int W, co
                      int64_t logits_step_stride, float *value_ws, uint64_t seed, int64_t lane0, int32_t *live_rows,
                      int64_t *n_live, int32_t *block_counts, void *stream);
 
+/* Tabular actor.  A lane's observation is a function of (state, player to move) alone (episode.py:62-68), so an actor with
+ * fixed weights can be evaluated once on the 2S distinct observations -- rnad_observe_all, then rnad_mlp_forward with
+ * N = 2S -- instead of on B lanes at each of the T steps.  logits_table: [2, S, A], row = player * S + state.  The rollout
+ * (policies, actions, indices, rewards, observations) is that of rnad_rollout_run bit for bit; traj->values is zeros. */
+int rnad_rollout_run_tabular(const rnad_tree_t *tree, const rnad_traj_t *traj, const float *logits_table, uint64_t seed,
+                             int64_t lane0, void *stream);
+
 /* alive[t] = #lanes with indices[t, :] != 0 for t in [0, T_cap]: one pass over the index buffer after the last
  * step.  The host reads it once to trim the trajectory to the reference's T (episode.py:194 stops when every lane
  * is absorbed) and to get the loss normalisers N_P = sum over t == P (mod 2) of alive[t]. */
@@ -261,6 +268,21 @@ int rnad_learn_fused(int T, int64_t B, int A, const int32_t *indices, const uint
                      const float *v, const float *v_target_net, const float *logit_reg, const float *logit_reg_,
                      const double *norm, const rnad_learn_params_t *hp, double *losses, float *dlogit, float *dv,
                      float *pi_out, float *v_target_out, float *q_out, void *stream);
+
+/* Tabular variant.  The four forward_batch calls of learn/rnad.py:373-380 evaluate nets on observations that depend on
+ * (state, player to move) only: 2S distinct inputs for T*B slots (132 862 vs 12.6 M on configs[1]).  Here the nets were
+ * evaluated once per distinct input -- tables [2, S, (A)], row = player * S + state (rnad_observe_all + rnad_mlp_forward) --
+ * and each slot gathers its row.  The weight gradient is linear in dL/dout, so the per-slot dL/dlogit, dL/dv are summed per
+ * row (fp64 hardware atomics; the states of the top levels, which the whole batch passes through, first in a per-block LDS
+ * table) and ONE rnad_mlp_backward over the 2S inputs with
+ * dlogit_tab [2S,A], dv_tab [2S] gives the same gradients as the per-slot backward, up to fp32 summation order.
+ * Per-slot net outputs are the same bits as in rnad_learn_fused (same inputs, same kernel), hence the same losses.
+ * acc: scratch, f64 [2S, A + 1]. */
+int rnad_learn_fused_tabular(const rnad_tree_t *tree, int T, int64_t B, const int32_t *indices, const uint8_t *mask_bits,
+                             const int32_t *actions, const float *rewards, const float *mu, const float *logit_tab,
+                             const float *v_tab, const float *v_target_tab, const float *logit_reg_tab,
+                             const float *logit_reg_tab_, const double *norm, const rnad_learn_params_t *hp, double *losses,
+                             double *acc, float *dlogit_tab, float *dv_tab, void *stream);
 
 /* ------------------------------------------------------------------------------------------------
  * NashConv  --  util/metric.py:93-175 (NashConvData.get_nashconv), level-batched on the GPU

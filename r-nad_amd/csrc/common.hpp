@@ -68,6 +68,9 @@ struct rnad_tree {
     int32_t *level_order = nullptr;      // device [S]
     std::vector<int64_t> level_offsets;  // host [n_levels + 1]
     std::vector<int32_t> level_of;       // host [S] (-1: unreachable)
+    // tabular learner: the states of the top levels (the first n_hot entries of level_order) get a slot in a per-block LDS table
+    int n_hot = 0;
+    int32_t *hot_slot = nullptr;         // device [S]: position in level_order if < n_hot, else -1
     size_t bytes = 0;
 };
 

@@ -314,8 +314,24 @@ __global__ __launch_bounds__(kThreads) void k_loss_nerd(int64_t N, const float *
     if (loss) block_atomic_add(part / (double)nf, loss);
 }
 
-// The fused learner pass (header comment of rnad_learn_fused).  Per (t, b): 69 B read, 16 B written (A = 3).
+// acc (fp64) -> dlogit_tab [2S,A], dv_tab [2S] (fp32)
 template <int A>
+__global__ __launch_bounds__(kThreads) void k_tab_finish(int64_t rows, const double *__restrict__ acc, float *__restrict__ dlogit,
+                                                         float *__restrict__ dv) {
+    const int64_t r = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    if (r >= rows) return;
+#pragma unroll
+    for (int a = 0; a < A; ++a) dlogit[r * A + a] = (float)acc[r * (A + 1) + a];
+    dv[r] = (float)acc[r * (A + 1) + A];
+}
+
+// The fused learner pass (header comment of rnad_learn_fused).  Per (t, b): 69 B read, 16 B written (A = 3).
+// TAB = false: logit_ / v_ / vtn_ / lreg_ / lreg2_ are per-slot arrays [T,B,(A)] and dlogit / dv are written per slot.
+// TAB = true ("tabular" evaluation): the observation is a function of (state, player to move) alone, so the nets were evaluated
+// once per (player, state) -- row = player * S + state of tables [2S,(A)] -- and every slot gathers its row; the per-slot
+// gradients dL/dlogit, dL/dv are summed per row into `acc` [2S][A + 1] (fp64), from which ONE backward pass over the 2S
+// distinct observations gives the weight gradients (the gradient is linear in dL/dout).
+template <int A, bool TAB>
 __global__ __launch_bounds__(kThreads) void k_learn_fused(int T, int64_t B, const int32_t *__restrict__ indices,
                                                           const uint8_t *__restrict__ mbits, const int32_t *__restrict__ actions,
                                                           const float *__restrict__ rewards, const float *__restrict__ mu_,
@@ -325,27 +341,40 @@ __global__ __launch_bounds__(kThreads) void k_learn_fused(int T, int64_t B, cons
                                                           rnad_learn_params_t hp, double *__restrict__ losses,
                                                           float *__restrict__ dlogit, float *__restrict__ dv,
                                                           float *__restrict__ pi_out, float *__restrict__ vt_out,
-                                                          float *__restrict__ q_out) {
-    const int64_t b = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+                                                          float *__restrict__ q_out, int64_t S, double *__restrict__ acc,
+                                                          const int32_t *__restrict__ hot_slot, const int32_t *__restrict__ hot_state,
+                                                          int n_hot) {
+    // TAB: per-row gradient sums.  Rows near the root are hit by the whole batch (every lane passes through the root, a ninth
+    // of them through each of its children, ...): atomics on them serialise in the memory system (measured: 7.5 ns per
+    // same-line fp64 atomic, 62 ms per step if every slot issued its own).  Those n_hot states (whole levels, top down, as many
+    // as fit the LDS) are summed per block in an LDS table -- a block is persistent and walks many lanes -- and flushed once;
+    // the remaining rows are deep in the tree, hit by few lanes each, and take fp64 atomics directly (25 G/s when spread).
+    extern __shared__ double hot[];  // TAB only: [2][n_hot][A + 1]
+    if (TAB) {
+        for (int i = threadIdx.x; i < 2 * n_hot * (A + 1); i += kThreads) hot[i] = 0.0;
+        __syncthreads();
+    }
     double part_v = 0.0, part_n = 0.0;
-    if (b < B) {
-        const float nf0 = norm_of(norm), nf1 = norm_of(norm + 1);
-        const VtHp vh{-hp.eta, hp.lambda_, hp.c, hp.rho, hp.gamma};
+    const float nf0 = norm_of(norm), nf1 = norm_of(norm + 1);
+    const VtHp vh{-hp.eta, hp.lambda_, hp.c, hp.rho, hp.gamma};
+    for (int64_t b = (int64_t)blockIdx.x * kThreads + threadIdx.x; b < B; b += (int64_t)gridDim.x * kThreads) {
         Carry cy[2];
         for (int t = T - 1; t >= 0; --t) {
             const int64_t i = (int64_t)t * B + b;
-            const bool valid = indices[i] != 0;  // rnad.py:369
+            const int state = indices[i];
+            const bool valid = state != 0;  // rnad.py:369
             const float valid_f = valid ? 1.0f : 0.0f;
             const int P = t & 1;  // turns[t, :] (episode.py:96-98)
+            const int64_t row = TAB ? (int64_t)P * S + state : i;  // where this slot's net outputs live
             const uint32_t bits = mbits[i];
             const int act = actions[i];
             float mu[A], lg[A], lr[A], lr2[A], legal[A], oh[A];
 #pragma unroll
             for (int a = 0; a < A; ++a) {
                 mu[a] = mu_[i * A + a];
-                lg[a] = logit_[i * A + a];
-                lr[a] = lreg_[i * A + a];
-                lr2[a] = lreg2_[i * A + a];
+                lg[a] = logit_[row * A + a];
+                lr[a] = lreg_[row * A + a];
+                lr2[a] = lreg2_[row * A + a];
                 legal[a] = (float)((bits >> a) & 1);
                 oh[a] = act == a ? 1.0f : 0.0f;
             }
@@ -357,7 +386,7 @@ __global__ __launch_bounds__(kThreads) void k_learn_fused(int T, int64_t B, cons
 #pragma unroll
             for (int a = 0; a < A; ++a) lpol[a] = lp[a] - (hp.alpha * lpr[a] + hp.one_minus_alpha * lpr2[a]);  // rnad.py:382
             const float rew = rewards[i];
-            const float vtn = vtn_[i];
+            const float vtn = vtn_[row];
             float vt[2], q[2][A];
             vtrace_step<A>(cy[0], vh, valid, P == 0, valid_f, vtn, rew, mu, pip, lpol, oh, vt[0], q[0]);   // player 0 (rnad.py:384-406)
             vtrace_step<A>(cy[1], vh, valid, P == 1, valid_f, vtn, -rew, mu, pip, lpol, oh, vt[1], q[1]);  // player 1: rewards = -r (:368)
@@ -367,7 +396,7 @@ __global__ __launch_bounds__(kThreads) void k_learn_fused(int T, int64_t B, cons
             for (int a = 0; a < A; ++a) g_l[a] = 0.0f;
             if (valid) {
                 const float nfp = P ? nf1 : nf0;
-                const float vv = v_[i];
+                const float vv = v_[row];
                 const float vtp = P ? vt[1] : vt[0];
                 const float d = vv - vtp;
                 part_v += (double)(d * d) / (double)nfp;
@@ -379,6 +408,16 @@ __global__ __launch_bounds__(kThreads) void k_learn_fused(int T, int64_t B, cons
                 part_n += -(double)nerd / (double)nfp;
 #pragma unroll
                 for (int a = 0; a < A; ++a) g_l[a] = hp.w_n * (-g[a] / nfp);
+            }
+            if (TAB) {
+                if (valid) {
+                    const int hs = hot_slot[state];
+                    double *dst = hs >= 0 ? hot + ((int64_t)P * n_hot + hs) * (A + 1) : acc + row * (A + 1);
+#pragma unroll
+                    for (int a = 0; a < A; ++a) unsafeAtomicAdd(dst + a, (double)g_l[a]);  // ds_add_f64 / global_atomic_add_f64
+                    unsafeAtomicAdd(dst + A, (double)g_v);
+                }
+                continue;  // the per-slot outputs below belong to the dense variant
             }
             dv[i] = g_v;
 #pragma unroll
@@ -397,6 +436,17 @@ __global__ __launch_bounds__(kThreads) void k_learn_fused(int T, int64_t B, cons
                     q_out[i * A + a] = q[0][a];
                     q_out[((int64_t)T * B + i) * A + a] = q[1][a];
                 }
+            }
+        }
+    }
+    if (TAB) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < 2 * n_hot; i += kThreads) {
+            const int64_t row = (int64_t)(i / n_hot) * S + hot_state[i % n_hot];
+#pragma unroll
+            for (int a = 0; a <= A; ++a) {
+                const double x = hot[(int64_t)i * (A + 1) + a];
+                if (x != 0.0) unsafeAtomicAdd(acc + row * (A + 1) + a, x);
             }
         }
     }
@@ -496,9 +546,51 @@ extern "C" int rnad_learn_fused(int T, int64_t B, int A, const int32_t *indices,
     if (losses) RNAD_HIP_OK(hipMemsetAsync(losses, 0, 2 * sizeof(double), stream));
     if (T == 0 || B == 0) return 0;
     ProfScope prof(PROF_LEARN, stream);
-    RNAD_DISPATCH_A(A, hipLaunchKernelGGL((k_learn_fused<kA>), dim3(blocks_for(B)), dim3(kThreads), 0, stream, T, B, indices, mask_bits,
-                                          actions, rewards, mu, logit, v, v_target_net, logit_reg, logit_reg_, norm, *hp, losses, dlogit,
-                                          dv, pi_out, v_target_out, q_out));
+    RNAD_DISPATCH_A(A, hipLaunchKernelGGL((k_learn_fused<kA, false>), dim3(blocks_for(B)), dim3(kThreads), 0, stream, T, B, indices,
+                                          mask_bits, actions, rewards, mu, logit, v, v_target_net, logit_reg, logit_reg_, norm, *hp, losses,
+                                          dlogit, dv, pi_out, v_target_out, q_out, (int64_t)0, (double *)nullptr,
+                                          (const int32_t *)nullptr, (const int32_t *)nullptr, 0));
+    RNAD_HIP_OK(hipGetLastError());
+    return 0;
+}
+
+extern "C" int rnad_learn_fused_tabular(const rnad_tree_t *tree, int T, int64_t B, const int32_t *indices, const uint8_t *mask_bits,
+                                        const int32_t *actions, const float *rewards, const float *mu, const float *logit_tab,
+                                        const float *v_tab, const float *v_target_tab, const float *logit_reg_tab,
+                                        const float *logit_reg_tab_, const double *norm, const rnad_learn_params_t *hp, double *losses,
+                                        double *acc, float *dlogit_tab, float *dv_tab, void *stream_) {
+    RNAD_REQUIRE(tree && indices && mask_bits && actions && rewards && mu && logit_tab && v_tab && v_target_tab && logit_reg_tab &&
+                     logit_reg_tab_ && norm && hp && acc && dlogit_tab && dv_tab,
+                 "rnad_learn_fused_tabular: null argument");
+    RNAD_REQUIRE(T >= 0 && B >= 0, "rnad_learn_fused_tabular: negative shape");
+    RNAD_REQUIRE(hp->n_disc >= 1, "rnad_learn_fused_tabular: n_disc must be positive");
+    hipStream_t stream = (hipStream_t)stream_;
+    const int A = tree->A;
+    const int64_t S = tree->S;
+    if (losses) RNAD_HIP_OK(hipMemsetAsync(losses, 0, 2 * sizeof(double), stream));
+    RNAD_HIP_OK(hipMemsetAsync(acc, 0, sizeof(double) * 2 * S * (A + 1), stream));
+    ProfScope prof(PROF_LEARN, stream);
+    if (T > 0 && B > 0) {
+        // persistent blocks: the LDS table of hot rows is flushed once per block, so few blocks walking many lanes each
+        int cus = 256;
+        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, tree->device);
+        const size_t lds = (size_t)2 * tree->n_hot * (A + 1) * sizeof(double);
+        const int per_cu = std::max(1, std::min(8, (int)((160 * 1024) / std::max<size_t>(lds, 1))));
+        const unsigned grid = (unsigned)std::min<int64_t>(blocks_for(B), (int64_t)cus * per_cu);
+#define RNAD_TAB_LAUNCH()                                                                                                         \
+    do {                                                                                                                           \
+        auto kern = k_learn_fused<kA, true>;                                                                                       \
+        if (lds > 64 * 1024) RNAD_HIP_OK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(kThreads), lds, stream, T, B, indices, mask_bits, actions, rewards, mu, logit_tab, \
+                           v_tab, v_target_tab, logit_reg_tab, logit_reg_tab_, norm, *hp, losses, (float *)nullptr, (float *)nullptr, \
+                           (float *)nullptr, (float *)nullptr, (float *)nullptr, S, acc, (const int32_t *)tree->hot_slot,           \
+                           (const int32_t *)tree->level_order, tree->n_hot);                                                       \
+    } while (0)
+        RNAD_DISPATCH_A(A, RNAD_TAB_LAUNCH());
+#undef RNAD_TAB_LAUNCH
+    }
+    RNAD_DISPATCH_A(A, hipLaunchKernelGGL((k_tab_finish<kA>), dim3(blocks_for(2 * S)), dim3(kThreads), 0, stream, 2 * S, acc, dlogit_tab,
+                                          dv_tab));
     RNAD_HIP_OK(hipGetLastError());
     return 0;
 }

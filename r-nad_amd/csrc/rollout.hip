@@ -204,12 +204,14 @@ __global__ __launch_bounds__(kThreads) void k_act(const Trans *__restrict__ tran
                                                   const int32_t *__restrict__ idx_t, const uint8_t *__restrict__ mbits_t,
                                                   const int32_t *__restrict__ act_prev, float *__restrict__ policy_t,
                                                   int32_t *__restrict__ act_t, float *__restrict__ rewards_t,
-                                                  float *__restrict__ values_t, int32_t *__restrict__ idx_next) {
+                                                  float *__restrict__ values_t, int32_t *__restrict__ idx_next, int64_t table_S) {
     const int64_t b = (int64_t)blockIdx.x * kThreads + threadIdx.x;
     if (b < B) {
         float in[A], pol[A];
+        // table_S != 0: net_out is a [2, S, A] table of the actor's logits per (player to move, state); the lane gathers its row
+        const int64_t src = table_S ? (int64_t)(t & 1) * table_S + idx_t[b] : b;
 #pragma unroll
-        for (int a = 0; a < A; ++a) in[a] = net_out[b * A + a];
+        for (int a = 0; a < A; ++a) in[a] = net_out[src * A + a];
         if (MODE == 0) {
             policy_head<A>(in, mbits_t[b], pol, nullptr);
         } else {
@@ -412,10 +414,9 @@ extern "C" int rnad_rollout_begin(const rnad_tree_t *tree, const rnad_traj_t *tr
     return launch_observe(tree, tr->B, tr->indices, 0, tr->observations, tr->obs_half, tr->mask_bits, nullptr, stream);
 }
 
-extern "C" int rnad_rollout_step(const rnad_tree_t *tree, const rnad_traj_t *tr, int t, int mode, const float *logits,
-                                 const float *policy_in, const int32_t *actions_in, const float *value,
-                                 const float *noise_action, const float *noise_chance, uint64_t seed, int64_t lane0,
-                                 void *stream_) {
+static int rollout_step_impl(const rnad_tree_t *tree, const rnad_traj_t *tr, int t, int mode, const float *logits,
+                             const float *policy_in, const int32_t *actions_in, const float *value, const float *noise_action,
+                             const float *noise_chance, uint64_t seed, int64_t lane0, int64_t table_S, void *stream_) {
     if (int rc = check_traj(tree, tr, "rnad_rollout_step")) return rc;
     RNAD_REQUIRE(t >= 0 && t < tr->T_cap, "rnad_rollout_step: step %d outside [0,%d)", t, tr->T_cap);
     RNAD_REQUIRE(mode >= 0 && mode <= 2, "rnad_rollout_step: mode %d", mode);
@@ -434,7 +435,7 @@ extern "C" int rnad_rollout_step(const rnad_tree_t *tree, const rnad_traj_t *tr,
     hipLaunchKernelGGL((k_act<kA, MODE_>), dim3(blocks_for(B)), dim3(kThreads), 0, stream, tree->trans, tree->C, B, t, net_out, \
                        actions_in, value, noise_action, noise_chance, seed, lane0, idx_t, tr->mask_bits + (int64_t)t * B,      \
                        act_prev, tr->policy + (int64_t)t * B * A, tr->actions + (int64_t)t * B, tr->rewards + (int64_t)t * B,  \
-                       tr->values + (int64_t)t * B, tr->indices + (int64_t)(t + 1) * B)
+                       tr->values + (int64_t)t * B, tr->indices + (int64_t)(t + 1) * B, table_S)
         RNAD_DISPATCH_A(A, {
             if (mode == 0) RNAD_ACT(0);
             else if (mode == 1) RNAD_ACT(1);
@@ -450,6 +451,13 @@ extern "C" int rnad_rollout_step(const rnad_tree_t *tree, const rnad_traj_t *tr,
                               tr->mask_bits + (int64_t)(t + 1) * B, nullptr, stream);
     }
     return 0;
+}
+
+extern "C" int rnad_rollout_step(const rnad_tree_t *tree, const rnad_traj_t *tr, int t, int mode, const float *logits,
+                                 const float *policy_in, const int32_t *actions_in, const float *value,
+                                 const float *noise_action, const float *noise_chance, uint64_t seed, int64_t lane0,
+                                 void *stream) {
+    return rollout_step_impl(tree, tr, t, mode, logits, policy_in, actions_in, value, noise_action, noise_chance, seed, lane0, 0, stream);
 }
 
 extern "C" int rnad_rollout_end(const rnad_tree_t *tree, const rnad_traj_t *tr, void *stream_) {
@@ -509,4 +517,20 @@ extern "C" int rnad_compact_valid(int64_t N, const int32_t *indices, int32_t *ro
     hipLaunchKernelGGL(k_compact_write, dim3(nb), dim3(kThreads), 0, stream, N, indices, block_counts, rows);
     RNAD_HIP_OK(hipGetLastError());
     return 0;
+}
+
+// ---------------------------------------------------------------------------------------- tabular actor
+// The observation of a lane is a function of (state, player to move) alone (episode.py:62-68), so an actor whose weights are
+// fixed for the rollout can be evaluated ONCE on the 2S distinct observations (rnad_observe_all + rnad_mlp_forward) instead of
+// on B lanes at each of the T steps; every step then gathers its logits row.  Same observation bits, same kernel: the policies,
+// actions and trajectories are those of rnad_rollout_run bit for bit.  traj->values is filled with zeros.
+extern "C" int rnad_rollout_run_tabular(const rnad_tree_t *tree, const rnad_traj_t *tr, const float *logits_table, uint64_t seed,
+                                        int64_t lane0, void *stream) {
+    if (int rc = check_traj(tree, tr, "rnad_rollout_run_tabular")) return rc;
+    RNAD_REQUIRE(logits_table, "rnad_rollout_run_tabular: null table");
+    if (int rc = rnad_rollout_begin(tree, tr, stream)) return rc;
+    for (int t = 0; t < tr->T_cap; ++t)
+        if (int rc = rollout_step_impl(tree, tr, t, 0, logits_table, nullptr, nullptr, nullptr, nullptr, nullptr, seed, lane0, tree->S, stream))
+            return rc;
+    return rnad_rollout_end(tree, tr, stream);
 }

@@ -173,7 +173,19 @@ extern "C" int rnad_tree_create(rnad_tree_t **out, int64_t S, int C, int A, cons
         return fail(e, "hipMemcpy(trans)");
     if ((e = hipMemcpy(tree->level_order, order.data(), order.size() * sizeof(int32_t), hipMemcpyHostToDevice)) != hipSuccess)
         return fail(e, "hipMemcpy(level_order)");
-    tree->bytes = node.size() * sizeof(float) + trans.size() * sizeof(Trans) + order.size() * sizeof(int32_t);
+    // hot states: whole levels from the root down while 2 * n_hot * (A + 1) doubles fit 96 KiB of LDS (rnad_learn_fused_tabular)
+    {
+        const int64_t cap = (96 * 1024) / (2 * (A + 1) * (int64_t)sizeof(double));
+        int64_t n_hot = 0;
+        for (int l = 0; l < tree->n_levels && count[l + 1] <= cap; ++l) n_hot = count[l + 1];
+        tree->n_hot = (int)n_hot;
+        std::vector<int32_t> slot((size_t)S, -1);
+        for (int64_t k = 0; k < n_hot; ++k) slot[(size_t)order[(size_t)k]] = (int32_t)k;
+        if ((e = hipMalloc((void **)&tree->hot_slot, slot.size() * sizeof(int32_t))) != hipSuccess) return fail(e, "hipMalloc(hot_slot)");
+        if ((e = hipMemcpy(tree->hot_slot, slot.data(), slot.size() * sizeof(int32_t), hipMemcpyHostToDevice)) != hipSuccess)
+            return fail(e, "hipMemcpy(hot_slot)");
+    }
+    tree->bytes = node.size() * sizeof(float) + trans.size() * sizeof(Trans) + order.size() * sizeof(int32_t) + (size_t)S * sizeof(int32_t);
     *out = tree;
     return 0;
 }
@@ -183,6 +195,7 @@ extern "C" void rnad_tree_destroy(rnad_tree_t *tree) {
     if (tree->node) (void)hipFree(tree->node);
     if (tree->trans) (void)hipFree(tree->trans);
     if (tree->level_order) (void)hipFree(tree->level_order);
+    if (tree->hot_slot) (void)hipFree(tree->hot_slot);
     delete tree;
 }
 

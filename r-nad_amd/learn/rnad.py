@@ -122,6 +122,11 @@ class RNaD:
         # rollout that just finished, with unchanged weights, so forward_batch(net) (rnad.py:373) recomputes bit-identical
         # logits / values; when True they are taken from the rollout and only the backward runs.
         self.reuse_actor_outputs = False
+        # Tabular net evaluation (off by default): observations are a function of (state, player to move), so the nets can be
+        # evaluated on the 2S distinct observations of the tree instead of on every (t, b) slot -- see __learn.  Same rollouts and
+        # losses bit for bit; weight gradients equal up to fp32 summation order (and, because the per-row sums use fp64 atomics,
+        # not bitwise reproducible from run to run).  Used only when 8 S <= T B.
+        self.tabular = False
         self.obs_half = False  # store observations as fp16 (BASELINE.json configs[4]); arithmetic stays fp32
         self.nashconv_history = []  # (m, total_steps, nashconv)
 
@@ -303,10 +308,13 @@ class RNaD:
 
     # ------------------------------------------------------------------ reference learn/rnad.py:353-456
     @staticmethod
-    def _logits_of(module, episodes, want_logits=True, want_value=True, live=None):
+    def _logits_of(module, episodes, want_logits=True, want_value=True, live=None, table=None):
         """Raw policy logits [T*B, A] and value [T*B, 1] of `module` on a trajectory (a head that is not wanted may be None).
-        live: evaluate only the (t, b) slots of that rnad_hip.LiveRows list (zeros elsewhere)."""
+        live: evaluate only the (t, b) slots of that rnad_hip.LiveRows list (zeros elsewhere).
+        table: evaluate on these [2S, 2, A, A] observations (one per player and state) instead of the trajectory's."""
         T = episodes.t_eff + 1
+        if table is not None:
+            return module.forward_logits(table, want_logits=want_logits, want_value=want_value)
         if hasattr(module, "forward_logits"):
             kw = {"live": live} if live is not None else {}
             return module.forward_logits(episodes.observations[:T], want_logits=want_logits, want_value=want_value, **kw)
@@ -330,36 +338,47 @@ class RNaD:
         # and masks the absorbed ones afterwards (valid, :369).  Here the nets run on the live slots only; the others hold
         # zeros, which the same masks discard -- losses and gradients are unchanged.  Logging steps stay dense, because
         # logit_mean / logit_max (:427-452) are taken over ALL slots.
+        fused_mlp = isinstance(self.net, net.MLP) and self.net._fusable() and rnad_hip.mlp_backward_supported(A, self.net.width)
+        # Tabular evaluation (opt-in, RNaD.tabular): an observation depends on (state, player to move) only, so each net is
+        # evaluated on the 2S distinct observations of the tree and every (t, b) slot gathers its row; the per-slot gradients
+        # are summed per row before ONE backward pass over those 2S observations (include/rnad_hip.h, rnad_learn_fused_tabular).
+        # Worth it when the tree is small next to the batch (configs[1]: 132 862 rows for 12.6 M slots).
+        table = None
+        if getattr(self, "tabular", False) and fused_mlp and log is None:
+            handle = self.tree.handle()
+            if 8 * handle.S <= T * B:
+                table = handle.observations_table(getattr(episodes, "obs_half", False))
         live = None
-        if (getattr(self, "skip_absorbed", True) and log is None and isinstance(self.net, net.MLP) and self.net._fusable()
-                and rnad_hip.mlp_backward_supported(A, self.net.width) and not self.tree.handle().uniform_length):
+        if (table is None and getattr(self, "skip_absorbed", True) and log is None and fused_mlp
+                and not self.tree.handle().uniform_length):
             live = rnad_hip.compact_valid(episodes.indices[:T])
         # The fused MLP is differentiated by hand (rnad_mlp_backward), so the learner's forward needs no autograd graph and its
         # gradients can be written straight into one flat bucket (the all-reduce buffer).  Any other net goes through autograd.
-        direct = isinstance(self.net, net.MLP) and self.net._fusable() and rnad_hip.mlp_backward_supported(A, self.net.width)
+        direct = fused_mlp
+        reuse = reuse and table is None
         if reuse:  # the rollout's own outputs: same weights, same observations, same kernel -> same bits as rnad.py:373
             logit, v = episodes.actor_logits.reshape(-1, A), episodes.values[:T].reshape(-1, 1)
         elif direct:
             with torch.no_grad():
-                logit, v = self._logits_of(self.net, episodes, live=live)  # rnad.py:373
+                logit, v = self._logits_of(self.net, episodes, live=live, table=table)  # rnad.py:373
         else:
             logit, v = self._logits_of(self.net, episodes, live=live)  # rnad.py:373, with grad
         with torch.no_grad():
             # the reference runs all four full nets (:378-380); only these heads are ever read (:382-406)
-            logit_target, v_target = self._logits_of(self.net_target, episodes, want_logits=log is not None, live=live)  # :378
+            logit_target, v_target = self._logits_of(self.net_target, episodes, want_logits=log is not None, live=live, table=table)  # :378
             # log_policy_reg = log_pi - (alpha * log_pi_reg + (1 - alpha) * log_pi_reg_) (:382).  A term whose weight is exactly 0
             # adds exactly 0 (log-policies are finite), and two nets with the same weights give the same bits: in the second half
             # of every outer iteration (alpha == 1, :497) and during all of m == 0 (both reg nets are copies of the initial net,
             # :183-186) one evaluation serves both operands.
             if alpha == 0:
-                logit_reg_, _ = self._logits_of(self.net_reg_, episodes, want_value=False, live=live)  # :380
+                logit_reg_, _ = self._logits_of(self.net_reg_, episodes, want_value=False, live=live, table=table)  # :380
                 logit_reg = logit_reg_
             else:
-                logit_reg, _ = self._logits_of(self.net_reg, episodes, want_value=False, live=live)  # :379
+                logit_reg, _ = self._logits_of(self.net_reg, episodes, want_value=False, live=live, table=table)  # :379
                 if alpha == 1 or self._reg_nets_identical():
                     logit_reg_ = logit_reg
                 else:
-                    logit_reg_, _ = self._logits_of(self.net_reg_, episodes, want_value=False, live=live)  # :380
+                    logit_reg_, _ = self._logits_of(self.net_reg_, episodes, want_value=False, live=live, table=table)  # :380
 
         if norm_work is not None:
             norm_work.wait()
@@ -367,17 +386,24 @@ class RNaD:
             alpha=alpha, eta=self.eta, lambda_=1.0, c=self.c_bar, rho=self.roh_bar, gamma=self.vtrace_gamma,
             clip=self.neurd_clip, threshold=self.beta, w_v=self.value_weight, w_n=self.neurd_weight,
             eps_threshold=self.epsilon_threshold, n_disc=self.n_discrete)
-        dlogit, dv, losses, pi, _, _ = rnad_hip.learn_fused(
-            episodes.indices[:T], episodes.mask_bits[:T], episodes.action_idx[:T], episodes.rewards[:T], episodes.policy[:T],
-            logit.detach().contiguous(), v.detach().reshape(T, B).contiguous(), v_target.reshape(T, B).contiguous(),
-            logit_reg.contiguous(), logit_reg_.contiguous(), norm, hp, want_aux=log is not None)
+        if table is not None:
+            dlogit, dv, losses = rnad_hip.learn_fused_tabular(
+                self.tree.handle(), episodes.indices[:T], episodes.mask_bits[:T], episodes.action_idx[:T], episodes.rewards[:T],
+                episodes.policy[:T], logit, v, v_target, logit_reg, logit_reg_, norm, hp)
+            pi = None
+            backward_obs = table            # dlogit [2S, A], dv [2S, 1]: per-row sums of the per-slot gradients
+        else:
+            dlogit, dv, losses, pi, _, _ = rnad_hip.learn_fused(
+                episodes.indices[:T], episodes.mask_bits[:T], episodes.action_idx[:T], episodes.rewards[:T], episodes.policy[:T],
+                logit.detach().contiguous(), v.detach().reshape(T, B).contiguous(), v_target.reshape(T, B).contiguous(),
+                logit_reg.contiguous(), logit_reg_.contiguous(), norm, hp, want_aux=log is not None)
+            backward_obs = episodes.observations[:T]
         # loss.backward() (rnad.py:424-425) with the closed-form dL/dlogit, dL/dv
         flat = None
         if reuse or direct:
             weights = self.net._weights()
             flat, views = self._grad_bucket(weights)
-            rnad_hip.mlp_backward(self.net.pack(), weights, episodes.observations[:T], A, dlogit.view(-1, A), dv.view(-1, 1), live=live,
-                                  out=views)
+            rnad_hip.mlp_backward(self.net.pack(), weights, backward_obs, A, dlogit.view(-1, A), dv.view(-1, 1), live=live, out=views)
             if all(p_.grad is None for p_ in weights):
                 for p_, g_ in zip(weights, views):
                     p_.grad = g_
@@ -438,7 +464,9 @@ class RNaD:
             # no host sync: trailing all-absorbed steps are masked by `valid`
             episodes.generate(self.net, trim=False, keep_logits=self.reuse_actor_outputs,
                               skip_absorbed=getattr(self, "skip_absorbed", True) and not self.reuse_actor_outputs,
-                              store_values=self.reuse_actor_outputs or getattr(self, "store_actor_values", False))
+                              store_values=self.reuse_actor_outputs or getattr(self, "store_actor_values", False),
+                              tabular=getattr(self, "tabular", False) and not self.reuse_actor_outputs
+                              and 8 * self.tree.handle().S <= 2 * self.tree.handle().max_depth * local_batch)
             episodes._actor_tag = (id(self.net), self.total_steps)
             buffer.append(episodes)
             self.last_episodes = episodes

@@ -120,6 +120,16 @@ class TreeHandle:
     def ptr(self):
         return self._h
 
+    def observations_table(self, half=False):
+        """[2S, 2, A, A]: the observation of every (player to move, state), row = player * S + state (rnad_observe_all).
+        Built on first use and kept; half=True rounds it to fp16 (what an fp16 trajectory buffer would hold)."""
+        key = "_obs_table_half" if half else "_obs_table"
+        if getattr(self, key, None) is None:
+            row, col = observe_all(self, self.device)
+            tab = torch.cat([row, col], dim=0)
+            setattr(self, key, tab.half() if half else tab)
+        return getattr(self, key)
+
     def __del__(self):
         try:
             if self._h:
@@ -339,6 +349,13 @@ def rollout_run(tree, traj, W, packed, seed=0, lane0=0, keep_logits=False, skip_
     return logits if keep_logits else None
 
 
+def rollout_run_tabular(tree, traj, logits_table, seed=0, lane0=0):
+    """Rollout whose actor was evaluated once per (player, state): logits_table [2S, A] (rnad_rollout_run_tabular)."""
+    assert logits_table.shape == (2 * tree.S, tree.A)
+    _check(lib().rnad_rollout_run_tabular(tree.ptr, C.byref(traj.c), _dp(logits_table, F32, "logits_table"), C.c_uint64(seed),
+                                          C.c_int64(lane0), _stream()))
+
+
 def rollout_end(tree, traj):
     _check(lib().rnad_rollout_end(tree.ptr, C.byref(traj.c), _stream()))
 
@@ -414,6 +431,26 @@ def learn_fused(indices, mask_bits, actions, rewards, mu, logit, v, v_target_net
                                   C.byref(hp), _dp(losses, F64, "losses"), _dp(dlogit, F32, "dlogit"), _dp(dv, F32, "dv"),
                                   _dp(pi, F32, "pi", True), _dp(vt, F32, "vt", True), _dp(q, F32, "q", True), _stream()))
     return dlogit, dv, losses, pi, vt, q
+
+
+def learn_fused_tabular(tree, indices, mask_bits, actions, rewards, mu, logit_tab, v_tab, v_target_tab, logit_reg_tab, logit_reg_tab_,
+                        norm, hp):
+    """rnad_learn_fused_tabular: net outputs given per (player, state) row [2S, (A)]; returns dlogit_tab [2S, A], dv_tab [2S, 1]
+    (the per-slot gradients summed per row) and losses f64[2]."""
+    T, B, A = mu.shape
+    dev = mu.device
+    S = tree.S
+    acc = torch.empty((2 * S, A + 1), dtype=F64, device=dev)
+    dlogit = torch.empty((2 * S, A), dtype=F32, device=dev)
+    dv = torch.empty((2 * S, 1), dtype=F32, device=dev)
+    losses = torch.empty((2,), dtype=F64, device=dev)
+    _check(lib().rnad_learn_fused_tabular(tree.ptr, T, C.c_int64(B), _dp(indices, I32, "indices"), _dp(mask_bits, U8, "mask_bits"),
+                                          _dp(actions, I32, "actions"), _dp(rewards, F32, "rewards"), _dp(mu, F32, "mu"),
+                                          _dp(logit_tab, F32, "logit_tab"), _dp(v_tab, F32, "v_tab"), _dp(v_target_tab, F32, "v_target_tab"),
+                                          _dp(logit_reg_tab, F32, "logit_reg_tab"), _dp(logit_reg_tab_, F32, "logit_reg_tab_"),
+                                          _dp(norm, F64, "norm"), C.byref(hp), _dp(losses, F64, "losses"), _dp(acc, F64, "acc"),
+                                          _dp(dlogit, F32, "dlogit_tab"), _dp(dv, F32, "dv_tab"), _stream()))
+    return dlogit, dv, losses
 
 
 def make_learn_params(alpha, eta, lambda_=1.0, c=1.0, rho=1.0, gamma=1.0, clip=1e3, threshold=2.0, w_v=1.0, w_n=1.0,

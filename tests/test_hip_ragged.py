@@ -206,3 +206,94 @@ def test_one_reg_net_evaluation_when_the_other_cannot_matter(monkeypatch):
     g0b = grads(0)                                                     # alpha == 0: net_reg must not matter
     assert all(torch.equal(a, b) for a, b in zip(g0, g0b))
     assert not all(torch.equal(a, b) for a, b in zip(g0, g1))
+
+
+# ------------------------------------------------------------------------------------------------ tabular evaluation
+@pytest.mark.parametrize("half", (False, True))
+@pytest.mark.parametrize("ragged", (False, True))
+def test_tabular_rollout_is_the_dense_rollout(half, ragged):
+    """One actor evaluation per (player, state) + per-lane gathers == one evaluation per lane and step, bit for bit."""
+    from environment.episode import Episodes
+    from environment.tree import Tree
+    from nn.net import MLP
+
+    torch.manual_seed(3)
+    if ragged:
+        tree = _ragged_tree()
+    else:
+        tree = Tree(device=DEV, max_actions=3, max_transitions=1, depth_bound=4)
+        tree.generate_native(seed=2)
+    net = MLP(3, 64, device=DEV)
+    B = 30_000
+    dense = Episodes(tree, B, seed=11, obs_half=half)
+    dense.generate(net, trim=False)
+    tab = Episodes(tree, B, seed=11, obs_half=half)
+    tab.generate(net, trim=False, tabular=True)
+    T = dense.t_eff + 1
+    for name in ("indices", "observations", "mask_bits", "policy", "action_idx", "rewards", "alive"):
+        assert torch.equal(getattr(tab, name)[:T], getattr(dense, name)[:T]), name  # absorbed lanes too: state 0 has a row as well
+    assert (tab.values == 0).all()
+
+
+@pytest.mark.parametrize("ragged", (False, True))
+def test_tabular_update_is_the_dense_update(ragged):
+    from environment.episode import Episodes
+    from environment.tree import Tree
+    from learn.rnad import RNaD
+
+    if ragged:
+        tree = _ragged_tree()
+    else:
+        tree = Tree(device=DEV, max_actions=3, max_transitions=1, depth_bound=4)
+        tree.generate_native(seed=2)
+    os.environ["RNAD_SAVE_DIR"] = tempfile.mkdtemp(prefix="rnad_test_")
+    B = 1 << 15
+    torch.manual_seed(6)
+    rn = RNaD(tree=tree, device=DEV, directory_name=f"tab{int(ragged)}", batch_size=B, eta=0.2, b1_adam=0.0,
+              net_params={"type": "MLP", "max_actions": 3, "width": 64})
+    rn.initialize()
+    with torch.no_grad():
+        for i, m in enumerate((rn.net_target, rn.net_reg, rn.net_reg_)):
+            for p_ in m.parameters():
+                p_.add_(0.05 * (i + 1) * torch.randn_like(p_))
+    ep = Episodes(tree, B, seed=3)
+    ep.generate(rn.net, trim=False)
+    assert 8 * tree.handle().S <= (ep.t_eff + 1) * B
+    out = []
+    for tabular in (False, True):
+        rn.tabular = tabular
+        rn.skip_absorbed = False
+        rn.optimizer.zero_grad()
+        rn._RNaD__learn(ep, 0.4)
+        out.append([p_.grad.detach().clone() for p_ in rn.net.parameters()])
+    for a, b in zip(*out):
+        scale = float(b.abs().max()) + 1e-12
+        assert torch.isfinite(a).all() and float(b.abs().max()) > 0
+        np.testing.assert_allclose(a.cpu().numpy() / scale, b.cpu().numpy() / scale, rtol=0, atol=1e-5)
+
+
+def test_tabular_training_steps_track_the_dense_ones():
+    from environment.episode import Buffer
+    from environment.tree import Tree
+    from learn.rnad import RNaD
+
+    tree = Tree(device=DEV, max_actions=3, max_transitions=1, depth_bound=4)
+    tree.generate_native(seed=2)
+    os.environ["RNAD_SAVE_DIR"] = tempfile.mkdtemp(prefix="rnad_test_")
+    finals = []
+    for tabular in (False, True):
+        torch.manual_seed(8)
+        rn = RNaD(tree=tree, device=DEV, directory_name=f"tabrun{int(tabular)}", batch_size=1 << 14, eta=0.2, b1_adam=0.0, lr=1e-4,
+                  net_params={"type": "MLP", "max_actions": 3, "width": 64})
+        rn.initialize()
+        rn.tabular = tabular
+        buf = Buffer(1)
+        for i in range(5):
+            rn.train_step(buf, alpha=0.2 * i)
+            rn.total_steps += 1
+        finals.append([p_.detach().clone() for p_ in rn.net.parameters()])
+    for a, b in zip(*finals):
+        # Adam (b1 = 0) moves every weight by ~lr per step whatever the gradient's size: a last-bit difference in a tiny gradient
+        # can flip a step, so compare at a few lr
+        np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=0, atol=1e-3)
+        assert torch.isfinite(a).all()
