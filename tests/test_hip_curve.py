@@ -10,7 +10,9 @@ from _util import load
 pytestmark = pytest.mark.gpu
 
 
-def test_nashconv_curve_matches_reference_band(tmp_path, monkeypatch):
+@pytest.mark.parametrize("tabular", (False, True))
+def test_nashconv_curve_matches_reference_band(tmp_path, monkeypatch, tabular):
+    """tabular=True: the same training with every net evaluated once per (player, state) (RNaD.tabular)."""
     from _gpu import DEV, golden_tree
     from learn.rnad import RNaD
 
@@ -21,12 +23,13 @@ def test_nashconv_curve_matches_reference_band(tmp_path, monkeypatch):
     tree, _ = golden_tree("small")
     monkeypatch.setenv("RNAD_SAVE_DIR", str(tmp_path))
     mine = []
-    for seed in (0, 1):
+    for seed in ((0,) if tabular else (0, 1)):
         torch.manual_seed(2000 + seed)
         rn = RNaD(tree=tree, device=DEV, directory_name=f"curve{seed}", eta=float(ref["eta"]), bounds=[M], delta_m=[delta],
                   lr=float(ref["lr"]), gamma_averaging=float(ref["gamma_averaging"]), batch_size=B, logit_clip=2, b1_adam=0.0,
                   net_params={"type": "MLP", "max_actions": 3, "width": 2**8})
         rn.initialize()
+        rn.tabular = tabular
         nc0 = rn._RNaD__nashconv()
         rn._RNaD__resume(checkpoint_mod=10**9, expl_mod=1, log_mod=10**9)
         nc = [nc0] + [v for _, _, v in rn.nashconv_history] + [rn._RNaD__nashconv()]
