@@ -136,44 +136,44 @@ def main():
     n_mlp, mlp_ms = rnad_hip.prof_read(rnad_hip.PROF_MLP)
     n_bwd, bwd_ms = rnad_hip.prof_read(rnad_hip.PROF_MLP_BWD)
     rnad_hip.prof_enable(False)
-    # the same step with the on-policy shortcut (RNaD.reuse_actor_outputs: the rollout's logits / values stand in for the
-    # learner's forward_batch, bit-identical when the buffer holds only the current batch); reported separately, NOT `value`
-    rn.reuse_actor_outputs = True
-    one_step(args.warmup + 2 * args.steps)
-    fence()
-    t_s = time.perf_counter()
-    for i in range(args.steps):
-        one_step(args.warmup + 2 * args.steps + 1 + i)
-    fence()
-    elapsed_reuse = time.perf_counter() - t_s
-    rn.reuse_actor_outputs = False
-    # the same step with tabular net evaluation (RNaD.tabular: nets evaluated once per (player, state) -- 2S rows -- instead of
-    # once per (t, b) slot; identical rollouts and losses, gradients equal up to fp32 summation order); reported separately
-    elapsed_tab = None
-    if 8 * tree.handle().S <= T * local_batch:
-        rn.tabular = True
-        one_step(args.warmup + 3 * args.steps + 1)
+    # the same step in the other net-evaluation modes of RNaD (reported separately, NOT `value`):
+    #   dense_nets   RNaD.tabular = False: every net on every (t, b) slot, as the reference does
+    #   forward      RNaD.tabular = "forward" (the default): forward evaluations once per (player, state), backward per slot;
+    #                every result bit-identical to dense_nets
+    #   tabular_nets RNaD.tabular = True: per-slot gradients summed per (player, state) row, one backward over the 2S rows;
+    #                same rollouts and losses, weight gradients equal up to fp32 summation order
+    default_mode = rn.tabular
+    base = args.warmup + 2 * args.steps
+    variants = {}
+    for name, mode in (("dense_nets", False), ("forward", "forward"), ("tabular_nets", True)):
+        if mode == default_mode or (mode and 8 * tree.handle().S > T * local_batch):
+            continue
+        rn.tabular = mode
+        one_step(base)
         fence()
         t_s = time.perf_counter()
         for i in range(args.steps):
-            one_step(args.warmup + 3 * args.steps + 2 + i)
+            one_step(base + 1 + i)
         fence()
-        elapsed_tab = time.perf_counter() - t_s
-        rn.tabular = False
+        variants[name] = time.perf_counter() - t_s
+        base += args.steps + 1
+    rn.tabular = default_mode
     # rollout alone (Episodes.generate, reference episode.py:175-230), outside the headline timed region
     from environment.episode import Episodes
     fence()
     t_r = time.perf_counter()
     for i in range(args.steps):
         Episodes(tree, local_batch, seed=1000 + i, lane_offset=rank * local_batch, obs_half=args.obs_half).generate(
-            rn.net, trim=False, skip_absorbed=True, store_values=False)  # as RNaD.train_step calls it
+            rn.net, trim=False, skip_absorbed=True, store_values=False,
+            tabular=bool(rn.tabular) and 8 * tree.handle().S <= T * local_batch)  # as RNaD.train_step calls it
     fence()
     rollout_s = time.perf_counter() - t_r
     if world > 1:
-        t = torch.tensor([elapsed, rollout_s, elapsed_reuse, elapsed_tab or 0.0], device=device, dtype=torch.float64)
+        names = sorted(variants)
+        t = torch.tensor([elapsed, rollout_s] + [variants[k] for k in names], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed, rollout_s, elapsed_reuse, et = t.tolist()
-        elapsed_tab = et if elapsed_tab is not None else None
+        elapsed, rollout_s, *rest = t.tolist()
+        variants = dict(zip(names, rest))
 
     if rank == 0:
         # the reference's loop (episode.py:194) runs until every lane is absorbed and counts all B lanes in each of those steps;
@@ -191,9 +191,14 @@ def main():
         # fused MLP: flops the matrix cores execute per sample (first layer, both heads; relu + second layer run on the VALU)
         K = 2 * A * A
         mlp_flops_per_sample = 2.0 * K * 2 * args.width
-        # per step: T rollout forwards of B + learner fwd (1) + target value head (.5) + 2 reg policy heads (1) of T*B samples
-        mlp_fwd_flops_per_step = mlp_flops_per_sample * local_batch * T * (1 + 1 + 0.5 + 1)
-        mlp_tflops = mlp_fwd_flops_per_step / (mlp_ms / args.steps / 1e3) / 1e12 if n_mlp else None
+        # backward per sample: recompute of the first layer + dW0 with the augmented input padded to 32-wide feature tiles
+        FT = (K + 1 + 31) // 32
+        bwd_flops_per_sample = mlp_flops_per_sample + 2.0 * 32 * FT * 2 * args.width
+        n_live = int(alive.sum()) if rn.skip_absorbed and not tree.handle().uniform_length else local_batch * T
+        bwd_tflops = bwd_flops_per_sample * n_live / (bwd_ms / max(n_bwd, 1) / 1e3) / 1e12 if n_bwd else None
+        what = {False: "every net evaluated on every (t, b) slot, as the reference does",
+                "forward": "forward evaluations once per (player, state) row and gathered per slot; backward per slot; bit-identical to dense",
+                True: "forward evaluations AND gradient sums per (player, state) row; gradients equal up to fp32 summation order"}
         out = {
             "metric": "env_steps_per_sec (rollout + R-NaD update, one iteration of learn/rnad.py:495-526 per step)",
             "value": env_steps / elapsed,
@@ -217,15 +222,12 @@ def main():
                 "parallelism": f"dp{world} (episodes sharded, RCCL all-reduce of 2 normalisers + 43 KB grads)",
             },
             "updates_per_sec": args.steps / elapsed,
-            "on_policy_shortcut": {"env_steps_per_sec": env_steps / elapsed_reuse, "updates_per_sec": args.steps / elapsed_reuse,
-                                   "ms_per_step": elapsed_reuse / args.steps * 1e3,
-                                   "what": "RNaD.reuse_actor_outputs=True: learner forward replaced by the rollout's own (bit-identical) logits/values"},
-            "tabular_nets": None if elapsed_tab is None else {
-                "env_steps_per_sec": env_steps / elapsed_tab, "updates_per_sec": args.steps / elapsed_tab,
-                "ms_per_step": elapsed_tab / args.steps * 1e3,
-                "what": f"RNaD.tabular=True (opt-in): each net evaluated on the 2S = {2 * tree.handle().S} distinct observations of the tree and "
-                        f"gathered per slot, instead of on the T*B = {T * local_batch} slots; same rollouts and losses bit for bit, weight "
-                        "gradients equal up to fp32 summation order (tests/test_hip_ragged.py)"},
+            "net_evaluation": {"mode": f"RNaD.tabular = {default_mode!r} (default)", "what": what[default_mode],
+                               "distinct_observations": 2 * tree.handle().S, "slots": T * local_batch},
+            "other_modes": {name: {"env_steps_per_sec": env_steps / sec, "updates_per_sec": args.steps / sec,
+                                   "ms_per_step": sec / args.steps * 1e3,
+                                   "what": what[{"dense_nets": False, "forward": "forward", "tabular_nets": True}[name]]}
+                            for name, sec in variants.items()},
             "rollout_env_steps_per_sec": env_steps / rollout_s,
             "rollout_ms_per_step": rollout_s / args.steps * 1e3,
             "roofline": {
@@ -236,11 +238,10 @@ def main():
             },
             "other_kernels": {
                 "k_act": {"launches": n_act, "avg_launch_us": act_ms * 1e3 / max(n_act, 1)},
-                "k_mlp_forward": {"launches": n_mlp, "total_ms_per_step": mlp_ms / args.steps, "bound": "mfma", "achieved": mlp_tflops,
-                                  "peak": 157.3, "unit": "TFLOP/s (fp32 MFMA, v_mfma_f32_32x32x2_f32)",
-                                  "frac": mlp_tflops / 157.3 if mlp_tflops else None,
-                                  "note": "dominant kernel by time; rollout actor + learner/target/reg forwards"},
-                "k_mlp_backward": {"launches": n_bwd, "total_ms_per_step": bwd_ms / args.steps},
+                "k_mlp_forward": {"launches": n_mlp, "total_ms_per_step": mlp_ms / args.steps},
+                "k_mlp_backward": {"launches": n_bwd, "total_ms_per_step": bwd_ms / args.steps, "bound": "mfma", "achieved": bwd_tflops,
+                                   "peak": 157.3, "unit": "TFLOP/s executed (fp32 MFMA, v_mfma_f32_32x32x2_f32)",
+                                   "frac": bwd_tflops / 157.3 if bwd_tflops else None, "note": "dominant kernel by time"},
                 "k_learn_fused": {"launches": n_learn, "avg_launch_us": learn_ms * 1e3 / max(n_learn, 1),
                                   "achieved_GBps": (learn_bytes / (learn_ms / 1e3 / max(n_learn, 1)) / 1e9) if learn_bytes and n_learn else None},
             },

@@ -283,6 +283,13 @@ int rnad_learn_fused_tabular(const rnad_tree_t *tree, int T, int64_t B, const in
                              const float *v_tab, const float *v_target_tab, const float *logit_reg_tab,
                              const float *logit_reg_tab_, const double *norm, const rnad_learn_params_t *hp, double *losses,
                              double *acc, float *dlogit_tab, float *dv_tab, void *stream);
+/* Same gathers, but dL/dlogit [T,B,A] and dL/dv [T,B] are written per slot (the bits of rnad_learn_fused): only the forward
+ * evaluations are deduplicated, and a per-slot rnad_mlp_backward then gives bit-identical, reproducible weight gradients. */
+int rnad_learn_fused_gather(const rnad_tree_t *tree, int T, int64_t B, const int32_t *indices, const uint8_t *mask_bits,
+                            const int32_t *actions, const float *rewards, const float *mu, const float *logit_tab,
+                            const float *v_tab, const float *v_target_tab, const float *logit_reg_tab,
+                            const float *logit_reg_tab_, const double *norm, const rnad_learn_params_t *hp, double *losses,
+                            float *dlogit, float *dv, void *stream);
 
 /* ------------------------------------------------------------------------------------------------
  * NashConv  --  util/metric.py:93-175 (NashConvData.get_nashconv), level-batched on the GPU

@@ -349,8 +349,9 @@ __global__ __launch_bounds__(kThreads) void k_learn_fused(int T, int64_t B, cons
     // same-line fp64 atomic, 62 ms per step if every slot issued its own).  Those n_hot states (whole levels, top down, as many
     // as fit the LDS) are summed per block in an LDS table -- a block is persistent and walks many lanes -- and flushed once;
     // the remaining rows are deep in the tree, hit by few lanes each, and take fp64 atomics directly (25 G/s when spread).
-    extern __shared__ double hot[];  // TAB only: [2][n_hot][A + 1]
-    if (TAB) {
+    // acc == null: the tables are only gathered from; dlogit / dv are written per slot as in the dense variant.
+    extern __shared__ double hot[];  // TAB with acc only: [2][n_hot][A + 1]
+    if (TAB && acc) {
         for (int i = threadIdx.x; i < 2 * n_hot * (A + 1); i += kThreads) hot[i] = 0.0;
         __syncthreads();
     }
@@ -409,7 +410,7 @@ __global__ __launch_bounds__(kThreads) void k_learn_fused(int T, int64_t B, cons
 #pragma unroll
                 for (int a = 0; a < A; ++a) g_l[a] = hp.w_n * (-g[a] / nfp);
             }
-            if (TAB) {
+            if (TAB && acc) {
                 if (valid) {
                     const int hs = hot_slot[state];
                     double *dst = hs >= 0 ? hot + ((int64_t)P * n_hot + hs) * (A + 1) : acc + row * (A + 1);
@@ -439,7 +440,7 @@ __global__ __launch_bounds__(kThreads) void k_learn_fused(int T, int64_t B, cons
             }
         }
     }
-    if (TAB) {
+    if (TAB && acc) {
         __syncthreads();
         for (int i = threadIdx.x; i < 2 * n_hot; i += kThreads) {
             const int64_t row = (int64_t)(i / n_hot) * S + hot_state[i % n_hot];
@@ -591,6 +592,32 @@ extern "C" int rnad_learn_fused_tabular(const rnad_tree_t *tree, int T, int64_t 
     }
     RNAD_DISPATCH_A(A, hipLaunchKernelGGL((k_tab_finish<kA>), dim3(blocks_for(2 * S)), dim3(kThreads), 0, stream, 2 * S, acc, dlogit_tab,
                                           dv_tab));
+    RNAD_HIP_OK(hipGetLastError());
+    return 0;
+}
+
+// Tables in, per-slot gradients out: the forward evaluations are deduplicated (2S rows instead of T*B slots), the backward is
+// not -- dlogit [T,B,A] and dv [T,B] are the bits rnad_learn_fused produces from per-slot net outputs, so a per-slot
+// rnad_mlp_backward gives bit-identical weight gradients.
+extern "C" int rnad_learn_fused_gather(const rnad_tree_t *tree, int T, int64_t B, const int32_t *indices, const uint8_t *mask_bits,
+                                       const int32_t *actions, const float *rewards, const float *mu, const float *logit_tab,
+                                       const float *v_tab, const float *v_target_tab, const float *logit_reg_tab,
+                                       const float *logit_reg_tab_, const double *norm, const rnad_learn_params_t *hp, double *losses,
+                                       float *dlogit, float *dv, void *stream_) {
+    RNAD_REQUIRE(tree && indices && mask_bits && actions && rewards && mu && logit_tab && v_tab && v_target_tab && logit_reg_tab &&
+                     logit_reg_tab_ && norm && hp && dlogit && dv,
+                 "rnad_learn_fused_gather: null argument");
+    RNAD_REQUIRE(T >= 0 && B >= 0, "rnad_learn_fused_gather: negative shape");
+    RNAD_REQUIRE(hp->n_disc >= 1, "rnad_learn_fused_gather: n_disc must be positive");
+    hipStream_t stream = (hipStream_t)stream_;
+    if (losses) RNAD_HIP_OK(hipMemsetAsync(losses, 0, 2 * sizeof(double), stream));
+    if (T == 0 || B == 0) return 0;
+    ProfScope prof(PROF_LEARN, stream);
+    RNAD_DISPATCH_A(tree->A, hipLaunchKernelGGL((k_learn_fused<kA, true>), dim3(blocks_for(B)), dim3(kThreads), 0, stream, T, B, indices,
+                                                mask_bits, actions, rewards, mu, logit_tab, v_tab, v_target_tab, logit_reg_tab,
+                                                logit_reg_tab_, norm, *hp, losses, dlogit, dv, (float *)nullptr, (float *)nullptr,
+                                                (float *)nullptr, tree->S, (double *)nullptr, (const int32_t *)nullptr,
+                                                (const int32_t *)nullptr, 0));
     RNAD_HIP_OK(hipGetLastError());
     return 0;
 }

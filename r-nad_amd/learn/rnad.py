@@ -122,11 +122,14 @@ class RNaD:
         # rollout that just finished, with unchanged weights, so forward_batch(net) (rnad.py:373) recomputes bit-identical
         # logits / values; when True they are taken from the rollout and only the backward runs.
         self.reuse_actor_outputs = False
-        # Tabular net evaluation (off by default): observations are a function of (state, player to move), so the nets can be
+        # Tabular net evaluation (default "forward"): observations are a function of (state, player to move), so the nets can be
         # evaluated on the 2S distinct observations of the tree instead of on every (t, b) slot -- see __learn.  Same rollouts and
         # losses bit for bit; weight gradients equal up to fp32 summation order (and, because the per-row sums use fp64 atomics,
-        # not bitwise reproducible from run to run).  Used only when 8 S <= T B.
-        self.tabular = False
+        # not bitwise reproducible from run to run).  "forward": only the forward evaluations are deduplicated, the backward
+        # stays per slot -- every result is then bit-identical to the dense path.  Used only when 8 S <= T B.
+        self.tabular = "forward"
+        # ragged trajectories: evaluate / differentiate the nets on live (t, b) slots only (see __learn); same losses and gradients
+        self.skip_absorbed = True
         self.obs_half = False  # store observations as fp16 (BASELINE.json configs[4]); arithmetic stays fp32
         self.nashconv_history = []  # (m, total_steps, nashconv)
 
@@ -343,15 +346,19 @@ class RNaD:
         # evaluated on the 2S distinct observations of the tree and every (t, b) slot gathers its row; the per-slot gradients
         # are summed per row before ONE backward pass over those 2S observations (include/rnad_hip.h, rnad_learn_fused_tabular).
         # Worth it when the tree is small next to the batch (configs[1]: 132 862 rows for 12.6 M slots).
-        table = None
-        if getattr(self, "tabular", False) and fused_mlp and log is None:
+        # RNaD.tabular = "forward": only the forward evaluations are deduplicated; dL/dlogit, dL/dv stay per slot and the backward
+        # runs on every (live) slot -- bit-identical, reproducible gradients.  True: the gradients are summed per row as well.
+        table, mode = None, getattr(self, "tabular", False)
+        if mode and fused_mlp and log is None:
             handle = self.tree.handle()
             if 8 * handle.S <= T * B:
                 table = handle.observations_table(getattr(episodes, "obs_half", False))
+        per_row_backward = table is not None and mode is True
         live = None
-        if (table is None and getattr(self, "skip_absorbed", True) and log is None and fused_mlp
+        if (not per_row_backward and getattr(self, "skip_absorbed", True) and log is None and fused_mlp
                 and not self.tree.handle().uniform_length):
             live = rnad_hip.compact_valid(episodes.indices[:T])
+        fwd_live = None if table is not None else live
         # The fused MLP is differentiated by hand (rnad_mlp_backward), so the learner's forward needs no autograd graph and its
         # gradients can be written straight into one flat bucket (the all-reduce buffer).  Any other net goes through autograd.
         direct = fused_mlp
@@ -360,25 +367,25 @@ class RNaD:
             logit, v = episodes.actor_logits.reshape(-1, A), episodes.values[:T].reshape(-1, 1)
         elif direct:
             with torch.no_grad():
-                logit, v = self._logits_of(self.net, episodes, live=live, table=table)  # rnad.py:373
+                logit, v = self._logits_of(self.net, episodes, live=fwd_live, table=table)  # rnad.py:373
         else:
-            logit, v = self._logits_of(self.net, episodes, live=live)  # rnad.py:373, with grad
+            logit, v = self._logits_of(self.net, episodes, live=fwd_live)  # rnad.py:373, with grad
         with torch.no_grad():
             # the reference runs all four full nets (:378-380); only these heads are ever read (:382-406)
-            logit_target, v_target = self._logits_of(self.net_target, episodes, want_logits=log is not None, live=live, table=table)  # :378
+            logit_target, v_target = self._logits_of(self.net_target, episodes, want_logits=log is not None, live=fwd_live, table=table)  # :378
             # log_policy_reg = log_pi - (alpha * log_pi_reg + (1 - alpha) * log_pi_reg_) (:382).  A term whose weight is exactly 0
             # adds exactly 0 (log-policies are finite), and two nets with the same weights give the same bits: in the second half
             # of every outer iteration (alpha == 1, :497) and during all of m == 0 (both reg nets are copies of the initial net,
             # :183-186) one evaluation serves both operands.
             if alpha == 0:
-                logit_reg_, _ = self._logits_of(self.net_reg_, episodes, want_value=False, live=live, table=table)  # :380
+                logit_reg_, _ = self._logits_of(self.net_reg_, episodes, want_value=False, live=fwd_live, table=table)  # :380
                 logit_reg = logit_reg_
             else:
-                logit_reg, _ = self._logits_of(self.net_reg, episodes, want_value=False, live=live, table=table)  # :379
+                logit_reg, _ = self._logits_of(self.net_reg, episodes, want_value=False, live=fwd_live, table=table)  # :379
                 if alpha == 1 or self._reg_nets_identical():
                     logit_reg_ = logit_reg
                 else:
-                    logit_reg_, _ = self._logits_of(self.net_reg_, episodes, want_value=False, live=live, table=table)  # :380
+                    logit_reg_, _ = self._logits_of(self.net_reg_, episodes, want_value=False, live=fwd_live, table=table)  # :380
 
         if norm_work is not None:
             norm_work.wait()
@@ -387,11 +394,12 @@ class RNaD:
             clip=self.neurd_clip, threshold=self.beta, w_v=self.value_weight, w_n=self.neurd_weight,
             eps_threshold=self.epsilon_threshold, n_disc=self.n_discrete)
         if table is not None:
-            dlogit, dv, losses = rnad_hip.learn_fused_tabular(
-                self.tree.handle(), episodes.indices[:T], episodes.mask_bits[:T], episodes.action_idx[:T], episodes.rewards[:T],
-                episodes.policy[:T], logit, v, v_target, logit_reg, logit_reg_, norm, hp)
+            fn = rnad_hip.learn_fused_tabular if per_row_backward else rnad_hip.learn_fused_gather
+            dlogit, dv, losses = fn(self.tree.handle(), episodes.indices[:T], episodes.mask_bits[:T], episodes.action_idx[:T],
+                                    episodes.rewards[:T], episodes.policy[:T], logit, v, v_target, logit_reg, logit_reg_, norm, hp)
             pi = None
-            backward_obs = table            # dlogit [2S, A], dv [2S, 1]: per-row sums of the per-slot gradients
+            # per-row: dlogit [2S, A], dv [2S, 1] are sums of the per-slot gradients; else they are per slot, as in the dense path
+            backward_obs = table if per_row_backward else episodes.observations[:T]
         else:
             dlogit, dv, losses, pi, _, _ = rnad_hip.learn_fused(
                 episodes.indices[:T], episodes.mask_bits[:T], episodes.action_idx[:T], episodes.rewards[:T], episodes.policy[:T],

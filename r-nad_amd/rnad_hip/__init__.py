@@ -453,6 +453,23 @@ def learn_fused_tabular(tree, indices, mask_bits, actions, rewards, mu, logit_ta
     return dlogit, dv, losses
 
 
+def learn_fused_gather(tree, indices, mask_bits, actions, rewards, mu, logit_tab, v_tab, v_target_tab, logit_reg_tab, logit_reg_tab_,
+                       norm, hp):
+    """rnad_learn_fused_gather: net outputs given per (player, state) row; returns per-slot dlogit [T,B,A], dv [T,B], losses."""
+    T, B, A = mu.shape
+    dev = mu.device
+    dlogit = torch.empty((T, B, A), dtype=F32, device=dev)
+    dv = torch.empty((T, B), dtype=F32, device=dev)
+    losses = torch.empty((2,), dtype=F64, device=dev)
+    _check(lib().rnad_learn_fused_gather(tree.ptr, T, C.c_int64(B), _dp(indices, I32, "indices"), _dp(mask_bits, U8, "mask_bits"),
+                                         _dp(actions, I32, "actions"), _dp(rewards, F32, "rewards"), _dp(mu, F32, "mu"),
+                                         _dp(logit_tab, F32, "logit_tab"), _dp(v_tab, F32, "v_tab"), _dp(v_target_tab, F32, "v_target_tab"),
+                                         _dp(logit_reg_tab, F32, "logit_reg_tab"), _dp(logit_reg_tab_, F32, "logit_reg_tab_"),
+                                         _dp(norm, F64, "norm"), C.byref(hp), _dp(losses, F64, "losses"), _dp(dlogit, F32, "dlogit"),
+                                         _dp(dv, F32, "dv"), _stream()))
+    return dlogit, dv, losses
+
+
 def make_learn_params(alpha, eta, lambda_=1.0, c=1.0, rho=1.0, gamma=1.0, clip=1e3, threshold=2.0, w_v=1.0, w_n=1.0,
                       eps_threshold=0.03, n_disc=32):
     # 1 - alpha is taken in double like the reference's python scalar (rnad.py:382), then rounded to fp32

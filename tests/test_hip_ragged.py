@@ -147,6 +147,7 @@ def test_update_that_skips_absorbed_slots_is_the_dense_update(reuse):
             for p_ in m.parameters():
                 p_.add_(0.05 * (i + 1) * torch.randn_like(p_))
     rn.reuse_actor_outputs = reuse
+    rn.tabular = False  # the per-slot forwards are what this test is about
     grads, losses = [], []
     for skip in (False, True):
         ep = Episodes(tree, B, seed=3)
@@ -177,6 +178,7 @@ def test_one_reg_net_evaluation_when_the_other_cannot_matter(monkeypatch):
     rn.initialize()
     ep = Episodes(tree, B, seed=3)
     ep.generate(rn.net, trim=False)
+    rn.tabular = False
 
     def grads(alpha):
         rn.optimizer.zero_grad()
@@ -259,17 +261,26 @@ def test_tabular_update_is_the_dense_update(ragged):
     ep = Episodes(tree, B, seed=3)
     ep.generate(rn.net, trim=False)
     assert 8 * tree.handle().S <= (ep.t_eff + 1) * B
-    out = []
-    for tabular in (False, True):
+    out = {}
+    for tabular in (False, "forward", True):
         rn.tabular = tabular
         rn.skip_absorbed = False
         rn.optimizer.zero_grad()
         rn._RNaD__learn(ep, 0.4)
-        out.append([p_.grad.detach().clone() for p_ in rn.net.parameters()])
-    for a, b in zip(*out):
+        out[tabular] = [p_.grad.detach().clone() for p_ in rn.net.parameters()]
+    for a, b in zip(out["forward"], out[False]):
+        assert torch.equal(a, b)  # deduplicated forwards, per-slot backward: the dense path's bits
+    for a, b in zip(out[True], out[False]):
         scale = float(b.abs().max()) + 1e-12
         assert torch.isfinite(a).all() and float(b.abs().max()) > 0
         np.testing.assert_allclose(a.cpu().numpy() / scale, b.cpu().numpy() / scale, rtol=0, atol=1e-5)
+    if ragged:  # forward mode + skipped absorbed slots in the backward
+        rn.tabular, rn.skip_absorbed = "forward", True
+        rn.optimizer.zero_grad()
+        rn._RNaD__learn(ep, 0.4)
+        for p_, b in zip(rn.net.parameters(), out[False]):
+            scale = float(b.abs().max()) + 1e-12
+            np.testing.assert_allclose(p_.grad.cpu().numpy() / scale, b.cpu().numpy() / scale, rtol=0, atol=1e-5)
 
 
 def test_tabular_training_steps_track_the_dense_ones():

@@ -15,7 +15,7 @@ rn.initialize()
 with torch.no_grad():
     for p in rn.net_reg_.parameters():
         p.mul_(1.001)
-rn.tabular = True
+rn.tabular = {"full": True, "forward": "forward", "off": False}[os.environ.get("TAB", "full")]
 buf = Buffer(1)
 for i in range(3):
     rn.train_step(buf, 0.1); rn.total_steps += 1
@@ -25,4 +25,4 @@ t = time.perf_counter()
 for i in range(n):
     rn.train_step(buf, 0.1); rn.total_steps += 1
 torch.cuda.synchronize()
-print(f"tabular step: {1e3 * (time.perf_counter() - t) / n:.3f} ms")
+print(f"tabular={rn.tabular} step: {1e3 * (time.perf_counter() - t) / n:.3f} ms")
