@@ -269,20 +269,23 @@ int rnad_learn_fused(int T, int64_t B, int A, const int32_t *indices, const uint
                      const double *norm, const rnad_learn_params_t *hp, double *losses, float *dlogit, float *dv,
                      float *pi_out, float *v_target_out, float *q_out, void *stream);
 
-/* Tabular variant.  The four forward_batch calls of learn/rnad.py:373-380 evaluate nets on observations that depend on
+/* Tabular variants.  The four forward_batch calls of learn/rnad.py:373-380 evaluate nets on observations that depend on
  * (state, player to move) only: 2S distinct inputs for T*B slots (132 862 vs 12.6 M on configs[1]).  Here the nets were
  * evaluated once per distinct input -- tables [2, S, (A)], row = player * S + state (rnad_observe_all + rnad_mlp_forward) --
- * and each slot gathers its row.  The weight gradient is linear in dL/dout, so the per-slot dL/dlogit, dL/dv are summed per
- * row (fp64 hardware atomics; the states of the top levels, which the whole batch passes through, first in a per-block LDS
- * table) and ONE rnad_mlp_backward over the 2S inputs with
- * dlogit_tab [2S,A], dv_tab [2S] gives the same gradients as the per-slot backward, up to fp32 summation order.
- * Per-slot net outputs are the same bits as in rnad_learn_fused (same inputs, same kernel), hence the same losses.
- * acc: scratch, f64 [2S, A + 1]. */
+ * and each slot gathers its row: per-slot net outputs are the same bits as in rnad_learn_fused (same inputs, same kernel),
+ * hence the same V-trace targets, losses and per-slot dL/dlogit, dL/dv.
+ *
+ * rnad_learn_fused_tabular additionally sums those per-slot gradients per row: the weight gradient is linear in dL/dout, so
+ * ONE rnad_mlp_backward over the 2S inputs with dlogit_tab [2S,A], dv_tab [2S] gives the gradients of the per-slot backward
+ * up to fp32 summation order.  The sums are taken in 64-bit fixed point (integer atomics: any order, same result; the states
+ * of the top levels, which the whole batch passes through, first in a per-block LDS table), so they are reproducible.
+ * workspace: rnad_learn_tabular_workspace(tree, T, B) bytes, 8-byte aligned.  B <= 2^21 per call. */
+int64_t rnad_learn_tabular_workspace(const rnad_tree_t *tree, int T, int64_t B);
 int rnad_learn_fused_tabular(const rnad_tree_t *tree, int T, int64_t B, const int32_t *indices, const uint8_t *mask_bits,
                              const int32_t *actions, const float *rewards, const float *mu, const float *logit_tab,
                              const float *v_tab, const float *v_target_tab, const float *logit_reg_tab,
                              const float *logit_reg_tab_, const double *norm, const rnad_learn_params_t *hp, double *losses,
-                             double *acc, float *dlogit_tab, float *dv_tab, void *stream);
+                             void *workspace, float *dlogit_tab, float *dv_tab, void *stream);
 /* Same gathers, but dL/dlogit [T,B,A] and dL/dv [T,B] are written per slot (the bits of rnad_learn_fused): only the forward
  * evaluations are deduplicated, and a per-slot rnad_mlp_backward then gives bit-identical, reproducible weight gradients. */
 int rnad_learn_fused_gather(const rnad_tree_t *tree, int T, int64_t B, const int32_t *indices, const uint8_t *mask_bits,

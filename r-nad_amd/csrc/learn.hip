@@ -314,23 +314,97 @@ __global__ __launch_bounds__(kThreads) void k_loss_nerd(int64_t N, const float *
     if (loss) block_atomic_add(part / (double)nf, loss);
 }
 
-// acc (fp64) -> dlogit_tab [2S,A], dv_tab [2S] (fp32)
+// ---------------------------------------------------------------------------------------- per-row gradient sums
+// dlogit_tab[row] = sum of dlogit over the slots of that row, dv_tab likewise (row = player * S + state), REPRODUCIBLY: the
+// addends are converted to 64-bit fixed point -- one scale per output column, 2^40 / 2^ceil(log2(max |g|)) with the maximum
+// taken over all slots by the gather kernel -- and integer addition is associative, so the atomics may land in any order.
+// An addend is at most 2^40 units and a row has at most 2^21 slots here (B <= 2^31 / T), so the sums stay below 2^62; the
+// rounding of an addend is at most 2^-41 of the column maximum, far below fp32 resolution of the sums.
+//
+// Rows near the root are hit by the whole batch (every lane passes through the root, a ninth of them through each of its
+// children, ...): atomics on them serialise in the memory system (measured with fp64 atomics: 7.5 ns per same-line atomic,
+// 62 ms per update if every slot issued its own).  The states of the top levels -- whole levels, top down, as many as fit
+// 96 KiB of LDS (tree->n_hot) -- are therefore summed per block in an LDS table by persistent blocks and flushed once per
+// block; the remaining rows are deep in the tree, hit by few slots each, and take global atomics directly (25 G/s spread).
+constexpr int kFixedBits = 40;
+
+__device__ __forceinline__ double fixed_scale(uint32_t max_bits) {  // 2^kFixedBits / 2^ceil(log2 max), 1 if the column is all zero
+    if (max_bits == 0) return 1.0;
+    const int e = (int)((max_bits >> 23) & 0xff) - 127 + 1;  // |g| < 2^e for every addend (denormal maxima: e = -126, still an upper bound)
+    return ldexp(1.0, kFixedBits - e);
+}
+
 template <int A>
-__global__ __launch_bounds__(kThreads) void k_tab_finish(int64_t rows, const double *__restrict__ acc, float *__restrict__ dlogit,
+__global__ __launch_bounds__(kThreads) void k_row_sums(int T, int64_t B, int64_t S, const int32_t *__restrict__ indices,
+                                                       const float *__restrict__ dlogit, const float *__restrict__ dv,
+                                                       const uint32_t *__restrict__ gmax, const int32_t *__restrict__ hot_slot,
+                                                       const int32_t *__restrict__ hot_state, int n_hot,
+                                                       unsigned long long *__restrict__ acc) {
+    extern __shared__ unsigned long long hot[];  // [2][n_hot][A + 1]
+    for (int i = threadIdx.x; i < 2 * n_hot * (A + 1); i += kThreads) hot[i] = 0ull;
+    __syncthreads();
+    double scale[A + 1];
+#pragma unroll
+    for (int a = 0; a <= A; ++a) scale[a] = fixed_scale(gmax[a]);
+    const int64_t N = (int64_t)T * B;
+    for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < N; i += (int64_t)gridDim.x * kThreads) {
+        const int state = indices[i];
+        if (state == 0) continue;  // invalid slots carry zero gradients (rnad.py:369)
+        const int P = (int)((i / B) & 1);
+        const int hs = hot_slot[state];
+        unsigned long long *dst = hs >= 0 ? hot + ((int64_t)P * n_hot + hs) * (A + 1) : acc + ((int64_t)P * S + state) * (A + 1);
+        long long q[A + 1];
+#pragma unroll
+        for (int a = 0; a < A; ++a) q[a] = __double2ll_rn((double)dlogit[i * A + a] * scale[a]);
+        q[A] = __double2ll_rn((double)dv[i] * scale[A]);
+        // a full wave on one row (the first two steps: every lane is at the root): add up in registers, one lane updates the table
+        // -- integer sums, so still order-independent
+        const bool full_wave = __ballot(1) == ~0ull;
+        if (full_wave && __all((int)(dst == (unsigned long long *)__shfl((long long)dst, 0, 64)))) {
+#pragma unroll
+            for (int a = 0; a <= A; ++a) {
+                long long v = q[a];
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+                q[a] = v;
+            }
+            if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+                for (int a = 0; a <= A; ++a) atomicAdd(dst + a, (unsigned long long)q[a]);
+            }
+            continue;
+        }
+#pragma unroll
+        for (int a = 0; a <= A; ++a) atomicAdd(dst + a, (unsigned long long)q[a]);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * n_hot; i += kThreads) {
+        const int64_t row = (int64_t)(i / n_hot) * S + hot_state[i % n_hot];
+#pragma unroll
+        for (int a = 0; a <= A; ++a) {
+            const unsigned long long x = hot[(int64_t)i * (A + 1) + a];
+            if (x != 0ull) atomicAdd(acc + row * (A + 1) + a, x);
+        }
+    }
+}
+
+// fixed point -> fp32 tables
+template <int A>
+__global__ __launch_bounds__(kThreads) void k_tab_finish(int64_t rows, const unsigned long long *__restrict__ acc,
+                                                         const uint32_t *__restrict__ gmax, float *__restrict__ dlogit,
                                                          float *__restrict__ dv) {
     const int64_t r = (int64_t)blockIdx.x * kThreads + threadIdx.x;
     if (r >= rows) return;
 #pragma unroll
-    for (int a = 0; a < A; ++a) dlogit[r * A + a] = (float)acc[r * (A + 1) + a];
-    dv[r] = (float)acc[r * (A + 1) + A];
+    for (int a = 0; a < A; ++a) dlogit[r * A + a] = (float)((double)(long long)acc[r * (A + 1) + a] / fixed_scale(gmax[a]));
+    dv[r] = (float)((double)(long long)acc[r * (A + 1) + A] / fixed_scale(gmax[A]));
 }
 
 // The fused learner pass (header comment of rnad_learn_fused).  Per (t, b): 69 B read, 16 B written (A = 3).
 // TAB = false: logit_ / v_ / vtn_ / lreg_ / lreg2_ are per-slot arrays [T,B,(A)] and dlogit / dv are written per slot.
 // TAB = true ("tabular" evaluation): the observation is a function of (state, player to move) alone, so the nets were evaluated
-// once per (player, state) -- row = player * S + state of tables [2S,(A)] -- and every slot gathers its row; the per-slot
-// gradients dL/dlogit, dL/dv are summed per row into `acc` [2S][A + 1] (fp64), from which ONE backward pass over the 2S
-// distinct observations gives the weight gradients (the gradient is linear in dL/dout).
+// once per (player, state) -- row = player * S + state of tables [2S,(A)] -- and every slot gathers its row.  dlogit / dv are
+// written per slot either way.
 template <int A, bool TAB>
 __global__ __launch_bounds__(kThreads) void k_learn_fused(int T, int64_t B, const int32_t *__restrict__ indices,
                                                           const uint8_t *__restrict__ mbits, const int32_t *__restrict__ actions,
@@ -341,20 +415,12 @@ __global__ __launch_bounds__(kThreads) void k_learn_fused(int T, int64_t B, cons
                                                           rnad_learn_params_t hp, double *__restrict__ losses,
                                                           float *__restrict__ dlogit, float *__restrict__ dv,
                                                           float *__restrict__ pi_out, float *__restrict__ vt_out,
-                                                          float *__restrict__ q_out, int64_t S, double *__restrict__ acc,
-                                                          const int32_t *__restrict__ hot_slot, const int32_t *__restrict__ hot_state,
-                                                          int n_hot) {
-    // TAB: per-row gradient sums.  Rows near the root are hit by the whole batch (every lane passes through the root, a ninth
-    // of them through each of its children, ...): atomics on them serialise in the memory system (measured: 7.5 ns per
-    // same-line fp64 atomic, 62 ms per step if every slot issued its own).  Those n_hot states (whole levels, top down, as many
-    // as fit the LDS) are summed per block in an LDS table -- a block is persistent and walks many lanes -- and flushed once;
-    // the remaining rows are deep in the tree, hit by few lanes each, and take fp64 atomics directly (25 G/s when spread).
-    // acc == null: the tables are only gathered from; dlogit / dv are written per slot as in the dense variant.
-    extern __shared__ double hot[];  // TAB with acc only: [2][n_hot][A + 1]
-    if (TAB && acc) {
-        for (int i = threadIdx.x; i < 2 * n_hot * (A + 1); i += kThreads) hot[i] = 0.0;
-        __syncthreads();
-    }
+                                                          float *__restrict__ q_out, int64_t S, uint32_t *__restrict__ gmax) {
+    // gmax (TAB, optional): [A + 1] running maxima of |dL/dlogit[:, a]|, |dL/dv| over all slots, as float bit patterns (the
+    // fixed-point scales of k_row_sums); the caller zeroes it.
+    uint32_t mx[A + 1];
+#pragma unroll
+    for (int a = 0; a <= A; ++a) mx[a] = 0u;
     double part_v = 0.0, part_n = 0.0;
     const float nf0 = norm_of(norm), nf1 = norm_of(norm + 1);
     const VtHp vh{-hp.eta, hp.lambda_, hp.c, hp.rho, hp.gamma};
@@ -410,15 +476,10 @@ __global__ __launch_bounds__(kThreads) void k_learn_fused(int T, int64_t B, cons
 #pragma unroll
                 for (int a = 0; a < A; ++a) g_l[a] = hp.w_n * (-g[a] / nfp);
             }
-            if (TAB && acc) {
-                if (valid) {
-                    const int hs = hot_slot[state];
-                    double *dst = hs >= 0 ? hot + ((int64_t)P * n_hot + hs) * (A + 1) : acc + row * (A + 1);
+            if (TAB && gmax) {
 #pragma unroll
-                    for (int a = 0; a < A; ++a) unsafeAtomicAdd(dst + a, (double)g_l[a]);  // ds_add_f64 / global_atomic_add_f64
-                    unsafeAtomicAdd(dst + A, (double)g_v);
-                }
-                continue;  // the per-slot outputs below belong to the dense variant
+                for (int a = 0; a < A; ++a) mx[a] = max(mx[a], __float_as_uint(fabsf(g_l[a])));
+                mx[A] = max(mx[A], __float_as_uint(fabsf(g_v)));
             }
             dv[i] = g_v;
 #pragma unroll
@@ -440,15 +501,14 @@ __global__ __launch_bounds__(kThreads) void k_learn_fused(int T, int64_t B, cons
             }
         }
     }
-    if (TAB && acc) {
-        __syncthreads();
-        for (int i = threadIdx.x; i < 2 * n_hot; i += kThreads) {
-            const int64_t row = (int64_t)(i / n_hot) * S + hot_state[i % n_hot];
+    if (TAB && gmax) {
 #pragma unroll
-            for (int a = 0; a <= A; ++a) {
-                const double x = hot[(int64_t)i * (A + 1) + a];
-                if (x != 0.0) unsafeAtomicAdd(acc + row * (A + 1) + a, x);
-            }
+        for (int a = 0; a <= A; ++a) {
+            uint32_t m = mx[a];
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, off, 64));
+            // one lane per wave, and only if it would raise the maximum (16 K same-line atomics cost 0.5 ms otherwise)
+            if ((threadIdx.x & 63) == 0 && m > __atomic_load_n(gmax + a, __ATOMIC_RELAXED)) atomicMax(gmax + a, m);
         }
     }
     if (losses) {
@@ -549,49 +609,29 @@ extern "C" int rnad_learn_fused(int T, int64_t B, int A, const int32_t *indices,
     ProfScope prof(PROF_LEARN, stream);
     RNAD_DISPATCH_A(A, hipLaunchKernelGGL((k_learn_fused<kA, false>), dim3(blocks_for(B)), dim3(kThreads), 0, stream, T, B, indices,
                                           mask_bits, actions, rewards, mu, logit, v, v_target_net, logit_reg, logit_reg_, norm, *hp, losses,
-                                          dlogit, dv, pi_out, v_target_out, q_out, (int64_t)0, (double *)nullptr,
-                                          (const int32_t *)nullptr, (const int32_t *)nullptr, 0));
+                                          dlogit, dv, pi_out, v_target_out, q_out, (int64_t)0, (uint32_t *)nullptr));
     RNAD_HIP_OK(hipGetLastError());
     return 0;
 }
 
-extern "C" int rnad_learn_fused_tabular(const rnad_tree_t *tree, int T, int64_t B, const int32_t *indices, const uint8_t *mask_bits,
-                                        const int32_t *actions, const float *rewards, const float *mu, const float *logit_tab,
-                                        const float *v_tab, const float *v_target_tab, const float *logit_reg_tab,
-                                        const float *logit_reg_tab_, const double *norm, const rnad_learn_params_t *hp, double *losses,
-                                        double *acc, float *dlogit_tab, float *dv_tab, void *stream_) {
+static int learn_fused_gather_impl(const rnad_tree_t *tree, int T, int64_t B, const int32_t *indices, const uint8_t *mask_bits,
+                                   const int32_t *actions, const float *rewards, const float *mu, const float *logit_tab,
+                                   const float *v_tab, const float *v_target_tab, const float *logit_reg_tab, const float *logit_reg_tab_,
+                                   const double *norm, const rnad_learn_params_t *hp, double *losses, float *dlogit, float *dv,
+                                   uint32_t *gmax, hipStream_t stream) {
     RNAD_REQUIRE(tree && indices && mask_bits && actions && rewards && mu && logit_tab && v_tab && v_target_tab && logit_reg_tab &&
-                     logit_reg_tab_ && norm && hp && acc && dlogit_tab && dv_tab,
-                 "rnad_learn_fused_tabular: null argument");
-    RNAD_REQUIRE(T >= 0 && B >= 0, "rnad_learn_fused_tabular: negative shape");
-    RNAD_REQUIRE(hp->n_disc >= 1, "rnad_learn_fused_tabular: n_disc must be positive");
-    hipStream_t stream = (hipStream_t)stream_;
-    const int A = tree->A;
-    const int64_t S = tree->S;
+                     logit_reg_tab_ && norm && hp && dlogit && dv,
+                 "rnad_learn_fused_gather: null argument");
+    RNAD_REQUIRE(T >= 0 && B >= 0, "rnad_learn_fused_gather: negative shape");
+    RNAD_REQUIRE(hp->n_disc >= 1, "rnad_learn_fused_gather: n_disc must be positive");
     if (losses) RNAD_HIP_OK(hipMemsetAsync(losses, 0, 2 * sizeof(double), stream));
-    RNAD_HIP_OK(hipMemsetAsync(acc, 0, sizeof(double) * 2 * S * (A + 1), stream));
+    if (gmax) RNAD_HIP_OK(hipMemsetAsync(gmax, 0, sizeof(uint32_t) * (tree->A + 1), stream));
+    if (T == 0 || B == 0) return 0;
     ProfScope prof(PROF_LEARN, stream);
-    if (T > 0 && B > 0) {
-        // persistent blocks: the LDS table of hot rows is flushed once per block, so few blocks walking many lanes each
-        int cus = 256;
-        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, tree->device);
-        const size_t lds = (size_t)2 * tree->n_hot * (A + 1) * sizeof(double);
-        const int per_cu = std::max(1, std::min(8, (int)((160 * 1024) / std::max<size_t>(lds, 1))));
-        const unsigned grid = (unsigned)std::min<int64_t>(blocks_for(B), (int64_t)cus * per_cu);
-#define RNAD_TAB_LAUNCH()                                                                                                         \
-    do {                                                                                                                           \
-        auto kern = k_learn_fused<kA, true>;                                                                                       \
-        if (lds > 64 * 1024) RNAD_HIP_OK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(kThreads), lds, stream, T, B, indices, mask_bits, actions, rewards, mu, logit_tab, \
-                           v_tab, v_target_tab, logit_reg_tab, logit_reg_tab_, norm, *hp, losses, (float *)nullptr, (float *)nullptr, \
-                           (float *)nullptr, (float *)nullptr, (float *)nullptr, S, acc, (const int32_t *)tree->hot_slot,           \
-                           (const int32_t *)tree->level_order, tree->n_hot);                                                       \
-    } while (0)
-        RNAD_DISPATCH_A(A, RNAD_TAB_LAUNCH());
-#undef RNAD_TAB_LAUNCH
-    }
-    RNAD_DISPATCH_A(A, hipLaunchKernelGGL((k_tab_finish<kA>), dim3(blocks_for(2 * S)), dim3(kThreads), 0, stream, 2 * S, acc, dlogit_tab,
-                                          dv_tab));
+    RNAD_DISPATCH_A(tree->A, hipLaunchKernelGGL((k_learn_fused<kA, true>), dim3(blocks_for(B)), dim3(kThreads), 0, stream, T, B, indices,
+                                                mask_bits, actions, rewards, mu, logit_tab, v_tab, v_target_tab, logit_reg_tab,
+                                                logit_reg_tab_, norm, *hp, losses, dlogit, dv, (float *)nullptr, (float *)nullptr,
+                                                (float *)nullptr, tree->S, gmax));
     RNAD_HIP_OK(hipGetLastError());
     return 0;
 }
@@ -603,21 +643,58 @@ extern "C" int rnad_learn_fused_gather(const rnad_tree_t *tree, int T, int64_t B
                                        const int32_t *actions, const float *rewards, const float *mu, const float *logit_tab,
                                        const float *v_tab, const float *v_target_tab, const float *logit_reg_tab,
                                        const float *logit_reg_tab_, const double *norm, const rnad_learn_params_t *hp, double *losses,
-                                       float *dlogit, float *dv, void *stream_) {
-    RNAD_REQUIRE(tree && indices && mask_bits && actions && rewards && mu && logit_tab && v_tab && v_target_tab && logit_reg_tab &&
-                     logit_reg_tab_ && norm && hp && dlogit && dv,
-                 "rnad_learn_fused_gather: null argument");
-    RNAD_REQUIRE(T >= 0 && B >= 0, "rnad_learn_fused_gather: negative shape");
-    RNAD_REQUIRE(hp->n_disc >= 1, "rnad_learn_fused_gather: n_disc must be positive");
+                                       float *dlogit, float *dv, void *stream) {
+    return learn_fused_gather_impl(tree, T, B, indices, mask_bits, actions, rewards, mu, logit_tab, v_tab, v_target_tab, logit_reg_tab,
+                                   logit_reg_tab_, norm, hp, losses, dlogit, dv, nullptr, (hipStream_t)stream);
+}
+
+// ... and the per-row sums of those per-slot gradients (k_row_sums), for ONE backward over the 2S distinct observations.
+// workspace: rnad_learn_tabular_workspace(tree, T, B) bytes = per-slot dlogit / dv + the fixed-point table + the column maxima.
+extern "C" int64_t rnad_learn_tabular_workspace(const rnad_tree_t *tree, int T, int64_t B) {
+    if (!tree || T < 0 || B < 0) return -1;
+    const int64_t A = tree->A, N = (int64_t)T * B;
+    return N * (A + 1) * 4 + 2 * tree->S * (A + 1) * 8 + 64;
+}
+
+extern "C" int rnad_learn_fused_tabular(const rnad_tree_t *tree, int T, int64_t B, const int32_t *indices, const uint8_t *mask_bits,
+                                        const int32_t *actions, const float *rewards, const float *mu, const float *logit_tab,
+                                        const float *v_tab, const float *v_target_tab, const float *logit_reg_tab,
+                                        const float *logit_reg_tab_, const double *norm, const rnad_learn_params_t *hp, double *losses,
+                                        void *workspace, float *dlogit_tab, float *dv_tab, void *stream_) {
+    RNAD_REQUIRE(tree && workspace && dlogit_tab && dv_tab, "rnad_learn_fused_tabular: null argument");
+    RNAD_REQUIRE(T >= 0 && B >= 0 && (int64_t)T * B < ((int64_t)1 << 40), "rnad_learn_fused_tabular: bad shape");
+    RNAD_REQUIRE(B <= ((int64_t)1 << 21), "rnad_learn_fused_tabular: more than 2^21 lanes per call overflow the fixed-point row sums");
     hipStream_t stream = (hipStream_t)stream_;
-    if (losses) RNAD_HIP_OK(hipMemsetAsync(losses, 0, 2 * sizeof(double), stream));
-    if (T == 0 || B == 0) return 0;
-    ProfScope prof(PROF_LEARN, stream);
-    RNAD_DISPATCH_A(tree->A, hipLaunchKernelGGL((k_learn_fused<kA, true>), dim3(blocks_for(B)), dim3(kThreads), 0, stream, T, B, indices,
-                                                mask_bits, actions, rewards, mu, logit_tab, v_tab, v_target_tab, logit_reg_tab,
-                                                logit_reg_tab_, norm, *hp, losses, dlogit, dv, (float *)nullptr, (float *)nullptr,
-                                                (float *)nullptr, tree->S, (double *)nullptr, (const int32_t *)nullptr,
-                                                (const int32_t *)nullptr, 0));
+    const int A = tree->A;
+    const int64_t S = tree->S, N = (int64_t)T * B;
+    char *ws = (char *)workspace;
+    unsigned long long *acc = (unsigned long long *)ws;                       // [2S][A + 1], 8-byte aligned at the front
+    uint32_t *gmax = (uint32_t *)(ws + 2 * S * (A + 1) * 8);                  // [A + 1]
+    float *dlogit = (float *)(ws + 2 * S * (A + 1) * 8 + 64);                 // [T,B,A]
+    float *dv = dlogit + N * A;                                               // [T,B]
+    if (int rc = learn_fused_gather_impl(tree, T, B, indices, mask_bits, actions, rewards, mu, logit_tab, v_tab, v_target_tab,
+                                         logit_reg_tab, logit_reg_tab_, norm, hp, losses, dlogit, dv, gmax, stream))
+        return rc;
+    RNAD_HIP_OK(hipMemsetAsync(acc, 0, sizeof(unsigned long long) * 2 * S * (A + 1), stream));
+    if (N > 0) {
+        // persistent blocks: the LDS table of hot rows is flushed once per block, so few blocks walking many slots each
+        int cus = 256;
+        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, tree->device);
+        const size_t lds = (size_t)2 * tree->n_hot * (A + 1) * sizeof(unsigned long long);
+        const int per_cu = std::max(1, std::min(8, (int)((160 * 1024) / std::max<size_t>(lds, 1))));
+        const unsigned grid = (unsigned)std::min<int64_t>(blocks_for(N), (int64_t)cus * per_cu);
+#define RNAD_ROWSUM_LAUNCH()                                                                                                       \
+    do {                                                                                                                           \
+        auto kern = k_row_sums<kA>;                                                                                                \
+        if (lds > 64 * 1024) RNAD_HIP_OK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(kThreads), lds, stream, T, B, S, indices, (const float *)dlogit, (const float *)dv,    \
+                           (const uint32_t *)gmax, (const int32_t *)tree->hot_slot, (const int32_t *)tree->level_order, tree->n_hot, acc); \
+    } while (0)
+        RNAD_DISPATCH_A(A, RNAD_ROWSUM_LAUNCH());
+#undef RNAD_ROWSUM_LAUNCH
+    }
+    RNAD_DISPATCH_A(A, hipLaunchKernelGGL((k_tab_finish<kA>), dim3(blocks_for(2 * S)), dim3(kThreads), 0, stream, 2 * S,
+                                          (const unsigned long long *)acc, (const uint32_t *)gmax, dlogit_tab, dv_tab));
     RNAD_HIP_OK(hipGetLastError());
     return 0;
 }

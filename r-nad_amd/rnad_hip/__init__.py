@@ -61,6 +61,7 @@ def lib():
         _lib.rnad_mlp_backward_workspace.restype = C.c_int64
         _lib.rnad_mlp_packed_size.restype = C.c_int64
         _lib.rnad_compact_workspace.restype = C.c_int64
+        _lib.rnad_learn_tabular_workspace.restype = C.c_int64
     return _lib
 
 
@@ -440,7 +441,7 @@ def learn_fused_tabular(tree, indices, mask_bits, actions, rewards, mu, logit_ta
     T, B, A = mu.shape
     dev = mu.device
     S = tree.S
-    acc = torch.empty((2 * S, A + 1), dtype=F64, device=dev)
+    ws = torch.empty((int(lib().rnad_learn_tabular_workspace(tree.ptr, T, C.c_int64(B))) // 8 + 1,), dtype=F64, device=dev)
     dlogit = torch.empty((2 * S, A), dtype=F32, device=dev)
     dv = torch.empty((2 * S, 1), dtype=F32, device=dev)
     losses = torch.empty((2,), dtype=F64, device=dev)
@@ -448,7 +449,7 @@ def learn_fused_tabular(tree, indices, mask_bits, actions, rewards, mu, logit_ta
                                           _dp(actions, I32, "actions"), _dp(rewards, F32, "rewards"), _dp(mu, F32, "mu"),
                                           _dp(logit_tab, F32, "logit_tab"), _dp(v_tab, F32, "v_tab"), _dp(v_target_tab, F32, "v_target_tab"),
                                           _dp(logit_reg_tab, F32, "logit_reg_tab"), _dp(logit_reg_tab_, F32, "logit_reg_tab_"),
-                                          _dp(norm, F64, "norm"), C.byref(hp), _dp(losses, F64, "losses"), _dp(acc, F64, "acc"),
+                                          _dp(norm, F64, "norm"), C.byref(hp), _dp(losses, F64, "losses"), _dp(ws, F64, "workspace"),
                                           _dp(dlogit, F32, "dlogit_tab"), _dp(dv, F32, "dv_tab"), _stream()))
     return dlogit, dv, losses
 

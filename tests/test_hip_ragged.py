@@ -274,6 +274,10 @@ def test_tabular_update_is_the_dense_update(ragged):
         scale = float(b.abs().max()) + 1e-12
         assert torch.isfinite(a).all() and float(b.abs().max()) > 0
         np.testing.assert_allclose(a.cpu().numpy() / scale, b.cpu().numpy() / scale, rtol=0, atol=1e-5)
+    rn.tabular = True  # fixed-point row sums: integer atomics, so a second run gives the same bits
+    rn.optimizer.zero_grad()
+    rn._RNaD__learn(ep, 0.4)
+    assert all(torch.equal(p_.grad, b) for p_, b in zip(rn.net.parameters(), out[True]))
     if ragged:  # forward mode + skipped absorbed slots in the backward
         rn.tabular, rn.skip_absorbed = "forward", True
         rn.optimizer.zero_grad()
