@@ -32,23 +32,31 @@ __global__ __launch_bounds__(64 * WAVES) void k_mlp_backward(int64_t N, int W, c
     const int W2 = 2 * W;
     const float *w1v = lds + img_w1v(K, W);
     const float *w1p = lds + img_w1p(K, W);
-    float *scratch = lds + img_floats(K, W, A);  // after the image: [waves][32][33]
+    float *scratch = lds + img_floats(K, W, A);  // after the image: [waves][2][32][33]
     load_image<nthreads>(packed, lds, img_floats(K, W, A) / 4);
     __syncthreads();
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int col = lane & 31, half = lane >> 5;
-    float *tr = scratch + wave * (kTile * 33);
+    float *tr_v = scratch + wave * (2 * kTile * 33), *tr_p = tr_v + kTile * 33;  // dz of the two heads, [hidden][sample], stride 33
     // blockIdx.y selects a group of (blockDim.x / 64) hidden tiles; this wave owns one of them, in both heads
     const int own = blockIdx.y * WAVES + wave;
     const int tile_v = own, tile_p = W / kTile + own;
 
-    f32x16 gW0v[FT], gW0p[FT];
+    // dW0aug[hidden 32][K + 1 features] of this wave's tile, per head: 16-wide feature tiles on v_mfma_f32_16x16x4_f32 (M = 16
+    // hidden rows, N = 16 features, K = 4 samples per instruction) and, when at most 4 features are left over, those on
+    // v_mfma_f32_4x4x1_16b_f32 (16 blocks of 4 hidden rows x 4 features, one sample per instruction, both heads at once).  A
+    // 32-wide tile (v_mfma_f32_32x32x2_f32) would spend 32/19 of the matrix time on the 19 features of A = 3.
+    constexpr int REM = (K + 1) % 16, N16 = (K + 1) / 16 + (REM > 4 ? 1 : 0), LO = REM > 4 ? 0 : REM;
+    constexpr int N16R = N16 > 0 ? N16 : 1;  // array extent
+    f32x4 gW0v[2][N16R], gW0p[2][N16R], gW0lo[4];  // four left-over accumulators, one per sample % 4
 #pragma unroll
-    for (int ft = 0; ft < FT; ++ft) {
-        gW0v[ft] = f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-        gW0p[ft] = gW0v[ft];
-    }
+    for (int c = 0; c < 4; ++c) gW0lo[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < N16R; ++nt) gW0v[mt][nt] = gW0p[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int m16 = lane & 15, q4 = lane >> 4;
     f32x2 gW1v[8], gW1p[A][8];  // second-layer weight-gradient partials of this lane's 16 hidden rows, as register pairs
     float gb1v = 0.0f, gb1p[A];
 #pragma unroll
@@ -64,7 +72,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_mlp_backward(int64_t N, int W, c
     // are fetched once with coalesced loads, one tile ahead, and handed over through a double-buffered LDS stage (one barrier
     // per tile).  Per-wave global loads of the same tile cost 13 % of the kernel (measured).
     constexpr int XN = kTile * K, STG = XN + kTile + kTile * A;  // floats per stage: x | dv | dlogits
-    float *stage = scratch + WAVES * (kTile * 33);               // [2][STG]
+    float *stage = scratch + WAVES * (2 * kTile * 33);           // [2][STG]
     const int64_t n_tiles = (N + kTile - 1) / kTile;
     // TPS threads share one sample of the tile: thread (smp, part) loads elements part, part + TPS, ... of that sample's row.
     // One row id per thread and tile, itself prefetched a further tile ahead (row-list launches: a lookup that the x loads
@@ -119,13 +127,6 @@ __global__ __launch_bounds__(64 * WAVES) void k_mlp_backward(int64_t N, int W, c
         float xk[KS];   // B operand of the forward product: x[sample = col][2 ks + half]
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) xk[ks] = xs[col * K + 2 * ks + half];
-        float xt[FT][16];   // B operand of the weight-gradient product: xaug[sample = 2 ks + half][feature = 32 ft + col]
-#pragma unroll
-        for (int ft = 0; ft < FT; ++ft) {
-            const int f = ft * kTile + col;
-#pragma unroll
-            for (int ks = 0; ks < 16; ++ks) xt[ft][ks] = f < K ? xs[(2 * ks + half) * K + f] : (f == K ? 1.0f : 0.0f);
-        }
         const float dvs = xs[XN + col];  // zero for samples past N, so padded lanes contribute nothing
         float dl[A];
 #pragma unroll
@@ -148,19 +149,11 @@ __global__ __launch_bounds__(64 * WAVES) void k_mlp_backward(int64_t N, int W, c
                     const float z0 = c[4 * g + 2 * j], z1 = c[4 * g + 2 * j + 1];
                     gW1v[2 * g + j] = __builtin_elementwise_fma(dv2, relu2(z0, z1), gW1v[2 * g + j]);
                     const f32x2 dz = wq[j] * dv2;  // dL/dz where the unit is active
-                    float *t = tr + (2 * j + 8 * g + 4 * half) * 33 + col;  // stored [hidden][sample]
+                    float *t = tr_v + (2 * j + 8 * g + 4 * half) * 33 + col;  // stored [hidden][sample]
                     t[0] = z0 > 0.0f ? dz.x : 0.0f;
                     t[33] = z1 > 0.0f ? dz.y : 0.0f;
                 }
             }
-            __builtin_amdgcn_wave_barrier();
-#pragma unroll
-            for (int ks = 0; ks < 16; ++ks) {
-                const float at = tr[col * 33 + 2 * ks + half];
-#pragma unroll
-                for (int ft = 0; ft < FT; ++ft) gW0v[ft] = __builtin_amdgcn_mfma_f32_32x32x2f32(at, xt[ft][ks], gW0v[ft], 0, 0, 0);
-            }
-            __builtin_amdgcn_wave_barrier();
         }
         // ---------------- policy head, hidden tile `tile_p`
         {
@@ -184,20 +177,55 @@ __global__ __launch_bounds__(64 * WAVES) void k_mlp_backward(int64_t N, int W, c
                     const f32x2 h = relu2(z0, z1);
 #pragma unroll
                     for (int a = 0; a < A; ++a) gW1p[a][2 * g + j] = __builtin_elementwise_fma(dl2[a], h, gW1p[a][2 * g + j]);
-                    float *t = tr + (2 * j + 8 * g + 4 * half) * 33 + col;
+                    float *t = tr_p + (2 * j + 8 * g + 4 * half) * 33 + col;
                     t[0] = z0 > 0.0f ? dh[j].x : 0.0f;
                     t[33] = z1 > 0.0f ? dh[j].y : 0.0f;
                 }
             }
-            __builtin_amdgcn_wave_barrier();
-#pragma unroll
-            for (int ks = 0; ks < 16; ++ks) {
-                const float at = tr[col * 33 + 2 * ks + half];
-#pragma unroll
-                for (int ft = 0; ft < FT; ++ft) gW0p[ft] = __builtin_amdgcn_mfma_f32_32x32x2f32(at, xt[ft][ks], gW0p[ft], 0, 0, 0);
-            }
-            __builtin_amdgcn_wave_barrier();
         }
+        // ---------------- dW0aug += dz^T xaug for both heads (samples are the contraction dimension)
+        __builtin_amdgcn_wave_barrier();
+        if (N16 > 0) {
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) {  // samples 4 ks .. 4 ks + 3; this lane supplies sample 4 ks + q4
+                float bx[N16R];
+#pragma unroll
+                for (int nt = 0; nt < N16; ++nt) {
+                    const int f = nt * 16 + m16;
+                    bx[nt] = f < K ? xs[(4 * ks + q4) * K + f] : (f == K ? 1.0f : 0.0f);
+                }
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) {
+                    const float av = tr_v[(mt * 16 + m16) * 33 + 4 * ks + q4], ap = tr_p[(mt * 16 + m16) * 33 + 4 * ks + q4];
+#pragma unroll
+                    for (int nt = 0; nt < N16; ++nt) {
+                        gW0v[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bx[nt], gW0v[mt][nt], 0, 0, 0);
+                        gW0p[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ap, bx[nt], gW0p[mt][nt], 0, 0, 0);
+                    }
+                }
+            }
+        }
+        if (LO > 0) {
+            // block b = lane / 4 holds hidden rows 4 b .. 4 b + 3 of the value tile (b < 8) or the policy tile; column lane % 4 is
+            // feature 16 N16 + lane % 4
+            const float *a_src = lane < 32 ? tr_v + lane * 33 : tr_p + (lane - 32) * 33;
+            const int f = N16 * 16 + (lane & 3);
+            const float *b_src = xs + (f < K ? f : 0);
+            const float b_const = f == K ? 1.0f : 0.0f;
+#pragma unroll
+            for (int s0 = 0; s0 < kTile; s0 += 8) {  // eight samples' operands are requested before the first is used
+                float av[8], bv[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    av[u] = a_src[s0 + u];
+                    bv[u] = b_src[(s0 + u) * K];
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    gW0lo[u & 3] = __builtin_amdgcn_mfma_f32_4x4x1f32(av[u], f < K ? bv[u] : b_const, gW0lo[u & 3], 0, 0, 0);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
         if (more) park(stage + (cur ^ 1) * STG);  // nobody reads that stage any more: every wave passed the last barrier
         __syncthreads();
         cur ^= 1;
@@ -208,13 +236,24 @@ __global__ __launch_bounds__(64 * WAVES) void k_mlp_backward(int64_t N, int W, c
     constexpr int FW = FT * kTile;
     float *out = partial + (int64_t)blockIdx.x * P;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+    for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-        for (int ft = 0; ft < FT; ++ft) {
-            out[(tile_v * kTile + row) * FW + ft * kTile + col] = gW0v[ft][r];
-            out[(tile_p * kTile + row) * FW + ft * kTile + col] = gW0p[ft][r];
+        for (int nt = 0; nt < N16; ++nt) {
+            const int f = nt * 16 + m16;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = mt * 16 + 4 * q4 + i;
+                if (f <= K) {
+                    out[(tile_v * kTile + row) * FW + f] = gW0v[mt][nt][i];
+                    out[(tile_p * kTile + row) * FW + f] = gW0p[mt][nt][i];
+                }
+            }
         }
+    if (LO > 0 && (lane & 3) < LO) {
+        const int b = lane >> 2, f = N16 * 16 + (lane & 3);
+        const int tile = b < 8 ? tile_v : tile_p;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) out[(tile * kTile + 4 * (b & 7) + i) * FW + f] = (gW0lo[0][i] + gW0lo[1][i]) + (gW0lo[2][i] + gW0lo[3][i]);
     }
     float *o1 = out + W2 * FW;
 #pragma unroll
@@ -302,7 +341,7 @@ static bool mlp_backward_plan(int64_t N, int W, int A, BwdPlan *p) {
     while (waves > 1 && T % waves) waves >>= 1;
     p->waves = waves;
     p->groups = T / waves;
-    p->lds_bytes = ((size_t)mlp_packed_floats(A, W) + (size_t)waves * kTile * 33 + 2 * (size_t)kTile * (K + 1 + A)) * sizeof(float);
+    p->lds_bytes = ((size_t)mlp_packed_floats(A, W) + (size_t)waves * 2 * kTile * 33 + 2 * (size_t)kTile * (K + 1 + A)) * sizeof(float);
     p->total = 2 * W * FT * kTile + W + A * W + 1 + A;
     p->P = (p->total + 3) & ~3;
     if (p->lds_bytes > 160 * 1024) return false;

@@ -35,6 +35,7 @@ __host__ __device__ constexpr int img_b1(int K, int W, int A) { return img_w1p(K
 __host__ __device__ constexpr int img_floats(int K, int W, int A) { return img_b1(K, W, A) + kB1Pad; }
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // Weight image -> LDS, 16 bytes per lane and request.  Eight requests are in flight per lane before the first LDS write: a
 // plain copy loop waits for every global load in turn (an L2 round trip per 4 KiB), which is most of a rollout-step launch
