@@ -7,6 +7,13 @@ using namespace rnad_mlp;
 
 namespace {
 
+// floats per sample row of the backward's LDS stage: the augmented input (x | 1) padded with zeros to whole MFMA feature tiles
+// (16-wide tiles, plus one 4-wide tile when at most 4 features are left over), made odd
+__host__ __device__ constexpr int bwd_stage_stride(int K) {
+    const int rem = (K + 1) % 16, n16 = (K + 1) / 16 + (rem > 4 ? 1 : 0), lo = rem > 4 ? 0 : rem;
+    return (n16 * 16 + (lo > 0 ? 4 : 0)) | 1;
+}
+
 // ------------------------------------------------------------------------------------------------ backward
 // Gradients of the 8 Linear tensors given dL/dlogits [N, A] and dL/dvalue [N] -- what autograd computes for
 // nn/net.py:40-43 -- in ONE pass over the samples with the hidden layer recomputed on chip:
@@ -71,7 +78,10 @@ __global__ __launch_bounds__(64 * WAVES) void k_mlp_backward(int64_t N, int W, c
     // The 32 samples of a tile (x, dL/dvalue, dL/dlogits: 32 (K + 1 + A) floats) are shared by every wave of the block: they
     // are fetched once with coalesced loads, one tile ahead, and handed over through a double-buffered LDS stage (one barrier
     // per tile).  Per-wave global loads of the same tile cost 13 % of the kernel (measured).
-    constexpr int XN = kTile * K, STG = XN + kTile + kTile * A;  // floats per stage: x | dv | dlogits
+    // stage row = xaug padded to the MFMA feature tiles: x[0..K) | 1 | 0 ..., so the dW0 operands are plain loads; the stride
+    // is made odd (no LDS bank conflicts between the 32 rows)
+    constexpr int XS = bwd_stage_stride(K);
+    constexpr int XN = kTile * XS, STG = XN + kTile + kTile * A;  // floats per stage: xaug | dv | dlogits
     float *stage = scratch + WAVES * (2 * kTile * 33);           // [2][STG]
     const int64_t n_tiles = (N + kTile - 1) / kTile;
     // TPS threads share one sample of the tile: thread (smp, part) loads elements part, part + TPS, ... of that sample's row.
@@ -103,7 +113,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_mlp_backward(int64_t N, int W, c
 #pragma unroll
         for (int u = 0; u < XU; ++u) {
             const int k = part + u * TPS;
-            if (k < K) dst[smp * K + k] = pre_x[u];
+            if (k < K) dst[smp * XS + k] = pre_x[u];
         }
         if (part == 0) dst[XN + smp] = pre_dv;
 #pragma unroll
@@ -112,6 +122,11 @@ __global__ __launch_bounds__(64 * WAVES) void k_mlp_backward(int64_t N, int W, c
             if (a < A) dst[XN + kTile + smp * A + a] = pre_dl[u];
         }
     };
+    for (int i = threadIdx.x; i < 2 * kTile * (XS - K); i += nthreads) {  // the constant columns of both stages, written once
+        const int buf = i / (kTile * (XS - K)), r = i % (kTile * (XS - K));
+        const int smp_ = r / (XS - K), f = K + r % (XS - K);
+        stage[buf * STG + smp_ * XS + f] = f == K ? 1.0f : 0.0f;
+    }
     int cur = 0;
     if ((int64_t)blockIdx.x < n_tiles) {
         fetch(row_of(blockIdx.x));
@@ -126,7 +141,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_mlp_backward(int64_t N, int W, c
         const float *xs = stage + cur * STG;
         float xk[KS];   // B operand of the forward product: x[sample = col][2 ks + half]
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) xk[ks] = xs[col * K + 2 * ks + half];
+        for (int ks = 0; ks < KS; ++ks) xk[ks] = xs[col * XS + 2 * ks + half];
         const float dvs = xs[XN + col];  // zero for samples past N, so padded lanes contribute nothing
         float dl[A];
 #pragma unroll
@@ -191,8 +206,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_mlp_backward(int64_t N, int W, c
                 float bx[N16R];
 #pragma unroll
                 for (int nt = 0; nt < N16; ++nt) {
-                    const int f = nt * 16 + m16;
-                    bx[nt] = f < K ? xs[(4 * ks + q4) * K + f] : (f == K ? 1.0f : 0.0f);
+                    bx[nt] = xs[(4 * ks + q4) * XS + nt * 16 + m16];
                 }
 #pragma unroll
                 for (int mt = 0; mt < 2; ++mt) {
@@ -209,20 +223,18 @@ __global__ __launch_bounds__(64 * WAVES) void k_mlp_backward(int64_t N, int W, c
             // block b = lane / 4 holds hidden rows 4 b .. 4 b + 3 of the value tile (b < 8) or the policy tile; column lane % 4 is
             // feature 16 N16 + lane % 4
             const float *a_src = lane < 32 ? tr_v + lane * 33 : tr_p + (lane - 32) * 33;
-            const int f = N16 * 16 + (lane & 3);
-            const float *b_src = xs + (f < K ? f : 0);
-            const float b_const = f == K ? 1.0f : 0.0f;
+            const float *b_src = xs + N16 * 16 + (lane & 3);
 #pragma unroll
             for (int s0 = 0; s0 < kTile; s0 += 8) {  // eight samples' operands are requested before the first is used
                 float av[8], bv[8];
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
                     av[u] = a_src[s0 + u];
-                    bv[u] = b_src[(s0 + u) * K];
+                    bv[u] = b_src[(s0 + u) * XS];
                 }
 #pragma unroll
                 for (int u = 0; u < 8; ++u)
-                    gW0lo[u & 3] = __builtin_amdgcn_mfma_f32_4x4x1f32(av[u], f < K ? bv[u] : b_const, gW0lo[u & 3], 0, 0, 0);
+                    gW0lo[u & 3] = __builtin_amdgcn_mfma_f32_4x4x1f32(av[u], bv[u], gW0lo[u & 3], 0, 0, 0);
             }
         }
         __builtin_amdgcn_wave_barrier();
@@ -341,7 +353,7 @@ static bool mlp_backward_plan(int64_t N, int W, int A, BwdPlan *p) {
     while (waves > 1 && T % waves) waves >>= 1;
     p->waves = waves;
     p->groups = T / waves;
-    p->lds_bytes = ((size_t)mlp_packed_floats(A, W) + (size_t)waves * 2 * kTile * 33 + 2 * (size_t)kTile * (K + 1 + A)) * sizeof(float);
+    p->lds_bytes = ((size_t)mlp_packed_floats(A, W) + (size_t)waves * 2 * kTile * 33 + 2 * (size_t)kTile * (bwd_stage_stride(K) + 1 + A)) * sizeof(float);
     p->total = 2 * W * FT * kTile + W + A * W + 1 + A;
     p->P = (p->total + 3) & ~3;
     if (p->lds_bytes > 160 * 1024) return false;
