@@ -7,6 +7,8 @@ using namespace rnad_mlp;
 
 namespace {
 
+constexpr int kTS = 36;  // row stride (floats) of the per-wave dz tiles
+
 // floats per sample row of the backward's LDS stage: the augmented input (x | 1) padded with zeros to whole MFMA feature tiles
 // (16-wide tiles, plus one 4-wide tile when at most 4 features are left over), made odd
 __host__ __device__ constexpr int bwd_stage_stride(int K) {
@@ -21,7 +23,7 @@ __host__ __device__ constexpr int bwd_stage_stride(int K) {
 //     dW1[o, j] += dout[o] * h[j]                     (VALU, per-lane partial sums over this lane's samples)
 //     dz[j] = (z[j] > 0) * sum_o W1[o, j] * dout[o]
 //     dW0aug[j, k] += dz[j] * xaug[k]                 (MFMA with the 32 SAMPLES of the tile as the contraction dimension:
-//                                                      A = dz^T via a per-wave 32x33 LDS transpose, B = x rows; the
+//                                                      A = dz^T via a per-wave 32x36 LDS transpose, B = x rows; the
 //                                                      bias gradient is the k = K column because xaug[K] = 1)
 // Block = W/32 waves; wave w owns hidden tile w of BOTH heads for every sample tile the block visits, so its two
 // 32x32 dW0aug accumulators (32 registers) and its dW1 partials (16 + 16 A registers) stay resident for the whole
@@ -39,13 +41,15 @@ __global__ __launch_bounds__(64 * WAVES) void k_mlp_backward(int64_t N, int W, c
     const int W2 = 2 * W;
     const float *w1v = lds + img_w1v(K, W);
     const float *w1p = lds + img_w1p(K, W);
-    float *scratch = lds + img_floats(K, W, A);  // after the image: [waves][2][32][33]
+    float *scratch = lds + img_floats(K, W, A);  // after the image: [waves][2][32][kTS]
     load_image<nthreads>(packed, lds, img_floats(K, W, A) / 4);
     __syncthreads();
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int col = lane & 31, half = lane >> 5;
-    float *tr_v = scratch + wave * (2 * kTile * 33), *tr_p = tr_v + kTile * 33;  // dz of the two heads, [hidden][sample], stride 33
+    // dz of the two heads, [hidden][sample]; row stride 36 floats: rows are 16-byte aligned (the left-over pass reads them as
+    // float4) and the strided accesses of the 16-wide pass stay at the 2-way minimum of 64 lanes over 32 banks
+    float *tr_v = scratch + wave * (2 * kTile * kTS), *tr_p = tr_v + kTile * kTS;
     // blockIdx.y selects a group of (blockDim.x / 64) hidden tiles; this wave owns one of them, in both heads
     const int own = blockIdx.y * WAVES + wave;
     const int tile_v = own, tile_p = W / kTile + own;
@@ -81,8 +85,9 @@ __global__ __launch_bounds__(64 * WAVES) void k_mlp_backward(int64_t N, int W, c
     // stage row = xaug padded to the MFMA feature tiles: x[0..K) | 1 | 0 ..., so the dW0 operands are plain loads; the stride
     // is made odd (no LDS bank conflicts between the 32 rows)
     constexpr int XS = bwd_stage_stride(K);
-    constexpr int XN = kTile * XS, STG = XN + kTile + kTile * A;  // floats per stage: xaug | dv | dlogits
-    float *stage = scratch + WAVES * (2 * kTile * 33);           // [2][STG]
+    // ... and the <= 4 left-over feature columns once more, transposed ([4][32]: a lane of the left-over pass reads one column)
+    constexpr int XN = kTile * XS, XLO = XN + kTile + kTile * A, STG = XLO + 4 * kTile;  // floats per stage: xaug | dv | dlogits | xlo
+    float *stage = scratch + WAVES * (2 * kTile * kTS);          // [2][STG]
     const int64_t n_tiles = (N + kTile - 1) / kTile;
     // TPS threads share one sample of the tile: thread (smp, part) loads elements part, part + TPS, ... of that sample's row.
     // One row id per thread and tile, itself prefetched a further tile ahead (row-list launches: a lookup that the x loads
@@ -113,7 +118,10 @@ __global__ __launch_bounds__(64 * WAVES) void k_mlp_backward(int64_t N, int W, c
 #pragma unroll
         for (int u = 0; u < XU; ++u) {
             const int k = part + u * TPS;
-            if (k < K) dst[smp * XS + k] = pre_x[u];
+            if (k < K) {
+                dst[smp * XS + k] = pre_x[u];
+                if (LO > 0 && k >= N16 * 16) dst[XLO + (k - N16 * 16) * kTile + smp] = pre_x[u];
+            }
         }
         if (part == 0) dst[XN + smp] = pre_dv;
 #pragma unroll
@@ -127,6 +135,11 @@ __global__ __launch_bounds__(64 * WAVES) void k_mlp_backward(int64_t N, int W, c
         const int smp_ = r / (XS - K), f = K + r % (XS - K);
         stage[buf * STG + smp_ * XS + f] = f == K ? 1.0f : 0.0f;
     }
+    if (LO > 0)
+        for (int i = threadIdx.x; i < 2 * 4 * kTile; i += nthreads) {
+            const int buf = i / (4 * kTile), f = N16 * 16 + (i % (4 * kTile)) / kTile;
+            if (f >= K) stage[buf * STG + XLO + i % (4 * kTile)] = f == K ? 1.0f : 0.0f;
+        }
     int cur = 0;
     if ((int64_t)blockIdx.x < n_tiles) {
         fetch(row_of(blockIdx.x));
@@ -164,9 +177,9 @@ __global__ __launch_bounds__(64 * WAVES) void k_mlp_backward(int64_t N, int W, c
                     const float z0 = c[4 * g + 2 * j], z1 = c[4 * g + 2 * j + 1];
                     gW1v[2 * g + j] = __builtin_elementwise_fma(dv2, relu2(z0, z1), gW1v[2 * g + j]);
                     const f32x2 dz = wq[j] * dv2;  // dL/dz where the unit is active
-                    float *t = tr_v + (2 * j + 8 * g + 4 * half) * 33 + col;  // stored [hidden][sample]
+                    float *t = tr_v + (2 * j + 8 * g + 4 * half) * kTS + col;  // stored [hidden][sample]
                     t[0] = z0 > 0.0f ? dz.x : 0.0f;
-                    t[33] = z1 > 0.0f ? dz.y : 0.0f;
+                    t[kTS] = z1 > 0.0f ? dz.y : 0.0f;
                 }
             }
         }
@@ -192,9 +205,9 @@ __global__ __launch_bounds__(64 * WAVES) void k_mlp_backward(int64_t N, int W, c
                     const f32x2 h = relu2(z0, z1);
 #pragma unroll
                     for (int a = 0; a < A; ++a) gW1p[a][2 * g + j] = __builtin_elementwise_fma(dl2[a], h, gW1p[a][2 * g + j]);
-                    float *t = tr_p + (2 * j + 8 * g + 4 * half) * 33 + col;
+                    float *t = tr_p + (2 * j + 8 * g + 4 * half) * kTS + col;
                     t[0] = z0 > 0.0f ? dh[j].x : 0.0f;
-                    t[33] = z1 > 0.0f ? dh[j].y : 0.0f;
+                    t[kTS] = z1 > 0.0f ? dh[j].y : 0.0f;
                 }
             }
         }
@@ -210,7 +223,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_mlp_backward(int64_t N, int W, c
                 }
 #pragma unroll
                 for (int mt = 0; mt < 2; ++mt) {
-                    const float av = tr_v[(mt * 16 + m16) * 33 + 4 * ks + q4], ap = tr_p[(mt * 16 + m16) * 33 + 4 * ks + q4];
+                    const float av = tr_v[(mt * 16 + m16) * kTS + 4 * ks + q4], ap = tr_p[(mt * 16 + m16) * kTS + 4 * ks + q4];
 #pragma unroll
                     for (int nt = 0; nt < N16; ++nt) {
                         gW0v[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bx[nt], gW0v[mt][nt], 0, 0, 0);
@@ -222,19 +235,19 @@ __global__ __launch_bounds__(64 * WAVES) void k_mlp_backward(int64_t N, int W, c
         if (LO > 0) {
             // block b = lane / 4 holds hidden rows 4 b .. 4 b + 3 of the value tile (b < 8) or the policy tile; column lane % 4 is
             // feature 16 N16 + lane % 4
-            const float *a_src = lane < 32 ? tr_v + lane * 33 : tr_p + (lane - 32) * 33;
-            const float *b_src = xs + N16 * 16 + (lane & 3);
+            const float4 *a_src = reinterpret_cast<const float4 *>(lane < 32 ? tr_v + lane * kTS : tr_p + (lane - 32) * kTS);
+            const float4 *b_src = reinterpret_cast<const float4 *>(xs + XLO + (lane & 3) * kTile);
 #pragma unroll
-            for (int s0 = 0; s0 < kTile; s0 += 8) {  // eight samples' operands are requested before the first is used
-                float av[8], bv[8];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    av[u] = a_src[s0 + u];
-                    bv[u] = b_src[(s0 + u) * XS];
-                }
-#pragma unroll
-                for (int u = 0; u < 8; ++u)
-                    gW0lo[u & 3] = __builtin_amdgcn_mfma_f32_4x4x1f32(av[u], bv[u], gW0lo[u & 3], 0, 0, 0);
+            for (int s0 = 0; s0 < kTile / 4; s0 += 2) {  // eight samples per round: two 16-byte reads per operand
+                const float4 a0 = a_src[s0], a1 = a_src[s0 + 1], b0 = b_src[s0], b1 = b_src[s0 + 1];
+                gW0lo[0] = __builtin_amdgcn_mfma_f32_4x4x1f32(a0.x, b0.x, gW0lo[0], 0, 0, 0);
+                gW0lo[1] = __builtin_amdgcn_mfma_f32_4x4x1f32(a0.y, b0.y, gW0lo[1], 0, 0, 0);
+                gW0lo[2] = __builtin_amdgcn_mfma_f32_4x4x1f32(a0.z, b0.z, gW0lo[2], 0, 0, 0);
+                gW0lo[3] = __builtin_amdgcn_mfma_f32_4x4x1f32(a0.w, b0.w, gW0lo[3], 0, 0, 0);
+                gW0lo[0] = __builtin_amdgcn_mfma_f32_4x4x1f32(a1.x, b1.x, gW0lo[0], 0, 0, 0);
+                gW0lo[1] = __builtin_amdgcn_mfma_f32_4x4x1f32(a1.y, b1.y, gW0lo[1], 0, 0, 0);
+                gW0lo[2] = __builtin_amdgcn_mfma_f32_4x4x1f32(a1.z, b1.z, gW0lo[2], 0, 0, 0);
+                gW0lo[3] = __builtin_amdgcn_mfma_f32_4x4x1f32(a1.w, b1.w, gW0lo[3], 0, 0, 0);
             }
         }
         __builtin_amdgcn_wave_barrier();
@@ -350,10 +363,13 @@ struct BwdPlan {
 static bool mlp_backward_plan(int64_t N, int W, int A, BwdPlan *p) {
     const int K = 2 * A * A, T = W / kTile, FT = (K + 1 + kTile - 1) / kTile;
     int waves = FT == 1 ? 8 : 4;
-    while (waves > 1 && T % waves) waves >>= 1;
+    auto lds_for = [&](int wv) {
+        return ((size_t)mlp_packed_floats(A, W) + (size_t)wv * 2 * kTile * kTS + 2 * (size_t)kTile * (bwd_stage_stride(K) + 1 + A + 4)) * sizeof(float);
+    };
+    while (waves > 1 && (T % waves || lds_for(waves) > 160 * 1024)) waves >>= 1;  // fewer waves per block: smaller dz scratch
     p->waves = waves;
     p->groups = T / waves;
-    p->lds_bytes = ((size_t)mlp_packed_floats(A, W) + (size_t)waves * 2 * kTile * 33 + 2 * (size_t)kTile * (bwd_stage_stride(K) + 1 + A)) * sizeof(float);
+    p->lds_bytes = lds_for(waves);
     p->total = 2 * W * FT * kTile + W + A * W + 1 + A;
     p->P = (p->total + 3) & ~3;
     if (p->lds_bytes > 160 * 1024) return false;
