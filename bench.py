@@ -191,9 +191,11 @@ def main():
         # fused MLP: flops the matrix cores execute per sample (first layer, both heads; relu + second layer run on the VALU)
         K = 2 * A * A
         mlp_flops_per_sample = 2.0 * K * 2 * args.width
-        # backward per sample: recompute of the first layer + dW0 with the augmented input padded to 32-wide feature tiles
-        FT = (K + 1 + 31) // 32
-        bwd_flops_per_sample = mlp_flops_per_sample + 2.0 * 32 * FT * 2 * args.width
+        # backward per sample: recompute of the first layer + dW0 over the augmented input padded to its MFMA feature tiles
+        # (16-wide tiles, plus a 4-wide one when at most 4 features are left over; csrc/mlp_bwd.hip)
+        rem = (K + 1) % 16
+        feat = 16 * ((K + 1) // 16 + (1 if rem > 4 else 0)) + (4 if 0 < rem <= 4 else 0)
+        bwd_flops_per_sample = mlp_flops_per_sample + 2.0 * feat * 2 * args.width
         n_live = int(alive.sum()) if rn.skip_absorbed and not tree.handle().uniform_length else local_batch * T
         bwd_tflops = bwd_flops_per_sample * n_live / (bwd_ms / max(n_bwd, 1) / 1e3) / 1e12 if n_bwd else None
         what = {False: "every net evaluated on every (t, b) slot, as the reference does",

@@ -35,7 +35,9 @@ def timeit(fn):
 
 
 fwd_flop = 2.0 * N * K * 2 * W  # executed MFMA flops of the first layer, both heads
-bwd_flop = fwd_flop + 2.0 * N * 32 * 2 * W  # recompute + dW0 with the feature tile padded to 32
+_rem = (K + 1) % 16
+_feat = 16 * ((K + 1) // 16 + (1 if _rem > 4 else 0)) + (4 if 0 < _rem <= 4 else 0)
+bwd_flop = fwd_flop + 2.0 * N * _feat * 2 * W  # recompute + dW0 over the tile-padded augmented input
 packed = rnad_hip.mlp_pack(w, A)
 ms = timeit(lambda: rnad_hip.mlp_forward(packed, W, x, A))
 print(f"forward  both heads: {ms:7.3f} ms  {fwd_flop / ms / 1e9:6.1f} TFLOP/s (MFMA-executed)")
