@@ -23,11 +23,14 @@ __host__ __device__ constexpr int bwd_stage_stride(int K) {
 //     dW1[o, j] += dout[o] * h[j]                     (VALU, per-lane partial sums over this lane's samples)
 //     dz[j] = (z[j] > 0) * sum_o W1[o, j] * dout[o]
 //     dW0aug[j, k] += dz[j] * xaug[k]                 (MFMA with the 32 SAMPLES of the tile as the contraction dimension:
-//                                                      A = dz^T via a per-wave 32x36 LDS transpose, B = x rows; the
-//                                                      bias gradient is the k = K column because xaug[K] = 1)
-// Block = W/32 waves; wave w owns hidden tile w of BOTH heads for every sample tile the block visits, so its two
-// 32x32 dW0aug accumulators (32 registers) and its dW1 partials (16 + 16 A registers) stay resident for the whole
-// launch.  Blocks write their partial gradients to `partial`; k_mlp_reduce sums them in a fixed order (deterministic).
+//                                                      A = dz^T via per-wave 32x36 LDS transposes, B = xaug rows from the
+//                                                      block's LDS stage; 16-wide feature tiles on 16x16x4, <= 4 left-over
+//                                                      features on 4x4x1_16b; the bias gradient is the k = K column
+//                                                      because xaug[K] = 1)
+// Block = up to 8 waves; wave w owns hidden tile w of BOTH heads for every sample tile the block visits, so its dW0aug
+// accumulators (2 heads x 2 row tiles x N16 feature tiles x 4 registers, + 16 for the left-overs) and its dW1 partials
+// (16 + 16 A registers) stay resident for the whole launch.  Blocks write their partial gradients to `partial`; k_mlp_reduce
+// sums them in a fixed order (deterministic).
 template <int A, typename ObsT, int WAVES>
 __global__ __launch_bounds__(64 * WAVES) void k_mlp_backward(int64_t N, int W, const float *__restrict__ packed,
                                                        const ObsT *__restrict__ obs, const float *__restrict__ dlogit,

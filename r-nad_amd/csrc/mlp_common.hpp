@@ -63,16 +63,10 @@ __device__ __forceinline__ float load_obs<float>(const float *p) { return *p; }
 template <>
 __device__ __forceinline__ float load_obs<__half>(const __half *p) { return __half2float(*p); }
 
-// LDS image (floats) = the packed weight image:  w0[(K + 2)][2W]  |  w1v[W]  |  w1p[A][W]  |  b1[1 + A] (padded to 12)
-//
-// HEADS: 1 = value only, 2 = policy only, 3 = both.  A wave keeps TWO hidden tiles in flight (two independent
-// accumulator chains) and is software-pipelined by hand: the MFMA chains of the next tile pair are issued before the
-// relu / second-layer VALU epilogue of the current pair.  (Measured on gfx950: fp32 MFMA and fp32 VALU work do NOT
-// overlap -- kernel time is the sum of the two -- so what counts is the VALU instruction count of the epilogue: built
-// with -mllvm -amdgpu-mfma-vgpr-form (no v_accvgpr_read) and -fno-honor-nans (no canonicalising v_max before relu).)
-// z tile = b0 + W0 x.  The accumulator starts as the first-layer bias of this lane's 16 hidden rows (four broadcast float4
-// reads, no VALU work), then K / 2 MFMAs walk the input features; their A operands are loaded up front from one base
-// address with immediate offsets.
+// One hidden tile of the first layer for one 32-sample tile (the backward's recompute; the forward has its own
+// two-sample-tile variant in mlp_fwd.hip).  z tile = b0 + W0 x.  The accumulator starts as the first-layer bias of this lane's
+// 16 hidden rows (four broadcast float4 reads, no VALU work), then K / 2 MFMAs walk the input features; their A operands are
+// loaded up front from one base address with immediate offsets.
 template <int A>
 __device__ __forceinline__ f32x16 mfma_chain(const float *__restrict__ lds, int W, int tile, int col, int half, const float (&xk)[A * A]) {
     constexpr int K = 2 * A * A, KS = A * A;
