@@ -5,16 +5,16 @@
 using namespace rnad;
 using namespace rnad_mlp;
 
+namespace rnad_mlp {
+size_t mlp_backward_t_lds(int A);
+int mlp_backward_t_launch(int A, int waves, dim3 grid, hipStream_t stream, int64_t N, int W, const float *packed, const void *obs,
+                           int obs_half, const float *dlogits, const float *dvalue, float *workspace, int P, const int32_t *rows,
+                           const int64_t *n_rows);
+}  // namespace rnad_mlp
+
 namespace {
 
 constexpr int kTS = 36;  // row stride (floats) of the per-wave dz tiles
-
-// floats per sample row of the backward's LDS stage: the augmented input (x | 1) padded with zeros to whole MFMA feature tiles
-// (16-wide tiles, plus one 4-wide tile when at most 4 features are left over), made odd
-__host__ __device__ constexpr int bwd_stage_stride(int K) {
-    const int rem = (K + 1) % 16, n16 = (K + 1) / 16 + (rem > 4 ? 1 : 0), lo = rem > 4 ? 0 : rem;
-    return (n16 * 16 + (lo > 0 ? 4 : 0)) | 1;
-}
 
 // ------------------------------------------------------------------------------------------------ backward
 // Gradients of the 8 Linear tensors given dL/dlogits [N, A] and dL/dvalue [N] -- what autograd computes for
@@ -359,12 +359,37 @@ __global__ __launch_bounds__(64 * kReduceSlices) void k_mlp_reduce(int nblocks, 
 struct BwdPlan {
     int waves, groups, grid_x, P, total;
     size_t lds_bytes;
+    bool resident;  // mlp_bwd_t.hip (dz and the wave's weights in registers) instead of the LDS-transpose kernel of this file
 };
+
+static bool use_resident_backward() {
+    static const int v = [] {
+        const char *e = getenv("RNAD_MLP_BWD");  // "lds": the kernel of this file; anything else / unset: the register-resident one
+        return (e && e[0] == 'l') ? 0 : 1;
+    }();
+    return v != 0;
+}
 
 // One wave per hidden tile (of both heads).  With one feature tile (A <= 3) a wave needs ~230 VGPRs: 8 waves per block, two
 // per SIMD.  With more feature tiles it needs up to ~400: 4 waves per block, one per SIMD, and blockIdx.y walks the tile groups.
 static bool mlp_backward_plan(int64_t N, int W, int A, BwdPlan *p) {
     const int K = 2 * A * A, T = W / kTile, FT = (K + 1 + kTile - 1) / kTile;
+    p->total = 2 * W * FT * kTile + W + A * W + 1 + A;
+    p->P = (p->total + 3) & ~3;
+    int dev0 = 0, cus0 = 256;
+    if (hipGetDevice(&dev0) == hipSuccess) (void)hipDeviceGetAttribute(&cus0, hipDeviceAttributeMultiprocessorCount, dev0);
+    const int64_t n_tiles0 = (N + kTile - 1) / kTile;
+    p->resident = use_resident_backward();
+    if (p->resident) {
+        // 4 waves per block (one per SIMD), up to 3 blocks per CU by registers; the LDS holds only the sample stage
+        int wv = 4;
+        while (wv > 1 && T % wv) wv >>= 1;
+        p->waves = wv;
+        p->groups = T / wv;
+        p->lds_bytes = mlp_backward_t_lds(A);
+        p->grid_x = (int)std::max<int64_t>(1, std::min<int64_t>(n_tiles0, std::max(1, cus0 * 3 * 4 / wv / p->groups)));
+        return true;
+    }
     int waves = FT == 1 ? 8 : 4;
     auto lds_for = [&](int wv) {
         return ((size_t)mlp_packed_floats(A, W) + (size_t)wv * 2 * kTile * kTS + 2 * (size_t)kTile * (bwd_stage_stride(K) + 1 + A + 4)) * sizeof(float);
@@ -373,8 +398,6 @@ static bool mlp_backward_plan(int64_t N, int W, int A, BwdPlan *p) {
     p->waves = waves;
     p->groups = T / waves;
     p->lds_bytes = lds_for(waves);
-    p->total = 2 * W * FT * kTile + W + A * W + 1 + A;
-    p->P = (p->total + 3) & ~3;
     if (p->lds_bytes > 160 * 1024) return false;
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
@@ -403,7 +426,13 @@ static int mlp_backward_launch(int64_t N, const int32_t *rows, const int64_t *n_
     const int grid = plan.grid_x, P = plan.P;
     const size_t lds_bytes = plan.lds_bytes;
     const int threads = 64 * plan.waves;
-    {
+    if (plan.resident) {
+        ProfScope prof(PROF_MLP_BWD, stream);
+        if (int rc = mlp_backward_t_launch(A, plan.waves, dim3(grid, plan.groups), stream, N, W, packed, obs, obs_half, dlogits, dvalue,
+                                           workspace, P, rows, n_rows))
+            return rc;
+        RNAD_HIP_OK(hipGetLastError());
+    } else {
         ProfScope prof(PROF_MLP_BWD, stream);
 #define RNAD_MLPB_LAUNCH(T_, WV_)                                                                                                 \
     do {                                                                                                                           \

@@ -88,6 +88,13 @@ __device__ __forceinline__ f32x16 mfma_chain(const float *__restrict__ lds, int 
 
 __device__ __forceinline__ f32x2 relu2(float a, float b) { return f32x2{fmaxf(a, 0.0f), fmaxf(b, 0.0f)}; }
 
+// floats per sample row of the backward's LDS stage: the augmented input (x | 1) padded with zeros to whole MFMA feature tiles
+// (16-wide tiles, plus one 4-wide tile when at most 4 features are left over), made odd
+__host__ __device__ constexpr int bwd_stage_stride(int K) {
+    const int rem = (K + 1) % 16, n16 = (K + 1) / 16 + (rem > 4 ? 1 : 0), lo = rem > 4 ? 0 : rem;
+    return (n16 * 16 + (lo > 0 ? 4 : 0)) | 1;
+}
+
 static inline int mlp_packed_floats(int A, int W) { return img_floats(2 * A * A, W, A); }
 
 }  // namespace rnad_mlp
