@@ -176,7 +176,7 @@ def test_mlp_forward_shapes_vs_oracle_and_torch(G, hip, A, W, N):
 
 
 @pytest.mark.parametrize("A,W,N", [(3, 256, 50_001), (2, 64, 333), (3, 32, 5), (1, 32, 1000), (3, 128, 20_000), (3, 512, 9_000), (4, 64, 3_000),
-                                   (5, 128, 12_345), (5, 256, 4_000), (6, 96, 777)])
+                                   (5, 128, 12_345), (5, 256, 4_000), (6, 96, 777), (7, 64, 500), (8, 32, 300)])
 def test_mlp_backward_vs_torch_autograd(G, hip, A, W, N):
     """rnad_mlp_backward == autograd through the four Linear layers (fp64 reference on the host for the tolerance)."""
     rng = np.random.default_rng(A * 100 + W + N)
@@ -215,6 +215,21 @@ def test_mlp_backward_vs_torch_autograd(G, hip, A, W, N):
     assert lo is None and torch.equal(vo, vg.detach())
     lh, vh = hip.FusedMLP.apply(G.gpu(x).half(), A, packed, *[g.detach().requires_grad_(True) for g in wg])  # fp16 observations
     assert lh.shape == (N, A) and vh.shape == (N, 1)
+
+
+def test_mlp_backward_lds_transpose_kernel_too():
+    """csrc/mlp_bwd.hip (RNAD_MLP_BWD=lds), the kernel the register-resident one replaced, is kept as a cross-check: the choice
+    is made once per process, so it is exercised in a child process."""
+    import os
+    import subprocess
+    import sys
+
+    env = dict(os.environ, RNAD_MLP_BWD="lds")
+    here = os.path.dirname(os.path.realpath(__file__))
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(here, "test_hip_parity.py"), "-q", "-x", "-k",
+                        "test_mlp_backward_vs_torch_autograd and not lds"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout
 
 
 # ------------------------------------------------------------------------------------------------ rollout driver
