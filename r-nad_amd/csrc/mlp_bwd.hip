@@ -7,6 +7,7 @@ using namespace rnad_mlp;
 
 namespace rnad_mlp {
 size_t mlp_backward_t_lds(int A);
+int mlp_backward_t_blocks_per_cu(int A, int waves);
 int mlp_backward_t_launch(int A, int waves, dim3 grid, hipStream_t stream, int64_t N, int W, const float *packed, const void *obs,
                            int obs_half, const float *dlogits, const float *dvalue, float *workspace, int P, const int32_t *rows,
                            const int64_t *n_rows);
@@ -381,13 +382,13 @@ static bool mlp_backward_plan(int64_t N, int W, int A, BwdPlan *p) {
     const int64_t n_tiles0 = (N + kTile - 1) / kTile;
     p->resident = use_resident_backward();
     if (p->resident) {
-        // 4 waves per block (one per SIMD), up to 3 blocks per CU by registers; the LDS holds only the sample stage
+        // 4 waves per block (one per SIMD), as many blocks per CU as the registers allow; the LDS holds only the sample stage
         int wv = 4;
         while (wv > 1 && T % wv) wv >>= 1;
         p->waves = wv;
         p->groups = T / wv;
         p->lds_bytes = mlp_backward_t_lds(A);
-        p->grid_x = (int)std::max<int64_t>(1, std::min<int64_t>(n_tiles0, std::max(1, cus0 * 3 * 4 / wv / p->groups)));
+        p->grid_x = (int)std::max<int64_t>(1, std::min<int64_t>(n_tiles0, std::max(1, cus0 * mlp_backward_t_blocks_per_cu(A, wv) / p->groups)));
         return true;
     }
     int waves = FT == 1 ? 8 : 4;

@@ -294,6 +294,35 @@ static void launch_t(int waves, dim3 grid, size_t lds_bytes, hipStream_t stream,
     }
 }
 
+// Resident blocks per CU of the instantiation that a launch would use (register-limited: the LDS stage is small), asked of the
+// runtime once per shape.  The grid is sized to exactly that many persistent blocks: more would run as a second, half-empty round.
+template <int A, typename ObsT>
+static int occupancy_t(int waves, size_t lds_bytes) {
+    int n = 0;
+    hipError_t e;
+    switch (waves) {
+        case 8: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_mlp_backward_t<A, ObsT, 8>, 512, lds_bytes); break;
+        case 4: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_mlp_backward_t<A, ObsT, 4>, 256, lds_bytes); break;
+        case 2: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_mlp_backward_t<A, ObsT, 2>, 128, lds_bytes); break;
+        default: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_mlp_backward_t<A, ObsT, 1>, 64, lds_bytes); break;
+    }
+    return (e == hipSuccess && n > 0) ? n : 1;
+}
+
+size_t mlp_backward_t_lds(int A);
+
+int mlp_backward_t_blocks_per_cu(int A, int waves) {
+    static int cache[RNAD_MAX_ACTIONS + 1][9] = {};
+    if (A < 1 || A > RNAD_MAX_ACTIONS || waves < 1 || waves > 8) return 1;
+    if (cache[A][waves] == 0) {
+        const size_t lds_bytes = mlp_backward_t_lds(A);
+        int n = 1;
+        RNAD_DISPATCH_A(A, n = occupancy_t<kA, float>(waves, lds_bytes));  // the fp16-observation instantiation uses the same registers
+        cache[A][waves] = n;
+    }
+    return cache[A][waves];
+}
+
 size_t mlp_backward_t_lds(int A) {
     const int K = 2 * A * A;
     return (size_t)2 * (kTile * bwd_stage_stride(K) + kTile + kTile * A + 4 * kTile) * sizeof(float);
