@@ -383,7 +383,7 @@ static bool mlp_backward_plan(int64_t N, int W, int A, BwdPlan *p) {
     p->resident = use_resident_backward();
     if (p->resident) {
         // 4 waves per block (one per SIMD), as many blocks per CU as the registers allow; the LDS holds only the sample stage
-        int wv = 4;
+        int wv = 4;  // measured: 4 waves per block 5.31 ms, 8: 5.41, 2: 5.72 (configs[1], 12.6 M samples)
         while (wv > 1 && T % wv) wv >>= 1;
         p->waves = wv;
         p->groups = T / wv;
