@@ -279,7 +279,7 @@ int rnad_learn_fused(int T, int64_t B, int A, const int32_t *indices, const uint
  * ONE rnad_mlp_backward over the 2S inputs with dlogit_tab [2S,A], dv_tab [2S] gives the gradients of the per-slot backward
  * up to fp32 summation order.  The sums are taken in 64-bit fixed point (integer atomics: any order, same result; the states
  * of the top levels, which the whole batch passes through, first in a per-block LDS table), so they are reproducible.
- * workspace: rnad_learn_tabular_workspace(tree, T, B) bytes, 8-byte aligned.  B <= 2^21 per call. */
+ * workspace: rnad_learn_tabular_workspace(tree, T, B) bytes, 16-byte aligned.  B <= 2^21 per call. */
 int64_t rnad_learn_tabular_workspace(const rnad_tree_t *tree, int T, int64_t B);
 int rnad_learn_fused_tabular(const rnad_tree_t *tree, int T, int64_t B, const int32_t *indices, const uint8_t *mask_bits,
                              const int32_t *actions, const float *rewards, const float *mu, const float *logit_tab,
@@ -287,12 +287,15 @@ int rnad_learn_fused_tabular(const rnad_tree_t *tree, int T, int64_t B, const in
                              const float *logit_reg_tab_, const double *norm, const rnad_learn_params_t *hp, double *losses,
                              void *workspace, float *dlogit_tab, float *dv_tab, void *stream);
 /* Same gathers, but dL/dlogit [T,B,A] and dL/dv [T,B] are written per slot (the bits of rnad_learn_fused): only the forward
- * evaluations are deduplicated, and a per-slot rnad_mlp_backward then gives bit-identical, reproducible weight gradients. */
+ * evaluations are deduplicated, and a per-slot rnad_mlp_backward then gives bit-identical, reproducible weight gradients.
+ * workspace: rnad_learn_gather_workspace(tree) bytes, 16-byte aligned (the five tables interleaved into one record per row,
+ * so that a slot gathers 48 contiguous bytes at A = 3 instead of five scattered pieces). */
+int64_t rnad_learn_gather_workspace(const rnad_tree_t *tree);
 int rnad_learn_fused_gather(const rnad_tree_t *tree, int T, int64_t B, const int32_t *indices, const uint8_t *mask_bits,
                             const int32_t *actions, const float *rewards, const float *mu, const float *logit_tab,
                             const float *v_tab, const float *v_target_tab, const float *logit_reg_tab,
                             const float *logit_reg_tab_, const double *norm, const rnad_learn_params_t *hp, double *losses,
-                            float *dlogit, float *dv, void *stream);
+                            void *workspace, float *dlogit, float *dv, void *stream);
 
 /* ------------------------------------------------------------------------------------------------
  * NashConv  --  util/metric.py:93-175 (NashConvData.get_nashconv), level-batched on the GPU

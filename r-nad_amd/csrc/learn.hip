@@ -400,11 +400,34 @@ __global__ __launch_bounds__(kThreads) void k_tab_finish(int64_t rows, const uns
     dv[r] = (float)((double)(long long)acc[r * (A + 1) + A] / fixed_scale(gmax[A]));
 }
 
+template <int A>
+constexpr int kRecStride = (3 * A + 2 + 3) & ~3;  // floats per row record of the tabular learner, a multiple of 4
+
+template <int A>
+__global__ __launch_bounds__(kThreads) void k_pack_records(int64_t rows, const float *__restrict__ logit, const float *__restrict__ v,
+                                                           const float *__restrict__ vt, const float *__restrict__ lr,
+                                                           const float *__restrict__ lr2, float *__restrict__ rec) {
+    const int64_t r = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    if (r >= rows) return;
+    float *o = rec + r * kRecStride<A>;
+#pragma unroll
+    for (int a = 0; a < A; ++a) {
+        o[a] = logit[r * A + a];
+        o[A + 2 + a] = lr[r * A + a];
+        o[2 * A + 2 + a] = lr2[r * A + a];
+    }
+    o[A] = v[r];
+    o[A + 1] = vt[r];
+#pragma unroll
+    for (int j = 3 * A + 2; j < kRecStride<A>; ++j) o[j] = 0.0f;
+}
+
 // The fused learner pass (header comment of rnad_learn_fused).  Per (t, b): 69 B read, 16 B written (A = 3).
 // TAB = false: logit_ / v_ / vtn_ / lreg_ / lreg2_ are per-slot arrays [T,B,(A)] and dlogit / dv are written per slot.
 // TAB = true ("tabular" evaluation): the observation is a function of (state, player to move) alone, so the nets were evaluated
-// once per (player, state) -- row = player * S + state of tables [2S,(A)] -- and every slot gathers its row.  dlogit / dv are
-// written per slot either way.
+// once per (player, state), row = player * S + state, and every slot gathers its row: logit_ then points to ONE table of
+// records [2S][kRecStride] = lg[A] | v | v_target | lr[A] | lr2[A] | pad (k_pack_records; one 48-byte gather per slot at
+// A = 3 instead of five scattered ones), the other four pointers are unused.  dlogit / dv are written per slot either way.
 template <int A, bool TAB>
 __global__ __launch_bounds__(kThreads) void k_learn_fused(int T, int64_t B, const int32_t *__restrict__ indices,
                                                           const uint8_t *__restrict__ mbits, const int32_t *__restrict__ actions,
@@ -436,12 +459,21 @@ __global__ __launch_bounds__(kThreads) void k_learn_fused(int T, int64_t B, cons
             const uint32_t bits = mbits[i];
             const int act = actions[i];
             float mu[A], lg[A], lr[A], lr2[A], legal[A], oh[A];
+            float rec[kRecStride<A>];  // TAB: this row's record lg[A] | v | v_target | lr[A] | lr2[A], fetched as 16-byte pieces
+            if (TAB) {
+                const float4 *rp = reinterpret_cast<const float4 *>(logit_ + row * kRecStride<A>);
+#pragma unroll
+                for (int j = 0; j < kRecStride<A> / 4; ++j) {
+                    const float4 r4 = rp[j];
+                    rec[4 * j] = r4.x; rec[4 * j + 1] = r4.y; rec[4 * j + 2] = r4.z; rec[4 * j + 3] = r4.w;
+                }
+            }
 #pragma unroll
             for (int a = 0; a < A; ++a) {
                 mu[a] = mu_[i * A + a];
-                lg[a] = logit_[row * A + a];
-                lr[a] = lreg_[row * A + a];
-                lr2[a] = lreg2_[row * A + a];
+                lg[a] = TAB ? rec[a] : logit_[row * A + a];
+                lr[a] = TAB ? rec[A + 2 + a] : lreg_[row * A + a];
+                lr2[a] = TAB ? rec[2 * A + 2 + a] : lreg2_[row * A + a];
                 legal[a] = (float)((bits >> a) & 1);
                 oh[a] = act == a ? 1.0f : 0.0f;
             }
@@ -453,7 +485,7 @@ __global__ __launch_bounds__(kThreads) void k_learn_fused(int T, int64_t B, cons
 #pragma unroll
             for (int a = 0; a < A; ++a) lpol[a] = lp[a] - (hp.alpha * lpr[a] + hp.one_minus_alpha * lpr2[a]);  // rnad.py:382
             const float rew = rewards[i];
-            const float vtn = vtn_[row];
+            const float vtn = TAB ? rec[A + 1] : vtn_[row];
             float vt[2], q[2][A];
             vtrace_step<A>(cy[0], vh, valid, P == 0, valid_f, vtn, rew, mu, pip, lpol, oh, vt[0], q[0]);   // player 0 (rnad.py:384-406)
             vtrace_step<A>(cy[1], vh, valid, P == 1, valid_f, vtn, -rew, mu, pip, lpol, oh, vt[1], q[1]);  // player 1: rewards = -r (:368)
@@ -463,7 +495,7 @@ __global__ __launch_bounds__(kThreads) void k_learn_fused(int T, int64_t B, cons
             for (int a = 0; a < A; ++a) g_l[a] = 0.0f;
             if (valid) {
                 const float nfp = P ? nf1 : nf0;
-                const float vv = v_[row];
+                const float vv = TAB ? rec[A] : v_[row];
                 const float vtp = P ? vt[1] : vt[0];
                 const float d = vv - vtp;
                 part_v += (double)(d * d) / (double)nfp;
@@ -618,9 +650,9 @@ static int learn_fused_gather_impl(const rnad_tree_t *tree, int T, int64_t B, co
                                    const int32_t *actions, const float *rewards, const float *mu, const float *logit_tab,
                                    const float *v_tab, const float *v_target_tab, const float *logit_reg_tab, const float *logit_reg_tab_,
                                    const double *norm, const rnad_learn_params_t *hp, double *losses, float *dlogit, float *dv,
-                                   uint32_t *gmax, hipStream_t stream) {
+                                   uint32_t *gmax, float *rec, hipStream_t stream) {
     RNAD_REQUIRE(tree && indices && mask_bits && actions && rewards && mu && logit_tab && v_tab && v_target_tab && logit_reg_tab &&
-                     logit_reg_tab_ && norm && hp && dlogit && dv,
+                     logit_reg_tab_ && norm && hp && dlogit && dv && rec,
                  "rnad_learn_fused_gather: null argument");
     RNAD_REQUIRE(T >= 0 && B >= 0, "rnad_learn_fused_gather: negative shape");
     RNAD_REQUIRE(hp->n_disc >= 1, "rnad_learn_fused_gather: n_disc must be positive");
@@ -628,10 +660,12 @@ static int learn_fused_gather_impl(const rnad_tree_t *tree, int T, int64_t B, co
     if (gmax) RNAD_HIP_OK(hipMemsetAsync(gmax, 0, sizeof(uint32_t) * (tree->A + 1), stream));
     if (T == 0 || B == 0) return 0;
     ProfScope prof(PROF_LEARN, stream);
+    RNAD_DISPATCH_A(tree->A, hipLaunchKernelGGL((k_pack_records<kA>), dim3(blocks_for(2 * tree->S)), dim3(kThreads), 0, stream, 2 * tree->S,
+                                                logit_tab, v_tab, v_target_tab, logit_reg_tab, logit_reg_tab_, rec));
     RNAD_DISPATCH_A(tree->A, hipLaunchKernelGGL((k_learn_fused<kA, true>), dim3(blocks_for(B)), dim3(kThreads), 0, stream, T, B, indices,
-                                                mask_bits, actions, rewards, mu, logit_tab, v_tab, v_target_tab, logit_reg_tab,
-                                                logit_reg_tab_, norm, *hp, losses, dlogit, dv, (float *)nullptr, (float *)nullptr,
-                                                (float *)nullptr, tree->S, gmax));
+                                                mask_bits, actions, rewards, mu, (const float *)rec, (const float *)nullptr,
+                                                (const float *)nullptr, (const float *)nullptr, (const float *)nullptr, norm, *hp, losses,
+                                                dlogit, dv, (float *)nullptr, (float *)nullptr, (float *)nullptr, tree->S, gmax));
     RNAD_HIP_OK(hipGetLastError());
     return 0;
 }
@@ -643,9 +677,14 @@ extern "C" int rnad_learn_fused_gather(const rnad_tree_t *tree, int T, int64_t B
                                        const int32_t *actions, const float *rewards, const float *mu, const float *logit_tab,
                                        const float *v_tab, const float *v_target_tab, const float *logit_reg_tab,
                                        const float *logit_reg_tab_, const double *norm, const rnad_learn_params_t *hp, double *losses,
-                                       float *dlogit, float *dv, void *stream) {
+                                       void *workspace, float *dlogit, float *dv, void *stream) {
     return learn_fused_gather_impl(tree, T, B, indices, mask_bits, actions, rewards, mu, logit_tab, v_tab, v_target_tab, logit_reg_tab,
-                                   logit_reg_tab_, norm, hp, losses, dlogit, dv, nullptr, (hipStream_t)stream);
+                                   logit_reg_tab_, norm, hp, losses, dlogit, dv, nullptr, (float *)workspace, (hipStream_t)stream);
+}
+
+extern "C" int64_t rnad_learn_gather_workspace(const rnad_tree_t *tree) {  // bytes: the [2S] record table
+    if (!tree) return -1;
+    return 2 * tree->S * (int64_t)((3 * tree->A + 2 + 3) & ~3) * 4;
 }
 
 // ... and the per-row sums of those per-slot gradients (k_row_sums), for ONE backward over the 2S distinct observations.
@@ -653,7 +692,7 @@ extern "C" int rnad_learn_fused_gather(const rnad_tree_t *tree, int T, int64_t B
 extern "C" int64_t rnad_learn_tabular_workspace(const rnad_tree_t *tree, int T, int64_t B) {
     if (!tree || T < 0 || B < 0) return -1;
     const int64_t A = tree->A, N = (int64_t)T * B;
-    return N * (A + 1) * 4 + 2 * tree->S * (A + 1) * 8 + 64;
+    return N * (A + 1) * 4 + 2 * tree->S * (A + 1) * 8 + 64 + 16 + rnad_learn_gather_workspace(tree);
 }
 
 extern "C" int rnad_learn_fused_tabular(const rnad_tree_t *tree, int T, int64_t B, const int32_t *indices, const uint8_t *mask_bits,
@@ -672,8 +711,9 @@ extern "C" int rnad_learn_fused_tabular(const rnad_tree_t *tree, int T, int64_t 
     uint32_t *gmax = (uint32_t *)(ws + 2 * S * (A + 1) * 8);                  // [A + 1]
     float *dlogit = (float *)(ws + 2 * S * (A + 1) * 8 + 64);                 // [T,B,A]
     float *dv = dlogit + N * A;                                               // [T,B]
+    float *rec = (float *)(((uintptr_t)(dv + N) + 15) & ~(uintptr_t)15);          // [2S][record], 16-byte aligned
     if (int rc = learn_fused_gather_impl(tree, T, B, indices, mask_bits, actions, rewards, mu, logit_tab, v_tab, v_target_tab,
-                                         logit_reg_tab, logit_reg_tab_, norm, hp, losses, dlogit, dv, gmax, stream))
+                                         logit_reg_tab, logit_reg_tab_, norm, hp, losses, dlogit, dv, gmax, rec, stream))
         return rc;
     RNAD_HIP_OK(hipMemsetAsync(acc, 0, sizeof(unsigned long long) * 2 * S * (A + 1), stream));
     if (N > 0) {

@@ -62,6 +62,7 @@ def lib():
         _lib.rnad_mlp_packed_size.restype = C.c_int64
         _lib.rnad_compact_workspace.restype = C.c_int64
         _lib.rnad_learn_tabular_workspace.restype = C.c_int64
+        _lib.rnad_learn_gather_workspace.restype = C.c_int64
     return _lib
 
 
@@ -462,12 +463,13 @@ def learn_fused_gather(tree, indices, mask_bits, actions, rewards, mu, logit_tab
     dlogit = torch.empty((T, B, A), dtype=F32, device=dev)
     dv = torch.empty((T, B), dtype=F32, device=dev)
     losses = torch.empty((2,), dtype=F64, device=dev)
+    ws = torch.empty((int(lib().rnad_learn_gather_workspace(tree.ptr)) // 4,), dtype=F32, device=dev)
     _check(lib().rnad_learn_fused_gather(tree.ptr, T, C.c_int64(B), _dp(indices, I32, "indices"), _dp(mask_bits, U8, "mask_bits"),
                                          _dp(actions, I32, "actions"), _dp(rewards, F32, "rewards"), _dp(mu, F32, "mu"),
                                          _dp(logit_tab, F32, "logit_tab"), _dp(v_tab, F32, "v_tab"), _dp(v_target_tab, F32, "v_target_tab"),
                                          _dp(logit_reg_tab, F32, "logit_reg_tab"), _dp(logit_reg_tab_, F32, "logit_reg_tab_"),
-                                         _dp(norm, F64, "norm"), C.byref(hp), _dp(losses, F64, "losses"), _dp(dlogit, F32, "dlogit"),
-                                         _dp(dv, F32, "dv"), _stream()))
+                                         _dp(norm, F64, "norm"), C.byref(hp), _dp(losses, F64, "losses"), _dp(ws, F32, "workspace"),
+                                         _dp(dlogit, F32, "dlogit"), _dp(dv, F32, "dv"), _stream()))
     return dlogit, dv, losses
 
 
