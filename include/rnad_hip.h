@@ -297,6 +297,11 @@ int rnad_learn_fused_gather(const rnad_tree_t *tree, int T, int64_t B, const int
                             const float *logit_reg_tab_, const double *norm, const rnad_learn_params_t *hp, double *losses,
                             void *workspace, float *dlogit, float *dv, void *stream);
 
+/* torch.nn.utils.clip_grad_norm_(parameters, max_norm) of learn/rnad.py:456 over one flat fp32 gradient bucket (all of a net's
+ * .grad tensors back to back): g *= min(max_norm / (||g||_2 + 1e-6), 1), in place, one launch.  total_norm: optional device
+ * float receiving ||g||_2. */
+int rnad_clip_grad_norm(int64_t n, float *grads, float max_norm, float *total_norm, void *stream);
+
 /* ------------------------------------------------------------------------------------------------
  * NashConv  --  util/metric.py:93-175 (NashConvData.get_nashconv), level-batched on the GPU
  * instead of one Python frame per state.  joint_policy f32 [S,2A] (device) for every state below

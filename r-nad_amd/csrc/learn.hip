@@ -738,3 +738,40 @@ extern "C" int rnad_learn_fused_tabular(const rnad_tree_t *tree, int T, int64_t 
     RNAD_HIP_OK(hipGetLastError());
     return 0;
 }
+
+// ---------------------------------------------------------------------------------------- gradient clipping
+// torch.nn.utils.clip_grad_norm_ (learn/rnad.py:456) over ONE flat gradient bucket: total 2-norm, then
+// g *= min(max_norm / (norm + 1e-6), 1).  One block (the bucket is 10 756 floats on configs[1]) instead of ~8 small torch
+// launches per update; the norm is accumulated in fp64 in a fixed order.  total_norm (optional) receives the norm.
+namespace {
+__global__ __launch_bounds__(1024) void k_clip_grad_norm(int64_t n, float *__restrict__ g, float max_norm, float *__restrict__ total_norm) {
+    __shared__ double part[16];
+    __shared__ float coef_s;
+    double s = 0.0;
+    for (int64_t i = threadIdx.x; i < n; i += 1024) s += (double)g[i] * (double)g[i];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) t += part[i];
+        const float norm = (float)sqrt(t);
+        if (total_norm) *total_norm = norm;
+        const float c = max_norm / (norm + 1e-6f);
+        coef_s = c < 1.0f ? c : 1.0f;
+    }
+    __syncthreads();
+    const float c = coef_s;
+    for (int64_t i = threadIdx.x; i < n; i += 1024) g[i] *= c;  // torch multiplies by the clamped coefficient unconditionally
+}
+}  // namespace
+
+extern "C" int rnad_clip_grad_norm(int64_t n, float *grads, float max_norm, float *total_norm, void *stream) {
+    RNAD_REQUIRE(n >= 0 && (n == 0 || grads), "rnad_clip_grad_norm: null argument");
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(k_clip_grad_norm, dim3(1), dim3(1024), 0, (hipStream_t)stream, n, grads, max_norm, total_norm);
+    RNAD_HIP_OK(hipGetLastError());
+    return 0;
+}

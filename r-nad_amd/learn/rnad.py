@@ -427,11 +427,11 @@ class RNaD:
                 dist.all_reduce(flat)  # one 43 KB bucket over RCCL, in place: the .grad tensors are views of it
             else:
                 grads = [p.grad for p in self.net.parameters()]
-                flat = torch.cat([g.reshape(-1) for g in grads])
-                dist.all_reduce(flat)
+                cat = torch.cat([g.reshape(-1) for g in grads])
+                dist.all_reduce(cat)
                 off = 0
                 for g in grads:
-                    g.copy_(flat[off: off + g.numel()].view_as(g))
+                    g.copy_(cat[off: off + g.numel()].view_as(g))
                     off += g.numel()
             if log is not None:
                 dist.all_reduce(losses)
@@ -458,7 +458,10 @@ class RNaD:
                 "actor_learner_kld": metric.kld(pi, episodes.policy[:T], valid, legal_actions=masks),
             })
 
-        nn.utils.clip_grad_norm_(self.net.parameters(), self.grad_clip)  # rnad.py:456
+        if flat is not None and flat.is_cuda:  # the .grad tensors are views of this bucket: one launch instead of ~8
+            rnad_hip.clip_grad_norm(flat, self.grad_clip)  # rnad.py:456
+        else:
+            nn.utils.clip_grad_norm_(self.net.parameters(), self.grad_clip)  # rnad.py:456
 
     # ------------------------------------------------------------------ reference learn/rnad.py:502-523
     def train_step(self, buffer, alpha, log=None):

@@ -473,6 +473,11 @@ def learn_fused_gather(tree, indices, mask_bits, actions, rewards, mu, logit_tab
     return dlogit, dv, losses
 
 
+def clip_grad_norm(flat, max_norm):
+    """In-place clip_grad_norm_ of one flat fp32 gradient bucket (rnad_clip_grad_norm)."""
+    _check(lib().rnad_clip_grad_norm(C.c_int64(flat.numel()), _dp(flat, F32, "grads"), C.c_float(max_norm), None, _stream()))
+
+
 def make_learn_params(alpha, eta, lambda_=1.0, c=1.0, rho=1.0, gamma=1.0, clip=1e3, threshold=2.0, w_v=1.0, w_n=1.0,
                       eps_threshold=0.03, n_disc=32):
     # 1 - alpha is taken in double like the reference's python scalar (rnad.py:382), then rounded to fp32
