@@ -312,3 +312,28 @@ def test_tabular_training_steps_track_the_dense_ones():
         # can flip a step, so compare at a few lr
         np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=0, atol=1e-3)
         assert torch.isfinite(a).all()
+
+
+@pytest.mark.parametrize("scale,max_norm", [(1.0, 1e3), (100.0, 1.0), (0.0, 1.0)])
+def test_clip_grad_norm_matches_torch(scale, max_norm):
+    import rnad_hip
+
+    g = torch.Generator().manual_seed(3)
+    shapes = [(256, 18), (256,), (1, 256), (1,), (256, 18), (256,), (3, 256), (3,)]
+    n = sum(int(np.prod(s)) for s in shapes)
+    flat = (torch.randn((n,), generator=g) * scale).to(DEV)
+    params, off = [], 0
+    for s in shapes:
+        p_ = torch.nn.Parameter(torch.zeros(s, device=DEV))
+        k = int(np.prod(s))
+        p_.grad = flat[off: off + k].view(s).clone()
+        params.append(p_)
+        off += k
+    want_norm = torch.nn.utils.clip_grad_norm_(params, max_norm)
+    mine = flat.clone()
+    rnad_hip.clip_grad_norm(mine, max_norm)
+    want = torch.cat([p_.grad.reshape(-1) for p_ in params])
+    if float(want_norm) <= max_norm:
+        assert torch.equal(mine, flat) and torch.equal(want, flat)  # coefficient clamped to exactly 1
+    else:
+        np.testing.assert_allclose(mine.cpu().numpy(), want.cpu().numpy(), rtol=2e-6, atol=0)
