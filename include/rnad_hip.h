@@ -99,6 +99,11 @@ int rnad_mlp_pack(int A, int W, const float *vw0, const float *vb0, const float 
                   const float *pb0, const float *pw1, const float *pb1, float *packed, void *stream);
 int rnad_mlp_forward(int64_t N, int A, int W, const float *packed, const void *obs, int obs_half, float *logits,
                      float *value, void *stream);
+/* n_nets (1..4) nets of the same shape on the same N inputs in one launch; packed / logits / value are HOST arrays of n_nets
+ * device pointers (a NULL logits[i] or value[i]: that output is not stored).  What the tabular update uses for the learner,
+ * target and two regularisation nets (learn/rnad.py:373-380) on the 2S observations of the tree. */
+int rnad_mlp_forward_multi(int n_nets, int64_t N, int A, int W, const float *const *packed, const void *obs, int obs_half,
+                           float *const *logits, float *const *value, void *stream);
 int64_t rnad_mlp_backward_workspace(int64_t N, int A, int W);
 int rnad_mlp_backward(int64_t N, int A, int W, const float *packed, const void *obs, int obs_half, const float *dlogits,
                       const float *dvalue, float *g_vw0, float *g_vb0, float *g_vw1, float *g_vb1, float *g_pw0,

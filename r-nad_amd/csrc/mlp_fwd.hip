@@ -92,11 +92,20 @@ __device__ __forceinline__ void mfma_chain2(const float *__restrict__ lds, int W
 // loaded while the current ones are in the matrix pipe.  (Measured on gfx950: fp32 MFMA and fp32 VALU share the ALUs --
 // tools/micro/mfma_peak.hip: every v_pk_fma_f32 adds 6.4 cycles to a 64-cycle MFMA -- so the VALU epilogue is kernel time and
 // is kept to relu + the second-layer FMAs.)
+// Up to four nets evaluated on the same inputs by one launch (blockIdx.y picks the net): the tabular update evaluates the
+// learner, target and two regularisation nets on the same 2S observations, and at that size a launch is mostly latency.
+struct NetSet {
+    const float *packed[4];
+    float *logits[4];
+    float *value[4];
+};
+
 template <int A, typename ObsT, int HEADS>
-__global__ __launch_bounds__(kFwdThreads) void k_mlp_forward(int64_t N, int W, const float *__restrict__ packed,
-                                                             const ObsT *__restrict__ obs, float *__restrict__ logits,
-                                                             float *__restrict__ value, const int32_t *__restrict__ rows,
-                                                             const int64_t *__restrict__ n_rows) {
+__global__ __launch_bounds__(kFwdThreads) void k_mlp_forward(int64_t N, int W, NetSet nets, const ObsT *__restrict__ obs,
+                                                             const int32_t *__restrict__ rows, const int64_t *__restrict__ n_rows) {
+    const float *__restrict__ packed = nets.packed[blockIdx.y];
+    float *__restrict__ logits = nets.logits[blockIdx.y];
+    float *__restrict__ value = nets.value[blockIdx.y];
     // rows != null: sample s of this launch is row rows[s] of obs / logits / value, and the sample count comes from device
     // memory (rnad_compact_valid's output: no host round trip between the compaction and this launch)
     if (n_rows) N = *n_rows;
@@ -229,9 +238,11 @@ extern "C" int rnad_mlp_pack(int A, int W, const float *vw0, const float *vb0, c
     return 0;
 }
 
-static int mlp_forward_launch(int64_t N, const int32_t *rows, const int64_t *n_rows, int A, int W, const float *packed, const void *obs,
-                              int obs_half, float *logits, float *value, void *stream_) {
-    RNAD_REQUIRE(packed && obs && (logits || value), "rnad_mlp_forward: null argument");
+static int mlp_forward_launch(int64_t N, const int32_t *rows, const int64_t *n_rows, int A, int W, int n_nets, const NetSet &nets,
+                              const void *obs, int obs_half, void *stream_) {
+    RNAD_REQUIRE(obs && n_nets >= 1 && n_nets <= 4, "rnad_mlp_forward: null argument");
+    for (int i = 0; i < n_nets; ++i)
+        RNAD_REQUIRE(nets.packed[i] && (nets.logits[i] || nets.value[i]), "rnad_mlp_forward: null argument (net %d)", i);
     RNAD_REQUIRE(W >= kTile && W % kTile == 0, "rnad_mlp_forward: width %d must be a positive multiple of %d", W, kTile);
     RNAD_REQUIRE(N >= 0, "rnad_mlp_forward: negative batch");
     if (N == 0) return 0;
@@ -247,14 +258,15 @@ static int mlp_forward_launch(int64_t N, const int32_t *rows, const int64_t *n_r
     const int blocks_per_cu = std::max(1, std::min(12 / kWaves, (int)(160 * 1024 / lds_bytes)));
     const int64_t n_spans = (N + 2 * kTile - 1) / (2 * kTile);  // a wave iteration covers 64 samples
     const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>((n_spans + kWaves - 1) / kWaves, (int64_t)cus * blocks_per_cu));
-    const int heads = (value ? 1 : 0) | (logits ? 2 : 0);
+    // one net: only the heads that are wanted are computed; several nets: both heads, unwanted outputs are simply not stored
+    const int heads = n_nets > 1 ? 3 : ((nets.value[0] ? 1 : 0) | (nets.logits[0] ? 2 : 0));
     ProfScope prof(PROF_MLP, stream);
 #define RNAD_MLP_LAUNCH2(T_, H_)                                                                                                  \
     do {                                                                                                                           \
         auto kern = k_mlp_forward<kA, T_, H_>;                                                                                     \
         if (lds_bytes > 64 * 1024)                                                                                       \
             RNAD_HIP_OK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes)); \
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(kFwdThreads), lds_bytes, stream, N, W, packed, (const T_ *)obs, logits, value, rows, n_rows);            \
+        hipLaunchKernelGGL(kern, dim3(grid, n_nets), dim3(kFwdThreads), lds_bytes, stream, N, W, nets, (const T_ *)obs, rows, n_rows);            \
                                                                         \
     } while (0)
 #define RNAD_MLP_LAUNCH(T_)                                   \
@@ -277,11 +289,25 @@ static int mlp_forward_launch(int64_t N, const int32_t *rows, const int64_t *n_r
 
 extern "C" int rnad_mlp_forward(int64_t N, int A, int W, const float *packed, const void *obs, int obs_half, float *logits, float *value,
                                 void *stream) {
-    return mlp_forward_launch(N, nullptr, nullptr, A, W, packed, obs, obs_half, logits, value, stream);
+    NetSet nets{};
+    nets.packed[0] = packed; nets.logits[0] = logits; nets.value[0] = value;
+    return mlp_forward_launch(N, nullptr, nullptr, A, W, 1, nets, obs, obs_half, stream);
+}
+
+extern "C" int rnad_mlp_forward_multi(int n_nets, int64_t N, int A, int W, const float *const *packed, const void *obs, int obs_half,
+                                      float *const *logits, float *const *value, void *stream) {
+    RNAD_REQUIRE(n_nets >= 1 && n_nets <= 4 && packed && logits && value, "rnad_mlp_forward_multi: 1..4 nets");
+    NetSet nets{};
+    for (int i = 0; i < n_nets; ++i) {
+        nets.packed[i] = packed[i]; nets.logits[i] = logits[i]; nets.value[i] = value[i];
+    }
+    return mlp_forward_launch(N, nullptr, nullptr, A, W, n_nets, nets, obs, obs_half, stream);
 }
 
 extern "C" int rnad_mlp_forward_rows(int64_t max_rows, const int32_t *rows, const int64_t *n_rows, int A, int W, const float *packed,
                                      const void *obs, int obs_half, float *logits, float *value, void *stream) {
     RNAD_REQUIRE(rows && n_rows, "rnad_mlp_forward_rows: null row list");
-    return mlp_forward_launch(max_rows, rows, n_rows, A, W, packed, obs, obs_half, logits, value, stream);
+    NetSet nets{};
+    nets.packed[0] = packed; nets.logits[0] = logits; nets.value[0] = value;
+    return mlp_forward_launch(max_rows, rows, n_rows, A, W, 1, nets, obs, obs_half, stream);
 }

@@ -363,29 +363,47 @@ class RNaD:
         # gradients can be written straight into one flat bucket (the all-reduce buffer).  Any other net goes through autograd.
         direct = fused_mlp
         reuse = reuse and table is None
-        if reuse:  # the rollout's own outputs: same weights, same observations, same kernel -> same bits as rnad.py:373
+        if table is not None:
+            # tabular: all nets on the same 2S observations, in ONE launch.  log_policy_reg (:382) needs one regularisation net only
+            # when alpha is 0 or 1 or both hold the same weights (see the dense branch below).
+            nets, wants = [self.net, self.net_target], [(True, True), (False, True)]
+            one_reg = alpha == 0 or alpha == 1 or self._reg_nets_identical()
+            if alpha == 0:
+                nets.append(self.net_reg_)
+            else:
+                nets.append(self.net_reg)
+                if not one_reg:
+                    nets.append(self.net_reg_)
+            wants += [(True, False)] * (len(nets) - 2)
+            with torch.no_grad():
+                outs = rnad_hip.mlp_forward_multi([n_.pack() for n_ in nets], self.net.width, table, A, wants)
+            (logit, v), (logit_target, v_target) = outs[0], outs[1]
+            logit_reg = outs[2][0]
+            logit_reg_ = outs[3][0] if len(outs) > 3 else logit_reg
+        elif reuse:  # the rollout's own outputs: same weights, same observations, same kernel -> same bits as rnad.py:373
             logit, v = episodes.actor_logits.reshape(-1, A), episodes.values[:T].reshape(-1, 1)
         elif direct:
             with torch.no_grad():
-                logit, v = self._logits_of(self.net, episodes, live=fwd_live, table=table)  # rnad.py:373
+                logit, v = self._logits_of(self.net, episodes, live=fwd_live)  # rnad.py:373
         else:
             logit, v = self._logits_of(self.net, episodes, live=fwd_live)  # rnad.py:373, with grad
-        with torch.no_grad():
-            # the reference runs all four full nets (:378-380); only these heads are ever read (:382-406)
-            logit_target, v_target = self._logits_of(self.net_target, episodes, want_logits=log is not None, live=fwd_live, table=table)  # :378
-            # log_policy_reg = log_pi - (alpha * log_pi_reg + (1 - alpha) * log_pi_reg_) (:382).  A term whose weight is exactly 0
-            # adds exactly 0 (log-policies are finite), and two nets with the same weights give the same bits: in the second half
-            # of every outer iteration (alpha == 1, :497) and during all of m == 0 (both reg nets are copies of the initial net,
-            # :183-186) one evaluation serves both operands.
-            if alpha == 0:
-                logit_reg_, _ = self._logits_of(self.net_reg_, episodes, want_value=False, live=fwd_live, table=table)  # :380
-                logit_reg = logit_reg_
-            else:
-                logit_reg, _ = self._logits_of(self.net_reg, episodes, want_value=False, live=fwd_live, table=table)  # :379
-                if alpha == 1 or self._reg_nets_identical():
-                    logit_reg_ = logit_reg
+        if table is None:
+            with torch.no_grad():
+                # the reference runs all four full nets (:378-380); only these heads are ever read (:382-406)
+                logit_target, v_target = self._logits_of(self.net_target, episodes, want_logits=log is not None, live=fwd_live)  # :378
+                # log_policy_reg = log_pi - (alpha * log_pi_reg + (1 - alpha) * log_pi_reg_) (:382).  A term whose weight is exactly
+                # 0 adds exactly 0 (log-policies are finite), and two nets with the same weights give the same bits: in the second
+                # half of every outer iteration (alpha == 1, :497) and during all of m == 0 (both reg nets are copies of the initial
+                # net, :183-186) one evaluation serves both operands.
+                if alpha == 0:
+                    logit_reg_, _ = self._logits_of(self.net_reg_, episodes, want_value=False, live=fwd_live)  # :380
+                    logit_reg = logit_reg_
                 else:
-                    logit_reg_, _ = self._logits_of(self.net_reg_, episodes, want_value=False, live=fwd_live, table=table)  # :380
+                    logit_reg, _ = self._logits_of(self.net_reg, episodes, want_value=False, live=fwd_live)  # :379
+                    if alpha == 1 or self._reg_nets_identical():
+                        logit_reg_ = logit_reg
+                    else:
+                        logit_reg_, _ = self._logits_of(self.net_reg_, episodes, want_value=False, live=fwd_live)  # :380
 
         if norm_work is not None:
             norm_work.wait()

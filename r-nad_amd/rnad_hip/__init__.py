@@ -246,6 +246,23 @@ def mlp_forward(packed, W, obs, A, want_logits=True, want_value=True, live=None)
     return logits, value
 
 
+def mlp_forward_multi(packed_list, W, obs, A, wants):
+    """Several nets of one shape on the same inputs in ONE launch (rnad_mlp_forward_multi).  packed_list: their weight images;
+    wants: per net (want_logits, want_value).  Returns a list of (logits [N, A] or None, value [N, 1] or None)."""
+    n = len(packed_list)
+    assert 1 <= n <= 4 and len(wants) == n
+    N = obs.numel() // (2 * A * A)
+    half = obs.dtype == F16
+    outs = [(torch.empty((N, A), dtype=F32, device=obs.device) if wl else None,
+             torch.empty((N, 1), dtype=F32, device=obs.device) if wv else None) for wl, wv in wants]
+    ptr = lambda t: t.data_ptr() if t is not None else None  # noqa: E731
+    P = (C.c_void_p * n)(*[_dp(p, F32, "packed").value for p in packed_list])
+    L = (C.c_void_p * n)(*[ptr(o[0]) for o in outs])
+    V = (C.c_void_p * n)(*[ptr(o[1]) for o in outs])
+    _check(lib().rnad_mlp_forward_multi(n, C.c_int64(N), A, W, P, _dp(obs, F16 if half else F32, "obs"), int(half), L, V, _stream()))
+    return outs
+
+
 def mlp_backward_supported(A, W):
     return W % 32 == 0 and lib().rnad_mlp_backward_workspace(C.c_int64(32), A, W) > 0
 
