@@ -342,10 +342,10 @@ class RNaD:
         # zeros, which the same masks discard -- losses and gradients are unchanged.  Logging steps stay dense, because
         # logit_mean / logit_max (:427-452) are taken over ALL slots.
         fused_mlp = isinstance(self.net, net.MLP) and self.net._fusable() and rnad_hip.mlp_backward_supported(A, self.net.width)
-        # Tabular evaluation (opt-in, RNaD.tabular): an observation depends on (state, player to move) only, so each net is
-        # evaluated on the 2S distinct observations of the tree and every (t, b) slot gathers its row; the per-slot gradients
-        # are summed per row before ONE backward pass over those 2S observations (include/rnad_hip.h, rnad_learn_fused_tabular).
-        # Worth it when the tree is small next to the batch (configs[1]: 132 862 rows for 12.6 M slots).
+        # Tabular evaluation (RNaD.tabular): an observation depends on (state, player to move) only, so each net is evaluated on
+        # the 2S distinct observations of the tree and every (t, b) slot gathers its row (include/rnad_hip.h,
+        # rnad_learn_fused_gather / _tabular).  Worth it when the tree is small next to the batch (configs[1]: 132 862 rows for
+        # 12.6 M slots).
         # RNaD.tabular = "forward": only the forward evaluations are deduplicated; dL/dlogit, dL/dv stay per slot and the backward
         # runs on every (live) slot -- bit-identical, reproducible gradients.  True: the gradients are summed per row as well.
         table, mode = None, getattr(self, "tabular", False)
