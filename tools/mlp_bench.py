@@ -11,7 +11,7 @@ import torch  # noqa: E402
 import rnad_hip  # noqa: E402
 
 A = int(os.environ.get("MLP_BENCH_A", 3))
-W = 256
+W = int(os.environ.get("MLP_BENCH_W", 256))
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 12 * 2**20
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
 dev = torch.device("cuda:0")
