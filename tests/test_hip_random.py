@@ -141,3 +141,45 @@ def test_rollout_step_count_limits():
     assert alive[0] == 4096 and (np.diff(alive) <= 0).all() and alive[T] == 0
     # a lane is rewarded exactly once, on the column step where it leaves the tree
     assert ((ep.rewards != 0).sum(0) == 1).all()
+
+
+@pytest.mark.parametrize("A,C,W", [(2, 3, 32), (3, 2, 64), (4, 2, 64), (5, 1, 32), (7, 3, 32)])
+def test_net_evaluation_modes_agree_on_random_trees(A, C, W, tmp_path, monkeypatch):
+    """RNaD.tabular False / "forward" / True on random forward-pointing trees with ragged legality (state ids in no particular
+    tree order, episodes of every length): identical rollouts, forward == dense bit for bit, True to summation order."""
+    from _gpu import DEV, tree_from_arrays
+    from environment.episode import Episodes
+    from learn.rnad import RNaD
+
+    rng = np.random.default_rng(7 * A + C)
+    tree = tree_from_arrays(_random_tree(rng, A, C, 400))
+    monkeypatch.setenv("RNAD_SAVE_DIR", str(tmp_path))
+    B = 1 << 13
+    torch.manual_seed(A + C)
+    rn = RNaD(tree=tree, device=DEV, directory_name=f"rand{A}{C}", batch_size=B, eta=0.2, b1_adam=0.0,
+              net_params={"type": "MLP", "max_actions": A, "width": W})
+    rn.initialize()
+    with torch.no_grad():
+        for i, m in enumerate((rn.net_target, rn.net_reg, rn.net_reg_)):
+            for p_ in m.parameters():
+                p_.add_(0.05 * (i + 1) * torch.randn_like(p_))
+    dense = Episodes(tree, B, seed=5)
+    dense.generate(rn.net, trim=False)
+    tab = Episodes(tree, B, seed=5)
+    tab.generate(rn.net, trim=False, tabular=True)
+    T = dense.t_eff + 1
+    for name in ("indices", "observations", "mask_bits", "policy", "action_idx", "rewards", "alive"):
+        assert torch.equal(getattr(tab, name)[:T], getattr(dense, name)[:T]), name
+    assert 8 * tree.handle().S <= T * B
+    grads = {}
+    for mode in (False, "forward", True):
+        rn.tabular = mode
+        rn.optimizer.zero_grad()
+        rn._RNaD__learn(dense, 0.3)
+        grads[mode] = [p_.grad.detach().clone() for p_ in rn.net.parameters()]
+    for a, b in zip(grads["forward"], grads[False]):
+        assert torch.equal(a, b)
+    for a, b in zip(grads[True], grads[False]):
+        scale = float(b.abs().max()) + 1e-12
+        assert torch.isfinite(a).all()
+        np.testing.assert_allclose(a.cpu().numpy() / scale, b.cpu().numpy() / scale, rtol=0, atol=1e-5)
