@@ -339,8 +339,8 @@ class RNaD:
                  and rnad_hip.mlp_backward_supported(A, getattr(self.net, "width", 0)))
         # Ragged trajectories (pruned trees, padded replay batches): the reference evaluates all four nets on every (t, b) slot
         # and masks the absorbed ones afterwards (valid, :369).  Here the nets run on the live slots only; the others hold
-        # zeros, which the same masks discard -- losses and gradients are unchanged.  Logging steps stay dense, because
-        # logit_mean / logit_max (:427-452) are taken over ALL slots.
+        # zeros, which the same masks discard -- losses and gradients are unchanged.  Logging steps of the dense mode evaluate
+        # every slot, because logit_mean / logit_max (:427-452) are taken over ALL slots.
         fused_mlp = isinstance(self.net, net.MLP) and self.net._fusable() and rnad_hip.mlp_backward_supported(A, self.net.width)
         # Tabular evaluation (RNaD.tabular): an observation depends on (state, player to move) only, so each net is evaluated on
         # the 2S distinct observations of the tree and every (t, b) slot gathers its row (include/rnad_hip.h,
@@ -349,7 +349,7 @@ class RNaD:
         # RNaD.tabular = "forward": only the forward evaluations are deduplicated; dL/dlogit, dL/dv stay per slot and the backward
         # runs on every (live) slot -- bit-identical, reproducible gradients.  True: the gradients are summed per row as well.
         table, mode = None, getattr(self, "tabular", False)
-        if mode and fused_mlp and log is None:
+        if mode and fused_mlp:
             handle = self.tree.handle()
             if 8 * handle.S <= T * B:
                 table = handle.observations_table(getattr(episodes, "obs_half", False))
@@ -366,7 +366,7 @@ class RNaD:
         if table is not None:
             # tabular: all nets on the same 2S observations, in ONE launch.  log_policy_reg (:382) needs one regularisation net only
             # when alpha is 0 or 1 or both hold the same weights (see the dense branch below).
-            nets, wants = [self.net, self.net_target], [(True, True), (False, True)]
+            nets, wants = [self.net, self.net_target], [(True, True), (log is not None, True)]
             one_reg = alpha == 0 or alpha == 1 or self._reg_nets_identical()
             if alpha == 0:
                 nets.append(self.net_reg_)
@@ -455,6 +455,16 @@ class RNaD:
                 dist.all_reduce(losses)
 
         if log is not None:
+            if table is not None:
+                # the logged statistics are over per-slot tensors (rnad.py:427-452): gather them from the tables.  An absorbed
+                # slot gathers the row of state 0 -- the reference's net output there, as it evaluates the net on state 0's
+                # observation -- so the statistics are those of the dense path.
+                S_ = self.tree.handle().S
+                rows = (episodes.indices[:T].long()
+                        + (torch.arange(T, device=logit.device) & 1).view(T, 1) * S_).reshape(-1)
+                logit = logit.index_select(0, rows)
+                logit_target = logit_target.index_select(0, rows)
+                pi = rnad_hip.policy_head(logit.contiguous(), mask_bits=episodes.mask_bits[:T].reshape(-1)).view(T, B, A)
             total_norm = 0
             for p in self.net.parameters():
                 total_norm += p.grad.detach().data.norm(2).item() ** 2

@@ -337,3 +337,47 @@ def test_clip_grad_norm_matches_torch(scale, max_norm):
         assert torch.equal(mine, flat) and torch.equal(want, flat)  # coefficient clamped to exactly 1
     else:
         np.testing.assert_allclose(mine.cpu().numpy(), want.cpu().numpy(), rtol=2e-6, atol=0)
+
+
+@pytest.mark.parametrize("ragged", (False, True))
+def test_logged_statistics_do_not_depend_on_the_mode(ragged):
+    """A logging step (rnad.py:427-452: per-slot logit / policy statistics) through the tables gives the dense path's numbers."""
+    from environment.episode import Episodes
+    from environment.tree import Tree
+    from learn.rnad import RNaD
+
+    if ragged:
+        tree = _ragged_tree()
+    else:
+        tree = Tree(device=DEV, max_actions=3, max_transitions=1, depth_bound=4)
+        tree.generate_native(seed=2)
+    os.environ["RNAD_SAVE_DIR"] = tempfile.mkdtemp(prefix="rnad_test_")
+    B = 1 << 13
+    torch.manual_seed(9)
+    rn = RNaD(tree=tree, device=DEV, directory_name=f"log{int(ragged)}", batch_size=B, eta=0.2, b1_adam=0.0,
+              net_params={"type": "MLP", "max_actions": 3, "width": 64})
+    rn.initialize()
+    with torch.no_grad():
+        for i, m in enumerate((rn.net_target, rn.net_reg, rn.net_reg_)):
+            for p_ in m.parameters():
+                p_.add_(0.05 * (i + 1) * torch.randn_like(p_))
+    ep = Episodes(tree, B, seed=3)
+    ep.generate(rn.net, trim=False)
+    logs, grads = {}, {}
+    for mode in (False, "forward", True):
+        rn.tabular = mode
+        rn.optimizer.zero_grad()
+        logs[mode] = {}
+        rn._RNaD__learn(ep, 0.4, log=logs[mode])
+        grads[mode] = [p_.grad.detach().clone() for p_ in rn.net.parameters()]
+    assert set(logs[False]) == set(logs["forward"]) == set(logs[True]) and "entropy" in logs[False]
+    for k, want in logs[False].items():
+        if k.startswith("loss"):  # fp64 atomic partial sums: the last bits vary from launch to launch
+            assert abs(logs["forward"][k] - want) <= 1e-9 * max(1.0, abs(want)), k
+            assert abs(logs[True][k] - want) <= 1e-9 * max(1.0, abs(want)), k
+        elif k == "gradient_norm":
+            assert logs["forward"][k] == want
+            assert abs(logs[True][k] - want) <= 1e-5 * want
+        else:
+            assert logs["forward"][k] == want and logs[True][k] == want, k
+    assert all(torch.equal(a, b) for a, b in zip(grads["forward"], grads[False]))
