@@ -6,8 +6,10 @@
         bench.py --gpus N --steps K --warmup W
 
 One "step" = one iteration of the reference's training loop (learn/rnad.py:495-526): roll out a batch of episodes with
-the learner net (Episodes.generate), sample the buffer, RNaD.__learn (4 MLP forwards, fused V-trace/NeuRD kernel,
-backward), Adam, EMA target.  Workload = BASELINE.json configs[1]: depth-6 ternary (3x3) tree, C = 1, 66 431 states,
+the learner net (Episodes.generate), sample the buffer, RNaD.__learn (4 MLP evaluations, fused V-trace/NeuRD kernel,
+backward), Adam, EMA target.  `value` times RNaD's default net-evaluation mode (tabular = "forward": the forward evaluations
+run once per (player, state) observation and are gathered per slot, the backward runs per slot -- every result bit-identical
+to evaluating every net on every slot); `other_modes` times that dense mode and tabular = True in the same process.  Workload = BASELINE.json configs[1]: depth-6 ternary (3x3) tree, C = 1, 66 431 states,
 GLOBAL batch 2^20 episodes x 12 env steps, MLP width 256, fp32.  N > 1 shards the episodes over the ranks (strong
 scaling, BASELINE north_star) with one RCCL all-reduce of the 2 loss normalisers and one of the 43 KB gradient bucket.
 
