@@ -55,6 +55,9 @@ def main():
                     help="each child's depth drops by 2 more with probability NUM/DEN (reference main.py:37); configs[3] uses a pruned tree")
     ap.add_argument("--threshold", type=float, default=None, help="transition_threshold (default 0 for C=1, 0.5/C otherwise)")
     ap.add_argument("--tree-seed", type=int, default=0)
+    ap.add_argument("--net-mode", choices=("default", "dense", "forward", "tabular"), default="default",
+                    help="RNaD.tabular for the timed `value`: dense = False, forward = 'forward' (RNaD's default), tabular = True; "
+                         "the other modes are reported under other_modes either way")
     ap.add_argument("--obs-half", action="store_true", help="fp16 observations (BASELINE configs[4])")
     ap.add_argument("--cpu-lanes-log2", type=int, default=15, help="episodes in the CPU-baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -96,6 +99,8 @@ def main():
               net_params={"type": "MLP", "max_actions": A, "width": args.width})
     rn.initialize()
     rn.obs_half = args.obs_half
+    if args.net_mode != "default":
+        rn.tabular = {"dense": False, "forward": "forward", "tabular": True}[args.net_mode]
     with torch.no_grad():
         # the general case of rnad.py:382: two DISTINCT regularisation nets and 0 < alpha < 1 (four net evaluations per update).
         # During m == 0 the two coincide and for alpha == 1 one of them has weight 0; RNaD then evaluates one net less --
@@ -116,6 +121,11 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # setup (untimed, before the caller's warmup): two priming steps, so that every code object, the caching allocator's pools
+    # and RCCL's channels exist whatever --warmup is (the first launches of a kernel load its code object: tens of ms)
+    for i in range(2):
+        one_step(i)
+    fence()
     for i in range(args.warmup):
         one_step(i)
     fence()
@@ -151,6 +161,7 @@ def main():
         if mode == default_mode or (mode and 8 * tree.handle().S > T * local_batch):
             continue
         rn.tabular = mode
+        one_step(base)
         one_step(base)
         fence()
         t_s = time.perf_counter()
@@ -226,7 +237,8 @@ def main():
                 "parallelism": f"dp{world} (episodes sharded, RCCL all-reduce of 2 normalisers + 43 KB grads)",
             },
             "updates_per_sec": args.steps / elapsed,
-            "net_evaluation": {"mode": f"RNaD.tabular = {default_mode!r} (default)", "what": what[default_mode],
+            "net_evaluation": {"mode": f"RNaD.tabular = {default_mode!r}" + (" (default)" if args.net_mode == "default" else ""),
+                               "what": what[default_mode],
                                "distinct_observations": 2 * tree.handle().S, "slots": T * local_batch},
             "other_modes": {name: {"env_steps_per_sec": env_steps / sec, "updates_per_sec": args.steps / sec,
                                    "ms_per_step": sec / args.steps * 1e3,
