@@ -197,9 +197,10 @@ int rnad_rollout_run(const rnad_tree_t *tree, const rnad_traj_t *traj, int W, co
 /* Tabular actor.  A lane's observation is a function of (state, player to move) alone (episode.py:62-68), so an actor with
  * fixed weights can be evaluated once on the 2S distinct observations -- rnad_observe_all, then rnad_mlp_forward with
  * N = 2S -- instead of on B lanes at each of the T steps.  logits_table: [2, S, A], row = player * S + state.  The rollout
- * (policies, actions, indices, rewards, observations) is that of rnad_rollout_run bit for bit; traj->values is zeros. */
-int rnad_rollout_run_tabular(const rnad_tree_t *tree, const rnad_traj_t *traj, const float *logits_table, uint64_t seed,
-                             int64_t lane0, void *stream);
+ * (policies, actions, indices, rewards, observations) is that of rnad_rollout_run bit for bit; value_table [2, S] (the actor's
+ * value head on the same rows) is gathered into traj->values, or NULL: zeros. */
+int rnad_rollout_run_tabular(const rnad_tree_t *tree, const rnad_traj_t *traj, const float *logits_table,
+                             const float *value_table, uint64_t seed, int64_t lane0, void *stream);
 
 /* alive[t] = #lanes with indices[t, :] != 0 for t in [0, T_cap]: one pass over the index buffer after the last
  * step.  The host reads it once to trim the trajectory to the reference's T (episode.py:194 stops when every lane

@@ -234,7 +234,7 @@ __global__ __launch_bounds__(kThreads) void k_act(const Trans *__restrict__ tran
 #pragma unroll
         for (int a = 0; a < A; ++a) policy_t[b * A + a] = pol[a];
         act_t[b] = action;
-        values_t[b] = value ? value[b] : 0.0f;  // no value head in this rollout: the slot is defined, and unread (rnad.py never reads it)
+        values_t[b] = value ? value[src] : 0.0f;  // no value head in this rollout: the slot is defined, and unread (rnad.py never reads it)
         const int s = idx_t[b];
         int next = s;
         float rew = 0.0f;  // row turn: torch.zeros (episode.py:101)
@@ -523,14 +523,16 @@ extern "C" int rnad_compact_valid(int64_t N, const int32_t *indices, int32_t *ro
 // The observation of a lane is a function of (state, player to move) alone (episode.py:62-68), so an actor whose weights are
 // fixed for the rollout can be evaluated ONCE on the 2S distinct observations (rnad_observe_all + rnad_mlp_forward) instead of
 // on B lanes at each of the T steps; every step then gathers its logits row.  Same observation bits, same kernel: the policies,
-// actions and trajectories are those of rnad_rollout_run bit for bit.  traj->values is filled with zeros.
-extern "C" int rnad_rollout_run_tabular(const rnad_tree_t *tree, const rnad_traj_t *tr, const float *logits_table, uint64_t seed,
-                                        int64_t lane0, void *stream) {
+// actions and trajectories are those of rnad_rollout_run bit for bit.  value_table [2S] (optional): the actor's value head on
+// the same rows, gathered into traj->values; NULL fills it with zeros.
+extern "C" int rnad_rollout_run_tabular(const rnad_tree_t *tree, const rnad_traj_t *tr, const float *logits_table,
+                                        const float *value_table, uint64_t seed, int64_t lane0, void *stream) {
     if (int rc = check_traj(tree, tr, "rnad_rollout_run_tabular")) return rc;
     RNAD_REQUIRE(logits_table, "rnad_rollout_run_tabular: null table");
     if (int rc = rnad_rollout_begin(tree, tr, stream)) return rc;
     for (int t = 0; t < tr->T_cap; ++t)
-        if (int rc = rollout_step_impl(tree, tr, t, 0, logits_table, nullptr, nullptr, nullptr, nullptr, nullptr, seed, lane0, tree->S, stream))
+        if (int rc = rollout_step_impl(tree, tr, t, 0, logits_table, nullptr, nullptr, value_table, nullptr, nullptr, seed, lane0, tree->S,
+                                       stream))
             return rc;
     return rnad_rollout_end(tree, tr, stream);
 }

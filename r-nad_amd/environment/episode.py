@@ -152,7 +152,7 @@ class Episodes:
 
     # ---------------------------------------------------------------- episode.py:175-230
     def generate(self, net: torch.nn.Module, noise_action=None, noise_chance=None, max_steps=None, trim=True, keep_logits=False,
-                 skip_absorbed=False, store_values=True, tabular=False):
+                 skip_absorbed=False, store_values=True, tabular=None):
         """Play the batch to the end with `net` as the actor.
 
         Nets exposing `forward_logits(obs) -> (logits [B,A], value [B,1])` (the MLP here) take the fast path: policy head,
@@ -170,9 +170,10 @@ class Episodes:
         net's output on state 0's observation (episode.py:203-212).  Those slots are invalid (`indices == 0`) for every
         consumer, so RNaD uses this too; leave it off to reproduce the reference's buffers slot for slot.
 
-        tabular=True (native MLP actor only): the actor is evaluated once on the 2S distinct observations of the tree (an
-        observation depends on the state and the player to move only, episode.py:62-68) and each step gathers its logits row --
-        the same rollout bit for bit (same inputs, same kernel) at 2S instead of T*B net evaluations; `values` is zeros.
+        tabular (native MLP actor only; default: whenever the tree is small next to the batch, 8 S <= T B): the actor is evaluated
+        once on the 2S distinct observations of the tree (an observation depends on the state and the player to move only,
+        episode.py:62-68) and each step gathers its logits / value row -- the same rollout bit for bit (same inputs, same
+        kernel) at 2S instead of T*B net evaluations.  tabular=False evaluates the net on every lane at every step.
 
         store_values=False (native MLP actor only): the actor's value head is not evaluated and `values` is zeros.  The
         reference stores the actor's values (episode.py:206,218) but nothing ever reads them (learn/rnad.py:373 recomputes v
@@ -188,10 +189,13 @@ class Episodes:
         net.eval()
         time_start = time.perf_counter()
         native = packed is not None and noise_action is None and noise_chance is None and type(net).forward_logits is _MLP.forward_logits
+        if tabular is None:
+            tabular = 8 * handle.S <= T_cap * B
         if native and tabular and not keep_logits:
             # one actor evaluation per (player, state), then the whole loop natively with per-lane gathers (rnad_rollout_run_tabular)
-            table, _ = rnad_hip.mlp_forward(packed, net.width, handle.observations_table(self.obs_half), tree.max_actions, want_value=False)
-            rnad_hip.rollout_run_tabular(handle, traj, table, seed=self.seed, lane0=self.lane_offset)
+            table, vtable = rnad_hip.mlp_forward(packed, net.width, handle.observations_table(self.obs_half), tree.max_actions,
+                                                 want_value=store_values)
+            rnad_hip.rollout_run_tabular(handle, traj, table, vtable, seed=self.seed, lane0=self.lane_offset)
         elif native:
             # the actor is this package's MLP: the whole loop is enqueued natively (rnad_rollout_run)
             self.actor_logits = rnad_hip.rollout_run(handle, traj, net.width, packed, seed=self.seed, lane0=self.lane_offset,

@@ -368,11 +368,12 @@ def rollout_run(tree, traj, W, packed, seed=0, lane0=0, keep_logits=False, skip_
     return logits if keep_logits else None
 
 
-def rollout_run_tabular(tree, traj, logits_table, seed=0, lane0=0):
-    """Rollout whose actor was evaluated once per (player, state): logits_table [2S, A] (rnad_rollout_run_tabular)."""
+def rollout_run_tabular(tree, traj, logits_table, value_table=None, seed=0, lane0=0):
+    """Rollout whose actor was evaluated once per (player, state): logits_table [2S, A], value_table [2S, 1] or None
+    (rnad_rollout_run_tabular)."""
     assert logits_table.shape == (2 * tree.S, tree.A)
-    _check(lib().rnad_rollout_run_tabular(tree.ptr, C.byref(traj.c), _dp(logits_table, F32, "logits_table"), C.c_uint64(seed),
-                                          C.c_int64(lane0), _stream()))
+    _check(lib().rnad_rollout_run_tabular(tree.ptr, C.byref(traj.c), _dp(logits_table, F32, "logits_table"),
+                                          _dp(value_table, F32, "value_table", True), C.c_uint64(seed), C.c_int64(lane0), _stream()))
 
 
 def rollout_end(tree, traj):

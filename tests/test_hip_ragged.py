@@ -94,9 +94,9 @@ def test_rollout_that_skips_absorbed_lanes_keeps_every_valid_slot(half):
     net = MLP(3, 64, device=DEV)
     B = 20_000
     dense = Episodes(tree, B, seed=9, obs_half=half)
-    dense.generate(net, trim=False)
+    dense.generate(net, trim=False, tabular=False)
     skip = Episodes(tree, B, seed=9, obs_half=half)
-    skip.generate(net, trim=False, skip_absorbed=True)
+    skip.generate(net, trim=False, skip_absorbed=True, tabular=False)
     T = dense.t_eff + 1
     assert skip.t_eff == dense.t_eff
     valid = dense.indices[:T] != 0
@@ -120,9 +120,9 @@ def test_rollout_without_the_actor_value_head_changes_nothing_else():
     tree = _ragged_tree()
     net = MLP(3, 64, device=DEV)
     full = Episodes(tree, 5000, seed=4)
-    full.generate(net)
+    full.generate(net, tabular=False)
     lean = Episodes(tree, 5000, seed=4)
-    lean.generate(net, store_values=False)
+    lean.generate(net, store_values=False, tabular=False)
     assert lean.t_eff == full.t_eff
     for name in ("indices", "observations", "mask_bits", "policy", "action_idx", "rewards", "alive"):
         assert torch.equal(getattr(lean, name), getattr(full, name)), name
@@ -151,7 +151,7 @@ def test_update_that_skips_absorbed_slots_is_the_dense_update(reuse):
     grads, losses = [], []
     for skip in (False, True):
         ep = Episodes(tree, B, seed=3)
-        ep.generate(rn.net, trim=False, keep_logits=reuse, skip_absorbed=skip and not reuse)
+        ep.generate(rn.net, trim=False, keep_logits=reuse, skip_absorbed=skip and not reuse, tabular=False)
         ep._actor_tag = (id(rn.net), rn.total_steps)
         rn.skip_absorbed = skip
         rn.optimizer.zero_grad()
@@ -228,13 +228,15 @@ def test_tabular_rollout_is_the_dense_rollout(half, ragged):
     net = MLP(3, 64, device=DEV)
     B = 30_000
     dense = Episodes(tree, B, seed=11, obs_half=half)
-    dense.generate(net, trim=False)
+    dense.generate(net, trim=False, tabular=False)
     tab = Episodes(tree, B, seed=11, obs_half=half)
     tab.generate(net, trim=False, tabular=True)
     T = dense.t_eff + 1
-    for name in ("indices", "observations", "mask_bits", "policy", "action_idx", "rewards", "alive"):
+    for name in ("indices", "observations", "mask_bits", "policy", "action_idx", "rewards", "values", "alive"):
         assert torch.equal(getattr(tab, name)[:T], getattr(dense, name)[:T]), name  # absorbed lanes too: state 0 has a row as well
-    assert (tab.values == 0).all()
+    lean = Episodes(tree, B, seed=11, obs_half=half)
+    lean.generate(net, trim=False, tabular=True, store_values=False)
+    assert (lean.values == 0).all() and torch.equal(lean.policy[:T], dense.policy[:T])
 
 
 @pytest.mark.parametrize("ragged", (False, True))

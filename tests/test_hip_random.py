@@ -164,11 +164,11 @@ def test_net_evaluation_modes_agree_on_random_trees(A, C, W, tmp_path, monkeypat
             for p_ in m.parameters():
                 p_.add_(0.05 * (i + 1) * torch.randn_like(p_))
     dense = Episodes(tree, B, seed=5)
-    dense.generate(rn.net, trim=False)
+    dense.generate(rn.net, trim=False, tabular=False)
     tab = Episodes(tree, B, seed=5)
     tab.generate(rn.net, trim=False, tabular=True)
     T = dense.t_eff + 1
-    for name in ("indices", "observations", "mask_bits", "policy", "action_idx", "rewards", "alive"):
+    for name in ("indices", "observations", "mask_bits", "policy", "action_idx", "rewards", "values", "alive"):
         assert torch.equal(getattr(tab, name)[:T], getattr(dense, name)[:T]), name
     assert 8 * tree.handle().S <= T * B
     grads = {}
