@@ -292,6 +292,13 @@ int rnad_learn_fused_tabular(const rnad_tree_t *tree, int T, int64_t B, const in
                              const float *v_tab, const float *v_target_tab, const float *logit_reg_tab,
                              const float *logit_reg_tab_, const double *norm, const rnad_learn_params_t *hp, double *losses,
                              void *workspace, float *dlogit_tab, float *dv_tab, void *stream);
+/* The per-row sums alone, for per-slot gradients that were computed elsewhere (e.g. by autograd behind a table gather in
+ * nn/net.py:64-85 forward_batch): dlogit_tab[row] = sum over the slots of that row of dlogit, dv_tab likewise, slots with
+ * indices == 0 skipped, in the same reproducible fixed-point arithmetic.  workspace: rnad_row_sums_workspace(tree) bytes. */
+int64_t rnad_row_sums_workspace(const rnad_tree_t *tree);
+int rnad_row_sums(const rnad_tree_t *tree, int T, int64_t B, const int32_t *indices, const float *dlogit, const float *dv,
+                  void *workspace, float *dlogit_tab, float *dv_tab, void *stream);
+
 /* Same gathers, but dL/dlogit [T,B,A] and dL/dv [T,B] are written per slot (the bits of rnad_learn_fused): only the forward
  * evaluations are deduplicated, and a per-slot rnad_mlp_backward then gives bit-identical, reproducible weight gradients.
  * workspace: rnad_learn_gather_workspace(tree) bytes, 16-byte aligned (the five tables interleaved into one record per row,

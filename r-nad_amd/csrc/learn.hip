@@ -670,6 +670,84 @@ static int learn_fused_gather_impl(const rnad_tree_t *tree, int T, int64_t B, co
     return 0;
 }
 
+// ---------------------------------------------------------------------------------------- rnad_row_sums (stand-alone)
+namespace {
+// column maxima of |dlogit[:, a]| and |dv| over the valid slots, as float bit patterns (the fixed-point scales of k_row_sums)
+template <int A>
+__global__ __launch_bounds__(kThreads) void k_grad_maxima(int64_t N, const int32_t *__restrict__ indices, const float *__restrict__ dlogit,
+                                                          const float *__restrict__ dv, uint32_t *__restrict__ gmax) {
+    uint32_t mx[A + 1];
+#pragma unroll
+    for (int a = 0; a <= A; ++a) mx[a] = 0u;
+    for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < N; i += (int64_t)gridDim.x * kThreads) {
+        if (indices[i] == 0) continue;
+#pragma unroll
+        for (int a = 0; a < A; ++a) mx[a] = max(mx[a], __float_as_uint(fabsf(dlogit[i * A + a])));
+        mx[A] = max(mx[A], __float_as_uint(fabsf(dv[i])));
+    }
+#pragma unroll
+    for (int a = 0; a <= A; ++a) {
+        uint32_t m = mx[a];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, off, 64));
+        if ((threadIdx.x & 63) == 0 && m > __atomic_load_n(gmax + a, __ATOMIC_RELAXED)) atomicMax(gmax + a, m);
+    }
+}
+}  // namespace
+
+static int row_sums_launch(const rnad_tree_t *tree, int T, int64_t B, const int32_t *indices, const float *dlogit, const float *dv,
+                           const uint32_t *gmax, unsigned long long *acc, float *dlogit_tab, float *dv_tab, hipStream_t stream) {
+    const int A = tree->A;
+    const int64_t S = tree->S, N = (int64_t)T * B;
+    RNAD_HIP_OK(hipMemsetAsync(acc, 0, sizeof(unsigned long long) * 2 * S * (A + 1), stream));
+    if (N > 0) {
+        // persistent blocks: the LDS table of hot rows is flushed once per block, so few blocks walking many slots each
+        int cus = 256;
+        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, tree->device);
+        const size_t lds = (size_t)2 * tree->n_hot * (A + 1) * sizeof(unsigned long long);
+        const int per_cu = std::max(1, std::min(8, (int)((160 * 1024) / std::max<size_t>(lds, 1))));
+        const unsigned grid = (unsigned)std::min<int64_t>(blocks_for(N), (int64_t)cus * per_cu);
+#define RNAD_ROWSUM_LAUNCH()                                                                                                       \
+    do {                                                                                                                           \
+        auto kern = k_row_sums<kA>;                                                                                                \
+        if (lds > 64 * 1024) RNAD_HIP_OK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(kThreads), lds, stream, T, B, S, indices, dlogit, dv, gmax,                      \
+                           (const int32_t *)tree->hot_slot, (const int32_t *)tree->level_order, tree->n_hot, acc);                 \
+    } while (0)
+        RNAD_DISPATCH_A(A, RNAD_ROWSUM_LAUNCH());
+#undef RNAD_ROWSUM_LAUNCH
+    }
+    RNAD_DISPATCH_A(A, hipLaunchKernelGGL((k_tab_finish<kA>), dim3(blocks_for(2 * S)), dim3(kThreads), 0, stream, 2 * S,
+                                          (const unsigned long long *)acc, gmax, dlogit_tab, dv_tab));
+    RNAD_HIP_OK(hipGetLastError());
+    return 0;
+}
+
+// Per-row sums of given per-slot gradients (what rnad_learn_fused_tabular does after its gather pass), for callers that computed
+// dL/dlogit [T,B,A], dL/dv [T,B] themselves -- e.g. autograd through a table gather.  Slots with indices == 0 are skipped.
+// workspace: rnad_row_sums_workspace(tree) bytes, 8-byte aligned.  B <= 2^21.
+extern "C" int64_t rnad_row_sums_workspace(const rnad_tree_t *tree) {
+    if (!tree) return -1;
+    return 2 * tree->S * (tree->A + 1) * 8 + 64;
+}
+
+extern "C" int rnad_row_sums(const rnad_tree_t *tree, int T, int64_t B, const int32_t *indices, const float *dlogit, const float *dv,
+                             void *workspace, float *dlogit_tab, float *dv_tab, void *stream_) {
+    RNAD_REQUIRE(tree && indices && dlogit && dv && workspace && dlogit_tab && dv_tab, "rnad_row_sums: null argument");
+    RNAD_REQUIRE(T >= 0 && B >= 0 && B <= ((int64_t)1 << 21), "rnad_row_sums: bad shape (at most 2^21 lanes per call)");
+    hipStream_t stream = (hipStream_t)stream_;
+    const int A = tree->A;
+    const int64_t N = (int64_t)T * B;
+    unsigned long long *acc = (unsigned long long *)workspace;
+    uint32_t *gmax = (uint32_t *)((char *)workspace + 2 * tree->S * (A + 1) * 8);
+    RNAD_HIP_OK(hipMemsetAsync(gmax, 0, sizeof(uint32_t) * (A + 1), stream));
+    if (N > 0) {
+        const unsigned grid = (unsigned)std::min<int64_t>(blocks_for(N), 2048);
+        RNAD_DISPATCH_A(A, hipLaunchKernelGGL((k_grad_maxima<kA>), dim3(grid), dim3(kThreads), 0, stream, N, indices, dlogit, dv, gmax));
+    }
+    return row_sums_launch(tree, T, B, indices, dlogit, dv, gmax, acc, dlogit_tab, dv_tab, stream);
+}
+
 // Tables in, per-slot gradients out: the forward evaluations are deduplicated (2S rows instead of T*B slots), the backward is
 // not -- dlogit [T,B,A] and dv [T,B] are the bits rnad_learn_fused produces from per-slot net outputs, so a per-slot
 // rnad_mlp_backward gives bit-identical weight gradients.
@@ -715,28 +793,8 @@ extern "C" int rnad_learn_fused_tabular(const rnad_tree_t *tree, int T, int64_t 
     if (int rc = learn_fused_gather_impl(tree, T, B, indices, mask_bits, actions, rewards, mu, logit_tab, v_tab, v_target_tab,
                                          logit_reg_tab, logit_reg_tab_, norm, hp, losses, dlogit, dv, gmax, rec, stream))
         return rc;
-    RNAD_HIP_OK(hipMemsetAsync(acc, 0, sizeof(unsigned long long) * 2 * S * (A + 1), stream));
-    if (N > 0) {
-        // persistent blocks: the LDS table of hot rows is flushed once per block, so few blocks walking many slots each
-        int cus = 256;
-        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, tree->device);
-        const size_t lds = (size_t)2 * tree->n_hot * (A + 1) * sizeof(unsigned long long);
-        const int per_cu = std::max(1, std::min(8, (int)((160 * 1024) / std::max<size_t>(lds, 1))));
-        const unsigned grid = (unsigned)std::min<int64_t>(blocks_for(N), (int64_t)cus * per_cu);
-#define RNAD_ROWSUM_LAUNCH()                                                                                                       \
-    do {                                                                                                                           \
-        auto kern = k_row_sums<kA>;                                                                                                \
-        if (lds > 64 * 1024) RNAD_HIP_OK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(kThreads), lds, stream, T, B, S, indices, (const float *)dlogit, (const float *)dv,    \
-                           (const uint32_t *)gmax, (const int32_t *)tree->hot_slot, (const int32_t *)tree->level_order, tree->n_hot, acc); \
-    } while (0)
-        RNAD_DISPATCH_A(A, RNAD_ROWSUM_LAUNCH());
-#undef RNAD_ROWSUM_LAUNCH
-    }
-    RNAD_DISPATCH_A(A, hipLaunchKernelGGL((k_tab_finish<kA>), dim3(blocks_for(2 * S)), dim3(kThreads), 0, stream, 2 * S,
-                                          (const unsigned long long *)acc, (const uint32_t *)gmax, dlogit_tab, dv_tab));
-    RNAD_HIP_OK(hipGetLastError());
-    return 0;
+    (void)S;
+    return row_sums_launch(tree, T, B, indices, dlogit, dv, gmax, acc, dlogit_tab, dv_tab, stream);
 }
 
 // ---------------------------------------------------------------------------------------- gradient clipping

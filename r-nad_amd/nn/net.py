@@ -98,7 +98,27 @@ class MLP(nn.Module):
         differentiates through them: learn/vtrace.py:418, learn/rnad.py:377-382)."""
         T, B = episodes.t_eff + 1, episodes.batch_size
         A = self.max_actions
-        logits, value = self.forward_logits(episodes.observations[:T])
+        logits = value = None
+        tree = getattr(episodes, "tree", None)
+        if (tree is not None and self._fusable() and rnad_hip.mlp_backward_supported(A, self.width)
+                and episodes.indices.dtype == torch.int32 and episodes.indices.is_cuda and B <= 2**21):
+            # the observations of a trajectory are rows of the tree's observation table (one per player and state): on a tree that
+            # is small next to the batch the net is evaluated on those rows and each slot gathers its own.  Values are the per-slot
+            # evaluation's bit for bit; under autograd the weight gradients are summed per row first (rnad_row_sums), i.e. they
+            # equal the per-slot ones up to fp32 summation order.  An absorbed slot (index 0) gets the row of state 0, whose
+            # observation differs from the zero padding of a collated batch -- those slots are masked by every consumer.
+            handle = tree.handle()
+            if 8 * handle.S <= T * B:
+                table = handle.observations_table(getattr(episodes, "obs_half", False))
+                idx = episodes.indices[:T].contiguous()
+                if torch.is_grad_enabled():
+                    logits, value = rnad_hip.TabularMLP.apply(table, idx, handle, A, self.pack(), *self._weights())
+                else:
+                    lt, vt = rnad_hip.mlp_forward(self.pack(), self.width, table, A)
+                    rows = (idx.long() + (torch.arange(T, device=idx.device) & 1).view(T, 1) * handle.S).reshape(-1)
+                    logits, value = lt.index_select(0, rows), vt.index_select(0, rows)
+        if logits is None:
+            logits, value = self.forward_logits(episodes.observations[:T])
         mask_bits = getattr(episodes, "mask_bits", None)
         if mask_bits is not None:
             policy, log_policy = rnad_hip.policy_head(logits.detach(), mask_bits=mask_bits[:T].reshape(-1), want_log=True)

@@ -63,6 +63,7 @@ def lib():
         _lib.rnad_compact_workspace.restype = C.c_int64
         _lib.rnad_learn_tabular_workspace.restype = C.c_int64
         _lib.rnad_learn_gather_workspace.restype = C.c_int64
+        _lib.rnad_row_sums_workspace.restype = C.c_int64
     return _lib
 
 
@@ -471,6 +472,41 @@ def learn_fused_tabular(tree, indices, mask_bits, actions, rewards, mu, logit_ta
                                           _dp(norm, F64, "norm"), C.byref(hp), _dp(losses, F64, "losses"), _dp(ws, F64, "workspace"),
                                           _dp(dlogit, F32, "dlogit_tab"), _dp(dv, F32, "dv_tab"), _stream()))
     return dlogit, dv, losses
+
+
+def row_sums(tree, indices, dlogit, dv):
+    """Per-(player, state)-row sums of per-slot gradients dlogit [T,B,A], dv [T,B] (rnad_row_sums) -> [2S, A], [2S, 1]."""
+    T, B = indices.shape
+    A, S, dev = tree.A, tree.S, indices.device
+    ws = torch.empty((int(lib().rnad_row_sums_workspace(tree.ptr)) // 8 + 1,), dtype=F64, device=dev)
+    out_l = torch.empty((2 * S, A), dtype=F32, device=dev)
+    out_v = torch.empty((2 * S, 1), dtype=F32, device=dev)
+    _check(lib().rnad_row_sums(tree.ptr, T, C.c_int64(B), _dp(indices, I32, "indices"), _dp(dlogit, F32, "dlogit"), _dp(dv, F32, "dv"),
+                               _dp(ws, F64, "workspace"), _dp(out_l, F32, "dlogit_tab"), _dp(out_v, F32, "dv_tab"), _stream()))
+    return out_l, out_v
+
+
+class TabularMLP(torch.autograd.Function):
+    """logits [T*B, A], value [T*B, 1] of an MLP on a trajectory whose observations are rows of the tree's observation table:
+    the net is evaluated on the 2S rows and every slot gathers its row; backward sums the per-slot gradients per row
+    (rnad_row_sums) and differentiates through the 2S evaluations.  apply(table, indices [T,B] int32, tree, A, packed, *weights)."""
+
+    @staticmethod
+    def forward(ctx, table, indices, tree, A, packed, *weights):
+        T, B = indices.shape
+        logit_tab, v_tab = mlp_forward(packed, weights[0].shape[0], table, A)
+        rows = (indices.long() + (torch.arange(T, device=indices.device) & 1).view(T, 1) * tree.S).reshape(-1)
+        ctx.A, ctx.tree = A, tree
+        ctx.save_for_backward(table, indices, packed, *weights)
+        return logit_tab.index_select(0, rows), v_tab.index_select(0, rows)
+
+    @staticmethod
+    def backward(ctx, dlogits, dvalue):
+        table, indices, packed, *weights = ctx.saved_tensors
+        T, B = indices.shape
+        dl_tab, dv_tab = row_sums(ctx.tree, indices, dlogits.contiguous().view(T, B, ctx.A), dvalue.contiguous().view(T, B))
+        grads = mlp_backward(packed, weights, table, ctx.A, dl_tab, dv_tab)
+        return (None, None, None, None, None, *grads)
 
 
 def learn_fused_gather(tree, indices, mask_bits, actions, rewards, mu, logit_tab, v_tab, v_target_tab, logit_reg_tab, logit_reg_tab_,

@@ -383,3 +383,42 @@ def test_logged_statistics_do_not_depend_on_the_mode(ragged):
         else:
             assert logs["forward"][k] == want and logs[True][k] == want, k
     assert all(torch.equal(a, b) for a, b in zip(grads["forward"], grads[False]))
+
+
+@pytest.mark.parametrize("ragged", (False, True))
+def test_forward_batch_through_the_observation_table(ragged):
+    """MLP.forward_batch (the reference learner's entry point, net.py:64-85) on a small tree: values are the per-slot
+    evaluation's bits, autograd gives the per-slot weight gradients up to summation order."""
+    from environment.episode import Episodes
+    from environment.tree import Tree
+    from nn.net import MLP
+
+    torch.manual_seed(4)
+    if ragged:
+        tree = _ragged_tree()
+    else:
+        tree = Tree(device=DEV, max_actions=3, max_transitions=1, depth_bound=4)
+        tree.generate_native(seed=2)
+    net = MLP(3, 64, device=DEV)
+    ep = Episodes(tree, 1 << 13, seed=2)
+    ep.generate(net)
+    T, B, A = ep.t_eff + 1, ep.batch_size, 3
+    assert 8 * tree.handle().S <= T * B
+    logit, log_pi, pi, v = net.forward_batch(ep)                       # through the table, with autograd
+    want_l, want_v = net.forward_logits(ep.observations[:T])           # per slot (FusedMLP autograd node)
+    assert torch.equal(logit.reshape(-1, A), want_l) and torch.equal(v.reshape(-1, 1), want_v)
+    with torch.no_grad():
+        l2, lp2, p2, v2 = net.forward_batch(ep)
+    assert torch.equal(l2, logit) and torch.equal(p2, pi) and torch.equal(lp2, log_pi) and torch.equal(v2, v)
+    g = torch.Generator().manual_seed(1)
+    valid = (ep.indices[:T] != 0).float()
+    dl = (torch.randn((T, B, A), generator=g).to(DEV) * valid[..., None]).contiguous()
+    dv = (torch.randn((T, B, 1), generator=g).to(DEV) * valid[..., None]).contiguous()
+    net.zero_grad()
+    torch.autograd.backward([logit, v], [dl, dv])
+    got = [p_.grad.clone() for p_ in net.parameters()]
+    net.zero_grad()
+    torch.autograd.backward([want_l, want_v], [dl.view(-1, A), dv.view(-1, 1)])
+    for a, p_ in zip(got, net.parameters()):
+        scale = float(p_.grad.abs().max()) + 1e-12
+        np.testing.assert_allclose(a.cpu().numpy() / scale, p_.grad.cpu().numpy() / scale, rtol=0, atol=1e-5)
