@@ -44,6 +44,20 @@ struct Trans {
 // node row: expected_value[A*A] | legal bits lo | legal bits hi | pad to a multiple of 4 floats (16 B)
 inline int node_stride_floats(int A) { return (A * A + 2 + 3) & ~3; }
 
+// Makes `device` current for the scope and restores the caller's device afterwards (entry points that own a device id).
+struct DeviceGuard {
+    int prev = -1;
+    bool ok = true;
+    explicit DeviceGuard(int device) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != device) ok = hipSetDevice(device) == hipSuccess;
+        else prev = -1;
+    }
+    ~DeviceGuard() {
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+};
+
 // Event bracketing for bench.py's roofline leg.
 enum ProfKernel { PROF_OBSERVE = 0, PROF_ACT = 1, PROF_LEARN = 2, PROF_MLP = 3, PROF_MLP_BWD = 4, PROF_COUNT = 5 };
 struct ProfScope {

@@ -120,7 +120,9 @@ extern "C" int rnad_nashconv(const rnad_tree_t *tree, const float *joint_policy,
     const int top = tree->level_of[(size_t)state_index];
     RNAD_REQUIRE(top >= 0, "rnad_nashconv: state %lld is not reachable from the root", (long long)state_index);
     hipStream_t stream = (hipStream_t)stream_;
-    RNAD_HIP_OK(hipSetDevice(tree->device));
+    DeviceGuard guard(tree->device);
+    RNAD_REQUIRE(guard.ok, "rnad_nashconv: cannot select device %d", tree->device);
+    RNAD_REQUIRE(tree->A >= 1 && tree->A <= RNAD_MAX_ACTIONS, "rnad_nashconv: bad tree");  // nothing below may return early: `mark` is owned here
     uint8_t *mark = nullptr;
     RNAD_HIP_OK(hipMallocAsync((void **)&mark, (size_t)tree->S, stream));
     RNAD_HIP_OK(hipMemsetAsync(mark, 0, (size_t)tree->S, stream));

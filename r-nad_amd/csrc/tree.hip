@@ -162,7 +162,8 @@ extern "C" int rnad_tree_create(rnad_tree_t **out, int64_t S, int C, int A, cons
         return 1;
     };
     hipError_t e;
-    if ((e = hipSetDevice(device)) != hipSuccess) return fail(e, "hipSetDevice");
+    DeviceGuard guard(device);  // the caller's current device is restored on return
+    if (!guard.ok) return fail(hipErrorInvalidDevice, "hipSetDevice");
     if ((e = hipMalloc((void **)&tree->node, node.size() * sizeof(float))) != hipSuccess) return fail(e, "hipMalloc(node)");
     if ((e = hipMalloc((void **)&tree->trans, trans.size() * sizeof(Trans))) != hipSuccess) return fail(e, "hipMalloc(trans)");
     if ((e = hipMalloc((void **)&tree->level_order, order.size() * sizeof(int32_t))) != hipSuccess)

@@ -27,6 +27,7 @@ import environment.tree as tree
 import nn.net as net
 import util.metric as metric
 import rnad_hip
+from learn import checkpoint
 
 
 def _save_root():
@@ -34,7 +35,9 @@ def _save_root():
 
 
 def _dist_on():
-    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    """Data parallel whenever a process group exists -- also a one-rank group: the collectives then still run (through RCCL on
+    a GPU), which is what lets a single-GPU box exercise the exact call sequence of the N-rank update."""
+    return dist.is_available() and dist.is_initialized()
 
 
 class RNaD:
@@ -118,6 +121,7 @@ class RNaD:
         self.net_reg = None
         self.net_reg_ = None
         self.last_log = None  # scalars of the most recent logged step (the reference sends them to wandb)
+        self.keep_last_log = False  # True: compute them every log_mod steps even without wandb (about ten host syncs per logged step)
         # On-policy shortcut (off by default): with the default one-batch buffer the learner net of __learn IS the actor of the
         # rollout that just finished, with unchanged weights, so forward_batch(net) (rnad.py:373) recomputes bit-identical
         # logits / values; when True they are taken from the rollout and only the backward runs.
@@ -181,113 +185,102 @@ class RNaD:
         return torch.optim.Adam(self.net.parameters(), lr=self.lr, betas=(float(self.b1_adam), float(self.b2_adam)),
                                 eps=self.epsilon_adam, fused=self.device.type == "cuda" if isinstance(self.device, torch.device) else False)
 
-    # ------------------------------------------------------------------ reference learn/rnad.py:190-280
-    def __initialize(self):
-        logging.info("Initializing R-NaD run: {}".format(self.directory_name))
-        if self._rank == 0:
-            os.makedirs(self.directory, exist_ok=True)
+    # ------------------------------------------------------------------ run directory: fresh start or resume
+    # Behaviour of reference learn/rnad.py:190-319 (a run directory with checkpoints is resumed from its last one, anything else
+    # starts fresh and writes `params` + checkpoint 0/0), rebuilt around learn/checkpoint.RunStore.  Under torch.distributed the
+    # ranks share the directory: rank 0 alone looks at the disk and decides, the others receive the decision, and every read of a
+    # file rank 0 writes sits behind a barrier.
+    def _state_nets(self):
+        return {"net": self.net, "net_target": self.net_target, "net_reg": self.net_reg, "net_reg_": self.net_reg_}
+
+    def _barrier(self):
         if _dist_on():
             dist.barrier()
-        saved_updates = [int(os.path.relpath(f.path, self.directory)) for f in os.scandir(self.directory) if f.is_dir()] \
-            if os.path.isdir(self.directory) else []
-        if not saved_updates:
-            self.tree_hash = self.tree.hash
-            if self._rank == 0:
-                params_dict = {key: self.__dict__[key] for key in self.saved_keys}
-                torch.save(params_dict, os.path.join(self.directory, "params"))
-                os.makedirs(os.path.join(self.directory, "0"), exist_ok=True)
-            self.net = self.__new_net()
-            if self.use_same_init_net_as:
-                net_dir = os.path.join(_save_root(), "saved_runs", self.use_same_init_net_as, "0", "0")
-                checkpoint = torch.load(net_dir, map_location=self.device, weights_only=False)
-                self.net.load_state_dict(checkpoint["net"])
-                logging.info("Loading init net from {}".format(self.use_same_init_net_as))
-            self._sync_from_rank0(self.net)
-            self.net.train()
-            self.net_target = self.__new_net()
-            self.net_target.load_state_dict(self.net.state_dict())
-            self.net_reg = self.__new_net()
-            self.net_reg.load_state_dict(self.net.state_dict())
-            self.net_reg_ = self.__new_net()
-            self.net_reg_.load_state_dict(self.net.state_dict())
-            self.optimizer = self.__new_optimizer()
-            self.m = 0
-            self.n = 0
-            self.__save_checkpoint()
-        else:
-            params_dict = torch.load(os.path.join(self.directory, "params"), weights_only=False)
-            for key, value in params_dict.items():
-                if key == "directory_name":
-                    params_dict[key] = self.directory_name
-                    continue
-                if key == "device":
-                    continue
-                if torch.is_tensor(value):
-                    params_dict[key] = params_dict[key].to(self.device)
-                if key == "tree_hash":
-                    assert params_dict["tree_hash"] == self.tree.hash  # resuming fails if the trees differ
-                self.__dict__[key] = value
-            if self._rank == 0:
-                torch.save(params_dict, os.path.join(self.directory, "params"))
-            self.m = max(saved_updates)
-            last_update = os.path.join(self.directory, str(self.m))
-            checkpoints = [int(os.path.relpath(f.path, last_update)) for f in os.scandir(last_update) if not f.is_dir()]
-            self.n = max(checkpoints)
-            self.__load_checkpoint(self.m, self.n)
 
+    def __initialize(self):
+        logging.info("R-NaD run '%s' in %s", self.directory_name, self.directory)
+        self._store = store = checkpoint.RunStore(self.directory)
+        decision = [store.latest() if self._rank == 0 else None]
+        if _dist_on():
+            dist.broadcast_object_list(decision, src=0)
+        resume_from = decision[0]
+        if resume_from is None:
+            self._start_fresh()
+        else:
+            self._resume_from(*resume_from)
+        self._barrier()  # rank 0 has finished writing before anyone returns (and possibly re-reads the directory)
         if self.wandb:
             import wandb
 
-            wandb.init(resume=bool(saved_updates), project="RNaD", config={key: self.__dict__[key] for key in self.saved_keys})
+            wandb.init(resume=resume_from is not None, project="RNaD", config={key: self.__dict__[key] for key in self.saved_keys})
             wandb.run.name = self.directory_name
 
-    # ------------------------------------------------------------------ reference learn/rnad.py:282-319
-    def __load_checkpoint(self, m, n):
-        saved_dict = torch.load(os.path.join(self.directory, str(m), str(n)), map_location=self.device, weights_only=False)
-        self.total_steps = saved_dict["total_steps"]
-        self.net_params = saved_dict["net_params"]
+    def _start_fresh(self):
+        self.tree_hash = self.tree.hash
+        self.m = self.n = 0
         self.net = self.__new_net()
-        self.net.load_state_dict(saved_dict["net"])
-        self.net_target = self.__new_net()
-        self.net_target.load_state_dict(saved_dict["net_target"])
-        self.net_reg = self.__new_net()
-        self.net_reg.load_state_dict(saved_dict["net_reg"])
-        self.net_reg_ = self.__new_net()
-        self.net_reg_.load_state_dict(saved_dict["net_reg_"])
+        if self.use_same_init_net_as:  # share the initial weights of another run: its checkpoint 0/0 (rnad.py:213-224)
+            other = checkpoint.RunStore(os.path.join(_save_root(), "saved_runs", self.use_same_init_net_as))
+            self.net.load_state_dict(other.read(0, 0, map_location=self.device)["net"])
+            logging.info("initial net taken from run '%s'", self.use_same_init_net_as)
+        self._sync_from_rank0(self.net)
+        self.net.train()
+        for name in ("net_target", "net_reg", "net_reg_"):  # all four nets start equal (rnad.py:226-231)
+            clone = self.__new_net()
+            clone.load_state_dict(self.net.state_dict())
+            setattr(self, name, clone)
         self.optimizer = self.__new_optimizer()
-        self.optimizer.load_state_dict(saved_dict["optimizer"])
+        if self._rank == 0:
+            self._store.write_params({key: self.__dict__[key] for key in self.saved_keys})
+        self.__save_checkpoint()
+
+    def _resume_from(self, m, n):
+        params = self._store.read_params()
+        if "tree_hash" in params and params["tree_hash"] != self.tree.hash:
+            raise AssertionError(f"run '{self.directory_name}' was trained on another tree (hash {params['tree_hash']} != {self.tree.hash})")
+        for key, value in params.items():
+            if key in ("directory_name", "device"):  # where the run lives now, not where it was started
+                continue
+            self.__dict__[key] = value.to(self.device) if torch.is_tensor(value) else value
+        self._barrier()  # every rank has read `params` before rank 0 rewrites it
+        if self._rank == 0 and params.get("directory_name") != self.directory_name:
+            self._store.write_params(dict(params, directory_name=self.directory_name))
+        self.m, self.n = m, n
+        saved = self._store.read(m, n, map_location=self.device)
+        self.total_steps = saved["total_steps"]
+        self.net_params = saved["net_params"]
+        for name in ("net", "net_target", "net_reg", "net_reg_"):
+            module = self.__new_net()
+            module.load_state_dict(saved[name])
+            setattr(self, name, module)
+        self.optimizer = self.__new_optimizer()
+        self.optimizer.load_state_dict(saved["optimizer"])
+        logging.info("resumed at m=%d n=%d (step %d)", m, n, self.total_steps)
 
     def __save_checkpoint(self):
         if self._rank != 0:
             return
-        saved_dict = {
-            "total_steps": self.total_steps,
-            "net_params": self.net_params,
-            "net": self.net.state_dict(),
-            "net_target": self.net_target.state_dict(),
-            "net_reg": self.net_reg.state_dict(),
-            "net_reg_": self.net_reg_.state_dict(),
-            "optimizer": self.optimizer.state_dict(),
-        }
-        os.makedirs(os.path.join(self.directory, str(self.m)), exist_ok=True)
-        torch.save(saved_dict, os.path.join(self.directory, str(self.m), str(self.n)))
+        payload = {name: module.state_dict() for name, module in self._state_nets().items()}
+        payload.update(total_steps=self.total_steps, net_params=self.net_params, optimizer=self.optimizer.state_dict())
+        self._store.write(self.m, self.n, payload)
 
-    # ------------------------------------------------------------------ reference learn/rnad.py:321-332
-    def __get_update_info(self):
-        bounding_indices = [i for i, bound in enumerate(self.bounds) if bound > self.m]
-        if not bounding_indices:
-            return False, 0
-        return True, self.delta_m[min(bounding_indices)]
+    # ------------------------------------------------------------------ schedule (reference learn/rnad.py:321-332)
+    def _steps_of_current_update(self):
+        """delta_m of regularisation update self.m: bounds[i] is the first m that belongs to phase i + 1.  None: training is over."""
+        for bound, steps in zip(self.bounds, self.delta_m):
+            if self.m < bound:
+                return steps
+        return None
 
-    # ------------------------------------------------------------------ reference learn/rnad.py:334-351
-    def __nashconv(self) -> float:
-        logging.info("NashConv at m: {}, n: {}, step {}".format(self.m, self.n, self.total_steps))
-        nashconv_data = metric.NashConvData(self.tree)
-        nashconv_data.get_nashconv_from_net(self.tree, self.net_target)
-        mean_nashconv: Dict[int, float] = nashconv_data.mean_nashconv_by_depth()
-        for depth, nashconv in mean_nashconv.items():
-            logging.info("depth:{}, nash_conv:{}".format(depth, nashconv))
-        return (nashconv_data.row_best[1] + nashconv_data.col_best[1]).item()
+    # ------------------------------------------------------------------ evaluation (reference learn/rnad.py:334-351)
+    def _evaluate_nashconv(self) -> float:
+        """NashConv of the target net over the whole tree (GPU level sweeps, util/metric.py), logged per depth like the reference."""
+        data = metric.NashConvData(self.tree)
+        data.get_nashconv_from_net(self.tree, self.net_target)
+        logging.info("NashConv at m=%d n=%d step %d", self.m, self.n, self.total_steps)
+        for depth, mean in data.mean_nashconv_by_depth().items():
+            logging.info("  depth %s: %s", depth, mean)
+        return (data.row_best[1] + data.col_best[1]).item()
 
     def _grad_bucket(self, weights):
         """One flat fp32 buffer holding the learner's gradients back to back (the RCCL bucket) and per-tensor views of it."""
@@ -531,15 +524,15 @@ class RNaD:
         rank = self._rank
         assert self.batch_size % self._world == 0, "batch_size must be divisible by the number of GPUs"
         for _ in range(max_updates):
-            may_resume, delta_m = self.__get_update_info()
-            if not may_resume:
+            delta_m = self._steps_of_current_update()
+            if delta_m is None:
                 return
             logging.info("m: {}, delta_m: {}".format(self.m, delta_m))
             buffer.max_size = self.n_batches_per_buffer
 
             if self.m % expl_mod == 0 and self.n == 0 and self.m != 0:
                 if rank == 0:
-                    nashconv = self.__nashconv()
+                    nashconv = self._evaluate_nashconv()
                     self.nashconv_history.append((self.m, self.total_steps, nashconv))
                     if self.wandb:
                         import wandb
@@ -552,7 +545,8 @@ class RNaD:
                 alpha = 1 if self.n > delta_m / 2 else self.n * 2 / delta_m  # rnad.py:497
                 if self.n % checkpoint_mod == 0:
                     self.__save_checkpoint()
-                log = {} if (self.n % log_mod == 0 and (self.wandb or log_mod < 10**8)) else None
+                # the reference logs only with wandb on (rnad.py:509); keep_last_log asks for the same scalars in RNaD.last_log
+                log = {} if (self.n % log_mod == 0 and (self.wandb or self.keep_last_log)) else None
                 self.train_step(buffer, alpha, log=log)
                 if log:
                     self.last_log = dict(log, m=self.m, n=self.n, total_steps=self.total_steps)

@@ -43,6 +43,43 @@ class LearnParams(C.Structure):
 
 
 _lib = None
+HEADER_PATH = os.path.join(_HERE, "..", "..", "include", "rnad_hip.h")
+
+_SCALARS = {"int": C.c_int, "int32_t": C.c_int32, "int64_t": C.c_int64, "uint64_t": C.c_uint64, "float": C.c_float,
+            "double": C.c_double}
+
+
+def _ctype_of(decl, what):
+    """C parameter / return declaration -> ctypes type.  Every pointer travels as c_void_p (tensor.data_ptr(), byref(struct),
+    arrays of pointers, or None)."""
+    decl = decl.strip()
+    if "*" in decl:
+        return C.c_char_p if what == "return" and "char" in decl else C.c_void_p
+    words = [w for w in decl.replace("const", " ").split()]
+    base = words[0] if what == "return" else (words[-2] if len(words) > 1 else words[-1])
+    if base == "void":
+        return None
+    if base not in _SCALARS:
+        raise RnadHipError(f"include/rnad_hip.h: cannot map '{decl}' to a ctypes type")
+    return _SCALARS[base]
+
+
+def header_prototypes(path=HEADER_PATH):
+    """{name: (restype, [argtypes])} for every function include/rnad_hip.h declares, so that the binding can never disagree with
+    the ABI about an argument's width (a bare Python int would otherwise travel as a C int)."""
+    import re
+
+    src = open(path).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    src = re.sub(r"//[^\n]*", "", src)
+    src = re.sub(r"^\s*#.*$", "", src, flags=re.M)
+    src = re.sub(r"typedef\s+struct\s+\w+\s*\{.*?\}\s*\w+\s*;", "", src, flags=re.S)
+    protos = {}
+    for m in re.finditer(r"([A-Za-z_][A-Za-z_0-9 \*]*?)\b(rnad_[a-z_0-9]+)\s*\(([^)]*)\)\s*;", src):
+        ret, name, params = m.group(1), m.group(2), " ".join(m.group(3).split())
+        args = [] if params in ("", "void") else [_ctype_of(a, "param") for a in params.split(",")]
+        protos[name] = (_ctype_of(ret, "return"), args)
+    return protos
 
 
 def lib():
@@ -53,17 +90,11 @@ def lib():
                 f"{os.path.normpath(SO_PATH)} is missing: build it with `make -C r-nad_amd/csrc` "
                 "(or __graft_entry__.build()).  There is no CPU fallback for the R-NaD hot path."
             )
-        _lib = C.CDLL(SO_PATH)
-        _lib.rnad_last_error.restype = C.c_char_p
-        _lib.rnad_tree_info.restype = C.c_int64
-        _lib.rnad_tree_generate.restype = C.c_int64
-        _lib.rnad_tree_destroy.restype = None
-        _lib.rnad_mlp_backward_workspace.restype = C.c_int64
-        _lib.rnad_mlp_packed_size.restype = C.c_int64
-        _lib.rnad_compact_workspace.restype = C.c_int64
-        _lib.rnad_learn_tabular_workspace.restype = C.c_int64
-        _lib.rnad_learn_gather_workspace.restype = C.c_int64
-        _lib.rnad_row_sums_workspace.restype = C.c_int64
+        handle = C.CDLL(SO_PATH)
+        for name, (restype, argtypes) in header_prototypes().items():
+            fn = getattr(handle, name)  # AttributeError: the library is older than the header
+            fn.restype, fn.argtypes = restype, argtypes
+        _lib = handle
     return _lib
 
 
@@ -84,6 +115,10 @@ def _dp(t, dtype, name, optional=False):
         raise RnadHipError(f"{name}: tensor required")
     if not t.is_cuda:
         raise RnadHipError(f"{name}: expected a GPU tensor, got device {t.device} (no CPU path)")
+    if t.get_device() != torch._C._cuda_getDevice():
+        # kernels are launched on HIP's current device and on torch's current stream of that device
+        raise RnadHipError(f"{name}: tensor lives on {t.device} but the current device is cuda:{torch.cuda.current_device()}; "
+                           "call torch.cuda.set_device (or use `with torch.cuda.device(...)`) first")
     if t.dtype != dtype:
         raise RnadHipError(f"{name}: expected dtype {dtype}, got {t.dtype}")
     if not t.is_contiguous():

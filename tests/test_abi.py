@@ -31,6 +31,26 @@ def test_library_loads_and_exports_every_declared_symbol():
     assert lib.rnad_version() >= 1
 
 
+def test_binding_takes_every_prototype_from_the_header():
+    """rnad_hip.lib() sets restype AND argtypes of every declared function from include/rnad_hip.h, so a Python int handed to an
+    int64_t / uint64_t parameter is converted at full width instead of silently travelling as a C int."""
+    import rnad_hip
+
+    lib = rnad_hip.lib()
+    protos = rnad_hip.header_prototypes()
+    assert sorted(protos) == declared_functions()
+    for name, (restype, argtypes) in protos.items():
+        fn = getattr(lib, name)
+        assert fn.argtypes is not None and list(fn.argtypes) == argtypes, name
+        assert fn.restype == restype, name
+    i64, u64, f32, ptr, i32 = ctypes.c_int64, ctypes.c_uint64, ctypes.c_float, ctypes.c_void_p, ctypes.c_int
+    assert list(lib.rnad_sample.argtypes) == [i64, i32, ptr, ptr, u64, i64, i32, i32, ptr, ptr]
+    assert list(lib.rnad_clip_grad_norm.argtypes) == [i64, ptr, f32, ptr, ptr]
+    assert lib.rnad_tree_info.restype == i64 and lib.rnad_last_error.restype == ctypes.c_char_p and lib.rnad_tree_destroy.restype is None
+    # full-width conversion of a bare Python int (no c_int64 wrapper at the call site)
+    assert lib.rnad_compact_workspace(2**40) == 2**40 // 2048 + 1
+
+
 def test_binding_fails_loudly_without_a_gpu_tensor():
     import pytest
     import torch

@@ -128,3 +128,55 @@ def test_two_rank_gradients_equal_reference_full_batch(tmp_path):
         want = g["g_net_" + k.replace(".", "_")]
         scale = np.abs(want).max() + 1e-12
         np.testing.assert_allclose(r0[k], want, rtol=1e-4, atol=2e-6 * scale, err_msg=k)
+
+
+# ---------------------------------------------------------------------------------------- shared run directory
+def _init_worker(rank, world, port, root):
+    """Two ranks, ONE saved_runs directory: fresh start, then a resume from a later checkpoint that only rank 0 wrote."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RNAD_SAVE_DIR=root)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from environment.tree import Tree
+        from learn.rnad import RNaD
+
+        tg = load_tree("c1")
+        tree = Tree(max_actions=2, max_transitions=1, depth_bound=3)
+        tree.hash = 1234
+        torch.manual_seed(100 + rank)  # different initial nets per rank unless rank 0's are broadcast
+
+        def make():
+            return RNaD(tree=tree, device=torch.device("cpu"), directory_name="shared", batch_size=64, eta=0.2, b1_adam=0.0,
+                        net_params={"type": "MLP", "max_actions": 2, "width": 16})
+
+        rn = make()
+        rn.initialize()
+        assert (rn.m, rn.n) == (0, 0)
+        store_dir = os.path.join(root, "saved_runs", "shared")
+        assert os.path.exists(os.path.join(store_dir, "params")) and os.path.exists(os.path.join(store_dir, "0", "0"))  # behind the barrier
+        w = torch.cat([p.detach().reshape(-1) for p in rn.net.parameters()])
+        both = [torch.zeros_like(w) for _ in range(world)]
+        dist.all_gather(both, w)
+        assert torch.equal(both[0], both[1]), "ranks must start from rank 0's weights"
+        # rank 0 trains on (pretend) and checkpoints at (m, n) = (1, 2); then everybody restarts
+        rn.m, rn.n, rn.total_steps = 1, 2, 7
+        with torch.no_grad():
+            for p in rn.net.parameters():
+                p.add_(1.0)
+        rn._RNaD__save_checkpoint()
+        dist.barrier()
+        rn2 = make()
+        rn2.lr = 123.0  # overwritten by the stored params on resume
+        rn2.initialize()
+        assert (rn2.m, rn2.n, rn2.total_steps) == (1, 2, 7) and rn2.lr == rn.lr
+        w2 = torch.cat([p.detach().reshape(-1) for p in rn2.net.parameters()])
+        assert torch.equal(w2, both[0] + 1.0)
+        assert sorted(os.listdir(store_dir)) == ["0", "1", "params"], os.listdir(store_dir)  # no temporary files left behind
+        del tg
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_two_ranks_share_one_run_directory(tmp_path):
+    """every rank used to scan the directory on its own while rank 0 was writing into it."""
+    mp.spawn(_init_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)

@@ -30,9 +30,9 @@ def test_nashconv_curve_matches_reference_band(tmp_path, monkeypatch, tabular):
                   net_params={"type": "MLP", "max_actions": 3, "width": 2**8})
         rn.initialize()
         rn.tabular = tabular
-        nc0 = rn._RNaD__nashconv()
+        nc0 = rn._evaluate_nashconv()
         rn._RNaD__resume(checkpoint_mod=10**9, expl_mod=1, log_mod=10**9)
-        nc = [nc0] + [v for _, _, v in rn.nashconv_history] + [rn._RNaD__nashconv()]
+        nc = [nc0] + [v for _, _, v in rn.nashconv_history] + [rn._evaluate_nashconv()]
         assert len(nc) == M + 1
         mine.append(nc)
     mine = np.array(mine)

@@ -63,23 +63,48 @@ def test_two_ranks_equal_one_process(tmp_path):
 
 
 def _nccl_single(rank, port, tmp):
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0",
+                      NCCL_DEBUG="INFO", NCCL_DEBUG_SUBSYS="COLL", NCCL_DEBUG_FILE=os.path.join(tmp, "rccl_%p.log"))
     torch.cuda.set_device(0)
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+    calls = {"all_reduce": 0, "broadcast": 0}
+    real_ar, real_bc = dist.all_reduce, dist.broadcast
+
+    def counting_all_reduce(t, *a, **kw):
+        assert t.is_cuda  # the RCCL backend only takes device buffers
+        calls["all_reduce"] += 1
+        return real_ar(t, *a, **kw)
+
+    def counting_broadcast(t, *a, **kw):
+        assert t.is_cuda
+        calls["broadcast"] += 1
+        return real_bc(t, *a, **kw)
+
+    dist.all_reduce, dist.broadcast = counting_all_reduce, counting_broadcast
     try:
         params, log = _one_step(tmp, "nccl1")
-        np.savez(os.path.join(tmp, "nccl1.npz"), loss_v=log["loss_v"], loss_nerd=log["loss_nerd"], **params)
+        np.savez(os.path.join(tmp, "nccl1.npz"), loss_v=log["loss_v"], loss_nerd=log["loss_nerd"], n_all_reduce=calls["all_reduce"],
+                 n_broadcast=calls["broadcast"], **params)
     finally:
+        dist.all_reduce, dist.broadcast = real_ar, real_bc
         dist.destroy_process_group()
 
 
 @pytest.mark.timeout(600)
-def test_one_rank_rccl_group_runs_the_collective_code_path(tmp_path):
-    """The box has one GPU, so RCCL cannot be given two ranks here; a one-rank `nccl` group still drives every collective call
-    of the update (f64 normaliser all-reduce with async_op, int64 seed broadcast, fp32 gradient bucket) through RCCL."""
+def test_one_rank_rccl_group_runs_every_collective_of_the_update(tmp_path):
+    """The box has one GPU, so RCCL cannot be given two ranks here; with a one-rank `nccl` group RNaD still takes its data-parallel
+    branch (learn/rnad.py `_dist_on`), so every collective of the N-rank update goes through RCCL: the initial weight broadcasts,
+    the int64 seed broadcast, the async f64 normaliser all-reduce, the fp32 gradient bucket and the logged losses.  Checked twice:
+    by counting the calls, and in RCCL's own NCCL_DEBUG=INFO/COLL log."""
     single, log = _one_step(str(tmp_path), "single2")
     mp.spawn(_nccl_single, args=(_free_port(), str(tmp_path)), nprocs=1, join=True)
     got = np.load(tmp_path / "nccl1.npz")
     for k, want in single.items():
-        np.testing.assert_array_equal(got[k], want)
+        np.testing.assert_array_equal(got[k], want)  # a one-rank sum changes nothing
     assert abs(float(got["loss_v"]) - log["loss_v"]) < 1e-9  # the logged scalars are fp64 atomic sums: last bits vary
+    assert int(got["n_all_reduce"]) >= 3, "normalisers, gradient bucket and logged losses must be all-reduced"
+    assert int(got["n_broadcast"]) >= 9, "8 weight tensors + the rollout seed must be broadcast from rank 0"
+    text = "".join(p.read_text(errors="replace") for p in tmp_path.glob("rccl_*.log"))
+    n_ar = sum(1 for ln in text.splitlines() if "AllReduce" in ln and "opCount" in ln)
+    n_bc = sum(1 for ln in text.splitlines() if "Broadcast" in ln and "opCount" in ln)
+    assert n_ar >= 3 and n_bc >= 9, f"RCCL logged {n_ar} AllReduce / {n_bc} Broadcast operations:\n{text[-2000:]}"

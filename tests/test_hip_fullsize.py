@@ -356,6 +356,7 @@ def test_off_policy_replay_buffer_path(tmp_path, monkeypatch):
     np.random.seed(1)
     rn = RNaD(tree=tree, device=dev, directory_name="offpolicy", batch_size=2048, eta=0.2, b1_adam=0.0, lr=1e-3, bounds=[1], delta_m=[6],
               n_batches_per_buffer=2, buffer_mod=2, net_params={"type": "MLP", "max_actions": 3, "width": 64})
+    rn.keep_last_log = True
     rn.run(checkpoint_mod=10**9, expl_mod=1, log_mod=1)
     assert rn.total_steps == 6 and rn.m == 1
     assert all(torch.isfinite(p).all() for p in rn.net.parameters())
