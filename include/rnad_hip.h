@@ -310,6 +310,45 @@ int rnad_learn_fused_gather(const rnad_tree_t *tree, int T, int64_t B, const int
                             const float *logit_reg_tab_, const double *norm, const rnad_learn_params_t *hp, double *losses,
                             void *workspace, float *dlogit, float *dv, void *stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Bucketed tabular pipeline (csrc/bucket.hip)  --  environment/episode.py:175-230 (Episodes.generate) and learn/rnad.py:365-425
+ * again, for trees that are small next to the batch, organised so that the per-(player, state) sums of the tabular update need
+ * no global atomics: lanes are grouped by the state they reach at depth k ("bucket"; state ids are DFS pre-order, tree.py:311-330,
+ * so the subtree below state s is the id range [s, s + size)), the trajectory buffers are written in bucket order, and one
+ * workgroup per bucket adds its lanes' gradients up in an LDS table indexed by (state - bucket state).
+ *
+ * rnad_bucket_plan: out[0] = k (partition depth), [1] = number of buckets, [2] = number of states above the buckets, [3] = rows
+ * of a bucket's table, [4] = capacity of the work-item list (items: int32 [out[4]][4]), [5] = bytes of `scratch` for
+ * rnad_rollout_bucketed, [6] = bytes of `accumulators` for rnad_learn_bucketed (zero them once; every update leaves them zero),
+ * [7] = LDS bytes of a learner workgroup.  Non-zero return: this tree / batch cannot be bucketed (use the entry points above).
+ *
+ * rnad_rollout_bucketed: the rollout of rnad_rollout_run_tabular -- same tabular actor (logits_table row = player * S + state,
+ * logits_stride floats apart: a [2S, A] table or the records of rnad_learn_records), same seeded noise keyed by the GLOBAL lane
+ * id lane0 + lane, hence the same episodes bit for bit -- with column j of every [T_cap, B] buffer holding lane lane_ids[j]
+ * (a stable sort of the lanes by bucket).  traj->observations is not written (may be NULL; an observation is a function of
+ * (t & 1, indices[t]): rnad_observe), traj->values only if non-NULL (value_table NULL: zeros).  items / n_items: the learner's
+ * work list.  T_cap <= 64, B <= 2^22.
+ *
+ * rnad_learn_records: the five [2S, .] net-output tables of a tabular update interleaved into one record per row
+ * (rnad_learn_record_stride(A) floats: logit[A] | v | v_target | logit_reg[A] | logit_reg_[A] | pad; 16-byte aligned).
+ *
+ * rnad_learn_bucketed: rnad_learn_fused_tabular on a bucket-ordered trajectory: dlogit_tab [2S, A], dv_tab [2S] = per-row sums
+ * of the per-slot gradients, accumulated in 64-bit fixed point with an a-priori scale (|dL/dlogit| <= 2 * clip / N_P by
+ * construction; |v - v_target| < 2^10 is checked, the tables are NaN if it fails), normalised by norm (f64[2], batch-global
+ * N_P) at the end.  Integer sums: reproducible bit for bit.  losses (f64[2], optional): loss_v, loss_nerd of this rank's slots.
+ * ---------------------------------------------------------------------------------------------- */
+int rnad_bucket_plan(const rnad_tree_t *tree, int64_t B, int64_t *out);
+int rnad_rollout_bucketed(const rnad_tree_t *tree, const rnad_traj_t *traj, const float *logits_table, int64_t logits_stride,
+                          const float *value_table, int64_t value_stride, uint64_t seed, int64_t lane0, void *scratch,
+                          int32_t *lane_ids, int32_t *items, int32_t *n_items, void *stream);
+int64_t rnad_learn_record_stride(int A);
+int rnad_learn_records(const rnad_tree_t *tree, const float *logit_tab, const float *v_tab, const float *v_target_tab,
+                       const float *logit_reg_tab, const float *logit_reg_tab_, float *records, void *stream);
+int rnad_learn_bucketed(const rnad_tree_t *tree, int T, int64_t B, const int32_t *indices, const int32_t *actions,
+                        const float *rewards, const float *mu, const float *records, const int32_t *items, const int32_t *n_items,
+                        const double *norm, const rnad_learn_params_t *hp, void *accumulators, double *losses, float *dlogit_tab,
+                        float *dv_tab, void *stream);
+
 /* torch.nn.utils.clip_grad_norm_(parameters, max_norm) of learn/rnad.py:456 over one flat fp32 gradient bucket (all of a net's
  * .grad tensors back to back): g *= min(max_norm / (||g||_2 + 1e-6), 1), in place, one launch.  total_norm: optional device
  * float receiving ||g||_2. */

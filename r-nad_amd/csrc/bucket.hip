@@ -1,0 +1,697 @@
+// bucket.hip -- the bucketed tabular pipeline: rollout in subtree order + per-(player, state) gradient sums in LDS (gfx950).
+//
+// Replaces, on trees that are small next to the batch (2S distinct net inputs for T*B slots): environment/episode.py:175-230
+// (Episodes.generate) and the tensor program of learn/rnad.py:365-425 including the reduction that loss.backward() performs over
+// the slots that share a net input.  Citations are baskuit/R-NaD file:line.
+//
+// Why buckets.  The weight gradient is linear in dL/dout, and a net's input depends on (player to move, state) only
+// (episode.py:62-68), so the update needs, per row (P, s), the SUM of the per-slot gradients of the slots that sit in s at a step
+// of parity P.  Summing 12.6 M slots into 132 862 rows with global atomics costs ~1 ms (16.8 M spread 64-bit atomics, round 1).
+// Here lanes are first grouped by the state they reach at depth k (their "bucket"; ids are DFS pre-order, tree.py:311-330, so
+// the subtree below a bucket state s is the id range [s, s + size)): one workgroup then owns ALL slots of the rows below its
+// bucket state and adds them up in a small LDS table indexed by (state - s); the rows above it are shared by the whole
+// workgroup (every lane of a bucket has the same ancestors) and take one wave reduction per step.  No global atomic on the
+// common path, results in 64-bit fixed point (integer sums: any order, same bits).
+//
+//   k_bucket_keys      lane-ordered: plays the first 2k env steps only, key = the depth-k state reached (or the last live one)
+//   k_bucket_hist/scan/items/scatter   stable counting sort of the lanes by key (deterministic), work items per bucket
+//   k_bucket_rollout   bucket-ordered: thread j replays lane lane_ids[j] from the root (counter-based noise keyed by the GLOBAL lane
+//                      id, include/rnad_rng.h) and records the trajectory -- column j of every [T, B] buffer
+//   k_bucket_learn     one workgroup per work item: backward-in-time V-trace / NeuRD pass per lane (learn_math.hpp), sums in LDS
+//   k_bucket_finish    fixed point -> fp32 tables dL/dlogit [2S, A], dL/dv [2S], normalised by the batch-global N_P
+#include "learn_math.hpp"
+#include "rollout_math.hpp"
+
+#include <algorithm>
+#include <cstdlib>
+
+using namespace rnad;
+using namespace rnad::dev;
+
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int kMaxPart = 4;          // deepest partition level: 2 * kMaxPart env steps above the buckets
+constexpr int kMaxBuckets = 12288;   // LDS histogram of the sort passes: 48 KiB of int32
+constexpr int kSortThreads = 1024;   // threads per block of the sort passes
+constexpr int kSortLanes = 4096;     // lanes per block of the sort passes (4 per thread, 256 contiguous per wave)
+constexpr int kChunk = 2048;         // lanes per work item of the learner
+constexpr int kReplicas = 64;        // copies of the upper-row table the workgroups spread their path sums over
+constexpr int kMaxSteps = 64;        // T_cap bound of the alive counters in LDS
+constexpr int kLaneBits = 22;        // B <= 2^22 lanes per call: a row receives at most one addend per lane
+constexpr int kLearnLds = 64 * 1024; // LDS budget of one learner workgroup
+
+inline unsigned blocks_for(int64_t n, int per = kThreads) { return (unsigned)((n + per - 1) / per); }
+
+struct Plan {
+    int k = -1, n_buckets = 0, n_upper = 0, sub_rows = 0, lds = 0, sort_blocks = 0;
+    int64_t max_items = 0;
+};
+
+// Partition level: the deepest level <= kMaxPart whose buckets still hold >= 128 lanes on average (a workgroup per bucket
+// should have at least two waves of work), subject to the LDS table of a bucket fitting; if even level 0 is too fine,
+// the shallowest level that fits.  false: this tree cannot be bucketed (ids not DFS pre-order, or no level fits).
+bool make_plan(const rnad_tree_t *tree, int64_t B, Plan &p) {
+    if (!tree->contiguous_subtrees || B < 1 || B > ((int64_t)1 << kLaneBits)) return false;
+    int best = -1, first = -1;
+    for (int k = 0; k < tree->n_levels && k <= kMaxPart; ++k) {
+        const int64_t n_buckets = tree->level_offsets[(size_t)k + 1];
+        if (n_buckets > kMaxBuckets) break;
+        const int64_t sub = tree->level_max_subtree[(size_t)k];
+        const int64_t lds = (2 * k + 2 * sub) * (tree->A + 1) * 8;
+        if (lds > kLearnLds) continue;
+        if (first < 0) first = k;
+        const int64_t level_states = tree->level_offsets[(size_t)k + 1] - tree->level_offsets[(size_t)k];
+        if (B / std::max<int64_t>(level_states, 1) >= 128) best = k;
+    }
+    int k = best >= 0 ? best : first;
+    if (k < 0) return false;
+    if (const char *force = getenv("RNAD_BUCKET_LEVEL")) {  // tuning / test knob: a specific partition depth, if it fits
+        const int want = atoi(force);
+        if (want < 0 || want >= tree->n_levels || want > kMaxPart || tree->level_offsets[(size_t)want + 1] > kMaxBuckets ||
+            (2 * want + 2 * tree->level_max_subtree[(size_t)want]) * (tree->A + 1) * 8 > kLearnLds)
+            return false;
+        k = want;
+    }
+    p.k = k;
+    p.n_buckets = (int)tree->level_offsets[(size_t)k + 1];
+    p.n_upper = (int)tree->level_offsets[(size_t)k];
+    p.sub_rows = (int)tree->level_max_subtree[(size_t)k];
+    p.lds = (2 * k + 2 * p.sub_rows) * (tree->A + 1) * 8;
+    p.sort_blocks = (int)((B + kSortLanes - 1) / kSortLanes);
+    p.max_items = (int64_t)p.n_buckets + B / kChunk + 1;
+    return true;
+}
+
+// ---------------------------------------------------------------------------------------- 1. keys
+// Lane b (lane order) plays env steps 0 .. n_steps - 1 (n_steps = 2k) exactly as k_bucket_rollout will, and keeps the last
+// non-absorbing state it has seen: the depth-k state it reaches, or the state it left the tree from if that happens earlier.
+template <int A>
+__global__ __launch_bounds__(kThreads) void k_bucket_keys(const Trans *__restrict__ trans, int C, int64_t S, int64_t B, int n_steps,
+                                                          const float *__restrict__ logit_tab, int64_t tab_stride,
+                                                          const uint8_t *__restrict__ mask_tab, const int32_t *__restrict__ order_pos,
+                                                          uint64_t seed, int64_t lane0, int32_t *__restrict__ keys) {
+    const int64_t b = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    if (b >= B) return;
+    int state = 1, key = 1, prev = 0;
+    for (int t = 0; t < n_steps && state != 0; ++t) {
+        const int64_t row = (int64_t)(t & 1) * S + state;
+        float in[A], pol[A], q[A];
+#pragma unroll
+        for (int a = 0; a < A; ++a) in[a] = logit_tab[row * tab_stride + a];
+        policy_head_ptr<A>(in, mask_tab[row], pol, nullptr);
+        rnad_exp_noise(seed, (uint64_t)(lane0 + b), (uint32_t)t, 0u, A, q);
+        const int action = race_argmax<A>(pol, q);
+        if (t & 1) {
+            int next;
+            float rew;
+            transition_lane<A>(trans, C, state, prev, action, nullptr, seed, (uint64_t)(lane0 + b), (uint32_t)t, next, rew);
+            state = next;
+            if (state != 0) key = state;
+        } else {
+            prev = action;
+        }
+    }
+    keys[b] = order_pos[key];
+}
+
+// ---------------------------------------------------------------------------------------- 2. stable counting sort by key
+// hist[blk][bucket] = #lanes of block blk (kSortLanes consecutive lanes) with that key.
+__global__ __launch_bounds__(kSortThreads) void k_bucket_hist(int64_t B, int n_buckets, const int32_t *__restrict__ keys,
+                                                              int32_t *__restrict__ hist) {
+    extern __shared__ int32_t cnt[];
+    for (int i = threadIdx.x; i < n_buckets; i += kSortThreads) cnt[i] = 0;
+    __syncthreads();
+    const int64_t base = (int64_t)blockIdx.x * kSortLanes;
+#pragma unroll
+    for (int r = 0; r < kSortLanes / kSortThreads; ++r) {
+        const int64_t b = base + (int64_t)r * kSortThreads + threadIdx.x;
+        if (b < B) atomicAdd(&cnt[keys[b]], 1);
+    }
+    __syncthreads();
+    int32_t *row = hist + (int64_t)blockIdx.x * n_buckets;
+    for (int i = threadIdx.x; i < n_buckets; i += kSortThreads) row[i] = cnt[i];
+}
+
+// Column-wise exclusive prefix of hist over the blocks (in place) and the column totals.  A workgroup takes 64 buckets; its 16
+// waves each take a contiguous sixteenth of the blocks: partial sums -> prefix over the 16 parts in LDS -> second sweep.
+__global__ __launch_bounds__(kSortThreads) void k_bucket_scan(int n_blocks, int n_buckets, int32_t *__restrict__ hist,
+                                                              int32_t *__restrict__ totals) {
+    __shared__ int32_t part[16][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), g = threadIdx.x >> 6;
+    const int per = (n_blocks + 15) / 16, r0 = g * per, r1 = min(n_blocks, r0 + per);
+    int32_t sum = 0;
+    if (c < n_buckets)
+        for (int r = r0; r < r1; ++r) sum += hist[(int64_t)r * n_buckets + c];
+    part[g][threadIdx.x & 63] = sum;
+    __syncthreads();
+    int32_t before = 0, total = 0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int32_t v = part[i][threadIdx.x & 63];
+        before += i < g ? v : 0;
+        total += v;
+    }
+    if (c < n_buckets) {
+        for (int r = r0; r < r1; ++r) {
+            const int32_t v = hist[(int64_t)r * n_buckets + c];
+            hist[(int64_t)r * n_buckets + c] = before;
+            before += v;
+        }
+        if (g == 0) totals[c] = total;
+    }
+}
+
+struct Item {
+    int32_t begin, count, state, single;  // lanes [begin, begin + count) of bucket `state`; single: the bucket's only item
+};
+
+// bucket_start = exclusive prefix of the totals; one work item per kChunk lanes of a non-empty bucket.  One workgroup.
+__global__ __launch_bounds__(kSortThreads) void k_bucket_items(int n_buckets, const int32_t *__restrict__ totals,
+                                                               const int32_t *__restrict__ level_order, int32_t *__restrict__ bucket_start,
+                                                               Item *__restrict__ items, int32_t *__restrict__ n_items) {
+    __shared__ int32_t wave_l[16], wave_i[16];
+    __shared__ int32_t carry_l, carry_i;
+    if (threadIdx.x == 0) carry_l = carry_i = 0;
+    __syncthreads();
+    for (int base = 0; base < n_buckets; base += kSortThreads) {
+        const int i = base + threadIdx.x;
+        const int32_t n = i < n_buckets ? totals[i] : 0;
+        const int32_t ni = (n + kChunk - 1) / kChunk;
+        int32_t sl = n, si = ni;  // inclusive scans within the wave
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int32_t a = __shfl_up(sl, off, 64), b = __shfl_up(si, off, 64);
+            if ((int)(threadIdx.x & 63) >= off) {
+                sl += a;
+                si += b;
+            }
+        }
+        if ((threadIdx.x & 63) == 63) {
+            wave_l[threadIdx.x >> 6] = sl;
+            wave_i[threadIdx.x >> 6] = si;
+        }
+        __syncthreads();
+        int32_t bl = carry_l, bi = carry_i;
+        for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) {
+            bl += wave_l[w];
+            bi += wave_i[w];
+        }
+        const int32_t start = bl + sl - n, first = bi + si - ni;
+        if (i < n_buckets) {
+            bucket_start[i] = start;
+            for (int32_t j = 0; j < ni; ++j)
+                items[first + j] = Item{start + j * kChunk, min(kChunk, n - j * kChunk), level_order[i], ni == 1 ? 1 : 0};
+        }
+        __syncthreads();
+        if (threadIdx.x == kSortThreads - 1) {
+            carry_l = bl + sl;
+            carry_i = bi + si;
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *n_items = carry_i;
+}
+
+// lane_ids[bucket_start[key] + (lanes of earlier blocks with that key) + (earlier lanes of this block with that key)] = lane.
+// The waves of a workgroup take turns (each owns 256 consecutive lanes), so the rank a lane draws from the LDS counter does not
+// depend on wave scheduling: the permutation is the stable counting sort.
+__global__ __launch_bounds__(kSortThreads) void k_bucket_scatter(int64_t B, int n_buckets, const int32_t *__restrict__ keys,
+                                                                 const int32_t *__restrict__ hist, const int32_t *__restrict__ bucket_start,
+                                                                 int32_t *__restrict__ lane_ids) {
+    extern __shared__ int32_t cnt[];
+    const int32_t *row = hist + (int64_t)blockIdx.x * n_buckets;
+    for (int i = threadIdx.x; i < n_buckets; i += kSortThreads) cnt[i] = bucket_start[i] + row[i];
+    __syncthreads();
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t base = (int64_t)blockIdx.x * kSortLanes + (int64_t)wave * (kSortLanes / 16);
+    for (int turn = 0; turn < 16; ++turn) {
+        if (turn == wave) {
+#pragma unroll
+            for (int r = 0; r < kSortLanes / kSortThreads; ++r) {
+                const int64_t b = base + r * 64 + lane;
+                if (b < B) {
+                    // lanes of one wave that hit the same counter are served in lane order: rank by ballot, one add per key
+                    const int32_t key = keys[b];
+                    uint64_t todo = __ballot(1);
+                    int32_t pos = 0;
+                    while (todo) {
+                        const int leader = __ffsll((unsigned long long)todo) - 1;
+                        const int32_t lk = __shfl(key, leader, 64);
+                        const uint64_t same = __ballot(key == lk) & todo;
+                        if (key == lk) {
+                            int32_t first = 0;
+                            if (lane == leader) first = atomicAdd(&cnt[lk], (int32_t)__popcll(same));
+                            first = __shfl(first, leader, 64);
+                            pos = first + (int32_t)__popcll(same & ((1ull << lane) - 1ull));
+                        }
+                        todo &= ~same;
+                    }
+                    lane_ids[pos] = (int32_t)b;
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------------- 3. rollout in bucket order
+// Episodes.generate (episode.py:194-212) for thread j = lane lane_ids[j]: per env step the tabular actor's logits row of
+// (player to move, state), the policy head (net.py:45-46), the Exp(1) race (net.py:49), the record, and on the column player's
+// turn the chance draw and transition (episode.py:106-121) -- the arithmetic of k_act, with state and the row action kept in
+// registers across the T_cap steps and column j of every [T_cap, B] buffer written coalesced.  Observations are not written
+// (a function of (t & 1, indices): materialised on demand), `values` only if asked for.
+// alive_part[block][t] = #lanes of the block with indices[t] != 0 (summed by k_bucket_alive: no atomics).
+template <int A>
+__global__ __launch_bounds__(kThreads) void k_bucket_rollout(const Trans *__restrict__ trans, int C, int64_t S, int64_t B, int T_cap,
+                                                             const float *__restrict__ logit_tab, int64_t tab_stride,
+                                                             const float *__restrict__ value_tab, int64_t value_stride,
+                                                             const uint8_t *__restrict__ mask_tab, uint64_t seed, int64_t lane0,
+                                                             const int32_t *__restrict__ lane_ids, int32_t *__restrict__ indices,
+                                                             uint8_t *__restrict__ mbits, float *__restrict__ policy,
+                                                             int32_t *__restrict__ actions, float *__restrict__ rewards,
+                                                             float *__restrict__ values, int32_t *__restrict__ alive_part) {
+    __shared__ int32_t cnt[kThreads / 64][kMaxSteps + 1];
+    const int64_t j = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    const bool active = j < B;
+    const uint64_t lane = active ? (uint64_t)(lane0 + lane_ids[j]) : 0;
+    const int wave = threadIdx.x >> 6;
+    int state = 1, prev = 0;
+    for (int t = 0; t < T_cap; ++t) {
+        const uint64_t live = __ballot(active && state != 0);
+        if ((threadIdx.x & 63) == 0) cnt[wave][t] = (int32_t)__popcll(live);
+        if (active) {
+            const int64_t i = (int64_t)t * B + j;
+            const int64_t row = (int64_t)(t & 1) * S + state;
+            const uint32_t bits = mask_tab[row];
+            float in[A], pol[A], q[A];
+#pragma unroll
+            for (int a = 0; a < A; ++a) in[a] = logit_tab[row * tab_stride + a];
+            policy_head_ptr<A>(in, bits, pol, nullptr);
+            rnad_exp_noise(seed, lane, (uint32_t)t, 0u, A, q);
+            const int action = race_argmax<A>(pol, q);
+            indices[i] = state;
+            mbits[i] = (uint8_t)bits;
+#pragma unroll
+            for (int a = 0; a < A; ++a) policy[i * A + a] = pol[a];
+            actions[i] = action;
+            if (values) values[i] = value_tab ? value_tab[row * value_stride] : 0.0f;
+            int next = state;
+            float rew = 0.0f;  // row turn: torch.zeros (episode.py:101)
+            if (t & 1)
+                transition_lane<A>(trans, C, state, prev, action, nullptr, seed, lane, (uint32_t)t, next, rew);
+            else
+                prev = action;
+            rewards[i] = rew;
+            state = next;
+        }
+    }
+    const uint64_t live = __ballot(active && state != 0);
+    if ((threadIdx.x & 63) == 0) cnt[wave][T_cap] = (int32_t)__popcll(live);
+    if (active) indices[(int64_t)T_cap * B + j] = state;
+    __syncthreads();
+    if ((int)threadIdx.x <= T_cap) {
+        int32_t s = 0;
+#pragma unroll
+        for (int w = 0; w < kThreads / 64; ++w) s += cnt[w][threadIdx.x];
+        alive_part[(int64_t)blockIdx.x * (T_cap + 1) + threadIdx.x] = s;
+    }
+}
+
+// alive[t] = sum over the blocks of alive_part[block][t].  grid = T_cap + 1 workgroups.
+__global__ __launch_bounds__(kThreads) void k_bucket_alive(int n_blocks, int T1, const int32_t *__restrict__ alive_part,
+                                                           int32_t *__restrict__ alive) {
+    const int t = blockIdx.x;
+    int32_t s = 0;
+    for (int r = threadIdx.x; r < n_blocks; r += kThreads) s += alive_part[(int64_t)r * T1 + t];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+    __shared__ int32_t part[kThreads / 64];
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int32_t x = 0;
+#pragma unroll
+        for (int w = 0; w < kThreads / 64; ++w) x += part[w];
+        alive[t] = x;
+    }
+}
+
+// ---------------------------------------------------------------------------------------- 4. learner
+// Sum over the 64 lanes of a wave in integer arithmetic on the VALU's data-parallel primitives (no LDS traffic): an inclusive
+// scan within each row of 16 lanes (row_shr 1, 2, 4, 8), then row 15 -> next row (row_bcast15) and lane 31 -> rows 2, 3
+// (row_bcast31); lane 63 ends up with the total.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ long long dpp_moved(long long v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(unsigned)(unsigned long long)v, CTRL, ROW_MASK, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(unsigned)((unsigned long long)v >> 32), CTRL, ROW_MASK, 0xf, false);
+    return (long long)(((unsigned long long)(unsigned)hi << 32) | (unsigned long long)(unsigned)lo);
+}
+
+__device__ __forceinline__ long long wave_total_in_lane63(long long v) {
+    v += dpp_moved<0x111, 0xf>(v);  // row_shr:1
+    v += dpp_moved<0x112, 0xf>(v);  // row_shr:2
+    v += dpp_moved<0x114, 0xf>(v);  // row_shr:4
+    v += dpp_moved<0x118, 0xf>(v);  // row_shr:8
+    v += dpp_moved<0x142, 0xa>(v);  // row_bcast15 into rows 1 and 3
+    v += dpp_moved<0x143, 0xc>(v);  // row_bcast31 into rows 2 and 3
+    return v;
+}
+
+struct FixedPoint {
+    double scale_l, scale_v;  // 2^f: units per 1.0 of an addend of dL/dlogit / dL/dv
+    float limit_l, limit_v;   // |addend| must stay below this (2^(62 - kLaneBits) units)
+};
+
+// The pass of k_learn_fused<TAB> (learn.hip; learn/rnad.py:365-425) for the lanes of ONE work item -- they all went through the
+// same states down to the bucket state -- with the per-slot gradients added up per (player, state) row instead of being written:
+//   rows at steps t < 2 * level(bucket state): one row per step for the whole workgroup -> wave reduction, one LDS add per wave;
+//   rows below: LDS table indexed by (state - bucket state), both players.
+// Addends are the UN-normalised gradients  G_l[a] = -(w - legal * sum(w) / A)  and  G_v = 2 (v - v_target)  in 64-bit fixed
+// point; k_bucket_finish applies w_n / N_P and w_v / N_P (the reference scales every slot by them: vtrace.py:374,389 and
+// rnad.py:424; summing first changes the rounding of the last bit only).  losses_raw[4] += sum d^2 (P = 0, 1), sum -nerd (P = 0, 1).
+template <int A>
+__global__ __launch_bounds__(kThreads) void k_bucket_learn(int T, int64_t B, int64_t S, int k, int sub_rows, int n_upper,
+                                                           const Item *__restrict__ items, const int32_t *__restrict__ n_items,
+                                                           const uint8_t *__restrict__ level_dev, const int32_t *__restrict__ order_pos,
+                                                           const uint8_t *__restrict__ mask_tab, const int32_t *__restrict__ indices,
+                                                           const int32_t *__restrict__ actions, const float *__restrict__ rewards,
+                                                           const float *__restrict__ mu_, const float *__restrict__ rec_,
+                                                           rnad_learn_params_t hp, FixedPoint fx, unsigned long long *__restrict__ acc,
+                                                           unsigned long long *__restrict__ rep, double *__restrict__ losses_raw,
+                                                           int32_t *__restrict__ overflow) {
+    extern __shared__ unsigned long long tab[];  // [2k path rows | sub_rows rows of player 0 | sub_rows rows of player 1][A + 1]
+    __shared__ int32_t path_state[2 * kMaxPart + 1];
+    __shared__ double loss_part[kThreads / 64][4];
+    if ((int)blockIdx.x >= *n_items) return;
+    const Item item = items[blockIdx.x];
+    const int s_b = item.state;
+    const int n_path = 2 * (int)level_dev[s_b];
+    constexpr int RS = kRecStride<A>;
+    const int n_tab = (2 * k + 2 * sub_rows) * (A + 1);
+    for (int i = threadIdx.x; i < n_tab; i += kThreads) tab[i] = 0ull;
+    __syncthreads();
+    const VtHp vh{-hp.eta, hp.lambda_, hp.c, hp.rho, hp.gamma};
+    double part[4] = {0.0, 0.0, 0.0, 0.0};
+    bool ovf = false;
+    for (int base = 0; base < item.count; base += kThreads) {
+        const bool active = base + (int)threadIdx.x < item.count;
+        const int64_t j = (int64_t)item.begin + base + threadIdx.x;
+        Carry cy[2];
+        for (int t = T - 1; t >= 0; --t) {
+            const int64_t i = (int64_t)t * B + j;
+            const int state = active ? indices[i] : 0;
+            const bool valid = state != 0;  // rnad.py:369
+            const int P = t & 1;            // turns[t, :] (episode.py:96-98)
+            long long q[A + 1];
+#pragma unroll
+            for (int a = 0; a <= A; ++a) q[a] = 0;
+            if (valid) {
+                const int64_t row = (int64_t)P * S + state;
+                const uint32_t bits = mask_tab[row];
+                const int act = actions[i];
+                float rec[RS];  // this row's record lg[A] | v | v_target | lr[A] | lr2[A] (k_pack_records), as 16-byte pieces
+                const float4 *rp = reinterpret_cast<const float4 *>(rec_ + row * RS);
+#pragma unroll
+                for (int u = 0; u < RS / 4; ++u) {
+                    const float4 r4 = rp[u];
+                    rec[4 * u] = r4.x; rec[4 * u + 1] = r4.y; rec[4 * u + 2] = r4.z; rec[4 * u + 3] = r4.w;
+                }
+                float mu[A], lg[A], lr[A], lr2[A], legal[A], oh[A];
+#pragma unroll
+                for (int a = 0; a < A; ++a) {
+                    mu[a] = mu_[i * A + a];
+                    lg[a] = rec[a];
+                    lr[a] = rec[A + 2 + a];
+                    lr2[a] = rec[2 * A + 2 + a];
+                    legal[a] = (float)((bits >> a) & 1);
+                    oh[a] = act == a ? 1.0f : 0.0f;
+                }
+                float pi[A], lp[A], lpr[A], lpr2[A], pip[A], lpol[A];
+                policy_head<A>(lg, bits, pi, lp);             // net.forward_batch of the learner (rnad.py:373)
+                log_policy_only<A>(lr, bits, lpr);            // net_reg (rnad.py:379)
+                log_policy_only<A>(lr2, bits, lpr2);          // net_reg_ (rnad.py:380)
+                process_policy_row<A>(pi, legal, hp.n_disc, hp.eps_threshold, pip);  // rnad.py:374
+#pragma unroll
+                for (int a = 0; a < A; ++a) lpol[a] = lp[a] - (hp.alpha * lpr[a] + hp.one_minus_alpha * lpr2[a]);  // rnad.py:382
+                const float rew = (t & 1) ? rewards[i] : 0.0f;  // row turns carry torch.zeros (episode.py:101)
+                const float vtn = rec[A + 1];
+                float vt[2], qv[2][A];
+                vtrace_step<A>(cy[0], vh, true, P == 0, 1.0f, vtn, rew, mu, pip, lpol, oh, vt[0], qv[0]);   // player 0 (rnad.py:384-406)
+                vtrace_step<A>(cy[1], vh, true, P == 1, 1.0f, vtn, -rew, mu, pip, lpol, oh, vt[1], qv[1]);  // player 1: rewards = -r (:368)
+                const float d = rec[A] - (P ? vt[1] : vt[0]);
+                float qp[A], g[A];
+#pragma unroll
+                for (int a = 0; a < A; ++a) qp[a] = P ? qv[1][a] : qv[0][a];
+                const float nerd = nerd_row<A>(lg, pip, qp, legal, hp.clip, hp.threshold, g);
+                part[P] += (double)(d * d);
+                part[2 + P] += -(double)nerd;
+                const float gv = 2.0f * d;
+                ovf |= !(fabsf(gv) < fx.limit_v);
+                q[A] = __double2ll_rn((double)gv * fx.scale_v);
+#pragma unroll
+                for (int a = 0; a < A; ++a) {
+                    ovf |= !(fabsf(g[a]) < fx.limit_l);
+                    q[a] = __double2ll_rn((double)(-g[a]) * fx.scale_l);
+                }
+            } else {
+                cy[0] = Carry{};  // reset_carry (vtrace.py:320)
+                cy[1] = Carry{};
+            }
+            if (t < n_path) {  // a step above the bucket state: one row for the whole workgroup
+                if (threadIdx.x == 0 && base == 0) path_state[t] = state;
+#pragma unroll
+                for (int a = 0; a <= A; ++a) {
+                    const long long s = wave_total_in_lane63(q[a]);
+                    if ((threadIdx.x & 63) == 63 && s != 0) atomicAdd(&tab[t * (A + 1) + a], (unsigned long long)s);
+                }
+            } else if (valid) {
+                unsigned long long *dst = tab + ((int64_t)(2 * k + P * sub_rows + (state - s_b))) * (A + 1);
+#pragma unroll
+                for (int a = 0; a <= A; ++a) atomicAdd(dst + a, (unsigned long long)q[a]);
+            }
+        }
+    }
+    // losses (logging): four fp64 partial sums per block
+    if (losses_raw) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            double x = part[u];
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
+            if ((threadIdx.x & 63) == 0) loss_part[threadIdx.x >> 6][u] = x;
+        }
+    }
+    if (ovf) *overflow = 1;
+    __syncthreads();
+    if (losses_raw && threadIdx.x < 4) {
+        double x = 0.0;
+#pragma unroll
+        for (int w = 0; w < kThreads / 64; ++w) x += loss_part[w][threadIdx.x];
+        if (x != 0.0) atomicAdd(losses_raw + threadIdx.x, x);
+    }
+    // path rows -> one of the replicas of the upper-row table (spreads the same-address atomics of the root rows)
+    for (int e = threadIdx.x; e < n_path * (A + 1); e += kThreads) {
+        const unsigned long long x = tab[e];
+        if (x != 0ull) {
+            const int t = e / (A + 1), a = e % (A + 1);
+            const int64_t slot = order_pos[path_state[t]];
+            atomicAdd(rep + (((int64_t)(blockIdx.x & (kReplicas - 1)) * 2 + (t & 1)) * n_upper + slot) * (A + 1) + a, x);
+        }
+    }
+    // rows of the bucket's own subtree: this workgroup owns them unless the bucket was split over several items
+    const int64_t end = S - s_b < sub_rows ? S - s_b : sub_rows;
+    for (int e = threadIdx.x; e < 2 * sub_rows * (A + 1); e += kThreads) {
+        const unsigned long long x = tab[2 * k * (A + 1) + e];
+        if (x != 0ull) {
+            const int P = e / (sub_rows * (A + 1)), r = e % (sub_rows * (A + 1));
+            if (r / (A + 1) < end) {
+                unsigned long long *dst = acc + ((int64_t)P * S + s_b) * (A + 1) + r;
+                if (item.single) *dst = x;
+                else atomicAdd(dst, x);
+            }
+        }
+    }
+}
+
+// acc (+ the replicas for rows above the buckets) -> fp32 tables, normalised: dlogit_tab[P * S + s] = w_n * (G_l / N_P),
+// dv_tab likewise with w_v (learn/vtrace.py:374,389; rnad.py:424).  Clears what it read, so that acc / rep are zero again for
+// the next update.  An addend beyond the fixed-point range poisons the tables with NaN instead of passing silently.
+template <int A>
+__global__ __launch_bounds__(kThreads) void k_bucket_finish(int64_t S, int n_upper, int up_stride, const int32_t *__restrict__ order_pos,
+                                                            unsigned long long *__restrict__ acc, unsigned long long *__restrict__ rep,
+                                                            const double *__restrict__ norm, float w_v, float w_n, FixedPoint fx,
+                                                            int32_t *__restrict__ overflow, double *__restrict__ losses_raw,
+                                                            double *__restrict__ losses, float *__restrict__ dlogit_tab,
+                                                            float *__restrict__ dv_tab) {
+    const int64_t r = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    const float nf0 = norm_of(norm), nf1 = norm_of(norm + 1);
+    if (r == 0 && losses) {
+        losses[0] = losses_raw[0] / (double)nf0 + losses_raw[1] / (double)nf1;
+        losses[1] = losses_raw[2] / (double)nf0 + losses_raw[3] / (double)nf1;
+    }
+    if (r >= 2 * S) return;
+    const int P = (int)(r / S);
+    const int64_t s = r % S;
+    long long x[A + 1];
+#pragma unroll
+    for (int a = 0; a <= A; ++a) {
+        x[a] = (long long)acc[r * (A + 1) + a];
+        if (x[a] != 0) acc[r * (A + 1) + a] = 0ull;
+    }
+    const int pos = order_pos[s];
+    if (pos >= 0 && pos < n_upper) {
+        for (int c = 0; c < kReplicas; ++c) {
+            unsigned long long *src = rep + (((int64_t)c * 2 + P) * up_stride + pos) * (A + 1);
+#pragma unroll
+            for (int a = 0; a <= A; ++a) {
+                const unsigned long long v = src[a];
+                if (v != 0ull) {
+                    x[a] += (long long)v;
+                    src[a] = 0ull;
+                }
+            }
+        }
+    }
+    const float nf = P ? nf1 : nf0;
+    const bool bad = *overflow != 0;
+    const float nan = __uint_as_float(0x7fc00000u);
+#pragma unroll
+    for (int a = 0; a < A; ++a) dlogit_tab[r * A + a] = bad ? nan : w_n * ((float)((double)x[a] / fx.scale_l) / nf);
+    dv_tab[r] = bad ? nan : w_v * ((float)((double)x[A] / fx.scale_v) / nf);
+}
+
+FixedPoint fixed_point_for(const rnad_learn_params_t &hp) {
+    // |G_l| <= 2 * clip by construction (vtrace.py:417: adv is clipped, w = legal * f, |f| <= |adv|); G_v = 2 (v - v_target) has no
+    // a-priori bound: 2^11 is far beyond any payoff scale the path produces (checked per addend, NaN on overflow).
+    const int budget = 62 - kLaneBits;  // bits an addend may use
+    int e_l = 1;
+    while (std::ldexp(1.0, e_l) <= 2.0 * std::fabs((double)hp.clip) && e_l < 30) ++e_l;
+    const int e_v = 11;
+    FixedPoint fx;
+    fx.scale_l = std::ldexp(1.0, budget - e_l);
+    fx.scale_v = std::ldexp(1.0, budget - e_v);
+    fx.limit_l = (float)std::ldexp(1.0, e_l);
+    fx.limit_v = (float)std::ldexp(1.0, e_v);
+    return fx;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------- entry points
+extern "C" int rnad_bucket_plan(const rnad_tree_t *tree, int64_t B, int64_t *out) {
+    RNAD_REQUIRE(tree && out, "rnad_bucket_plan: null argument");
+    Plan p;
+    if (!make_plan(tree, B, p)) {
+        set_error("rnad_bucket_plan: this tree / batch cannot be bucketed (ids not DFS pre-order, no level whose subtree table fits "
+                  "the LDS, or more than 2^%d lanes)", kLaneBits);
+        return 3;
+    }
+    const int64_t A1 = tree->A + 1;
+    out[0] = p.k;
+    out[1] = p.n_buckets;
+    out[2] = p.n_upper;
+    out[3] = p.sub_rows;
+    out[4] = p.max_items;
+    // scratch of the rollout (bytes): keys [B] | hist [sort_blocks][n_buckets] | totals [n_buckets] | bucket_start [n_buckets] |
+    // alive_part [blocks][T_cap + 1 <= kMaxSteps + 1]
+    out[5] = 4 * (B + (int64_t)p.sort_blocks * p.n_buckets + 2 * (int64_t)p.n_buckets + (int64_t)blocks_for(B) * (kMaxSteps + 1)) + 256;
+    // accumulators of the learner (bytes, must be zero before the first update): acc [2S][A+1] u64 | rep [64][2][n_upper][A+1] u64 |
+    // losses_raw [4] f64 | overflow [1] i32
+    out[6] = 8 * (2 * tree->S * A1 + (int64_t)kReplicas * 2 * std::max(p.n_upper, 1) * A1 + 4) + 16;
+    out[7] = p.lds;
+    return 0;
+}
+
+namespace {
+struct Scratch {
+    int32_t *keys, *hist, *totals, *bucket_start, *alive_part;
+};
+Scratch carve_scratch(void *ws, int64_t B, const Plan &p) {
+    Scratch s;
+    s.keys = (int32_t *)ws;
+    s.hist = s.keys + B;
+    s.totals = s.hist + (int64_t)p.sort_blocks * p.n_buckets;
+    s.bucket_start = s.totals + p.n_buckets;
+    s.alive_part = s.bucket_start + p.n_buckets;
+    return s;
+}
+}  // namespace
+
+extern "C" int rnad_rollout_bucketed(const rnad_tree_t *tree, const rnad_traj_t *tr, const float *logits_table, int64_t logits_stride,
+                                     const float *value_table, int64_t value_stride, uint64_t seed, int64_t lane0, void *scratch,
+                                     int32_t *lane_ids, int32_t *items, int32_t *n_items, void *stream_) {
+    RNAD_REQUIRE(tree && tr && logits_table && scratch && lane_ids && items && n_items, "rnad_rollout_bucketed: null argument");
+    RNAD_REQUIRE(tr->indices && tr->mask_bits && tr->policy && tr->actions && tr->rewards && tr->alive,
+                 "rnad_rollout_bucketed: trajectory has a null buffer");
+    RNAD_REQUIRE(tr->T_cap >= 1 && tr->T_cap <= kMaxSteps && tr->B >= 1, "rnad_rollout_bucketed: bad trajectory shape T_cap=%d B=%lld",
+                 tr->T_cap, (long long)tr->B);
+    RNAD_REQUIRE(logits_stride >= tree->A && (!value_table || value_stride >= 1), "rnad_rollout_bucketed: bad table stride");
+    Plan p;
+    RNAD_REQUIRE(make_plan(tree, tr->B, p), "rnad_rollout_bucketed: this tree / batch cannot be bucketed (see rnad_bucket_plan)");
+    hipStream_t stream = (hipStream_t)stream_;
+    const int64_t B = tr->B, S = tree->S;
+    const Scratch s = carve_scratch(scratch, B, p);
+    const int n_steps = std::min(2 * p.k, (int)tr->T_cap);
+    ProfScope prof(PROF_ACT, stream);
+    RNAD_DISPATCH_A(tree->A, hipLaunchKernelGGL((k_bucket_keys<kA>), dim3(blocks_for(B)), dim3(kThreads), 0, stream, tree->trans, tree->C,
+                                                S, B, n_steps, logits_table, logits_stride, (const uint8_t *)tree->mask_tab,
+                                                (const int32_t *)tree->order_pos, seed, lane0, s.keys));
+    const size_t lds = (size_t)p.n_buckets * sizeof(int32_t);
+    hipLaunchKernelGGL(k_bucket_hist, dim3(p.sort_blocks), dim3(kSortThreads), lds, stream, B, p.n_buckets, (const int32_t *)s.keys, s.hist);
+    hipLaunchKernelGGL(k_bucket_scan, dim3((p.n_buckets + 63) / 64), dim3(kSortThreads), 0, stream, p.sort_blocks, p.n_buckets, s.hist,
+                       s.totals);
+    hipLaunchKernelGGL(k_bucket_items, dim3(1), dim3(kSortThreads), 0, stream, p.n_buckets, (const int32_t *)s.totals,
+                       (const int32_t *)tree->level_order, s.bucket_start, (Item *)items, n_items);
+    hipLaunchKernelGGL(k_bucket_scatter, dim3(p.sort_blocks), dim3(kSortThreads), lds, stream, B, p.n_buckets, (const int32_t *)s.keys,
+                       (const int32_t *)s.hist, (const int32_t *)s.bucket_start, lane_ids);
+    RNAD_HIP_OK(hipGetLastError());
+    const unsigned grid = blocks_for(B);
+    RNAD_DISPATCH_A(tree->A, hipLaunchKernelGGL((k_bucket_rollout<kA>), dim3(grid), dim3(kThreads), 0, stream, tree->trans, tree->C, S, B,
+                                                (int)tr->T_cap, logits_table, logits_stride, value_table, value_stride,
+                                                (const uint8_t *)tree->mask_tab, seed, lane0, (const int32_t *)lane_ids, tr->indices,
+                                                tr->mask_bits, tr->policy, tr->actions, tr->rewards, tr->values, s.alive_part));
+    hipLaunchKernelGGL(k_bucket_alive, dim3(tr->T_cap + 1), dim3(kThreads), 0, stream, (int)grid, (int)tr->T_cap + 1,
+                       (const int32_t *)s.alive_part, tr->alive);
+    RNAD_HIP_OK(hipGetLastError());
+    return 0;
+}
+
+extern "C" int rnad_learn_bucketed(const rnad_tree_t *tree, int T, int64_t B, const int32_t *indices, const int32_t *actions,
+                                   const float *rewards, const float *mu, const float *records, const int32_t *items,
+                                   const int32_t *n_items, const double *norm, const rnad_learn_params_t *hp, void *accumulators,
+                                   double *losses, float *dlogit_tab, float *dv_tab, void *stream_) {
+    RNAD_REQUIRE(tree && indices && actions && rewards && mu && records && items && n_items && norm && hp && accumulators && dlogit_tab &&
+                     dv_tab,
+                 "rnad_learn_bucketed: null argument");
+    RNAD_REQUIRE(T >= 1 && B >= 1, "rnad_learn_bucketed: bad shape");
+    RNAD_REQUIRE(hp->n_disc >= 1, "rnad_learn_bucketed: n_disc must be positive");
+    Plan p;
+    RNAD_REQUIRE(make_plan(tree, B, p), "rnad_learn_bucketed: this tree / batch cannot be bucketed (see rnad_bucket_plan)");
+    hipStream_t stream = (hipStream_t)stream_;
+    const int64_t S = tree->S, A1 = tree->A + 1;
+    unsigned long long *acc = (unsigned long long *)accumulators;
+    unsigned long long *rep = acc + 2 * S * A1;
+    double *losses_raw = (double *)(rep + (int64_t)kReplicas * 2 * std::max(p.n_upper, 1) * A1);
+    int32_t *overflow = (int32_t *)(losses_raw + 4);
+    const FixedPoint fx = fixed_point_for(*hp);
+    RNAD_HIP_OK(hipMemsetAsync(losses_raw, 0, 4 * sizeof(double) + sizeof(int32_t), stream));  // loss sums and the overflow flag
+    ProfScope prof(PROF_LEARN, stream);
+#define RNAD_BUCKET_LEARN()                                                                                                           \
+    do {                                                                                                                              \
+        auto kern = k_bucket_learn<kA>;                                                                                               \
+        if (p.lds > 48 * 1024) RNAD_HIP_OK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, p.lds)); \
+        hipLaunchKernelGGL(kern, dim3((unsigned)p.max_items), dim3(kThreads), (size_t)p.lds, stream, T, B, S, p.k, p.sub_rows,        \
+                           std::max(p.n_upper, 1), (const Item *)items, n_items, (const uint8_t *)tree->level_dev,                    \
+                           (const int32_t *)tree->order_pos, (const uint8_t *)tree->mask_tab, indices, actions, rewards, mu, records, \
+                           *hp, fx, acc, rep, losses ? losses_raw : (double *)nullptr, overflow);                                     \
+    } while (0)
+    RNAD_DISPATCH_A(tree->A, RNAD_BUCKET_LEARN());
+#undef RNAD_BUCKET_LEARN
+    RNAD_HIP_OK(hipGetLastError());
+    RNAD_DISPATCH_A(tree->A, hipLaunchKernelGGL((k_bucket_finish<kA>), dim3(blocks_for(2 * S)), dim3(kThreads), 0, stream, S,
+                                                p.n_upper, std::max(p.n_upper, 1), (const int32_t *)tree->order_pos, acc, rep,
+                                                norm, hp->w_v, hp->w_n, fx, overflow, losses_raw, losses, dlogit_tab, dv_tab));
+    RNAD_HIP_OK(hipGetLastError());
+    return 0;
+}

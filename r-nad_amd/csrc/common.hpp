@@ -85,6 +85,12 @@ struct rnad_tree {
     // tabular learner: the states of the top levels (the first n_hot entries of level_order) get a slot in a per-block LDS table
     int n_hot = 0;
     int32_t *hot_slot = nullptr;         // device [S]: position in level_order if < n_hot, else -1
+    // bucketed tabular pipeline (bucket.hip)
+    int32_t *order_pos = nullptr;        // device [S]: position of the state in level_order (-1: unreachable / state 0)
+    uint8_t *level_dev = nullptr;        // device [S]: depth below the root (255: unreachable / state 0)
+    uint8_t *mask_tab = nullptr;         // device [2][S]: the mover's legal-action bits at (player to move, state) (episode.py:208)
+    std::vector<int64_t> level_max_subtree;  // host [n_levels]: largest subtree (states, the root of it included) below a state of that level
+    bool contiguous_subtrees = false;    // ids are DFS pre-order: the subtree of s is exactly [s, s + size(s))  (tree.py:311-330)
     size_t bytes = 0;
 };
 

@@ -10,182 +10,17 @@
 // three-way select per step -- and B >> 256 CUs x 2048 lanes, so parallelism comes from the batch, not from T.
 // All fp32 expressions keep the reference's association order; the file is built with -ffp-contract=off.
 #include "common.hpp"
+#include "learn_math.hpp"
 
 #include <algorithm>
 
 using namespace rnad;
+using namespace rnad::dev;
 
 namespace {
 
 constexpr int kThreads = 256;
 inline unsigned blocks_for(int64_t n) { return (unsigned)((n + kThreads - 1) / kThreads); }
-
-// ---------------------------------------------------------------------------------------- device helpers
-// nn/net.py:45-46,76-77 (same function as in rollout.hip, kept local so each kernel file stands alone)
-template <int A>
-__device__ __forceinline__ void policy_head(const float (&logit)[A], uint32_t legal_bits, float (&policy)[A], float (&log_policy)[A]) {
-    float ex[A];
-    float s = 0.0f, s2 = 0.0f;
-#pragma unroll
-    for (int a = 0; a < A; ++a) {
-        ex[a] = ((legal_bits >> a) & 1) ? expf(logit[a]) : 0.0f;
-        s += fabsf(ex[a]);
-        s2 += ex[a];
-    }
-    const float d = fmaxf(s, 1e-12f);
-    const float ls = logf(s2);
-#pragma unroll
-    for (int a = 0; a < A; ++a) {
-        policy[a] = ex[a] / d;
-        log_policy[a] = ((legal_bits >> a) & 1) ? logit[a] - ls : 0.0f;
-    }
-}
-
-template <int A>
-__device__ __forceinline__ void log_policy_only(const float (&logit)[A], uint32_t legal_bits, float (&log_policy)[A]) {
-    float s2 = 0.0f;
-#pragma unroll
-    for (int a = 0; a < A; ++a) s2 += ((legal_bits >> a) & 1) ? expf(logit[a]) : 0.0f;
-    const float ls = logf(s2);
-#pragma unroll
-    for (int a = 0; a < A; ++a) log_policy[a] = ((legal_bits >> a) & 1) ? logit[a] - ls : 0.0f;
-}
-
-// learn/vtrace.py:24-55 for one row.  `mask` holds the caller's mask VALUES (0/1 in practice).
-template <int A>
-__device__ __forceinline__ void process_policy_row(const float (&pi)[A], const float (&mask)[A], int n_disc, float eps,
-                                                   float (&out)[A]) {
-    float mx = pi[0];
-#pragma unroll
-    for (int a = 1; a < A; ++a) mx = pi[a] > mx ? pi[a] : mx;
-    const bool all_below = mx < eps;  // :37 "prevent degen case where all < eps"
-    float m[A], p[A];
-    float s = 0.0f;
-#pragma unroll
-    for (int a = 0; a < A; ++a) {
-        m[a] = mask[a] * ((pi[a] >= eps) || all_below ? 1.0f : 0.0f);  // :34-39
-        s += m[a] * pi[a];
-    }
-#pragma unroll
-    for (int a = 0; a < A; ++a) {
-        p[a] = m[a] * pi[a] / s;  // :40
-        out[a] = 0.0f;
-    }
-    // argsort(descending) with ties in index order == rank by (#greater) + (#equal with lower index)  (:46)
-    int rank[A];
-#pragma unroll
-    for (int a = 0; a < A; ++a) {
-        int r = 0;
-#pragma unroll
-        for (int j = 0; j < A; ++j) r += (p[j] > p[a]) || (p[j] == p[a] && j < a);
-        rank[a] = r;
-    }
-    float leftover = (float)n_disc;
-    const float nf = (float)n_disc;
-#pragma unroll
-    for (int i = 0; i < A; ++i) {  // :47-51
-#pragma unroll
-        for (int a = 0; a < A; ++a) {
-            if (rank[a] == i) {
-                const float block = (float)(int32_t)ceilf(nf * p[a]);
-                const float x = fminf(leftover, block);
-                leftover -= x;
-                out[a] += x;
-            }
-        }
-    }
-#pragma unroll
-    for (int a = 0; a < A; ++a) out[a] /= nf;  // :52
-}
-
-__device__ __forceinline__ float clamp_max(float x, float hi) { return x != x ? x : (x < hi ? x : hi); }  // torch.clamp(max=)
-
-// Carry of the reverse scan, learn/vtrace.py:58-67 and :241-247.
-struct Carry {
-    float r = 0.0f, ru = 0.0f, nv = 0.0f, nvt = 0.0f, is = 1.0f;
-};
-
-struct VtHp {
-    float neg_eta, lambda_, c, rho, gamma;
-};
-
-// One timestep of _loop_v_trace (learn/vtrace.py:249-333) for one lane and one `player`.
-//   ours: valid && player_id == player.  oh[a] is the action one-hot VALUE (literal multiply as in :291).
-// Writes vt / q[] (zeros unless ours) and advances the carry.
-template <int A>
-__device__ __forceinline__ void vtrace_step(Carry &cy, const VtHp &hp, bool valid, bool ours, float valid_f, float vv, float rew,
-                                            const float (&mu)[A], const float (&pi)[A], const float (&logpi)[A],
-                                            const float (&oh)[A], float &vt_out, float (&q_out)[A]) {
-    // _policy_ratio (:199-204): sum(a_oh * pi) * valid + (1 - valid)
-    float s_pi = 0.0f, s_mu = 0.0f, s_one = 0.0f, ent = 0.0f;
-#pragma unroll
-    for (int a = 0; a < A; ++a) {
-        s_pi += oh[a] * pi[a];
-        s_mu += oh[a] * mu[a];
-        s_one += oh[a] * 1.0f;
-        ent += pi[a] * logpi[a];
-    }
-    const float inv = 1.0f - valid_f;
-    const float sel_mu = s_mu * valid_f + inv;
-    const float cs = (s_pi * valid_f + inv) / sel_mu;
-    const float inv_mu = (s_one * valid_f + inv) / sel_mu;
-    const float po = (ours ? 1.0f : -1.0f) * valid_f;  // _player_others (:83-87)
-    const float ere = hp.neg_eta * ent * po;           // eta_reg_entropy (:234-238)
-
-    const float ru = rew + hp.gamma * cy.ru + ere;  // reward_uncorrected (:262)
-    const float dr = rew + hp.gamma * cy.r;         // discounted_reward (:263)
-    const float w = cs * cy.is;
-    if (valid && ours) {
-        // our_v_target (:266-282)
-        const float vt = vv + clamp_max(w, hp.rho) * (ru + hp.gamma * cy.nv - vv) +
-                         hp.lambda_ * clamp_max(w, hp.c) * hp.gamma * (cy.nvt - cy.nv);
-        const float tail = dr + hp.gamma * cy.is * cy.nvt - vv;
-#pragma unroll
-        for (int a = 0; a < A; ++a) {
-            const float elp = hp.neg_eta * logpi[a] * po;  // eta_log_policy (:239)
-            q_out[a] = vv + elp + oh[a] * inv_mu * tail;   // our_learning_output (:288-300)
-        }
-        vt_out = vt;
-        cy.r = 0.0f; cy.ru = 0.0f; cy.nv = vv; cy.nvt = vt; cy.is = 1.0f;  // our_carry (:306-312)
-    } else {
-        vt_out = 0.0f;
-#pragma unroll
-        for (int a = 0; a < A; ++a) q_out[a] = 0.0f;
-        if (valid) {  // opp_carry (:313-319)
-            cy.r = ere + cs * dr; cy.ru = ru; cy.nv = hp.gamma * cy.nv; cy.nvt = hp.gamma * cy.nvt; cy.is = w;
-        } else {  // reset_carry (:320)
-            cy = Carry{};
-        }
-    }
-}
-
-// get_loss_nerd for one row and one player (learn/vtrace.py:410-429), with the closed-form gradient
-//   d/dlogit sum_a legal*l*f = w - legal * sum(w) / A,  w = legal * f   (f detached, :367,:418)
-template <int A>
-__device__ __forceinline__ float nerd_row(const float (&logit)[A], const float (&pi)[A], const float (&q)[A], const float (&legal)[A],
-                                          float clip, float thr, float (&grad)[A]) {
-    float base = 0.0f, mean = 0.0f;
-#pragma unroll
-    for (int a = 0; a < A; ++a) {
-        base += pi[a] * q[a];
-        mean += logit[a] * legal[a];
-    }
-    mean = mean / (float)A;  // torch.mean over ALL A (:420)
-    float w[A], wsum = 0.0f, nerd = 0.0f;
-#pragma unroll
-    for (int a = 0; a < A; ++a) {
-        float adv = q[a] - base;                                   // :415 (is_c == 1, :416)
-        adv = adv != adv ? adv : fminf(fmaxf(adv, -clip), clip);   // :417
-        const float l = logit[a] - mean;
-        const float f = (l > -thr ? 1.0f : 0.0f) * fminf(adv, 0.0f) + (l < thr ? 1.0f : 0.0f) * fmaxf(adv, 0.0f);  // :362-366
-        nerd += legal[a] * (l * f);                                // :424-428
-        w[a] = legal[a] * f;
-        wsum += w[a];
-    }
-#pragma unroll
-    for (int a = 0; a < A; ++a) grad[a] = w[a] - legal[a] * wsum / (float)A;
-    return nerd;
-}
 
 // Sum `x` over the block in double and add it to *dst with one atomic.
 __device__ __forceinline__ void block_atomic_add(double x, double *dst) {
@@ -256,11 +91,6 @@ __global__ __launch_bounds__(kThreads) void k_mask_sum(int64_t N, const float *_
     double s = 0.0;
     for (int64_t n = (int64_t)blockIdx.x * kThreads + threadIdx.x; n < N; n += (int64_t)gridDim.x * kThreads) s += (double)mask[n];
     block_atomic_add(s, out);
-}
-
-__device__ __forceinline__ float norm_of(const double *norm) {
-    const float n = (float)norm[0];
-    return n + (n == 0.0f ? 1.0f : 0.0f);  // normalization + (normalization == 0.0)  (:374,:389)
 }
 
 template <bool ACC>
@@ -399,9 +229,6 @@ __global__ __launch_bounds__(kThreads) void k_tab_finish(int64_t rows, const uns
     for (int a = 0; a < A; ++a) dlogit[r * A + a] = (float)((double)(long long)acc[r * (A + 1) + a] / fixed_scale(gmax[a]));
     dv[r] = (float)((double)(long long)acc[r * (A + 1) + A] / fixed_scale(gmax[A]));
 }
-
-template <int A>
-constexpr int kRecStride = (3 * A + 2 + 3) & ~3;  // floats per row record of the tabular learner, a multiple of 4
 
 template <int A>
 __global__ __launch_bounds__(kThreads) void k_pack_records(int64_t rows, const float *__restrict__ logit, const float *__restrict__ v,
@@ -746,6 +573,20 @@ extern "C" int rnad_row_sums(const rnad_tree_t *tree, int T, int64_t B, const in
         RNAD_DISPATCH_A(A, hipLaunchKernelGGL((k_grad_maxima<kA>), dim3(grid), dim3(kThreads), 0, stream, N, indices, dlogit, dv, gmax));
     }
     return row_sums_launch(tree, T, B, indices, dlogit, dv, gmax, acc, dlogit_tab, dv_tab, stream);
+}
+
+// The five net-output tables of a tabular update interleaved into one record per (player, state) row:
+//   lg[A] | v | v_target | lr[A] | lr2[A] | pad to a multiple of 4 floats   (rnad_learn_record_stride(A) floats per row)
+extern "C" int64_t rnad_learn_record_stride(int A) { return (3 * (int64_t)A + 2 + 3) & ~(int64_t)3; }
+
+extern "C" int rnad_learn_records(const rnad_tree_t *tree, const float *logit_tab, const float *v_tab, const float *v_target_tab,
+                                  const float *logit_reg_tab, const float *logit_reg_tab_, float *records, void *stream) {
+    RNAD_REQUIRE(tree && logit_tab && v_tab && v_target_tab && logit_reg_tab && logit_reg_tab_ && records, "rnad_learn_records: null argument");
+    RNAD_REQUIRE(((uintptr_t)records & 15) == 0, "rnad_learn_records: records must be 16-byte aligned");
+    RNAD_DISPATCH_A(tree->A, hipLaunchKernelGGL((k_pack_records<kA>), dim3(blocks_for(2 * tree->S)), dim3(kThreads), 0, (hipStream_t)stream,
+                                                2 * tree->S, logit_tab, v_tab, v_target_tab, logit_reg_tab, logit_reg_tab_, records));
+    RNAD_HIP_OK(hipGetLastError());
+    return 0;
 }
 
 // Tables in, per-slot gradients out: the forward evaluations are deduplicated (2S rows instead of T*B slots), the backward is

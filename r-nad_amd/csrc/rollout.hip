@@ -3,10 +3,12 @@
 // Replaces: nn/net.py:45-49,74-77 (masked exp-normalise, log-policy, multinomial), environment/episode.py:96-125
 // (States.step) and :175-230 (Episodes.generate).  Citations are baskuit/R-NaD file:line.
 #include "common.hpp"
+#include "rollout_math.hpp"
 
 #include <algorithm>
 
 using namespace rnad;
+using namespace rnad::dev;
 
 namespace rnad {
 int launch_observe(const rnad_tree_t *tree, int64_t B, const int32_t *idx, int player, void *obs, int obs_half, uint8_t *mbits,
@@ -16,87 +18,6 @@ int launch_observe(const rnad_tree_t *tree, int64_t B, const int32_t *idx, int p
 namespace {
 
 constexpr int kThreads = 256;
-
-// nn/net.py:45-46: exp_logits = where(legal, exp(logits), 0); policy = normalize(exp_logits, p=1) (eps 1e-12).
-// :76-77: log_policy = where(legal, logits - log(sum(exp_logits)), 0).
-template <int A>
-__device__ __forceinline__ void policy_head(const float *logit, uint32_t legal_bits, float *policy, float *log_policy) {
-    float ex[A];
-    float s = 0.0f;
-#pragma unroll
-    for (int a = 0; a < A; ++a) {
-        ex[a] = ((legal_bits >> a) & 1) ? expf(logit[a]) : 0.0f;
-        s += fabsf(ex[a]);
-    }
-    const float d = fmaxf(s, 1e-12f);
-#pragma unroll
-    for (int a = 0; a < A; ++a) policy[a] = ex[a] / d;
-    if (log_policy) {
-        float s2 = 0.0f;
-#pragma unroll
-        for (int a = 0; a < A; ++a) s2 += ex[a];
-        const float ls = logf(s2);
-#pragma unroll
-        for (int a = 0; a < A; ++a) log_policy[a] = ((legal_bits >> a) & 1) ? logit[a] - ls : 0.0f;
-    }
-}
-
-// torch CPU multinomial(p, 1) == argmax(p / q), q ~ Exp(1), first maximum wins (Distributions.cpp, n_sample == 1).
-template <int N>
-__device__ __forceinline__ int race_argmax(const float *p, const float *q) {
-    int best = 0;
-    float bv = p[0] / q[0];
-#pragma unroll
-    for (int a = 1; a < N; ++a) {
-        const float r = p[a] / q[a];
-        if (r > bv) {
-            bv = r;
-            best = a;
-        }
-    }
-    return best;
-}
-
-// Runtime category count n <= NMAX without runtime-indexed arrays (those would live in scratch): fully
-// unrolled, predicated on k < n.
-template <int NMAX>
-__device__ __forceinline__ void exp_noise_n(uint64_t seed, uint64_t lane, uint32_t step, uint32_t stream, int n,
-                                            float (&q)[NMAX]) {
-#pragma unroll
-    for (int j = 0; j < NMAX; j += 4) {
-        if (j < n) {
-            uint32_t c[4] = {(uint32_t)lane, (uint32_t)(lane >> 32), step | (stream << 24), (uint32_t)(j >> 2)};
-            rnad_philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-                if (j + i < NMAX) q[j + i] = rnad_neg_log_u(c[i]);
-        }
-    }
-}
-
-template <int NMAX>
-__device__ __forceinline__ void load_n(const float *__restrict__ src, int n, float (&dst)[NMAX]) {
-#pragma unroll
-    for (int k = 0; k < NMAX; ++k)
-        if (k < n) dst[k] = src[k];
-}
-
-template <int NMAX>
-__device__ __forceinline__ int race_argmax_n(int n, const float (&p)[NMAX], const float (&q)[NMAX]) {
-    int best = 0;
-    float bv = p[0] / q[0];
-#pragma unroll
-    for (int a = 1; a < NMAX; ++a) {
-        if (a < n) {
-            const float r = p[a] / q[a];
-            if (r > bv) {
-                bv = r;
-                best = a;
-            }
-        }
-    }
-    return best;
-}
 
 template <int A>
 __global__ __launch_bounds__(kThreads) void k_policy_head(int64_t N, const float *__restrict__ logits,
@@ -112,7 +33,7 @@ __global__ __launch_bounds__(kThreads) void k_policy_head(int64_t N, const float
         if (!mbits) bits |= (maskf[n * A + a] != 0.0f ? 1u : 0u) << a;
     }
     if (mbits) bits = mbits[n];
-    policy_head<A>(l, bits, p, log_policy ? lp : nullptr);
+    policy_head_ptr<A>(l, bits, p, log_policy ? lp : nullptr);
 #pragma unroll
     for (int a = 0; a < A; ++a) {
         policy[n * A + a] = p[a];
@@ -132,34 +53,6 @@ __global__ __launch_bounds__(kThreads) void k_sample(int64_t B, int n, const flo
     else
         exp_noise_n<RNAD_MAX_ACTIONS>(seed, (uint64_t)(lane0 + b), (uint32_t)step, (uint32_t)stream_id, n, q);
     out[b] = race_argmax_n<RNAD_MAX_ACTIONS>(n, p, q);
-}
-
-// environment/episode.py:106-121 for one lane: the C chance outcomes of joint action (r, c) are 12*C contiguous bytes.
-template <int A>
-__device__ __forceinline__ void transition_lane(const Trans *__restrict__ trans, int C, int s, int r, int c,
-                                                const float *__restrict__ noise_c, uint64_t seed, uint64_t lane, uint32_t step,
-                                                int &next, float &reward) {
-    const Trans *e = trans + (((int64_t)s * A + r) * A + c) * C;
-    float q[RNAD_MAX_TRANSITIONS];
-    if (noise_c)
-        load_n<RNAD_MAX_TRANSITIONS>(noise_c, C, q);
-    else
-        exp_noise_n<RNAD_MAX_TRANSITIONS>(seed, lane, step, 1u, C, q);
-    Trans best = e[0];
-    float bv = best.chance / q[0];
-#pragma unroll
-    for (int t = 1; t < RNAD_MAX_TRANSITIONS; ++t) {
-        if (t < C) {
-            const Trans et = e[t];
-            const float rr = et.chance / q[t];
-            if (rr > bv) {
-                bv = rr;
-                best = et;
-            }
-        }
-    }
-    next = best.next;
-    reward = best.value * (next == 0 ? 1.0f : 0.0f);  // rewards *= (indices == 0): keeps -0.0
 }
 
 template <int A>
@@ -213,7 +106,7 @@ __global__ __launch_bounds__(kThreads) void k_act(const Trans *__restrict__ tran
 #pragma unroll
         for (int a = 0; a < A; ++a) in[a] = net_out[src * A + a];
         if (MODE == 0) {
-            policy_head<A>(in, mbits_t[b], pol, nullptr);
+            policy_head_ptr<A>(in, mbits_t[b], pol, nullptr);
         } else {
 #pragma unroll
             for (int a = 0; a < A; ++a) pol[a] = in[a];

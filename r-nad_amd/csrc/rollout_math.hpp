@@ -1,0 +1,122 @@
+// rollout_math.hpp -- per-lane device arithmetic of the rollout, shared by rollout.hip and bucket.hip (gfx950).
+//
+// nn/net.py:45-49 (masked exp-normalise policy head, multinomial as an Exp(1) race) and environment/episode.py:106-121 (the
+// chance draw and transition of States.step) for one lane.  Citations are baskuit/R-NaD file:line.
+#pragma once
+
+#include "common.hpp"
+
+namespace rnad {
+namespace dev {
+
+// nn/net.py:45-46: exp_logits = where(legal, exp(logits), 0); policy = normalize(exp_logits, p=1) (eps 1e-12).
+// :76-77: log_policy = where(legal, logits - log(sum(exp_logits)), 0).
+template <int A>
+__device__ __forceinline__ void policy_head_ptr(const float *logit, uint32_t legal_bits, float *policy, float *log_policy) {
+    float ex[A];
+    float s = 0.0f;
+#pragma unroll
+    for (int a = 0; a < A; ++a) {
+        ex[a] = ((legal_bits >> a) & 1) ? expf(logit[a]) : 0.0f;
+        s += fabsf(ex[a]);
+    }
+    const float d = fmaxf(s, 1e-12f);
+#pragma unroll
+    for (int a = 0; a < A; ++a) policy[a] = ex[a] / d;
+    if (log_policy) {
+        float s2 = 0.0f;
+#pragma unroll
+        for (int a = 0; a < A; ++a) s2 += ex[a];
+        const float ls = logf(s2);
+#pragma unroll
+        for (int a = 0; a < A; ++a) log_policy[a] = ((legal_bits >> a) & 1) ? logit[a] - ls : 0.0f;
+    }
+}
+
+// torch CPU multinomial(p, 1) == argmax(p / q), q ~ Exp(1), first maximum wins (Distributions.cpp, n_sample == 1).
+template <int N>
+__device__ __forceinline__ int race_argmax(const float *p, const float *q) {
+    int best = 0;
+    float bv = p[0] / q[0];
+#pragma unroll
+    for (int a = 1; a < N; ++a) {
+        const float r = p[a] / q[a];
+        if (r > bv) {
+            bv = r;
+            best = a;
+        }
+    }
+    return best;
+}
+
+// Runtime category count n <= NMAX without runtime-indexed arrays (those would live in scratch): fully
+// unrolled, predicated on k < n.
+template <int NMAX>
+__device__ __forceinline__ void exp_noise_n(uint64_t seed, uint64_t lane, uint32_t step, uint32_t stream, int n,
+                                            float (&q)[NMAX]) {
+#pragma unroll
+    for (int j = 0; j < NMAX; j += 4) {
+        if (j < n) {
+            uint32_t c[4] = {(uint32_t)lane, (uint32_t)(lane >> 32), step | (stream << 24), (uint32_t)(j >> 2)};
+            rnad_philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (j + i < NMAX) q[j + i] = rnad_neg_log_u(c[i]);
+        }
+    }
+}
+
+template <int NMAX>
+__device__ __forceinline__ void load_n(const float *__restrict__ src, int n, float (&dst)[NMAX]) {
+#pragma unroll
+    for (int k = 0; k < NMAX; ++k)
+        if (k < n) dst[k] = src[k];
+}
+
+template <int NMAX>
+__device__ __forceinline__ int race_argmax_n(int n, const float (&p)[NMAX], const float (&q)[NMAX]) {
+    int best = 0;
+    float bv = p[0] / q[0];
+#pragma unroll
+    for (int a = 1; a < NMAX; ++a) {
+        if (a < n) {
+            const float r = p[a] / q[a];
+            if (r > bv) {
+                bv = r;
+                best = a;
+            }
+        }
+    }
+    return best;
+}
+
+// environment/episode.py:106-121 for one lane: the C chance outcomes of joint action (r, c) are 12*C contiguous bytes.
+template <int A>
+__device__ __forceinline__ void transition_lane(const Trans *__restrict__ trans, int C, int s, int r, int c,
+                                                const float *__restrict__ noise_c, uint64_t seed, uint64_t lane, uint32_t step,
+                                                int &next, float &reward) {
+    const Trans *e = trans + (((int64_t)s * A + r) * A + c) * C;
+    float q[RNAD_MAX_TRANSITIONS];
+    if (noise_c)
+        load_n<RNAD_MAX_TRANSITIONS>(noise_c, C, q);
+    else
+        exp_noise_n<RNAD_MAX_TRANSITIONS>(seed, lane, step, 1u, C, q);
+    Trans best = e[0];
+    float bv = best.chance / q[0];
+#pragma unroll
+    for (int t = 1; t < RNAD_MAX_TRANSITIONS; ++t) {
+        if (t < C) {
+            const Trans et = e[t];
+            const float rr = et.chance / q[t];
+            if (rr > bv) {
+                bv = rr;
+                best = et;
+            }
+        }
+    }
+    next = best.next;
+    reward = best.value * (next == 0 ? 1.0f : 0.0f);  // rewards *= (indices == 0): keeps -0.0
+}
+
+}  // namespace dev
+}  // namespace rnad

@@ -186,7 +186,52 @@ extern "C" int rnad_tree_create(rnad_tree_t **out, int64_t S, int C, int A, cons
         if ((e = hipMemcpy(tree->hot_slot, slot.data(), slot.size() * sizeof(int32_t), hipMemcpyHostToDevice)) != hipSuccess)
             return fail(e, "hipMemcpy(hot_slot)");
     }
-    tree->bytes = node.size() * sizeof(float) + trans.size() * sizeof(Trans) + order.size() * sizeof(int32_t) + (size_t)S * sizeof(int32_t);
+    // bucketed tabular pipeline: level-order position, depth and mover's legal bits per state; subtree sizes per level
+    {
+        std::vector<int32_t> pos((size_t)S, -1);
+        std::vector<uint8_t> lev((size_t)S, 255);
+        for (int64_t k = 0; k < count[tree->n_levels]; ++k) pos[(size_t)order[(size_t)k]] = (int32_t)k;
+        for (int64_t s = 1; s < S; ++s)
+            if (tree->level_of[s] >= 0) lev[(size_t)s] = (uint8_t)std::min(tree->level_of[s], 254);
+        std::vector<uint8_t> mtab((size_t)2 * S, 0);
+        for (int64_t s = 0; s < S; ++s)
+            for (int P = 0; P < 2; ++P) {
+                uint32_t mb = 0;
+                for (int i = 0; i < A; ++i) {
+                    const int src = P ? i : i * A;  // observations[:, 1, i, 0] of the mover's view (k_observe)
+                    if (legal[s * AA + src] != 0.0f) mb |= 1u << i;
+                }
+                mtab[(size_t)P * S + s] = (uint8_t)mb;
+            }
+        // subtree extents: children have larger ids, so a descending pass sees every child before its parent
+        std::vector<int64_t> end((size_t)S), desc((size_t)S, 0);
+        for (int64_t s = 0; s < S; ++s) end[(size_t)s] = s + 1;
+        bool contiguous = true;
+        for (int64_t s = S - 1; s >= 1; --s) {
+            if (tree->level_of[s] < 0) continue;
+            for (int k = 0; k < AA * C; ++k) {
+                const Trans &e = trans[(size_t)s * AA * C + k];
+                if (e.next != 0 && e.chance > 0.0f) {
+                    end[(size_t)s] = std::max(end[(size_t)s], end[(size_t)e.next]);
+                    desc[(size_t)s] += 1 + desc[(size_t)e.next];
+                }
+            }
+            if (end[(size_t)s] - s != 1 + desc[(size_t)s]) contiguous = false;
+        }
+        tree->contiguous_subtrees = contiguous;
+        tree->level_max_subtree.assign((size_t)tree->n_levels, 1);
+        for (int64_t s = 1; s < S; ++s)
+            if (tree->level_of[s] >= 0)
+                tree->level_max_subtree[(size_t)tree->level_of[s]] = std::max(tree->level_max_subtree[(size_t)tree->level_of[s]], 1 + desc[(size_t)s]);
+        if ((e = hipMalloc((void **)&tree->order_pos, pos.size() * sizeof(int32_t))) != hipSuccess) return fail(e, "hipMalloc(order_pos)");
+        if ((e = hipMalloc((void **)&tree->level_dev, lev.size())) != hipSuccess) return fail(e, "hipMalloc(level_dev)");
+        if ((e = hipMalloc((void **)&tree->mask_tab, mtab.size())) != hipSuccess) return fail(e, "hipMalloc(mask_tab)");
+        if ((e = hipMemcpy(tree->order_pos, pos.data(), pos.size() * sizeof(int32_t), hipMemcpyHostToDevice)) != hipSuccess)
+            return fail(e, "hipMemcpy(order_pos)");
+        if ((e = hipMemcpy(tree->level_dev, lev.data(), lev.size(), hipMemcpyHostToDevice)) != hipSuccess) return fail(e, "hipMemcpy(level_dev)");
+        if ((e = hipMemcpy(tree->mask_tab, mtab.data(), mtab.size(), hipMemcpyHostToDevice)) != hipSuccess) return fail(e, "hipMemcpy(mask_tab)");
+    }
+    tree->bytes = (size_t)S * (sizeof(int32_t) + 3) + node.size() * sizeof(float) + trans.size() * sizeof(Trans) + order.size() * sizeof(int32_t) + (size_t)S * sizeof(int32_t);
     *out = tree;
     return 0;
 }
@@ -197,6 +242,9 @@ extern "C" void rnad_tree_destroy(rnad_tree_t *tree) {
     if (tree->trans) (void)hipFree(tree->trans);
     if (tree->level_order) (void)hipFree(tree->level_order);
     if (tree->hot_slot) (void)hipFree(tree->hot_slot);
+    if (tree->order_pos) (void)hipFree(tree->order_pos);
+    if (tree->level_dev) (void)hipFree(tree->level_dev);
+    if (tree->mask_tab) (void)hipFree(tree->mask_tab);
     delete tree;
 }
 

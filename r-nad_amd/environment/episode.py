@@ -95,6 +95,8 @@ class Episodes:
     """A parallel batch of rollout trajectories from the root (reference episode.py:131-290)."""
 
     _PRIMARY = ("indices", "observations", "mask_bits", "policy", "action_idx", "rewards", "values")
+    _observations = _values = None  # class-level defaults: objects assembled without __init__ (tests, collate) behave the same
+    lane_ids = buckets = None
 
     def __init__(self, tree: Tree, batch_size, seed=None, lane_offset=0, obs_half=False):
         self.tree: Tree = tree
@@ -107,8 +109,11 @@ class Episodes:
         self.generation_time: float = 0
         self.estimation_time: float = 0
         self.t_eff: int = -1
-        self.indices = self.observations = self.mask_bits = self.policy = None
-        self.action_idx = self.rewards = self.values = None
+        self.indices = self.mask_bits = self.policy = None
+        self.action_idx = self.rewards = None
+        self._observations = self._values = None  # lazily materialised when the rollout did not store them (bucketed rollout)
+        self.lane_ids = None  # int32 [B]: lane (0-based within this batch) held by column j; None = column j is lane j
+        self.buckets = None   # rnad_hip.Buckets of a bucket-ordered batch (work list of rnad_learn_bucketed)
         self.alive = None  # int32 [T + 1] on the device: lanes with indices[t] != 0
         self.actor_logits = None  # [T, B, A] raw logits of the actor (generate(keep_logits=True), native rollout only)
         self._lazy = {}
@@ -118,6 +123,34 @@ class Episodes:
         if key not in self._lazy:
             self._lazy[key] = make()
         return self._lazy[key]
+
+    @property
+    def observations(self):
+        """[T, B, 2, A, A] (episode.py:199,221).  An observation is a function of (player to move, state) alone (episode.py:62-68):
+        a rollout that did not store it (the bucketed one) gets it from K1 on first access."""
+        if self._observations is None and self.indices is not None:
+            T, B, A = self.t_eff + 1, self.batch_size, self.tree.max_actions
+            handle = self.tree.handle()
+            obs = torch.empty((T, B, 2, A, A), dtype=torch.float16 if self.obs_half else torch.float32, device=self.indices.device)
+            for t in range(T):
+                rnad_hip.observe(handle, self.indices[t], t & 1, obs=obs[t], half=self.obs_half)
+            self._observations = obs
+        return self._observations
+
+    @observations.setter
+    def observations(self, value):
+        self._observations = value
+
+    @property
+    def values(self):
+        """[T, B] actor values (episode.py:206,218); zeros when the rollout skipped the actor's value head (nothing reads them)."""
+        if self._values is None and self.indices is not None:
+            self._values = torch.zeros((self.t_eff + 1, self.batch_size), dtype=torch.float32, device=self.indices.device)
+        return self._values
+
+    @values.setter
+    def values(self, value):
+        self._values = value
 
     @property
     def turns(self):
@@ -132,8 +165,10 @@ class Episodes:
 
     @property
     def masks(self):
-        """[T, B, A] legal actions of the mover == observations[:, :, 1, :, 0] (episode.py:208); a strided view."""
-        return self._get("masks", lambda: self.observations[:, :, 1, :, 0].to(torch.float))
+        """[T, B, A] legal actions of the mover == observations[:, :, 1, :, 0] (episode.py:208), expanded from `mask_bits`."""
+        A = self.tree.max_actions
+        return self._get("masks", lambda: ((self.mask_bits.unsqueeze(-1) >> torch.arange(A, device=self.mask_bits.device, dtype=torch.uint8)) & 1)
+                         .to(torch.float))
 
     @property
     def q_estimates(self):
@@ -152,7 +187,7 @@ class Episodes:
 
     # ---------------------------------------------------------------- episode.py:175-230
     def generate(self, net: torch.nn.Module, noise_action=None, noise_chance=None, max_steps=None, trim=True, keep_logits=False,
-                 skip_absorbed=False, store_values=True, tabular=None):
+                 skip_absorbed=False, store_values=True, tabular=None, bucketed=False, logits_table=None, value_table=None):
         """Play the batch to the end with `net` as the actor.
 
         Nets exposing `forward_logits(obs) -> (logits [B,A], value [B,1])` (the MLP here) take the fast path: policy head,
@@ -175,6 +210,12 @@ class Episodes:
         episode.py:62-68) and each step gathers its logits / value row -- the same rollout bit for bit (same inputs, same
         kernel) at 2S instead of T*B net evaluations.  tabular=False evaluates the net on every lane at every step.
 
+        bucketed=True (tabular actor only; what RNaD's per-row update uses): the same episodes, but column j of every buffer holds
+        lane `lane_ids[j]` -- the lanes stably sorted by the state they reach at a fixed depth of the tree -- and `buckets` carries
+        the work list of rnad_learn_bucketed; `observations` are not stored (materialised on first access).  Falls back to the
+        lane-ordered rollout when the tree cannot be bucketed.  logits_table / value_table: the actor already evaluated on the
+        tree's 2S observations (row = player * S + state; logits in the first A columns), instead of evaluating `net` here.
+
         store_values=False (native MLP actor only): the actor's value head is not evaluated and `values` is zeros.  The
         reference stores the actor's values (episode.py:206,218) but nothing ever reads them (learn/rnad.py:373 recomputes v
         with the learner net), so RNaD's own rollouts do without, unless `reuse_actor_outputs` needs them.
@@ -183,7 +224,6 @@ class Episodes:
         handle = tree.handle()
         T_cap = 2 * handle.max_depth if max_steps is None else int(max_steps)
         dev = self.states.indices.device
-        traj = rnad_hip.Trajectory(handle, B, T_cap, dev, half=self.obs_half)
         fast = hasattr(net, "forward_logits")
         packed = net.pack() if fast and hasattr(net, "pack") else None  # weights are fixed for the whole rollout
         net.eval()
@@ -191,11 +231,24 @@ class Episodes:
         native = packed is not None and noise_action is None and noise_chance is None and type(net).forward_logits is _MLP.forward_logits
         if tabular is None:
             tabular = 8 * handle.S <= T_cap * B
-        if native and tabular and not keep_logits:
-            # one actor evaluation per (player, state), then the whole loop natively with per-lane gathers (rnad_rollout_run_tabular)
-            table, vtable = rnad_hip.mlp_forward(packed, net.width, handle.observations_table(self.obs_half), tree.max_actions,
-                                                 want_value=store_values)
-            rnad_hip.rollout_run_tabular(handle, traj, table, vtable, seed=self.seed, lane0=self.lane_offset)
+        tabular = native and tabular and not keep_logits
+        bucketed = bool(bucketed) and tabular and T_cap <= 64 and rnad_hip.bucket_plan(handle, B) is not None
+        traj = rnad_hip.Trajectory(handle, B, T_cap, dev, half=self.obs_half, with_observations=not bucketed,
+                                   with_values=store_values or not bucketed)
+        self.buckets = self.lane_ids = None
+        if tabular:
+            # one actor evaluation per (player, state), then the whole loop natively with per-lane gathers
+            table, vtable = logits_table, value_table
+            if table is None:
+                table, vtable = rnad_hip.mlp_forward(packed, net.width, handle.observations_table(self.obs_half), tree.max_actions,
+                                                     want_value=store_values)
+            if bucketed:
+                self.buckets = rnad_hip.rollout_bucketed(handle, traj, table, vtable if store_values else None, seed=self.seed,
+                                                         lane0=self.lane_offset)
+                self.lane_ids = self.buckets.lane_ids
+            else:
+                rnad_hip.rollout_run_tabular(handle, traj, table[:, : tree.max_actions].contiguous(), vtable if store_values else None,
+                                             seed=self.seed, lane0=self.lane_offset)
         elif native:
             # the actor is this package's MLP: the whole loop is enqueued natively (rnad_rollout_run)
             self.actor_logits = rnad_hip.rollout_run(handle, traj, net.width, packed, seed=self.seed, lane0=self.lane_offset,
@@ -229,12 +282,12 @@ class Episodes:
         self._traj = traj
         self.t_eff = T - 1
         self.indices = traj.indices[:T]
-        self.observations = traj.observations[:T]
+        self.observations = traj.observations[:T] if traj.observations is not None else None
         self.mask_bits = traj.mask_bits[:T]
         self.policy = traj.policy[:T]
         self.action_idx = traj.actions[:T]
         self.rewards = traj.rewards[:T]
-        self.values = traj.values[:T]
+        self.values = traj.values[:T] if traj.values is not None else None
         self.alive = traj.alive[: T + 1]
         if self.actor_logits is not None:
             self.actor_logits = self.actor_logits[:T]
@@ -259,8 +312,10 @@ class Episodes:
         result.finished = True
         return result
 
-    def sample(self, batch_size, shuffle=False):
+    def sample(self, batch_size, shuffle=False, selected=None):
         """A uniformly random subset of `batch_size` lanes (reference: `random.sample` + index_select on every tensor).
+        selected: take exactly these lanes, in this order (an int64 index tensor / sequence) instead of drawing them -- how the
+        tests replay the reference's own `random.sample` draws.
 
         Asking for the whole batch -- what RNaD does every step with the default one-batch buffer (rnad.py:507) -- is a
         pure permutation of lanes in the reference, and no loss term depends on the lane order, so it returns `self`
@@ -268,17 +323,24 @@ class Episodes:
         a device permutation seeded from python's `random`."""
         assert self.finished
         batch_size = min(batch_size, self.batch_size)
-        if batch_size == self.batch_size and not shuffle:
-            return self
         dev = self.indices.device
-        g = torch.Generator(device=dev)
-        g.manual_seed(random.getrandbits(62))
-        selected = torch.randperm(self.batch_size, generator=g, device=dev)[:batch_size]
+        drawn = selected is None
+        if selected is not None:
+            selected = torch.as_tensor(selected, dtype=torch.long, device=dev)
+            assert selected.numel() == batch_size, "`selected` must list min(batch_size, self.batch_size) lanes"
+        elif batch_size == self.batch_size and not shuffle:
+            return self
+        else:
+            g = torch.Generator(device=dev)
+            g.manual_seed(random.getrandbits(62))
+            selected = torch.randperm(self.batch_size, generator=g, device=dev)[:batch_size]
         result = self._like(batch_size)
         for key in self._PRIMARY:
             setattr(result, key, torch.index_select(getattr(self, key), dim=1, index=selected))
         result.t_eff = self.t_eff
-        if batch_size == self.batch_size:
+        if self.lane_ids is not None:
+            result.lane_ids = torch.index_select(self.lane_ids, 0, selected)
+        if drawn and batch_size == self.batch_size:
             result.alive = self.alive  # a permutation keeps the per-step counts
         else:
             alive = torch.zeros_like(self.alive)

@@ -126,12 +126,18 @@ class RNaD:
         # rollout that just finished, with unchanged weights, so forward_batch(net) (rnad.py:373) recomputes bit-identical
         # logits / values; when True they are taken from the rollout and only the backward runs.
         self.reuse_actor_outputs = False
-        # Tabular net evaluation (default "forward"): observations are a function of (state, player to move), so the nets can be
-        # evaluated on the 2S distinct observations of the tree instead of on every (t, b) slot -- see __learn.  Same rollouts and
-        # losses bit for bit; weight gradients equal up to fp32 summation order (and, because the per-row sums use fp64 atomics,
-        # not bitwise reproducible from run to run).  "forward": only the forward evaluations are deduplicated, the backward
-        # stays per slot -- every result is then bit-identical to the dense path.  Used only when 8 S <= T B.
-        self.tabular = "forward"
+        # Tabular net evaluation: observations are a function of (state, player to move), so on a tree that is small next to the
+        # batch (tabular_gate * S <= T * B) the nets are evaluated on the 2S distinct observations instead of on every (t, b) slot
+        # -- see __learn.  Rollouts, per-slot net outputs, V-trace targets and losses are the dense path's bits in every mode.
+        #   True (default)  the per-slot gradients are also summed per (player, state) row (64-bit fixed point: reproducible bit
+        #                   for bit) and ONE backward over the 2S observations gives the weight gradients -- equal to the dense
+        #                   path's up to fp32 summation order (1e-5 of the largest entry; pinned against the reference's own
+        #                   gradients in tests/test_hip_parity.py and tests/test_hip_replay.py);
+        #   "forward"       only the forward evaluations are deduplicated, the backward runs per slot: weight gradients
+        #                   bit-identical to the dense path;
+        #   False           every net on every slot, as the reference does.
+        self.tabular = True
+        self.tabular_gate = 8
         # ragged trajectories: evaluate / differentiate the nets on live (t, b) slots only (see __learn); same losses and gradients
         self.skip_absorbed = True
         self.obs_half = False  # store observations as fp16 (BASELINE.json configs[4]); arithmetic stays fp32
@@ -302,6 +308,41 @@ class RNaD:
             self._reg_identical_key = key
         return self._reg_identical
 
+    # ------------------------------------------------------------------ tabular evaluation of the four nets
+    def _fused_mlp(self):
+        A = self.tree.max_actions
+        return isinstance(self.net, net.MLP) and self.net._fusable() and rnad_hip.mlp_backward_supported(A, self.net.width)
+
+    def _tabular_mode(self, T, B):
+        """RNaD.tabular if the tree is small enough next to a [T, B] trajectory for the table evaluation to pay, else False."""
+        mode = getattr(self, "tabular", False)
+        if not mode or not self._fused_mlp():
+            return False
+        if getattr(self, "tabular_gate", 8) * self.tree.handle().S > T * B:
+            return False
+        if mode is True and B > 2**21:  # the fixed-point row sums take at most 2^21 lanes per call
+            return "forward"
+        return mode
+
+    def _table_outputs(self, alpha, obs_half=False, want_target_logits=False):
+        """learner / target / regularisation nets on the 2S observations of the tree, ONE launch (rnad.py:373-380 on every distinct
+        input).  log_policy_reg (:382) needs one regularisation net only when alpha is 0 or 1, or while both hold the same weights."""
+        A = self.tree.max_actions
+        table = self.tree.handle().observations_table(obs_half)
+        nets, wants = [self.net, self.net_target], [(True, True), (want_target_logits, True)]
+        if alpha == 0:
+            nets.append(self.net_reg_)
+        else:
+            nets.append(self.net_reg)
+            if not (alpha == 1 or self._reg_nets_identical()):
+                nets.append(self.net_reg_)
+        wants += [(True, False)] * (len(nets) - 2)
+        with torch.no_grad():
+            outs = rnad_hip.mlp_forward_multi([n_.pack() for n_ in nets], self.net.width, table, A, wants)
+        out = dict(table=table, logit=outs[0][0], v=outs[0][1], logit_target=outs[1][0], v_target=outs[1][1], logit_reg=outs[2][0],
+                   logit_reg_=outs[3][0] if len(outs) > 3 else outs[2][0])
+        return out
+
     # ------------------------------------------------------------------ reference learn/rnad.py:353-456
     @staticmethod
     def _logits_of(module, episodes, want_logits=True, want_value=True, live=None, table=None):
@@ -318,8 +359,9 @@ class RNaD:
         A = logit.shape[-1]
         return logit.reshape(-1, A), v.reshape(-1, 1)
 
-    def __learn(self, episodes: episode.Episodes, alpha: float, log: dict = None):
-        """Gradients of the learner net from a batch of trajectories (reward transform + V-trace + NeuRD)."""
+    def __learn(self, episodes: episode.Episodes, alpha: float, log: dict = None, tables: dict = None):
+        """Gradients of the learner net from a batch of trajectories (reward transform + V-trace + NeuRD).
+        tables: _table_outputs(alpha) of the CURRENT nets, when train_step already evaluated them for the rollout."""
         T, B, A = episodes.t_eff + 1, episodes.batch_size, self.tree.max_actions
 
         # N_P = #(valid & turn == P): batch-global loss normalisers (vtrace.py:373,388).  Their all-reduce over the ranks is
@@ -334,19 +376,19 @@ class RNaD:
         # and masks the absorbed ones afterwards (valid, :369).  Here the nets run on the live slots only; the others hold
         # zeros, which the same masks discard -- losses and gradients are unchanged.  Logging steps of the dense mode evaluate
         # every slot, because logit_mean / logit_max (:427-452) are taken over ALL slots.
-        fused_mlp = isinstance(self.net, net.MLP) and self.net._fusable() and rnad_hip.mlp_backward_supported(A, self.net.width)
+        fused_mlp = self._fused_mlp()
         # Tabular evaluation (RNaD.tabular): an observation depends on (state, player to move) only, so each net is evaluated on
         # the 2S distinct observations of the tree and every (t, b) slot gathers its row (include/rnad_hip.h,
-        # rnad_learn_fused_gather / _tabular).  Worth it when the tree is small next to the batch (configs[1]: 132 862 rows for
-        # 12.6 M slots).
-        # RNaD.tabular = "forward": only the forward evaluations are deduplicated; dL/dlogit, dL/dv stay per slot and the backward
-        # runs on every (live) slot -- bit-identical, reproducible gradients.  True: the gradients are summed per row as well.
-        table, mode = None, getattr(self, "tabular", False)
-        if mode and fused_mlp:
-            handle = self.tree.handle()
-            if 8 * handle.S <= T * B:
-                table = handle.observations_table(getattr(episodes, "obs_half", False))
+        # rnad_learn_fused_gather / rnad_learn_fused_tabular / rnad_learn_bucketed).  Worth it when the tree is small next to the
+        # batch (configs[1]: 132 862 rows for 12.6 M slots).
+        mode = self._tabular_mode(T, B)
+        table = None
+        if mode:
+            if tables is None:
+                tables = self._table_outputs(alpha, getattr(episodes, "obs_half", False), want_target_logits=log is not None)
+            table = tables["table"]
         per_row_backward = table is not None and mode is True
+        bucketed = per_row_backward and getattr(episodes, "buckets", None) is not None
         live = None
         if (not per_row_backward and getattr(self, "skip_absorbed", True) and log is None and fused_mlp
                 and not self.tree.handle().uniform_length):
@@ -357,22 +399,10 @@ class RNaD:
         direct = fused_mlp
         reuse = reuse and table is None
         if table is not None:
-            # tabular: all nets on the same 2S observations, in ONE launch.  log_policy_reg (:382) needs one regularisation net only
-            # when alpha is 0 or 1 or both hold the same weights (see the dense branch below).
-            nets, wants = [self.net, self.net_target], [(True, True), (log is not None, True)]
-            one_reg = alpha == 0 or alpha == 1 or self._reg_nets_identical()
-            if alpha == 0:
-                nets.append(self.net_reg_)
-            else:
-                nets.append(self.net_reg)
-                if not one_reg:
-                    nets.append(self.net_reg_)
-            wants += [(True, False)] * (len(nets) - 2)
-            with torch.no_grad():
-                outs = rnad_hip.mlp_forward_multi([n_.pack() for n_ in nets], self.net.width, table, A, wants)
-            (logit, v), (logit_target, v_target) = outs[0], outs[1]
-            logit_reg = outs[2][0]
-            logit_reg_ = outs[3][0] if len(outs) > 3 else logit_reg
+            logit, v, logit_target, v_target = tables["logit"], tables["v"], tables["logit_target"], tables["v_target"]
+            logit_reg, logit_reg_ = tables["logit_reg"], tables["logit_reg_"]
+            if log is not None and logit_target is None:
+                logit_target = self.net_target.forward_logits(table, want_value=False)[0]
         elif reuse:  # the rollout's own outputs: same weights, same observations, same kernel -> same bits as rnad.py:373
             logit, v = episodes.actor_logits.reshape(-1, A), episodes.values[:T].reshape(-1, 1)
         elif direct:
@@ -404,7 +434,17 @@ class RNaD:
             alpha=alpha, eta=self.eta, lambda_=1.0, c=self.c_bar, rho=self.roh_bar, gamma=self.vtrace_gamma,
             clip=self.neurd_clip, threshold=self.beta, w_v=self.value_weight, w_n=self.neurd_weight,
             eps_threshold=self.epsilon_threshold, n_disc=self.n_discrete)
-        if table is not None:
+        if bucketed:
+            # bucket-ordered batch (Episodes.generate(bucketed=True)): per-row sums in LDS, no global atomics (csrc/bucket.hip)
+            records = tables.get("records")
+            if records is None:
+                records = rnad_hip.learn_records(self.tree.handle(), logit, v, v_target, logit_reg, logit_reg_)
+            dlogit, dv, losses = rnad_hip.learn_bucketed(self.tree.handle(), episodes.buckets, episodes.indices[:T], episodes.action_idx[:T],
+                                                         episodes.rewards[:T], episodes.policy[:T], records, norm, hp,
+                                                         want_losses=log is not None)
+            pi = None
+            backward_obs = table
+        elif table is not None:
             fn = rnad_hip.learn_fused_tabular if per_row_backward else rnad_hip.learn_fused_gather
             dlogit, dv, losses = fn(self.tree.handle(), episodes.indices[:T], episodes.mask_bits[:T], episodes.action_idx[:T],
                                     episodes.rewards[:T], episodes.policy[:T], logit, v, v_target, logit_reg, logit_reg_, norm, hp)
@@ -490,20 +530,31 @@ class RNaD:
         Adam -> EMA target.  Also what bench.py times as one "step"."""
         world, rank = self._world, self._rank
         local_batch = self.batch_size // world
+        handle = self.tree.handle()
+        T_cap = 2 * handle.max_depth
+        mode = False if self.reuse_actor_outputs else self._tabular_mode(T_cap, local_batch)
+        tables = None
+        if mode is True:
+            # the nets do not change between this step's rollout and its update: one evaluation of the 2S observations serves the
+            # actor (= the learner net, rnad.py:503-505) and all four nets of __learn
+            tables = self._table_outputs(alpha, getattr(self, "obs_half", False), want_target_logits=log is not None)
+            tables["records"] = rnad_hip.learn_records(handle, tables["logit"], tables["v"], tables["v_target"], tables["logit_reg"],
+                                                       tables["logit_reg_"])
         if self.total_steps % self.buffer_mod == 0:
             episodes = episode.Episodes(self.tree, local_batch, seed=self._new_seed(), lane_offset=rank * local_batch,
                                         obs_half=getattr(self, "obs_half", False))
             # no host sync: trailing all-absorbed steps are masked by `valid`
+            store_values = self.reuse_actor_outputs or getattr(self, "store_actor_values", False)
             episodes.generate(self.net, trim=False, keep_logits=self.reuse_actor_outputs,
                               skip_absorbed=getattr(self, "skip_absorbed", True) and not self.reuse_actor_outputs,
-                              store_values=self.reuse_actor_outputs or getattr(self, "store_actor_values", False),
-                              tabular=getattr(self, "tabular", False) and not self.reuse_actor_outputs
-                              and 8 * self.tree.handle().S <= 2 * self.tree.handle().max_depth * local_batch)
+                              store_values=store_values, tabular=bool(mode), bucketed=mode is True,
+                              logits_table=tables["records"] if tables is not None else None,
+                              value_table=tables["v"] if tables is not None and store_values else None)
             episodes._actor_tag = (id(self.net), self.total_steps)
             buffer.append(episodes)
             self.last_episodes = episodes
         episodes_sample = buffer.sample(local_batch)
-        self.__learn(episodes_sample, alpha, log=log)
+        self.__learn(episodes_sample, alpha, log=log, tables=tables)
         self.optimizer.step()
         self.optimizer.zero_grad()
         # EMA target, rnad.py:516-523: target <- gamma * net + (1 - gamma) * target for every state_dict entry, as two

@@ -361,19 +361,22 @@ class FusedMLPRows(torch.autograd.Function):
 class Trajectory:
     """Preallocated [T_cap, B, ...] device buffers of one batch of episodes (struct rnad_traj)."""
 
-    def __init__(self, tree, B, T_cap, device, half=False):
+    def __init__(self, tree, B, T_cap, device, half=False, with_observations=True, with_values=True):
+        """with_observations / with_values = False: those buffers are not allocated (bucketed rollout: observations are a function
+        of (t & 1, indices) and are materialised on demand; the actor's values are only stored when asked for)."""
         A = tree.A
         self.T_cap, self.B, self.A, self.half = T_cap, B, A, half
         self.indices = torch.empty((T_cap + 1, B), dtype=I32, device=device)
-        self.observations = torch.empty((T_cap, B, 2, A, A), dtype=F16 if half else F32, device=device)
+        self.observations = torch.empty((T_cap, B, 2, A, A), dtype=F16 if half else F32, device=device) if with_observations else None
         self.mask_bits = torch.empty((T_cap, B), dtype=U8, device=device)
         self.policy = torch.empty((T_cap, B, A), dtype=F32, device=device)
         self.actions = torch.empty((T_cap, B), dtype=I32, device=device)
         self.rewards = torch.empty((T_cap, B), dtype=F32, device=device)
-        self.values = torch.empty((T_cap, B), dtype=F32, device=device)
+        self.values = torch.empty((T_cap, B), dtype=F32, device=device) if with_values else None
         self.alive = torch.empty((T_cap + 1,), dtype=I32, device=device)
-        self.c = Traj(T_cap, int(half), B, self.indices.data_ptr(), self.observations.data_ptr(), self.mask_bits.data_ptr(),
-                      self.policy.data_ptr(), self.actions.data_ptr(), self.rewards.data_ptr(), self.values.data_ptr(),
+        ptr = lambda t: t.data_ptr() if t is not None else None  # noqa: E731
+        self.c = Traj(T_cap, int(half), B, self.indices.data_ptr(), ptr(self.observations), self.mask_bits.data_ptr(),
+                      self.policy.data_ptr(), self.actions.data_ptr(), self.rewards.data_ptr(), ptr(self.values),
                       self.alive.data_ptr())
 
 
@@ -559,6 +562,81 @@ def learn_fused_gather(tree, indices, mask_bits, actions, rewards, mu, logit_tab
                                          _dp(logit_reg_tab, F32, "logit_reg_tab"), _dp(logit_reg_tab_, F32, "logit_reg_tab_"),
                                          _dp(norm, F64, "norm"), C.byref(hp), _dp(losses, F64, "losses"), _dp(ws, F32, "workspace"),
                                          _dp(dlogit, F32, "dlogit"), _dp(dv, F32, "dv"), _stream()))
+    return dlogit, dv, losses
+
+
+# --------------------------------------------------------------------------------------- bucketed tabular pipeline
+class BucketPlan:
+    """rnad_bucket_plan for (tree, B): partition depth, list capacities and workspace sizes; plus the device workspaces themselves
+    (`scratch` of the rollout, zero-initialised `accumulators` of the learner), allocated once per (tree, B) and reused."""
+
+    def __init__(self, tree, B, out):
+        self.B = B
+        self.k, self.n_buckets, self.n_upper, self.sub_rows, self.max_items, self.scratch_bytes, self.acc_bytes, self.lds = (int(x) for x in out)
+        dev = tree.device
+        self.scratch = torch.empty((self.scratch_bytes // 4 + 1,), dtype=I32, device=dev)
+        self.accumulators = torch.zeros((self.acc_bytes // 8 + 1,), dtype=torch.int64, device=dev)
+
+
+def bucket_plan(tree, B):
+    """The BucketPlan of (tree, B) (cached on the tree handle), or None when this tree / batch cannot be bucketed."""
+    cache = tree.__dict__.setdefault("_bucket_plans", {})
+    key = (B, os.environ.get("RNAD_BUCKET_LEVEL"))  # the partition-depth override of csrc/bucket.hip (tuning / tests)
+    if key not in cache:
+        out = (C.c_int64 * 8)()
+        rc = lib().rnad_bucket_plan(tree.ptr, B, out)
+        cache[key] = BucketPlan(tree, B, list(out)) if rc == 0 else None
+    return cache[key]
+
+
+class Buckets:
+    """Lane permutation and learner work list of one bucket-ordered batch (outputs of rnad_rollout_bucketed)."""
+
+    def __init__(self, plan, device):
+        self.plan = plan
+        self.lane_ids = torch.empty((plan.B,), dtype=I32, device=device)
+        self.items = torch.empty((plan.max_items, 4), dtype=I32, device=device)
+        self.n_items = torch.empty((1,), dtype=I32, device=device)
+
+
+def rollout_bucketed(tree, traj, logits_table, value_table=None, seed=0, lane0=0):
+    """rnad_rollout_bucketed.  logits_table: [2S, A] logits or the [2S, stride] records of learn_records (the learner's logits
+    are the first A floats of a record); value_table [2S, 1] or None.  Returns the Buckets of the batch."""
+    plan = bucket_plan(tree, traj.B)
+    if plan is None:
+        raise RnadHipError(lib().rnad_last_error().decode())
+    assert logits_table.shape[0] == 2 * tree.S and logits_table.shape[1] >= tree.A
+    buckets = Buckets(plan, traj.indices.device)
+    _check(lib().rnad_rollout_bucketed(tree.ptr, C.byref(traj.c), _dp(logits_table, F32, "logits_table"), logits_table.shape[1],
+                                       _dp(value_table, F32, "value_table", True), 1, seed, lane0, _dp(plan.scratch, I32, "scratch"),
+                                       _dp(buckets.lane_ids, I32, "lane_ids"), _dp(buckets.items, I32, "items"),
+                                       _dp(buckets.n_items, I32, "n_items"), _stream()))
+    return buckets
+
+
+def learn_records(tree, logit_tab, v_tab, v_target_tab, logit_reg_tab, logit_reg_tab_):
+    """The five [2S, .] net-output tables interleaved into one record per (player, state) row (rnad_learn_records)."""
+    stride = int(lib().rnad_learn_record_stride(tree.A))
+    rec = torch.empty((2 * tree.S, stride), dtype=F32, device=logit_tab.device)
+    _check(lib().rnad_learn_records(tree.ptr, _dp(logit_tab, F32, "logit_tab"), _dp(v_tab, F32, "v_tab"), _dp(v_target_tab, F32, "v_target_tab"),
+                                    _dp(logit_reg_tab, F32, "logit_reg_tab"), _dp(logit_reg_tab_, F32, "logit_reg_tab_"),
+                                    _dp(rec, F32, "records"), _stream()))
+    return rec
+
+
+def learn_bucketed(tree, buckets, indices, actions, rewards, mu, records, norm, hp, want_losses=False):
+    """rnad_learn_bucketed on a bucket-ordered trajectory -> dlogit_tab [2S, A], dv_tab [2S, 1], losses f64[2] or None."""
+    T, B, A = mu.shape
+    assert buckets.plan.B == B
+    dev = mu.device
+    dlogit = torch.empty((2 * tree.S, A), dtype=F32, device=dev)
+    dv = torch.empty((2 * tree.S, 1), dtype=F32, device=dev)
+    losses = torch.empty((2,), dtype=F64, device=dev) if want_losses else None
+    _check(lib().rnad_learn_bucketed(tree.ptr, T, B, _dp(indices, I32, "indices"), _dp(actions, I32, "actions"), _dp(rewards, F32, "rewards"),
+                                     _dp(mu, F32, "mu"), _dp(records, F32, "records"), _dp(buckets.items, I32, "items"),
+                                     _dp(buckets.n_items, I32, "n_items"), _dp(norm, F64, "norm"), C.byref(hp),
+                                     _dp(buckets.plan.accumulators, torch.int64, "accumulators"), _dp(losses, F64, "losses", True),
+                                     _dp(dlogit, F32, "dlogit_tab"), _dp(dv, F32, "dv_tab"), _stream()))
     return dlogit, dv, losses
 
 

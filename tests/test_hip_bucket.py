@@ -1,0 +1,277 @@
+"""The bucketed tabular pipeline (csrc/bucket.hip): the bucket-ordered rollout is the lane-ordered one column for column, the
+LDS row sums are the per-slot gradients added up, and the resulting weight gradients are the reference's."""
+import numpy as np
+import pytest
+import torch
+
+from _util import load, mlp_weights  # noqa: F401
+
+pytestmark = pytest.mark.gpu
+
+DEV = torch.device("cuda:0")
+
+
+def _native_tree(A, C, depth, seed, prune=(0, 0), threshold=None):
+    from environment.tree import Tree
+
+    thr = threshold if threshold is not None else (0.0 if C == 1 else 0.5 / C)
+    tree = Tree(device=DEV, max_actions=A, max_transitions=C, depth_bound=depth, transition_threshold=thr)
+    tree.generate_native(seed=seed, prune=prune)
+    return tree
+
+
+TREES = {
+    "ternary4": dict(A=3, C=1, depth=4, seed=0),                      # configs[1] shape, two levels shallower
+    "pruned": dict(A=3, C=2, depth=5, seed=3, prune=(1, 3)),          # ragged episode lengths: buckets above the partition depth
+    "a5c4": dict(A=5, C=4, depth=3, seed=5, prune=(1, 2), threshold=0.1),  # configs[3] shape
+    "binary": dict(A=2, C=1, depth=3, seed=1),                        # configs[0] shape
+}
+
+
+def _levels(tree):
+    """level_order / order_pos exactly as rnad_tree_create builds them: states grouped by depth, ascending id within a depth."""
+    index = tree.index_tensor.cpu().numpy()
+    chance = tree.chance_tensor.cpu().numpy()
+    S = index.shape[0]
+    level = np.full(S, -1, np.int64)
+    level[1] = 0
+    for s in range(1, S):
+        if level[s] < 0:
+            continue
+        nxt = index[s][(index[s] != 0) & (chance[s] > 0)]
+        level[nxt] = level[s] + 1
+    order = np.concatenate([np.flatnonzero(level == l) for l in range(level.max() + 1)])
+    pos = np.full(S, -1, np.int64)
+    pos[order] = np.arange(order.size)
+    return level, order, pos
+
+
+@pytest.mark.parametrize("name", sorted(TREES))
+@pytest.mark.parametrize("B", (4096, 3000))
+def test_bucketed_rollout_is_the_lane_ordered_rollout(name, B):
+    import rnad_hip
+    from environment.episode import Episodes
+    from nn.net import MLP
+
+    tree = _native_tree(**TREES[name])
+    h = tree.handle()
+    plan = rnad_hip.bucket_plan(h, B)
+    assert plan is not None, "these trees are DFS pre-order and small: they must be bucketable"
+    torch.manual_seed(0)
+    net = MLP(tree.max_actions, 64, device=DEV)
+    nat = Episodes(tree, B, seed=77, lane_offset=1000)
+    nat.generate(net, tabular=True, trim=False)
+    buc = Episodes(tree, B, seed=77, lane_offset=1000)
+    buc.generate(net, tabular=True, bucketed=True, trim=False)
+    assert buc.buckets is not None and buc.t_eff == nat.t_eff
+    perm = buc.lane_ids.long()
+    assert torch.equal(torch.sort(perm).values, torch.arange(B, device=DEV)), "lane_ids must be a permutation of the lanes"
+    for key in ("indices", "mask_bits", "policy", "action_idx", "rewards"):
+        assert torch.equal(getattr(buc, key), getattr(nat, key)[:, perm]), key
+    assert torch.equal(buc.alive, nat.alive) and torch.equal(buc.states.indices, nat.states.indices[perm])
+    assert torch.equal(buc.observations, nat.observations[:, perm])  # materialised on demand from (t & 1, indices)
+    assert torch.equal(buc.masks, nat.masks[:, perm]) and torch.equal(buc.values, nat.values[:, perm])
+    # deterministic: the same seed gives the same permutation
+    again = Episodes(tree, B, seed=77, lane_offset=1000)
+    again.generate(net, tabular=True, bucketed=True, trim=False)
+    assert torch.equal(again.lane_ids, buc.lane_ids) and torch.equal(again.indices, buc.indices)
+    # bucket structure: stable sort by the state reached at depth k (or the last live state before it)
+    level, order, pos = _levels(tree)
+    idx = nat.indices.cpu().numpy()
+    n_steps = min(2 * plan.k, idx.shape[0])
+    key = np.ones(B, np.int64)
+    for t in range(n_steps + 1):
+        st = idx[t] if t < idx.shape[0] else nat.states.indices.cpu().numpy()
+        key = np.where(st != 0, st, key)
+    want = np.argsort(pos[key], kind="stable")
+    np.testing.assert_array_equal(buc.lane_ids.cpu().numpy(), want)
+    items = buc.buckets.items.cpu().numpy()[: int(buc.buckets.n_items.item())]
+    assert items[:, 1].sum() == B and (items[:, 1] > 0).all() and (items[:, 1] <= 2048).all()
+    np.testing.assert_array_equal(items[:, 0], np.concatenate([[0], np.cumsum(items[:, 1])[:-1]]))
+    sorted_keys = key[want]
+    for begin, count, state, single in items:
+        assert (sorted_keys[begin: begin + count] == state).all()
+        assert bool(single) == ((sorted_keys == state).sum() <= 2048)
+
+
+def _four_nets(A, W, seed):
+    from nn.net import MLP
+
+    torch.manual_seed(seed)
+    return [MLP(A, W, device=DEV) for _ in range(4)]
+
+
+def _tables(tree, nets, A):
+    import rnad_hip
+
+    table = tree.handle().observations_table()
+    outs = rnad_hip.mlp_forward_multi([n.pack() for n in nets], nets[0].width, table, A, [(True, True), (False, True), (True, False), (True, False)])
+    return outs[0][0], outs[0][1], outs[1][1], outs[2][0], outs[3][0]
+
+
+@pytest.mark.parametrize("name", sorted(TREES))
+def test_bucketed_row_sums_are_the_per_slot_gradients_added_up(name):
+    import rnad_hip
+    from environment.episode import Episodes
+
+    tree = _native_tree(**TREES[name])
+    h = tree.handle()
+    A, S, B = tree.max_actions, h.S, 8192
+    nets = _four_nets(A, 64, seed=1)
+    ep = Episodes(tree, B, seed=5)
+    ep.generate(nets[0], tabular=True, bucketed=True, trim=False)
+    T = ep.t_eff + 1
+    logit, v, vt, lr, lr_ = _tables(tree, nets, A)
+    rec = rnad_hip.learn_records(h, logit, v, vt, lr, lr_)
+    norm = ep.valid_counts
+    hp = rnad_hip.make_learn_params(alpha=0.3, eta=0.2, w_v=0.7, w_n=1.3)
+    dl_tab, dv_tab, losses = rnad_hip.learn_bucketed(h, ep.buckets, ep.indices, ep.action_idx, ep.rewards, ep.policy, rec, norm, hp, want_losses=True)
+    # per-slot gradients (the dense path's bits) summed per row in float64 on the host
+    dl, dv, losses_slot = rnad_hip.learn_fused_gather(h, ep.indices, ep.mask_bits, ep.action_idx, ep.rewards, ep.policy, logit, v, vt, lr, lr_, norm, hp)
+    idx = ep.indices.cpu().numpy().astype(np.int64)
+    rows = idx + (np.arange(T) % 2)[:, None] * S
+    want_l = np.zeros((2 * S, A))
+    want_v = np.zeros(2 * S)
+    live = idx != 0
+    np.add.at(want_l, rows[live], dl.cpu().numpy().astype(np.float64)[live])
+    np.add.at(want_v, rows[live], dv.cpu().numpy().astype(np.float64)[live])
+    for got, want in ((dl_tab.cpu().numpy(), want_l), (dv_tab.cpu().numpy()[:, 0], want_v)):
+        np.testing.assert_allclose(got, want, rtol=2e-6, atol=2e-7 * np.abs(want).max())
+    np.testing.assert_allclose(losses.cpu().numpy(), losses_slot.cpu().numpy(), rtol=1e-9)
+    # ... and the round-1 atomics path gives the same tables (fp32 rounding of the final conversion aside)
+    old_l, old_v, _ = rnad_hip.learn_fused_tabular(h, ep.indices, ep.mask_bits, ep.action_idx, ep.rewards, ep.policy, logit, v, vt, lr, lr_, norm, hp)
+    np.testing.assert_allclose(dl_tab.cpu().numpy(), old_l.cpu().numpy(), rtol=2e-6, atol=2e-7 * np.abs(want_l).max())
+    np.testing.assert_allclose(dv_tab.cpu().numpy(), old_v.cpu().numpy(), rtol=2e-6, atol=2e-7 * np.abs(want_v).max())
+    # integer sums: bit-reproducible, and the accumulators are left clean for the next update
+    dl2, dv2, _ = rnad_hip.learn_bucketed(h, ep.buckets, ep.indices, ep.action_idx, ep.rewards, ep.policy, rec, norm, hp)
+    assert torch.equal(dl2, dl_tab) and torch.equal(dv2, dv_tab)
+    plan = ep.buckets.plan
+    assert (plan.accumulators[: (2 * S + 128 * max(plan.n_upper, 1)) * (A + 1)] == 0).all()
+
+
+def test_value_gradient_beyond_the_fixed_point_range_poisons_the_tables():
+    import rnad_hip
+    from environment.episode import Episodes
+
+    tree = _native_tree(**TREES["ternary4"])
+    h = tree.handle()
+    A, B = 3, 2048
+    nets = _four_nets(A, 64, seed=2)
+    ep = Episodes(tree, B, seed=6)
+    ep.generate(nets[0], tabular=True, bucketed=True, trim=False)
+    logit, v, vt, lr, lr_ = _tables(tree, nets, A)
+    rec = rnad_hip.learn_records(h, logit, (v + 5000.0).contiguous(), vt, lr, lr_)  # |v - v_target| far beyond 2^10
+    hp = rnad_hip.make_learn_params(alpha=0.3, eta=0.2)
+    dl, dv, _ = rnad_hip.learn_bucketed(h, ep.buckets, ep.indices, ep.action_idx, ep.rewards, ep.policy, rec, ep.valid_counts, hp)
+    assert torch.isnan(dv).all() and torch.isnan(dl).all()
+    rec = rnad_hip.learn_records(h, logit, v, vt, lr, lr_)  # the flag is cleared by the next call
+    dl, dv, _ = rnad_hip.learn_bucketed(h, ep.buckets, ep.indices, ep.action_idx, ep.rewards, ep.policy, rec, ep.valid_counts, hp)
+    assert torch.isfinite(dv).all() and torch.isfinite(dl).all()
+
+
+# ------------------------------------------------------------------------------------------------ pinned against the reference
+def _bucketize(G, tree, ep):
+    """Host-side bucketisation of an episode batch that was NOT produced by rnad_rollout_bucketed (the reference's recorded
+    episodes): the same stable sort and work list, built with numpy, so that rnad_learn_bucketed can be fed the reference's data."""
+    import rnad_hip
+
+    h = tree.handle()
+    B = ep.batch_size
+    plan = rnad_hip.bucket_plan(h, B)
+    assert plan is not None
+    level, order, pos = _levels(tree)
+    idx = ep.indices.cpu().numpy()
+    key = np.ones(B, np.int64)
+    for t in range(min(2 * plan.k, idx.shape[0] - 1) + 1):
+        key = np.where(idx[t] != 0, idx[t], key)
+    perm = np.argsort(pos[key], kind="stable")
+    out = type(ep)(tree, B, seed=0)
+    out.t_eff, out.finished = ep.t_eff, True
+    sel = torch.as_tensor(perm, device=DEV)
+    for k in ("indices", "observations", "mask_bits", "policy", "action_idx", "rewards", "values"):
+        setattr(out, k, getattr(ep, k)[:, sel].contiguous())
+    out.alive = ep.alive
+    items = []
+    sk = key[perm]
+    start = 0
+    while start < B:
+        n = int((sk == sk[start]).sum())
+        chunks = (n + 2047) // 2048
+        for c in range(chunks):
+            items.append((start + c * 2048, min(2048, n - c * 2048), int(sk[start]), int(chunks == 1)))
+        start += n
+    b = rnad_hip.Buckets(plan, DEV)
+    b.lane_ids.copy_(sel.to(torch.int32))
+    b.items[: len(items)] = torch.as_tensor(items, dtype=torch.int32, device=DEV)
+    b.n_items.fill_(len(items))
+    out.buckets, out.lane_ids = b, b.lane_ids
+    return out
+
+
+@pytest.mark.parametrize("level", (None, 0, 1, 2))
+@pytest.mark.parametrize("name", ("c1_eta0.2", "small_eta0", "small_eta0.2", "ragged_eta0.5", "a5_eta0.2"))
+def test_bucketed_update_gives_the_reference_parameter_gradients(name, level, monkeypatch):
+    """RNaD.__learn in its default mode on the reference's own recorded episodes (bucketised on the host) -> the reference's
+    parameter gradients and losses (tests/golden/learn_*.npz), at the tolerance the dense mode is held to.  level: the
+    partition depth the planner would pick for these small batches (None), or a forced one (buckets at every depth)."""
+    import _gpu as G
+    import rnad_hip
+    from learn.rnad import RNaD
+    from test_hip_parity import _learn
+
+    g, ro, hp, clip, thr = _learn(name)
+    tree, _ = G.golden_tree(name.split("_")[0])
+    if level is not None:
+        monkeypatch.setenv("RNAD_BUCKET_LEVEL", str(level))
+        if rnad_hip.bucket_plan(tree.handle(), ro["indices"].shape[1]) is None:
+            pytest.skip(f"partition depth {level} does not exist / fit on this tree")
+    A = tree.max_actions
+    rn = RNaD.__new__(RNaD)
+    rn.tree, rn.device = tree, G.DEV
+    rn.net, rn.net_target = G.mlp_from(g, A, "w_net_"), G.mlp_from(g, A, "w_target_")
+    rn.net_reg, rn.net_reg_ = G.mlp_from(g, A, "w_reg_"), G.mlp_from(g, A, "w_reg__")
+    rn.eta, rn.c_bar, rn.roh_bar, rn.vtrace_gamma = hp["eta"], hp["c"], hp["rho"], hp["gamma"]
+    rn.neurd_clip, rn.beta, rn.grad_clip = clip, thr, 10**3
+    rn.value_weight, rn.neurd_weight, rn.epsilon_threshold, rn.n_discrete = 1, 1, 0.03, 32
+    rn.tabular, rn.tabular_gate = True, 0
+    ep = _bucketize(G, tree, G.episodes_from_golden(tree, ro))
+    log = {}
+    rn._RNaD__learn(ep, float(g["alpha"]), log=log)
+    for k, p in rn.net.named_parameters():
+        want = g["g_net_" + k.replace(".", "_")]
+        scale = np.abs(want).max() + 1e-12
+        np.testing.assert_allclose(G.cpu(p.grad), want, rtol=1e-3, atol=2e-5 * scale, err_msg=k)
+    np.testing.assert_allclose(log["loss_v"], g["loss_v"], rtol=1e-4)
+    np.testing.assert_allclose(log["loss_nerd"], g["loss_nerd"], rtol=1e-3, atol=1e-6)
+
+
+@pytest.mark.parametrize("name", ("ternary4", "pruned", "a5c4"))
+def test_train_step_modes_agree(name, tmp_path, monkeypatch):
+    """One RNaD.train_step from the same weights and rollout seed in the three net-evaluation modes: dense and "forward" give
+    identical gradients; the default (per-row sums, bucketed) gives them up to fp32 summation order."""
+    from environment.episode import Buffer
+    from learn.rnad import RNaD
+
+    monkeypatch.setenv("RNAD_SAVE_DIR", str(tmp_path))
+    tree = _native_tree(**TREES[name])
+    grads = {}
+    for mode in (False, "forward", True):
+        torch.manual_seed(11)
+        rn = RNaD(tree=tree, device=DEV, directory_name=f"m{mode}", batch_size=1 << 14, eta=0.2, b1_adam=0.0, lr=1e-3,
+                  net_params={"type": "MLP", "max_actions": tree.max_actions, "width": 64})
+        rn.initialize()
+        rn.tabular, rn.tabular_gate = mode, 0
+        with torch.no_grad():
+            for p in rn.net_reg_.parameters():
+                p.mul_(1.01)
+        captured = {}
+        real = rn.optimizer.step
+        rn.optimizer.step = lambda: (captured.update(g=[p.grad.detach().clone() for p in rn.net.parameters()]), real())[1]
+        rn.train_step(Buffer(1), alpha=0.4)
+        grads[mode] = captured["g"]
+        assert (rn.last_episodes.buckets is not None) == (mode is True)
+    for a, b in zip(grads[False], grads["forward"]):
+        assert torch.equal(a, b)
+    for a, b in zip(grads[False], grads[True]):
+        scale = a.abs().max().item() + 1e-12
+        np.testing.assert_allclose(b.cpu().numpy(), a.cpu().numpy(), rtol=1e-4, atol=1e-5 * scale)
