@@ -322,28 +322,32 @@ int rnad_learn_fused_gather(const rnad_tree_t *tree, int T, int64_t B, const int
  * rnad_rollout_bucketed, [6] = bytes of `accumulators` for rnad_learn_bucketed (zero them once; every update leaves them zero),
  * [7] = LDS bytes of a learner workgroup.  Non-zero return: this tree / batch cannot be bucketed (use the entry points above).
  *
- * rnad_rollout_bucketed: the rollout of rnad_rollout_run_tabular -- same tabular actor (logits_table row = player * S + state,
- * logits_stride floats apart: a [2S, A] table or the records of rnad_learn_records), same seeded noise keyed by the GLOBAL lane
+ * rnad_rollout_bucketed: the rollout of rnad_rollout_run_tabular -- same tabular actor (table row = player * S + state,
+ * table_stride floats apart; table_is_policy == 0: the actor's logits, whose policy head is then taken once per row;
+ * != 0: the actor's policy rows, e.g. the pi columns of rnad_bucket_records), same seeded noise keyed by the GLOBAL lane
  * id lane0 + lane, hence the same episodes bit for bit -- with column j of every [T_cap, B] buffer holding lane lane_ids[j]
  * (a stable sort of the lanes by bucket).  traj->observations is not written (may be NULL; an observation is a function of
  * (t & 1, indices[t]): rnad_observe), traj->values only if non-NULL (value_table NULL: zeros).  items / n_items: the learner's
  * work list.  T_cap <= 64, B <= 2^22.
  *
- * rnad_learn_records: the five [2S, .] net-output tables of a tabular update interleaved into one record per row
- * (rnad_learn_record_stride(A) floats: logit[A] | v | v_target | logit_reg[A] | logit_reg_[A] | pad; 16-byte aligned).
+ * rnad_bucket_records: one record per (player, state) row from the five [2S, .] net-output tables of a tabular update, holding
+ * everything of learn/rnad.py:373-382 that depends on the row alone (rnad_bucket_record_stride(A) floats, 16-byte aligned):
+ *   logit[A] | v | v_target | process_policy(pi)[A] | log_policy_reg[A] | pi[A] | legal bits | pad
+ * with pi, log_pi = the learner's policy head (net.py:74-77), log_policy_reg = log_pi - (alpha log_pi_reg + (1 - alpha) log_pi_reg_).
  *
- * rnad_learn_bucketed: rnad_learn_fused_tabular on a bucket-ordered trajectory: dlogit_tab [2S, A], dv_tab [2S] = per-row sums
+ * rnad_learn_bucketed: rnad_learn_fused_tabular on a bucket-ordered trajectory and those records: dlogit_tab [2S, A], dv_tab [2S] = per-row sums
  * of the per-slot gradients, accumulated in 64-bit fixed point with an a-priori scale (|dL/dlogit| <= 2 * clip / N_P by
  * construction; |v - v_target| < 2^10 is checked, the tables are NaN if it fails), normalised by norm (f64[2], batch-global
  * N_P) at the end.  Integer sums: reproducible bit for bit.  losses (f64[2], optional): loss_v, loss_nerd of this rank's slots.
  * ---------------------------------------------------------------------------------------------- */
 int rnad_bucket_plan(const rnad_tree_t *tree, int64_t B, int64_t *out);
-int rnad_rollout_bucketed(const rnad_tree_t *tree, const rnad_traj_t *traj, const float *logits_table, int64_t logits_stride,
-                          const float *value_table, int64_t value_stride, uint64_t seed, int64_t lane0, void *scratch,
-                          int32_t *lane_ids, int32_t *items, int32_t *n_items, void *stream);
-int64_t rnad_learn_record_stride(int A);
-int rnad_learn_records(const rnad_tree_t *tree, const float *logit_tab, const float *v_tab, const float *v_target_tab,
-                       const float *logit_reg_tab, const float *logit_reg_tab_, float *records, void *stream);
+int rnad_rollout_bucketed(const rnad_tree_t *tree, const rnad_traj_t *traj, const float *table, int64_t table_stride,
+                          int table_is_policy, const float *value_table, int64_t value_stride, uint64_t seed, int64_t lane0,
+                          void *scratch, int32_t *lane_ids, int32_t *items, int32_t *n_items, void *stream);
+int64_t rnad_bucket_record_stride(int A);
+int rnad_bucket_records(const rnad_tree_t *tree, const float *logit_tab, const float *v_tab, const float *v_target_tab,
+                        const float *logit_reg_tab, const float *logit_reg_tab_, const rnad_learn_params_t *hp, float *records,
+                        void *stream);
 int rnad_learn_bucketed(const rnad_tree_t *tree, int T, int64_t B, const int32_t *indices, const int32_t *actions,
                         const float *rewards, const float *mu, const float *records, const int32_t *items, const int32_t *n_items,
                         const double *norm, const rnad_learn_params_t *hp, void *accumulators, double *losses, float *dlogit_tab,

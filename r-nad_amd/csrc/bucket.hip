@@ -18,7 +18,8 @@
 //   k_bucket_rollout   bucket-ordered: thread j replays lane lane_ids[j] from the root (counter-based noise keyed by the GLOBAL lane
 //                      id, include/rnad_rng.h) and records the trajectory -- column j of every [T, B] buffer
 //   k_bucket_learn     one workgroup per work item: backward-in-time V-trace / NeuRD pass per lane (learn_math.hpp), sums in LDS
-//   k_bucket_finish    fixed point -> fp32 tables dL/dlogit [2S, A], dL/dv [2S], normalised by the batch-global N_P
+//   k_policy_rows / k_row_records   everything that depends on the (player, state) row alone, once per row instead of per slot
+//   k_bucket_upper / k_bucket_finish    fixed point -> fp32 tables dL/dlogit [2S, A], dL/dv [2S], normalised by the batch-global N_P
 #include "learn_math.hpp"
 #include "rollout_math.hpp"
 
@@ -83,23 +84,82 @@ bool make_plan(const rnad_tree_t *tree, int64_t B, Plan &p) {
     return true;
 }
 
+// ---------------------------------------------------------------------------------------- 0. per-row tables
+// Everything of the rollout and of the update that depends on the (player, state) row alone is evaluated once per row (2S rows)
+// instead of once per slot (T * B): same functions on the same inputs, hence the same bits.
+//
+// k_policy_rows: policy[row] = policy head (net.py:45-46) of the actor's logits row under the mover's legal mask.
+template <int A>
+__global__ __launch_bounds__(kThreads) void k_policy_rows(int64_t rows, const float *__restrict__ logits, int64_t stride,
+                                                          const uint8_t *__restrict__ mask_tab, float *__restrict__ policy) {
+    const int64_t r = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    if (r >= rows) return;
+    float in[A], pol[A];
+#pragma unroll
+    for (int a = 0; a < A; ++a) in[a] = logits[r * stride + a];
+    policy_head_ptr<A>(in, mask_tab[r], pol, nullptr);
+#pragma unroll
+    for (int a = 0; a < A; ++a) policy[r * A + a] = pol[a];
+}
+
+// Row record of the bucketed update, kRowStride<A> floats:  logit[A] | v | v_target | pi_processed[A] | log_policy_reg[A] | pi[A] |
+// legal bits | pad   (64 bytes at A = 3).  From the five net-output tables: pi / log_pi = policy head of the learner (rnad.py:373,
+// net.py:74-77), pi_processed = process_policy (rnad.py:374), log_policy_reg = log_pi - (alpha log_pi_reg + (1 - alpha) log_pi_reg_)
+// (rnad.py:382) -- the per-slot arithmetic of k_learn_fused that does not depend on the slot.
+template <int A>
+constexpr int kRowStride = (4 * A + 3 + 3) & ~3;
+
+template <int A>
+__global__ __launch_bounds__(kThreads) void k_row_records(int64_t rows, const float *__restrict__ logit, const float *__restrict__ v,
+                                                          const float *__restrict__ vt, const float *__restrict__ lr_,
+                                                          const float *__restrict__ lr2_, const uint8_t *__restrict__ mask_tab,
+                                                          rnad_learn_params_t hp, float *__restrict__ rec) {
+    const int64_t r = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    if (r >= rows) return;
+    const uint32_t bits = mask_tab[r];
+    float lg[A], lr[A], lr2[A], legal[A], pi[A], lp[A], lpr[A], lpr2[A], pip[A];
+#pragma unroll
+    for (int a = 0; a < A; ++a) {
+        lg[a] = logit[r * A + a];
+        lr[a] = lr_[r * A + a];
+        lr2[a] = lr2_[r * A + a];
+        legal[a] = (float)((bits >> a) & 1);
+    }
+    policy_head<A>(lg, bits, pi, lp);
+    log_policy_only<A>(lr, bits, lpr);
+    log_policy_only<A>(lr2, bits, lpr2);
+    process_policy_row<A>(pi, legal, hp.n_disc, hp.eps_threshold, pip);
+    float *o = rec + r * kRowStride<A>;
+#pragma unroll
+    for (int a = 0; a < A; ++a) {
+        o[a] = lg[a];
+        o[A + 2 + a] = pip[a];
+        o[2 * A + 2 + a] = lp[a] - (hp.alpha * lpr[a] + hp.one_minus_alpha * lpr2[a]);
+        o[3 * A + 2 + a] = pi[a];
+    }
+    o[A] = v[r];
+    o[A + 1] = vt[r];
+    o[4 * A + 2] = __uint_as_float(bits);
+#pragma unroll
+    for (int u = 4 * A + 3; u < kRowStride<A>; ++u) o[u] = 0.0f;
+}
+
 // ---------------------------------------------------------------------------------------- 1. keys
 // Lane b (lane order) plays env steps 0 .. n_steps - 1 (n_steps = 2k) exactly as k_bucket_rollout will, and keeps the last
 // non-absorbing state it has seen: the depth-k state it reaches, or the state it left the tree from if that happens earlier.
 template <int A>
 __global__ __launch_bounds__(kThreads) void k_bucket_keys(const Trans *__restrict__ trans, int C, int64_t S, int64_t B, int n_steps,
-                                                          const float *__restrict__ logit_tab, int64_t tab_stride,
-                                                          const uint8_t *__restrict__ mask_tab, const int32_t *__restrict__ order_pos,
-                                                          uint64_t seed, int64_t lane0, int32_t *__restrict__ keys) {
+                                                          const float *__restrict__ policy_tab, int64_t tab_stride,
+                                                          const int32_t *__restrict__ order_pos, uint64_t seed, int64_t lane0,
+                                                          int32_t *__restrict__ keys) {
     const int64_t b = (int64_t)blockIdx.x * kThreads + threadIdx.x;
     if (b >= B) return;
     int state = 1, key = 1, prev = 0;
     for (int t = 0; t < n_steps && state != 0; ++t) {
         const int64_t row = (int64_t)(t & 1) * S + state;
-        float in[A], pol[A], q[A];
+        float pol[A], q[A];
 #pragma unroll
-        for (int a = 0; a < A; ++a) in[a] = logit_tab[row * tab_stride + a];
-        policy_head_ptr<A>(in, mask_tab[row], pol, nullptr);
+        for (int a = 0; a < A; ++a) pol[a] = policy_tab[row * tab_stride + a];
         rnad_exp_noise(seed, (uint64_t)(lane0 + b), (uint32_t)t, 0u, A, q);
         const int action = race_argmax<A>(pol, q);
         if (t & 1) {
@@ -214,40 +274,31 @@ __global__ __launch_bounds__(kSortThreads) void k_bucket_items(int n_buckets, co
 }
 
 // lane_ids[bucket_start[key] + (lanes of earlier blocks with that key) + (earlier lanes of this block with that key)] = lane.
-// The waves of a workgroup take turns (each owns 256 consecutive lanes), so the rank a lane draws from the LDS counter does not
-// depend on wave scheduling: the permutation is the stable counting sort.
+// The waves of a workgroup take turns (each owns 256 consecutive lanes) and a wave's rows are issued in order, so the rank a lane
+// draws from the LDS counter does not depend on wave scheduling; within one LDS atomic instruction the lanes that hit the same
+// counter are served in lane order.  The permutation is therefore the stable counting sort, the same on every run.
 __global__ __launch_bounds__(kSortThreads) void k_bucket_scatter(int64_t B, int n_buckets, const int32_t *__restrict__ keys,
                                                                  const int32_t *__restrict__ hist, const int32_t *__restrict__ bucket_start,
                                                                  int32_t *__restrict__ lane_ids) {
     extern __shared__ int32_t cnt[];
     const int32_t *row = hist + (int64_t)blockIdx.x * n_buckets;
     for (int i = threadIdx.x; i < n_buckets; i += kSortThreads) cnt[i] = bucket_start[i] + row[i];
-    __syncthreads();
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int64_t base = (int64_t)blockIdx.x * kSortLanes + (int64_t)wave * (kSortLanes / 16);
+    int32_t key[kSortLanes / kSortThreads];
+#pragma unroll
+    for (int r = 0; r < kSortLanes / kSortThreads; ++r) {
+        const int64_t b = base + r * 64 + lane;
+        key[r] = b < B ? keys[b] : -1;
+    }
+    __syncthreads();
     for (int turn = 0; turn < 16; ++turn) {
         if (turn == wave) {
 #pragma unroll
             for (int r = 0; r < kSortLanes / kSortThreads; ++r) {
-                const int64_t b = base + r * 64 + lane;
-                if (b < B) {
-                    // lanes of one wave that hit the same counter are served in lane order: rank by ballot, one add per key
-                    const int32_t key = keys[b];
-                    uint64_t todo = __ballot(1);
-                    int32_t pos = 0;
-                    while (todo) {
-                        const int leader = __ffsll((unsigned long long)todo) - 1;
-                        const int32_t lk = __shfl(key, leader, 64);
-                        const uint64_t same = __ballot(key == lk) & todo;
-                        if (key == lk) {
-                            int32_t first = 0;
-                            if (lane == leader) first = atomicAdd(&cnt[lk], (int32_t)__popcll(same));
-                            first = __shfl(first, leader, 64);
-                            pos = first + (int32_t)__popcll(same & ((1ull << lane) - 1ull));
-                        }
-                        todo &= ~same;
-                    }
-                    lane_ids[pos] = (int32_t)b;
+                if (key[r] >= 0) {
+                    const int32_t pos = atomicAdd(&cnt[key[r]], 1);
+                    lane_ids[pos] = (int32_t)(base + r * 64 + lane);
                 }
             }
         }
@@ -256,15 +307,16 @@ __global__ __launch_bounds__(kSortThreads) void k_bucket_scatter(int64_t B, int 
 }
 
 // ---------------------------------------------------------------------------------------- 3. rollout in bucket order
-// Episodes.generate (episode.py:194-212) for thread j = lane lane_ids[j]: per env step the tabular actor's logits row of
-// (player to move, state), the policy head (net.py:45-46), the Exp(1) race (net.py:49), the record, and on the column player's
+// Episodes.generate (episode.py:194-212) for thread j = lane lane_ids[j]: per env step the tabular actor's policy row of
+// (player to move, state) (the policy head of net.py:45-46, evaluated once per row by k_policy_rows / k_row_records instead of
+// once per slot: same function, same input, same bits), the Exp(1) race (net.py:49), the record, and on the column player's
 // turn the chance draw and transition (episode.py:106-121) -- the arithmetic of k_act, with state and the row action kept in
 // registers across the T_cap steps and column j of every [T_cap, B] buffer written coalesced.  Observations are not written
 // (a function of (t & 1, indices): materialised on demand), `values` only if asked for.
 // alive_part[block][t] = #lanes of the block with indices[t] != 0 (summed by k_bucket_alive: no atomics).
 template <int A>
 __global__ __launch_bounds__(kThreads) void k_bucket_rollout(const Trans *__restrict__ trans, int C, int64_t S, int64_t B, int T_cap,
-                                                             const float *__restrict__ logit_tab, int64_t tab_stride,
+                                                             const float *__restrict__ policy_tab, int64_t tab_stride,
                                                              const float *__restrict__ value_tab, int64_t value_stride,
                                                              const uint8_t *__restrict__ mask_tab, uint64_t seed, int64_t lane0,
                                                              const int32_t *__restrict__ lane_ids, int32_t *__restrict__ indices,
@@ -284,10 +336,9 @@ __global__ __launch_bounds__(kThreads) void k_bucket_rollout(const Trans *__rest
             const int64_t i = (int64_t)t * B + j;
             const int64_t row = (int64_t)(t & 1) * S + state;
             const uint32_t bits = mask_tab[row];
-            float in[A], pol[A], q[A];
+            float pol[A], q[A];
 #pragma unroll
-            for (int a = 0; a < A; ++a) in[a] = logit_tab[row * tab_stride + a];
-            policy_head_ptr<A>(in, bits, pol, nullptr);
+            for (int a = 0; a < A; ++a) pol[a] = policy_tab[row * tab_stride + a];
             rnad_exp_noise(seed, lane, (uint32_t)t, 0u, A, q);
             const int action = race_argmax<A>(pol, q);
             indices[i] = state;
@@ -374,7 +425,7 @@ template <int A>
 __global__ __launch_bounds__(kThreads) void k_bucket_learn(int T, int64_t B, int64_t S, int k, int sub_rows, int n_upper,
                                                            const Item *__restrict__ items, const int32_t *__restrict__ n_items,
                                                            const uint8_t *__restrict__ level_dev, const int32_t *__restrict__ order_pos,
-                                                           const uint8_t *__restrict__ mask_tab, const int32_t *__restrict__ indices,
+                                                           const int32_t *__restrict__ indices,
                                                            const int32_t *__restrict__ actions, const float *__restrict__ rewards,
                                                            const float *__restrict__ mu_, const float *__restrict__ rec_,
                                                            rnad_learn_params_t hp, FixedPoint fx, unsigned long long *__restrict__ acc,
@@ -387,7 +438,7 @@ __global__ __launch_bounds__(kThreads) void k_bucket_learn(int T, int64_t B, int
     const Item item = items[blockIdx.x];
     const int s_b = item.state;
     const int n_path = 2 * (int)level_dev[s_b];
-    constexpr int RS = kRecStride<A>;
+    constexpr int RS = kRowStride<A>;
     const int n_tab = (2 * k + 2 * sub_rows) * (A + 1);
     for (int i = threadIdx.x; i < n_tab; i += kThreads) tab[i] = 0ull;
     __syncthreads();
@@ -408,32 +459,25 @@ __global__ __launch_bounds__(kThreads) void k_bucket_learn(int T, int64_t B, int
             for (int a = 0; a <= A; ++a) q[a] = 0;
             if (valid) {
                 const int64_t row = (int64_t)P * S + state;
-                const uint32_t bits = mask_tab[row];
                 const int act = actions[i];
-                float rec[RS];  // this row's record lg[A] | v | v_target | lr[A] | lr2[A] (k_pack_records), as 16-byte pieces
+                float rec[RS];  // this row's record (k_row_records), fetched as 16-byte pieces
                 const float4 *rp = reinterpret_cast<const float4 *>(rec_ + row * RS);
 #pragma unroll
                 for (int u = 0; u < RS / 4; ++u) {
                     const float4 r4 = rp[u];
                     rec[4 * u] = r4.x; rec[4 * u + 1] = r4.y; rec[4 * u + 2] = r4.z; rec[4 * u + 3] = r4.w;
                 }
-                float mu[A], lg[A], lr[A], lr2[A], legal[A], oh[A];
+                const uint32_t bits = __float_as_uint(rec[4 * A + 2]);
+                float mu[A], lg[A], pip[A], lpol[A], legal[A], oh[A];
 #pragma unroll
                 for (int a = 0; a < A; ++a) {
                     mu[a] = mu_[i * A + a];
                     lg[a] = rec[a];
-                    lr[a] = rec[A + 2 + a];
-                    lr2[a] = rec[2 * A + 2 + a];
+                    pip[a] = rec[A + 2 + a];    // process_policy(pi) of the learner (rnad.py:374)
+                    lpol[a] = rec[2 * A + 2 + a];  // log_policy_reg (rnad.py:382)
                     legal[a] = (float)((bits >> a) & 1);
                     oh[a] = act == a ? 1.0f : 0.0f;
                 }
-                float pi[A], lp[A], lpr[A], lpr2[A], pip[A], lpol[A];
-                policy_head<A>(lg, bits, pi, lp);             // net.forward_batch of the learner (rnad.py:373)
-                log_policy_only<A>(lr, bits, lpr);            // net_reg (rnad.py:379)
-                log_policy_only<A>(lr2, bits, lpr2);          // net_reg_ (rnad.py:380)
-                process_policy_row<A>(pi, legal, hp.n_disc, hp.eps_threshold, pip);  // rnad.py:374
-#pragma unroll
-                for (int a = 0; a < A; ++a) lpol[a] = lp[a] - (hp.alpha * lpr[a] + hp.one_minus_alpha * lpr2[a]);  // rnad.py:382
                 const float rew = (t & 1) ? rewards[i] : 0.0f;  // row turns carry torch.zeros (episode.py:101)
                 const float vtn = rec[A + 1];
                 float vt[2], qv[2][A];
@@ -496,7 +540,7 @@ __global__ __launch_bounds__(kThreads) void k_bucket_learn(int T, int64_t B, int
         if (x != 0ull) {
             const int t = e / (A + 1), a = e % (A + 1);
             const int64_t slot = order_pos[path_state[t]];
-            atomicAdd(rep + (((int64_t)(blockIdx.x & (kReplicas - 1)) * 2 + (t & 1)) * n_upper + slot) * (A + 1) + a, x);
+            atomicAdd(rep + (((int64_t)(blockIdx.x & (kReplicas - 1)) * 2 + (t & 1)) * n_upper + slot) * (A + 1) + a, x);  // n_upper >= 1 here
         }
     }
     // rows of the bucket's own subtree: this workgroup owns them unless the bucket was split over several items
@@ -514,16 +558,34 @@ __global__ __launch_bounds__(kThreads) void k_bucket_learn(int T, int64_t B, int
     }
 }
 
-// acc (+ the replicas for rows above the buckets) -> fp32 tables, normalised: dlogit_tab[P * S + s] = w_n * (G_l / N_P),
-// dv_tab likewise with w_v (learn/vtrace.py:374,389; rnad.py:424).  Clears what it read, so that acc / rep are zero again for
-// the next update.  An addend beyond the fixed-point range poisons the tables with NaN instead of passing silently.
+// Rows above the buckets: the kReplicas copies of a row are read by the 64 lanes of ONE wave (lane c: replica c), summed on the
+// DPP network and added into acc; the copies are cleared for the next update.  grid = ceil(2 * n_upper / 4) workgroups of 4 waves.
 template <int A>
-__global__ __launch_bounds__(kThreads) void k_bucket_finish(int64_t S, int n_upper, int up_stride, const int32_t *__restrict__ order_pos,
-                                                            unsigned long long *__restrict__ acc, unsigned long long *__restrict__ rep,
-                                                            const double *__restrict__ norm, float w_v, float w_n, FixedPoint fx,
-                                                            int32_t *__restrict__ overflow, double *__restrict__ losses_raw,
-                                                            double *__restrict__ losses, float *__restrict__ dlogit_tab,
-                                                            float *__restrict__ dv_tab) {
+__global__ __launch_bounds__(kThreads) void k_bucket_upper(int64_t S, int n_upper, const int32_t *__restrict__ level_order,
+                                                           unsigned long long *__restrict__ acc, unsigned long long *__restrict__ rep) {
+    static_assert(kReplicas == 64, "one replica per lane");
+    const int u = blockIdx.x * (kThreads / 64) + (threadIdx.x >> 6), c = threadIdx.x & 63;
+    if (u >= 2 * n_upper) return;
+    const int P = u / n_upper, pos = u % n_upper;
+    unsigned long long *src = rep + (((int64_t)c * 2 + P) * n_upper + pos) * (A + 1);
+    unsigned long long *dst = acc + ((int64_t)P * S + level_order[pos]) * (A + 1);
+#pragma unroll
+    for (int a = 0; a <= A; ++a) {
+        const unsigned long long v = src[a];
+        if (v != 0ull) src[a] = 0ull;
+        const long long total = wave_total_in_lane63((long long)v);
+        if (c == 63 && total != 0) dst[a] += (unsigned long long)total;
+    }
+}
+
+// acc -> fp32 tables, normalised: dlogit_tab[P * S + s] = w_n * (G_l / N_P), dv_tab likewise with w_v (learn/vtrace.py:374,389;
+// rnad.py:424).  Clears what it read, so that acc is zero again for the next update.  An addend beyond the fixed-point range
+// poisons the tables with NaN instead of passing silently.
+template <int A>
+__global__ __launch_bounds__(kThreads) void k_bucket_finish(int64_t S, unsigned long long *__restrict__ acc, const double *__restrict__ norm,
+                                                            float w_v, float w_n, FixedPoint fx, const int32_t *__restrict__ overflow,
+                                                            const double *__restrict__ losses_raw, double *__restrict__ losses,
+                                                            float *__restrict__ dlogit_tab, float *__restrict__ dv_tab) {
     const int64_t r = (int64_t)blockIdx.x * kThreads + threadIdx.x;
     const float nf0 = norm_of(norm), nf1 = norm_of(norm + 1);
     if (r == 0 && losses) {
@@ -531,29 +593,13 @@ __global__ __launch_bounds__(kThreads) void k_bucket_finish(int64_t S, int n_upp
         losses[1] = losses_raw[2] / (double)nf0 + losses_raw[3] / (double)nf1;
     }
     if (r >= 2 * S) return;
-    const int P = (int)(r / S);
-    const int64_t s = r % S;
     long long x[A + 1];
 #pragma unroll
     for (int a = 0; a <= A; ++a) {
         x[a] = (long long)acc[r * (A + 1) + a];
         if (x[a] != 0) acc[r * (A + 1) + a] = 0ull;
     }
-    const int pos = order_pos[s];
-    if (pos >= 0 && pos < n_upper) {
-        for (int c = 0; c < kReplicas; ++c) {
-            unsigned long long *src = rep + (((int64_t)c * 2 + P) * up_stride + pos) * (A + 1);
-#pragma unroll
-            for (int a = 0; a <= A; ++a) {
-                const unsigned long long v = src[a];
-                if (v != 0ull) {
-                    x[a] += (long long)v;
-                    src[a] = 0ull;
-                }
-            }
-        }
-    }
-    const float nf = P ? nf1 : nf0;
+    const float nf = r >= S ? nf1 : nf0;
     const bool bad = *overflow != 0;
     const float nan = __uint_as_float(0x7fc00000u);
 #pragma unroll
@@ -594,8 +640,9 @@ extern "C" int rnad_bucket_plan(const rnad_tree_t *tree, int64_t B, int64_t *out
     out[3] = p.sub_rows;
     out[4] = p.max_items;
     // scratch of the rollout (bytes): keys [B] | hist [sort_blocks][n_buckets] | totals [n_buckets] | bucket_start [n_buckets] |
-    // alive_part [blocks][T_cap + 1 <= kMaxSteps + 1]
-    out[5] = 4 * (B + (int64_t)p.sort_blocks * p.n_buckets + 2 * (int64_t)p.n_buckets + (int64_t)blocks_for(B) * (kMaxSteps + 1)) + 256;
+    // alive_part [blocks][T_cap + 1 <= kMaxSteps + 1] | policy [2S][A]
+    out[5] = 4 * (B + (int64_t)p.sort_blocks * p.n_buckets + 2 * (int64_t)p.n_buckets + (int64_t)blocks_for(B) * (kMaxSteps + 1) +
+                  2 * tree->S * tree->A) + 256;
     // accumulators of the learner (bytes, must be zero before the first update): acc [2S][A+1] u64 | rep [64][2][n_upper][A+1] u64 |
     // losses_raw [4] f64 | overflow [1] i32
     out[6] = 8 * (2 * tree->S * A1 + (int64_t)kReplicas * 2 * std::max(p.n_upper, 1) * A1 + 4) + 16;
@@ -606,6 +653,7 @@ extern "C" int rnad_bucket_plan(const rnad_tree_t *tree, int64_t B, int64_t *out
 namespace {
 struct Scratch {
     int32_t *keys, *hist, *totals, *bucket_start, *alive_part;
+    float *policy;  // [2S][A]: the actor's policy per row when the caller hands logits
 };
 Scratch carve_scratch(void *ws, int64_t B, const Plan &p) {
     Scratch s;
@@ -614,19 +662,36 @@ Scratch carve_scratch(void *ws, int64_t B, const Plan &p) {
     s.totals = s.hist + (int64_t)p.sort_blocks * p.n_buckets;
     s.bucket_start = s.totals + p.n_buckets;
     s.alive_part = s.bucket_start + p.n_buckets;
+    s.policy = (float *)(s.alive_part + (int64_t)blocks_for(B) * (kMaxSteps + 1));
     return s;
 }
 }  // namespace
 
-extern "C" int rnad_rollout_bucketed(const rnad_tree_t *tree, const rnad_traj_t *tr, const float *logits_table, int64_t logits_stride,
-                                     const float *value_table, int64_t value_stride, uint64_t seed, int64_t lane0, void *scratch,
-                                     int32_t *lane_ids, int32_t *items, int32_t *n_items, void *stream_) {
-    RNAD_REQUIRE(tree && tr && logits_table && scratch && lane_ids && items && n_items, "rnad_rollout_bucketed: null argument");
+extern "C" int64_t rnad_bucket_record_stride(int A) { return (4 * (int64_t)A + 3 + 3) & ~(int64_t)3; }
+
+extern "C" int rnad_bucket_records(const rnad_tree_t *tree, const float *logit_tab, const float *v_tab, const float *v_target_tab,
+                                   const float *logit_reg_tab, const float *logit_reg_tab_, const rnad_learn_params_t *hp,
+                                   float *records, void *stream) {
+    RNAD_REQUIRE(tree && logit_tab && v_tab && v_target_tab && logit_reg_tab && logit_reg_tab_ && hp && records,
+                 "rnad_bucket_records: null argument");
+    RNAD_REQUIRE(((uintptr_t)records & 15) == 0, "rnad_bucket_records: records must be 16-byte aligned");
+    RNAD_REQUIRE(hp->n_disc >= 1, "rnad_bucket_records: n_disc must be positive");
+    RNAD_DISPATCH_A(tree->A, hipLaunchKernelGGL((k_row_records<kA>), dim3(blocks_for(2 * tree->S)), dim3(kThreads), 0, (hipStream_t)stream,
+                                                2 * tree->S, logit_tab, v_tab, v_target_tab, logit_reg_tab, logit_reg_tab_,
+                                                (const uint8_t *)tree->mask_tab, *hp, records));
+    RNAD_HIP_OK(hipGetLastError());
+    return 0;
+}
+
+extern "C" int rnad_rollout_bucketed(const rnad_tree_t *tree, const rnad_traj_t *tr, const float *table, int64_t table_stride,
+                                     int table_is_policy, const float *value_table, int64_t value_stride, uint64_t seed, int64_t lane0,
+                                     void *scratch, int32_t *lane_ids, int32_t *items, int32_t *n_items, void *stream_) {
+    RNAD_REQUIRE(tree && tr && table && scratch && lane_ids && items && n_items, "rnad_rollout_bucketed: null argument");
     RNAD_REQUIRE(tr->indices && tr->mask_bits && tr->policy && tr->actions && tr->rewards && tr->alive,
                  "rnad_rollout_bucketed: trajectory has a null buffer");
     RNAD_REQUIRE(tr->T_cap >= 1 && tr->T_cap <= kMaxSteps && tr->B >= 1, "rnad_rollout_bucketed: bad trajectory shape T_cap=%d B=%lld",
                  tr->T_cap, (long long)tr->B);
-    RNAD_REQUIRE(logits_stride >= tree->A && (!value_table || value_stride >= 1), "rnad_rollout_bucketed: bad table stride");
+    RNAD_REQUIRE(table_stride >= tree->A && (!value_table || value_stride >= 1), "rnad_rollout_bucketed: bad table stride");
     Plan p;
     RNAD_REQUIRE(make_plan(tree, tr->B, p), "rnad_rollout_bucketed: this tree / batch cannot be bucketed (see rnad_bucket_plan)");
     hipStream_t stream = (hipStream_t)stream_;
@@ -634,9 +699,17 @@ extern "C" int rnad_rollout_bucketed(const rnad_tree_t *tree, const rnad_traj_t 
     const Scratch s = carve_scratch(scratch, B, p);
     const int n_steps = std::min(2 * p.k, (int)tr->T_cap);
     ProfScope prof(PROF_ACT, stream);
+    const float *policy_tab = table;
+    int64_t policy_stride = table_stride;
+    if (!table_is_policy) {  // logits given: the policy head once per (player, state) row
+        RNAD_DISPATCH_A(tree->A, hipLaunchKernelGGL((k_policy_rows<kA>), dim3(blocks_for(2 * S)), dim3(kThreads), 0, stream, 2 * S, table,
+                                                    table_stride, (const uint8_t *)tree->mask_tab, s.policy));
+        policy_tab = s.policy;
+        policy_stride = tree->A;
+    }
     RNAD_DISPATCH_A(tree->A, hipLaunchKernelGGL((k_bucket_keys<kA>), dim3(blocks_for(B)), dim3(kThreads), 0, stream, tree->trans, tree->C,
-                                                S, B, n_steps, logits_table, logits_stride, (const uint8_t *)tree->mask_tab,
-                                                (const int32_t *)tree->order_pos, seed, lane0, s.keys));
+                                                S, B, n_steps, policy_tab, policy_stride, (const int32_t *)tree->order_pos, seed, lane0,
+                                                s.keys));
     const size_t lds = (size_t)p.n_buckets * sizeof(int32_t);
     hipLaunchKernelGGL(k_bucket_hist, dim3(p.sort_blocks), dim3(kSortThreads), lds, stream, B, p.n_buckets, (const int32_t *)s.keys, s.hist);
     hipLaunchKernelGGL(k_bucket_scan, dim3((p.n_buckets + 63) / 64), dim3(kSortThreads), 0, stream, p.sort_blocks, p.n_buckets, s.hist,
@@ -648,7 +721,7 @@ extern "C" int rnad_rollout_bucketed(const rnad_tree_t *tree, const rnad_traj_t 
     RNAD_HIP_OK(hipGetLastError());
     const unsigned grid = blocks_for(B);
     RNAD_DISPATCH_A(tree->A, hipLaunchKernelGGL((k_bucket_rollout<kA>), dim3(grid), dim3(kThreads), 0, stream, tree->trans, tree->C, S, B,
-                                                (int)tr->T_cap, logits_table, logits_stride, value_table, value_stride,
+                                                (int)tr->T_cap, policy_tab, policy_stride, value_table, value_stride,
                                                 (const uint8_t *)tree->mask_tab, seed, lane0, (const int32_t *)lane_ids, tr->indices,
                                                 tr->mask_bits, tr->policy, tr->actions, tr->rewards, tr->values, s.alive_part));
     hipLaunchKernelGGL(k_bucket_alive, dim3(tr->T_cap + 1), dim3(kThreads), 0, stream, (int)grid, (int)tr->T_cap + 1,
@@ -665,7 +738,6 @@ extern "C" int rnad_learn_bucketed(const rnad_tree_t *tree, int T, int64_t B, co
                      dv_tab,
                  "rnad_learn_bucketed: null argument");
     RNAD_REQUIRE(T >= 1 && B >= 1, "rnad_learn_bucketed: bad shape");
-    RNAD_REQUIRE(hp->n_disc >= 1, "rnad_learn_bucketed: n_disc must be positive");
     Plan p;
     RNAD_REQUIRE(make_plan(tree, B, p), "rnad_learn_bucketed: this tree / batch cannot be bucketed (see rnad_bucket_plan)");
     hipStream_t stream = (hipStream_t)stream_;
@@ -683,15 +755,18 @@ extern "C" int rnad_learn_bucketed(const rnad_tree_t *tree, int T, int64_t B, co
         if (p.lds > 48 * 1024) RNAD_HIP_OK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, p.lds)); \
         hipLaunchKernelGGL(kern, dim3((unsigned)p.max_items), dim3(kThreads), (size_t)p.lds, stream, T, B, S, p.k, p.sub_rows,        \
                            std::max(p.n_upper, 1), (const Item *)items, n_items, (const uint8_t *)tree->level_dev,                    \
-                           (const int32_t *)tree->order_pos, (const uint8_t *)tree->mask_tab, indices, actions, rewards, mu, records, \
-                           *hp, fx, acc, rep, losses ? losses_raw : (double *)nullptr, overflow);                                     \
+                           (const int32_t *)tree->order_pos, indices, actions, rewards, mu, records, *hp, fx, acc, rep,               \
+                           losses ? losses_raw : (double *)nullptr, overflow);                                                        \
     } while (0)
     RNAD_DISPATCH_A(tree->A, RNAD_BUCKET_LEARN());
 #undef RNAD_BUCKET_LEARN
     RNAD_HIP_OK(hipGetLastError());
-    RNAD_DISPATCH_A(tree->A, hipLaunchKernelGGL((k_bucket_finish<kA>), dim3(blocks_for(2 * S)), dim3(kThreads), 0, stream, S,
-                                                p.n_upper, std::max(p.n_upper, 1), (const int32_t *)tree->order_pos, acc, rep,
-                                                norm, hp->w_v, hp->w_n, fx, overflow, losses_raw, losses, dlogit_tab, dv_tab));
+    if (p.n_upper > 0)
+        RNAD_DISPATCH_A(tree->A, hipLaunchKernelGGL((k_bucket_upper<kA>), dim3(blocks_for(2 * (int64_t)p.n_upper, kThreads / 64)), dim3(kThreads),
+                                                    0, stream, S, p.n_upper, (const int32_t *)tree->level_order, acc, rep));
+    RNAD_DISPATCH_A(tree->A, hipLaunchKernelGGL((k_bucket_finish<kA>), dim3(blocks_for(2 * S)), dim3(kThreads), 0, stream, S, acc, norm,
+                                                hp->w_v, hp->w_n, fx, (const int32_t *)overflow, (const double *)losses_raw, losses,
+                                                dlogit_tab, dv_tab));
     RNAD_HIP_OK(hipGetLastError());
     return 0;
 }

@@ -575,20 +575,6 @@ extern "C" int rnad_row_sums(const rnad_tree_t *tree, int T, int64_t B, const in
     return row_sums_launch(tree, T, B, indices, dlogit, dv, gmax, acc, dlogit_tab, dv_tab, stream);
 }
 
-// The five net-output tables of a tabular update interleaved into one record per (player, state) row:
-//   lg[A] | v | v_target | lr[A] | lr2[A] | pad to a multiple of 4 floats   (rnad_learn_record_stride(A) floats per row)
-extern "C" int64_t rnad_learn_record_stride(int A) { return (3 * (int64_t)A + 2 + 3) & ~(int64_t)3; }
-
-extern "C" int rnad_learn_records(const rnad_tree_t *tree, const float *logit_tab, const float *v_tab, const float *v_target_tab,
-                                  const float *logit_reg_tab, const float *logit_reg_tab_, float *records, void *stream) {
-    RNAD_REQUIRE(tree && logit_tab && v_tab && v_target_tab && logit_reg_tab && logit_reg_tab_ && records, "rnad_learn_records: null argument");
-    RNAD_REQUIRE(((uintptr_t)records & 15) == 0, "rnad_learn_records: records must be 16-byte aligned");
-    RNAD_DISPATCH_A(tree->A, hipLaunchKernelGGL((k_pack_records<kA>), dim3(blocks_for(2 * tree->S)), dim3(kThreads), 0, (hipStream_t)stream,
-                                                2 * tree->S, logit_tab, v_tab, v_target_tab, logit_reg_tab, logit_reg_tab_, records));
-    RNAD_HIP_OK(hipGetLastError());
-    return 0;
-}
-
 // Tables in, per-slot gradients out: the forward evaluations are deduplicated (2S rows instead of T*B slots), the backward is
 // not -- dlogit [T,B,A] and dv [T,B] are the bits rnad_learn_fused produces from per-slot net outputs, so a per-slot
 // rnad_mlp_backward gives bit-identical weight gradients.

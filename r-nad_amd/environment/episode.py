@@ -187,7 +187,7 @@ class Episodes:
 
     # ---------------------------------------------------------------- episode.py:175-230
     def generate(self, net: torch.nn.Module, noise_action=None, noise_chance=None, max_steps=None, trim=True, keep_logits=False,
-                 skip_absorbed=False, store_values=True, tabular=None, bucketed=False, logits_table=None, value_table=None):
+                 skip_absorbed=False, store_values=True, tabular=None, bucketed=False, logits_table=None, value_table=None, policy_table=None):
         """Play the batch to the end with `net` as the actor.
 
         Nets exposing `forward_logits(obs) -> (logits [B,A], value [B,1])` (the MLP here) take the fast path: policy head,
@@ -215,6 +215,8 @@ class Episodes:
         the work list of rnad_learn_bucketed; `observations` are not stored (materialised on first access).  Falls back to the
         lane-ordered rollout when the tree cannot be bucketed.  logits_table / value_table: the actor already evaluated on the
         tree's 2S observations (row = player * S + state; logits in the first A columns), instead of evaluating `net` here.
+        policy_table = (table, column): additionally the actor's POLICY rows (A floats from `column` on, e.g. inside
+        rnad_hip.bucket_records), which the bucketed rollout reads instead of taking the policy head of the logits itself.
 
         store_values=False (native MLP actor only): the actor's value head is not evaluated and `values` is zeros.  The
         reference stores the actor's values (episode.py:206,218) but nothing ever reads them (learn/rnad.py:373 recomputes v
@@ -239,10 +241,14 @@ class Episodes:
         if tabular:
             # one actor evaluation per (player, state), then the whole loop natively with per-lane gathers
             table, vtable = logits_table, value_table
-            if table is None:
+            if table is None and not (bucketed and policy_table is not None):
                 table, vtable = rnad_hip.mlp_forward(packed, net.width, handle.observations_table(self.obs_half), tree.max_actions,
                                                      want_value=store_values)
-            if bucketed:
+            if bucketed and policy_table is not None:
+                self.buckets = rnad_hip.rollout_bucketed(handle, traj, policy_table[0], vtable if store_values else None, seed=self.seed,
+                                                         lane0=self.lane_offset, table_is_policy=True, column=policy_table[1])
+                self.lane_ids = self.buckets.lane_ids
+            elif bucketed:
                 self.buckets = rnad_hip.rollout_bucketed(handle, traj, table, vtable if store_values else None, seed=self.seed,
                                                          lane0=self.lane_offset)
                 self.lane_ids = self.buckets.lane_ids

@@ -324,6 +324,12 @@ class RNaD:
             return "forward"
         return mode
 
+    def _learn_params(self, alpha):
+        return rnad_hip.make_learn_params(
+            alpha=alpha, eta=self.eta, lambda_=1.0, c=self.c_bar, rho=self.roh_bar, gamma=self.vtrace_gamma,
+            clip=self.neurd_clip, threshold=self.beta, w_v=self.value_weight, w_n=self.neurd_weight,
+            eps_threshold=self.epsilon_threshold, n_disc=self.n_discrete)
+
     def _table_outputs(self, alpha, obs_half=False, want_target_logits=False):
         """learner / target / regularisation nets on the 2S observations of the tree, ONE launch (rnad.py:373-380 on every distinct
         input).  log_policy_reg (:382) needs one regularisation net only when alpha is 0 or 1, or while both hold the same weights."""
@@ -430,15 +436,12 @@ class RNaD:
 
         if norm_work is not None:
             norm_work.wait()
-        hp = rnad_hip.make_learn_params(
-            alpha=alpha, eta=self.eta, lambda_=1.0, c=self.c_bar, rho=self.roh_bar, gamma=self.vtrace_gamma,
-            clip=self.neurd_clip, threshold=self.beta, w_v=self.value_weight, w_n=self.neurd_weight,
-            eps_threshold=self.epsilon_threshold, n_disc=self.n_discrete)
+        hp = self._learn_params(alpha)
         if bucketed:
             # bucket-ordered batch (Episodes.generate(bucketed=True)): per-row sums in LDS, no global atomics (csrc/bucket.hip)
             records = tables.get("records")
             if records is None:
-                records = rnad_hip.learn_records(self.tree.handle(), logit, v, v_target, logit_reg, logit_reg_)
+                records = rnad_hip.bucket_records(self.tree.handle(), logit, v, v_target, logit_reg, logit_reg_, hp)
             dlogit, dv, losses = rnad_hip.learn_bucketed(self.tree.handle(), episodes.buckets, episodes.indices[:T], episodes.action_idx[:T],
                                                          episodes.rewards[:T], episodes.policy[:T], records, norm, hp,
                                                          want_losses=log is not None)
@@ -538,8 +541,8 @@ class RNaD:
             # the nets do not change between this step's rollout and its update: one evaluation of the 2S observations serves the
             # actor (= the learner net, rnad.py:503-505) and all four nets of __learn
             tables = self._table_outputs(alpha, getattr(self, "obs_half", False), want_target_logits=log is not None)
-            tables["records"] = rnad_hip.learn_records(handle, tables["logit"], tables["v"], tables["v_target"], tables["logit_reg"],
-                                                       tables["logit_reg_"])
+            tables["records"] = rnad_hip.bucket_records(handle, tables["logit"], tables["v"], tables["v_target"], tables["logit_reg"],
+                                                        tables["logit_reg_"], self._learn_params(alpha))
         if self.total_steps % self.buffer_mod == 0:
             episodes = episode.Episodes(self.tree, local_batch, seed=self._new_seed(), lane_offset=rank * local_batch,
                                         obs_half=getattr(self, "obs_half", False))
@@ -548,8 +551,9 @@ class RNaD:
             episodes.generate(self.net, trim=False, keep_logits=self.reuse_actor_outputs,
                               skip_absorbed=getattr(self, "skip_absorbed", True) and not self.reuse_actor_outputs,
                               store_values=store_values, tabular=bool(mode), bucketed=mode is True,
-                              logits_table=tables["records"] if tables is not None else None,
-                              value_table=tables["v"] if tables is not None and store_values else None)
+                              logits_table=tables["logit"] if tables is not None else None,
+                              value_table=tables["v"] if tables is not None and store_values else None,
+                              policy_table=(tables["records"], rnad_hip.policy_column(self.tree.max_actions)) if tables is not None else None)
             episodes._actor_tag = (id(self.net), self.total_steps)
             buffer.append(episodes)
             self.last_episodes = episodes

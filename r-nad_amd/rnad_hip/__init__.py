@@ -599,28 +599,36 @@ class Buckets:
         self.n_items = torch.empty((1,), dtype=I32, device=device)
 
 
-def rollout_bucketed(tree, traj, logits_table, value_table=None, seed=0, lane0=0):
-    """rnad_rollout_bucketed.  logits_table: [2S, A] logits or the [2S, stride] records of learn_records (the learner's logits
-    are the first A floats of a record); value_table [2S, 1] or None.  Returns the Buckets of the batch."""
+def rollout_bucketed(tree, traj, table, value_table=None, seed=0, lane0=0, table_is_policy=False, column=0):
+    """rnad_rollout_bucketed.  table [2S, stride]: the tabular actor per (player, state) row, A floats starting at `column` -- its
+    logits (table_is_policy=False: a [2S, A] logits table) or its policy (True: e.g. the pi columns of bucket_records, see
+    policy_column).  value_table [2S, 1] or None.  Returns the Buckets of the batch."""
     plan = bucket_plan(tree, traj.B)
     if plan is None:
         raise RnadHipError(lib().rnad_last_error().decode())
-    assert logits_table.shape[0] == 2 * tree.S and logits_table.shape[1] >= tree.A
+    assert table.shape[0] == 2 * tree.S and table.shape[1] >= column + tree.A
     buckets = Buckets(plan, traj.indices.device)
-    _check(lib().rnad_rollout_bucketed(tree.ptr, C.byref(traj.c), _dp(logits_table, F32, "logits_table"), logits_table.shape[1],
+    base = _dp(table, F32, "table")
+    _check(lib().rnad_rollout_bucketed(tree.ptr, C.byref(traj.c), C.c_void_p(base.value + 4 * column), table.shape[1], int(table_is_policy),
                                        _dp(value_table, F32, "value_table", True), 1, seed, lane0, _dp(plan.scratch, I32, "scratch"),
                                        _dp(buckets.lane_ids, I32, "lane_ids"), _dp(buckets.items, I32, "items"),
                                        _dp(buckets.n_items, I32, "n_items"), _stream()))
     return buckets
 
 
-def learn_records(tree, logit_tab, v_tab, v_target_tab, logit_reg_tab, logit_reg_tab_):
-    """The five [2S, .] net-output tables interleaved into one record per (player, state) row (rnad_learn_records)."""
-    stride = int(lib().rnad_learn_record_stride(tree.A))
+def policy_column(A):
+    """First column of the learner's policy pi[A] inside a bucket_records row."""
+    return 3 * A + 2
+
+
+def bucket_records(tree, logit_tab, v_tab, v_target_tab, logit_reg_tab, logit_reg_tab_, hp):
+    """One record per (player, state) row with everything of the update that depends on the row alone (rnad_bucket_records):
+    logit[A] | v | v_target | process_policy(pi)[A] | log_policy_reg[A] | pi[A] | legal bits | pad."""
+    stride = int(lib().rnad_bucket_record_stride(tree.A))
     rec = torch.empty((2 * tree.S, stride), dtype=F32, device=logit_tab.device)
-    _check(lib().rnad_learn_records(tree.ptr, _dp(logit_tab, F32, "logit_tab"), _dp(v_tab, F32, "v_tab"), _dp(v_target_tab, F32, "v_target_tab"),
-                                    _dp(logit_reg_tab, F32, "logit_reg_tab"), _dp(logit_reg_tab_, F32, "logit_reg_tab_"),
-                                    _dp(rec, F32, "records"), _stream()))
+    _check(lib().rnad_bucket_records(tree.ptr, _dp(logit_tab, F32, "logit_tab"), _dp(v_tab, F32, "v_tab"), _dp(v_target_tab, F32, "v_target_tab"),
+                                     _dp(logit_reg_tab, F32, "logit_reg_tab"), _dp(logit_reg_tab_, F32, "logit_reg_tab_"), C.byref(hp),
+                                     _dp(rec, F32, "records"), _stream()))
     return rec
 
 

@@ -122,9 +122,9 @@ def test_bucketed_row_sums_are_the_per_slot_gradients_added_up(name):
     ep.generate(nets[0], tabular=True, bucketed=True, trim=False)
     T = ep.t_eff + 1
     logit, v, vt, lr, lr_ = _tables(tree, nets, A)
-    rec = rnad_hip.learn_records(h, logit, v, vt, lr, lr_)
     norm = ep.valid_counts
     hp = rnad_hip.make_learn_params(alpha=0.3, eta=0.2, w_v=0.7, w_n=1.3)
+    rec = rnad_hip.bucket_records(h, logit, v, vt, lr, lr_, hp)
     dl_tab, dv_tab, losses = rnad_hip.learn_bucketed(h, ep.buckets, ep.indices, ep.action_idx, ep.rewards, ep.policy, rec, norm, hp, want_losses=True)
     # per-slot gradients (the dense path's bits) summed per row in float64 on the host
     dl, dv, losses_slot = rnad_hip.learn_fused_gather(h, ep.indices, ep.mask_bits, ep.action_idx, ep.rewards, ep.policy, logit, v, vt, lr, lr_, norm, hp)
@@ -160,11 +160,11 @@ def test_value_gradient_beyond_the_fixed_point_range_poisons_the_tables():
     ep = Episodes(tree, B, seed=6)
     ep.generate(nets[0], tabular=True, bucketed=True, trim=False)
     logit, v, vt, lr, lr_ = _tables(tree, nets, A)
-    rec = rnad_hip.learn_records(h, logit, (v + 5000.0).contiguous(), vt, lr, lr_)  # |v - v_target| far beyond 2^10
     hp = rnad_hip.make_learn_params(alpha=0.3, eta=0.2)
+    rec = rnad_hip.bucket_records(h, logit, (v + 5000.0).contiguous(), vt, lr, lr_, hp)  # |v - v_target| far beyond 2^10
     dl, dv, _ = rnad_hip.learn_bucketed(h, ep.buckets, ep.indices, ep.action_idx, ep.rewards, ep.policy, rec, ep.valid_counts, hp)
     assert torch.isnan(dv).all() and torch.isnan(dl).all()
-    rec = rnad_hip.learn_records(h, logit, v, vt, lr, lr_)  # the flag is cleared by the next call
+    rec = rnad_hip.bucket_records(h, logit, v, vt, lr, lr_, hp)  # the flag is cleared by the next call
     dl, dv, _ = rnad_hip.learn_bucketed(h, ep.buckets, ep.indices, ep.action_idx, ep.rewards, ep.policy, rec, ep.valid_counts, hp)
     assert torch.isfinite(dv).all() and torch.isfinite(dl).all()
 

@@ -260,6 +260,7 @@ def test_on_policy_shortcut_gives_the_same_update(tmp_path, monkeypatch):
                   net_params={"type": "MLP", "max_actions": 3, "width": 64})
         rn.initialize()
         rn.reuse_actor_outputs = reuse
+        rn.tabular = False  # the shortcut replaces the learner's per-slot forward: compare it with the per-slot (dense) mode
         buf = Buffer(1)
         for i in range(3):
             rn.train_step(buf, alpha=0.3 * i)
