@@ -340,14 +340,25 @@ int rnad_learn_fused_gather(const rnad_tree_t *tree, int T, int64_t B, const int
  * construction; |v - v_target| < 2^10 is checked, the tables are NaN if it fails), normalised by norm (f64[2], batch-global
  * N_P) at the end.  Integer sums: reproducible bit for bit.  losses (f64[2], optional): loss_v, loss_nerd of this rank's slots.
  * ---------------------------------------------------------------------------------------------- */
+/* Per-step scalars in DEVICE memory (optional everywhere: NULL = use the immediate arguments).  With them a captured hipGraph of a
+ * whole training step can be replayed step after step: the host only rewrites these 16 bytes. */
+typedef struct rnad_step_params {
+    uint64_t seed;                  /* noise seed of the rollout (replaces the `seed` argument) */
+    float alpha, one_minus_alpha;   /* rnad.py:497 (replace the fields of rnad_learn_params_t) */
+} rnad_step_params_t;
+
+/* *device_params = {seed, alpha, one_minus_alpha}, enqueued on `stream` (the values travel as kernel arguments: safe to call again
+ * before the GPU has consumed the previous values). */
+int rnad_step_params_set(rnad_step_params_t *device_params, uint64_t seed, float alpha, float one_minus_alpha, void *stream);
 int rnad_bucket_plan(const rnad_tree_t *tree, int64_t B, int64_t *out);
 int rnad_rollout_bucketed(const rnad_tree_t *tree, const rnad_traj_t *traj, const float *table, int64_t table_stride,
                           int table_is_policy, const float *value_table, int64_t value_stride, uint64_t seed, int64_t lane0,
-                          void *scratch, int32_t *lane_ids, int32_t *items, int32_t *n_items, void *stream);
+                          const rnad_step_params_t *device_params, void *scratch, int32_t *lane_ids, int32_t *items, int32_t *n_items,
+                          void *stream);
 int64_t rnad_bucket_record_stride(int A);
 int rnad_bucket_records(const rnad_tree_t *tree, const float *logit_tab, const float *v_tab, const float *v_target_tab,
-                        const float *logit_reg_tab, const float *logit_reg_tab_, const rnad_learn_params_t *hp, float *records,
-                        void *stream);
+                        const float *logit_reg_tab, const float *logit_reg_tab_, const rnad_learn_params_t *hp,
+                        const rnad_step_params_t *device_params, float *records, void *stream);
 int rnad_learn_bucketed(const rnad_tree_t *tree, int T, int64_t B, const int32_t *indices, const int32_t *actions,
                         const float *rewards, const float *mu, const float *records, const int32_t *items, const int32_t *n_items,
                         const double *norm, const rnad_learn_params_t *hp, void *accumulators, double *losses, float *dlogit_tab,

@@ -113,9 +113,14 @@ template <int A>
 __global__ __launch_bounds__(kThreads) void k_row_records(int64_t rows, const float *__restrict__ logit, const float *__restrict__ v,
                                                           const float *__restrict__ vt, const float *__restrict__ lr_,
                                                           const float *__restrict__ lr2_, const uint8_t *__restrict__ mask_tab,
-                                                          rnad_learn_params_t hp, float *__restrict__ rec) {
+                                                          rnad_learn_params_t hp, const rnad_step_params_t *__restrict__ sp,
+                                                          float *__restrict__ rec) {
     const int64_t r = (int64_t)blockIdx.x * kThreads + threadIdx.x;
     if (r >= rows) return;
+    if (sp) {
+        hp.alpha = sp->alpha;
+        hp.one_minus_alpha = sp->one_minus_alpha;
+    }
     const uint32_t bits = mask_tab[r];
     float lg[A], lr[A], lr2[A], legal[A], pi[A], lp[A], lpr[A], lpr2[A], pip[A];
 #pragma unroll
@@ -150,10 +155,12 @@ __global__ __launch_bounds__(kThreads) void k_row_records(int64_t rows, const fl
 template <int A>
 __global__ __launch_bounds__(kThreads) void k_bucket_keys(const Trans *__restrict__ trans, int C, int64_t S, int64_t B, int n_steps,
                                                           const float *__restrict__ policy_tab, int64_t tab_stride,
-                                                          const int32_t *__restrict__ order_pos, uint64_t seed, int64_t lane0,
+                                                          const int32_t *__restrict__ order_pos, uint64_t seed,
+                                                          const rnad_step_params_t *__restrict__ sp, int64_t lane0,
                                                           int32_t *__restrict__ keys) {
     const int64_t b = (int64_t)blockIdx.x * kThreads + threadIdx.x;
     if (b >= B) return;
+    if (sp) seed = sp->seed;  // per-step scalars in device memory: a captured graph of the step replays with new values
     int state = 1, key = 1, prev = 0;
     for (int t = 0; t < n_steps && state != 0; ++t) {
         const int64_t row = (int64_t)(t & 1) * S + state;
@@ -318,7 +325,8 @@ template <int A>
 __global__ __launch_bounds__(kThreads) void k_bucket_rollout(const Trans *__restrict__ trans, int C, int64_t S, int64_t B, int T_cap,
                                                              const float *__restrict__ policy_tab, int64_t tab_stride,
                                                              const float *__restrict__ value_tab, int64_t value_stride,
-                                                             const uint8_t *__restrict__ mask_tab, uint64_t seed, int64_t lane0,
+                                                             const uint8_t *__restrict__ mask_tab, uint64_t seed,
+                                                             const rnad_step_params_t *__restrict__ sp, int64_t lane0,
                                                              const int32_t *__restrict__ lane_ids, int32_t *__restrict__ indices,
                                                              uint8_t *__restrict__ mbits, float *__restrict__ policy,
                                                              int32_t *__restrict__ actions, float *__restrict__ rewards,
@@ -326,6 +334,7 @@ __global__ __launch_bounds__(kThreads) void k_bucket_rollout(const Trans *__rest
     __shared__ int32_t cnt[kThreads / 64][kMaxSteps + 1];
     const int64_t j = (int64_t)blockIdx.x * kThreads + threadIdx.x;
     const bool active = j < B;
+    if (sp) seed = sp->seed;
     const uint64_t lane = active ? (uint64_t)(lane0 + lane_ids[j]) : 0;
     const int wave = threadIdx.x >> 6;
     int state = 1, prev = 0;
@@ -667,25 +676,43 @@ Scratch carve_scratch(void *ws, int64_t B, const Plan &p) {
 }
 }  // namespace
 
+namespace {
+__global__ void k_step_params_set(rnad_step_params_t *dst, uint64_t seed, float alpha, float one_minus_alpha) {
+    dst->seed = seed;
+    dst->alpha = alpha;
+    dst->one_minus_alpha = one_minus_alpha;
+}
+}  // namespace
+
+// The values travel as kernel arguments (copied at launch), so the host may call this again before the GPU has consumed the
+// previous step's values -- unlike an asynchronous copy from a host buffer that is about to be overwritten.
+extern "C" int rnad_step_params_set(rnad_step_params_t *device_params, uint64_t seed, float alpha, float one_minus_alpha, void *stream) {
+    RNAD_REQUIRE(device_params, "rnad_step_params_set: null argument");
+    hipLaunchKernelGGL(k_step_params_set, dim3(1), dim3(1), 0, (hipStream_t)stream, device_params, seed, alpha, one_minus_alpha);
+    RNAD_HIP_OK(hipGetLastError());
+    return 0;
+}
+
 extern "C" int64_t rnad_bucket_record_stride(int A) { return (4 * (int64_t)A + 3 + 3) & ~(int64_t)3; }
 
 extern "C" int rnad_bucket_records(const rnad_tree_t *tree, const float *logit_tab, const float *v_tab, const float *v_target_tab,
                                    const float *logit_reg_tab, const float *logit_reg_tab_, const rnad_learn_params_t *hp,
-                                   float *records, void *stream) {
+                                   const rnad_step_params_t *device_params, float *records, void *stream) {
     RNAD_REQUIRE(tree && logit_tab && v_tab && v_target_tab && logit_reg_tab && logit_reg_tab_ && hp && records,
                  "rnad_bucket_records: null argument");
     RNAD_REQUIRE(((uintptr_t)records & 15) == 0, "rnad_bucket_records: records must be 16-byte aligned");
     RNAD_REQUIRE(hp->n_disc >= 1, "rnad_bucket_records: n_disc must be positive");
     RNAD_DISPATCH_A(tree->A, hipLaunchKernelGGL((k_row_records<kA>), dim3(blocks_for(2 * tree->S)), dim3(kThreads), 0, (hipStream_t)stream,
                                                 2 * tree->S, logit_tab, v_tab, v_target_tab, logit_reg_tab, logit_reg_tab_,
-                                                (const uint8_t *)tree->mask_tab, *hp, records));
+                                                (const uint8_t *)tree->mask_tab, *hp, device_params, records));
     RNAD_HIP_OK(hipGetLastError());
     return 0;
 }
 
 extern "C" int rnad_rollout_bucketed(const rnad_tree_t *tree, const rnad_traj_t *tr, const float *table, int64_t table_stride,
                                      int table_is_policy, const float *value_table, int64_t value_stride, uint64_t seed, int64_t lane0,
-                                     void *scratch, int32_t *lane_ids, int32_t *items, int32_t *n_items, void *stream_) {
+                                     const rnad_step_params_t *device_params, void *scratch, int32_t *lane_ids, int32_t *items,
+                                     int32_t *n_items, void *stream_) {
     RNAD_REQUIRE(tree && tr && table && scratch && lane_ids && items && n_items, "rnad_rollout_bucketed: null argument");
     RNAD_REQUIRE(tr->indices && tr->mask_bits && tr->policy && tr->actions && tr->rewards && tr->alive,
                  "rnad_rollout_bucketed: trajectory has a null buffer");
@@ -708,8 +735,8 @@ extern "C" int rnad_rollout_bucketed(const rnad_tree_t *tree, const rnad_traj_t 
         policy_stride = tree->A;
     }
     RNAD_DISPATCH_A(tree->A, hipLaunchKernelGGL((k_bucket_keys<kA>), dim3(blocks_for(B)), dim3(kThreads), 0, stream, tree->trans, tree->C,
-                                                S, B, n_steps, policy_tab, policy_stride, (const int32_t *)tree->order_pos, seed, lane0,
-                                                s.keys));
+                                                S, B, n_steps, policy_tab, policy_stride, (const int32_t *)tree->order_pos, seed,
+                                                device_params, lane0, s.keys));
     const size_t lds = (size_t)p.n_buckets * sizeof(int32_t);
     hipLaunchKernelGGL(k_bucket_hist, dim3(p.sort_blocks), dim3(kSortThreads), lds, stream, B, p.n_buckets, (const int32_t *)s.keys, s.hist);
     hipLaunchKernelGGL(k_bucket_scan, dim3((p.n_buckets + 63) / 64), dim3(kSortThreads), 0, stream, p.sort_blocks, p.n_buckets, s.hist,
@@ -722,7 +749,8 @@ extern "C" int rnad_rollout_bucketed(const rnad_tree_t *tree, const rnad_traj_t 
     const unsigned grid = blocks_for(B);
     RNAD_DISPATCH_A(tree->A, hipLaunchKernelGGL((k_bucket_rollout<kA>), dim3(grid), dim3(kThreads), 0, stream, tree->trans, tree->C, S, B,
                                                 (int)tr->T_cap, policy_tab, policy_stride, value_table, value_stride,
-                                                (const uint8_t *)tree->mask_tab, seed, lane0, (const int32_t *)lane_ids, tr->indices,
+                                                (const uint8_t *)tree->mask_tab, seed, device_params, lane0, (const int32_t *)lane_ids,
+                                                tr->indices,
                                                 tr->mask_bits, tr->policy, tr->actions, tr->rewards, tr->values, s.alive_part));
     hipLaunchKernelGGL(k_bucket_alive, dim3(tr->T_cap + 1), dim3(kThreads), 0, stream, (int)grid, (int)tr->T_cap + 1,
                        (const int32_t *)s.alive_part, tr->alive);

@@ -30,6 +30,8 @@ static std::vector<ProfPair> g_prof[PROF_COUNT];
 
 ProfScope::ProfScope(int which_, hipStream_t stream_) : which(which_), stream(stream_) {
     if (!((g_prof_mask >> which_) & 1u)) return;
+    hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;  // timing events do not belong in a captured graph
+    if (hipStreamIsCapturing(stream_, &capturing) != hipSuccess || capturing != hipStreamCaptureStatusNone) return;
     if (hipEventCreate(&start) != hipSuccess) {
         start = nullptr;
         return;

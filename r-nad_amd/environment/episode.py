@@ -187,7 +187,7 @@ class Episodes:
 
     # ---------------------------------------------------------------- episode.py:175-230
     def generate(self, net: torch.nn.Module, noise_action=None, noise_chance=None, max_steps=None, trim=True, keep_logits=False,
-                 skip_absorbed=False, store_values=True, tabular=None, bucketed=False, logits_table=None, value_table=None, policy_table=None):
+                 skip_absorbed=False, store_values=True, tabular=None, bucketed=False, logits_table=None, value_table=None, policy_table=None, step_params=None):
         """Play the batch to the end with `net` as the actor.
 
         Nets exposing `forward_logits(obs) -> (logits [B,A], value [B,1])` (the MLP here) take the fast path: policy head,
@@ -217,6 +217,8 @@ class Episodes:
         tree's 2S observations (row = player * S + state; logits in the first A columns), instead of evaluating `net` here.
         policy_table = (table, column): additionally the actor's POLICY rows (A floats from `column` on, e.g. inside
         rnad_hip.bucket_records), which the bucketed rollout reads instead of taking the policy head of the logits itself.
+        step_params (bucketed only): a device int64 [2] holding struct rnad_step_params; the kernels then take the noise seed from
+        there instead of `self.seed` (a captured graph of the step is replayed with a new seed).
 
         store_values=False (native MLP actor only): the actor's value head is not evaluated and `values` is zeros.  The
         reference stores the actor's values (episode.py:206,218) but nothing ever reads them (learn/rnad.py:373 recomputes v
@@ -246,11 +248,12 @@ class Episodes:
                                                      want_value=store_values)
             if bucketed and policy_table is not None:
                 self.buckets = rnad_hip.rollout_bucketed(handle, traj, policy_table[0], vtable if store_values else None, seed=self.seed,
-                                                         lane0=self.lane_offset, table_is_policy=True, column=policy_table[1])
+                                                         lane0=self.lane_offset, table_is_policy=True, column=policy_table[1],
+                                                         step_params=step_params)
                 self.lane_ids = self.buckets.lane_ids
             elif bucketed:
                 self.buckets = rnad_hip.rollout_bucketed(handle, traj, table, vtable if store_values else None, seed=self.seed,
-                                                         lane0=self.lane_offset)
+                                                         lane0=self.lane_offset, step_params=step_params)
                 self.lane_ids = self.buckets.lane_ids
             else:
                 rnad_hip.rollout_run_tabular(handle, traj, table[:, : tree.max_actions].contiguous(), vtable if store_values else None,

@@ -138,6 +138,7 @@ class RNaD:
         #   False           every net on every slot, as the reference does.
         self.tabular = True
         self.tabular_gate = 8
+        self.use_graph = True  # capture the on-policy tabular step as a hipGraph and replay it (train_step)
         # ragged trajectories: evaluate / differentiate the nets on live (t, b) slots only (see __learn); same losses and gradients
         self.skip_absorbed = True
         self.obs_half = False  # store observations as fp16 (BASELINE.json configs[4]); arithmetic stays fp32
@@ -161,6 +162,8 @@ class RNaD:
         """Noise seed of the next rollout.  The first one is drawn from torch's generator (so torch.manual_seed makes runs
         repeatable) and, under torch.distributed, broadcast from rank 0 -- once: the following seeds are a counter hashed with
         it on the host, so the ranks stay in lock step without a broadcast + host sync in every step."""
+        if getattr(self, "_seed_override", None) is not None:
+            return self._seed_override
         if getattr(self, "_seed_base", None) is None:
             s = torch.randint(0, 2**62, (1,), dtype=torch.int64)
             if _dist_on():
@@ -188,8 +191,10 @@ class RNaD:
 
     def __new_optimizer(self):
         # fused=True: one kernel for all eight tensors instead of ~10 foreach launches (same update rule)
+        # capturable=True: the step counter lives on the device, so optimizer.step() can be part of a captured graph (train_step)
+        on_gpu = isinstance(self.device, torch.device) and self.device.type == "cuda"
         return torch.optim.Adam(self.net.parameters(), lr=self.lr, betas=(float(self.b1_adam), float(self.b2_adam)),
-                                eps=self.epsilon_adam, fused=self.device.type == "cuda" if isinstance(self.device, torch.device) else False)
+                                eps=self.epsilon_adam, fused=on_gpu, capturable=on_gpu)
 
     # ------------------------------------------------------------------ run directory: fresh start or resume
     # Behaviour of reference learn/rnad.py:190-319 (a run directory with checkpoints is resumed from its last one, anything else
@@ -330,24 +335,45 @@ class RNaD:
             clip=self.neurd_clip, threshold=self.beta, w_v=self.value_weight, w_n=self.neurd_weight,
             eps_threshold=self.epsilon_threshold, n_disc=self.n_discrete)
 
+    def _reg_tables(self, table):
+        """Logits of net_reg and net_reg_ on the tree's 2S observations.  The regularisation nets are constant between two
+        rotations (rnad.py:528-531), so their tables are evaluated when their weights change (tensor version counters: bumped by
+        load_state_dict and by in-place edits under no_grad) and kept, in place: the buffers keep their addresses for as long as
+        the observation table does (a captured graph of the step reads them).  Call invalidate_tables() after editing the nets
+        in a way autograd's version counters do not see."""
+        key = (id(self.net_reg), id(self.net_reg_), table.data_ptr(), tuple(table.shape),
+               sum(p._version for p in self.net_reg.parameters()), sum(p._version for p in self.net_reg_.parameters()))
+        cache = getattr(self, "_reg_table_cache", None)
+        if cache is None or cache["key"][:4] != key[:4]:
+            cache = self._reg_table_cache = {"key": None, "logit_reg": None, "logit_reg_": None}
+        if cache["key"] != key:
+            A = self.tree.max_actions
+            with torch.no_grad():
+                outs = rnad_hip.mlp_forward_multi([self.net_reg.pack(), self.net_reg_.pack()], self.net.width, table, A,
+                                                  [(True, False), (True, False)])
+            for name, out in (("logit_reg", outs[0][0]), ("logit_reg_", outs[1][0])):
+                if cache[name] is None:
+                    cache[name] = out
+                else:
+                    cache[name].copy_(out)
+            cache["key"] = key
+        return cache["logit_reg"], cache["logit_reg_"]
+
+    def invalidate_tables(self):
+        self._reg_table_cache = None
+
     def _table_outputs(self, alpha, obs_half=False, want_target_logits=False):
-        """learner / target / regularisation nets on the 2S observations of the tree, ONE launch (rnad.py:373-380 on every distinct
-        input).  log_policy_reg (:382) needs one regularisation net only when alpha is 0 or 1, or while both hold the same weights."""
+        """learner / target / regularisation nets on the 2S observations of the tree (rnad.py:373-380 on every distinct input):
+        learner and target in ONE launch per step, the two regularisation nets from _reg_tables.  Both regularisation tables are
+        always there: a term of log_policy_reg (:382) whose weight is exactly 0 adds exactly 0."""
         A = self.tree.max_actions
         table = self.tree.handle().observations_table(obs_half)
-        nets, wants = [self.net, self.net_target], [(True, True), (want_target_logits, True)]
-        if alpha == 0:
-            nets.append(self.net_reg_)
-        else:
-            nets.append(self.net_reg)
-            if not (alpha == 1 or self._reg_nets_identical()):
-                nets.append(self.net_reg_)
-        wants += [(True, False)] * (len(nets) - 2)
         with torch.no_grad():
-            outs = rnad_hip.mlp_forward_multi([n_.pack() for n_ in nets], self.net.width, table, A, wants)
-        out = dict(table=table, logit=outs[0][0], v=outs[0][1], logit_target=outs[1][0], v_target=outs[1][1], logit_reg=outs[2][0],
-                   logit_reg_=outs[3][0] if len(outs) > 3 else outs[2][0])
-        return out
+            outs = rnad_hip.mlp_forward_multi([self.net.pack(), self.net_target.pack()], self.net.width, table, A,
+                                              [(True, True), (want_target_logits, True)])
+        logit_reg, logit_reg_ = self._reg_tables(table)
+        return dict(table=table, logit=outs[0][0], v=outs[0][1], logit_target=outs[1][0], v_target=outs[1][1], logit_reg=logit_reg,
+                    logit_reg_=logit_reg_)
 
     # ------------------------------------------------------------------ reference learn/rnad.py:353-456
     @staticmethod
@@ -530,7 +556,18 @@ class RNaD:
     # ------------------------------------------------------------------ reference learn/rnad.py:502-523
     def train_step(self, buffer, alpha, log=None):
         """One iteration of the reference's inner loop: rollout (every buffer_mod steps) -> buffer sample -> __learn ->
-        Adam -> EMA target.  Also what bench.py times as one "step"."""
+        Adam -> EMA target.  Also what bench.py times as one "step".
+
+        RNaD.use_graph (default on): on-policy steps of the per-row tabular mode are captured ONCE as a hipGraph (every kernel of
+        the step is enqueued on torch's current stream, so torch.cuda.graph records them all) and replayed afterwards: the host
+        then only rewrites the 16 bytes of per-step scalars (noise seed, alpha: struct rnad_step_params in device memory) and
+        launches the graph -- ~30 launches and their Python bookkeeping become one call.  Same kernels, same inputs: the replayed
+        steps are bit-identical to the eager ones (tests/test_hip_graph.py)."""
+        if self._graph_eligible(buffer, log):
+            return self._graph_step(buffer, alpha)
+        return self._step_body(buffer, alpha, log)
+
+    def _step_body(self, buffer, alpha, log=None, step_params=None):
         world, rank = self._world, self._rank
         local_batch = self.batch_size // world
         handle = self.tree.handle()
@@ -542,7 +579,7 @@ class RNaD:
             # actor (= the learner net, rnad.py:503-505) and all four nets of __learn
             tables = self._table_outputs(alpha, getattr(self, "obs_half", False), want_target_logits=log is not None)
             tables["records"] = rnad_hip.bucket_records(handle, tables["logit"], tables["v"], tables["v_target"], tables["logit_reg"],
-                                                        tables["logit_reg_"], self._learn_params(alpha))
+                                                        tables["logit_reg_"], self._learn_params(alpha), step_params=step_params)
         if self.total_steps % self.buffer_mod == 0:
             episodes = episode.Episodes(self.tree, local_batch, seed=self._new_seed(), lane_offset=rank * local_batch,
                                         obs_half=getattr(self, "obs_half", False))
@@ -553,7 +590,8 @@ class RNaD:
                               store_values=store_values, tabular=bool(mode), bucketed=mode is True,
                               logits_table=tables["logit"] if tables is not None else None,
                               value_table=tables["v"] if tables is not None and store_values else None,
-                              policy_table=(tables["records"], rnad_hip.policy_column(self.tree.max_actions)) if tables is not None else None)
+                              policy_table=(tables["records"], rnad_hip.policy_column(self.tree.max_actions)) if tables is not None else None,
+                              step_params=step_params)
             episodes._actor_tag = (id(self.net), self.total_steps)
             buffer.append(episodes)
             self.last_episodes = episodes
@@ -568,6 +606,73 @@ class RNaD:
             src = [t for k, t in self.net.state_dict().items() if t.is_floating_point()]
             torch._foreach_mul_(tgt, 1 - self.gamma_averaging)
             torch._foreach_add_(tgt, src, alpha=self.gamma_averaging)
+
+    # ------------------------------------------------------------------ hipGraph replay of the on-policy tabular step
+    _GRAPH_WARMUP = 3  # eager steps before capture: code objects loaded, allocator pools and the table caches exist
+
+    def _graph_eligible(self, buffer, log):
+        if not getattr(self, "use_graph", True) or log is not None or self.reuse_actor_outputs or _dist_on():
+            return False
+        dev = self.device if isinstance(self.device, torch.device) else torch.device(self.device)
+        if dev.type != "cuda" or self.buffer_mod != 1 or buffer.max_size != 1:
+            return False
+        g = getattr(self, "_graph", None)
+        if g is not None and g.get("failed"):
+            return False
+        handle = self.tree.handle()
+        if self._tabular_mode(2 * handle.max_depth, self.batch_size) is not True or rnad_hip.bucket_plan(handle, self.batch_size) is None:
+            return False
+        if not getattr(self.optimizer, "defaults", {}).get("capturable", False):
+            return False
+        return True
+
+    def _graph_key(self, buffer):
+        """Everything a captured step has baked in: replay is only valid while none of it changed."""
+        return (id(buffer), id(self.net), id(self.net_target), id(self.net_reg), id(self.net_reg_), id(self.optimizer), id(self.tree.handle()),
+                self.batch_size, self.tabular, getattr(self, "tabular_gate", 8), self.eta, self.beta, self.neurd_clip, self.grad_clip,
+                self.c_bar, self.roh_bar, self.vtrace_gamma, self.value_weight, self.neurd_weight, self.epsilon_threshold, self.n_discrete,
+                self.gamma_averaging, getattr(self, "obs_half", False), getattr(self, "store_actor_values", False),
+                os.environ.get("RNAD_BUCKET_LEVEL"))
+
+    def _graph_step(self, buffer, alpha):
+        g = getattr(self, "_graph", None)
+        key = self._graph_key(buffer)
+        if g is None or g["key"] != key:
+            g = self._graph = {"key": key, "eager_steps": 0, "graph": None, "failed": False}
+        if g["graph"] is None and g["eager_steps"] < self._GRAPH_WARMUP:
+            g["eager_steps"] += 1
+            return self._step_body(buffer, alpha, None)
+        seed = self._new_seed()
+        if g["graph"] is None:
+            g["dev"] = torch.zeros((2,), dtype=torch.int64, device=self.device)
+        rnad_hip.step_params_set(g["dev"], seed, alpha)
+        # the regularisation nets are constant inside a captured step: refresh their tables (in place) when their weights changed
+        self._reg_tables(self.tree.handle().observations_table(getattr(self, "obs_half", False)))
+        if g["graph"] is None:
+            graph = torch.cuda.CUDAGraph()
+            self._seed_override = seed  # the captured body (and an eager retry) must use THIS step's seed, not draw another
+            ok = False
+            try:
+                with torch.cuda.graph(graph):
+                    self._step_body(buffer, alpha, None, step_params=g["dev"])
+                # only the native bucketed rollout takes its seed from device memory: anything else would replay stale noise
+                ok = getattr(self.last_episodes, "buckets", None) is not None
+                why = "the rollout of this step is not the native bucketed one"
+            except Exception as err:  # capture is an optimisation: fall back to eager steps, loudly
+                why = str(err)
+            if not ok:
+                logging.warning("hipGraph capture of the training step not used (%s); continuing with eager steps", why)
+                g["failed"] = True
+                del graph
+                torch.cuda.synchronize()
+                try:
+                    return self._step_body(buffer, alpha, None)
+                finally:
+                    self._seed_override = None
+            self._seed_override = None
+            g["graph"] = graph
+        g["graph"].replay()
+        self.last_episodes.seed = self.last_episodes.states.seed = seed
 
     def initialize(self):
         """Public alias of the reference's private __initialize (nets, optimizer, checkpoint 0/0)."""

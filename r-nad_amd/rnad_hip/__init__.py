@@ -599,7 +599,7 @@ class Buckets:
         self.n_items = torch.empty((1,), dtype=I32, device=device)
 
 
-def rollout_bucketed(tree, traj, table, value_table=None, seed=0, lane0=0, table_is_policy=False, column=0):
+def rollout_bucketed(tree, traj, table, value_table=None, seed=0, lane0=0, table_is_policy=False, column=0, step_params=None):
     """rnad_rollout_bucketed.  table [2S, stride]: the tabular actor per (player, state) row, A floats starting at `column` -- its
     logits (table_is_policy=False: a [2S, A] logits table) or its policy (True: e.g. the pi columns of bucket_records, see
     policy_column).  value_table [2S, 1] or None.  Returns the Buckets of the batch."""
@@ -610,10 +610,17 @@ def rollout_bucketed(tree, traj, table, value_table=None, seed=0, lane0=0, table
     buckets = Buckets(plan, traj.indices.device)
     base = _dp(table, F32, "table")
     _check(lib().rnad_rollout_bucketed(tree.ptr, C.byref(traj.c), C.c_void_p(base.value + 4 * column), table.shape[1], int(table_is_policy),
-                                       _dp(value_table, F32, "value_table", True), 1, seed, lane0, _dp(plan.scratch, I32, "scratch"),
+                                       _dp(value_table, F32, "value_table", True), 1, seed, lane0,
+                                       _dp(step_params, torch.int64, "step_params", True), _dp(plan.scratch, I32, "scratch"),
                                        _dp(buckets.lane_ids, I32, "lane_ids"), _dp(buckets.items, I32, "items"),
                                        _dp(buckets.n_items, I32, "n_items"), _stream()))
     return buckets
+
+
+def step_params_set(step_params, seed, alpha):
+    """step_params (device int64 [2] = struct rnad_step_params) <- seed, alpha, 1 - alpha; enqueued on the current stream."""
+    _check(lib().rnad_step_params_set(_dp(step_params, torch.int64, "step_params"), int(seed) & 0xFFFFFFFFFFFFFFFF, float(alpha),
+                                      1.0 - float(alpha), _stream()))
 
 
 def policy_column(A):
@@ -621,14 +628,14 @@ def policy_column(A):
     return 3 * A + 2
 
 
-def bucket_records(tree, logit_tab, v_tab, v_target_tab, logit_reg_tab, logit_reg_tab_, hp):
+def bucket_records(tree, logit_tab, v_tab, v_target_tab, logit_reg_tab, logit_reg_tab_, hp, step_params=None):
     """One record per (player, state) row with everything of the update that depends on the row alone (rnad_bucket_records):
     logit[A] | v | v_target | process_policy(pi)[A] | log_policy_reg[A] | pi[A] | legal bits | pad."""
     stride = int(lib().rnad_bucket_record_stride(tree.A))
     rec = torch.empty((2 * tree.S, stride), dtype=F32, device=logit_tab.device)
     _check(lib().rnad_bucket_records(tree.ptr, _dp(logit_tab, F32, "logit_tab"), _dp(v_tab, F32, "v_tab"), _dp(v_target_tab, F32, "v_target_tab"),
                                      _dp(logit_reg_tab, F32, "logit_reg_tab"), _dp(logit_reg_tab_, F32, "logit_reg_tab_"), C.byref(hp),
-                                     _dp(rec, F32, "records"), _stream()))
+                                     _dp(step_params, torch.int64, "step_params", True), _dp(rec, F32, "records"), _stream()))
     return rec
 
 

@@ -287,6 +287,7 @@ def test_run_replays_the_reference_run_given_its_noise(tmp_path, monkeypatch):
     rn = RNaD(tree=tree, device=DEV, directory_name="replay", batch_size=int(g["batch"]), eta=0.2, bounds=[2], delta_m=[3], lr=1e-2,
               gamma_averaging=0.1, b1_adam=0.0, net_params={"type": "MLP", "max_actions": 2, "width": 16})
     rn.initialize()
+    rn.use_graph = False  # Episodes.generate is patched below to inject the reference's noise: nothing to capture
     for n in (rn.net, rn.net_target, rn.net_reg, rn.net_reg_):  # the reference's initial net (all four start equal, rnad.py:226-231)
         n.load_state_dict(sd("w0_"))
     step = {"i": 0}
