@@ -155,6 +155,168 @@ def test_c2_update_step_runs_and_is_finite(c2):
         np.testing.assert_allclose(pt.detach().cpu().numpy(), (0.001 * pn + 0.999 * p0).detach().cpu().numpy(), rtol=1e-5, atol=1e-7)
 
 
+def _modes_agree(tree, batch, tmp_path, obs_half=False, width=256):
+    """One RNaD.train_step from the same weights and rollout seed in the three net-evaluation modes (eager, no graph): dense and
+    "forward" give identical gradients; the default (per-row sums, bucketed rollout) gives them up to fp32 summation order."""
+    import os
+
+    from environment.episode import Buffer
+    from learn.rnad import RNaD
+
+    os.environ["RNAD_SAVE_DIR"] = str(tmp_path)
+    grads, losses = {}, {}
+    for mode in (False, "forward", True):
+        torch.manual_seed(11)
+        rn = RNaD(tree=tree, device=tree.device, directory_name=f"modes{mode}{int(obs_half)}", batch_size=batch, eta=0.2, b1_adam=0.0, lr=1e-3,
+                  net_params={"type": "MLP", "max_actions": tree.max_actions, "width": width})
+        rn.initialize()
+        rn.tabular, rn.use_graph, rn.obs_half = mode, False, obs_half
+        with torch.no_grad():
+            for p in rn.net_reg_.parameters():
+                p.mul_(1.01)
+        captured = {}
+        real = rn.optimizer.step
+        rn.optimizer.step = lambda: (captured.update(g=[p.grad.detach().clone() for p in rn.net.parameters()]), real())[1]
+        rn.train_step(Buffer(1), alpha=0.4)
+        torch.cuda.synchronize()
+        grads[mode] = captured["g"]
+        import rnad_hip
+
+        assert (rn.last_episodes.buckets is not None) == (mode is True and rnad_hip.bucket_plan(tree.handle(), batch) is not None)
+        assert all(torch.isfinite(p).all() for p in rn.net.parameters())
+        del rn
+        torch.cuda.empty_cache()
+    for a, b in zip(grads[False], grads["forward"]):
+        assert torch.equal(a, b)
+    for a, b in zip(grads[False], grads[True]):
+        scale = a.abs().max().item() + 1e-12
+        np.testing.assert_allclose(b.cpu().numpy(), a.cpu().numpy(), rtol=1e-4, atol=1e-5 * scale)
+
+
+def test_c2_fp16_observations_full_size(c2, tmp_path):
+    """The single-GPU half of BASELINE.json configs[4]: c2 tree, batch 2^20, observations stored as fp16, arithmetic fp32."""
+    from environment.episode import Episodes
+
+    tree, net, ep32 = c2
+    B = 1 << 20
+    ep = Episodes(tree, B, seed=99, obs_half=True)
+    ep.generate(net, tabular=False)  # every lane through K1 (fp16 stores) and the fused MLP (fp16 loads)
+    assert ep.observations.dtype == torch.float16 and ep.t_eff + 1 == 12
+    lanes = np.random.default_rng(3).choice(B, size=2048, replace=False)
+    _check_lanes_against_oracle(ep, _arrays(tree), lanes, seed=99, C=1, half=True)
+    # the tabular actor on the fp16-rounded observation table plays the same episodes
+    tab = Episodes(tree, B, seed=99, obs_half=True)
+    tab.generate(net, tabular=True)
+    for key in ("indices", "policy", "action_idx", "rewards", "observations"):
+        assert torch.equal(getattr(tab, key), getattr(ep, key)), key
+    del ep, tab
+    torch.cuda.empty_cache()
+    _modes_agree(tree, B, tmp_path, obs_half=True)
+
+
+@pytest.fixture(scope="module")
+def c4():
+    """BASELINE.json configs[3]: depth-8 5x5 tree, chance branching 4, pruned (reference main.py:37) to ~10^6 states, batch 2^20."""
+    from environment.episode import Episodes
+    from environment.tree import Tree
+    from nn.net import MLP
+
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    tree = Tree(device=dev, max_actions=5, max_transitions=4, depth_bound=8, transition_threshold=0.1)
+    tree.generate_native(seed=0, prune=(7, 8))
+    net = MLP(5, 256, device=dev)
+    ep = Episodes(tree, 1 << 20, seed=41)
+    ep.generate(net)
+    return tree, net, ep
+
+
+def test_c4_full_size_rollout(c4):
+    import rnad_hip
+    from environment.episode import Episodes
+
+    tree, net, ep = c4
+    B, S = 1 << 20, tree.index_tensor.shape[0]
+    assert S == 959540 and 8 * S <= 16 * B  # the tabular actor applies
+    T = ep.t_eff + 1
+    assert T % 2 == 0 and 6 <= T <= 16
+    alive = ep.alive.cpu().numpy()
+    assert alive[0] == B and (np.diff(alive) <= 0).all() and alive[T] == 0 and alive[T - 1] > 0
+    np.testing.assert_array_equal(alive[:T], (ep.indices != 0).sum(1).cpu().numpy())
+    assert alive[:T].sum() < 0.6 * T * B  # ragged: well under half of the slots of the padded buffer are live
+    assert (ep.rewards[0::2] == 0).all()
+    s = ep.policy.sum(-1)
+    assert torch.allclose(s, torch.ones_like(s), atol=1e-5)
+    lanes = np.random.default_rng(4).choice(B, size=2048, replace=False)
+    lanes[:3] = (0, B - 1, B // 3)
+    _check_lanes_against_oracle(ep, _arrays(tree), lanes, seed=41, C=4)
+    # every lane through the net at every step (the reference's way) plays the same episodes
+    dense = Episodes(tree, B, seed=41)
+    dense.generate(net, tabular=False)
+    for key in ("indices", "action_idx", "rewards", "mask_bits"):
+        assert torch.equal(getattr(dense, key), getattr(ep, key)), key
+    assert torch.equal(dense.policy, ep.policy)
+    del dense
+    # and the bucket-ordered rollout is the same batch, permuted
+    if rnad_hip.bucket_plan(tree.handle(), B) is not None:
+        buc = Episodes(tree, B, seed=41)
+        buc.generate(net, bucketed=True)
+        perm = buc.lane_ids.long()
+        for key in ("indices", "action_idx", "rewards", "mask_bits", "policy"):
+            assert torch.equal(getattr(buc, key), getattr(ep, key)[:, perm]), key
+        assert torch.equal(buc.alive, ep.alive)
+
+
+def test_c4_full_size_learner_is_lane_independent(c4):
+    """rnad_learn_fused at 2^20 lanes x T (A = 5): a subset of lanes run on its own gives the same bits, and the oracle's
+    composition of the reference functions agrees on it."""
+    import rnad_hip
+    from nn.net import MLP
+    from oracle import oracle
+
+    tree, net, ep = c4
+    dev = ep.indices.device
+    T, B, A = ep.t_eff + 1, 1 << 20, 5
+    torch.manual_seed(1)
+    nets = [net] + [MLP(5, 256, device=dev) for _ in range(3)]
+    with torch.no_grad():
+        logit, v = nets[0].forward_logits(ep.observations)
+        _, vt = nets[1].forward_logits(ep.observations, want_logits=False)
+        lr, _ = nets[2].forward_logits(ep.observations, want_value=False)
+        lr_, _ = nets[3].forward_logits(ep.observations, want_value=False)
+    norm = ep.valid_counts
+    hp = rnad_hip.make_learn_params(alpha=0.3, eta=0.2)
+    full = rnad_hip.learn_fused(ep.indices, ep.mask_bits, ep.action_idx, ep.rewards, ep.policy, logit, v.view(T, B), vt.view(T, B), lr, lr_, norm, hp)
+    n = 2048
+    lanes = torch.as_tensor(np.random.default_rng(5).choice(B, size=n, replace=False), device=dev)
+    sub = lambda x: x.view(T, B, -1)[:, lanes].contiguous()  # noqa: E731
+    sub2 = lambda x: x.view(T, B)[:, lanes].contiguous()  # noqa: E731
+    part = rnad_hip.learn_fused(sub2(ep.indices), sub2(ep.mask_bits), sub2(ep.action_idx), sub2(ep.rewards), sub(ep.policy), sub(logit),
+                                sub2(v), sub2(vt), sub(lr), sub(lr_), norm, hp, want_aux=True)
+    assert torch.equal(part[0], full[0][:, lanes]) and torch.equal(part[1], full[1][:, lanes])
+    c = lambda t: t.cpu().numpy()  # noqa: E731
+    masks = c(ep.masks[:, lanes])
+    pi = c(part[3])
+    pip = oracle.process_policy(pi, masks, 32, 0.03)
+    _, log_pi = oracle.policy_head(c(sub(logit)), masks)
+    _, log_r = oracle.policy_head(c(sub(lr)), masks)
+    _, log_r_ = oracle.policy_head(c(sub(lr_)), masks)
+    lpol = log_pi - (np.float32(0.3) * log_r + np.float32(1 - 0.3) * log_r_)
+    valid = (c(sub2(ep.indices)) != 0).astype(np.float32)
+    turns = np.broadcast_to((np.arange(T) % 2)[:, None], (T, n)).astype(np.int64)
+    a_oh = np.eye(A, dtype=np.float32)[c(sub2(ep.action_idx))]
+    for p in range(2):
+        rew = c(sub2(ep.rewards)) * (1 if p == 0 else -1)
+        vt_p, _, q_p = oracle.vtrace(c(sub2(vt))[..., None], valid, turns, c(sub(ep.policy)), pip, lpol, a_oh, rew, p, 0.2, 1.0, 1.0, 1.0, 1.0)
+        np.testing.assert_allclose(c(part[4][p]), vt_p[..., 0], rtol=1e-4, atol=2e-5)
+        np.testing.assert_allclose(c(part[5][p]), q_p, rtol=1e-4, atol=2e-5)
+
+
+def test_c4_full_size_update_modes_agree(c4, tmp_path):
+    tree, _, _ = c4
+    _modes_agree(tree, 1 << 20, tmp_path)
+
+
 @pytest.mark.parametrize("half", (False, True))
 def test_c4_like_tree_five_actions_four_chance_outcomes(half):
     """BASELINE.json configs[3] shape (5x5 actions, chance branching 4, pruned) at a size the oracle finishes in seconds;
