@@ -1,23 +1,25 @@
 #!/usr/bin/env python3
 """bench.py -- the R-NaD self-play hot path on MI355X: env-steps/s and updates/s at batch 2^20.
 
-    python bench.py --gpus 1 --steps 5 --warmup 2
+    python bench.py --gpus 1 --steps 2000 --warmup 20
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \\
         bench.py --gpus N --steps K --warmup W
 
-One "step" = one iteration of the reference's training loop (learn/rnad.py:495-526): roll out a batch of episodes with
-the learner net (Episodes.generate), sample the buffer, RNaD.__learn (4 MLP evaluations, fused V-trace/NeuRD kernel,
-backward), Adam, EMA target.  `value` times RNaD's default net-evaluation mode (tabular = "forward": the forward evaluations
-run once per (player, state) observation and are gathered per slot, the backward runs per slot -- every result bit-identical
-to evaluating every net on every slot); `other_modes` times that dense mode and tabular = True in the same process.  Workload = BASELINE.json configs[1]: depth-6 ternary (3x3) tree, C = 1, 66 431 states,
-GLOBAL batch 2^20 episodes x 12 env steps, MLP width 256, fp32.  N > 1 shards the episodes over the ranks (strong
-scaling, BASELINE north_star) with one RCCL all-reduce of the 2 loss normalisers and one of the 43 KB gradient bucket.
+One "step" = one iteration of the reference's training loop (learn/rnad.py:495-526): roll out a batch of episodes with the
+learner net (Episodes.generate), sample the buffer, RNaD.__learn (the four nets, V-trace / NeuRD, backward), Adam, EMA target.
+Workload = BASELINE.json configs[1]: depth-6 ternary (3x3) tree, C = 1, 66 431 states, GLOBAL batch 2^20 episodes x 12 env steps,
+MLP width 256, fp32.  `value` times RNaD's default net-evaluation mode (tabular = True: the nets are evaluated once per (player,
+state) observation -- 132 862 rows for 12.6 M slots --, the rollout is bucket-ordered, the per-slot gradients are summed per row in
+LDS and one backward over the rows gives the weight gradients; the step is replayed from a captured hipGraph); `other_modes` times
+"forward" (backward per slot: bit-identical to dense) and dense (every net on every slot, as the reference does) in the same process.
+N > 1 shards the episodes over the ranks (strong scaling, BASELINE north_star) with one RCCL all-reduce of the 2 loss normalisers
+and one of the 43 KB gradient bucket.
 
-Prints ONE JSON line on rank 0.  `value` = env steps of all ranks / wall time of the K timed steps (inputs resident in HBM;
-the tree is generated and uploaded before the timed region).  `roofline` is for K1, the episode-gather kernel
-(rnad_observe): algorithmic bytes per launch (160 B per env step at A = 3 fp32) / mean launch duration
-measured with hipEvents on the launching stream inside the timed region.  `cpu_baseline` times the CPU port
-(oracle/port.py: C oracle + PyTorch-CPU MLP) of the same step on a bounded sample, rank 0, N = 1 only.
+Prints ONE JSON line on rank 0.  `value` = env steps of all ranks / wall time of the K timed steps (inputs resident in HBM; the
+tree is generated and uploaded before the timed region).  `roofline` is for the kernel that takes the largest share of the step,
+its launches bracketed with hipEvents on the launching stream in an eager (un-captured) leg of the same steps right after the
+timed region (events cannot sit inside a replayed graph); `kernels` lists every bracketed kernel of the step the same way.
+`cpu_baseline` times the CPU port (oracle/port.py: C oracle + PyTorch-CPU MLP) of the same step on a bounded sample, rank 0, N = 1.
 """
 import argparse
 import json
@@ -44,8 +46,8 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICRO
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch-log2", type=int, default=20, help="log2 of the GLOBAL episode batch")
     ap.add_argument("--depth", type=int, default=6)
     ap.add_argument("--actions", type=int, default=3)
@@ -56,9 +58,11 @@ def main():
     ap.add_argument("--threshold", type=float, default=None, help="transition_threshold (default 0 for C=1, 0.5/C otherwise)")
     ap.add_argument("--tree-seed", type=int, default=0)
     ap.add_argument("--net-mode", choices=("default", "dense", "forward", "tabular"), default="default",
-                    help="RNaD.tabular for the timed `value`: dense = False, forward = 'forward' (RNaD's default), tabular = True; "
+                    help="RNaD.tabular for the timed `value`: dense = False, forward = 'forward', tabular = True (RNaD's default); "
                          "the other modes are reported under other_modes either way")
+    ap.add_argument("--no-graph", action="store_true", help="RNaD.use_graph = False: enqueue every step eagerly")
     ap.add_argument("--obs-half", action="store_true", help="fp16 observations (BASELINE configs[4])")
+    ap.add_argument("--other-steps", type=int, default=20, help="timed steps of each entry of other_modes and of the eager kernel-timing leg")
     ap.add_argument("--cpu-lanes-log2", type=int, default=15, help="episodes in the CPU-baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -77,7 +81,7 @@ def main():
         dist.init_process_group("nccl", device_id=device)
 
     import rnad_hip
-    from environment.episode import Buffer
+    from environment.episode import Buffer, Episodes
     from environment.tree import Tree
     from learn.rnad import RNaD
 
@@ -91,7 +95,7 @@ def main():
     threshold = args.threshold if args.threshold is not None else (0.0 if C == 1 else 0.5 / C)
     tree = Tree(device=device, max_actions=A, max_transitions=C, depth_bound=depth, transition_threshold=threshold)
     tree.generate_native(seed=args.tree_seed, prune=tuple(args.prune))
-    tree.handle()
+    handle = tree.handle()
     setup_tree_s = time.perf_counter() - t0
     os.environ["RNAD_SAVE_DIR"] = tempfile.mkdtemp(prefix="rnad_bench_")
     torch.manual_seed(0)
@@ -99,21 +103,23 @@ def main():
               net_params={"type": "MLP", "max_actions": A, "width": args.width})
     rn.initialize()
     rn.obs_half = args.obs_half
+    rn.use_graph = not args.no_graph
     if args.net_mode != "default":
         rn.tabular = {"dense": False, "forward": "forward", "tabular": True}[args.net_mode]
     with torch.no_grad():
-        # the general case of rnad.py:382: two DISTINCT regularisation nets and 0 < alpha < 1 (four net evaluations per update).
-        # During m == 0 the two coincide and for alpha == 1 one of them has weight 0; RNaD then evaluates one net less --
-        # that is not what is timed here.
+        # the general case of rnad.py:382: two DISTINCT regularisation nets and 0 < alpha < 1 (all four nets matter)
         for p in rn.net_reg_.parameters():
             p.mul_(1.001)
     buffer = Buffer(rn.n_batches_per_buffer)
     delta_m = 10_000
+    counter = {"i": 0}
 
-    def one_step(i):
+    def one_step():
+        i = counter["i"]
         alpha = 1 if i > delta_m / 2 else i * 2 / delta_m
         rn.train_step(buffer, alpha)
         rn.total_steps += 1
+        counter["i"] = i + 1
 
     def fence():
         torch.cuda.synchronize()
@@ -121,72 +127,100 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # setup (untimed, before the caller's warmup): two priming steps, so that every code object, the caching allocator's pools
-    # and RCCL's channels exist whatever --warmup is (the first launches of a kernel load its code object: tens of ms)
-    for i in range(2):
-        one_step(i)
-    fence()
-    for i in range(args.warmup):
-        one_step(i)
-    fence()
-    # timed region: hipEvent brackets around K1 only (every bracket costs a few us of dispatch latency)
-    rnad_hip.prof_enable([rnad_hip.PROF_OBSERVE])
-    t_start = time.perf_counter()
-    for i in range(args.steps):
-        one_step(args.warmup + i)
-    fence()
-    elapsed = time.perf_counter() - t_start
-    n_obs, obs_ms = rnad_hip.prof_read(rnad_hip.PROF_OBSERVE)
-    T = rn.last_episodes.t_eff + 1
-    # the other kernels: the same steps again with every kernel bracketed, outside the headline timing
-    rnad_hip.prof_enable(True)
-    for i in range(args.steps):
-        one_step(args.warmup + args.steps + i)
-    fence()
-    n_act, act_ms = rnad_hip.prof_read(rnad_hip.PROF_ACT)
-    n_learn, learn_ms = rnad_hip.prof_read(rnad_hip.PROF_LEARN)
-    n_mlp, mlp_ms = rnad_hip.prof_read(rnad_hip.PROF_MLP)
-    n_bwd, bwd_ms = rnad_hip.prof_read(rnad_hip.PROF_MLP_BWD)
-    rnad_hip.prof_enable(False)
-    # the same step in the other net-evaluation modes of RNaD (reported separately, NOT `value`):
-    #   dense_nets   RNaD.tabular = False: every net on every (t, b) slot, as the reference does
-    #   forward      RNaD.tabular = "forward" (the default): forward evaluations once per (player, state), backward per slot;
-    #                every result bit-identical to dense_nets
-    #   tabular_nets RNaD.tabular = True: per-slot gradients summed per (player, state) row, one backward over the 2S rows;
-    #                same rollouts and losses, weight gradients equal up to fp32 summation order
-    default_mode = rn.tabular
-    base = args.warmup + 2 * args.steps
-    variants = {}
-    for name, mode in (("dense_nets", False), ("forward", "forward"), ("tabular_nets", True)):
-        if mode == default_mode or (mode and 8 * tree.handle().S > T * local_batch):
-            continue
-        rn.tabular = mode
-        one_step(base)
-        one_step(base)
+    def timed(n):
         fence()
         t_s = time.perf_counter()
-        for i in range(args.steps):
-            one_step(base + 1 + i)
+        host = 0.0
+        for _ in range(n):
+            h0 = time.perf_counter()
+            one_step()
+            host += time.perf_counter() - h0
         fence()
-        variants[name] = time.perf_counter() - t_s
-        base += args.steps + 1
+        return time.perf_counter() - t_s, host
+
+    # setup (untimed, before the caller's warmup): priming steps, so that every code object, the caching allocator's pools, RCCL's
+    # channels and -- in the default mode -- the captured graph of the step exist whatever --warmup is
+    for _ in range(6):
+        one_step()
+    fence()
+    for _ in range(args.warmup):
+        one_step()
+    # ---- timed region: EXACTLY --steps steps between two fences
+    elapsed, host_s = timed(args.steps)
+    graph_state = getattr(rn, "_graph", None)
+    replayed = bool(graph_state and graph_state.get("graph") is not None)
+    T = rn.last_episodes.t_eff + 1
+    default_mode = rn.tabular
+    mode_now = rn._tabular_mode(T, local_batch)
+
+    # ---- per-kernel durations: the same steps again, eagerly, every kernel bracketed with hipEvents on the launching stream
+    E = max(1, min(args.other_steps, args.steps))
+    rn.use_graph = False
+    for _ in range(2):
+        one_step()
+    fence()
+    rnad_hip.prof_enable(True)
+    for _ in range(E):
+        one_step()
+    fence()
+    names = {rnad_hip.PROF_OBSERVE: "k_observe", rnad_hip.PROF_ACT: "rollout (all kernels of Episodes.generate)",
+             rnad_hip.PROF_LEARN: "learner (all kernels between the forwards and the backward)", rnad_hip.PROF_MLP: "k_mlp_forward",
+             rnad_hip.PROF_MLP_BWD: "k_mlp_backward", rnad_hip.PROF_BUCKET_KEYS: "k_bucket_keys",
+             rnad_hip.PROF_BUCKET_SORT: "k_bucket_hist+scan+items+scatter", rnad_hip.PROF_BUCKET_ROLLOUT: "k_bucket_rollout",
+             rnad_hip.PROF_BUCKET_LEARN: "k_bucket_learn", rnad_hip.PROF_BUCKET_FINISH: "k_bucket_upper+finish"}
+    prof = {}
+    for k, nm in names.items():
+        n, ms = rnad_hip.prof_read(k)
+        if n:
+            prof[k] = dict(name=nm, launches_per_step=n / E, avg_launch_us=ms * 1e3 / n, us_per_step=ms * 1e3 / E)
+    rnad_hip.prof_enable(False)
+    rn.use_graph = not args.no_graph
+
+    # ---- the same step in the other net-evaluation modes of RNaD (reported separately, NOT `value`), eager
+    variants = {}
+    for name, mode in (("dense_nets", False), ("forward", "forward"), ("tabular_nets", True)):
+        if mode == default_mode or (mode and not rn._fused_mlp()):
+            continue
+        rn.tabular = mode
+        if rn._tabular_mode(T, local_batch) != mode:
+            continue
+        one_step()
+        one_step()
+        variants[name] = timed(E)[0]
     rn.tabular = default_mode
-    # rollout alone (Episodes.generate, reference episode.py:175-230), outside the headline timed region
-    from environment.episode import Episodes
+    # rollout alone (Episodes.generate as RNaD.train_step calls it), outside the headline timed region
+    actor_tables = rn._table_outputs(0.5) if mode_now is True else None
     fence()
     t_r = time.perf_counter()
-    for i in range(args.steps):
-        Episodes(tree, local_batch, seed=1000 + i, lane_offset=rank * local_batch, obs_half=args.obs_half).generate(
-            rn.net, trim=False, skip_absorbed=True, store_values=False,
-            tabular=bool(rn.tabular) and 8 * tree.handle().S <= T * local_batch)  # as RNaD.train_step calls it
+    for i in range(E):
+        ep = Episodes(tree, local_batch, seed=1000 + i, lane_offset=rank * local_batch, obs_half=args.obs_half)
+        ep.generate(rn.net, trim=False, skip_absorbed=True, store_values=False, tabular=bool(mode_now), bucketed=mode_now is True,
+                    logits_table=actor_tables["logit"] if actor_tables else None)
     fence()
     rollout_s = time.perf_counter() - t_r
+    # K1, the API's episode-gather kernel (States.observations): not part of the default step any more (observations are
+    # materialised on demand); timed on its own over the T steps of the last rollout
+    k1 = None
+    if rank == 0:
+        obs = torch.empty((local_batch, 2, A, A), dtype=torch.float16 if args.obs_half else torch.float32, device=device)
+        bits = torch.empty((local_batch,), dtype=torch.uint8, device=device)
+        for t in range(T):
+            rnad_hip.observe(handle, ep.indices[t], t & 1, obs=obs, half=args.obs_half, mask_bits=bits)
+        fence_local = torch.cuda.synchronize
+        fence_local()
+        rnad_hip.prof_enable([rnad_hip.PROF_OBSERVE])
+        for _ in range(3):
+            for t in range(T):
+                rnad_hip.observe(handle, ep.indices[t], t & 1, obs=obs, half=args.obs_half, mask_bits=bits)
+        n_obs, obs_ms = rnad_hip.prof_read(rnad_hip.PROF_OBSERVE)
+        rnad_hip.prof_enable(False)
+        k1 = (n_obs, obs_ms)
     if world > 1:
-        names = sorted(variants)
-        t = torch.tensor([elapsed, rollout_s] + [variants[k] for k in names], device=device, dtype=torch.float64)
+        keys = sorted(variants)
+        t = torch.tensor([elapsed, rollout_s, host_s] + [variants[k] for k in keys], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed, rollout_s, *rest = t.tolist()
-        variants = dict(zip(names, rest))
+        elapsed, rollout_s, host_s, *rest = t.tolist()
+        variants = dict(zip(keys, rest))
 
     if rank == 0:
         # the reference's loop (episode.py:194) runs until every lane is absorbed and counts all B lanes in each of those steps;
@@ -194,26 +228,14 @@ def main():
         alive = rn.last_episodes.alive.cpu().numpy()[:T]
         T_ref = int((alive > 0).sum())
         env_steps = global_batch * T_ref * args.steps
+        live_slots = int(alive.sum())
         default_workload = (A, C, depth, tuple(args.prune), args.batch_log2, args.width) == (3, 1, 6, (0, 0), 20, 256)
-        obs_elem = 2 if args.obs_half else 4
-        k1_bytes_per_step = 4 + 8 * A * A + 2 * A * A * obs_elem + 4 * A  # idx + ev row + legal row + obs + mask
-        k1_bytes_per_launch = k1_bytes_per_step * local_batch
-        k1_avg_s = obs_ms / 1e3 / max(n_obs, 1)
-        achieved = k1_bytes_per_launch / k1_avg_s / 1e9 if n_obs else 0.0
-        learn_bytes = (69 + 16) * local_batch * T if A == 3 else None
-        # fused MLP: flops the matrix cores execute per sample (first layer, both heads; relu + second layer run on the VALU)
-        K = 2 * A * A
-        mlp_flops_per_sample = 2.0 * K * 2 * args.width
-        # backward per sample: recompute of the first layer + dW0 over the augmented input padded to its MFMA feature tiles
-        # (16-wide tiles, plus a 4-wide one when at most 4 features are left over; csrc/mlp_bwd.hip)
-        rem = (K + 1) % 16
-        feat = 16 * ((K + 1) // 16 + (1 if rem > 4 else 0)) + (4 if 0 < rem <= 4 else 0)
-        bwd_flops_per_sample = mlp_flops_per_sample + 2.0 * feat * 2 * args.width
-        n_live = int(alive.sum()) if rn.skip_absorbed and not tree.handle().uniform_length else local_batch * T
-        bwd_tflops = bwd_flops_per_sample * n_live / (bwd_ms / max(n_bwd, 1) / 1e3) / 1e12 if n_bwd else None
         what = {False: "every net evaluated on every (t, b) slot, as the reference does",
                 "forward": "forward evaluations once per (player, state) row and gathered per slot; backward per slot; bit-identical to dense",
-                True: "forward evaluations AND gradient sums per (player, state) row; gradients equal up to fp32 summation order"}
+                True: "nets evaluated once per (player, state) row; bucket-ordered rollout; per-slot gradients summed per row in LDS (64-bit "
+                      "fixed point, reproducible); one backward over the rows; gradients equal the dense ones up to fp32 summation order"}
+        kernels = kernel_report(prof, A, C, args, local_batch, T, live_slots, tree, mode_now)
+        dominant = max((k for k in kernels.values() if k.get("single_kernel")), key=lambda k: k["us_per_step"], default=None)
         out = {
             "metric": "env_steps_per_sec (rollout + R-NaD update, one iteration of learn/rnad.py:495-526 per step)",
             "value": env_steps / elapsed,
@@ -233,35 +255,25 @@ def main():
                             + (", BASELINE.json configs[1]" if default_workload else
                                f", prune {args.prune[0]}/{args.prune[1]}, threshold {threshold:g} (a BASELINE.json configs[3]/[4]-style variant)"),
                 "global_batch": global_batch, "per_gpu_batch": local_batch, "T": T_ref, "T_buffer": T,
-                "valid_env_steps_per_step": int(alive.sum()) * world,
+                "valid_env_steps_per_step": live_slots * world,
                 "parallelism": f"dp{world} (episodes sharded, RCCL all-reduce of 2 normalisers + 43 KB grads)",
             },
             "updates_per_sec": args.steps / elapsed,
+            "host_enqueue_ms_per_step": host_s / args.steps * 1e3,
             "net_evaluation": {"mode": f"RNaD.tabular = {default_mode!r}" + (" (default)" if args.net_mode == "default" else ""),
-                               "what": what[default_mode],
-                               "distinct_observations": 2 * tree.handle().S, "slots": T * local_batch},
-            "other_modes": {name: {"env_steps_per_sec": env_steps / sec, "updates_per_sec": args.steps / sec,
-                                   "ms_per_step": sec / args.steps * 1e3,
+                               "in_effect": repr(mode_now), "what": what[mode_now],
+                               "step_replayed_from_hipGraph": replayed,
+                               "distinct_observations": 2 * handle.S, "slots": T * local_batch},
+            "other_modes": {name: {"env_steps_per_sec": global_batch * T_ref * E / sec, "updates_per_sec": E / sec,
+                                   "ms_per_step": sec / E * 1e3, "steps": E,
                                    "what": what[{"dense_nets": False, "forward": "forward", "tabular_nets": True}[name]]}
                             for name, sec in variants.items()},
-            "rollout_env_steps_per_sec": env_steps / rollout_s,
-            "rollout_ms_per_step": rollout_s / args.steps * 1e3,
-            "roofline": {
-                "kernel": "k_observe (K1 episode gather, rnad_observe)",
-                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                "traffic": k1_traffic(A, args),
-                "bytes_per_launch": k1_bytes_per_launch, "avg_launch_us": k1_avg_s * 1e6, "launches": n_obs,
-            },
-            "other_kernels": {
-                "k_act": {"launches": n_act, "avg_launch_us": act_ms * 1e3 / max(n_act, 1)},
-                "k_mlp_forward": {"launches": n_mlp, "total_ms_per_step": mlp_ms / args.steps},
-                "k_mlp_backward": {"launches": n_bwd, "total_ms_per_step": bwd_ms / args.steps, "bound": "mfma", "achieved": bwd_tflops,
-                                   "peak": 157.3, "unit": "TFLOP/s executed (fp32 MFMA, v_mfma_f32_32x32x2_f32)",
-                                   "frac": bwd_tflops / 157.3 if bwd_tflops else None, "note": "dominant kernel by time"},
-                "k_learn_fused": {"launches": n_learn, "avg_launch_us": learn_ms * 1e3 / max(n_learn, 1),
-                                  "achieved_GBps": (learn_bytes / (learn_ms / 1e3 / max(n_learn, 1)) / 1e9) if learn_bytes and n_learn else None},
-            },
-            "setup": {"tree_generate_and_upload_s": setup_tree_s, "tree_table_bytes": tree.handle().table_bytes},
+            "rollout_env_steps_per_sec": global_batch * T_ref * E / rollout_s,
+            "rollout_ms_per_step": rollout_s / E * 1e3,
+            "roofline": roofline_of(dominant),
+            "kernels": kernels,
+            "k1_observe": k1_report(k1, A, args, local_batch),
+            "setup": {"tree_generate_and_upload_s": setup_tree_s, "tree_table_bytes": handle.table_bytes},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(tree, args, T)
@@ -271,10 +283,98 @@ def main():
         dist.destroy_process_group()
 
 
+FP32_PEAK_TFLOPS = 157.3  # fp32 MFMA == fp32 vector peak (/opt/skills/guides/MI355X_MICROARCH.md)
+
+
+def kernel_report(prof, A, C, args, B, T, live_slots, tree, mode_now):
+    """Per bracketed kernel: time per step and, where one kernel is bracketed alone, its algorithmic bytes / flops per launch
+    (DESIGN.md section 5 states each figure) against the HBM or fp32-MFMA peak."""
+    import rnad_hip as rh
+
+    rec = ((4 * A + 3 + 3) & ~3) * 4  # bytes of a row record (rnad_bucket_record_stride)
+    S2 = 2 * tree.handle().S
+    K = 2 * A * A
+    W = args.width
+    rem = (K + 1) % 16
+    feat = 16 * ((K + 1) // 16 + (1 if rem > 4 else 0)) + (4 if 0 < rem <= 4 else 0)
+    slots = B * T
+    model = {
+        # bytes the kernel must move per launch (streams; the L2-resident tables it gathers from are not HBM traffic)
+        rh.PROF_BUCKET_ROLLOUT: ("hbm", 4 * B + slots * (4 + 1 + 4 * A + 4 + 4) + 4 * B,
+                                 "lane_ids 4 B/lane + per slot: state 4, legal bits 1, policy 4A, action 4, reward 4 (+ final state 4 B/lane)"),
+        rh.PROF_BUCKET_LEARN: ("hbm", live_slots * (4 + 4 + 4 * A) + (live_slots // 2) * 4,
+                               "per live slot: state 4, action 4, acting policy 4A; reward 4 on column steps; sums stay in LDS"),
+        rh.PROF_BUCKET_KEYS: ("hbm", 4 * B, "keys 4 B/lane written; everything else is gathered from L2-resident tables"),
+        rh.PROF_OBSERVE: ("hbm", B * (4 + 8 * A * A + 2 * A * A * (2 if args.obs_half else 4) + 4 * A), "SURVEY 8d"),
+    }
+    out = {}
+    for k, p in prof.items():
+        e = dict(p)
+        e["single_kernel"] = k in (rh.PROF_BUCKET_KEYS, rh.PROF_BUCKET_ROLLOUT, rh.PROF_BUCKET_LEARN, rh.PROF_OBSERVE, rh.PROF_MLP, rh.PROF_MLP_BWD)
+        if k in model:
+            bound, nbytes, how = model[k]
+            gbs = nbytes / (p["avg_launch_us"] * 1e-6) / 1e9
+            e.update(bound=bound, algorithmic_bytes_per_launch=nbytes, achieved=gbs, peak=HBM_PEAK_GBS, unit="GB/s", frac=gbs / HBM_PEAK_GBS, bytes_model=how)
+        out[p["name"]] = e
+    # the fused MLP kernels: flops the matrix cores execute per sample (first layer of a head: 2 K W; relu + second layer run on the
+    # VALU; backward: recompute of both heads + dW0 over the augmented input padded to its MFMA tiles)
+    uniform = tree.handle().uniform_length
+    bwd_samples = S2 if mode_now is True else (live_slots if not uniform else slots)
+    if rh.PROF_MLP_BWD in prof:
+        p = prof[rh.PROF_MLP_BWD]
+        flops = (2.0 * K * 2 * W + 2.0 * feat * 2 * W) * bwd_samples
+        tf = flops / (p["us_per_step"] * 1e-6) / 1e12  # the launches of a step together (backward + its reduction)
+        out[p["name"]].update(bound="mfma", achieved=tf, peak=FP32_PEAK_TFLOPS, unit="TFLOP/s", frac=tf / FP32_PEAK_TFLOPS,
+                              samples_per_step=bwd_samples, flops_model="per sample 2*K*2W (recompute) + 2*feat*2W (dW0 tiles), K = 2A^2")
+    if rh.PROF_MLP in prof and mode_now is True:
+        p = prof[rh.PROF_MLP]
+        flops = 2.0 * K * W * 3 * S2  # learner: both heads, target: value head, on the 2S rows (regularisation tables are cached)
+        tf = flops / (p["us_per_step"] * 1e-6) / 1e12
+        out[p["name"]].update(bound="mfma", achieved=tf, peak=FP32_PEAK_TFLOPS, unit="TFLOP/s", frac=tf / FP32_PEAK_TFLOPS, samples_per_step=S2,
+                              flops_model="2*K*W per head and row: learner 2 heads + target value head")
+    return out
+
+
+def roofline_of(k):
+    if k is None:
+        return None
+    r = {"kernel": k["name"], "bound": k.get("bound"), "achieved": k.get("achieved"), "peak": k.get("peak"), "unit": k.get("unit"),
+         "frac": k.get("frac"), "traffic": None, "avg_launch_us": k["avg_launch_us"], "launches_per_step": k["launches_per_step"],
+         "bytes_per_launch": k.get("algorithmic_bytes_per_launch"), "bytes_model": k.get("bytes_model"),
+         "share_of_step_us": k["us_per_step"],
+         "measured": "hipEvents around each launch, eager leg of the same steps after the timed region (the timed steps replay a graph)"}
+    path = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
+    if os.path.exists(path):
+        with open(path) as f:
+            pmc = json.load(f)
+        hit = pmc.get(k["name"])
+        if hit:
+            r["traffic"] = hit["traffic_bytes_per_launch"]
+            r["traffic_source"] = hit["source"]
+    return r
+
+
+def k1_report(k1, A, args, B):
+    if not k1 or not k1[0]:
+        return None
+    n, ms = k1
+    us = ms * 1e3 / n
+    algo = B * (4 + 8 * A * A + 2 * A * A * (2 if args.obs_half else 4) + 4 * A)
+    out = {"kernel": "k_observe (K1, States.observations: the API's episode-gather kernel; not in the default step any more)",
+           "avg_launch_us": us, "launches": n, "algorithmic_bytes_per_launch_survey_8d": algo,
+           "algorithmic_GBps": algo / (us * 1e-6) / 1e9}
+    traffic = k1_traffic(A, args)
+    if traffic:
+        out.update(counter_bytes_per_launch=traffic, frac_of_hbm_peak_from_counter_bytes=traffic / (us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                   note="counter bytes = 2 x FETCH_SIZE + WRITE_SIZE of a separate rocprofv3 --pmc pass (profiles/r02_k1_pmc.json); the "
+                        "SURVEY model over-counts (node rows are L2 hits, the mask travels as 1 byte), so the fraction is taken from the counters")
+    return out
+
+
 def k1_traffic(A, args):
-    """HBM bytes per K1 launch from the separate rocprofv3 PMC passes (profiles/r01_k1_pmc.json: FETCH_SIZE doubled per the
+    """HBM bytes per K1 launch from the separate rocprofv3 PMC passes (profiles/r02_k1_pmc.json: FETCH_SIZE doubled per the
     gfx950 correction + WRITE_SIZE), valid for the default workload only; None otherwise."""
-    path = os.path.join(ROOT, "profiles", "r01_k1_pmc.json")
+    path = os.path.join(ROOT, "profiles", "r02_k1_pmc.json")
     if A != 3 or args.batch_log2 != 20 or args.gpus != 1 or args.obs_half or not os.path.exists(path):
         return None
     with open(path) as f:

@@ -405,7 +405,8 @@ int rnad_solve_matrix(const float *M, int ra, int ca, int max_actions, float *so
 /* ------------------------------------------------------------------------------------------------
  * Kernel timing (bench.py's roofline leg): rnad_prof_enable(mask) brackets every launch of kernel k with a pair of
  * hipEvents on the launching stream when bit (1 << k) of `mask` is set (k: 0 = observe, 1 = act/transition,
- * 2 = learn_fused, 3 = mlp_forward, 4 = mlp_backward; -1 = all, 0 = off) and drops earlier measurements.  Each
+ * 2 = learn_fused, 3 = mlp_forward, 4 = mlp_backward, 5 = bucket keys, 6 = bucket sort passes, 7 = bucket rollout,
+ * 8 = bucket learner, 9 = bucket finish; -1 = all, 0 = off) and drops earlier measurements.  Each
  * bracket costs a few microseconds of dispatch latency, so bracket only what is being measured.
  * rnad_prof_read synchronises the device and returns launches and total milliseconds since the last enable.
  * ---------------------------------------------------------------------------------------------- */

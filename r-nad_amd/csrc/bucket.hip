@@ -36,7 +36,7 @@ constexpr int kMaxPart = 4;          // deepest partition level: 2 * kMaxPart en
 constexpr int kMaxBuckets = 12288;   // LDS histogram of the sort passes: 48 KiB of int32
 constexpr int kSortThreads = 1024;   // threads per block of the sort passes
 constexpr int kSortLanes = 4096;     // lanes per block of the sort passes (4 per thread, 256 contiguous per wave)
-constexpr int kChunk = 2048;         // lanes per work item of the learner
+constexpr int kChunkDefault = 256;   // lanes per work item of the learner: one pass of a 256-thread workgroup (no long tail items)
 constexpr int kReplicas = 64;        // copies of the upper-row table the workgroups spread their path sums over
 constexpr int kMaxSteps = 64;        // T_cap bound of the alive counters in LDS
 constexpr int kLaneBits = 22;        // B <= 2^22 lanes per call: a row receives at most one addend per lane
@@ -45,12 +45,12 @@ constexpr int kLearnLds = 64 * 1024; // LDS budget of one learner workgroup
 inline unsigned blocks_for(int64_t n, int per = kThreads) { return (unsigned)((n + per - 1) / per); }
 
 struct Plan {
-    int k = -1, n_buckets = 0, n_upper = 0, sub_rows = 0, lds = 0, sort_blocks = 0;
+    int k = -1, n_buckets = 0, n_upper = 0, sub_rows = 0, lds = 0, sort_blocks = 0, chunk = kChunkDefault;
     int64_t max_items = 0;
 };
 
-// Partition level: the deepest level <= kMaxPart whose buckets still hold >= 128 lanes on average (a workgroup per bucket
-// should have at least two waves of work), subject to the LDS table of a bucket fitting; if even level 0 is too fine,
+// Partition level: the deepest level <= kMaxPart whose buckets still hold >= 512 lanes on average (measured on configs[1]: full
+// 256-lane work items beat many small buckets), subject to the LDS table of a bucket fitting; if even level 0 is too fine,
 // the shallowest level that fits.  false: this tree cannot be bucketed (ids not DFS pre-order, or no level fits).
 bool make_plan(const rnad_tree_t *tree, int64_t B, Plan &p) {
     if (!tree->contiguous_subtrees || B < 1 || B > ((int64_t)1 << kLaneBits)) return false;
@@ -63,7 +63,7 @@ bool make_plan(const rnad_tree_t *tree, int64_t B, Plan &p) {
         if (lds > kLearnLds) continue;
         if (first < 0) first = k;
         const int64_t level_states = tree->level_offsets[(size_t)k + 1] - tree->level_offsets[(size_t)k];
-        if (B / std::max<int64_t>(level_states, 1) >= 128) best = k;
+        if (B / std::max<int64_t>(level_states, 1) >= 512) best = k;
     }
     int k = best >= 0 ? best : first;
     if (k < 0) return false;
@@ -80,7 +80,8 @@ bool make_plan(const rnad_tree_t *tree, int64_t B, Plan &p) {
     p.sub_rows = (int)tree->level_max_subtree[(size_t)k];
     p.lds = (2 * k + 2 * p.sub_rows) * (tree->A + 1) * 8;
     p.sort_blocks = (int)((B + kSortLanes - 1) / kSortLanes);
-    p.max_items = (int64_t)p.n_buckets + B / kChunk + 1;
+    if (const char *c = getenv("RNAD_BUCKET_CHUNK")) p.chunk = std::max(64, atoi(c));  // tuning knob
+    p.max_items = (int64_t)p.n_buckets + B / p.chunk + 1;
     return true;
 }
 
@@ -233,8 +234,8 @@ struct Item {
     int32_t begin, count, state, single;  // lanes [begin, begin + count) of bucket `state`; single: the bucket's only item
 };
 
-// bucket_start = exclusive prefix of the totals; one work item per kChunk lanes of a non-empty bucket.  One workgroup.
-__global__ __launch_bounds__(kSortThreads) void k_bucket_items(int n_buckets, const int32_t *__restrict__ totals,
+// bucket_start = exclusive prefix of the totals; one work item per `chunk` lanes of a non-empty bucket.  One workgroup.
+__global__ __launch_bounds__(kSortThreads) void k_bucket_items(int n_buckets, int chunk, const int32_t *__restrict__ totals,
                                                                const int32_t *__restrict__ level_order, int32_t *__restrict__ bucket_start,
                                                                Item *__restrict__ items, int32_t *__restrict__ n_items) {
     __shared__ int32_t wave_l[16], wave_i[16];
@@ -244,7 +245,7 @@ __global__ __launch_bounds__(kSortThreads) void k_bucket_items(int n_buckets, co
     for (int base = 0; base < n_buckets; base += kSortThreads) {
         const int i = base + threadIdx.x;
         const int32_t n = i < n_buckets ? totals[i] : 0;
-        const int32_t ni = (n + kChunk - 1) / kChunk;
+        const int32_t ni = (n + chunk - 1) / chunk;
         int32_t sl = n, si = ni;  // inclusive scans within the wave
 #pragma unroll
         for (int off = 1; off < 64; off <<= 1) {
@@ -268,7 +269,7 @@ __global__ __launch_bounds__(kSortThreads) void k_bucket_items(int n_buckets, co
         if (i < n_buckets) {
             bucket_start[i] = start;
             for (int32_t j = 0; j < ni; ++j)
-                items[first + j] = Item{start + j * kChunk, min(kChunk, n - j * kChunk), level_order[i], ni == 1 ? 1 : 0};
+                items[first + j] = Item{start + j * chunk, min(chunk, n - j * chunk), level_order[i], ni == 1 ? 1 : 0};
         }
         __syncthreads();
         if (threadIdx.x == kSortThreads - 1) {
@@ -734,24 +735,33 @@ extern "C" int rnad_rollout_bucketed(const rnad_tree_t *tree, const rnad_traj_t 
         policy_tab = s.policy;
         policy_stride = tree->A;
     }
-    RNAD_DISPATCH_A(tree->A, hipLaunchKernelGGL((k_bucket_keys<kA>), dim3(blocks_for(B)), dim3(kThreads), 0, stream, tree->trans, tree->C,
-                                                S, B, n_steps, policy_tab, policy_stride, (const int32_t *)tree->order_pos, seed,
-                                                device_params, lane0, s.keys));
+    {
+        ProfScope one(PROF_BUCKET_KEYS, stream);
+        RNAD_DISPATCH_A(tree->A, hipLaunchKernelGGL((k_bucket_keys<kA>), dim3(blocks_for(B)), dim3(kThreads), 0, stream, tree->trans, tree->C,
+                                                    S, B, n_steps, policy_tab, policy_stride, (const int32_t *)tree->order_pos, seed,
+                                                    device_params, lane0, s.keys));
+    }
     const size_t lds = (size_t)p.n_buckets * sizeof(int32_t);
+    {
+        ProfScope sort_passes(PROF_BUCKET_SORT, stream);
     hipLaunchKernelGGL(k_bucket_hist, dim3(p.sort_blocks), dim3(kSortThreads), lds, stream, B, p.n_buckets, (const int32_t *)s.keys, s.hist);
     hipLaunchKernelGGL(k_bucket_scan, dim3((p.n_buckets + 63) / 64), dim3(kSortThreads), 0, stream, p.sort_blocks, p.n_buckets, s.hist,
                        s.totals);
-    hipLaunchKernelGGL(k_bucket_items, dim3(1), dim3(kSortThreads), 0, stream, p.n_buckets, (const int32_t *)s.totals,
+    hipLaunchKernelGGL(k_bucket_items, dim3(1), dim3(kSortThreads), 0, stream, p.n_buckets, p.chunk, (const int32_t *)s.totals,
                        (const int32_t *)tree->level_order, s.bucket_start, (Item *)items, n_items);
     hipLaunchKernelGGL(k_bucket_scatter, dim3(p.sort_blocks), dim3(kSortThreads), lds, stream, B, p.n_buckets, (const int32_t *)s.keys,
                        (const int32_t *)s.hist, (const int32_t *)s.bucket_start, lane_ids);
+    }
     RNAD_HIP_OK(hipGetLastError());
     const unsigned grid = blocks_for(B);
-    RNAD_DISPATCH_A(tree->A, hipLaunchKernelGGL((k_bucket_rollout<kA>), dim3(grid), dim3(kThreads), 0, stream, tree->trans, tree->C, S, B,
-                                                (int)tr->T_cap, policy_tab, policy_stride, value_table, value_stride,
-                                                (const uint8_t *)tree->mask_tab, seed, device_params, lane0, (const int32_t *)lane_ids,
-                                                tr->indices,
-                                                tr->mask_bits, tr->policy, tr->actions, tr->rewards, tr->values, s.alive_part));
+    {
+        ProfScope one(PROF_BUCKET_ROLLOUT, stream);
+        RNAD_DISPATCH_A(tree->A, hipLaunchKernelGGL((k_bucket_rollout<kA>), dim3(grid), dim3(kThreads), 0, stream, tree->trans, tree->C, S, B,
+                                                    (int)tr->T_cap, policy_tab, policy_stride, value_table, value_stride,
+                                                    (const uint8_t *)tree->mask_tab, seed, device_params, lane0,
+                                                    (const int32_t *)lane_ids, tr->indices, tr->mask_bits, tr->policy, tr->actions,
+                                                    tr->rewards, tr->values, s.alive_part));
+    }
     hipLaunchKernelGGL(k_bucket_alive, dim3(tr->T_cap + 1), dim3(kThreads), 0, stream, (int)grid, (int)tr->T_cap + 1,
                        (const int32_t *)s.alive_part, tr->alive);
     RNAD_HIP_OK(hipGetLastError());
@@ -786,9 +796,13 @@ extern "C" int rnad_learn_bucketed(const rnad_tree_t *tree, int T, int64_t B, co
                            (const int32_t *)tree->order_pos, indices, actions, rewards, mu, records, *hp, fx, acc, rep,               \
                            losses ? losses_raw : (double *)nullptr, overflow);                                                        \
     } while (0)
-    RNAD_DISPATCH_A(tree->A, RNAD_BUCKET_LEARN());
+    {
+        ProfScope one(PROF_BUCKET_LEARN, stream);
+        RNAD_DISPATCH_A(tree->A, RNAD_BUCKET_LEARN());
+    }
 #undef RNAD_BUCKET_LEARN
     RNAD_HIP_OK(hipGetLastError());
+    ProfScope fin(PROF_BUCKET_FINISH, stream);
     if (p.n_upper > 0)
         RNAD_DISPATCH_A(tree->A, hipLaunchKernelGGL((k_bucket_upper<kA>), dim3(blocks_for(2 * (int64_t)p.n_upper, kThreads / 64)), dim3(kThreads),
                                                     0, stream, S, p.n_upper, (const int32_t *)tree->level_order, acc, rep));

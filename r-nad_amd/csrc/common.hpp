@@ -59,7 +59,10 @@ struct DeviceGuard {
 };
 
 // Event bracketing for bench.py's roofline leg.
-enum ProfKernel { PROF_OBSERVE = 0, PROF_ACT = 1, PROF_LEARN = 2, PROF_MLP = 3, PROF_MLP_BWD = 4, PROF_COUNT = 5 };
+enum ProfKernel {
+    PROF_OBSERVE = 0, PROF_ACT = 1, PROF_LEARN = 2, PROF_MLP = 3, PROF_MLP_BWD = 4,
+    PROF_BUCKET_KEYS = 5, PROF_BUCKET_SORT = 6, PROF_BUCKET_ROLLOUT = 7, PROF_BUCKET_LEARN = 8, PROF_BUCKET_FINISH = 9, PROF_COUNT = 10
+};
 struct ProfScope {
     int which;
     hipStream_t stream;

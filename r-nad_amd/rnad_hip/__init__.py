@@ -581,7 +581,7 @@ class BucketPlan:
 def bucket_plan(tree, B):
     """The BucketPlan of (tree, B) (cached on the tree handle), or None when this tree / batch cannot be bucketed."""
     cache = tree.__dict__.setdefault("_bucket_plans", {})
-    key = (B, os.environ.get("RNAD_BUCKET_LEVEL"))  # the partition-depth override of csrc/bucket.hip (tuning / tests)
+    key = (B, os.environ.get("RNAD_BUCKET_LEVEL"), os.environ.get("RNAD_BUCKET_CHUNK"))  # the tuning overrides of csrc/bucket.hip
     if key not in cache:
         out = (C.c_int64 * 8)()
         rc = lib().rnad_bucket_plan(tree.ptr, B, out)
@@ -711,6 +711,7 @@ def tree_generate(A, Cc, depth_bound, transition_threshold=0.0, terminal_values=
 
 # --------------------------------------------------------------------------------------- profiling hooks
 PROF_OBSERVE, PROF_ACT, PROF_LEARN, PROF_MLP, PROF_MLP_BWD = 0, 1, 2, 3, 4
+PROF_BUCKET_KEYS, PROF_BUCKET_SORT, PROF_BUCKET_ROLLOUT, PROF_BUCKET_LEARN, PROF_BUCKET_FINISH = 5, 6, 7, 8, 9
 
 
 def prof_enable(on):

@@ -86,12 +86,12 @@ def test_bucketed_rollout_is_the_lane_ordered_rollout(name, B):
     want = np.argsort(pos[key], kind="stable")
     np.testing.assert_array_equal(buc.lane_ids.cpu().numpy(), want)
     items = buc.buckets.items.cpu().numpy()[: int(buc.buckets.n_items.item())]
-    assert items[:, 1].sum() == B and (items[:, 1] > 0).all() and (items[:, 1] <= 2048).all()
+    assert items[:, 1].sum() == B and (items[:, 1] > 0).all() and (items[:, 1] <= 256).all()
     np.testing.assert_array_equal(items[:, 0], np.concatenate([[0], np.cumsum(items[:, 1])[:-1]]))
     sorted_keys = key[want]
     for begin, count, state, single in items:
         assert (sorted_keys[begin: begin + count] == state).all()
-        assert bool(single) == ((sorted_keys == state).sum() <= 2048)
+        assert bool(single) == ((sorted_keys == state).sum() <= 256)
 
 
 def _four_nets(A, W, seed):
@@ -196,9 +196,9 @@ def _bucketize(G, tree, ep):
     start = 0
     while start < B:
         n = int((sk == sk[start]).sum())
-        chunks = (n + 2047) // 2048
+        chunks = (n + 255) // 256
         for c in range(chunks):
-            items.append((start + c * 2048, min(2048, n - c * 2048), int(sk[start]), int(chunks == 1)))
+            items.append((start + c * 256, min(256, n - c * 256), int(sk[start]), int(chunks == 1)))
         start += n
     b = rnad_hip.Buckets(plan, DEV)
     b.lane_ids.copy_(sel.to(torch.int32))
