@@ -313,14 +313,18 @@ int rnad_learn_fused_gather(const rnad_tree_t *tree, int T, int64_t B, const int
 /* ------------------------------------------------------------------------------------------------
  * Bucketed tabular pipeline (csrc/bucket.hip)  --  environment/episode.py:175-230 (Episodes.generate) and learn/rnad.py:365-425
  * again, for trees that are small next to the batch, organised so that the per-(player, state) sums of the tabular update need
- * no global atomics: lanes are grouped by the state they reach at depth k ("bucket"; state ids are DFS pre-order, tree.py:311-330,
- * so the subtree below state s is the id range [s, s + size)), the trajectory buffers are written in bucket order, and one
- * workgroup per bucket adds its lanes' gradients up in an LDS table indexed by (state - bucket state).
+ * no global atomics.  State ids are DFS pre-order (tree.py:311-330), so the subtree of s is the id range [s, s + size(s)).  The
+ * tree is cut by subtree size: states whose subtree exceeds R rows are "upper"; the other children of an upper state, packed into
+ * runs of consecutive siblings spanning at most R ids, are the "groups".  Lanes are sorted by the group they descend into
+ * (bucket), the trajectory buffers are written in that order, and one workgroup per <= 256 lanes of a bucket adds its lanes'
+ * gradients up in an LDS table indexed by (state - first id of the group); the upper rows above it are common to the workgroup.
  *
- * rnad_bucket_plan: out[0] = k (partition depth), [1] = number of buckets, [2] = number of states above the buckets, [3] = rows
- * of a bucket's table, [4] = capacity of the work-item list (items: int32 [out[4]][4]), [5] = bytes of `scratch` for
- * rnad_rollout_bucketed, [6] = bytes of `accumulators` for rnad_learn_bucketed (zero them once; every update leaves them zero),
- * [7] = LDS bytes of a learner workgroup.  Non-zero return: this tree / batch cannot be bucketed (use the entry points above).
+ * rnad_bucket_plan: out[0] = R (rows of a bucket's table), [1] = number of buckets (groups + one terminal bucket per upper state),
+ * [2] = number of upper states, [3] = number of groups, [4] = capacity of the work-item list (items: int32 [out[4]][4] = first lane,
+ * lanes, bucket, 1 if the bucket's only item), [5] = bytes of `scratch` for rnad_rollout_bucketed, [6] = bytes of `accumulators` for
+ * rnad_learn_bucketed (zero them once; every update leaves them zero), [7] = LDS bytes of a learner workgroup.  Non-zero return: this
+ * tree / batch cannot be bucketed (use the entry points above).  rnad_bucket_map: the bucket of every state (host int32 [S]; < *n_groups:
+ * a group, else n_groups + upper slot; -1: state 0 / unreachable) -- what tests and tools need to reproduce the lane order.
  *
  * rnad_rollout_bucketed: the rollout of rnad_rollout_run_tabular -- same tabular actor (table row = player * S + state,
  * table_stride floats apart; table_is_policy == 0: the actor's logits, whose policy head is then taken once per row;
@@ -351,6 +355,7 @@ typedef struct rnad_step_params {
  * before the GPU has consumed the previous values). */
 int rnad_step_params_set(rnad_step_params_t *device_params, uint64_t seed, float alpha, float one_minus_alpha, void *stream);
 int rnad_bucket_plan(const rnad_tree_t *tree, int64_t B, int64_t *out);
+int rnad_bucket_map(const rnad_tree_t *tree, int64_t B, int32_t *bucket_of, int32_t *n_groups);
 int rnad_rollout_bucketed(const rnad_tree_t *tree, const rnad_traj_t *traj, const float *table, int64_t table_stride,
                           int table_is_policy, const float *value_table, int64_t value_stride, uint64_t seed, int64_t lane0,
                           const rnad_step_params_t *device_params, void *scratch, int32_t *lane_ids, int32_t *items, int32_t *n_items,

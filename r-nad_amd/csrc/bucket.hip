@@ -7,13 +7,15 @@
 // Why buckets.  The weight gradient is linear in dL/dout, and a net's input depends on (player to move, state) only
 // (episode.py:62-68), so the update needs, per row (P, s), the SUM of the per-slot gradients of the slots that sit in s at a step
 // of parity P.  Summing 12.6 M slots into 132 862 rows with global atomics costs ~1 ms (16.8 M spread 64-bit atomics, round 1).
-// Here lanes are first grouped by the state they reach at depth k (their "bucket"; ids are DFS pre-order, tree.py:311-330, so
-// the subtree below a bucket state s is the id range [s, s + size)): one workgroup then owns ALL slots of the rows below its
-// bucket state and adds them up in a small LDS table indexed by (state - s); the rows above it are shared by the whole
-// workgroup (every lane of a bucket has the same ancestors) and take one wave reduction per step.  No global atomic on the
-// common path, results in 64-bit fixed point (integer sums: any order, same bits).
+// Here the tree is cut by subtree size (ids are DFS pre-order, tree.py:311-330, so the subtree of s is the id range
+// [s, s + size(s))): states whose subtree exceeds R rows are "upper"; the other children of an upper state, packed into runs of
+// consecutive siblings spanning at most R ids, are the "groups".  Lanes are sorted by the group they descend into (their
+// bucket): one workgroup then owns ALL slots of the rows of its group and adds them up in an LDS table indexed by
+// (state - first id of the group); the rows above are upper states every lane of the bucket went through, one row per step
+// for the whole workgroup, and take one wave reduction per step.  No global atomic on the common path, results in 64-bit fixed
+// point (integer sums: any order, same bits).  On a regular tree the cut is a level; on a pruned one it follows the subtrees.
 //
-//   k_bucket_keys      lane-ordered: plays the first 2k env steps only, key = the depth-k state reached (or the last live one)
+//   k_bucket_keys      lane-ordered: plays the env steps above the cut only, key = the group reached (or the upper state the lane ends in)
 //   k_bucket_hist/scan/items/scatter   stable counting sort of the lanes by key (deterministic), work items per bucket
 //   k_bucket_rollout   bucket-ordered: thread j replays lane lane_ids[j] from the root (counter-based noise keyed by the GLOBAL lane
 //                      id, include/rnad_rng.h) and records the trajectory -- column j of every [T, B] buffer
@@ -32,8 +34,9 @@ using namespace rnad::dev;
 namespace {
 
 constexpr int kThreads = 256;
-constexpr int kMaxPart = 4;          // deepest partition level: 2 * kMaxPart env steps above the buckets
+constexpr int kMaxPath = 32;         // env steps above a group (path rows of the LDS table)
 constexpr int kMaxBuckets = 12288;   // LDS histogram of the sort passes: 48 KiB of int32
+constexpr int kMaxUpper = 8192;      // upper states (64 replicas of their rows are kept)
 constexpr int kSortThreads = 1024;   // threads per block of the sort passes
 constexpr int kSortLanes = 4096;     // lanes per block of the sort passes (4 per thread, 256 contiguous per wave)
 constexpr int kChunkDefault = 256;   // lanes per work item of the learner: one pass of a 256-thread workgroup (no long tail items)
@@ -41,47 +44,126 @@ constexpr int kReplicas = 64;        // copies of the upper-row table the workgr
 constexpr int kMaxSteps = 64;        // T_cap bound of the alive counters in LDS
 constexpr int kLaneBits = 22;        // B <= 2^22 lanes per call: a row receives at most one addend per lane
 constexpr int kLearnLds = 64 * 1024; // LDS budget of one learner workgroup
+constexpr int kTargetLanes = 1024;   // finest cut whose groups still hold this many lanes on average (configs[1]: full work items win)
 
 inline unsigned blocks_for(int64_t n, int per = kThreads) { return (unsigned)((n + per - 1) / per); }
 
 struct Plan {
-    int k = -1, n_buckets = 0, n_upper = 0, sub_rows = 0, lds = 0, sort_blocks = 0, chunk = kChunkDefault;
+    const BucketCut *cut = nullptr;
+    int lds = 0, sort_blocks = 0, chunk = kChunkDefault;
     int64_t max_items = 0;
 };
 
-// Partition level: the deepest level <= kMaxPart whose buckets still hold >= 512 lanes on average (measured on configs[1]: full
-// 256-lane work items beat many small buckets), subject to the LDS table of a bucket fitting; if even level 0 is too fine,
-// the shallowest level that fits.  false: this tree cannot be bucketed (ids not DFS pre-order, or no level fits).
+// The cut of `tree` for tables of `rows` rows (host, O(S)); cached with the handle.  nullptr: HIP allocation failed.
+const BucketCut *get_cut(const rnad_tree_t *tree, int rows) {
+    auto it = tree->cuts.find(rows);
+    if (it != tree->cuts.end()) return &it->second;
+    const int64_t S = tree->S;
+    std::vector<int32_t> bucket_of((size_t)S, -1), lo, path, upper_list;
+    std::vector<int32_t> upper_slot((size_t)S, -1);
+    auto is_upper = [&](int64_t s) { return tree->subtree_size[(size_t)s] > rows; };
+    int max_path = 0;
+    if (!is_upper(1)) {  // the whole tree fits one table: a single group, nothing above it
+        lo.push_back(1);
+        path.push_back(0);
+        for (int64_t s = 1; s < S; ++s)
+            if (tree->level_of[(size_t)s] >= 0) bucket_of[(size_t)s] = 0;
+    } else {
+        for (int64_t u = 1; u < S; ++u) {
+            if (tree->level_of[(size_t)u] < 0 || !is_upper(u)) continue;
+            upper_slot[(size_t)u] = (int32_t)upper_list.size();
+            upper_list.push_back((int32_t)u);
+            const int level = tree->level_of[(size_t)u];
+            int64_t g_lo = -1, g_hi = -1;
+            auto close = [&]() {
+                if (g_lo < 0) return;
+                const int32_t gid = (int32_t)lo.size();
+                lo.push_back((int32_t)g_lo);
+                path.push_back(2 * (level + 1));
+                for (int64_t x = g_lo; x < g_hi; ++x) bucket_of[(size_t)x] = gid;
+                g_lo = g_hi = -1;
+            };
+            for (int64_t i = tree->child_offsets[(size_t)u]; i < tree->child_offsets[(size_t)u + 1]; ++i) {
+                const int64_t c = tree->children[(size_t)i];
+                if (is_upper(c)) {
+                    close();
+                    continue;
+                }
+                const int64_t c_hi = c + tree->subtree_size[(size_t)c];
+                if (g_lo >= 0 && c == g_hi && c_hi - g_lo <= rows) {
+                    g_hi = c_hi;
+                } else {
+                    close();
+                    g_lo = c;
+                    g_hi = c_hi;
+                }
+            }
+            close();
+        }
+    }
+    BucketCut cut;
+    cut.rows = rows;
+    cut.n_groups = (int)lo.size();
+    cut.n_upper = (int)upper_list.size();
+    cut.n_buckets = cut.n_groups + cut.n_upper;
+    for (int i = 0; i < cut.n_upper; ++i) {  // terminal buckets: lanes that leave the tree from an upper state
+        const int32_t u = upper_list[(size_t)i];
+        bucket_of[(size_t)u] = cut.n_groups + i;
+        lo.push_back(u);
+        path.push_back(2 * tree->level_of[(size_t)u] + 2);
+    }
+    for (int32_t v : path) max_path = std::max(max_path, (int)v);
+    cut.max_path = max_path;
+    if (upper_list.empty()) upper_list.push_back(0);
+    DeviceGuard guard(tree->device);
+    auto up = [&](int32_t **dst, const std::vector<int32_t> &src) {
+        if (hipMalloc((void **)dst, std::max<size_t>(src.size(), 1) * sizeof(int32_t)) != hipSuccess) return false;
+        return src.empty() || hipMemcpy(*dst, src.data(), src.size() * sizeof(int32_t), hipMemcpyHostToDevice) == hipSuccess;
+    };
+    if (!guard.ok || !up(&cut.bucket_of, bucket_of) || !up(&cut.bucket_lo, lo) || !up(&cut.bucket_path, path) || !up(&cut.upper_list, upper_list)) {
+        if (cut.bucket_of) (void)hipFree(cut.bucket_of);
+        if (cut.bucket_lo) (void)hipFree(cut.bucket_lo);
+        if (cut.bucket_path) (void)hipFree(cut.bucket_path);
+        if (cut.upper_list) (void)hipFree(cut.upper_list);
+        return nullptr;
+    }
+    cut.host_bucket_of = std::move(bucket_of);
+    return &tree->cuts.emplace(rows, std::move(cut)).first->second;
+}
+
+bool cut_fits(const BucketCut *c) {
+    return c && c->n_buckets <= kMaxBuckets && c->n_upper <= kMaxUpper && c->max_path <= kMaxPath;
+}
+
+// Table size: the finest cut (rows halved from the LDS budget down) whose groups still hold kTargetLanes lanes on average;
+// if even the coarsest is finer than that, the coarsest.  false: this tree cannot be bucketed (ids not DFS pre-order, or no
+// cut fits the limits above).  RNAD_BUCKET_ROWS forces a table size (tuning / tests).
 bool make_plan(const rnad_tree_t *tree, int64_t B, Plan &p) {
     if (!tree->contiguous_subtrees || B < 1 || B > ((int64_t)1 << kLaneBits)) return false;
-    int best = -1, first = -1;
-    for (int k = 0; k < tree->n_levels && k <= kMaxPart; ++k) {
-        const int64_t n_buckets = tree->level_offsets[(size_t)k + 1];
-        if (n_buckets > kMaxBuckets) break;
-        const int64_t sub = tree->level_max_subtree[(size_t)k];
-        const int64_t lds = (2 * k + 2 * sub) * (tree->A + 1) * 8;
-        if (lds > kLearnLds) continue;
-        if (first < 0) first = k;
-        const int64_t level_states = tree->level_offsets[(size_t)k + 1] - tree->level_offsets[(size_t)k];
-        if (B / std::max<int64_t>(level_states, 1) >= 512) best = k;
-    }
-    int k = best >= 0 ? best : first;
-    if (k < 0) return false;
-    if (const char *force = getenv("RNAD_BUCKET_LEVEL")) {  // tuning / test knob: a specific partition depth, if it fits
+    const int rows_max = (kLearnLds / ((tree->A + 1) * 8) - kMaxPath) / 2;
+    const BucketCut *chosen = nullptr;
+    if (const char *force = getenv("RNAD_BUCKET_ROWS")) {
         const int want = atoi(force);
-        if (want < 0 || want >= tree->n_levels || want > kMaxPart || tree->level_offsets[(size_t)want + 1] > kMaxBuckets ||
-            (2 * want + 2 * tree->level_max_subtree[(size_t)want]) * (tree->A + 1) * 8 > kLearnLds)
-            return false;
-        k = want;
+        if (want < 1 || want > rows_max) return false;
+        chosen = get_cut(tree, want);
+        if (!cut_fits(chosen)) return false;
+    } else {
+        for (int rows = rows_max; rows >= 4; rows /= 2) {
+            const BucketCut *c = get_cut(tree, rows);
+            if (!cut_fits(c)) {
+                if (chosen) break;  // finer cuts only have more buckets
+                continue;
+            }
+            if (chosen && B / std::max(c->n_groups, 1) < kTargetLanes) break;
+            chosen = c;
+        }
     }
-    p.k = k;
-    p.n_buckets = (int)tree->level_offsets[(size_t)k + 1];
-    p.n_upper = (int)tree->level_offsets[(size_t)k];
-    p.sub_rows = (int)tree->level_max_subtree[(size_t)k];
-    p.lds = (2 * k + 2 * p.sub_rows) * (tree->A + 1) * 8;
+    if (!chosen) return false;
+    p.cut = chosen;
+    p.lds = (kMaxPath + 2 * chosen->rows) * (tree->A + 1) * 8;
     p.sort_blocks = (int)((B + kSortLanes - 1) / kSortLanes);
     if (const char *c = getenv("RNAD_BUCKET_CHUNK")) p.chunk = std::max(64, atoi(c));  // tuning knob
-    p.max_items = (int64_t)p.n_buckets + B / p.chunk + 1;
+    p.max_items = (int64_t)chosen->n_buckets + B / p.chunk + 1;
     return true;
 }
 
@@ -151,19 +233,19 @@ __global__ __launch_bounds__(kThreads) void k_row_records(int64_t rows, const fl
 }
 
 // ---------------------------------------------------------------------------------------- 1. keys
-// Lane b (lane order) plays env steps 0 .. n_steps - 1 (n_steps = 2k) exactly as k_bucket_rollout will, and keeps the last
-// non-absorbing state it has seen: the depth-k state it reaches, or the state it left the tree from if that happens earlier.
+// Lane b (lane order) plays env steps exactly as k_bucket_rollout will, for as long as it sits in an upper state: its key is the
+// group it descends into, or the terminal bucket of the upper state it leaves the tree from.
 template <int A>
 __global__ __launch_bounds__(kThreads) void k_bucket_keys(const Trans *__restrict__ trans, int C, int64_t S, int64_t B, int n_steps,
                                                           const float *__restrict__ policy_tab, int64_t tab_stride,
-                                                          const int32_t *__restrict__ order_pos, uint64_t seed,
+                                                          const int32_t *__restrict__ bucket_of, int n_groups, uint64_t seed,
                                                           const rnad_step_params_t *__restrict__ sp, int64_t lane0,
                                                           int32_t *__restrict__ keys) {
     const int64_t b = (int64_t)blockIdx.x * kThreads + threadIdx.x;
     if (b >= B) return;
     if (sp) seed = sp->seed;  // per-step scalars in device memory: a captured graph of the step replays with new values
-    int state = 1, key = 1, prev = 0;
-    for (int t = 0; t < n_steps && state != 0; ++t) {
+    int state = 1, key = bucket_of[1], prev = 0;
+    for (int t = 0; t < n_steps && key >= n_groups; ++t) {
         const int64_t row = (int64_t)(t & 1) * S + state;
         float pol[A], q[A];
 #pragma unroll
@@ -175,12 +257,13 @@ __global__ __launch_bounds__(kThreads) void k_bucket_keys(const Trans *__restric
             float rew;
             transition_lane<A>(trans, C, state, prev, action, nullptr, seed, (uint64_t)(lane0 + b), (uint32_t)t, next, rew);
             state = next;
-            if (state != 0) key = state;
+            if (state == 0) break;
+            key = bucket_of[state];
         } else {
             prev = action;
         }
     }
-    keys[b] = order_pos[key];
+    keys[b] = key;
 }
 
 // ---------------------------------------------------------------------------------------- 2. stable counting sort by key
@@ -231,12 +314,12 @@ __global__ __launch_bounds__(kSortThreads) void k_bucket_scan(int n_blocks, int 
 }
 
 struct Item {
-    int32_t begin, count, state, single;  // lanes [begin, begin + count) of bucket `state`; single: the bucket's only item
+    int32_t begin, count, bucket, single;  // lanes [begin, begin + count) of that bucket; single: the bucket's only item
 };
 
 // bucket_start = exclusive prefix of the totals; one work item per `chunk` lanes of a non-empty bucket.  One workgroup.
 __global__ __launch_bounds__(kSortThreads) void k_bucket_items(int n_buckets, int chunk, const int32_t *__restrict__ totals,
-                                                               const int32_t *__restrict__ level_order, int32_t *__restrict__ bucket_start,
+                                                               int32_t *__restrict__ bucket_start,
                                                                Item *__restrict__ items, int32_t *__restrict__ n_items) {
     __shared__ int32_t wave_l[16], wave_i[16];
     __shared__ int32_t carry_l, carry_i;
@@ -269,7 +352,7 @@ __global__ __launch_bounds__(kSortThreads) void k_bucket_items(int n_buckets, in
         if (i < n_buckets) {
             bucket_start[i] = start;
             for (int32_t j = 0; j < ni; ++j)
-                items[first + j] = Item{start + j * chunk, min(chunk, n - j * chunk), level_order[i], ni == 1 ? 1 : 0};
+                items[first + j] = Item{start + j * chunk, min(chunk, n - j * chunk), i, ni == 1 ? 1 : 0};
         }
         __syncthreads();
         if (threadIdx.x == kSortThreads - 1) {
@@ -432,24 +515,24 @@ struct FixedPoint {
 // point; k_bucket_finish applies w_n / N_P and w_v / N_P (the reference scales every slot by them: vtrace.py:374,389 and
 // rnad.py:424; summing first changes the rounding of the last bit only).  losses_raw[4] += sum d^2 (P = 0, 1), sum -nerd (P = 0, 1).
 template <int A>
-__global__ __launch_bounds__(kThreads) void k_bucket_learn(int T, int64_t B, int64_t S, int k, int sub_rows, int n_upper,
+__global__ __launch_bounds__(kThreads) void k_bucket_learn(int T, int64_t B, int64_t S, int sub_rows, int n_groups, int up_stride,
                                                            const Item *__restrict__ items, const int32_t *__restrict__ n_items,
-                                                           const uint8_t *__restrict__ level_dev, const int32_t *__restrict__ order_pos,
-                                                           const int32_t *__restrict__ indices,
+                                                           const int32_t *__restrict__ bucket_of, const int32_t *__restrict__ bucket_lo,
+                                                           const int32_t *__restrict__ bucket_path, const int32_t *__restrict__ indices,
                                                            const int32_t *__restrict__ actions, const float *__restrict__ rewards,
                                                            const float *__restrict__ mu_, const float *__restrict__ rec_,
                                                            rnad_learn_params_t hp, FixedPoint fx, unsigned long long *__restrict__ acc,
                                                            unsigned long long *__restrict__ rep, double *__restrict__ losses_raw,
                                                            int32_t *__restrict__ overflow) {
-    extern __shared__ unsigned long long tab[];  // [2k path rows | sub_rows rows of player 0 | sub_rows rows of player 1][A + 1]
-    __shared__ int32_t path_state[2 * kMaxPart + 1];
+    extern __shared__ unsigned long long tab[];  // [kMaxPath path rows | sub_rows rows of player 0 | sub_rows rows of player 1][A + 1]
+    __shared__ int32_t path_state[kMaxPath];
     __shared__ double loss_part[kThreads / 64][4];
     if ((int)blockIdx.x >= *n_items) return;
     const Item item = items[blockIdx.x];
-    const int s_b = item.state;
-    const int n_path = 2 * (int)level_dev[s_b];
+    const int s_b = bucket_lo[item.bucket];        // first state id of the group (terminal buckets: the upper state; no rows below)
+    const int n_path = bucket_path[item.bucket];   // env steps above the group: upper states shared by every lane of the bucket
     constexpr int RS = kRowStride<A>;
-    const int n_tab = (2 * k + 2 * sub_rows) * (A + 1);
+    const int n_tab = (item.bucket < n_groups ? kMaxPath + 2 * sub_rows : n_path) * (A + 1);
     for (int i = threadIdx.x; i < n_tab; i += kThreads) tab[i] = 0ull;
     __syncthreads();
     const VtHp vh{-hp.eta, hp.lambda_, hp.c, hp.rho, hp.gamma};
@@ -520,7 +603,7 @@ __global__ __launch_bounds__(kThreads) void k_bucket_learn(int T, int64_t B, int
                     if ((threadIdx.x & 63) == 63 && s != 0) atomicAdd(&tab[t * (A + 1) + a], (unsigned long long)s);
                 }
             } else if (valid) {
-                unsigned long long *dst = tab + ((int64_t)(2 * k + P * sub_rows + (state - s_b))) * (A + 1);
+                unsigned long long *dst = tab + ((int64_t)(kMaxPath + P * sub_rows + (state - s_b))) * (A + 1);
 #pragma unroll
                 for (int a = 0; a <= A; ++a) atomicAdd(dst + a, (unsigned long long)q[a]);
             }
@@ -549,14 +632,15 @@ __global__ __launch_bounds__(kThreads) void k_bucket_learn(int T, int64_t B, int
         const unsigned long long x = tab[e];
         if (x != 0ull) {
             const int t = e / (A + 1), a = e % (A + 1);
-            const int64_t slot = order_pos[path_state[t]];
-            atomicAdd(rep + (((int64_t)(blockIdx.x & (kReplicas - 1)) * 2 + (t & 1)) * n_upper + slot) * (A + 1) + a, x);  // n_upper >= 1 here
+            const int64_t slot = bucket_of[path_state[t]] - n_groups;  // path states are upper states
+            atomicAdd(rep + (((int64_t)(blockIdx.x & (kReplicas - 1)) * 2 + (t & 1)) * up_stride + slot) * (A + 1) + a, x);
         }
     }
     // rows of the bucket's own subtree: this workgroup owns them unless the bucket was split over several items
+    if (item.bucket >= n_groups) return;  // terminal bucket: every step was a path step
     const int64_t end = S - s_b < sub_rows ? S - s_b : sub_rows;
     for (int e = threadIdx.x; e < 2 * sub_rows * (A + 1); e += kThreads) {
-        const unsigned long long x = tab[2 * k * (A + 1) + e];
+        const unsigned long long x = tab[kMaxPath * (A + 1) + e];
         if (x != 0ull) {
             const int P = e / (sub_rows * (A + 1)), r = e % (sub_rows * (A + 1));
             if (r / (A + 1) < end) {
@@ -571,14 +655,14 @@ __global__ __launch_bounds__(kThreads) void k_bucket_learn(int T, int64_t B, int
 // Rows above the buckets: the kReplicas copies of a row are read by the 64 lanes of ONE wave (lane c: replica c), summed on the
 // DPP network and added into acc; the copies are cleared for the next update.  grid = ceil(2 * n_upper / 4) workgroups of 4 waves.
 template <int A>
-__global__ __launch_bounds__(kThreads) void k_bucket_upper(int64_t S, int n_upper, const int32_t *__restrict__ level_order,
+__global__ __launch_bounds__(kThreads) void k_bucket_upper(int64_t S, int n_upper, const int32_t *__restrict__ upper_list,
                                                            unsigned long long *__restrict__ acc, unsigned long long *__restrict__ rep) {
     static_assert(kReplicas == 64, "one replica per lane");
     const int u = blockIdx.x * (kThreads / 64) + (threadIdx.x >> 6), c = threadIdx.x & 63;
     if (u >= 2 * n_upper) return;
     const int P = u / n_upper, pos = u % n_upper;
     unsigned long long *src = rep + (((int64_t)c * 2 + P) * n_upper + pos) * (A + 1);
-    unsigned long long *dst = acc + ((int64_t)P * S + level_order[pos]) * (A + 1);
+    unsigned long long *dst = acc + ((int64_t)P * S + upper_list[pos]) * (A + 1);
 #pragma unroll
     for (int a = 0; a <= A; ++a) {
         const unsigned long long v = src[a];
@@ -644,19 +728,29 @@ extern "C" int rnad_bucket_plan(const rnad_tree_t *tree, int64_t B, int64_t *out
         return 3;
     }
     const int64_t A1 = tree->A + 1;
-    out[0] = p.k;
-    out[1] = p.n_buckets;
-    out[2] = p.n_upper;
-    out[3] = p.sub_rows;
+    const int nb = p.cut->n_buckets, nu = p.cut->n_upper;
+    out[0] = p.cut->rows;
+    out[1] = nb;
+    out[2] = nu;
+    out[3] = p.cut->n_groups;
     out[4] = p.max_items;
     // scratch of the rollout (bytes): keys [B] | hist [sort_blocks][n_buckets] | totals [n_buckets] | bucket_start [n_buckets] |
     // alive_part [blocks][T_cap + 1 <= kMaxSteps + 1] | policy [2S][A]
-    out[5] = 4 * (B + (int64_t)p.sort_blocks * p.n_buckets + 2 * (int64_t)p.n_buckets + (int64_t)blocks_for(B) * (kMaxSteps + 1) +
+    out[5] = 4 * (B + (int64_t)p.sort_blocks * nb + 2 * (int64_t)nb + (int64_t)blocks_for(B) * (kMaxSteps + 1) +
                   2 * tree->S * tree->A) + 256;
     // accumulators of the learner (bytes, must be zero before the first update): acc [2S][A+1] u64 | rep [64][2][n_upper][A+1] u64 |
     // losses_raw [4] f64 | overflow [1] i32
-    out[6] = 8 * (2 * tree->S * A1 + (int64_t)kReplicas * 2 * std::max(p.n_upper, 1) * A1 + 4) + 16;
+    out[6] = 8 * (2 * tree->S * A1 + (int64_t)kReplicas * 2 * std::max(nu, 1) * A1 + 4) + 16;
     out[7] = p.lds;
+    return 0;
+}
+
+extern "C" int rnad_bucket_map(const rnad_tree_t *tree, int64_t B, int32_t *bucket_of, int32_t *n_groups) {
+    RNAD_REQUIRE(tree && bucket_of && n_groups, "rnad_bucket_map: null argument");
+    Plan p;
+    RNAD_REQUIRE(make_plan(tree, B, p), "rnad_bucket_map: this tree / batch cannot be bucketed (see rnad_bucket_plan)");
+    std::copy(p.cut->host_bucket_of.begin(), p.cut->host_bucket_of.end(), bucket_of);
+    *n_groups = p.cut->n_groups;
     return 0;
 }
 
@@ -669,9 +763,9 @@ Scratch carve_scratch(void *ws, int64_t B, const Plan &p) {
     Scratch s;
     s.keys = (int32_t *)ws;
     s.hist = s.keys + B;
-    s.totals = s.hist + (int64_t)p.sort_blocks * p.n_buckets;
-    s.bucket_start = s.totals + p.n_buckets;
-    s.alive_part = s.bucket_start + p.n_buckets;
+    s.totals = s.hist + (int64_t)p.sort_blocks * p.cut->n_buckets;
+    s.bucket_start = s.totals + p.cut->n_buckets;
+    s.alive_part = s.bucket_start + p.cut->n_buckets;
     s.policy = (float *)(s.alive_part + (int64_t)blocks_for(B) * (kMaxSteps + 1));
     return s;
 }
@@ -725,7 +819,7 @@ extern "C" int rnad_rollout_bucketed(const rnad_tree_t *tree, const rnad_traj_t 
     hipStream_t stream = (hipStream_t)stream_;
     const int64_t B = tr->B, S = tree->S;
     const Scratch s = carve_scratch(scratch, B, p);
-    const int n_steps = std::min(2 * p.k, (int)tr->T_cap);
+    const int n_steps = std::min(p.cut->max_path, (int)tr->T_cap), nb = p.cut->n_buckets;
     ProfScope prof(PROF_ACT, stream);
     const float *policy_tab = table;
     int64_t policy_stride = table_stride;
@@ -738,18 +832,18 @@ extern "C" int rnad_rollout_bucketed(const rnad_tree_t *tree, const rnad_traj_t 
     {
         ProfScope one(PROF_BUCKET_KEYS, stream);
         RNAD_DISPATCH_A(tree->A, hipLaunchKernelGGL((k_bucket_keys<kA>), dim3(blocks_for(B)), dim3(kThreads), 0, stream, tree->trans, tree->C,
-                                                    S, B, n_steps, policy_tab, policy_stride, (const int32_t *)tree->order_pos, seed,
-                                                    device_params, lane0, s.keys));
+                                                    S, B, n_steps, policy_tab, policy_stride, (const int32_t *)p.cut->bucket_of,
+                                                    p.cut->n_groups, seed, device_params, lane0, s.keys));
     }
-    const size_t lds = (size_t)p.n_buckets * sizeof(int32_t);
+    const size_t lds = (size_t)nb * sizeof(int32_t);
     {
         ProfScope sort_passes(PROF_BUCKET_SORT, stream);
-    hipLaunchKernelGGL(k_bucket_hist, dim3(p.sort_blocks), dim3(kSortThreads), lds, stream, B, p.n_buckets, (const int32_t *)s.keys, s.hist);
-    hipLaunchKernelGGL(k_bucket_scan, dim3((p.n_buckets + 63) / 64), dim3(kSortThreads), 0, stream, p.sort_blocks, p.n_buckets, s.hist,
+    hipLaunchKernelGGL(k_bucket_hist, dim3(p.sort_blocks), dim3(kSortThreads), lds, stream, B, nb, (const int32_t *)s.keys, s.hist);
+    hipLaunchKernelGGL(k_bucket_scan, dim3((nb + 63) / 64), dim3(kSortThreads), 0, stream, p.sort_blocks, nb, s.hist,
                        s.totals);
-    hipLaunchKernelGGL(k_bucket_items, dim3(1), dim3(kSortThreads), 0, stream, p.n_buckets, p.chunk, (const int32_t *)s.totals,
-                       (const int32_t *)tree->level_order, s.bucket_start, (Item *)items, n_items);
-    hipLaunchKernelGGL(k_bucket_scatter, dim3(p.sort_blocks), dim3(kSortThreads), lds, stream, B, p.n_buckets, (const int32_t *)s.keys,
+    hipLaunchKernelGGL(k_bucket_items, dim3(1), dim3(kSortThreads), 0, stream, nb, p.chunk, (const int32_t *)s.totals, s.bucket_start,
+                       (Item *)items, n_items);
+    hipLaunchKernelGGL(k_bucket_scatter, dim3(p.sort_blocks), dim3(kSortThreads), lds, stream, B, nb, (const int32_t *)s.keys,
                        (const int32_t *)s.hist, (const int32_t *)s.bucket_start, lane_ids);
     }
     RNAD_HIP_OK(hipGetLastError());
@@ -782,7 +876,8 @@ extern "C" int rnad_learn_bucketed(const rnad_tree_t *tree, int T, int64_t B, co
     const int64_t S = tree->S, A1 = tree->A + 1;
     unsigned long long *acc = (unsigned long long *)accumulators;
     unsigned long long *rep = acc + 2 * S * A1;
-    double *losses_raw = (double *)(rep + (int64_t)kReplicas * 2 * std::max(p.n_upper, 1) * A1);
+    const int nu = p.cut->n_upper;
+    double *losses_raw = (double *)(rep + (int64_t)kReplicas * 2 * std::max(nu, 1) * A1);
     int32_t *overflow = (int32_t *)(losses_raw + 4);
     const FixedPoint fx = fixed_point_for(*hp);
     RNAD_HIP_OK(hipMemsetAsync(losses_raw, 0, 4 * sizeof(double) + sizeof(int32_t), stream));  // loss sums and the overflow flag
@@ -791,9 +886,10 @@ extern "C" int rnad_learn_bucketed(const rnad_tree_t *tree, int T, int64_t B, co
     do {                                                                                                                              \
         auto kern = k_bucket_learn<kA>;                                                                                               \
         if (p.lds > 48 * 1024) RNAD_HIP_OK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, p.lds)); \
-        hipLaunchKernelGGL(kern, dim3((unsigned)p.max_items), dim3(kThreads), (size_t)p.lds, stream, T, B, S, p.k, p.sub_rows,        \
-                           std::max(p.n_upper, 1), (const Item *)items, n_items, (const uint8_t *)tree->level_dev,                    \
-                           (const int32_t *)tree->order_pos, indices, actions, rewards, mu, records, *hp, fx, acc, rep,               \
+        hipLaunchKernelGGL(kern, dim3((unsigned)p.max_items), dim3(kThreads), (size_t)p.lds, stream, T, B, S, p.cut->rows,            \
+                           p.cut->n_groups, std::max(nu, 1), (const Item *)items, n_items, (const int32_t *)p.cut->bucket_of,         \
+                           (const int32_t *)p.cut->bucket_lo, (const int32_t *)p.cut->bucket_path, indices, actions, rewards, mu,     \
+                           records, *hp, fx, acc, rep,                                                                                \
                            losses ? losses_raw : (double *)nullptr, overflow);                                                        \
     } while (0)
     {
@@ -803,9 +899,9 @@ extern "C" int rnad_learn_bucketed(const rnad_tree_t *tree, int T, int64_t B, co
 #undef RNAD_BUCKET_LEARN
     RNAD_HIP_OK(hipGetLastError());
     ProfScope fin(PROF_BUCKET_FINISH, stream);
-    if (p.n_upper > 0)
-        RNAD_DISPATCH_A(tree->A, hipLaunchKernelGGL((k_bucket_upper<kA>), dim3(blocks_for(2 * (int64_t)p.n_upper, kThreads / 64)), dim3(kThreads),
-                                                    0, stream, S, p.n_upper, (const int32_t *)tree->level_order, acc, rep));
+    if (nu > 0)
+        RNAD_DISPATCH_A(tree->A, hipLaunchKernelGGL((k_bucket_upper<kA>), dim3(blocks_for(2 * (int64_t)nu, kThreads / 64)), dim3(kThreads), 0,
+                                                    stream, S, nu, (const int32_t *)p.cut->upper_list, acc, rep));
     RNAD_DISPATCH_A(tree->A, hipLaunchKernelGGL((k_bucket_finish<kA>), dim3(blocks_for(2 * S)), dim3(kThreads), 0, stream, S, acc, norm,
                                                 hp->w_v, hp->w_n, fx, (const int32_t *)overflow, (const double *)losses_raw, losses,
                                                 dlogit_tab, dv_tab));

@@ -7,6 +7,7 @@
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <map>
 #include <string>
 #include <vector>
 
@@ -73,6 +74,19 @@ struct ProfScope {
 
 }  // namespace rnad
 
+// One partition of the tree into bucket subtrees (bucket.hip, "cut by subtree size"): states whose subtree holds more than `rows`
+// states are UPPER; the non-upper children of an upper state, packed into runs of consecutive siblings spanning at most `rows`
+// state ids, are the GROUPS.  Bucket ids: groups 0 .. n_groups - 1, then one terminal bucket per upper state (lanes that leave
+// the tree from it).  Built on the host on first use for a given `rows` and kept with the tree handle.
+struct BucketCut {
+    int rows = 0, n_groups = 0, n_upper = 0, n_buckets = 0, max_path = 0;
+    int32_t *bucket_of = nullptr;    // device [S]: bucket of a state (group for every state of a group's id range, n_groups + slot for upper states, -1 else)
+    int32_t *bucket_lo = nullptr;    // device [n_buckets]: first state id of the group / the upper state itself
+    int32_t *bucket_path = nullptr;  // device [n_buckets]: env steps a lane of the bucket spends above the group (terminal buckets: all of them)
+    int32_t *upper_list = nullptr;   // device [max(n_upper, 1)]: the upper states in slot order
+    std::vector<int32_t> host_bucket_of;  // the same map on the host (rnad_bucket_map: tests and tools)
+};
+
 struct rnad_tree {
     int64_t S = 0;
     int C = 0, A = 0, NS = 0, device = 0, max_depth = 0;
@@ -94,6 +108,10 @@ struct rnad_tree {
     uint8_t *mask_tab = nullptr;         // device [2][S]: the mover's legal-action bits at (player to move, state) (episode.py:208)
     std::vector<int64_t> level_max_subtree;  // host [n_levels]: largest subtree (states, the root of it included) below a state of that level
     bool contiguous_subtrees = false;    // ids are DFS pre-order: the subtree of s is exactly [s, s + size(s))  (tree.py:311-330)
+    std::vector<int32_t> subtree_size;   // host [S]: states in the subtree of s, s included (0: unreachable / state 0)
+    std::vector<int64_t> child_offsets;  // host CSR of the live children (index != 0, chance > 0) of every state, ascending ids
+    std::vector<int32_t> children;
+    mutable std::map<int, BucketCut> cuts;  // by rows; handles are used from one host thread (include/rnad_hip.h)
     size_t bytes = 0;
 };
 

@@ -221,6 +221,29 @@ extern "C" int rnad_tree_create(rnad_tree_t **out, int64_t S, int C, int A, cons
             if (end[(size_t)s] - s != 1 + desc[(size_t)s]) contiguous = false;
         }
         tree->contiguous_subtrees = contiguous;
+        tree->subtree_size.assign((size_t)S, 0);
+        tree->child_offsets.assign((size_t)S + 1, 0);
+        for (int64_t s = 1; s < S; ++s) {
+            if (tree->level_of[s] >= 0) tree->subtree_size[(size_t)s] = (int32_t)(1 + desc[(size_t)s]);
+            int64_t n = 0;
+            if (tree->level_of[s] >= 0)
+                for (int k = 0; k < AA * C; ++k) {
+                    const Trans &e = trans[(size_t)s * AA * C + k];
+                    n += (e.next != 0 && e.chance > 0.0f) ? 1 : 0;
+                }
+            tree->child_offsets[(size_t)s + 1] = n;
+        }
+        for (int64_t s = 0; s < S; ++s) tree->child_offsets[(size_t)s + 1] += tree->child_offsets[(size_t)s];
+        tree->children.resize((size_t)tree->child_offsets[(size_t)S]);
+        for (int64_t s = 1; s < S; ++s) {
+            if (tree->level_of[s] < 0) continue;
+            int64_t w = tree->child_offsets[(size_t)s];
+            for (int k = 0; k < AA * C; ++k) {
+                const Trans &e = trans[(size_t)s * AA * C + k];
+                if (e.next != 0 && e.chance > 0.0f) tree->children[(size_t)w++] = e.next;
+            }
+            std::sort(tree->children.begin() + tree->child_offsets[(size_t)s], tree->children.begin() + w);
+        }
         tree->level_max_subtree.assign((size_t)tree->n_levels, 1);
         for (int64_t s = 1; s < S; ++s)
             if (tree->level_of[s] >= 0)
@@ -247,6 +270,13 @@ extern "C" void rnad_tree_destroy(rnad_tree_t *tree) {
     if (tree->order_pos) (void)hipFree(tree->order_pos);
     if (tree->level_dev) (void)hipFree(tree->level_dev);
     if (tree->mask_tab) (void)hipFree(tree->mask_tab);
+    for (auto &kv : tree->cuts) {
+        BucketCut &c = kv.second;
+        if (c.bucket_of) (void)hipFree(c.bucket_of);
+        if (c.bucket_lo) (void)hipFree(c.bucket_lo);
+        if (c.bucket_path) (void)hipFree(c.bucket_path);
+        if (c.upper_list) (void)hipFree(c.upper_list);
+    }
     delete tree;
 }
 

@@ -632,7 +632,7 @@ class RNaD:
                 self.batch_size, self.tabular, getattr(self, "tabular_gate", 8), self.eta, self.beta, self.neurd_clip, self.grad_clip,
                 self.c_bar, self.roh_bar, self.vtrace_gamma, self.value_weight, self.neurd_weight, self.epsilon_threshold, self.n_discrete,
                 self.gamma_averaging, getattr(self, "obs_half", False), getattr(self, "store_actor_values", False),
-                os.environ.get("RNAD_BUCKET_LEVEL"))
+                os.environ.get("RNAD_BUCKET_ROWS"), os.environ.get("RNAD_BUCKET_CHUNK"))
 
     def _graph_step(self, buffer, alpha):
         g = getattr(self, "_graph", None)

@@ -572,7 +572,7 @@ class BucketPlan:
 
     def __init__(self, tree, B, out):
         self.B = B
-        self.k, self.n_buckets, self.n_upper, self.sub_rows, self.max_items, self.scratch_bytes, self.acc_bytes, self.lds = (int(x) for x in out)
+        self.rows, self.n_buckets, self.n_upper, self.n_groups, self.max_items, self.scratch_bytes, self.acc_bytes, self.lds = (int(x) for x in out)
         dev = tree.device
         self.scratch = torch.empty((self.scratch_bytes // 4 + 1,), dtype=I32, device=dev)
         self.accumulators = torch.zeros((self.acc_bytes // 8 + 1,), dtype=torch.int64, device=dev)
@@ -581,12 +581,20 @@ class BucketPlan:
 def bucket_plan(tree, B):
     """The BucketPlan of (tree, B) (cached on the tree handle), or None when this tree / batch cannot be bucketed."""
     cache = tree.__dict__.setdefault("_bucket_plans", {})
-    key = (B, os.environ.get("RNAD_BUCKET_LEVEL"), os.environ.get("RNAD_BUCKET_CHUNK"))  # the tuning overrides of csrc/bucket.hip
+    key = (B, os.environ.get("RNAD_BUCKET_ROWS"), os.environ.get("RNAD_BUCKET_CHUNK"))  # the tuning overrides of csrc/bucket.hip
     if key not in cache:
         out = (C.c_int64 * 8)()
         rc = lib().rnad_bucket_plan(tree.ptr, B, out)
         cache[key] = BucketPlan(tree, B, list(out)) if rc == 0 else None
     return cache[key]
+
+
+def bucket_map(tree, B):
+    """(bucket_of int32 [S] CPU tensor, n_groups): the bucket of every state under the plan of (tree, B) (rnad_bucket_map)."""
+    out = torch.empty((tree.S,), dtype=I32)
+    n_groups = C.c_int32()
+    _check(lib().rnad_bucket_map(tree.ptr, B, C.c_void_p(out.data_ptr()), C.byref(n_groups)))
+    return out, n_groups.value
 
 
 class Buckets:

@@ -28,22 +28,22 @@ TREES = {
 }
 
 
-def _levels(tree):
-    """level_order / order_pos exactly as rnad_tree_create builds them: states grouped by depth, ascending id within a depth."""
-    index = tree.index_tensor.cpu().numpy()
-    chance = tree.chance_tensor.cpu().numpy()
-    S = index.shape[0]
-    level = np.full(S, -1, np.int64)
-    level[1] = 0
-    for s in range(1, S):
-        if level[s] < 0:
-            continue
-        nxt = index[s][(index[s] != 0) & (chance[s] > 0)]
-        level[nxt] = level[s] + 1
-    order = np.concatenate([np.flatnonzero(level == l) for l in range(level.max() + 1)])
-    pos = np.full(S, -1, np.int64)
-    pos[order] = np.arange(order.size)
-    return level, order, pos
+def _keys_of(tree, B, idx, last):
+    """Bucket of every lane from its recorded states: the first state on its path that lies in a group, or -- if it leaves the tree
+    before reaching one -- the terminal bucket of its last (upper) state.  idx [T, B] states at the start of each step, last [B]."""
+    import rnad_hip
+
+    bucket_of, n_groups = rnad_hip.bucket_map(tree.handle(), B)
+    bucket_of = bucket_of.numpy().astype(np.int64)
+    states = np.concatenate([idx, last[None]], 0)
+    key = bucket_of[states[0]]
+    done = key < n_groups
+    for t in range(1, states.shape[0]):
+        st = states[t]
+        upd = (~done) & (st != 0)
+        key = np.where(upd, bucket_of[st], key)
+        done |= key < n_groups
+    return key, n_groups
 
 
 @pytest.mark.parametrize("name", sorted(TREES))
@@ -75,23 +75,18 @@ def test_bucketed_rollout_is_the_lane_ordered_rollout(name, B):
     again = Episodes(tree, B, seed=77, lane_offset=1000)
     again.generate(net, tabular=True, bucketed=True, trim=False)
     assert torch.equal(again.lane_ids, buc.lane_ids) and torch.equal(again.indices, buc.indices)
-    # bucket structure: stable sort by the state reached at depth k (or the last live state before it)
-    level, order, pos = _levels(tree)
-    idx = nat.indices.cpu().numpy()
-    n_steps = min(2 * plan.k, idx.shape[0])
-    key = np.ones(B, np.int64)
-    for t in range(n_steps + 1):
-        st = idx[t] if t < idx.shape[0] else nat.states.indices.cpu().numpy()
-        key = np.where(st != 0, st, key)
-    want = np.argsort(pos[key], kind="stable")
+    # bucket structure: stable sort by the group reached (or the upper state the lane ends in)
+    key, n_groups = _keys_of(tree, B, nat.indices.cpu().numpy(), nat.states.indices.cpu().numpy())
+    assert n_groups == plan.n_groups and key.max() < plan.n_buckets
+    want = np.argsort(key, kind="stable")
     np.testing.assert_array_equal(buc.lane_ids.cpu().numpy(), want)
     items = buc.buckets.items.cpu().numpy()[: int(buc.buckets.n_items.item())]
     assert items[:, 1].sum() == B and (items[:, 1] > 0).all() and (items[:, 1] <= 256).all()
     np.testing.assert_array_equal(items[:, 0], np.concatenate([[0], np.cumsum(items[:, 1])[:-1]]))
     sorted_keys = key[want]
-    for begin, count, state, single in items:
-        assert (sorted_keys[begin: begin + count] == state).all()
-        assert bool(single) == ((sorted_keys == state).sum() <= 256)
+    for begin, count, bucket, single in items:
+        assert (sorted_keys[begin: begin + count] == bucket).all()
+        assert bool(single) == ((sorted_keys == bucket).sum() <= 256)
 
 
 def _four_nets(A, W, seed):
@@ -179,12 +174,9 @@ def _bucketize(G, tree, ep):
     B = ep.batch_size
     plan = rnad_hip.bucket_plan(h, B)
     assert plan is not None
-    level, order, pos = _levels(tree)
     idx = ep.indices.cpu().numpy()
-    key = np.ones(B, np.int64)
-    for t in range(min(2 * plan.k, idx.shape[0] - 1) + 1):
-        key = np.where(idx[t] != 0, idx[t], key)
-    perm = np.argsort(pos[key], kind="stable")
+    key, _ = _keys_of(tree, B, idx, np.zeros(B, idx.dtype))
+    perm = np.argsort(key, kind="stable")
     out = type(ep)(tree, B, seed=0)
     out.t_eff, out.finished = ep.t_eff, True
     sel = torch.as_tensor(perm, device=DEV)
@@ -208,12 +200,12 @@ def _bucketize(G, tree, ep):
     return out
 
 
-@pytest.mark.parametrize("level", (None, 0, 1, 2))
+@pytest.mark.parametrize("level", (None, 1000, 40, 8, 2))
 @pytest.mark.parametrize("name", ("c1_eta0.2", "small_eta0", "small_eta0.2", "ragged_eta0.5", "a5_eta0.2"))
 def test_bucketed_update_gives_the_reference_parameter_gradients(name, level, monkeypatch):
     """RNaD.__learn in its default mode on the reference's own recorded episodes (bucketised on the host) -> the reference's
     parameter gradients and losses (tests/golden/learn_*.npz), at the tolerance the dense mode is held to.  level: the
-    partition depth the planner would pick for these small batches (None), or a forced one (buckets at every depth)."""
+    table size the planner would pick for these small batches (None), or a forced one (cuts at every depth of the tree)."""
     import _gpu as G
     import rnad_hip
     from learn.rnad import RNaD
@@ -222,9 +214,9 @@ def test_bucketed_update_gives_the_reference_parameter_gradients(name, level, mo
     g, ro, hp, clip, thr = _learn(name)
     tree, _ = G.golden_tree(name.split("_")[0])
     if level is not None:
-        monkeypatch.setenv("RNAD_BUCKET_LEVEL", str(level))
+        monkeypatch.setenv("RNAD_BUCKET_ROWS", str(level))
         if rnad_hip.bucket_plan(tree.handle(), ro["indices"].shape[1]) is None:
-            pytest.skip(f"partition depth {level} does not exist / fit on this tree")
+            pytest.skip(f"a table of {level} rows does not fit the LDS with A = {tree.max_actions}")
     A = tree.max_actions
     rn = RNaD.__new__(RNaD)
     rn.tree, rn.device = tree, G.DEV
