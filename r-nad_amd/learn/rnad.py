@@ -611,8 +611,10 @@ class RNaD:
     _GRAPH_WARMUP = 3  # eager steps before capture: code objects loaded, allocator pools and the table caches exist
 
     def _graph_eligible(self, buffer, log):
-        if not getattr(self, "use_graph", True) or log is not None or self.reuse_actor_outputs or _dist_on():
+        if not getattr(self, "use_graph", True) or log is not None or self.reuse_actor_outputs:
             return False
+        if _dist_on() and (dist.get_backend() != "nccl" or os.environ.get("RNAD_GRAPH_DIST", "1") == "0"):
+            return False  # RCCL collectives are captured with the step (torch's NCCL backend supports stream capture); gloo cannot be
         dev = self.device if isinstance(self.device, torch.device) else torch.device(self.device)
         if dev.type != "cuda" or self.buffer_mod != 1 or buffer.max_size != 1:
             return False
@@ -620,7 +622,8 @@ class RNaD:
         if g is not None and g.get("failed"):
             return False
         handle = self.tree.handle()
-        if self._tabular_mode(2 * handle.max_depth, self.batch_size) is not True or rnad_hip.bucket_plan(handle, self.batch_size) is None:
+        local_batch = self.batch_size // self._world
+        if self._tabular_mode(2 * handle.max_depth, local_batch) is not True or rnad_hip.bucket_plan(handle, local_batch) is None:
             return False
         if not getattr(self.optimizer, "defaults", {}).get("capturable", False):
             return False

@@ -108,3 +108,48 @@ def test_one_rank_rccl_group_runs_every_collective_of_the_update(tmp_path):
     n_ar = sum(1 for ln in text.splitlines() if "AllReduce" in ln and "opCount" in ln)
     n_bc = sum(1 for ln in text.splitlines() if "Broadcast" in ln and "opCount" in ln)
     assert n_ar >= 3 and n_bc >= 9, f"RCCL logged {n_ar} AllReduce / {n_bc} Broadcast operations:\n{text[-2000:]}"
+
+
+def _nccl_graph(rank, port, tmp):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0", RNAD_SAVE_DIR=os.path.join(tmp, "g"))
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+    try:
+        from environment.episode import Buffer
+        from environment.tree import Tree
+        from learn.rnad import RNaD
+
+        dev = torch.device("cuda:0")
+        tree = Tree(device=dev, max_actions=3, max_transitions=1, depth_bound=4)
+        tree.generate_native(seed=0)
+        out = {}
+        for use_graph in (False, True):
+            torch.manual_seed(SEED)
+            rn = RNaD(tree=tree, device=dev, directory_name=f"g{int(use_graph)}", batch_size=1 << 14, eta=0.2, b1_adam=0.0, lr=1e-3,
+                      net_params={"type": "MLP", "max_actions": 3, "width": 64})
+            rn.initialize()
+            rn.use_graph = use_graph
+            buf = Buffer(1)
+            for i in range(8):
+                rn.train_step(buf, alpha=0.1 * i)
+                rn.total_steps += 1
+            torch.cuda.synchronize()
+            out[use_graph] = [p.detach().cpu().numpy() for p in rn.net.parameters()]
+            if use_graph:
+                g = getattr(rn, "_graph", None)
+                out["captured"] = bool(g and g.get("graph") is not None and not g.get("failed"))
+        np.savez(os.path.join(tmp, "nccl_graph.npz"), captured=out["captured"], **{f"e{i}": a for i, a in enumerate(out[False])},
+                 **{f"g{i}": a for i, a in enumerate(out[True])})
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_graph_replay_with_rccl_collectives_inside(tmp_path):
+    """Data-parallel steps are captured too: the normaliser and gradient all-reduces (RCCL) become nodes of the step's hipGraph.
+    One rank here (one GPU on the box): the replayed steps must equal the eager ones bit for bit."""
+    mp.spawn(_nccl_graph, args=(_free_port(), str(tmp_path)), nprocs=1, join=True)
+    got = np.load(tmp_path / "nccl_graph.npz")
+    assert bool(got["captured"]), "the step with RCCL collectives inside must have been captured"
+    for i in range(8):
+        np.testing.assert_array_equal(got[f"e{i}"], got[f"g{i}"])

@@ -1,2 +1,1 @@
-tools/step_sweep.sh
-tools/step_sweep.sh --batch-log2 17
+timeout 600 python -m pytest tests/test_hip_distributed.py -m gpu -x -q 2>&1 | tail -25
