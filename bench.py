@@ -146,7 +146,16 @@ def main():
     for _ in range(args.warmup):
         one_step()
     # ---- timed region: EXACTLY --steps steps between two fences
-    elapsed, host_s = timed(args.steps)
+    elapsed, _ = timed(args.steps)
+    # host cost of enqueueing one step, measured with the queue kept short (a long un-synchronised run measures back-pressure)
+    host_s, host_n = 0.0, min(64, args.steps)
+    for i in range(host_n):
+        h0 = time.perf_counter()
+        one_step()
+        host_s += time.perf_counter() - h0
+        if i % 4 == 3:
+            torch.cuda.synchronize()
+    fence()
     graph_state = getattr(rn, "_graph", None)
     replayed = bool(graph_state and graph_state.get("graph") is not None)
     T = rn.last_episodes.t_eff + 1
@@ -259,7 +268,7 @@ def main():
                 "parallelism": f"dp{world} (episodes sharded, RCCL all-reduce of 2 normalisers + 43 KB grads)",
             },
             "updates_per_sec": args.steps / elapsed,
-            "host_enqueue_ms_per_step": host_s / args.steps * 1e3,
+            "host_enqueue_ms_per_step": host_s / host_n * 1e3,
             "net_evaluation": {"mode": f"RNaD.tabular = {default_mode!r}" + (" (default)" if args.net_mode == "default" else ""),
                                "in_effect": repr(mode_now), "what": what[mode_now],
                                "step_replayed_from_hipGraph": replayed,

@@ -332,7 +332,8 @@ int rnad_learn_fused_gather(const rnad_tree_t *tree, int T, int64_t B, const int
  * id lane0 + lane, hence the same episodes bit for bit -- with column j of every [T_cap, B] buffer holding lane lane_ids[j]
  * (a stable sort of the lanes by bucket).  traj->observations is not written (may be NULL; an observation is a function of
  * (t & 1, indices[t]): rnad_observe), traj->values only if non-NULL (value_table NULL: zeros).  items / n_items: the learner's
- * work list.  T_cap <= 64, B <= 2^22.
+ * work list.  norm (optional, device f64[2]): the loss normalisers N_P = number of live slots of parity P (learn/vtrace.py:373,388).
+ * T_cap <= 64, B <= 2^22.
  *
  * rnad_bucket_records: one record per (player, state) row from the five [2S, .] net-output tables of a tabular update, holding
  * everything of learn/rnad.py:373-382 that depends on the row alone (rnad_bucket_record_stride(A) floats, 16-byte aligned):
@@ -359,7 +360,7 @@ int rnad_bucket_map(const rnad_tree_t *tree, int64_t B, int32_t *bucket_of, int3
 int rnad_rollout_bucketed(const rnad_tree_t *tree, const rnad_traj_t *traj, const float *table, int64_t table_stride,
                           int table_is_policy, const float *value_table, int64_t value_stride, uint64_t seed, int64_t lane0,
                           const rnad_step_params_t *device_params, void *scratch, int32_t *lane_ids, int32_t *items, int32_t *n_items,
-                          void *stream);
+                          double *norm, void *stream);
 int64_t rnad_bucket_record_stride(int A);
 int rnad_bucket_records(const rnad_tree_t *tree, const float *logit_tab, const float *v_tab, const float *v_target_tab,
                         const float *logit_reg_tab, const float *logit_reg_tab_, const rnad_learn_params_t *hp,

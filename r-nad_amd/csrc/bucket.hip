@@ -167,6 +167,26 @@ bool make_plan(const rnad_tree_t *tree, int64_t B, Plan &p) {
     return true;
 }
 
+// Sum over the 64 lanes of a wave in integer arithmetic on the VALU's data-parallel primitives (no LDS traffic): an inclusive
+// scan within each row of 16 lanes (row_shr 1, 2, 4, 8), then row 15 -> next row (row_bcast15) and lane 31 -> rows 2, 3
+// (row_bcast31); lane 63 ends up with the total.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ long long dpp_moved(long long v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(unsigned)(unsigned long long)v, CTRL, ROW_MASK, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(unsigned)((unsigned long long)v >> 32), CTRL, ROW_MASK, 0xf, false);
+    return (long long)(((unsigned long long)(unsigned)hi << 32) | (unsigned long long)(unsigned)lo);
+}
+
+__device__ __forceinline__ long long wave_total_in_lane63(long long v) {
+    v += dpp_moved<0x111, 0xf>(v);  // row_shr:1
+    v += dpp_moved<0x112, 0xf>(v);  // row_shr:2
+    v += dpp_moved<0x114, 0xf>(v);  // row_shr:4
+    v += dpp_moved<0x118, 0xf>(v);  // row_shr:8
+    v += dpp_moved<0x142, 0xa>(v);  // row_bcast15 into rows 1 and 3
+    v += dpp_moved<0x143, 0xc>(v);  // row_bcast31 into rows 2 and 3
+    return v;
+}
+
 // ---------------------------------------------------------------------------------------- 0. per-row tables
 // Everything of the rollout and of the update that depends on the (player, state) row alone is evaluated once per row (2S rows)
 // instead of once per slot (T * B): same functions on the same inputs, hence the same bits.
@@ -462,46 +482,31 @@ __global__ __launch_bounds__(kThreads) void k_bucket_rollout(const Trans *__rest
     }
 }
 
-// alive[t] = sum over the blocks of alive_part[block][t].  grid = T_cap + 1 workgroups.
+// alive[t] = sum over the blocks of alive_part[block][t], and norm[P] = sum of alive[t] over the steps of parity P: the loss
+// normalisers N_P of learn/vtrace.py:373,388 (f64, what RNaD all-reduces over the ranks).  ONE workgroup: wave w takes the steps
+// t = w, w + 4, ...
 __global__ __launch_bounds__(kThreads) void k_bucket_alive(int n_blocks, int T1, const int32_t *__restrict__ alive_part,
-                                                           int32_t *__restrict__ alive) {
-    const int t = blockIdx.x;
-    int32_t s = 0;
-    for (int r = threadIdx.x; r < n_blocks; r += kThreads) s += alive_part[(int64_t)r * T1 + t];
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
-    __shared__ int32_t part[kThreads / 64];
-    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+                                                           int32_t *__restrict__ alive, double *__restrict__ norm) {
+    __shared__ long long per_step[kMaxSteps + 1];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int t = wave; t < T1; t += kThreads / 64) {
+        long long s = 0;
+        for (int r = lane; r < n_blocks; r += 64) s += alive_part[(int64_t)r * T1 + t];
+        s = wave_total_in_lane63(s);
+        if (lane == 63) {
+            alive[t] = (int32_t)s;
+            per_step[t] = s;
+        }
+    }
     __syncthreads();
-    if (threadIdx.x == 0) {
-        int32_t x = 0;
-#pragma unroll
-        for (int w = 0; w < kThreads / 64; ++w) x += part[w];
-        alive[t] = x;
+    if (norm && threadIdx.x < 2) {
+        long long n = 0;
+        for (int t = threadIdx.x; t < T1 - 1; t += 2) n += per_step[t];  // steps 0 .. T_cap - 1 (alive[T_cap]: after the last step)
+        norm[threadIdx.x] = (double)n;
     }
 }
 
 // ---------------------------------------------------------------------------------------- 4. learner
-// Sum over the 64 lanes of a wave in integer arithmetic on the VALU's data-parallel primitives (no LDS traffic): an inclusive
-// scan within each row of 16 lanes (row_shr 1, 2, 4, 8), then row 15 -> next row (row_bcast15) and lane 31 -> rows 2, 3
-// (row_bcast31); lane 63 ends up with the total.
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ long long dpp_moved(long long v) {
-    const int lo = __builtin_amdgcn_update_dpp(0, (int)(unsigned)(unsigned long long)v, CTRL, ROW_MASK, 0xf, false);
-    const int hi = __builtin_amdgcn_update_dpp(0, (int)(unsigned)((unsigned long long)v >> 32), CTRL, ROW_MASK, 0xf, false);
-    return (long long)(((unsigned long long)(unsigned)hi << 32) | (unsigned long long)(unsigned)lo);
-}
-
-__device__ __forceinline__ long long wave_total_in_lane63(long long v) {
-    v += dpp_moved<0x111, 0xf>(v);  // row_shr:1
-    v += dpp_moved<0x112, 0xf>(v);  // row_shr:2
-    v += dpp_moved<0x114, 0xf>(v);  // row_shr:4
-    v += dpp_moved<0x118, 0xf>(v);  // row_shr:8
-    v += dpp_moved<0x142, 0xa>(v);  // row_bcast15 into rows 1 and 3
-    v += dpp_moved<0x143, 0xc>(v);  // row_bcast31 into rows 2 and 3
-    return v;
-}
-
 struct FixedPoint {
     double scale_l, scale_v;  // 2^f: units per 1.0 of an addend of dL/dlogit / dL/dv
     float limit_l, limit_v;   // |addend| must stay below this (2^(62 - kLaneBits) units)
@@ -807,7 +812,7 @@ extern "C" int rnad_bucket_records(const rnad_tree_t *tree, const float *logit_t
 extern "C" int rnad_rollout_bucketed(const rnad_tree_t *tree, const rnad_traj_t *tr, const float *table, int64_t table_stride,
                                      int table_is_policy, const float *value_table, int64_t value_stride, uint64_t seed, int64_t lane0,
                                      const rnad_step_params_t *device_params, void *scratch, int32_t *lane_ids, int32_t *items,
-                                     int32_t *n_items, void *stream_) {
+                                     int32_t *n_items, double *norm, void *stream_) {
     RNAD_REQUIRE(tree && tr && table && scratch && lane_ids && items && n_items, "rnad_rollout_bucketed: null argument");
     RNAD_REQUIRE(tr->indices && tr->mask_bits && tr->policy && tr->actions && tr->rewards && tr->alive,
                  "rnad_rollout_bucketed: trajectory has a null buffer");
@@ -856,8 +861,8 @@ extern "C" int rnad_rollout_bucketed(const rnad_tree_t *tree, const rnad_traj_t 
                                                     (const int32_t *)lane_ids, tr->indices, tr->mask_bits, tr->policy, tr->actions,
                                                     tr->rewards, tr->values, s.alive_part));
     }
-    hipLaunchKernelGGL(k_bucket_alive, dim3(tr->T_cap + 1), dim3(kThreads), 0, stream, (int)grid, (int)tr->T_cap + 1,
-                       (const int32_t *)s.alive_part, tr->alive);
+    hipLaunchKernelGGL(k_bucket_alive, dim3(1), dim3(kThreads), 0, stream, (int)grid, (int)tr->T_cap + 1, (const int32_t *)s.alive_part,
+                       tr->alive, norm);
     RNAD_HIP_OK(hipGetLastError());
     return 0;
 }

@@ -39,9 +39,7 @@ class States:
     def __init__(self, tree: Tree, batch_size, seed=None, lane_offset=0):
         self.tree = tree
         self.batch_size = batch_size
-        dev = tree.device
-        self.indices = torch.ones((batch_size,), dtype=torch.int32, device=dev)
-        self.player_to_move = torch.zeros((batch_size,), dtype=torch.long, device=dev)
+        self._indices = self._player_to_move = None  # created on first use: a native rollout never touches them
         self.row_actions = None
         self.col_actions = None
         self._player = 0  # host copy: the reference itself only ever looks at player_to_move[0] (episode.py:96-98)
@@ -50,6 +48,27 @@ class States:
         self._terminal_stale = False
         self.seed = _draw_seed() if seed is None else int(seed)
         self.lane_offset = int(lane_offset)
+
+    @property
+    def indices(self):
+        """[B] int32 state ids, all at the root (1) to start with (episode.py:22)."""
+        if self._indices is None:
+            self._indices = torch.ones((self.batch_size,), dtype=torch.int32, device=self.tree.device)
+        return self._indices
+
+    @indices.setter
+    def indices(self, value):
+        self._indices = value
+
+    @property
+    def player_to_move(self):
+        if self._player_to_move is None:
+            self._player_to_move = torch.full((self.batch_size,), self._player, dtype=torch.long, device=self.tree.device)
+        return self._player_to_move
+
+    @player_to_move.setter
+    def player_to_move(self, value):
+        self._player_to_move = value
 
     @property
     def terminal(self):
@@ -85,7 +104,8 @@ class States:
             self.row_actions = None
             self.col_actions = None
         self._player = 1 - self._player
-        self.player_to_move = 1 - self.player_to_move
+        if self._player_to_move is not None:
+            self._player_to_move = 1 - self._player_to_move
         self._step += 1
         self._terminal_stale = True
         return rewards
@@ -182,6 +202,9 @@ class Episodes:
     def valid_counts(self):
         """f64 [2] on the device: number of valid steps of player 0 / player 1 (= N_P of the losses)."""
         T = self.t_eff + 1
+        traj = getattr(self, "_traj", None)
+        if self.buckets is not None and traj is not None and T == traj.T_cap:
+            return self.buckets.norm  # counted by the rollout itself (rnad_rollout_bucketed); callers must not modify it in place
         a = self.alive[:T].to(torch.float64)
         return torch.stack([a[0::2].sum(), a[1::2].sum()])
 
@@ -227,7 +250,7 @@ class Episodes:
         tree, B = self.tree, self.batch_size
         handle = tree.handle()
         T_cap = 2 * handle.max_depth if max_steps is None else int(max_steps)
-        dev = self.states.indices.device
+        dev = torch.device(tree.device)
         fast = hasattr(net, "forward_logits")
         packed = net.pack() if fast and hasattr(net, "pack") else None  # weights are fixed for the whole rollout
         net.eval()

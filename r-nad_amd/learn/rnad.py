@@ -399,7 +399,10 @@ class RNaD:
         # N_P = #(valid & turn == P): batch-global loss normalisers (vtrace.py:373,388).  Their all-reduce over the ranks is
         # issued first and overlaps the MLP forwards below (RCCL runs it on its own stream).
         norm = episodes.valid_counts
-        norm_work = dist.all_reduce(norm, async_op=True) if _dist_on() else None
+        norm_work = None
+        if _dist_on():
+            norm = norm.clone()  # the all-reduce is in place, and the episodes keep their own count
+            norm_work = dist.all_reduce(norm, async_op=True)
 
         reuse = (getattr(self, "reuse_actor_outputs", False) and getattr(episodes, "actor_logits", None) is not None
                  and getattr(episodes, "_actor_tag", None) == (id(self.net), self.total_steps)

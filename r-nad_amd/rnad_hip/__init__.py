@@ -605,6 +605,7 @@ class Buckets:
         self.lane_ids = torch.empty((plan.B,), dtype=I32, device=device)
         self.items = torch.empty((plan.max_items, 4), dtype=I32, device=device)
         self.n_items = torch.empty((1,), dtype=I32, device=device)
+        self.norm = torch.empty((2,), dtype=F64, device=device)  # N_P of the batch: live slots of parity P
 
 
 def rollout_bucketed(tree, traj, table, value_table=None, seed=0, lane0=0, table_is_policy=False, column=0, step_params=None):
@@ -621,7 +622,7 @@ def rollout_bucketed(tree, traj, table, value_table=None, seed=0, lane0=0, table
                                        _dp(value_table, F32, "value_table", True), 1, seed, lane0,
                                        _dp(step_params, torch.int64, "step_params", True), _dp(plan.scratch, I32, "scratch"),
                                        _dp(buckets.lane_ids, I32, "lane_ids"), _dp(buckets.items, I32, "items"),
-                                       _dp(buckets.n_items, I32, "n_items"), _stream()))
+                                       _dp(buckets.n_items, I32, "n_items"), _dp(buckets.norm, F64, "norm"), _stream()))
     return buckets
 
 

@@ -1,1 +1,3 @@
-timeout 600 python -m pytest tests/test_hip_distributed.py -m gpu -x -q 2>&1 | tail -25
+python -m pytest tests -m gpu -x -q 2>&1 | tail -5
+python tools/step_probe.py --steps 300
+python tools/step_probe.py --steps 300 --batch-log2 17

@@ -1,0 +1,32 @@
+#!/bin/bash
+# Everything the round's measurement row is judged on, from the CURRENT build, on the GPU box:  tools/round_artifacts.sh <tag>
+# Writes under gpurun_out/ (copy what should be kept into profiles/).
+tag=${1:-r02}
+R=${GRAFT_REPO_ROOT:-/root/repo}
+cd $R
+O=gpurun_out
+# 1. headline bench (default flags) + the per-GPU share of an 8-GPU run + configs[3] + fp16 observations
+python bench.py > $O/${tag}_bench.log 2>&1; grep '^{' $O/${tag}_bench.log | tail -1 > $O/${tag}_bench.json.log
+python bench.py --batch-log2 17 --no-cpu-baseline > $O/${tag}_bench_b17.log 2>&1; grep '^{' $O/${tag}_bench_b17.log | tail -1 > $O/${tag}_bench_b17.json.log
+python bench.py --actions 5 --transitions 4 --depth 8 --prune 7 8 --threshold 0.1 --steps 200 --no-cpu-baseline > $O/${tag}_bench_c4.log 2>&1; grep '^{' $O/${tag}_bench_c4.log | tail -1 > $O/${tag}_bench_c4.json.log
+python bench.py --obs-half --steps 500 --no-cpu-baseline > $O/${tag}_bench_half.log 2>&1; grep '^{' $O/${tag}_bench_half.log | tail -1 > $O/${tag}_bench_half.json.log
+# 2. rocprofv3 kernel trace of the same bench command
+bash tools/profile_bench.sh ${tag} --steps 300 > $O/${tag}_profile.log 2>&1
+# 3. HBM counters of the step's kernels (default mode, eager so that every launch is its own dispatch) and of K1
+K="k_bucket_learn|k_bucket_rollout|k_bucket_keys|k_bucket_scatter|k_bucket_finish|k_mlp"
+RNAD_NO_GRAPH=1 tools/pmc_run.sh ${tag}_fetch "FETCH_SIZE" "$K" -- python tools/step_probe.py --steps 20 --no-graph > /dev/null
+RNAD_NO_GRAPH=1 tools/pmc_run.sh ${tag}_write "WRITE_SIZE" "$K" -- python tools/step_probe.py --steps 20 --no-graph > /dev/null
+python tools/pmc_traffic.py $O/pmc_${tag}_fetch.csv $O/pmc_${tag}_write.csv $O/${tag}_pmc_traffic.json
+tools/pmc_run.sh ${tag}_k1_fetch "FETCH_SIZE" "k_observe|vectorized_elementwise_kernel" -- python tools/k1_pmc.py > /dev/null
+tools/pmc_run.sh ${tag}_k1_write "WRITE_SIZE" "k_observe|vectorized_elementwise_kernel" -- python tools/k1_pmc.py > /dev/null
+head -5 $O/pmc_${tag}_k1_fetch.csv $O/pmc_${tag}_k1_write.csv
+python - <<PY
+import json
+for n in ("", "_b17", "_c4", "_half"):
+    try:
+        j = json.load(open("$O/${tag}_bench%s.json.log" % n))
+        print(n or "default", "ms/step %.4f" % j["ms_per_step"], "value %.3e" % j["value"], "graph", j["net_evaluation"]["step_replayed_from_hipGraph"],
+              "roofline", j["roofline"]["kernel"], "%.3f" % (j["roofline"]["frac"] or 0))
+    except Exception as e:
+        print(n, "failed", e)
+PY

@@ -30,6 +30,7 @@ def main():
     ap.add_argument("--prune", type=int, nargs=2, default=(0, 0))
     ap.add_argument("--threshold", type=float, default=None)
     ap.add_argument("--width", type=int, default=256)
+    ap.add_argument("--no-graph", action="store_true", help="enqueue every step eagerly (one dispatch per kernel launch for the counter passes)")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     torch.cuda.set_device(0)
@@ -43,6 +44,7 @@ def main():
               net_params={"type": "MLP", "max_actions": A, "width": args.width})
     rn.initialize()
     rn.tabular = {"tabular": True, "forward": "forward", "dense": False}[args.mode]
+    rn.use_graph = not args.no_graph
     with torch.no_grad():
         for p in rn.net_reg_.parameters():
             p.mul_(1.001)
