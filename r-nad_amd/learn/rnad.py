@@ -1,17 +1,21 @@
-"""RNaD trainer -- drop-in for reference learn/rnad.py (same constructor kwargs, `run()`, schedule and checkpoints).
+"""RNaD trainer -- drop-in for reference learn/rnad.py (same constructor kwargs, `run()`, schedule and checkpoint formats).
 
 The host loop is the reference's (`__resume`, learn/rnad.py:458-531): (m, n) schedule, alpha ramp, rollout cadence, Adam,
-EMA target, regularisation-net rotation.  What changed is what one iteration executes:
+EMA target, regularisation-net rotation.  What one iteration executes depends on `RNaD.tabular`:
 
-  rollout   Episodes.generate -> HIP kernels K1/K2/K3 around the PyTorch-ROCm MLP forward (environment/episode.py)
-  update    4 flattened MLP forwards (PyTorch-ROCm) -> ONE fused HIP kernel (policy heads, process_policy, both players'
-            V-trace, NeuRD + value loss gradients, learn/rnad.py:365-425) -> autograd.backward through the MLP with the
-            closed-form dL/dlogit, dL/dv -> clip -> Adam -> EMA.
+  True (default, trees that are small next to the batch)
+            the nets on the tree's 2S observations (fused fp32-MFMA kernels) -> row records -> bucket-ordered rollout ->
+            rnad_learn_bucketed (V-trace / NeuRD per lane, gradients summed per (player, state) row in LDS) -> one MLP backward
+            over the 2S rows -> clip -> Adam -> EMA; the whole step is captured once as a hipGraph and replayed (train_step).
+  "forward" nets on the 2S observations, per-slot gradients, per-slot MLP backward: bit-identical to the dense mode.
+  False     rollout with K1/K2/K3 around the fused MLP forward on every lane; four MLP forwards over the trajectory -> ONE fused
+            kernel (policy heads, process_policy, both players' V-trace, NeuRD + value loss gradients, learn/rnad.py:365-425) ->
+            fused MLP backward with the closed-form dL/dlogit, dL/dv -> clip -> Adam -> EMA.  What the reference does, slot for slot.
 
 Data parallel: when torch.distributed is initialised (one process per GPU, backend "nccl" == RCCL over xGMI), every rank
 plays `batch_size // world_size` lanes of the SAME seeded noise stream (global lane ids), the two loss normalisers are
-all-reduced before the fused kernel scales gradients (they are batch-global, learn/vtrace.py:373,388), and the 10 756
-parameter gradients are all-reduced (sum) in one flat bucket before clipping.  No other communication.
+all-reduced (they are batch-global, learn/vtrace.py:373,388), and the 10 756 parameter gradients are all-reduced (sum) in one
+flat bucket before clipping.  No other communication.
 """
 import logging
 import os

@@ -1,10 +1,13 @@
 """MLP policy/value net -- drop-in for reference nn/net.py:18-85 (interface + parameter names kept).
 
-Per BASELINE.json's north_star the tiny MLP itself (two parallel 2-layer perceptrons, 10 756 parameters at A = 3,
-width 256) stays in PyTorch-ROCm: its contraction depth is 2*A^2 = 18, nowhere near an MFMA-shaped GEMM.  What moves
-to HIP is everything around the GEMMs: the masked exp-normalise policy head (net.py:45-46, :74-77) and the multinomial
-sampler (net.py:49).  `forward_batch` runs the four Linear layers ONCE over the flattened `[T*B, 2A^2]` trajectory
-instead of a Python loop over t (net.py:67).
+The net is two parallel 2-layer perceptrons (10 756 parameters at A = 3, width 256).  north_star kept it in PyTorch-ROCm "unless
+rocprof shows the GEMM is large enough to be a dense contraction"; round 1's profile did (the hidden activations of 12.6 M samples
+made the torch MLP 99.5 % of a step), so `forward_logits` runs ONE fused fp32-MFMA HIP kernel that keeps the hidden layer in
+registers (rnad_mlp_forward), with rnad_mlp_backward as its autograd backward.  The masked exp-normalise policy head (net.py:45-46,
+:74-77) and the multinomial sampler (net.py:49) are HIP kernels too.  Shapes the fused kernels do not cover (width not a multiple of
+32, non-fp32 weights, a weight image beyond the 160 KiB LDS) and CPU tensors fall back to four torch Linear calls.
+`forward_batch` evaluates the net once over the flattened `[T*B, 2A^2]` trajectory -- or, on a tree that is small next to the
+batch, over the tree's 2S distinct observations -- instead of a Python loop over t (net.py:67).
 
 State-dict keys (`value_fc0.weight`, ...) are the reference's, so its checkpoints load unchanged.
 """
