@@ -337,7 +337,7 @@ int rnad_learn_fused_gather(const rnad_tree_t *tree, int T, int64_t B, const int
  *
  * rnad_bucket_records: one record per (player, state) row from the five [2S, .] net-output tables of a tabular update, holding
  * everything of learn/rnad.py:373-382 that depends on the row alone (rnad_bucket_record_stride(A) floats, 16-byte aligned):
- *   logit[A] | v | v_target | process_policy(pi)[A] | log_policy_reg[A] | pi[A] | legal bits | pad
+ *   logit[A] | v | v_target | process_policy(pi)[A] | log_policy_reg[A] | legal bits | pi[A] | pad
  * with pi, log_pi = the learner's policy head (net.py:74-77), log_policy_reg = log_pi - (alpha log_pi_reg + (1 - alpha) log_pi_reg_).
  *
  * rnad_learn_bucketed: rnad_learn_fused_tabular on a bucket-ordered trajectory and those records: dlogit_tab [2S, A], dv_tab [2S] = per-row sums

@@ -35,6 +35,7 @@ namespace {
 
 constexpr int kThreads = 256;
 constexpr int kMaxPath = 32;         // env steps above a group (path rows of the LDS table)
+constexpr int kPathSlots = 16;       // copies of a path row in LDS: lane l adds into copy l & 15 (4-way instead of 64-way same-address adds)
 constexpr int kMaxBuckets = 12288;   // LDS histogram of the sort passes: 48 KiB of int32
 constexpr int kMaxUpper = 8192;      // upper states (64 replicas of their rows are kept)
 constexpr int kSortThreads = 1024;   // threads per block of the sort passes
@@ -44,6 +45,7 @@ constexpr int kReplicas = 64;        // copies of the upper-row table the workgr
 constexpr int kMaxSteps = 64;        // T_cap bound of the alive counters in LDS
 constexpr int kLaneBits = 22;        // B <= 2^22 lanes per call: a row receives at most one addend per lane
 constexpr int kLearnLds = 64 * 1024; // LDS budget of one learner workgroup
+constexpr int kPackedSteps = 10;      // env steps whose decisions k_bucket_keys hands to k_bucket_rollout (6 bits each)
 constexpr int kTargetLanes = 1024;   // finest cut whose groups still hold this many lanes on average (configs[1]: full work items win)
 
 inline unsigned blocks_for(int64_t n, int per = kThreads) { return (unsigned)((n + per - 1) / per); }
@@ -140,7 +142,8 @@ bool cut_fits(const BucketCut *c) {
 // cut fits the limits above).  RNAD_BUCKET_ROWS forces a table size (tuning / tests).
 bool make_plan(const rnad_tree_t *tree, int64_t B, Plan &p) {
     if (!tree->contiguous_subtrees || B < 1 || B > ((int64_t)1 << kLaneBits)) return false;
-    const int rows_max = (kLearnLds / ((tree->A + 1) * 8) - kMaxPath) / 2;
+    const int path_words = kMaxPath * kPathSlots * ((tree->A + 1) | 1);  // u64 words of the path region (slot stride odd: distinct banks)
+    const int rows_max = (kLearnLds / 8 - path_words) / (2 * (tree->A + 1));
     const BucketCut *chosen = nullptr;
     if (const char *force = getenv("RNAD_BUCKET_ROWS")) {
         const int want = atoi(force);
@@ -160,7 +163,7 @@ bool make_plan(const rnad_tree_t *tree, int64_t B, Plan &p) {
     }
     if (!chosen) return false;
     p.cut = chosen;
-    p.lds = (kMaxPath + 2 * chosen->rows) * (tree->A + 1) * 8;
+    p.lds = (path_words + 2 * chosen->rows * (tree->A + 1)) * 8;
     p.sort_blocks = (int)((B + kSortLanes - 1) / kSortLanes);
     if (const char *c = getenv("RNAD_BUCKET_CHUNK")) p.chunk = std::max(64, atoi(c));  // tuning knob
     p.max_items = (int64_t)chosen->n_buckets + B / p.chunk + 1;
@@ -205,12 +208,14 @@ __global__ __launch_bounds__(kThreads) void k_policy_rows(int64_t rows, const fl
     for (int a = 0; a < A; ++a) policy[r * A + a] = pol[a];
 }
 
-// Row record of the bucketed update, kRowStride<A> floats:  logit[A] | v | v_target | pi_processed[A] | log_policy_reg[A] | pi[A] |
-// legal bits | pad   (64 bytes at A = 3).  From the five net-output tables: pi / log_pi = policy head of the learner (rnad.py:373,
+// Row record of the bucketed update, kRowStride<A> floats:  logit[A] | v | v_target | pi_processed[A] | log_policy_reg[A] |
+// legal bits | pi[A] | pad   (64 bytes at A = 3; the learner reads the first kRowLearn<A> floats = 48 bytes, the rollout pi).  From the five net-output tables: pi / log_pi = policy head of the learner (rnad.py:373,
 // net.py:74-77), pi_processed = process_policy (rnad.py:374), log_policy_reg = log_pi - (alpha log_pi_reg + (1 - alpha) log_pi_reg_)
 // (rnad.py:382) -- the per-slot arithmetic of k_learn_fused that does not depend on the slot.
 template <int A>
 constexpr int kRowStride = (4 * A + 3 + 3) & ~3;
+template <int A>
+constexpr int kRowLearn = (3 * A + 3 + 3) & ~3;  // what k_bucket_learn fetches of a record
 
 template <int A>
 __global__ __launch_bounds__(kThreads) void k_row_records(int64_t rows, const float *__restrict__ logit, const float *__restrict__ v,
@@ -243,11 +248,11 @@ __global__ __launch_bounds__(kThreads) void k_row_records(int64_t rows, const fl
         o[a] = lg[a];
         o[A + 2 + a] = pip[a];
         o[2 * A + 2 + a] = lp[a] - (hp.alpha * lpr[a] + hp.one_minus_alpha * lpr2[a]);
-        o[3 * A + 2 + a] = pi[a];
+        o[3 * A + 3 + a] = pi[a];
     }
     o[A] = v[r];
     o[A + 1] = vt[r];
-    o[4 * A + 2] = __uint_as_float(bits);
+    o[3 * A + 2] = __uint_as_float(bits);
 #pragma unroll
     for (int u = 4 * A + 3; u < kRowStride<A>; ++u) o[u] = 0.0f;
 }
@@ -260,30 +265,44 @@ __global__ __launch_bounds__(kThreads) void k_bucket_keys(const Trans *__restric
                                                           const float *__restrict__ policy_tab, int64_t tab_stride,
                                                           const int32_t *__restrict__ bucket_of, int n_groups, uint64_t seed,
                                                           const rnad_step_params_t *__restrict__ sp, int64_t lane0,
-                                                          int32_t *__restrict__ keys) {
+                                                          int32_t *__restrict__ keys, unsigned long long *__restrict__ decisions,
+                                                          double *__restrict__ norm) {
     const int64_t b = (int64_t)blockIdx.x * kThreads + threadIdx.x;
     if (b >= B) return;
+    if (b == 0 && norm) norm[0] = norm[1] = 0.0;  // summed up by k_bucket_alive at the end of this rollout
     if (sp) seed = sp->seed;  // per-step scalars in device memory: a captured graph of the step replays with new values
     int state = 1, key = bucket_of[1], prev = 0;
-    for (int t = 0; t < n_steps && key >= n_groups; ++t) {
+    // decisions: what this lane drew at its first kPackedSteps env steps -- 3 bits of action and 3 bits of chance outcome per step,
+    // the number of steps recorded in the top 4 bits -- so that k_bucket_rollout replays them without drawing the noise again
+    unsigned long long packed = 0ull;
+    int t = 0;
+    for (; t < n_steps && key >= n_groups; ++t) {
         const int64_t row = (int64_t)(t & 1) * S + state;
         float pol[A], q[A];
 #pragma unroll
         for (int a = 0; a < A; ++a) pol[a] = policy_tab[row * tab_stride + a];
         rnad_exp_noise(seed, (uint64_t)(lane0 + b), (uint32_t)t, 0u, A, q);
         const int action = race_argmax<A>(pol, q);
+        int chosen = 0;
         if (t & 1) {
             int next;
             float rew;
-            transition_lane<A>(trans, C, state, prev, action, nullptr, seed, (uint64_t)(lane0 + b), (uint32_t)t, next, rew);
+            transition_lane<A>(trans, C, state, prev, action, nullptr, seed, (uint64_t)(lane0 + b), (uint32_t)t, next, rew, &chosen);
             state = next;
-            if (state == 0) break;
-            key = bucket_of[state];
         } else {
             prev = action;
         }
+        if (t < kPackedSteps) packed |= (unsigned long long)(action | (chosen << 3)) << (6 * t);
+        if (t & 1) {
+            if (state == 0) {
+                ++t;
+                break;
+            }
+            key = bucket_of[state];
+        }
     }
     keys[b] = key;
+    decisions[b] = packed | ((unsigned long long)min(t, kPackedSteps) << 60);
 }
 
 // ---------------------------------------------------------------------------------------- 2. stable counting sort by key
@@ -431,7 +450,8 @@ __global__ __launch_bounds__(kThreads) void k_bucket_rollout(const Trans *__rest
                                                              const float *__restrict__ value_tab, int64_t value_stride,
                                                              const uint8_t *__restrict__ mask_tab, uint64_t seed,
                                                              const rnad_step_params_t *__restrict__ sp, int64_t lane0,
-                                                             const int32_t *__restrict__ lane_ids, int32_t *__restrict__ indices,
+                                                             const int32_t *__restrict__ lane_ids,
+                                                             const unsigned long long *__restrict__ decisions, int32_t *__restrict__ indices,
                                                              uint8_t *__restrict__ mbits, float *__restrict__ policy,
                                                              int32_t *__restrict__ actions, float *__restrict__ rewards,
                                                              float *__restrict__ values, int32_t *__restrict__ alive_part) {
@@ -439,7 +459,10 @@ __global__ __launch_bounds__(kThreads) void k_bucket_rollout(const Trans *__rest
     const int64_t j = (int64_t)blockIdx.x * kThreads + threadIdx.x;
     const bool active = j < B;
     if (sp) seed = sp->seed;
-    const uint64_t lane = active ? (uint64_t)(lane0 + lane_ids[j]) : 0;
+    const int32_t lane_local = active ? lane_ids[j] : 0;
+    const uint64_t lane = (uint64_t)(lane0 + lane_local);
+    const unsigned long long packed = active ? decisions[lane_local] : 0ull;  // the lane's first decisions, drawn by k_bucket_keys
+    const int n_packed = (int)(packed >> 60);
     const int wave = threadIdx.x >> 6;
     int state = 1, prev = 0;
     for (int t = 0; t < T_cap; ++t) {
@@ -449,11 +472,17 @@ __global__ __launch_bounds__(kThreads) void k_bucket_rollout(const Trans *__rest
             const int64_t i = (int64_t)t * B + j;
             const int64_t row = (int64_t)(t & 1) * S + state;
             const uint32_t bits = mask_tab[row];
-            float pol[A], q[A];
+            float pol[A];
 #pragma unroll
             for (int a = 0; a < A; ++a) pol[a] = policy_tab[row * tab_stride + a];
-            rnad_exp_noise(seed, lane, (uint32_t)t, 0u, A, q);
-            const int action = race_argmax<A>(pol, q);
+            const bool replay = t < n_packed;
+            const int bits6 = (int)(packed >> (6 * t)) & 63;
+            int action = bits6 & 7;
+            if (!replay) {
+                float q[A];
+                rnad_exp_noise(seed, lane, (uint32_t)t, 0u, A, q);
+                action = race_argmax<A>(pol, q);
+            }
             indices[i] = state;
             mbits[i] = (uint8_t)bits;
 #pragma unroll
@@ -462,10 +491,14 @@ __global__ __launch_bounds__(kThreads) void k_bucket_rollout(const Trans *__rest
             if (values) values[i] = value_tab ? value_tab[row * value_stride] : 0.0f;
             int next = state;
             float rew = 0.0f;  // row turn: torch.zeros (episode.py:101)
-            if (t & 1)
-                transition_lane<A>(trans, C, state, prev, action, nullptr, seed, lane, (uint32_t)t, next, rew);
-            else
+            if (t & 1) {
+                if (replay)
+                    transition_apply<A>(trans, C, state, prev, action, bits6 >> 3, next, rew);
+                else
+                    transition_lane<A>(trans, C, state, prev, action, nullptr, seed, lane, (uint32_t)t, next, rew);
+            } else {
                 prev = action;
+            }
             rewards[i] = rew;
             state = next;
         }
@@ -482,31 +515,35 @@ __global__ __launch_bounds__(kThreads) void k_bucket_rollout(const Trans *__rest
     }
 }
 
-// alive[t] = sum over the blocks of alive_part[block][t], and norm[P] = sum of alive[t] over the steps of parity P: the loss
-// normalisers N_P of learn/vtrace.py:373,388 (f64, what RNaD all-reduces over the ranks).  ONE workgroup: wave w takes the steps
-// t = w, w + 4, ...
+// alive[t] = sum over the blocks of alive_part[block][t]; norm[P] += alive[t] for the steps of parity P: the loss normalisers N_P
+// of learn/vtrace.py:373,388 (f64 sums of integers: exact in any order; zeroed by k_bucket_keys).  grid = T_cap + 1 workgroups.
 __global__ __launch_bounds__(kThreads) void k_bucket_alive(int n_blocks, int T1, const int32_t *__restrict__ alive_part,
                                                            int32_t *__restrict__ alive, double *__restrict__ norm) {
-    __shared__ long long per_step[kMaxSteps + 1];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    for (int t = wave; t < T1; t += kThreads / 64) {
-        long long s = 0;
-        for (int r = lane; r < n_blocks; r += 64) s += alive_part[(int64_t)r * T1 + t];
-        s = wave_total_in_lane63(s);
-        if (lane == 63) {
-            alive[t] = (int32_t)s;
-            per_step[t] = s;
-        }
-    }
+    const int t = blockIdx.x;
+    int32_t s = 0;
+    for (int r = threadIdx.x; r < n_blocks; r += kThreads) s += alive_part[(int64_t)r * T1 + t];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+    __shared__ int32_t part[kThreads / 64];
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
     __syncthreads();
-    if (norm && threadIdx.x < 2) {
-        long long n = 0;
-        for (int t = threadIdx.x; t < T1 - 1; t += 2) n += per_step[t];  // steps 0 .. T_cap - 1 (alive[T_cap]: after the last step)
-        norm[threadIdx.x] = (double)n;
+    if (threadIdx.x == 0) {
+        int32_t x = 0;
+#pragma unroll
+        for (int w = 0; w < kThreads / 64; ++w) x += part[w];
+        alive[t] = x;
+        if (norm && t < T1 - 1 && x != 0) atomicAdd(norm + (t & 1), (double)x);  // alive[T_cap]: after the last step, not a slot
     }
 }
 
 // ---------------------------------------------------------------------------------------- 4. learner
+// round-to-nearest-even of a double that holds |d| < 2^51, as an integer: adding 1.5 * 2^52 leaves the rounded integer in the low
+// mantissa bits (3 instructions instead of the ~20 of a generic f64 -> i64 conversion; same result as __double2ll_rn).
+__device__ __forceinline__ long long round_to_ll(double d) {
+    constexpr double kMagic = 6755399441055744.0;  // 1.5 * 2^52
+    return __double_as_longlong(d + kMagic) - __double_as_longlong(kMagic);
+}
+
 struct FixedPoint {
     double scale_l, scale_v;  // 2^f: units per 1.0 of an addend of dL/dlogit / dL/dv
     float limit_l, limit_v;   // |addend| must stay below this (2^(62 - kLaneBits) units)
@@ -529,7 +566,9 @@ __global__ __launch_bounds__(kThreads) void k_bucket_learn(int T, int64_t B, int
                                                            rnad_learn_params_t hp, FixedPoint fx, unsigned long long *__restrict__ acc,
                                                            unsigned long long *__restrict__ rep, double *__restrict__ losses_raw,
                                                            int32_t *__restrict__ overflow) {
-    extern __shared__ unsigned long long tab[];  // [kMaxPath path rows | sub_rows rows of player 0 | sub_rows rows of player 1][A + 1]
+    // [kMaxPath path rows][kPathSlots copies][(A + 1) | 1]  |  [sub_rows rows of player 0 | sub_rows rows of player 1][A + 1]
+    extern __shared__ unsigned long long tab[];
+    constexpr int PS = (A + 1) | 1, kPathWords = kMaxPath * kPathSlots * PS;
     __shared__ int32_t path_state[kMaxPath];
     __shared__ double loss_part[kThreads / 64][4];
     if ((int)blockIdx.x >= *n_items) return;
@@ -537,7 +576,7 @@ __global__ __launch_bounds__(kThreads) void k_bucket_learn(int T, int64_t B, int
     const int s_b = bucket_lo[item.bucket];        // first state id of the group (terminal buckets: the upper state; no rows below)
     const int n_path = bucket_path[item.bucket];   // env steps above the group: upper states shared by every lane of the bucket
     constexpr int RS = kRowStride<A>;
-    const int n_tab = (item.bucket < n_groups ? kMaxPath + 2 * sub_rows : n_path) * (A + 1);
+    const int n_tab = item.bucket < n_groups ? kPathWords + 2 * sub_rows * (A + 1) : n_path * kPathSlots * PS;
     for (int i = threadIdx.x; i < n_tab; i += kThreads) tab[i] = 0ull;
     __syncthreads();
     const VtHp vh{-hp.eta, hp.lambda_, hp.c, hp.rho, hp.gamma};
@@ -547,36 +586,59 @@ __global__ __launch_bounds__(kThreads) void k_bucket_learn(int T, int64_t B, int
         const bool active = base + (int)threadIdx.x < item.count;
         const int64_t j = (int64_t)item.begin + base + threadIdx.x;
         Carry cy[2];
-        for (int t = T - 1; t >= 0; --t) {
+        // Software pipeline over the time loop: the states of step t - 2 and the slot's inputs of step t - 1 (action, acting policy,
+        // reward, the row record -- whose address needs that step's state) are requested before the arithmetic of step t, so the
+        // two dependent memory latencies of a step (state -> record) overlap the V-trace / NeuRD arithmetic of its successors.
+        struct Slot {
+            int act;
+            float rew;
+            float mu[A];
+            float rec[kRowLearn<A>];
+        };
+        auto fetch = [&](int t, int state, Slot &o) {
+            if (state == 0) return;
             const int64_t i = (int64_t)t * B + j;
-            const int state = active ? indices[i] : 0;
+            const float4 *rp = reinterpret_cast<const float4 *>(rec_ + ((int64_t)(t & 1) * S + state) * RS);
+#pragma unroll
+            for (int u = 0; u < kRowLearn<A> / 4; ++u) {
+                const float4 r4 = rp[u];
+                o.rec[4 * u] = r4.x; o.rec[4 * u + 1] = r4.y; o.rec[4 * u + 2] = r4.z; o.rec[4 * u + 3] = r4.w;
+            }
+            o.act = actions[i];
+#pragma unroll
+            for (int a = 0; a < A; ++a) o.mu[a] = mu_[i * A + a];
+            o.rew = (t & 1) ? rewards[i] : 0.0f;  // row turns carry torch.zeros (episode.py:101)
+        };
+        int s_next = active ? indices[(int64_t)(T - 1) * B + j] : 0;
+        int s_next2 = (active && T >= 2) ? indices[(int64_t)(T - 2) * B + j] : 0;
+        Slot nxt;
+        fetch(T - 1, s_next, nxt);
+        for (int t = T - 1; t >= 0; --t) {
+            const int state = s_next;
+            const Slot cur = nxt;
+            s_next = s_next2;
+            if (t >= 1) fetch(t - 1, s_next, nxt);
+            s_next2 = (active && t >= 2) ? indices[(int64_t)(t - 2) * B + j] : 0;
             const bool valid = state != 0;  // rnad.py:369
             const int P = t & 1;            // turns[t, :] (episode.py:96-98)
             long long q[A + 1];
 #pragma unroll
             for (int a = 0; a <= A; ++a) q[a] = 0;
             if (valid) {
-                const int64_t row = (int64_t)P * S + state;
-                const int act = actions[i];
-                float rec[RS];  // this row's record (k_row_records), fetched as 16-byte pieces
-                const float4 *rp = reinterpret_cast<const float4 *>(rec_ + row * RS);
-#pragma unroll
-                for (int u = 0; u < RS / 4; ++u) {
-                    const float4 r4 = rp[u];
-                    rec[4 * u] = r4.x; rec[4 * u + 1] = r4.y; rec[4 * u + 2] = r4.z; rec[4 * u + 3] = r4.w;
-                }
-                const uint32_t bits = __float_as_uint(rec[4 * A + 2]);
+                const int act = cur.act;
+                const float *rec = cur.rec;  // this row's record (k_row_records)
+                const uint32_t bits = __float_as_uint(rec[3 * A + 2]);
                 float mu[A], lg[A], pip[A], lpol[A], legal[A], oh[A];
 #pragma unroll
                 for (int a = 0; a < A; ++a) {
-                    mu[a] = mu_[i * A + a];
+                    mu[a] = cur.mu[a];
                     lg[a] = rec[a];
                     pip[a] = rec[A + 2 + a];    // process_policy(pi) of the learner (rnad.py:374)
                     lpol[a] = rec[2 * A + 2 + a];  // log_policy_reg (rnad.py:382)
                     legal[a] = (float)((bits >> a) & 1);
                     oh[a] = act == a ? 1.0f : 0.0f;
                 }
-                const float rew = (t & 1) ? rewards[i] : 0.0f;  // row turns carry torch.zeros (episode.py:101)
+                const float rew = cur.rew;
                 const float vtn = rec[A + 1];
                 float vt[2], qv[2][A];
                 vtrace_step<A>(cy[0], vh, true, P == 0, 1.0f, vtn, rew, mu, pip, lpol, oh, vt[0], qv[0]);   // player 0 (rnad.py:384-406)
@@ -590,25 +652,25 @@ __global__ __launch_bounds__(kThreads) void k_bucket_learn(int T, int64_t B, int
                 part[2 + P] += -(double)nerd;
                 const float gv = 2.0f * d;
                 ovf |= !(fabsf(gv) < fx.limit_v);
-                q[A] = __double2ll_rn((double)gv * fx.scale_v);
+                q[A] = round_to_ll((double)gv * fx.scale_v);
 #pragma unroll
                 for (int a = 0; a < A; ++a) {
                     ovf |= !(fabsf(g[a]) < fx.limit_l);
-                    q[a] = __double2ll_rn((double)(-g[a]) * fx.scale_l);
+                    q[a] = round_to_ll((double)(-g[a]) * fx.scale_l);
                 }
             } else {
                 cy[0] = Carry{};  // reset_carry (vtrace.py:320)
                 cy[1] = Carry{};
             }
-            if (t < n_path) {  // a step above the bucket state: one row for the whole workgroup
+            if (t < n_path) {  // a step above the bucket state: one row for the whole workgroup, kPathSlots copies of it in LDS
                 if (threadIdx.x == 0 && base == 0) path_state[t] = state;
+                if (valid) {
+                    unsigned long long *dst = tab + (t * kPathSlots + (threadIdx.x & (kPathSlots - 1))) * PS;
 #pragma unroll
-                for (int a = 0; a <= A; ++a) {
-                    const long long s = wave_total_in_lane63(q[a]);
-                    if ((threadIdx.x & 63) == 63 && s != 0) atomicAdd(&tab[t * (A + 1) + a], (unsigned long long)s);
+                    for (int a = 0; a <= A; ++a) atomicAdd(dst + a, (unsigned long long)q[a]);
                 }
             } else if (valid) {
-                unsigned long long *dst = tab + ((int64_t)(kMaxPath + P * sub_rows + (state - s_b))) * (A + 1);
+                unsigned long long *dst = tab + kPathWords + ((int64_t)(P * sub_rows + (state - s_b))) * (A + 1);
 #pragma unroll
                 for (int a = 0; a <= A; ++a) atomicAdd(dst + a, (unsigned long long)q[a]);
             }
@@ -634,9 +696,11 @@ __global__ __launch_bounds__(kThreads) void k_bucket_learn(int T, int64_t B, int
     }
     // path rows -> one of the replicas of the upper-row table (spreads the same-address atomics of the root rows)
     for (int e = threadIdx.x; e < n_path * (A + 1); e += kThreads) {
-        const unsigned long long x = tab[e];
+        const int t = e / (A + 1), a = e % (A + 1);
+        unsigned long long x = 0ull;
+#pragma unroll
+        for (int c = 0; c < kPathSlots; ++c) x += tab[(t * kPathSlots + c) * PS + a];
         if (x != 0ull) {
-            const int t = e / (A + 1), a = e % (A + 1);
             const int64_t slot = bucket_of[path_state[t]] - n_groups;  // path states are upper states
             atomicAdd(rep + (((int64_t)(blockIdx.x & (kReplicas - 1)) * 2 + (t & 1)) * up_stride + slot) * (A + 1) + a, x);
         }
@@ -645,7 +709,7 @@ __global__ __launch_bounds__(kThreads) void k_bucket_learn(int T, int64_t B, int
     if (item.bucket >= n_groups) return;  // terminal bucket: every step was a path step
     const int64_t end = S - s_b < sub_rows ? S - s_b : sub_rows;
     for (int e = threadIdx.x; e < 2 * sub_rows * (A + 1); e += kThreads) {
-        const unsigned long long x = tab[kMaxPath * (A + 1) + e];
+        const unsigned long long x = tab[kPathWords + e];
         if (x != 0ull) {
             const int P = e / (sub_rows * (A + 1)), r = e % (sub_rows * (A + 1));
             if (r / (A + 1) < end) {
@@ -739,9 +803,9 @@ extern "C" int rnad_bucket_plan(const rnad_tree_t *tree, int64_t B, int64_t *out
     out[2] = nu;
     out[3] = p.cut->n_groups;
     out[4] = p.max_items;
-    // scratch of the rollout (bytes): keys [B] | hist [sort_blocks][n_buckets] | totals [n_buckets] | bucket_start [n_buckets] |
+    // scratch of the rollout (bytes): decisions [B] u64 | keys [B] | hist [sort_blocks][n_buckets] | totals [n_buckets] | bucket_start [n_buckets] |
     // alive_part [blocks][T_cap + 1 <= kMaxSteps + 1] | policy [2S][A]
-    out[5] = 4 * (B + (int64_t)p.sort_blocks * nb + 2 * (int64_t)nb + (int64_t)blocks_for(B) * (kMaxSteps + 1) +
+    out[5] = 8 * B + 4 * (B + (int64_t)p.sort_blocks * nb + 2 * (int64_t)nb + (int64_t)blocks_for(B) * (kMaxSteps + 1) +
                   2 * tree->S * tree->A) + 256;
     // accumulators of the learner (bytes, must be zero before the first update): acc [2S][A+1] u64 | rep [64][2][n_upper][A+1] u64 |
     // losses_raw [4] f64 | overflow [1] i32
@@ -761,12 +825,14 @@ extern "C" int rnad_bucket_map(const rnad_tree_t *tree, int64_t B, int32_t *buck
 
 namespace {
 struct Scratch {
+    unsigned long long *decisions;  // [B]
     int32_t *keys, *hist, *totals, *bucket_start, *alive_part;
     float *policy;  // [2S][A]: the actor's policy per row when the caller hands logits
 };
 Scratch carve_scratch(void *ws, int64_t B, const Plan &p) {
     Scratch s;
-    s.keys = (int32_t *)ws;
+    s.decisions = (unsigned long long *)ws;
+    s.keys = (int32_t *)(s.decisions + B);
     s.hist = s.keys + B;
     s.totals = s.hist + (int64_t)p.sort_blocks * p.cut->n_buckets;
     s.bucket_start = s.totals + p.cut->n_buckets;
@@ -838,7 +904,7 @@ extern "C" int rnad_rollout_bucketed(const rnad_tree_t *tree, const rnad_traj_t 
         ProfScope one(PROF_BUCKET_KEYS, stream);
         RNAD_DISPATCH_A(tree->A, hipLaunchKernelGGL((k_bucket_keys<kA>), dim3(blocks_for(B)), dim3(kThreads), 0, stream, tree->trans, tree->C,
                                                     S, B, n_steps, policy_tab, policy_stride, (const int32_t *)p.cut->bucket_of,
-                                                    p.cut->n_groups, seed, device_params, lane0, s.keys));
+                                                    p.cut->n_groups, seed, device_params, lane0, s.keys, s.decisions, norm));
     }
     const size_t lds = (size_t)nb * sizeof(int32_t);
     {
@@ -858,11 +924,12 @@ extern "C" int rnad_rollout_bucketed(const rnad_tree_t *tree, const rnad_traj_t 
         RNAD_DISPATCH_A(tree->A, hipLaunchKernelGGL((k_bucket_rollout<kA>), dim3(grid), dim3(kThreads), 0, stream, tree->trans, tree->C, S, B,
                                                     (int)tr->T_cap, policy_tab, policy_stride, value_table, value_stride,
                                                     (const uint8_t *)tree->mask_tab, seed, device_params, lane0,
-                                                    (const int32_t *)lane_ids, tr->indices, tr->mask_bits, tr->policy, tr->actions,
+                                                    (const int32_t *)lane_ids, (const unsigned long long *)s.decisions, tr->indices,
+                                                    tr->mask_bits, tr->policy, tr->actions,
                                                     tr->rewards, tr->values, s.alive_part));
     }
-    hipLaunchKernelGGL(k_bucket_alive, dim3(1), dim3(kThreads), 0, stream, (int)grid, (int)tr->T_cap + 1, (const int32_t *)s.alive_part,
-                       tr->alive, norm);
+    hipLaunchKernelGGL(k_bucket_alive, dim3(tr->T_cap + 1), dim3(kThreads), 0, stream, (int)grid, (int)tr->T_cap + 1,
+                       (const int32_t *)s.alive_part, tr->alive, norm);
     RNAD_HIP_OK(hipGetLastError());
     return 0;
 }

@@ -91,31 +91,46 @@ __device__ __forceinline__ int race_argmax_n(int n, const float (&p)[NMAX], cons
 }
 
 // environment/episode.py:106-121 for one lane: the C chance outcomes of joint action (r, c) are 12*C contiguous bytes.
+// `chosen` (optional): the index of the sampled outcome, for callers that replay the decision later (transition_apply).
 template <int A>
 __device__ __forceinline__ void transition_lane(const Trans *__restrict__ trans, int C, int s, int r, int c,
                                                 const float *__restrict__ noise_c, uint64_t seed, uint64_t lane, uint32_t step,
-                                                int &next, float &reward) {
+                                                int &next, float &reward, int *chosen = nullptr) {
     const Trans *e = trans + (((int64_t)s * A + r) * A + c) * C;
-    float q[RNAD_MAX_TRANSITIONS];
-    if (noise_c)
-        load_n<RNAD_MAX_TRANSITIONS>(noise_c, C, q);
-    else
-        exp_noise_n<RNAD_MAX_TRANSITIONS>(seed, lane, step, 1u, C, q);
     Trans best = e[0];
-    float bv = best.chance / q[0];
+    int which = 0;
+    if (C > 1) {  // a single outcome wins the race whatever the noise is: no draw needed (same result, the noise is counter-based)
+        float q[RNAD_MAX_TRANSITIONS];
+        if (noise_c)
+            load_n<RNAD_MAX_TRANSITIONS>(noise_c, C, q);
+        else
+            exp_noise_n<RNAD_MAX_TRANSITIONS>(seed, lane, step, 1u, C, q);
+        float bv = best.chance / q[0];
 #pragma unroll
-    for (int t = 1; t < RNAD_MAX_TRANSITIONS; ++t) {
-        if (t < C) {
-            const Trans et = e[t];
-            const float rr = et.chance / q[t];
-            if (rr > bv) {
-                bv = rr;
-                best = et;
+        for (int t = 1; t < RNAD_MAX_TRANSITIONS; ++t) {
+            if (t < C) {
+                const Trans et = e[t];
+                const float rr = et.chance / q[t];
+                if (rr > bv) {
+                    bv = rr;
+                    best = et;
+                    which = t;
+                }
             }
         }
     }
     next = best.next;
     reward = best.value * (next == 0 ? 1.0f : 0.0f);  // rewards *= (indices == 0): keeps -0.0
+    if (chosen) *chosen = which;
+}
+
+// The transition of a decision taken earlier: outcome `chosen` of joint action (r, c) in state s.
+template <int A>
+__device__ __forceinline__ void transition_apply(const Trans *__restrict__ trans, int C, int s, int r, int c, int chosen, int &next,
+                                                 float &reward) {
+    const Trans best = trans[(((int64_t)s * A + r) * A + c) * C + chosen];
+    next = best.next;
+    reward = best.value * (next == 0 ? 1.0f : 0.0f);
 }
 
 }  // namespace dev

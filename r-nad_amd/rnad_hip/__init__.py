@@ -634,12 +634,12 @@ def step_params_set(step_params, seed, alpha):
 
 def policy_column(A):
     """First column of the learner's policy pi[A] inside a bucket_records row."""
-    return 3 * A + 2
+    return 3 * A + 3
 
 
 def bucket_records(tree, logit_tab, v_tab, v_target_tab, logit_reg_tab, logit_reg_tab_, hp, step_params=None):
     """One record per (player, state) row with everything of the update that depends on the row alone (rnad_bucket_records):
-    logit[A] | v | v_target | process_policy(pi)[A] | log_policy_reg[A] | pi[A] | legal bits | pad."""
+    logit[A] | v | v_target | process_policy(pi)[A] | log_policy_reg[A] | legal bits | pi[A] | pad."""
     stride = int(lib().rnad_bucket_record_stride(tree.A))
     rec = torch.empty((2 * tree.S, stride), dtype=F32, device=logit_tab.device)
     _check(lib().rnad_bucket_records(tree.ptr, _dp(logit_tab, F32, "logit_tab"), _dp(v_tab, F32, "v_tab"), _dp(v_target_tab, F32, "v_target_tab"),
