@@ -97,6 +97,9 @@ int rnad_policy_head(int64_t N, int A, const float *logits, const uint8_t *mask_
 int64_t rnad_mlp_packed_size(int A, int W);
 int rnad_mlp_pack(int A, int W, const float *vw0, const float *vb0, const float *vw1, const float *vb1, const float *pw0,
                   const float *pb0, const float *pw1, const float *pb1, float *packed, void *stream);
+/* n_nets (1..4) weight images in one launch: weights = HOST array of 8 * n_nets device pointers (net i: entries 8i .. 8i + 7 in the
+ * order of rnad_mlp_pack), packed = HOST array of n_nets output images. */
+int rnad_mlp_pack_multi(int n_nets, int A, int W, const float *const *weights, float *const *packed, void *stream);
 int rnad_mlp_forward(int64_t N, int A, int W, const float *packed, const void *obs, int obs_half, float *logits,
                      float *value, void *stream);
 /* n_nets (1..4) nets of the same shape on the same N inputs in one launch; packed / logits / value are HOST arrays of n_nets
@@ -374,6 +377,20 @@ int rnad_learn_bucketed(const rnad_tree_t *tree, int T, int64_t B, const int32_t
  * .grad tensors back to back): g *= min(max_norm / (||g||_2 + 1e-6), 1), in place, one launch.  total_norm: optional device
  * float receiving ||g||_2. */
 int rnad_clip_grad_norm(int64_t n, float *grads, float max_norm, float *total_norm, void *stream);
+
+/* The tail of a training step in ONE launch  --  learn/rnad.py:456 (clip_grad_norm_), :514 (torch.optim.Adam.step: no weight decay,
+ * no amsgrad, as constructed at rnad.py:232-237) and :516-523 (EMA target) for up to 8 parameter tensors whose gradients lie back to
+ * back in one flat fp32 bucket `grads` (clipped in place).  sizes: HOST array of element counts; param / exp_avg / exp_avg_sq / step /
+ * target: HOST arrays of device pointers (step: torch's per-tensor fp32 step counters on the device, incremented here; target may be
+ * NULL: no EMA).  The state tensors are torch.optim.Adam's own, so checkpoints keep the reference format. */
+typedef struct rnad_adam_params {
+    float lr, beta1, beta2, eps;  /* rnad.py:232-237 */
+    float max_norm;               /* grad_clip, rnad.py:456 */
+    float ema;                    /* gamma_averaging, rnad.py:516-523 */
+} rnad_adam_params_t;
+int rnad_optimizer_step(int n_tensors, const int64_t *sizes, float *const *param, float *grads, float *const *exp_avg,
+                        float *const *exp_avg_sq, float *const *step, float *const *target, const rnad_adam_params_t *hp,
+                        float *total_norm, void *stream);
 
 /* ------------------------------------------------------------------------------------------------
  * NashConv  --  util/metric.py:93-175 (NashConvData.get_nashconv), level-batched on the GPU

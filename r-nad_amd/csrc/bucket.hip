@@ -544,6 +544,10 @@ __device__ __forceinline__ long long round_to_ll(double d) {
     return __double_as_longlong(d + kMagic) - __double_as_longlong(kMagic);
 }
 
+__global__ void k_zero_words(uint32_t *__restrict__ p, int n) {
+    if ((int)threadIdx.x < n) p[threadIdx.x] = 0u;
+}
+
 struct FixedPoint {
     double scale_l, scale_v;  // 2^f: units per 1.0 of an addend of dL/dlogit / dL/dv
     float limit_l, limit_v;   // |addend| must stay below this (2^(62 - kLaneBits) units)
@@ -952,7 +956,9 @@ extern "C" int rnad_learn_bucketed(const rnad_tree_t *tree, int T, int64_t B, co
     double *losses_raw = (double *)(rep + (int64_t)kReplicas * 2 * std::max(nu, 1) * A1);
     int32_t *overflow = (int32_t *)(losses_raw + 4);
     const FixedPoint fx = fixed_point_for(*hp);
-    RNAD_HIP_OK(hipMemsetAsync(losses_raw, 0, 4 * sizeof(double) + sizeof(int32_t), stream));  // loss sums and the overflow flag
+    // loss sums and the overflow flag start at zero: a 1-wave kernel, not hipMemsetAsync -- the memset node of a captured graph was
+    // seen to write garbage after ~57 replays on ROCm 7.2 (tests/test_hip_graph.py::test_many_replays_stay_finite)
+    hipLaunchKernelGGL(k_zero_words, dim3(1), dim3(64), 0, stream, (uint32_t *)losses_raw, (int)((4 * sizeof(double) + sizeof(int32_t)) / 4));
     ProfScope prof(PROF_LEARN, stream);
 #define RNAD_BUCKET_LEARN()                                                                                                           \
     do {                                                                                                                              \

@@ -193,12 +193,17 @@ __global__ __launch_bounds__(kFwdThreads) void k_mlp_forward(int64_t N, int W, N
 }
 
 
-// Lay the eight torch Linear tensors out as the LDS image described at the top of this file.
-__global__ __launch_bounds__(kThreads) void k_mlp_pack(int A, int W, const float *__restrict__ vw0, const float *__restrict__ vb0,
-                                                       const float *__restrict__ vw1, const float *__restrict__ vb1,
-                                                       const float *__restrict__ pw0, const float *__restrict__ pb0,
-                                                       const float *__restrict__ pw1, const float *__restrict__ pb1,
-                                                       float *__restrict__ packed, int total) {
+// Lay the eight torch Linear tensors out as the LDS image described at the top of this file; blockIdx.y picks the net (up to 4 per launch).
+struct PackSet {
+    const float *w[4][8];  // vw0, vb0, vw1, vb1, pw0, pb0, pw1, pb1 of each net
+    float *packed[4];
+};
+
+__global__ __launch_bounds__(kThreads) void k_mlp_pack(int A, int W, PackSet ps, int total) {
+    const float *const *w = ps.w[blockIdx.y];
+    const float *__restrict__ vw0 = w[0], *__restrict__ vb0 = w[1], *__restrict__ vw1 = w[2], *__restrict__ vb1 = w[3];
+    const float *__restrict__ pw0 = w[4], *__restrict__ pb0 = w[5], *__restrict__ pw1 = w[6], *__restrict__ pb1 = w[7];
+    float *__restrict__ packed = ps.packed[blockIdx.y];
     const int K = 2 * A * A, KS = A * A;
     const int i = blockIdx.x * kThreads + threadIdx.x;
     if (i >= total) return;
@@ -227,15 +232,29 @@ __global__ __launch_bounds__(kThreads) void k_mlp_pack(int A, int W, const float
 
 extern "C" int64_t rnad_mlp_packed_size(int A, int W) { return mlp_packed_floats(A, W); }
 
-extern "C" int rnad_mlp_pack(int A, int W, const float *vw0, const float *vb0, const float *vw1, const float *vb1, const float *pw0,
-                             const float *pb0, const float *pw1, const float *pb1, float *packed, void *stream) {
-    RNAD_REQUIRE(vw0 && vb0 && vw1 && vb1 && pw0 && pb0 && pw1 && pb1 && packed, "rnad_mlp_pack: null argument");
+extern "C" int rnad_mlp_pack_multi(int n_nets, int A, int W, const float *const *weights, float *const *packed, void *stream) {
+    RNAD_REQUIRE(n_nets >= 1 && n_nets <= 4 && weights && packed, "rnad_mlp_pack_multi: 1..4 nets");
     RNAD_REQUIRE(A >= 1 && A <= RNAD_MAX_ACTIONS && W >= kTile && W % kTile == 0, "rnad_mlp_pack: bad shape (A=%d, width=%d)", A, W);
+    PackSet ps{};
+    for (int i = 0; i < n_nets; ++i) {
+        for (int j = 0; j < 8; ++j) {
+            RNAD_REQUIRE(weights[8 * i + j], "rnad_mlp_pack: null weight tensor %d of net %d", j, i);
+            ps.w[i][j] = weights[8 * i + j];
+        }
+        RNAD_REQUIRE(packed[i], "rnad_mlp_pack: null output %d", i);
+        ps.packed[i] = packed[i];
+    }
     const int total = mlp_packed_floats(A, W);
-    hipLaunchKernelGGL(k_mlp_pack, dim3((total + kThreads - 1) / kThreads), dim3(kThreads), 0, (hipStream_t)stream, A, W, vw0, vb0, vw1,
-                       vb1, pw0, pb0, pw1, pb1, packed, total);
+    hipLaunchKernelGGL(k_mlp_pack, dim3((total + kThreads - 1) / kThreads, n_nets), dim3(kThreads), 0, (hipStream_t)stream, A, W, ps, total);
     RNAD_HIP_OK(hipGetLastError());
     return 0;
+}
+
+extern "C" int rnad_mlp_pack(int A, int W, const float *vw0, const float *vb0, const float *vw1, const float *vb1, const float *pw0,
+                             const float *pb0, const float *pw1, const float *pb1, float *packed, void *stream) {
+    const float *w[8] = {vw0, vb0, vw1, vb1, pw0, pb0, pw1, pb1};
+    float *out[1] = {packed};
+    return rnad_mlp_pack_multi(1, A, W, w, out, stream);
 }
 
 static int mlp_forward_launch(int64_t N, const int32_t *rows, const int64_t *n_rows, int A, int W, int n_nets, const NetSet &nets,
@@ -258,8 +277,8 @@ static int mlp_forward_launch(int64_t N, const int32_t *rows, const int64_t *n_r
     const int blocks_per_cu = std::max(1, std::min(12 / kWaves, (int)(160 * 1024 / lds_bytes)));
     const int64_t n_spans = (N + 2 * kTile - 1) / (2 * kTile);  // a wave iteration covers 64 samples
     const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>((n_spans + kWaves - 1) / kWaves, (int64_t)cus * blocks_per_cu));
-    // one net: only the heads that are wanted are computed; several nets: both heads, unwanted outputs are simply not stored
-    const int heads = n_nets > 1 ? 3 : ((nets.value[0] ? 1 : 0) | (nets.logits[0] ? 2 : 0));
+    // only the heads that are wanted are computed: the nets of one launch all want the same heads (rnad_mlp_forward_multi groups them)
+    const int heads = (nets.value[0] ? 1 : 0) | (nets.logits[0] ? 2 : 0);
     ProfScope prof(PROF_MLP, stream);
 #define RNAD_MLP_LAUNCH2(T_, H_)                                                                                                  \
     do {                                                                                                                           \
@@ -297,11 +316,20 @@ extern "C" int rnad_mlp_forward(int64_t N, int A, int W, const float *packed, co
 extern "C" int rnad_mlp_forward_multi(int n_nets, int64_t N, int A, int W, const float *const *packed, const void *obs, int obs_half,
                                       float *const *logits, float *const *value, void *stream) {
     RNAD_REQUIRE(n_nets >= 1 && n_nets <= 4 && packed && logits && value, "rnad_mlp_forward_multi: 1..4 nets");
-    NetSet nets{};
-    for (int i = 0; i < n_nets; ++i) {
-        nets.packed[i] = packed[i]; nets.logits[i] = logits[i]; nets.value[i] = value[i];
+    // one launch per set of wanted heads (value only / logits only / both): a head that is not wanted is not computed
+    for (int heads = 1; heads <= 3; ++heads) {
+        NetSet nets{};
+        int n = 0;
+        for (int i = 0; i < n_nets; ++i) {
+            RNAD_REQUIRE(logits[i] || value[i], "rnad_mlp_forward_multi: net %d wants no output", i);
+            if (((value[i] ? 1 : 0) | (logits[i] ? 2 : 0)) != heads) continue;
+            nets.packed[n] = packed[i]; nets.logits[n] = logits[i]; nets.value[n] = value[i];
+            ++n;
+        }
+        if (n)
+            if (int rc = mlp_forward_launch(N, nullptr, nullptr, A, W, n, nets, obs, obs_half, stream)) return rc;
     }
-    return mlp_forward_launch(N, nullptr, nullptr, A, W, n_nets, nets, obs, obs_half, stream);
+    return 0;
 }
 
 extern "C" int rnad_mlp_forward_rows(int64_t max_rows, const int32_t *rows, const int64_t *n_rows, int A, int W, const float *packed,

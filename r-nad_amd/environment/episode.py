@@ -252,10 +252,12 @@ class Episodes:
         T_cap = 2 * handle.max_depth if max_steps is None else int(max_steps)
         dev = torch.device(tree.device)
         fast = hasattr(net, "forward_logits")
-        packed = net.pack() if fast and hasattr(net, "pack") else None  # weights are fixed for the whole rollout
+        # weights are fixed for the whole rollout: pack them once -- unless the caller hands the actor's table in (nothing to evaluate)
+        packed = net.pack() if fast and hasattr(net, "pack") and logits_table is None and policy_table is None else None
         net.eval()
         time_start = time.perf_counter()
-        native = packed is not None and noise_action is None and noise_chance is None and type(net).forward_logits is _MLP.forward_logits
+        native = ((packed is not None or logits_table is not None or policy_table is not None) and noise_action is None
+                  and noise_chance is None and type(net).forward_logits is _MLP.forward_logits)
         if tabular is None:
             tabular = 8 * handle.S <= T_cap * B
         tabular = native and tabular and not keep_logits
@@ -267,6 +269,7 @@ class Episodes:
             # one actor evaluation per (player, state), then the whole loop natively with per-lane gathers
             table, vtable = logits_table, value_table
             if table is None and not (bucketed and policy_table is not None):
+                packed = packed if packed is not None else net.pack()
                 table, vtable = rnad_hip.mlp_forward(packed, net.width, handle.observations_table(self.obs_half), tree.max_actions,
                                                      want_value=store_values)
             if bucketed and policy_table is not None:
@@ -283,6 +286,7 @@ class Episodes:
                                              seed=self.seed, lane0=self.lane_offset)
         elif native:
             # the actor is this package's MLP: the whole loop is enqueued natively (rnad_rollout_run)
+            packed = packed if packed is not None else net.pack()
             self.actor_logits = rnad_hip.rollout_run(handle, traj, net.width, packed, seed=self.seed, lane0=self.lane_offset,
                                                      keep_logits=keep_logits,
                                                      skip_absorbed=skip_absorbed and not keep_logits and not handle.uniform_length,

@@ -143,6 +143,7 @@ class RNaD:
         self.tabular = True
         self.tabular_gate = 8
         self.use_graph = True  # capture the on-policy tabular step as a hipGraph and replay it (train_step)
+        self.fused_optimizer = True  # clip + Adam + EMA target of the MLP in one launch (csrc/optim.hip) instead of ~8 torch launches
         # ragged trajectories: evaluate / differentiate the nets on live (t, b) slots only (see __learn); same losses and gradients
         self.skip_absorbed = True
         self.obs_half = False  # store observations as fp16 (BASELINE.json configs[4]); arithmetic stays fp32
@@ -353,7 +354,8 @@ class RNaD:
         if cache["key"] != key:
             A = self.tree.max_actions
             with torch.no_grad():
-                outs = rnad_hip.mlp_forward_multi([self.net_reg.pack(), self.net_reg_.pack()], self.net.width, table, A,
+                outs = rnad_hip.mlp_forward_multi(rnad_hip.mlp_pack_many([self.net_reg._weights(), self.net_reg_._weights()], A),
+                                                  self.net.width, table, A,
                                                   [(True, False), (True, False)])
             for name, out in (("logit_reg", outs[0][0]), ("logit_reg_", outs[1][0])):
                 if cache[name] is None:
@@ -372,12 +374,13 @@ class RNaD:
         always there: a term of log_policy_reg (:382) whose weight is exactly 0 adds exactly 0."""
         A = self.tree.max_actions
         table = self.tree.handle().observations_table(obs_half)
+        packed, packed_target = rnad_hip.mlp_pack_many([self.net._weights(), self.net_target._weights()], A)
         with torch.no_grad():
-            outs = rnad_hip.mlp_forward_multi([self.net.pack(), self.net_target.pack()], self.net.width, table, A,
+            outs = rnad_hip.mlp_forward_multi([packed, packed_target], self.net.width, table, A,
                                               [(True, True), (want_target_logits, True)])
         logit_reg, logit_reg_ = self._reg_tables(table)
         return dict(table=table, logit=outs[0][0], v=outs[0][1], logit_target=outs[1][0], v_target=outs[1][1], logit_reg=logit_reg,
-                    logit_reg_=logit_reg_)
+                    logit_reg_=logit_reg_, packed_net=packed)
 
     # ------------------------------------------------------------------ reference learn/rnad.py:353-456
     @staticmethod
@@ -395,9 +398,11 @@ class RNaD:
         A = logit.shape[-1]
         return logit.reshape(-1, A), v.reshape(-1, 1)
 
-    def __learn(self, episodes: episode.Episodes, alpha: float, log: dict = None, tables: dict = None):
+    def __learn(self, episodes: episode.Episodes, alpha: float, log: dict = None, tables: dict = None, defer_clip: bool = False):
         """Gradients of the learner net from a batch of trajectories (reward transform + V-trace + NeuRD).
-        tables: _table_outputs(alpha) of the CURRENT nets, when train_step already evaluated them for the rollout."""
+        tables: _table_outputs(alpha) of the CURRENT nets, when train_step already evaluated them for the rollout.
+        defer_clip: leave clip_grad_norm_ (rnad.py:456) to the fused optimiser kernel of train_step; the flat gradient bucket is
+        then handed over in self._pending_flat."""
         T, B, A = episodes.t_eff + 1, episodes.batch_size, self.tree.max_actions
 
         # N_P = #(valid & turn == P): batch-global loss normalisers (vtrace.py:373,388).  Their all-reduce over the ranks is
@@ -498,7 +503,8 @@ class RNaD:
         if reuse or direct:
             weights = self.net._weights()
             flat, views = self._grad_bucket(weights)
-            rnad_hip.mlp_backward(self.net.pack(), weights, backward_obs, A, dlogit.view(-1, A), dv.view(-1, 1), live=live, out=views)
+            packed = tables["packed_net"] if tables is not None and "packed_net" in tables else self.net.pack()  # same weights as the forward
+            rnad_hip.mlp_backward(packed, weights, backward_obs, A, dlogit.view(-1, A), dv.view(-1, 1), live=live, out=views)
             if all(p_.grad is None for p_ in weights):
                 for p_, g_ in zip(weights, views):
                     p_.grad = g_
@@ -555,7 +561,10 @@ class RNaD:
                 "actor_learner_kld": metric.kld(pi, episodes.policy[:T], valid, legal_actions=masks),
             })
 
-        if flat is not None and flat.is_cuda:  # the .grad tensors are views of this bucket: one launch instead of ~8
+        self._pending_flat = None
+        if defer_clip and flat is not None and flat.is_cuda:
+            self._pending_flat = flat  # clipped by rnad_optimizer_step together with Adam and the EMA
+        elif flat is not None and flat.is_cuda:  # the .grad tensors are views of this bucket: one launch instead of ~8
             rnad_hip.clip_grad_norm(flat, self.grad_clip)  # rnad.py:456
         else:
             nn.utils.clip_grad_norm_(self.net.parameters(), self.grad_clip)  # rnad.py:456
@@ -603,7 +612,16 @@ class RNaD:
             buffer.append(episodes)
             self.last_episodes = episodes
         episodes_sample = buffer.sample(local_batch)
-        self.__learn(episodes_sample, alpha, log=log, tables=tables)
+        fused_tail = self._fused_tail()
+        self.__learn(episodes_sample, alpha, log=log, tables=tables, defer_clip=fused_tail is not None)
+        if fused_tail is not None and self._pending_flat is not None:
+            fused_tail(self._pending_flat)  # clip + Adam + EMA target in one launch (csrc/optim.hip)
+            self._pending_flat = None
+            self.optimizer.zero_grad()
+            return
+        if self._pending_flat is not None:
+            rnad_hip.clip_grad_norm(self._pending_flat, self.grad_clip)
+            self._pending_flat = None
         self.optimizer.step()
         self.optimizer.zero_grad()
         # EMA target, rnad.py:516-523: target <- gamma * net + (1 - gamma) * target for every state_dict entry, as two
@@ -613,6 +631,38 @@ class RNaD:
             src = [t for k, t in self.net.state_dict().items() if t.is_floating_point()]
             torch._foreach_mul_(tgt, 1 - self.gamma_averaging)
             torch._foreach_add_(tgt, src, alpha=self.gamma_averaging)
+
+    def _fused_tail(self):
+        """rnad_hip.OptimizerStep over the learner's eight tensors (clip + Adam + EMA in one launch), or None when the plain torch
+        sequence must run: another net type, a CPU run, an optimiser that is not the reference's Adam (rnad.py:232-237), or Adam
+        state that does not exist yet (torch creates it in its first step())."""
+        if not getattr(self, "fused_optimizer", True) or not self._fused_mlp() or not isinstance(self.net_target, net.MLP):
+            return None
+        opt = self.optimizer
+        if type(opt) is not torch.optim.Adam or len(opt.param_groups) != 1:
+            return None
+        grp = opt.param_groups[0]
+        if grp.get("amsgrad") or grp.get("weight_decay") or grp.get("maximize") or grp.get("differentiable"):
+            return None
+        weights = self.net._weights()
+        key = (id(opt), id(self.net), id(self.net_target), grp["lr"], tuple(grp["betas"]), grp["eps"], self.grad_clip, self.gamma_averaging)
+        cached = getattr(self, "_fused_tail_cache", None)
+        if cached is not None and cached[0] == key:
+            return cached[1]
+        states = [opt.state.get(w) for w in weights]
+        if any(not st or "exp_avg" not in st for st in states):
+            return None
+        steps = [st["step"] for st in states]
+        if any((not torch.is_tensor(x)) or (not x.is_cuda) or x.dtype != torch.float32 for x in steps):
+            return None
+        lr = grp["lr"]
+        if torch.is_tensor(lr):
+            return None
+        tail = rnad_hip.OptimizerStep(weights, [st["exp_avg"] for st in states], [st["exp_avg_sq"] for st in states], steps,
+                                      self.net_target._weights(), lr, grp["betas"][0], grp["betas"][1], grp["eps"], self.grad_clip,
+                                      self.gamma_averaging)
+        self._fused_tail_cache = (key, tail)
+        return tail
 
     # ------------------------------------------------------------------ hipGraph replay of the on-policy tabular step
     _GRAPH_WARMUP = 3  # eager steps before capture: code objects loaded, allocator pools and the table caches exist
@@ -641,7 +691,7 @@ class RNaD:
         return (id(buffer), id(self.net), id(self.net_target), id(self.net_reg), id(self.net_reg_), id(self.optimizer), id(self.tree.handle()),
                 self.batch_size, self.tabular, getattr(self, "tabular_gate", 8), self.eta, self.beta, self.neurd_clip, self.grad_clip,
                 self.c_bar, self.roh_bar, self.vtrace_gamma, self.value_weight, self.neurd_weight, self.epsilon_threshold, self.n_discrete,
-                self.gamma_averaging, getattr(self, "obs_half", False), getattr(self, "store_actor_values", False),
+                self.gamma_averaging, getattr(self, "obs_half", False), getattr(self, "store_actor_values", False), getattr(self, "fused_optimizer", True),
                 os.environ.get("RNAD_BUCKET_ROWS"), os.environ.get("RNAD_BUCKET_CHUNK"))
 
     def _graph_step(self, buffer, alpha):

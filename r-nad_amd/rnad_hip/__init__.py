@@ -241,6 +241,20 @@ def mlp_pack(weights, A):
     return packed
 
 
+def mlp_pack_many(weight_lists, A):
+    """mlp_pack for up to four nets of one shape in ONE launch (rnad_mlp_pack_multi) -> list of packed images."""
+    n = len(weight_lists)
+    assert 1 <= n <= 4 and all(len(w) == 8 for w in weight_lists)
+    W = weight_lists[0][0].shape[0]
+    size = lib().rnad_mlp_packed_size(A, W)
+    dev = weight_lists[0][0].device
+    outs = [torch.empty((size,), dtype=F32, device=dev) for _ in range(n)]
+    wp = (C.c_void_p * (8 * n))(*[_dp(w.detach(), F32, "weight").value for ws in weight_lists for w in ws])
+    op = (C.c_void_p * n)(*[_dp(o, F32, "packed").value for o in outs])
+    _check(lib().rnad_mlp_pack_multi(n, A, W, wp, op, _stream()))
+    return outs
+
+
 class LiveRows:
     """Ascending list of the positions with indices != 0 (rnad_compact_valid): `rows` int32 [N] of which the first `count`
     (a device int64) are meaningful.  Built and consumed on the stream, never read by the host."""
@@ -667,6 +681,34 @@ def learn_bucketed(tree, buckets, indices, actions, rewards, mu, records, norm, 
 def clip_grad_norm(flat, max_norm):
     """In-place clip_grad_norm_ of one flat fp32 gradient bucket (rnad_clip_grad_norm)."""
     _check(lib().rnad_clip_grad_norm(C.c_int64(flat.numel()), _dp(flat, F32, "grads"), C.c_float(max_norm), None, _stream()))
+
+
+class AdamParams(C.Structure):
+    """struct rnad_adam_params (include/rnad_hip.h)."""
+
+    _fields_ = [("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float), ("max_norm", C.c_float), ("ema", C.c_float)]
+
+
+class OptimizerStep:
+    """rnad_optimizer_step bound to fixed tensors: clip + Adam + EMA of `params` (gradients back to back in one flat bucket, in that
+    order) in one launch, on torch.optim.Adam's own state tensors.  The pointer arrays are built once."""
+
+    def __init__(self, params, exp_avg, exp_avg_sq, steps, targets, lr, beta1, beta2, eps, max_norm, ema):
+        n = len(params)
+        assert 1 <= n <= 8 and len(exp_avg) == len(exp_avg_sq) == len(steps) == n and (targets is None or len(targets) == n)
+        self._keep = (params, exp_avg, exp_avg_sq, steps, targets)
+        self.n = n
+        self.numel = sum(p.numel() for p in params)
+        arr = lambda ts, name: (C.c_void_p * n)(*[_dp(t, F32, name).value for t in ts])  # noqa: E731
+        self.sizes = (C.c_int64 * n)(*[p.numel() for p in params])
+        self.param, self.m, self.v, self.step = arr(params, "param"), arr(exp_avg, "exp_avg"), arr(exp_avg_sq, "exp_avg_sq"), arr(steps, "step")
+        self.target = arr(targets, "target") if targets is not None else None
+        self.hp = AdamParams(float(lr), float(beta1), float(beta2), float(eps), float(max_norm), float(ema))
+
+    def __call__(self, flat):
+        assert flat.numel() == self.numel
+        _check(lib().rnad_optimizer_step(self.n, self.sizes, self.param, _dp(flat, F32, "grads"), self.m, self.v, self.step, self.target,
+                                         C.byref(self.hp), None, _stream()))
 
 
 def make_learn_params(alpha, eta, lambda_=1.0, c=1.0, rho=1.0, gamma=1.0, clip=1e3, threshold=2.0, w_v=1.0, w_n=1.0,

@@ -256,6 +256,7 @@ def test_train_step_modes_agree(name, tmp_path, monkeypatch):
         with torch.no_grad():
             for p in rn.net_reg_.parameters():
                 p.mul_(1.01)
+        rn.fused_optimizer = False  # the gradients are read where torch's optimizer.step() would be called
         captured = {}
         real = rn.optimizer.step
         rn.optimizer.step = lambda: (captured.update(g=[p.grad.detach().clone() for p in rn.net.parameters()]), real())[1]

@@ -54,6 +54,31 @@ def test_graph_replay_equals_eager_steps(name, tmp_path):
     assert np.isfinite(sum(float(p.abs().sum()) for p in nets_g))
 
 
+def test_many_replays_stay_finite(tmp_path):
+    """150 replays of one captured step on the small golden tree (one group, no upper states, B = 512).  Regression: the loss sums
+    and the overflow flag used to be cleared by hipMemsetAsync, and the memset node of the captured graph wrote garbage into them
+    after ~57 replays (ROCm 7.2) -- a set overflow flag poisons the gradient tables with NaN.  They are cleared by a kernel now."""
+    import os
+
+    from _gpu import golden_tree
+    from environment.episode import Buffer
+    from learn.rnad import RNaD
+
+    tree, _ = golden_tree("small")
+    os.environ["RNAD_SAVE_DIR"] = str(tmp_path)
+    torch.manual_seed(2000)
+    rn = RNaD(tree=tree, device=DEV, directory_name="many", batch_size=512, eta=0.2, b1_adam=0.0, lr=5e-3,
+              net_params={"type": "MLP", "max_actions": 3, "width": 256})
+    rn.initialize()
+    buf = Buffer(1)
+    for i in range(150):
+        rn.train_step(buf, alpha=min(1.0, i / 50))
+        rn.total_steps += 1
+    torch.cuda.synchronize()
+    assert rn._graph["graph"] is not None and not rn._graph["failed"]
+    assert all(torch.isfinite(p).all() for n in (rn.net, rn.net_target) for p in n.parameters())
+
+
 def test_logging_steps_and_mode_changes_leave_the_graph(tmp_path):
     """A logging step runs eagerly between replays; changing a baked-in hyper-parameter re-captures."""
     from environment.episode import Buffer
@@ -73,3 +98,34 @@ def test_logging_steps_and_mode_changes_leave_the_graph(tmp_path):
     assert rn._graph["graph"] is not None and rn._graph["graph"] is not first
     torch.cuda.synchronize()
     assert all(torch.isfinite(p).all() for p in rn.net.parameters())
+
+
+def test_fused_optimizer_tail_is_clip_adam_ema(tmp_path):
+    """rnad_optimizer_step (clip + Adam + EMA target in one launch, on torch.optim.Adam's own state) against the torch sequence it
+    replaces (rnad_clip_grad_norm / clip_grad_norm_, Adam.step, _foreach EMA), step after step from the same start."""
+    import os
+
+    from environment.episode import Buffer
+    from learn.rnad import RNaD
+    from test_hip_bucket import TREES, _native_tree
+
+    tree = _native_tree(**TREES["ternary4"])
+    os.environ["RNAD_SAVE_DIR"] = str(tmp_path)
+    runs = {}
+    for fused in (False, True):
+        torch.manual_seed(3)
+        rn = RNaD(tree=tree, device=DEV, directory_name=f"opt{int(fused)}", batch_size=1 << 13, eta=0.2, b1_adam=0.0, lr=1e-3, grad_clip=0.05,
+                  gamma_averaging=0.01, net_params={"type": "MLP", "max_actions": 3, "width": 64})
+        rn.initialize()
+        rn.use_graph, rn.fused_optimizer = False, fused
+        buf = Buffer(1)
+        for i in range(6):
+            rn.train_step(buf, alpha=0.2 * i)
+            rn.total_steps += 1
+        assert (rn._fused_tail() is not None) == fused
+        st = rn.optimizer.state_dict()["state"]
+        runs[fused] = ([p.detach().clone() for n in (rn.net, rn.net_target) for p in n.parameters()],
+                       [st[k]["exp_avg_sq"].clone() for k in sorted(st)], [float(st[k]["step"]) for k in sorted(st)])
+    assert runs[True][2] == runs[False][2] == [6.0] * 8
+    for a, b in zip(runs[False][0] + runs[False][1], runs[True][0] + runs[True][1]):
+        np.testing.assert_allclose(b.cpu().numpy(), a.cpu().numpy(), rtol=2e-5, atol=1e-8)
