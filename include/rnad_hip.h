@@ -347,6 +347,16 @@ int rnad_learn_fused_gather(const rnad_tree_t *tree, int T, int64_t B, const int
  * of the per-slot gradients, accumulated in 64-bit fixed point with an a-priori scale (|dL/dlogit| <= 2 * clip / N_P by
  * construction; |v - v_target| < 2^10 is checked, the tables are NaN if it fails), normalised by norm (f64[2], batch-global
  * N_P) at the end.  Integer sums: reproducible bit for bit.  losses (f64[2], optional): loss_v, loss_nerd of this rank's slots.
+ *
+ * Compact trajectory (on-policy updates: the batch is learned from in the step that played it, learn/rnad.py:502-510 with the
+ * default one-batch buffer).  Of a slot's record only the state cannot be recomputed: the mask and the acting policy are rows of
+ * tables, the action takes 3 bits, and rewards *= (indices == 0) (episode.py:120-121) leaves one non-zero reward per episode.
+ * rnad_rollout_bucketed_compact plays the same episodes as rnad_rollout_bucketed with the pi columns of `records` as the actor and
+ * writes indices [T_cap + 1, B], alive, acts (uint64 [B]: action of step t in bits 3t .. 3t + 2) and final_reward (f32 [B]) -- 64
+ * instead of 300 bytes per lane at A = 3, T = 12; T_cap <= 21.  rnad_learn_bucketed_compact is rnad_learn_bucketed on that
+ * trajectory, with the acting policy of a slot read from its record (the very floats the rollout sampled from): same gradients
+ * bit for bit.  rnad_bucket_expand writes the dense [T, B] buffers of such a trajectory (mask_bits, policy, actions, rewards) when
+ * something asks for them; slots of absorbed lanes get action 0 (the dense rollout keeps drawing there; nothing reads them).
  * ---------------------------------------------------------------------------------------------- */
 /* Per-step scalars in DEVICE memory (optional everywhere: NULL = use the immediate arguments).  With them a captured hipGraph of a
  * whole training step can be replayed step after step: the host only rewrites these 16 bytes. */
@@ -364,6 +374,13 @@ int rnad_rollout_bucketed(const rnad_tree_t *tree, const rnad_traj_t *traj, cons
                           int table_is_policy, const float *value_table, int64_t value_stride, uint64_t seed, int64_t lane0,
                           const rnad_step_params_t *device_params, void *scratch, int32_t *lane_ids, int32_t *items, int32_t *n_items,
                           double *norm, void *stream);
+int rnad_rollout_bucketed_compact(const rnad_tree_t *tree, int T_cap, int64_t B, const float *records, uint64_t seed, int64_t lane0,
+                                  const rnad_step_params_t *device_params, void *scratch, int32_t *lane_ids, int32_t *items,
+                                  int32_t *n_items, double *norm, int32_t *indices, int32_t *alive, uint64_t *acts,
+                                  float *final_reward, void *stream);
+int rnad_bucket_expand(const rnad_tree_t *tree, int T, int64_t B, const int32_t *indices, const uint64_t *acts,
+                       const float *final_reward, const float *records, uint8_t *mask_bits, float *policy, int32_t *actions,
+                       float *rewards, void *stream);
 int64_t rnad_bucket_record_stride(int A);
 int rnad_bucket_records(const rnad_tree_t *tree, const float *logit_tab, const float *v_tab, const float *v_target_tab,
                         const float *logit_reg_tab, const float *logit_reg_tab_, const rnad_learn_params_t *hp,
@@ -372,6 +389,10 @@ int rnad_learn_bucketed(const rnad_tree_t *tree, int T, int64_t B, const int32_t
                         const float *rewards, const float *mu, const float *records, const int32_t *items, const int32_t *n_items,
                         const double *norm, const rnad_learn_params_t *hp, void *accumulators, double *losses, float *dlogit_tab,
                         float *dv_tab, void *stream);
+int rnad_learn_bucketed_compact(const rnad_tree_t *tree, int T, int64_t B, const int32_t *indices, const uint64_t *acts,
+                                const float *final_reward, const float *records, const int32_t *items, const int32_t *n_items,
+                                const double *norm, const rnad_learn_params_t *hp, void *accumulators, double *losses,
+                                float *dlogit_tab, float *dv_tab, void *stream);
 
 /* torch.nn.utils.clip_grad_norm_(parameters, max_norm) of learn/rnad.py:456 over one flat fp32 gradient bucket (all of a net's
  * .grad tensors back to back): g *= min(max_norm / (||g||_2 + 1e-6), 1), in place, one launch.  total_norm: optional device

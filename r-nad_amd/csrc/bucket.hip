@@ -46,6 +46,7 @@ constexpr int kMaxSteps = 64;        // T_cap bound of the alive counters in LDS
 constexpr int kLaneBits = 22;        // B <= 2^22 lanes per call: a row receives at most one addend per lane
 constexpr int kLearnLds = 64 * 1024; // LDS budget of one learner workgroup
 constexpr int kPackedSteps = 10;      // env steps whose decisions k_bucket_keys hands to k_bucket_rollout (6 bits each)
+constexpr int kCompactSteps = 21;     // env steps of a compact trajectory: 3 bits of action per step in one 64-bit word
 constexpr int kTargetLanes = 1024;   // finest cut whose groups still hold this many lanes on average (configs[1]: full work items win)
 
 inline unsigned blocks_for(int64_t n, int per = kThreads) { return (unsigned)((n + per - 1) / per); }
@@ -444,7 +445,12 @@ __global__ __launch_bounds__(kSortThreads) void k_bucket_scatter(int64_t B, int 
 // registers across the T_cap steps and column j of every [T_cap, B] buffer written coalesced.  Observations are not written
 // (a function of (t & 1, indices): materialised on demand), `values` only if asked for.
 // alive_part[block][t] = #lanes of the block with indices[t] != 0 (summed by k_bucket_alive: no atomics).
-template <int A>
+//
+// COMPACT: the trajectory as 64 bytes per lane instead of 25 per slot -- indices [T_cap + 1, B], the lane's actions packed 3 bits
+// per step (acts_out) and the one non-zero reward of the episode (rewards *= (indices == 0), episode.py:120-121: only the transition
+// into state 0 pays; reward_out).  Everything else of a slot is a function of (t & 1, indices[t]) and the actor's table
+// (k_bucket_expand writes the dense buffers on demand).  An absorbed lane stops: no draws, no table reads.
+template <int A, bool COMPACT>
 __global__ __launch_bounds__(kThreads) void k_bucket_rollout(const Trans *__restrict__ trans, int C, int64_t S, int64_t B, int T_cap,
                                                              const float *__restrict__ policy_tab, int64_t tab_stride,
                                                              const float *__restrict__ value_tab, int64_t value_stride,
@@ -454,7 +460,8 @@ __global__ __launch_bounds__(kThreads) void k_bucket_rollout(const Trans *__rest
                                                              const unsigned long long *__restrict__ decisions, int32_t *__restrict__ indices,
                                                              uint8_t *__restrict__ mbits, float *__restrict__ policy,
                                                              int32_t *__restrict__ actions, float *__restrict__ rewards,
-                                                             float *__restrict__ values, int32_t *__restrict__ alive_part) {
+                                                             float *__restrict__ values, int32_t *__restrict__ alive_part,
+                                                             unsigned long long *__restrict__ acts_out, float *__restrict__ reward_out) {
     __shared__ int32_t cnt[kThreads / 64][kMaxSteps + 1];
     const int64_t j = (int64_t)blockIdx.x * kThreads + threadIdx.x;
     const bool active = j < B;
@@ -465,43 +472,79 @@ __global__ __launch_bounds__(kThreads) void k_bucket_rollout(const Trans *__rest
     const int n_packed = (int)(packed >> 60);
     const int wave = threadIdx.x >> 6;
     int state = 1, prev = 0;
+    unsigned long long acts = 0ull;
+    float reward_final = 0.0f;
     for (int t = 0; t < T_cap; ++t) {
         const uint64_t live = __ballot(active && state != 0);
         if ((threadIdx.x & 63) == 0) cnt[wave][t] = (int32_t)__popcll(live);
+        if (COMPACT && live == 0ull) {  // the whole wave is absorbed (uniform branch)
+            if (active) indices[(int64_t)t * B + j] = 0;
+            continue;
+        }
         if (active) {
             const int64_t i = (int64_t)t * B + j;
             const int64_t row = (int64_t)(t & 1) * S + state;
-            const uint32_t bits = mask_tab[row];
-            float pol[A];
-#pragma unroll
-            for (int a = 0; a < A; ++a) pol[a] = policy_tab[row * tab_stride + a];
             const bool replay = t < n_packed;
             const int bits6 = (int)(packed >> (6 * t)) & 63;
             int action = bits6 & 7;
-            if (!replay) {
-                float q[A];
-                rnad_exp_noise(seed, lane, (uint32_t)t, 0u, A, q);
-                action = race_argmax<A>(pol, q);
-            }
-            indices[i] = state;
-            mbits[i] = (uint8_t)bits;
+            if (COMPACT) {
+                indices[i] = state;
+                if (state != 0) {
+                    if (!replay) {
+                        float pol[A], q[A];
 #pragma unroll
-            for (int a = 0; a < A; ++a) policy[i * A + a] = pol[a];
-            actions[i] = action;
-            if (values) values[i] = value_tab ? value_tab[row * value_stride] : 0.0f;
-            int next = state;
-            float rew = 0.0f;  // row turn: torch.zeros (episode.py:101)
-            if (t & 1) {
-                if (replay)
-                    transition_apply<A>(trans, C, state, prev, action, bits6 >> 3, next, rew);
-                else
-                    transition_lane<A>(trans, C, state, prev, action, nullptr, seed, lane, (uint32_t)t, next, rew);
+                        for (int a = 0; a < A; ++a) pol[a] = policy_tab[row * tab_stride + a];
+                        rnad_exp_noise(seed, lane, (uint32_t)t, 0u, A, q);
+                        action = race_argmax<A>(pol, q);
+                    }
+                    acts |= (unsigned long long)action << (3 * t);
+                    if (t & 1) {
+                        int next;
+                        float rew;
+                        if (replay)
+                            transition_apply<A>(trans, C, state, prev, action, bits6 >> 3, next, rew);
+                        else
+                            transition_lane<A>(trans, C, state, prev, action, nullptr, seed, lane, (uint32_t)t, next, rew);
+                        if (next == 0) reward_final = rew;
+                        state = next;
+                    } else {
+                        prev = action;
+                    }
+                }
             } else {
-                prev = action;
+                const uint32_t bits = mask_tab[row];
+                float pol[A];
+#pragma unroll
+                for (int a = 0; a < A; ++a) pol[a] = policy_tab[row * tab_stride + a];
+                if (!replay) {
+                    float q[A];
+                    rnad_exp_noise(seed, lane, (uint32_t)t, 0u, A, q);
+                    action = race_argmax<A>(pol, q);
+                }
+                indices[i] = state;
+                mbits[i] = (uint8_t)bits;
+#pragma unroll
+                for (int a = 0; a < A; ++a) policy[i * A + a] = pol[a];
+                actions[i] = action;
+                if (values) values[i] = value_tab ? value_tab[row * value_stride] : 0.0f;
+                int next = state;
+                float rew = 0.0f;  // row turn: torch.zeros (episode.py:101)
+                if (t & 1) {
+                    if (replay)
+                        transition_apply<A>(trans, C, state, prev, action, bits6 >> 3, next, rew);
+                    else
+                        transition_lane<A>(trans, C, state, prev, action, nullptr, seed, lane, (uint32_t)t, next, rew);
+                } else {
+                    prev = action;
+                }
+                rewards[i] = rew;
+                state = next;
             }
-            rewards[i] = rew;
-            state = next;
         }
+    }
+    if (COMPACT && active) {
+        acts_out[j] = acts;
+        reward_out[j] = reward_final;
     }
     const uint64_t live = __ballot(active && state != 0);
     if ((threadIdx.x & 63) == 0) cnt[wave][T_cap] = (int32_t)__popcll(live);
@@ -560,14 +603,19 @@ struct FixedPoint {
 // Addends are the UN-normalised gradients  G_l[a] = -(w - legal * sum(w) / A)  and  G_v = 2 (v - v_target)  in 64-bit fixed
 // point; k_bucket_finish applies w_n / N_P and w_v / N_P (the reference scales every slot by them: vtrace.py:374,389 and
 // rnad.py:424; summing first changes the rounding of the last bit only).  losses_raw[4] += sum d^2 (P = 0, 1), sum -nerd (P = 0, 1).
-template <int A>
+//
+// COMPACT: the trajectory of k_bucket_rollout<A, true> -- indices [T + 1, B], the lane's packed actions and its one reward -- played
+// with the pi columns of these very records as the actor: the acting policy of a slot is read from its record (on-policy:
+// mu == pi, the same floats the rollout sampled from) instead of a [T, B, A] buffer.  Same arithmetic, same sums.
+template <int A, bool COMPACT>
 __global__ __launch_bounds__(kThreads) void k_bucket_learn(int T, int64_t B, int64_t S, int sub_rows, int n_groups, int up_stride,
                                                            const Item *__restrict__ items, const int32_t *__restrict__ n_items,
                                                            const int32_t *__restrict__ bucket_of, const int32_t *__restrict__ bucket_lo,
                                                            const int32_t *__restrict__ bucket_path, const int32_t *__restrict__ indices,
                                                            const int32_t *__restrict__ actions, const float *__restrict__ rewards,
                                                            const float *__restrict__ mu_, const float *__restrict__ rec_,
-                                                           rnad_learn_params_t hp, FixedPoint fx, unsigned long long *__restrict__ acc,
+                                                           const unsigned long long *__restrict__ acts_,
+                                                           const float *__restrict__ reward_, rnad_learn_params_t hp, FixedPoint fx, unsigned long long *__restrict__ acc,
                                                            unsigned long long *__restrict__ rep, double *__restrict__ losses_raw,
                                                            int32_t *__restrict__ overflow) {
     // [kMaxPath path rows][kPathSlots copies][(A + 1) | 1]  |  [sub_rows rows of player 0 | sub_rows rows of player 1][A + 1]
@@ -593,26 +641,32 @@ __global__ __launch_bounds__(kThreads) void k_bucket_learn(int T, int64_t B, int
         // Software pipeline over the time loop: the states of step t - 2 and the slot's inputs of step t - 1 (action, acting policy,
         // reward, the row record -- whose address needs that step's state) are requested before the arithmetic of step t, so the
         // two dependent memory latencies of a step (state -> record) overlap the V-trace / NeuRD arithmetic of its successors.
+        constexpr int kFetch = COMPACT ? RS : kRowLearn<A>;  // floats of a record this variant reads (COMPACT: pi as well)
         struct Slot {
             int act;
             float rew;
             float mu[A];
-            float rec[kRowLearn<A>];
+            float rec[kFetch];
         };
         auto fetch = [&](int t, int state, Slot &o) {
             if (state == 0) return;
             const int64_t i = (int64_t)t * B + j;
             const float4 *rp = reinterpret_cast<const float4 *>(rec_ + ((int64_t)(t & 1) * S + state) * RS);
 #pragma unroll
-            for (int u = 0; u < kRowLearn<A> / 4; ++u) {
+            for (int u = 0; u < kFetch / 4; ++u) {
                 const float4 r4 = rp[u];
                 o.rec[4 * u] = r4.x; o.rec[4 * u + 1] = r4.y; o.rec[4 * u + 2] = r4.z; o.rec[4 * u + 3] = r4.w;
             }
-            o.act = actions[i];
+            if (!COMPACT) {
+                o.act = actions[i];
 #pragma unroll
-            for (int a = 0; a < A; ++a) o.mu[a] = mu_[i * A + a];
-            o.rew = (t & 1) ? rewards[i] : 0.0f;  // row turns carry torch.zeros (episode.py:101)
+                for (int a = 0; a < A; ++a) o.mu[a] = mu_[i * A + a];
+                o.rew = (t & 1) ? rewards[i] : 0.0f;  // row turns carry torch.zeros (episode.py:101)
+            }
         };
+        const unsigned long long acts = (COMPACT && active) ? acts_[j] : 0ull;
+        const float reward_final = (COMPACT && active) ? reward_[j] : 0.0f;
+        int s_after = (COMPACT && active) ? indices[(int64_t)T * B + j] : 0;  // the state the slot's step led to
         int s_next = active ? indices[(int64_t)(T - 1) * B + j] : 0;
         int s_next2 = (active && T >= 2) ? indices[(int64_t)(T - 2) * B + j] : 0;
         Slot nxt;
@@ -629,20 +683,21 @@ __global__ __launch_bounds__(kThreads) void k_bucket_learn(int T, int64_t B, int
 #pragma unroll
             for (int a = 0; a <= A; ++a) q[a] = 0;
             if (valid) {
-                const int act = cur.act;
+                const int act = COMPACT ? (int)(acts >> (3 * t)) & 7 : cur.act;
                 const float *rec = cur.rec;  // this row's record (k_row_records)
                 const uint32_t bits = __float_as_uint(rec[3 * A + 2]);
                 float mu[A], lg[A], pip[A], lpol[A], legal[A], oh[A];
 #pragma unroll
                 for (int a = 0; a < A; ++a) {
-                    mu[a] = cur.mu[a];
+                    mu[a] = COMPACT ? rec[(3 * A + 3 + a) % kFetch] : cur.mu[a];  // (% kFetch: in range in the variant that never reads it)
                     lg[a] = rec[a];
                     pip[a] = rec[A + 2 + a];    // process_policy(pi) of the learner (rnad.py:374)
                     lpol[a] = rec[2 * A + 2 + a];  // log_policy_reg (rnad.py:382)
                     legal[a] = (float)((bits >> a) & 1);
                     oh[a] = act == a ? 1.0f : 0.0f;
                 }
-                const float rew = cur.rew;
+                // COMPACT: rewards *= (indices == 0) (episode.py:120-121) -- only the step into state 0 carries the lane's reward
+                const float rew = COMPACT ? (((t & 1) && s_after == 0) ? reward_final : 0.0f) : cur.rew;
                 const float vtn = rec[A + 1];
                 float vt[2], qv[2][A];
                 vtrace_step<A>(cy[0], vh, true, P == 0, 1.0f, vtn, rew, mu, pip, lpol, oh, vt[0], qv[0]);   // player 0 (rnad.py:384-406)
@@ -666,6 +721,7 @@ __global__ __launch_bounds__(kThreads) void k_bucket_learn(int T, int64_t B, int
                 cy[0] = Carry{};  // reset_carry (vtrace.py:320)
                 cy[1] = Carry{};
             }
+            s_after = state;
             if (t < n_path) {  // a step above the bucket state: one row for the whole workgroup, kPathSlots copies of it in LDS
                 if (threadIdx.x == 0 && base == 0) path_state[t] = state;
                 if (valid) {
@@ -879,22 +935,29 @@ extern "C" int rnad_bucket_records(const rnad_tree_t *tree, const float *logit_t
     return 0;
 }
 
-extern "C" int rnad_rollout_bucketed(const rnad_tree_t *tree, const rnad_traj_t *tr, const float *table, int64_t table_stride,
-                                     int table_is_policy, const float *value_table, int64_t value_stride, uint64_t seed, int64_t lane0,
-                                     const rnad_step_params_t *device_params, void *scratch, int32_t *lane_ids, int32_t *items,
-                                     int32_t *n_items, double *norm, void *stream_) {
-    RNAD_REQUIRE(tree && tr && table && scratch && lane_ids && items && n_items, "rnad_rollout_bucketed: null argument");
-    RNAD_REQUIRE(tr->indices && tr->mask_bits && tr->policy && tr->actions && tr->rewards && tr->alive,
-                 "rnad_rollout_bucketed: trajectory has a null buffer");
-    RNAD_REQUIRE(tr->T_cap >= 1 && tr->T_cap <= kMaxSteps && tr->B >= 1, "rnad_rollout_bucketed: bad trajectory shape T_cap=%d B=%lld",
-                 tr->T_cap, (long long)tr->B);
-    RNAD_REQUIRE(table_stride >= tree->A && (!value_table || value_stride >= 1), "rnad_rollout_bucketed: bad table stride");
+namespace {
+struct RolloutBuffers {  // the dense trajectory (rnad_traj_t) or the compact one
+    int T_cap;
+    int64_t B;
+    int32_t *indices;
+    uint8_t *mask_bits;
+    float *policy;
+    int32_t *actions;
+    float *rewards, *values;
+    int32_t *alive;
+    unsigned long long *acts;  // compact: 3 bits per step
+    float *final_reward;       // compact
+};
+
+int rollout_bucketed_impl(const rnad_tree_t *tree, const RolloutBuffers &tr, bool compact, const float *table, int64_t table_stride,
+                          int table_is_policy, const float *value_table, int64_t value_stride, uint64_t seed, int64_t lane0,
+                          const rnad_step_params_t *device_params, void *scratch, int32_t *lane_ids, int32_t *items, int32_t *n_items,
+                          double *norm, hipStream_t stream) {
     Plan p;
-    RNAD_REQUIRE(make_plan(tree, tr->B, p), "rnad_rollout_bucketed: this tree / batch cannot be bucketed (see rnad_bucket_plan)");
-    hipStream_t stream = (hipStream_t)stream_;
-    const int64_t B = tr->B, S = tree->S;
+    RNAD_REQUIRE(make_plan(tree, tr.B, p), "rnad_rollout_bucketed: this tree / batch cannot be bucketed (see rnad_bucket_plan)");
+    const int64_t B = tr.B, S = tree->S;
     const Scratch s = carve_scratch(scratch, B, p);
-    const int n_steps = std::min(p.cut->max_path, (int)tr->T_cap), nb = p.cut->n_buckets;
+    const int n_steps = std::min(p.cut->max_path, tr.T_cap), nb = p.cut->n_buckets;
     ProfScope prof(PROF_ACT, stream);
     const float *policy_tab = table;
     int64_t policy_stride = table_stride;
@@ -913,42 +976,110 @@ extern "C" int rnad_rollout_bucketed(const rnad_tree_t *tree, const rnad_traj_t 
     const size_t lds = (size_t)nb * sizeof(int32_t);
     {
         ProfScope sort_passes(PROF_BUCKET_SORT, stream);
-    hipLaunchKernelGGL(k_bucket_hist, dim3(p.sort_blocks), dim3(kSortThreads), lds, stream, B, nb, (const int32_t *)s.keys, s.hist);
-    hipLaunchKernelGGL(k_bucket_scan, dim3((nb + 63) / 64), dim3(kSortThreads), 0, stream, p.sort_blocks, nb, s.hist,
-                       s.totals);
-    hipLaunchKernelGGL(k_bucket_items, dim3(1), dim3(kSortThreads), 0, stream, nb, p.chunk, (const int32_t *)s.totals, s.bucket_start,
-                       (Item *)items, n_items);
-    hipLaunchKernelGGL(k_bucket_scatter, dim3(p.sort_blocks), dim3(kSortThreads), lds, stream, B, nb, (const int32_t *)s.keys,
-                       (const int32_t *)s.hist, (const int32_t *)s.bucket_start, lane_ids);
+        hipLaunchKernelGGL(k_bucket_hist, dim3(p.sort_blocks), dim3(kSortThreads), lds, stream, B, nb, (const int32_t *)s.keys, s.hist);
+        hipLaunchKernelGGL(k_bucket_scan, dim3((nb + 63) / 64), dim3(kSortThreads), 0, stream, p.sort_blocks, nb, s.hist, s.totals);
+        hipLaunchKernelGGL(k_bucket_items, dim3(1), dim3(kSortThreads), 0, stream, nb, p.chunk, (const int32_t *)s.totals, s.bucket_start,
+                           (Item *)items, n_items);
+        hipLaunchKernelGGL(k_bucket_scatter, dim3(p.sort_blocks), dim3(kSortThreads), lds, stream, B, nb, (const int32_t *)s.keys,
+                           (const int32_t *)s.hist, (const int32_t *)s.bucket_start, lane_ids);
     }
     RNAD_HIP_OK(hipGetLastError());
     const unsigned grid = blocks_for(B);
     {
         ProfScope one(PROF_BUCKET_ROLLOUT, stream);
-        RNAD_DISPATCH_A(tree->A, hipLaunchKernelGGL((k_bucket_rollout<kA>), dim3(grid), dim3(kThreads), 0, stream, tree->trans, tree->C, S, B,
-                                                    (int)tr->T_cap, policy_tab, policy_stride, value_table, value_stride,
-                                                    (const uint8_t *)tree->mask_tab, seed, device_params, lane0,
-                                                    (const int32_t *)lane_ids, (const unsigned long long *)s.decisions, tr->indices,
-                                                    tr->mask_bits, tr->policy, tr->actions,
-                                                    tr->rewards, tr->values, s.alive_part));
+#define RNAD_BUCKET_ROLLOUT(COMPACT)                                                                                                     \
+    hipLaunchKernelGGL((k_bucket_rollout<kA, COMPACT>), dim3(grid), dim3(kThreads), 0, stream, tree->trans, tree->C, S, B, tr.T_cap,         \
+                       policy_tab, policy_stride, value_table, value_stride, (const uint8_t *)tree->mask_tab, seed, device_params, lane0,   \
+                       (const int32_t *)lane_ids, (const unsigned long long *)s.decisions, tr.indices, tr.mask_bits, tr.policy, tr.actions, \
+                       tr.rewards, tr.values, s.alive_part, tr.acts, tr.final_reward)
+        if (compact) {
+            RNAD_DISPATCH_A(tree->A, RNAD_BUCKET_ROLLOUT(true));
+        } else {
+            RNAD_DISPATCH_A(tree->A, RNAD_BUCKET_ROLLOUT(false));
+        }
+#undef RNAD_BUCKET_ROLLOUT
     }
-    hipLaunchKernelGGL(k_bucket_alive, dim3(tr->T_cap + 1), dim3(kThreads), 0, stream, (int)grid, (int)tr->T_cap + 1,
-                       (const int32_t *)s.alive_part, tr->alive, norm);
+    hipLaunchKernelGGL(k_bucket_alive, dim3(tr.T_cap + 1), dim3(kThreads), 0, stream, (int)grid, tr.T_cap + 1, (const int32_t *)s.alive_part,
+                       tr.alive, norm);
+    RNAD_HIP_OK(hipGetLastError());
+    return 0;
+}
+}  // namespace
+
+extern "C" int rnad_rollout_bucketed(const rnad_tree_t *tree, const rnad_traj_t *tr, const float *table, int64_t table_stride,
+                                     int table_is_policy, const float *value_table, int64_t value_stride, uint64_t seed, int64_t lane0,
+                                     const rnad_step_params_t *device_params, void *scratch, int32_t *lane_ids, int32_t *items,
+                                     int32_t *n_items, double *norm, void *stream) {
+    RNAD_REQUIRE(tree && tr && table && scratch && lane_ids && items && n_items, "rnad_rollout_bucketed: null argument");
+    RNAD_REQUIRE(tr->indices && tr->mask_bits && tr->policy && tr->actions && tr->rewards && tr->alive,
+                 "rnad_rollout_bucketed: trajectory has a null buffer");
+    RNAD_REQUIRE(tr->T_cap >= 1 && tr->T_cap <= kMaxSteps && tr->B >= 1, "rnad_rollout_bucketed: bad trajectory shape T_cap=%d B=%lld",
+                 tr->T_cap, (long long)tr->B);
+    RNAD_REQUIRE(table_stride >= tree->A && (!value_table || value_stride >= 1), "rnad_rollout_bucketed: bad table stride");
+    const RolloutBuffers out{(int)tr->T_cap, tr->B, tr->indices, tr->mask_bits, tr->policy, tr->actions, tr->rewards, tr->values, tr->alive,
+                             nullptr, nullptr};
+    return rollout_bucketed_impl(tree, out, false, table, table_stride, table_is_policy, value_table, value_stride, seed, lane0, device_params,
+                                 scratch, lane_ids, items, n_items, norm, (hipStream_t)stream);
+}
+
+extern "C" int rnad_rollout_bucketed_compact(const rnad_tree_t *tree, int T_cap, int64_t B, const float *records, uint64_t seed, int64_t lane0,
+                                             const rnad_step_params_t *device_params, void *scratch, int32_t *lane_ids, int32_t *items,
+                                             int32_t *n_items, double *norm, int32_t *indices, int32_t *alive, uint64_t *acts,
+                                             float *final_reward, void *stream) {
+    RNAD_REQUIRE(tree && records && scratch && lane_ids && items && n_items && indices && alive && acts && final_reward,
+                 "rnad_rollout_bucketed_compact: null argument");
+    RNAD_REQUIRE(T_cap >= 1 && T_cap <= kCompactSteps && B >= 1, "rnad_rollout_bucketed_compact: 1 <= T_cap <= %d (3 bits per step), got %d",
+                 kCompactSteps, T_cap);
+    static_assert(RNAD_MAX_ACTIONS <= 8, "3 bits per action");
+    const RolloutBuffers out{T_cap, B, indices, nullptr, nullptr, nullptr, nullptr, nullptr, alive, (unsigned long long *)acts, final_reward};
+    return rollout_bucketed_impl(tree, out, true, records + 3 * tree->A + 3, rnad_bucket_record_stride(tree->A), 1, nullptr, 1, seed, lane0,
+                                 device_params, scratch, lane_ids, items, n_items, norm, (hipStream_t)stream);
+}
+
+// The dense buffers of a compact trajectory: slot (t, j) from indices[t, j] (and indices[t + 1, j] for the reward) alone.
+namespace {
+template <int A>
+__global__ __launch_bounds__(kThreads) void k_bucket_expand(int T, int64_t B, int64_t S, const int32_t *__restrict__ indices,
+                                                            const unsigned long long *__restrict__ acts,
+                                                            const float *__restrict__ final_reward, const float *__restrict__ rec_,
+                                                            const uint8_t *__restrict__ mask_tab, uint8_t *__restrict__ mbits,
+                                                            float *__restrict__ policy, int32_t *__restrict__ actions,
+                                                            float *__restrict__ rewards) {
+    const int64_t j = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    const int t = blockIdx.y;
+    if (j >= B) return;
+    const int64_t i = (int64_t)t * B + j;
+    const int state = indices[i];
+    const int64_t row = (int64_t)(t & 1) * S + state;  // an absorbed slot shows the row of state 0, as the dense rollout writes it
+    mbits[i] = mask_tab[row];
+#pragma unroll
+    for (int a = 0; a < A; ++a) policy[i * A + a] = rec_[row * kRowStride<A> + 3 * A + 3 + a];
+    actions[i] = state != 0 ? (int)(acts[j] >> (3 * t)) & 7 : 0;
+    rewards[i] = ((t & 1) && state != 0 && indices[i + B] == 0) ? final_reward[j] : 0.0f;
+}
+}  // namespace
+
+extern "C" int rnad_bucket_expand(const rnad_tree_t *tree, int T, int64_t B, const int32_t *indices, const uint64_t *acts,
+                                  const float *final_reward, const float *records, uint8_t *mask_bits, float *policy, int32_t *actions,
+                                  float *rewards, void *stream) {
+    RNAD_REQUIRE(tree && indices && acts && final_reward && records && mask_bits && policy && actions && rewards,
+                 "rnad_bucket_expand: null argument");
+    RNAD_REQUIRE(T >= 1 && T <= kCompactSteps && B >= 1, "rnad_bucket_expand: bad shape");
+    RNAD_DISPATCH_A(tree->A, hipLaunchKernelGGL((k_bucket_expand<kA>), dim3(blocks_for(B), (unsigned)T), dim3(kThreads), 0, (hipStream_t)stream,
+                                                T, B, tree->S, indices, (const unsigned long long *)acts, final_reward, records,
+                                                (const uint8_t *)tree->mask_tab, mask_bits, policy, actions, rewards));
     RNAD_HIP_OK(hipGetLastError());
     return 0;
 }
 
-extern "C" int rnad_learn_bucketed(const rnad_tree_t *tree, int T, int64_t B, const int32_t *indices, const int32_t *actions,
-                                   const float *rewards, const float *mu, const float *records, const int32_t *items,
-                                   const int32_t *n_items, const double *norm, const rnad_learn_params_t *hp, void *accumulators,
-                                   double *losses, float *dlogit_tab, float *dv_tab, void *stream_) {
-    RNAD_REQUIRE(tree && indices && actions && rewards && mu && records && items && n_items && norm && hp && accumulators && dlogit_tab &&
-                     dv_tab,
-                 "rnad_learn_bucketed: null argument");
-    RNAD_REQUIRE(T >= 1 && B >= 1, "rnad_learn_bucketed: bad shape");
+namespace {
+int learn_bucketed_impl(const rnad_tree_t *tree, int T, int64_t B, const int32_t *indices, const int32_t *actions, const float *rewards,
+                        const float *mu, const unsigned long long *acts, const float *final_reward, const float *records,
+                        const int32_t *items, const int32_t *n_items, const double *norm, const rnad_learn_params_t *hp,
+                        void *accumulators, double *losses, float *dlogit_tab, float *dv_tab, hipStream_t stream) {
+    const bool compact = acts != nullptr;
     Plan p;
     RNAD_REQUIRE(make_plan(tree, B, p), "rnad_learn_bucketed: this tree / batch cannot be bucketed (see rnad_bucket_plan)");
-    hipStream_t stream = (hipStream_t)stream_;
     const int64_t S = tree->S, A1 = tree->A + 1;
     unsigned long long *acc = (unsigned long long *)accumulators;
     unsigned long long *rep = acc + 2 * S * A1;
@@ -960,19 +1091,22 @@ extern "C" int rnad_learn_bucketed(const rnad_tree_t *tree, int T, int64_t B, co
     // seen to write garbage after ~57 replays on ROCm 7.2 (tests/test_hip_graph.py::test_many_replays_stay_finite)
     hipLaunchKernelGGL(k_zero_words, dim3(1), dim3(64), 0, stream, (uint32_t *)losses_raw, (int)((4 * sizeof(double) + sizeof(int32_t)) / 4));
     ProfScope prof(PROF_LEARN, stream);
-#define RNAD_BUCKET_LEARN()                                                                                                           \
+#define RNAD_BUCKET_LEARN(COMPACT)                                                                                                    \
     do {                                                                                                                              \
-        auto kern = k_bucket_learn<kA>;                                                                                               \
+        auto kern = k_bucket_learn<kA, COMPACT>;                                                                                      \
         if (p.lds > 48 * 1024) RNAD_HIP_OK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, p.lds)); \
         hipLaunchKernelGGL(kern, dim3((unsigned)p.max_items), dim3(kThreads), (size_t)p.lds, stream, T, B, S, p.cut->rows,            \
                            p.cut->n_groups, std::max(nu, 1), (const Item *)items, n_items, (const int32_t *)p.cut->bucket_of,         \
                            (const int32_t *)p.cut->bucket_lo, (const int32_t *)p.cut->bucket_path, indices, actions, rewards, mu,     \
-                           records, *hp, fx, acc, rep,                                                                                \
-                           losses ? losses_raw : (double *)nullptr, overflow);                                                        \
+                           records, acts, final_reward, *hp, fx, acc, rep, losses ? losses_raw : (double *)nullptr, overflow);        \
     } while (0)
     {
         ProfScope one(PROF_BUCKET_LEARN, stream);
-        RNAD_DISPATCH_A(tree->A, RNAD_BUCKET_LEARN());
+        if (compact) {
+            RNAD_DISPATCH_A(tree->A, RNAD_BUCKET_LEARN(true));
+        } else {
+            RNAD_DISPATCH_A(tree->A, RNAD_BUCKET_LEARN(false));
+        }
     }
 #undef RNAD_BUCKET_LEARN
     RNAD_HIP_OK(hipGetLastError());
@@ -985,4 +1119,28 @@ extern "C" int rnad_learn_bucketed(const rnad_tree_t *tree, int T, int64_t B, co
                                                 dlogit_tab, dv_tab));
     RNAD_HIP_OK(hipGetLastError());
     return 0;
+}
+}  // namespace
+
+extern "C" int rnad_learn_bucketed(const rnad_tree_t *tree, int T, int64_t B, const int32_t *indices, const int32_t *actions,
+                                   const float *rewards, const float *mu, const float *records, const int32_t *items,
+                                   const int32_t *n_items, const double *norm, const rnad_learn_params_t *hp, void *accumulators,
+                                   double *losses, float *dlogit_tab, float *dv_tab, void *stream) {
+    RNAD_REQUIRE(tree && indices && actions && rewards && mu && records && items && n_items && norm && hp && accumulators && dlogit_tab &&
+                     dv_tab,
+                 "rnad_learn_bucketed: null argument");
+    RNAD_REQUIRE(T >= 1 && B >= 1, "rnad_learn_bucketed: bad shape");
+    return learn_bucketed_impl(tree, T, B, indices, actions, rewards, mu, nullptr, nullptr, records, items, n_items, norm, hp, accumulators,
+                               losses, dlogit_tab, dv_tab, (hipStream_t)stream);
+}
+
+extern "C" int rnad_learn_bucketed_compact(const rnad_tree_t *tree, int T, int64_t B, const int32_t *indices, const uint64_t *acts,
+                                           const float *final_reward, const float *records, const int32_t *items, const int32_t *n_items,
+                                           const double *norm, const rnad_learn_params_t *hp, void *accumulators, double *losses,
+                                           float *dlogit_tab, float *dv_tab, void *stream) {
+    RNAD_REQUIRE(tree && indices && acts && final_reward && records && items && n_items && norm && hp && accumulators && dlogit_tab && dv_tab,
+                 "rnad_learn_bucketed_compact: null argument");
+    RNAD_REQUIRE(T >= 1 && T <= kCompactSteps && B >= 1, "rnad_learn_bucketed_compact: bad shape");
+    return learn_bucketed_impl(tree, T, B, indices, nullptr, nullptr, nullptr, (const unsigned long long *)acts, final_reward, records, items,
+                               n_items, norm, hp, accumulators, losses, dlogit_tab, dv_tab, (hipStream_t)stream);
 }

@@ -115,8 +115,10 @@ class Episodes:
     """A parallel batch of rollout trajectories from the root (reference episode.py:131-290)."""
 
     _PRIMARY = ("indices", "observations", "mask_bits", "policy", "action_idx", "rewards", "values")
+    _DENSE = {"mask_bits": "mask_bits", "policy": "policy", "action_idx": "actions", "rewards": "rewards"}  # attribute -> Trajectory buffer
     _observations = _values = None  # class-level defaults: objects assembled without __init__ (tests, collate) behave the same
     lane_ids = buckets = None
+    _compact = None  # (rnad_hip.Trajectory(compact=True), records) of a compact bucketed rollout: dense fields expand on first access
 
     def __init__(self, tree: Tree, batch_size, seed=None, lane_offset=0, obs_half=False):
         self.tree: Tree = tree
@@ -132,6 +134,7 @@ class Episodes:
         self.indices = self.mask_bits = self.policy = None
         self.action_idx = self.rewards = None
         self._observations = self._values = None  # lazily materialised when the rollout did not store them (bucketed rollout)
+        self._compact = None
         self.lane_ids = None  # int32 [B]: lane (0-based within this batch) held by column j; None = column j is lane j
         self.buckets = None   # rnad_hip.Buckets of a bucket-ordered batch (work list of rnad_learn_bucketed)
         self.alive = None  # int32 [T + 1] on the device: lanes with indices[t] != 0
@@ -172,6 +175,16 @@ class Episodes:
     def values(self, value):
         self._values = value
 
+    def _expand(self):
+        """Dense mask_bits / policy / action_idx / rewards of a compact rollout (rnad_bucket_expand), on first access."""
+        traj, records = self._compact
+        if traj.policy is None:
+            rnad_hip.bucket_expand(self.tree.handle(), traj, records)
+        T = self.t_eff + 1
+        for name, src in self._DENSE.items():
+            if self.__dict__.get("_" + name) is None:
+                self.__dict__["_" + name] = getattr(traj, src)[:T]
+
     @property
     def turns(self):
         """[T, B] int64, == t mod 2 for every lane (episode.py:197); an expanded view, no memory."""
@@ -210,7 +223,8 @@ class Episodes:
 
     # ---------------------------------------------------------------- episode.py:175-230
     def generate(self, net: torch.nn.Module, noise_action=None, noise_chance=None, max_steps=None, trim=True, keep_logits=False,
-                 skip_absorbed=False, store_values=True, tabular=None, bucketed=False, logits_table=None, value_table=None, policy_table=None, step_params=None):
+                 skip_absorbed=False, store_values=True, tabular=None, bucketed=False, logits_table=None, value_table=None, policy_table=None, step_params=None,
+                 compact=False):
         """Play the batch to the end with `net` as the actor.
 
         Nets exposing `forward_logits(obs) -> (logits [B,A], value [B,1])` (the MLP here) take the fast path: policy head,
@@ -243,6 +257,12 @@ class Episodes:
         step_params (bucketed only): a device int64 [2] holding struct rnad_step_params; the kernels then take the noise seed from
         there instead of `self.seed` (a captured graph of the step is replayed with a new seed).
 
+        compact=True (bucketed with policy_table = (rnad_hip.bucket_records(...), rnad_hip.policy_column(A)), store_values=False,
+        at most 21 steps): the rollout stores 64 bytes per lane -- `indices`, the packed actions and the episode's one non-zero
+        reward (rnad_rollout_bucketed_compact) -- which is all RNaD's on-policy update reads; `mask_bits`, `policy`, `action_idx`,
+        `rewards` (and what derives from them) are written by rnad_bucket_expand on first access.  Slots of absorbed lanes then show
+        action 0 where the dense rollout keeps drawing (nothing reads them).
+
         store_values=False (native MLP actor only): the actor's value head is not evaluated and `values` is zeros.  The
         reference stores the actor's values (episode.py:206,218) but nothing ever reads them (learn/rnad.py:373 recomputes v
         with the learner net), so RNaD's own rollouts do without, unless `reuse_actor_outputs` needs them.
@@ -262,9 +282,11 @@ class Episodes:
             tabular = 8 * handle.S <= T_cap * B
         tabular = native and tabular and not keep_logits
         bucketed = bool(bucketed) and tabular and T_cap <= 64 and rnad_hip.bucket_plan(handle, B) is not None
+        compact = (bool(compact) and bucketed and policy_table is not None and not store_values and T_cap <= rnad_hip.COMPACT_MAX_STEPS
+                   and policy_table[1] == rnad_hip.policy_column(tree.max_actions))
         traj = rnad_hip.Trajectory(handle, B, T_cap, dev, half=self.obs_half, with_observations=not bucketed,
-                                   with_values=store_values or not bucketed)
-        self.buckets = self.lane_ids = None
+                                   with_values=store_values or not bucketed, compact=compact)
+        self.buckets = self.lane_ids = self._compact = None
         if tabular:
             # one actor evaluation per (player, state), then the whole loop natively with per-lane gathers
             table, vtable = logits_table, value_table
@@ -272,7 +294,12 @@ class Episodes:
                 packed = packed if packed is not None else net.pack()
                 table, vtable = rnad_hip.mlp_forward(packed, net.width, handle.observations_table(self.obs_half), tree.max_actions,
                                                      want_value=store_values)
-            if bucketed and policy_table is not None:
+            if compact:
+                self.buckets = rnad_hip.rollout_bucketed_compact(handle, traj, policy_table[0], seed=self.seed, lane0=self.lane_offset,
+                                                                 step_params=step_params)
+                self.lane_ids = self.buckets.lane_ids
+                self._compact = (traj, policy_table[0])
+            elif bucketed and policy_table is not None:
                 self.buckets = rnad_hip.rollout_bucketed(handle, traj, policy_table[0], vtable if store_values else None, seed=self.seed,
                                                          lane0=self.lane_offset, table_is_policy=True, column=policy_table[1],
                                                          step_params=step_params)
@@ -319,10 +346,8 @@ class Episodes:
         self.t_eff = T - 1
         self.indices = traj.indices[:T]
         self.observations = traj.observations[:T] if traj.observations is not None else None
-        self.mask_bits = traj.mask_bits[:T]
-        self.policy = traj.policy[:T]
-        self.action_idx = traj.actions[:T]
-        self.rewards = traj.rewards[:T]
+        for name, src in self._DENSE.items():
+            setattr(self, name, None if compact else getattr(traj, src)[:T])
         self.values = traj.values[:T] if traj.values is not None else None
         self.alive = traj.alive[: T + 1]
         if self.actor_logits is not None:
@@ -411,6 +436,27 @@ class Episodes:
         result.alive = alive
         result.t_eff = t_eff
         return result
+
+
+def _dense_field(name):
+    """mask_bits / policy / action_idx / rewards: plain attributes, except that a compact rollout fills them on first access."""
+    private = "_" + name
+
+    def get(self):
+        value = self.__dict__.get(private)
+        if value is None and self.__dict__.get("_compact") is not None:
+            self._expand()
+            value = self.__dict__.get(private)
+        return value
+
+    def put(self, value):
+        self.__dict__[private] = value
+
+    return property(get, put)
+
+
+for _name in Episodes._DENSE:
+    setattr(Episodes, _name, _dense_field(_name))
 
 
 class Buffer:

@@ -143,6 +143,9 @@ class RNaD:
         self.tabular = True
         self.tabular_gate = 8
         self.use_graph = True  # capture the on-policy tabular step as a hipGraph and replay it (train_step)
+        # the on-policy step keeps 64 bytes per lane of its batch (states, packed actions, one reward): csrc/bucket.hip COMPACT;
+        # the dense Episodes fields are written when something reads them
+        self.compact_trajectory = True
         self.fused_optimizer = True  # clip + Adam + EMA target of the MLP in one launch (csrc/optim.hip) instead of ~8 torch launches
         # ragged trajectories: evaluate / differentiate the nets on live (t, b) slots only (see __learn); same losses and gradients
         self.skip_absorbed = True
@@ -480,9 +483,15 @@ class RNaD:
             records = tables.get("records")
             if records is None:
                 records = rnad_hip.bucket_records(self.tree.handle(), logit, v, v_target, logit_reg, logit_reg_, hp)
-            dlogit, dv, losses = rnad_hip.learn_bucketed(self.tree.handle(), episodes.buckets, episodes.indices[:T], episodes.action_idx[:T],
-                                                         episodes.rewards[:T], episodes.policy[:T], records, norm, hp,
-                                                         want_losses=log is not None)
+            compact = getattr(episodes, "_compact", None)
+            if compact is not None and compact[1] is records:
+                # the batch was played this very step with the pi columns of these records as the actor: 64 bytes per lane
+                dlogit, dv, losses = rnad_hip.learn_bucketed_compact(self.tree.handle(), episodes.buckets, compact[0], T, records, norm, hp,
+                                                                     want_losses=log is not None)
+            else:
+                dlogit, dv, losses = rnad_hip.learn_bucketed(self.tree.handle(), episodes.buckets, episodes.indices[:T], episodes.action_idx[:T],
+                                                             episodes.rewards[:T], episodes.policy[:T], records, norm, hp,
+                                                             want_losses=log is not None)
             pi = None
             backward_obs = table
         elif table is not None:
@@ -607,7 +616,7 @@ class RNaD:
                               logits_table=tables["logit"] if tables is not None else None,
                               value_table=tables["v"] if tables is not None and store_values else None,
                               policy_table=(tables["records"], rnad_hip.policy_column(self.tree.max_actions)) if tables is not None else None,
-                              step_params=step_params)
+                              step_params=step_params, compact=getattr(self, "compact_trajectory", True))
             episodes._actor_tag = (id(self.net), self.total_steps)
             buffer.append(episodes)
             self.last_episodes = episodes
@@ -692,7 +701,7 @@ class RNaD:
                 self.batch_size, self.tabular, getattr(self, "tabular_gate", 8), self.eta, self.beta, self.neurd_clip, self.grad_clip,
                 self.c_bar, self.roh_bar, self.vtrace_gamma, self.value_weight, self.neurd_weight, self.epsilon_threshold, self.n_discrete,
                 self.gamma_averaging, getattr(self, "obs_half", False), getattr(self, "store_actor_values", False), getattr(self, "fused_optimizer", True),
-                os.environ.get("RNAD_BUCKET_ROWS"), os.environ.get("RNAD_BUCKET_CHUNK"))
+                getattr(self, "compact_trajectory", True), os.environ.get("RNAD_BUCKET_ROWS"), os.environ.get("RNAD_BUCKET_CHUNK"))
 
     def _graph_step(self, buffer, alpha):
         g = getattr(self, "_graph", None)

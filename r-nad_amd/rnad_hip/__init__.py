@@ -375,12 +375,22 @@ class FusedMLPRows(torch.autograd.Function):
 class Trajectory:
     """Preallocated [T_cap, B, ...] device buffers of one batch of episodes (struct rnad_traj)."""
 
-    def __init__(self, tree, B, T_cap, device, half=False, with_observations=True, with_values=True):
+    def __init__(self, tree, B, T_cap, device, half=False, with_observations=True, with_values=True, compact=False):
         """with_observations / with_values = False: those buffers are not allocated (bucketed rollout: observations are a function
-        of (t & 1, indices) and are materialised on demand; the actor's values are only stored when asked for)."""
+        of (t & 1, indices) and are materialised on demand; the actor's values are only stored when asked for).
+        compact=True (rollout_bucketed_compact): only indices, alive, `acts` (int64 [B], 3 bits per step) and `final_reward` [B]
+        exist; mask_bits / policy / actions / rewards are None until bucket_expand fills them."""
         A = tree.A
         self.T_cap, self.B, self.A, self.half = T_cap, B, A, half
+        self.compact = bool(compact)
         self.indices = torch.empty((T_cap + 1, B), dtype=I32, device=device)
+        if compact:
+            self.observations = self.mask_bits = self.policy = self.actions = self.rewards = self.values = None
+            self.acts = torch.empty((B,), dtype=torch.int64, device=device)
+            self.final_reward = torch.empty((B,), dtype=F32, device=device)
+            self.alive = torch.empty((T_cap + 1,), dtype=I32, device=device)
+            self.c = None
+            return
         self.observations = torch.empty((T_cap, B, 2, A, A), dtype=F16 if half else F32, device=device) if with_observations else None
         self.mask_bits = torch.empty((T_cap, B), dtype=U8, device=device)
         self.policy = torch.empty((T_cap, B, A), dtype=F32, device=device)
@@ -638,6 +648,56 @@ def rollout_bucketed(tree, traj, table, value_table=None, seed=0, lane0=0, table
                                        _dp(buckets.lane_ids, I32, "lane_ids"), _dp(buckets.items, I32, "items"),
                                        _dp(buckets.n_items, I32, "n_items"), _dp(buckets.norm, F64, "norm"), _stream()))
     return buckets
+
+
+COMPACT_MAX_STEPS = 21  # 3 bits of action per step in one 64-bit word (csrc/bucket.hip kCompactSteps)
+
+
+def rollout_bucketed_compact(tree, traj, records, seed=0, lane0=0, step_params=None):
+    """rnad_rollout_bucketed_compact: the episodes of rollout_bucketed(table=records, table_is_policy=True, column=policy_column(A))
+    into a Trajectory(compact=True).  Returns the Buckets of the batch."""
+    assert traj.compact and traj.T_cap <= COMPACT_MAX_STEPS
+    plan = bucket_plan(tree, traj.B)
+    if plan is None:
+        raise RnadHipError(lib().rnad_last_error().decode())
+    assert records.shape == (2 * tree.S, int(lib().rnad_bucket_record_stride(tree.A)))
+    buckets = Buckets(plan, traj.indices.device)
+    _check(lib().rnad_rollout_bucketed_compact(tree.ptr, traj.T_cap, traj.B, _dp(records, F32, "records"), seed, lane0,
+                                               _dp(step_params, torch.int64, "step_params", True), _dp(plan.scratch, I32, "scratch"),
+                                               _dp(buckets.lane_ids, I32, "lane_ids"), _dp(buckets.items, I32, "items"),
+                                               _dp(buckets.n_items, I32, "n_items"), _dp(buckets.norm, F64, "norm"),
+                                               _dp(traj.indices, I32, "indices"), _dp(traj.alive, I32, "alive"),
+                                               _dp(traj.acts, torch.int64, "acts"), _dp(traj.final_reward, F32, "final_reward"), _stream()))
+    return buckets
+
+
+def bucket_expand(tree, traj, records):
+    """rnad_bucket_expand: the dense mask_bits / policy / actions / rewards [T_cap, B] buffers of a compact trajectory."""
+    dev, T, B, A = traj.indices.device, traj.T_cap, traj.B, tree.A
+    traj.mask_bits = torch.empty((T, B), dtype=U8, device=dev)
+    traj.policy = torch.empty((T, B, A), dtype=F32, device=dev)
+    traj.actions = torch.empty((T, B), dtype=I32, device=dev)
+    traj.rewards = torch.empty((T, B), dtype=F32, device=dev)
+    _check(lib().rnad_bucket_expand(tree.ptr, T, B, _dp(traj.indices, I32, "indices"), _dp(traj.acts, torch.int64, "acts"),
+                                    _dp(traj.final_reward, F32, "final_reward"), _dp(records, F32, "records"),
+                                    _dp(traj.mask_bits, U8, "mask_bits"), _dp(traj.policy, F32, "policy"), _dp(traj.actions, I32, "actions"),
+                                    _dp(traj.rewards, F32, "rewards"), _stream()))
+
+
+def learn_bucketed_compact(tree, buckets, traj, T, records, norm, hp, want_losses=False):
+    """rnad_learn_bucketed_compact on the first T steps of a compact trajectory played with the pi columns of `records`."""
+    B, A = traj.B, tree.A
+    assert buckets.plan.B == B and traj.compact and 1 <= T <= traj.T_cap
+    dev = traj.indices.device
+    dlogit = torch.empty((2 * tree.S, A), dtype=F32, device=dev)
+    dv = torch.empty((2 * tree.S, 1), dtype=F32, device=dev)
+    losses = torch.empty((2,), dtype=F64, device=dev) if want_losses else None
+    _check(lib().rnad_learn_bucketed_compact(tree.ptr, T, B, _dp(traj.indices, I32, "indices"), _dp(traj.acts, torch.int64, "acts"),
+                                             _dp(traj.final_reward, F32, "final_reward"), _dp(records, F32, "records"),
+                                             _dp(buckets.items, I32, "items"), _dp(buckets.n_items, I32, "n_items"), _dp(norm, F64, "norm"),
+                                             C.byref(hp), _dp(buckets.plan.accumulators, torch.int64, "accumulators"),
+                                             _dp(losses, F64, "losses", True), _dp(dlogit, F32, "dlogit_tab"), _dp(dv, F32, "dv_tab"), _stream()))
+    return dlogit, dv, losses
 
 
 def step_params_set(step_params, seed, alpha):

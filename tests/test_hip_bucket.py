@@ -268,3 +268,77 @@ def test_train_step_modes_agree(name, tmp_path, monkeypatch):
     for a, b in zip(grads[False], grads[True]):
         scale = a.abs().max().item() + 1e-12
         np.testing.assert_allclose(b.cpu().numpy(), a.cpu().numpy(), rtol=1e-4, atol=1e-5 * scale)
+
+
+@pytest.mark.parametrize("name", sorted(TREES))
+@pytest.mark.parametrize("B", (8192, 3000))
+def test_compact_trajectory_is_the_dense_one(name, B):
+    """rnad_rollout_bucketed_compact + rnad_bucket_expand against rnad_rollout_bucketed, and rnad_learn_bucketed_compact against
+    rnad_learn_bucketed: same episodes, same lane order, same gradient tables and losses bit for bit."""
+    import rnad_hip
+    from environment.episode import Episodes
+
+    tree = _native_tree(**TREES[name])
+    h = tree.handle()
+    A = tree.max_actions
+    nets = _four_nets(A, 64, seed=2)
+    logit, v, vt, lr, lr_ = _tables(tree, nets, A)
+    hp = rnad_hip.make_learn_params(alpha=0.3, eta=0.2, w_v=0.7, w_n=1.3)
+    rec = rnad_hip.bucket_records(h, logit, v, vt, lr, lr_, hp)
+    actor = (rec, rnad_hip.policy_column(A))
+    dense = Episodes(tree, B, seed=9, lane_offset=123)
+    dense.generate(nets[0], tabular=True, bucketed=True, trim=False, store_values=False, policy_table=actor)
+    comp = Episodes(tree, B, seed=9, lane_offset=123)
+    comp.generate(nets[0], tabular=True, bucketed=True, trim=False, store_values=False, policy_table=actor, compact=True)
+    assert comp._compact is not None and comp._compact[0].policy is None, "nothing dense may exist before it is asked for"
+    T = dense.t_eff + 1
+    assert comp.t_eff == dense.t_eff and torch.equal(comp.lane_ids, dense.lane_ids) and torch.equal(comp.indices, dense.indices)
+    assert torch.equal(comp.alive, dense.alive) and torch.equal(comp.valid_counts, dense.valid_counts)
+    assert torch.equal(comp.states.indices, dense.states.indices)
+    # the update, before anything expanded the trajectory
+    want = rnad_hip.learn_bucketed(h, dense.buckets, dense.indices, dense.action_idx, dense.rewards, dense.policy, rec, dense.valid_counts, hp,
+                                   want_losses=True)
+    got = rnad_hip.learn_bucketed_compact(h, comp.buckets, comp._compact[0], T, rec, comp.valid_counts, hp, want_losses=True)
+    assert comp._compact[0].policy is None
+    assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1])
+    np.testing.assert_allclose(got[2].cpu().numpy(), want[2].cpu().numpy(), rtol=1e-12)  # f64 sums over the workgroups in any order
+    assert torch.isfinite(got[0]).all() and float(got[0].abs().sum()) > 0
+    # the dense fields on demand
+    live = dense.indices != 0
+    assert torch.equal(comp.policy, dense.policy) and torch.equal(comp.mask_bits, dense.mask_bits) and torch.equal(comp.rewards, dense.rewards)
+    assert torch.equal(comp.action_idx[live], dense.action_idx[live]) and (comp.action_idx[~live] == 0).all()
+    assert torch.equal(comp.masks, dense.masks) and torch.equal(comp.observations, dense.observations)
+    assert torch.equal(comp.actions[live], dense.actions[live])
+    # a proper subset (what a replay buffer draws) is a dense batch
+    sel = torch.arange(0, B, 3, device=DEV)
+    sub = comp.sample(sel.numel(), selected=sel)
+    assert sub._compact is None and torch.equal(sub.policy, dense.policy[:, sel]) and torch.equal(sub.rewards, dense.rewards[:, sel])
+
+
+def test_compact_train_steps_are_the_dense_ones(tmp_path, monkeypatch):
+    """RNaD.train_step with the compact trajectory (default) and with the dense one: identical parameters after several steps."""
+    from environment.episode import Buffer
+    from learn.rnad import RNaD
+
+    monkeypatch.setenv("RNAD_SAVE_DIR", str(tmp_path))
+    tree = _native_tree(**TREES["pruned"])
+    params = {}
+    for compact in (True, False):
+        torch.manual_seed(5)
+        rn = RNaD(tree=tree, device=DEV, directory_name=f"k{int(compact)}", batch_size=1 << 13, eta=0.2, b1_adam=0.0, lr=1e-3,
+                  net_params={"type": "MLP", "max_actions": tree.max_actions, "width": 64})
+        rn.initialize()
+        rn.compact_trajectory = compact
+        rn.use_graph = False
+        buf = Buffer(1)
+        log = {}
+        for i in range(4):
+            rn.train_step(buf, alpha=0.25 * i, log=log if i == 3 else None)
+            rn.total_steps += 1
+        assert (rn.last_episodes._compact is not None) == compact
+        params[compact] = ([p.detach().clone() for p in rn.net.parameters()], dict(log))
+    for a, b in zip(params[True][0], params[False][0]):
+        assert torch.equal(a, b)
+    for k, x in params[False][1].items():
+        if isinstance(x, float):
+            assert params[True][1][k] == pytest.approx(x, rel=1e-6, abs=1e-9), k
