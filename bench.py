@@ -12,8 +12,11 @@ MLP width 256, fp32.  `value` times RNaD's default net-evaluation mode (tabular 
 state) observation -- 132 862 rows for 12.6 M slots --, the rollout is bucket-ordered, the per-slot gradients are summed per row in
 LDS and one backward over the rows gives the weight gradients; the step is replayed from a captured hipGraph); `other_modes` times
 "forward" (backward per slot: bit-identical to dense) and dense (every net on every slot, as the reference does) in the same process.
-N > 1 shards the episodes over the ranks (strong scaling, BASELINE north_star) with one RCCL all-reduce of the 2 loss normalisers
-and one of the 43 KB gradient bucket.
+N > 1: every rank plays and learns from its own 2^20 episodes (weak scaling: the per-GPU work of configs[1] is held fixed, the
+global batch is N x 2^20; --scaling strong shards ONE 2^20 batch over the ranks instead, the north_star's arrangement) with one RCCL
+all-reduce of the 2 loss normalisers (beside the learner kernel) and one of the 43 KB gradient bucket per step.  The N > 1 run
+times the eagerly enqueued step first and then the step replayed from a hipGraph with the RCCL collectives captured inside it,
+under a watchdog: if the captured variant does not finish, the eager measurement is what gets printed.
 
 Prints ONE JSON line on rank 0.  `value` = env steps of all ranks / wall time of the K timed steps (inputs resident in HBM; the
 tree is generated and uploaded before the timed region).  `roofline` is for the kernel that takes the largest share of the step,
@@ -48,7 +51,12 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--batch-log2", type=int, default=20, help="log2 of the GLOBAL episode batch")
+    ap.add_argument("--batch-log2", type=int, default=20,
+                    help="log2 of the episode batch: per GPU under weak scaling (default), of the whole job under --scaling strong")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
+                    help="N > 1: weak = every GPU gets 2^batch-log2 episodes (default); strong = one 2^batch-log2 batch sharded over the GPUs")
+    ap.add_argument("--graph-timeout", type=float, default=120.0,
+                    help="N > 1: seconds the captured-graph leg may take before the eager measurement is printed instead")
     ap.add_argument("--depth", type=int, default=6)
     ap.add_argument("--actions", type=int, default=3)
     ap.add_argument("--transitions", type=int, default=1)
@@ -74,11 +82,19 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    # RNAD_BENCH_REHEARSAL=1: the N > 1 control flow on a one-GPU box -- every rank on cuda:0, gloo transport (RCCL refuses two ranks
+    # on one device; gloo collectives cannot be captured, so the graph leg reports "could not be captured").  Not a measurement.
+    rehearsal = os.environ.get("RNAD_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=device)
 
     import rnad_hip
     from environment.episode import Buffer, Episodes
@@ -86,9 +102,13 @@ def main():
     from learn.rnad import RNaD
 
     A, C, depth = args.actions, args.transitions, args.depth
-    global_batch = 1 << args.batch_log2
-    assert global_batch % world == 0
-    local_batch = global_batch // world
+    if args.scaling == "weak":
+        local_batch = 1 << args.batch_log2
+        global_batch = local_batch * world
+    else:
+        global_batch = 1 << args.batch_log2
+        assert global_batch % world == 0
+        local_batch = global_batch // world
 
     # ---- setup (untimed): tree tables into HBM, nets, optimizer
     t0 = time.perf_counter()
@@ -140,13 +160,28 @@ def main():
 
     # setup (untimed, before the caller's warmup): priming steps, so that every code object, the caching allocator's pools, RCCL's
     # channels and -- in the default mode -- the captured graph of the step exist whatever --warmup is
-    for _ in range(6):
-        one_step()
-    fence()
-    for _ in range(args.warmup):
-        one_step()
-    # ---- timed region: EXACTLY --steps steps between two fences
-    elapsed, _ = timed(args.steps)
+    def timed_leg(use_graph):
+        rn.use_graph = use_graph
+        for _ in range(6):
+            one_step()
+        fence()
+        for _ in range(args.warmup):
+            one_step()
+        # ---- timed region: EXACTLY --steps steps between two fences
+        sec = timed(args.steps)[0]
+        if world > 1:
+            t = torch.tensor([sec], device=device, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            sec = float(t.item())
+        return sec
+
+    legs = {}
+    if world == 1:
+        elapsed = timed_leg(not args.no_graph)
+    else:
+        # the eagerly enqueued step first: RCCL's ordinary path.  The captured step (collectives inside the graph) is measured after
+        # everything the JSON line needs exists, under a watchdog (see below).
+        elapsed = legs["eager"] = timed_leg(False)
     # host cost of enqueueing one step, measured with the queue kept short (a long un-synchronised run measures back-pressure)
     host_s, host_n = 0.0, min(64, args.steps)
     for i in range(host_n):
@@ -188,6 +223,8 @@ def main():
     # ---- the same step in the other net-evaluation modes of RNaD (reported separately, NOT `value`), eager
     variants = {}
     for name, mode in (("dense_nets", False), ("forward", "forward"), ("tabular_nets", True)):
+        if world > 1:
+            break  # the N > 1 lines are for the scaling curve: the other modes are reported at N = 1
         if mode == default_mode or (mode and not rn._fused_mlp()):
             continue
         rn.tabular = mode
@@ -225,16 +262,18 @@ def main():
         rnad_hip.prof_enable(False)
         k1 = (n_obs, obs_ms)
     if world > 1:
-        keys = sorted(variants)
-        t = torch.tensor([elapsed, rollout_s, host_s] + [variants[k] for k in keys], device=device, dtype=torch.float64)
+        t = torch.tensor([rollout_s, host_s], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed, rollout_s, host_s, *rest = t.tolist()
-        variants = dict(zip(keys, rest))
+        rollout_s, host_s = t.tolist()
 
-    if rank == 0:
+    # read back NOW: emit() may be called from the watchdog thread while the device queue is stuck
+    alive = rn.last_episodes.alive.cpu().numpy()[:T]
+
+    def emit(elapsed, replayed, note=None):
+        if rank != 0:
+            return
         # the reference's loop (episode.py:194) runs until every lane is absorbed and counts all B lanes in each of those steps;
         # on the regular c2 tree that is all T = 2 * depth steps, on pruned trees the trailing all-absorbed steps are not counted
-        alive = rn.last_episodes.alive.cpu().numpy()[:T]
         T_ref = int((alive > 0).sum())
         env_steps = global_batch * T_ref * args.steps
         live_slots = int(alive.sum())
@@ -254,13 +293,14 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "strong",
+            "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": "f32" if not args.obs_half else "f32 (fp16 observations)",
             "data": "synthetic",
             "config": {
-                "workload": f"depth-{depth} {A}x{A} matrix tree, C={C}, S={tree.index_tensor.shape[0]}, global batch 2^{args.batch_log2}"
-                            f" episodes x T={T_ref} env steps, MLP width {args.width}"
+                "workload": f"depth-{depth} {A}x{A} matrix tree, C={C}, S={tree.index_tensor.shape[0]}, "
+                            + (f"2^{args.batch_log2} episodes per GPU" if world > 1 and args.scaling == "weak" else f"global batch 2^{args.batch_log2} episodes")
+                            + f" x T={T_ref} env steps, MLP width {args.width}"
                             + (", BASELINE.json configs[1]" if default_workload else
                                f", prune {args.prune[0]}/{args.prune[1]}, threshold {threshold:g} (a BASELINE.json configs[3]/[4]-style variant)"),
                 "global_batch": global_batch, "per_gpu_batch": local_batch, "T": T_ref, "T_buffer": T,
@@ -284,12 +324,45 @@ def main():
             "k1_observe": k1_report(k1, A, args, local_batch),
             "setup": {"tree_generate_and_upload_s": setup_tree_s, "tree_table_bytes": handle.table_bytes},
         }
+        if world > 1:
+            out["legs_ms_per_step"] = {k: v / args.steps * 1e3 for k, v in legs.items()}
+            if note:
+                out["note"] = note
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(tree, args, T)
         print(json.dumps(out), flush=True)
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+
+    if world == 1:
+        emit(elapsed, replayed)
+        return
+    if args.no_graph:
+        emit(elapsed, False)
+    else:
+        # ---- N > 1: the same K steps replayed from a hipGraph with the RCCL collectives captured inside.  A rank that gets stuck
+        # (capture of collectives is the one thing a one-GPU box cannot rehearse) must not cost the run its line: after
+        # --graph-timeout seconds every rank leaves, rank 0 printing the eager measurement first.
+        import threading
+
+        def bail():
+            emit(elapsed, False, note=f"the captured-graph leg did not finish within {args.graph_timeout:g} s: eager measurement")
+            sys.stdout.flush()
+            os._exit(0)
+
+        watchdog = threading.Timer(args.graph_timeout, bail)
+        watchdog.daemon = True
+        watchdog.start()
+        graph_sec = legs["graph"] = timed_leg(True)
+        g = getattr(rn, "_graph", None)
+        flag = torch.tensor([1 if (g and g.get("graph") is not None) else 0], dtype=torch.int32, device=device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        watchdog.cancel()
+        if int(flag.item()) == 1 and graph_sec < elapsed:
+            emit(graph_sec, True)
+        else:
+            emit(elapsed, False, note="eager steps were not slower than the replayed graph" if int(flag.item()) == 1 else
+                 "the step could not be captured on every rank")
+    dist.barrier()
+    dist.destroy_process_group()
 
 
 FP32_PEAK_TFLOPS = 157.3  # fp32 MFMA == fp32 vector peak (/opt/skills/guides/MI355X_MICROARCH.md)

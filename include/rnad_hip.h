@@ -357,6 +357,10 @@ int rnad_learn_fused_gather(const rnad_tree_t *tree, int T, int64_t B, const int
  * trajectory, with the acting policy of a slot read from its record (the very floats the rollout sampled from): same gradients
  * bit for bit.  rnad_bucket_expand writes the dense [T, B] buffers of such a trajectory (mask_bits, policy, actions, rewards) when
  * something asks for them; slots of absorbed lanes get action 0 (the dense rollout keeps drawing there; nothing reads them).
+ *
+ * norm == NULL in rnad_learn_bucketed / rnad_learn_bucketed_compact: the sums stay in `accumulators` (losses, dlogit_tab, dv_tab are
+ * not written) and rnad_bucket_finish completes the update -- so that a data-parallel caller's all-reduce of the normalisers
+ * (learn/vtrace.py:373,388 are batch-global counts) runs beside the learner kernel instead of in front of it.
  * ---------------------------------------------------------------------------------------------- */
 /* Per-step scalars in DEVICE memory (optional everywhere: NULL = use the immediate arguments).  With them a captured hipGraph of a
  * whole training step can be replayed step after step: the host only rewrites these 16 bytes. */
@@ -393,6 +397,8 @@ int rnad_learn_bucketed_compact(const rnad_tree_t *tree, int T, int64_t B, const
                                 const float *final_reward, const float *records, const int32_t *items, const int32_t *n_items,
                                 const double *norm, const rnad_learn_params_t *hp, void *accumulators, double *losses,
                                 float *dlogit_tab, float *dv_tab, void *stream);
+int rnad_bucket_finish(const rnad_tree_t *tree, int64_t B, const double *norm, const rnad_learn_params_t *hp, void *accumulators,
+                       double *losses, float *dlogit_tab, float *dv_tab, void *stream);
 
 /* torch.nn.utils.clip_grad_norm_(parameters, max_norm) of learn/rnad.py:456 over one flat fp32 gradient bucket (all of a net's
  * .grad tensors back to back): g *= min(max_norm / (||g||_2 + 1e-6), 1), in place, one launch.  total_norm: optional device

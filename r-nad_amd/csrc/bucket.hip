@@ -1073,6 +1073,27 @@ extern "C" int rnad_bucket_expand(const rnad_tree_t *tree, int T, int64_t B, con
 }
 
 namespace {
+// upper rows out of their replicas, then sums -> normalised fp32 tables (and the two logged losses)
+int finish_impl(const rnad_tree_t *tree, const Plan &p, const double *norm, const rnad_learn_params_t *hp, void *accumulators, double *losses,
+                float *dlogit_tab, float *dv_tab, hipStream_t stream) {
+    const int64_t S = tree->S, A1 = tree->A + 1;
+    unsigned long long *acc = (unsigned long long *)accumulators;
+    unsigned long long *rep = acc + 2 * S * A1;
+    const int nu = p.cut->n_upper;
+    double *losses_raw = (double *)(rep + (int64_t)kReplicas * 2 * std::max(nu, 1) * A1);
+    int32_t *overflow = (int32_t *)(losses_raw + 4);
+    const FixedPoint fx = fixed_point_for(*hp);
+    ProfScope fin(PROF_BUCKET_FINISH, stream);
+    if (nu > 0)
+        RNAD_DISPATCH_A(tree->A, hipLaunchKernelGGL((k_bucket_upper<kA>), dim3(blocks_for(2 * (int64_t)nu, kThreads / 64)), dim3(kThreads), 0,
+                                                    stream, S, nu, (const int32_t *)p.cut->upper_list, acc, rep));
+    RNAD_DISPATCH_A(tree->A, hipLaunchKernelGGL((k_bucket_finish<kA>), dim3(blocks_for(2 * S)), dim3(kThreads), 0, stream, S, acc, norm,
+                                                hp->w_v, hp->w_n, fx, (const int32_t *)overflow, (const double *)losses_raw, losses,
+                                                dlogit_tab, dv_tab));
+    RNAD_HIP_OK(hipGetLastError());
+    return 0;
+}
+
 int learn_bucketed_impl(const rnad_tree_t *tree, int T, int64_t B, const int32_t *indices, const int32_t *actions, const float *rewards,
                         const float *mu, const unsigned long long *acts, const float *final_reward, const float *records,
                         const int32_t *items, const int32_t *n_items, const double *norm, const rnad_learn_params_t *hp,
@@ -1110,24 +1131,24 @@ int learn_bucketed_impl(const rnad_tree_t *tree, int T, int64_t B, const int32_t
     }
 #undef RNAD_BUCKET_LEARN
     RNAD_HIP_OK(hipGetLastError());
-    ProfScope fin(PROF_BUCKET_FINISH, stream);
-    if (nu > 0)
-        RNAD_DISPATCH_A(tree->A, hipLaunchKernelGGL((k_bucket_upper<kA>), dim3(blocks_for(2 * (int64_t)nu, kThreads / 64)), dim3(kThreads), 0,
-                                                    stream, S, nu, (const int32_t *)p.cut->upper_list, acc, rep));
-    RNAD_DISPATCH_A(tree->A, hipLaunchKernelGGL((k_bucket_finish<kA>), dim3(blocks_for(2 * S)), dim3(kThreads), 0, stream, S, acc, norm,
-                                                hp->w_v, hp->w_n, fx, (const int32_t *)overflow, (const double *)losses_raw, losses,
-                                                dlogit_tab, dv_tab));
-    RNAD_HIP_OK(hipGetLastError());
-    return 0;
+    if (!norm) return 0;  // the caller completes the update with rnad_bucket_finish once the normalisers are known
+    return finish_impl(tree, p, norm, hp, accumulators, losses, dlogit_tab, dv_tab, stream);
 }
 }  // namespace
+
+extern "C" int rnad_bucket_finish(const rnad_tree_t *tree, int64_t B, const double *norm, const rnad_learn_params_t *hp, void *accumulators,
+                                  double *losses, float *dlogit_tab, float *dv_tab, void *stream) {
+    RNAD_REQUIRE(tree && norm && hp && accumulators && dlogit_tab && dv_tab, "rnad_bucket_finish: null argument");
+    Plan p;
+    RNAD_REQUIRE(make_plan(tree, B, p), "rnad_bucket_finish: this tree / batch cannot be bucketed (see rnad_bucket_plan)");
+    return finish_impl(tree, p, norm, hp, accumulators, losses, dlogit_tab, dv_tab, (hipStream_t)stream);
+}
 
 extern "C" int rnad_learn_bucketed(const rnad_tree_t *tree, int T, int64_t B, const int32_t *indices, const int32_t *actions,
                                    const float *rewards, const float *mu, const float *records, const int32_t *items,
                                    const int32_t *n_items, const double *norm, const rnad_learn_params_t *hp, void *accumulators,
                                    double *losses, float *dlogit_tab, float *dv_tab, void *stream) {
-    RNAD_REQUIRE(tree && indices && actions && rewards && mu && records && items && n_items && norm && hp && accumulators && dlogit_tab &&
-                     dv_tab,
+    RNAD_REQUIRE(tree && indices && actions && rewards && mu && records && items && n_items && hp && accumulators && dlogit_tab && dv_tab,
                  "rnad_learn_bucketed: null argument");
     RNAD_REQUIRE(T >= 1 && B >= 1, "rnad_learn_bucketed: bad shape");
     return learn_bucketed_impl(tree, T, B, indices, actions, rewards, mu, nullptr, nullptr, records, items, n_items, norm, hp, accumulators,
@@ -1138,7 +1159,7 @@ extern "C" int rnad_learn_bucketed_compact(const rnad_tree_t *tree, int T, int64
                                            const float *final_reward, const float *records, const int32_t *items, const int32_t *n_items,
                                            const double *norm, const rnad_learn_params_t *hp, void *accumulators, double *losses,
                                            float *dlogit_tab, float *dv_tab, void *stream) {
-    RNAD_REQUIRE(tree && indices && acts && final_reward && records && items && n_items && norm && hp && accumulators && dlogit_tab && dv_tab,
+    RNAD_REQUIRE(tree && indices && acts && final_reward && records && items && n_items && hp && accumulators && dlogit_tab && dv_tab,
                  "rnad_learn_bucketed_compact: null argument");
     RNAD_REQUIRE(T >= 1 && T <= kCompactSteps && B >= 1, "rnad_learn_bucketed_compact: bad shape");
     return learn_bucketed_impl(tree, T, B, indices, nullptr, nullptr, nullptr, (const unsigned long long *)acts, final_reward, records, items,

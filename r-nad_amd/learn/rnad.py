@@ -475,7 +475,9 @@ class RNaD:
                     else:
                         logit_reg_, _ = self._logits_of(self.net_reg_, episodes, want_value=False, live=fwd_live)  # :380
 
-        if norm_work is not None:
+        # the bucketed learner needs the normalisers only in its last kernel: their all-reduce runs beside k_bucket_learn
+        late_norm = bucketed and norm_work is not None
+        if norm_work is not None and not late_norm:
             norm_work.wait()
         hp = self._learn_params(alpha)
         if bucketed:
@@ -486,12 +488,15 @@ class RNaD:
             compact = getattr(episodes, "_compact", None)
             if compact is not None and compact[1] is records:
                 # the batch was played this very step with the pi columns of these records as the actor: 64 bytes per lane
-                dlogit, dv, losses = rnad_hip.learn_bucketed_compact(self.tree.handle(), episodes.buckets, compact[0], T, records, norm, hp,
-                                                                     want_losses=log is not None)
+                dlogit, dv, losses = rnad_hip.learn_bucketed_compact(self.tree.handle(), episodes.buckets, compact[0], T, records,
+                                                                     None if late_norm else norm, hp, want_losses=log is not None)
             else:
                 dlogit, dv, losses = rnad_hip.learn_bucketed(self.tree.handle(), episodes.buckets, episodes.indices[:T], episodes.action_idx[:T],
-                                                             episodes.rewards[:T], episodes.policy[:T], records, norm, hp,
-                                                             want_losses=log is not None)
+                                                             episodes.rewards[:T], episodes.policy[:T], records,
+                                                             None if late_norm else norm, hp, want_losses=log is not None)
+            if late_norm:
+                norm_work.wait()
+                rnad_hip.bucket_finish(self.tree.handle(), episodes.buckets, norm, hp, dlogit, dv, losses)
             pi = None
             backward_obs = table
         elif table is not None:
@@ -729,6 +734,11 @@ class RNaD:
                 why = "the rollout of this step is not the native bucketed one"
             except Exception as err:  # capture is an optimisation: fall back to eager steps, loudly
                 why = str(err)
+            if _dist_on():  # every rank replays, or none does (a rank replaying collectives the others enqueue eagerly would hang)
+                flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=self.device)
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                if ok and int(flag.item()) == 0:
+                    ok, why = False, "another rank could not capture its step"
             if not ok:
                 logging.warning("hipGraph capture of the training step not used (%s); continuing with eager steps", why)
                 g["failed"] = True

@@ -694,7 +694,7 @@ def learn_bucketed_compact(tree, buckets, traj, T, records, norm, hp, want_losse
     losses = torch.empty((2,), dtype=F64, device=dev) if want_losses else None
     _check(lib().rnad_learn_bucketed_compact(tree.ptr, T, B, _dp(traj.indices, I32, "indices"), _dp(traj.acts, torch.int64, "acts"),
                                              _dp(traj.final_reward, F32, "final_reward"), _dp(records, F32, "records"),
-                                             _dp(buckets.items, I32, "items"), _dp(buckets.n_items, I32, "n_items"), _dp(norm, F64, "norm"),
+                                             _dp(buckets.items, I32, "items"), _dp(buckets.n_items, I32, "n_items"), _dp(norm, F64, "norm", True),
                                              C.byref(hp), _dp(buckets.plan.accumulators, torch.int64, "accumulators"),
                                              _dp(losses, F64, "losses", True), _dp(dlogit, F32, "dlogit_tab"), _dp(dv, F32, "dv_tab"), _stream()))
     return dlogit, dv, losses
@@ -732,10 +732,17 @@ def learn_bucketed(tree, buckets, indices, actions, rewards, mu, records, norm, 
     losses = torch.empty((2,), dtype=F64, device=dev) if want_losses else None
     _check(lib().rnad_learn_bucketed(tree.ptr, T, B, _dp(indices, I32, "indices"), _dp(actions, I32, "actions"), _dp(rewards, F32, "rewards"),
                                      _dp(mu, F32, "mu"), _dp(records, F32, "records"), _dp(buckets.items, I32, "items"),
-                                     _dp(buckets.n_items, I32, "n_items"), _dp(norm, F64, "norm"), C.byref(hp),
+                                     _dp(buckets.n_items, I32, "n_items"), _dp(norm, F64, "norm", True), C.byref(hp),
                                      _dp(buckets.plan.accumulators, torch.int64, "accumulators"), _dp(losses, F64, "losses", True),
                                      _dp(dlogit, F32, "dlogit_tab"), _dp(dv, F32, "dv_tab"), _stream()))
     return dlogit, dv, losses
+
+
+def bucket_finish(tree, buckets, norm, hp, dlogit, dv, losses=None):
+    """rnad_bucket_finish: completes a learn_bucketed / learn_bucketed_compact call that was made with norm=None."""
+    _check(lib().rnad_bucket_finish(tree.ptr, buckets.plan.B, _dp(norm, F64, "norm"), C.byref(hp),
+                                    _dp(buckets.plan.accumulators, torch.int64, "accumulators"), _dp(losses, F64, "losses", True),
+                                    _dp(dlogit, F32, "dlogit_tab"), _dp(dv, F32, "dv_tab"), _stream()))
 
 
 def clip_grad_norm(flat, max_norm):
