@@ -354,8 +354,13 @@ int rnad_learn_fused_gather(const rnad_tree_t *tree, int T, int64_t B, const int
  * rnad_rollout_bucketed_compact plays the same episodes as rnad_rollout_bucketed with the pi columns of `records` as the actor and
  * writes indices [T_cap + 1, B], alive, acts (uint64 [B]: action of step t in bits 3t .. 3t + 2) and final_reward (f32 [B]) -- 64
  * instead of 300 bytes per lane at A = 3, T = 12; T_cap <= 21.  rnad_learn_bucketed_compact is rnad_learn_bucketed on that
- * trajectory, with the acting policy of a slot read from its record (the very floats the rollout sampled from): same gradients
- * bit for bit.  rnad_bucket_expand writes the dense [T, B] buffers of such a trajectory (mask_bits, policy, actions, rewards) when
+ * trajectory with the actor's own pi as the acting policy (the very floats the rollout sampled from), so that every operand of a
+ * slot's V-trace / NeuRD arithmetic except the carries is the ROW's: rnad_bucket_records writes them once per row into
+ * fast_records (optional output; rnad_bucket_fast_record_stride(A) = 4 + 4A floats:
+ *   v | v_target | -eta sum(pi_processed log_policy_reg) | legal and threshold-gate bits | pi_processed[A] | -eta log_policy_reg[A] |
+ *   pi_processed[A] / pi[A] | 1 / pi[A])
+ * with the operations learn/vtrace.py applies per slot, and the learner does the rest: same gradients bit for bit.  `records` is
+ * only read when `losses` is asked for (the logits).  rnad_bucket_expand writes the dense [T, B] buffers of such a trajectory (mask_bits, policy, actions, rewards) when
  * something asks for them; slots of absorbed lanes get action 0 (the dense rollout keeps drawing there; nothing reads them).
  *
  * norm == NULL in rnad_learn_bucketed / rnad_learn_bucketed_compact: the sums stay in `accumulators` (losses, dlogit_tab, dv_tab are
@@ -386,17 +391,18 @@ int rnad_bucket_expand(const rnad_tree_t *tree, int T, int64_t B, const int32_t 
                        const float *final_reward, const float *records, uint8_t *mask_bits, float *policy, int32_t *actions,
                        float *rewards, void *stream);
 int64_t rnad_bucket_record_stride(int A);
+int64_t rnad_bucket_fast_record_stride(int A);
 int rnad_bucket_records(const rnad_tree_t *tree, const float *logit_tab, const float *v_tab, const float *v_target_tab,
                         const float *logit_reg_tab, const float *logit_reg_tab_, const rnad_learn_params_t *hp,
-                        const rnad_step_params_t *device_params, float *records, void *stream);
+                        const rnad_step_params_t *device_params, float *records, float *fast_records, void *stream);
 int rnad_learn_bucketed(const rnad_tree_t *tree, int T, int64_t B, const int32_t *indices, const int32_t *actions,
                         const float *rewards, const float *mu, const float *records, const int32_t *items, const int32_t *n_items,
                         const double *norm, const rnad_learn_params_t *hp, void *accumulators, double *losses, float *dlogit_tab,
                         float *dv_tab, void *stream);
 int rnad_learn_bucketed_compact(const rnad_tree_t *tree, int T, int64_t B, const int32_t *indices, const uint64_t *acts,
-                                const float *final_reward, const float *records, const int32_t *items, const int32_t *n_items,
-                                const double *norm, const rnad_learn_params_t *hp, void *accumulators, double *losses,
-                                float *dlogit_tab, float *dv_tab, void *stream);
+                                const float *final_reward, const float *fast_records, const float *records, const int32_t *items,
+                                const int32_t *n_items, const double *norm, const rnad_learn_params_t *hp, void *accumulators,
+                                double *losses, float *dlogit_tab, float *dv_tab, void *stream);
 int rnad_bucket_finish(const rnad_tree_t *tree, int64_t B, const double *norm, const rnad_learn_params_t *hp, void *accumulators,
                        double *losses, float *dlogit_tab, float *dv_tab, void *stream);
 

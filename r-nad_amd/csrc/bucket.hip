@@ -218,12 +218,23 @@ constexpr int kRowStride = (4 * A + 3 + 3) & ~3;
 template <int A>
 constexpr int kRowLearn = (3 * A + 3 + 3) & ~3;  // what k_bucket_learn fetches of a record
 
+// "Fast" record of the on-policy learner (k_bucket_learn<A, true, .>), kFastStride<A> floats = 64 bytes at A = 3:
+//   v | v_target | e0 | bits | pi_processed[A] | elp[A] | cs[A] | inv_mu[A]
+// Everything of a slot's V-trace / NeuRD arithmetic whose operands are the row's alone, computed with the operations (and in the
+// order) learn_math.hpp's vtrace_step / nerd_row use per slot, once per row instead:
+//   e0 = -eta * sum_a pi_processed[a] * log_policy_reg[a]   eta_reg_entropy up to the sign of _player_others (vtrace.py:234-238)
+//   elp[a] = -eta * log_policy_reg[a]                        eta_log_policy of the mover (:239)
+//   cs[a] = pi_processed[a] / pi[a], inv_mu[a] = 1 / pi[a]   _policy_ratio with the actor's own pi as mu, had action a been taken (:199-204)
+//   bits = legal | (logit - mean > -threshold) << 8 | (logit - mean < threshold) << 16    the gates of apply_force_with_threshold (:362-366)
+template <int A>
+constexpr int kFastStride = 4 + 4 * A;
+
 template <int A>
 __global__ __launch_bounds__(kThreads) void k_row_records(int64_t rows, const float *__restrict__ logit, const float *__restrict__ v,
                                                           const float *__restrict__ vt, const float *__restrict__ lr_,
                                                           const float *__restrict__ lr2_, const uint8_t *__restrict__ mask_tab,
                                                           rnad_learn_params_t hp, const rnad_step_params_t *__restrict__ sp,
-                                                          float *__restrict__ rec) {
+                                                          float *__restrict__ rec, float *__restrict__ fast) {
     const int64_t r = (int64_t)blockIdx.x * kThreads + threadIdx.x;
     if (r >= rows) return;
     if (sp) {
@@ -256,6 +267,32 @@ __global__ __launch_bounds__(kThreads) void k_row_records(int64_t rows, const fl
     o[3 * A + 2] = __uint_as_float(bits);
 #pragma unroll
     for (int u = 4 * A + 3; u < kRowStride<A>; ++u) o[u] = 0.0f;
+    if (!fast) return;
+    float *f = fast + r * kFastStride<A>;
+    const float neg_eta = -hp.eta;
+    float ent = 0.0f, mean = 0.0f;
+#pragma unroll
+    for (int a = 0; a < A; ++a) {
+        const float lpol = lp[a] - (hp.alpha * lpr[a] + hp.one_minus_alpha * lpr2[a]);
+        ent += pip[a] * lpol;
+        mean += lg[a] * legal[a];
+        f[4 + a] = pip[a];
+        f[4 + A + a] = neg_eta * lpol;
+        f[4 + 2 * A + a] = pip[a] / pi[a];
+        f[4 + 3 * A + a] = 1.0f / pi[a];
+    }
+    mean = mean / (float)A;
+    uint32_t gates = bits & 0xffu;
+#pragma unroll
+    for (int a = 0; a < A; ++a) {
+        const float l = lg[a] - mean;
+        gates |= (l > -hp.threshold ? 1u : 0u) << (8 + a);
+        gates |= (l < hp.threshold ? 1u : 0u) << (16 + a);
+    }
+    f[0] = v[r];
+    f[1] = vt[r];
+    f[2] = neg_eta * ent;
+    f[3] = __uint_as_float(gates);
 }
 
 // ---------------------------------------------------------------------------------------- 1. keys
@@ -596,6 +633,75 @@ struct FixedPoint {
     float limit_l, limit_v;   // |addend| must stay below this (2^(62 - kLaneBits) units)
 };
 
+// One slot of the on-policy update from its row's fast record f (k_row_records): vtrace_step for the mover P ("ours") and for the
+// other player ("opp"), nerd_row and the fixed-point addends, with the row-only operands read instead of recomputed.  Operation for
+// operation what learn_math.hpp does per slot (products with the one-hot action and with valid == 1 drop out exactly).
+template <int A, bool LOSSES, int P>
+__device__ __forceinline__ void fast_slot(const float *__restrict__ f, const float *__restrict__ lg, int act, float rew, const VtHp &vh,
+                                          const rnad_learn_params_t &hp, const FixedPoint &fx, Carry (&cy)[2], long long (&out)[A + 1],
+                                          double (&part)[4], bool &ovf) {
+    const float v = f[0], vv = f[1], e0 = f[2];
+    const uint32_t bits = __float_as_uint(f[3]);
+    float cs = f[4 + 2 * A], inv_mu = f[4 + 3 * A];
+#pragma unroll
+    for (int a = 1; a < A; ++a) {
+        cs = act == a ? f[4 + 2 * A + a] : cs;
+        inv_mu = act == a ? f[4 + 3 * A + a] : inv_mu;
+    }
+    Carry &me = cy[P], &op = cy[1 - P];  // P is a template parameter: the carries stay in registers
+    const float r_me = P ? -rew : rew, r_op = P ? rew : -rew;  // player 1 is paid -r (rnad.py:368)
+    // ours (vtrace.py:262-312)
+    const float ru = r_me + vh.gamma * me.ru + e0;
+    const float dr = r_me + vh.gamma * me.r;
+    const float w = cs * me.is;
+    const float vt = vv + clamp_max(w, vh.rho) * (ru + vh.gamma * me.nv - vv) + vh.lambda_ * clamp_max(w, vh.c) * vh.gamma * (me.nvt - me.nv);
+    const float tail = dr + vh.gamma * me.is * me.nvt - vv;
+    const float bonus = inv_mu * tail;
+    float q[A], base = 0.0f;
+#pragma unroll
+    for (int a = 0; a < A; ++a) {
+        q[a] = vv + f[4 + A + a] + (act == a ? bonus : 0.0f);
+        base += f[4 + a] * q[a];
+    }
+    me.r = 0.0f; me.ru = 0.0f; me.nv = vv; me.nvt = vt; me.is = 1.0f;
+    // opp (vtrace.py:313-319): _player_others = -1
+    const float ne0 = -e0;
+    const float ru_x = r_op + vh.gamma * op.ru + ne0;
+    const float dr_x = r_op + vh.gamma * op.r;
+    op.r = ne0 + cs * dr_x; op.ru = ru_x; op.nv = vh.gamma * op.nv; op.nvt = vh.gamma * op.nvt; op.is = cs * op.is;
+    // get_loss_nerd row (vtrace.py:410-429) and its gradient
+    float wv[A], wsum = 0.0f, nerd = 0.0f, mean = 0.0f;
+    if (LOSSES) {
+#pragma unroll
+        for (int a = 0; a < A; ++a) mean += lg[a] * (float)((bits >> a) & 1);
+        mean = mean / (float)A;
+    }
+#pragma unroll
+    for (int a = 0; a < A; ++a) {
+        float adv = q[a] - base;
+        adv = adv != adv ? adv : fminf(fmaxf(adv, -hp.clip), hp.clip);
+        const float fo = ((bits >> (8 + a)) & 1 ? fminf(adv, 0.0f) : 0.0f) + ((bits >> (16 + a)) & 1 ? fmaxf(adv, 0.0f) : 0.0f);
+        wv[a] = (bits >> a) & 1 ? fo : 0.0f;
+        wsum += wv[a];
+        if (LOSSES) nerd += (float)((bits >> a) & 1) * ((lg[a] - mean) * fo);
+    }
+    const float share = wsum / (float)A;
+    const float d = v - vt;
+    if (LOSSES) {
+        part[P] += (double)(d * d);
+        part[2 + P] += -(double)nerd;
+    }
+    const float gv = 2.0f * d;
+    ovf |= !(fabsf(gv) < fx.limit_v);
+    out[A] = round_to_ll((double)gv * fx.scale_v);
+#pragma unroll
+    for (int a = 0; a < A; ++a) {
+        const float g = (bits >> a) & 1 ? wv[a] - share : 0.0f;
+        ovf |= !(fabsf(g) < fx.limit_l);
+        out[a] = round_to_ll((double)(-g) * fx.scale_l);
+    }
+}
+
 // The pass of k_learn_fused<TAB> (learn.hip; learn/rnad.py:365-425) for the lanes of ONE work item -- they all went through the
 // same states down to the bucket state -- with the per-slot gradients added up per (player, state) row instead of being written:
 //   rows at steps t < 2 * level(bucket state): one row per step for the whole workgroup -> wave reduction, one LDS add per wave;
@@ -605,9 +711,12 @@ struct FixedPoint {
 // rnad.py:424; summing first changes the rounding of the last bit only).  losses_raw[4] += sum d^2 (P = 0, 1), sum -nerd (P = 0, 1).
 //
 // COMPACT: the trajectory of k_bucket_rollout<A, true> -- indices [T + 1, B], the lane's packed actions and its one reward -- played
-// with the pi columns of these very records as the actor: the acting policy of a slot is read from its record (on-policy:
-// mu == pi, the same floats the rollout sampled from) instead of a [T, B, A] buffer.  Same arithmetic, same sums.
-template <int A, bool COMPACT>
+// with the pi columns of the records as the actor (on-policy: mu == pi, the very floats the rollout sampled from).  rec_ then
+// points at the FAST records (k_row_records): whatever of vtrace_step / nerd_row has row-only operands arrives precomputed, and a
+// slot is left with the carries, the value target, q, the advantage and one division -- the same operations on the same operands as
+// the dense variant, hence the same sums.  LOSSES (COMPACT only; the dense variant always adds them up): loss_v / loss_nerd sums
+// for a logging step, which need the logits of the dense record (logit_).
+template <int A, bool COMPACT, bool LOSSES>
 __global__ __launch_bounds__(kThreads) void k_bucket_learn(int T, int64_t B, int64_t S, int sub_rows, int n_groups, int up_stride,
                                                            const Item *__restrict__ items, const int32_t *__restrict__ n_items,
                                                            const int32_t *__restrict__ bucket_of, const int32_t *__restrict__ bucket_lo,
@@ -615,7 +724,8 @@ __global__ __launch_bounds__(kThreads) void k_bucket_learn(int T, int64_t B, int
                                                            const int32_t *__restrict__ actions, const float *__restrict__ rewards,
                                                            const float *__restrict__ mu_, const float *__restrict__ rec_,
                                                            const unsigned long long *__restrict__ acts_,
-                                                           const float *__restrict__ reward_, rnad_learn_params_t hp, FixedPoint fx, unsigned long long *__restrict__ acc,
+                                                           const float *__restrict__ reward_, const float *__restrict__ logit_,
+                                                           rnad_learn_params_t hp, FixedPoint fx, unsigned long long *__restrict__ acc,
                                                            unsigned long long *__restrict__ rep, double *__restrict__ losses_raw,
                                                            int32_t *__restrict__ overflow) {
     // [kMaxPath path rows][kPathSlots copies][(A + 1) | 1]  |  [sub_rows rows of player 0 | sub_rows rows of player 1][A + 1]
@@ -641,21 +751,28 @@ __global__ __launch_bounds__(kThreads) void k_bucket_learn(int T, int64_t B, int
         // Software pipeline over the time loop: the states of step t - 2 and the slot's inputs of step t - 1 (action, acting policy,
         // reward, the row record -- whose address needs that step's state) are requested before the arithmetic of step t, so the
         // two dependent memory latencies of a step (state -> record) overlap the V-trace / NeuRD arithmetic of its successors.
-        constexpr int kFetch = COMPACT ? RS : kRowLearn<A>;  // floats of a record this variant reads (COMPACT: pi as well)
+        constexpr int kFetch = COMPACT ? kFastStride<A> : kRowLearn<A>;  // floats of a record this variant reads
+        constexpr int kRecStride_ = COMPACT ? kFastStride<A> : RS;
         struct Slot {
             int act;
             float rew;
             float mu[A];
             float rec[kFetch];
+            float lg[A];  // LOSSES: the row's logits
         };
         auto fetch = [&](int t, int state, Slot &o) {
             if (state == 0) return;
             const int64_t i = (int64_t)t * B + j;
-            const float4 *rp = reinterpret_cast<const float4 *>(rec_ + ((int64_t)(t & 1) * S + state) * RS);
+            const int64_t row = (int64_t)(t & 1) * S + state;
+            const float4 *rp = reinterpret_cast<const float4 *>(rec_ + row * kRecStride_);
 #pragma unroll
             for (int u = 0; u < kFetch / 4; ++u) {
                 const float4 r4 = rp[u];
                 o.rec[4 * u] = r4.x; o.rec[4 * u + 1] = r4.y; o.rec[4 * u + 2] = r4.z; o.rec[4 * u + 3] = r4.w;
+            }
+            if (COMPACT && LOSSES) {
+#pragma unroll
+                for (int a = 0; a < A; ++a) o.lg[a] = logit_[row * RS + a];
             }
             if (!COMPACT) {
                 o.act = actions[i];
@@ -683,39 +800,47 @@ __global__ __launch_bounds__(kThreads) void k_bucket_learn(int T, int64_t B, int
 #pragma unroll
             for (int a = 0; a <= A; ++a) q[a] = 0;
             if (valid) {
-                const int act = COMPACT ? (int)(acts >> (3 * t)) & 7 : cur.act;
-                const float *rec = cur.rec;  // this row's record (k_row_records)
-                const uint32_t bits = __float_as_uint(rec[3 * A + 2]);
-                float mu[A], lg[A], pip[A], lpol[A], legal[A], oh[A];
+                if constexpr (COMPACT) {
+                    const int act = (int)(acts >> (3 * t)) & 7;
+                    if (t & 1)  // uniform: the mover is a template parameter of the slot arithmetic
+                        fast_slot<A, LOSSES, 1>(cur.rec, cur.lg, act, s_after == 0 ? reward_final : 0.0f,  // rewards *= (indices == 0), episode.py:120-121
+                                                vh, hp, fx, cy, q, part, ovf);
+                    else
+                        fast_slot<A, LOSSES, 0>(cur.rec, cur.lg, act, 0.0f, vh, hp, fx, cy, q, part, ovf);  // row turns: torch.zeros (episode.py:101)
+                } else {
+                    const int act = cur.act;
+                    const float *rec = cur.rec;  // this row's record (k_row_records)
+                    const uint32_t bits = __float_as_uint(rec[3 * A + 2]);
+                    float mu[A], lg[A], pip[A], lpol[A], legal[A], oh[A];
 #pragma unroll
-                for (int a = 0; a < A; ++a) {
-                    mu[a] = COMPACT ? rec[(3 * A + 3 + a) % kFetch] : cur.mu[a];  // (% kFetch: in range in the variant that never reads it)
-                    lg[a] = rec[a];
-                    pip[a] = rec[A + 2 + a];    // process_policy(pi) of the learner (rnad.py:374)
-                    lpol[a] = rec[2 * A + 2 + a];  // log_policy_reg (rnad.py:382)
-                    legal[a] = (float)((bits >> a) & 1);
-                    oh[a] = act == a ? 1.0f : 0.0f;
-                }
-                // COMPACT: rewards *= (indices == 0) (episode.py:120-121) -- only the step into state 0 carries the lane's reward
-                const float rew = COMPACT ? (((t & 1) && s_after == 0) ? reward_final : 0.0f) : cur.rew;
-                const float vtn = rec[A + 1];
-                float vt[2], qv[2][A];
-                vtrace_step<A>(cy[0], vh, true, P == 0, 1.0f, vtn, rew, mu, pip, lpol, oh, vt[0], qv[0]);   // player 0 (rnad.py:384-406)
-                vtrace_step<A>(cy[1], vh, true, P == 1, 1.0f, vtn, -rew, mu, pip, lpol, oh, vt[1], qv[1]);  // player 1: rewards = -r (:368)
-                const float d = rec[A] - (P ? vt[1] : vt[0]);
-                float qp[A], g[A];
+                    for (int a = 0; a < A; ++a) {
+                        mu[a] = cur.mu[a];
+                        lg[a] = rec[a];
+                        pip[a] = rec[A + 2 + a];    // process_policy(pi) of the learner (rnad.py:374)
+                        lpol[a] = rec[2 * A + 2 + a];  // log_policy_reg (rnad.py:382)
+                        legal[a] = (float)((bits >> a) & 1);
+                        oh[a] = act == a ? 1.0f : 0.0f;
+                    }
+                    const float rew = cur.rew;
+                    const float vtn = rec[A + 1];
+                    float vt[2], qv[2][A];
+                    vtrace_step<A>(cy[0], vh, true, P == 0, 1.0f, vtn, rew, mu, pip, lpol, oh, vt[0], qv[0]);   // player 0 (rnad.py:384-406)
+                    vtrace_step<A>(cy[1], vh, true, P == 1, 1.0f, vtn, -rew, mu, pip, lpol, oh, vt[1], qv[1]);  // player 1: rewards = -r (:368)
+                    const float d = rec[A] - (P ? vt[1] : vt[0]);
+                    float qp[A], g[A];
 #pragma unroll
-                for (int a = 0; a < A; ++a) qp[a] = P ? qv[1][a] : qv[0][a];
-                const float nerd = nerd_row<A>(lg, pip, qp, legal, hp.clip, hp.threshold, g);
-                part[P] += (double)(d * d);
-                part[2 + P] += -(double)nerd;
-                const float gv = 2.0f * d;
-                ovf |= !(fabsf(gv) < fx.limit_v);
-                q[A] = round_to_ll((double)gv * fx.scale_v);
+                    for (int a = 0; a < A; ++a) qp[a] = P ? qv[1][a] : qv[0][a];
+                    const float nerd = nerd_row<A>(lg, pip, qp, legal, hp.clip, hp.threshold, g);
+                    part[P] += (double)(d * d);
+                    part[2 + P] += -(double)nerd;
+                    const float gv = 2.0f * d;
+                    ovf |= !(fabsf(gv) < fx.limit_v);
+                    q[A] = round_to_ll((double)gv * fx.scale_v);
 #pragma unroll
-                for (int a = 0; a < A; ++a) {
-                    ovf |= !(fabsf(g[a]) < fx.limit_l);
-                    q[a] = round_to_ll((double)(-g[a]) * fx.scale_l);
+                    for (int a = 0; a < A; ++a) {
+                        ovf |= !(fabsf(g[a]) < fx.limit_l);
+                        q[a] = round_to_ll((double)(-g[a]) * fx.scale_l);
+                    }
                 }
             } else {
                 cy[0] = Carry{};  // reset_carry (vtrace.py:320)
@@ -920,17 +1045,18 @@ extern "C" int rnad_step_params_set(rnad_step_params_t *device_params, uint64_t 
 }
 
 extern "C" int64_t rnad_bucket_record_stride(int A) { return (4 * (int64_t)A + 3 + 3) & ~(int64_t)3; }
+extern "C" int64_t rnad_bucket_fast_record_stride(int A) { return 4 + 4 * (int64_t)A; }
 
 extern "C" int rnad_bucket_records(const rnad_tree_t *tree, const float *logit_tab, const float *v_tab, const float *v_target_tab,
                                    const float *logit_reg_tab, const float *logit_reg_tab_, const rnad_learn_params_t *hp,
-                                   const rnad_step_params_t *device_params, float *records, void *stream) {
+                                   const rnad_step_params_t *device_params, float *records, float *fast_records, void *stream) {
     RNAD_REQUIRE(tree && logit_tab && v_tab && v_target_tab && logit_reg_tab && logit_reg_tab_ && hp && records,
                  "rnad_bucket_records: null argument");
-    RNAD_REQUIRE(((uintptr_t)records & 15) == 0, "rnad_bucket_records: records must be 16-byte aligned");
+    RNAD_REQUIRE(((uintptr_t)records & 15) == 0 && ((uintptr_t)fast_records & 15) == 0, "rnad_bucket_records: records must be 16-byte aligned");
     RNAD_REQUIRE(hp->n_disc >= 1, "rnad_bucket_records: n_disc must be positive");
     RNAD_DISPATCH_A(tree->A, hipLaunchKernelGGL((k_row_records<kA>), dim3(blocks_for(2 * tree->S)), dim3(kThreads), 0, (hipStream_t)stream,
                                                 2 * tree->S, logit_tab, v_tab, v_target_tab, logit_reg_tab, logit_reg_tab_,
-                                                (const uint8_t *)tree->mask_tab, *hp, device_params, records));
+                                                (const uint8_t *)tree->mask_tab, *hp, device_params, records, fast_records));
     RNAD_HIP_OK(hipGetLastError());
     return 0;
 }
@@ -1096,7 +1222,7 @@ int finish_impl(const rnad_tree_t *tree, const Plan &p, const double *norm, cons
 
 int learn_bucketed_impl(const rnad_tree_t *tree, int T, int64_t B, const int32_t *indices, const int32_t *actions, const float *rewards,
                         const float *mu, const unsigned long long *acts, const float *final_reward, const float *records,
-                        const int32_t *items, const int32_t *n_items, const double *norm, const rnad_learn_params_t *hp,
+                        const float *fast, const int32_t *items, const int32_t *n_items, const double *norm, const rnad_learn_params_t *hp,
                         void *accumulators, double *losses, float *dlogit_tab, float *dv_tab, hipStream_t stream) {
     const bool compact = acts != nullptr;
     Plan p;
@@ -1112,21 +1238,24 @@ int learn_bucketed_impl(const rnad_tree_t *tree, int T, int64_t B, const int32_t
     // seen to write garbage after ~57 replays on ROCm 7.2 (tests/test_hip_graph.py::test_many_replays_stay_finite)
     hipLaunchKernelGGL(k_zero_words, dim3(1), dim3(64), 0, stream, (uint32_t *)losses_raw, (int)((4 * sizeof(double) + sizeof(int32_t)) / 4));
     ProfScope prof(PROF_LEARN, stream);
-#define RNAD_BUCKET_LEARN(COMPACT)                                                                                                    \
+#define RNAD_BUCKET_LEARN(COMPACT, LOSSES)                                                                                            \
     do {                                                                                                                              \
-        auto kern = k_bucket_learn<kA, COMPACT>;                                                                                      \
+        auto kern = k_bucket_learn<kA, COMPACT, LOSSES>;                                                                              \
         if (p.lds > 48 * 1024) RNAD_HIP_OK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, p.lds)); \
         hipLaunchKernelGGL(kern, dim3((unsigned)p.max_items), dim3(kThreads), (size_t)p.lds, stream, T, B, S, p.cut->rows,            \
                            p.cut->n_groups, std::max(nu, 1), (const Item *)items, n_items, (const int32_t *)p.cut->bucket_of,         \
                            (const int32_t *)p.cut->bucket_lo, (const int32_t *)p.cut->bucket_path, indices, actions, rewards, mu,     \
-                           records, acts, final_reward, *hp, fx, acc, rep, losses ? losses_raw : (double *)nullptr, overflow);        \
+                           compact ? fast : records, acts, final_reward, records, *hp, fx, acc, rep,                                  \
+                           losses ? losses_raw : (double *)nullptr, overflow);                                                        \
     } while (0)
     {
         ProfScope one(PROF_BUCKET_LEARN, stream);
-        if (compact) {
-            RNAD_DISPATCH_A(tree->A, RNAD_BUCKET_LEARN(true));
+        if (compact && losses) {
+            RNAD_DISPATCH_A(tree->A, RNAD_BUCKET_LEARN(true, true));
+        } else if (compact) {
+            RNAD_DISPATCH_A(tree->A, RNAD_BUCKET_LEARN(true, false));
         } else {
-            RNAD_DISPATCH_A(tree->A, RNAD_BUCKET_LEARN(false));
+            RNAD_DISPATCH_A(tree->A, RNAD_BUCKET_LEARN(false, false));
         }
     }
 #undef RNAD_BUCKET_LEARN
@@ -1151,17 +1280,19 @@ extern "C" int rnad_learn_bucketed(const rnad_tree_t *tree, int T, int64_t B, co
     RNAD_REQUIRE(tree && indices && actions && rewards && mu && records && items && n_items && hp && accumulators && dlogit_tab && dv_tab,
                  "rnad_learn_bucketed: null argument");
     RNAD_REQUIRE(T >= 1 && B >= 1, "rnad_learn_bucketed: bad shape");
-    return learn_bucketed_impl(tree, T, B, indices, actions, rewards, mu, nullptr, nullptr, records, items, n_items, norm, hp, accumulators,
-                               losses, dlogit_tab, dv_tab, (hipStream_t)stream);
+    return learn_bucketed_impl(tree, T, B, indices, actions, rewards, mu, nullptr, nullptr, records, nullptr, items, n_items, norm, hp,
+                               accumulators, losses, dlogit_tab, dv_tab, (hipStream_t)stream);
 }
 
 extern "C" int rnad_learn_bucketed_compact(const rnad_tree_t *tree, int T, int64_t B, const int32_t *indices, const uint64_t *acts,
-                                           const float *final_reward, const float *records, const int32_t *items, const int32_t *n_items,
-                                           const double *norm, const rnad_learn_params_t *hp, void *accumulators, double *losses,
-                                           float *dlogit_tab, float *dv_tab, void *stream) {
-    RNAD_REQUIRE(tree && indices && acts && final_reward && records && items && n_items && hp && accumulators && dlogit_tab && dv_tab,
+                                           const float *final_reward, const float *fast_records, const float *records,
+                                           const int32_t *items, const int32_t *n_items, const double *norm, const rnad_learn_params_t *hp,
+                                           void *accumulators, double *losses, float *dlogit_tab, float *dv_tab, void *stream) {
+    RNAD_REQUIRE(tree && indices && acts && final_reward && fast_records && items && n_items && hp && accumulators && dlogit_tab && dv_tab,
                  "rnad_learn_bucketed_compact: null argument");
+    RNAD_REQUIRE(!losses || records, "rnad_learn_bucketed_compact: the losses need the dense records (logits)");
+    RNAD_REQUIRE(((uintptr_t)fast_records & 15) == 0, "rnad_learn_bucketed_compact: fast_records must be 16-byte aligned");
     RNAD_REQUIRE(T >= 1 && T <= kCompactSteps && B >= 1, "rnad_learn_bucketed_compact: bad shape");
-    return learn_bucketed_impl(tree, T, B, indices, nullptr, nullptr, nullptr, (const unsigned long long *)acts, final_reward, records, items,
-                               n_items, norm, hp, accumulators, losses, dlogit_tab, dv_tab, (hipStream_t)stream);
+    return learn_bucketed_impl(tree, T, B, indices, nullptr, nullptr, nullptr, (const unsigned long long *)acts, final_reward, records,
+                               fast_records, items, n_items, norm, hp, accumulators, losses, dlogit_tab, dv_tab, (hipStream_t)stream);
 }

@@ -486,10 +486,11 @@ class RNaD:
             if records is None:
                 records = rnad_hip.bucket_records(self.tree.handle(), logit, v, v_target, logit_reg, logit_reg_, hp)
             compact = getattr(episodes, "_compact", None)
-            if compact is not None and compact[1] is records:
+            if compact is not None and compact[1] is records and tables.get("fast_records") is not None:
                 # the batch was played this very step with the pi columns of these records as the actor: 64 bytes per lane
                 dlogit, dv, losses = rnad_hip.learn_bucketed_compact(self.tree.handle(), episodes.buckets, compact[0], T, records,
-                                                                     None if late_norm else norm, hp, want_losses=log is not None)
+                                                                     tables["fast_records"], None if late_norm else norm, hp,
+                                                                     want_losses=log is not None)
             else:
                 dlogit, dv, losses = rnad_hip.learn_bucketed(self.tree.handle(), episodes.buckets, episodes.indices[:T], episodes.action_idx[:T],
                                                              episodes.rewards[:T], episodes.policy[:T], records,
@@ -608,8 +609,9 @@ class RNaD:
             # the nets do not change between this step's rollout and its update: one evaluation of the 2S observations serves the
             # actor (= the learner net, rnad.py:503-505) and all four nets of __learn
             tables = self._table_outputs(alpha, getattr(self, "obs_half", False), want_target_logits=log is not None)
-            tables["records"] = rnad_hip.bucket_records(handle, tables["logit"], tables["v"], tables["v_target"], tables["logit_reg"],
-                                                        tables["logit_reg_"], self._learn_params(alpha), step_params=step_params)
+            tables["records"], tables["fast_records"] = rnad_hip.bucket_records(
+                handle, tables["logit"], tables["v"], tables["v_target"], tables["logit_reg"], tables["logit_reg_"], self._learn_params(alpha),
+                step_params=step_params, fast=True)
         if self.total_steps % self.buffer_mod == 0:
             episodes = episode.Episodes(self.tree, local_batch, seed=self._new_seed(), lane_offset=rank * local_batch,
                                         obs_half=getattr(self, "obs_half", False))

@@ -684,8 +684,9 @@ def bucket_expand(tree, traj, records):
                                     _dp(traj.rewards, F32, "rewards"), _stream()))
 
 
-def learn_bucketed_compact(tree, buckets, traj, T, records, norm, hp, want_losses=False):
-    """rnad_learn_bucketed_compact on the first T steps of a compact trajectory played with the pi columns of `records`."""
+def learn_bucketed_compact(tree, buckets, traj, T, records, fast_records, norm, hp, want_losses=False):
+    """rnad_learn_bucketed_compact on the first T steps of a compact trajectory played with the pi columns of `records`;
+    (records, fast_records) = bucket_records(..., fast=True)."""
     B, A = traj.B, tree.A
     assert buckets.plan.B == B and traj.compact and 1 <= T <= traj.T_cap
     dev = traj.indices.device
@@ -693,9 +694,10 @@ def learn_bucketed_compact(tree, buckets, traj, T, records, norm, hp, want_losse
     dv = torch.empty((2 * tree.S, 1), dtype=F32, device=dev)
     losses = torch.empty((2,), dtype=F64, device=dev) if want_losses else None
     _check(lib().rnad_learn_bucketed_compact(tree.ptr, T, B, _dp(traj.indices, I32, "indices"), _dp(traj.acts, torch.int64, "acts"),
-                                             _dp(traj.final_reward, F32, "final_reward"), _dp(records, F32, "records"),
-                                             _dp(buckets.items, I32, "items"), _dp(buckets.n_items, I32, "n_items"), _dp(norm, F64, "norm", True),
-                                             C.byref(hp), _dp(buckets.plan.accumulators, torch.int64, "accumulators"),
+                                             _dp(traj.final_reward, F32, "final_reward"), _dp(fast_records, F32, "fast_records"),
+                                             _dp(records, F32, "records"), _dp(buckets.items, I32, "items"),
+                                             _dp(buckets.n_items, I32, "n_items"), _dp(norm, F64, "norm", True), C.byref(hp),
+                                             _dp(buckets.plan.accumulators, torch.int64, "accumulators"),
                                              _dp(losses, F64, "losses", True), _dp(dlogit, F32, "dlogit_tab"), _dp(dv, F32, "dv_tab"), _stream()))
     return dlogit, dv, losses
 
@@ -711,15 +713,19 @@ def policy_column(A):
     return 3 * A + 3
 
 
-def bucket_records(tree, logit_tab, v_tab, v_target_tab, logit_reg_tab, logit_reg_tab_, hp, step_params=None):
+def bucket_records(tree, logit_tab, v_tab, v_target_tab, logit_reg_tab, logit_reg_tab_, hp, step_params=None, fast=False):
     """One record per (player, state) row with everything of the update that depends on the row alone (rnad_bucket_records):
-    logit[A] | v | v_target | process_policy(pi)[A] | log_policy_reg[A] | legal bits | pi[A] | pad."""
+    logit[A] | v | v_target | process_policy(pi)[A] | log_policy_reg[A] | legal bits | pi[A] | pad.
+    fast=True: returns (records, fast_records) -- the second table holds the row-only operands of the on-policy learner
+    (learn_bucketed_compact; layout in include/rnad_hip.h)."""
     stride = int(lib().rnad_bucket_record_stride(tree.A))
     rec = torch.empty((2 * tree.S, stride), dtype=F32, device=logit_tab.device)
+    quick = torch.empty((2 * tree.S, int(lib().rnad_bucket_fast_record_stride(tree.A))), dtype=F32, device=logit_tab.device) if fast else None
     _check(lib().rnad_bucket_records(tree.ptr, _dp(logit_tab, F32, "logit_tab"), _dp(v_tab, F32, "v_tab"), _dp(v_target_tab, F32, "v_target_tab"),
                                      _dp(logit_reg_tab, F32, "logit_reg_tab"), _dp(logit_reg_tab_, F32, "logit_reg_tab_"), C.byref(hp),
-                                     _dp(step_params, torch.int64, "step_params", True), _dp(rec, F32, "records"), _stream()))
-    return rec
+                                     _dp(step_params, torch.int64, "step_params", True), _dp(rec, F32, "records"),
+                                     _dp(quick, F32, "fast_records", True), _stream()))
+    return (rec, quick) if fast else rec
 
 
 def learn_bucketed(tree, buckets, indices, actions, rewards, mu, records, norm, hp, want_losses=False):

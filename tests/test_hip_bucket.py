@@ -284,7 +284,7 @@ def test_compact_trajectory_is_the_dense_one(name, B):
     nets = _four_nets(A, 64, seed=2)
     logit, v, vt, lr, lr_ = _tables(tree, nets, A)
     hp = rnad_hip.make_learn_params(alpha=0.3, eta=0.2, w_v=0.7, w_n=1.3)
-    rec = rnad_hip.bucket_records(h, logit, v, vt, lr, lr_, hp)
+    rec, fast = rnad_hip.bucket_records(h, logit, v, vt, lr, lr_, hp, fast=True)
     actor = (rec, rnad_hip.policy_column(A))
     dense = Episodes(tree, B, seed=9, lane_offset=123)
     dense.generate(nets[0], tabular=True, bucketed=True, trim=False, store_values=False, policy_table=actor)
@@ -298,7 +298,9 @@ def test_compact_trajectory_is_the_dense_one(name, B):
     # the update, before anything expanded the trajectory
     want = rnad_hip.learn_bucketed(h, dense.buckets, dense.indices, dense.action_idx, dense.rewards, dense.policy, rec, dense.valid_counts, hp,
                                    want_losses=True)
-    got = rnad_hip.learn_bucketed_compact(h, comp.buckets, comp._compact[0], T, rec, comp.valid_counts, hp, want_losses=True)
+    got = rnad_hip.learn_bucketed_compact(h, comp.buckets, comp._compact[0], T, rec, fast, comp.valid_counts, hp, want_losses=True)
+    quiet = rnad_hip.learn_bucketed_compact(h, comp.buckets, comp._compact[0], T, rec, fast, comp.valid_counts, hp)  # the variant without loss sums
+    assert torch.equal(quiet[0], want[0]) and torch.equal(quiet[1], want[1]) and quiet[2] is None
     assert comp._compact[0].policy is None
     assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1])
     np.testing.assert_allclose(got[2].cpu().numpy(), want[2].cpu().numpy(), rtol=1e-12)  # f64 sums over the workgroups in any order
