@@ -413,7 +413,7 @@ int rnad_clip_grad_norm(int64_t n, float *grads, float max_norm, float *total_no
 
 /* The tail of a training step in ONE launch  --  learn/rnad.py:456 (clip_grad_norm_), :514 (torch.optim.Adam.step: no weight decay,
  * no amsgrad, as constructed at rnad.py:232-237) and :516-523 (EMA target) for up to 8 parameter tensors whose gradients lie back to
- * back in one flat fp32 bucket `grads` (clipped in place).  sizes: HOST array of element counts; param / exp_avg / exp_avg_sq / step /
+ * back in one flat fp32 bucket `grads` (read only: the clipped values go straight into Adam).  sizes: HOST array of element counts; param / exp_avg / exp_avg_sq / step /
  * target: HOST arrays of device pointers (step: torch's per-tensor fp32 step counters on the device, incremented here; target may be
  * NULL: no EMA).  The state tensors are torch.optim.Adam's own, so checkpoints keep the reference format. */
 typedef struct rnad_adam_params {

@@ -16,7 +16,7 @@ using namespace rnad;
 
 namespace {
 
-constexpr int kOptThreads = 512;
+constexpr int kOptThreads = 1024;
 constexpr int kMaxTensors = 8;
 
 struct OptTensors {
@@ -25,16 +25,19 @@ struct OptTensors {
     float *param[kMaxTensors], *exp_avg[kMaxTensors], *exp_avg_sq[kMaxTensors], *step[kMaxTensors], *target[kMaxTensors];
 };
 
-// ONE workgroup (the bucket is 43 KB), everything latency: the loads of kBatch strided elements per thread are issued together
-// (one memory round trip per batch instead of one per element), the per-tensor pointers sit in LDS (indexed per lane without
-// waterfall loops), the Adam scalars are computed once per tensor.  A single workgroup needs no inter-workgroup ordering for the
-// in-place clip and the step counters.
-constexpr int kBatch = 8;  // 512 threads x 8: registers only (a kernel that needs scratch memory is best kept out of captured graphs)
+// Everything here is latency (the bucket is 43 KB).  One element per thread, ceil(n / 1024) workgroups; EVERY workgroup first takes
+// the 2-norm of the whole bucket for itself -- the same loads in the same order, hence the same clip coefficient everywhere, and no
+// inter-workgroup dependency -- with all of a thread's loads in flight together.  The gradients are read only (the clipped values
+// go straight into Adam; nothing reads .grad between clip_grad_norm_ and zero_grad in learn/rnad.py:456-514), so a workgroup may
+// still be summing while another one updates.  The per-tensor pointers and Adam scalars sit in LDS (indexed per lane without
+// waterfall loops).  The step counters are advanced by whichever workgroup takes the last ticket: by then all have read them.
+constexpr int kNormBatch = 8;
+__device__ unsigned int g_ticket = 0;  // one optimiser step at a time per device (one process per GPU, one training stream)
 
-__global__ __launch_bounds__(kOptThreads) void k_optimizer_step(OptTensors ts, float *__restrict__ grads, rnad_adam_params_t hp,
+__global__ __launch_bounds__(kOptThreads) void k_optimizer_step(OptTensors ts, const float *__restrict__ grads, rnad_adam_params_t hp,
                                                                 float *__restrict__ total_norm) {
     __shared__ double part[kOptThreads / 64];
-    __shared__ float coef_s, step_s[kMaxTensors], step_size_s[kMaxTensors], bc2s_s[kMaxTensors];
+    __shared__ float coef_s, step_size_s[kMaxTensors], bc2s_s[kMaxTensors];
     __shared__ float *ptr_s[4][kMaxTensors];
     __shared__ int64_t off_s[kMaxTensors + 1];
     const int64_t n = ts.offset[ts.n];
@@ -50,21 +53,23 @@ __global__ __launch_bounds__(kOptThreads) void k_optimizer_step(OptTensors ts, f
         if (on) {  // every tensor has its own step counter in torch's state; they move together
             const float step = *ts.step[k] + 1.0f;
             const double bc1 = 1.0 - pow((double)hp.beta1, (double)step);
-            step_s[k] = step;
             step_size_s[k] = (float)((double)hp.lr / bc1);
             bc2s_s[k] = (float)sqrt(1.0 - pow((double)hp.beta2, (double)step));
         }
     }
+    // this thread's own element: requested before the norm so that its latency hides behind it
+    const int64_t i = (int64_t)blockIdx.x * kOptThreads + threadIdx.x;
+    const float g_own = i < n ? grads[i] : 0.0f;
     double s = 0.0;
-    for (int64_t base = threadIdx.x; base < n; base += (int64_t)kOptThreads * kBatch) {
-        float g[kBatch];
+    for (int64_t base = threadIdx.x; base < n; base += (int64_t)kOptThreads * kNormBatch) {
+        float g[kNormBatch];
 #pragma unroll
-        for (int u = 0; u < kBatch; ++u) {
-            const int64_t i = base + (int64_t)u * kOptThreads;
-            g[u] = i < n ? grads[i] : 0.0f;
+        for (int u = 0; u < kNormBatch; ++u) {
+            const int64_t e = base + (int64_t)u * kOptThreads;
+            g[u] = e < n ? grads[e] : 0.0f;
         }
 #pragma unroll
-        for (int u = 0; u < kBatch; ++u) s += (double)g[u] * (double)g[u];
+        for (int u = 0; u < kNormBatch; ++u) s += (double)g[u] * (double)g[u];
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
@@ -73,50 +78,35 @@ __global__ __launch_bounds__(kOptThreads) void k_optimizer_step(OptTensors ts, f
     if (threadIdx.x == 0) {
         double t = 0.0;
 #pragma unroll
-        for (int i = 0; i < kOptThreads / 64; ++i) t += part[i];
+        for (int w = 0; w < kOptThreads / 64; ++w) t += part[w];
         const float norm = (float)sqrt(t);
-        if (total_norm) *total_norm = norm;
+        if (total_norm && blockIdx.x == 0) *total_norm = norm;
         const float c = hp.max_norm / (norm + 1e-6f);
         coef_s = c < 1.0f ? c : 1.0f;  // torch multiplies by the clamped coefficient unconditionally
     }
     __syncthreads();
-    const float coef = coef_s, w = 1.0f - hp.beta1;
-    for (int64_t base = threadIdx.x; base < n; base += (int64_t)kOptThreads * kBatch) {
-        int k[kBatch];
-        int32_t e[kBatch];
-        float g[kBatch], m[kBatch], v[kBatch], p[kBatch], tg[kBatch];
-#pragma unroll
-        for (int u = 0; u < kBatch; ++u) {  // all loads of the batch first
-            const int64_t i = base + (int64_t)u * kOptThreads;
-            const bool on = i < n;
-            int kk = 0;
-#pragma unroll
-            for (int q = 1; q < kMaxTensors; ++q) kk += (on && i >= off_s[q]) ? 1 : 0;
-            k[u] = on ? kk : -1;
-            e[u] = on ? (int32_t)(i - off_s[kk]) : 0;
-            g[u] = on ? grads[i] : 0.0f;
-            m[u] = on ? ptr_s[1][kk][e[u]] : 0.0f;
-            v[u] = on ? ptr_s[2][kk][e[u]] : 0.0f;
-            p[u] = on ? ptr_s[0][kk][e[u]] : 0.0f;
-            tg[u] = (on && ptr_s[3][kk]) ? ptr_s[3][kk][e[u]] : 0.0f;
-        }
-#pragma unroll
-        for (int u = 0; u < kBatch; ++u) {
-            if (k[u] < 0) continue;
-            const int kk = k[u];
-            const float grad = g[u] * coef;
-            grads[base + (int64_t)u * kOptThreads] = grad;
-            const float m_new = w < 0.5f ? m[u] + w * (grad - m[u]) : grad - (grad - m[u]) * (1.0f - w);  // at::lerp
-            const float v_new = hp.beta2 * v[u] + (1.0f - hp.beta2) * grad * grad;
-            ptr_s[1][kk][e[u]] = m_new;
-            ptr_s[2][kk][e[u]] = v_new;
-            const float denom = sqrtf(v_new) / bc2s_s[kk] + hp.eps;
-            const float p_new = p[u] - step_size_s[kk] * m_new / denom;
-            ptr_s[0][kk][e[u]] = p_new;
-            if (ptr_s[3][kk]) ptr_s[3][kk][e[u]] = tg[u] * (1.0f - hp.ema) + hp.ema * p_new;
+    if (threadIdx.x == 0) {
+        if (atomicAdd(&g_ticket, 1u) == gridDim.x - 1) {
+            g_ticket = 0;
+            for (int t = 0; t < ts.n; ++t) *ts.step[t] += 1.0f;
         }
     }
-    if ((int)threadIdx.x < ts.n) *ts.step[threadIdx.x] = step_s[threadIdx.x];  // read above by this same thread
+    if (i >= n) return;
+    int k = 0;
+#pragma unroll
+    for (int q = 1; q < kMaxTensors; ++q) k += i >= off_s[q] ? 1 : 0;
+    const int32_t e = (int32_t)(i - off_s[k]);
+    float *pp = ptr_s[0][k] + e, *pm = ptr_s[1][k] + e, *pv = ptr_s[2][k] + e, *pt = ptr_s[3][k] ? ptr_s[3][k] + e : nullptr;
+    const float m = *pm, v = *pv, p = *pp, tg = pt ? *pt : 0.0f;
+    const float grad = g_own * coef_s, w = 1.0f - hp.beta1;
+    const float m_new = w < 0.5f ? m + w * (grad - m) : grad - (grad - m) * (1.0f - w);  // at::lerp
+    const float v_new = hp.beta2 * v + (1.0f - hp.beta2) * grad * grad;
+    *pm = m_new;
+    *pv = v_new;
+    const float denom = sqrtf(v_new) / bc2s_s[k] + hp.eps;
+    const float p_new = p - step_size_s[k] * m_new / denom;
+    *pp = p_new;
+    if (pt) *pt = tg * (1.0f - hp.ema) + hp.ema * p_new;
 }
 
 }  // namespace
@@ -135,7 +125,8 @@ extern "C" int rnad_optimizer_step(int n_tensors, const int64_t *sizes, float *c
         ts.param[k] = param[k]; ts.exp_avg[k] = exp_avg[k]; ts.exp_avg_sq[k] = exp_avg_sq[k]; ts.step[k] = step[k];
         ts.target[k] = target ? target[k] : nullptr;
     }
-    hipLaunchKernelGGL(k_optimizer_step, dim3(1), dim3(kOptThreads), 0, (hipStream_t)stream, ts, grads, *hp, total_norm);
+    const unsigned grid = (unsigned)std::max<int64_t>(1, (ts.offset[n_tensors] + kOptThreads - 1) / kOptThreads);
+    hipLaunchKernelGGL(k_optimizer_step, dim3(grid), dim3(kOptThreads), 0, (hipStream_t)stream, ts, (const float *)grads, *hp, total_norm);
     RNAD_HIP_OK(hipGetLastError());
     return 0;
 }
