@@ -21,7 +21,7 @@
 //                      id, include/rnad_rng.h) and records the trajectory -- column j of every [T, B] buffer
 //   k_bucket_learn     one workgroup per work item: backward-in-time V-trace / NeuRD pass per lane (learn_math.hpp), sums in LDS
 //   k_policy_rows / k_row_records   everything that depends on the (player, state) row alone, once per row instead of per slot
-//   k_bucket_upper / k_bucket_finish    fixed point -> fp32 tables dL/dlogit [2S, A], dL/dv [2S], normalised by the batch-global N_P
+//   k_bucket_finish                     fixed point -> fp32 tables dL/dlogit [2S, A], dL/dv [2S], normalised by the batch-global N_P
 #include "learn_math.hpp"
 #include "rollout_math.hpp"
 
@@ -47,6 +47,7 @@ constexpr int kLaneBits = 22;        // B <= 2^22 lanes per call: a row receives
 constexpr int kLearnLds = 64 * 1024; // LDS budget of one learner workgroup
 constexpr int kPackedSteps = 10;      // env steps whose decisions k_bucket_keys hands to k_bucket_rollout (6 bits each)
 constexpr int kCompactSteps = 21;     // env steps of a compact trajectory: 3 bits of action per step in one 64-bit word
+constexpr int kFinishRows = 4;        // rows per thread of k_bucket_finish
 constexpr int kTargetLanes = 1024;   // finest cut whose groups still hold this many lanes on average (configs[1]: full work items win)
 
 inline unsigned blocks_for(int64_t n, int per = kThreads) { return (unsigned)((n + per - 1) / per); }
@@ -624,10 +625,6 @@ __device__ __forceinline__ long long round_to_ll(double d) {
     return __double_as_longlong(d + kMagic) - __double_as_longlong(kMagic);
 }
 
-__global__ void k_zero_words(uint32_t *__restrict__ p, int n) {
-    if ((int)threadIdx.x < n) p[threadIdx.x] = 0u;
-}
-
 struct FixedPoint {
     double scale_l, scale_v;  // 2^f: units per 1.0 of an addend of dL/dlogit / dL/dv
     float limit_l, limit_v;   // |addend| must stay below this (2^(62 - kLaneBits) units)
@@ -906,53 +903,80 @@ __global__ __launch_bounds__(kThreads) void k_bucket_learn(int T, int64_t B, int
     }
 }
 
-// Rows above the buckets: the kReplicas copies of a row are read by the 64 lanes of ONE wave (lane c: replica c), summed on the
-// DPP network and added into acc; the copies are cleared for the next update.  grid = ceil(2 * n_upper / 4) workgroups of 4 waves.
-template <int A>
-__global__ __launch_bounds__(kThreads) void k_bucket_upper(int64_t S, int n_upper, const int32_t *__restrict__ upper_list,
-                                                           unsigned long long *__restrict__ acc, unsigned long long *__restrict__ rep) {
-    static_assert(kReplicas == 64, "one replica per lane");
-    const int u = blockIdx.x * (kThreads / 64) + (threadIdx.x >> 6), c = threadIdx.x & 63;
-    if (u >= 2 * n_upper) return;
-    const int P = u / n_upper, pos = u % n_upper;
-    unsigned long long *src = rep + (((int64_t)c * 2 + P) * n_upper + pos) * (A + 1);
-    unsigned long long *dst = acc + ((int64_t)P * S + upper_list[pos]) * (A + 1);
-#pragma unroll
-    for (int a = 0; a <= A; ++a) {
-        const unsigned long long v = src[a];
-        if (v != 0ull) src[a] = 0ull;
-        const long long total = wave_total_in_lane63((long long)v);
-        if (c == 63 && total != 0) dst[a] += (unsigned long long)total;
-    }
-}
-
 // acc -> fp32 tables, normalised: dlogit_tab[P * S + s] = w_n * (G_l / N_P), dv_tab likewise with w_v (learn/vtrace.py:374,389;
-// rnad.py:424).  Clears what it read, so that acc is zero again for the next update.  An addend beyond the fixed-point range
-// poisons the tables with NaN instead of passing silently.
+// rnad.py:424).  Clears what it read, so that the accumulators are zero again for the next update.  An addend beyond the
+// fixed-point range poisons the tables with NaN instead of passing silently.
+//   workgroups [0, row_blocks): one thread per (player, state) row below the cut;
+//   the others: the rows above the buckets, one WAVE per row -- its kReplicas copies are read by the 64 lanes (lane c: replica c)
+//   and summed on the DPP network; lane 63 converts.
+// The workgroup that takes the last ticket clears the loss sums and the overflow flag: every workgroup has read them by then.
 template <int A>
-__global__ __launch_bounds__(kThreads) void k_bucket_finish(int64_t S, unsigned long long *__restrict__ acc, const double *__restrict__ norm,
-                                                            float w_v, float w_n, FixedPoint fx, const int32_t *__restrict__ overflow,
-                                                            const double *__restrict__ losses_raw, double *__restrict__ losses,
-                                                            float *__restrict__ dlogit_tab, float *__restrict__ dv_tab) {
-    const int64_t r = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+__global__ __launch_bounds__(kThreads) void k_bucket_finish(int64_t S, int row_blocks, int n_upper, int n_groups,
+                                                            const int32_t *__restrict__ upper_list, const int32_t *__restrict__ bucket_of,
+                                                            unsigned long long *__restrict__ acc, unsigned long long *__restrict__ rep,
+                                                            const double *__restrict__ norm, float w_v, float w_n, FixedPoint fx,
+                                                            int32_t *__restrict__ overflow, double *__restrict__ losses_raw,
+                                                            double *__restrict__ losses, float *__restrict__ dlogit_tab,
+                                                            float *__restrict__ dv_tab) {
+    static_assert(kReplicas == 64, "one replica per lane");
     const float nf0 = norm_of(norm), nf1 = norm_of(norm + 1);
-    if (r == 0 && losses) {
+    const bool bad = *overflow != 0;
+    const float nan = __uint_as_float(0x7fc00000u);
+    if (blockIdx.x == 0 && threadIdx.x == 0 && losses) {
         losses[0] = losses_raw[0] / (double)nf0 + losses_raw[1] / (double)nf1;
         losses[1] = losses_raw[2] / (double)nf0 + losses_raw[3] / (double)nf1;
     }
-    if (r >= 2 * S) return;
-    long long x[A + 1];
+    if ((int)blockIdx.x < row_blocks) {
 #pragma unroll
-    for (int a = 0; a <= A; ++a) {
-        x[a] = (long long)acc[r * (A + 1) + a];
-        if (x[a] != 0) acc[r * (A + 1) + a] = 0ull;
+        for (int part = 0; part < kFinishRows; ++part) {  // (few, fat workgroups: every one of them takes a ticket below)
+            const int64_t r = ((int64_t)blockIdx.x * kFinishRows + part) * kThreads + threadIdx.x;
+            const int64_t s = r >= S ? r - S : r;
+            if (r < 2 * S && !(n_upper > 0 && bucket_of[s] >= n_groups)) {  // (rows above the cut: the wave-per-row workgroups)
+                long long x[A + 1];
+#pragma unroll
+                for (int a = 0; a <= A; ++a) {
+                    x[a] = (long long)acc[r * (A + 1) + a];
+                    if (x[a] != 0) acc[r * (A + 1) + a] = 0ull;
+                }
+                const float nf = r >= S ? nf1 : nf0;
+#pragma unroll
+                for (int a = 0; a < A; ++a) dlogit_tab[r * A + a] = bad ? nan : w_n * ((float)((double)x[a] / fx.scale_l) / nf);
+                dv_tab[r] = bad ? nan : w_v * ((float)((double)x[A] / fx.scale_v) / nf);
+            }
+        }
+    } else {
+        const int u = ((int)blockIdx.x - row_blocks) * (kThreads / 64) + (threadIdx.x >> 6), c = threadIdx.x & 63;
+        if (u < 2 * n_upper) {
+            const int P = u / n_upper, pos = u % n_upper;
+            unsigned long long *src = rep + (((int64_t)c * 2 + P) * n_upper + pos) * (A + 1);
+            const int64_t r = (int64_t)P * S + upper_list[pos];
+            long long x[A + 1];
+#pragma unroll
+            for (int a = 0; a <= A; ++a) {
+                const unsigned long long v = src[a];
+                if (v != 0ull) src[a] = 0ull;
+                x[a] = wave_total_in_lane63((long long)v);
+            }
+            if (c == 63) {
+                const float nf = P ? nf1 : nf0;
+#pragma unroll
+                for (int a = 0; a < A; ++a) dlogit_tab[r * A + a] = bad ? nan : w_n * ((float)((double)x[a] / fx.scale_l) / nf);
+                dv_tab[r] = bad ? nan : w_v * ((float)((double)x[A] / fx.scale_v) / nf);
+            }
+        }
     }
-    const float nf = r >= S ? nf1 : nf0;
-    const bool bad = *overflow != 0;
-    const float nan = __uint_as_float(0x7fc00000u);
+    __syncthreads();  // this workgroup's reads of the flag and the loss sums are complete
+    if (threadIdx.x == 0) {
+        // (no __threadfence: a device-scope release writes the XCD's L2 back -- 22 us here -- and nothing this workgroup wrote is read
+        // by the clearing one)
+        int32_t *ticket = overflow + 1;
+        if (atomicAdd(ticket, 1) == (int)gridDim.x - 1) {
+            *ticket = 0;
+            *overflow = 0;
 #pragma unroll
-    for (int a = 0; a < A; ++a) dlogit_tab[r * A + a] = bad ? nan : w_n * ((float)((double)x[a] / fx.scale_l) / nf);
-    dv_tab[r] = bad ? nan : w_v * ((float)((double)x[A] / fx.scale_v) / nf);
+            for (int u = 0; u < 4; ++u) losses_raw[u] = 0.0;
+        }
+    }
 }
 
 FixedPoint fixed_point_for(const rnad_learn_params_t &hp) {
@@ -1210,12 +1234,11 @@ int finish_impl(const rnad_tree_t *tree, const Plan &p, const double *norm, cons
     int32_t *overflow = (int32_t *)(losses_raw + 4);
     const FixedPoint fx = fixed_point_for(*hp);
     ProfScope fin(PROF_BUCKET_FINISH, stream);
-    if (nu > 0)
-        RNAD_DISPATCH_A(tree->A, hipLaunchKernelGGL((k_bucket_upper<kA>), dim3(blocks_for(2 * (int64_t)nu, kThreads / 64)), dim3(kThreads), 0,
-                                                    stream, S, nu, (const int32_t *)p.cut->upper_list, acc, rep));
-    RNAD_DISPATCH_A(tree->A, hipLaunchKernelGGL((k_bucket_finish<kA>), dim3(blocks_for(2 * S)), dim3(kThreads), 0, stream, S, acc, norm,
-                                                hp->w_v, hp->w_n, fx, (const int32_t *)overflow, (const double *)losses_raw, losses,
-                                                dlogit_tab, dv_tab));
+    const unsigned row_blocks = blocks_for(2 * S, kThreads * kFinishRows), upper_blocks = nu > 0 ? blocks_for(2 * (int64_t)nu, kThreads / 64) : 0;
+    RNAD_DISPATCH_A(tree->A, hipLaunchKernelGGL((k_bucket_finish<kA>), dim3(row_blocks + upper_blocks), dim3(kThreads), 0, stream, S,
+                                                (int)row_blocks, nu, p.cut->n_groups, (const int32_t *)p.cut->upper_list,
+                                                (const int32_t *)p.cut->bucket_of, acc, rep, norm, hp->w_v, hp->w_n, fx, overflow,
+                                                losses_raw, losses, dlogit_tab, dv_tab));
     RNAD_HIP_OK(hipGetLastError());
     return 0;
 }
@@ -1234,9 +1257,9 @@ int learn_bucketed_impl(const rnad_tree_t *tree, int T, int64_t B, const int32_t
     double *losses_raw = (double *)(rep + (int64_t)kReplicas * 2 * std::max(nu, 1) * A1);
     int32_t *overflow = (int32_t *)(losses_raw + 4);
     const FixedPoint fx = fixed_point_for(*hp);
-    // loss sums and the overflow flag start at zero: a 1-wave kernel, not hipMemsetAsync -- the memset node of a captured graph was
-    // seen to write garbage after ~57 replays on ROCm 7.2 (tests/test_hip_graph.py::test_many_replays_stay_finite)
-    hipLaunchKernelGGL(k_zero_words, dim3(1), dim3(64), 0, stream, (uint32_t *)losses_raw, (int)((4 * sizeof(double) + sizeof(int32_t)) / 4));
+    // (the loss sums and the overflow flag are zero here: k_bucket_finish of the previous update cleared them.  Not hipMemsetAsync:
+    // the memset node of a captured graph was seen to write garbage after ~57 replays on ROCm 7.2,
+    // tests/test_hip_graph.py::test_many_replays_stay_finite)
     ProfScope prof(PROF_LEARN, stream);
 #define RNAD_BUCKET_LEARN(COMPACT, LOSSES)                                                                                            \
     do {                                                                                                                              \
