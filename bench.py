@@ -194,6 +194,7 @@ def main():
     graph_state = getattr(rn, "_graph", None)
     replayed = bool(graph_state and graph_state.get("graph") is not None)
     T = rn.last_episodes.t_eff + 1
+    args.compact_in_effect = getattr(rn.last_episodes, "_compact", None) is not None
     default_mode = rn.tabular
     mode_now = rn._tabular_mode(T, local_batch)
 
@@ -311,7 +312,7 @@ def main():
             "host_enqueue_ms_per_step": host_s / host_n * 1e3,
             "net_evaluation": {"mode": f"RNaD.tabular = {default_mode!r}" + (" (default)" if args.net_mode == "default" else ""),
                                "in_effect": repr(mode_now), "what": what[mode_now],
-                               "step_replayed_from_hipGraph": replayed,
+                               "step_replayed_from_hipGraph": replayed, "compact_trajectory": bool(args.compact_in_effect),
                                "distinct_observations": 2 * handle.S, "slots": T * local_batch},
             "other_modes": {name: {"env_steps_per_sec": global_batch * T_ref * E / sec, "updates_per_sec": E / sec,
                                    "ms_per_step": sec / E * 1e3, "steps": E,
@@ -380,13 +381,25 @@ def kernel_report(prof, A, C, args, B, T, live_slots, tree, mode_now):
     rem = (K + 1) % 16
     feat = 16 * ((K + 1) // 16 + (1 if rem > 4 else 0)) + (4 if 0 < rem <= 4 else 0)
     slots = B * T
+    compact = bool(args.compact_in_effect)
+    fast = (4 + 4 * A) * 4  # bytes of a fast row record (rnad_bucket_fast_record_stride)
+    if compact:
+        rollout_model = (4 * B + 8 * B + slots * 4 + 4 * B + 8 * B + 4 * B,
+                         "per lane: lane id 4, drawn decisions 8 (read); per slot: state 4 (written); per lane: final state 4, packed actions 8, "
+                         "reward 4 (written).  Policy rows are gathered from the L2-resident records")
+        learn_model = (live_slots * 4 + B * (4 + 8 + 4) + S2 * fast,
+                       "per live slot: state 4; per lane: final state 4, packed actions 8, reward 4; the 2S fast records (64 B at A = 3) once "
+                       "each -- they are gathered per slot, from L2 / MALL after the first touch; sums stay in LDS")
+    else:
+        rollout_model = (4 * B + slots * (4 + 1 + 4 * A + 4 + 4) + 4 * B,
+                         "lane_ids 4 B/lane + per slot: state 4, legal bits 1, policy 4A, action 4, reward 4 (+ final state 4 B/lane)")
+        learn_model = (live_slots * (4 + 4 + 4 * A) + (live_slots // 2) * 4,
+                       "per live slot: state 4, action 4, acting policy 4A; reward 4 on column steps; sums stay in LDS")
     model = {
         # bytes the kernel must move per launch (streams; the L2-resident tables it gathers from are not HBM traffic)
-        rh.PROF_BUCKET_ROLLOUT: ("hbm", 4 * B + slots * (4 + 1 + 4 * A + 4 + 4) + 4 * B,
-                                 "lane_ids 4 B/lane + per slot: state 4, legal bits 1, policy 4A, action 4, reward 4 (+ final state 4 B/lane)"),
-        rh.PROF_BUCKET_LEARN: ("hbm", live_slots * (4 + 4 + 4 * A) + (live_slots // 2) * 4,
-                               "per live slot: state 4, action 4, acting policy 4A; reward 4 on column steps; sums stay in LDS"),
-        rh.PROF_BUCKET_KEYS: ("hbm", 4 * B, "keys 4 B/lane written; everything else is gathered from L2-resident tables"),
+        rh.PROF_BUCKET_ROLLOUT: ("hbm",) + rollout_model,
+        rh.PROF_BUCKET_LEARN: ("hbm",) + learn_model,
+        rh.PROF_BUCKET_KEYS: ("hbm", 4 * B + 8 * B, "keys 4 B/lane and drawn decisions 8 B/lane written; everything else is gathered from L2-resident tables"),
         rh.PROF_OBSERVE: ("hbm", B * (4 + 8 * A * A + 2 * A * A * (2 if args.obs_half else 4) + 4 * A), "SURVEY 8d"),
     }
     out = {}
@@ -425,6 +438,9 @@ def roofline_of(k):
          "bytes_per_launch": k.get("algorithmic_bytes_per_launch"), "bytes_model": k.get("bytes_model"),
          "share_of_step_us": k["us_per_step"],
          "measured": "hipEvents around each launch, eager leg of the same steps after the timed region (the timed steps replay a graph)"}
+    if k["name"] == "k_bucket_learn":
+        r["limiter"] = ("fp32 VALU, not HBM: ~280 vector instructions per slot (V-trace carries of both players, NeuRD advantage and gates, one "
+                        "IEEE division, 4 fixed-point conversions, 4 LDS atomics); DESIGN.md section 5 has the SQ counters")
     path = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
     if os.path.exists(path):
         with open(path) as f:

@@ -130,13 +130,9 @@ __global__ __launch_bounds__(kFwdThreads) void k_mlp_forward(int64_t N, int W, N
 #pragma unroll
     for (int a = 0; a < A; ++a) bp[a] = b1[1 + a];
 
-    // A WORKGROUP owns 64 consecutive samples per iteration and its waves split the hidden tiles of each head between them
-    // (wave w: tiles w, w + kWaves, ...); the per-wave partial outputs meet in LDS and are added in wave order.  The unit of work is
-    // thus a quarter of a wave-span: at the tabular update's 132 862 rows (2 076 spans for 1 024 SIMDs) whole-wave spans left most
-    // SIMDs idle for a third of the kernel.
-    constexpr int kSpan = 2 * kTile, kWaves = kFwdThreads / 64;
-    __shared__ float red[2][kWaves][kSpan][1 + A];
+    constexpr int kSpan = 2 * kTile;  // samples per wave iteration
     const int64_t n_spans = (N + kSpan - 1) / kSpan;
+    const int64_t span0 = block * (kFwdThreads / 64) + wave, dspan = n_blocks * (kFwdThreads / 64);
     float xn[2][KS];  // inputs of the next span, in flight during the current one
     auto fetch = [&](int64_t span) {
 #pragma unroll
@@ -147,13 +143,12 @@ __global__ __launch_bounds__(kFwdThreads) void k_mlp_forward(int64_t N, int W, N
             for (int ks = 0; ks < KS; ++ks) xn[s][ks] = sample < N ? load_obs<ObsT>(obs + row * K + 2 * ks + half) : 0.0f;
         }
     };
-    if (block < n_spans) fetch(block);
-    int par = 0;
-    for (int64_t span = block; span < n_spans; span += n_blocks, par ^= 1) {
+    if (span0 < n_spans) fetch(span0);
+    for (int64_t span = span0; span < n_spans; span += dspan) {
         float x0[KS], x1[KS];
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) { x0[ks] = xn[0][ks]; x1[ks] = xn[1][ks]; }
-        if (span + n_blocks < n_spans) fetch(span + n_blocks);
+        if (span + dspan < n_spans) fetch(span + dspan);
 
         f32x2 acc_v[2][2], acc_p[2][A][2];
 #pragma unroll
@@ -163,7 +158,7 @@ __global__ __launch_bounds__(kFwdThreads) void k_mlp_forward(int64_t N, int W, N
             for (int a = 0; a < A; ++a) acc_p[s][a][0] = acc_p[s][a][1] = f32x2{0.f, 0.f};
         }
         if ((HEADS & 1) && value) {  // (uniform: a net of the launch that does not want this head skips it)
-            for (int t = wave; t < T; t += kWaves) {
+            for (int t = 0; t < T; ++t) {
                 f32x16 c0, c1;
                 mfma_chain2<A>(lds, W, t, col, half, x0, x1, c0, c1);
                 epilogue_value(c0, w1v + t * kTile + 4 * half, acc_v[0]);
@@ -171,16 +166,17 @@ __global__ __launch_bounds__(kFwdThreads) void k_mlp_forward(int64_t N, int W, N
             }
         }
         if ((HEADS & 2) && logits) {
-            for (int t = wave; t < T; t += kWaves) {
+            for (int t = 0; t < T; ++t) {
                 f32x16 c0, c1;
                 mfma_chain2<A>(lds, W, T + t, col, half, x0, x1, c0, c1);
                 epilogue_policy<A>(c0, w1p + t * kTile + 4 * half, W, acc_p[0]);
                 epilogue_policy<A>(c1, w1p + t * kTile + 4 * half, W, acc_p[1]);
             }
         }
-        // lane-local sums, then the two half-waves (complementary hidden rows of the same 32 samples), then the waves
+        // lane-local sums, then the two half-waves (complementary hidden rows of the same 32 samples)
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
+            const int64_t sample = span * kSpan + s * kTile + col;
             float out_v = (acc_v[s][0].x + acc_v[s][0].y) + (acc_v[s][1].x + acc_v[s][1].y), out_p[A];
 #pragma unroll
             for (int a = 0; a < A; ++a) out_p[a] = (acc_p[s][a][0].x + acc_p[s][a][0].y) + (acc_p[s][a][1].x + acc_p[s][a][1].y);
@@ -189,34 +185,12 @@ __global__ __launch_bounds__(kFwdThreads) void k_mlp_forward(int64_t N, int W, N
 #pragma unroll
                 for (int a = 0; a < A; ++a) out_p[a] += __shfl_xor(out_p[a], 32, 64);
             }
-            if (half == 0) {
-                float *dst = red[par][wave][s * kTile + col];
-                if (HEADS & 1) dst[0] = out_v;
-                if (HEADS & 2) {
-#pragma unroll
-                    for (int a = 0; a < A; ++a) dst[1 + a] = out_p[a];
-                }
-            }
-        }
-        __syncthreads();  // red[par] is next written two iterations from now, after the sync of the iteration in between
-        if (wave == 0) {
-            const int64_t sample = span * kSpan + lane;
-            if (sample < N) {
+            if (sample < N && half == 0) {
                 const int64_t row = rows ? (int64_t)rows[sample] : sample;
-                if ((HEADS & 1) && value) {
-                    float o = red[par][0][lane][0];
-#pragma unroll
-                    for (int w = 1; w < kWaves; ++w) o += red[par][w][lane][0];
-                    value[row] = o + bv;
-                }
+                if ((HEADS & 1) && value) value[row] = out_v + bv;
                 if ((HEADS & 2) && logits) {
 #pragma unroll
-                    for (int a = 0; a < A; ++a) {
-                        float o = red[par][0][lane][1 + a];
-#pragma unroll
-                        for (int w = 1; w < kWaves; ++w) o += red[par][w][lane][1 + a];
-                        logits[row * A + a] = o + bp[a];
-                    }
+                    for (int a = 0; a < A; ++a) logits[row * A + a] = out_p[a] + bp[a];
                 }
             }
         }
@@ -305,19 +279,15 @@ static int mlp_forward_launch(int64_t N, const int32_t *rows, const int64_t *n_r
     RNAD_HIP_OK(hipGetDevice(&dev));
     RNAD_HIP_OK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
     constexpr int kWaves = kFwdThreads / 64;
-    const int blocks_per_cu = std::max(1, std::min(12 / kWaves, (int)(156 * 1024 / lds_bytes)));
-    const int64_t n_spans = (N + 2 * kTile - 1) / (2 * kTile);  // a workgroup iteration covers 64 samples
-    // every net gets a full resident round of workgroups (cus * blocks_per_cu), so a launch of n nets is n rounds deep and the
-    // dispatcher balances the nets' unequal costs; measured at 132 862 rows x (learner: both heads, target: value): 53.6 us this
-    // way, 59.8 / 64.5 us with one persistent round split evenly / by cost, 59.2 us as two launches
-    const int64_t budget = (int64_t)cus * blocks_per_cu;  // (2-4 rounds per net: 57-60 us)
+    const int blocks_per_cu = std::max(1, std::min(12 / kWaves, (int)(160 * 1024 / lds_bytes)));
+    const int64_t n_spans = (N + 2 * kTile - 1) / (2 * kTile);  // a wave iteration covers 64 samples
+    // every net of the launch gets its own full round of workgroups, in one linear grid (a launch per head set cost ~6 us more at
+    // the tabular update's 132 862 rows; one persistent round split evenly / by cost over the nets: 59.8 / 64.5 us instead of 53;
+    // workgroups whose waves split the hidden tiles of one span: no faster there and 46 % slower at 1.9 M rows)
+    const int64_t per_net = std::max<int64_t>(1, std::min<int64_t>((n_spans + kWaves - 1) / kWaves, (int64_t)cus * blocks_per_cu));
     NetSet launch = nets;
     launch.first_block[0] = 0;
-    for (int i = 0; i < 4; ++i) {
-        const int64_t share = i < n_nets ? std::max<int64_t>(1, std::min<int64_t>(n_spans, budget)) : 0;
-        launch.first_block[i + 1] = launch.first_block[i] + (int)share;
-    }
-    for (int i = n_nets; i < 4; ++i) launch.first_block[i + 1] = 0x7fffffff;  // never selected
+    for (int i = 0; i < 4; ++i) launch.first_block[i + 1] = i < n_nets ? launch.first_block[i] + (int)per_net : 0x7fffffff;
     const unsigned grid = (unsigned)launch.first_block[n_nets];
     // only the heads that are wanted are computed: the kernel is instantiated for their union over the nets of the launch
     int heads = 0;
@@ -359,8 +329,7 @@ extern "C" int rnad_mlp_forward(int64_t N, int A, int W, const float *packed, co
 extern "C" int rnad_mlp_forward_multi(int n_nets, int64_t N, int A, int W, const float *const *packed, const void *obs, int obs_half,
                                       float *const *logits, float *const *value, void *stream) {
     RNAD_REQUIRE(n_nets >= 1 && n_nets <= 4 && packed && logits && value, "rnad_mlp_forward_multi: 1..4 nets");
-    // ONE launch for all nets (blockIdx.y picks the net), instantiated for the union of the wanted heads; a net that does not want a
-    // head skips it at run time (a launch per head set cost ~12 us of fixed latency each at the tabular update's 132 862 rows)
+    // ONE launch for all nets, instantiated for the union of the wanted heads; a net that does not want a head skips it at run time
     NetSet nets{};
     for (int i = 0; i < n_nets; ++i) {
         RNAD_REQUIRE(logits[i] || value[i], "rnad_mlp_forward_multi: net %d wants no output", i);

@@ -17,6 +17,8 @@ K="k_bucket_learn|k_bucket_rollout|k_bucket_keys|k_bucket_scatter|k_bucket_finis
 RNAD_NO_GRAPH=1 tools/pmc_run.sh ${tag}_fetch "FETCH_SIZE" "$K" -- python tools/step_probe.py --steps 20 --no-graph > /dev/null
 RNAD_NO_GRAPH=1 tools/pmc_run.sh ${tag}_write "WRITE_SIZE" "$K" -- python tools/step_probe.py --steps 20 --no-graph > /dev/null
 python tools/pmc_traffic.py $O/pmc_${tag}_fetch.csv $O/pmc_${tag}_write.csv $O/${tag}_pmc_traffic.json
+# 3b. what the learner / rollout / keys kernels are bound by: SQ issue counters (their own pass)
+RNAD_NO_GRAPH=1 tools/pmc_run.sh ${tag}_sq "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_LDS" "$K" -- python tools/step_probe.py --steps 20 --no-graph > /dev/null
 tools/pmc_run.sh ${tag}_k1_fetch "FETCH_SIZE" "k_observe|vectorized_elementwise_kernel" -- python tools/k1_pmc.py > /dev/null
 tools/pmc_run.sh ${tag}_k1_write "WRITE_SIZE" "k_observe|vectorized_elementwise_kernel" -- python tools/k1_pmc.py > /dev/null
 head -5 $O/pmc_${tag}_k1_fetch.csv $O/pmc_${tag}_k1_write.csv
