@@ -212,7 +212,7 @@ def main():
              rnad_hip.PROF_LEARN: "learner (all kernels between the forwards and the backward)", rnad_hip.PROF_MLP: "k_mlp_forward",
              rnad_hip.PROF_MLP_BWD: "k_mlp_backward", rnad_hip.PROF_BUCKET_KEYS: "k_bucket_keys",
              rnad_hip.PROF_BUCKET_SORT: "k_bucket_hist+scan+items+scatter", rnad_hip.PROF_BUCKET_ROLLOUT: "k_bucket_rollout",
-             rnad_hip.PROF_BUCKET_LEARN: "k_bucket_learn", rnad_hip.PROF_BUCKET_FINISH: "k_bucket_upper+finish"}
+             rnad_hip.PROF_BUCKET_LEARN: "k_bucket_learn", rnad_hip.PROF_BUCKET_FINISH: "k_bucket_finish"}
     prof = {}
     for k, nm in names.items():
         n, ms = rnad_hip.prof_read(k)
