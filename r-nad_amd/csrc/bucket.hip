@@ -12,16 +12,19 @@
 // consecutive siblings spanning at most R ids, are the "groups".  Lanes are sorted by the group they descend into (their
 // bucket): one workgroup then owns ALL slots of the rows of its group and adds them up in an LDS table indexed by
 // (state - first id of the group); the rows above are upper states every lane of the bucket went through, one row per step
-// for the whole workgroup, and take one wave reduction per step.  No global atomic on the common path, results in 64-bit fixed
+// for the whole workgroup, and are added into 16 LDS copies of that row.  No global atomic on the common path, results in 64-bit fixed
 // point (integer sums: any order, same bits).  On a regular tree the cut is a level; on a pruned one it follows the subtrees.
 //
 //   k_bucket_keys      lane-ordered: plays the env steps above the cut only, key = the group reached (or the upper state the lane ends in)
 //   k_bucket_hist/scan/items/scatter   stable counting sort of the lanes by key (deterministic), work items per bucket
 //   k_bucket_rollout   bucket-ordered: thread j replays lane lane_ids[j] from the root (counter-based noise keyed by the GLOBAL lane
-//                      id, include/rnad_rng.h) and records the trajectory -- column j of every [T, B] buffer
-//   k_bucket_learn     one workgroup per work item: backward-in-time V-trace / NeuRD pass per lane (learn_math.hpp), sums in LDS
+//                      id, include/rnad_rng.h) and records the trajectory -- column j of every [T, B] buffer, or (COMPACT) of
+//                      `indices` alone plus 12 bytes per lane: packed actions and the episode's one reward
+//   k_bucket_expand    the dense [T, B] buffers of a compact trajectory, when something asks for them
+//   k_bucket_learn     one workgroup per work item: backward-in-time V-trace / NeuRD pass per lane (learn_math.hpp; COMPACT:
+//                      fast_slot on row-precomputed operands), sums in LDS
 //   k_policy_rows / k_row_records   everything that depends on the (player, state) row alone, once per row instead of per slot
-//   k_bucket_finish                     fixed point -> fp32 tables dL/dlogit [2S, A], dL/dv [2S], normalised by the batch-global N_P
+//   k_bucket_finish    fixed point -> fp32 tables dL/dlogit [2S, A], dL/dv [2S], normalised by the batch-global N_P
 #include "learn_math.hpp"
 #include "rollout_math.hpp"
 

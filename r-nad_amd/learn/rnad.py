@@ -4,9 +4,11 @@ The host loop is the reference's (`__resume`, learn/rnad.py:458-531): (m, n) sch
 EMA target, regularisation-net rotation.  What one iteration executes depends on `RNaD.tabular`:
 
   True (default, trees that are small next to the batch)
-            the nets on the tree's 2S observations (fused fp32-MFMA kernels) -> row records -> bucket-ordered rollout ->
-            rnad_learn_bucketed (V-trace / NeuRD per lane, gradients summed per (player, state) row in LDS) -> one MLP backward
-            over the 2S rows -> clip -> Adam -> EMA; the whole step is captured once as a hipGraph and replayed (train_step).
+            the nets on the tree's 2S observations (fused fp32-MFMA kernels, one launch) -> row records -> bucket-ordered rollout
+            keeping 64 bytes per lane (compact_trajectory) -> rnad_learn_bucketed_compact (V-trace / NeuRD per lane from
+            row-precomputed operands, gradients summed per (player, state) row in LDS) -> one MLP backward over the 2S rows ->
+            clip + Adam + EMA in one launch (fused_optimizer); the whole step is captured once as a hipGraph and replayed
+            (train_step).
   "forward" nets on the 2S observations, per-slot gradients, per-slot MLP backward: bit-identical to the dense mode.
   False     rollout with K1/K2/K3 around the fused MLP forward on every lane; four MLP forwards over the trajectory -> ONE fused
             kernel (policy heads, process_policy, both players' V-trace, NeuRD + value loss gradients, learn/rnad.py:365-425) ->
@@ -14,8 +16,8 @@ EMA target, regularisation-net rotation.  What one iteration executes depends on
 
 Data parallel: when torch.distributed is initialised (one process per GPU, backend "nccl" == RCCL over xGMI), every rank
 plays `batch_size // world_size` lanes of the SAME seeded noise stream (global lane ids), the two loss normalisers are
-all-reduced (they are batch-global, learn/vtrace.py:373,388), and the 10 756 parameter gradients are all-reduced (sum) in one
-flat bucket before clipping.  No other communication.
+all-reduced (they are batch-global, learn/vtrace.py:373,388; beside the learner kernel, which sums un-normalised addends), and the
+10 756 parameter gradients are all-reduced (sum) in one flat bucket before clipping.  No other communication.
 """
 import logging
 import os
