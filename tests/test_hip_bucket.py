@@ -344,3 +344,60 @@ def test_compact_train_steps_are_the_dense_ones(tmp_path, monkeypatch):
     for k, x in params[False][1].items():
         if isinstance(x, float):
             assert params[True][1][k] == pytest.approx(x, rel=1e-6, abs=1e-9), k
+
+
+def test_long_episodes_fall_back_to_the_dense_trajectory(tmp_path, monkeypatch):
+    """More than 21 env steps do not fit the 3-bits-per-step action word: the default step then keeps the dense trajectory
+    (same bucketed learner, acting policy read from the [T, B, A] buffer) and trains all the same."""
+    from environment.episode import Buffer
+    from learn.rnad import RNaD
+
+    monkeypatch.setenv("RNAD_SAVE_DIR", str(tmp_path))
+    from environment.tree import Tree
+
+    # one row action, two column actions everywhere: 2^11 leaves, episodes of 22 env steps
+    tree = Tree(device=DEV, max_actions=2, max_transitions=1, row_actions=1, col_actions=2, depth_bound=11,
+                row_actions_lambda=lambda t: 1, col_actions_lambda=lambda t: 2)
+    tree.generate()
+    assert 2 * tree.handle().max_depth > 21
+    torch.manual_seed(1)
+    rn = RNaD(tree=tree, device=DEV, directory_name="long", batch_size=1 << 13, eta=0.2, b1_adam=0.0, lr=1e-3,
+              net_params={"type": "MLP", "max_actions": 2, "width": 64})
+    rn.initialize()
+    rn.tabular_gate = 0
+    buf = Buffer(1)
+    for i in range(6):
+        rn.train_step(buf, alpha=0.2 * i)
+        rn.total_steps += 1
+    torch.cuda.synchronize()
+    ep = rn.last_episodes
+    assert ep.buckets is not None and ep._compact is None and ep.policy.shape[0] == 2 * tree.handle().max_depth
+    assert all(torch.isfinite(p).all() for p in rn.net.parameters())
+
+
+def test_compact_rollout_with_a_ragged_last_workgroup_and_two_actions():
+    """B not a multiple of the workgroup size, A = 2 (fast record of 12 floats), explicit lane offset: compact == dense."""
+    import rnad_hip
+    from environment.episode import Episodes
+
+    tree = _native_tree(**TREES["binary"])
+    h = tree.handle()
+    A, B = 2, 777
+    nets = _four_nets(A, 64, seed=4)
+    logit, v, vt, lr, lr_ = _tables(tree, nets, A)
+    hp = rnad_hip.make_learn_params(alpha=1.0, eta=0.5)
+    rec, fast = rnad_hip.bucket_records(h, logit, v, vt, lr, lr_, hp, fast=True)
+    assert fast.shape[1] == 12
+    actor = (rec, rnad_hip.policy_column(A))
+    eps = []
+    for compact in (False, True):
+        ep = Episodes(tree, B, seed=31, lane_offset=5 * B)
+        ep.generate(nets[0], tabular=True, bucketed=True, trim=False, store_values=False, policy_table=actor, compact=compact)
+        eps.append(ep)
+    dense, comp = eps
+    assert comp._compact is not None and torch.equal(comp.indices, dense.indices) and torch.equal(comp.lane_ids, dense.lane_ids)
+    T = dense.t_eff + 1
+    want = rnad_hip.learn_bucketed(h, dense.buckets, dense.indices, dense.action_idx, dense.rewards, dense.policy, rec, dense.valid_counts, hp)
+    got = rnad_hip.learn_bucketed_compact(h, comp.buckets, comp._compact[0], T, rec, fast, comp.valid_counts, hp)
+    assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1])
+    assert torch.equal(comp.rewards, dense.rewards) and torch.equal(comp.policy, dense.policy)
