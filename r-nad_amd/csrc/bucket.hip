@@ -57,7 +57,7 @@ inline unsigned blocks_for(int64_t n, int per = kThreads) { return (unsigned)((n
 
 struct Plan {
     const BucketCut *cut = nullptr;
-    int lds = 0, sort_blocks = 0, chunk = kChunkDefault;
+    int lds = 0, path_words = 0, sort_blocks = 0, chunk = kChunkDefault;
     int64_t max_items = 0;
 };
 
@@ -168,7 +168,9 @@ bool make_plan(const rnad_tree_t *tree, int64_t B, Plan &p) {
     }
     if (!chosen) return false;
     p.cut = chosen;
-    p.lds = (path_words + 2 * chosen->rows * (tree->A + 1)) * 8;
+    // the path region holds the rows of THIS cut's upper steps (not kMaxPath of them: LDS per workgroup bounds the resident waves)
+    p.path_words = std::min(kMaxPath, std::max(chosen->max_path, 1)) * kPathSlots * ((tree->A + 1) | 1);
+    p.lds = (p.path_words + 2 * chosen->rows * (tree->A + 1)) * 8;
     p.sort_blocks = (int)((B + kSortLanes - 1) / kSortLanes);
     if (const char *c = getenv("RNAD_BUCKET_CHUNK")) p.chunk = std::max(64, atoi(c));  // tuning knob
     p.max_items = (int64_t)chosen->n_buckets + B / p.chunk + 1;
@@ -717,7 +719,7 @@ __device__ __forceinline__ void fast_slot(const float *__restrict__ f, const flo
 // the dense variant, hence the same sums.  LOSSES (COMPACT only; the dense variant always adds them up): loss_v / loss_nerd sums
 // for a logging step, which need the logits of the dense record (logit_).
 template <int A, bool COMPACT, bool LOSSES>
-__global__ __launch_bounds__(kThreads) void k_bucket_learn(int T, int64_t B, int64_t S, int sub_rows, int n_groups, int up_stride,
+__global__ __launch_bounds__(kThreads) void k_bucket_learn(int T, int64_t B, int64_t S, int sub_rows, int path_words, int n_groups, int up_stride,
                                                            const Item *__restrict__ items, const int32_t *__restrict__ n_items,
                                                            const int32_t *__restrict__ bucket_of, const int32_t *__restrict__ bucket_lo,
                                                            const int32_t *__restrict__ bucket_path, const int32_t *__restrict__ indices,
@@ -730,7 +732,8 @@ __global__ __launch_bounds__(kThreads) void k_bucket_learn(int T, int64_t B, int
                                                            int32_t *__restrict__ overflow) {
     // [kMaxPath path rows][kPathSlots copies][(A + 1) | 1]  |  [sub_rows rows of player 0 | sub_rows rows of player 1][A + 1]
     extern __shared__ unsigned long long tab[];
-    constexpr int PS = (A + 1) | 1, kPathWords = kMaxPath * kPathSlots * PS;
+    constexpr int PS = (A + 1) | 1;
+    const int kPathWords = path_words;  // u64 words of the path region: max_path rows of the cut x kPathSlots copies
     __shared__ int32_t path_state[kMaxPath];
     __shared__ double loss_part[kThreads / 64][4];
     if ((int)blockIdx.x >= *n_items) return;
@@ -1268,7 +1271,7 @@ int learn_bucketed_impl(const rnad_tree_t *tree, int T, int64_t B, const int32_t
     do {                                                                                                                              \
         auto kern = k_bucket_learn<kA, COMPACT, LOSSES>;                                                                              \
         if (p.lds > 48 * 1024) RNAD_HIP_OK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, p.lds)); \
-        hipLaunchKernelGGL(kern, dim3((unsigned)p.max_items), dim3(kThreads), (size_t)p.lds, stream, T, B, S, p.cut->rows,            \
+        hipLaunchKernelGGL(kern, dim3((unsigned)p.max_items), dim3(kThreads), (size_t)p.lds, stream, T, B, S, p.cut->rows, p.path_words, \
                            p.cut->n_groups, std::max(nu, 1), (const Item *)items, n_items, (const int32_t *)p.cut->bucket_of,         \
                            (const int32_t *)p.cut->bucket_lo, (const int32_t *)p.cut->bucket_path, indices, actions, rewards, mu,     \
                            compact ? fast : records, acts, final_reward, records, *hp, fx, acc, rep,                                  \
