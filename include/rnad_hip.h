@@ -351,7 +351,8 @@ int rnad_learn_fused_gather(const rnad_tree_t *tree, int T, int64_t B, const int
  * Compact trajectory (on-policy updates: the batch is learned from in the step that played it, learn/rnad.py:502-510 with the
  * default one-batch buffer).  Of a slot's record only the state cannot be recomputed: the mask and the acting policy are rows of
  * tables, the action takes 3 bits, and rewards *= (indices == 0) (episode.py:120-121) leaves one non-zero reward per episode.
- * rnad_rollout_bucketed_compact plays the same episodes as rnad_rollout_bucketed with the pi columns of `records` as the actor and
+ * rnad_rollout_bucketed_compact plays the same episodes as rnad_rollout_bucketed (same table arguments: e.g. the pi columns of
+ * `records`: table = records + 3A + 3, table_stride = rnad_bucket_record_stride(A), table_is_policy = 1) and
  * writes indices [T_cap + 1, B], alive, acts (uint64 [B]: action of step t in bits 3t .. 3t + 2) and final_reward (f32 [B]) -- 64
  * instead of 300 bytes per lane at A = 3, T = 12; T_cap <= 21.  rnad_learn_bucketed_compact is rnad_learn_bucketed on that
  * trajectory with the actor's own pi as the acting policy (the very floats the rollout sampled from), so that every operand of a
@@ -362,6 +363,14 @@ int rnad_learn_fused_gather(const rnad_tree_t *tree, int T, int64_t B, const int
  * with the operations learn/vtrace.py applies per slot, and the learner does the rest: same gradients bit for bit.  `records` is
  * only read when `losses` is asked for (the logits).  rnad_bucket_expand writes the dense [T, B] buffers of such a trajectory (mask_bits, policy, actions, rewards) when
  * something asks for them; slots of absorbed lanes get action 0 (the dense rollout keeps drawing there; nothing reads them).
+ *
+ * Lazy rows (trees that are large next to the batch: configs[3] has 1.9 M rows of which a 2^20-lane batch visits 5 %).  The compact
+ * rollout only needs the actor's policy, so: the learner's POLICY head on all 2S rows (table = its logits, table_is_policy = 0: the
+ * policy head is taken once per row into scratch, or table = policy rows) -> rnad_rollout_bucketed_compact with `visited` (int32
+ * [2S], optional: set to 1 for every (player, state) row a live slot sits in, plus the two rows of the absorbing state; cleared
+ * first) -> rnad_compact_valid(2S, visited, rows, n_rows) -> the value heads on the listed rows (rnad_mlp_forward_rows) ->
+ * rnad_bucket_records / rnad_learn_bucketed_compact / rnad_bucket_finish with that row list (rows, n_rows: device memory, both NULL =
+ * all rows; rows that are not listed are neither read nor written, and their accumulators are zero) -> rnad_mlp_backward_rows.
  *
  * norm == NULL in rnad_learn_bucketed / rnad_learn_bucketed_compact: the sums stay in `accumulators` (losses, dlogit_tab, dv_tab are
  * not written) and rnad_bucket_finish completes the update -- so that a data-parallel caller's all-reduce of the normalisers
@@ -383,10 +392,10 @@ int rnad_rollout_bucketed(const rnad_tree_t *tree, const rnad_traj_t *traj, cons
                           int table_is_policy, const float *value_table, int64_t value_stride, uint64_t seed, int64_t lane0,
                           const rnad_step_params_t *device_params, void *scratch, int32_t *lane_ids, int32_t *items, int32_t *n_items,
                           double *norm, void *stream);
-int rnad_rollout_bucketed_compact(const rnad_tree_t *tree, int T_cap, int64_t B, const float *records, uint64_t seed, int64_t lane0,
-                                  const rnad_step_params_t *device_params, void *scratch, int32_t *lane_ids, int32_t *items,
-                                  int32_t *n_items, double *norm, int32_t *indices, int32_t *alive, uint64_t *acts,
-                                  float *final_reward, void *stream);
+int rnad_rollout_bucketed_compact(const rnad_tree_t *tree, int T_cap, int64_t B, const float *table, int64_t table_stride,
+                                  int table_is_policy, uint64_t seed, int64_t lane0, const rnad_step_params_t *device_params,
+                                  void *scratch, int32_t *lane_ids, int32_t *items, int32_t *n_items, double *norm, int32_t *indices,
+                                  int32_t *alive, uint64_t *acts, float *final_reward, int32_t *visited, void *stream);
 int rnad_bucket_expand(const rnad_tree_t *tree, int T, int64_t B, const int32_t *indices, const uint64_t *acts,
                        const float *final_reward, const float *records, uint8_t *mask_bits, float *policy, int32_t *actions,
                        float *rewards, void *stream);
@@ -394,7 +403,8 @@ int64_t rnad_bucket_record_stride(int A);
 int64_t rnad_bucket_fast_record_stride(int A);
 int rnad_bucket_records(const rnad_tree_t *tree, const float *logit_tab, const float *v_tab, const float *v_target_tab,
                         const float *logit_reg_tab, const float *logit_reg_tab_, const rnad_learn_params_t *hp,
-                        const rnad_step_params_t *device_params, float *records, float *fast_records, void *stream);
+                        const rnad_step_params_t *device_params, float *records, float *fast_records, const int32_t *rows,
+                        const int64_t *n_rows, void *stream);
 int rnad_learn_bucketed(const rnad_tree_t *tree, int T, int64_t B, const int32_t *indices, const int32_t *actions,
                         const float *rewards, const float *mu, const float *records, const int32_t *items, const int32_t *n_items,
                         const double *norm, const rnad_learn_params_t *hp, void *accumulators, double *losses, float *dlogit_tab,
@@ -402,9 +412,10 @@ int rnad_learn_bucketed(const rnad_tree_t *tree, int T, int64_t B, const int32_t
 int rnad_learn_bucketed_compact(const rnad_tree_t *tree, int T, int64_t B, const int32_t *indices, const uint64_t *acts,
                                 const float *final_reward, const float *fast_records, const float *records, const int32_t *items,
                                 const int32_t *n_items, const double *norm, const rnad_learn_params_t *hp, void *accumulators,
-                                double *losses, float *dlogit_tab, float *dv_tab, void *stream);
+                                double *losses, float *dlogit_tab, float *dv_tab, const int32_t *rows, const int64_t *n_rows,
+                                void *stream);
 int rnad_bucket_finish(const rnad_tree_t *tree, int64_t B, const double *norm, const rnad_learn_params_t *hp, void *accumulators,
-                       double *losses, float *dlogit_tab, float *dv_tab, void *stream);
+                       double *losses, float *dlogit_tab, float *dv_tab, const int32_t *rows, const int64_t *n_rows, void *stream);
 
 /* torch.nn.utils.clip_grad_norm_(parameters, max_norm) of learn/rnad.py:456 over one flat fp32 gradient bucket (all of a net's
  * .grad tensors back to back): g *= min(max_norm / (||g||_2 + 1e-6), 1), in place, one launch.  total_norm: optional device

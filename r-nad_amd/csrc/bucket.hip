@@ -240,9 +240,11 @@ __global__ __launch_bounds__(kThreads) void k_row_records(int64_t rows, const fl
                                                           const float *__restrict__ vt, const float *__restrict__ lr_,
                                                           const float *__restrict__ lr2_, const uint8_t *__restrict__ mask_tab,
                                                           rnad_learn_params_t hp, const rnad_step_params_t *__restrict__ sp,
-                                                          float *__restrict__ rec, float *__restrict__ fast) {
-    const int64_t r = (int64_t)blockIdx.x * kThreads + threadIdx.x;
-    if (r >= rows) return;
+                                                          float *__restrict__ rec, float *__restrict__ fast,
+                                                          const int32_t *__restrict__ row_list, const int64_t *__restrict__ n_rows) {
+    const int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    if (i >= (row_list ? *n_rows : rows)) return;
+    const int64_t r = row_list ? (int64_t)row_list[i] : i;  // row list: only the rows a batch visited (lazy rows, learn/rnad.py)
     if (sp) {
         hp.alpha = sp->alpha;
         hp.one_minus_alpha = sp->one_minus_alpha;
@@ -504,7 +506,8 @@ __global__ __launch_bounds__(kThreads) void k_bucket_rollout(const Trans *__rest
                                                              uint8_t *__restrict__ mbits, float *__restrict__ policy,
                                                              int32_t *__restrict__ actions, float *__restrict__ rewards,
                                                              float *__restrict__ values, int32_t *__restrict__ alive_part,
-                                                             unsigned long long *__restrict__ acts_out, float *__restrict__ reward_out) {
+                                                             unsigned long long *__restrict__ acts_out, float *__restrict__ reward_out,
+                                                             int32_t *__restrict__ visited) {
     __shared__ int32_t cnt[kThreads / 64][kMaxSteps + 1];
     const int64_t j = (int64_t)blockIdx.x * kThreads + threadIdx.x;
     const bool active = j < B;
@@ -533,6 +536,7 @@ __global__ __launch_bounds__(kThreads) void k_bucket_rollout(const Trans *__rest
             if (COMPACT) {
                 indices[i] = state;
                 if (state != 0) {
+                    if (visited) visited[row] = 1;  // (every writer stores the same value)
                     if (!replay) {
                         float pol[A], q[A];
 #pragma unroll
@@ -917,7 +921,8 @@ __global__ __launch_bounds__(kThreads) void k_bucket_learn(int T, int64_t B, int
 //   and summed on the DPP network; lane 63 converts.
 // The workgroup that takes the last ticket clears the loss sums and the overflow flag: every workgroup has read them by then.
 template <int A>
-__global__ __launch_bounds__(kThreads) void k_bucket_finish(int64_t S, int row_blocks, int n_upper, int n_groups,
+__global__ __launch_bounds__(kThreads) void k_bucket_finish(int64_t S, int row_blocks, const int32_t *__restrict__ row_list,
+                                                            const int64_t *__restrict__ n_rows, int n_upper, int n_groups,
                                                             const int32_t *__restrict__ upper_list, const int32_t *__restrict__ bucket_of,
                                                             unsigned long long *__restrict__ acc, unsigned long long *__restrict__ rep,
                                                             const double *__restrict__ norm, float w_v, float w_n, FixedPoint fx,
@@ -933,11 +938,13 @@ __global__ __launch_bounds__(kThreads) void k_bucket_finish(int64_t S, int row_b
         losses[1] = losses_raw[2] / (double)nf0 + losses_raw[3] / (double)nf1;
     }
     if ((int)blockIdx.x < row_blocks) {
-#pragma unroll
-        for (int part = 0; part < kFinishRows; ++part) {  // (few, fat workgroups: every one of them takes a ticket below)
-            const int64_t r = ((int64_t)blockIdx.x * kFinishRows + part) * kThreads + threadIdx.x;
+        // (few, fat workgroups: every one of them takes a ticket below)
+        const int64_t limit = row_list ? *n_rows : 2 * S;
+        for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < limit; i += (int64_t)row_blocks * kThreads) {
+            const bool in = true;
+            const int64_t r = (in && row_list) ? (int64_t)row_list[i] : i;  // row list: the rows the batch visited (all others hold zero sums)
             const int64_t s = r >= S ? r - S : r;
-            if (r < 2 * S && !(n_upper > 0 && bucket_of[s] >= n_groups)) {  // (rows above the cut: the wave-per-row workgroups)
+            if (in && !(n_upper > 0 && bucket_of[s] >= n_groups)) {  // (rows above the cut: the wave-per-row workgroups)
                 long long x[A + 1];
 #pragma unroll
                 for (int a = 0; a <= A; ++a) {
@@ -1079,19 +1086,30 @@ extern "C" int64_t rnad_bucket_fast_record_stride(int A) { return 4 + 4 * (int64
 
 extern "C" int rnad_bucket_records(const rnad_tree_t *tree, const float *logit_tab, const float *v_tab, const float *v_target_tab,
                                    const float *logit_reg_tab, const float *logit_reg_tab_, const rnad_learn_params_t *hp,
-                                   const rnad_step_params_t *device_params, float *records, float *fast_records, void *stream) {
+                                   const rnad_step_params_t *device_params, float *records, float *fast_records, const int32_t *rows,
+                                   const int64_t *n_rows, void *stream) {
     RNAD_REQUIRE(tree && logit_tab && v_tab && v_target_tab && logit_reg_tab && logit_reg_tab_ && hp && records,
                  "rnad_bucket_records: null argument");
     RNAD_REQUIRE(((uintptr_t)records & 15) == 0 && ((uintptr_t)fast_records & 15) == 0, "rnad_bucket_records: records must be 16-byte aligned");
     RNAD_REQUIRE(hp->n_disc >= 1, "rnad_bucket_records: n_disc must be positive");
+    RNAD_REQUIRE(!rows == !n_rows, "rnad_bucket_records: rows and n_rows go together");
     RNAD_DISPATCH_A(tree->A, hipLaunchKernelGGL((k_row_records<kA>), dim3(blocks_for(2 * tree->S)), dim3(kThreads), 0, (hipStream_t)stream,
                                                 2 * tree->S, logit_tab, v_tab, v_target_tab, logit_reg_tab, logit_reg_tab_,
-                                                (const uint8_t *)tree->mask_tab, *hp, device_params, records, fast_records));
+                                                (const uint8_t *)tree->mask_tab, *hp, device_params, records, fast_records, rows, n_rows));
     RNAD_HIP_OK(hipGetLastError());
     return 0;
 }
 
 namespace {
+// visited[r] = 0, except the two rows of the absorbing state: absorbed slots of the dense buffers show them (k_bucket_expand)
+__global__ __launch_bounds__(kThreads) void k_clear_visited(int64_t rows, int64_t S, int32_t *__restrict__ visited) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int64_t r = ((int64_t)blockIdx.x * 4 + u) * kThreads + threadIdx.x;
+        if (r < rows) visited[r] = (r == 0 || r == S) ? 1 : 0;
+    }
+}
+
 struct RolloutBuffers {  // the dense trajectory (rnad_traj_t) or the compact one
     int T_cap;
     int64_t B;
@@ -1103,6 +1121,7 @@ struct RolloutBuffers {  // the dense trajectory (rnad_traj_t) or the compact on
     int32_t *alive;
     unsigned long long *acts;  // compact: 3 bits per step
     float *final_reward;       // compact
+    int32_t *visited;          // compact, optional: [2S] flags of the rows the batch went through
 };
 
 int rollout_bucketed_impl(const rnad_tree_t *tree, const RolloutBuffers &tr, bool compact, const float *table, int64_t table_stride,
@@ -1115,6 +1134,8 @@ int rollout_bucketed_impl(const rnad_tree_t *tree, const RolloutBuffers &tr, boo
     const Scratch s = carve_scratch(scratch, B, p);
     const int n_steps = std::min(p.cut->max_path, tr.T_cap), nb = p.cut->n_buckets;
     ProfScope prof(PROF_ACT, stream);
+    if (tr.visited)  // cleared by a kernel (memset nodes of captured graphs are not to be trusted, see learn_bucketed_impl)
+        hipLaunchKernelGGL(k_clear_visited, dim3(blocks_for(2 * S, kThreads * 4)), dim3(kThreads), 0, stream, 2 * S, S, tr.visited);
     const float *policy_tab = table;
     int64_t policy_stride = table_stride;
     if (!table_is_policy) {  // logits given: the policy head once per (player, state) row
@@ -1147,7 +1168,7 @@ int rollout_bucketed_impl(const rnad_tree_t *tree, const RolloutBuffers &tr, boo
     hipLaunchKernelGGL((k_bucket_rollout<kA, COMPACT>), dim3(grid), dim3(kThreads), 0, stream, tree->trans, tree->C, S, B, tr.T_cap,         \
                        policy_tab, policy_stride, value_table, value_stride, (const uint8_t *)tree->mask_tab, seed, device_params, lane0,   \
                        (const int32_t *)lane_ids, (const unsigned long long *)s.decisions, tr.indices, tr.mask_bits, tr.policy, tr.actions, \
-                       tr.rewards, tr.values, s.alive_part, tr.acts, tr.final_reward)
+                       tr.rewards, tr.values, s.alive_part, tr.acts, tr.final_reward, tr.visited)
         if (compact) {
             RNAD_DISPATCH_A(tree->A, RNAD_BUCKET_ROLLOUT(true));
         } else {
@@ -1173,23 +1194,26 @@ extern "C" int rnad_rollout_bucketed(const rnad_tree_t *tree, const rnad_traj_t 
                  tr->T_cap, (long long)tr->B);
     RNAD_REQUIRE(table_stride >= tree->A && (!value_table || value_stride >= 1), "rnad_rollout_bucketed: bad table stride");
     const RolloutBuffers out{(int)tr->T_cap, tr->B, tr->indices, tr->mask_bits, tr->policy, tr->actions, tr->rewards, tr->values, tr->alive,
-                             nullptr, nullptr};
+                             nullptr, nullptr, nullptr};
     return rollout_bucketed_impl(tree, out, false, table, table_stride, table_is_policy, value_table, value_stride, seed, lane0, device_params,
                                  scratch, lane_ids, items, n_items, norm, (hipStream_t)stream);
 }
 
-extern "C" int rnad_rollout_bucketed_compact(const rnad_tree_t *tree, int T_cap, int64_t B, const float *records, uint64_t seed, int64_t lane0,
-                                             const rnad_step_params_t *device_params, void *scratch, int32_t *lane_ids, int32_t *items,
-                                             int32_t *n_items, double *norm, int32_t *indices, int32_t *alive, uint64_t *acts,
-                                             float *final_reward, void *stream) {
-    RNAD_REQUIRE(tree && records && scratch && lane_ids && items && n_items && indices && alive && acts && final_reward,
+extern "C" int rnad_rollout_bucketed_compact(const rnad_tree_t *tree, int T_cap, int64_t B, const float *table, int64_t table_stride,
+                                             int table_is_policy, uint64_t seed, int64_t lane0, const rnad_step_params_t *device_params,
+                                             void *scratch, int32_t *lane_ids, int32_t *items, int32_t *n_items, double *norm,
+                                             int32_t *indices, int32_t *alive, uint64_t *acts, float *final_reward, int32_t *visited,
+                                             void *stream) {
+    RNAD_REQUIRE(tree && table && scratch && lane_ids && items && n_items && indices && alive && acts && final_reward,
                  "rnad_rollout_bucketed_compact: null argument");
     RNAD_REQUIRE(T_cap >= 1 && T_cap <= kCompactSteps && B >= 1, "rnad_rollout_bucketed_compact: 1 <= T_cap <= %d (3 bits per step), got %d",
                  kCompactSteps, T_cap);
+    RNAD_REQUIRE(table_stride >= tree->A, "rnad_rollout_bucketed_compact: bad table stride");
     static_assert(RNAD_MAX_ACTIONS <= 8, "3 bits per action");
-    const RolloutBuffers out{T_cap, B, indices, nullptr, nullptr, nullptr, nullptr, nullptr, alive, (unsigned long long *)acts, final_reward};
-    return rollout_bucketed_impl(tree, out, true, records + 3 * tree->A + 3, rnad_bucket_record_stride(tree->A), 1, nullptr, 1, seed, lane0,
-                                 device_params, scratch, lane_ids, items, n_items, norm, (hipStream_t)stream);
+    const RolloutBuffers out{T_cap, B, indices, nullptr, nullptr, nullptr, nullptr, nullptr, alive, (unsigned long long *)acts, final_reward,
+                             visited};
+    return rollout_bucketed_impl(tree, out, true, table, table_stride, table_is_policy, nullptr, 1, seed, lane0, device_params, scratch,
+                                 lane_ids, items, n_items, norm, (hipStream_t)stream);
 }
 
 // The dense buffers of a compact trajectory: slot (t, j) from indices[t, j] (and indices[t + 1, j] for the reward) alone.
@@ -1231,7 +1255,7 @@ extern "C" int rnad_bucket_expand(const rnad_tree_t *tree, int T, int64_t B, con
 namespace {
 // upper rows out of their replicas, then sums -> normalised fp32 tables (and the two logged losses)
 int finish_impl(const rnad_tree_t *tree, const Plan &p, const double *norm, const rnad_learn_params_t *hp, void *accumulators, double *losses,
-                float *dlogit_tab, float *dv_tab, hipStream_t stream) {
+                float *dlogit_tab, float *dv_tab, const int32_t *rows, const int64_t *n_rows, hipStream_t stream) {
     const int64_t S = tree->S, A1 = tree->A + 1;
     unsigned long long *acc = (unsigned long long *)accumulators;
     unsigned long long *rep = acc + 2 * S * A1;
@@ -1240,9 +1264,9 @@ int finish_impl(const rnad_tree_t *tree, const Plan &p, const double *norm, cons
     int32_t *overflow = (int32_t *)(losses_raw + 4);
     const FixedPoint fx = fixed_point_for(*hp);
     ProfScope fin(PROF_BUCKET_FINISH, stream);
-    const unsigned row_blocks = blocks_for(2 * S, kThreads * kFinishRows), upper_blocks = nu > 0 ? blocks_for(2 * (int64_t)nu, kThreads / 64) : 0;
+    const unsigned row_blocks = std::min(blocks_for(2 * S, kThreads * kFinishRows), 512u), upper_blocks = nu > 0 ? blocks_for(2 * (int64_t)nu, kThreads / 64) : 0;
     RNAD_DISPATCH_A(tree->A, hipLaunchKernelGGL((k_bucket_finish<kA>), dim3(row_blocks + upper_blocks), dim3(kThreads), 0, stream, S,
-                                                (int)row_blocks, nu, p.cut->n_groups, (const int32_t *)p.cut->upper_list,
+                                                (int)row_blocks, rows, n_rows, nu, p.cut->n_groups, (const int32_t *)p.cut->upper_list,
                                                 (const int32_t *)p.cut->bucket_of, acc, rep, norm, hp->w_v, hp->w_n, fx, overflow,
                                                 losses_raw, losses, dlogit_tab, dv_tab));
     RNAD_HIP_OK(hipGetLastError());
@@ -1252,7 +1276,8 @@ int finish_impl(const rnad_tree_t *tree, const Plan &p, const double *norm, cons
 int learn_bucketed_impl(const rnad_tree_t *tree, int T, int64_t B, const int32_t *indices, const int32_t *actions, const float *rewards,
                         const float *mu, const unsigned long long *acts, const float *final_reward, const float *records,
                         const float *fast, const int32_t *items, const int32_t *n_items, const double *norm, const rnad_learn_params_t *hp,
-                        void *accumulators, double *losses, float *dlogit_tab, float *dv_tab, hipStream_t stream) {
+                        void *accumulators, double *losses, float *dlogit_tab, float *dv_tab, const int32_t *rows, const int64_t *n_rows,
+                        hipStream_t stream) {
     const bool compact = acts != nullptr;
     Plan p;
     RNAD_REQUIRE(make_plan(tree, B, p), "rnad_learn_bucketed: this tree / batch cannot be bucketed (see rnad_bucket_plan)");
@@ -1290,16 +1315,17 @@ int learn_bucketed_impl(const rnad_tree_t *tree, int T, int64_t B, const int32_t
 #undef RNAD_BUCKET_LEARN
     RNAD_HIP_OK(hipGetLastError());
     if (!norm) return 0;  // the caller completes the update with rnad_bucket_finish once the normalisers are known
-    return finish_impl(tree, p, norm, hp, accumulators, losses, dlogit_tab, dv_tab, stream);
+    return finish_impl(tree, p, norm, hp, accumulators, losses, dlogit_tab, dv_tab, rows, n_rows, stream);
 }
 }  // namespace
 
 extern "C" int rnad_bucket_finish(const rnad_tree_t *tree, int64_t B, const double *norm, const rnad_learn_params_t *hp, void *accumulators,
-                                  double *losses, float *dlogit_tab, float *dv_tab, void *stream) {
+                                  double *losses, float *dlogit_tab, float *dv_tab, const int32_t *rows, const int64_t *n_rows, void *stream) {
     RNAD_REQUIRE(tree && norm && hp && accumulators && dlogit_tab && dv_tab, "rnad_bucket_finish: null argument");
+    RNAD_REQUIRE(!rows == !n_rows, "rnad_bucket_finish: rows and n_rows go together");
     Plan p;
     RNAD_REQUIRE(make_plan(tree, B, p), "rnad_bucket_finish: this tree / batch cannot be bucketed (see rnad_bucket_plan)");
-    return finish_impl(tree, p, norm, hp, accumulators, losses, dlogit_tab, dv_tab, (hipStream_t)stream);
+    return finish_impl(tree, p, norm, hp, accumulators, losses, dlogit_tab, dv_tab, rows, n_rows, (hipStream_t)stream);
 }
 
 extern "C" int rnad_learn_bucketed(const rnad_tree_t *tree, int T, int64_t B, const int32_t *indices, const int32_t *actions,
@@ -1310,18 +1336,21 @@ extern "C" int rnad_learn_bucketed(const rnad_tree_t *tree, int T, int64_t B, co
                  "rnad_learn_bucketed: null argument");
     RNAD_REQUIRE(T >= 1 && B >= 1, "rnad_learn_bucketed: bad shape");
     return learn_bucketed_impl(tree, T, B, indices, actions, rewards, mu, nullptr, nullptr, records, nullptr, items, n_items, norm, hp,
-                               accumulators, losses, dlogit_tab, dv_tab, (hipStream_t)stream);
+                               accumulators, losses, dlogit_tab, dv_tab, nullptr, nullptr, (hipStream_t)stream);
 }
 
 extern "C" int rnad_learn_bucketed_compact(const rnad_tree_t *tree, int T, int64_t B, const int32_t *indices, const uint64_t *acts,
                                            const float *final_reward, const float *fast_records, const float *records,
                                            const int32_t *items, const int32_t *n_items, const double *norm, const rnad_learn_params_t *hp,
-                                           void *accumulators, double *losses, float *dlogit_tab, float *dv_tab, void *stream) {
+                                           void *accumulators, double *losses, float *dlogit_tab, float *dv_tab, const int32_t *rows,
+                                           const int64_t *n_rows, void *stream) {
+    RNAD_REQUIRE(!rows == !n_rows, "rnad_learn_bucketed_compact: rows and n_rows go together");
     RNAD_REQUIRE(tree && indices && acts && final_reward && fast_records && items && n_items && hp && accumulators && dlogit_tab && dv_tab,
                  "rnad_learn_bucketed_compact: null argument");
     RNAD_REQUIRE(!losses || records, "rnad_learn_bucketed_compact: the losses need the dense records (logits)");
     RNAD_REQUIRE(((uintptr_t)fast_records & 15) == 0, "rnad_learn_bucketed_compact: fast_records must be 16-byte aligned");
     RNAD_REQUIRE(T >= 1 && T <= kCompactSteps && B >= 1, "rnad_learn_bucketed_compact: bad shape");
     return learn_bucketed_impl(tree, T, B, indices, nullptr, nullptr, nullptr, (const unsigned long long *)acts, final_reward, records,
-                               fast_records, items, n_items, norm, hp, accumulators, losses, dlogit_tab, dv_tab, (hipStream_t)stream);
+                               fast_records, items, n_items, norm, hp, accumulators, losses, dlogit_tab, dv_tab, rows, n_rows,
+                               (hipStream_t)stream);
 }

@@ -178,6 +178,8 @@ class Episodes:
     def _expand(self):
         """Dense mask_bits / policy / action_idx / rewards of a compact rollout (rnad_bucket_expand), on first access."""
         traj, records = self._compact
+        if records is None:
+            raise RuntimeError("this compact batch has no row records attached yet (Episodes.generate(compact=True, logits_table=...))")
         if traj.policy is None:
             rnad_hip.bucket_expand(self.tree.handle(), traj, records)
         T = self.t_eff + 1
@@ -224,7 +226,7 @@ class Episodes:
     # ---------------------------------------------------------------- episode.py:175-230
     def generate(self, net: torch.nn.Module, noise_action=None, noise_chance=None, max_steps=None, trim=True, keep_logits=False,
                  skip_absorbed=False, store_values=True, tabular=None, bucketed=False, logits_table=None, value_table=None, policy_table=None, step_params=None,
-                 compact=False):
+                 compact=False, visited=None):
         """Play the batch to the end with `net` as the actor.
 
         Nets exposing `forward_logits(obs) -> (logits [B,A], value [B,1])` (the MLP here) take the fast path: policy head,
@@ -261,7 +263,9 @@ class Episodes:
         at most 21 steps): the rollout stores 64 bytes per lane -- `indices`, the packed actions and the episode's one non-zero
         reward (rnad_rollout_bucketed_compact) -- which is all RNaD's on-policy update reads; `mask_bits`, `policy`, `action_idx`,
         `rewards` (and what derives from them) are written by rnad_bucket_expand on first access.  Slots of absorbed lanes then show
-        action 0 where the dense rollout keeps drawing (nothing reads them).
+        action 0 where the dense rollout keeps drawing (nothing reads them).  With logits_table instead of policy_table the actor is
+        the policy head of those logits and the caller attaches the records later.  visited (int32 [2S], compact only): receives a
+        1 for every (player, state) row a live slot of the batch sits in.
 
         store_values=False (native MLP actor only): the actor's value head is not evaluated and `values` is zeros.  The
         reference stores the actor's values (episode.py:206,218) but nothing ever reads them (learn/rnad.py:373 recomputes v
@@ -282,8 +286,10 @@ class Episodes:
             tabular = 8 * handle.S <= T_cap * B
         tabular = native and tabular and not keep_logits
         bucketed = bool(bucketed) and tabular and T_cap <= 64 and rnad_hip.bucket_plan(handle, B) is not None
-        compact = (bool(compact) and bucketed and policy_table is not None and not store_values and T_cap <= rnad_hip.COMPACT_MAX_STEPS
-                   and policy_table[1] == rnad_hip.policy_column(tree.max_actions))
+        # compact: the actor is the pi columns of a records table (the learner then reads them as the acting policy), or -- records not
+        # made yet (RNaD's lazy rows) -- the logits table they will be made from
+        compact = (bool(compact) and bucketed and not store_values and T_cap <= rnad_hip.COMPACT_MAX_STEPS
+                   and (policy_table[1] == rnad_hip.policy_column(tree.max_actions) if policy_table is not None else logits_table is not None))
         traj = rnad_hip.Trajectory(handle, B, T_cap, dev, half=self.obs_half, with_observations=not bucketed,
                                    with_values=store_values or not bucketed, compact=compact)
         self.buckets = self.lane_ids = self._compact = None
@@ -294,11 +300,16 @@ class Episodes:
                 packed = packed if packed is not None else net.pack()
                 table, vtable = rnad_hip.mlp_forward(packed, net.width, handle.observations_table(self.obs_half), tree.max_actions,
                                                      want_value=store_values)
-            if compact:
+            if compact and policy_table is not None:
                 self.buckets = rnad_hip.rollout_bucketed_compact(handle, traj, policy_table[0], seed=self.seed, lane0=self.lane_offset,
-                                                                 step_params=step_params)
+                                                                 step_params=step_params, visited=visited)
                 self.lane_ids = self.buckets.lane_ids
                 self._compact = (traj, policy_table[0])
+            elif compact:
+                self.buckets = rnad_hip.rollout_bucketed_compact(handle, traj, table, seed=self.seed, lane0=self.lane_offset,
+                                                                 step_params=step_params, table_is_policy=False, visited=visited)
+                self.lane_ids = self.buckets.lane_ids
+                self._compact = (traj, None)  # the caller attaches the records once they exist (learn/rnad.py, lazy rows)
             elif bucketed and policy_table is not None:
                 self.buckets = rnad_hip.rollout_bucketed(handle, traj, policy_table[0], vtable if store_values else None, seed=self.seed,
                                                          lane0=self.lane_offset, table_is_policy=True, column=policy_table[1],

@@ -148,6 +148,9 @@ class RNaD:
         # the on-policy step keeps 64 bytes per lane of its batch (states, packed actions, one reward): csrc/bucket.hip COMPACT;
         # the dense Episodes fields are written when something reads them
         self.compact_trajectory = True
+        # trees that are large next to the batch (None: when 2S > lanes per rank): only the learner's policy head runs on all 2S rows;
+        # the value heads, the row records, the gradient tables and the backward cover the rows the batch visited (5 % on configs[3])
+        self.lazy_rows = None
         self.fused_optimizer = True  # clip + Adam + EMA target of the MLP in one launch (csrc/optim.hip) instead of ~8 torch launches
         # ragged trajectories: evaluate / differentiate the nets on live (t, b) slots only (see __learn); same losses and gradients
         self.skip_absorbed = True
@@ -373,19 +376,48 @@ class RNaD:
     def invalidate_tables(self):
         self._reg_table_cache = None
 
-    def _table_outputs(self, alpha, obs_half=False, want_target_logits=False):
+    def _table_outputs(self, alpha, obs_half=False, want_target_logits=False, policy_only=False):
         """learner / target / regularisation nets on the 2S observations of the tree (rnad.py:373-380 on every distinct input):
         learner and target in ONE launch per step, the two regularisation nets from _reg_tables.  Both regularisation tables are
-        always there: a term of log_policy_reg (:382) whose weight is exactly 0 adds exactly 0."""
+        always there: a term of log_policy_reg (:382) whose weight is exactly 0 adds exactly 0.
+        policy_only: the learner's logits alone (what the rollout needs); _value_tables adds the value heads on the visited rows."""
         A = self.tree.max_actions
         table = self.tree.handle().observations_table(obs_half)
         packed, packed_target = rnad_hip.mlp_pack_many([self.net._weights(), self.net_target._weights()], A)
+        if policy_only:
+            with torch.no_grad():
+                logit = rnad_hip.mlp_forward(packed, self.net.width, table, A, want_logits=True, want_value=False)[0]
+            logit_reg, logit_reg_ = self._reg_tables(table)
+            return dict(table=table, logit=logit, v=None, logit_target=None, v_target=None, logit_reg=logit_reg, logit_reg_=logit_reg_,
+                        packed_net=packed, packed_target=packed_target)
         with torch.no_grad():
             outs = rnad_hip.mlp_forward_multi([packed, packed_target], self.net.width, table, A,
                                               [(True, True), (want_target_logits, True)])
         logit_reg, logit_reg_ = self._reg_tables(table)
         return dict(table=table, logit=outs[0][0], v=outs[0][1], logit_target=outs[1][0], v_target=outs[1][1], logit_reg=logit_reg,
                     logit_reg_=logit_reg_, packed_net=packed)
+
+    def _value_tables(self, tables, visited, alpha, step_params=None):
+        """Lazy rows, after the rollout: the learner's and the target's value heads, the row records and (in __learn) the gradient
+        tables and the backward on the rows the batch visited -- `visited` int32 [2S] from the rollout, compacted on the stream."""
+        handle, A = self.tree.handle(), self.tree.max_actions
+        rows = rnad_hip.compact_valid(visited)
+        with torch.no_grad():
+            tables["v"] = rnad_hip.mlp_forward(tables["packed_net"], self.net.width, tables["table"], A, want_logits=False, live=rows)[1]
+            tables["v_target"] = rnad_hip.mlp_forward(tables["packed_target"], self.net.width, tables["table"], A, want_logits=False, live=rows)[1]
+        tables["records"], tables["fast_records"] = rnad_hip.bucket_records(
+            handle, tables["logit"], tables["v"], tables["v_target"], tables["logit_reg"], tables["logit_reg_"], self._learn_params(alpha),
+            step_params=step_params, fast=True, rows=rows)
+        tables["rows"] = rows
+        return tables
+
+    def _use_lazy_rows(self, handle, local_batch, T_cap, log, buffer):
+        want = getattr(self, "lazy_rows", None)
+        if want is None:
+            want = 2 * handle.S > local_batch
+        return bool(want and log is None and getattr(self, "compact_trajectory", True) and T_cap <= rnad_hip.COMPACT_MAX_STEPS
+                    and self.buffer_mod == 1 and buffer.max_size == 1 and not getattr(self, "store_actor_values", False)
+                    and rnad_hip.bucket_plan(handle, local_batch) is not None)
 
     # ------------------------------------------------------------------ reference learn/rnad.py:353-456
     @staticmethod
@@ -492,14 +524,15 @@ class RNaD:
                 # the batch was played this very step with the pi columns of these records as the actor: 64 bytes per lane
                 dlogit, dv, losses = rnad_hip.learn_bucketed_compact(self.tree.handle(), episodes.buckets, compact[0], T, records,
                                                                      tables["fast_records"], None if late_norm else norm, hp,
-                                                                     want_losses=log is not None)
+                                                                     want_losses=log is not None, rows=tables.get("rows"))
+                live = tables.get("rows")  # lazy rows: the backward runs on the visited rows only
             else:
                 dlogit, dv, losses = rnad_hip.learn_bucketed(self.tree.handle(), episodes.buckets, episodes.indices[:T], episodes.action_idx[:T],
                                                              episodes.rewards[:T], episodes.policy[:T], records,
                                                              None if late_norm else norm, hp, want_losses=log is not None)
             if late_norm:
                 norm_work.wait()
-                rnad_hip.bucket_finish(self.tree.handle(), episodes.buckets, norm, hp, dlogit, dv, losses)
+                rnad_hip.bucket_finish(self.tree.handle(), episodes.buckets, norm, hp, dlogit, dv, losses, rows=tables.get("rows"))
             pi = None
             backward_obs = table
         elif table is not None:
@@ -607,7 +640,12 @@ class RNaD:
         T_cap = 2 * handle.max_depth
         mode = False if self.reuse_actor_outputs else self._tabular_mode(T_cap, local_batch)
         tables = None
-        if mode is True:
+        lazy = mode is True and self._use_lazy_rows(handle, local_batch, T_cap, log, buffer)
+        visited = None
+        if lazy:
+            tables = self._table_outputs(alpha, getattr(self, "obs_half", False), policy_only=True)
+            visited = torch.empty((2 * handle.S,), dtype=torch.int32, device=self.device)
+        elif mode is True:
             # the nets do not change between this step's rollout and its update: one evaluation of the 2S observations serves the
             # actor (= the learner net, rnad.py:503-505) and all four nets of __learn
             tables = self._table_outputs(alpha, getattr(self, "obs_half", False), want_target_logits=log is not None)
@@ -624,8 +662,14 @@ class RNaD:
                               store_values=store_values, tabular=bool(mode), bucketed=mode is True,
                               logits_table=tables["logit"] if tables is not None else None,
                               value_table=tables["v"] if tables is not None and store_values else None,
-                              policy_table=(tables["records"], rnad_hip.policy_column(self.tree.max_actions)) if tables is not None else None,
-                              step_params=step_params, compact=getattr(self, "compact_trajectory", True))
+                              policy_table=((tables["records"], rnad_hip.policy_column(self.tree.max_actions))
+                                            if tables is not None and not lazy else None),
+                              step_params=step_params, compact=getattr(self, "compact_trajectory", True), visited=visited)
+            if lazy:
+                # the rows this batch went through are known now: value heads, records, gradient tables, backward on those only
+                assert episodes._compact is not None, "lazy rows need the compact bucketed rollout"
+                self._value_tables(tables, visited, alpha, step_params=step_params)
+                episodes._compact = (episodes._compact[0], tables["records"])
             episodes._actor_tag = (id(self.net), self.total_steps)
             buffer.append(episodes)
             self.last_episodes = episodes
@@ -710,7 +754,7 @@ class RNaD:
                 self.batch_size, self.tabular, getattr(self, "tabular_gate", 8), self.eta, self.beta, self.neurd_clip, self.grad_clip,
                 self.c_bar, self.roh_bar, self.vtrace_gamma, self.value_weight, self.neurd_weight, self.epsilon_threshold, self.n_discrete,
                 self.gamma_averaging, getattr(self, "obs_half", False), getattr(self, "store_actor_values", False), getattr(self, "fused_optimizer", True),
-                getattr(self, "compact_trajectory", True), os.environ.get("RNAD_BUCKET_ROWS"), os.environ.get("RNAD_BUCKET_CHUNK"))
+                getattr(self, "compact_trajectory", True), getattr(self, "lazy_rows", None), os.environ.get("RNAD_BUCKET_ROWS"), os.environ.get("RNAD_BUCKET_CHUNK"))
 
     def _graph_step(self, buffer, alpha):
         g = getattr(self, "_graph", None)

@@ -653,21 +653,28 @@ def rollout_bucketed(tree, traj, table, value_table=None, seed=0, lane0=0, table
 COMPACT_MAX_STEPS = 21  # 3 bits of action per step in one 64-bit word (csrc/bucket.hip kCompactSteps)
 
 
-def rollout_bucketed_compact(tree, traj, records, seed=0, lane0=0, step_params=None):
-    """rnad_rollout_bucketed_compact: the episodes of rollout_bucketed(table=records, table_is_policy=True, column=policy_column(A))
-    into a Trajectory(compact=True).  Returns the Buckets of the batch."""
+def rollout_bucketed_compact(tree, traj, table, seed=0, lane0=0, step_params=None, table_is_policy=True, column=None, visited=None):
+    """rnad_rollout_bucketed_compact: the episodes of rollout_bucketed(table, table_is_policy, column) into a Trajectory(compact=True).
+    table: bucket_records(...) (the default: its pi columns are the actor), any [2S, stride] table with the actor's policy rows from
+    `column` on, or (table_is_policy=False) the actor's logits [2S, A].  visited (int32 [2S], optional): set to 1 for every (player,
+    state) row a live slot sits in (and the two rows of the absorbing state), 0 elsewhere.  Returns the Buckets of the batch."""
     assert traj.compact and traj.T_cap <= COMPACT_MAX_STEPS
     plan = bucket_plan(tree, traj.B)
     if plan is None:
         raise RnadHipError(lib().rnad_last_error().decode())
-    assert records.shape == (2 * tree.S, int(lib().rnad_bucket_record_stride(tree.A)))
+    if column is None:
+        column = policy_column(tree.A) if table_is_policy else 0
+    assert table.shape[0] == 2 * tree.S and table.shape[1] >= column + tree.A
+    assert visited is None or visited.numel() == 2 * tree.S
     buckets = Buckets(plan, traj.indices.device)
-    _check(lib().rnad_rollout_bucketed_compact(tree.ptr, traj.T_cap, traj.B, _dp(records, F32, "records"), seed, lane0,
-                                               _dp(step_params, torch.int64, "step_params", True), _dp(plan.scratch, I32, "scratch"),
-                                               _dp(buckets.lane_ids, I32, "lane_ids"), _dp(buckets.items, I32, "items"),
-                                               _dp(buckets.n_items, I32, "n_items"), _dp(buckets.norm, F64, "norm"),
-                                               _dp(traj.indices, I32, "indices"), _dp(traj.alive, I32, "alive"),
-                                               _dp(traj.acts, torch.int64, "acts"), _dp(traj.final_reward, F32, "final_reward"), _stream()))
+    base = _dp(table, F32, "table")
+    _check(lib().rnad_rollout_bucketed_compact(tree.ptr, traj.T_cap, traj.B, C.c_void_p(base.value + 4 * column), table.shape[1],
+                                               int(table_is_policy), seed, lane0, _dp(step_params, torch.int64, "step_params", True),
+                                               _dp(plan.scratch, I32, "scratch"), _dp(buckets.lane_ids, I32, "lane_ids"),
+                                               _dp(buckets.items, I32, "items"), _dp(buckets.n_items, I32, "n_items"),
+                                               _dp(buckets.norm, F64, "norm"), _dp(traj.indices, I32, "indices"), _dp(traj.alive, I32, "alive"),
+                                               _dp(traj.acts, torch.int64, "acts"), _dp(traj.final_reward, F32, "final_reward"),
+                                               _dp(visited, I32, "visited", True), _stream()))
     return buckets
 
 
@@ -684,11 +691,13 @@ def bucket_expand(tree, traj, records):
                                     _dp(traj.rewards, F32, "rewards"), _stream()))
 
 
-def learn_bucketed_compact(tree, buckets, traj, T, records, fast_records, norm, hp, want_losses=False):
+def learn_bucketed_compact(tree, buckets, traj, T, records, fast_records, norm, hp, want_losses=False, rows=None):
     """rnad_learn_bucketed_compact on the first T steps of a compact trajectory played with the pi columns of `records`;
-    (records, fast_records) = bucket_records(..., fast=True)."""
+    (records, fast_records) = bucket_records(..., fast=True).  rows: a LiveRows over the 2S rows -- only those rows of the gradient
+    tables are written (the batch visited no others)."""
     B, A = traj.B, tree.A
     assert buckets.plan.B == B and traj.compact and 1 <= T <= traj.T_cap
+    assert rows is None or rows.N == 2 * tree.S
     dev = traj.indices.device
     dlogit = torch.empty((2 * tree.S, A), dtype=F32, device=dev)
     dv = torch.empty((2 * tree.S, 1), dtype=F32, device=dev)
@@ -698,8 +707,16 @@ def learn_bucketed_compact(tree, buckets, traj, T, records, fast_records, norm, 
                                              _dp(records, F32, "records"), _dp(buckets.items, I32, "items"),
                                              _dp(buckets.n_items, I32, "n_items"), _dp(norm, F64, "norm", True), C.byref(hp),
                                              _dp(buckets.plan.accumulators, torch.int64, "accumulators"),
-                                             _dp(losses, F64, "losses", True), _dp(dlogit, F32, "dlogit_tab"), _dp(dv, F32, "dv_tab"), _stream()))
+                                             _dp(losses, F64, "losses", True), _dp(dlogit, F32, "dlogit_tab"), _dp(dv, F32, "dv_tab"),
+                                             *_row_list(rows), _stream()))
     return dlogit, dv, losses
+
+
+def _row_list(rows):
+    """(rows, n_rows) pointer arguments of a LiveRows, or two NULLs."""
+    if rows is None:
+        return None, None
+    return _dp(rows.rows, I32, "rows"), C.c_void_p(rows.count.data_ptr())
 
 
 def step_params_set(step_params, seed, alpha):
@@ -713,18 +730,19 @@ def policy_column(A):
     return 3 * A + 3
 
 
-def bucket_records(tree, logit_tab, v_tab, v_target_tab, logit_reg_tab, logit_reg_tab_, hp, step_params=None, fast=False):
+def bucket_records(tree, logit_tab, v_tab, v_target_tab, logit_reg_tab, logit_reg_tab_, hp, step_params=None, fast=False, rows=None):
     """One record per (player, state) row with everything of the update that depends on the row alone (rnad_bucket_records):
     logit[A] | v | v_target | process_policy(pi)[A] | log_policy_reg[A] | legal bits | pi[A] | pad.
     fast=True: returns (records, fast_records) -- the second table holds the row-only operands of the on-policy learner
-    (learn_bucketed_compact; layout in include/rnad_hip.h)."""
+    (learn_bucketed_compact; layout in include/rnad_hip.h).  rows: a LiveRows over the 2S rows -- only those records are written."""
     stride = int(lib().rnad_bucket_record_stride(tree.A))
+    assert rows is None or rows.N == 2 * tree.S
     rec = torch.empty((2 * tree.S, stride), dtype=F32, device=logit_tab.device)
     quick = torch.empty((2 * tree.S, int(lib().rnad_bucket_fast_record_stride(tree.A))), dtype=F32, device=logit_tab.device) if fast else None
     _check(lib().rnad_bucket_records(tree.ptr, _dp(logit_tab, F32, "logit_tab"), _dp(v_tab, F32, "v_tab"), _dp(v_target_tab, F32, "v_target_tab"),
                                      _dp(logit_reg_tab, F32, "logit_reg_tab"), _dp(logit_reg_tab_, F32, "logit_reg_tab_"), C.byref(hp),
                                      _dp(step_params, torch.int64, "step_params", True), _dp(rec, F32, "records"),
-                                     _dp(quick, F32, "fast_records", True), _stream()))
+                                     _dp(quick, F32, "fast_records", True), *_row_list(rows), _stream()))
     return (rec, quick) if fast else rec
 
 
@@ -744,11 +762,11 @@ def learn_bucketed(tree, buckets, indices, actions, rewards, mu, records, norm, 
     return dlogit, dv, losses
 
 
-def bucket_finish(tree, buckets, norm, hp, dlogit, dv, losses=None):
+def bucket_finish(tree, buckets, norm, hp, dlogit, dv, losses=None, rows=None):
     """rnad_bucket_finish: completes a learn_bucketed / learn_bucketed_compact call that was made with norm=None."""
     _check(lib().rnad_bucket_finish(tree.ptr, buckets.plan.B, _dp(norm, F64, "norm"), C.byref(hp),
                                     _dp(buckets.plan.accumulators, torch.int64, "accumulators"), _dp(losses, F64, "losses", True),
-                                    _dp(dlogit, F32, "dlogit_tab"), _dp(dv, F32, "dv_tab"), _stream()))
+                                    _dp(dlogit, F32, "dlogit_tab"), _dp(dv, F32, "dv_tab"), *_row_list(rows), _stream()))
 
 
 def clip_grad_norm(flat, max_norm):

