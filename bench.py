@@ -195,6 +195,8 @@ def main():
     replayed = bool(graph_state and graph_state.get("graph") is not None)
     T = rn.last_episodes.t_eff + 1
     args.compact_in_effect = getattr(rn.last_episodes, "_compact", None) is not None
+    lazy_now = rn._use_lazy_rows(handle, local_batch, T, None, buffer) and mode_now_is_true(rn, T, local_batch)
+    args.visited_rows = int(rn.last_rows.count.item()) if (lazy_now and rn.last_rows is not None) else 0
     default_mode = rn.tabular
     mode_now = rn._tabular_mode(T, local_batch)
 
@@ -205,7 +207,8 @@ def main():
         one_step()
     fence()
     rnad_hip.prof_enable(True)
-    for _ in range(E):
+    EP = max(E, min(200, args.steps))  # steps of the bracketed leg (eager steps are host-paced: short legs see the clocks ramp)
+    for _ in range(EP):
         one_step()
     fence()
     names = {rnad_hip.PROF_OBSERVE: "k_observe", rnad_hip.PROF_ACT: "rollout (all kernels of Episodes.generate)",
@@ -217,7 +220,7 @@ def main():
     for k, nm in names.items():
         n, ms = rnad_hip.prof_read(k)
         if n:
-            prof[k] = dict(name=nm, launches_per_step=n / E, avg_launch_us=ms * 1e3 / n, us_per_step=ms * 1e3 / E)
+            prof[k] = dict(name=nm, launches_per_step=n / EP, avg_launch_us=ms * 1e3 / n, us_per_step=ms * 1e3 / EP)
     rnad_hip.prof_enable(False)
     rn.use_graph = not args.no_graph
 
@@ -313,6 +316,7 @@ def main():
             "net_evaluation": {"mode": f"RNaD.tabular = {default_mode!r}" + (" (default)" if args.net_mode == "default" else ""),
                                "in_effect": repr(mode_now), "what": what[mode_now],
                                "step_replayed_from_hipGraph": replayed, "compact_trajectory": bool(args.compact_in_effect),
+                               "lazy_rows_visited": args.visited_rows or None,
                                "distinct_observations": 2 * handle.S, "slots": T * local_batch},
             "other_modes": {name: {"env_steps_per_sec": global_batch * T_ref * E / sec, "updates_per_sec": E / sec,
                                    "ms_per_step": sec / E * 1e3, "steps": E,
@@ -369,6 +373,10 @@ def main():
 FP32_PEAK_TFLOPS = 157.3  # fp32 MFMA == fp32 vector peak (/opt/skills/guides/MI355X_MICROARCH.md)
 
 
+def mode_now_is_true(rn, T, local_batch):
+    return rn._tabular_mode(T, local_batch) is True
+
+
 def kernel_report(prof, A, C, args, B, T, live_slots, tree, mode_now):
     """Per bracketed kernel: time per step and, where one kernel is bracketed alone, its algorithmic bytes / flops per launch
     (DESIGN.md section 5 states each figure) against the HBM or fp32-MFMA peak."""
@@ -414,7 +422,8 @@ def kernel_report(prof, A, C, args, B, T, live_slots, tree, mode_now):
     # the fused MLP kernels: flops the matrix cores execute per sample (first layer of a head: 2 K W; relu + second layer run on the
     # VALU; backward: recompute of both heads + dW0 over the augmented input padded to its MFMA tiles)
     uniform = tree.handle().uniform_length
-    bwd_samples = S2 if mode_now is True else (live_slots if not uniform else slots)
+    visited = args.visited_rows  # lazy rows: the value heads and the backward run on the rows the batch visited
+    bwd_samples = (visited or S2) if mode_now is True else (live_slots if not uniform else slots)
     if rh.PROF_MLP_BWD in prof:
         p = prof[rh.PROF_MLP_BWD]
         flops = (2.0 * K * 2 * W + 2.0 * feat * 2 * W) * bwd_samples
@@ -423,10 +432,13 @@ def kernel_report(prof, A, C, args, B, T, live_slots, tree, mode_now):
                               samples_per_step=bwd_samples, flops_model="per sample 2*K*2W (recompute) + 2*feat*2W (dW0 tiles), K = 2A^2")
     if rh.PROF_MLP in prof and mode_now is True:
         p = prof[rh.PROF_MLP]
-        flops = 2.0 * K * W * 3 * S2  # learner: both heads, target: value head, on the 2S rows (regularisation tables are cached)
+        # learner: both heads, target: value head, on the 2S rows (regularisation tables are cached); lazy rows: the two value heads
+        # on the visited rows only
+        flops = 2.0 * K * W * (3 * S2 if not visited else S2 + 2 * visited)
         tf = flops / (p["us_per_step"] * 1e-6) / 1e12
         out[p["name"]].update(bound="mfma", achieved=tf, peak=FP32_PEAK_TFLOPS, unit="TFLOP/s", frac=tf / FP32_PEAK_TFLOPS, samples_per_step=S2,
-                              flops_model="2*K*W per head and row: learner 2 heads + target value head")
+                              flops_model="2*K*W per head and row: learner 2 heads + target value head"
+                                          + (f"; lazy rows: policy head on {S2} rows, the two value heads on the {visited} visited rows" if visited else ""))
     return out
 
 

@@ -151,6 +151,7 @@ class RNaD:
         # trees that are large next to the batch (None: when 2S > lanes per rank): only the learner's policy head runs on all 2S rows;
         # the value heads, the row records, the gradient tables and the backward cover the rows the batch visited (5 % on configs[3])
         self.lazy_rows = None
+        self.last_rows = None  # rnad_hip.LiveRows of the last lazy step
         self.fused_optimizer = True  # clip + Adam + EMA target of the MLP in one launch (csrc/optim.hip) instead of ~8 torch launches
         # ragged trajectories: evaluate / differentiate the nets on live (t, b) slots only (see __learn); same losses and gradients
         self.skip_absorbed = True
@@ -409,6 +410,7 @@ class RNaD:
             handle, tables["logit"], tables["v"], tables["v_target"], tables["logit_reg"], tables["logit_reg_"], self._learn_params(alpha),
             step_params=step_params, fast=True, rows=rows)
         tables["rows"] = rows
+        self.last_rows = rows  # (bench.py reads how many rows a step visited)
         return tables
 
     def _use_lazy_rows(self, handle, local_batch, T_cap, log, buffer):
