@@ -231,7 +231,8 @@ constexpr int kRowLearn = (3 * A + 3 + 3) & ~3;  // what k_bucket_learn fetches 
 //   e0 = -eta * sum_a pi_processed[a] * log_policy_reg[a]   eta_reg_entropy up to the sign of _player_others (vtrace.py:234-238)
 //   elp[a] = -eta * log_policy_reg[a]                        eta_log_policy of the mover (:239)
 //   cs[a] = pi_processed[a] / pi[a], inv_mu[a] = 1 / pi[a]   _policy_ratio with the actor's own pi as mu, had action a been taken (:199-204)
-//   bits = legal | (logit - mean > -threshold) << 8 | (logit - mean < threshold) << 16    the gates of apply_force_with_threshold (:362-366)
+//   bits = legal | (legal & logit - mean > -threshold) << 8 | (legal & logit - mean < threshold) << 16    the gates of
+//          apply_force_with_threshold (:362-366), closed for illegal actions (whose force :424-428 multiplies by legal == 0)
 template <int A>
 constexpr int kFastStride = 4 + 4 * A;
 
@@ -294,8 +295,9 @@ __global__ __launch_bounds__(kThreads) void k_row_records(int64_t rows, const fl
 #pragma unroll
     for (int a = 0; a < A; ++a) {
         const float l = lg[a] - mean;
-        gates |= (l > -hp.threshold ? 1u : 0u) << (8 + a);
-        gates |= (l < hp.threshold ? 1u : 0u) << (16 + a);
+        // (an illegal action's force is multiplied by legal == 0 further down, vtrace.py:424-428: its gates are left closed instead)
+        gates |= ((l > -hp.threshold ? 1u : 0u) & (bits >> a)) << (8 + a);
+        gates |= ((l < hp.threshold ? 1u : 0u) & (bits >> a)) << (16 + a);
     }
     f[0] = v[r];
     f[1] = vt[r];
@@ -660,7 +662,9 @@ __device__ __forceinline__ void fast_slot(const float *__restrict__ f, const flo
     const float ru = r_me + vh.gamma * me.ru + e0;
     const float dr = r_me + vh.gamma * me.r;
     const float w = cs * me.is;
-    const float vt = vv + clamp_max(w, vh.rho) * (ru + vh.gamma * me.nv - vv) + vh.lambda_ * clamp_max(w, vh.c) * vh.gamma * (me.nvt - me.nv);
+    // torch.clamp(max=) hands a NaN on (and the NaN would poison the tables through the value gradient): fminf + the flag do the same
+    ovf |= w != w;
+    const float vt = vv + fminf(w, vh.rho) * (ru + vh.gamma * me.nv - vv) + vh.lambda_ * fminf(w, vh.c) * vh.gamma * (me.nvt - me.nv);
     const float tail = dr + vh.gamma * me.is * me.nvt - vv;
     const float bonus = inv_mu * tail;
     float q[A], base = 0.0f;
@@ -685,9 +689,10 @@ __device__ __forceinline__ void fast_slot(const float *__restrict__ f, const flo
 #pragma unroll
     for (int a = 0; a < A; ++a) {
         float adv = q[a] - base;
-        adv = adv != adv ? adv : fminf(fmaxf(adv, -hp.clip), hp.clip);
+        ovf |= adv != adv;  // (a NaN advantage reaches the gradient in the reference; here it sets the flag that poisons the tables)
+        adv = __builtin_amdgcn_fmed3f(adv, -hp.clip, hp.clip);  // torch.clamp(adv, -clip, clip) of a non-NaN
         const float fo = ((bits >> (8 + a)) & 1 ? fminf(adv, 0.0f) : 0.0f) + ((bits >> (16 + a)) & 1 ? fmaxf(adv, 0.0f) : 0.0f);
-        wv[a] = (bits >> a) & 1 ? fo : 0.0f;
+        wv[a] = fo;  // legal * f: the gates of an illegal action are closed
         wsum += wv[a];
         if (LOSSES) nerd += (float)((bits >> a) & 1) * ((lg[a] - mean) * fo);
     }
@@ -710,7 +715,8 @@ __device__ __forceinline__ void fast_slot(const float *__restrict__ f, const flo
 
 // The pass of k_learn_fused<TAB> (learn.hip; learn/rnad.py:365-425) for the lanes of ONE work item -- they all went through the
 // same states down to the bucket state -- with the per-slot gradients added up per (player, state) row instead of being written:
-//   rows at steps t < 2 * level(bucket state): one row per step for the whole workgroup -> wave reduction, one LDS add per wave;
+//   rows at steps t < n_path (above the bucket): one row per step for the whole workgroup -> kPathSlots LDS copies of it, lane l adds
+//   into copy l & 15;
 //   rows below: LDS table indexed by (state - bucket state), both players.
 // Addends are the UN-normalised gradients  G_l[a] = -(w - legal * sum(w) / A)  and  G_v = 2 (v - v_target)  in 64-bit fixed
 // point; k_bucket_finish applies w_n / N_P and w_v / N_P (the reference scales every slot by them: vtrace.py:374,389 and
