@@ -639,6 +639,7 @@ __device__ __forceinline__ long long round_to_ll(double d) {
 struct FixedPoint {
     double scale_l, scale_v;  // 2^f: units per 1.0 of an addend of dL/dlogit / dL/dv
     float limit_l, limit_v;   // |addend| must stay below this (2^(62 - kLaneBits) units)
+    float scale_l32, scale_v32;  // the same scales as floats (exact: powers of two)
 };
 
 // One slot of the on-policy update from its row's fast record f (k_row_records): vtrace_step for the mover P ("ours") and for the
@@ -704,12 +705,13 @@ __device__ __forceinline__ void fast_slot(const float *__restrict__ f, const flo
     }
     const float gv = 2.0f * d;
     ovf |= !(fabsf(gv) < fx.limit_v);
-    out[A] = round_to_ll((double)gv * fx.scale_v);
+    // the scales are powers of two: the product is exact in fp32 (no f64 multiply), the rounding happens in round_to_ll
+    out[A] = round_to_ll((double)(gv * fx.scale_v32));
 #pragma unroll
     for (int a = 0; a < A; ++a) {
+        // |g| <= 2 clip < limit_l by construction here (adv is clamped and not NaN, or the flag is set): no range check
         const float g = (bits >> a) & 1 ? wv[a] - share : 0.0f;
-        ovf |= !(fabsf(g) < fx.limit_l);
-        out[a] = round_to_ll((double)(-g) * fx.scale_l);
+        out[a] = round_to_ll((double)(-g * fx.scale_l32));
     }
 }
 
@@ -1010,6 +1012,8 @@ FixedPoint fixed_point_for(const rnad_learn_params_t &hp) {
     fx.scale_v = std::ldexp(1.0, budget - e_v);
     fx.limit_l = (float)std::ldexp(1.0, e_l);
     fx.limit_v = (float)std::ldexp(1.0, e_v);
+    fx.scale_l32 = (float)fx.scale_l;
+    fx.scale_v32 = (float)fx.scale_v;
     return fx;
 }
 
