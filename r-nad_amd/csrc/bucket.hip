@@ -50,6 +50,7 @@ constexpr int kLaneBits = 22;        // B <= 2^22 lanes per call: a row receives
 constexpr int kLearnLds = 64 * 1024; // LDS budget of one learner workgroup
 constexpr int kPackedSteps = 10;      // env steps whose decisions k_bucket_keys hands to k_bucket_rollout (6 bits each)
 constexpr int kCompactSteps = 21;     // env steps of a compact trajectory: 3 bits of action per step in one 64-bit word
+constexpr int kSharedRoot = 256;      // flag in bucket_path: the group is one subtree (its root row is shared by the bucket's lanes)
 constexpr int kFinishRows = 4;        // rows per thread of k_bucket_finish
 constexpr int kTargetLanes = 1024;   // finest cut whose groups still hold this many lanes on average (configs[1]: full work items win)
 
@@ -72,7 +73,7 @@ const BucketCut *get_cut(const rnad_tree_t *tree, int rows) {
     int max_path = 0;
     if (!is_upper(1)) {  // the whole tree fits one table: a single group, nothing above it
         lo.push_back(1);
-        path.push_back(0);
+        path.push_back(kSharedRoot);  // (every lane starts in state 1)
         for (int64_t s = 1; s < S; ++s)
             if (tree->level_of[(size_t)s] >= 0) bucket_of[(size_t)s] = 0;
     } else {
@@ -82,11 +83,13 @@ const BucketCut *get_cut(const rnad_tree_t *tree, int rows) {
             upper_list.push_back((int32_t)u);
             const int level = tree->level_of[(size_t)u];
             int64_t g_lo = -1, g_hi = -1;
+            int g_subtrees = 0;
             auto close = [&]() {
                 if (g_lo < 0) return;
                 const int32_t gid = (int32_t)lo.size();
                 lo.push_back((int32_t)g_lo);
-                path.push_back(2 * (level + 1));
+                // a group of ONE subtree: every lane of the bucket also shares the group's root for two more steps (kSharedRoot)
+                path.push_back(2 * (level + 1) | (g_subtrees == 1 ? kSharedRoot : 0));
                 for (int64_t x = g_lo; x < g_hi; ++x) bucket_of[(size_t)x] = gid;
                 g_lo = g_hi = -1;
             };
@@ -99,10 +102,12 @@ const BucketCut *get_cut(const rnad_tree_t *tree, int rows) {
                 const int64_t c_hi = c + tree->subtree_size[(size_t)c];
                 if (g_lo >= 0 && c == g_hi && c_hi - g_lo <= rows) {
                     g_hi = c_hi;
+                    ++g_subtrees;
                 } else {
                     close();
                     g_lo = c;
                     g_hi = c_hi;
+                    g_subtrees = 1;
                 }
             }
             close();
@@ -119,7 +124,7 @@ const BucketCut *get_cut(const rnad_tree_t *tree, int rows) {
         lo.push_back(u);
         path.push_back(2 * tree->level_of[(size_t)u] + 2);
     }
-    for (int32_t v : path) max_path = std::max(max_path, (int)v);
+    for (int32_t v : path) max_path = std::max(max_path, (int)(v & (kSharedRoot - 1)) + ((v & kSharedRoot) ? 2 : 0));
     cut.max_path = max_path;
     if (upper_list.empty()) upper_list.push_back(0);
     DeviceGuard guard(tree->device);
@@ -751,7 +756,10 @@ __global__ __launch_bounds__(kThreads) void k_bucket_learn(int T, int64_t B, int
     if ((int)blockIdx.x >= *n_items) return;
     const Item item = items[blockIdx.x];
     const int s_b = bucket_lo[item.bucket];        // first state id of the group (terminal buckets: the upper state; no rows below)
-    const int n_path = bucket_path[item.bucket];   // env steps above the group: upper states shared by every lane of the bucket
+    const int n_path = bucket_path[item.bucket] & (kSharedRoot - 1);  // env steps above the group: upper states shared by every lane of the bucket
+    // ... and, when the group is a single subtree, the two steps at its root: all lanes of the item add into the same two rows
+    // (64-way same-address LDS atomics otherwise), so those take copies in the path region too and are folded into the table at the end
+    const int n_shared = n_path + ((bucket_path[item.bucket] & kSharedRoot) ? 2 : 0);
     constexpr int RS = kRowStride<A>;
     const int n_tab = item.bucket < n_groups ? kPathWords + 2 * sub_rows * (A + 1) : n_path * kPathSlots * PS;
     for (int i = threadIdx.x; i < n_tab; i += kThreads) tab[i] = 0ull;
@@ -862,7 +870,7 @@ __global__ __launch_bounds__(kThreads) void k_bucket_learn(int T, int64_t B, int
                 cy[1] = Carry{};
             }
             s_after = state;
-            if (t < n_path) {  // a step above the bucket state: one row for the whole workgroup, kPathSlots copies of it in LDS
+            if (t < n_shared) {  // a step above the bucket state (or at a shared root): one row for the whole workgroup, kPathSlots copies of it in LDS
                 if (threadIdx.x == 0 && base == 0) path_state[t] = state;
                 if (valid) {
                     unsigned long long *dst = tab + (t * kPathSlots + (threadIdx.x & (kPathSlots - 1))) * PS;
@@ -907,6 +915,14 @@ __global__ __launch_bounds__(kThreads) void k_bucket_learn(int T, int64_t B, int
     }
     // rows of the bucket's own subtree: this workgroup owns them unless the bucket was split over several items
     if (item.bucket >= n_groups) return;  // terminal bucket: every step was a path step
+    for (int e = threadIdx.x; e < (n_shared - n_path) * (A + 1); e += kThreads) {  // the shared root's two rows join the table
+        const int t = n_path + e / (A + 1), a = e % (A + 1);
+        unsigned long long x = 0ull;
+#pragma unroll
+        for (int c = 0; c < kPathSlots; ++c) x += tab[(t * kPathSlots + c) * PS + a];
+        tab[kPathWords + ((int64_t)((t & 1) * sub_rows + (path_state[t] - s_b))) * (A + 1) + a] += x;
+    }
+    __syncthreads();
     const int64_t end = S - s_b < sub_rows ? S - s_b : sub_rows;
     for (int e = threadIdx.x; e < 2 * sub_rows * (A + 1); e += kThreads) {
         const unsigned long long x = tab[kPathWords + e];
