@@ -497,12 +497,7 @@ __global__ __launch_bounds__(kSortThreads) void k_bucket_scatter(int64_t B, int 
 // registers across the T_cap steps and column j of every [T_cap, B] buffer written coalesced.  Observations are not written
 // (a function of (t & 1, indices): materialised on demand), `values` only if asked for.
 // alive_part[block][t] = #lanes of the block with indices[t] != 0 (summed by k_bucket_alive: no atomics).
-//
-// COMPACT: the trajectory as 64 bytes per lane instead of 25 per slot -- indices [T_cap + 1, B], the lane's actions packed 3 bits
-// per step (acts_out) and the one non-zero reward of the episode (rewards *= (indices == 0), episode.py:120-121: only the transition
-// into state 0 pays; reward_out).  Everything else of a slot is a function of (t & 1, indices[t]) and the actor's table
-// (k_bucket_expand writes the dense buffers on demand).  An absorbed lane stops: no draws, no table reads.
-template <int A, bool COMPACT>
+template <int A>
 __global__ __launch_bounds__(kThreads) void k_bucket_rollout(const Trans *__restrict__ trans, int C, int64_t S, int64_t B, int T_cap,
                                                              const float *__restrict__ policy_tab, int64_t tab_stride,
                                                              const float *__restrict__ value_tab, int64_t value_stride,
@@ -512,9 +507,7 @@ __global__ __launch_bounds__(kThreads) void k_bucket_rollout(const Trans *__rest
                                                              const unsigned long long *__restrict__ decisions, int32_t *__restrict__ indices,
                                                              uint8_t *__restrict__ mbits, float *__restrict__ policy,
                                                              int32_t *__restrict__ actions, float *__restrict__ rewards,
-                                                             float *__restrict__ values, int32_t *__restrict__ alive_part,
-                                                             unsigned long long *__restrict__ acts_out, float *__restrict__ reward_out,
-                                                             int32_t *__restrict__ visited) {
+                                                             float *__restrict__ values, int32_t *__restrict__ alive_part) {
     __shared__ int32_t cnt[kThreads / 64][kMaxSteps + 1];
     const int64_t j = (int64_t)blockIdx.x * kThreads + threadIdx.x;
     const bool active = j < B;
@@ -525,78 +518,130 @@ __global__ __launch_bounds__(kThreads) void k_bucket_rollout(const Trans *__rest
     const int n_packed = (int)(packed >> 60);
     const int wave = threadIdx.x >> 6;
     int state = 1, prev = 0;
-    unsigned long long acts = 0ull;
-    float reward_final = 0.0f;
     for (int t = 0; t < T_cap; ++t) {
         const uint64_t live = __ballot(active && state != 0);
         if ((threadIdx.x & 63) == 0) cnt[wave][t] = (int32_t)__popcll(live);
-        if (COMPACT && live == 0ull) {  // the whole wave is absorbed (uniform branch)
-            if (active) indices[(int64_t)t * B + j] = 0;
-            continue;
-        }
         if (active) {
             const int64_t i = (int64_t)t * B + j;
             const int64_t row = (int64_t)(t & 1) * S + state;
             const bool replay = t < n_packed;
-            const int bits6 = (int)(packed >> (6 * t)) & 63;
+            const int bits6 = replay ? (int)(packed >> (6 * t)) & 63 : 0;
             int action = bits6 & 7;
-            if (COMPACT) {
-                indices[i] = state;
-                if (state != 0) {
-                    if (visited) visited[row] = 1;  // (every writer stores the same value)
-                    if (!replay) {
-                        float pol[A], q[A];
+            const uint32_t bits = mask_tab[row];
+            float pol[A];
 #pragma unroll
-                        for (int a = 0; a < A; ++a) pol[a] = policy_tab[row * tab_stride + a];
-                        rnad_exp_noise(seed, lane, (uint32_t)t, 0u, A, q);
-                        action = race_argmax<A>(pol, q);
-                    }
-                    acts |= (unsigned long long)action << (3 * t);
-                    if (t & 1) {
-                        int next;
-                        float rew;
-                        if (replay)
-                            transition_apply<A>(trans, C, state, prev, action, bits6 >> 3, next, rew);
-                        else
-                            transition_lane<A>(trans, C, state, prev, action, nullptr, seed, lane, (uint32_t)t, next, rew);
-                        if (next == 0) reward_final = rew;
-                        state = next;
-                    } else {
-                        prev = action;
-                    }
-                }
-            } else {
-                const uint32_t bits = mask_tab[row];
-                float pol[A];
-#pragma unroll
-                for (int a = 0; a < A; ++a) pol[a] = policy_tab[row * tab_stride + a];
-                if (!replay) {
-                    float q[A];
-                    rnad_exp_noise(seed, lane, (uint32_t)t, 0u, A, q);
-                    action = race_argmax<A>(pol, q);
-                }
-                indices[i] = state;
-                mbits[i] = (uint8_t)bits;
-#pragma unroll
-                for (int a = 0; a < A; ++a) policy[i * A + a] = pol[a];
-                actions[i] = action;
-                if (values) values[i] = value_tab ? value_tab[row * value_stride] : 0.0f;
-                int next = state;
-                float rew = 0.0f;  // row turn: torch.zeros (episode.py:101)
-                if (t & 1) {
-                    if (replay)
-                        transition_apply<A>(trans, C, state, prev, action, bits6 >> 3, next, rew);
-                    else
-                        transition_lane<A>(trans, C, state, prev, action, nullptr, seed, lane, (uint32_t)t, next, rew);
-                } else {
-                    prev = action;
-                }
-                rewards[i] = rew;
-                state = next;
+            for (int a = 0; a < A; ++a) pol[a] = policy_tab[row * tab_stride + a];
+            if (!replay) {
+                float q[A];
+                rnad_exp_noise(seed, lane, (uint32_t)t, 0u, A, q);
+                action = race_argmax<A>(pol, q);
             }
+            indices[i] = state;
+            mbits[i] = (uint8_t)bits;
+#pragma unroll
+            for (int a = 0; a < A; ++a) policy[i * A + a] = pol[a];
+            actions[i] = action;
+            if (values) values[i] = value_tab ? value_tab[row * value_stride] : 0.0f;
+            int next = state;
+            float rew = 0.0f;  // row turn: torch.zeros (episode.py:101)
+            if (t & 1) {
+                if (replay)
+                    transition_apply<A>(trans, C, state, prev, action, bits6 >> 3, next, rew);
+                else
+                    transition_lane<A>(trans, C, state, prev, action, nullptr, seed, lane, (uint32_t)t, next, rew);
+            } else {
+                prev = action;
+            }
+            rewards[i] = rew;
+            state = next;
         }
     }
-    if (COMPACT && active) {
+    const uint64_t live = __ballot(active && state != 0);
+    if ((threadIdx.x & 63) == 0) cnt[wave][T_cap] = (int32_t)__popcll(live);
+    if (active) indices[(int64_t)T_cap * B + j] = state;
+    __syncthreads();
+    if ((int)threadIdx.x <= T_cap) {
+        int32_t s = 0;
+#pragma unroll
+        for (int w = 0; w < kThreads / 64; ++w) s += cnt[w][threadIdx.x];
+        alive_part[(int64_t)blockIdx.x * (T_cap + 1) + threadIdx.x] = s;
+    }
+}
+
+// The COMPACT rollout: the trajectory as 64 bytes per lane instead of 25 per slot -- indices [T_cap + 1, B], the lane's actions
+// packed 3 bits per step (acts_out) and the one non-zero reward of the episode (rewards *= (indices == 0), episode.py:120-121: only
+// the transition into state 0 pays; reward_out).  Everything else of a slot is a function of (t & 1, indices[t]) and the actor's
+// table (k_bucket_expand writes the dense buffers on demand).
+// One TRANSITION (the row player's step and the column player's step in the same state) per iteration: both
+// policy rows of the state are requested together and both noise draws are computed while they travel, so a transition costs two
+// dependent memory latencies (policy rows, transition record) instead of three.  Same draws (noise keyed by lane and step), same
+// episodes as k_bucket_rollout.  An absorbed lane stops: no draws, no table reads.
+template <int A>
+__global__ __launch_bounds__(kThreads) void k_bucket_rollout_compact(const Trans *__restrict__ trans, int C, int64_t S, int64_t B, int T_cap,
+                                                                     const float *__restrict__ policy_tab, int64_t tab_stride, uint64_t seed,
+                                                                     const rnad_step_params_t *__restrict__ sp, int64_t lane0,
+                                                                     const int32_t *__restrict__ lane_ids,
+                                                                     const unsigned long long *__restrict__ decisions,
+                                                                     int32_t *__restrict__ indices, int32_t *__restrict__ alive_part,
+                                                                     unsigned long long *__restrict__ acts_out,
+                                                                     float *__restrict__ reward_out, int32_t *__restrict__ visited) {
+    __shared__ int32_t cnt[kThreads / 64][kMaxSteps + 1];
+    const int64_t j = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    const bool active = j < B;
+    if (sp) seed = sp->seed;
+    const int32_t lane_local = active ? lane_ids[j] : 0;
+    const uint64_t lane = (uint64_t)(lane0 + lane_local);
+    const unsigned long long packed = active ? decisions[lane_local] : 0ull;  // the lane's first decisions, drawn by k_bucket_keys
+    const int n_packed = (int)(packed >> 60);
+    const int wave = threadIdx.x >> 6;
+    int state = 1;
+    unsigned long long acts = 0ull;
+    float reward_final = 0.0f;
+    for (int t = 0; t < T_cap; t += 2) {
+        const bool two = t + 1 < T_cap;  // (an odd T_cap ends with a row step alone)
+        const uint64_t live = __ballot(active && state != 0);
+        if ((threadIdx.x & 63) == 0) {
+            cnt[wave][t] = (int32_t)__popcll(live);
+            if (two) cnt[wave][t + 1] = (int32_t)__popcll(live);  // the row player's step leaves the state as it is
+        }
+        if (!active) continue;
+        const int64_t i = (int64_t)t * B + j;
+        indices[i] = state;
+        if (two) indices[i + B] = state;
+        if (state == 0) continue;
+        const bool replay0 = t < n_packed, replay1 = t + 1 < n_packed;
+        const int64_t row0 = state, row1 = S + state;
+        if (visited) {
+            visited[row0] = 1;  // (every writer stores the same value)
+            if (two) visited[row1] = 1;
+        }
+        float pol0[A], pol1[A], q0[A], q1[A];
+        if (!replay0) {
+#pragma unroll
+            for (int a = 0; a < A; ++a) pol0[a] = policy_tab[row0 * tab_stride + a];
+        }
+        if (two && !replay1) {
+#pragma unroll
+            for (int a = 0; a < A; ++a) pol1[a] = policy_tab[row1 * tab_stride + a];
+        }
+        if (!replay0) rnad_exp_noise(seed, lane, (uint32_t)t, 0u, A, q0);
+        if (two && !replay1) rnad_exp_noise(seed, lane, (uint32_t)(t + 1), 0u, A, q1);
+        const int bits0 = replay0 ? (int)(packed >> (6 * t)) & 63 : 0, bits1 = replay1 ? (int)(packed >> (6 * (t + 1))) & 63 : 0;
+        const int a0 = replay0 ? (bits0 & 7) : race_argmax<A>(pol0, q0);
+        acts |= (unsigned long long)a0 << (3 * t);
+        if (!two) continue;
+        const int a1 = replay1 ? (bits1 & 7) : race_argmax<A>(pol1, q1);
+        acts |= (unsigned long long)a1 << (3 * (t + 1));
+        int next;
+        float rew;
+        if (replay1)
+            transition_apply<A>(trans, C, state, a0, a1, bits1 >> 3, next, rew);
+        else
+            transition_lane<A>(trans, C, state, a0, a1, nullptr, seed, lane, (uint32_t)(t + 1), next, rew);
+        if (next == 0) reward_final = rew;
+        state = next;
+    }
+    if (active) {
         acts_out[j] = acts;
         reward_out[j] = reward_final;
     }
@@ -1190,16 +1235,21 @@ int rollout_bucketed_impl(const rnad_tree_t *tree, const RolloutBuffers &tr, boo
     const unsigned grid = blocks_for(B);
     {
         ProfScope one(PROF_BUCKET_ROLLOUT, stream);
-#define RNAD_BUCKET_ROLLOUT(COMPACT)                                                                                                     \
-    hipLaunchKernelGGL((k_bucket_rollout<kA, COMPACT>), dim3(grid), dim3(kThreads), 0, stream, tree->trans, tree->C, S, B, tr.T_cap,         \
-                       policy_tab, policy_stride, value_table, value_stride, (const uint8_t *)tree->mask_tab, seed, device_params, lane0,   \
+#define RNAD_BUCKET_ROLLOUT()                                                                                                            \
+    hipLaunchKernelGGL((k_bucket_rollout<kA>), dim3(grid), dim3(kThreads), 0, stream, tree->trans, tree->C, S, B, tr.T_cap, policy_tab,     \
+                       policy_stride, value_table, value_stride, (const uint8_t *)tree->mask_tab, seed, device_params, lane0,               \
                        (const int32_t *)lane_ids, (const unsigned long long *)s.decisions, tr.indices, tr.mask_bits, tr.policy, tr.actions, \
-                       tr.rewards, tr.values, s.alive_part, tr.acts, tr.final_reward, tr.visited)
+                       tr.rewards, tr.values, s.alive_part)
+#define RNAD_BUCKET_ROLLOUT_COMPACT()                                                                                                    \
+    hipLaunchKernelGGL((k_bucket_rollout_compact<kA>), dim3(grid), dim3(kThreads), 0, stream, tree->trans, tree->C, S, B, tr.T_cap,         \
+                       policy_tab, policy_stride, seed, device_params, lane0, (const int32_t *)lane_ids,                                    \
+                       (const unsigned long long *)s.decisions, tr.indices, s.alive_part, tr.acts, tr.final_reward, tr.visited)
         if (compact) {
-            RNAD_DISPATCH_A(tree->A, RNAD_BUCKET_ROLLOUT(true));
+            RNAD_DISPATCH_A(tree->A, RNAD_BUCKET_ROLLOUT_COMPACT());
         } else {
-            RNAD_DISPATCH_A(tree->A, RNAD_BUCKET_ROLLOUT(false));
+            RNAD_DISPATCH_A(tree->A, RNAD_BUCKET_ROLLOUT());
         }
+#undef RNAD_BUCKET_ROLLOUT_COMPACT
 #undef RNAD_BUCKET_ROLLOUT
     }
     hipLaunchKernelGGL(k_bucket_alive, dim3(tr.T_cap + 1), dim3(kThreads), 0, stream, (int)grid, tr.T_cap + 1, (const int32_t *)s.alive_part,
