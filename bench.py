@@ -457,7 +457,7 @@ def roofline_of(k):
     if os.path.exists(path):
         with open(path) as f:
             pmc = json.load(f)
-        hit = pmc.get(k["name"])
+        hit = pmc.get(k["name"]) or pmc.get(k["name"] + "_compact")
         if hit:
             r["traffic"] = hit["traffic_bytes_per_launch"]
             r["traffic_source"] = hit["source"]
