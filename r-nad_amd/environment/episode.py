@@ -187,6 +187,20 @@ class Episodes:
             if self.__dict__.get("_" + name) is None:
                 self.__dict__["_" + name] = getattr(traj, src)[:T]
 
+    def invalidate_derived(self):
+        """Forget everything that was derived from the rollout's own buffers (lazily built observations / one-hot actions / masks,
+        the dense fields of a compact rollout): RNaD calls this after replaying the captured step, which rewrites those buffers in
+        place -- the next access rebuilds from the new batch."""
+        self._lazy = {}
+        if self.buckets is not None:  # the bucketed rollouts do not store observations / values: both were built on access
+            self._observations = None
+            self._values = None
+        if self._compact is not None:
+            traj = self._compact[0]
+            traj.mask_bits = traj.policy = traj.actions = traj.rewards = None
+            for name in self._DENSE:
+                self.__dict__["_" + name] = None
+
     @property
     def turns(self):
         """[T, B] int64, == t mod 2 for every lane (episode.py:197); an expanded view, no memory."""

@@ -802,6 +802,7 @@ class RNaD:
             g["graph"] = graph
         g["graph"].replay()
         self.last_episodes.seed = self.last_episodes.states.seed = seed
+        self.last_episodes.invalidate_derived()  # the replay rewrote the batch in place
 
     def initialize(self):
         """Public alias of the reference's private __initialize (nets, optimizer, checkpoint 0/0)."""

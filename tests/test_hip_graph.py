@@ -7,6 +7,9 @@ pytestmark = pytest.mark.gpu
 DEV = torch.device("cuda:0")
 
 
+_BUFFERS = {}  # the replay buffer of each _run (the captured graph is bound to it)
+
+
 def _run(tree, tmp_path, use_graph, steps, rotate_at=None, tag=""):
     import os
 
@@ -23,6 +26,7 @@ def _run(tree, tmp_path, use_graph, steps, rotate_at=None, tag=""):
         for p in rn.net_reg_.parameters():
             p.mul_(1.01)
     buf = Buffer(1)
+    _BUFFERS[id(rn)] = buf
     seeds = []
     for i in range(steps):
         if i == rotate_at:  # what __resume does between two regularisation updates (rnad.py:528-531)
@@ -77,6 +81,39 @@ def test_many_replays_stay_finite(tmp_path):
     torch.cuda.synchronize()
     assert rn._graph["graph"] is not None and not rn._graph["failed"]
     assert all(torch.isfinite(p).all() for n in (rn.net, rn.net_target) for p in n.parameters())
+
+
+def test_derived_episode_fields_follow_the_replayed_batch(tmp_path):
+    """The captured step rewrites last_episodes' buffers in place: fields that are built on access (dense fields of the compact
+    trajectory, observations, one-hot actions) must be rebuilt from the new batch after every replay."""
+    from test_hip_bucket import TREES, _native_tree
+
+    tree = _native_tree(**TREES["pruned"])
+    rn, _, _ = _run(tree, tmp_path, True, 6, tag="inv")
+    assert rn._graph["graph"] is not None
+    ep = rn.last_episodes
+    before = {k: getattr(ep, k).clone() for k in ("indices", "policy", "action_idx", "rewards", "observations", "actions", "masks")}
+    # one more replay with another seed: a different batch in the same buffers
+    rn.train_step(_BUFFERS[id(rn)], alpha=0.9)
+    torch.cuda.synchronize()
+    assert rn.last_episodes is ep
+    assert not torch.equal(ep.indices, before["indices"]), "another seed must give another batch"
+    A, S = tree.max_actions, tree.handle().S
+    T = ep.t_eff + 1
+    live = ep.indices != 0
+    # the acting policy of every live slot is the row of the records the step used; rebuilt fields agree with the new indices
+    rows = ep.indices.long() + (torch.arange(T, device=DEV) % 2).view(T, 1) * S
+    rec = ep._compact[1]
+    col = 3 * A + 3
+    assert torch.equal(ep.policy[live], rec[rows[live]][:, col:col + A])
+    assert torch.equal(ep.actions.argmax(-1)[live], ep.action_idx.long()[live])
+    obs_now = ep.observations
+    fresh = torch.empty_like(obs_now)
+    import rnad_hip
+
+    for t in range(T):
+        rnad_hip.observe(tree.handle(), ep.indices[t], t & 1, obs=fresh[t])
+    assert torch.equal(obs_now, fresh)
 
 
 def test_logging_steps_and_mode_changes_leave_the_graph(tmp_path):
