@@ -59,6 +59,11 @@ struct DeviceGuard {
     }
 };
 
+// Zero `bytes` (a multiple of 4) at a 4-byte aligned device pointer with a KERNEL on `stream`.  Not hipMemsetAsync: the memset node of a
+// captured hipGraph was seen to write garbage after ~57 replays (ROCm 7.2; tests/test_hip_graph.py::test_many_replays_stay_finite),
+// so nothing on a path that may be captured clears memory that way.
+int zero_async(void *ptr, size_t bytes, hipStream_t stream);
+
 // Event bracketing for bench.py's roofline leg.
 enum ProfKernel {
     PROF_OBSERVE = 0, PROF_ACT = 1, PROF_LEARN = 2, PROF_MLP = 3, PROF_MLP_BWD = 4,

@@ -413,7 +413,7 @@ extern "C" int rnad_vtrace(int T, int64_t B, int A, const float *v, const float 
 
 extern "C" int rnad_mask_sum(int64_t N, const float *mask, double *out, void *stream) {
     RNAD_REQUIRE(mask && out, "rnad_mask_sum: null argument");
-    RNAD_HIP_OK(hipMemsetAsync(out, 0, sizeof(double), (hipStream_t)stream));
+    if (int rc = zero_async(out, sizeof(double), (hipStream_t)stream)) return rc;
     if (N == 0) return 0;
     const unsigned grid = (unsigned)std::min<int64_t>(blocks_for(N), 2048);
     hipLaunchKernelGGL(k_mask_sum, dim3(grid), dim3(kThreads), 0, (hipStream_t)stream, N, mask, out);
@@ -463,7 +463,9 @@ extern "C" int rnad_learn_fused(int T, int64_t B, int A, const int32_t *indices,
     RNAD_REQUIRE(T >= 0 && B >= 0, "rnad_learn_fused: negative shape");
     RNAD_REQUIRE(hp->n_disc >= 1, "rnad_learn_fused: n_disc must be positive");
     hipStream_t stream = (hipStream_t)stream_;
-    if (losses) RNAD_HIP_OK(hipMemsetAsync(losses, 0, 2 * sizeof(double), stream));
+    if (losses) {
+        if (int rc = zero_async(losses, 2 * sizeof(double), stream)) return rc;
+    }
     if (T == 0 || B == 0) return 0;
     ProfScope prof(PROF_LEARN, stream);
     RNAD_DISPATCH_A(A, hipLaunchKernelGGL((k_learn_fused<kA, false>), dim3(blocks_for(B)), dim3(kThreads), 0, stream, T, B, indices,
@@ -483,8 +485,12 @@ static int learn_fused_gather_impl(const rnad_tree_t *tree, int T, int64_t B, co
                  "rnad_learn_fused_gather: null argument");
     RNAD_REQUIRE(T >= 0 && B >= 0, "rnad_learn_fused_gather: negative shape");
     RNAD_REQUIRE(hp->n_disc >= 1, "rnad_learn_fused_gather: n_disc must be positive");
-    if (losses) RNAD_HIP_OK(hipMemsetAsync(losses, 0, 2 * sizeof(double), stream));
-    if (gmax) RNAD_HIP_OK(hipMemsetAsync(gmax, 0, sizeof(uint32_t) * (tree->A + 1), stream));
+    if (losses) {
+        if (int rc = zero_async(losses, 2 * sizeof(double), stream)) return rc;
+    }
+    if (gmax) {
+        if (int rc = zero_async(gmax, sizeof(uint32_t) * (tree->A + 1), stream)) return rc;
+    }
     if (T == 0 || B == 0) return 0;
     ProfScope prof(PROF_LEARN, stream);
     RNAD_DISPATCH_A(tree->A, hipLaunchKernelGGL((k_pack_records<kA>), dim3(blocks_for(2 * tree->S)), dim3(kThreads), 0, stream, 2 * tree->S,
@@ -526,7 +532,7 @@ static int row_sums_launch(const rnad_tree_t *tree, int T, int64_t B, const int3
                            const uint32_t *gmax, unsigned long long *acc, float *dlogit_tab, float *dv_tab, hipStream_t stream) {
     const int A = tree->A;
     const int64_t S = tree->S, N = (int64_t)T * B;
-    RNAD_HIP_OK(hipMemsetAsync(acc, 0, sizeof(unsigned long long) * 2 * S * (A + 1), stream));
+    if (int rc = zero_async(acc, sizeof(unsigned long long) * 2 * S * (A + 1), stream)) return rc;
     if (N > 0) {
         // persistent blocks: the LDS table of hot rows is flushed once per block, so few blocks walking many slots each
         int cus = 256;
@@ -567,7 +573,7 @@ extern "C" int rnad_row_sums(const rnad_tree_t *tree, int T, int64_t B, const in
     const int64_t N = (int64_t)T * B;
     unsigned long long *acc = (unsigned long long *)workspace;
     uint32_t *gmax = (uint32_t *)((char *)workspace + 2 * tree->S * (A + 1) * 8);
-    RNAD_HIP_OK(hipMemsetAsync(gmax, 0, sizeof(uint32_t) * (A + 1), stream));
+    if (int rc = zero_async(gmax, sizeof(uint32_t) * (A + 1), stream)) return rc;
     if (N > 0) {
         const unsigned grid = (unsigned)std::min<int64_t>(blocks_for(N), 2048);
         RNAD_DISPATCH_A(A, hipLaunchKernelGGL((k_grad_maxima<kA>), dim3(grid), dim3(kThreads), 0, stream, N, indices, dlogit, dv, gmax));

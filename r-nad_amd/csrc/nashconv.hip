@@ -124,8 +124,12 @@ extern "C" int rnad_nashconv(const rnad_tree_t *tree, const float *joint_policy,
     RNAD_REQUIRE(guard.ok, "rnad_nashconv: cannot select device %d", tree->device);
     RNAD_REQUIRE(tree->A >= 1 && tree->A <= RNAD_MAX_ACTIONS, "rnad_nashconv: bad tree");  // nothing below may return early: `mark` is owned here
     uint8_t *mark = nullptr;
-    RNAD_HIP_OK(hipMallocAsync((void **)&mark, (size_t)tree->S, stream));
-    RNAD_HIP_OK(hipMemsetAsync(mark, 0, (size_t)tree->S, stream));
+    const size_t mark_bytes = ((size_t)tree->S + 3) & ~(size_t)3;  // zero_async clears whole words
+    RNAD_HIP_OK(hipMallocAsync((void **)&mark, mark_bytes, stream));
+    if (int rc = zero_async(mark, mark_bytes, stream)) {
+        (void)hipFreeAsync(mark, stream);
+        return rc;
+    }
     hipLaunchKernelGGL(k_seed, dim3(1), dim3(1), 0, stream, (int)state_index, reach, mark, reach_out);
     const int root = (int)state_index;
     RNAD_DISPATCH_A(tree->A, {

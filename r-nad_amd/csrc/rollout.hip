@@ -356,7 +356,7 @@ extern "C" int rnad_rollout_step(const rnad_tree_t *tree, const rnad_traj_t *tr,
 extern "C" int rnad_rollout_end(const rnad_tree_t *tree, const rnad_traj_t *tr, void *stream_) {
     if (int rc = check_traj(tree, tr, "rnad_rollout_end")) return rc;
     hipStream_t stream = (hipStream_t)stream_;
-    RNAD_HIP_OK(hipMemsetAsync(tr->alive, 0, sizeof(int32_t) * (tr->T_cap + 1), stream));
+    if (int rc = zero_async(tr->alive, sizeof(int32_t) * (tr->T_cap + 1), stream)) return rc;
     const unsigned chunks = (unsigned)std::min<int64_t>(64, blocks_for(tr->B));
     hipLaunchKernelGGL(k_count_alive, dim3(chunks, tr->T_cap + 1), dim3(kThreads), 0, stream, tr->B, tr->indices, tr->alive);
     RNAD_HIP_OK(hipGetLastError());
@@ -401,7 +401,7 @@ extern "C" int rnad_compact_valid(int64_t N, const int32_t *indices, int32_t *ro
     RNAD_REQUIRE(n_rows && (N == 0 || (indices && rows && block_counts)), "rnad_compact_valid: null argument");
     hipStream_t stream = (hipStream_t)stream_;
     if (N == 0) {
-        RNAD_HIP_OK(hipMemsetAsync(n_rows, 0, sizeof(int64_t), stream));
+        if (int rc = zero_async(n_rows, sizeof(int64_t), stream)) return rc;
         return 0;
     }
     const int nb = (int)((N + kCompactChunk - 1) / kCompactChunk);

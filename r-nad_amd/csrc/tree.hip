@@ -28,6 +28,24 @@ struct ProfPair {
 };
 static std::vector<ProfPair> g_prof[PROF_COUNT];
 
+namespace {
+__global__ __launch_bounds__(256) void k_zero_words(uint32_t *__restrict__ p, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) p[i] = 0u;
+}
+}  // namespace
+
+int zero_async(void *ptr, size_t bytes, hipStream_t stream) {
+    if (bytes == 0) return 0;
+    if (((uintptr_t)ptr & 3) || (bytes & 3)) {
+        set_error("zero_async: pointer / size not 4-byte aligned");
+        return 2;
+    }
+    const size_t n = bytes / 4;
+    const unsigned grid = (unsigned)std::min<size_t>((n + 255) / 256, 2048);
+    hipLaunchKernelGGL(k_zero_words, dim3(grid), dim3(256), 0, stream, (uint32_t *)ptr, n);
+    return hipGetLastError() == hipSuccess ? 0 : 2;
+}
+
 ProfScope::ProfScope(int which_, hipStream_t stream_) : which(which_), stream(stream_) {
     if (!((g_prof_mask >> which_) & 1u)) return;
     hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;  // timing events do not belong in a captured graph
