@@ -376,32 +376,39 @@ __global__ __launch_bounds__(kSortThreads) void k_bucket_hist(int64_t B, int n_b
     for (int i = threadIdx.x; i < n_buckets; i += kSortThreads) row[i] = cnt[i];
 }
 
-// Column-wise exclusive prefix of hist over the blocks (in place) and the column totals.  A workgroup takes 64 buckets; its 16
-// waves each take a contiguous sixteenth of the blocks: partial sums -> prefix over the 16 parts in LDS -> second sweep.
+// Column-wise exclusive prefix of hist over the blocks (in place) and the column totals.  A workgroup takes kScanCols buckets; its
+// threads split the blocks into kSortThreads / kScanCols contiguous parts: partial sums -> prefix over the parts in LDS -> second
+// sweep.  (Few rows per thread: the two sweeps are chains of dependent loads.)
+constexpr int kScanCols = 16, kScanParts = kSortThreads / kScanCols;
+
 __global__ __launch_bounds__(kSortThreads) void k_bucket_scan(int n_blocks, int n_buckets, int32_t *__restrict__ hist,
                                                               int32_t *__restrict__ totals) {
-    __shared__ int32_t part[16][64];
-    const int c = blockIdx.x * 64 + (threadIdx.x & 63), g = threadIdx.x >> 6;
-    const int per = (n_blocks + 15) / 16, r0 = g * per, r1 = min(n_blocks, r0 + per);
+    __shared__ int32_t part[kScanParts][kScanCols + 1];
+    const int col = threadIdx.x & (kScanCols - 1), g = threadIdx.x / kScanCols;
+    const int c = blockIdx.x * kScanCols + col;
+    const int per = (n_blocks + kScanParts - 1) / kScanParts, r0 = min(n_blocks, g * per), r1 = min(n_blocks, r0 + per);
     int32_t sum = 0;
     if (c < n_buckets)
         for (int r = r0; r < r1; ++r) sum += hist[(int64_t)r * n_buckets + c];
-    part[g][threadIdx.x & 63] = sum;
+    part[g][col] = sum;
     __syncthreads();
-    int32_t before = 0, total = 0;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        const int32_t v = part[i][threadIdx.x & 63];
-        before += i < g ? v : 0;
-        total += v;
+    if (g == 0) {  // one thread per column: exclusive prefix over the parts, total
+        int32_t run = 0;
+        for (int i = 0; i < kScanParts; ++i) {
+            const int32_t v = part[i][col];
+            part[i][col] = run;
+            run += v;
+        }
+        if (c < n_buckets) totals[c] = run;
     }
+    __syncthreads();
     if (c < n_buckets) {
+        int32_t before = part[g][col];
         for (int r = r0; r < r1; ++r) {
             const int32_t v = hist[(int64_t)r * n_buckets + c];
             hist[(int64_t)r * n_buckets + c] = before;
             before += v;
         }
-        if (g == 0) totals[c] = total;
     }
 }
 
@@ -1225,7 +1232,7 @@ int rollout_bucketed_impl(const rnad_tree_t *tree, const RolloutBuffers &tr, boo
     {
         ProfScope sort_passes(PROF_BUCKET_SORT, stream);
         hipLaunchKernelGGL(k_bucket_hist, dim3(p.sort_blocks), dim3(kSortThreads), lds, stream, B, nb, (const int32_t *)s.keys, s.hist);
-        hipLaunchKernelGGL(k_bucket_scan, dim3((nb + 63) / 64), dim3(kSortThreads), 0, stream, p.sort_blocks, nb, s.hist, s.totals);
+        hipLaunchKernelGGL(k_bucket_scan, dim3((nb + kScanCols - 1) / kScanCols), dim3(kSortThreads), 0, stream, p.sort_blocks, nb, s.hist, s.totals);
         hipLaunchKernelGGL(k_bucket_items, dim3(1), dim3(kSortThreads), 0, stream, nb, p.chunk, (const int32_t *)s.totals, s.bucket_start,
                            (Item *)items, n_items);
         hipLaunchKernelGGL(k_bucket_scatter, dim3(p.sort_blocks), dim3(kSortThreads), lds, stream, B, nb, (const int32_t *)s.keys,
