@@ -317,7 +317,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_mlp_backward(int64_t N, int W, c
 // Sum the per-block partials (fixed order, fp64 accumulate) into the eight gradient tensors (torch Linear layouts).
 // blockDim = (64 outputs, kReduceSlices): slice s adds blocks s, s + kReduceSlices, ... of its output, then the slices are
 // added in order -- the same grouping on every run, 1 / kReduceSlices of the dependent-load chain of one thread per output.
-constexpr int kReduceSlices = 8;
+constexpr int kReduceSlices = 16;
 template <int A>
 __global__ __launch_bounds__(64 * kReduceSlices) void k_mlp_reduce(int nblocks, int W, int P, const float *__restrict__ partial,
                                                                    float *__restrict__ g_vw0, float *__restrict__ g_vb0,
@@ -329,7 +329,8 @@ __global__ __launch_bounds__(64 * kReduceSlices) void k_mlp_reduce(int nblocks, 
     const int e = blockIdx.x * 64 + threadIdx.x;
     const int total = 2 * W * FW + W + A * W + 1 + A;
     double s = 0.0;
-    if (e < total)
+    const bool padding = e < 2 * W * FW && e % FW > K;  // columns of the dW0aug tiles beyond the bias column: never stored
+    if (e < total && !padding)
         for (int b = threadIdx.y; b < nblocks; b += kReduceSlices) s += (double)partial[(int64_t)b * P + e];
     part[threadIdx.y][threadIdx.x] = s;
     __syncthreads();
