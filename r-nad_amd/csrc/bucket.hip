@@ -268,7 +268,10 @@ __global__ __launch_bounds__(kThreads) void k_row_records(int64_t rows, const fl
     log_policy_only<A>(lr, bits, lpr);
     log_policy_only<A>(lr2, bits, lpr2);
     process_policy_row<A>(pi, legal, hp.n_disc, hp.eps_threshold, pip);
-    float *o = rec + r * kRowStride<A>;
+    // both records are assembled in registers and leave as 16-byte stores (a store instruction per float would touch 64 different
+    // 64-byte segments each)
+    const float vr = v[r], vtr = vt[r];
+    float o[kRowStride<A>];
 #pragma unroll
     for (int a = 0; a < A; ++a) {
         o[a] = lg[a];
@@ -276,13 +279,16 @@ __global__ __launch_bounds__(kThreads) void k_row_records(int64_t rows, const fl
         o[2 * A + 2 + a] = lp[a] - (hp.alpha * lpr[a] + hp.one_minus_alpha * lpr2[a]);
         o[3 * A + 3 + a] = pi[a];
     }
-    o[A] = v[r];
-    o[A + 1] = vt[r];
+    o[A] = vr;
+    o[A + 1] = vtr;
     o[3 * A + 2] = __uint_as_float(bits);
 #pragma unroll
     for (int u = 4 * A + 3; u < kRowStride<A>; ++u) o[u] = 0.0f;
+    float4 *o4 = reinterpret_cast<float4 *>(rec + r * kRowStride<A>);
+#pragma unroll
+    for (int u = 0; u < kRowStride<A> / 4; ++u) o4[u] = float4{o[4 * u], o[4 * u + 1], o[4 * u + 2], o[4 * u + 3]};
     if (!fast) return;
-    float *f = fast + r * kFastStride<A>;
+    float f[kFastStride<A>];
     const float neg_eta = -hp.eta;
     float ent = 0.0f, mean = 0.0f;
 #pragma unroll
@@ -304,10 +310,13 @@ __global__ __launch_bounds__(kThreads) void k_row_records(int64_t rows, const fl
         gates |= ((l > -hp.threshold ? 1u : 0u) & (bits >> a)) << (8 + a);
         gates |= ((l < hp.threshold ? 1u : 0u) & (bits >> a)) << (16 + a);
     }
-    f[0] = v[r];
-    f[1] = vt[r];
+    f[0] = vr;
+    f[1] = vtr;
     f[2] = neg_eta * ent;
     f[3] = __uint_as_float(gates);
+    float4 *f4 = reinterpret_cast<float4 *>(fast + r * kFastStride<A>);
+#pragma unroll
+    for (int u = 0; u < kFastStride<A> / 4; ++u) f4[u] = float4{f[4 * u], f[4 * u + 1], f[4 * u + 2], f[4 * u + 3]};
 }
 
 // ---------------------------------------------------------------------------------------- 1. keys
