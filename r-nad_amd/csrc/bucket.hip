@@ -425,13 +425,19 @@ struct Item {
     int32_t begin, count, bucket, single;  // lanes [begin, begin + count) of that bucket; single: the bucket's only item
 };
 
-// bucket_start = exclusive prefix of the totals; one work item per `chunk` lanes of a non-empty bucket.  One workgroup.
+// bucket_start = exclusive prefix of the totals; one work item per `chunk` lanes of a non-empty bucket.  One workgroup, two phases:
+// the prefixes (lanes and items) of all buckets, then the items.  While no bucket has more than kItemsInline items a thread writes
+// out the buckets it scanned; otherwise (most of the lanes end up in a few buckets once the policy sharpens: thousands of items in
+// one bucket) item k finds its bucket by bisection in the item prefix kept in LDS.
+constexpr int kItemsInline = 16;
+
 __global__ __launch_bounds__(kSortThreads) void k_bucket_items(int n_buckets, int chunk, const int32_t *__restrict__ totals,
                                                                int32_t *__restrict__ bucket_start,
                                                                Item *__restrict__ items, int32_t *__restrict__ n_items) {
+    __shared__ int32_t first_s[kMaxBuckets + 1];  // first item of every bucket (exclusive prefix of the item counts)
     __shared__ int32_t wave_l[16], wave_i[16];
-    __shared__ int32_t carry_l, carry_i;
-    if (threadIdx.x == 0) carry_l = carry_i = 0;
+    __shared__ int32_t carry_l, carry_i, most;
+    if (threadIdx.x == 0) carry_l = carry_i = most = 0;
     __syncthreads();
     for (int base = 0; base < n_buckets; base += kSortThreads) {
         const int i = base + threadIdx.x;
@@ -450,17 +456,16 @@ __global__ __launch_bounds__(kSortThreads) void k_bucket_items(int n_buckets, in
             wave_l[threadIdx.x >> 6] = sl;
             wave_i[threadIdx.x >> 6] = si;
         }
+        if (ni > kItemsInline) most = ni;  // (any writer: only "> kItemsInline" matters)
         __syncthreads();
         int32_t bl = carry_l, bi = carry_i;
         for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) {
             bl += wave_l[w];
             bi += wave_i[w];
         }
-        const int32_t start = bl + sl - n, first = bi + si - ni;
         if (i < n_buckets) {
-            bucket_start[i] = start;
-            for (int32_t j = 0; j < ni; ++j)
-                items[first + j] = Item{start + j * chunk, min(chunk, n - j * chunk), i, ni == 1 ? 1 : 0};
+            bucket_start[i] = bl + sl - n;
+            first_s[i] = bi + si - ni;
         }
         __syncthreads();
         if (threadIdx.x == kSortThreads - 1) {
@@ -469,7 +474,29 @@ __global__ __launch_bounds__(kSortThreads) void k_bucket_items(int n_buckets, in
         }
         __syncthreads();
     }
-    if (threadIdx.x == 0) *n_items = carry_i;
+    const int32_t total = carry_i;
+    if (threadIdx.x == 0) {
+        first_s[n_buckets] = total;
+        *n_items = total;
+    }
+    __syncthreads();  // (bucket_start was written by this workgroup: visible to it after the barrier)
+    if (most <= kItemsInline) {
+        for (int i = threadIdx.x; i < n_buckets; i += kSortThreads) {
+            const int32_t n = totals[i], first = first_s[i], ni = first_s[i + 1] - first, start = bucket_start[i];
+            for (int32_t j = 0; j < ni; ++j) items[first + j] = Item{start + j * chunk, min(chunk, n - j * chunk), i, ni == 1 ? 1 : 0};
+        }
+        return;
+    }
+    for (int32_t k = threadIdx.x; k < total; k += kSortThreads) {
+        int lo = 0, hi = n_buckets;  // the last bucket with first_s[bucket] <= k (empty buckets share their successor's prefix)
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (first_s[mid] <= k) lo = mid;
+            else hi = mid;
+        }
+        const int32_t n = totals[lo], j = k - first_s[lo], start = bucket_start[lo];
+        items[k] = Item{start + j * chunk, min(chunk, n - j * chunk), lo, n <= chunk ? 1 : 0};
+    }
 }
 
 // lane_ids[bucket_start[key] + (lanes of earlier blocks with that key) + (earlier lanes of this block with that key)] = lane.

@@ -482,3 +482,45 @@ def test_lazy_rows_first_step_is_exact_where_it_can_be(tmp_path, monkeypatch):
     assert (want[0][rest] == 0).all() and (want[1][rest] == 0).all(), "rows the batch did not visit carry no gradient"
     lazy._compact = (lazy._compact[0], rec2)
     assert torch.equal(lazy.policy, full.policy) and torch.equal(lazy.rewards, full.rewards) and torch.equal(lazy.action_idx, full.action_idx)
+
+
+def test_a_sharp_policy_puts_most_lanes_into_one_bucket():
+    """Lanes concentrate as the policy sharpens: one bucket then holds most of the batch and is cut into many work items.  The items
+    must tile the lanes exactly, and the row sums must still be the per-slot gradients added up."""
+    import rnad_hip
+    from environment.episode import Episodes
+
+    tree = _native_tree(**TREES["ternary4"])
+    h = tree.handle()
+    A, S, B = tree.max_actions, h.S, 1 << 15
+    nets = _four_nets(A, 64, seed=8)
+    with torch.no_grad():
+        for name, p in nets[0].named_parameters():
+            if name.startswith("policy_fc1"):
+                p.mul_(40.0)  # near-deterministic actor
+    logit, v, vt, lr, lr_ = _tables(tree, nets, A)
+    hp = rnad_hip.make_learn_params(alpha=0.5, eta=0.2)
+    rec, fast = rnad_hip.bucket_records(h, logit, v, vt, lr, lr_, hp, fast=True)
+    ep = Episodes(tree, B, seed=21)
+    ep.generate(nets[0], tabular=True, bucketed=True, trim=False, store_values=False, policy_table=(rec, rnad_hip.policy_column(A)), compact=True)
+    n = int(ep.buckets.n_items.item())
+    items = ep.buckets.items[:n].cpu().numpy()
+    begin, count, bucket, single = items.T
+    assert count.min() >= 1 and count.max() <= 256 and count.sum() == B
+    assert (begin == np.concatenate([[0], np.cumsum(count)[:-1]])).all(), "the items tile the sorted lanes in order"
+    per_bucket = np.bincount(bucket, weights=count)
+    assert per_bucket.max() > B / 4, "the test wants a dominant bucket"
+    assert ((np.bincount(bucket)[bucket] == 1) == (single == 1)).all()
+    T = ep.t_eff + 1
+    got = rnad_hip.learn_bucketed_compact(h, ep.buckets, ep._compact[0], T, rec, fast, ep.valid_counts, hp)
+    dl, dv, _ = rnad_hip.learn_fused_gather(h, ep.indices, ep.mask_bits, ep.action_idx, ep.rewards, ep.policy, logit, v, vt, lr, lr_,
+                                            ep.valid_counts, hp)
+    idx = ep.indices.cpu().numpy().astype(np.int64)
+    rows = idx + (np.arange(T) % 2)[:, None] * S
+    live = idx != 0
+    want_l = np.zeros((2 * S, A))
+    want_v = np.zeros(2 * S)
+    np.add.at(want_l, rows[live], dl.cpu().numpy().astype(np.float64)[live])
+    np.add.at(want_v, rows[live], dv.cpu().numpy().astype(np.float64)[live])
+    np.testing.assert_allclose(got[0].cpu().numpy(), want_l, rtol=2e-6, atol=2e-7 * np.abs(want_l).max())
+    np.testing.assert_allclose(got[1].cpu().numpy()[:, 0], want_v, rtol=2e-6, atol=2e-7 * np.abs(want_v).max())
