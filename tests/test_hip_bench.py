@@ -39,16 +39,18 @@ def test_one_gpu_line_has_the_contract_fields():
 
 
 @pytest.mark.timeout(900)
-def test_two_rank_control_flow():
+@pytest.mark.parametrize("scaling", ("weak", "strong"))
+def test_two_rank_control_flow(scaling):
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     env = dict(os.environ, RNAD_BENCH_REHEARSAL="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", *SMALL]
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--scaling", scaling, *SMALL]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=850, env=env)
     assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
     j = _json_line(r.stdout)
-    assert j["n_gpus"] == 2 and j["scaling"] == "weak" and j["config"]["global_batch"] == 2 * j["config"]["per_gpu_batch"] == 2 << 14
+    assert j["n_gpus"] == 2 and j["scaling"] == scaling and j["config"]["global_batch"] == 2 * j["config"]["per_gpu_batch"]
+    assert j["config"]["global_batch"] == ((2 << 14) if scaling == "weak" else (1 << 14))
     assert j["value"] > 0 and "eager" in j["legs_ms_per_step"] and "cpu_baseline" not in j
     assert abs(j["value"] - j["config"]["global_batch"] * j["config"]["T"] / (j["ms_per_step"] * 1e-3)) < 1e-6 * j["value"]
