@@ -23,7 +23,10 @@
  *   - fp32 arithmetic follows the reference's operation order and is compiled with
  *     -ffp-contract=off; integer results are bit-exact, fp32 results within 1e-5 (exp/log use the
  *     device libm).
- *   - one host thread per GPU; handles are not thread-safe.
+ *   - one host thread per GPU; handles are not thread-safe.  ONE trainer per (tree handle, batch size) and device at a time:
+ *     the `scratch` / `accumulators` workspaces of the bucketed pipeline are shared by every call made with them, and
+ *     rnad_optimizer_step keeps one device-global ticket counter -- two updates in flight on different streams of one device
+ *     would race on both (one process per GPU with one training stream, the arrangement of learn/rnad.py, never does).
  */
 #ifndef RNAD_HIP_H
 #define RNAD_HIP_H

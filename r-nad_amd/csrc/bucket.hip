@@ -733,6 +733,7 @@ struct FixedPoint {
     double scale_l, scale_v;  // 2^f: units per 1.0 of an addend of dL/dlogit / dL/dv
     float limit_l, limit_v;   // |addend| must stay below this (2^(62 - kLaneBits) units)
     float scale_l32, scale_v32;  // the same scales as floats (exact: powers of two)
+    int check_l;                 // 2 * clip does not fit below limit_l (neurd_clip >= 2^29, e.g. "no clipping"): range-check every dL/dlogit addend
 };
 
 // One slot of the on-policy update from its row's fast record f (k_row_records): vtrace_step for the mover P ("ours") and for the
@@ -802,8 +803,10 @@ __device__ __forceinline__ void fast_slot(const float *__restrict__ f, const flo
     out[A] = round_to_ll((double)(gv * fx.scale_v32));
 #pragma unroll
     for (int a = 0; a < A; ++a) {
-        // |g| <= 2 clip < limit_l by construction here (adv is clamped and not NaN, or the flag is set): no range check
+        // |g| <= 2 clip < limit_l by construction here (adv is clamped and not NaN, or the flag is set): no range check -- unless the
+        // clip itself is beyond the fixed-point range (fx.check_l, a kernel argument: a scalar branch)
         const float g = (bits >> a) & 1 ? wv[a] - share : 0.0f;
+        if (fx.check_l) ovf |= !(fabsf(g) < fx.limit_l);
         out[a] = round_to_ll((double)(-g * fx.scale_l32));
     }
 }
@@ -1118,6 +1121,7 @@ FixedPoint fixed_point_for(const rnad_learn_params_t &hp) {
     fx.limit_v = (float)std::ldexp(1.0, e_v);
     fx.scale_l32 = (float)fx.scale_l;
     fx.scale_v32 = (float)fx.scale_v;
+    fx.check_l = !(2.0 * std::fabs((double)hp.clip) < std::ldexp(1.0, e_l)) ? 1 : 0;  // (also true for a NaN / infinite clip)
     return fx;
 }
 

@@ -280,7 +280,24 @@ class RNaD:
             setattr(self, name, module)
         self.optimizer = self.__new_optimizer()
         self.optimizer.load_state_dict(saved["optimizer"])
+        self._adopt_optimizer_state()
         logging.info("resumed at m=%d n=%d (step %d)", m, n, self.total_steps)
+
+    def _adopt_optimizer_state(self):
+        """load_state_dict replaces param_groups with the saved ones -- a reference-written checkpoint (rnad.py:232-237, :318) has
+        capturable=False / fused=None and keeps `step` as a CPU tensor -- which would leave the captured step and the one-launch
+        optimiser tail unusable for the rest of the run.  On a GPU: back to what __new_optimizer constructs, counters on the device."""
+        dev = self.device if isinstance(self.device, torch.device) else torch.device(self.device)
+        if dev.type != "cuda":
+            return
+        for group in self.optimizer.param_groups:
+            group["capturable"] = True
+            group["fused"] = True
+            group["foreach"] = False
+        for st in self.optimizer.state.values():
+            step = st.get("step")
+            if step is not None:
+                st["step"] = torch.as_tensor(float(step), dtype=torch.float32).to(dev)
 
     def __save_checkpoint(self):
         if self._rank != 0:
@@ -358,8 +375,8 @@ class RNaD:
         key = (id(self.net_reg), id(self.net_reg_), table.data_ptr(), tuple(table.shape),
                sum(p._version for p in self.net_reg.parameters()), sum(p._version for p in self.net_reg_.parameters()))
         cache = getattr(self, "_reg_table_cache", None)
-        if cache is None or cache["key"][:4] != key[:4]:
-            cache = self._reg_table_cache = {"key": None, "logit_reg": None, "logit_reg_": None}
+        if cache is None or cache["ident"] != key[:4]:
+            cache = self._reg_table_cache = {"key": None, "ident": key[:4], "logit_reg": None, "logit_reg_": None}
         if cache["key"] != key:
             A = self.tree.max_actions
             with torch.no_grad():
@@ -375,7 +392,11 @@ class RNaD:
         return cache["logit_reg"], cache["logit_reg_"]
 
     def invalidate_tables(self):
-        self._reg_table_cache = None
+        """Force the next _reg_tables() call to re-evaluate the regularisation nets -- IN PLACE: the buffers keep their addresses,
+        which a captured graph of the step has baked in (a fresh allocation would leave the replays reading the old ones)."""
+        cache = getattr(self, "_reg_table_cache", None)
+        if cache is not None:
+            cache["key"] = None
 
     def _table_outputs(self, alpha, obs_half=False, want_target_logits=False, policy_only=False):
         """learner / target / regularisation nets on the 2S observations of the tree (rnad.py:373-380 on every distinct input):
@@ -746,13 +767,16 @@ class RNaD:
         local_batch = self.batch_size // self._world
         if self._tabular_mode(2 * handle.max_depth, local_batch) is not True or rnad_hip.bucket_plan(handle, local_batch) is None:
             return False
-        if not getattr(self.optimizer, "defaults", {}).get("capturable", False):
+        if not all(group.get("capturable", False) for group in self.optimizer.param_groups):
             return False
         return True
 
     def _graph_key(self, buffer):
         """Everything a captured step has baked in: replay is only valid while none of it changed."""
-        return (id(buffer), id(self.net), id(self.net_target), id(self.net_reg), id(self.net_reg_), id(self.optimizer), id(self.tree.handle()),
+        grp = self.optimizer.param_groups[0]
+        lr = grp["lr"]
+        opt = (float(lr) if not torch.is_tensor(lr) else id(lr), tuple(float(b) for b in grp["betas"]), float(grp["eps"]))  # by value in the captured launch
+        return (id(buffer), id(self.net), id(self.net_target), id(self.net_reg), id(self.net_reg_), id(self.optimizer), id(self.tree.handle()), opt,
                 self.batch_size, self.tabular, getattr(self, "tabular_gate", 8), self.eta, self.beta, self.neurd_clip, self.grad_clip,
                 self.c_bar, self.roh_bar, self.vtrace_gamma, self.value_weight, self.neurd_weight, self.epsilon_threshold, self.n_discrete,
                 self.gamma_averaging, getattr(self, "obs_half", False), getattr(self, "store_actor_values", False), getattr(self, "fused_optimizer", True),
@@ -800,9 +824,16 @@ class RNaD:
                     self._seed_override = None
             self._seed_override = None
             g["graph"] = graph
+            g["episodes"] = self.last_episodes
         g["graph"].replay()
-        self.last_episodes.seed = self.last_episodes.states.seed = seed
-        self.last_episodes.invalidate_derived()  # the replay rewrote the batch in place
+        # the replay rewrote the CAPTURED batch in place: an eager (logging) step in between left another Episodes object in
+        # last_episodes and in the buffer
+        ep = g["episodes"]
+        if self.last_episodes is not ep:
+            self.last_episodes = ep
+            buffer.append(ep)
+        ep.seed = ep.states.seed = seed
+        ep.invalidate_derived()
 
     def initialize(self):
         """Public alias of the reference's private __initialize (nets, optimizer, checkpoint 0/0)."""

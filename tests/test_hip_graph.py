@@ -166,3 +166,114 @@ def test_fused_optimizer_tail_is_clip_adam_ema(tmp_path):
     assert runs[True][2] == runs[False][2] == [6.0] * 8
     for a, b in zip(runs[False][0] + runs[False][1], runs[True][0] + runs[True][1]):
         np.testing.assert_allclose(b.cpu().numpy(), a.cpu().numpy(), rtol=2e-5, atol=1e-8)
+
+
+def test_invalidate_tables_refreshes_the_captured_buffers_in_place(tmp_path):
+    """invalidate_tables() after an edit autograd's version counters do not see: the regularisation tables a captured step reads
+    must be refreshed at the addresses the graph has baked in -- replays then equal eager steps from the same edit."""
+    from test_hip_bucket import TREES, _native_tree
+
+    tree = _native_tree(**TREES["ternary4"])
+    out = {}
+    for use_graph in (False, True):
+        rn, _, _ = _run(tree, tmp_path, use_graph, 5, tag="inval")
+        buf = _BUFFERS[id(rn)]
+        ptrs = [t.data_ptr() for t in rn._reg_tables(tree.handle().observations_table())]
+        for p in rn.net_reg.parameters():
+            p.data = p.data * 1.05  # a new tensor behind the same Parameter: no version bump on the old storage
+        rn.invalidate_tables()
+        for i in range(3):
+            rn.train_step(buf, alpha=0.5)
+            rn.total_steps += 1
+        torch.cuda.synchronize()
+        assert [t.data_ptr() for t in rn._reg_tables(tree.handle().observations_table())] == ptrs, "the tables must be refreshed in place"
+        if use_graph:
+            assert rn._graph["graph"] is not None and not rn._graph["failed"]
+        out[use_graph] = [p.detach().clone() for n in (rn.net, rn.net_target) for p in n.parameters()]
+    for a, b in zip(out[False], out[True]):
+        assert torch.equal(a, b)
+
+
+def test_last_episodes_is_the_replayed_batch_after_an_eager_logging_step(tmp_path):
+    """A logging step between two replays leaves its own Episodes in last_episodes / the buffer; the next replay must put the
+    captured batch (the one it rewrites) back, labelled with that replay's seed."""
+    from test_hip_bucket import TREES, _native_tree
+
+    tree = _native_tree(**TREES["ternary4"])
+    rn, _, _ = _run(tree, tmp_path, True, 6, tag="lastep")
+    buf = _BUFFERS[id(rn)]
+    captured = rn.last_episodes
+    assert rn._graph["graph"] is not None and rn._graph["episodes"] is captured
+    rn.train_step(buf, alpha=0.5, log={})
+    assert rn.last_episodes is not captured
+    rn.train_step(buf, alpha=0.5)
+    torch.cuda.synchronize()
+    assert rn.last_episodes is captured and buf.episodes_buffer[-1] is captured
+    # the label matches the content: an eager rollout with that seed and these records' actor plays the same batch
+    from environment.episode import Episodes
+
+    again = Episodes(tree, captured.batch_size, seed=captured.seed)
+    rec = captured._compact[1]
+    import rnad_hip
+
+    again.generate(rn.net, trim=False, store_values=False, tabular=True, bucketed=True, policy_table=(rec, rnad_hip.policy_column(tree.max_actions)),
+                   compact=True)
+    assert torch.equal(again.indices, captured.indices) and torch.equal(again.lane_ids, captured.lane_ids)
+
+
+def test_changing_the_learning_rate_recaptures_the_step(tmp_path):
+    """lr / betas / eps travel by value in the captured optimiser launch: editing param_groups must not be silently ignored."""
+    from test_hip_bucket import TREES, _native_tree
+
+    tree = _native_tree(**TREES["ternary4"])
+    rn, _, _ = _run(tree, tmp_path, True, 5, tag="lr")
+    buf = _BUFFERS[id(rn)]
+    first = rn._graph["graph"]
+    assert first is not None
+    before = [p.detach().clone() for p in rn.net.parameters()]
+    rn.optimizer.param_groups[0]["lr"] = 0.0
+    for _ in range(5):
+        rn.train_step(buf, alpha=0.5)
+    torch.cuda.synchronize()
+    assert rn._graph["graph"] is not None and rn._graph["graph"] is not first
+    for a, b in zip(before, rn.net.parameters()):
+        assert torch.equal(a, b), "with lr = 0 Adam must leave the parameters where they were"
+
+
+def test_resume_from_a_reference_style_checkpoint_keeps_the_graph_and_the_fused_tail(tmp_path, monkeypatch):
+    """optimizer.load_state_dict brings the checkpoint's param_groups -- the reference writes capturable=False, fused=None and CPU
+    step counters (rnad.py:232-237, :318; tests/golden/ref_run_ckpt_1_0 is one, at a width the fused MLP does not take) -- after
+    _resume_from the captured step and the one-launch optimiser tail must still be in use."""
+    from environment.episode import Buffer
+    from learn.rnad import RNaD
+    from test_hip_bucket import TREES, _native_tree
+
+    monkeypatch.setenv("RNAD_SAVE_DIR", str(tmp_path))
+    tree = _native_tree(**TREES["ternary4"])
+    kw = dict(tree=tree, device=DEV, directory_name="refstyle", batch_size=1 << 13, eta=0.2, b1_adam=0.0, lr=1e-3, bounds=[4], delta_m=[3],
+              net_params={"type": "MLP", "max_actions": 3, "width": 64})
+    torch.manual_seed(4)
+    first = RNaD(**kw)
+    first.run(max_updates=1, checkpoint_mod=1, expl_mod=10**9, log_mod=10**9)  # m = 0: checkpoints 0/0, 0/1, 0/2
+    ck_path = tmp_path / "saved_runs" / "refstyle" / "0" / "2"
+    ck = torch.load(ck_path, weights_only=False)
+    for grp in ck["optimizer"]["param_groups"]:  # what torch 2.0's Adam(...) of the reference saves
+        grp.update(capturable=False, fused=None, foreach=None)
+    for st in ck["optimizer"]["state"].values():
+        st["step"] = st["step"].detach().cpu()
+    torch.save(ck, ck_path)
+    rn = RNaD(**kw)
+    rn.initialize()
+    assert (rn.m, rn.n) == (0, 2)
+    grp = rn.optimizer.param_groups[0]
+    assert grp["capturable"] and grp["fused"]
+    assert all(st["step"].is_cuda and st["step"].dtype == torch.float32 and float(st["step"]) == 2.0 for st in rn.optimizer.state.values())
+    buf = Buffer(1)
+    for i in range(6):
+        rn.train_step(buf, alpha=0.5)
+        rn.total_steps += 1
+    torch.cuda.synchronize()
+    assert rn._fused_tail() is not None
+    assert rn._graph["graph"] is not None and not rn._graph["failed"]
+    assert all(float(st["step"]) == 8.0 for st in rn.optimizer.state.values())
+    assert all(torch.isfinite(p).all() for p in rn.net.parameters())
