@@ -12,11 +12,12 @@ MLP width 256, fp32.  `value` times RNaD's default net-evaluation mode (tabular 
 state) observation -- 132 862 rows for 12.6 M slots --, the rollout is bucket-ordered, the per-slot gradients are summed per row in
 LDS and one backward over the rows gives the weight gradients; the step is replayed from a captured hipGraph); `other_modes` times
 "forward" (backward per slot: bit-identical to dense) and dense (every net on every slot, as the reference does) in the same process.
-N > 1: every rank plays and learns from its own 2^20 episodes (weak scaling: the per-GPU work of configs[1] is held fixed, the
-global batch is N x 2^20; --scaling strong shards ONE 2^20 batch over the ranks instead, the north_star's arrangement) with one RCCL
-all-reduce of the 2 loss normalisers (beside the learner kernel) and one of the 43 KB gradient bucket per step.  The N > 1 run
-times the eagerly enqueued step first and then the step replayed from a hipGraph with the RCCL collectives captured inside it,
-under a watchdog: if the captured variant does not finish, the eager measurement is what gets printed.
+N > 1 (default): BASELINE.json configs[2] -- ONE batch of 2^22 episodes sharded over the ranks (2^19 per GPU at N = 8; "scaling": "strong")
+with one RCCL all-reduce of the 2 loss normalisers (beside the learner kernel) and one of the 43 KB gradient bucket per step; rank 0
+also times the same 2^22 batch on its GPU alone (`strong_scaling.base`), the N = 1 point of that curve.  --scaling weak gives every
+rank its own 2^batch-log2 episodes instead.  The N > 1 run times the eagerly enqueued step first and then the step replayed from a
+hipGraph with the RCCL collectives captured inside it, under a watchdog: if the captured variant does not finish, the eager
+measurement is what gets printed.
 
 Prints ONE JSON line on rank 0.  `value` = env steps of all ranks / wall time of the K timed steps (inputs resident in HBM; the
 tree is generated and uploaded before the timed region).  `roofline` is for the kernel that takes the largest share of the step,
@@ -44,6 +45,27 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+CLOCK_HZ = 2.4e9       # max shader clock (same guide)
+SIMDS = 256 * 4        # 256 CUs x 4 SIMDs
+# VALU issue roof: wave-instructions per second if every SIMD issued one wave64 VALU instruction every 4 cycles -- what this path's
+# instruction mix costs (SQ_ACTIVE_INST_VALU x 4 cycles / SQ_INSTS_VALU = 4.0 in profiles/*_pmc_sq.csv: 64-bit integer and fp64
+# conversions, divisions and transcendental steps next to the 2-cycle fp32 ops)
+VALU_PEAK_GINST = SIMDS * CLOCK_HZ / 4 / 1e9
+PMC_FILE = os.path.join(ROOT, "profiles", "r03_pmc.json")
+
+
+def pmc_counters():
+    """Counter evidence of the step's kernels from the separate rocprofv3 --pmc passes (tools/round_artifacts.sh -> tools/pmc_json.py),
+    or {} when the file was measured on another build (its source hash is not this tree's): stale counters are not reported."""
+    if not os.path.exists(PMC_FILE):
+        return {}
+    import rnad_hip
+
+    with open(PMC_FILE) as f:
+        pmc = json.load(f)
+    if pmc.get("source_hash") != rnad_hip.source_hash():
+        return {}
+    return pmc.get("kernels", {})
 
 
 def main():
@@ -51,10 +73,13 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--batch-log2", type=int, default=20,
-                    help="log2 of the episode batch: per GPU under weak scaling (default), of the whole job under --scaling strong")
-    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
-                    help="N > 1: weak = every GPU gets 2^batch-log2 episodes (default); strong = one 2^batch-log2 batch sharded over the GPUs")
+    ap.add_argument("--batch-log2", type=int, default=None,
+                    help="log2 of the episode batch: of the whole job under --scaling strong, per GPU under --scaling weak.  Default: 20 on "
+                         "one GPU (BASELINE.json configs[1]), 22 on several (configs[2]: one 2^22 batch sharded over the GPUs)")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default=None,
+                    help="N > 1: strong (default) = one 2^batch-log2 batch sharded over the GPUs (configs[2]); weak = every GPU gets 2^batch-log2 episodes")
+    ap.add_argument("--no-base-leg", action="store_true",
+                    help="N > 1, strong scaling: do not time the same global batch on rank 0's GPU alone (the N = 1 point of the curve)")
     ap.add_argument("--graph-timeout", type=float, default=120.0,
                     help="N > 1: seconds the captured-graph leg may take before the eager measurement is printed instead")
     ap.add_argument("--depth", type=int, default=6)
@@ -77,6 +102,10 @@ def main():
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
+    if args.scaling is None:
+        args.scaling = "strong" if world > 1 else "weak"  # (one GPU: the two coincide)
+    if args.batch_log2 is None:
+        args.batch_log2 = 22 if (world > 1 and args.scaling == "strong") else 20
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
@@ -118,28 +147,35 @@ def main():
     handle = tree.handle()
     setup_tree_s = time.perf_counter() - t0
     os.environ["RNAD_SAVE_DIR"] = tempfile.mkdtemp(prefix="rnad_bench_")
-    torch.manual_seed(0)
-    rn = RNaD(tree=tree, device=device, directory_name=f"bench-r{rank}", batch_size=global_batch, eta=0.2, b1_adam=0.0,
-              net_params={"type": "MLP", "max_actions": A, "width": args.width})
-    rn.initialize()
-    rn.obs_half = args.obs_half
-    rn.use_graph = not args.no_graph
-    if args.net_mode != "default":
-        rn.tabular = {"dense": False, "forward": "forward", "tabular": True}[args.net_mode]
-    with torch.no_grad():
-        # the general case of rnad.py:382: two DISTINCT regularisation nets and 0 < alpha < 1 (all four nets matter)
-        for p in rn.net_reg_.parameters():
-            p.mul_(1.001)
-    buffer = Buffer(rn.n_batches_per_buffer)
     delta_m = 10_000
-    counter = {"i": 0}
 
-    def one_step():
-        i = counter["i"]
-        alpha = 1 if i > delta_m / 2 else i * 2 / delta_m
-        rn.train_step(buffer, alpha)
-        rn.total_steps += 1
-        counter["i"] = i + 1
+    def make_trainer(batch, name, data_parallel=True):
+        torch.manual_seed(0)
+        t = RNaD(tree=tree, device=device, directory_name=name, batch_size=batch, eta=0.2, b1_adam=0.0,
+                 net_params={"type": "MLP", "max_actions": A, "width": args.width})
+        t.data_parallel = data_parallel
+        t.initialize()
+        t.obs_half = args.obs_half
+        t.use_graph = not args.no_graph
+        if args.net_mode != "default":
+            t.tabular = {"dense": False, "forward": "forward", "tabular": True}[args.net_mode]
+        with torch.no_grad():
+            # the general case of rnad.py:382: two DISTINCT regularisation nets and 0 < alpha < 1 (all four nets matter)
+            for p in t.net_reg_.parameters():
+                p.mul_(1.001)
+        buf = Buffer(t.n_batches_per_buffer)
+        count = {"i": 0}
+
+        def step():
+            i = count["i"]
+            alpha = 1 if i > delta_m / 2 else i * 2 / delta_m
+            t.train_step(buf, alpha)
+            t.total_steps += 1
+            count["i"] = i + 1
+
+        return t, buf, step
+
+    rn, buffer, one_step = make_trainer(global_batch, f"bench-r{rank}")
 
     def fence():
         torch.cuda.synchronize()
@@ -273,6 +309,31 @@ def main():
     # read back NOW: emit() may be called from the watchdog thread while the device queue is stuck
     alive = rn.last_episodes.alive.cpu().numpy()[:T]
 
+    # ---- strong scaling: the N = 1 point of this curve -- the SAME global batch on rank 0's GPU alone (no collectives), same mode,
+    # same replayed graph; the other ranks wait at the barrier below
+    base = None
+    if world > 1 and args.scaling == "strong" and not args.no_base_leg:
+        if rank == 0:
+            try:
+                solo, _, solo_step = make_trainer(global_batch, "bench-solo", data_parallel=False)
+                for _ in range(6 + args.warmup):
+                    solo_step()
+                torch.cuda.synchronize()
+                n_base = max(1, min(args.steps, 200))
+                t_b = time.perf_counter()
+                for _ in range(n_base):
+                    solo_step()
+                torch.cuda.synchronize()
+                g_b = getattr(solo, "_graph", None)
+                base = {"n_gpus": 1, "global_batch": global_batch, "steps": n_base, "ms_per_step": (time.perf_counter() - t_b) / n_base * 1e3,
+                        "net_mode_in_effect": repr(solo._tabular_mode(T, global_batch)),
+                        "step_replayed_from_hipGraph": bool(g_b and g_b.get("graph") is not None)}
+                del solo, solo_step
+                torch.cuda.empty_cache()
+            except Exception as err:  # the reference leg must not cost the run its line
+                base = {"error": str(err)[:300]}
+        dist.barrier()
+
     def emit(elapsed, replayed, note=None):
         if rank != 0:
             return
@@ -281,7 +342,17 @@ def main():
         T_ref = int((alive > 0).sum())
         env_steps = global_batch * T_ref * args.steps
         live_slots = int(alive.sum())
-        default_workload = (A, C, depth, tuple(args.prune), args.batch_log2, args.width) == (3, 1, 6, (0, 0), 20, 256)
+        c2_tree = (A, C, depth, tuple(args.prune), args.width) == (3, 1, 6, (0, 0), 256)
+        default_workload = c2_tree and global_batch == 1 << 20 and world == 1
+        configs2 = c2_tree and global_batch == 1 << 22 and world > 1 and args.scaling == "strong"
+        if default_workload:
+            which = ", BASELINE.json configs[1]"
+        elif configs2:
+            which = f", BASELINE.json configs[2] (one 2^22 batch sharded over {world} GPUs" + ("" if world == 8 else "; configs[2] names 8") + ")"
+        elif c2_tree:
+            which = ", the BASELINE.json configs[1]/[2] tree at another batch"
+        else:
+            which = f", prune {args.prune[0]}/{args.prune[1]}, threshold {threshold:g} (a BASELINE.json configs[3]/[4]-style variant)"
         what = {False: "every net evaluated on every (t, b) slot, as the reference does",
                 "forward": "forward evaluations once per (player, state) row and gathered per slot; backward per slot; bit-identical to dense",
                 True: "nets evaluated once per (player, state) row; bucket-ordered rollout; per-slot gradients summed per row in LDS (64-bit "
@@ -304,9 +375,7 @@ def main():
             "config": {
                 "workload": f"depth-{depth} {A}x{A} matrix tree, C={C}, S={tree.index_tensor.shape[0]}, "
                             + (f"2^{args.batch_log2} episodes per GPU" if world > 1 and args.scaling == "weak" else f"global batch 2^{args.batch_log2} episodes")
-                            + f" x T={T_ref} env steps, MLP width {args.width}"
-                            + (", BASELINE.json configs[1]" if default_workload else
-                               f", prune {args.prune[0]}/{args.prune[1]}, threshold {threshold:g} (a BASELINE.json configs[3]/[4]-style variant)"),
+                            + f" x T={T_ref} env steps, MLP width {args.width}" + which,
                 "global_batch": global_batch, "per_gpu_batch": local_batch, "T": T_ref, "T_buffer": T,
                 "valid_env_steps_per_step": live_slots * world,
                 "parallelism": f"dp{world} (episodes sharded, RCCL all-reduce of 2 normalisers + 43 KB grads)",
@@ -331,6 +400,12 @@ def main():
         }
         if world > 1:
             out["legs_ms_per_step"] = {k: v / args.steps * 1e3 for k, v in legs.items()}
+            out["collectives"] = {"backend": dist.get_backend(), "rccl_ranks": dist.get_world_size() if dist.get_backend() == "nccl" else None,
+                                  "ranks": dist.get_world_size(), "per_step": "all_reduce(2 x f64 normalisers) + all_reduce(43 KB fp32 gradient bucket)"}
+            if base is not None:
+                out["strong_scaling"] = {"base": base}
+                if base.get("ms_per_step"):
+                    out["strong_scaling"]["speedup_vs_one_gpu_same_batch"] = base["ms_per_step"] / (elapsed / args.steps * 1e3)
             if note:
                 out["note"] = note
         if world == 1 and not args.no_cpu_baseline:
@@ -411,13 +486,35 @@ def kernel_report(prof, A, C, args, B, T, live_slots, tree, mode_now):
         rh.PROF_OBSERVE: ("hbm", B * (4 + 8 * A * A + 2 * A * A * (2 if args.obs_half else 4) + 4 * A), "SURVEY 8d"),
     }
     out = {}
+    pmc = pmc_counters() if (A, C, args.depth, tuple(args.prune), B, args.width, args.obs_half) == (3, 1, 6, (0, 0), 1 << 20, 256, False) else {}
+    pmc_name = {rh.PROF_BUCKET_KEYS: "k_bucket_keys", rh.PROF_BUCKET_ROLLOUT: "k_bucket_rollout_compact" if compact else "k_bucket_rollout",
+                rh.PROF_BUCKET_LEARN: "k_bucket_learn", rh.PROF_OBSERVE: "k_observe"}
+    units = {rh.PROF_BUCKET_KEYS: (B, "lane"), rh.PROF_BUCKET_ROLLOUT: (slots, "slot"), rh.PROF_BUCKET_LEARN: (max(live_slots, 1), "live slot")}
     for k, p in prof.items():
         e = dict(p)
         e["single_kernel"] = k in (rh.PROF_BUCKET_KEYS, rh.PROF_BUCKET_ROLLOUT, rh.PROF_BUCKET_LEARN, rh.PROF_OBSERVE, rh.PROF_MLP, rh.PROF_MLP_BWD)
         if k in model:
             bound, nbytes, how = model[k]
-            gbs = nbytes / (p["avg_launch_us"] * 1e-6) / 1e9
-            e.update(bound=bound, algorithmic_bytes_per_launch=nbytes, achieved=gbs, peak=HBM_PEAK_GBS, unit="GB/s", frac=gbs / HBM_PEAK_GBS, bytes_model=how)
+            sec = p["avg_launch_us"] * 1e-6
+            gbs = nbytes / sec / 1e9
+            hbm = dict(bound="hbm", algorithmic_bytes_per_launch=nbytes, achieved=gbs, peak=HBM_PEAK_GBS, unit="GB/s", frac=gbs / HBM_PEAK_GBS, bytes_model=how)
+            c = pmc.get(pmc_name.get(k, ""), {})
+            hbm["traffic"] = c.get("traffic_bytes_per_launch")
+            if k in units and c.get("SQ_INSTS_VALU"):
+                # these kernels are bound by VALU issue, not by bandwidth: the roof that binds is the one reported,
+                # the HBM figure stays beside it.  Instructions per launch are the counters' (a property of the build and the workload,
+                # the file carries the build's source hash); the duration is this run's.
+                n_inst = c["SQ_INSTS_VALU"]
+                ginst = n_inst / sec / 1e9
+                e.update(bound="valu", achieved=ginst, peak=VALU_PEAK_GINST, unit="Gwave-inst/s", frac=ginst / VALU_PEAK_GINST,
+                         valu_wave_instructions_per_launch=n_inst,
+                         valu_instructions_per_unit={"per": units[k][1], "value": n_inst * 64 / units[k][0]},
+                         valu_busy_frac_from_SQ_ACTIVE_INST_VALU=(c["SQ_ACTIVE_INST_VALU"] * 4 / (SIMDS * sec * CLOCK_HZ) if c.get("SQ_ACTIVE_INST_VALU") else None),
+                         lds_wave_instructions_per_launch=c.get("SQ_INSTS_LDS"),
+                         roof_model=f"{SIMDS} SIMDs x {CLOCK_HZ / 1e9:g} GHz / 4 cycles per wave64 VALU instruction of this mix",
+                         traffic=hbm["traffic"], hbm=hbm, algorithmic_bytes_per_launch=nbytes, bytes_model=how)
+            else:
+                e.update(hbm)
         out[p["name"]] = e
     # the fused MLP kernels: flops the matrix cores execute per sample (first layer of a head: 2 K W; relu + second layer run on the
     # VALU; backward: recompute of both heads + dW0 over the augmented input padded to its MFMA tiles)
@@ -446,21 +543,17 @@ def roofline_of(k):
     if k is None:
         return None
     r = {"kernel": k["name"], "bound": k.get("bound"), "achieved": k.get("achieved"), "peak": k.get("peak"), "unit": k.get("unit"),
-         "frac": k.get("frac"), "traffic": None, "avg_launch_us": k["avg_launch_us"], "launches_per_step": k["launches_per_step"],
+         "frac": k.get("frac"), "traffic": k.get("traffic"), "avg_launch_us": k["avg_launch_us"], "launches_per_step": k["launches_per_step"],
          "bytes_per_launch": k.get("algorithmic_bytes_per_launch"), "bytes_model": k.get("bytes_model"),
          "share_of_step_us": k["us_per_step"],
          "measured": "hipEvents around each launch, eager leg of the same steps after the timed region (the timed steps replay a graph)"}
-    if k["name"] == "k_bucket_learn":
-        r["limiter"] = ("fp32 VALU, not HBM: ~280 vector instructions per slot (V-trace carries of both players, NeuRD advantage and gates, one "
-                        "IEEE division, 4 fixed-point conversions, 4 LDS atomics); DESIGN.md section 5 has the SQ counters")
-    path = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
-    if os.path.exists(path):
-        with open(path) as f:
-            pmc = json.load(f)
-        hit = pmc.get(k["name"]) or pmc.get(k["name"] + "_compact")
-        if hit:
-            r["traffic"] = hit["traffic_bytes_per_launch"]
-            r["traffic_source"] = hit["source"]
+    for extra in ("valu_wave_instructions_per_launch", "valu_instructions_per_unit", "valu_busy_frac_from_SQ_ACTIVE_INST_VALU",
+                  "lds_wave_instructions_per_launch", "roof_model", "hbm", "flops_model", "samples_per_step"):
+        if k.get(extra) is not None:
+            r[extra] = k[extra]
+    if r["traffic"] is not None or k.get("bound") == "valu":
+        r["counters_source"] = ("profiles/r03_pmc.json: separate rocprofv3 --pmc passes (FETCH_SIZE | WRITE_SIZE | SQ_*), traffic = 2 x FETCH_SIZE + "
+                                "WRITE_SIZE; used because its source_hash is this build's")
     return r
 
 
@@ -476,19 +569,17 @@ def k1_report(k1, A, args, B):
     traffic = k1_traffic(A, args)
     if traffic:
         out.update(counter_bytes_per_launch=traffic, frac_of_hbm_peak_from_counter_bytes=traffic / (us * 1e-6) / 1e9 / HBM_PEAK_GBS,
-                   note="counter bytes = 2 x FETCH_SIZE + WRITE_SIZE of a separate rocprofv3 --pmc pass (profiles/r02_k1_pmc.json); the "
+                   note="counter bytes = 2 x FETCH_SIZE + WRITE_SIZE of a separate rocprofv3 --pmc pass (profiles/r03_pmc.json); the "
                         "SURVEY model over-counts (node rows are L2 hits, the mask travels as 1 byte), so the fraction is taken from the counters")
     return out
 
 
 def k1_traffic(A, args):
-    """HBM bytes per K1 launch from the separate rocprofv3 PMC passes (profiles/r02_k1_pmc.json: FETCH_SIZE doubled per the
-    gfx950 correction + WRITE_SIZE), valid for the default workload only; None otherwise."""
-    path = os.path.join(ROOT, "profiles", "r02_k1_pmc.json")
-    if A != 3 or args.batch_log2 != 20 or args.gpus != 1 or args.obs_half or not os.path.exists(path):
+    """HBM bytes per K1 launch from the separate rocprofv3 PMC passes over tools/k1_pmc.py (FETCH_SIZE doubled per the gfx950
+    correction + WRITE_SIZE), valid for the default workload and for the build the counters were taken on; None otherwise."""
+    if A != 3 or args.batch_log2 != 20 or args.gpus != 1 or args.obs_half:
         return None
-    with open(path) as f:
-        return json.load(f)["traffic_bytes_per_launch"]
+    return pmc_counters().get("k_observe", {}).get("traffic_bytes_per_launch")
 
 
 def cpu_baseline(tree, args, T):

@@ -1342,7 +1342,8 @@ extern "C" int rnad_rollout_bucketed_compact(const rnad_tree_t *tree, int T_cap,
 // The dense buffers of a compact trajectory: slot (t, j) from indices[t, j] (and indices[t + 1, j] for the reward) alone.
 namespace {
 template <int A>
-__global__ __launch_bounds__(kThreads) void k_bucket_expand(int T, int64_t B, int64_t S, const int32_t *__restrict__ indices,
+__global__ __launch_bounds__(kThreads) void k_bucket_expand(const Trans *__restrict__ trans, int C, int T, int64_t B, int64_t S,
+                                                            const int32_t *__restrict__ indices,
                                                             const unsigned long long *__restrict__ acts,
                                                             const float *__restrict__ final_reward, const float *__restrict__ rec_,
                                                             const uint8_t *__restrict__ mask_tab, uint8_t *__restrict__ mbits,
@@ -1357,8 +1358,28 @@ __global__ __launch_bounds__(kThreads) void k_bucket_expand(int T, int64_t B, in
     mbits[i] = mask_tab[row];
 #pragma unroll
     for (int a = 0; a < A; ++a) policy[i * A + a] = rec_[row * kRowStride<A> + 3 * A + 3 + a];
-    actions[i] = state != 0 ? (int)(acts[j] >> (3 * t)) & 7 : 0;
-    rewards[i] = ((t & 1) && state != 0 && indices[i + B] == 0) ? final_reward[j] : 0.0f;
+    const int action = state != 0 ? (int)(acts[j] >> (3 * t)) & 7 : 0;
+    actions[i] = action;
+    float rew = 0.0f;  // row turns: torch.zeros (episode.py:101); absorbed slots: state 0 pays value 0
+    if ((t & 1) && state != 0) {
+        const int next = indices[i + B];
+        if (next == 0) {
+            rew = final_reward[j];
+        } else {
+            // rewards *= (indices == 0) (episode.py:120-121) keeps the sign of the payoff it zeroes: -0.0 under a negative value.  The
+            // outcome taken is the one that leads to `next` (child ids are unique).
+            const int prev = (int)(acts[j] >> (3 * (t - 1))) & 7;
+            const Trans *e = trans + (((int64_t)state * A + prev) * A + action) * C;
+            for (int c = 0; c < C; ++c) {
+                const Trans et = e[c];
+                if (et.next == next) {
+                    rew = et.value * 0.0f;
+                    break;
+                }
+            }
+        }
+    }
+    rewards[i] = rew;
 }
 }  // namespace
 
@@ -1369,7 +1390,7 @@ extern "C" int rnad_bucket_expand(const rnad_tree_t *tree, int T, int64_t B, con
                  "rnad_bucket_expand: null argument");
     RNAD_REQUIRE(T >= 1 && T <= kCompactSteps && B >= 1, "rnad_bucket_expand: bad shape");
     RNAD_DISPATCH_A(tree->A, hipLaunchKernelGGL((k_bucket_expand<kA>), dim3(blocks_for(B), (unsigned)T), dim3(kThreads), 0, (hipStream_t)stream,
-                                                T, B, tree->S, indices, (const unsigned long long *)acts, final_reward, records,
+                                                tree->trans, tree->C, T, B, tree->S, indices, (const unsigned long long *)acts, final_reward, records,
                                                 (const uint8_t *)tree->mask_tab, mask_bits, policy, actions, rewards));
     RNAD_HIP_OK(hipGetLastError());
     return 0;

@@ -159,16 +159,21 @@ class RNaD:
         self.nashconv_history = []  # (m, total_steps, nashconv)
 
     # ------------------------------------------------------------------ data-parallel helpers
+    def _dp(self):
+        """Data parallel over the default process group -- unless this trainer was told to stand alone (data_parallel = False:
+        bench.py's single-GPU reference leg inside an N-rank run)."""
+        return getattr(self, "data_parallel", True) and _dist_on()
+
     @property
     def _rank(self):
-        return dist.get_rank() if _dist_on() else 0
+        return dist.get_rank() if self._dp() else 0
 
     @property
     def _world(self):
-        return dist.get_world_size() if _dist_on() else 1
+        return dist.get_world_size() if self._dp() else 1
 
     def _sync_from_rank0(self, module):
-        if _dist_on():
+        if self._dp():
             for t in list(module.parameters()) + list(module.buffers()):
                 dist.broadcast(t.data, src=0)
 
@@ -180,7 +185,7 @@ class RNaD:
             return self._seed_override
         if getattr(self, "_seed_base", None) is None:
             s = torch.randint(0, 2**62, (1,), dtype=torch.int64)
-            if _dist_on():
+            if self._dp():
                 s = s.to(self.device)
                 dist.broadcast(s, src=0)
             self._seed_base, self._seed_count = int(s.item()), 0
@@ -219,14 +224,14 @@ class RNaD:
         return {"net": self.net, "net_target": self.net_target, "net_reg": self.net_reg, "net_reg_": self.net_reg_}
 
     def _barrier(self):
-        if _dist_on():
+        if self._dp():
             dist.barrier()
 
     def __initialize(self):
         logging.info("R-NaD run '%s' in %s", self.directory_name, self.directory)
         self._store = store = checkpoint.RunStore(self.directory)
         decision = [store.latest() if self._rank == 0 else None]
-        if _dist_on():
+        if self._dp():
             dist.broadcast_object_list(decision, src=0)
         resume_from = decision[0]
         if resume_from is None:
@@ -356,7 +361,9 @@ class RNaD:
             return False
         if getattr(self, "tabular_gate", 8) * self.tree.handle().S > T * B:
             return False
-        if mode is True and B > 2**21:  # the fixed-point row sums take at most 2^21 lanes per call
+        # the per-row sums are fixed point with headroom for one addend per lane: 2^22 lanes per call in the bucketed learner
+        # (csrc/bucket.hip kLaneBits), 2^21 in the round-1 global-atomics kernel that non-bucketable trees fall back to
+        if mode is True and (B > rnad_hip.BUCKET_MAX_LANES or (B > 2**21 and rnad_hip.bucket_plan(self.tree.handle(), B) is None)):
             return "forward"
         return mode
 
@@ -469,7 +476,7 @@ class RNaD:
         # issued first and overlaps the MLP forwards below (RCCL runs it on its own stream).
         norm = episodes.valid_counts
         norm_work = None
-        if _dist_on():
+        if self._dp():
             norm = norm.clone()  # the all-reduce is in place, and the episodes keep their own count
             norm_work = dist.all_reduce(norm, async_op=True)
 
@@ -493,6 +500,8 @@ class RNaD:
             table = tables["table"]
         per_row_backward = table is not None and mode is True
         bucketed = per_row_backward and getattr(episodes, "buckets", None) is not None
+        if per_row_backward and not bucketed and B > 2**21:
+            per_row_backward = False  # a batch that is not bucket-ordered (a replay sample) beyond the atomics kernel's 2^21 lanes: per-slot backward
         live = None
         if (not per_row_backward and getattr(self, "skip_absorbed", True) and log is None and fused_mlp
                 and not self.tree.handle().uniform_length):
@@ -588,7 +597,7 @@ class RNaD:
         else:
             torch.autograd.backward([logit, v], [dlogit.view(-1, A), dv.view(-1, 1)])
 
-        if _dist_on():
+        if self._dp():
             if flat is not None:
                 dist.all_reduce(flat)  # one 43 KB bucket over RCCL, in place: the .grad tensors are views of it
             else:
@@ -755,7 +764,7 @@ class RNaD:
     def _graph_eligible(self, buffer, log):
         if not getattr(self, "use_graph", True) or log is not None or self.reuse_actor_outputs:
             return False
-        if _dist_on() and (dist.get_backend() != "nccl" or os.environ.get("RNAD_GRAPH_DIST", "1") == "0"):
+        if self._dp() and (dist.get_backend() != "nccl" or os.environ.get("RNAD_GRAPH_DIST", "1") == "0"):
             return False  # RCCL collectives are captured with the step (torch's NCCL backend supports stream capture); gloo cannot be
         dev = self.device if isinstance(self.device, torch.device) else torch.device(self.device)
         if dev.type != "cuda" or self.buffer_mod != 1 or buffer.max_size != 1:
@@ -808,7 +817,7 @@ class RNaD:
                 why = "the rollout of this step is not the native bucketed one"
             except Exception as err:  # capture is an optimisation: fall back to eager steps, loudly
                 why = str(err)
-            if _dist_on():  # every rank replays, or none does (a rank replaying collectives the others enqueue eagerly would hang)
+            if self._dp():  # every rank replays, or none does (a rank replaying collectives the others enqueue eagerly would hang)
                 flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=self.device)
                 dist.all_reduce(flag, op=dist.ReduceOp.MIN)
                 if ok and int(flag.item()) == 0:
@@ -859,7 +868,7 @@ class RNaD:
                         import wandb
 
                         wandb.log({"nashconv": nashconv}, step=self.total_steps)
-                if _dist_on():
+                if self._dp():
                     dist.barrier()
 
             while self.n < delta_m:

@@ -651,6 +651,7 @@ def rollout_bucketed(tree, traj, table, value_table=None, seed=0, lane0=0, table
 
 
 COMPACT_MAX_STEPS = 21  # 3 bits of action per step in one 64-bit word (csrc/bucket.hip kCompactSteps)
+BUCKET_MAX_LANES = 1 << 22  # lanes per call of the bucketed pipeline (csrc/bucket.hip kLaneBits: fixed-point headroom of the row sums)
 
 
 def rollout_bucketed_compact(tree, traj, table, seed=0, lane0=0, step_params=None, table_is_policy=True, column=None, visited=None):
@@ -854,6 +855,24 @@ def tree_generate(A, Cc, depth_bound, transition_threshold=0.0, terminal_values=
 # --------------------------------------------------------------------------------------- profiling hooks
 PROF_OBSERVE, PROF_ACT, PROF_LEARN, PROF_MLP, PROF_MLP_BWD = 0, 1, 2, 3, 4
 PROF_BUCKET_KEYS, PROF_BUCKET_SORT, PROF_BUCKET_ROLLOUT, PROF_BUCKET_LEARN, PROF_BUCKET_FINISH = 5, 6, 7, 8, 9
+
+
+def source_hash():
+    """sha256 (first 16 hex digits) over the sources librnad_hip.so is built from (csrc/*.hip, *.hpp, *.cpp, Makefile, include/*.h):
+    what a measurement that is kept in a file (rocprofv3 counter passes, profiles/) names as the build it was taken on."""
+    import glob
+    import hashlib
+
+    csrc = os.path.join(_HERE, "..", "csrc")
+    inc = os.path.join(_HERE, "..", "..", "include")
+    files = sorted(glob.glob(os.path.join(csrc, "*.hip")) + glob.glob(os.path.join(csrc, "*.hpp")) + glob.glob(os.path.join(csrc, "*.cpp"))
+                   + [os.path.join(csrc, "Makefile")] + glob.glob(os.path.join(inc, "*.h")))
+    h = hashlib.sha256()
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
 
 
 def prof_enable(on):

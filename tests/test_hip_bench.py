@@ -31,7 +31,7 @@ def test_one_gpu_line_has_the_contract_fields():
     assert j["n_gpus"] == 1 and j["steps"] == 40 and j["warmup"] == 3 and j["value"] > 0 and j["unit"] == "env-steps/s"
     assert j["net_evaluation"]["step_replayed_from_hipGraph"] is True
     roof = j["roofline"]
-    assert roof["bound"] in ("hbm", "mfma") and roof["unit"] in ("GB/s", "TFLOP/s") and 0 < roof["frac"] < 1
+    assert roof["bound"] in ("hbm", "mfma", "valu") and roof["unit"] in ("GB/s", "TFLOP/s", "Gwave-inst/s") and 0 < roof["frac"] < 1
     assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-9
     cpu = j["cpu_baseline"]
     assert cpu["kind"] == "port" and cpu["value"] > 0 and cpu["cores"] >= 1 and cpu["sample"]
@@ -53,4 +53,34 @@ def test_two_rank_control_flow(scaling):
     assert j["n_gpus"] == 2 and j["scaling"] == scaling and j["config"]["global_batch"] == 2 * j["config"]["per_gpu_batch"]
     assert j["config"]["global_batch"] == ((2 << 14) if scaling == "weak" else (1 << 14))
     assert j["value"] > 0 and "eager" in j["legs_ms_per_step"] and "cpu_baseline" not in j
+    assert j["collectives"]["ranks"] == 2 and j["collectives"]["backend"] == "gloo" and j["collectives"]["rccl_ranks"] is None
+    if scaling == "strong":  # rank 0 also timed the same global batch alone: the N = 1 point of the curve
+        base = j["strong_scaling"]["base"]
+        assert base["global_batch"] == 1 << 14 and base["ms_per_step"] > 0 and j["strong_scaling"]["speedup_vs_one_gpu_same_batch"] > 0
+    else:
+        assert "strong_scaling" not in j
     assert abs(j["value"] - j["config"]["global_batch"] * j["config"]["T"] / (j["ms_per_step"] * 1e-3)) < 1e-6 * j["value"]
+
+
+@pytest.mark.timeout(1500)
+def test_eight_ranks_with_no_other_flags_run_configs_2():
+    """`bench.py --gpus 8` as the driver launches it: BASELINE.json configs[2] -- one 2^22 batch, 2^19 lanes per rank, strong scaling --
+    rehearsed with the eight ranks sharing this box's GPU over gloo.  Rank 0's stand-alone leg is the 2^22 batch on ONE GPU in the
+    default mode (the N = 1 point of that curve)."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, RNAD_BENCH_REHEARSAL="1", HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="2")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "20", "--warmup", "2", "--other-steps", "2"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=1400, env=env)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    j = _json_line(r.stdout)
+    cfg = j["config"]
+    assert j["n_gpus"] == 8 and j["scaling"] == "strong" and "configs[2]" in cfg["workload"]
+    assert cfg["global_batch"] == 1 << 22 and cfg["per_gpu_batch"] == 1 << 19 and cfg["T"] == 12
+    assert j["net_evaluation"]["in_effect"] == "True" and j["collectives"]["ranks"] == 8
+    base = j["strong_scaling"]["base"]
+    assert base["global_batch"] == 1 << 22 and base["net_mode_in_effect"] == "True" and base["step_replayed_from_hipGraph"] is True
+    assert base["ms_per_step"] > 0 and j["value"] > 0
+    assert abs(j["value"] - cfg["global_batch"] * cfg["T"] / (j["ms_per_step"] * 1e-3)) < 1e-6 * j["value"]

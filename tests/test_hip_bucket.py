@@ -29,21 +29,9 @@ TREES = {
 
 
 def _keys_of(tree, B, idx, last):
-    """Bucket of every lane from its recorded states: the first state on its path that lies in a group, or -- if it leaves the tree
-    before reaching one -- the terminal bucket of its last (upper) state.  idx [T, B] states at the start of each step, last [B]."""
-    import rnad_hip
+    import _gpu
 
-    bucket_of, n_groups = rnad_hip.bucket_map(tree.handle(), B)
-    bucket_of = bucket_of.numpy().astype(np.int64)
-    states = np.concatenate([idx, last[None]], 0)
-    key = bucket_of[states[0]]
-    done = key < n_groups
-    for t in range(1, states.shape[0]):
-        st = states[t]
-        upd = (~done) & (st != 0)
-        key = np.where(upd, bucket_of[st], key)
-        done |= key < n_groups
-    return key, n_groups
+    return _gpu.bucket_keys(tree, B, idx, last)
 
 
 @pytest.mark.parametrize("name", sorted(TREES))
@@ -168,35 +156,16 @@ def test_value_gradient_beyond_the_fixed_point_range_poisons_the_tables():
 def _bucketize(G, tree, ep):
     """Host-side bucketisation of an episode batch that was NOT produced by rnad_rollout_bucketed (the reference's recorded
     episodes): the same stable sort and work list, built with numpy, so that rnad_learn_bucketed can be fed the reference's data."""
-    import rnad_hip
-
-    h = tree.handle()
     B = ep.batch_size
-    plan = rnad_hip.bucket_plan(h, B)
-    assert plan is not None
-    idx = ep.indices.cpu().numpy()
-    key, _ = _keys_of(tree, B, idx, np.zeros(B, idx.dtype))
-    perm = np.argsort(key, kind="stable")
+    perm, items = G.bucket_order(tree, B, ep.indices.cpu().numpy())
     out = type(ep)(tree, B, seed=0)
     out.t_eff, out.finished = ep.t_eff, True
     sel = torch.as_tensor(perm, device=DEV)
     for k in ("indices", "observations", "mask_bits", "policy", "action_idx", "rewards", "values"):
         setattr(out, k, getattr(ep, k)[:, sel].contiguous())
     out.alive = ep.alive
-    items = []
-    sk = key[perm]
-    start = 0
-    while start < B:
-        n = int((sk == sk[start]).sum())
-        chunks = (n + 255) // 256
-        for c in range(chunks):
-            items.append((start + c * 256, min(256, n - c * 256), int(sk[start]), int(chunks == 1)))
-        start += n
-    b = rnad_hip.Buckets(plan, DEV)
-    b.lane_ids.copy_(sel.to(torch.int32))
-    b.items[: len(items)] = torch.as_tensor(items, dtype=torch.int32, device=DEV)
-    b.n_items.fill_(len(items))
-    out.buckets, out.lane_ids = b, b.lane_ids
+    out.buckets = G.buckets_of(tree, B, perm, items)
+    out.lane_ids = out.buckets.lane_ids
     return out
 
 
@@ -307,7 +276,8 @@ def test_compact_trajectory_is_the_dense_one(name, B):
     assert torch.isfinite(got[0]).all() and float(got[0].abs().sum()) > 0
     # the dense fields on demand
     live = dense.indices != 0
-    assert torch.equal(comp.policy, dense.policy) and torch.equal(comp.mask_bits, dense.mask_bits) and torch.equal(comp.rewards, dense.rewards)
+    assert torch.equal(comp.policy, dense.policy) and torch.equal(comp.mask_bits, dense.mask_bits)
+    assert torch.equal(comp.rewards.view(torch.int32), dense.rewards.view(torch.int32)), "rewards bit for bit: -0.0 where a negative payoff is zeroed"
     assert torch.equal(comp.action_idx[live], dense.action_idx[live]) and (comp.action_idx[~live] == 0).all()
     assert torch.equal(comp.masks, dense.masks) and torch.equal(comp.observations, dense.observations)
     assert torch.equal(comp.actions[live], dense.actions[live])

@@ -14,12 +14,16 @@ def _arrays(tree):
                 expected_value=tree.expected_value_tensor.cpu().numpy(), legal=tree.legal_tensor.cpu().numpy())
 
 
-def _check_lanes_against_oracle(ep, arrs, lanes, seed, C, half=False):
-    """Given the policy bits the GPU produced and the seeded noise, every recorded step of `lanes` must be what the oracle computes."""
+def _check_lanes_against_oracle(ep, arrs, lanes, seed, C, half=False, lane_ids=None):
+    """Given the policy bits the GPU produced and the seeded noise, every recorded step of `lanes` must be what the oracle computes.
+    lane_ids (bucket-ordered batches): `lanes` are COLUMNS of the buffers, column j holds lane lane_ids[j] -- the id its noise is keyed by."""
     from oracle import oracle
 
     T = ep.t_eff + 1
     lanes_t = torch.as_tensor(lanes, device=ep.indices.device)
+    columns = lanes
+    if lane_ids is not None:
+        lanes = lane_ids[lanes_t].cpu().numpy()
     idx = ep.indices[:, lanes_t].cpu().numpy().astype(np.int64)
     act = ep.action_idx[:, lanes_t].cpu().numpy().astype(np.int64)
     pol = ep.policy[:, lanes_t].cpu().numpy()
@@ -27,12 +31,15 @@ def _check_lanes_against_oracle(ep, arrs, lanes, seed, C, half=False):
     rew = ep.rewards[:, lanes_t].cpu().numpy()
     nxt_last = ep.states.indices[lanes_t].cpu().numpy()
     A = pol.shape[-1]
-    n = len(lanes)
+    n = len(columns)
     for t in range(T):
         want_obs, want_mask = oracle.observe(arrs["expected_value"], arrs["legal"], idx[t], np.full(n, t & 1))
         assert_bits_equal(obs[t], want_obs.astype(np.float16) if half else want_obs, f"observe t={t}")
         noise = np.stack([oracle.noise(1, A, seed, int(b), t, 0)[0] for b in lanes])
-        np.testing.assert_array_equal(oracle.sample(pol[t], noise), act[t], err_msg=f"sample t={t}")
+        drawn = oracle.sample(pol[t], noise)
+        if lane_ids is not None:  # a compact batch stops drawing once a lane is absorbed (its slots show action 0; nothing reads them)
+            drawn = np.where(idx[t] != 0, drawn, 0)
+        np.testing.assert_array_equal(drawn, act[t], err_msg=f"sample t={t}")
         assert ((pol[t] > 0) == (want_mask > 0)).all()
         if t & 1:
             noise_c = np.stack([oracle.noise(1, C, seed, int(b), t, 1)[0] for b in lanes])
@@ -155,7 +162,7 @@ def test_c2_update_step_runs_and_is_finite(c2):
         np.testing.assert_allclose(pt.detach().cpu().numpy(), (0.001 * pn + 0.999 * p0).detach().cpu().numpy(), rtol=1e-5, atol=1e-7)
 
 
-def _modes_agree(tree, batch, tmp_path, obs_half=False, width=256):
+def _modes_agree(tree, batch, tmp_path, obs_half=False, width=256, modes=(False, "forward", True)):
     """One RNaD.train_step from the same weights and rollout seed in the three net-evaluation modes (eager, no graph): dense and
     "forward" give identical gradients; the default (per-row sums, bucketed rollout) gives them up to fp32 summation order."""
     import os
@@ -165,7 +172,7 @@ def _modes_agree(tree, batch, tmp_path, obs_half=False, width=256):
 
     os.environ["RNAD_SAVE_DIR"] = str(tmp_path)
     grads, losses = {}, {}
-    for mode in (False, "forward", True):
+    for mode in modes:
         torch.manual_seed(11)
         rn = RNaD(tree=tree, device=tree.device, directory_name=f"modes{mode}{int(obs_half)}", batch_size=batch, eta=0.2, b1_adam=0.0, lr=1e-3,
                   net_params={"type": "MLP", "max_actions": tree.max_actions, "width": width})
@@ -187,11 +194,91 @@ def _modes_agree(tree, batch, tmp_path, obs_half=False, width=256):
         assert all(torch.isfinite(p).all() for p in rn.net.parameters())
         del rn
         torch.cuda.empty_cache()
-    for a, b in zip(grads[False], grads["forward"]):
-        assert torch.equal(a, b)
-    for a, b in zip(grads[False], grads[True]):
+    if False in modes:
+        for a, b in zip(grads[False], grads["forward"]):
+            assert torch.equal(a, b)
+    for a, b in zip(grads["forward"], grads[True]):
         scale = a.abs().max().item() + 1e-12
         np.testing.assert_allclose(b.cpu().numpy(), a.cpu().numpy(), rtol=1e-4, atol=1e-5 * scale)
+
+
+def test_c2_tree_at_2_to_22_lanes_on_one_gpu_keeps_the_default_mode(c2, tmp_path):
+    """The single-GPU point of BASELINE.json configs[2] (one 2^22 batch): the bucketed learner takes 2^22 lanes per call, so the
+    default mode stays in effect (no fall-back to "forward" above 2^21) and gives the per-slot mode's gradients."""
+    import os
+
+    from environment.episode import Buffer
+    from learn.rnad import RNaD
+
+    tree, _, _ = c2
+    B = 1 << 22
+    os.environ["RNAD_SAVE_DIR"] = str(tmp_path)
+    probe = RNaD(tree=tree, device=tree.device, directory_name="probe22", batch_size=B, eta=0.2, b1_adam=0.0, lr=1e-3)
+    probe.initialize()
+    assert probe._tabular_mode(12, B) is True
+    buf = Buffer(1)
+    for i in range(5):  # three eager steps, the capture, one replay
+        probe.train_step(buf, alpha=0.5)
+        probe.total_steps += 1
+    torch.cuda.synchronize()
+    assert probe._graph["graph"] is not None and not probe._graph["failed"]
+    assert probe.last_episodes._compact is not None and probe.last_episodes.batch_size == B
+    assert probe.last_episodes.alive.tolist() == [B] * 12 + [0]
+    assert all(torch.isfinite(p).all() for p in probe.net.parameters())
+    del probe, buf
+    torch.cuda.empty_cache()
+    _modes_agree(tree, B, tmp_path, modes=("forward", True))
+
+
+def test_c2_fp32_update_modes_agree_full_size(c2, tmp_path):
+    """configs[1] at its full size in fp32: the default step (compact bucketed rollout, k_bucket_learn, one backward over the rows)
+    against the dense and "forward" modes from the same weights and rollout seed."""
+    tree, _, _ = c2
+    _modes_agree(tree, 1 << 20, tmp_path)
+
+
+def _compact_rollout_is_the_lane_ordered_one(tree, net, ep, seed, C, rng_seed):
+    """The rollout the default step runs (k_bucket_keys -> sort -> k_bucket_rollout_compact, acting on the pi columns of the row
+    records) at 2^20 lanes: the same episodes as the lane-ordered rollout `ep`, column j holding lane lane_ids[j]; its expanded
+    fields (rnad_bucket_expand) against the oracle on sampled columns."""
+    import rnad_hip
+    from environment.episode import Episodes
+
+    h, A, B = tree.handle(), tree.max_actions, ep.batch_size
+    assert rnad_hip.bucket_plan(h, B) is not None
+    with torch.no_grad():
+        logit, v = rnad_hip.mlp_forward(net.pack(), net.width, h.observations_table(), A)
+    hp = rnad_hip.make_learn_params(alpha=0.5, eta=0.2)
+    rec, fast = rnad_hip.bucket_records(h, logit, v, v, logit, logit, hp, fast=True)
+    comp = Episodes(tree, B, seed=seed)
+    comp.generate(net, tabular=True, bucketed=True, store_values=False, policy_table=(rec, rnad_hip.policy_column(A)), compact=True)
+    assert comp._compact is not None and comp._compact[0].policy is None and comp.t_eff == ep.t_eff
+    perm = comp.lane_ids.long()
+    assert torch.equal(torch.sort(perm).values, torch.arange(B, device=perm.device))
+    assert torch.equal(comp.indices, ep.indices[:, perm]) and torch.equal(comp.alive, ep.alive)
+    assert torch.equal(comp.states.indices, ep.states.indices[perm])
+    live = comp.indices != 0
+    # the dense fields, written by rnad_bucket_expand on first access
+    assert torch.equal(comp.policy, ep.policy[:, perm]) and torch.equal(comp.rewards, ep.rewards[:, perm])
+    assert torch.equal(comp.mask_bits, ep.mask_bits[:, perm])
+    assert torch.equal(comp.action_idx[live], ep.action_idx[:, perm][live]) and (comp.action_idx[~live] == 0).all()
+    cols = np.random.default_rng(rng_seed).choice(B, size=2048, replace=False)
+    cols[:3] = (0, B - 1, B // 2)
+    _check_lanes_against_oracle(comp, _arrays(tree), cols, seed=seed, C=C, lane_ids=comp.lane_ids)
+    return comp, rec, fast, hp
+
+
+def test_c2_compact_bucketed_rollout_full_size(c2):
+    tree, net, ep = c2
+    comp, rec, fast, hp = _compact_rollout_is_the_lane_ordered_one(tree, net, ep, seed=99, C=1, rng_seed=7)
+    # ... and the learner on it: the compact variant's tables are the dense-record variant's, bit for bit, at 12.6 M slots
+    import rnad_hip
+
+    h, T = tree.handle(), comp.t_eff + 1
+    got = rnad_hip.learn_bucketed_compact(h, comp.buckets, comp._compact[0], T, rec, fast, comp.valid_counts, hp)
+    want = rnad_hip.learn_bucketed(h, comp.buckets, comp.indices, comp.action_idx, comp.rewards, comp.policy, rec, comp.valid_counts, hp)
+    assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1])
+    assert torch.isfinite(got[0]).all() and float(got[0].abs().sum()) > 0
 
 
 def test_c2_fp16_observations_full_size(c2, tmp_path):
@@ -266,6 +353,13 @@ def test_c4_full_size_rollout(c4):
         for key in ("indices", "action_idx", "rewards", "mask_bits", "policy"):
             assert torch.equal(getattr(buc, key), getattr(ep, key)[:, perm]), key
         assert torch.equal(buc.alive, ep.alive)
+
+
+def test_c4_compact_bucketed_rollout_full_size(c4):
+    tree, net, ep = c4
+    if __import__("rnad_hip").bucket_plan(tree.handle(), 1 << 20) is None:
+        pytest.skip("this tree cannot be bucketed")
+    _compact_rollout_is_the_lane_ordered_one(tree, net, ep, seed=41, C=4, rng_seed=8)
 
 
 def test_c4_full_size_learner_is_lane_independent(c4):

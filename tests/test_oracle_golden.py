@@ -182,3 +182,41 @@ def test_nashconv_reference_test_semantics():
                                            tree["solution"][1], zeros)
         assert rb[1] + cb[1] == 0
         assert reach.sum() == 2
+
+
+@pytest.mark.parametrize("name", TREES)
+def test_on_policy_step_losses(name):
+    """tests/golden/onpolicy_*.npz (make_onpolicy.py): the learner net plays the batch it then learns from.  The oracle's
+    composition -- observe -> MLP x4 -> policy heads -> process_policy -> v_trace x2 -> losses -- reproduces the recorded acting
+    policy (actor == learner) and the reference's two losses."""
+    tree, g = load_tree(name), load("onpolicy_" + name)
+    A = tree["index"].shape[-1]
+    idx, masks = g["indices"], g["masks"]
+    T, B = idx.shape
+    turns = np.broadcast_to((np.arange(T) % 2)[:, None], (T, B)).astype(np.int64)
+    obs = np.stack([oracle.observe(tree["expected_value"], tree["legal"], idx[t], turns[t])[0] for t in range(T)])
+    out = {}
+    for tag in ("net", "target", "reg", "reg_"):
+        lg, v = oracle.mlp_forward(mlp_weights(g, f"w_{tag}_"), obs.reshape((T * B,) + obs.shape[2:]), A)
+        out[tag] = (lg.reshape(T, B, A), v.reshape(T, B, 1))
+    pi, log_pi = oracle.policy_head(out["net"][0], masks)
+    live = idx != 0
+    np.testing.assert_allclose(pi[live], g["policy"][live], rtol=TOL, atol=1e-7)  # on-policy: mu is the learner's pi
+    _, log_r = oracle.policy_head(out["reg"][0], masks)
+    _, log_r_ = oracle.policy_head(out["reg_"][0], masks)
+    alpha = float(g["alpha"])
+    lpol = log_pi - (np.float32(alpha) * log_r + np.float32(1 - alpha) * log_r_)
+    pip = oracle.process_policy(pi, masks, 32, 0.03)
+    valid = live.astype(np.float32)
+    a_oh = np.eye(A, dtype=np.float32)[g["actions"]]
+    hp = dict(eta=float(g["eta"]), lambda_=1.0, c=float(g.get("hp_c_bar", 1.0)), rho=float(g.get("hp_roh_bar", 1.0)),
+              gamma=float(g.get("hp_vtrace_gamma", 1.0)))
+    vt, has, q = [], [], []
+    for p in range(2):
+        rew = g["rewards"] if p == 0 else -g["rewards"]
+        a, b, c = oracle.vtrace(out["target"][1], valid, turns, g["policy"], pip, lpol, a_oh, rew, p, **hp)
+        vt.append(a), has.append(b), q.append(c)
+    lv, _ = oracle.loss_v(out["net"][1], vt[0], vt[1], has[0], has[1])
+    ln, _ = oracle.loss_nerd(out["net"][0], pip, q[0], q[1], valid, turns, masks, float(g.get("hp_neurd_clip", 1e3)), float(g.get("hp_beta", 2.0)))
+    np.testing.assert_allclose(lv, g["loss_v"], rtol=1e-4)
+    np.testing.assert_allclose(ln, g["loss_nerd"], rtol=1e-3, atol=1e-6)

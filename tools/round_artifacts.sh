@@ -1,30 +1,36 @@
 #!/bin/bash
 # Everything the round's measurement row is judged on, from the CURRENT build, on the GPU box:  tools/round_artifacts.sh <tag>
 # Writes under gpurun_out/ (copy what should be kept into profiles/).
-tag=${1:-r02}
+tag=${1:-r03}
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd $R
 O=gpurun_out
-# 1. headline bench (default flags) + the per-GPU share of an 8-GPU run + configs[3] + fp16 observations
-python bench.py > $O/${tag}_bench.log 2>&1; grep '^{' $O/${tag}_bench.log | tail -1 > $O/${tag}_bench.json.log
-python bench.py --batch-log2 17 --no-cpu-baseline > $O/${tag}_bench_b17.log 2>&1; grep '^{' $O/${tag}_bench_b17.log | tail -1 > $O/${tag}_bench_b17.json.log
-python bench.py --actions 5 --transitions 4 --depth 8 --prune 7 8 --threshold 0.1 --steps 200 --no-cpu-baseline > $O/${tag}_bench_c4.log 2>&1; grep '^{' $O/${tag}_bench_c4.log | tail -1 > $O/${tag}_bench_c4.json.log
-python bench.py --obs-half --steps 500 --no-cpu-baseline > $O/${tag}_bench_half.log 2>&1; grep '^{' $O/${tag}_bench_half.log | tail -1 > $O/${tag}_bench_half.json.log
-# 2. rocprofv3 kernel trace of the same bench command
-bash tools/profile_bench.sh ${tag} --steps 300 > $O/${tag}_profile.log 2>&1
 # 3. HBM counters of the step's kernels (default mode, eager so that every launch is its own dispatch) and of K1
 K="k_bucket_learn|k_bucket_rollout|k_bucket_keys|k_bucket_scatter|k_bucket_finish|k_mlp"
 RNAD_NO_GRAPH=1 tools/pmc_run.sh ${tag}_fetch "FETCH_SIZE" "$K" -- python tools/step_probe.py --steps 20 --no-graph > /dev/null
 RNAD_NO_GRAPH=1 tools/pmc_run.sh ${tag}_write "WRITE_SIZE" "$K" -- python tools/step_probe.py --steps 20 --no-graph > /dev/null
-python tools/pmc_traffic.py $O/pmc_${tag}_fetch.csv $O/pmc_${tag}_write.csv $O/${tag}_pmc_traffic.json
 # 3b. what the learner / rollout / keys kernels are bound by: SQ issue counters (their own pass)
 RNAD_NO_GRAPH=1 tools/pmc_run.sh ${tag}_sq "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_LDS" "$K" -- python tools/step_probe.py --steps 20 --no-graph > /dev/null
 tools/pmc_run.sh ${tag}_k1_fetch "FETCH_SIZE" "k_observe|vectorized_elementwise_kernel" -- python tools/k1_pmc.py > /dev/null
 tools/pmc_run.sh ${tag}_k1_write "WRITE_SIZE" "k_observe|vectorized_elementwise_kernel" -- python tools/k1_pmc.py > /dev/null
 head -5 $O/pmc_${tag}_k1_fetch.csv $O/pmc_${tag}_k1_write.csv
+# 3c. the counter file bench.py's roofline reads (it carries the source hash of this build): written into profiles/ ON THE BOX so that the
+# bench lines below already use it, and into gpurun_out/ for the way back
+python tools/pmc_json.py $O/pmc_${tag}_fetch.csv $O/pmc_${tag}_write.csv $O/pmc_${tag}_sq.csv $O/r03_pmc.json $O/pmc_${tag}_k1_fetch.csv $O/pmc_${tag}_k1_write.csv
+cp $O/r03_pmc.json profiles/r03_pmc.json
+# 3d. MFMA pipe busy cycles of the MLP kernels
+RNAD_NO_GRAPH=1 tools/pmc_run.sh ${tag}_mfma "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU" "k_mlp" -- python tools/step_probe.py --steps 20 --no-graph > /dev/null
+# 1. headline bench (default flags) + the per-GPU share of an 8-GPU run + configs[3] + fp16 observations
+python bench.py > $O/${tag}_bench.log 2>&1; grep '^{' $O/${tag}_bench.log | tail -1 > $O/${tag}_bench.json.log
+python bench.py --batch-log2 19 --steps 1000 --no-cpu-baseline > $O/${tag}_bench_b19.log 2>&1; grep '^{' $O/${tag}_bench_b19.log | tail -1 > $O/${tag}_bench_b19.json.log
+python bench.py --batch-log2 22 --steps 500 --no-cpu-baseline > $O/${tag}_bench_b22.log 2>&1; grep '^{' $O/${tag}_bench_b22.log | tail -1 > $O/${tag}_bench_b22.json.log
+python bench.py --actions 5 --transitions 4 --depth 8 --prune 7 8 --threshold 0.1 --steps 200 --no-cpu-baseline > $O/${tag}_bench_c4.log 2>&1; grep '^{' $O/${tag}_bench_c4.log | tail -1 > $O/${tag}_bench_c4.json.log
+python bench.py --obs-half --steps 500 --no-cpu-baseline > $O/${tag}_bench_half.log 2>&1; grep '^{' $O/${tag}_bench_half.log | tail -1 > $O/${tag}_bench_half.json.log
+# 2. rocprofv3 kernel trace of the same bench command
+bash tools/profile_bench.sh ${tag} --steps 300 > $O/${tag}_profile.log 2>&1
 python - <<PY
 import json
-for n in ("", "_b17", "_c4", "_half"):
+for n in ("", "_b19", "_b22", "_c4", "_half"):
     try:
         j = json.load(open("$O/${tag}_bench%s.json.log" % n))
         print(n or "default", "ms/step %.4f" % j["ms_per_step"], "value %.3e" % j["value"], "graph", j["net_evaluation"]["step_replayed_from_hipGraph"],
