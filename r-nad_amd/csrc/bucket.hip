@@ -785,13 +785,21 @@ __device__ __forceinline__ void fast_slot(const float *__restrict__ f, const flo
     for (int a = 0; a < A; ++a) {
         float adv = q[a] - base;
         ovf |= adv != adv;  // (a NaN advantage reaches the gradient in the reference; here it sets the flag that poisons the tables)
+#ifdef RNAD_NO_OPT_MED3
         adv = __builtin_amdgcn_fmed3f(adv, -hp.clip, hp.clip);  // torch.clamp(adv, -clip, clip) of a non-NaN
         const float fo = ((bits >> (8 + a)) & 1 ? fminf(adv, 0.0f) : 0.0f) + ((bits >> (16 + a)) & 1 ? fmaxf(adv, 0.0f) : 0.0f);
+#else
+        // torch.clamp(adv, -clip, clip) of a non-NaN, then apply_force_with_threshold (vtrace.py:362-366, :417):
+        //   [gate_lo] min(adv_c, 0) + [gate_hi] max(adv_c, 0)  ==  median(adv, gate_lo ? -clip : 0, gate_hi ? clip : 0)
+        // (one of the two terms is always a zero, so the sum is the other one exactly)
+        const float lo = (bits >> (8 + a)) & 1 ? -hp.clip : 0.0f, hi = (bits >> (16 + a)) & 1 ? hp.clip : 0.0f;
+        const float fo = __builtin_amdgcn_fmed3f(adv, lo, hi);
+#endif
         wv[a] = fo;  // legal * f: the gates of an illegal action are closed
         wsum += wv[a];
         if (LOSSES) nerd += (float)((bits >> a) & 1) * ((lg[a] - mean) * fo);
     }
-    const float share = wsum / (float)A;
+    const float share = div_by<A>(wsum);
     const float d = v - vt;
     if (LOSSES) {
         part[P] += (double)(d * d);
@@ -804,9 +812,13 @@ __device__ __forceinline__ void fast_slot(const float *__restrict__ f, const flo
 #pragma unroll
     for (int a = 0; a < A; ++a) {
         // |g| <= 2 clip < limit_l by construction here (adv is clamped and not NaN, or the flag is set): no range check -- unless the
-        // clip itself is beyond the fixed-point range (fx.check_l, a kernel argument: a scalar branch)
+        // clip itself is beyond the fixed-point range (fx.check_l)
         const float g = (bits >> a) & 1 ? wv[a] - share : 0.0f;
+#ifdef RNAD_NO_OPT_CHECK
         if (fx.check_l) ovf |= !(fabsf(g) < fx.limit_l);
+#else
+        if (LOSSES && fx.check_l) ovf |= !(fabsf(g) < fx.limit_l);  // (such updates are routed to the LOSSES instantiation)
+#endif
         out[a] = round_to_ll((double)(-g * fx.scale_l32));
     }
 }
@@ -1448,7 +1460,8 @@ int learn_bucketed_impl(const rnad_tree_t *tree, int T, int64_t B, const int32_t
     } while (0)
     {
         ProfScope one(PROF_BUCKET_LEARN, stream);
-        if (compact && losses) {
+        if (compact && (losses || fx.check_l)) {  // (the LOSSES instantiation also range-checks the dL/dlogit addends of a clip >= 2^29)
+            RNAD_REQUIRE(records, "rnad_learn_bucketed_compact: a NeuRD clip of 2^29 or more needs the dense records too");
             RNAD_DISPATCH_A(tree->A, RNAD_BUCKET_LEARN(true, true));
         } else if (compact) {
             RNAD_DISPATCH_A(tree->A, RNAD_BUCKET_LEARN(true, false));

@@ -420,6 +420,8 @@ class RNaD:
             return dict(table=table, logit=logit, v=None, logit_target=None, v_target=None, logit_reg=logit_reg, logit_reg_=logit_reg_,
                         packed_net=packed, packed_target=packed_target)
         with torch.no_grad():
+            # (one launch entry per (net, head) -- three equal work units per 64-row span -- was measured: 45.5 instead of 43.4 us, every
+            # workgroup loads its net's 43 KB weight image first)
             outs = rnad_hip.mlp_forward_multi([packed, packed_target], self.net.width, table, A,
                                               [(True, True), (want_target_logits, True)])
         logit_reg, logit_reg_ = self._reg_tables(table)
