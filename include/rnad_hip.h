@@ -375,6 +375,12 @@ int rnad_learn_fused_gather(const rnad_tree_t *tree, int T, int64_t B, const int
  * rnad_bucket_records / rnad_learn_bucketed_compact / rnad_bucket_finish with that row list (rows, n_rows: device memory, both NULL =
  * all rows; rows that are not listed are neither read nor written, and their accumulators are zero) -> rnad_mlp_backward_rows.
  *
+ * alive == NULL in rnad_rollout_bucketed_compact: the per-workgroup alive counts stay un-summed in `scratch` (one launch less); either
+ * the learner adds them up -- rnad_learn_bucketed_compact(..., rollout_scratch = that scratch, rollout_T_cap, alive, norm_out), whose first
+ * T_cap + 1 workgroups then write alive [T_cap + 1] and add N_P into norm_out (cleared by the rollout) before k_bucket_finish reads it --
+ * or rnad_bucket_alive does, on its own (a data-parallel caller that all-reduces N_P beside the learner kernel; anything that reads
+ * `alive` before the update).  rollout_scratch == NULL: nothing of this.
+ *
  * norm == NULL in rnad_learn_bucketed / rnad_learn_bucketed_compact: the sums stay in `accumulators` (losses, dlogit_tab, dv_tab are
  * not written) and rnad_bucket_finish completes the update -- so that a data-parallel caller's all-reduce of the normalisers
  * (learn/vtrace.py:373,388 are batch-global counts) runs beside the learner kernel instead of in front of it.
@@ -416,7 +422,8 @@ int rnad_learn_bucketed_compact(const rnad_tree_t *tree, int T, int64_t B, const
                                 const float *final_reward, const float *fast_records, const float *records, const int32_t *items,
                                 const int32_t *n_items, const double *norm, const rnad_learn_params_t *hp, void *accumulators,
                                 double *losses, float *dlogit_tab, float *dv_tab, const int32_t *rows, const int64_t *n_rows,
-                                void *stream);
+                                const void *rollout_scratch, int rollout_T_cap, int32_t *alive, double *norm_out, void *stream);
+int rnad_bucket_alive(const rnad_tree_t *tree, int T_cap, int64_t B, const void *scratch, int32_t *alive, double *norm, void *stream);
 int rnad_bucket_finish(const rnad_tree_t *tree, int64_t B, const double *norm, const rnad_learn_params_t *hp, void *accumulators,
                        double *losses, float *dlogit_tab, float *dv_tab, const int32_t *rows, const int64_t *n_rows, void *stream);
 
@@ -429,7 +436,10 @@ int rnad_clip_grad_norm(int64_t n, float *grads, float max_norm, float *total_no
  * no amsgrad, as constructed at rnad.py:232-237) and :516-523 (EMA target) for up to 8 parameter tensors whose gradients lie back to
  * back in one flat fp32 bucket `grads` (read only: the clipped values go straight into Adam).  sizes: HOST array of element counts; param / exp_avg / exp_avg_sq / step /
  * target: HOST arrays of device pointers (step: torch's per-tensor fp32 step counters on the device, incremented here; target may be
- * NULL: no EMA).  The state tensors are torch.optim.Adam's own, so checkpoints keep the reference format. */
+ * NULL: no EMA).  The state tensors are torch.optim.Adam's own, so checkpoints keep the reference format.
+ * mlp_A > 0 (with mlp_W, packed_param, packed_target; either image may be NULL): the 8 tensors are the fused MLP's Linear tensors in
+ * the order rnad_mlp_pack takes them, and every new weight / new target weight is ALSO written into its slot of that net's packed
+ * image (rnad_mlp_pack's layout) -- the images stay current without a pack launch per step.  mlp_A == 0: none of this. */
 typedef struct rnad_adam_params {
     float lr, beta1, beta2, eps;  /* rnad.py:232-237 */
     float max_norm;               /* grad_clip, rnad.py:456 */
@@ -437,7 +447,7 @@ typedef struct rnad_adam_params {
 } rnad_adam_params_t;
 int rnad_optimizer_step(int n_tensors, const int64_t *sizes, float *const *param, float *grads, float *const *exp_avg,
                         float *const *exp_avg_sq, float *const *step, float *const *target, const rnad_adam_params_t *hp,
-                        float *total_norm, void *stream);
+                        float *total_norm, int mlp_A, int mlp_W, float *packed_param, float *packed_target, void *stream);
 
 /* ------------------------------------------------------------------------------------------------
  * NashConv  --  util/metric.py:93-175 (NashConvData.get_nashconv), level-batched on the GPU

@@ -390,6 +390,91 @@ __global__ __launch_bounds__(kSortThreads) void k_bucket_hist(int64_t B, int n_b
 // sweep.  (Few rows per thread: the two sweeps are chains of dependent loads.)
 constexpr int kScanCols = 16, kScanParts = kSortThreads / kScanCols;
 
+struct Item {
+    int32_t begin, count, bucket, single;  // lanes [begin, begin + count) of that bucket; single: the bucket's only item
+};
+
+// bucket_start = exclusive prefix of the totals; one work item per `chunk` lanes of a non-empty bucket.  Two phases (every workgroup of
+// k_bucket_scatter runs the first for itself -- a launch of its own for it costs more than redoing a 1 000-entry prefix 256 times --,
+// workgroup 0 alone the second):
+// the prefixes (lanes and items) of all buckets, then the items.  While no bucket has more than kItemsInline items a thread writes
+// out the buckets it scanned; otherwise (most of the lanes end up in a few buckets once the policy sharpens: thousands of items in
+// one bucket) item k finds its bucket by bisection in the item prefix kept in LDS.
+constexpr int kItemsInline = 16;
+
+// start_s (LDS, [n_buckets]): receives bucket_start for the caller.  write_items: this workgroup also writes the work list.
+// first_s (LDS, [n_buckets + 1]): scratch, the first item of every bucket (exclusive prefix of the item counts).
+__device__ __forceinline__ void items_phase(int n_buckets, int chunk, const int32_t *__restrict__ totals, int32_t *__restrict__ start_s,
+                                            int32_t *__restrict__ first_s, bool write_items, Item *__restrict__ items,
+                                            int32_t *__restrict__ n_items) {
+    __shared__ int32_t wave_l[16], wave_i[16];
+    __shared__ int32_t carry_l, carry_i, most;
+    if (threadIdx.x == 0) carry_l = carry_i = most = 0;
+    __syncthreads();
+    for (int base = 0; base < n_buckets; base += kSortThreads) {
+        const int i = base + threadIdx.x;
+        const int32_t n = i < n_buckets ? totals[i] : 0;
+        const int32_t ni = (n + chunk - 1) / chunk;
+        int32_t sl = n, si = ni;  // inclusive scans within the wave
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int32_t a = __shfl_up(sl, off, 64), b = __shfl_up(si, off, 64);
+            if ((int)(threadIdx.x & 63) >= off) {
+                sl += a;
+                si += b;
+            }
+        }
+        if ((threadIdx.x & 63) == 63) {
+            wave_l[threadIdx.x >> 6] = sl;
+            wave_i[threadIdx.x >> 6] = si;
+        }
+        if (ni > kItemsInline) most = ni;  // (any writer: only "> kItemsInline" matters)
+        __syncthreads();
+        int32_t bl = carry_l, bi = carry_i;
+        for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) {
+            bl += wave_l[w];
+            bi += wave_i[w];
+        }
+        if (i < n_buckets) {
+            start_s[i] = bl + sl - n;
+            first_s[i] = bi + si - ni;
+        }
+        __syncthreads();
+        if (threadIdx.x == kSortThreads - 1) {
+            carry_l = bl + sl;
+            carry_i = bi + si;
+        }
+        __syncthreads();
+    }
+    const int32_t total = carry_i;
+    if (threadIdx.x == 0) {
+        first_s[n_buckets] = total;
+        if (write_items) *n_items = total;
+    }
+    __syncthreads();
+    if (!write_items) return;
+    if (most <= kItemsInline) {
+        for (int i = threadIdx.x; i < n_buckets; i += kSortThreads) {
+            const int32_t n = totals[i], first = first_s[i], ni = first_s[i + 1] - first, start = start_s[i];
+            for (int32_t j = 0; j < ni; ++j) items[first + j] = Item{start + j * chunk, min(chunk, n - j * chunk), i, ni == 1 ? 1 : 0};
+        }
+        return;
+    }
+    for (int32_t k = threadIdx.x; k < total; k += kSortThreads) {
+        int lo = 0, hi = n_buckets;  // the last bucket with first_s[bucket] <= k (empty buckets share their successor's prefix)
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (first_s[mid] <= k) lo = mid;
+            else hi = mid;
+        }
+        const int32_t n = totals[lo], j = k - first_s[lo], start = start_s[lo];
+        items[k] = Item{start + j * chunk, min(chunk, n - j * chunk), lo, n <= chunk ? 1 : 0};
+    }
+}
+
+// (The items were tried in this kernel's last workgroup, elected by a ticket: the device-scope release / acquire fences that the
+// election needs -- the workgroups sit on different XCDs -- write back whatever the previous kernels left dirty in the L2s:
+// 14.5 us against 5.2 + 5.6 for two launches.  They ride in k_bucket_scatter instead.)
 __global__ __launch_bounds__(kSortThreads) void k_bucket_scan(int n_blocks, int n_buckets, int32_t *__restrict__ hist,
                                                               int32_t *__restrict__ totals) {
     __shared__ int32_t part[kScanParts][kScanCols + 1];
@@ -421,94 +506,17 @@ __global__ __launch_bounds__(kSortThreads) void k_bucket_scan(int n_blocks, int 
     }
 }
 
-struct Item {
-    int32_t begin, count, bucket, single;  // lanes [begin, begin + count) of that bucket; single: the bucket's only item
-};
-
-// bucket_start = exclusive prefix of the totals; one work item per `chunk` lanes of a non-empty bucket.  One workgroup, two phases:
-// the prefixes (lanes and items) of all buckets, then the items.  While no bucket has more than kItemsInline items a thread writes
-// out the buckets it scanned; otherwise (most of the lanes end up in a few buckets once the policy sharpens: thousands of items in
-// one bucket) item k finds its bucket by bisection in the item prefix kept in LDS.
-constexpr int kItemsInline = 16;
-
-__global__ __launch_bounds__(kSortThreads) void k_bucket_items(int n_buckets, int chunk, const int32_t *__restrict__ totals,
-                                                               int32_t *__restrict__ bucket_start,
-                                                               Item *__restrict__ items, int32_t *__restrict__ n_items) {
-    __shared__ int32_t first_s[kMaxBuckets + 1];  // first item of every bucket (exclusive prefix of the item counts)
-    __shared__ int32_t wave_l[16], wave_i[16];
-    __shared__ int32_t carry_l, carry_i, most;
-    if (threadIdx.x == 0) carry_l = carry_i = most = 0;
-    __syncthreads();
-    for (int base = 0; base < n_buckets; base += kSortThreads) {
-        const int i = base + threadIdx.x;
-        const int32_t n = i < n_buckets ? totals[i] : 0;
-        const int32_t ni = (n + chunk - 1) / chunk;
-        int32_t sl = n, si = ni;  // inclusive scans within the wave
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const int32_t a = __shfl_up(sl, off, 64), b = __shfl_up(si, off, 64);
-            if ((int)(threadIdx.x & 63) >= off) {
-                sl += a;
-                si += b;
-            }
-        }
-        if ((threadIdx.x & 63) == 63) {
-            wave_l[threadIdx.x >> 6] = sl;
-            wave_i[threadIdx.x >> 6] = si;
-        }
-        if (ni > kItemsInline) most = ni;  // (any writer: only "> kItemsInline" matters)
-        __syncthreads();
-        int32_t bl = carry_l, bi = carry_i;
-        for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) {
-            bl += wave_l[w];
-            bi += wave_i[w];
-        }
-        if (i < n_buckets) {
-            bucket_start[i] = bl + sl - n;
-            first_s[i] = bi + si - ni;
-        }
-        __syncthreads();
-        if (threadIdx.x == kSortThreads - 1) {
-            carry_l = bl + sl;
-            carry_i = bi + si;
-        }
-        __syncthreads();
-    }
-    const int32_t total = carry_i;
-    if (threadIdx.x == 0) {
-        first_s[n_buckets] = total;
-        *n_items = total;
-    }
-    __syncthreads();  // (bucket_start was written by this workgroup: visible to it after the barrier)
-    if (most <= kItemsInline) {
-        for (int i = threadIdx.x; i < n_buckets; i += kSortThreads) {
-            const int32_t n = totals[i], first = first_s[i], ni = first_s[i + 1] - first, start = bucket_start[i];
-            for (int32_t j = 0; j < ni; ++j) items[first + j] = Item{start + j * chunk, min(chunk, n - j * chunk), i, ni == 1 ? 1 : 0};
-        }
-        return;
-    }
-    for (int32_t k = threadIdx.x; k < total; k += kSortThreads) {
-        int lo = 0, hi = n_buckets;  // the last bucket with first_s[bucket] <= k (empty buckets share their successor's prefix)
-        while (hi - lo > 1) {
-            const int mid = (lo + hi) >> 1;
-            if (first_s[mid] <= k) lo = mid;
-            else hi = mid;
-        }
-        const int32_t n = totals[lo], j = k - first_s[lo], start = bucket_start[lo];
-        items[k] = Item{start + j * chunk, min(chunk, n - j * chunk), lo, n <= chunk ? 1 : 0};
-    }
-}
-
 // lane_ids[bucket_start[key] + (lanes of earlier blocks with that key) + (earlier lanes of this block with that key)] = lane.
 // The waves of a workgroup take turns (each owns 256 consecutive lanes) and a wave's rows are issued in order, so the rank a lane
 // draws from the LDS counter does not depend on wave scheduling; within one LDS atomic instruction the lanes that hit the same
 // counter are served in lane order.  The permutation is therefore the stable counting sort, the same on every run.
+// bucket_start (the exclusive prefix of the column totals) is taken by every workgroup for itself; workgroup 0 also writes the
+// learner's work list (items_phase).
 __global__ __launch_bounds__(kSortThreads) void k_bucket_scatter(int64_t B, int n_buckets, const int32_t *__restrict__ keys,
-                                                                 const int32_t *__restrict__ hist, const int32_t *__restrict__ bucket_start,
+                                                                 const int32_t *__restrict__ hist, const int32_t *__restrict__ totals, int chunk,
+                                                                 Item *__restrict__ items, int32_t *__restrict__ n_items,
                                                                  int32_t *__restrict__ lane_ids) {
     extern __shared__ int32_t cnt[];
-    const int32_t *row = hist + (int64_t)blockIdx.x * n_buckets;
-    for (int i = threadIdx.x; i < n_buckets; i += kSortThreads) cnt[i] = bucket_start[i] + row[i];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int64_t base = (int64_t)blockIdx.x * kSortLanes + (int64_t)wave * (kSortLanes / 16);
     int32_t key[kSortLanes / kSortThreads];
@@ -517,6 +525,10 @@ __global__ __launch_bounds__(kSortThreads) void k_bucket_scatter(int64_t B, int 
         const int64_t b = base + r * 64 + lane;
         key[r] = b < B ? keys[b] : -1;
     }
+    items_phase(n_buckets, chunk, totals, cnt, cnt + n_buckets, blockIdx.x == 0, items, n_items);  // cnt = bucket_start
+    __syncthreads();
+    const int32_t *row = hist + (int64_t)blockIdx.x * n_buckets;
+    for (int i = threadIdx.x; i < n_buckets; i += kSortThreads) cnt[i] += row[i];
     __syncthreads();
     for (int turn = 0; turn < 16; ++turn) {
         if (turn == wave) {
@@ -701,10 +713,9 @@ __global__ __launch_bounds__(kThreads) void k_bucket_rollout_compact(const Trans
 }
 
 // alive[t] = sum over the blocks of alive_part[block][t]; norm[P] += alive[t] for the steps of parity P: the loss normalisers N_P
-// of learn/vtrace.py:373,388 (f64 sums of integers: exact in any order; zeroed by k_bucket_keys).  grid = T_cap + 1 workgroups.
-__global__ __launch_bounds__(kThreads) void k_bucket_alive(int n_blocks, int T1, const int32_t *__restrict__ alive_part,
-                                                           int32_t *__restrict__ alive, double *__restrict__ norm) {
-    const int t = blockIdx.x;
+// of learn/vtrace.py:373,388 (f64 sums of integers: exact in any order; zeroed by k_bucket_keys).  One workgroup per column t.
+__device__ __forceinline__ void alive_column(int n_blocks, int T1, int t, const int32_t *__restrict__ alive_part, int32_t *__restrict__ alive,
+                                             double *__restrict__ norm) {
     int32_t s = 0;
     for (int r = threadIdx.x; r < n_blocks; r += kThreads) s += alive_part[(int64_t)r * T1 + t];
 #pragma unroll
@@ -719,6 +730,11 @@ __global__ __launch_bounds__(kThreads) void k_bucket_alive(int n_blocks, int T1,
         alive[t] = x;
         if (norm && t < T1 - 1 && x != 0) atomicAdd(norm + (t & 1), (double)x);  // alive[T_cap]: after the last step, not a slot
     }
+}
+
+__global__ __launch_bounds__(kThreads) void k_bucket_alive(int n_blocks, int T1, const int32_t *__restrict__ alive_part,
+                                                           int32_t *__restrict__ alive, double *__restrict__ norm) {
+    alive_column(n_blocks, T1, blockIdx.x, alive_part, alive, norm);
 }
 
 // ---------------------------------------------------------------------------------------- 4. learner
@@ -849,13 +865,18 @@ __global__ __launch_bounds__(kThreads) void k_bucket_learn(int T, int64_t B, int
                                                            const float *__restrict__ reward_, const float *__restrict__ logit_,
                                                            rnad_learn_params_t hp, FixedPoint fx, unsigned long long *__restrict__ acc,
                                                            unsigned long long *__restrict__ rep, double *__restrict__ losses_raw,
-                                                           int32_t *__restrict__ overflow) {
+                                                           int32_t *__restrict__ overflow, const int32_t *__restrict__ alive_part,
+                                                           int alive_blocks, int T1, int32_t *__restrict__ alive,
+                                                           double *__restrict__ norm_out) {
     // [kMaxPath path rows][kPathSlots copies][(A + 1) | 1]  |  [sub_rows rows of player 0 | sub_rows rows of player 1][A + 1]
     extern __shared__ unsigned long long tab[];
     constexpr int PS = (A + 1) | 1;
     const int kPathWords = path_words;  // u64 words of the path region: max_path rows of the cut x kPathSlots copies
     __shared__ int32_t path_state[kMaxPath];
     __shared__ double loss_part[kThreads / 64][4];
+    // The rollout left its per-workgroup alive counts un-summed (rnad_rollout_bucketed_compact with alive == NULL): workgroup t < T1
+    // adds up column t first -- k_bucket_alive's work without its launch; the normalisers are read by k_bucket_finish, after this kernel.
+    if (alive_part && (int)blockIdx.x < T1) alive_column(alive_blocks, T1, blockIdx.x, alive_part, alive, norm_out);
     if ((int)blockIdx.x >= *n_items) return;
     const Item item = items[blockIdx.x];
     const int s_b = bucket_lo[item.bucket];        // first state id of the group (terminal buckets: the upper state; no rows below)
@@ -1285,10 +1306,11 @@ int rollout_bucketed_impl(const rnad_tree_t *tree, const RolloutBuffers &tr, boo
         ProfScope sort_passes(PROF_BUCKET_SORT, stream);
         hipLaunchKernelGGL(k_bucket_hist, dim3(p.sort_blocks), dim3(kSortThreads), lds, stream, B, nb, (const int32_t *)s.keys, s.hist);
         hipLaunchKernelGGL(k_bucket_scan, dim3((nb + kScanCols - 1) / kScanCols), dim3(kSortThreads), 0, stream, p.sort_blocks, nb, s.hist, s.totals);
-        hipLaunchKernelGGL(k_bucket_items, dim3(1), dim3(kSortThreads), 0, stream, nb, p.chunk, (const int32_t *)s.totals, s.bucket_start,
-                           (Item *)items, n_items);
-        hipLaunchKernelGGL(k_bucket_scatter, dim3(p.sort_blocks), dim3(kSortThreads), lds, stream, B, nb, (const int32_t *)s.keys,
-                           (const int32_t *)s.hist, (const int32_t *)s.bucket_start, lane_ids);
+        const size_t scatter_lds = (2 * (size_t)nb + 1) * sizeof(int32_t);  // bucket_start -> rank counters | first item of every bucket
+        if (scatter_lds > 48 * 1024)
+            RNAD_HIP_OK(hipFuncSetAttribute((const void *)k_bucket_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, (int)scatter_lds));
+        hipLaunchKernelGGL(k_bucket_scatter, dim3(p.sort_blocks), dim3(kSortThreads), scatter_lds, stream, B, nb, (const int32_t *)s.keys,
+                           (const int32_t *)s.hist, (const int32_t *)s.totals, p.chunk, (Item *)items, n_items, lane_ids);
     }
     RNAD_HIP_OK(hipGetLastError());
     const unsigned grid = blocks_for(B);
@@ -1311,12 +1333,25 @@ int rollout_bucketed_impl(const rnad_tree_t *tree, const RolloutBuffers &tr, boo
 #undef RNAD_BUCKET_ROLLOUT_COMPACT
 #undef RNAD_BUCKET_ROLLOUT
     }
-    hipLaunchKernelGGL(k_bucket_alive, dim3(tr.T_cap + 1), dim3(kThreads), 0, stream, (int)grid, tr.T_cap + 1, (const int32_t *)s.alive_part,
-                       tr.alive, norm);
+    if (tr.alive)  // (NULL: the caller lets rnad_learn_bucketed_compact add the counts up, or calls rnad_bucket_alive)
+        hipLaunchKernelGGL(k_bucket_alive, dim3(tr.T_cap + 1), dim3(kThreads), 0, stream, (int)grid, tr.T_cap + 1, (const int32_t *)s.alive_part,
+                           tr.alive, norm);
     RNAD_HIP_OK(hipGetLastError());
     return 0;
 }
 }  // namespace
+
+extern "C" int rnad_bucket_alive(const rnad_tree_t *tree, int T_cap, int64_t B, const void *scratch, int32_t *alive, double *norm, void *stream) {
+    RNAD_REQUIRE(tree && scratch && alive, "rnad_bucket_alive: null argument");
+    RNAD_REQUIRE(T_cap >= 1 && T_cap <= kMaxSteps && B >= 1, "rnad_bucket_alive: bad shape");
+    Plan p;
+    RNAD_REQUIRE(make_plan(tree, B, p), "rnad_bucket_alive: this tree / batch cannot be bucketed (see rnad_bucket_plan)");
+    const Scratch s = carve_scratch(const_cast<void *>(scratch), B, p);
+    hipLaunchKernelGGL(k_bucket_alive, dim3(T_cap + 1), dim3(kThreads), 0, (hipStream_t)stream, (int)blocks_for(B), T_cap + 1,
+                       (const int32_t *)s.alive_part, alive, norm);
+    RNAD_HIP_OK(hipGetLastError());
+    return 0;
+}
 
 extern "C" int rnad_rollout_bucketed(const rnad_tree_t *tree, const rnad_traj_t *tr, const float *table, int64_t table_stride,
                                      int table_is_policy, const float *value_table, int64_t value_stride, uint64_t seed, int64_t lane0,
@@ -1339,8 +1374,9 @@ extern "C" int rnad_rollout_bucketed_compact(const rnad_tree_t *tree, int T_cap,
                                              void *scratch, int32_t *lane_ids, int32_t *items, int32_t *n_items, double *norm,
                                              int32_t *indices, int32_t *alive, uint64_t *acts, float *final_reward, int32_t *visited,
                                              void *stream) {
-    RNAD_REQUIRE(tree && table && scratch && lane_ids && items && n_items && indices && alive && acts && final_reward,
+    RNAD_REQUIRE(tree && table && scratch && lane_ids && items && n_items && indices && acts && final_reward,
                  "rnad_rollout_bucketed_compact: null argument");
+    RNAD_REQUIRE(alive || norm, "rnad_rollout_bucketed_compact: deferred alive counts (alive == NULL) need `norm` (it is cleared here)");
     RNAD_REQUIRE(T_cap >= 1 && T_cap <= kCompactSteps && B >= 1, "rnad_rollout_bucketed_compact: 1 <= T_cap <= %d (3 bits per step), got %d",
                  kCompactSteps, T_cap);
     RNAD_REQUIRE(table_stride >= tree->A, "rnad_rollout_bucketed_compact: bad table stride");
@@ -1433,7 +1469,7 @@ int learn_bucketed_impl(const rnad_tree_t *tree, int T, int64_t B, const int32_t
                         const float *mu, const unsigned long long *acts, const float *final_reward, const float *records,
                         const float *fast, const int32_t *items, const int32_t *n_items, const double *norm, const rnad_learn_params_t *hp,
                         void *accumulators, double *losses, float *dlogit_tab, float *dv_tab, const int32_t *rows, const int64_t *n_rows,
-                        hipStream_t stream) {
+                        const void *rollout_scratch, int rollout_T_cap, int32_t *alive_out, double *norm_out, hipStream_t stream) {
     const bool compact = acts != nullptr;
     Plan p;
     RNAD_REQUIRE(make_plan(tree, B, p), "rnad_learn_bucketed: this tree / batch cannot be bucketed (see rnad_bucket_plan)");
@@ -1444,6 +1480,10 @@ int learn_bucketed_impl(const rnad_tree_t *tree, int T, int64_t B, const int32_t
     double *losses_raw = (double *)(rep + (int64_t)kReplicas * 2 * std::max(nu, 1) * A1);
     int32_t *overflow = (int32_t *)(losses_raw + 4);
     const FixedPoint fx = fixed_point_for(*hp);
+    const int32_t *alive_part = nullptr;
+    const int T1 = rollout_T_cap + 1;
+    if (rollout_scratch) alive_part = carve_scratch(const_cast<void *>(rollout_scratch), B, p).alive_part;
+    const unsigned learn_grid = (unsigned)std::max<int64_t>(p.max_items, alive_part ? T1 : 0);
     // (the loss sums and the overflow flag are zero here: k_bucket_finish of the previous update cleared them.  Not hipMemsetAsync:
     // the memset node of a captured graph was seen to write garbage after ~57 replays on ROCm 7.2,
     // tests/test_hip_graph.py::test_many_replays_stay_finite)
@@ -1452,11 +1492,11 @@ int learn_bucketed_impl(const rnad_tree_t *tree, int T, int64_t B, const int32_t
     do {                                                                                                                              \
         auto kern = k_bucket_learn<kA, COMPACT, LOSSES>;                                                                              \
         if (p.lds > 48 * 1024) RNAD_HIP_OK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, p.lds)); \
-        hipLaunchKernelGGL(kern, dim3((unsigned)p.max_items), dim3(kThreads), (size_t)p.lds, stream, T, B, S, p.cut->rows, p.path_words, \
+        hipLaunchKernelGGL(kern, dim3(learn_grid), dim3(kThreads), (size_t)p.lds, stream, T, B, S, p.cut->rows, p.path_words,         \
                            p.cut->n_groups, std::max(nu, 1), (const Item *)items, n_items, (const int32_t *)p.cut->bucket_of,         \
                            (const int32_t *)p.cut->bucket_lo, (const int32_t *)p.cut->bucket_path, indices, actions, rewards, mu,     \
                            compact ? fast : records, acts, final_reward, records, *hp, fx, acc, rep,                                  \
-                           losses ? losses_raw : (double *)nullptr, overflow);                                                        \
+                           losses ? losses_raw : (double *)nullptr, overflow, alive_part, (int)blocks_for(B), T1, alive_out, norm_out); \
     } while (0)
     {
         ProfScope one(PROF_BUCKET_LEARN, stream);
@@ -1493,15 +1533,18 @@ extern "C" int rnad_learn_bucketed(const rnad_tree_t *tree, int T, int64_t B, co
                  "rnad_learn_bucketed: null argument");
     RNAD_REQUIRE(T >= 1 && B >= 1, "rnad_learn_bucketed: bad shape");
     return learn_bucketed_impl(tree, T, B, indices, actions, rewards, mu, nullptr, nullptr, records, nullptr, items, n_items, norm, hp,
-                               accumulators, losses, dlogit_tab, dv_tab, nullptr, nullptr, (hipStream_t)stream);
+                               accumulators, losses, dlogit_tab, dv_tab, nullptr, nullptr, nullptr, 0, nullptr, nullptr, (hipStream_t)stream);
 }
 
 extern "C" int rnad_learn_bucketed_compact(const rnad_tree_t *tree, int T, int64_t B, const int32_t *indices, const uint64_t *acts,
                                            const float *final_reward, const float *fast_records, const float *records,
                                            const int32_t *items, const int32_t *n_items, const double *norm, const rnad_learn_params_t *hp,
                                            void *accumulators, double *losses, float *dlogit_tab, float *dv_tab, const int32_t *rows,
-                                           const int64_t *n_rows, void *stream) {
+                                           const int64_t *n_rows, const void *rollout_scratch, int rollout_T_cap, int32_t *alive,
+                                           double *norm_out, void *stream) {
     RNAD_REQUIRE(!rows == !n_rows, "rnad_learn_bucketed_compact: rows and n_rows go together");
+    RNAD_REQUIRE(!rollout_scratch || (alive && rollout_T_cap >= T && rollout_T_cap <= kCompactSteps),
+                 "rnad_learn_bucketed_compact: completing the rollout's alive counts needs `alive` and the rollout's T_cap");
     RNAD_REQUIRE(tree && indices && acts && final_reward && fast_records && items && n_items && hp && accumulators && dlogit_tab && dv_tab,
                  "rnad_learn_bucketed_compact: null argument");
     RNAD_REQUIRE(!losses || records, "rnad_learn_bucketed_compact: the losses need the dense records (logits)");
@@ -1509,5 +1552,5 @@ extern "C" int rnad_learn_bucketed_compact(const rnad_tree_t *tree, int T, int64
     RNAD_REQUIRE(T >= 1 && T <= kCompactSteps && B >= 1, "rnad_learn_bucketed_compact: bad shape");
     return learn_bucketed_impl(tree, T, B, indices, nullptr, nullptr, nullptr, (const unsigned long long *)acts, final_reward, records,
                                fast_records, items, n_items, norm, hp, accumulators, losses, dlogit_tab, dv_tab, rows, n_rows,
-                               (hipStream_t)stream);
+                               rollout_scratch, rollout_T_cap, alive, norm_out, (hipStream_t)stream);
 }

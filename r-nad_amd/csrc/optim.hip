@@ -8,7 +8,7 @@
 // EMA target = target * (1 - gamma) + gamma * param, two roundings like _foreach_mul_ + _foreach_add_(alpha).
 // The optimiser state lives in torch.optim.Adam's own tensors (exp_avg, exp_avg_sq, step), so checkpoints keep the reference format.
 // Citations are baskuit/R-NaD file:line.
-#include "common.hpp"
+#include "mlp_common.hpp"
 
 #include <cmath>
 
@@ -34,8 +34,32 @@ struct OptTensors {
 constexpr int kNormBatch = 8;
 __device__ unsigned int g_ticket = 0;  // one optimiser step at a time per device (one process per GPU, one training stream)
 
+// Where element e of Linear tensor k (MLP_KEYS order: value_fc0.weight, .bias, value_fc1.weight, .bias, policy_fc0.weight, ...) sits in
+// the packed LDS image the MLP kernels read (mlp_common.hpp; k_mlp_pack is the forward map).
+__device__ __forceinline__ int image_index(int k, int e, int A, int W) {
+    using namespace rnad_mlp;
+    const int K = 2 * A * A, KS = A * A;
+    switch (k) {
+        case 0:
+        case 4: {
+            const int h = e / K + (k == 4 ? W : 0), kk = e % K;
+            return (h / kTile) * (KS * 64) + (kk / 2) * 64 + (kk % 2) * 32 + (h % kTile);
+        }
+        case 1: return img_b0(K, W) + e;
+        case 5: return img_b0(K, W) + W + e;
+        case 2: return img_w1v(K, W) + e;
+        case 3: return img_b1(K, W, A);
+        case 6: return img_w1p(K, W) + e;
+        default: return img_b1(K, W, A) + 1 + e;
+    }
+}
+
+// mlp_A > 0: the n == 8 tensors are the Linear tensors of the fused MLP in MLP_KEYS order, and every updated weight (and EMA target
+// weight) is also written into its slot of the packed images packed_param / packed_target -- the images the next step's forward and
+// backward kernels read, kept current here instead of by a k_mlp_pack launch per step.
 __global__ __launch_bounds__(kOptThreads) void k_optimizer_step(OptTensors ts, const float *__restrict__ grads, rnad_adam_params_t hp,
-                                                                float *__restrict__ total_norm) {
+                                                                float *__restrict__ total_norm, int mlp_A, int mlp_W,
+                                                                float *__restrict__ packed_param, float *__restrict__ packed_target) {
     __shared__ double part[kOptThreads / 64];
     __shared__ float coef_s, step_size_s[kMaxTensors], bc2s_s[kMaxTensors];
     __shared__ float *ptr_s[4][kMaxTensors];
@@ -106,15 +130,29 @@ __global__ __launch_bounds__(kOptThreads) void k_optimizer_step(OptTensors ts, c
     const float denom = sqrtf(v_new) / bc2s_s[k] + hp.eps;
     const float p_new = p - step_size_s[k] * m_new / denom;
     *pp = p_new;
-    if (pt) *pt = tg * (1.0f - hp.ema) + hp.ema * p_new;
+    const float t_new = tg * (1.0f - hp.ema) + hp.ema * p_new;
+    if (pt) *pt = t_new;
+    if (mlp_A > 0) {
+        const int at = image_index(k, e, mlp_A, mlp_W);
+        if (packed_param) packed_param[at] = p_new;
+        if (packed_target && pt) packed_target[at] = t_new;
+    }
 }
 
 }  // namespace
 
 extern "C" int rnad_optimizer_step(int n_tensors, const int64_t *sizes, float *const *param, float *grads, float *const *exp_avg,
                                    float *const *exp_avg_sq, float *const *step, float *const *target, const rnad_adam_params_t *hp,
-                                   float *total_norm, void *stream) {
+                                   float *total_norm, int mlp_A, int mlp_W, float *packed_param, float *packed_target, void *stream) {
     RNAD_REQUIRE(sizes && param && grads && exp_avg && exp_avg_sq && step && hp, "rnad_optimizer_step: null argument");
+    if (mlp_A > 0) {
+        RNAD_REQUIRE(n_tensors == 8 && mlp_A <= RNAD_MAX_ACTIONS && mlp_W >= rnad_mlp::kTile && mlp_W % rnad_mlp::kTile == 0,
+                     "rnad_optimizer_step: packed images go with the 8 Linear tensors of the fused MLP (A=%d, width=%d)", mlp_A, mlp_W);
+        const int64_t K = 2 * (int64_t)mlp_A * mlp_A;
+        const int64_t want[8] = {mlp_W * K, mlp_W, mlp_W, 1, mlp_W * K, mlp_W, (int64_t)mlp_A * mlp_W, mlp_A};
+        for (int k = 0; k < 8; ++k) RNAD_REQUIRE(sizes[k] == want[k], "rnad_optimizer_step: tensor %d does not have the MLP's shape", k);
+        RNAD_REQUIRE(!packed_target || target, "rnad_optimizer_step: a packed target image needs the target tensors");
+    }
     RNAD_REQUIRE(n_tensors >= 1 && n_tensors <= kMaxTensors, "rnad_optimizer_step: 1..%d tensors", kMaxTensors);
     OptTensors ts{};
     ts.n = n_tensors;
@@ -126,7 +164,8 @@ extern "C" int rnad_optimizer_step(int n_tensors, const int64_t *sizes, float *c
         ts.target[k] = target ? target[k] : nullptr;
     }
     const unsigned grid = (unsigned)std::max<int64_t>(1, (ts.offset[n_tensors] + kOptThreads - 1) / kOptThreads);
-    hipLaunchKernelGGL(k_optimizer_step, dim3(grid), dim3(kOptThreads), 0, (hipStream_t)stream, ts, (const float *)grads, *hp, total_norm);
+    hipLaunchKernelGGL(k_optimizer_step, dim3(grid), dim3(kOptThreads), 0, (hipStream_t)stream, ts, (const float *)grads, *hp, total_norm, mlp_A,
+                       mlp_W, mlp_A > 0 ? packed_param : nullptr, mlp_A > 0 ? packed_target : nullptr);
     RNAD_HIP_OK(hipGetLastError());
     return 0;
 }

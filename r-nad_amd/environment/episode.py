@@ -116,7 +116,7 @@ class Episodes:
 
     _PRIMARY = ("indices", "observations", "mask_bits", "policy", "action_idx", "rewards", "values")
     _DENSE = {"mask_bits": "mask_bits", "policy": "policy", "action_idx": "actions", "rewards": "rewards"}  # attribute -> Trajectory buffer
-    _observations = _values = None  # class-level defaults: objects assembled without __init__ (tests, collate) behave the same
+    _observations = _values = _alive = None  # class-level defaults: objects assembled without __init__ (tests, collate) behave the same
     lane_ids = buckets = None
     _compact = None  # (rnad_hip.Trajectory(compact=True), records) of a compact bucketed rollout: dense fields expand on first access
 
@@ -228,19 +228,32 @@ class Episodes:
         return self._get("v_estimates", lambda: torch.zeros_like(self.rewards))  # episode.py:227 (unused)
 
     @property
+    def alive(self):
+        """int32 [T + 1] on the device: lanes with indices[t] != 0 (completed first if the rollout deferred it)."""
+        if self.buckets is not None and getattr(self.buckets, "alive_pending", None) is not None:
+            rnad_hip.bucket_alive(self.tree.handle(), self.buckets)
+        return self.__dict__.get("_alive")
+
+    @alive.setter
+    def alive(self, value):
+        self.__dict__["_alive"] = value
+
+    @property
     def valid_counts(self):
         """f64 [2] on the device: number of valid steps of player 0 / player 1 (= N_P of the losses)."""
         T = self.t_eff + 1
         traj = getattr(self, "_traj", None)
         if self.buckets is not None and traj is not None and T == traj.T_cap:
-            return self.buckets.norm  # counted by the rollout itself (rnad_rollout_bucketed); callers must not modify it in place
+            # counted by the rollout itself (rnad_rollout_bucketed) -- or, deferred, by the learner's launch that is about to read it on
+            # the stream; callers must not modify it in place
+            return self.buckets.norm
         a = self.alive[:T].to(torch.float64)
         return torch.stack([a[0::2].sum(), a[1::2].sum()])
 
     # ---------------------------------------------------------------- episode.py:175-230
     def generate(self, net: torch.nn.Module, noise_action=None, noise_chance=None, max_steps=None, trim=True, keep_logits=False,
                  skip_absorbed=False, store_values=True, tabular=None, bucketed=False, logits_table=None, value_table=None, policy_table=None, step_params=None,
-                 compact=False, visited=None):
+                 compact=False, visited=None, defer_alive=False):
         """Play the batch to the end with `net` as the actor.
 
         Nets exposing `forward_logits(obs) -> (logits [B,A], value [B,1])` (the MLP here) take the fast path: policy head,
@@ -279,7 +292,9 @@ class Episodes:
         `rewards` (and what derives from them) are written by rnad_bucket_expand on first access.  Slots of absorbed lanes then show
         action 0 where the dense rollout keeps drawing (nothing reads them).  With logits_table instead of policy_table the actor is
         the policy head of those logits and the caller attaches the records later.  visited (int32 [2S], compact only): receives a
-        1 for every (player, state) row a live slot of the batch sits in.
+        1 for every (player, state) row a live slot of the batch sits in.  defer_alive (compact, trim=False): the per-step alive
+        counters and the loss normalisers are added up by the learner's launch (rnad_hip.learn_bucketed_compact) instead of by a
+        kernel of their own; reading `alive` or `valid_counts` before that completes them on the spot.
 
         store_values=False (native MLP actor only): the actor's value head is not evaluated and `values` is zeros.  The
         reference stores the actor's values (episode.py:206,218) but nothing ever reads them (learn/rnad.py:373 recomputes v
@@ -314,14 +329,16 @@ class Episodes:
                 packed = packed if packed is not None else net.pack()
                 table, vtable = rnad_hip.mlp_forward(packed, net.width, handle.observations_table(self.obs_half), tree.max_actions,
                                                      want_value=store_values)
+            defer_alive = bool(defer_alive) and compact and not trim
             if compact and policy_table is not None:
                 self.buckets = rnad_hip.rollout_bucketed_compact(handle, traj, policy_table[0], seed=self.seed, lane0=self.lane_offset,
-                                                                 step_params=step_params, visited=visited)
+                                                                 step_params=step_params, visited=visited, defer_alive=defer_alive)
                 self.lane_ids = self.buckets.lane_ids
                 self._compact = (traj, policy_table[0])
             elif compact:
                 self.buckets = rnad_hip.rollout_bucketed_compact(handle, traj, table, seed=self.seed, lane0=self.lane_offset,
-                                                                 step_params=step_params, table_is_policy=False, visited=visited)
+                                                                 step_params=step_params, table_is_policy=False, visited=visited,
+                                                                 defer_alive=defer_alive)
                 self.lane_ids = self.buckets.lane_ids
                 self._compact = (traj, None)  # the caller attaches the records once they exist (learn/rnad.py, lazy rows)
             elif bucketed and policy_table is not None:

@@ -405,6 +405,24 @@ class RNaD:
         if cache is not None:
             cache["key"] = None
 
+    def _packed_images(self):
+        """(image of net, image of net_target): the packed weight layouts the fused MLP kernels read (rnad_hip.mlp_pack), in two
+        persistent buffers.  They are written here whenever the nets' tensors changed as far as torch can tell (version counters, data
+        pointers) and kept current by the one-launch optimiser tail (rnad_optimizer_step writes every new weight into both the
+        tensor and its image slot), so a training step carries no pack launch."""
+        A = self.tree.max_actions
+        ws = (self.net._weights(), self.net_target._weights())
+        key = tuple((id(w), w.data_ptr(), w._version) for group in ws for w in group)
+        cache = getattr(self, "_packed_cache", None)
+        if cache is None or cache["shape"] != (A, self.net.width, ws[0][0].device):
+            size = int(rnad_hip.lib().rnad_mlp_packed_size(A, self.net.width))
+            cache = self._packed_cache = {"shape": (A, self.net.width, ws[0][0].device), "key": None,
+                                          "images": [torch.empty((size,), dtype=torch.float32, device=ws[0][0].device) for _ in range(2)]}
+        if cache["key"] != key:
+            rnad_hip.mlp_pack_many(list(ws), A, out=cache["images"])
+            cache["key"] = key
+        return cache["images"]
+
     def _table_outputs(self, alpha, obs_half=False, want_target_logits=False, policy_only=False):
         """learner / target / regularisation nets on the 2S observations of the tree (rnad.py:373-380 on every distinct input):
         learner and target in ONE launch per step, the two regularisation nets from _reg_tables.  Both regularisation tables are
@@ -412,7 +430,7 @@ class RNaD:
         policy_only: the learner's logits alone (what the rollout needs); _value_tables adds the value heads on the visited rows."""
         A = self.tree.max_actions
         table = self.tree.handle().observations_table(obs_half)
-        packed, packed_target = rnad_hip.mlp_pack_many([self.net._weights(), self.net_target._weights()], A)
+        packed, packed_target = self._packed_images()
         if policy_only:
             with torch.no_grad():
                 logit = rnad_hip.mlp_forward(packed, self.net.width, table, A, want_logits=True, want_value=False)[0]
@@ -561,6 +579,7 @@ class RNaD:
                                                                      want_losses=log is not None, rows=tables.get("rows"))
                 live = tables.get("rows")  # lazy rows: the backward runs on the visited rows only
             else:
+                rnad_hip.bucket_alive(self.tree.handle(), episodes.buckets)  # (a no-op unless the rollout left its counts to a compact learner)
                 dlogit, dv, losses = rnad_hip.learn_bucketed(self.tree.handle(), episodes.buckets, episodes.indices[:T], episodes.action_idx[:T],
                                                              episodes.rewards[:T], episodes.policy[:T], records,
                                                              None if late_norm else norm, hp, want_losses=log is not None)
@@ -698,7 +717,10 @@ class RNaD:
                               value_table=tables["v"] if tables is not None and store_values else None,
                               policy_table=((tables["records"], rnad_hip.policy_column(self.tree.max_actions))
                                             if tables is not None and not lazy else None),
-                              step_params=step_params, compact=getattr(self, "compact_trajectory", True), visited=visited)
+                              step_params=step_params, compact=getattr(self, "compact_trajectory", True), visited=visited,
+                              # single process: the learner's launch adds up the alive counts (one kernel less); data parallel: the
+                              # normalisers are all-reduced beside the learner kernel, so they are needed before it
+                              defer_alive=mode is True and log is None and not self._dp())
             if lazy:
                 # the rows this batch went through are known now: value heads, records, gradient tables, backward on those only
                 assert episodes._compact is not None, "lazy rows need the compact bucketed rollout"
@@ -756,7 +778,7 @@ class RNaD:
             return None
         tail = rnad_hip.OptimizerStep(weights, [st["exp_avg"] for st in states], [st["exp_avg_sq"] for st in states], steps,
                                       self.net_target._weights(), lr, grp["betas"][0], grp["betas"][1], grp["eps"], self.grad_clip,
-                                      self.gamma_averaging)
+                                      self.gamma_averaging, packed=tuple(self._packed_images()), A=self.tree.max_actions)
         self._fused_tail_cache = (key, tail)
         return tail
 
@@ -807,6 +829,7 @@ class RNaD:
         rnad_hip.step_params_set(g["dev"], seed, alpha)
         # the regularisation nets are constant inside a captured step: refresh their tables (in place) when their weights changed
         self._reg_tables(self.tree.handle().observations_table(getattr(self, "obs_half", False)))
+        self._packed_images()  # (re-packed here, in place, if somebody edited net / net_target since the last step: no pack inside the graph)
         if g["graph"] is None:
             graph = torch.cuda.CUDAGraph()
             self._seed_override = seed  # the captured body (and an eager retry) must use THIS step's seed, not draw another

@@ -241,14 +241,16 @@ def mlp_pack(weights, A):
     return packed
 
 
-def mlp_pack_many(weight_lists, A):
-    """mlp_pack for up to four nets of one shape in ONE launch (rnad_mlp_pack_multi) -> list of packed images."""
+def mlp_pack_many(weight_lists, A, out=None):
+    """mlp_pack for up to four nets of one shape in ONE launch (rnad_mlp_pack_multi) -> list of packed images (written into `out`,
+    a list of preallocated images, when given)."""
     n = len(weight_lists)
     assert 1 <= n <= 4 and all(len(w) == 8 for w in weight_lists)
     W = weight_lists[0][0].shape[0]
     size = lib().rnad_mlp_packed_size(A, W)
     dev = weight_lists[0][0].device
-    outs = [torch.empty((size,), dtype=F32, device=dev) for _ in range(n)]
+    outs = [torch.empty((size,), dtype=F32, device=dev) for _ in range(n)] if out is None else list(out)
+    assert len(outs) == n and all(o.numel() == size for o in outs)
     wp = (C.c_void_p * (8 * n))(*[_dp(w.detach(), F32, "weight").value for ws in weight_lists for w in ws])
     op = (C.c_void_p * n)(*[_dp(o, F32, "packed").value for o in outs])
     _check(lib().rnad_mlp_pack_multi(n, A, W, wp, op, _stream()))
@@ -630,6 +632,7 @@ class Buckets:
         self.items = torch.empty((plan.max_items, 4), dtype=I32, device=device)
         self.n_items = torch.empty((1,), dtype=I32, device=device)
         self.norm = torch.empty((2,), dtype=F64, device=device)  # N_P of the batch: live slots of parity P
+        self.alive_pending = None  # the compact Trajectory whose alive counts / norm are still un-summed (rollout_bucketed_compact(defer_alive=True))
 
 
 def rollout_bucketed(tree, traj, table, value_table=None, seed=0, lane0=0, table_is_policy=False, column=0, step_params=None):
@@ -654,11 +657,14 @@ COMPACT_MAX_STEPS = 21  # 3 bits of action per step in one 64-bit word (csrc/buc
 BUCKET_MAX_LANES = 1 << 22  # lanes per call of the bucketed pipeline (csrc/bucket.hip kLaneBits: fixed-point headroom of the row sums)
 
 
-def rollout_bucketed_compact(tree, traj, table, seed=0, lane0=0, step_params=None, table_is_policy=True, column=None, visited=None):
+def rollout_bucketed_compact(tree, traj, table, seed=0, lane0=0, step_params=None, table_is_policy=True, column=None, visited=None,
+                             defer_alive=False):
     """rnad_rollout_bucketed_compact: the episodes of rollout_bucketed(table, table_is_policy, column) into a Trajectory(compact=True).
     table: bucket_records(...) (the default: its pi columns are the actor), any [2S, stride] table with the actor's policy rows from
     `column` on, or (table_is_policy=False) the actor's logits [2S, A].  visited (int32 [2S], optional): set to 1 for every (player,
-    state) row a live slot sits in (and the two rows of the absorbing state), 0 elsewhere.  Returns the Buckets of the batch."""
+    state) row a live slot sits in (and the two rows of the absorbing state), 0 elsewhere.  defer_alive: `traj.alive` and the
+    normalisers `buckets.norm` are left to the learner (learn_bucketed_compact adds them up in its own launch: one kernel less per
+    step) or to bucket_alive(); `buckets.alive_pending` says so until one of them ran.  Returns the Buckets of the batch."""
     assert traj.compact and traj.T_cap <= COMPACT_MAX_STEPS
     plan = bucket_plan(tree, traj.B)
     if plan is None:
@@ -673,10 +679,22 @@ def rollout_bucketed_compact(tree, traj, table, seed=0, lane0=0, step_params=Non
                                                int(table_is_policy), seed, lane0, _dp(step_params, torch.int64, "step_params", True),
                                                _dp(plan.scratch, I32, "scratch"), _dp(buckets.lane_ids, I32, "lane_ids"),
                                                _dp(buckets.items, I32, "items"), _dp(buckets.n_items, I32, "n_items"),
-                                               _dp(buckets.norm, F64, "norm"), _dp(traj.indices, I32, "indices"), _dp(traj.alive, I32, "alive"),
+                                               _dp(buckets.norm, F64, "norm"), _dp(traj.indices, I32, "indices"),
+                                               None if defer_alive else _dp(traj.alive, I32, "alive"),
                                                _dp(traj.acts, torch.int64, "acts"), _dp(traj.final_reward, F32, "final_reward"),
                                                _dp(visited, I32, "visited", True), _stream()))
+    buckets.alive_pending = traj if defer_alive else None
     return buckets
+
+
+def bucket_alive(tree, buckets):
+    """rnad_bucket_alive: completes a rollout_bucketed_compact(defer_alive=True) -- traj.alive and buckets.norm -- on its own."""
+    traj = buckets.alive_pending
+    if traj is None:
+        return
+    _check(lib().rnad_bucket_alive(tree.ptr, traj.T_cap, traj.B, _dp(buckets.plan.scratch, I32, "scratch"), _dp(traj.alive, I32, "alive"),
+                                   _dp(buckets.norm, F64, "norm"), _stream()))
+    buckets.alive_pending = None
 
 
 def bucket_expand(tree, traj, records):
@@ -703,13 +721,18 @@ def learn_bucketed_compact(tree, buckets, traj, T, records, fast_records, norm, 
     dlogit = torch.empty((2 * tree.S, A), dtype=F32, device=dev)
     dv = torch.empty((2 * tree.S, 1), dtype=F32, device=dev)
     losses = torch.empty((2,), dtype=F64, device=dev) if want_losses else None
+    # the rollout left its alive counts to this launch (defer_alive): its first T_cap + 1 workgroups add them up
+    pending = (None, 0, None, None)
+    if getattr(buckets, "alive_pending", None) is traj:
+        pending = (_dp(buckets.plan.scratch, I32, "scratch"), traj.T_cap, _dp(traj.alive, I32, "alive"), _dp(buckets.norm, F64, "norm"))
     _check(lib().rnad_learn_bucketed_compact(tree.ptr, T, B, _dp(traj.indices, I32, "indices"), _dp(traj.acts, torch.int64, "acts"),
                                              _dp(traj.final_reward, F32, "final_reward"), _dp(fast_records, F32, "fast_records"),
                                              _dp(records, F32, "records"), _dp(buckets.items, I32, "items"),
                                              _dp(buckets.n_items, I32, "n_items"), _dp(norm, F64, "norm", True), C.byref(hp),
                                              _dp(buckets.plan.accumulators, torch.int64, "accumulators"),
                                              _dp(losses, F64, "losses", True), _dp(dlogit, F32, "dlogit_tab"), _dp(dv, F32, "dv_tab"),
-                                             *_row_list(rows), _stream()))
+                                             *_row_list(rows), *pending, _stream()))
+    buckets.alive_pending = None
     return dlogit, dv, losses
 
 
@@ -785,10 +808,13 @@ class OptimizerStep:
     """rnad_optimizer_step bound to fixed tensors: clip + Adam + EMA of `params` (gradients back to back in one flat bucket, in that
     order) in one launch, on torch.optim.Adam's own state tensors.  The pointer arrays are built once."""
 
-    def __init__(self, params, exp_avg, exp_avg_sq, steps, targets, lr, beta1, beta2, eps, max_norm, ema):
+    def __init__(self, params, exp_avg, exp_avg_sq, steps, targets, lr, beta1, beta2, eps, max_norm, ema, packed=None, A=0):
+        """packed = (image of params, image of targets) with A: the tensors are the fused MLP's (MLP_KEYS order) and the kernel also
+        keeps those two packed weight images (mlp_pack) current -- no pack launch per step."""
         n = len(params)
         assert 1 <= n <= 8 and len(exp_avg) == len(exp_avg_sq) == len(steps) == n and (targets is None or len(targets) == n)
-        self._keep = (params, exp_avg, exp_avg_sq, steps, targets)
+        self._keep = (params, exp_avg, exp_avg_sq, steps, targets, packed)
+        self.packed, self.A, self.W = packed, (int(A) if packed is not None else 0), (params[0].shape[0] if packed is not None else 0)
         self.n = n
         self.numel = sum(p.numel() for p in params)
         arr = lambda ts, name: (C.c_void_p * n)(*[_dp(t, F32, name).value for t in ts])  # noqa: E731
@@ -799,8 +825,10 @@ class OptimizerStep:
 
     def __call__(self, flat):
         assert flat.numel() == self.numel
+        img = self.packed or (None, None)
         _check(lib().rnad_optimizer_step(self.n, self.sizes, self.param, _dp(flat, F32, "grads"), self.m, self.v, self.step, self.target,
-                                         C.byref(self.hp), None, _stream()))
+                                         C.byref(self.hp), None, self.A, self.W, _dp(img[0], F32, "packed_param", True),
+                                         _dp(img[1], F32, "packed_target", True), _stream()))
 
 
 def make_learn_params(alpha, eta, lambda_=1.0, c=1.0, rho=1.0, gamma=1.0, clip=1e3, threshold=2.0, w_v=1.0, w_n=1.0,

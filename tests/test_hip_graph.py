@@ -277,3 +277,36 @@ def test_resume_from_a_reference_style_checkpoint_keeps_the_graph_and_the_fused_
     assert rn._graph["graph"] is not None and not rn._graph["failed"]
     assert all(float(st["step"]) == 8.0 for st in rn.optimizer.state.values())
     assert all(torch.isfinite(p).all() for p in rn.net.parameters())
+
+
+@pytest.mark.parametrize("use_graph", (False, True))
+def test_packed_weight_images_follow_the_optimiser(use_graph, tmp_path):
+    """No pack launch per step: rnad_optimizer_step writes every new weight (and EMA target weight) into the packed images the MLP
+    kernels read.  After a run of steps the two images must be exactly what rnad_mlp_pack makes of the tensors -- also after an
+    edit of the weights behind the trainer's back (picked up through the version counters before the next step / replay)."""
+    import rnad_hip
+    from test_hip_bucket import TREES, _native_tree
+
+    tree = _native_tree(**TREES["ternary4"])
+    rn, _, _ = _run(tree, tmp_path, use_graph, 7, tag="img")
+    buf = _BUFFERS[id(rn)]
+    A = tree.max_actions
+
+    def check():
+        torch.cuda.synchronize()
+        fresh = rnad_hip.mlp_pack_many([rn.net._weights(), rn.net_target._weights()], A)
+        held = rn._packed_cache["images"]
+        assert torch.equal(held[0], fresh[0]) and torch.equal(held[1], fresh[1])
+
+    check()
+    ptrs = [t.data_ptr() for t in rn._packed_cache["images"]]
+    with torch.no_grad():
+        for p in rn.net.parameters():
+            p.mul_(0.5)  # bumps the version counters
+    for i in range(3):
+        rn.train_step(buf, alpha=0.5)
+        rn.total_steps += 1
+    check()
+    assert [t.data_ptr() for t in rn._packed_cache["images"]] == ptrs, "the images are re-packed in place (a captured step reads them)"
+    if use_graph:
+        assert rn._graph["graph"] is not None and not rn._graph["failed"]
