@@ -209,15 +209,40 @@ __device__ __forceinline__ long long wave_total_in_lane63(long long v) {
 // k_policy_rows: policy[row] = policy head (net.py:45-46) of the actor's logits row under the mover's legal mask.
 template <int A>
 __global__ __launch_bounds__(kThreads) void k_policy_rows(int64_t rows, const float *__restrict__ logits, int64_t stride,
-                                                          const uint8_t *__restrict__ mask_tab, float *__restrict__ policy) {
-    const int64_t r = (int64_t)blockIdx.x * kThreads + threadIdx.x;
-    if (r >= rows) return;
+                                                          const uint8_t *__restrict__ mask_tab, float *__restrict__ policy,
+                                                          const int32_t *__restrict__ row_list, const int64_t *__restrict__ n_rows,
+                                                          const int32_t *__restrict__ upper_list, int n_upper, int64_t S) {
+    const int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    int64_t r = i;
+    if (upper_list) {  // the rows of the upper states (both players) and of the absorbing state
+        if (i >= 2 * ((int64_t)n_upper + 1)) return;
+        const int64_t P = i / (n_upper + 1), k = i % (n_upper + 1);
+        r = P * S + (k < n_upper ? upper_list[k] : 0);
+    } else if (row_list) {  // a listed subset (count in device memory)
+        if (i >= *n_rows) return;
+        r = row_list[i];
+    } else if (i >= rows) {
+        return;
+    }
     float in[A], pol[A];
 #pragma unroll
     for (int a = 0; a < A; ++a) in[a] = logits[r * stride + a];
     policy_head_ptr<A>(in, mask_tab[r], pol, nullptr);
 #pragma unroll
     for (int a = 0; a < A; ++a) policy[r * A + a] = pol[a];
+}
+
+// flags[P * S + s] = 1 for both rows of every state that lies in a group some lane of the batch descends into (totals[group] > 0),
+// 0 elsewhere -- also for the upper states, whose rows the caller evaluated before the keys pass.  What a staged actor still has to
+// evaluate between the sort and the rollout (rnad_bucket_sort / rnad_bucket_play).
+__global__ __launch_bounds__(kThreads) void k_group_flags(int64_t S, const int32_t *__restrict__ bucket_of, int n_groups,
+                                                          const int32_t *__restrict__ totals, int32_t *__restrict__ flags) {
+    const int64_t s = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    if (s >= S) return;
+    const int b = bucket_of[s];
+    const int32_t on = (b >= 0 && b < n_groups && totals[b] > 0) ? 1 : 0;
+    flags[s] = on;
+    flags[S + s] = on;
 }
 
 // Row record of the bucketed update, kRowStride<A> floats:  logit[A] | v | v_target | pi_processed[A] | log_policy_reg[A] |
@@ -1275,34 +1300,52 @@ struct RolloutBuffers {  // the dense trajectory (rnad_traj_t) or the compact on
     int32_t *visited;          // compact, optional: [2S] flags of the rows the batch went through
 };
 
+// phases: 1 = keys + sort (needs the actor's rows of the upper states), 2 = the rollout in bucket order (needs the rows of every
+// non-empty group), 3 = both.  A caller that splits them (rnad_bucket_sort / rnad_bucket_play) evaluates its actor in stages:
+// the upper rows, then -- once the sort has shown which groups the batch descends into (group_flags) -- the rows of those groups.
+// play_rows / n_play_rows (phase 2 of a split call with a logits table): the rows that were evaluated for it.
 int rollout_bucketed_impl(const rnad_tree_t *tree, const RolloutBuffers &tr, bool compact, const float *table, int64_t table_stride,
                           int table_is_policy, const float *value_table, int64_t value_stride, uint64_t seed, int64_t lane0,
                           const rnad_step_params_t *device_params, void *scratch, int32_t *lane_ids, int32_t *items, int32_t *n_items,
-                          double *norm, hipStream_t stream) {
+                          double *norm, hipStream_t stream, int phases = 3, int32_t *group_flags = nullptr,
+                          const int32_t *play_rows = nullptr, const int64_t *n_play_rows = nullptr) {
     Plan p;
     RNAD_REQUIRE(make_plan(tree, tr.B, p), "rnad_rollout_bucketed: this tree / batch cannot be bucketed (see rnad_bucket_plan)");
     const int64_t B = tr.B, S = tree->S;
     const Scratch s = carve_scratch(scratch, B, p);
     const int n_steps = std::min(p.cut->max_path, tr.T_cap), nb = p.cut->n_buckets;
     ProfScope prof(PROF_ACT, stream);
-    if (tr.visited)  // cleared by a kernel (memset nodes of captured graphs are not to be trusted, see learn_bucketed_impl)
+    const bool sort_phase = (phases & 1) != 0, play_phase = (phases & 2) != 0;
+    if (tr.visited && play_phase)  // cleared by a kernel (memset nodes of captured graphs are not to be trusted, see learn_bucketed_impl)
         hipLaunchKernelGGL(k_clear_visited, dim3(blocks_for(2 * S, kThreads * 4)), dim3(kThreads), 0, stream, 2 * S, S, tr.visited);
     const float *policy_tab = table;
     int64_t policy_stride = table_stride;
-    if (!table_is_policy) {  // logits given: the policy head once per (player, state) row
-        RNAD_DISPATCH_A(tree->A, hipLaunchKernelGGL((k_policy_rows<kA>), dim3(blocks_for(2 * S)), dim3(kThreads), 0, stream, 2 * S, table,
-                                                    table_stride, (const uint8_t *)tree->mask_tab, s.policy));
+    if (!table_is_policy) {  // logits given: the policy head once per (player, state) row -- of the rows this phase can need
+        const uint8_t *mt = (const uint8_t *)tree->mask_tab;
+        if (phases == 3) {
+            RNAD_DISPATCH_A(tree->A, hipLaunchKernelGGL((k_policy_rows<kA>), dim3(blocks_for(2 * S)), dim3(kThreads), 0, stream, 2 * S, table,
+                                                        table_stride, mt, s.policy, nullptr, nullptr, nullptr, 0, S));
+        } else if (sort_phase) {
+            const int nu = p.cut->n_upper;
+            RNAD_DISPATCH_A(tree->A, hipLaunchKernelGGL((k_policy_rows<kA>), dim3(blocks_for(2 * ((int64_t)nu + 1))), dim3(kThreads), 0, stream,
+                                                        2 * S, table, table_stride, mt, s.policy, nullptr, nullptr,
+                                                        (const int32_t *)p.cut->upper_list, nu, S));
+        } else {
+            RNAD_REQUIRE(play_rows && n_play_rows, "rnad_bucket_play: a logits table needs the list of rows that were evaluated for it");
+            RNAD_DISPATCH_A(tree->A, hipLaunchKernelGGL((k_policy_rows<kA>), dim3(blocks_for(2 * S)), dim3(kThreads), 0, stream, 2 * S, table,
+                                                        table_stride, mt, s.policy, play_rows, n_play_rows, nullptr, 0, S));
+        }
         policy_tab = s.policy;
         policy_stride = tree->A;
     }
-    {
+    if (sort_phase) {
         ProfScope one(PROF_BUCKET_KEYS, stream);
         RNAD_DISPATCH_A(tree->A, hipLaunchKernelGGL((k_bucket_keys<kA>), dim3(blocks_for(B)), dim3(kThreads), 0, stream, tree->trans, tree->C,
                                                     S, B, n_steps, policy_tab, policy_stride, (const int32_t *)p.cut->bucket_of,
                                                     p.cut->n_groups, seed, device_params, lane0, s.keys, s.decisions, norm));
     }
     const size_t lds = (size_t)nb * sizeof(int32_t);
-    {
+    if (sort_phase) {
         ProfScope sort_passes(PROF_BUCKET_SORT, stream);
         hipLaunchKernelGGL(k_bucket_hist, dim3(p.sort_blocks), dim3(kSortThreads), lds, stream, B, nb, (const int32_t *)s.keys, s.hist);
         hipLaunchKernelGGL(k_bucket_scan, dim3((nb + kScanCols - 1) / kScanCols), dim3(kSortThreads), 0, stream, p.sort_blocks, nb, s.hist, s.totals);
@@ -1311,8 +1354,12 @@ int rollout_bucketed_impl(const rnad_tree_t *tree, const RolloutBuffers &tr, boo
             RNAD_HIP_OK(hipFuncSetAttribute((const void *)k_bucket_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, (int)scatter_lds));
         hipLaunchKernelGGL(k_bucket_scatter, dim3(p.sort_blocks), dim3(kSortThreads), scatter_lds, stream, B, nb, (const int32_t *)s.keys,
                            (const int32_t *)s.hist, (const int32_t *)s.totals, p.chunk, (Item *)items, n_items, lane_ids);
+        if (group_flags)
+            hipLaunchKernelGGL(k_group_flags, dim3(blocks_for(S)), dim3(kThreads), 0, stream, S, (const int32_t *)p.cut->bucket_of,
+                               p.cut->n_groups, (const int32_t *)s.totals, group_flags);
     }
     RNAD_HIP_OK(hipGetLastError());
+    if (!play_phase) return 0;
     const unsigned grid = blocks_for(B);
     {
         ProfScope one(PROF_BUCKET_ROLLOUT, stream);
@@ -1340,6 +1387,30 @@ int rollout_bucketed_impl(const rnad_tree_t *tree, const RolloutBuffers &tr, boo
     return 0;
 }
 }  // namespace
+
+extern "C" int rnad_bucket_sort(const rnad_tree_t *tree, int T_cap, int64_t B, const float *table, int64_t table_stride, int table_is_policy,
+                                uint64_t seed, int64_t lane0, const rnad_step_params_t *device_params, void *scratch, int32_t *lane_ids,
+                                int32_t *items, int32_t *n_items, double *norm, int32_t *group_flags, void *stream) {
+    RNAD_REQUIRE(tree && table && scratch && lane_ids && items && n_items, "rnad_bucket_sort: null argument");
+    RNAD_REQUIRE(T_cap >= 1 && T_cap <= kCompactSteps && B >= 1, "rnad_bucket_sort: 1 <= T_cap <= %d, got %d", kCompactSteps, T_cap);
+    RNAD_REQUIRE(table_stride >= tree->A, "rnad_bucket_sort: bad table stride");
+    const RolloutBuffers out{T_cap, B, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    return rollout_bucketed_impl(tree, out, true, table, table_stride, table_is_policy, nullptr, 1, seed, lane0, device_params, scratch,
+                                 lane_ids, items, n_items, norm, (hipStream_t)stream, 1, group_flags);
+}
+
+extern "C" int rnad_bucket_play(const rnad_tree_t *tree, int T_cap, int64_t B, const float *table, int64_t table_stride, int table_is_policy,
+                                const int32_t *rows, const int64_t *n_rows, uint64_t seed, int64_t lane0,
+                                const rnad_step_params_t *device_params, void *scratch, const int32_t *lane_ids, double *norm,
+                                int32_t *indices, int32_t *alive, uint64_t *acts, float *final_reward, int32_t *visited, void *stream) {
+    RNAD_REQUIRE(tree && table && scratch && lane_ids && indices && acts && final_reward, "rnad_bucket_play: null argument");
+    RNAD_REQUIRE(T_cap >= 1 && T_cap <= kCompactSteps && B >= 1, "rnad_bucket_play: 1 <= T_cap <= %d, got %d", kCompactSteps, T_cap);
+    RNAD_REQUIRE(table_stride >= tree->A && (!rows == !n_rows), "rnad_bucket_play: bad table stride / row list");
+    const RolloutBuffers out{T_cap, B, indices, nullptr, nullptr, nullptr, nullptr, nullptr, alive, (unsigned long long *)acts, final_reward,
+                             visited};
+    return rollout_bucketed_impl(tree, out, true, table, table_stride, table_is_policy, nullptr, 1, seed, lane0, device_params, scratch,
+                                 const_cast<int32_t *>(lane_ids), nullptr, nullptr, norm, (hipStream_t)stream, 2, nullptr, rows, n_rows);
+}
 
 extern "C" int rnad_bucket_alive(const rnad_tree_t *tree, int T_cap, int64_t B, const void *scratch, int32_t *alive, double *norm, void *stream) {
     RNAD_REQUIRE(tree && scratch && alive, "rnad_bucket_alive: null argument");

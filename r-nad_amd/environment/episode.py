@@ -253,7 +253,7 @@ class Episodes:
     # ---------------------------------------------------------------- episode.py:175-230
     def generate(self, net: torch.nn.Module, noise_action=None, noise_chance=None, max_steps=None, trim=True, keep_logits=False,
                  skip_absorbed=False, store_values=True, tabular=None, bucketed=False, logits_table=None, value_table=None, policy_table=None, step_params=None,
-                 compact=False, visited=None, defer_alive=False):
+                 compact=False, visited=None, defer_alive=False, staged_actor=None):
         """Play the batch to the end with `net` as the actor.
 
         Nets exposing `forward_logits(obs) -> (logits [B,A], value [B,1])` (the MLP here) take the fast path: policy head,
@@ -294,7 +294,11 @@ class Episodes:
         the policy head of those logits and the caller attaches the records later.  visited (int32 [2S], compact only): receives a
         1 for every (player, state) row a live slot of the batch sits in.  defer_alive (compact, trim=False): the per-step alive
         counters and the loss normalisers are added up by the learner's launch (rnad_hip.learn_bucketed_compact) instead of by a
-        kernel of their own; reading `alive` or `valid_counts` before that completes them on the spot.
+        kernel of their own; reading `alive` or `valid_counts` before that completes them on the spot.  staged_actor (compact with
+        logits_table; trees that are large next to the batch): a callable `f(rows)` that evaluates the actor's logits INTO
+        logits_table on the given rnad_hip.LiveRows / RowList -- called twice: with the rows of the cut's upper states before the keys
+        pass and the sort, then with the rows of the groups the batch turned out to descend into, before the rollout itself
+        (rnad_bucket_sort / rnad_bucket_play).
 
         store_values=False (native MLP actor only): the actor's value head is not evaluated and `values` is zeros.  The
         reference stores the actor's values (episode.py:206,218) but nothing ever reads them (learn/rnad.py:373 recomputes v
@@ -335,6 +339,15 @@ class Episodes:
                                                                  step_params=step_params, visited=visited, defer_alive=defer_alive)
                 self.lane_ids = self.buckets.lane_ids
                 self._compact = (traj, policy_table[0])
+            elif compact and staged_actor is not None:
+                staged_actor(rnad_hip.bucket_upper_rows(handle, B))
+                self.buckets, flags = rnad_hip.bucket_sort(handle, traj, table, seed=self.seed, lane0=self.lane_offset, step_params=step_params)
+                rows = rnad_hip.compact_valid(flags)
+                staged_actor(rows)
+                rnad_hip.bucket_play(handle, traj, self.buckets, table, rows=rows, seed=self.seed, lane0=self.lane_offset,
+                                     step_params=step_params, visited=visited, defer_alive=defer_alive)
+                self.lane_ids = self.buckets.lane_ids
+                self._compact = (traj, None)  # the caller attaches the records once they exist (learn/rnad.py, lazy rows)
             elif compact:
                 self.buckets = rnad_hip.rollout_bucketed_compact(handle, traj, table, seed=self.seed, lane0=self.lane_offset,
                                                                  step_params=step_params, table_is_policy=False, visited=visited,

@@ -432,11 +432,17 @@ class RNaD:
         table = self.tree.handle().observations_table(obs_half)
         packed, packed_target = self._packed_images()
         if policy_only:
-            with torch.no_grad():
-                logit = rnad_hip.mlp_forward(packed, self.net.width, table, A, want_logits=True, want_value=False)[0]
+            # lazy rows: the learner's policy head is evaluated in stages by the rollout (staged_actor below: the upper rows of the cut,
+            # then the rows of the groups the batch descends into); rows no lane can reach stay uninitialised and are never read
+            logit = torch.empty((table.shape[0], A), dtype=torch.float32, device=table.device)
+
+            def staged_actor(rows, packed=packed, logit=logit, table=table, width=self.net.width):
+                with torch.no_grad():
+                    rnad_hip.mlp_forward(packed, width, table, A, live=rows, out=(logit, None))
+
             logit_reg, logit_reg_ = self._reg_tables(table)
             return dict(table=table, logit=logit, v=None, logit_target=None, v_target=None, logit_reg=logit_reg, logit_reg_=logit_reg_,
-                        packed_net=packed, packed_target=packed_target)
+                        packed_net=packed, packed_target=packed_target, staged_actor=staged_actor)
         with torch.no_grad():
             # (one launch entry per (net, head) -- three equal work units per 64-row span -- was measured: 45.5 instead of 43.4 us, every
             # workgroup loads its net's 43 KB weight image first)
@@ -452,8 +458,10 @@ class RNaD:
         handle, A = self.tree.handle(), self.tree.max_actions
         rows = rnad_hip.compact_valid(visited)
         with torch.no_grad():
-            tables["v"] = rnad_hip.mlp_forward(tables["packed_net"], self.net.width, tables["table"], A, want_logits=False, live=rows)[1]
-            tables["v_target"] = rnad_hip.mlp_forward(tables["packed_target"], self.net.width, tables["table"], A, want_logits=False, live=rows)[1]
+            # (the rows that are not listed are never read: records, gradient tables and the backward all go by the same list)
+            tables["v"] = rnad_hip.mlp_forward(tables["packed_net"], self.net.width, tables["table"], A, want_logits=False, live=rows, zero_rest=False)[1]
+            tables["v_target"] = rnad_hip.mlp_forward(tables["packed_target"], self.net.width, tables["table"], A, want_logits=False, live=rows,
+                                                      zero_rest=False)[1]
         tables["records"], tables["fast_records"] = rnad_hip.bucket_records(
             handle, tables["logit"], tables["v"], tables["v_target"], tables["logit_reg"], tables["logit_reg_"], self._learn_params(alpha),
             step_params=step_params, fast=True, rows=rows)
@@ -720,7 +728,8 @@ class RNaD:
                               step_params=step_params, compact=getattr(self, "compact_trajectory", True), visited=visited,
                               # single process: the learner's launch adds up the alive counts (one kernel less); data parallel: the
                               # normalisers are all-reduced beside the learner kernel, so they are needed before it
-                              defer_alive=mode is True and log is None and not self._dp())
+                              defer_alive=mode is True and log is None and not self._dp(),
+                              staged_actor=tables.get("staged_actor") if (tables is not None and lazy) else None)
             if lazy:
                 # the rows this batch went through are known now: value heads, records, gradient tables, backward on those only
                 assert episodes._compact is not None, "lazy rows need the compact bucketed rollout"

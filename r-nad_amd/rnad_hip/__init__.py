@@ -278,15 +278,31 @@ def compact_valid(indices):
     return LiveRows(indices)
 
 
-def mlp_forward(packed, W, obs, A, want_logits=True, want_value=True, live=None):
+class RowList:
+    """A fixed list of rows in the shape of a LiveRows (rows int32 [n], count int64 [1] on the device), e.g. the upper rows of a cut."""
+
+    def __init__(self, rows, N, device):
+        self.N = N
+        self.rows = torch.as_tensor(rows, dtype=I32).to(device).contiguous()
+        self.count = torch.tensor([self.rows.numel()], dtype=torch.int64, device=device)
+
+
+def mlp_forward(packed, W, obs, A, want_logits=True, want_value=True, live=None, out=None, zero_rest=True):
     """packed: mlp_pack(weights, A); obs [N, 2, A, A] fp32/fp16 -> logits [N, A], value [N, 1].
     A head that is not wanted is not computed (returns None for it).
-    live: a LiveRows over the N samples -- only those rows are evaluated, the others come back as zeros."""
+    live: a LiveRows / RowList over the N samples -- only those rows are evaluated; the others come back as zeros (zero_rest=False:
+    uninitialised -- for callers that never read them).  out = (logits, value): existing tables to write into (their other rows
+    are left alone)."""
     N = obs.numel() // (2 * A * A)
     half = obs.dtype == F16
-    alloc = torch.zeros if live is not None else torch.empty
-    logits = alloc((N, A), dtype=F32, device=obs.device) if want_logits else None
-    value = alloc((N, 1), dtype=F32, device=obs.device) if want_value else None
+    alloc = torch.zeros if (live is not None and zero_rest) else torch.empty
+    if out is not None:
+        logits, value = out
+        want_logits, want_value = logits is not None, value is not None
+        assert (logits is None or logits.shape == (N, A)) and (value is None or value.shape == (N, 1))
+    else:
+        logits = alloc((N, A), dtype=F32, device=obs.device) if want_logits else None
+        value = alloc((N, 1), dtype=F32, device=obs.device) if want_value else None
     if live is None:
         _check(lib().rnad_mlp_forward(C.c_int64(N), A, W, _dp(packed, F32, "packed"), _dp(obs, F16 if half else F32, "obs"), int(half),
                                       _dp(logits, F32, "logits", True), _dp(value, F32, "value", True), _stream()))
@@ -685,6 +701,52 @@ def rollout_bucketed_compact(tree, traj, table, seed=0, lane0=0, step_params=Non
                                                _dp(visited, I32, "visited", True), _stream()))
     buckets.alive_pending = traj if defer_alive else None
     return buckets
+
+
+def bucket_upper_rows(tree, B):
+    """RowList of the (player, state) rows a staged actor must have evaluated BEFORE bucket_sort: both rows of every upper state of
+    the cut of (tree, B) and of the absorbing state.  Cached on the plan."""
+    plan = bucket_plan(tree, B)
+    if getattr(plan, "upper_rows", None) is None:
+        bucket_of, n_groups = bucket_map(tree, B)
+        upper = torch.nonzero(bucket_of >= n_groups).view(-1).to(torch.int64)
+        states = torch.cat([torch.zeros((1,), dtype=torch.int64), upper])
+        plan.upper_rows = RowList(torch.cat([states, states + tree.S]), 2 * tree.S, tree.device)
+    return plan.upper_rows
+
+
+def bucket_sort(tree, traj, table, seed=0, lane0=0, step_params=None, table_is_policy=False, column=0, want_flags=True):
+    """rnad_bucket_sort: the first half of rollout_bucketed_compact (keys + sort) for an actor evaluated in stages; `table` needs the
+    rows of bucket_upper_rows() only.  Returns (buckets, flags): flags int32 [2S] marks the rows of the groups the batch descends into
+    -- evaluate the actor on compact_valid(flags), then call bucket_play."""
+    assert traj.compact and traj.T_cap <= COMPACT_MAX_STEPS
+    plan = bucket_plan(tree, traj.B)
+    if plan is None:
+        raise RnadHipError(lib().rnad_last_error().decode())
+    assert table.shape[0] == 2 * tree.S and table.shape[1] >= column + tree.A
+    buckets = Buckets(plan, traj.indices.device)
+    flags = torch.empty((2 * tree.S,), dtype=I32, device=traj.indices.device) if want_flags else None
+    base = _dp(table, F32, "table")
+    _check(lib().rnad_bucket_sort(tree.ptr, traj.T_cap, traj.B, C.c_void_p(base.value + 4 * column), table.shape[1], int(table_is_policy), seed,
+                                  lane0, _dp(step_params, torch.int64, "step_params", True), _dp(plan.scratch, I32, "scratch"),
+                                  _dp(buckets.lane_ids, I32, "lane_ids"), _dp(buckets.items, I32, "items"), _dp(buckets.n_items, I32, "n_items"),
+                                  _dp(buckets.norm, F64, "norm"), _dp(flags, I32, "group_flags", True), _stream()))
+    return buckets, flags
+
+
+def bucket_play(tree, traj, buckets, table, rows=None, seed=0, lane0=0, step_params=None, table_is_policy=False, column=0, visited=None,
+                defer_alive=False):
+    """rnad_bucket_play: the second half (the rollout in bucket order + alive counts); same seed / lane0 / step_params as bucket_sort.
+    rows: the LiveRows the actor was evaluated on since the sort (a logits table: their policy head is taken here)."""
+    assert table.shape[0] == 2 * tree.S and table.shape[1] >= column + tree.A
+    base = _dp(table, F32, "table")
+    _check(lib().rnad_bucket_play(tree.ptr, traj.T_cap, traj.B, C.c_void_p(base.value + 4 * column), table.shape[1], int(table_is_policy),
+                                  *_row_list(rows), seed, lane0, _dp(step_params, torch.int64, "step_params", True),
+                                  _dp(buckets.plan.scratch, I32, "scratch"), _dp(buckets.lane_ids, I32, "lane_ids"),
+                                  _dp(buckets.norm, F64, "norm"), _dp(traj.indices, I32, "indices"),
+                                  None if defer_alive else _dp(traj.alive, I32, "alive"), _dp(traj.acts, torch.int64, "acts"),
+                                  _dp(traj.final_reward, F32, "final_reward"), _dp(visited, I32, "visited", True), _stream()))
+    buckets.alive_pending = traj if defer_alive else None
 
 
 def bucket_alive(tree, buckets):

@@ -494,3 +494,46 @@ def test_a_sharp_policy_puts_most_lanes_into_one_bucket():
     np.add.at(want_v, rows[live], dv.cpu().numpy().astype(np.float64)[live])
     np.testing.assert_allclose(got[0].cpu().numpy(), want_l, rtol=2e-6, atol=2e-7 * np.abs(want_l).max())
     np.testing.assert_allclose(got[1].cpu().numpy()[:, 0], want_v, rtol=2e-6, atol=2e-7 * np.abs(want_v).max())
+
+
+@pytest.mark.parametrize("rows", (None, 40, 8))
+@pytest.mark.parametrize("name", ("pruned", "a5c4", "ternary4"))
+def test_staged_actor_plays_the_same_batch(name, rows, monkeypatch):
+    """rnad_bucket_sort + rnad_bucket_play with the actor evaluated in two stages (the upper rows of the cut, then the rows of the groups
+    the batch descends into) against rnad_rollout_bucketed_compact on the fully evaluated table: the same batch bit for bit, and every
+    row the batch visits was evaluated."""
+    import rnad_hip
+    from environment.episode import Episodes
+
+    tree = _native_tree(**TREES[name])
+    h = tree.handle()
+    A, S, B = tree.max_actions, h.S, 4096
+    if rows is not None:
+        monkeypatch.setenv("RNAD_BUCKET_ROWS", str(rows))
+        if rnad_hip.bucket_plan(h, B) is None:
+            pytest.skip(f"a table of {rows} rows does not fit this tree")
+    nets = _four_nets(A, 64, seed=12)
+    table = h.observations_table()
+    packed = nets[0].pack()
+    full_logit = rnad_hip.mlp_forward(packed, 64, table, A, want_value=False)[0]
+    full = Episodes(tree, B, seed=17, lane_offset=3)
+    vis_full = torch.empty((2 * S,), dtype=torch.int32, device=DEV)
+    full.generate(nets[0], tabular=True, bucketed=True, trim=False, store_values=False, logits_table=full_logit, compact=True, visited=vis_full)
+    staged_logit = torch.full((2 * S, A), float("nan"), device=DEV)  # a row that was not evaluated would poison the rollout
+    calls = []
+
+    def actor(row_list):
+        calls.append(int(row_list.count.item()))
+        rnad_hip.mlp_forward(packed, 64, table, A, live=row_list, out=(staged_logit, None))
+
+    staged = Episodes(tree, B, seed=17, lane_offset=3)
+    vis = torch.empty((2 * S,), dtype=torch.int32, device=DEV)
+    staged.generate(nets[0], tabular=True, bucketed=True, trim=False, store_values=False, logits_table=staged_logit, compact=True, visited=vis,
+                    staged_actor=actor)
+    assert len(calls) == 2 and calls[0] >= 2 and calls[0] + calls[1] <= 2 * S
+    assert torch.equal(staged.lane_ids, full.lane_ids) and torch.equal(staged.indices, full.indices)
+    assert torch.equal(staged._compact[0].acts, full._compact[0].acts) and torch.equal(staged._compact[0].final_reward, full._compact[0].final_reward)
+    assert torch.equal(staged.alive, full.alive) and torch.equal(vis, vis_full)
+    seen = vis.bool()
+    assert torch.isfinite(staged_logit[seen]).all(), "every visited row must have been evaluated"
+    assert torch.equal(staged_logit[seen], full_logit[seen])
