@@ -131,6 +131,26 @@ int rnad_mlp_backward_rows(int64_t max_rows, const int32_t *rows, const int64_t 
                            float *g_vb0, float *g_vw1, float *g_vb1, float *g_pw0, float *g_pb0, float *g_pw1, float *g_pb1,
                            float *workspace, void *stream);
 
+/* The legal fold.  An observation is [expected value A x A | legal mask A x A] (episode.py:62-68); on a tree whose states all have the
+ * full A x A action set -- every configuration of BASELINE.json -- the legal plane is all ones in every row except the two rows of
+ * the absorbing state, where it is e0 = [1, 0, ..., 0] (tree.py:133).  The first layer of nn/net.py:40-43 is then
+ *     z = W_ev ev + (b0 + W_legal 1) + [absorbing row] (W_legal e0 - W_legal 1)
+ * -- A^2 + 1 input features instead of 2 A^2 (5 MFMA k-steps instead of 9 at A = 3): the same function of the same weights, summed
+ * in another order.  These entry points are the fused MLP kernels instantiated for it; observations keep their layout (row stride
+ * 2 A^2; the kernels read the expected values and legal[0][1]) and the CALLER guarantees the premise for every row it passes
+ * (rnad_hip.TreeHandle checks its observation table once).  A >= 2.  The packed image (rnad_mlp_fold_packed_size floats) keeps the
+ * raw weights, so rnad_optimizer_step(mlp_fold = 1) maintains it element by element; the kernels fold when they load it.
+ * rnad_mlp_forward_fold: rnad_mlp_forward_multi / _rows in one (rows, n_rows: NULL or a row list, N its capacity).
+ * rnad_mlp_backward_fold: the gradients of the eight ORIGINAL tensors (exactly recoverable: dW_legal[h][0] = db0[h], dW_legal[h][j >= 1]
+ * = db0[h] - the indicator column's gradient); workspace: rnad_mlp_backward_workspace(N, A, W) bytes. */
+int64_t rnad_mlp_fold_packed_size(int A, int W);
+int rnad_mlp_pack_fold_multi(int n_nets, int A, int W, const float *const *weights, float *const *packed, void *stream);
+int rnad_mlp_forward_fold(int n_nets, int64_t N, const int32_t *rows, const int64_t *n_rows, int A, int W, const float *const *packed,
+                          const void *obs, int obs_half, float *const *logits, float *const *value, void *stream);
+int rnad_mlp_backward_fold(int64_t N, const int32_t *rows, const int64_t *n_rows, int A, int W, const float *packed, const void *obs,
+                           int obs_half, const float *dlogits, const float *dvalue, float *g_vw0, float *g_vb0, float *g_vw1, float *g_vb1,
+                           float *g_pw0, float *g_pb0, float *g_pw1, float *g_pb1, float *workspace, void *stream);
+
 /* ------------------------------------------------------------------------------------------------
  * K3  sample  --  torch.multinomial(policy, 1) at nn/net.py:49, i.e. argmax_a(policy[a] / q[a]) with
  * q ~ Exp(1), first maximum wins.  q is `noise` (f32 [B,n]) when given, otherwise the seeded
@@ -453,7 +473,8 @@ int rnad_clip_grad_norm(int64_t n, float *grads, float max_norm, float *total_no
  * NULL: no EMA).  The state tensors are torch.optim.Adam's own, so checkpoints keep the reference format.
  * mlp_A > 0 (with mlp_W, packed_param, packed_target; either image may be NULL): the 8 tensors are the fused MLP's Linear tensors in
  * the order rnad_mlp_pack takes them, and every new weight / new target weight is ALSO written into its slot of that net's packed
- * image (rnad_mlp_pack's layout) -- the images stay current without a pack launch per step.  mlp_A == 0: none of this. */
+ * image (rnad_mlp_pack's layout; mlp_fold != 0: rnad_mlp_pack_fold_multi's) -- the images stay current without a pack launch per
+ * step.  mlp_A == 0: none of this. */
 typedef struct rnad_adam_params {
     float lr, beta1, beta2, eps;  /* rnad.py:232-237 */
     float max_norm;               /* grad_clip, rnad.py:456 */
@@ -461,7 +482,7 @@ typedef struct rnad_adam_params {
 } rnad_adam_params_t;
 int rnad_optimizer_step(int n_tensors, const int64_t *sizes, float *const *param, float *grads, float *const *exp_avg,
                         float *const *exp_avg_sq, float *const *step, float *const *target, const rnad_adam_params_t *hp,
-                        float *total_norm, int mlp_A, int mlp_W, float *packed_param, float *packed_target, void *stream);
+                        float *total_norm, int mlp_A, int mlp_W, int mlp_fold, float *packed_param, float *packed_target, void *stream);
 
 /* ------------------------------------------------------------------------------------------------
  * NashConv  --  util/metric.py:93-175 (NashConvData.get_nashconv), level-batched on the GPU

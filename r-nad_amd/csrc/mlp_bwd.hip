@@ -6,11 +6,11 @@ using namespace rnad;
 using namespace rnad_mlp;
 
 namespace rnad_mlp {
-size_t mlp_backward_t_lds(int A);
-int mlp_backward_t_blocks_per_cu(int A, int waves);
+size_t mlp_backward_t_lds(int A, bool fold);
+int mlp_backward_t_blocks_per_cu(int A, int waves, bool fold);
 int mlp_backward_t_launch(int A, int waves, dim3 grid, hipStream_t stream, int64_t N, int W, const float *packed, const void *obs,
                            int obs_half, const float *dlogits, const float *dvalue, float *workspace, int P, const int32_t *rows,
-                           const int64_t *n_rows);
+                           const int64_t *n_rows, bool fold);
 }  // namespace rnad_mlp
 
 namespace {
@@ -317,34 +317,58 @@ __global__ __launch_bounds__(64 * WAVES) void k_mlp_backward(int64_t N, int W, c
 // Sum the per-block partials (fixed order, fp64 accumulate) into the eight gradient tensors (torch Linear layouts).
 // blockDim = (64 outputs, kReduceSlices): slice s adds blocks s, s + kReduceSlices, ... of its output, then the slices are
 // added in order -- the same grouping on every run, 1 / kReduceSlices of the dependent-load chain of one thread per output.
+// FOLD (mlp_common.hpp "the legal fold"): the partials are those of the folded first layer -- columns ev [A^2] | indicator | (padding) |
+// bias -- and the gradients of the eight ORIGINAL tensors follow from them exactly:
+//   dW0[h][k < A^2] = column k;   db0[h] = bias column;   with d_abs = indicator column (the rows of the absorbing state):
+//   dW0[h][A^2 + j] = sum_rows dz legal[row][j] = (db0 - d_abs) + d_abs e0[j]  ->  db0 for j = 0, db0 - d_abs for j >= 1.
 constexpr int kReduceSlices = 16;
-template <int A>
+template <int A, bool FOLD>
 __global__ __launch_bounds__(64 * kReduceSlices) void k_mlp_reduce(int nblocks, int W, int P, const float *__restrict__ partial,
                                                                    float *__restrict__ g_vw0, float *__restrict__ g_vb0,
                                                                    float *__restrict__ g_vw1, float *__restrict__ g_vb1,
                                                                    float *__restrict__ g_pw0, float *__restrict__ g_pb0,
                                                                    float *__restrict__ g_pw1, float *__restrict__ g_pb1) {
-    constexpr int K = 2 * A * A, FW = ((K + 1 + kTile - 1) / kTile) * kTile;
-    __shared__ double part[kReduceSlices][64];
+    constexpr int K = MlpShape<A, FOLD>::K, OBS = MlpShape<A, FOLD>::OBS, FW = ((K + 1 + kTile - 1) / kTile) * kTile;
+    __shared__ double part[kReduceSlices][64], part_ind[kReduceSlices][64];
     const int e = blockIdx.x * 64 + threadIdx.x;
     const int total = 2 * W * FW + W + A * W + 1 + A;
-    double s = 0.0;
+    double s = 0.0, s_ind = 0.0;
     const bool padding = e < 2 * W * FW && e % FW > K;  // columns of the dW0aug tiles beyond the bias column: never stored
+    const bool bias_col = FOLD && e < 2 * W * FW && e % FW == K;  // (it also needs its row's indicator column)
     if (e < total && !padding)
-        for (int b = threadIdx.y; b < nblocks; b += kReduceSlices) s += (double)partial[(int64_t)b * P + e];
+        for (int b = threadIdx.y; b < nblocks; b += kReduceSlices) {
+            s += (double)partial[(int64_t)b * P + e];
+            if (bias_col) s_ind += (double)partial[(int64_t)b * P + e - (K - A * A)];
+        }
     part[threadIdx.y][threadIdx.x] = s;
+    if (FOLD) part_ind[threadIdx.y][threadIdx.x] = s_ind;
     __syncthreads();
     if (threadIdx.y != 0 || e >= total) return;
 #pragma unroll
-    for (int i = 1; i < kReduceSlices; ++i) s += part[i][threadIdx.x];
+    for (int i = 1; i < kReduceSlices; ++i) {
+        s += part[i][threadIdx.x];
+        if (FOLD) s_ind += part_ind[i][threadIdx.x];
+    }
     const float v = (float)s;
     const int n0 = 2 * W * FW;
     if (e < n0) {
         const int h = e / FW, k = e % FW;
         float *gw = h < W ? g_vw0 : g_pw0, *gb = h < W ? g_vb0 : g_pb0;
         const int hh = h < W ? h : h - W;
-        if (k < K) gw[hh * K + k] = v;
-        else if (k == K) gb[hh] = v;
+        if constexpr (FOLD) {
+            if (k < A * A) {
+                gw[hh * OBS + k] = v;
+            } else if (k == K) {
+                gb[hh] = v;
+                gw[hh * OBS + A * A] = v;
+                const float rest = (float)(s - s_ind);
+#pragma unroll
+                for (int j = 1; j < A * A; ++j) gw[hh * OBS + A * A + j] = rest;
+            }
+        } else {
+            if (k < K) gw[hh * K + k] = v;
+            else if (k == K) gb[hh] = v;
+        }
     } else if (e < n0 + W) {
         g_vw1[e - n0] = v;
     } else if (e < n0 + W + A * W) {
@@ -374,22 +398,22 @@ static bool use_resident_backward() {
 
 // One wave per hidden tile (of both heads).  With one feature tile (A <= 3) a wave needs ~230 VGPRs: 8 waves per block, two
 // per SIMD.  With more feature tiles it needs up to ~400: 4 waves per block, one per SIMD, and blockIdx.y walks the tile groups.
-static bool mlp_backward_plan(int64_t N, int W, int A, BwdPlan *p) {
-    const int K = 2 * A * A, T = W / kTile, FT = (K + 1 + kTile - 1) / kTile;
+static bool mlp_backward_plan(int64_t N, int W, int A, BwdPlan *p, bool fold = false) {
+    const int K = fold ? mlp_fold_k(A) : 2 * A * A, T = W / kTile, FT = (K + 1 + kTile - 1) / kTile;
     p->total = 2 * W * FT * kTile + W + A * W + 1 + A;
     p->P = (p->total + 3) & ~3;
     int dev0 = 0, cus0 = 256;
     if (hipGetDevice(&dev0) == hipSuccess) (void)hipDeviceGetAttribute(&cus0, hipDeviceAttributeMultiprocessorCount, dev0);
     const int64_t n_tiles0 = (N + kTile - 1) / kTile;
-    p->resident = use_resident_backward();
+    p->resident = fold || use_resident_backward();  // (the fold exists in the register-resident kernel only)
     if (p->resident) {
         // 4 waves per block (one per SIMD), as many blocks per CU as the registers allow; the LDS holds only the sample stage
         int wv = 4;  // measured: 4 waves per block 5.31 ms, 8: 5.41, 2: 5.72 (configs[1], 12.6 M samples)
         while (wv > 1 && T % wv) wv >>= 1;
         p->waves = wv;
         p->groups = T / wv;
-        p->lds_bytes = mlp_backward_t_lds(A);
-        p->grid_x = (int)std::max<int64_t>(1, std::min<int64_t>(n_tiles0, std::max(1, cus0 * mlp_backward_t_blocks_per_cu(A, wv) / p->groups)));
+        p->lds_bytes = mlp_backward_t_lds(A, fold);
+        p->grid_x = (int)std::max<int64_t>(1, std::min<int64_t>(n_tiles0, std::max(1, cus0 * mlp_backward_t_blocks_per_cu(A, wv, fold) / p->groups)));
         return true;
     }
     int waves = FT == 1 ? 8 : 4;
@@ -411,19 +435,24 @@ static bool mlp_backward_plan(int64_t N, int W, int A, BwdPlan *p) {
 extern "C" int64_t rnad_mlp_backward_workspace(int64_t N, int A, int W) {
     BwdPlan p;
     if (A < 1 || A > RNAD_MAX_ACTIONS || W < kTile || W % kTile || !mlp_backward_plan(N, W, A, &p)) return -1;
-    return (int64_t)p.grid_x * p.P * (int64_t)sizeof(float);
+    int64_t bytes = (int64_t)p.grid_x * p.P * (int64_t)sizeof(float);
+    BwdPlan f;  // (rnad_mlp_backward_fold shares the workspace: its plan may run more, smaller blocks)
+    if (A >= 2 && mlp_backward_plan(N, W, A, &f, true)) bytes = std::max(bytes, (int64_t)f.grid_x * f.P * (int64_t)sizeof(float));
+    return bytes;
 }
 
 static int mlp_backward_launch(int64_t N, const int32_t *rows, const int64_t *n_rows, int A, int W, const float *packed, const void *obs,
                                int obs_half, const float *dlogits, const float *dvalue, float *g_vw0, float *g_vb0, float *g_vw1,
-                               float *g_vb1, float *g_pw0, float *g_pb0, float *g_pw1, float *g_pb1, float *workspace, void *stream_) {
+                               float *g_vb1, float *g_pw0, float *g_pb0, float *g_pw1, float *g_pb1, float *workspace, void *stream_,
+                               bool fold = false) {
     RNAD_REQUIRE(packed && obs && dlogits && dvalue && g_vw0 && g_vb0 && g_vw1 && g_vb1 && g_pw0 && g_pb0 && g_pw1 && g_pb1 && workspace,
                  "rnad_mlp_backward: null argument");
     RNAD_REQUIRE(W >= kTile && W % kTile == 0, "rnad_mlp_backward: width %d must be a positive multiple of %d", W, kTile);
     RNAD_REQUIRE(N >= 1, "rnad_mlp_backward: empty batch");
     hipStream_t stream = (hipStream_t)stream_;
     BwdPlan plan;
-    RNAD_REQUIRE(A >= 1 && A <= RNAD_MAX_ACTIONS && mlp_backward_plan(N, W, A, &plan),
+    RNAD_REQUIRE(!fold || A >= 2, "rnad_mlp_backward_fold: the legal fold needs at least two actions");
+    RNAD_REQUIRE(A >= 1 && A <= RNAD_MAX_ACTIONS && mlp_backward_plan(N, W, A, &plan, fold),
                  "rnad_mlp_backward: weights do not fit the LDS (A=%d, width=%d)", A, W);
     const int grid = plan.grid_x, P = plan.P;
     const size_t lds_bytes = plan.lds_bytes;
@@ -431,7 +460,7 @@ static int mlp_backward_launch(int64_t N, const int32_t *rows, const int64_t *n_
     if (plan.resident) {
         ProfScope prof(PROF_MLP_BWD, stream);
         if (int rc = mlp_backward_t_launch(A, plan.waves, dim3(grid, plan.groups), stream, N, W, packed, obs, obs_half, dlogits, dvalue,
-                                           workspace, P, rows, n_rows))
+                                           workspace, P, rows, n_rows, fold))
             return rc;
         RNAD_HIP_OK(hipGetLastError());
     } else {
@@ -462,8 +491,13 @@ static int mlp_backward_launch(int64_t N, const int32_t *rows, const int64_t *n_
     }
     const int total = plan.total;
     const unsigned rgrid = (unsigned)((total + 63) / 64);
-    RNAD_DISPATCH_A(A, hipLaunchKernelGGL((k_mlp_reduce<kA>), dim3(rgrid), dim3(64, kReduceSlices), 0, stream, grid, W, P, workspace, g_vw0, g_vb0,
-                                          g_vw1, g_vb1, g_pw0, g_pb0, g_pw1, g_pb1));
+    if (fold) {
+        RNAD_DISPATCH_A(A, hipLaunchKernelGGL((k_mlp_reduce<kA, true>), dim3(rgrid), dim3(64, kReduceSlices), 0, stream, grid, W, P, workspace,
+                                              g_vw0, g_vb0, g_vw1, g_vb1, g_pw0, g_pb0, g_pw1, g_pb1));
+    } else {
+        RNAD_DISPATCH_A(A, hipLaunchKernelGGL((k_mlp_reduce<kA, false>), dim3(rgrid), dim3(64, kReduceSlices), 0, stream, grid, W, P, workspace,
+                                              g_vw0, g_vb0, g_vw1, g_vb1, g_pw0, g_pb0, g_pw1, g_pb1));
+    }
     RNAD_HIP_OK(hipGetLastError());
     return 0;
 }
@@ -482,4 +516,15 @@ extern "C" int rnad_mlp_backward_rows(int64_t max_rows, const int32_t *rows, con
     RNAD_REQUIRE(rows && n_rows, "rnad_mlp_backward_rows: null row list");
     return mlp_backward_launch(max_rows, rows, n_rows, A, W, packed, obs, obs_half, dlogits, dvalue, g_vw0, g_vb0, g_vw1, g_vb1, g_pw0,
                                g_pb0, g_pw1, g_pb1, workspace, stream);
+}
+
+// The FOLD instantiation (mlp_common.hpp "the legal fold"; packed: rnad_mlp_pack_fold_multi; obs rows as in rnad_mlp_forward_fold): the
+// gradients of the eight ORIGINAL Linear tensors.  rows / n_rows: NULL or a row list (N = its capacity).  workspace:
+// rnad_mlp_backward_workspace(N, A, W) bytes are enough.
+extern "C" int rnad_mlp_backward_fold(int64_t N, const int32_t *rows, const int64_t *n_rows, int A, int W, const float *packed, const void *obs,
+                                      int obs_half, const float *dlogits, const float *dvalue, float *g_vw0, float *g_vb0, float *g_vw1,
+                                      float *g_vb1, float *g_pw0, float *g_pb0, float *g_pw1, float *g_pb1, float *workspace, void *stream) {
+    RNAD_REQUIRE(!rows == !n_rows, "rnad_mlp_backward_fold: rows and n_rows go together");
+    return mlp_backward_launch(N, rows, n_rows, A, W, packed, obs, obs_half, dlogits, dvalue, g_vw0, g_vb0, g_vw1, g_vb1, g_pw0, g_pb0, g_pw1,
+                               g_pb1, workspace, stream, true);
 }

@@ -21,13 +21,15 @@ using namespace rnad_mlp;
 
 namespace rnad_mlp {
 
-template <int A, typename ObsT, int WAVES>
+template <int A, typename ObsT, int WAVES, bool FOLD>
 __global__ __launch_bounds__(64 * WAVES) void k_mlp_backward_t(int64_t N, int W, const float *__restrict__ packed,
                                                               const ObsT *__restrict__ obs, const float *__restrict__ dlogit,
                                                               const float *__restrict__ dv, float *__restrict__ partial, int P,
                                                               const int32_t *__restrict__ rows, const int64_t *__restrict__ n_rows) {
     if (n_rows) N = *n_rows;  // row-list launch: sample s is row rows[s]; the count lives in device memory
-    constexpr int K = 2 * A * A, KS = K / 2;
+    // FOLD (mlp_common.hpp "the legal fold"): K = A^2 + 1 (+ padding) input features -- the expected values and the absorbing-state
+    // indicator --, the legal columns of the raw weight image folded into this wave's bias and indicator weight below
+    constexpr int K = MlpShape<A, FOLD>::K, KS = K / 2, OBS = MlpShape<A, FOLD>::OBS;
     constexpr int FT = (K + 1 + kTile - 1) / kTile, FW = FT * kTile;  // row stride of dW0aug in the partial buffer
     constexpr int REM = (K + 1) % 16, N16 = (K + 1) / 16 + (REM > 4 ? 1 : 0), LO = REM > 4 ? 0 : REM;
     constexpr int N16R = N16 > 0 ? N16 : 1;
@@ -53,14 +55,19 @@ __global__ __launch_bounds__(64 * WAVES) void k_mlp_backward_t(int64_t N, int W,
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) {
             const int h = (hd ? tile_p : tile_v) * kTile + 16 * mt + m16;  // row of the stacked [2W] first layer
+            float b = packed[img_b0(K, W) + h], w_ind = 0.0f;
+            if constexpr (FOLD) {
+                const float *lc = packed + img_legal(K, W, A) + h;
+                fold_hidden_unit<A>([&](int k) { return lc[k * 2 * W]; }, b, b, w_ind);
+            }
 #pragma unroll
             for (int kk = 0; kk < KQ; ++kk) {
                 const int k = 4 * kk + q;
                 float w = 0.0f;
                 if (k < K) w = packed[(h / kTile) * (KS * 64) + (k / 2) * 64 + (k % 2) * 32 + (h % kTile)];
+                if (FOLD && k == A * A) w = w_ind;
                 wB[hd][mt][kk] = w;
             }
-            const float b = packed[img_b0(K, W) + h];
             bias4[hd][mt] = f32x4{b, b, b, b};
         }
     float w1v_[2], w1p_[A][2];
@@ -99,7 +106,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_mlp_backward_t(int64_t N, int W,
 #pragma unroll
         for (int u = 0; u < XU; ++u) {
             const int k = part + u * TPS;
-            pre_x[u] = (in && k < K) ? load_obs<ObsT>(obs + row * K + k) : 0.0f;
+            pre_x[u] = (in && k < K) ? obs_feature<A, FOLD, ObsT>(obs + row * OBS, k) : 0.0f;
         }
         pre_dv = (in && part == 0) ? dv[row] : 0.0f;
 #pragma unroll
@@ -283,58 +290,64 @@ __global__ __launch_bounds__(64 * WAVES) void k_mlp_backward_t(int64_t N, int W,
 }
 
 // Launch: WAVES = 4 waves per block (a quarter of the hidden tiles of width 128 per head); the block's LDS is only the stage.
-template <int A, typename ObsT>
+template <int A, typename ObsT, bool FOLD>
 static void launch_t(int waves, dim3 grid, size_t lds_bytes, hipStream_t stream, int64_t N, int W, const float *packed, const void *obs,
                      const float *dlogits, const float *dvalue, float *workspace, int P, const int32_t *rows, const int64_t *n_rows) {
     switch (waves) {
-        case 8: hipLaunchKernelGGL((k_mlp_backward_t<A, ObsT, 8>), grid, dim3(512), lds_bytes, stream, N, W, packed, (const ObsT *)obs, dlogits, dvalue, workspace, P, rows, n_rows); break;
-        case 4: hipLaunchKernelGGL((k_mlp_backward_t<A, ObsT, 4>), grid, dim3(256), lds_bytes, stream, N, W, packed, (const ObsT *)obs, dlogits, dvalue, workspace, P, rows, n_rows); break;
-        case 2: hipLaunchKernelGGL((k_mlp_backward_t<A, ObsT, 2>), grid, dim3(128), lds_bytes, stream, N, W, packed, (const ObsT *)obs, dlogits, dvalue, workspace, P, rows, n_rows); break;
-        default: hipLaunchKernelGGL((k_mlp_backward_t<A, ObsT, 1>), grid, dim3(64), lds_bytes, stream, N, W, packed, (const ObsT *)obs, dlogits, dvalue, workspace, P, rows, n_rows); break;
+        case 8: hipLaunchKernelGGL((k_mlp_backward_t<A, ObsT, 8, FOLD>), grid, dim3(512), lds_bytes, stream, N, W, packed, (const ObsT *)obs, dlogits, dvalue, workspace, P, rows, n_rows); break;
+        case 4: hipLaunchKernelGGL((k_mlp_backward_t<A, ObsT, 4, FOLD>), grid, dim3(256), lds_bytes, stream, N, W, packed, (const ObsT *)obs, dlogits, dvalue, workspace, P, rows, n_rows); break;
+        case 2: hipLaunchKernelGGL((k_mlp_backward_t<A, ObsT, 2, FOLD>), grid, dim3(128), lds_bytes, stream, N, W, packed, (const ObsT *)obs, dlogits, dvalue, workspace, P, rows, n_rows); break;
+        default: hipLaunchKernelGGL((k_mlp_backward_t<A, ObsT, 1, FOLD>), grid, dim3(64), lds_bytes, stream, N, W, packed, (const ObsT *)obs, dlogits, dvalue, workspace, P, rows, n_rows); break;
     }
 }
 
 // Resident blocks per CU of the instantiation that a launch would use (register-limited: the LDS stage is small), asked of the
 // runtime once per shape.  The grid is sized to exactly that many persistent blocks: more would run as a second, half-empty round.
-template <int A, typename ObsT>
+template <int A, typename ObsT, bool FOLD>
 static int occupancy_t(int waves, size_t lds_bytes) {
     int n = 0;
     hipError_t e;
     switch (waves) {
-        case 8: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_mlp_backward_t<A, ObsT, 8>, 512, lds_bytes); break;
-        case 4: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_mlp_backward_t<A, ObsT, 4>, 256, lds_bytes); break;
-        case 2: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_mlp_backward_t<A, ObsT, 2>, 128, lds_bytes); break;
-        default: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_mlp_backward_t<A, ObsT, 1>, 64, lds_bytes); break;
+        case 8: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_mlp_backward_t<A, ObsT, 8, FOLD>, 512, lds_bytes); break;
+        case 4: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_mlp_backward_t<A, ObsT, 4, FOLD>, 256, lds_bytes); break;
+        case 2: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_mlp_backward_t<A, ObsT, 2, FOLD>, 128, lds_bytes); break;
+        default: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_mlp_backward_t<A, ObsT, 1, FOLD>, 64, lds_bytes); break;
     }
     return (e == hipSuccess && n > 0) ? n : 1;
 }
 
-size_t mlp_backward_t_lds(int A);
+size_t mlp_backward_t_lds(int A, bool fold);
 
-int mlp_backward_t_blocks_per_cu(int A, int waves) {
-    static int cache[RNAD_MAX_ACTIONS + 1][9] = {};
+int mlp_backward_t_blocks_per_cu(int A, int waves, bool fold) {
+    static int cache[2][RNAD_MAX_ACTIONS + 1][9] = {};
     if (A < 1 || A > RNAD_MAX_ACTIONS || waves < 1 || waves > 8) return 1;
-    if (cache[A][waves] == 0) {
-        const size_t lds_bytes = mlp_backward_t_lds(A);
+    if (cache[fold][A][waves] == 0) {
+        const size_t lds_bytes = mlp_backward_t_lds(A, fold);
         int n = 1;
-        RNAD_DISPATCH_A(A, n = occupancy_t<kA, float>(waves, lds_bytes));  // the fp16-observation instantiation uses the same registers
-        cache[A][waves] = n;
+        // (the fp16-observation instantiation uses the same registers)
+        RNAD_DISPATCH_A(A, n = fold ? occupancy_t<kA, float, true>(waves, lds_bytes) : occupancy_t<kA, float, false>(waves, lds_bytes));
+        cache[fold][A][waves] = n;
     }
-    return cache[A][waves];
+    return cache[fold][A][waves];
 }
 
-size_t mlp_backward_t_lds(int A) {
-    const int K = 2 * A * A;
+size_t mlp_backward_t_lds(int A, bool fold) {
+    const int K = fold ? mlp_fold_k(A) : 2 * A * A;
     return (size_t)2 * (kTile * bwd_stage_stride(K) + kTile + kTile * A + 4 * kTile) * sizeof(float);
 }
 
 int mlp_backward_t_launch(int A, int waves, dim3 grid, hipStream_t stream, int64_t N, int W, const float *packed, const void *obs,
                            int obs_half, const float *dlogits, const float *dvalue, float *workspace, int P, const int32_t *rows,
-                           const int64_t *n_rows) {
-    const size_t lds_bytes = mlp_backward_t_lds(A);
+                           const int64_t *n_rows, bool fold) {
+    const size_t lds_bytes = mlp_backward_t_lds(A, fold);
     RNAD_DISPATCH_A(A, {
-        if (obs_half) launch_t<kA, __half>(waves, grid, lds_bytes, stream, N, W, packed, obs, dlogits, dvalue, workspace, P, rows, n_rows);
-        else launch_t<kA, float>(waves, grid, lds_bytes, stream, N, W, packed, obs, dlogits, dvalue, workspace, P, rows, n_rows);
+        if (fold) {
+            if (obs_half) launch_t<kA, __half, true>(waves, grid, lds_bytes, stream, N, W, packed, obs, dlogits, dvalue, workspace, P, rows, n_rows);
+            else launch_t<kA, float, true>(waves, grid, lds_bytes, stream, N, W, packed, obs, dlogits, dvalue, workspace, P, rows, n_rows);
+        } else {
+            if (obs_half) launch_t<kA, __half, false>(waves, grid, lds_bytes, stream, N, W, packed, obs, dlogits, dvalue, workspace, P, rows, n_rows);
+            else launch_t<kA, float, false>(waves, grid, lds_bytes, stream, N, W, packed, obs, dlogits, dvalue, workspace, P, rows, n_rows);
+        }
     });
     return 0;
 }

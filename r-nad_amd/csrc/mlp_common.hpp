@@ -37,6 +37,23 @@ __host__ __device__ constexpr int img_floats(int K, int W, int A) { return img_b
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// ---------------------------------------------------------------------------------------------------------------- the legal fold
+// An observation is [expected value A x A | legal mask A x A] from the mover's point of view (environment/episode.py:62-68).  On a tree
+// whose states all have the full A x A action set (every configuration of BASELINE.json) the legal plane is the SAME in every row --
+// all ones -- except in the two rows of the absorbing state, where it is e0 = [1, 0, ..., 0] (tree.py:133 with one action each).  The
+// first layer then is   z = W_ev ev + (b0 + W_legal 1) + [row is absorbing] (W_legal e0 - W_legal 1):
+// A^2 + 1 input features (the expected values and the indicator 1 - legal[0][1]) instead of 2 A^2, i.e. 5 MFMA k-steps instead of 9 at
+// A = 3 -- the same function of the same weights, summed in another order.  The FOLD instantiations of the MLP kernels take the
+// observations in the usual layout (row stride 2 A^2), read only what they need, and fold the legal columns of the weight image into
+// the bias and the indicator column when they load it (the image keeps the raw weights: the optimiser writes it element by element).
+//   MlpShape<A, FOLD>::K   input features of the first layer as the kernels see them (even: an MFMA k-step takes two)
+template <int A, bool FOLD>
+struct MlpShape {
+    static constexpr int OBS = 2 * A * A;                             // floats of an observation row
+    static constexpr int K = FOLD ? ((A * A + 2) & ~1) : 2 * A * A;  // FOLD: ev [A^2] | indicator | zero padding to an even count
+    static constexpr int KS = K / 2;
+};
+
 // Weight image -> LDS, 16 bytes per lane and request.  Eight requests are in flight per lane before the first LDS write: a
 // plain copy loop waits for every global load in turn (an L2 round trip per 4 KiB), which is most of a rollout-step launch
 // at 2^17 samples.
@@ -56,12 +73,40 @@ __device__ __forceinline__ void load_image(const float *__restrict__ packed, flo
     for (; i < n4; i += NT) dst[i] = src[i];
 }
 
+// raw legal columns of a FOLD image, after the output biases: [A^2][2W] (column major: the fold reads them coalesced over hidden units)
+__host__ __device__ constexpr int img_legal(int K, int W, int A) { return img_b1(K, W, A) + kB1Pad; }
+__host__ __device__ constexpr int img_floats_fold(int K, int W, int A) { return img_legal(K, W, A) + A * A * 2 * W; }
+
 template <typename T>
 __device__ __forceinline__ float load_obs(const T *p);
 template <>
 __device__ __forceinline__ float load_obs<float>(const float *p) { return *p; }
 template <>
 __device__ __forceinline__ float load_obs<__half>(const __half *p) { return __half2float(*p); }
+
+// Input feature k of an observation row as the first layer sees it.
+template <int A, bool FOLD, typename T>
+__device__ __forceinline__ float obs_feature(const T *row, int k) {
+    if constexpr (!FOLD) {
+        return load_obs<T>(row + k);
+    } else {
+        if (k < A * A) return load_obs<T>(row + k);
+        if (k == A * A) return 1.0f - load_obs<T>(row + A * A + (A > 1 ? 1 : 0));  // 1 in the rows of the absorbing state, else 0
+        return 0.0f;
+    }
+}
+
+// FOLD: what a kernel does to the first layer of a freshly loaded weight image (`img`: LDS or registers behind a lambda):
+//   s = sum_k W_legal[h][k] (k ascending), b0'[h] = b0[h] + s, w_ind[h] = W_legal[h][0] - s.
+// The same order everywhere, so the recomputed hidden layer of the backward is the forward's.
+template <int A, typename Load>
+__device__ __forceinline__ void fold_hidden_unit(Load legal_col, float b0, float &b0_folded, float &w_ind) {
+    float s = 0.0f;
+#pragma unroll
+    for (int k = 0; k < A * A; ++k) s += legal_col(k);
+    b0_folded = b0 + s;
+    w_ind = legal_col(0) - s;
+}
 
 // One hidden tile of the first layer for one 32-sample tile (the backward's recompute; the forward has its own
 // two-sample-tile variant in mlp_fwd.hip).  z tile = b0 + W0 x.  The accumulator starts as the first-layer bias of this lane's
@@ -96,5 +141,7 @@ __host__ __device__ constexpr int bwd_stage_stride(int K) {
 }
 
 static inline int mlp_packed_floats(int A, int W) { return img_floats(2 * A * A, W, A); }
+static inline int mlp_fold_k(int A) { return (A * A + 2) & ~1; }
+static inline int mlp_packed_floats_fold(int A, int W) { return img_floats_fold(mlp_fold_k(A), W, A); }
 
 }  // namespace rnad_mlp

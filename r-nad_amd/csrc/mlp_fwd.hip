@@ -62,10 +62,10 @@ __device__ __forceinline__ void epilogue_policy(const f32x16 &c, const float *__
 // First layer for ONE hidden tile and TWO 32-sample tiles: the A operand (weights) and the bias tile are read from LDS once
 // and feed two independent accumulator chains.  The first-layer bias enters as the C operand of each chain's first MFMA
 // (destination != source, so no register copies and no tenth MFMA).
-template <int A>
-__device__ __forceinline__ void mfma_chain2(const float *__restrict__ lds, int W, int tile, int col, int half, const float (&x0)[A * A],
-                                            const float (&x1)[A * A], f32x16 &c0, f32x16 &c1) {
-    constexpr int K = 2 * A * A, KS = A * A;
+template <int KS>
+__device__ __forceinline__ void mfma_chain2(const float *__restrict__ lds, int W, int tile, int col, int half, const float (&x0)[KS],
+                                            const float (&x1)[KS], f32x16 &c0, f32x16 &c1) {
+    constexpr int K = 2 * KS;
     const float *wa = lds + tile * (KS * 64) + half * 32 + col;
     const float *brow = lds + img_b0(K, W) + tile * kTile + 4 * half;
     float a[KS];
@@ -101,7 +101,7 @@ struct NetSet {
     int first_block[5];  // workgroups [first_block[i], first_block[i + 1]) serve net i
 };
 
-template <int A, typename ObsT, int HEADS>
+template <int A, typename ObsT, int HEADS, bool FOLD>
 __global__ __launch_bounds__(kFwdThreads) void k_mlp_forward(int64_t N, int W, NetSet nets, const ObsT *__restrict__ obs,
                                                              const int32_t *__restrict__ rows, const int64_t *__restrict__ n_rows) {
     int net = 0;
@@ -114,10 +114,21 @@ __global__ __launch_bounds__(kFwdThreads) void k_mlp_forward(int64_t N, int W, N
     // rows != null: sample s of this launch is row rows[s] of obs / logits / value, and the sample count comes from device
     // memory (rnad_compact_valid's output: no host round trip between the compaction and this launch)
     if (n_rows) N = *n_rows;
-    constexpr int K = 2 * A * A, KS = K / 2;  // MFMA k-steps per hidden tile
+    constexpr int K = MlpShape<A, FOLD>::K, KS = K / 2, OBS = MlpShape<A, FOLD>::OBS;  // KS: MFMA k-steps per hidden tile
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    load_image<kFwdThreads>(packed, lds, img_floats(K, W, A) / 4);  // the image rnad_mlp_pack laid out, copied as is
+    load_image<kFwdThreads>(packed, lds, (FOLD ? img_floats_fold(K, W, A) : img_floats(K, W, A)) / 4);  // the image rnad_mlp_pack laid out, copied as is
     __syncthreads();
+    if constexpr (FOLD) {  // the legal columns of the raw weights -> bias and indicator column (mlp_common.hpp)
+        for (int h = threadIdx.x; h < 2 * W; h += kFwdThreads) {
+            const float *lc = lds + img_legal(K, W, A) + h;
+            float b, wi;
+            fold_hidden_unit<A>([&](int k) { return lc[k * 2 * W]; }, lds[img_b0(K, W) + h], b, wi);
+            lds[img_b0(K, W) + h] = b;
+            constexpr int kk = A * A;  // the indicator's input slot
+            lds[(h / kTile) * (KS * 64) + (kk / 2) * 64 + (kk % 2) * 32 + (h % kTile)] = wi;
+        }
+        __syncthreads();
+    }
     const float *w1v = lds + img_w1v(K, W);
     const float *w1p = lds + img_w1p(K, W);
     const float *b1 = lds + img_b1(K, W, A);  // [1 + A]: value_fc1.bias, policy_fc1.bias
@@ -140,7 +151,7 @@ __global__ __launch_bounds__(kFwdThreads) void k_mlp_forward(int64_t N, int W, N
             const int64_t sample = span * kSpan + s * kTile + col;
             const int64_t row = (rows && sample < N) ? (int64_t)rows[sample] : sample;
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks) xn[s][ks] = sample < N ? load_obs<ObsT>(obs + row * K + 2 * ks + half) : 0.0f;
+            for (int ks = 0; ks < KS; ++ks) xn[s][ks] = sample < N ? obs_feature<A, FOLD, ObsT>(obs + row * OBS, 2 * ks + half) : 0.0f;
         }
     };
     if (span0 < n_spans) fetch(span0);
@@ -160,7 +171,7 @@ __global__ __launch_bounds__(kFwdThreads) void k_mlp_forward(int64_t N, int W, N
         if ((HEADS & 1) && value) {  // (uniform: a net of the launch that does not want this head skips it)
             for (int t = 0; t < T; ++t) {
                 f32x16 c0, c1;
-                mfma_chain2<A>(lds, W, t, col, half, x0, x1, c0, c1);
+                mfma_chain2<KS>(lds, W, t, col, half, x0, x1, c0, c1);
                 epilogue_value(c0, w1v + t * kTile + 4 * half, acc_v[0]);
                 epilogue_value(c1, w1v + t * kTile + 4 * half, acc_v[1]);
             }
@@ -168,7 +179,7 @@ __global__ __launch_bounds__(kFwdThreads) void k_mlp_forward(int64_t N, int W, N
         if ((HEADS & 2) && logits) {
             for (int t = 0; t < T; ++t) {
                 f32x16 c0, c1;
-                mfma_chain2<A>(lds, W, T + t, col, half, x0, x1, c0, c1);
+                mfma_chain2<KS>(lds, W, T + t, col, half, x0, x1, c0, c1);
                 epilogue_policy<A>(c0, w1p + t * kTile + 4 * half, W, acc_p[0]);
                 epilogue_policy<A>(c1, w1p + t * kTile + 4 * half, W, acc_p[1]);
             }
@@ -204,12 +215,14 @@ struct PackSet {
     float *packed[4];
 };
 
-__global__ __launch_bounds__(kThreads) void k_mlp_pack(int A, int W, PackSet ps, int total) {
+__global__ __launch_bounds__(kThreads) void k_mlp_pack(int A, int W, PackSet ps, int total, int fold) {
     const float *const *w = ps.w[blockIdx.y];
     const float *__restrict__ vw0 = w[0], *__restrict__ vb0 = w[1], *__restrict__ vw1 = w[2], *__restrict__ vb1 = w[3];
     const float *__restrict__ pw0 = w[4], *__restrict__ pb0 = w[5], *__restrict__ pw1 = w[6], *__restrict__ pb1 = w[7];
     float *__restrict__ packed = ps.packed[blockIdx.y];
-    const int K = 2 * A * A, KS = A * A;
+    // fold: the first-layer region holds the A^2 expected-value columns (the indicator slot and the padding stay zero: the kernels
+    // fill the slot when they load the image), the raw legal columns follow the output biases
+    const int OBS = 2 * A * A, K = fold ? ((A * A + 2) & ~1) : OBS, KS = K / 2;
     const int i = blockIdx.x * kThreads + threadIdx.x;
     if (i >= total) return;
     float x = 0.0f;
@@ -217,7 +230,10 @@ __global__ __launch_bounds__(kThreads) void k_mlp_pack(int A, int W, PackSet ps,
         const int tile = i / (KS * 64), rem = i % (KS * 64);
         const int ks = rem / 64, half = (rem % 64) / 32, col = rem % 32;
         const int h = tile * kTile + col, k = 2 * ks + half;
-        x = h < W ? vw0[h * K + k] : pw0[(h - W) * K + k];
+        if (!fold || k < A * A) x = h < W ? vw0[h * OBS + k] : pw0[(h - W) * OBS + k];
+    } else if (fold && i >= img_legal(K, W, A)) {
+        const int r = i - img_legal(K, W, A), k = r / (2 * W), h = r % (2 * W);
+        x = h < W ? vw0[h * OBS + A * A + k] : pw0[(h - W) * OBS + A * A + k];
     } else if (i < img_w1v(K, W)) {
         const int h = i - img_b0(K, W);
         x = h < W ? vb0[h] : pb0[h - W];
@@ -237,7 +253,20 @@ __global__ __launch_bounds__(kThreads) void k_mlp_pack(int A, int W, PackSet ps,
 
 extern "C" int64_t rnad_mlp_packed_size(int A, int W) { return mlp_packed_floats(A, W); }
 
+static int mlp_pack_launch(int n_nets, int A, int W, const float *const *weights, float *const *packed, int fold, void *stream);
+
 extern "C" int rnad_mlp_pack_multi(int n_nets, int A, int W, const float *const *weights, float *const *packed, void *stream) {
+    return mlp_pack_launch(n_nets, A, W, weights, packed, 0, stream);
+}
+
+extern "C" int64_t rnad_mlp_fold_packed_size(int A, int W) { return mlp_packed_floats_fold(A, W); }
+
+extern "C" int rnad_mlp_pack_fold_multi(int n_nets, int A, int W, const float *const *weights, float *const *packed, void *stream) {
+    RNAD_REQUIRE(A >= 2, "rnad_mlp_pack_fold: the legal fold needs at least two actions");
+    return mlp_pack_launch(n_nets, A, W, weights, packed, 1, stream);
+}
+
+static int mlp_pack_launch(int n_nets, int A, int W, const float *const *weights, float *const *packed, int fold, void *stream) {
     RNAD_REQUIRE(n_nets >= 1 && n_nets <= 4 && weights && packed, "rnad_mlp_pack_multi: 1..4 nets");
     RNAD_REQUIRE(A >= 1 && A <= RNAD_MAX_ACTIONS && W >= kTile && W % kTile == 0, "rnad_mlp_pack: bad shape (A=%d, width=%d)", A, W);
     PackSet ps{};
@@ -249,8 +278,8 @@ extern "C" int rnad_mlp_pack_multi(int n_nets, int A, int W, const float *const 
         RNAD_REQUIRE(packed[i], "rnad_mlp_pack: null output %d", i);
         ps.packed[i] = packed[i];
     }
-    const int total = mlp_packed_floats(A, W);
-    hipLaunchKernelGGL(k_mlp_pack, dim3((total + kThreads - 1) / kThreads, n_nets), dim3(kThreads), 0, (hipStream_t)stream, A, W, ps, total);
+    const int total = fold ? mlp_packed_floats_fold(A, W) : mlp_packed_floats(A, W);
+    hipLaunchKernelGGL(k_mlp_pack, dim3((total + kThreads - 1) / kThreads, n_nets), dim3(kThreads), 0, (hipStream_t)stream, A, W, ps, total, fold);
     RNAD_HIP_OK(hipGetLastError());
     return 0;
 }
@@ -263,7 +292,7 @@ extern "C" int rnad_mlp_pack(int A, int W, const float *vw0, const float *vb0, c
 }
 
 static int mlp_forward_launch(int64_t N, const int32_t *rows, const int64_t *n_rows, int A, int W, int n_nets, const NetSet &nets,
-                              const void *obs, int obs_half, void *stream_) {
+                              const void *obs, int obs_half, void *stream_, bool fold = false) {
     RNAD_REQUIRE(obs && n_nets >= 1 && n_nets <= 4, "rnad_mlp_forward: null argument");
     for (int i = 0; i < n_nets; ++i)
         RNAD_REQUIRE(nets.packed[i] && (nets.logits[i] || nets.value[i]), "rnad_mlp_forward: null argument (net %d)", i);
@@ -271,9 +300,8 @@ static int mlp_forward_launch(int64_t N, const int32_t *rows, const int64_t *n_r
     RNAD_REQUIRE(N >= 0, "rnad_mlp_forward: negative batch");
     if (N == 0) return 0;
     hipStream_t stream = (hipStream_t)stream_;
-    const int K = 2 * A * A;
-    (void)K;
-    const size_t lds_bytes = (size_t)mlp_packed_floats(A, W) * sizeof(float);
+    RNAD_REQUIRE(!fold || A >= 2, "rnad_mlp_forward_fold: the legal fold needs at least two actions");
+    const size_t lds_bytes = (size_t)(fold ? mlp_packed_floats_fold(A, W) : mlp_packed_floats(A, W)) * sizeof(float);
     RNAD_REQUIRE(lds_bytes <= 160 * 1024, "rnad_mlp_forward: weights (%zu B) do not fit the 160 KiB LDS (A=%d, width=%d)", lds_bytes, A, W);
     int dev = 0, cus = 256;
     RNAD_HIP_OK(hipGetDevice(&dev));
@@ -295,7 +323,7 @@ static int mlp_forward_launch(int64_t N, const int32_t *rows, const int64_t *n_r
     ProfScope prof(PROF_MLP, stream);
 #define RNAD_MLP_LAUNCH2(T_, H_)                                                                                                  \
     do {                                                                                                                           \
-        auto kern = k_mlp_forward<kA, T_, H_>;                                                                                     \
+        auto kern = fold ? k_mlp_forward<kA, T_, H_, true> : k_mlp_forward<kA, T_, H_, false>;                                     \
         if (lds_bytes > 64 * 1024)                                                                                       \
             RNAD_HIP_OK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes)); \
         hipLaunchKernelGGL(kern, dim3(grid), dim3(kFwdThreads), lds_bytes, stream, N, W, launch, (const T_ *)obs, rows, n_rows);            \
@@ -344,4 +372,20 @@ extern "C" int rnad_mlp_forward_rows(int64_t max_rows, const int32_t *rows, cons
     NetSet nets{};
     nets.packed[0] = packed; nets.logits[0] = logits; nets.value[0] = value;
     return mlp_forward_launch(max_rows, rows, n_rows, A, W, 1, nets, obs, obs_half, stream);
+}
+
+// The FOLD instantiation (mlp_common.hpp "the legal fold"): `packed` images from rnad_mlp_pack_fold_multi; every row of `obs` must carry
+// an all-ones legal plane or e0 = [1, 0, ..., 0] (the caller checks its table once).  rows / n_rows: NULL, or a row list as in
+// rnad_mlp_forward_rows (N is then the capacity of the list).
+extern "C" int rnad_mlp_forward_fold(int n_nets, int64_t N, const int32_t *rows, const int64_t *n_rows, int A, int W,
+                                     const float *const *packed, const void *obs, int obs_half, float *const *logits, float *const *value,
+                                     void *stream) {
+    RNAD_REQUIRE(n_nets >= 1 && n_nets <= 4 && packed && logits && value, "rnad_mlp_forward_fold: 1..4 nets");
+    RNAD_REQUIRE(!rows == !n_rows, "rnad_mlp_forward_fold: rows and n_rows go together");
+    NetSet nets{};
+    for (int i = 0; i < n_nets; ++i) {
+        RNAD_REQUIRE(logits[i] || value[i], "rnad_mlp_forward_fold: net %d wants no output", i);
+        nets.packed[i] = packed[i]; nets.logits[i] = logits[i]; nets.value[i] = value[i];
+    }
+    return mlp_forward_launch(N, rows, n_rows, A, W, n_nets, nets, obs, obs_half, stream, true);
 }

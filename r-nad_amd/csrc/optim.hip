@@ -36,13 +36,16 @@ __device__ unsigned int g_ticket = 0;  // one optimiser step at a time per devic
 
 // Where element e of Linear tensor k (MLP_KEYS order: value_fc0.weight, .bias, value_fc1.weight, .bias, policy_fc0.weight, ...) sits in
 // the packed LDS image the MLP kernels read (mlp_common.hpp; k_mlp_pack is the forward map).
-__device__ __forceinline__ int image_index(int k, int e, int A, int W) {
+// fold: the image of the FOLD kernels (rnad_mlp_pack_fold_multi): the expected-value columns in the first-layer region, the raw legal
+// columns in their own region behind the output biases.
+__device__ __forceinline__ int image_index(int k, int e, int A, int W, bool fold) {
     using namespace rnad_mlp;
-    const int K = 2 * A * A, KS = A * A;
+    const int OBS = 2 * A * A, K = fold ? ((A * A + 2) & ~1) : OBS, KS = K / 2;
     switch (k) {
         case 0:
         case 4: {
-            const int h = e / K + (k == 4 ? W : 0), kk = e % K;
+            const int h = e / OBS + (k == 4 ? W : 0), kk = e % OBS;
+            if (fold && kk >= A * A) return img_legal(K, W, A) + (kk - A * A) * 2 * W + h;
             return (h / kTile) * (KS * 64) + (kk / 2) * 64 + (kk % 2) * 32 + (h % kTile);
         }
         case 1: return img_b0(K, W) + e;
@@ -58,7 +61,7 @@ __device__ __forceinline__ int image_index(int k, int e, int A, int W) {
 // weight) is also written into its slot of the packed images packed_param / packed_target -- the images the next step's forward and
 // backward kernels read, kept current here instead of by a k_mlp_pack launch per step.
 __global__ __launch_bounds__(kOptThreads) void k_optimizer_step(OptTensors ts, const float *__restrict__ grads, rnad_adam_params_t hp,
-                                                                float *__restrict__ total_norm, int mlp_A, int mlp_W,
+                                                                float *__restrict__ total_norm, int mlp_A, int mlp_W, int mlp_fold,
                                                                 float *__restrict__ packed_param, float *__restrict__ packed_target) {
     __shared__ double part[kOptThreads / 64];
     __shared__ float coef_s, step_size_s[kMaxTensors], bc2s_s[kMaxTensors];
@@ -133,7 +136,7 @@ __global__ __launch_bounds__(kOptThreads) void k_optimizer_step(OptTensors ts, c
     const float t_new = tg * (1.0f - hp.ema) + hp.ema * p_new;
     if (pt) *pt = t_new;
     if (mlp_A > 0) {
-        const int at = image_index(k, e, mlp_A, mlp_W);
+        const int at = image_index(k, e, mlp_A, mlp_W, mlp_fold != 0);
         if (packed_param) packed_param[at] = p_new;
         if (packed_target && pt) packed_target[at] = t_new;
     }
@@ -143,7 +146,8 @@ __global__ __launch_bounds__(kOptThreads) void k_optimizer_step(OptTensors ts, c
 
 extern "C" int rnad_optimizer_step(int n_tensors, const int64_t *sizes, float *const *param, float *grads, float *const *exp_avg,
                                    float *const *exp_avg_sq, float *const *step, float *const *target, const rnad_adam_params_t *hp,
-                                   float *total_norm, int mlp_A, int mlp_W, float *packed_param, float *packed_target, void *stream) {
+                                   float *total_norm, int mlp_A, int mlp_W, int mlp_fold, float *packed_param, float *packed_target,
+                                   void *stream) {
     RNAD_REQUIRE(sizes && param && grads && exp_avg && exp_avg_sq && step && hp, "rnad_optimizer_step: null argument");
     if (mlp_A > 0) {
         RNAD_REQUIRE(n_tensors == 8 && mlp_A <= RNAD_MAX_ACTIONS && mlp_W >= rnad_mlp::kTile && mlp_W % rnad_mlp::kTile == 0,
@@ -164,8 +168,9 @@ extern "C" int rnad_optimizer_step(int n_tensors, const int64_t *sizes, float *c
         ts.target[k] = target ? target[k] : nullptr;
     }
     const unsigned grid = (unsigned)std::max<int64_t>(1, (ts.offset[n_tensors] + kOptThreads - 1) / kOptThreads);
+    RNAD_REQUIRE(!mlp_fold || mlp_A >= 2, "rnad_optimizer_step: the legal fold needs at least two actions");
     hipLaunchKernelGGL(k_optimizer_step, dim3(grid), dim3(kOptThreads), 0, (hipStream_t)stream, ts, (const float *)grads, *hp, total_norm, mlp_A,
-                       mlp_W, mlp_A > 0 ? packed_param : nullptr, mlp_A > 0 ? packed_target : nullptr);
+                       mlp_W, mlp_fold, mlp_A > 0 ? packed_param : nullptr, mlp_A > 0 ? packed_target : nullptr);
     RNAD_HIP_OK(hipGetLastError());
     return 0;
 }

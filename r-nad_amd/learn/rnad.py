@@ -153,6 +153,10 @@ class RNaD:
         self.lazy_rows = None
         self.last_rows = None  # rnad_hip.LiveRows of the last lazy step
         self.fused_optimizer = True  # clip + Adam + EMA target of the MLP in one launch (csrc/optim.hip) instead of ~8 torch launches
+        # The legal fold (include/rnad_hip.h): on a tree whose observation rows all carry the same legal plane (all ones; e0 in the
+        # absorbing state) the table evaluations of the per-row mode run the MLP with A^2 + 1 input features instead of 2 A^2 -- the
+        # same function of the same weights in another summation order, ~45 % fewer matrix instructions in the first layer.
+        self.fold_legal = True
         # ragged trajectories: evaluate / differentiate the nets on live (t, b) slots only (see __learn); same losses and gradients
         self.skip_absorbed = True
         self.obs_half = False  # store observations as fp16 (BASELINE.json configs[4]); arithmetic stays fp32
@@ -373,23 +377,23 @@ class RNaD:
             clip=self.neurd_clip, threshold=self.beta, w_v=self.value_weight, w_n=self.neurd_weight,
             eps_threshold=self.epsilon_threshold, n_disc=self.n_discrete)
 
-    def _reg_tables(self, table):
+    def _reg_tables(self, table, fold=False):
         """Logits of net_reg and net_reg_ on the tree's 2S observations.  The regularisation nets are constant between two
         rotations (rnad.py:528-531), so their tables are evaluated when their weights change (tensor version counters: bumped by
         load_state_dict and by in-place edits under no_grad) and kept, in place: the buffers keep their addresses for as long as
         the observation table does (a captured graph of the step reads them).  Call invalidate_tables() after editing the nets
         in a way autograd's version counters do not see."""
         key = (id(self.net_reg), id(self.net_reg_), table.data_ptr(), tuple(table.shape),
-               sum(p._version for p in self.net_reg.parameters()), sum(p._version for p in self.net_reg_.parameters()))
+               sum(p._version for p in self.net_reg.parameters()), sum(p._version for p in self.net_reg_.parameters()), bool(fold))
         cache = getattr(self, "_reg_table_cache", None)
         if cache is None or cache["ident"] != key[:4]:
             cache = self._reg_table_cache = {"key": None, "ident": key[:4], "logit_reg": None, "logit_reg_": None}
         if cache["key"] != key:
             A = self.tree.max_actions
             with torch.no_grad():
-                outs = rnad_hip.mlp_forward_multi(rnad_hip.mlp_pack_many([self.net_reg._weights(), self.net_reg_._weights()], A),
+                outs = rnad_hip.mlp_forward_multi(rnad_hip.mlp_pack_many([self.net_reg._weights(), self.net_reg_._weights()], A, fold=fold),
                                                   self.net.width, table, A,
-                                                  [(True, False), (True, False)])
+                                                  [(True, False), (True, False)], fold=fold)
             for name, out in (("logit_reg", outs[0][0]), ("logit_reg_", outs[1][0])):
                 if cache[name] is None:
                     cache[name] = out
@@ -405,32 +409,43 @@ class RNaD:
         if cache is not None:
             cache["key"] = None
 
-    def _packed_images(self):
-        """(image of net, image of net_target): the packed weight layouts the fused MLP kernels read (rnad_hip.mlp_pack), in two
-        persistent buffers.  They are written here whenever the nets' tensors changed as far as torch can tell (version counters, data
-        pointers) and kept current by the one-launch optimiser tail (rnad_optimizer_step writes every new weight into both the
-        tensor and its image slot), so a training step carries no pack launch."""
+    def _fold(self):
+        """The table evaluations of the per-row mode use the FOLD kernels: asked for, and the tree's observation table allows it."""
+        return bool(getattr(self, "fold_legal", True)) and self.tree.handle().legal_foldable
+
+    def _packed_images(self, fold=None):
+        """(image of net, image of net_target): the packed weight layouts the fused MLP kernels read (rnad_hip.mlp_pack), in persistent
+        buffers -- one pair per layout (plain / FOLD).  The pair the one-launch optimiser tail maintains (rnad_optimizer_step writes
+        every new weight into the tensor AND its image slot: a training step carries no pack launch) is re-packed only when the nets'
+        tensors changed as far as torch can tell (version counters, data pointers); the other pair on every request.
+        fold: which layout (default: the maintained one)."""
         A = self.tree.max_actions
         ws = (self.net._weights(), self.net_target._weights())
+        cache = self.__dict__.setdefault("_packed_cache", {"layouts": {}, "maintained": None})
+        if fold is None:
+            fold = bool(cache["maintained"])
+        fold = bool(fold)
         key = tuple((id(w), w.data_ptr(), w._version) for group in ws for w in group)
-        cache = getattr(self, "_packed_cache", None)
-        if cache is None or cache["shape"] != (A, self.net.width, ws[0][0].device):
-            size = int(rnad_hip.lib().rnad_mlp_packed_size(A, self.net.width))
-            cache = self._packed_cache = {"shape": (A, self.net.width, ws[0][0].device), "key": None,
-                                          "images": [torch.empty((size,), dtype=torch.float32, device=ws[0][0].device) for _ in range(2)]}
-        if cache["key"] != key:
-            rnad_hip.mlp_pack_many(list(ws), A, out=cache["images"])
-            cache["key"] = key
-        return cache["images"]
+        shape = (A, self.net.width, ws[0][0].device)
+        entry = cache["layouts"].get(fold)
+        if entry is None or entry["shape"] != shape:
+            size = rnad_hip.mlp_packed_size(A, self.net.width, fold)
+            entry = cache["layouts"][fold] = {"shape": shape, "key": None,
+                                              "images": [torch.empty((size,), dtype=torch.float32, device=ws[0][0].device) for _ in range(2)]}
+        if entry["key"] != key or cache["maintained"] != fold:
+            rnad_hip.mlp_pack_many(list(ws), A, out=entry["images"], fold=fold)
+            entry["key"] = key
+        return entry["images"]
 
-    def _table_outputs(self, alpha, obs_half=False, want_target_logits=False, policy_only=False):
+    def _table_outputs(self, alpha, obs_half=False, want_target_logits=False, policy_only=False, fold=False):
         """learner / target / regularisation nets on the 2S observations of the tree (rnad.py:373-380 on every distinct input):
         learner and target in ONE launch per step, the two regularisation nets from _reg_tables.  Both regularisation tables are
         always there: a term of log_policy_reg (:382) whose weight is exactly 0 adds exactly 0.
         policy_only: the learner's logits alone (what the rollout needs); _value_tables adds the value heads on the visited rows."""
         A = self.tree.max_actions
         table = self.tree.handle().observations_table(obs_half)
-        packed, packed_target = self._packed_images()
+        packed, packed_target = self._packed_images(fold)
+        self._layout_in_use = bool(fold)  # (what the optimiser tail of this step will keep current)
         if policy_only:
             # lazy rows: the learner's policy head is evaluated in stages by the rollout (staged_actor below: the upper rows of the cut,
             # then the rows of the groups the batch descends into); rows no lane can reach stay uninitialised and are never read
@@ -438,19 +453,19 @@ class RNaD:
 
             def staged_actor(rows, packed=packed, logit=logit, table=table, width=self.net.width):
                 with torch.no_grad():
-                    rnad_hip.mlp_forward(packed, width, table, A, live=rows, out=(logit, None))
+                    rnad_hip.mlp_forward(packed, width, table, A, live=rows, out=(logit, None), fold=fold)
 
-            logit_reg, logit_reg_ = self._reg_tables(table)
+            logit_reg, logit_reg_ = self._reg_tables(table, fold)
             return dict(table=table, logit=logit, v=None, logit_target=None, v_target=None, logit_reg=logit_reg, logit_reg_=logit_reg_,
-                        packed_net=packed, packed_target=packed_target, staged_actor=staged_actor)
+                        packed_net=packed, packed_target=packed_target, staged_actor=staged_actor, fold=fold)
         with torch.no_grad():
             # (one launch entry per (net, head) -- three equal work units per 64-row span -- was measured: 45.5 instead of 43.4 us, every
             # workgroup loads its net's 43 KB weight image first)
             outs = rnad_hip.mlp_forward_multi([packed, packed_target], self.net.width, table, A,
-                                              [(True, True), (want_target_logits, True)])
-        logit_reg, logit_reg_ = self._reg_tables(table)
+                                              [(True, True), (want_target_logits, True)], fold=fold)
+        logit_reg, logit_reg_ = self._reg_tables(table, fold)
         return dict(table=table, logit=outs[0][0], v=outs[0][1], logit_target=outs[1][0], v_target=outs[1][1], logit_reg=logit_reg,
-                    logit_reg_=logit_reg_, packed_net=packed)
+                    logit_reg_=logit_reg_, packed_net=packed, fold=fold)
 
     def _value_tables(self, tables, visited, alpha, step_params=None):
         """Lazy rows, after the rollout: the learner's and the target's value heads, the row records and (in __learn) the gradient
@@ -459,9 +474,11 @@ class RNaD:
         rows = rnad_hip.compact_valid(visited)
         with torch.no_grad():
             # (the rows that are not listed are never read: records, gradient tables and the backward all go by the same list)
-            tables["v"] = rnad_hip.mlp_forward(tables["packed_net"], self.net.width, tables["table"], A, want_logits=False, live=rows, zero_rest=False)[1]
+            fold = tables.get("fold", False)
+            tables["v"] = rnad_hip.mlp_forward(tables["packed_net"], self.net.width, tables["table"], A, want_logits=False, live=rows, zero_rest=False,
+                                               fold=fold)[1]
             tables["v_target"] = rnad_hip.mlp_forward(tables["packed_target"], self.net.width, tables["table"], A, want_logits=False, live=rows,
-                                                      zero_rest=False)[1]
+                                                      zero_rest=False, fold=fold)[1]
         tables["records"], tables["fast_records"] = rnad_hip.bucket_records(
             handle, tables["logit"], tables["v"], tables["v_target"], tables["logit_reg"], tables["logit_reg_"], self._learn_params(alpha),
             step_params=step_params, fast=True, rows=rows)
@@ -524,7 +541,8 @@ class RNaD:
         table = None
         if mode:
             if tables is None:
-                tables = self._table_outputs(alpha, getattr(episodes, "obs_half", False), want_target_logits=log is not None)
+                tables = self._table_outputs(alpha, getattr(episodes, "obs_half", False), want_target_logits=log is not None,
+                                             fold=mode is True and self._fold())
             table = tables["table"]
         per_row_backward = table is not None and mode is True
         bucketed = per_row_backward and getattr(episodes, "buckets", None) is not None
@@ -614,8 +632,12 @@ class RNaD:
         if reuse or direct:
             weights = self.net._weights()
             flat, views = self._grad_bucket(weights)
-            packed = tables["packed_net"] if tables is not None and "packed_net" in tables else self.net.pack()  # same weights as the forward
-            rnad_hip.mlp_backward(packed, weights, backward_obs, A, dlogit.view(-1, A), dv.view(-1, 1), live=live, out=views)
+            fold = tables is not None and tables.get("fold", False)
+            if fold and backward_obs is not table:  # (per-slot backward of a batch that could not take the per-row path: unfolded image)
+                packed, fold = self.net.pack(), False
+            else:
+                packed = tables["packed_net"] if tables is not None and "packed_net" in tables else self.net.pack()  # same weights as the forward
+            rnad_hip.mlp_backward(packed, weights, backward_obs, A, dlogit.view(-1, A), dv.view(-1, 1), live=live, out=views, fold=fold)
             if all(p_.grad is None for p_ in weights):
                 for p_, g_ in zip(weights, views):
                     p_.grad = g_
@@ -703,13 +725,14 @@ class RNaD:
         tables = None
         lazy = mode is True and self._use_lazy_rows(handle, local_batch, T_cap, log, buffer)
         visited = None
+        fold = mode is True and self._fold()
         if lazy:
-            tables = self._table_outputs(alpha, getattr(self, "obs_half", False), policy_only=True)
+            tables = self._table_outputs(alpha, getattr(self, "obs_half", False), policy_only=True, fold=fold)
             visited = torch.empty((2 * handle.S,), dtype=torch.int32, device=self.device)
         elif mode is True:
             # the nets do not change between this step's rollout and its update: one evaluation of the 2S observations serves the
             # actor (= the learner net, rnad.py:503-505) and all four nets of __learn
-            tables = self._table_outputs(alpha, getattr(self, "obs_half", False), want_target_logits=log is not None)
+            tables = self._table_outputs(alpha, getattr(self, "obs_half", False), want_target_logits=log is not None, fold=fold)
             tables["records"], tables["fast_records"] = rnad_hip.bucket_records(
                 handle, tables["logit"], tables["v"], tables["v_target"], tables["logit_reg"], tables["logit_reg_"], self._learn_params(alpha),
                 step_params=step_params, fast=True)
@@ -772,7 +795,10 @@ class RNaD:
         if grp.get("amsgrad") or grp.get("weight_decay") or grp.get("maximize") or grp.get("differentiable"):
             return None
         weights = self.net._weights()
-        key = (id(opt), id(self.net), id(self.net_target), grp["lr"], tuple(grp["betas"]), grp["eps"], self.grad_clip, self.gamma_averaging)
+        fold = bool(getattr(self, "_layout_in_use", False))
+        images = self._packed_images(fold)  # (the layout this step's table evaluations used: the tail keeps exactly these two buffers current)
+        key = (id(opt), id(self.net), id(self.net_target), grp["lr"], tuple(grp["betas"]), grp["eps"], self.grad_clip, self.gamma_averaging,
+               fold, images[0].data_ptr())
         cached = getattr(self, "_fused_tail_cache", None)
         if cached is not None and cached[0] == key:
             return cached[1]
@@ -787,8 +813,9 @@ class RNaD:
             return None
         tail = rnad_hip.OptimizerStep(weights, [st["exp_avg"] for st in states], [st["exp_avg_sq"] for st in states], steps,
                                       self.net_target._weights(), lr, grp["betas"][0], grp["betas"][1], grp["eps"], self.grad_clip,
-                                      self.gamma_averaging, packed=tuple(self._packed_images()), A=self.tree.max_actions)
+                                      self.gamma_averaging, packed=tuple(images), A=self.tree.max_actions, fold=fold)
         self._fused_tail_cache = (key, tail)
+        self._packed_cache["maintained"] = fold
         return tail
 
     # ------------------------------------------------------------------ hipGraph replay of the on-policy tabular step
@@ -822,7 +849,8 @@ class RNaD:
                 self.batch_size, self.tabular, getattr(self, "tabular_gate", 8), self.eta, self.beta, self.neurd_clip, self.grad_clip,
                 self.c_bar, self.roh_bar, self.vtrace_gamma, self.value_weight, self.neurd_weight, self.epsilon_threshold, self.n_discrete,
                 self.gamma_averaging, getattr(self, "obs_half", False), getattr(self, "store_actor_values", False), getattr(self, "fused_optimizer", True),
-                getattr(self, "compact_trajectory", True), getattr(self, "lazy_rows", None), os.environ.get("RNAD_BUCKET_ROWS"), os.environ.get("RNAD_BUCKET_CHUNK"))
+                getattr(self, "compact_trajectory", True), getattr(self, "lazy_rows", None), os.environ.get("RNAD_BUCKET_ROWS"), os.environ.get("RNAD_BUCKET_CHUNK"),
+                getattr(self, "fold_legal", True))
 
     def _graph_step(self, buffer, alpha):
         g = getattr(self, "_graph", None)
@@ -837,7 +865,7 @@ class RNaD:
             g["dev"] = torch.zeros((2,), dtype=torch.int64, device=self.device)
         rnad_hip.step_params_set(g["dev"], seed, alpha)
         # the regularisation nets are constant inside a captured step: refresh their tables (in place) when their weights changed
-        self._reg_tables(self.tree.handle().observations_table(getattr(self, "obs_half", False)))
+        self._reg_tables(self.tree.handle().observations_table(getattr(self, "obs_half", False)), self._fold())
         self._packed_images()  # (re-packed here, in place, if somebody edited net / net_target since the last step: no pack inside the graph)
         if g["graph"] is None:
             graph = torch.cuda.CUDAGraph()

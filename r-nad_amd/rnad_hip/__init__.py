@@ -168,6 +168,21 @@ class TreeHandle:
             setattr(self, key, tab.half() if half else tab)
         return getattr(self, key)
 
+    @property
+    def legal_foldable(self):
+        """True when every (player, state) row of the observation table carries an all-ones legal plane, or -- the absorbing state -- e0 =
+        [1, 0, ..., 0]: the premise of the FOLD instantiations of the MLP kernels (include/rnad_hip.h "The legal fold").  Checked once."""
+        if getattr(self, "_legal_foldable", None) is None:
+            ok = False
+            if self.A >= 2:
+                legal = self.observations_table()[:, 1].reshape(2 * self.S, -1)
+                e0 = torch.zeros_like(legal[0])
+                e0[0] = 1.0
+                ones = (legal == 1.0).all(dim=1)
+                ok = bool((ones | (legal == e0).all(dim=1)).all().item())
+            self._legal_foldable = ok
+        return self._legal_foldable
+
     def __del__(self):
         try:
             if self._h:
@@ -241,20 +256,24 @@ def mlp_pack(weights, A):
     return packed
 
 
-def mlp_pack_many(weight_lists, A, out=None):
+def mlp_pack_many(weight_lists, A, out=None, fold=False):
     """mlp_pack for up to four nets of one shape in ONE launch (rnad_mlp_pack_multi) -> list of packed images (written into `out`,
-    a list of preallocated images, when given)."""
+    a list of preallocated images, when given).  fold: the images of the FOLD kernels (rnad_mlp_pack_fold_multi)."""
     n = len(weight_lists)
     assert 1 <= n <= 4 and all(len(w) == 8 for w in weight_lists)
     W = weight_lists[0][0].shape[0]
-    size = lib().rnad_mlp_packed_size(A, W)
+    size = mlp_packed_size(A, W, fold)
     dev = weight_lists[0][0].device
     outs = [torch.empty((size,), dtype=F32, device=dev) for _ in range(n)] if out is None else list(out)
     assert len(outs) == n and all(o.numel() == size for o in outs)
     wp = (C.c_void_p * (8 * n))(*[_dp(w.detach(), F32, "weight").value for ws in weight_lists for w in ws])
     op = (C.c_void_p * n)(*[_dp(o, F32, "packed").value for o in outs])
-    _check(lib().rnad_mlp_pack_multi(n, A, W, wp, op, _stream()))
+    _check((lib().rnad_mlp_pack_fold_multi if fold else lib().rnad_mlp_pack_multi)(n, A, W, wp, op, _stream()))
     return outs
+
+
+def mlp_packed_size(A, W, fold=False):
+    return int((lib().rnad_mlp_fold_packed_size if fold else lib().rnad_mlp_packed_size)(A, W))
 
 
 class LiveRows:
@@ -287,7 +306,7 @@ class RowList:
         self.count = torch.tensor([self.rows.numel()], dtype=torch.int64, device=device)
 
 
-def mlp_forward(packed, W, obs, A, want_logits=True, want_value=True, live=None, out=None, zero_rest=True):
+def mlp_forward(packed, W, obs, A, want_logits=True, want_value=True, live=None, out=None, zero_rest=True, fold=False):
     """packed: mlp_pack(weights, A); obs [N, 2, A, A] fp32/fp16 -> logits [N, A], value [N, 1].
     A head that is not wanted is not computed (returns None for it).
     live: a LiveRows / RowList over the N samples -- only those rows are evaluated; the others come back as zeros (zero_rest=False:
@@ -303,7 +322,15 @@ def mlp_forward(packed, W, obs, A, want_logits=True, want_value=True, live=None,
     else:
         logits = alloc((N, A), dtype=F32, device=obs.device) if want_logits else None
         value = alloc((N, 1), dtype=F32, device=obs.device) if want_value else None
-    if live is None:
+    if fold:  # the FOLD instantiation (packed: mlp_pack_many(..., fold=True); obs rows with a foldable legal plane)
+        assert live is None or live.N == N, "live-row list built for a different batch"
+        ptr = lambda t: t.data_ptr() if t is not None else None  # noqa: E731
+        P = (C.c_void_p * 1)(_dp(packed, F32, "packed").value)
+        L = (C.c_void_p * 1)(ptr(logits))
+        V = (C.c_void_p * 1)(ptr(value))
+        _check(lib().rnad_mlp_forward_fold(1, C.c_int64(N), *_row_list(live), A, W, P, _dp(obs, F16 if half else F32, "obs"), int(half), L, V,
+                                           _stream()))
+    elif live is None:
         _check(lib().rnad_mlp_forward(C.c_int64(N), A, W, _dp(packed, F32, "packed"), _dp(obs, F16 if half else F32, "obs"), int(half),
                                       _dp(logits, F32, "logits", True), _dp(value, F32, "value", True), _stream()))
     else:
@@ -314,7 +341,7 @@ def mlp_forward(packed, W, obs, A, want_logits=True, want_value=True, live=None,
     return logits, value
 
 
-def mlp_forward_multi(packed_list, W, obs, A, wants):
+def mlp_forward_multi(packed_list, W, obs, A, wants, fold=False):
     """Several nets of one shape on the same inputs in ONE launch (rnad_mlp_forward_multi).  packed_list: their weight images;
     wants: per net (want_logits, want_value).  Returns a list of (logits [N, A] or None, value [N, 1] or None)."""
     n = len(packed_list)
@@ -327,7 +354,10 @@ def mlp_forward_multi(packed_list, W, obs, A, wants):
     P = (C.c_void_p * n)(*[_dp(p, F32, "packed").value for p in packed_list])
     L = (C.c_void_p * n)(*[ptr(o[0]) for o in outs])
     V = (C.c_void_p * n)(*[ptr(o[1]) for o in outs])
-    _check(lib().rnad_mlp_forward_multi(n, C.c_int64(N), A, W, P, _dp(obs, F16 if half else F32, "obs"), int(half), L, V, _stream()))
+    if fold:
+        _check(lib().rnad_mlp_forward_fold(n, C.c_int64(N), None, None, A, W, P, _dp(obs, F16 if half else F32, "obs"), int(half), L, V, _stream()))
+    else:
+        _check(lib().rnad_mlp_forward_multi(n, C.c_int64(N), A, W, P, _dp(obs, F16 if half else F32, "obs"), int(half), L, V, _stream()))
     return outs
 
 
@@ -335,7 +365,7 @@ def mlp_backward_supported(A, W):
     return W % 32 == 0 and lib().rnad_mlp_backward_workspace(C.c_int64(32), A, W) > 0
 
 
-def mlp_backward(packed, weights, obs, A, dlogits, dvalue, live=None, out=None):
+def mlp_backward(packed, weights, obs, A, dlogits, dvalue, live=None, out=None, fold=False):
     """Gradients of the 8 Linear tensors (MLP_KEYS order) for dL/dlogits [N, A], dL/dvalue [N(,1)].
     live: a LiveRows -- only those rows contribute (the caller guarantees the others carry zero gradients).
     out: eight preallocated tensors shaped like the weights (e.g. views of one flat all-reduce bucket) to write into."""
@@ -347,7 +377,10 @@ def mlp_backward(packed, weights, obs, A, dlogits, dvalue, live=None, out=None):
     ws = torch.empty((lib().rnad_mlp_backward_workspace(C.c_int64(N), A, W) // 4,), dtype=F32, device=obs.device)
     common = (A, W, _dp(packed, F32, "packed"), _dp(obs, F16 if half else F32, "obs"), int(half), _dp(dlogits, F32, "dlogits"),
               _dp(dvalue, F32, "dvalue"), *[_dp(g, F32, "grad") for g in grads], _dp(ws, F32, "workspace"), _stream())
-    if live is None:
+    if fold:  # (packed: the fold image; gradients of the eight original tensors)
+        assert live is None or live.N == N, "live-row list built for a different batch"
+        _check(lib().rnad_mlp_backward_fold(C.c_int64(N), *_row_list(live), *common))
+    elif live is None:
         _check(lib().rnad_mlp_backward(C.c_int64(N), *common))
     else:
         assert live.N == N, "live-row list built for a different batch"
@@ -870,13 +903,14 @@ class OptimizerStep:
     """rnad_optimizer_step bound to fixed tensors: clip + Adam + EMA of `params` (gradients back to back in one flat bucket, in that
     order) in one launch, on torch.optim.Adam's own state tensors.  The pointer arrays are built once."""
 
-    def __init__(self, params, exp_avg, exp_avg_sq, steps, targets, lr, beta1, beta2, eps, max_norm, ema, packed=None, A=0):
+    def __init__(self, params, exp_avg, exp_avg_sq, steps, targets, lr, beta1, beta2, eps, max_norm, ema, packed=None, A=0, fold=False):
         """packed = (image of params, image of targets) with A: the tensors are the fused MLP's (MLP_KEYS order) and the kernel also
         keeps those two packed weight images (mlp_pack) current -- no pack launch per step."""
         n = len(params)
         assert 1 <= n <= 8 and len(exp_avg) == len(exp_avg_sq) == len(steps) == n and (targets is None or len(targets) == n)
         self._keep = (params, exp_avg, exp_avg_sq, steps, targets, packed)
         self.packed, self.A, self.W = packed, (int(A) if packed is not None else 0), (params[0].shape[0] if packed is not None else 0)
+        self.fold = int(bool(fold) and packed is not None)  # the images are in the FOLD layout
         self.n = n
         self.numel = sum(p.numel() for p in params)
         arr = lambda ts, name: (C.c_void_p * n)(*[_dp(t, F32, name).value for t in ts])  # noqa: E731
@@ -889,7 +923,7 @@ class OptimizerStep:
         assert flat.numel() == self.numel
         img = self.packed or (None, None)
         _check(lib().rnad_optimizer_step(self.n, self.sizes, self.param, _dp(flat, F32, "grads"), self.m, self.v, self.step, self.target,
-                                         C.byref(self.hp), None, self.A, self.W, _dp(img[0], F32, "packed_param", True),
+                                         C.byref(self.hp), None, self.A, self.W, self.fold, _dp(img[0], F32, "packed_param", True),
                                          _dp(img[1], F32, "packed_target", True), _stream()))
 
 

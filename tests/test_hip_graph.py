@@ -292,14 +292,17 @@ def test_packed_weight_images_follow_the_optimiser(use_graph, tmp_path):
     buf = _BUFFERS[id(rn)]
     A = tree.max_actions
 
+    fold = rn._packed_cache["maintained"]
+    assert fold is True, "this tree's legal planes are uniform: the FOLD layout must be the one in use"
+
     def check():
         torch.cuda.synchronize()
-        fresh = rnad_hip.mlp_pack_many([rn.net._weights(), rn.net_target._weights()], A)
-        held = rn._packed_cache["images"]
+        fresh = rnad_hip.mlp_pack_many([rn.net._weights(), rn.net_target._weights()], A, fold=fold)
+        held = rn._packed_cache["layouts"][fold]["images"]
         assert torch.equal(held[0], fresh[0]) and torch.equal(held[1], fresh[1])
 
     check()
-    ptrs = [t.data_ptr() for t in rn._packed_cache["images"]]
+    ptrs = [t.data_ptr() for t in rn._packed_cache["layouts"][fold]["images"]]
     with torch.no_grad():
         for p in rn.net.parameters():
             p.mul_(0.5)  # bumps the version counters
@@ -307,6 +310,6 @@ def test_packed_weight_images_follow_the_optimiser(use_graph, tmp_path):
         rn.train_step(buf, alpha=0.5)
         rn.total_steps += 1
     check()
-    assert [t.data_ptr() for t in rn._packed_cache["images"]] == ptrs, "the images are re-packed in place (a captured step reads them)"
+    assert [t.data_ptr() for t in rn._packed_cache["layouts"][fold]["images"]] == ptrs, "the images are re-packed in place (a captured step reads them)"
     if use_graph:
         assert rn._graph["graph"] is not None and not rn._graph["failed"]

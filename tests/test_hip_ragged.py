@@ -359,6 +359,7 @@ def test_logged_statistics_do_not_depend_on_the_mode(ragged):
     rn = RNaD(tree=tree, device=DEV, directory_name=f"log{int(ragged)}", batch_size=B, eta=0.2, b1_adam=0.0,
               net_params={"type": "MLP", "max_actions": 3, "width": 64})
     rn.initialize()
+    rn.fold_legal = False  # the table evaluations with the very kernels of the per-slot modes: identical net outputs in every mode
     with torch.no_grad():
         for i, m in enumerate((rn.net_target, rn.net_reg, rn.net_reg_)):
             for p_ in m.parameters():
@@ -366,12 +367,23 @@ def test_logged_statistics_do_not_depend_on_the_mode(ragged):
     ep = Episodes(tree, B, seed=3)
     ep.generate(rn.net, trim=False)
     logs, grads = {}, {}
-    for mode in (False, "forward", True):
-        rn.tabular = mode
+    for mode in (False, "forward", True, "folded"):
+        if mode == "folded":
+            if not tree.handle().legal_foldable:
+                continue
+            rn.tabular, rn.fold_legal = True, True
+        else:
+            rn.tabular = mode
         rn.optimizer.zero_grad()
         logs[mode] = {}
         rn._RNaD__learn(ep, 0.4, log=logs[mode])
         grads[mode] = [p_.grad.detach().clone() for p_ in rn.net.parameters()]
+    if "folded" in logs:  # the legal fold sums the first layer in another order: the same statistics to fp32 rounding
+        for k, want in logs[True].items():
+            assert abs(logs["folded"][k] - want) <= 2e-6 * max(1.0, abs(want)), k
+        for a, b in zip(grads["folded"], grads[True]):
+            np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=1e-4, atol=1e-5 * (b.abs().max().item() + 1e-12))
+        del logs["folded"], grads["folded"]
     assert set(logs[False]) == set(logs["forward"]) == set(logs[True]) and "entropy" in logs[False]
     for k, want in logs[False].items():
         if k.startswith("loss"):  # fp64 atomic partial sums: the last bits vary from launch to launch
