@@ -365,6 +365,9 @@ int rnad_learn_fused_gather(const rnad_tree_t *tree, int T, int64_t B, const int
  * everything of learn/rnad.py:373-382 that depends on the row alone (rnad_bucket_record_stride(A) floats, 16-byte aligned):
  *   logit[A] | v | v_target | process_policy(pi)[A] | log_policy_reg[A] | legal bits | pi[A] | pad
  * with pi, log_pi = the learner's policy head (net.py:74-77), log_policy_reg = log_pi - (alpha log_pi_reg + (1 - alpha) log_pi_reg_).
+ * policy_rows (optional output, rnad_bucket_policy_row_stride(A) floats per row, 16-byte aligned): the pi columns once more, as a table
+ * of their own -- 16 bytes per row at A <= 4, 2 MB on configs[1]: what the rollout kernels should gather the actor from (it stays in
+ * an XCD's L2 where the 64-byte records do not).
  *
  * rnad_learn_bucketed: rnad_learn_fused_tabular on a bucket-ordered trajectory and those records: dlogit_tab [2S, A], dv_tab [2S] = per-row sums
  * of the per-slot gradients, accumulated in 64-bit fixed point with an a-priori scale (|dL/dlogit| <= 2 * clip / N_P by
@@ -430,10 +433,11 @@ int rnad_bucket_expand(const rnad_tree_t *tree, int T, int64_t B, const int32_t 
                        float *rewards, void *stream);
 int64_t rnad_bucket_record_stride(int A);
 int64_t rnad_bucket_fast_record_stride(int A);
+int64_t rnad_bucket_policy_row_stride(int A);
 int rnad_bucket_records(const rnad_tree_t *tree, const float *logit_tab, const float *v_tab, const float *v_target_tab,
                         const float *logit_reg_tab, const float *logit_reg_tab_, const rnad_learn_params_t *hp,
-                        const rnad_step_params_t *device_params, float *records, float *fast_records, const int32_t *rows,
-                        const int64_t *n_rows, void *stream);
+                        const rnad_step_params_t *device_params, float *records, float *fast_records, float *policy_rows,
+                        const int32_t *rows, const int64_t *n_rows, void *stream);
 int rnad_learn_bucketed(const rnad_tree_t *tree, int T, int64_t B, const int32_t *indices, const int32_t *actions,
                         const float *rewards, const float *mu, const float *records, const int32_t *items, const int32_t *n_items,
                         const double *norm, const rnad_learn_params_t *hp, void *accumulators, double *losses, float *dlogit_tab,

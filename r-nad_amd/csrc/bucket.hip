@@ -265,13 +265,35 @@ constexpr int kRowLearn = (3 * A + 3 + 3) & ~3;  // what k_bucket_learn fetches 
 //          apply_force_with_threshold (:362-366), closed for illegal actions (whose force :424-428 multiplies by legal == 0)
 template <int A>
 constexpr int kFastStride = 4 + 4 * A;
+// The actor's policy rows as a table of their own (16 bytes per row at A <= 4): the whole configs[1] table is 2 MB and stays in an
+// XCD's L2, where the 64-byte row records -- 8.5 MB, of which the rollout wants 12 bytes per row -- do not.
+template <int A>
+constexpr int kPolStride = (A + 3) & ~3;
+
+template <int A>
+__device__ __forceinline__ void load_policy_row(const float *__restrict__ tab, int64_t row, int64_t stride, bool vec4, float (&out)[A]) {
+    if (vec4) {  // rows of a multiple of 4 floats, 16-byte aligned (k_row_records' policy rows)
+        const float4 *p = reinterpret_cast<const float4 *>(tab + row * stride);
+#pragma unroll
+        for (int u = 0; u < (A + 3) / 4; ++u) {
+            const float4 v = p[u];
+            if (4 * u < A) out[4 * u] = v.x;
+            if (4 * u + 1 < A) out[4 * u + 1] = v.y;
+            if (4 * u + 2 < A) out[4 * u + 2] = v.z;
+            if (4 * u + 3 < A) out[4 * u + 3] = v.w;
+        }
+    } else {
+#pragma unroll
+        for (int a = 0; a < A; ++a) out[a] = tab[row * stride + a];
+    }
+}
 
 template <int A>
 __global__ __launch_bounds__(kThreads) void k_row_records(int64_t rows, const float *__restrict__ logit, const float *__restrict__ v,
                                                           const float *__restrict__ vt, const float *__restrict__ lr_,
                                                           const float *__restrict__ lr2_, const uint8_t *__restrict__ mask_tab,
                                                           rnad_learn_params_t hp, const rnad_step_params_t *__restrict__ sp,
-                                                          float *__restrict__ rec, float *__restrict__ fast,
+                                                          float *__restrict__ rec, float *__restrict__ fast, float *__restrict__ pol_rows,
                                                           const int32_t *__restrict__ row_list, const int64_t *__restrict__ n_rows) {
     const int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x;
     if (i >= (row_list ? *n_rows : rows)) return;
@@ -312,6 +334,13 @@ __global__ __launch_bounds__(kThreads) void k_row_records(int64_t rows, const fl
     float4 *o4 = reinterpret_cast<float4 *>(rec + r * kRowStride<A>);
 #pragma unroll
     for (int u = 0; u < kRowStride<A> / 4; ++u) o4[u] = float4{o[4 * u], o[4 * u + 1], o[4 * u + 2], o[4 * u + 3]};
+    if (pol_rows) {  // the actor's policy rows on their own, kPolStride<A> floats apart: the table the rollout kernels gather from
+        float4 *p4 = reinterpret_cast<float4 *>(pol_rows + r * kPolStride<A>);
+#pragma unroll
+        for (int u = 0; u < kPolStride<A> / 4; ++u)
+            p4[u] = float4{4 * u < A ? pi[4 * u] : 0.0f, 4 * u + 1 < A ? pi[4 * u + 1] : 0.0f, 4 * u + 2 < A ? pi[4 * u + 2] : 0.0f,
+                           4 * u + 3 < A ? pi[4 * u + 3] : 0.0f};
+    }
     if (!fast) return;
     float f[kFastStride<A>];
     const float neg_eta = -hp.eta;
@@ -349,7 +378,7 @@ __global__ __launch_bounds__(kThreads) void k_row_records(int64_t rows, const fl
 // group it descends into, or the terminal bucket of the upper state it leaves the tree from.
 template <int A>
 __global__ __launch_bounds__(kThreads) void k_bucket_keys(const Trans *__restrict__ trans, int C, int64_t S, int64_t B, int n_steps,
-                                                          const float *__restrict__ policy_tab, int64_t tab_stride,
+                                                          const float *__restrict__ policy_tab, int64_t tab_stride, int vec4,
                                                           const int32_t *__restrict__ bucket_of, int n_groups, uint64_t seed,
                                                           const rnad_step_params_t *__restrict__ sp, int64_t lane0,
                                                           int32_t *__restrict__ keys, unsigned long long *__restrict__ decisions,
@@ -366,8 +395,7 @@ __global__ __launch_bounds__(kThreads) void k_bucket_keys(const Trans *__restric
     for (; t < n_steps && key >= n_groups; ++t) {
         const int64_t row = (int64_t)(t & 1) * S + state;
         float pol[A], q[A];
-#pragma unroll
-        for (int a = 0; a < A; ++a) pol[a] = policy_tab[row * tab_stride + a];
+        load_policy_row<A>(policy_tab, row, tab_stride, vec4 != 0, pol);
         rnad_exp_noise(seed, (uint64_t)(lane0 + b), (uint32_t)t, 0u, A, q);
         const int action = race_argmax<A>(pol, q);
         int chosen = 0;
@@ -658,8 +686,8 @@ __global__ __launch_bounds__(kThreads) void k_bucket_rollout(const Trans *__rest
 // episodes as k_bucket_rollout.  An absorbed lane stops: no draws, no table reads.
 template <int A>
 __global__ __launch_bounds__(kThreads) void k_bucket_rollout_compact(const Trans *__restrict__ trans, int C, int64_t S, int64_t B, int T_cap,
-                                                                     const float *__restrict__ policy_tab, int64_t tab_stride, uint64_t seed,
-                                                                     const rnad_step_params_t *__restrict__ sp, int64_t lane0,
+                                                                     const float *__restrict__ policy_tab, int64_t tab_stride, int vec4,
+                                                                     uint64_t seed, const rnad_step_params_t *__restrict__ sp, int64_t lane0,
                                                                      const int32_t *__restrict__ lane_ids,
                                                                      const unsigned long long *__restrict__ decisions,
                                                                      int32_t *__restrict__ indices, int32_t *__restrict__ alive_part,
@@ -686,8 +714,13 @@ __global__ __launch_bounds__(kThreads) void k_bucket_rollout_compact(const Trans
         }
         if (!active) continue;
         const int64_t i = (int64_t)t * B + j;
+#ifdef RNAD_NT_INDICES
+        __builtin_nontemporal_store(state, indices + i);
+        if (two) __builtin_nontemporal_store(state, indices + i + B);
+#else
         indices[i] = state;
         if (two) indices[i + B] = state;
+#endif
         if (state == 0) continue;
         const bool replay0 = t < n_packed, replay1 = t + 1 < n_packed;
         const int64_t row0 = state, row1 = S + state;
@@ -696,14 +729,8 @@ __global__ __launch_bounds__(kThreads) void k_bucket_rollout_compact(const Trans
             if (two) visited[row1] = 1;
         }
         float pol0[A], pol1[A], q0[A], q1[A];
-        if (!replay0) {
-#pragma unroll
-            for (int a = 0; a < A; ++a) pol0[a] = policy_tab[row0 * tab_stride + a];
-        }
-        if (two && !replay1) {
-#pragma unroll
-            for (int a = 0; a < A; ++a) pol1[a] = policy_tab[row1 * tab_stride + a];
-        }
+        if (!replay0) load_policy_row<A>(policy_tab, row0, tab_stride, vec4 != 0, pol0);
+        if (two && !replay1) load_policy_row<A>(policy_tab, row1, tab_stride, vec4 != 0, pol1);
         if (!replay0) rnad_exp_noise(seed, lane, (uint32_t)t, 0u, A, q0);
         if (two && !replay1) rnad_exp_noise(seed, lane, (uint32_t)(t + 1), 0u, A, q1);
         const int bits0 = replay0 ? (int)(packed >> (6 * t)) & 63 : 0, bits1 = replay1 ? (int)(packed >> (6 * (t + 1))) & 63 : 0;
@@ -1259,19 +1286,21 @@ extern "C" int rnad_step_params_set(rnad_step_params_t *device_params, uint64_t 
 
 extern "C" int64_t rnad_bucket_record_stride(int A) { return (4 * (int64_t)A + 3 + 3) & ~(int64_t)3; }
 extern "C" int64_t rnad_bucket_fast_record_stride(int A) { return 4 + 4 * (int64_t)A; }
+extern "C" int64_t rnad_bucket_policy_row_stride(int A) { return ((int64_t)A + 3) & ~(int64_t)3; }
 
 extern "C" int rnad_bucket_records(const rnad_tree_t *tree, const float *logit_tab, const float *v_tab, const float *v_target_tab,
                                    const float *logit_reg_tab, const float *logit_reg_tab_, const rnad_learn_params_t *hp,
-                                   const rnad_step_params_t *device_params, float *records, float *fast_records, const int32_t *rows,
-                                   const int64_t *n_rows, void *stream) {
+                                   const rnad_step_params_t *device_params, float *records, float *fast_records, float *policy_rows,
+                                   const int32_t *rows, const int64_t *n_rows, void *stream) {
     RNAD_REQUIRE(tree && logit_tab && v_tab && v_target_tab && logit_reg_tab && logit_reg_tab_ && hp && records,
                  "rnad_bucket_records: null argument");
-    RNAD_REQUIRE(((uintptr_t)records & 15) == 0 && ((uintptr_t)fast_records & 15) == 0, "rnad_bucket_records: records must be 16-byte aligned");
+    RNAD_REQUIRE(((uintptr_t)records & 15) == 0 && ((uintptr_t)fast_records & 15) == 0 && ((uintptr_t)policy_rows & 15) == 0,
+                 "rnad_bucket_records: records must be 16-byte aligned");
     RNAD_REQUIRE(hp->n_disc >= 1, "rnad_bucket_records: n_disc must be positive");
     RNAD_REQUIRE(!rows == !n_rows, "rnad_bucket_records: rows and n_rows go together");
     RNAD_DISPATCH_A(tree->A, hipLaunchKernelGGL((k_row_records<kA>), dim3(blocks_for(2 * tree->S)), dim3(kThreads), 0, (hipStream_t)stream,
                                                 2 * tree->S, logit_tab, v_tab, v_target_tab, logit_reg_tab, logit_reg_tab_,
-                                                (const uint8_t *)tree->mask_tab, *hp, device_params, records, fast_records, rows, n_rows));
+                                                (const uint8_t *)tree->mask_tab, *hp, device_params, records, fast_records, policy_rows, rows, n_rows));
     RNAD_HIP_OK(hipGetLastError());
     return 0;
 }
@@ -1338,10 +1367,11 @@ int rollout_bucketed_impl(const rnad_tree_t *tree, const RolloutBuffers &tr, boo
         policy_tab = s.policy;
         policy_stride = tree->A;
     }
+    const int vec4 = (policy_stride % 4 == 0 && ((uintptr_t)policy_tab & 15) == 0) ? 1 : 0;
     if (sort_phase) {
         ProfScope one(PROF_BUCKET_KEYS, stream);
         RNAD_DISPATCH_A(tree->A, hipLaunchKernelGGL((k_bucket_keys<kA>), dim3(blocks_for(B)), dim3(kThreads), 0, stream, tree->trans, tree->C,
-                                                    S, B, n_steps, policy_tab, policy_stride, (const int32_t *)p.cut->bucket_of,
+                                                    S, B, n_steps, policy_tab, policy_stride, vec4, (const int32_t *)p.cut->bucket_of,
                                                     p.cut->n_groups, seed, device_params, lane0, s.keys, s.decisions, norm));
     }
     const size_t lds = (size_t)nb * sizeof(int32_t);
@@ -1370,7 +1400,7 @@ int rollout_bucketed_impl(const rnad_tree_t *tree, const RolloutBuffers &tr, boo
                        tr.rewards, tr.values, s.alive_part)
 #define RNAD_BUCKET_ROLLOUT_COMPACT()                                                                                                    \
     hipLaunchKernelGGL((k_bucket_rollout_compact<kA>), dim3(grid), dim3(kThreads), 0, stream, tree->trans, tree->C, S, B, tr.T_cap,         \
-                       policy_tab, policy_stride, seed, device_params, lane0, (const int32_t *)lane_ids,                                    \
+                       policy_tab, policy_stride, vec4, seed, device_params, lane0, (const int32_t *)lane_ids,                              \
                        (const unsigned long long *)s.decisions, tr.indices, s.alive_part, tr.acts, tr.final_reward, tr.visited)
         if (compact) {
             RNAD_DISPATCH_A(tree->A, RNAD_BUCKET_ROLLOUT_COMPACT());

@@ -718,6 +718,9 @@ def rollout_bucketed_compact(tree, traj, table, seed=0, lane0=0, step_params=Non
     plan = bucket_plan(tree, traj.B)
     if plan is None:
         raise RnadHipError(lib().rnad_last_error().decode())
+    pol_rows = getattr(table, "_policy_rows", None)
+    if table_is_policy and column is None and pol_rows is not None:
+        table, column = pol_rows, 0  # the same floats as the pi columns of the records, 16 bytes per row
     if column is None:
         column = policy_column(tree.A) if table_is_policy else 0
     assert table.shape[0] == 2 * tree.S and table.shape[1] >= column + tree.A
@@ -858,10 +861,16 @@ def bucket_records(tree, logit_tab, v_tab, v_target_tab, logit_reg_tab, logit_re
     assert rows is None or rows.N == 2 * tree.S
     rec = torch.empty((2 * tree.S, stride), dtype=F32, device=logit_tab.device)
     quick = torch.empty((2 * tree.S, int(lib().rnad_bucket_fast_record_stride(tree.A))), dtype=F32, device=logit_tab.device) if fast else None
+    # the actor's policy rows on their own (16 bytes per row at A <= 4): what the rollout kernels gather from.  Only a full table can
+    # be an actor, so a row-list call does without
+    pol = (torch.empty((2 * tree.S, int(lib().rnad_bucket_policy_row_stride(tree.A))), dtype=F32, device=logit_tab.device)
+           if (fast and rows is None and os.environ.get("RNAD_POLICY_ROWS", "1") == "1") else None)
     _check(lib().rnad_bucket_records(tree.ptr, _dp(logit_tab, F32, "logit_tab"), _dp(v_tab, F32, "v_tab"), _dp(v_target_tab, F32, "v_target_tab"),
                                      _dp(logit_reg_tab, F32, "logit_reg_tab"), _dp(logit_reg_tab_, F32, "logit_reg_tab_"), C.byref(hp),
                                      _dp(step_params, torch.int64, "step_params", True), _dp(rec, F32, "records"),
-                                     _dp(quick, F32, "fast_records", True), *_row_list(rows), _stream()))
+                                     _dp(quick, F32, "fast_records", True), _dp(pol, F32, "policy_rows", True), *_row_list(rows), _stream()))
+    if pol is not None:
+        rec._policy_rows = pol  # travels with the records: rollout_bucketed_compact(table=records) gathers from it
     return (rec, quick) if fast else rec
 
 
