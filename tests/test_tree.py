@@ -81,6 +81,43 @@ def test_solver_matches_linear_programming():
         assert (x @ M).min() >= val - 1e-5 and (M @ y).max() <= val + 1e-5  # (x, y) is an equilibrium
 
 
+def test_equilibrium_choice_on_degenerate_matrices_is_the_documented_tie_break():
+    """`Tree._solve` (tree.py:199-234) keeps `solutions[0]` after a STABLE sort of pygambit's `enummixed_solve` output by purity score.
+    Which equilibrium that is depends on the order in which pygambit 16.0.2 (not vendored, not installable here) lists the extreme
+    equilibria -- PARITY UNPINNED for `solution_tensor` whenever a matrix game has several.  What IS pinned here, on +-1 matrices with
+    many equilibria: the native solver picks exactly the pair the reference's own selection rule picks from the list enumerated in the
+    order INTEGRATION.md documents (supports by size, then rows, then columns lexicographically; pairs x-major), every candidate is
+    an equilibrium of the same value, so NashConv(solution) and every value tensor are the same whichever one is kept."""
+    import sys
+
+    from _util import GOLDEN
+
+    sys.path.insert(0, GOLDEN)
+    from _pygambit_stub import extreme_strategies
+
+    rng = np.random.default_rng(7)
+    several = 0
+    for trial in range(200):
+        ra, ca = int(rng.integers(2, 5)), int(rng.integers(2, 5))
+        M = rng.choice([-1.0, 1.0], size=(ra, ca)).astype(np.float32)
+        xs, ys = extreme_strategies(M)
+        assert xs and ys
+        solutions = [list(x) + [0.0] * (4 - ra) + list(y) + [0.0] * (4 - ca) for x in xs for y in ys]  # tree.py:213-218 with max_actions = 4
+        several += len(solutions) > 1
+        value = None
+        for sol in solutions:  # every listed pair is an equilibrium, all of one value
+            x, y = np.array(sol[:ra]), np.array(sol[4:4 + ca])
+            v = float(x @ M @ y)
+            value = v if value is None else value
+            assert abs(v - value) < 1e-9 and (x @ M).min() >= v - 1e-9 and (M @ y).max() <= v + 1e-9
+        purity = lambda sol: -int(1 in sol[:4]) - int(1 in sol[4:])  # noqa: E731  (tree.py:227-229)
+        want = sorted(solutions, key=purity)[0]  # list.sort is stable (tree.py:230)
+        got, val = rnad_hip.solve_matrix(torch.tensor(M), 4)
+        np.testing.assert_allclose(got.numpy(), np.array(want, np.float32), atol=1e-6)
+        assert abs(val - value) < 1e-6
+    assert several > 50, "the test wants matrices with several equilibria"
+
+
 @pytest.mark.parametrize("A,C,depth,thr", [(2, 1, 3, 0.0), (3, 1, 4, 0.0), (3, 2, 3, 0.3), (5, 4, 2, 0.2)])
 def test_native_generator_invariants(A, C, depth, thr):
     t = Tree(max_actions=A, max_transitions=C, depth_bound=depth, transition_threshold=thr)
