@@ -233,6 +233,9 @@ def main():
     args.compact_in_effect = getattr(rn.last_episodes, "_compact", None) is not None
     lazy_now = rn._use_lazy_rows(handle, local_batch, T, None, buffer) and mode_now_is_true(rn, T, local_batch)
     args.visited_rows = int(rn.last_rows.count.item()) if (lazy_now and rn.last_rows is not None) else 0
+    staged = getattr(rn.last_episodes, "staged_rows", None) if lazy_now else None
+    args.policy_rows = int(staged[0].count.item() + staged[1].count.item()) if staged else 0  # rows the staged policy head was evaluated on
+    args.fold = bool(rn._fold() and mode_now_is_true(rn, T, local_batch))
     default_mode = rn.tabular
     mode_now = rn._tabular_mode(T, local_batch)
 
@@ -275,7 +278,7 @@ def main():
         variants[name] = timed(E)[0]
     rn.tabular = default_mode
     # rollout alone (Episodes.generate as RNaD.train_step calls it), outside the headline timed region
-    actor_tables = rn._table_outputs(0.5) if mode_now is True else None
+    actor_tables = rn._table_outputs(0.5, fold=args.fold) if mode_now is True else None
     fence()
     t_r = time.perf_counter()
     for i in range(E):
@@ -385,7 +388,8 @@ def main():
             "net_evaluation": {"mode": f"RNaD.tabular = {default_mode!r}" + (" (default)" if args.net_mode == "default" else ""),
                                "in_effect": repr(mode_now), "what": what[mode_now],
                                "step_replayed_from_hipGraph": replayed, "compact_trajectory": bool(args.compact_in_effect),
-                               "lazy_rows_visited": args.visited_rows or None,
+                               "lazy_rows_visited": args.visited_rows or None, "staged_policy_rows": args.policy_rows or None,
+                               "legal_fold": args.fold,
                                "distinct_observations": 2 * handle.S, "slots": T * local_batch},
             "other_modes": {name: {"env_steps_per_sec": global_batch * T_ref * E / sec, "updates_per_sec": E / sec,
                                    "ms_per_step": sec / E * 1e3, "steps": E,
@@ -459,7 +463,8 @@ def kernel_report(prof, A, C, args, B, T, live_slots, tree, mode_now):
 
     rec = ((4 * A + 3 + 3) & ~3) * 4  # bytes of a row record (rnad_bucket_record_stride)
     S2 = 2 * tree.handle().S
-    K = 2 * A * A
+    # input features of the first layer as the kernels of this mode see them: the legal fold (include/rnad_hip.h) leaves A^2 + 1 (+ padding)
+    K = ((A * A + 2) & ~1) if getattr(args, "fold", False) else 2 * A * A
     W = args.width
     rem = (K + 1) % 16
     feat = 16 * ((K + 1) // 16 + (1 if rem > 4 else 0)) + (4 if 0 < rem <= 4 else 0)
@@ -526,16 +531,20 @@ def kernel_report(prof, A, C, args, B, T, live_slots, tree, mode_now):
         flops = (2.0 * K * 2 * W + 2.0 * feat * 2 * W) * bwd_samples
         tf = flops / (p["us_per_step"] * 1e-6) / 1e12  # the launches of a step together (backward + its reduction)
         out[p["name"]].update(bound="mfma", achieved=tf, peak=FP32_PEAK_TFLOPS, unit="TFLOP/s", frac=tf / FP32_PEAK_TFLOPS,
-                              samples_per_step=bwd_samples, flops_model="per sample 2*K*2W (recompute) + 2*feat*2W (dW0 tiles), K = 2A^2")
+                              samples_per_step=bwd_samples,
+                              flops_model=f"per sample 2*K*2W (recompute) + 2*feat*2W (dW0 tiles), K = {K}" + (" (legal fold)" if getattr(args, "fold", False) else ""))
     if rh.PROF_MLP in prof and mode_now is True:
         p = prof[rh.PROF_MLP]
         # learner: both heads, target: value head, on the 2S rows (regularisation tables are cached); lazy rows: the two value heads
         # on the visited rows only
-        flops = 2.0 * K * W * (3 * S2 if not visited else S2 + 2 * visited)
+        policy_rows = (getattr(args, "policy_rows", 0) or S2) if visited else S2
+        flops = 2.0 * K * W * (3 * S2 if not visited else policy_rows + 2 * visited)
         tf = flops / (p["us_per_step"] * 1e-6) / 1e12
         out[p["name"]].update(bound="mfma", achieved=tf, peak=FP32_PEAK_TFLOPS, unit="TFLOP/s", frac=tf / FP32_PEAK_TFLOPS, samples_per_step=S2,
-                              flops_model="2*K*W per head and row: learner 2 heads + target value head"
-                                          + (f"; lazy rows: policy head on {S2} rows, the two value heads on the {visited} visited rows" if visited else ""))
+                              flops_model=f"2*K*W per head and row, K = {K} input features" + (" (legal fold)" if getattr(args, "fold", False) else "")
+                                          + ": learner 2 heads + target value head"
+                                          + (f"; lazy rows: policy head on {policy_rows} rows (upper states + the groups the batch descends into), "
+                                             f"the two value heads on the {visited} visited rows" if visited else ""))
     return out
 
 

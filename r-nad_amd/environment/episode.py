@@ -340,10 +340,12 @@ class Episodes:
                 self.lane_ids = self.buckets.lane_ids
                 self._compact = (traj, policy_table[0])
             elif compact and staged_actor is not None:
-                staged_actor(rnad_hip.bucket_upper_rows(handle, B))
+                upper = rnad_hip.bucket_upper_rows(handle, B)
+                staged_actor(upper)
                 self.buckets, flags = rnad_hip.bucket_sort(handle, traj, table, seed=self.seed, lane0=self.lane_offset, step_params=step_params)
                 rows = rnad_hip.compact_valid(flags)
                 staged_actor(rows)
+                self.staged_rows = (upper, rows)  # (bench.py reads how many rows the actor was evaluated on)
                 rnad_hip.bucket_play(handle, traj, self.buckets, table, rows=rows, seed=self.seed, lane0=self.lane_offset,
                                      step_params=step_params, visited=visited, defer_alive=defer_alive)
                 self.lane_ids = self.buckets.lane_ids
