@@ -28,13 +28,13 @@ def _bare_rnad(G, tree, nets, hp):
     return rn
 
 
-def _default_path_update(G, rn, tree, indices, actions, rewards, alpha, log):
+def _default_path_update(G, rn, tree, indices, actions, rewards, alpha, log, fold=False):
     """What RNaD._step_body does around its rollout, with a recorded batch in the rollout's place: the nets on the 2S rows, the row
     records (their pi columns are the actor), the compact batch, __learn."""
     import rnad_hip
 
     ep, perm = G.compact_episodes_from_recorded(tree, indices, actions, rewards)
-    tables = rn._table_outputs(alpha, False, want_target_logits=log is not None)
+    tables = rn._table_outputs(alpha, False, want_target_logits=log is not None, fold=fold)  # fold: the legal fold of DESIGN.md section 5.3
     tables["records"], tables["fast_records"] = rnad_hip.bucket_records(
         tree.handle(), tables["logit"], tables["v"], tables["v_target"], tables["logit_reg"], tables["logit_reg_"], rn._learn_params(alpha), fast=True)
     ep._compact = (ep._compact[0], tables["records"])
@@ -78,12 +78,15 @@ def _mlp(G, weights, A):
     return net
 
 
+@pytest.mark.parametrize("fold", (False, True))
 @pytest.mark.parametrize("logged", (False, True))
 @pytest.mark.parametrize("level", (None, 40, 8, 2))
 @pytest.mark.parametrize("name", ONPOLICY)
-def test_compact_default_path_gives_the_reference_gradients_on_its_own_on_policy_batch(name, level, logged, monkeypatch):
+def test_compact_default_path_gives_the_reference_gradients_on_its_own_on_policy_batch(name, level, logged, fold, monkeypatch):
     """level: the table size the planner picks for these small batches (None: one group, nothing above it) or a forced one (cuts at
-    every depth: upper rows, shared group roots, several items per bucket).  logged: the LOSSES variant of the learner kernel."""
+    every depth: upper rows, shared group roots, several items per bucket).  logged: the LOSSES variant of the learner kernel.
+    fold: the table forwards and the backward through the legal-fold instantiations of the MLP kernels (what the default step uses
+    wherever the tree allows it)."""
     import _gpu as G
     import rnad_hip
 
@@ -95,11 +98,14 @@ def test_compact_default_path_gives_the_reference_gradients_on_its_own_on_policy
         monkeypatch.setenv("RNAD_BUCKET_ROWS", str(level))
         if rnad_hip.bucket_plan(tree.handle(), B) is None:
             pytest.skip(f"a table of {level} rows does not fit this tree / the LDS with A = {A}")
+    if fold and not tree.handle().legal_foldable:
+        pytest.skip("this tree's legal planes differ from state to state: no fold")
     hp = _hp_of(g)
     nets = [G.mlp_from(g, A, f"w_{tag}_") for tag in ("net", "target", "reg", "reg_")]
     rn = _bare_rnad(G, tree, nets, hp)
+    rn.fold_legal = fold
     log = {} if logged else None
-    ep, perm, tables = _default_path_update(G, rn, tree, g["indices"], g["actions"], g["rewards"], float(g["alpha"]), log)
+    ep, perm, tables = _default_path_update(G, rn, tree, g["indices"], g["actions"], g["rewards"], float(g["alpha"]), log, fold=fold)
     # the premise of the compact learner: the acting policy the reference recorded IS the learner's pi of the slot's row
     T, S = g["indices"].shape[0], tree.handle().S
     rows = g["indices"].astype(np.int64) + (np.arange(T) % 2)[:, None] * S
@@ -122,8 +128,9 @@ def test_compact_default_path_gives_the_reference_gradients_on_its_own_on_policy
         assert torch.equal(ep.masks.cpu(), torch.as_tensor(g["masks"][:, perm]))
 
 
+@pytest.mark.parametrize("fold", (False, True))
 @pytest.mark.parametrize("step", range(6))
-def test_compact_default_path_on_every_step_of_the_reference_run(step):
+def test_compact_default_path_on_every_step_of_the_reference_run(step, fold):
     """tests/golden/run_c1.npz: the reference's RNaD.run (2 regularisation updates x 3 steps, B = 64, on-policy).  Step i with the
     nets the reference had going into it (learner = actor: s{i}_w_actor; target: the EMA after step i - 1; reg / reg_: as rotated) and
     the batch it recorded -> the gradients it recorded (rnad.py:456: after clip_grad_norm_, which does not bind at 10^3).  The run's
@@ -137,7 +144,10 @@ def test_compact_default_path_on_every_step_of_the_reference_run(step):
     nets = [_mlp(G, _pad_width(mlp_weights(g, prefix), 32), A)
             for prefix in (f"s{i}_w_actor_", prev, f"s{i}_net_reg_", f"s{i}_net_reg__")]
     rn = _bare_rnad(G, tree, nets, dict(eta=float(g["eta"]), c=1.0, rho=1.0, gamma=1.0, clip=1e3, thr=2.0))
-    _default_path_update(G, rn, tree, g[f"s{i}_indices"], g[f"s{i}_actions"].argmax(-1), g[f"s{i}_rewards"], float(g[f"s{i}_alpha"]), None)
+    rn.fold_legal = fold
+    assert tree.handle().legal_foldable
+    _default_path_update(G, rn, tree, g[f"s{i}_indices"], g[f"s{i}_actions"].argmax(-1), g[f"s{i}_rewards"], float(g[f"s{i}_alpha"]), None,
+                         fold=fold)
     for k, p in rn.net.named_parameters():
         want = g[f"s{i}_grads_" + k.replace(".", "_")]
         got = G.cpu(p.grad)
