@@ -238,15 +238,22 @@ class Episodes:
     def alive(self, value):
         self.__dict__["_alive"] = value
 
+    def norm_for_learner(self):
+        """The normalisers as rnad_hip.learn_bucketed_compact wants them: when the rollout deferred its alive counts, the device buffer the
+        learner's own launch is about to fill (and read, in its last kernel); valid_counts otherwise."""
+        if self.buckets is not None and getattr(self.buckets, "alive_pending", None) is not None and self._compact is not None:
+            return self.buckets.norm
+        return self.valid_counts
+
     @property
     def valid_counts(self):
         """f64 [2] on the device: number of valid steps of player 0 / player 1 (= N_P of the losses)."""
         T = self.t_eff + 1
         traj = getattr(self, "_traj", None)
         if self.buckets is not None and traj is not None and T == traj.T_cap:
-            # counted by the rollout itself (rnad_rollout_bucketed) -- or, deferred, by the learner's launch that is about to read it on
-            # the stream; callers must not modify it in place
-            return self.buckets.norm
+            if getattr(self.buckets, "alive_pending", None) is not None:  # (deferred to a learner launch that has not happened: complete it)
+                rnad_hip.bucket_alive(self.tree.handle(), self.buckets)
+            return self.buckets.norm  # counted by the rollout itself (rnad_rollout_bucketed); callers must not modify it in place
         a = self.alive[:T].to(torch.float64)
         return torch.stack([a[0::2].sum(), a[1::2].sum()])
 

@@ -519,7 +519,7 @@ class RNaD:
 
         # N_P = #(valid & turn == P): batch-global loss normalisers (vtrace.py:373,388).  Their all-reduce over the ranks is
         # issued first and overlaps the MLP forwards below (RCCL runs it on its own stream).
-        norm = episodes.valid_counts
+        norm = episodes.norm_for_learner() if hasattr(episodes, "norm_for_learner") else episodes.valid_counts
         norm_work = None
         if self._dp():
             norm = norm.clone()  # the all-reduce is in place, and the episodes keep their own count
@@ -548,6 +548,8 @@ class RNaD:
         bucketed = per_row_backward and getattr(episodes, "buckets", None) is not None
         if per_row_backward and not bucketed and B > 2**21:
             per_row_backward = False  # a batch that is not bucket-ordered (a replay sample) beyond the atomics kernel's 2^21 lanes: per-slot backward
+        if not bucketed and getattr(episodes, "buckets", None) is not None:
+            rnad_hip.bucket_alive(self.tree.handle(), episodes.buckets)  # (a no-op unless the rollout left its alive counts to the compact learner)
         live = None
         if (not per_row_backward and getattr(self, "skip_absorbed", True) and log is None and fused_mlp
                 and not self.tree.handle().uniform_length):

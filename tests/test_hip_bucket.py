@@ -537,3 +537,44 @@ def test_staged_actor_plays_the_same_batch(name, rows, monkeypatch):
     seen = vis.bool()
     assert torch.isfinite(staged_logit[seen]).all(), "every visited row must have been evaluated"
     assert torch.equal(staged_logit[seen], full_logit[seen])
+
+
+@pytest.mark.parametrize("name", ("pruned", "ternary4"))
+def test_deferred_alive_counts_are_completed_by_the_learner_or_on_first_read(name):
+    """Episodes.generate(defer_alive=True) leaves the per-step alive counts and the loss normalisers un-summed (one launch less per
+    step).  The compact learner's own launch adds them up before its last kernel reads them; reading `alive` / `valid_counts` earlier
+    completes them on the spot.  Same numbers, same gradient tables as the rollout that sums them itself."""
+    import rnad_hip
+    from environment.episode import Episodes
+
+    tree = _native_tree(**TREES[name])
+    h = tree.handle()
+    A, B = tree.max_actions, 5000
+    nets = _four_nets(A, 64, seed=3)
+    logit, v, vt, lr, lr_ = _tables(tree, nets, A)
+    hp = rnad_hip.make_learn_params(alpha=0.3, eta=0.2)
+    rec, fast = rnad_hip.bucket_records(h, logit, v, vt, lr, lr_, hp, fast=True)
+    actor = (rec, rnad_hip.policy_column(A))
+    kw = dict(tabular=True, bucketed=True, trim=False, store_values=False, policy_table=actor, compact=True)
+    plain = Episodes(tree, B, seed=4)
+    plain.generate(nets[0], **kw)
+    T = plain.t_eff + 1
+    want = rnad_hip.learn_bucketed_compact(h, plain.buckets, plain._compact[0], T, rec, fast, plain.valid_counts, hp)
+    want_alive, want_norm = plain.alive.clone(), plain.valid_counts.clone()
+    # (a) the learner completes them
+    lazy = Episodes(tree, B, seed=4)
+    lazy.generate(nets[0], defer_alive=True, **kw)
+    assert lazy.buckets.alive_pending is lazy._compact[0]
+    got = rnad_hip.learn_bucketed_compact(h, lazy.buckets, lazy._compact[0], T, rec, fast, lazy.norm_for_learner(), hp)
+    assert lazy.buckets.alive_pending is None
+    assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1])
+    assert torch.equal(lazy.alive, want_alive) and torch.equal(lazy.valid_counts, want_norm)
+    # (b) a reader that comes first
+    early = Episodes(tree, B, seed=4)
+    early.generate(nets[0], defer_alive=True, **kw)
+    assert torch.equal(early.alive, want_alive) and early.buckets.alive_pending is None
+    assert torch.equal(early.valid_counts, want_norm)
+    # (c) trim=True reads the counters on the host: never deferred
+    trimmed = Episodes(tree, B, seed=4)
+    trimmed.generate(nets[0], defer_alive=True, **dict(kw, trim=True))
+    assert trimmed.buckets.alive_pending is None and torch.equal(trimmed.alive, want_alive[: trimmed.t_eff + 2])
