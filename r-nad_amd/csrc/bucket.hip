@@ -409,7 +409,7 @@ __global__ __launch_bounds__(kThreads) void k_bucket_keys(const Trans *__restric
         float pol[A], q[A];
         load_policy_row<A>(policy_tab, row, tab_stride, vec4 != 0, pol);
         rnad_exp_noise(seed, (uint64_t)(lane0 + b), (uint32_t)t, 0u, A, q);
-        const int action = race_argmax<A>(pol, q);
+        const int action = race_argmax_drawn<A>(pol, q);
         int chosen = 0;
         if (t & 1) {
             int next;
@@ -654,7 +654,7 @@ __global__ __launch_bounds__(kThreads) void k_bucket_rollout(const Trans *__rest
             if (!replay) {
                 float q[A];
                 rnad_exp_noise(seed, lane, (uint32_t)t, 0u, A, q);
-                action = race_argmax<A>(pol, q);
+                action = race_argmax_drawn<A>(pol, q);
             }
             indices[i] = state;
             mbits[i] = (uint8_t)bits;
@@ -743,10 +743,10 @@ __global__ __launch_bounds__(kThreads) void k_bucket_rollout_compact(const Trans
         if (!replay0) rnad_exp_noise(seed, lane, (uint32_t)t, 0u, A, q0);
         if (two && !replay1) rnad_exp_noise(seed, lane, (uint32_t)(t + 1), 0u, A, q1);
         const int bits0 = replay0 ? (int)(packed >> (6 * t)) & 63 : 0, bits1 = replay1 ? (int)(packed >> (6 * (t + 1))) & 63 : 0;
-        const int a0 = replay0 ? (bits0 & 7) : race_argmax<A>(pol0, q0);
+        const int a0 = replay0 ? (bits0 & 7) : race_argmax_drawn<A>(pol0, q0);
         acts |= (unsigned long long)a0 << (3 * t);
         if (!two) continue;
-        const int a1 = replay1 ? (bits1 & 7) : race_argmax<A>(pol1, q1);
+        const int a1 = replay1 ? (bits1 & 7) : race_argmax_drawn<A>(pol1, q1);
         acts |= (unsigned long long)a1 << (3 * (t + 1));
         int next;
         float rew;

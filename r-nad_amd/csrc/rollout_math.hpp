@@ -49,6 +49,43 @@ __device__ __forceinline__ int race_argmax(const float *p, const float *q) {
     return best;
 }
 
+// RN(pa / qa) > RN(pb / qb), the comparison race_argmax makes, decided without the two IEEE divisions (11 VALU instructions each)
+// whenever the cross products are not within 2^-20 of each other -- all but ~2^-19 of the draws; the rest divide, so the verdict is
+// the reference's in every case.  For noise out of rnad_neg_log_u (q in [2^-24.0, 16.7]) and probabilities (0 <= p <= 2):
+//   x = RN(pa qb), y = RN(pb qa).  x > y (1 + 2^-20) and x >= 2^-100 (x normal, so |x - pa qb| <= 2^-24 x; y's error is relative
+//   2^-24 or absolute 2^-150) give pa/qa > (pb/qb)(1 + 2^-21); pa/qa = x' / (qa qb) >= 2^-100 / 2^9 is a normal number, so its
+//   rounding loses at most 2^-24 of it and RN(pb/qb) gains at most 2^-24 of pb/qb (or 2^-150): strictly greater.
+//   y > x (1 + 2^-20) and y >= 2^-100 give pa/qa < pb/qb, and rounding is monotone: not greater.  pa == 0: RN = 0, never greater.
+// (tests/test_sampling_math.py replays this on the host over adversarial near-ties.)
+__device__ __forceinline__ bool race_beats(float pa, float qa, float pb, float qb) {
+#ifdef RNAD_NO_OPT_RACE
+    return pa / qa > pb / qb;
+#else
+    constexpr float kMargin = 0x1p-20f, kFloor = 0x1p-100f;
+    const float x = pa * qb, y = pb * qa;
+    const bool win = x > fmaxf(fmaf(y, kMargin, y), kFloor);
+    const bool lose = y > fmaxf(fmaf(x, kMargin, x), kFloor) || !(pa > 0.0f);
+    if (win || lose) return win;  // (never both)
+    return pa / qa > pb / qb;
+#endif
+}
+
+// race_argmax for noise drawn by rnad_exp_noise (the range race_beats assumes): same result, no divisions on the common path.
+template <int N>
+__device__ __forceinline__ int race_argmax_drawn(const float *p, const float *q) {
+    int best = 0;
+    float pb = p[0], qb = q[0];
+#pragma unroll
+    for (int a = 1; a < N; ++a) {
+        if (race_beats(p[a], q[a], pb, qb)) {
+            pb = p[a];
+            qb = q[a];
+            best = a;
+        }
+    }
+    return best;
+}
+
 // Runtime category count n <= NMAX without runtime-indexed arrays (those would live in scratch): fully
 // unrolled, predicated on k < n.
 template <int NMAX>
