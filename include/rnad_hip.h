@@ -152,9 +152,13 @@ int rnad_mlp_backward_fold(int64_t N, const int32_t *rows, const int64_t *n_rows
                            float *g_pw0, float *g_pb0, float *g_pw1, float *g_pb1, float *workspace, void *stream);
 
 /* ------------------------------------------------------------------------------------------------
- * K3  sample  --  torch.multinomial(policy, 1) at nn/net.py:49, i.e. argmax_a(policy[a] / q[a]) with
- * q ~ Exp(1), first maximum wins.  q is `noise` (f32 [B,n]) when given, otherwise the seeded
- * stream of include/rnad_rng.h at (seed, lane0 + b, step, stream).
+ * K3  sample  --  torch.multinomial(policy, 1) at nn/net.py:49: one draw from Cat(probs[b]) per lane.
+ * noise (f32 [B,n]) given: torch's own n_sample == 1 algorithm on it, argmax_a(probs[a] / q[a]) with
+ * q = noise ~ Exp(1), first maximum wins -- with the q the reference consumed, the reference's draw.
+ * noise NULL: the SEEDED draw of include/rnad_rng.h -- the inverse CDF of the counter-based uniform of
+ * decision (seed, lane0 + b, step): stream_id 0 = the action of env step `step`, 1 = the chance
+ * draw of the game transition `step` belongs to.  Same distribution, one generator call per
+ * transition, no logarithms or divisions.
  * ---------------------------------------------------------------------------------------------- */
 int rnad_sample(int64_t B, int n, const float *probs, const float *noise, uint64_t seed, int64_t lane0, int step,
                 int stream_id, int32_t *out, void *stream);
@@ -162,7 +166,8 @@ int rnad_sample(int64_t B, int n, const float *probs, const float *noise, uint64
 /* ------------------------------------------------------------------------------------------------
  * K2  transition  --  environment/episode.py:102-123 (States.step, column branch):
  *   t ~ multinomial(chance[s,:,r,c]);  s' = index[s,t,r,c];  reward = value[s,t,r,c] * (s' == 0)
- * noise: f32 [B,C] or NULL (seeded, stream 1).  alive (optional, int32[1]) is incremented by the
+ * noise: f32 [B,C] Exp(1) noise for torch's race, or NULL: the seeded chance draw of env step `step`
+ * (include/rnad_rng.h).  alive (optional, int32[1]) is incremented by the
  * number of lanes with s' != 0 (replaces the host sync of episode.py:124).
  * ---------------------------------------------------------------------------------------------- */
 int rnad_transition(const rnad_tree_t *tree, int64_t B, const int32_t *idx, const int32_t *row_actions,
@@ -199,7 +204,8 @@ int rnad_rollout_begin(const rnad_tree_t *tree, const rnad_traj_t *traj, void *s
  * (even t) indices[t+1] = indices[t], rewards[t] = 0 (episode.py:99-101); and, if t + 1 < T_cap, K1 for
  * step t + 1 as a second launch.  The alive counters are NOT touched per step (one contended atomic word
  * caps at ~90 updates/us on gfx950): rnad_rollout_end counts them once.
- * noise_action [B,A] / noise_chance [B,C]: explicit Exp(1) noise or NULL for the seeded stream. */
+ * noise_action [B,A] / noise_chance [B,C]: explicit Exp(1) noise (torch's race) or NULL for the seeded draws
+ * (include/rnad_rng.h: the uniforms of lane lane0 + b at env step t, inverse CDF). */
 int rnad_rollout_step(const rnad_tree_t *tree, const rnad_traj_t *traj, int t, int mode, const float *logits,
                       const float *policy_in, const int32_t *actions_in, const float *value,
                       const float *noise_action, const float *noise_chance, uint64_t seed, int64_t lane0,
@@ -211,7 +217,7 @@ int rnad_rollout_step(const rnad_tree_t *tree, const rnad_traj_t *traj, int t, i
  * the actor's value head is then not evaluated and traj->values is filled with zeros (the reference stores the actor's
  * values, episode.py:206,218, and never reads them: learn/rnad.py:373 recomputes v from the learner net);
  * logits_ws: [B,A] scratch with logits_step_stride = 0, or a [T_cap,B,A] buffer with logits_step_stride = B*A that
- * keeps the actor's raw logits of every step.  Seeded noise only.
+ * keeps the actor's raw logits of every step.  Seeded draws only.
  * live_rows [B] int32 / n_live [1] / block_counts [rnad_compact_workspace(B)]: all NULL = the actor runs on every lane at
  * every step, as the reference does; all given (logits_step_stride must be 0) = from step 1 on it runs only on the lanes
  * still in the tree (rnad_compact_valid + rnad_mlp_forward_rows); absorbed lanes then carry the logits / value of their
@@ -354,7 +360,7 @@ int rnad_learn_fused_gather(const rnad_tree_t *tree, int T, int64_t B, const int
  *
  * rnad_rollout_bucketed: the rollout of rnad_rollout_run_tabular -- same tabular actor (table row = player * S + state,
  * table_stride floats apart; table_is_policy == 0: the actor's logits, whose policy head is then taken once per row;
- * != 0: the actor's policy rows, e.g. the pi columns of rnad_bucket_records), same seeded noise keyed by the GLOBAL lane
+ * != 0: the actor's policy rows, e.g. the pi columns of rnad_bucket_records), same seeded draws keyed by the GLOBAL lane
  * id lane0 + lane, hence the same episodes bit for bit -- with column j of every [T_cap, B] buffer holding lane lane_ids[j]
  * (a stable sort of the lanes by bucket).  traj->observations is not written (may be NULL; an observation is a function of
  * (t & 1, indices[t]): rnad_observe), traj->values only if non-NULL (value_table NULL: zeros).  items / n_items: the learner's

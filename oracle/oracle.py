@@ -36,6 +36,7 @@ def lib():
         _lib.oracle_loss_v.restype = C.c_double
         _lib.oracle_loss_nerd.restype = C.c_double
         _lib.oracle_neg_log_u.restype = C.c_float
+        _lib.oracle_uniform.restype = C.c_float
         _lib.oracle_rollout.restype = C.c_int
     return _lib
 
@@ -76,15 +77,45 @@ def noise(B, n, seed, lane0, t, stream):
     return out
 
 
+def uniforms(B, seed, lane0, t):
+    """[B, 3]: the seeded uniforms of lanes lane0 .. lane0 + B - 1 for the game transition of env step t (include/rnad_rng.h):
+    column 0 the row player's action draw, 1 the column player's, 2 the chance draw."""
+    out = np.empty((B, 3), np.float32)
+    lib().oracle_uniforms(C.c_int64(B), C.c_uint64(seed), C.c_int64(lane0), t, _p(out))
+    return out
+
+
+def action_uniform(B, seed, lane0, t):
+    """[B]: the uniform that decides the action of env step t."""
+    return np.ascontiguousarray(uniforms(B, seed, lane0, t)[:, t & 1])
+
+
+def chance_uniform(B, seed, lane0, t):
+    """[B]: the uniform that decides the chance outcome of the transition env step t belongs to."""
+    return np.ascontiguousarray(uniforms(B, seed, lane0, t)[:, 2])
+
+
+def pick(policy, u):
+    """The seeded draw: inverse CDF of u over the rows of policy."""
+    policy, u = _f32(policy), _f32(u)
+    B, A = policy.shape
+    assert u.shape == (B,)
+    out = np.empty((B,), np.int64)
+    lib().oracle_pick(C.c_int64(B), A, _p(policy), _p(u), _p(out))
+    return out
+
+
 def transition(index, chance, value, idx, row_a, col_a, noise_c):
+    """noise_c [B, C]: explicit Exp(1) noise (torch's race); [B]: the seeded chance uniform (inverse CDF)."""
     index, chance, value = _i64(index), _f32(chance), _f32(value)
     idx, row_a, col_a, noise_c = _i64(idx), _i64(row_a), _i64(col_a), _f32(noise_c)
     _, Cc, A, _ = index.shape
     B = idx.shape[0]
     out = np.empty((B,), np.int64)
     rew = np.empty((B,), np.float32)
-    lib().oracle_transition(C.c_int64(B), A, Cc, _p(index), _p(chance), _p(value), _p(idx), _p(row_a), _p(col_a),
-                            _p(noise_c), _p(out), _p(rew))
+    fn = lib().oracle_transition_pick if noise_c.ndim == 1 else lib().oracle_transition
+    assert noise_c.shape == ((B,) if noise_c.ndim == 1 else (B, Cc))
+    fn(C.c_int64(B), A, Cc, _p(index), _p(chance), _p(value), _p(idx), _p(row_a), _p(col_a), _p(noise_c), _p(out), _p(rew))
     return out, rew
 
 

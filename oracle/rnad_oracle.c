@@ -79,8 +79,23 @@ EXPORT void oracle_sample(int64_t B, int A, const float *policy, const float *no
     for (int64_t b = 0; b < B; ++b) actions[b] = race_argmax(A, policy + b * A, noise + b * A);
 }
 
-/* Seeded variant: the Exp(1) noise for lane `lane`, step `t`, stream `stream` comes from the
- * counter-based generator in rnad_rng.h (shared, bit for bit, with the HIP kernels). */
+/* The SEEDED draw of include/rnad_rng.h (shared, bit for bit, with the HIP kernels): torch.multinomial's
+ * contract -- one sample of Cat(p / sum p) -- from the decision's own counter-based uniform by the
+ * inverse CDF.  u[b] is lane b's uniform for this decision (oracle_uniforms). */
+EXPORT void oracle_pick(int64_t B, int A, const float *policy, const float *u, int64_t *actions) {
+#pragma omp parallel for schedule(static)
+    for (int64_t b = 0; b < B; ++b) actions[b] = rnad_pick(policy + b * A, A, u[b]);
+}
+
+/* u[b, 0..2] = the uniforms of lane lane0 + b for the game transition env step t belongs to:
+ * [0] row player's action, [1] column player's action, [2] chance outcome. */
+EXPORT void oracle_uniforms(int64_t B, uint64_t seed, int64_t lane0, int t, float *u) {
+#pragma omp parallel for schedule(static)
+    for (int64_t b = 0; b < B; ++b) rnad_decision_uniforms(seed, (uint64_t)(lane0 + b), (uint32_t)t, u + 3 * b);
+}
+
+/* Reproducible Exp(1) noise for the explicit-noise entry points: lane `lane`, step `t`, stream
+ * `stream` of the counter-based generator in rnad_rng.h. */
 EXPORT void oracle_noise(int64_t B, int n, uint64_t seed, int64_t lane0, int t, int stream, float *noise) {
 #pragma omp parallel for schedule(static)
     for (int64_t b = 0; b < B; ++b) rnad_exp_noise(seed, (uint64_t)(lane0 + b), (uint32_t)t, (uint32_t)stream, n, noise + b * n);
@@ -104,6 +119,23 @@ EXPORT void oracle_transition(int64_t B, int A, int C, const int64_t *index_t, c
         const int64_t nxt = index_t[base + (int64_t)t * AA];
         idx_out[b] = nxt;
         reward[b] = value[base + (int64_t)t * AA] * (nxt == 0 ? 1.0f : 0.0f); /* rewards *= (indices == 0) */
+    }
+}
+
+/* The same step with the seeded chance draw: outcome = rnad_pick(chance[s,:,r,c], u[b]). */
+EXPORT void oracle_transition_pick(int64_t B, int A, int C, const int64_t *index_t, const float *chance,
+                                   const float *value, const int64_t *idx, const int64_t *row_a,
+                                   const int64_t *col_a, const float *u, int64_t *idx_out, float *reward) {
+    const int AA = A * A;
+#pragma omp parallel for schedule(static)
+    for (int64_t b = 0; b < B; ++b) {
+        float p[64];
+        const int64_t base = idx[b] * C * AA + row_a[b] * A + col_a[b];
+        for (int t = 0; t < C; ++t) p[t] = chance[base + (int64_t)t * AA];
+        const int t = rnad_pick(p, C, u[b]);
+        const int64_t nxt = index_t[base + (int64_t)t * AA];
+        idx_out[b] = nxt;
+        reward[b] = value[base + (int64_t)t * AA] * (nxt == 0 ? 1.0f : 0.0f);
     }
 }
 
@@ -445,7 +477,7 @@ EXPORT int oracle_rollout(int64_t B, int A, int C, int W, int T_cap, const int64
     int64_t *idx = (int64_t *)malloc(sizeof(int64_t) * B);
     int64_t *player = (int64_t *)malloc(sizeof(int64_t) * B);
     int64_t *row_a = (int64_t *)malloc(sizeof(int64_t) * B);
-    float *noise = (float *)malloc(sizeof(float) * B * (A > C ? A : C));
+    float *u3 = (float *)malloc(sizeof(float) * B * 3), *u = (float *)malloc(sizeof(float) * B);
     float *logits = (float *)malloc(sizeof(float) * B * A);
     for (int64_t b = 0; b < B; ++b) idx[b] = 1;
     int t = 0;
@@ -464,20 +496,22 @@ EXPORT int oracle_rollout(int64_t B, int A, int C, int W, int T_cap, const int64
                            values + (int64_t)t * B);
         if (logits_out) memcpy(logits_out + (int64_t)t * B * A, logits, sizeof(float) * B * A);
         oracle_policy_head(B, A, logits, mask_t, pol_t, NULL);
-        oracle_noise(B, A, seed, lane0, t, 0, noise);
-        oracle_sample(B, A, pol_t, noise, act_t);
+        if ((t & 1) == 0) oracle_uniforms(B, seed, lane0, t, u3);  /* one generator call per game transition */
+        for (int64_t b = 0; b < B; ++b) u[b] = u3[3 * b + (t & 1)];
+        oracle_pick(B, A, pol_t, u, act_t);
         if ((t & 1) == 0) {
             memcpy(row_a, act_t, sizeof(int64_t) * B);
             memset(rewards + (int64_t)t * B, 0, sizeof(float) * B);
         } else {
-            oracle_noise(B, C, seed, lane0, t, 1, noise);
-            oracle_transition(B, A, C, index_t, chance, value, idx, row_a, act_t, noise, idx, rewards + (int64_t)t * B);
+            for (int64_t b = 0; b < B; ++b) u[b] = u3[3 * b + 2];
+            oracle_transition_pick(B, A, C, index_t, chance, value, idx, row_a, act_t, u, idx, rewards + (int64_t)t * B);
         }
     }
-    free(idx); free(player); free(row_a); free(noise); free(logits);
+    free(idx); free(player); free(row_a); free(u3); free(u); free(logits);
     return t;
 }
 
 /* Known-answer hook for the counter-based generator (tests/test_rng.py). */
 EXPORT void oracle_philox(uint32_t *ctr, uint32_t k0, uint32_t k1) { rnad_philox4x32_10(ctr, k0, k1); }
 EXPORT float oracle_neg_log_u(uint32_t x) { return rnad_neg_log_u(x); }
+EXPORT float oracle_uniform(uint32_t x) { return rnad_uniform(x); }

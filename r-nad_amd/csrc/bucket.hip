@@ -17,7 +17,7 @@
 //
 //   k_bucket_keys      lane-ordered: plays the env steps above the cut only, key = the group reached (or the upper state the lane ends in)
 //   k_bucket_hist/scan/items/scatter   stable counting sort of the lanes by key (deterministic), work items per bucket
-//   k_bucket_rollout   bucket-ordered: thread j replays lane lane_ids[j] from the root (counter-based noise keyed by the GLOBAL lane
+//   k_bucket_rollout   bucket-ordered: thread j replays lane lane_ids[j] from the root (counter-based draws keyed by the GLOBAL lane
 //                      id, include/rnad_rng.h) and records the trajectory -- column j of every [T, B] buffer, or (COMPACT) of
 //                      `indices` alone plus 12 bytes per lane: packed actions and the episode's one reward
 //   k_bucket_expand    the dense [T, B] buffers of a compact trajectory, when something asks for them
@@ -399,34 +399,30 @@ __global__ __launch_bounds__(kThreads) void k_bucket_keys(const Trans *__restric
     if (b >= B) return;
     if (b == 0 && norm) norm[0] = norm[1] = 0.0;  // summed up by k_bucket_alive at the end of this rollout
     if (sp) seed = sp->seed;  // per-step scalars in device memory: a captured graph of the step replays with new values
-    int state = 1, key = bucket_of[1], prev = 0;
+    int state = 1, key = bucket_of[1];
     // decisions: what this lane drew at its first kPackedSteps env steps -- 3 bits of action and 3 bits of chance outcome per step,
-    // the number of steps recorded in the top 4 bits -- so that k_bucket_rollout replays them without drawing the noise again
+    // the number of steps recorded in the top 4 bits -- so that k_bucket_rollout replays them without drawing again
     unsigned long long packed = 0ull;
     int t = 0;
-    for (; t < n_steps && key >= n_groups; ++t) {
-        const int64_t row = (int64_t)(t & 1) * S + state;
-        float pol[A], q[A];
-        load_policy_row<A>(policy_tab, row, tab_stride, vec4 != 0, pol);
-        rnad_exp_noise(seed, (uint64_t)(lane0 + b), (uint32_t)t, 0u, A, q);
-        const int action = race_argmax_drawn<A>(pol, q);
-        int chosen = 0;
-        if (t & 1) {
-            int next;
-            float rew;
-            transition_lane<A>(trans, C, state, prev, action, nullptr, seed, (uint64_t)(lane0 + b), (uint32_t)t, next, rew, &chosen);
-            state = next;
-        } else {
-            prev = action;
-        }
-        if (t < kPackedSteps) packed |= (unsigned long long)(action | (chosen << 3)) << (6 * t);
-        if (t & 1) {
-            if (state == 0) {
-                ++t;
-                break;
-            }
-            key = bucket_of[state];
-        }
+    while (t < n_steps && key >= n_groups) {  // one game transition per iteration: both players' steps in `state`, then the chance draw
+        const bool two = t + 1 < n_steps;
+        float u[3], pol0[A], pol1[A];
+        load_policy_row<A>(policy_tab, state, tab_stride, vec4 != 0, pol0);
+        if (two) load_policy_row<A>(policy_tab, S + state, tab_stride, vec4 != 0, pol1);
+        rnad_decision_uniforms(seed, (uint64_t)(lane0 + b), (uint32_t)t, u);
+        const int a0 = pick<A>(pol0, u[0]);
+        if (t < kPackedSteps) packed |= (unsigned long long)a0 << (6 * t);
+        ++t;
+        if (!two) break;
+        const int a1 = pick<A>(pol1, u[1]);
+        int next, chosen = 0;
+        float rew;
+        transition_lane<A>(trans, C, state, a0, a1, nullptr, u[2], next, rew, &chosen);
+        if (t < kPackedSteps) packed |= (unsigned long long)(a1 | (chosen << 3)) << (6 * t);
+        ++t;
+        state = next;
+        if (state == 0) break;
+        key = bucket_of[state];
     }
     keys[b] = key;
     decisions[b] = packed | ((unsigned long long)min(t, kPackedSteps) << 60);
@@ -612,7 +608,7 @@ __global__ __launch_bounds__(kSortThreads) void k_bucket_scatter(int64_t B, int 
 // ---------------------------------------------------------------------------------------- 3. rollout in bucket order
 // Episodes.generate (episode.py:194-212) for thread j = lane lane_ids[j]: per env step the tabular actor's policy row of
 // (player to move, state) (the policy head of net.py:45-46, evaluated once per row by k_policy_rows / k_row_records instead of
-// once per slot: same function, same input, same bits), the Exp(1) race (net.py:49), the record, and on the column player's
+// once per slot: same function, same input, same bits), the seeded draw (net.py:49; include/rnad_rng.h), the record, and on the column player's
 // turn the chance draw and transition (episode.py:106-121) -- the arithmetic of k_act, with state and the row action kept in
 // registers across the T_cap steps and column j of every [T_cap, B] buffer written coalesced.  Observations are not written
 // (a function of (t & 1, indices): materialised on demand), `values` only if asked for.
@@ -638,10 +634,12 @@ __global__ __launch_bounds__(kThreads) void k_bucket_rollout(const Trans *__rest
     const int n_packed = (int)(packed >> 60);
     const int wave = threadIdx.x >> 6;
     int state = 1, prev = 0;
+    float u[3] = {0.0f, 0.0f, 0.0f};  // the seeded uniforms of the current game transition
     for (int t = 0; t < T_cap; ++t) {
         const uint64_t live = __ballot(active && state != 0);
         if ((threadIdx.x & 63) == 0) cnt[wave][t] = (int32_t)__popcll(live);
         if (active) {
+            if (!(t & 1) && t + 1 >= n_packed) rnad_decision_uniforms(seed, lane, (uint32_t)t, u);  // (some step of it is not a replay)
             const int64_t i = (int64_t)t * B + j;
             const int64_t row = (int64_t)(t & 1) * S + state;
             const bool replay = t < n_packed;
@@ -651,11 +649,7 @@ __global__ __launch_bounds__(kThreads) void k_bucket_rollout(const Trans *__rest
             float pol[A];
 #pragma unroll
             for (int a = 0; a < A; ++a) pol[a] = policy_tab[row * tab_stride + a];
-            if (!replay) {
-                float q[A];
-                rnad_exp_noise(seed, lane, (uint32_t)t, 0u, A, q);
-                action = race_argmax_drawn<A>(pol, q);
-            }
+            if (!replay) action = pick<A>(pol, u[t & 1]);
             indices[i] = state;
             mbits[i] = (uint8_t)bits;
 #pragma unroll
@@ -668,7 +662,7 @@ __global__ __launch_bounds__(kThreads) void k_bucket_rollout(const Trans *__rest
                 if (replay)
                     transition_apply<A>(trans, C, state, prev, action, bits6 >> 3, next, rew);
                 else
-                    transition_lane<A>(trans, C, state, prev, action, nullptr, seed, lane, (uint32_t)t, next, rew);
+                    transition_lane<A>(trans, C, state, prev, action, nullptr, u[2], next, rew);
             } else {
                 prev = action;
             }
@@ -693,8 +687,8 @@ __global__ __launch_bounds__(kThreads) void k_bucket_rollout(const Trans *__rest
 // the transition into state 0 pays; reward_out).  Everything else of a slot is a function of (t & 1, indices[t]) and the actor's
 // table (k_bucket_expand writes the dense buffers on demand).
 // One TRANSITION (the row player's step and the column player's step in the same state) per iteration: both
-// policy rows of the state are requested together and both noise draws are computed while they travel, so a transition costs two
-// dependent memory latencies (policy rows, transition record) instead of three.  Same draws (noise keyed by lane and step), same
+// policy rows of the state are requested together and the transition's uniforms are computed while they travel, so a transition costs two
+// dependent memory latencies (policy rows, transition record) instead of three.  Same draws (keyed by lane and step), same
 // episodes as k_bucket_rollout.  An absorbed lane stops: no draws, no table reads.
 template <int A>
 __global__ __launch_bounds__(kThreads) void k_bucket_rollout_compact(const Trans *__restrict__ trans, int C, int64_t S, int64_t B, int T_cap,
@@ -737,23 +731,22 @@ __global__ __launch_bounds__(kThreads) void k_bucket_rollout_compact(const Trans
             visited[row0] = 1;  // (every writer stores the same value)
             if (two) visited[row1] = 1;
         }
-        float pol0[A], pol1[A], q0[A], q1[A];
+        float pol0[A], pol1[A], u[3];
         if (!replay0) load_policy_row<A>(policy_tab, row0, tab_stride, vec4 != 0, pol0);
         if (two && !replay1) load_policy_row<A>(policy_tab, row1, tab_stride, vec4 != 0, pol1);
-        if (!replay0) rnad_exp_noise(seed, lane, (uint32_t)t, 0u, A, q0);
-        if (two && !replay1) rnad_exp_noise(seed, lane, (uint32_t)(t + 1), 0u, A, q1);
+        if (!replay0 || (two && !replay1)) rnad_decision_uniforms(seed, lane, (uint32_t)t, u);  // computed while the rows travel
         const int bits0 = replay0 ? (int)(packed >> (6 * t)) & 63 : 0, bits1 = replay1 ? (int)(packed >> (6 * (t + 1))) & 63 : 0;
-        const int a0 = replay0 ? (bits0 & 7) : race_argmax_drawn<A>(pol0, q0);
+        const int a0 = replay0 ? (bits0 & 7) : pick<A>(pol0, u[0]);
         acts |= (unsigned long long)a0 << (3 * t);
         if (!two) continue;
-        const int a1 = replay1 ? (bits1 & 7) : race_argmax_drawn<A>(pol1, q1);
+        const int a1 = replay1 ? (bits1 & 7) : pick<A>(pol1, u[1]);
         acts |= (unsigned long long)a1 << (3 * (t + 1));
         int next;
         float rew;
         if (replay1)
             transition_apply<A>(trans, C, state, a0, a1, bits1 >> 3, next, rew);
         else
-            transition_lane<A>(trans, C, state, a0, a1, nullptr, seed, lane, (uint32_t)(t + 1), next, rew);
+            transition_lane<A>(trans, C, state, a0, a1, nullptr, u[2], next, rew);
         if (next == 0) reward_final = rew;
         state = next;
     }

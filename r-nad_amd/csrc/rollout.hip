@@ -46,13 +46,17 @@ __global__ __launch_bounds__(kThreads) void k_sample(int64_t B, int n, const flo
                                                      int stream_id, int32_t *__restrict__ out) {
     const int64_t b = (int64_t)blockIdx.x * kThreads + threadIdx.x;
     if (b >= B) return;
-    float p[RNAD_MAX_ACTIONS], q[RNAD_MAX_ACTIONS];
+    float p[RNAD_MAX_ACTIONS];
     load_n<RNAD_MAX_ACTIONS>(probs + b * n, n, p);
-    if (noise)
+    if (noise) {  // explicit Exp(1) noise: torch's race
+        float q[RNAD_MAX_ACTIONS];
         load_n<RNAD_MAX_ACTIONS>(noise + b * n, n, q);
-    else
-        exp_noise_n<RNAD_MAX_ACTIONS>(seed, (uint64_t)(lane0 + b), (uint32_t)step, (uint32_t)stream_id, n, q);
-    out[b] = race_argmax_n<RNAD_MAX_ACTIONS>(n, p, q);
+        out[b] = race_argmax_n<RNAD_MAX_ACTIONS>(n, p, q);
+    } else {  // seeded: the uniform of this decision (stream 0: the action of env step `step`; 1: the chance draw of its transition)
+        float u[3];
+        rnad_decision_uniforms(seed, (uint64_t)(lane0 + b), (uint32_t)step, u);
+        out[b] = pick_n<RNAD_MAX_ACTIONS>(n, p, stream_id ? u[2] : u[step & 1]);
+    }
 }
 
 template <int A>
@@ -66,8 +70,9 @@ __global__ __launch_bounds__(kThreads) void k_transition(const Trans *__restrict
     if (b < B) {
         int next;
         float rew;
-        transition_lane<A>(trans, C, idx[b], row_a[b], col_a[b], noise ? noise + b * C : nullptr, seed, (uint64_t)(lane0 + b),
-                           (uint32_t)step, next, rew);
+        float u[3] = {0.0f, 0.0f, 0.0f};
+        if (!noise && C > 1) rnad_decision_uniforms(seed, (uint64_t)(lane0 + b), (uint32_t)step, u);
+        transition_lane<A>(trans, C, idx[b], row_a[b], col_a[b], noise ? noise + b * C : nullptr, u[2], next, rew);
         idx_out[b] = next;
         reward[b] = rew;
         live = next != 0;
@@ -112,17 +117,17 @@ __global__ __launch_bounds__(kThreads) void k_act(const Trans *__restrict__ tran
             for (int a = 0; a < A; ++a) pol[a] = in[a];
         }
         int action;
+        float u[3] = {0.0f, 0.0f, 0.0f};  // the seeded uniforms of this step's game transition (include/rnad_rng.h)
+        if ((MODE != 2 && !noise_a) || ((t & 1) && !noise_c && C > 1)) rnad_decision_uniforms(seed, (uint64_t)(lane0 + b), (uint32_t)t, u);
         if (MODE == 2) {
             action = actions_in[b];
-        } else {
+        } else if (noise_a) {  // explicit Exp(1) noise: torch's race
             float q[A];
-            if (noise_a) {
 #pragma unroll
-                for (int a = 0; a < A; ++a) q[a] = noise_a[b * A + a];
-            } else {
-                rnad_exp_noise(seed, (uint64_t)(lane0 + b), (uint32_t)t, 0u, A, q);
-            }
+            for (int a = 0; a < A; ++a) q[a] = noise_a[b * A + a];
             action = race_argmax<A>(pol, q);
+        } else {
+            action = pick<A>(pol, u[t & 1]);
         }
 #pragma unroll
         for (int a = 0; a < A; ++a) policy_t[b * A + a] = pol[a];
@@ -132,8 +137,7 @@ __global__ __launch_bounds__(kThreads) void k_act(const Trans *__restrict__ tran
         int next = s;
         float rew = 0.0f;  // row turn: torch.zeros (episode.py:101)
         if (t & 1)
-            transition_lane<A>(trans, C, s, act_prev[b], action, noise_c ? noise_c + b * C : nullptr, seed,
-                               (uint64_t)(lane0 + b), (uint32_t)t, next, rew);
+            transition_lane<A>(trans, C, s, act_prev[b], action, noise_c ? noise_c + b * C : nullptr, u[2], next, rew);
         idx_next[b] = next;
         rewards_t[b] = rew;
     }

@@ -13,9 +13,12 @@ What differs from the reference (all documented in INTEGRATION.md):
     absorbed);
   * `turns`, `actions` (one-hot), `masks`, `q_estimates`, `v_estimates` are materialised lazily from the compact
     primaries (`t & 1`, `action_idx` int32, `mask_bits` u8 / a strided view of `observations`);
-  * randomness: the sampler is the reference's (`argmax(p / q)`, q ~ Exp(1) == torch CPU multinomial) but q comes from
-    the counter-based stream of include/rnad_rng.h keyed by (seed, global lane, step) instead of torch's global
-    generator.  `seed` defaults to a draw from torch's generator, so `torch.manual_seed` still makes runs repeatable.
+  * randomness: torch.multinomial's global sequential generator cannot feed 2^20 lanes, so every decision is a function of
+    (seed, global lane, env step): a counter-based uniform (one philox call per game transition) turned into a category by
+    the inverse CDF (include/rnad_rng.h) -- one draw from Cat(p) per lane, as torch.multinomial(p, 1) gives.  Explicit
+    Exp(1) noise (`noise_action`, `noise_chance`) goes through torch's own algorithm instead, `argmax(p / q)`: with the
+    noise the reference consumed, the reference's episodes.  `seed` defaults to a draw from torch's generator, so
+    `torch.manual_seed` still makes runs repeatable.
 """
 import random
 import time
@@ -91,7 +94,7 @@ class States:
 
     def step(self, actions: torch.Tensor, noise=None) -> torch.Tensor:
         """Commit the mover's actions; on the column player's turn sample chance and transition (episode.py:84-125).
-        `noise` (f32 [B, C], Exp(1)) replaces the seeded chance noise; tests use it to replay the reference."""
+        `noise` (f32 [B, C], Exp(1)) replaces the seeded chance draw by torch's race on it; tests use it to replay the reference."""
         actions = actions.to(device=self.indices.device, dtype=torch.int32).contiguous().view(-1)
         if self._player == 0:
             self.row_actions = actions

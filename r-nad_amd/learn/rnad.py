@@ -15,7 +15,7 @@ EMA target, regularisation-net rotation.  What one iteration executes depends on
             fused MLP backward with the closed-form dL/dlogit, dL/dv -> clip -> Adam -> EMA.  What the reference does, slot for slot.
 
 Data parallel: when torch.distributed is initialised (one process per GPU, backend "nccl" == RCCL over xGMI), every rank
-plays `batch_size // world_size` lanes of the SAME seeded noise stream (global lane ids), the two loss normalisers are
+plays `batch_size // world_size` lanes of the SAME seeded draws (global lane ids), the two loss normalisers are
 all-reduced (they are batch-global, learn/vtrace.py:373,388; beside the learner kernel, which sums un-normalised addends), and the
 10 756 parameter gradients are all-reduced (sum) in one flat bucket before clipping.  No other communication.
 """

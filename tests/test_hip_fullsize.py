@@ -15,8 +15,8 @@ def _arrays(tree):
 
 
 def _check_lanes_against_oracle(ep, arrs, lanes, seed, C, half=False, lane_ids=None):
-    """Given the policy bits the GPU produced and the seeded noise, every recorded step of `lanes` must be what the oracle computes.
-    lane_ids (bucket-ordered batches): `lanes` are COLUMNS of the buffers, column j holds lane lane_ids[j] -- the id its noise is keyed by."""
+    """Given the policy bits the GPU produced and the seeded uniforms (include/rnad_rng.h), every recorded step of `lanes` must be what the oracle computes.
+    lane_ids (bucket-ordered batches): `lanes` are COLUMNS of the buffers, column j holds lane lane_ids[j] -- the id its draws are keyed by."""
     from oracle import oracle
 
     T = ep.t_eff + 1
@@ -35,15 +35,14 @@ def _check_lanes_against_oracle(ep, arrs, lanes, seed, C, half=False, lane_ids=N
     for t in range(T):
         want_obs, want_mask = oracle.observe(arrs["expected_value"], arrs["legal"], idx[t], np.full(n, t & 1))
         assert_bits_equal(obs[t], want_obs.astype(np.float16) if half else want_obs, f"observe t={t}")
-        noise = np.stack([oracle.noise(1, A, seed, int(b), t, 0)[0] for b in lanes])
-        drawn = oracle.sample(pol[t], noise)
+        u3 = np.stack([oracle.uniforms(1, seed, int(b), t)[0] for b in lanes])  # [n, 3]: row action, column action, chance
+        drawn = oracle.pick(pol[t], np.ascontiguousarray(u3[:, t & 1]))
         if lane_ids is not None:  # a compact batch stops drawing once a lane is absorbed (its slots show action 0; nothing reads them)
             drawn = np.where(idx[t] != 0, drawn, 0)
         np.testing.assert_array_equal(drawn, act[t], err_msg=f"sample t={t}")
         assert ((pol[t] > 0) == (want_mask > 0)).all()
         if t & 1:
-            noise_c = np.stack([oracle.noise(1, C, seed, int(b), t, 1)[0] for b in lanes])
-            nxt, r = oracle.transition(arrs["index"], arrs["chance"], arrs["value"], idx[t], act[t - 1], act[t], noise_c)
+            nxt, r = oracle.transition(arrs["index"], arrs["chance"], arrs["value"], idx[t], act[t - 1], act[t], np.ascontiguousarray(u3[:, 2]))
             np.testing.assert_array_equal(nxt, idx[t + 1] if t + 1 < T else nxt_last)
             assert_bits_equal(rew[t], r, f"reward t={t}")
         else:

@@ -90,7 +90,7 @@ def test_sampler_and_transition_replay_reference_noise(G, hip, name):
             assert int(alive.item()) == int((want_next != 0).sum())
 
 
-def test_seeded_noise_matches_oracle_bit_for_bit(G, hip):
+def test_seeded_draws_match_oracle_bit_for_bit(G, hip):
     from oracle import oracle
 
     rng = np.random.default_rng(3)
@@ -101,7 +101,9 @@ def test_seeded_noise_matches_oracle_bit_for_bit(G, hip):
         p[:, 0] = np.maximum(p[:, 0], 1e-3)
         for seed, lane0, step, stream in ((1, 0, 0, 0), (2**40 + 17, 2**33, 11, 1), (99, 123456, 31, 0)):
             got = hip.sample(G.gpu(p), seed=seed, lane0=lane0, step=step, stream_id=stream)
-            want = oracle.sample(p, oracle.noise(B, n, seed, lane0, step, stream))
+            u = oracle.chance_uniform(B, seed, lane0, step) if stream else oracle.action_uniform(B, seed, lane0, step)
+            want = oracle.pick(p, u)
+            assert (p[np.arange(B), want] > 0).all()  # a category of weight zero is never drawn
             np.testing.assert_array_equal(G.cpu(got), want)
 
 
@@ -120,7 +122,7 @@ def test_seeded_transition_matches_oracle(G, hip, name):
     seed, lane0, step = 77, 10**6, 5
     nxt, rew = hip.transition(tree.handle(), G.gpu(idx, torch.int32), G.gpu(r, torch.int32), G.gpu(c, torch.int32), seed=seed,
                               lane0=lane0, step=step)
-    want_next, want_rew = oracle.transition(g["index"], g["chance"], g["value"], idx, r, c, oracle.noise(B, C, seed, lane0, step, 1))
+    want_next, want_rew = oracle.transition(g["index"], g["chance"], g["value"], idx, r, c, oracle.chance_uniform(B, seed, lane0, step))
     np.testing.assert_array_equal(G.cpu(nxt), want_next)
     assert_bits_equal(G.cpu(rew), want_rew, "reward")
 

@@ -64,7 +64,7 @@ def test_env_kernels_on_random_trees(A, C):
     r = np.array([rng.choice(np.flatnonzero(lg[b, :, 0])) for b in range(B)])
     c = np.array([rng.choice(np.flatnonzero(lg[b, 0, :])) for b in range(B)])
     for mode in ("seeded", "explicit"):
-        noise = rng.exponential(size=(B, C)).astype(np.float32) if mode == "explicit" else oracle.noise(B, C, 11, 7, 3, 1)
+        noise = rng.exponential(size=(B, C)).astype(np.float32) if mode == "explicit" else oracle.chance_uniform(B, 11, 7, 3)
         nxt, rew = rnad_hip.transition(h, gpu(idx, torch.int32), gpu(r, torch.int32), gpu(c, torch.int32),
                                        noise=gpu(noise) if mode == "explicit" else None, seed=11, lane0=7, step=3)
         want_next, want_rew = oracle.transition(arrs["index"], arrs["chance"], arrs["value"], idx, r, c, noise)

@@ -1,4 +1,4 @@
-"""Known-answer tests for the seeded-noise contract (include/rnad_rng.h), via the oracle build."""
+"""Known-answer and distribution tests for the seeded-draw contract (include/rnad_rng.h), via the oracle build."""
 import numpy as np
 
 from oracle import oracle
@@ -40,3 +40,69 @@ def test_noise_is_exponential_and_lane_addressed():
     # 5 slots = two philox blocks
     c = oracle.noise(16, 5, seed=7, lane0=0, t=4, stream=0)
     np.testing.assert_array_equal(c[:, :3], a[:16])
+
+
+def test_decision_uniforms_are_the_documented_philox_words():
+    """u[i] = (2 (x[i] >> 9) + 1) 2^-24 of philox(counter {lane_lo, lane_hi, t_even | 2 << 24, 0}, key {seed_lo, seed_hi})."""
+    seed, lane0 = 2**40 + 17, 2**33 + 5
+    for t in (0, 1, 6, 7, 31):
+        u = oracle.uniforms(4, seed, lane0, t)
+        for b in range(4):
+            lane = lane0 + b
+            x = oracle.philox((lane & 0xFFFFFFFF, lane >> 32, (t & ~1) | (2 << 24), 0), seed & 0xFFFFFFFF, seed >> 32)
+            want = [np.float32((2 * (int(w) >> 9) + 1) * 2.0**-24) for w in x[:3]]
+            assert [float(v) for v in u[b]] == [float(v) for v in want]
+    # both steps of a transition read the same block; lanes are addressed globally (sharding invariance)
+    np.testing.assert_array_equal(oracle.uniforms(8, 3, 100, 4), oracle.uniforms(8, 3, 100, 5))
+    np.testing.assert_array_equal(oracle.uniforms(200, 3, 0, 4)[100:108], oracle.uniforms(8, 3, 100, 4))
+    assert not np.array_equal(oracle.uniforms(8, 3, 100, 4), oracle.uniforms(8, 3, 100, 6))
+    assert not np.array_equal(oracle.uniforms(8, 3, 100, 4), oracle.uniforms(8, 4, 100, 4))
+    u = oracle.uniforms(1 << 18, 1, 0, 0)
+    assert u.min() > 0 and u.max() < 1 and abs(u.mean() - 0.5) < 2e-3
+    assert abs(np.corrcoef(u[:, 0], u[:, 1])[0, 1]) < 0.01 and abs(np.corrcoef(u[:, 1], u[:, 2])[0, 1]) < 0.01
+
+
+def _pick_reference(p, u):
+    """The definition in plain numpy fp32: the number of running sums (index order) that are <= u * total."""
+    c = np.zeros(len(p), np.float32)
+    k = np.zeros(len(p), np.int64)
+    s = np.zeros(len(p), np.float32)
+    for a in range(p.shape[1]):
+        s = (s + p[:, a]).astype(np.float32)
+    target = (u * s).astype(np.float32)
+    for a in range(p.shape[1] - 1):
+        c = (c + p[:, a]).astype(np.float32)
+        k += c <= target
+    return k
+
+
+def test_pick_is_the_inverse_cdf_and_never_draws_a_zero_weight():
+    rng = np.random.default_rng(4)
+    for n in (1, 2, 3, 5, 8):
+        B = 200_000
+        p = rng.dirichlet(np.ones(n), size=B).astype(np.float32)
+        p[rng.random((B, n)) < 0.3] = 0
+        p[np.arange(B), rng.integers(0, n, B)] += np.float32(1e-3)  # at least one positive weight, anywhere
+        for u in (rng.random(B).astype(np.float32).clip(2.0**-24, 1 - 2.0**-24), np.full(B, 1 - 2.0**-24, np.float32),
+                  np.full(B, 2.0**-24, np.float32)):
+            got = oracle.pick(p, u)
+            np.testing.assert_array_equal(got, _pick_reference(p, u))
+            assert (p[np.arange(B), got] > 0).all()
+    # unnormalised weights (the chance tensor of a pruned tree is renormalised, a policy row sums to 1 +- ulps): same law
+    w = np.array([[0.5, 0.0, 1.5, 2.0]], np.float32)
+    got = oracle.pick(np.repeat(w, 1 << 20, 0), oracle.action_uniform(1 << 20, 9, 0, 2))
+    freq = np.bincount(got, minlength=4) / float(1 << 20)
+    np.testing.assert_allclose(freq, w[0] / w.sum(), atol=2e-3)
+
+
+def test_seeded_draws_follow_the_policy():
+    """Chi-square of the drawn categories against the weights, for both action uniforms and the chance uniform."""
+    n = 1 << 20
+    p = np.array([0.03, 0.17, 0.0, 0.45, 0.35], np.float32)
+    for which, t in ((oracle.action_uniform, 0), (oracle.action_uniform, 1), (oracle.chance_uniform, 1)):
+        got = oracle.pick(np.repeat(p[None], n, 0), which(n, 123, 0, t))
+        cnt = np.bincount(got, minlength=5).astype(np.float64)
+        assert cnt[2] == 0
+        live = p > 0
+        chi2 = (((cnt - n * p) ** 2)[live] / (n * p[live])).sum()
+        assert chi2 < 21.1, chi2  # 3 degrees of freedom: P(chi2 > 21.1) ~ 1e-4
