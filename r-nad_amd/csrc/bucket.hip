@@ -48,6 +48,7 @@ constexpr int kReplicas = 64;        // copies of the upper-row table the workgr
 constexpr int kMaxSteps = 64;        // T_cap bound of the alive counters in LDS
 constexpr int kLaneBits = 22;        // B <= 2^22 lanes per call: a row receives at most one addend per lane
 constexpr int kLearnLds = 64 * 1024; // LDS budget of one learner workgroup
+constexpr int kKeysLds = 48 * 1024;  // LDS budget of k_bucket_keys_lds (the upper states' tables)
 constexpr int kPackedSteps = 10;      // env steps whose decisions k_bucket_keys hands to k_bucket_rollout (6 bits each)
 constexpr int kCompactSteps = 21;     // env steps of a compact trajectory: 3 bits of action per step in one 64-bit word
 constexpr int kSharedRoot = 256;      // flag in bucket_path: the group is one subtree (its root row is shared by the bucket's lanes)
@@ -61,6 +62,21 @@ struct Plan {
     int lds = 0, path_words = 0, sort_blocks = 0, chunk = kChunkDefault;
     int64_t max_items = 0;
 };
+
+// One outcome of one joint action of an upper state, as k_bucket_keys walks it: where it leads, which bucket that state belongs to
+// (group, upper slot + n_groups, or -1 for state 0), and the outcome's probability for the chance draw.
+struct UpperWalk {
+    int32_t next, key;
+    float chance;
+};
+
+__global__ __launch_bounds__(kThreads) void k_upper_walk(int n, int AAC, const int32_t *__restrict__ upper_list, const Trans *__restrict__ trans,
+                                                         const int32_t *__restrict__ bucket_of, UpperWalk *__restrict__ out) {
+    const int i = blockIdx.x * kThreads + threadIdx.x;
+    if (i >= n * AAC) return;
+    const Trans t = trans[(int64_t)upper_list[i / AAC] * AAC + i % AAC];
+    out[i] = UpperWalk{t.next, bucket_of[t.next], t.chance};
+}
 
 // The cut of `tree` for tables of `rows` rows (host, O(S)); cached with the handle.  nullptr: HIP allocation failed.
 const BucketCut *get_cut(const rnad_tree_t *tree, int rows) {
@@ -138,6 +154,17 @@ const BucketCut *get_cut(const rnad_tree_t *tree, int rows) {
         if (cut.bucket_path) (void)hipFree(cut.bucket_path);
         if (cut.upper_list) (void)hipFree(cut.upper_list);
         return nullptr;
+    }
+    if (cut.n_upper > 0) {  // (built on the device: the transition table has no host copy)
+        const int AAC = tree->A * tree->A * tree->C, n = cut.n_upper * AAC;
+        if (hipMalloc(&cut.upper_walk, (size_t)n * sizeof(UpperWalk)) == hipSuccess) {
+            hipLaunchKernelGGL(k_upper_walk, dim3(blocks_for(n)), dim3(kThreads), 0, (hipStream_t)0, cut.n_upper, AAC, (const int32_t *)cut.upper_list,
+                               (const Trans *)tree->trans, (const int32_t *)cut.bucket_of, (UpperWalk *)cut.upper_walk);
+            if (hipStreamSynchronize((hipStream_t)0) != hipSuccess) {
+                (void)hipFree(cut.upper_walk);
+                cut.upper_walk = nullptr;  // (k_bucket_keys then walks the global tables)
+            }
+        }
     }
     cut.host_bucket_of = std::move(bucket_of);
     return &tree->cuts.emplace(rows, std::move(cut)).first->second;
@@ -388,44 +415,186 @@ __global__ __launch_bounds__(kThreads) void k_row_records(int64_t rows, const fl
 // ---------------------------------------------------------------------------------------- 1. keys
 // Lane b (lane order) plays env steps exactly as k_bucket_rollout will, for as long as it sits in an upper state: its key is the
 // group it descends into, or the terminal bucket of the upper state it leaves the tree from.
-template <int A>
+// kPlay lanes per thread, in lock step: the walk is a chain of dependent gathers (policy rows -> transition record -> next state) with
+// little arithmetic between them since the draws became one uniform each, so a thread keeps several independent chains in flight.
+// A lane that has stopped keeps walking state 0 (its loads hit one line, its results are dropped), which keeps the code branch-free.
+#ifndef RNAD_PLAY
+#define RNAD_PLAY 2
+#endif
+constexpr int kPlay = RNAD_PLAY;
+
+template <int A, int L>
 __global__ __launch_bounds__(kThreads) void k_bucket_keys(const Trans *__restrict__ trans, int C, int64_t S, int64_t B, int n_steps,
                                                           const float *__restrict__ policy_tab, int64_t tab_stride, int vec4,
                                                           const int32_t *__restrict__ bucket_of, int n_groups, uint64_t seed,
                                                           const rnad_step_params_t *__restrict__ sp, int64_t lane0,
                                                           int32_t *__restrict__ keys, unsigned long long *__restrict__ decisions,
                                                           double *__restrict__ norm) {
-    const int64_t b = (int64_t)blockIdx.x * kThreads + threadIdx.x;
-    if (b >= B) return;
-    if (b == 0 && norm) norm[0] = norm[1] = 0.0;  // summed up by k_bucket_alive at the end of this rollout
+    const int64_t b0 = (int64_t)blockIdx.x * (kThreads * L) + threadIdx.x;  // this thread's lanes: b0 + l * kThreads
+    if (b0 == 0 && norm) norm[0] = norm[1] = 0.0;  // summed up by k_bucket_alive at the end of this rollout
     if (sp) seed = sp->seed;  // per-step scalars in device memory: a captured graph of the step replays with new values
-    int state = 1, key = bucket_of[1];
-    // decisions: what this lane drew at its first kPackedSteps env steps -- 3 bits of action and 3 bits of chance outcome per step,
+    const int key_root = bucket_of[1];
+    // decisions: what a lane drew at its first kPackedSteps env steps -- 3 bits of action and 3 bits of chance outcome per step,
     // the number of steps recorded in the top 4 bits -- so that k_bucket_rollout replays them without drawing again
-    unsigned long long packed = 0ull;
-    int t = 0;
-    while (t < n_steps && key >= n_groups) {  // one game transition per iteration: both players' steps in `state`, then the chance draw
-        const bool two = t + 1 < n_steps;
-        float u[3], pol0[A], pol1[A];
-        load_policy_row<A>(policy_tab, state, tab_stride, vec4 != 0, pol0);
-        if (two) load_policy_row<A>(policy_tab, S + state, tab_stride, vec4 != 0, pol1);
-        rnad_decision_uniforms(seed, (uint64_t)(lane0 + b), (uint32_t)t, u);
-        const int a0 = pick<A>(pol0, u[0]);
-        if (t < kPackedSteps) packed |= (unsigned long long)a0 << (6 * t);
-        ++t;
-        if (!two) break;
-        const int a1 = pick<A>(pol1, u[1]);
-        int next, chosen = 0;
-        float rew;
-        transition_lane<A>(trans, C, state, a0, a1, nullptr, u[2], next, rew, &chosen);
-        if (t < kPackedSteps) packed |= (unsigned long long)(a1 | (chosen << 3)) << (6 * t);
-        ++t;
-        state = next;
-        if (state == 0) break;
-        key = bucket_of[state];
+    int state[L], key[L], steps[L];
+    unsigned long long packed[L];
+    bool on[L];  // still in an upper state
+#pragma unroll
+    for (int l = 0; l < L; ++l) {
+        state[l] = 1;
+        key[l] = key_root;
+        steps[l] = 0;
+        packed[l] = 0ull;
+        on[l] = b0 + (int64_t)l * kThreads < B && key_root >= n_groups;
     }
-    keys[b] = key;
-    decisions[b] = packed | ((unsigned long long)min(t, kPackedSteps) << 60);
+    for (int t = 0; t < n_steps; t += 2) {  // one game transition per iteration: both players' steps in `state`, then the chance draw
+        bool any = false;
+#pragma unroll
+        for (int l = 0; l < L; ++l) any |= on[l];
+        if (!any) break;
+        const bool two = t + 1 < n_steps;
+        float u[L][3], pol0[L][A], pol1[L][A];
+        int a0[L];
+#pragma unroll
+        for (int l = 0; l < L; ++l) {
+            const int64_t st = on[l] ? state[l] : 0;
+            load_policy_row<A>(policy_tab, st, tab_stride, vec4 != 0, pol0[l]);
+            if (two) load_policy_row<A>(policy_tab, S + st, tab_stride, vec4 != 0, pol1[l]);
+        }
+#pragma unroll
+        for (int l = 0; l < L; ++l) rnad_decision_uniforms(seed, (uint64_t)(lane0 + b0 + (int64_t)l * kThreads), (uint32_t)t, u[l]);
+#pragma unroll
+        for (int l = 0; l < L; ++l) {
+            a0[l] = pick<A>(pol0[l], u[l][0]);
+            if (on[l]) {
+                if (t < kPackedSteps) packed[l] |= (unsigned long long)a0[l] << (6 * t);
+                steps[l] = t + 1;
+            }
+        }
+        if (!two) break;
+#pragma unroll
+        for (int l = 0; l < L; ++l) {
+            const int a1 = pick<A>(pol1[l], u[l][1]);
+            int next, chosen = 0;
+            float rew;
+            transition_lane<A>(trans, C, on[l] ? state[l] : 0, a0[l], a1, nullptr, u[l][2], next, rew, &chosen);
+            const int key_next = bucket_of[next];
+            if (on[l]) {
+                if (t + 1 < kPackedSteps) packed[l] |= (unsigned long long)(a1 | (chosen << 3)) << (6 * (t + 1));
+                steps[l] = t + 2;
+                state[l] = next;
+                if (next != 0) key[l] = key_next;  // (a lane that leaves the tree from an upper state keeps that state's bucket)
+                on[l] = next != 0 && key_next >= n_groups;
+            }
+        }
+    }
+#pragma unroll
+    for (int l = 0; l < L; ++l) {
+        const int64_t b = b0 + (int64_t)l * kThreads;
+        if (b < B) {
+            keys[b] = key[l];
+            decisions[b] = packed[l] | ((unsigned long long)min(steps[l], kPackedSteps) << 60);
+        }
+    }
+}
+
+// The same walk with the upper states' tables in LDS.  Lanes arrive here in lane order, so at depth d a wave's lanes sit in up to
+// min(64, (A^2 C)^d) different states and every gather of the global-table walk (two policy rows, the transition record, the bucket of
+// the next state) touches that many cache lines: the walk is bound by the L1's line rate (counters: DESIGN.md section 5.1), not by
+// arithmetic or HBM.  The upper states are few (configs[1]: 91), so each workgroup copies their policy rows and the compact
+// transition table of the cut (BucketCut::upper_walk) into LDS once and walks there; a lane is at an upper SLOT instead of a state id.
+// Same draws, same arithmetic, same keys and decisions as k_bucket_keys.
+inline size_t keys_lds_bytes(int n_upper, int A, int C) {
+    return (((size_t)n_upper * A * A * C * sizeof(UpperWalk) + 15) & ~(size_t)15) + (size_t)n_upper * 2 * ((A + 3) & ~3) * sizeof(float);
+}
+
+template <int A, int L>
+__global__ __launch_bounds__(kThreads) void k_bucket_keys_lds(const UpperWalk *__restrict__ walk, const int32_t *__restrict__ upper_list,
+                                                              int n_upper, int C, int64_t S, int64_t B, int n_steps,
+                                                              const float *__restrict__ policy_tab, int64_t tab_stride, int key_root,
+                                                              int n_groups, uint64_t seed, const rnad_step_params_t *__restrict__ sp,
+                                                              int64_t lane0, int32_t *__restrict__ keys,
+                                                              unsigned long long *__restrict__ decisions, double *__restrict__ norm) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char keys_smem[];
+    constexpr int PS = kPolStride<A>;
+    const int AAC = A * A * C;
+    UpperWalk *w = reinterpret_cast<UpperWalk *>(keys_smem);                                                             // [n_upper][A][A][C]
+    float *pol = reinterpret_cast<float *>(keys_smem + (((size_t)n_upper * AAC * sizeof(UpperWalk) + 15) & ~(size_t)15));  // [n_upper][2][PS]
+    for (int i = threadIdx.x; i < n_upper * AAC; i += kThreads) w[i] = walk[i];
+    for (int i = threadIdx.x; i < n_upper * 2 * PS; i += kThreads) {
+        const int slot = i / (2 * PS), player = (i / PS) & 1, a = i % PS;
+        pol[i] = a < A ? policy_tab[((int64_t)player * S + upper_list[slot]) * tab_stride + a] : 0.0f;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0 && norm) norm[0] = norm[1] = 0.0;  // summed up by k_bucket_alive at the end of this rollout
+    if (sp) seed = sp->seed;
+    __syncthreads();
+    for (int64_t base = (int64_t)blockIdx.x * (kThreads * L); base < B; base += (int64_t)gridDim.x * (kThreads * L)) {
+        const int64_t b0 = base + threadIdx.x;  // this thread's lanes: b0 + l * kThreads
+        int slot[L], key[L], steps[L];
+        unsigned long long packed[L];
+        bool on[L];
+#pragma unroll
+        for (int l = 0; l < L; ++l) {
+            slot[l] = key_root - n_groups;
+            key[l] = key_root;
+            steps[l] = 0;
+            packed[l] = 0ull;
+            on[l] = b0 + (int64_t)l * kThreads < B && key_root >= n_groups;
+        }
+        for (int t = 0; t < n_steps; t += 2) {
+            bool any = false;
+#pragma unroll
+            for (int l = 0; l < L; ++l) any |= on[l];
+            if (!any) break;
+            const bool two = t + 1 < n_steps;
+            float u[L][3];
+            int a0[L];
+#pragma unroll
+            for (int l = 0; l < L; ++l) rnad_decision_uniforms(seed, (uint64_t)(lane0 + b0 + (int64_t)l * kThreads), (uint32_t)t, u[l]);
+#pragma unroll
+            for (int l = 0; l < L; ++l) {
+                float p0[A];
+                load_policy_row<A>(pol, (int64_t)(on[l] ? slot[l] : 0) * 2, PS, true, p0);
+                a0[l] = pick<A>(p0, u[l][0]);
+                if (on[l]) {
+                    if (t < kPackedSteps) packed[l] |= (unsigned long long)a0[l] << (6 * t);
+                    steps[l] = t + 1;
+                }
+            }
+            if (!two) break;
+#pragma unroll
+            for (int l = 0; l < L; ++l) {
+                const int sl = on[l] ? slot[l] : 0;
+                float p1[A];
+                load_policy_row<A>(pol, (int64_t)sl * 2 + 1, PS, true, p1);
+                const int a1 = pick<A>(p1, u[l][1]);
+                const UpperWalk *e = w + ((sl * A + a0[l]) * A + a1) * C;
+                int chosen = 0;
+                if (C > 1) {
+                    float ch[RNAD_MAX_TRANSITIONS];
+#pragma unroll
+                    for (int k = 0; k < RNAD_MAX_TRANSITIONS; ++k) ch[k] = k < C ? e[k].chance : 0.0f;
+                    chosen = pick_n<RNAD_MAX_TRANSITIONS>(C, ch, u[l][2]);
+                }
+                const UpperWalk hit = e[chosen];
+                if (on[l]) {
+                    if (t + 1 < kPackedSteps) packed[l] |= (unsigned long long)(a1 | (chosen << 3)) << (6 * (t + 1));
+                    steps[l] = t + 2;
+                    if (hit.next != 0) key[l] = hit.key;  // (a lane that leaves the tree from an upper state keeps that state's bucket)
+                    on[l] = hit.next != 0 && hit.key >= n_groups;
+                    slot[l] = on[l] ? hit.key - n_groups : 0;
+                }
+            }
+        }
+#pragma unroll
+        for (int l = 0; l < L; ++l) {
+            const int64_t b = b0 + (int64_t)l * kThreads;
+            if (b < B) {
+                keys[b] = key[l];
+                decisions[b] = packed[l] | ((unsigned long long)min(steps[l], kPackedSteps) << 60);
+            }
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------- 2. stable counting sort by key
@@ -690,7 +859,8 @@ __global__ __launch_bounds__(kThreads) void k_bucket_rollout(const Trans *__rest
 // policy rows of the state are requested together and the transition's uniforms are computed while they travel, so a transition costs two
 // dependent memory latencies (policy rows, transition record) instead of three.  Same draws (keyed by lane and step), same
 // episodes as k_bucket_rollout.  An absorbed lane stops: no draws, no table reads.
-template <int A>
+// L lanes per thread in lock step (see kPlay): an absorbed lane keeps walking state 0 with its results dropped.
+template <int A, int L>
 __global__ __launch_bounds__(kThreads) void k_bucket_rollout_compact(const Trans *__restrict__ trans, int C, int64_t S, int64_t B, int T_cap,
                                                                      const float *__restrict__ policy_tab, int64_t tab_stride, int vec4,
                                                                      uint64_t seed, const rnad_step_params_t *__restrict__ sp, int64_t lane0,
@@ -700,69 +870,130 @@ __global__ __launch_bounds__(kThreads) void k_bucket_rollout_compact(const Trans
                                                                      unsigned long long *__restrict__ acts_out,
                                                                      float *__restrict__ reward_out, int32_t *__restrict__ visited) {
     __shared__ int32_t cnt[kThreads / 64][kMaxSteps + 1];
-    const int64_t j = (int64_t)blockIdx.x * kThreads + threadIdx.x;
-    const bool active = j < B;
+    const int64_t j0 = (int64_t)blockIdx.x * (kThreads * L) + threadIdx.x;  // this thread's columns: j0 + l * kThreads
     if (sp) seed = sp->seed;
-    const int32_t lane_local = active ? lane_ids[j] : 0;
-    const uint64_t lane = (uint64_t)(lane0 + lane_local);
-    const unsigned long long packed = active ? decisions[lane_local] : 0ull;  // the lane's first decisions, drawn by k_bucket_keys
-    const int n_packed = (int)(packed >> 60);
     const int wave = threadIdx.x >> 6;
-    int state = 1;
-    unsigned long long acts = 0ull;
-    float reward_final = 0.0f;
+    bool active[L];
+    uint64_t lane[L];
+    unsigned long long packed[L], acts[L];  // packed: the lane's first decisions, drawn by k_bucket_keys
+    int n_packed[L], state[L];
+    float reward_final[L];
+#pragma unroll
+    for (int l = 0; l < L; ++l) {
+        const int64_t j = j0 + (int64_t)l * kThreads;
+        active[l] = j < B;
+        const int32_t lane_local = active[l] ? lane_ids[j] : 0;
+        lane[l] = (uint64_t)(lane0 + lane_local);
+        packed[l] = active[l] ? decisions[lane_local] : 0ull;
+        n_packed[l] = (int)(packed[l] >> 60);
+        state[l] = active[l] ? 1 : 0;
+        acts[l] = 0ull;
+        reward_final[l] = 0.0f;
+    }
     for (int t = 0; t < T_cap; t += 2) {
         const bool two = t + 1 < T_cap;  // (an odd T_cap ends with a row step alone)
-        const uint64_t live = __ballot(active && state != 0);
-        if ((threadIdx.x & 63) == 0) {
-            cnt[wave][t] = (int32_t)__popcll(live);
-            if (two) cnt[wave][t + 1] = (int32_t)__popcll(live);  // the row player's step leaves the state as it is
+        bool go[L], draw0[L], draw1[L];
+        int alive_now = 0;
+        bool draws = false;
+#pragma unroll
+        for (int l = 0; l < L; ++l) {
+            go[l] = state[l] != 0;
+            alive_now += (int)__popcll(__ballot(go[l]));
+            draw0[l] = go[l] && t >= n_packed[l];
+            draw1[l] = go[l] && two && t + 1 >= n_packed[l];
+            draws |= draw0[l] || draw1[l];
         }
-        if (!active) continue;
-        const int64_t i = (int64_t)t * B + j;
+        if ((threadIdx.x & 63) == 0) {
+            cnt[wave][t] = alive_now;
+            if (two) cnt[wave][t + 1] = alive_now;  // the row player's step leaves the state as it is
+        }
         // (non-temporal stores here were measured: the rollout 48.0 -> 46.8 us, but the learner, which reads these columns next, 73.4 ->
         // 75.2: the L2 / MALL copy they leave behind is worth more than the write-allocate they cost)
-        indices[i] = state;
-        if (two) indices[i + B] = state;
-        if (state == 0) continue;
-        const bool replay0 = t < n_packed, replay1 = t + 1 < n_packed;
-        const int64_t row0 = state, row1 = S + state;
-        if (visited) {
-            visited[row0] = 1;  // (every writer stores the same value)
-            if (two) visited[row1] = 1;
-        }
-        float pol0[A], pol1[A], u[3];
-        if (!replay0) load_policy_row<A>(policy_tab, row0, tab_stride, vec4 != 0, pol0);
-        if (two && !replay1) load_policy_row<A>(policy_tab, row1, tab_stride, vec4 != 0, pol1);
-        if (!replay0 || (two && !replay1)) rnad_decision_uniforms(seed, lane, (uint32_t)t, u);  // computed while the rows travel
-        const int bits0 = replay0 ? (int)(packed >> (6 * t)) & 63 : 0, bits1 = replay1 ? (int)(packed >> (6 * (t + 1))) & 63 : 0;
-        const int a0 = replay0 ? (bits0 & 7) : pick<A>(pol0, u[0]);
-        acts |= (unsigned long long)a0 << (3 * t);
-        if (!two) continue;
-        const int a1 = replay1 ? (bits1 & 7) : pick<A>(pol1, u[1]);
-        acts |= (unsigned long long)a1 << (3 * (t + 1));
-        int next;
-        float rew;
-        if (replay1)
-            transition_apply<A>(trans, C, state, a0, a1, bits1 >> 3, next, rew);
-        else
-            transition_lane<A>(trans, C, state, a0, a1, nullptr, u[2], next, rew);
-        if (next == 0) reward_final = rew;
-        state = next;
-    }
-    if (active) {
-        acts_out[j] = acts;
-        reward_out[j] = reward_final;
-    }
-    const uint64_t live = __ballot(active && state != 0);
-    if ((threadIdx.x & 63) == 0) cnt[wave][T_cap] = (int32_t)__popcll(live);
-    if (active) indices[(int64_t)T_cap * B + j] = state;
-    __syncthreads();
-    if ((int)threadIdx.x <= T_cap) {
-        int32_t s = 0;
 #pragma unroll
-        for (int w = 0; w < kThreads / 64; ++w) s += cnt[w][threadIdx.x];
-        alive_part[(int64_t)blockIdx.x * (T_cap + 1) + threadIdx.x] = s;
+        for (int l = 0; l < L; ++l) {
+            if (active[l]) {
+                const int64_t i = (int64_t)t * B + j0 + (int64_t)l * kThreads;
+                indices[i] = state[l];
+                if (two) indices[i + B] = state[l];
+            }
+            if (visited && go[l]) {
+                visited[state[l]] = 1;  // (every writer stores the same value)
+                if (two) visited[S + state[l]] = 1;
+            }
+        }
+        float pol0[L][A], pol1[L][A], u[L][3];
+#pragma unroll
+        for (int l = 0; l < L; ++l) {
+            u[l][0] = u[l][1] = u[l][2] = 0.0f;
+#pragma unroll
+            for (int a = 0; a < A; ++a) pol0[l][a] = pol1[l][a] = 0.0f;
+        }
+        if (__ballot(draws) != 0ull) {  // (wave-uniform: a wave whose lanes all replay skips the rows and the generator)
+#pragma unroll
+            for (int l = 0; l < L; ++l) {
+                load_policy_row<A>(policy_tab, state[l], tab_stride, vec4 != 0, pol0[l]);
+                if (two) load_policy_row<A>(policy_tab, S + state[l], tab_stride, vec4 != 0, pol1[l]);
+            }
+#pragma unroll
+            for (int l = 0; l < L; ++l) rnad_decision_uniforms(seed, lane[l], (uint32_t)t, u[l]);  // computed while the rows travel
+        }
+        const int sh0 = t < kPackedSteps ? 6 * t : 0, sh1 = t + 1 < kPackedSteps ? 6 * (t + 1) : 0;
+        int a0[L];
+#pragma unroll
+        for (int l = 0; l < L; ++l) {
+            const int drawn = pick<A>(pol0[l], u[l][0]);
+            a0[l] = draw0[l] ? drawn : (go[l] ? (int)(packed[l] >> sh0) & 7 : 0);
+            acts[l] |= (unsigned long long)a0[l] << (3 * t);
+        }
+        if (!two) continue;
+#pragma unroll
+        for (int l = 0; l < L; ++l) {
+            const int bits1 = (int)(packed[l] >> sh1) & 63;
+            const int drawn = pick<A>(pol1[l], u[l][1]);
+            const int a1 = draw1[l] ? drawn : (go[l] ? bits1 & 7 : 0);
+            acts[l] |= (unsigned long long)a1 << (3 * (t + 1));
+            const Trans *e = trans + (((int64_t)state[l] * A + a0[l]) * A + a1) * C;
+            int which = 0;
+            if (C > 1) {
+                if (draw1[l]) {
+                    float ch[RNAD_MAX_TRANSITIONS];
+#pragma unroll
+                    for (int k = 0; k < RNAD_MAX_TRANSITIONS; ++k) ch[k] = k < C ? e[k].chance : 0.0f;
+                    which = pick_n<RNAD_MAX_TRANSITIONS>(C, ch, u[l][2]);
+                } else if (go[l]) {
+                    which = bits1 >> 3;
+                }
+            }
+            const Trans best = e[which];
+            if (go[l]) {
+                if (best.next == 0) reward_final[l] = best.value;  // rewards *= (indices == 0): only the step into state 0 pays
+                state[l] = best.next;
+            }
+        }
+    }
+    int alive_end = 0;
+#pragma unroll
+    for (int l = 0; l < L; ++l) {
+        const int64_t j = j0 + (int64_t)l * kThreads;
+        if (active[l]) {
+            acts_out[j] = acts[l];
+            reward_out[j] = reward_final[l];
+            indices[(int64_t)T_cap * B + j] = state[l];
+        }
+        alive_end += (int)__popcll(__ballot(state[l] != 0));
+    }
+    if ((threadIdx.x & 63) == 0) cnt[wave][T_cap] = alive_end;
+    __syncthreads();
+    if ((int)threadIdx.x <= T_cap) {  // alive_part has a row per kThreads lanes: this block's sums in its first row, zeros in the others
+        int32_t sum = 0;
+#pragma unroll
+        for (int w = 0; w < kThreads / 64; ++w) sum += cnt[w][threadIdx.x];
+        const int64_t rows = (B + kThreads - 1) / kThreads;
+#pragma unroll
+        for (int l = 0; l < L; ++l) {
+            const int64_t row = (int64_t)blockIdx.x * L + l;
+            if (row < rows) alive_part[row * (T_cap + 1) + threadIdx.x] = l == 0 ? sum : 0;
+        }
     }
 }
 
@@ -1372,9 +1603,22 @@ int rollout_bucketed_impl(const rnad_tree_t *tree, const RolloutBuffers &tr, boo
     const int vec4 = (policy_stride % 4 == 0 && ((uintptr_t)policy_tab & 15) == 0) ? 1 : 0;
     if (sort_phase) {
         ProfScope one(PROF_BUCKET_KEYS, stream);
-        RNAD_DISPATCH_A(tree->A, hipLaunchKernelGGL((k_bucket_keys<kA>), dim3(blocks_for(B)), dim3(kThreads), 0, stream, tree->trans, tree->C,
-                                                    S, B, n_steps, policy_tab, policy_stride, vec4, (const int32_t *)p.cut->bucket_of,
-                                                    p.cut->n_groups, seed, device_params, lane0, s.keys, s.decisions, norm));
+        const size_t keys_lds = keys_lds_bytes(p.cut->n_upper, tree->A, tree->C);
+        static const bool walk_global = getenv("RNAD_KEYS_GLOBAL") && atoi(getenv("RNAD_KEYS_GLOBAL")) != 0;  // (tests: the fallback on any tree)
+        if (p.cut->upper_walk && keys_lds <= kKeysLds && !walk_global) {  // the upper states' tables fit the LDS: walk there
+            int dev = 0, cus = 256;
+            if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+            const int key_root = p.cut->host_bucket_of[1];
+            const unsigned kgrid = std::min(blocks_for(B, kThreads * kPlay), (unsigned)(cus * std::max<size_t>(1, std::min<size_t>(8, (size_t)(160 * 1024) / keys_lds))));
+            RNAD_DISPATCH_A(tree->A, hipLaunchKernelGGL((k_bucket_keys_lds<kA, kPlay>), dim3(kgrid), dim3(kThreads), keys_lds, stream,
+                                                        (const UpperWalk *)p.cut->upper_walk, (const int32_t *)p.cut->upper_list, p.cut->n_upper,
+                                                        tree->C, S, B, n_steps, policy_tab, policy_stride, key_root, p.cut->n_groups, seed,
+                                                        device_params, lane0, s.keys, s.decisions, norm));
+        } else {
+            RNAD_DISPATCH_A(tree->A, hipLaunchKernelGGL((k_bucket_keys<kA, kPlay>), dim3(blocks_for(B, kThreads * kPlay)), dim3(kThreads), 0, stream, tree->trans, tree->C,
+                                                        S, B, n_steps, policy_tab, policy_stride, vec4, (const int32_t *)p.cut->bucket_of,
+                                                        p.cut->n_groups, seed, device_params, lane0, s.keys, s.decisions, norm));
+        }
     }
     const size_t lds = (size_t)nb * sizeof(int32_t);
     if (sort_phase) {
@@ -1401,7 +1645,7 @@ int rollout_bucketed_impl(const rnad_tree_t *tree, const RolloutBuffers &tr, boo
                        (const int32_t *)lane_ids, (const unsigned long long *)s.decisions, tr.indices, tr.mask_bits, tr.policy, tr.actions, \
                        tr.rewards, tr.values, s.alive_part)
 #define RNAD_BUCKET_ROLLOUT_COMPACT()                                                                                                    \
-    hipLaunchKernelGGL((k_bucket_rollout_compact<kA>), dim3(grid), dim3(kThreads), 0, stream, tree->trans, tree->C, S, B, tr.T_cap,         \
+    hipLaunchKernelGGL((k_bucket_rollout_compact<kA, kPlay>), dim3(blocks_for(B, kThreads * kPlay)), dim3(kThreads), 0, stream, tree->trans, tree->C, S, B, tr.T_cap,         \
                        policy_tab, policy_stride, vec4, seed, device_params, lane0, (const int32_t *)lane_ids,                              \
                        (const unsigned long long *)s.decisions, tr.indices, s.alive_part, tr.acts, tr.final_reward, tr.visited)
         if (compact) {

@@ -89,6 +89,8 @@ struct BucketCut {
     int32_t *bucket_lo = nullptr;    // device [n_buckets]: first state id of the group / the upper state itself
     int32_t *bucket_path = nullptr;  // device [n_buckets]: env steps a lane of the bucket spends above the group (terminal buckets: all of them)
     int32_t *upper_list = nullptr;   // device [max(n_upper, 1)]: the upper states in slot order
+    void *upper_walk = nullptr;      // device [n_upper][A][A][C] {next state, its bucket, chance}: the transition table of the upper states,
+                                     // compact, for k_bucket_keys to stage in LDS
     std::vector<int32_t> host_bucket_of;  // the same map on the host (rnad_bucket_map: tests and tools)
 };
 
