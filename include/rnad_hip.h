@@ -458,16 +458,16 @@ int rnad_bucket_alive(const rnad_tree_t *tree, int T_cap, int64_t B, const void 
  * rnad_bucket_sort = the keys pass + the sort; it reads the actor's rows of the UPPER states of the cut and of the absorbing state
  * only (rnad_bucket_plan / rnad_bucket_map say which).  group_flags (int32 [2S], optional): 1 for both rows of every state inside a
  * group some lane descends into, 0 elsewhere -- after rnad_compact_valid, the rows the actor still has to be evaluated on.
- * rnad_bucket_play = the rollout itself (+ the alive counts), same scratch, same seed / lane0 / device_params, the lane_ids of the
- * sort; with a logits table (table_is_policy == 0) `rows` / `n_rows` name the rows that were evaluated since (their policy head is
+ * rnad_bucket_play = the rollout itself (+ the alive counts), same scratch, same seed / lane0 / device_params, the lane_ids and
+ * the work list (items / n_items) of the sort; with a logits table (table_is_policy == 0) `rows` / `n_rows` name the rows that were evaluated since (their policy head is
  * taken here), NULL = all. */
 int rnad_bucket_sort(const rnad_tree_t *tree, int T_cap, int64_t B, const float *table, int64_t table_stride, int table_is_policy,
                      uint64_t seed, int64_t lane0, const rnad_step_params_t *device_params, void *scratch, int32_t *lane_ids,
                      int32_t *items, int32_t *n_items, double *norm, int32_t *group_flags, void *stream);
 int rnad_bucket_play(const rnad_tree_t *tree, int T_cap, int64_t B, const float *table, int64_t table_stride, int table_is_policy,
                      const int32_t *rows, const int64_t *n_rows, uint64_t seed, int64_t lane0, const rnad_step_params_t *device_params,
-                     void *scratch, const int32_t *lane_ids, double *norm, int32_t *indices, int32_t *alive, uint64_t *acts,
-                     float *final_reward, int32_t *visited, void *stream);
+                     void *scratch, const int32_t *lane_ids, const int32_t *items, const int32_t *n_items, double *norm, int32_t *indices,
+                     int32_t *alive, uint64_t *acts, float *final_reward, int32_t *visited, void *stream);
 int rnad_bucket_finish(const rnad_tree_t *tree, int64_t B, const double *norm, const rnad_learn_params_t *hp, void *accumulators,
                        double *losses, float *dlogit_tab, float *dv_tab, const int32_t *rows, const int64_t *n_rows, void *stream);
 

@@ -997,6 +997,124 @@ __global__ __launch_bounds__(kThreads) void k_bucket_rollout_compact(const Trans
     }
 }
 
+// The compact rollout, one workgroup per work item (the learner's list: <= chunk lanes of one bucket).  Every lane of a bucket that
+// is ONE subtree took the same path to its root (ids are DFS pre-order: a state has exactly one parent entry), so the steps above
+// the cut are played once per workgroup from the first lane's decision word -- uniform values, scalar loads -- instead of a random
+// 8-byte gather (128 B of fabric traffic) and a replay per lane; below the cut every lane draws for itself as in
+// k_bucket_rollout_compact.  Same draws, same arithmetic, same outputs.  Workgroups beyond the item count leave zero alive counts.
+// (Staging the group's transition records and policy rows in LDS for the drawn steps was measured: 42.0 us against 36.3 without --
+// 12.7 KB of copies per 256 lanes cost more than the gathers they replace.)
+template <int A>
+__global__ __launch_bounds__(kThreads) void k_bucket_rollout_items(const Trans *__restrict__ trans, int C, int64_t S, int64_t B, int T_cap,
+                                                                   const float *__restrict__ policy_tab, int64_t tab_stride, int vec4,
+                                                                   uint64_t seed, const rnad_step_params_t *__restrict__ sp, int64_t lane0,
+                                                                   const int32_t *__restrict__ lane_ids,
+                                                                   const unsigned long long *__restrict__ decisions,
+                                                                   const Item *__restrict__ items, const int32_t *__restrict__ n_items,
+                                                                   const int32_t *__restrict__ bucket_path, int n_groups,
+                                                                   int32_t *__restrict__ indices, int32_t *__restrict__ alive_part,
+                                                                   unsigned long long *__restrict__ acts_out,
+                                                                   float *__restrict__ reward_out, int32_t *__restrict__ visited) {
+    __shared__ int32_t cnt[kThreads / 64][kMaxSteps + 1];
+    int32_t *my_alive = alive_part + (int64_t)blockIdx.x * (T_cap + 1);
+    if ((int)blockIdx.x >= *n_items) {
+        if ((int)threadIdx.x <= T_cap) my_alive[threadIdx.x] = 0;
+        return;
+    }
+    const Item item = items[blockIdx.x];
+    if (sp) seed = sp->seed;
+    const bool active = (int)threadIdx.x < item.count;
+    const int64_t j = (int64_t)item.begin + threadIdx.x;
+    const int32_t lane_local = active ? lane_ids[j] : 0;
+    const uint64_t lane = (uint64_t)(lane0 + lane_local);
+    const int wave = threadIdx.x >> 6;
+    const bool shared = item.bucket < n_groups && (bucket_path[item.bucket] & kSharedRoot) != 0;
+    unsigned long long packed;  // the first decisions, drawn by k_bucket_keys: of the bucket (shared) or of this lane
+    if (shared) {
+        const unsigned long long first = decisions[lane_ids[item.begin]];
+        packed = ((unsigned long long)(unsigned int)__builtin_amdgcn_readfirstlane((int)(first >> 32)) << 32) |
+                 (unsigned int)__builtin_amdgcn_readfirstlane((int)first);
+    } else {
+        packed = active ? decisions[lane_local] : 0ull;
+    }
+    const int n_packed = (int)(packed >> 60);
+    int state = active ? 1 : 0, t_from = 0;
+    unsigned long long acts = 0ull;
+    float reward_final = 0.0f;
+    if (shared) {  // the transitions above the cut, once for the workgroup
+        const int n_pre = min(n_packed, T_cap) & ~1;
+        const int32_t live_now = (int32_t)__popcll(__ballot(active));
+        int at = 1;
+        for (int t = 0; t < n_pre; t += 2) {
+            if ((threadIdx.x & 63) == 0) cnt[wave][t] = cnt[wave][t + 1] = live_now;
+            const int bits0 = (int)(packed >> (6 * t)) & 63, bits1 = (int)(packed >> (6 * (t + 1))) & 63;
+            if (active) {
+                const int64_t i = (int64_t)t * B + j;
+                indices[i] = at;
+                indices[i + B] = at;
+            }
+            if (visited && threadIdx.x == 0) visited[at] = visited[S + at] = 1;
+            acts |= (unsigned long long)(bits0 & 7) << (3 * t) | (unsigned long long)(bits1 & 7) << (3 * (t + 1));
+            at = trans[(((int64_t)at * A + (bits0 & 7)) * A + (bits1 & 7)) * C + (bits1 >> 3)].next;  // (never 0: it leads to the group)
+        }
+        t_from = n_pre;
+        state = active ? at : 0;
+    }
+    for (int t = t_from; t < T_cap; t += 2) {
+        const bool two = t + 1 < T_cap;  // (an odd T_cap ends with a row step alone)
+        const uint64_t live = __ballot(state != 0);
+        if ((threadIdx.x & 63) == 0) {
+            cnt[wave][t] = (int32_t)__popcll(live);
+            if (two) cnt[wave][t + 1] = (int32_t)__popcll(live);  // the row player's step leaves the state as it is
+        }
+        if (!active) continue;
+        const int64_t i = (int64_t)t * B + j;
+        // (non-temporal stores here were measured: the rollout 48.0 -> 46.8 us, but the learner, which reads these columns next, 73.4 ->
+        // 75.2: the L2 / MALL copy they leave behind is worth more than the write-allocate they cost)
+        indices[i] = state;
+        if (two) indices[i + B] = state;
+        if (state == 0) continue;
+        const bool replay0 = t < n_packed, replay1 = t + 1 < n_packed;
+        const int64_t row0 = state, row1 = S + state;
+        if (visited) {
+            visited[row0] = 1;  // (every writer stores the same value)
+            if (two) visited[row1] = 1;
+        }
+        float pol0[A], pol1[A], u[3];
+        if (!replay0) load_policy_row<A>(policy_tab, row0, tab_stride, vec4 != 0, pol0);
+        if (two && !replay1) load_policy_row<A>(policy_tab, row1, tab_stride, vec4 != 0, pol1);
+        if (!replay0 || (two && !replay1)) rnad_decision_uniforms(seed, lane, (uint32_t)t, u);  // computed while the rows travel
+        const int bits0 = replay0 ? (int)(packed >> (6 * t)) & 63 : 0, bits1 = replay1 ? (int)(packed >> (6 * (t + 1))) & 63 : 0;
+        const int a0 = replay0 ? (bits0 & 7) : pick<A>(pol0, u[0]);
+        acts |= (unsigned long long)a0 << (3 * t);
+        if (!two) continue;
+        const int a1 = replay1 ? (bits1 & 7) : pick<A>(pol1, u[1]);
+        acts |= (unsigned long long)a1 << (3 * (t + 1));
+        int next;
+        float rew;
+        if (replay1)
+            transition_apply<A>(trans, C, state, a0, a1, bits1 >> 3, next, rew);
+        else
+            transition_lane<A>(trans, C, state, a0, a1, nullptr, u[2], next, rew);
+        if (next == 0) reward_final = rew;
+        state = next;
+    }
+    if (active) {
+        acts_out[j] = acts;
+        reward_out[j] = reward_final;
+        indices[(int64_t)T_cap * B + j] = state;
+    }
+    const uint64_t live = __ballot(state != 0);
+    if ((threadIdx.x & 63) == 0) cnt[wave][T_cap] = (int32_t)__popcll(live);
+    __syncthreads();
+    if ((int)threadIdx.x <= T_cap) {
+        int32_t sum = 0;
+#pragma unroll
+        for (int w = 0; w < kThreads / 64; ++w) sum += cnt[w][threadIdx.x];
+        my_alive[threadIdx.x] = sum;
+    }
+}
+
 // alive[t] = sum over the blocks of alive_part[block][t]; norm[P] += alive[t] for the steps of parity P: the loss normalisers N_P
 // of learn/vtrace.py:373,388 (f64 sums of integers: exact in any order; zeroed by k_bucket_keys).  One workgroup per column t.
 __device__ __forceinline__ void alive_column(int n_blocks, int T1, int t, const int32_t *__restrict__ alive_part, int32_t *__restrict__ alive,
@@ -1463,7 +1581,7 @@ extern "C" int rnad_bucket_plan(const rnad_tree_t *tree, int64_t B, int64_t *out
     out[4] = p.max_items;
     // scratch of the rollout (bytes): decisions [B] u64 | keys [B] | hist [sort_blocks][n_buckets] | totals [n_buckets] | bucket_start [n_buckets] |
     // alive_part [blocks][T_cap + 1 <= kMaxSteps + 1] | policy [2S][A]
-    out[5] = 8 * B + 4 * (B + (int64_t)p.sort_blocks * nb + 2 * (int64_t)nb + (int64_t)blocks_for(B) * (kMaxSteps + 1) +
+    out[5] = 8 * B + 4 * (B + (int64_t)p.sort_blocks * nb + 2 * (int64_t)nb + std::max<int64_t>(p.max_items, (int64_t)blocks_for(B)) * (kMaxSteps + 1) +
                   2 * tree->S * tree->A) + 256;
     // accumulators of the learner (bytes, must be zero before the first update): acc [2S][A+1] u64 | rep [64][2][n_upper][A+1] u64 |
     // losses_raw [4] f64 | overflow [1] i32
@@ -1482,6 +1600,17 @@ extern "C" int rnad_bucket_map(const rnad_tree_t *tree, int64_t B, int32_t *buck
 }
 
 namespace {
+// The compact rollout runs one workgroup per work item (k_bucket_rollout_items) unless RNAD_ROLLOUT_GLOBAL asks for the
+// lane-tiled kernel (k_bucket_rollout_compact: kThreads * kPlay columns per workgroup).  Either leaves one row of alive counts per workgroup.
+bool rollout_by_items(const rnad_tree_t *, const Plan &) {
+    static const bool off = getenv("RNAD_ROLLOUT_GLOBAL") && atoi(getenv("RNAD_ROLLOUT_GLOBAL")) != 0;
+    return !off;
+}
+int64_t alive_rows(const rnad_tree_t *tree, int64_t B, const Plan &p, bool compact) {
+    return compact && rollout_by_items(tree, p) ? p.max_items : (int64_t)blocks_for(B);
+}
+int64_t alive_rows_max(int64_t B, const Plan &p) { return std::max<int64_t>(p.max_items, (int64_t)blocks_for(B)); }
+
 struct Scratch {
     unsigned long long *decisions;  // [B]
     int32_t *keys, *hist, *totals, *bucket_start, *alive_part;
@@ -1495,7 +1624,7 @@ Scratch carve_scratch(void *ws, int64_t B, const Plan &p) {
     s.totals = s.hist + (int64_t)p.sort_blocks * p.cut->n_buckets;
     s.bucket_start = s.totals + p.cut->n_buckets;
     s.alive_part = s.bucket_start + p.cut->n_buckets;
-    s.policy = (float *)(s.alive_part + (int64_t)blocks_for(B) * (kMaxSteps + 1));
+    s.policy = (float *)(s.alive_part + alive_rows_max(B, p) * (kMaxSteps + 1));
     return s;
 }
 }  // namespace
@@ -1637,6 +1766,7 @@ int rollout_bucketed_impl(const rnad_tree_t *tree, const RolloutBuffers &tr, boo
     RNAD_HIP_OK(hipGetLastError());
     if (!play_phase) return 0;
     const unsigned grid = blocks_for(B);
+    int alive_n = (int)grid;  // rows of alive_part the rollout kernel leaves
     {
         ProfScope one(PROF_BUCKET_ROLLOUT, stream);
 #define RNAD_BUCKET_ROLLOUT()                                                                                                            \
@@ -1648,7 +1778,15 @@ int rollout_bucketed_impl(const rnad_tree_t *tree, const RolloutBuffers &tr, boo
     hipLaunchKernelGGL((k_bucket_rollout_compact<kA, kPlay>), dim3(blocks_for(B, kThreads * kPlay)), dim3(kThreads), 0, stream, tree->trans, tree->C, S, B, tr.T_cap,         \
                        policy_tab, policy_stride, vec4, seed, device_params, lane0, (const int32_t *)lane_ids,                              \
                        (const unsigned long long *)s.decisions, tr.indices, s.alive_part, tr.acts, tr.final_reward, tr.visited)
-        if (compact) {
+        if (compact && rollout_by_items(tree, p)) {
+            RNAD_REQUIRE(items && n_items, "rnad_rollout_bucketed_compact: the work list of the sort is needed to play");
+            alive_n = (int)p.max_items;
+            RNAD_DISPATCH_A(tree->A, hipLaunchKernelGGL((k_bucket_rollout_items<kA>), dim3((unsigned)p.max_items), dim3(kThreads), 0, stream,
+                                                        tree->trans, tree->C, S, B, tr.T_cap, policy_tab, policy_stride, vec4, seed,
+                                                        device_params, lane0, (const int32_t *)lane_ids, (const unsigned long long *)s.decisions,
+                                                        (const Item *)items, (const int32_t *)n_items, (const int32_t *)p.cut->bucket_path,
+                                                        p.cut->n_groups, tr.indices, s.alive_part, tr.acts, tr.final_reward, tr.visited));
+        } else if (compact) {
             RNAD_DISPATCH_A(tree->A, RNAD_BUCKET_ROLLOUT_COMPACT());
         } else {
             RNAD_DISPATCH_A(tree->A, RNAD_BUCKET_ROLLOUT());
@@ -1657,7 +1795,7 @@ int rollout_bucketed_impl(const rnad_tree_t *tree, const RolloutBuffers &tr, boo
 #undef RNAD_BUCKET_ROLLOUT
     }
     if (tr.alive)  // (NULL: the caller lets rnad_learn_bucketed_compact add the counts up, or calls rnad_bucket_alive)
-        hipLaunchKernelGGL(k_bucket_alive, dim3(tr.T_cap + 1), dim3(kThreads), 0, stream, (int)grid, tr.T_cap + 1, (const int32_t *)s.alive_part,
+        hipLaunchKernelGGL(k_bucket_alive, dim3(tr.T_cap + 1), dim3(kThreads), 0, stream, alive_n, tr.T_cap + 1, (const int32_t *)s.alive_part,
                            tr.alive, norm);
     RNAD_HIP_OK(hipGetLastError());
     return 0;
@@ -1677,15 +1815,17 @@ extern "C" int rnad_bucket_sort(const rnad_tree_t *tree, int T_cap, int64_t B, c
 
 extern "C" int rnad_bucket_play(const rnad_tree_t *tree, int T_cap, int64_t B, const float *table, int64_t table_stride, int table_is_policy,
                                 const int32_t *rows, const int64_t *n_rows, uint64_t seed, int64_t lane0,
-                                const rnad_step_params_t *device_params, void *scratch, const int32_t *lane_ids, double *norm,
-                                int32_t *indices, int32_t *alive, uint64_t *acts, float *final_reward, int32_t *visited, void *stream) {
-    RNAD_REQUIRE(tree && table && scratch && lane_ids && indices && acts && final_reward, "rnad_bucket_play: null argument");
+                                const rnad_step_params_t *device_params, void *scratch, const int32_t *lane_ids, const int32_t *items,
+                                const int32_t *n_items, double *norm, int32_t *indices, int32_t *alive, uint64_t *acts, float *final_reward,
+                                int32_t *visited, void *stream) {
+    RNAD_REQUIRE(tree && table && scratch && lane_ids && items && n_items && indices && acts && final_reward, "rnad_bucket_play: null argument");
     RNAD_REQUIRE(T_cap >= 1 && T_cap <= kCompactSteps && B >= 1, "rnad_bucket_play: 1 <= T_cap <= %d, got %d", kCompactSteps, T_cap);
     RNAD_REQUIRE(table_stride >= tree->A && (!rows == !n_rows), "rnad_bucket_play: bad table stride / row list");
     const RolloutBuffers out{T_cap, B, indices, nullptr, nullptr, nullptr, nullptr, nullptr, alive, (unsigned long long *)acts, final_reward,
                              visited};
     return rollout_bucketed_impl(tree, out, true, table, table_stride, table_is_policy, nullptr, 1, seed, lane0, device_params, scratch,
-                                 const_cast<int32_t *>(lane_ids), nullptr, nullptr, norm, (hipStream_t)stream, 2, nullptr, rows, n_rows);
+                                 const_cast<int32_t *>(lane_ids), const_cast<int32_t *>(items), const_cast<int32_t *>(n_items), norm,
+                                 (hipStream_t)stream, 2, nullptr, rows, n_rows);
 }
 
 extern "C" int rnad_bucket_alive(const rnad_tree_t *tree, int T_cap, int64_t B, const void *scratch, int32_t *alive, double *norm, void *stream) {
@@ -1694,7 +1834,7 @@ extern "C" int rnad_bucket_alive(const rnad_tree_t *tree, int T_cap, int64_t B, 
     Plan p;
     RNAD_REQUIRE(make_plan(tree, B, p), "rnad_bucket_alive: this tree / batch cannot be bucketed (see rnad_bucket_plan)");
     const Scratch s = carve_scratch(const_cast<void *>(scratch), B, p);
-    hipLaunchKernelGGL(k_bucket_alive, dim3(T_cap + 1), dim3(kThreads), 0, (hipStream_t)stream, (int)blocks_for(B), T_cap + 1,
+    hipLaunchKernelGGL(k_bucket_alive, dim3(T_cap + 1), dim3(kThreads), 0, (hipStream_t)stream, (int)alive_rows(tree, B, p, true), T_cap + 1,
                        (const int32_t *)s.alive_part, alive, norm);
     RNAD_HIP_OK(hipGetLastError());
     return 0;
@@ -1843,7 +1983,7 @@ int learn_bucketed_impl(const rnad_tree_t *tree, int T, int64_t B, const int32_t
                            p.cut->n_groups, std::max(nu, 1), (const Item *)items, n_items, (const int32_t *)p.cut->bucket_of,         \
                            (const int32_t *)p.cut->bucket_lo, (const int32_t *)p.cut->bucket_path, indices, actions, rewards, mu,     \
                            compact ? fast : records, acts, final_reward, records, *hp, fx, acc, rep,                                  \
-                           losses ? losses_raw : (double *)nullptr, overflow, alive_part, (int)blocks_for(B), T1, alive_out, norm_out); \
+                           losses ? losses_raw : (double *)nullptr, overflow, alive_part, (int)alive_rows(tree, B, p, true), T1, alive_out, norm_out); \
     } while (0)
     {
         ProfScope one(PROF_BUCKET_LEARN, stream);

@@ -779,6 +779,7 @@ def bucket_play(tree, traj, buckets, table, rows=None, seed=0, lane0=0, step_par
     _check(lib().rnad_bucket_play(tree.ptr, traj.T_cap, traj.B, C.c_void_p(base.value + 4 * column), table.shape[1], int(table_is_policy),
                                   *_row_list(rows), seed, lane0, _dp(step_params, torch.int64, "step_params", True),
                                   _dp(buckets.plan.scratch, I32, "scratch"), _dp(buckets.lane_ids, I32, "lane_ids"),
+                                  _dp(buckets.items, I32, "items"), _dp(buckets.n_items, I32, "n_items"),
                                   _dp(buckets.norm, F64, "norm"), _dp(traj.indices, I32, "indices"),
                                   None if defer_alive else _dp(traj.alive, I32, "alive"), _dp(traj.acts, torch.int64, "acts"),
                                   _dp(traj.final_reward, F32, "final_reward"), _dp(visited, I32, "visited", True), _stream()))
