@@ -504,32 +504,39 @@ __global__ __launch_bounds__(kThreads) void k_bucket_keys(const Trans *__restric
 // arithmetic or HBM.  The upper states are few (configs[1]: 91), so each workgroup copies their policy rows and the compact
 // transition table of the cut (BucketCut::upper_walk) into LDS once and walks there; a lane is at an upper SLOT instead of a state id.
 // Same draws, same arithmetic, same keys and decisions as k_bucket_keys.
-inline size_t keys_lds_bytes(int n_upper, int A, int C) {
-    return (((size_t)n_upper * A * A * C * sizeof(UpperWalk) + 15) & ~(size_t)15) + (size_t)n_upper * 2 * ((A + 3) & ~3) * sizeof(float);
+// One workgroup per sort tile (kSortLanes consecutive lanes, kSortThreads threads): it also counts its lanes per bucket in LDS and
+// writes the tile's histogram row -- k_bucket_hist's work without its launch and without reading the keys back.
+inline size_t keys_lds_bytes(int n_upper, int n_buckets, int A, int C) {
+    return (((size_t)n_upper * A * A * C * sizeof(UpperWalk) + 15) & ~(size_t)15) + (size_t)n_upper * 2 * ((A + 3) & ~3) * sizeof(float) +
+           (size_t)n_buckets * sizeof(int32_t);
 }
 
 template <int A, int L>
-__global__ __launch_bounds__(kThreads) void k_bucket_keys_lds(const UpperWalk *__restrict__ walk, const int32_t *__restrict__ upper_list,
-                                                              int n_upper, int C, int64_t S, int64_t B, int n_steps,
-                                                              const float *__restrict__ policy_tab, int64_t tab_stride, int key_root,
-                                                              int n_groups, uint64_t seed, const rnad_step_params_t *__restrict__ sp,
-                                                              int64_t lane0, int32_t *__restrict__ keys,
-                                                              unsigned long long *__restrict__ decisions, double *__restrict__ norm) {
+__global__ __launch_bounds__(kSortThreads) void k_bucket_keys_lds(const UpperWalk *__restrict__ walk, const int32_t *__restrict__ upper_list,
+                                                                  int n_upper, int n_buckets, int C, int64_t S, int64_t B, int n_steps,
+                                                                  const float *__restrict__ policy_tab, int64_t tab_stride, int key_root,
+                                                                  int n_groups, uint64_t seed, const rnad_step_params_t *__restrict__ sp,
+                                                                  int64_t lane0, int32_t *__restrict__ keys,
+                                                                  unsigned long long *__restrict__ decisions, int32_t *__restrict__ hist,
+                                                                  double *__restrict__ norm) {
     extern __shared__ __attribute__((aligned(16))) unsigned char keys_smem[];
     constexpr int PS = kPolStride<A>;
     const int AAC = A * A * C;
     UpperWalk *w = reinterpret_cast<UpperWalk *>(keys_smem);                                                             // [n_upper][A][A][C]
     float *pol = reinterpret_cast<float *>(keys_smem + (((size_t)n_upper * AAC * sizeof(UpperWalk) + 15) & ~(size_t)15));  // [n_upper][2][PS]
-    for (int i = threadIdx.x; i < n_upper * AAC; i += kThreads) w[i] = walk[i];
-    for (int i = threadIdx.x; i < n_upper * 2 * PS; i += kThreads) {
+    int32_t *cnt = reinterpret_cast<int32_t *>(pol + (size_t)n_upper * 2 * PS);                                            // [n_buckets]
+    for (int i = threadIdx.x; i < n_upper * AAC; i += kSortThreads) w[i] = walk[i];
+    for (int i = threadIdx.x; i < n_upper * 2 * PS; i += kSortThreads) {
         const int slot = i / (2 * PS), player = (i / PS) & 1, a = i % PS;
         pol[i] = a < A ? policy_tab[((int64_t)player * S + upper_list[slot]) * tab_stride + a] : 0.0f;
     }
+    for (int i = threadIdx.x; i < n_buckets; i += kSortThreads) cnt[i] = 0;
     if (blockIdx.x == 0 && threadIdx.x == 0 && norm) norm[0] = norm[1] = 0.0;  // summed up by k_bucket_alive at the end of this rollout
     if (sp) seed = sp->seed;
     __syncthreads();
-    for (int64_t base = (int64_t)blockIdx.x * (kThreads * L); base < B; base += (int64_t)gridDim.x * (kThreads * L)) {
-        const int64_t b0 = base + threadIdx.x;  // this thread's lanes: b0 + l * kThreads
+    static_assert(kSortLanes % (kSortThreads * L) == 0, "a sort tile is a whole number of passes");
+    for (int pass = 0; pass < kSortLanes / (kSortThreads * L); ++pass) {
+        const int64_t b0 = (int64_t)blockIdx.x * kSortLanes + (int64_t)pass * (kSortThreads * L) + threadIdx.x;  // lanes b0 + l * kSortThreads
         int slot[L], key[L], steps[L];
         unsigned long long packed[L];
         bool on[L];
@@ -539,7 +546,7 @@ __global__ __launch_bounds__(kThreads) void k_bucket_keys_lds(const UpperWalk *_
             key[l] = key_root;
             steps[l] = 0;
             packed[l] = 0ull;
-            on[l] = b0 + (int64_t)l * kThreads < B && key_root >= n_groups;
+            on[l] = b0 + (int64_t)l * kSortThreads < B && key_root >= n_groups;
         }
         for (int t = 0; t < n_steps; t += 2) {
             bool any = false;
@@ -550,7 +557,7 @@ __global__ __launch_bounds__(kThreads) void k_bucket_keys_lds(const UpperWalk *_
             float u[L][3];
             int a0[L];
 #pragma unroll
-            for (int l = 0; l < L; ++l) rnad_decision_uniforms(seed, (uint64_t)(lane0 + b0 + (int64_t)l * kThreads), (uint32_t)t, u[l]);
+            for (int l = 0; l < L; ++l) rnad_decision_uniforms(seed, (uint64_t)(lane0 + b0 + (int64_t)l * kSortThreads), (uint32_t)t, u[l]);
 #pragma unroll
             for (int l = 0; l < L; ++l) {
                 float p0[A];
@@ -588,13 +595,17 @@ __global__ __launch_bounds__(kThreads) void k_bucket_keys_lds(const UpperWalk *_
         }
 #pragma unroll
         for (int l = 0; l < L; ++l) {
-            const int64_t b = b0 + (int64_t)l * kThreads;
+            const int64_t b = b0 + (int64_t)l * kSortThreads;
             if (b < B) {
                 keys[b] = key[l];
                 decisions[b] = packed[l] | ((unsigned long long)min(steps[l], kPackedSteps) << 60);
+                atomicAdd(&cnt[key[l]], 1);
             }
         }
     }
+    __syncthreads();
+    int32_t *row = hist + (int64_t)blockIdx.x * n_buckets;
+    for (int i = threadIdx.x; i < n_buckets; i += kSortThreads) row[i] = cnt[i];
 }
 
 // ---------------------------------------------------------------------------------------- 2. stable counting sort by key
@@ -1730,19 +1741,17 @@ int rollout_bucketed_impl(const rnad_tree_t *tree, const RolloutBuffers &tr, boo
         policy_stride = tree->A;
     }
     const int vec4 = (policy_stride % 4 == 0 && ((uintptr_t)policy_tab & 15) == 0) ? 1 : 0;
+    bool keys_with_hist = false;
     if (sort_phase) {
         ProfScope one(PROF_BUCKET_KEYS, stream);
-        const size_t keys_lds = keys_lds_bytes(p.cut->n_upper, tree->A, tree->C);
+        const size_t keys_lds = keys_lds_bytes(p.cut->n_upper, nb, tree->A, tree->C);
         static const bool walk_global = getenv("RNAD_KEYS_GLOBAL") && atoi(getenv("RNAD_KEYS_GLOBAL")) != 0;  // (tests: the fallback on any tree)
-        if (p.cut->upper_walk && keys_lds <= kKeysLds && !walk_global) {  // the upper states' tables fit the LDS: walk there
-            int dev = 0, cus = 256;
-            if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-            const int key_root = p.cut->host_bucket_of[1];
-            const unsigned kgrid = std::min(blocks_for(B, kThreads * kPlay), (unsigned)(cus * std::max<size_t>(1, std::min<size_t>(8, (size_t)(160 * 1024) / keys_lds))));
-            RNAD_DISPATCH_A(tree->A, hipLaunchKernelGGL((k_bucket_keys_lds<kA, kPlay>), dim3(kgrid), dim3(kThreads), keys_lds, stream,
-                                                        (const UpperWalk *)p.cut->upper_walk, (const int32_t *)p.cut->upper_list, p.cut->n_upper,
-                                                        tree->C, S, B, n_steps, policy_tab, policy_stride, key_root, p.cut->n_groups, seed,
-                                                        device_params, lane0, s.keys, s.decisions, norm));
+        if (p.cut->upper_walk && keys_lds <= kKeysLds && !walk_global) {  // the upper states' tables fit the LDS: walk there, one sort tile per workgroup
+            keys_with_hist = true;
+            RNAD_DISPATCH_A(tree->A, hipLaunchKernelGGL((k_bucket_keys_lds<kA, kPlay>), dim3(p.sort_blocks), dim3(kSortThreads), keys_lds, stream,
+                                                        (const UpperWalk *)p.cut->upper_walk, (const int32_t *)p.cut->upper_list, p.cut->n_upper, nb,
+                                                        tree->C, S, B, n_steps, policy_tab, policy_stride, (int)p.cut->host_bucket_of[1],
+                                                        p.cut->n_groups, seed, device_params, lane0, s.keys, s.decisions, s.hist, norm));
         } else {
             RNAD_DISPATCH_A(tree->A, hipLaunchKernelGGL((k_bucket_keys<kA, kPlay>), dim3(blocks_for(B, kThreads * kPlay)), dim3(kThreads), 0, stream, tree->trans, tree->C,
                                                         S, B, n_steps, policy_tab, policy_stride, vec4, (const int32_t *)p.cut->bucket_of,
@@ -1752,7 +1761,7 @@ int rollout_bucketed_impl(const rnad_tree_t *tree, const RolloutBuffers &tr, boo
     const size_t lds = (size_t)nb * sizeof(int32_t);
     if (sort_phase) {
         ProfScope sort_passes(PROF_BUCKET_SORT, stream);
-        hipLaunchKernelGGL(k_bucket_hist, dim3(p.sort_blocks), dim3(kSortThreads), lds, stream, B, nb, (const int32_t *)s.keys, s.hist);
+        if (!keys_with_hist) hipLaunchKernelGGL(k_bucket_hist, dim3(p.sort_blocks), dim3(kSortThreads), lds, stream, B, nb, (const int32_t *)s.keys, s.hist);
         hipLaunchKernelGGL(k_bucket_scan, dim3((nb + kScanCols - 1) / kScanCols), dim3(kSortThreads), 0, stream, p.sort_blocks, nb, s.hist, s.totals);
         const size_t scatter_lds = (2 * (size_t)nb + 1) * sizeof(int32_t);  // bucket_start -> rank counters | first item of every bucket
         if (scatter_lds > 48 * 1024)
