@@ -756,7 +756,7 @@ __global__ __launch_bounds__(kSortThreads) void k_bucket_scan(int n_blocks, int 
 __global__ __launch_bounds__(kSortThreads) void k_bucket_scatter(int64_t B, int n_buckets, const int32_t *__restrict__ keys,
                                                                  const int32_t *__restrict__ hist, const int32_t *__restrict__ totals, int chunk,
                                                                  Item *__restrict__ items, int32_t *__restrict__ n_items,
-                                                                 int32_t *__restrict__ lane_ids) {
+                                                                 int32_t *__restrict__ lane_ids, int wave_counts) {
     extern __shared__ int32_t cnt[];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int64_t base = (int64_t)blockIdx.x * kSortLanes + (int64_t)wave * (kSortLanes / 16);
@@ -771,6 +771,33 @@ __global__ __launch_bounds__(kSortThreads) void k_bucket_scatter(int64_t B, int 
     const int32_t *row = hist + (int64_t)blockIdx.x * n_buckets;
     for (int i = threadIdx.x; i < n_buckets; i += kSortThreads) cnt[i] += row[i];
     __syncthreads();
+    if (wave_counts) {
+        // Every wave ranks its own lanes against a counter row of its own (all 16 at once), the rows are then turned into the waves'
+        // starting offsets -- wave w starts where waves 0 .. w - 1 end -- and the ranks become positions.  Same permutation as the
+        // turn-taking loop below: a lane's position is the bucket's start + the tile's offset + the lanes of earlier waves + its rank
+        // among its wave's (rows in order, lanes of one atomic instruction in lane order).
+        int32_t *wcnt = cnt + 2 * n_buckets + 1;  // [16][n_buckets]
+        for (int i = threadIdx.x; i < 16 * n_buckets; i += kSortThreads) wcnt[i] = 0;
+        __syncthreads();
+        int32_t rank[kSortLanes / kSortThreads];
+#pragma unroll
+        for (int r = 0; r < kSortLanes / kSortThreads; ++r)
+            rank[r] = key[r] >= 0 ? atomicAdd(&wcnt[wave * n_buckets + key[r]], 1) : 0;
+        __syncthreads();
+        for (int i = threadIdx.x; i < n_buckets; i += kSortThreads) {
+            int32_t at = cnt[i];
+            for (int w = 0; w < 16; ++w) {
+                const int32_t n = wcnt[w * n_buckets + i];
+                wcnt[w * n_buckets + i] = at;
+                at += n;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < kSortLanes / kSortThreads; ++r)
+            if (key[r] >= 0) lane_ids[wcnt[wave * n_buckets + key[r]] + rank[r]] = (int32_t)(base + r * 64 + lane);
+        return;
+    }
     for (int turn = 0; turn < 16; ++turn) {
         if (turn == wave) {
 #pragma unroll
@@ -1502,21 +1529,37 @@ __global__ __launch_bounds__(kThreads) void k_bucket_finish(int64_t S, int row_b
     if ((int)blockIdx.x < row_blocks) {
         // (few, fat workgroups: every one of them takes a ticket below)
         const int64_t limit = row_list ? *n_rows : 2 * S;
-        for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < limit; i += (int64_t)row_blocks * kThreads) {
-            const bool in = true;
-            const int64_t r = (in && row_list) ? (int64_t)row_list[i] : i;  // row list: the rows the batch visited (all others hold zero sums)
-            const int64_t s = r >= S ? r - S : r;
-            if (in && !(n_upper > 0 && bucket_of[s] >= n_groups)) {  // (rows above the cut: the wave-per-row workgroups)
-                long long x[A + 1];
+        const int64_t stride = (int64_t)row_blocks * kThreads;
+        // kFinishRows rows per thread and pass, all their loads in flight together (a row at a time is a chain of memory round trips)
+        for (int64_t i0 = (int64_t)blockIdx.x * kThreads + threadIdx.x; i0 < limit; i0 += stride * kFinishRows) {
+            int64_t r[kFinishRows];
+            bool on[kFinishRows];
+            long long x[kFinishRows][A + 1];
 #pragma unroll
-                for (int a = 0; a <= A; ++a) {
-                    x[a] = (long long)acc[r * (A + 1) + a];
-                    if (x[a] != 0) acc[r * (A + 1) + a] = 0ull;
-                }
-                const float nf = r >= S ? nf1 : nf0;
+            for (int k = 0; k < kFinishRows; ++k) {
+                const int64_t i = i0 + k * stride;
+                r[k] = i < limit ? (row_list ? (int64_t)row_list[i] : i) : 0;  // row list: the rows the batch visited (all others hold zero sums)
+                on[k] = i < limit;
+            }
 #pragma unroll
-                for (int a = 0; a < A; ++a) dlogit_tab[r * A + a] = bad ? nan : w_n * ((float)((double)x[a] / fx.scale_l) / nf);
-                dv_tab[r] = bad ? nan : w_v * ((float)((double)x[A] / fx.scale_v) / nf);
+            for (int k = 0; k < kFinishRows; ++k) {
+                const int64_t s = r[k] >= S ? r[k] - S : r[k];
+                on[k] = on[k] && !(n_upper > 0 && bucket_of[s] >= n_groups);  // (rows above the cut: the wave-per-row workgroups)
+            }
+#pragma unroll
+            for (int k = 0; k < kFinishRows; ++k)
+#pragma unroll
+                for (int a = 0; a <= A; ++a) x[k][a] = on[k] ? (long long)acc[r[k] * (A + 1) + a] : 0ll;
+#pragma unroll
+            for (int k = 0; k < kFinishRows; ++k) {
+                if (!on[k]) continue;
+#pragma unroll
+                for (int a = 0; a <= A; ++a)
+                    if (x[k][a] != 0) acc[r[k] * (A + 1) + a] = 0ull;
+                const float nf = r[k] >= S ? nf1 : nf0;
+#pragma unroll
+                for (int a = 0; a < A; ++a) dlogit_tab[r[k] * A + a] = bad ? nan : w_n * ((float)((double)x[k][a] / fx.scale_l) / nf);
+                dv_tab[r[k]] = bad ? nan : w_v * ((float)((double)x[k][A] / fx.scale_v) / nf);
             }
         }
     } else {
@@ -1763,11 +1806,13 @@ int rollout_bucketed_impl(const rnad_tree_t *tree, const RolloutBuffers &tr, boo
         ProfScope sort_passes(PROF_BUCKET_SORT, stream);
         if (!keys_with_hist) hipLaunchKernelGGL(k_bucket_hist, dim3(p.sort_blocks), dim3(kSortThreads), lds, stream, B, nb, (const int32_t *)s.keys, s.hist);
         hipLaunchKernelGGL(k_bucket_scan, dim3((nb + kScanCols - 1) / kScanCols), dim3(kSortThreads), 0, stream, p.sort_blocks, nb, s.hist, s.totals);
-        const size_t scatter_lds = (2 * (size_t)nb + 1) * sizeof(int32_t);  // bucket_start -> rank counters | first item of every bucket
+        // bucket_start -> rank counters | first item of every bucket | a counter row per wave when that fits (else the waves take turns)
+        const bool wave_counts = (18 * (size_t)nb + 1) * sizeof(int32_t) <= 96 * 1024;
+        const size_t scatter_lds = ((wave_counts ? 18 : 2) * (size_t)nb + 1) * sizeof(int32_t);
         if (scatter_lds > 48 * 1024)
             RNAD_HIP_OK(hipFuncSetAttribute((const void *)k_bucket_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, (int)scatter_lds));
         hipLaunchKernelGGL(k_bucket_scatter, dim3(p.sort_blocks), dim3(kSortThreads), scatter_lds, stream, B, nb, (const int32_t *)s.keys,
-                           (const int32_t *)s.hist, (const int32_t *)s.totals, p.chunk, (Item *)items, n_items, lane_ids);
+                           (const int32_t *)s.hist, (const int32_t *)s.totals, p.chunk, (Item *)items, n_items, lane_ids, wave_counts ? 1 : 0);
         if (group_flags)
             hipLaunchKernelGGL(k_group_flags, dim3(blocks_for(S)), dim3(kThreads), 0, stream, S, (const int32_t *)p.cut->bucket_of,
                                p.cut->n_groups, (const int32_t *)s.totals, group_flags);
