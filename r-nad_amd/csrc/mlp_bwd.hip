@@ -39,7 +39,6 @@ __global__ __launch_bounds__(64 * WAVES) void k_mlp_backward(int64_t N, int W, c
                                                        const int32_t *__restrict__ rows, const int64_t *__restrict__ n_rows) {
     if (n_rows) N = *n_rows;  // row-list launch (see k_mlp_forward): sample s is row rows[s]; the count lives in device memory
     constexpr int K = 2 * A * A, KS = K / 2;
-    constexpr int FT = (K + 1 + kTile - 1) / kTile;  // 32-wide feature tiles of the augmented input (x | 1)
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int nthreads = 64 * WAVES;
     const int W2 = 2 * W;
@@ -261,8 +260,8 @@ __global__ __launch_bounds__(64 * WAVES) void k_mlp_backward(int64_t N, int W, c
     }
 
     // ---------------- write this block's partial gradients
-    // layout: dW0aug [2W][32 FT] | dW1v [W] | dW1p [A][W] | db1v | db1p [A]
-    constexpr int FW = FT * kTile;
+    // layout: dW0aug [2W][FW] | dW1v [W] | dW1p [A][W] | db1v | db1p [A]
+    constexpr int FW = bwd_feature_stride(K);
     float *out = partial + (int64_t)blockIdx.x * P;
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
@@ -328,7 +327,7 @@ __global__ __launch_bounds__(64 * kReduceSlices) void k_mlp_reduce(int nblocks, 
                                                                    float *__restrict__ g_vw1, float *__restrict__ g_vb1,
                                                                    float *__restrict__ g_pw0, float *__restrict__ g_pb0,
                                                                    float *__restrict__ g_pw1, float *__restrict__ g_pb1) {
-    constexpr int K = MlpShape<A, FOLD>::K, OBS = MlpShape<A, FOLD>::OBS, FW = ((K + 1 + kTile - 1) / kTile) * kTile;
+    constexpr int K = MlpShape<A, FOLD>::K, OBS = MlpShape<A, FOLD>::OBS, FW = bwd_feature_stride(K);
     __shared__ double part[kReduceSlices][64], part_ind[kReduceSlices][64];
     const int e = blockIdx.x * 64 + threadIdx.x;
     const int total = 2 * W * FW + W + A * W + 1 + A;
@@ -400,7 +399,7 @@ static bool use_resident_backward() {
 // per SIMD.  With more feature tiles it needs up to ~400: 4 waves per block, one per SIMD, and blockIdx.y walks the tile groups.
 static bool mlp_backward_plan(int64_t N, int W, int A, BwdPlan *p, bool fold = false) {
     const int K = fold ? mlp_fold_k(A) : 2 * A * A, T = W / kTile, FT = (K + 1 + kTile - 1) / kTile;
-    p->total = 2 * W * FT * kTile + W + A * W + 1 + A;
+    p->total = 2 * W * bwd_feature_stride(K) + W + A * W + 1 + A;
     p->P = (p->total + 3) & ~3;
     int dev0 = 0, cus0 = 256;
     if (hipGetDevice(&dev0) == hipSuccess) (void)hipDeviceGetAttribute(&cus0, hipDeviceAttributeMultiprocessorCount, dev0);

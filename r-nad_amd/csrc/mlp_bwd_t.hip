@@ -30,7 +30,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_mlp_backward_t(int64_t N, int W,
     // FOLD (mlp_common.hpp "the legal fold"): K = A^2 + 1 (+ padding) input features -- the expected values and the absorbing-state
     // indicator --, the legal columns of the raw weight image folded into this wave's bias and indicator weight below
     constexpr int K = MlpShape<A, FOLD>::K, KS = K / 2, OBS = MlpShape<A, FOLD>::OBS;
-    constexpr int FT = (K + 1 + kTile - 1) / kTile, FW = FT * kTile;  // row stride of dW0aug in the partial buffer
+    constexpr int FW = bwd_feature_stride(K);  // row stride of dW0aug in the partial buffer
     constexpr int REM = (K + 1) % 16, N16 = (K + 1) / 16 + (REM > 4 ? 1 : 0), LO = REM > 4 ? 0 : REM;
     constexpr int N16R = N16 > 0 ? N16 : 1;
     constexpr int KQ = (K + 3) / 4;  // k-steps of the recompute (four input features each; the stage rows are zero-padded)
