@@ -252,8 +252,8 @@ def main():
     fence()
     names = {rnad_hip.PROF_OBSERVE: "k_observe", rnad_hip.PROF_ACT: "rollout (all kernels of Episodes.generate)",
              rnad_hip.PROF_LEARN: "learner (all kernels between the forwards and the backward)", rnad_hip.PROF_MLP: "k_mlp_forward",
-             rnad_hip.PROF_MLP_BWD: "k_mlp_backward", rnad_hip.PROF_BUCKET_KEYS: "k_bucket_keys",
-             rnad_hip.PROF_BUCKET_SORT: "k_bucket_hist+scan+items+scatter", rnad_hip.PROF_BUCKET_ROLLOUT: "k_bucket_rollout",
+             rnad_hip.PROF_MLP_BWD: "k_mlp_backward", rnad_hip.PROF_BUCKET_KEYS: "k_bucket_keys (with the sort tile's histogram)",
+             rnad_hip.PROF_BUCKET_SORT: "k_bucket_scan+scatter (+hist on the global-table fallback)", rnad_hip.PROF_BUCKET_ROLLOUT: "k_bucket_rollout",
              rnad_hip.PROF_BUCKET_LEARN: "k_bucket_learn", rnad_hip.PROF_BUCKET_FINISH: "k_bucket_finish"}
     prof = {}
     for k, nm in names.items():
@@ -472,9 +472,10 @@ def kernel_report(prof, A, C, args, B, T, live_slots, tree, mode_now):
     compact = bool(args.compact_in_effect)
     fast = (4 + 4 * A) * 4  # bytes of a fast row record (rnad_bucket_fast_record_stride)
     if compact:
-        rollout_model = (4 * B + 8 * B + slots * 4 + 4 * B + 8 * B + 4 * B,
-                         "per lane: lane id 4, drawn decisions 8 (read); per slot: state 4 (written); per lane: final state 4, packed actions 8, "
-                         "reward 4 (written).  Policy rows are gathered from the L2-resident records")
+        rollout_model = (4 * B + slots * 4 + 4 * B + 8 * B + 4 * B,
+                         "per lane: lane id 4 (read; the decisions above the cut are one word per work item); per slot: state 4 (written); "
+                         "per lane: final state 4, packed actions 8, reward 4 (written).  Policy rows and transition records are gathered "
+                         "from the L2-resident tables")
         learn_model = (live_slots * 4 + B * (4 + 8 + 4) + S2 * fast,
                        "per live slot: state 4; per lane: final state 4, packed actions 8, reward 4; the 2S fast records (64 B at A = 3) once "
                        "each -- they are gathered per slot, from L2 / MALL after the first touch; sums stay in LDS")
@@ -487,12 +488,15 @@ def kernel_report(prof, A, C, args, B, T, live_slots, tree, mode_now):
         # bytes the kernel must move per launch (streams; the L2-resident tables it gathers from are not HBM traffic)
         rh.PROF_BUCKET_ROLLOUT: ("hbm",) + rollout_model,
         rh.PROF_BUCKET_LEARN: ("hbm",) + learn_model,
-        rh.PROF_BUCKET_KEYS: ("hbm", 4 * B + 8 * B, "keys 4 B/lane and drawn decisions 8 B/lane written; everything else is gathered from L2-resident tables"),
+        rh.PROF_BUCKET_KEYS: ("hbm", 4 * B + 8 * B, "keys 4 B/lane and drawn decisions 8 B/lane written (+ one histogram row per 4096 lanes); the upper "
+                              "states' tables are staged in LDS once per workgroup"),
         rh.PROF_OBSERVE: ("hbm", B * (4 + 8 * A * A + 2 * A * A * (2 if args.obs_half else 4) + 4 * A), "SURVEY 8d"),
     }
     out = {}
     pmc = pmc_counters() if (A, C, args.depth, tuple(args.prune), B, args.width, args.obs_half) == (3, 1, 6, (0, 0), 1 << 20, 256, False) else {}
-    pmc_name = {rh.PROF_BUCKET_KEYS: "k_bucket_keys", rh.PROF_BUCKET_ROLLOUT: "k_bucket_rollout_compact" if compact else "k_bucket_rollout",
+    # (the kernel a scope ran depends on the tree: LDS walk / global-table walk, by work item / by lane tile -- the counter file has one of each pair)
+    pmc_name = {rh.PROF_BUCKET_KEYS: "k_bucket_keys_lds" if "k_bucket_keys_lds" in pmc else "k_bucket_keys",
+                rh.PROF_BUCKET_ROLLOUT: ("k_bucket_rollout_items" if "k_bucket_rollout_items" in pmc else "k_bucket_rollout_compact") if compact else "k_bucket_rollout",
                 rh.PROF_BUCKET_LEARN: "k_bucket_learn", rh.PROF_OBSERVE: "k_observe"}
     units = {rh.PROF_BUCKET_KEYS: (B, "lane"), rh.PROF_BUCKET_ROLLOUT: (slots, "slot"), rh.PROF_BUCKET_LEARN: (max(live_slots, 1), "live slot")}
     for k, p in prof.items():
