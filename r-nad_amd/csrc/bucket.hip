@@ -48,7 +48,7 @@ constexpr int kReplicas = 64;        // copies of the upper-row table the workgr
 constexpr int kMaxSteps = 64;        // T_cap bound of the alive counters in LDS
 constexpr int kLaneBits = 22;        // B <= 2^22 lanes per call: a row receives at most one addend per lane
 constexpr int kLearnLds = 64 * 1024; // LDS budget of one learner workgroup
-constexpr int kKeysLds = 48 * 1024;  // LDS budget of k_bucket_keys_lds (the upper states' tables)
+constexpr int kKeysLds = 144 * 1024;  // LDS budget of k_bucket_keys_lds (the upper states' tables + the tile's histogram): one 1024-thread workgroup per CU still fits
 constexpr int kPackedSteps = 10;      // env steps whose decisions k_bucket_keys hands to k_bucket_rollout (6 bits each)
 constexpr int kCompactSteps = 21;     // env steps of a compact trajectory: 3 bits of action per step in one 64-bit word
 constexpr int kSharedRoot = 256;      // flag in bucket_path: the group is one subtree (its root row is shared by the bucket's lanes)
@@ -1791,6 +1791,9 @@ int rollout_bucketed_impl(const rnad_tree_t *tree, const RolloutBuffers &tr, boo
         static const bool walk_global = getenv("RNAD_KEYS_GLOBAL") && atoi(getenv("RNAD_KEYS_GLOBAL")) != 0;  // (tests: the fallback on any tree)
         if (p.cut->upper_walk && keys_lds <= kKeysLds && !walk_global) {  // the upper states' tables fit the LDS: walk there, one sort tile per workgroup
             keys_with_hist = true;
+            if (keys_lds > 48 * 1024)
+                RNAD_DISPATCH_A(tree->A, RNAD_HIP_OK(hipFuncSetAttribute((const void *)k_bucket_keys_lds<kA, kPlay>,
+                                                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)keys_lds)));
             RNAD_DISPATCH_A(tree->A, hipLaunchKernelGGL((k_bucket_keys_lds<kA, kPlay>), dim3(p.sort_blocks), dim3(kSortThreads), keys_lds, stream,
                                                         (const UpperWalk *)p.cut->upper_walk, (const int32_t *)p.cut->upper_list, p.cut->n_upper, nb,
                                                         tree->C, S, B, n_steps, policy_tab, policy_stride, (int)p.cut->host_bucket_of[1],
