@@ -267,8 +267,12 @@ __global__ __launch_bounds__(kThreads) void k_policy_rows(int64_t rows, const fl
 #pragma unroll
     for (int a = 0; a < A; ++a) in[a] = logits[r * stride + a];
     policy_head_ptr<A>(in, mask_tab[r], pol, nullptr);
+    constexpr int PS = (A + 3) & ~3;  // rows as the rollout kernels gather them: 16-byte loads
+    float4 *p4 = reinterpret_cast<float4 *>(policy + r * PS);
 #pragma unroll
-    for (int a = 0; a < A; ++a) policy[r * A + a] = pol[a];
+    for (int u = 0; u < PS / 4; ++u)
+        p4[u] = float4{4 * u < A ? pol[4 * u] : 0.0f, 4 * u + 1 < A ? pol[4 * u + 1] : 0.0f, 4 * u + 2 < A ? pol[4 * u + 2] : 0.0f,
+                       4 * u + 3 < A ? pol[4 * u + 3] : 0.0f};
 }
 
 // flags[P * S + s] = 1 for both rows of every state that lies in a group some lane of the batch descends into (totals[group] > 0),
@@ -1634,9 +1638,9 @@ extern "C" int rnad_bucket_plan(const rnad_tree_t *tree, int64_t B, int64_t *out
     out[3] = p.cut->n_groups;
     out[4] = p.max_items;
     // scratch of the rollout (bytes): decisions [B] u64 | keys [B] | hist [sort_blocks][n_buckets] | totals [n_buckets] | bucket_start [n_buckets] |
-    // alive_part [blocks][T_cap + 1 <= kMaxSteps + 1] | policy [2S][A]
+    // alive_part [blocks][T_cap + 1 <= kMaxSteps + 1] | policy [2S][(A + 3) & ~3] (16-byte aligned rows)
     out[5] = 8 * B + 4 * (B + (int64_t)p.sort_blocks * nb + 2 * (int64_t)nb + std::max<int64_t>(p.max_items, (int64_t)blocks_for(B)) * (kMaxSteps + 1) +
-                  2 * tree->S * tree->A) + 256;
+                  2 * tree->S * ((tree->A + 3) & ~3)) + 256;
     // accumulators of the learner (bytes, must be zero before the first update): acc [2S][A+1] u64 | rep [64][2][n_upper][A+1] u64 |
     // losses_raw [4] f64 | overflow [1] i32
     out[6] = 8 * (2 * tree->S * A1 + (int64_t)kReplicas * 2 * std::max(nu, 1) * A1 + 4) + 16;
@@ -1678,7 +1682,7 @@ Scratch carve_scratch(void *ws, int64_t B, const Plan &p) {
     s.totals = s.hist + (int64_t)p.sort_blocks * p.cut->n_buckets;
     s.bucket_start = s.totals + p.cut->n_buckets;
     s.alive_part = s.bucket_start + p.cut->n_buckets;
-    s.policy = (float *)(s.alive_part + alive_rows_max(B, p) * (kMaxSteps + 1));
+    s.policy = (float *)(((uintptr_t)(s.alive_part + alive_rows_max(B, p) * (kMaxSteps + 1)) + 15) & ~(uintptr_t)15);  // rows of (A + 3) & ~3 floats
     return s;
 }
 }  // namespace
@@ -1781,7 +1785,7 @@ int rollout_bucketed_impl(const rnad_tree_t *tree, const RolloutBuffers &tr, boo
                                                         table_stride, mt, s.policy, play_rows, n_play_rows, nullptr, 0, S));
         }
         policy_tab = s.policy;
-        policy_stride = tree->A;
+        policy_stride = (tree->A + 3) & ~3;
     }
     const int vec4 = (policy_stride % 4 == 0 && ((uintptr_t)policy_tab & 15) == 0) ? 1 : 0;
     bool keys_with_hist = false;
