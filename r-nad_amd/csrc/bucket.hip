@@ -1661,7 +1661,7 @@ namespace {
 // The compact rollout runs one workgroup per work item (k_bucket_rollout_items) unless RNAD_ROLLOUT_GLOBAL asks for the
 // lane-tiled kernel (k_bucket_rollout_compact: kThreads * kPlay columns per workgroup).  Either leaves one row of alive counts per workgroup.
 bool rollout_by_items(const rnad_tree_t *, const Plan &) {
-    static const bool off = getenv("RNAD_ROLLOUT_GLOBAL") && atoi(getenv("RNAD_ROLLOUT_GLOBAL")) != 0;
+    const bool off = getenv("RNAD_ROLLOUT_GLOBAL") && atoi(getenv("RNAD_ROLLOUT_GLOBAL")) != 0;
     return !off;
 }
 int64_t alive_rows(const rnad_tree_t *tree, int64_t B, const Plan &p, bool compact) {
@@ -1792,7 +1792,7 @@ int rollout_bucketed_impl(const rnad_tree_t *tree, const RolloutBuffers &tr, boo
     if (sort_phase) {
         ProfScope one(PROF_BUCKET_KEYS, stream);
         const size_t keys_lds = keys_lds_bytes(p.cut->n_upper, nb, tree->A, tree->C);
-        static const bool walk_global = getenv("RNAD_KEYS_GLOBAL") && atoi(getenv("RNAD_KEYS_GLOBAL")) != 0;  // (tests: the fallback on any tree)
+        const bool walk_global = getenv("RNAD_KEYS_GLOBAL") && atoi(getenv("RNAD_KEYS_GLOBAL")) != 0;  // (tests: the fallback on any tree)
         if (p.cut->upper_walk && keys_lds <= kKeysLds && !walk_global) {  // the upper states' tables fit the LDS: walk there, one sort tile per workgroup
             keys_with_hist = true;
             if (keys_lds > 48 * 1024)

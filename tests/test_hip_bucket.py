@@ -287,6 +287,50 @@ def test_compact_trajectory_is_the_dense_one(name, B):
     assert sub._compact is None and torch.equal(sub.policy, dense.policy[:, sel]) and torch.equal(sub.rewards, dense.rewards[:, sel])
 
 
+@pytest.mark.parametrize("rows", (None, 40, 8, 2))
+@pytest.mark.parametrize("name", sorted(TREES))
+def test_walk_kernel_variants_play_the_same_batch(name, rows, monkeypatch):
+    """The keys pass in LDS with its histogram (k_bucket_keys_lds) and the rollout by work item with the steps above the cut played
+    once per workgroup (k_bucket_rollout_items) against the global-table walk + k_bucket_hist and the lane-tiled rollout with a
+    per-lane replay (RNAD_KEYS_GLOBAL / RNAD_ROLLOUT_GLOBAL): same keys, same permutation, same work list, same trajectory, same alive
+    counts -- at the planner's cut and at forced ones (upper states, runs of several sibling subtrees per group, terminal buckets)."""
+    import rnad_hip
+    from environment.episode import Episodes
+
+    tree = _native_tree(**TREES[name])
+    h = tree.handle()
+    A = tree.max_actions
+    B = 6000
+    if rows is not None:
+        monkeypatch.setenv("RNAD_BUCKET_ROWS", str(rows))
+        if rnad_hip.bucket_plan(h, B) is None:
+            pytest.skip(f"a table of {rows} rows does not fit this tree")
+    nets = _four_nets(A, 64, seed=4)
+    logit, v, vt, lr, lr_ = _tables(tree, nets, A)
+    hp = rnad_hip.make_learn_params(alpha=0.3, eta=0.2, w_v=0.7, w_n=1.3)
+    rec, fast = rnad_hip.bucket_records(h, logit, v, vt, lr, lr_, hp, fast=True)
+    actor = (rec, rnad_hip.policy_column(A))
+    out = {}
+    for variant, env in (("default", {}), ("fallback", {"RNAD_KEYS_GLOBAL": "1", "RNAD_ROLLOUT_GLOBAL": "1"}),
+                         ("keys only", {"RNAD_KEYS_GLOBAL": "1"}), ("rollout only", {"RNAD_ROLLOUT_GLOBAL": "1"})):
+        for k in ("RNAD_KEYS_GLOBAL", "RNAD_ROLLOUT_GLOBAL"):
+            monkeypatch.delenv(k, raising=False)
+        for k, val in env.items():
+            monkeypatch.setenv(k, val)
+        ep = Episodes(tree, B, seed=21, lane_offset=77)
+        ep.generate(nets[0], tabular=True, bucketed=True, trim=False, store_values=False, policy_table=actor, compact=True)
+        traj = ep._compact[0]
+        n_items = int(ep.buckets.n_items.item())
+        got = rnad_hip.learn_bucketed_compact(h, ep.buckets, traj, ep.t_eff + 1, rec, fast, ep.valid_counts, hp)
+        out[variant] = (ep.lane_ids.clone(), ep.indices.clone(), traj.acts.clone(), traj.final_reward.clone(), ep.alive.clone(),
+                        ep.valid_counts.clone(), ep.buckets.items[:n_items].clone(), got[0].clone(), got[1].clone())
+    for variant in ("fallback", "keys only", "rollout only"):
+        for a, b, what in zip(out["default"], out[variant], ("lane_ids", "indices", "acts", "final_reward", "alive", "valid_counts", "items",
+                                                             "dlogit", "dv")):
+            assert torch.equal(a, b), f"{variant}: {what}"
+    assert float(out["default"][7].abs().sum()) > 0
+
+
 def test_compact_train_steps_are_the_dense_ones(tmp_path, monkeypatch):
     """RNaD.train_step with the compact trajectory (default) and with the dense one: identical parameters after several steps."""
     from environment.episode import Buffer
