@@ -107,6 +107,21 @@ def test_seeded_draws_match_oracle_bit_for_bit(G, hip):
             np.testing.assert_array_equal(G.cpu(got), want)
 
 
+def test_seeded_draws_follow_the_policy_on_the_device(G, hip):
+    """torch.multinomial's contract: the drawn categories are distributed as the weights.  2^20 seeded draws per decision slot (row
+    player's action, column player's action, chance) against a fixed policy: chi-square, and no draw of a zero weight."""
+    n = 1 << 20
+    p = np.array([0.03, 0.17, 0.0, 0.45, 0.35], np.float32)
+    probs = G.gpu(np.repeat(p[None], n, 0))
+    for step, stream in ((0, 0), (1, 0), (1, 1), (7, 0)):
+        got = G.cpu(hip.sample(probs, seed=2024, lane0=0, step=step, stream_id=stream))
+        cnt = np.bincount(got, minlength=5).astype(np.float64)
+        assert cnt[2] == 0
+        live = p > 0
+        chi2 = (((cnt - n * p) ** 2)[live] / (n * p[live])).sum()
+        assert chi2 < 21.1, (step, stream, chi2)  # 3 degrees of freedom: P(chi2 > 21.1) ~ 1e-4
+
+
 @pytest.mark.parametrize("name", ("small", "ragged", "a5"))
 def test_seeded_transition_matches_oracle(G, hip, name):
     from oracle import oracle
