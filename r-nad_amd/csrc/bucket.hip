@@ -1660,9 +1660,9 @@ extern "C" int rnad_bucket_map(const rnad_tree_t *tree, int64_t B, int32_t *buck
 namespace {
 // The compact rollout runs one workgroup per work item (k_bucket_rollout_items) unless RNAD_ROLLOUT_GLOBAL asks for the
 // lane-tiled kernel (k_bucket_rollout_compact: kThreads * kPlay columns per workgroup).  Either leaves one row of alive counts per workgroup.
-bool rollout_by_items(const rnad_tree_t *, const Plan &) {
+bool rollout_by_items(const rnad_tree_t *, const Plan &p) {
     const bool off = getenv("RNAD_ROLLOUT_GLOBAL") && atoi(getenv("RNAD_ROLLOUT_GLOBAL")) != 0;
-    return !off;
+    return !off && p.chunk <= kThreads;  // (a thread per lane of the item: RNAD_BUCKET_CHUNK beyond a workgroup takes the lane-tiled kernel)
 }
 int64_t alive_rows(const rnad_tree_t *tree, int64_t B, const Plan &p, bool compact) {
     return compact && rollout_by_items(tree, p) ? p.max_items : (int64_t)blocks_for(B);

@@ -331,6 +331,39 @@ def test_walk_kernel_variants_play_the_same_batch(name, rows, monkeypatch):
     assert float(out["default"][7].abs().sum()) > 0
 
 
+@pytest.mark.timeout(120)
+@pytest.mark.parametrize("chunk", (64, 512))
+def test_work_items_of_another_size_give_the_same_update(chunk, monkeypatch):
+    """RNAD_BUCKET_CHUNK (lanes per work item; 256 by default): the trajectory and the per-row sums do not depend on how a bucket's
+    lanes are cut into items.  Items larger than a workgroup take the lane-tiled rollout kernel and several passes of the learner."""
+    import rnad_hip
+    from environment.episode import Episodes
+
+    tree = _native_tree(**TREES["ternary4"])
+    h = tree.handle()
+    A = tree.max_actions
+    B = 20000
+    nets = _four_nets(A, 64, seed=6)
+    logit, v, vt, lr, lr_ = _tables(tree, nets, A)
+    hp = rnad_hip.make_learn_params(alpha=0.3, eta=0.2, w_v=0.7, w_n=1.3)
+    rec, fast = rnad_hip.bucket_records(h, logit, v, vt, lr, lr_, hp, fast=True)
+    actor = (rec, rnad_hip.policy_column(A))
+    out = []
+    for c in (None, chunk):
+        if c is None:
+            monkeypatch.delenv("RNAD_BUCKET_CHUNK", raising=False)
+        else:
+            monkeypatch.setenv("RNAD_BUCKET_CHUNK", str(c))
+        ep = Episodes(tree, B, seed=33)
+        ep.generate(nets[0], tabular=True, bucketed=True, trim=False, store_values=False, policy_table=actor, compact=True)
+        traj = ep._compact[0]
+        got = rnad_hip.learn_bucketed_compact(h, ep.buckets, traj, ep.t_eff + 1, rec, fast, ep.valid_counts, hp)
+        out.append((ep.lane_ids.clone(), ep.indices.clone(), traj.acts.clone(), traj.final_reward.clone(), ep.alive.clone(), got[0].clone(),
+                    got[1].clone()))
+    for a, b, what in zip(out[0], out[1], ("lane_ids", "indices", "acts", "final_reward", "alive", "dlogit", "dv")):
+        assert torch.equal(a, b), what
+
+
 def test_compact_train_steps_are_the_dense_ones(tmp_path, monkeypatch):
     """RNaD.train_step with the compact trajectory (default) and with the dense one: identical parameters after several steps."""
     from environment.episode import Buffer
