@@ -9,7 +9,12 @@
  * fixtures under tests/golden/ that were produced by importing the reference itself
  * (tests/golden/make_golden.py).  Tensors use the REFERENCE's layouts ([S,C,A,A] tables, int64
  * indices, one-hot actions), not the packed layouts of the HIP library, so that the packing code
- * is checked too.
+ * is checked too.  One exception, stated where it stands: the reference draws with
+ * torch.multinomial from torch's global generator, which has no counterpart in a seeded rollout;
+ * oracle_sample / oracle_transition restate torch's algorithm on recorded noise (pinned by the
+ * golden rollouts), oracle_pick / oracle_transition_pick / oracle_uniforms restate the seeded
+ * draw of include/rnad_rng.h (pinned by its documented counter layout, the philox known answers,
+ * its definition in numpy and chi-square tests: tests/test_rng.py).
  *
  * All arithmetic is fp32 in the reference's operation order; build with -ffp-contract=off so the
  * compiler cannot fuse a*b+c (the reference runs one torch op per arithmetic step).
