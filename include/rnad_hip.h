@@ -354,7 +354,8 @@ int rnad_learn_fused_gather(const rnad_tree_t *tree, int T, int64_t B, const int
  * rnad_bucket_plan: out[0] = R (rows of a bucket's table), [1] = number of buckets (groups + one terminal bucket per upper state),
  * [2] = number of upper states, [3] = number of groups, [4] = capacity of the work-item list (items: int32 [out[4]][4] = first lane,
  * lanes, bucket, 1 if the bucket's only item), [5] = bytes of `scratch` for rnad_rollout_bucketed, [6] = bytes of `accumulators` for
- * rnad_learn_bucketed (zero them once; every update leaves them zero), [7] = LDS bytes of a learner workgroup.  Non-zero return: this
+ * rnad_learn_bucketed (zero them once; every update leaves them zero), [7] = LDS bytes of a learner workgroup, [8] = bytes of a relative
+ * state of the compact trajectory (1 or 2; out must hold 9 values).  Non-zero return: this
  * tree / batch cannot be bucketed (use the entry points above).  rnad_bucket_map: the bucket of every state (host int32 [S]; < *n_groups:
  * a group, else n_groups + upper slot; -1: state 0 / unreachable) -- what tests and tools need to reproduce the lane order.
  *
@@ -385,8 +386,14 @@ int rnad_learn_fused_gather(const rnad_tree_t *tree, int T, int64_t B, const int
  * tables, the action takes 3 bits, and rewards *= (indices == 0) (episode.py:120-121) leaves one non-zero reward per episode.
  * rnad_rollout_bucketed_compact plays the same episodes as rnad_rollout_bucketed (same table arguments: e.g. the pi columns of
  * `records`: table = records + 3A + 3, table_stride = rnad_bucket_record_stride(A), table_is_policy = 1) and
- * writes indices [T_cap + 1, B], alive, acts (uint64 [B]: action of step t in bits 3t .. 3t + 2) and final_reward (f32 [B]) -- 64
- * instead of 300 bytes per lane at A = 3, T = 12; T_cap <= 21.  rnad_learn_bucketed_compact is rnad_learn_bucketed on that
+ * writes states [T_cap + 1, B], alive, acts (uint64 [B]: action of step t in bits 3t .. 3t + 2) and final_reward (f32 [B]); T_cap <= 21.
+ * `states` holds RELATIVE states, rnad_bucket_plan's out[8] bytes each (1 while the cut's tables have <= 255 rows, else 2): column j
+ * belongs to a work item of some bucket b (items: {begin, count, bucket, single}); a lane of b sits in the bucket's own path state at
+ * every env step above its group (and at the root of a group that is a single subtree) -- those rows of the column are neither
+ * written nor read -- and below in bucket_lo[b] + (value - 1), value 0 = absorbed.  25 instead of 300 bytes per lane at A = 3,
+ * T = 12 on configs[1] (5 state bytes + actions + reward + lane id).  rnad_bucket_indices rebuilds the reference's indices
+ * (int32 [T1, B], episode.py:218) from it, rnad_bucket_pack_states is the inverse (a recorded bucket-ordered trajectory into the
+ * compact layout; *mismatch is set when a column is not a lane of its item's bucket).  rnad_learn_bucketed_compact is rnad_learn_bucketed on that
  * trajectory with the actor's own pi as the acting policy (the very floats the rollout sampled from), so that every operand of a
  * slot's V-trace / NeuRD arithmetic except the carries is the ROW's: rnad_bucket_records writes them once per row into
  * fast_records (optional output; rnad_bucket_fast_record_stride(A) = 4 + 4A floats:
@@ -432,8 +439,12 @@ int rnad_rollout_bucketed(const rnad_tree_t *tree, const rnad_traj_t *traj, cons
                           double *norm, void *stream);
 int rnad_rollout_bucketed_compact(const rnad_tree_t *tree, int T_cap, int64_t B, const float *table, int64_t table_stride,
                                   int table_is_policy, uint64_t seed, int64_t lane0, const rnad_step_params_t *device_params,
-                                  void *scratch, int32_t *lane_ids, int32_t *items, int32_t *n_items, double *norm, int32_t *indices,
+                                  void *scratch, int32_t *lane_ids, int32_t *items, int32_t *n_items, double *norm, void *states,
                                   int32_t *alive, uint64_t *acts, float *final_reward, int32_t *visited, void *stream);
+int rnad_bucket_indices(const rnad_tree_t *tree, int T1, int64_t B, const void *states, const int32_t *items, const int32_t *n_items,
+                        int32_t *indices, void *stream);
+int rnad_bucket_pack_states(const rnad_tree_t *tree, int T1, int64_t B, const int32_t *indices, const int32_t *items,
+                            const int32_t *n_items, void *states, int32_t *mismatch, void *stream);
 int rnad_bucket_expand(const rnad_tree_t *tree, int T, int64_t B, const int32_t *indices, const uint64_t *acts,
                        const float *final_reward, const float *records, uint8_t *mask_bits, float *policy, int32_t *actions,
                        float *rewards, void *stream);
@@ -448,7 +459,7 @@ int rnad_learn_bucketed(const rnad_tree_t *tree, int T, int64_t B, const int32_t
                         const float *rewards, const float *mu, const float *records, const int32_t *items, const int32_t *n_items,
                         const double *norm, const rnad_learn_params_t *hp, void *accumulators, double *losses, float *dlogit_tab,
                         float *dv_tab, void *stream);
-int rnad_learn_bucketed_compact(const rnad_tree_t *tree, int T, int64_t B, const int32_t *indices, const uint64_t *acts,
+int rnad_learn_bucketed_compact(const rnad_tree_t *tree, int T, int64_t B, const void *states, const uint64_t *acts,
                                 const float *final_reward, const float *fast_records, const float *records, const int32_t *items,
                                 const int32_t *n_items, const double *norm, const rnad_learn_params_t *hp, void *accumulators,
                                 double *losses, float *dlogit_tab, float *dv_tab, const int32_t *rows, const int64_t *n_rows,
@@ -466,7 +477,7 @@ int rnad_bucket_sort(const rnad_tree_t *tree, int T_cap, int64_t B, const float 
                      int32_t *items, int32_t *n_items, double *norm, int32_t *group_flags, void *stream);
 int rnad_bucket_play(const rnad_tree_t *tree, int T_cap, int64_t B, const float *table, int64_t table_stride, int table_is_policy,
                      const int32_t *rows, const int64_t *n_rows, uint64_t seed, int64_t lane0, const rnad_step_params_t *device_params,
-                     void *scratch, const int32_t *lane_ids, const int32_t *items, const int32_t *n_items, double *norm, int32_t *indices,
+                     void *scratch, const int32_t *lane_ids, const int32_t *items, const int32_t *n_items, double *norm, void *states,
                      int32_t *alive, uint64_t *acts, float *final_reward, int32_t *visited, void *stream);
 int rnad_bucket_finish(const rnad_tree_t *tree, int64_t B, const double *norm, const rnad_learn_params_t *hp, void *accumulators,
                        double *losses, float *dlogit_tab, float *dv_tab, const int32_t *rows, const int64_t *n_rows, void *stream);

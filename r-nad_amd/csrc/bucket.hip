@@ -34,6 +34,10 @@
 using namespace rnad;
 using namespace rnad::dev;
 
+#ifndef RNAD_ABLATE
+#define RNAD_ABLATE 0  // bit mask of k_bucket_learn ablations (tools/ablate_learn.sh: what the kernel's time is made of; results are wrong)
+#endif
+
 namespace {
 
 constexpr int kThreads = 256;
@@ -60,6 +64,7 @@ inline unsigned blocks_for(int64_t n, int per = kThreads) { return (unsigned)((n
 struct Plan {
     const BucketCut *cut = nullptr;
     int lds = 0, path_words = 0, sort_blocks = 0, chunk = kChunkDefault;
+    int rel_bytes = 1;  // width of a relative state of the compact trajectory: states of a group are bucket_lo + (0 .. rows - 1)
     int64_t max_items = 0;
 };
 
@@ -78,24 +83,30 @@ __global__ __launch_bounds__(kThreads) void k_upper_walk(int n, int AAC, const i
     out[i] = UpperWalk{t.next, bucket_of[t.next], t.chance};
 }
 
-// The cut of `tree` for tables of `rows` rows (host, O(S)); cached with the handle.  nullptr: HIP allocation failed.
-const BucketCut *get_cut(const rnad_tree_t *tree, int rows) {
-    auto it = tree->cuts.find(rows);
-    if (it != tree->cuts.end()) return &it->second;
+// The cut of `tree` for tables of `rows` rows, on the host (O(S)).
+struct HostCut {
+    int rows = 0, n_groups = 0, n_upper = 0, n_buckets = 0, max_path = 0;
+    std::vector<int32_t> bucket_of, lo, path, upper_list, path_states;  // path_states: [n_buckets][max(max_path, 1)]
+};
+
+HostCut build_cut(const rnad_tree_t *tree, int rows) {
+    HostCut h;
+    h.rows = rows;
     const int64_t S = tree->S;
-    std::vector<int32_t> bucket_of((size_t)S, -1), lo, path, upper_list;
-    std::vector<int32_t> upper_slot((size_t)S, -1);
+    std::vector<int32_t> &bucket_of = h.bucket_of, &lo = h.lo, &path = h.path, &upper_list = h.upper_list;
+    bucket_of.assign((size_t)S, -1);
+    std::vector<int32_t> parent_upper((size_t)S, 0);  // upper state -> the upper state above it (0: the root)
+    std::vector<int32_t> group_parent;                // bucket -> the upper state it hangs below (0: none)
     auto is_upper = [&](int64_t s) { return tree->subtree_size[(size_t)s] > rows; };
-    int max_path = 0;
     if (!is_upper(1)) {  // the whole tree fits one table: a single group, nothing above it
         lo.push_back(1);
         path.push_back(kSharedRoot);  // (every lane starts in state 1)
+        group_parent.push_back(0);
         for (int64_t s = 1; s < S; ++s)
             if (tree->level_of[(size_t)s] >= 0) bucket_of[(size_t)s] = 0;
     } else {
         for (int64_t u = 1; u < S; ++u) {
             if (tree->level_of[(size_t)u] < 0 || !is_upper(u)) continue;
-            upper_slot[(size_t)u] = (int32_t)upper_list.size();
             upper_list.push_back((int32_t)u);
             const int level = tree->level_of[(size_t)u];
             int64_t g_lo = -1, g_hi = -1;
@@ -106,12 +117,14 @@ const BucketCut *get_cut(const rnad_tree_t *tree, int rows) {
                 lo.push_back((int32_t)g_lo);
                 // a group of ONE subtree: every lane of the bucket also shares the group's root for two more steps (kSharedRoot)
                 path.push_back(2 * (level + 1) | (g_subtrees == 1 ? kSharedRoot : 0));
+                group_parent.push_back((int32_t)u);
                 for (int64_t x = g_lo; x < g_hi; ++x) bucket_of[(size_t)x] = gid;
                 g_lo = g_hi = -1;
             };
             for (int64_t i = tree->child_offsets[(size_t)u]; i < tree->child_offsets[(size_t)u + 1]; ++i) {
                 const int64_t c = tree->children[(size_t)i];
                 if (is_upper(c)) {
+                    parent_upper[(size_t)c] = (int32_t)u;
                     close();
                     continue;
                 }
@@ -129,30 +142,64 @@ const BucketCut *get_cut(const rnad_tree_t *tree, int rows) {
             close();
         }
     }
-    BucketCut cut;
-    cut.rows = rows;
-    cut.n_groups = (int)lo.size();
-    cut.n_upper = (int)upper_list.size();
-    cut.n_buckets = cut.n_groups + cut.n_upper;
-    for (int i = 0; i < cut.n_upper; ++i) {  // terminal buckets: lanes that leave the tree from an upper state
+    h.n_groups = (int)lo.size();
+    h.n_upper = (int)upper_list.size();
+    h.n_buckets = h.n_groups + h.n_upper;
+    for (int i = 0; i < h.n_upper; ++i) {  // terminal buckets: lanes that leave the tree from an upper state
         const int32_t u = upper_list[(size_t)i];
-        bucket_of[(size_t)u] = cut.n_groups + i;
+        bucket_of[(size_t)u] = h.n_groups + i;
         lo.push_back(u);
         path.push_back(2 * tree->level_of[(size_t)u] + 2);
+        group_parent.push_back(u);
     }
+    int max_path = 0;
     for (int32_t v : path) max_path = std::max(max_path, (int)(v & (kSharedRoot - 1)) + ((v & kSharedRoot) ? 2 : 0));
-    cut.max_path = max_path;
+    h.max_path = max_path;
+    // the states a bucket's lanes share: the upper states from the root down to the one the bucket hangs below (a state holds both
+    // players' steps of its level), then -- a group that is one subtree -- its root
+    const int stride = std::max(max_path, 1);
+    h.path_states.assign((size_t)h.n_buckets * stride, 0);
+    if (max_path <= kMaxPath) {  // (deeper cuts are rejected by cut_fits)
+        for (int b = 0; b < h.n_buckets; ++b) {
+            int32_t *row = h.path_states.data() + (size_t)b * stride;
+            for (int32_t u = group_parent[(size_t)b]; u != 0; u = parent_upper[(size_t)u]) {
+                const int l = tree->level_of[(size_t)u];
+                row[2 * l] = row[2 * l + 1] = u;
+            }
+            if (path[(size_t)b] & kSharedRoot) {
+                const int n_path = path[(size_t)b] & (kSharedRoot - 1);
+                row[n_path] = row[n_path + 1] = lo[(size_t)b];
+            }
+        }
+    }
     if (upper_list.empty()) upper_list.push_back(0);
+    return h;
+}
+
+bool cut_fits(const HostCut &c) { return c.n_buckets <= kMaxBuckets && c.n_upper <= kMaxUpper && c.max_path <= kMaxPath; }
+
+// The cut on the device, cached with the handle.  nullptr: HIP allocation failed.  (Called from make_plan for the CHOSEN cut only; the
+// planner's candidates live on the host.  k_upper_walk runs on the null stream: rnad_bucket_plan is what a caller invokes before it
+// captures a step.)
+const BucketCut *get_cut(const rnad_tree_t *tree, int rows) {
+    auto it = tree->cuts.find(rows);
+    if (it != tree->cuts.end()) return &it->second;
+    HostCut h = build_cut(tree, rows);
+    BucketCut cut;
+    cut.rows = rows;
+    cut.n_groups = h.n_groups;
+    cut.n_upper = h.n_upper;
+    cut.n_buckets = h.n_buckets;
+    cut.max_path = h.max_path;
     DeviceGuard guard(tree->device);
     auto up = [&](int32_t **dst, const std::vector<int32_t> &src) {
         if (hipMalloc((void **)dst, std::max<size_t>(src.size(), 1) * sizeof(int32_t)) != hipSuccess) return false;
         return src.empty() || hipMemcpy(*dst, src.data(), src.size() * sizeof(int32_t), hipMemcpyHostToDevice) == hipSuccess;
     };
-    if (!guard.ok || !up(&cut.bucket_of, bucket_of) || !up(&cut.bucket_lo, lo) || !up(&cut.bucket_path, path) || !up(&cut.upper_list, upper_list)) {
-        if (cut.bucket_of) (void)hipFree(cut.bucket_of);
-        if (cut.bucket_lo) (void)hipFree(cut.bucket_lo);
-        if (cut.bucket_path) (void)hipFree(cut.bucket_path);
-        if (cut.upper_list) (void)hipFree(cut.upper_list);
+    if (!guard.ok || !up(&cut.bucket_of, h.bucket_of) || !up(&cut.bucket_lo, h.lo) || !up(&cut.bucket_path, h.path) ||
+        !up(&cut.upper_list, h.upper_list) || !up(&cut.path_states, h.path_states)) {
+        for (int32_t *ptr : {cut.bucket_of, cut.bucket_lo, cut.bucket_path, cut.upper_list, cut.path_states})
+            if (ptr) (void)hipFree(ptr);
         return nullptr;
     }
     if (cut.n_upper > 0) {  // (built on the device: the transition table has no host copy)
@@ -166,55 +213,60 @@ const BucketCut *get_cut(const rnad_tree_t *tree, int rows) {
             }
         }
     }
-    cut.host_bucket_of = std::move(bucket_of);
+    cut.host_bucket_of = std::move(h.bucket_of);
     return &tree->cuts.emplace(rows, std::move(cut)).first->second;
-}
-
-bool cut_fits(const BucketCut *c) {
-    return c && c->n_buckets <= kMaxBuckets && c->n_upper <= kMaxUpper && c->max_path <= kMaxPath;
 }
 
 // Table size: the finest cut (rows halved from the LDS budget down) whose groups still hold kTargetLanes lanes on average;
 // if even the coarsest is finer than that, the coarsest.  false: this tree cannot be bucketed (ids not DFS pre-order, or no
-// cut fits the limits above).  RNAD_BUCKET_ROWS forces a table size (tuning / tests).
-bool make_plan(const rnad_tree_t *tree, int64_t B, Plan &p) {
-    if (!tree->contiguous_subtrees || B < 1 || B > ((int64_t)1 << kLaneBits)) return false;
-    const int path_words = kMaxPath * kPathSlots * ((tree->A + 1) | 1);  // u64 words of the path region (slot stride odd: distinct banks)
-    const int rows_max = (kLearnLds / 8 - path_words) / (2 * (tree->A + 1));
-    const BucketCut *chosen = nullptr;
-    if (const char *force = getenv("RNAD_BUCKET_ROWS")) {
-        const int want = atoi(force);
-        if (want < 1 || want > rows_max) return false;
-        chosen = get_cut(tree, want);
-        if (!cut_fits(chosen)) return false;
-    } else if (2 * tree->S > B) {
+// cut fits the limits above).  RNAD_BUCKET_ROWS forces a table size (tuning / tests).  Candidates are evaluated on the host alone
+// (counts of a HostCut that is dropped again); the choice is kept per (lanes, forced rows), the chosen cut's device tables per rows.
+int choose_rows(const rnad_tree_t *tree, int64_t B, int forced, int rows_max) {
+    if (forced) return (forced >= 1 && forced <= rows_max && cut_fits(build_cut(tree, forced))) ? forced : 0;
+    int chosen = 0;
+    if (2 * tree->S > B) {
         // A tree that is large next to the batch (lazy rows, staged actor: learn/rnad.py): the finer the cut, the fewer states sit in
         // the groups the batch descends into -- the rows the policy head has to be evaluated on (configs[3]: 384 -> 307 rows per
         // table, 0.846 -> 0.81 ms per step).  The finest cut that fits the limits, in steps of 0.8.
         for (int rows = rows_max; rows >= 4; rows = rows * 4 / 5) {
-            const BucketCut *c = get_cut(tree, rows);
-            if (!cut_fits(c)) {
+            if (!cut_fits(build_cut(tree, rows))) {
                 if (chosen) break;  // finer cuts only have more buckets
                 continue;
             }
-            chosen = c;
+            chosen = rows;
         }
     } else {
         for (int rows = rows_max; rows >= 4; rows /= 2) {
-            const BucketCut *c = get_cut(tree, rows);
+            const HostCut c = build_cut(tree, rows);
             if (!cut_fits(c)) {
                 if (chosen) break;  // finer cuts only have more buckets
                 continue;
             }
-            if (chosen && B / std::max(c->n_groups, 1) < kTargetLanes) break;
-            chosen = c;
+            if (chosen && B / std::max(c.n_groups, 1) < kTargetLanes) break;
+            chosen = rows;
         }
     }
+    return chosen;
+}
+
+bool make_plan(const rnad_tree_t *tree, int64_t B, Plan &p) {
+    if (!tree->contiguous_subtrees || B < 1 || B > ((int64_t)1 << kLaneBits)) return false;
+    const int path_words = kMaxPath * kPathSlots * ((tree->A + 1) | 1);  // u64 words of the path region (slot stride odd: distinct banks)
+    const int rows_max = (kLearnLds / 8 - path_words) / (2 * ((tree->A + 1) | 1));
+    const char *force = getenv("RNAD_BUCKET_ROWS");
+    const int forced = force ? std::max(atoi(force), -1) : 0;
+    if (force && forced < 1) return false;
+    const auto key = std::make_pair(B, forced);
+    auto it = tree->plan_rows.find(key);
+    if (it == tree->plan_rows.end()) it = tree->plan_rows.emplace(key, choose_rows(tree, B, forced, rows_max)).first;
+    if (it->second == 0) return false;
+    const BucketCut *chosen = get_cut(tree, it->second);
     if (!chosen) return false;
     p.cut = chosen;
     // the path region holds the rows of THIS cut's upper steps (not kMaxPath of them: LDS per workgroup bounds the resident waves)
     p.path_words = std::min(kMaxPath, std::max(chosen->max_path, 1)) * kPathSlots * ((tree->A + 1) | 1);
-    p.lds = (p.path_words + 2 * chosen->rows * (tree->A + 1)) * 8;
+    p.lds = (p.path_words + 2 * chosen->rows * ((tree->A + 1) | 1)) * 8;
+    p.rel_bytes = chosen->rows <= 255 ? 1 : 2;
     p.sort_blocks = (int)((B + kSortLanes - 1) / kSortLanes);
     if (const char *c = getenv("RNAD_BUCKET_CHUNK")) p.chunk = std::max(64, atoi(c));  // tuning knob
     p.max_items = (int64_t)chosen->n_buckets + B / p.chunk + 1;
@@ -893,168 +945,50 @@ __global__ __launch_bounds__(kThreads) void k_bucket_rollout(const Trans *__rest
     }
 }
 
-// The COMPACT rollout: the trajectory as 64 bytes per lane instead of 25 per slot -- indices [T_cap + 1, B], the lane's actions
-// packed 3 bits per step (acts_out) and the one non-zero reward of the episode (rewards *= (indices == 0), episode.py:120-121: only
-// the transition into state 0 pays; reward_out).  Everything else of a slot is a function of (t & 1, indices[t]) and the actor's
-// table (k_bucket_expand writes the dense buffers on demand).
-// One TRANSITION (the row player's step and the column player's step in the same state) per iteration: both
-// policy rows of the state are requested together and the transition's uniforms are computed while they travel, so a transition costs two
-// dependent memory latencies (policy rows, transition record) instead of three.  Same draws (keyed by lane and step), same
-// episodes as k_bucket_rollout.  An absorbed lane stops: no draws, no table reads.
-// L lanes per thread in lock step (see kPlay): an absorbed lane keeps walking state 0 with its results dropped.
-template <int A, int L>
-__global__ __launch_bounds__(kThreads) void k_bucket_rollout_compact(const Trans *__restrict__ trans, int C, int64_t S, int64_t B, int T_cap,
-                                                                     const float *__restrict__ policy_tab, int64_t tab_stride, int vec4,
-                                                                     uint64_t seed, const rnad_step_params_t *__restrict__ sp, int64_t lane0,
-                                                                     const int32_t *__restrict__ lane_ids,
-                                                                     const unsigned long long *__restrict__ decisions,
-                                                                     int32_t *__restrict__ indices, int32_t *__restrict__ alive_part,
-                                                                     unsigned long long *__restrict__ acts_out,
-                                                                     float *__restrict__ reward_out, int32_t *__restrict__ visited) {
-    __shared__ int32_t cnt[kThreads / 64][kMaxSteps + 1];
-    const int64_t j0 = (int64_t)blockIdx.x * (kThreads * L) + threadIdx.x;  // this thread's columns: j0 + l * kThreads
-    if (sp) seed = sp->seed;
-    const int wave = threadIdx.x >> 6;
-    bool active[L];
-    uint64_t lane[L];
-    unsigned long long packed[L], acts[L];  // packed: the lane's first decisions, drawn by k_bucket_keys
-    int n_packed[L], state[L];
-    float reward_final[L];
-#pragma unroll
-    for (int l = 0; l < L; ++l) {
-        const int64_t j = j0 + (int64_t)l * kThreads;
-        active[l] = j < B;
-        const int32_t lane_local = active[l] ? lane_ids[j] : 0;
-        lane[l] = (uint64_t)(lane0 + lane_local);
-        packed[l] = active[l] ? decisions[lane_local] : 0ull;
-        n_packed[l] = (int)(packed[l] >> 60);
-        state[l] = active[l] ? 1 : 0;
-        acts[l] = 0ull;
-        reward_final[l] = 0.0f;
-    }
-    for (int t = 0; t < T_cap; t += 2) {
-        const bool two = t + 1 < T_cap;  // (an odd T_cap ends with a row step alone)
-        bool go[L], draw0[L], draw1[L];
-        int alive_now = 0;
-        bool draws = false;
-#pragma unroll
-        for (int l = 0; l < L; ++l) {
-            go[l] = state[l] != 0;
-            alive_now += (int)__popcll(__ballot(go[l]));
-            draw0[l] = go[l] && t >= n_packed[l];
-            draw1[l] = go[l] && two && t + 1 >= n_packed[l];
-            draws |= draw0[l] || draw1[l];
-        }
-        if ((threadIdx.x & 63) == 0) {
-            cnt[wave][t] = alive_now;
-            if (two) cnt[wave][t + 1] = alive_now;  // the row player's step leaves the state as it is
-        }
-        // (non-temporal stores here were measured: the rollout 48.0 -> 46.8 us, but the learner, which reads these columns next, 73.4 ->
-        // 75.2: the L2 / MALL copy they leave behind is worth more than the write-allocate they cost)
-#pragma unroll
-        for (int l = 0; l < L; ++l) {
-            if (active[l]) {
-                const int64_t i = (int64_t)t * B + j0 + (int64_t)l * kThreads;
-                indices[i] = state[l];
-                if (two) indices[i + B] = state[l];
-            }
-            if (visited && go[l]) {
-                visited[state[l]] = 1;  // (every writer stores the same value)
-                if (two) visited[S + state[l]] = 1;
-            }
-        }
-        float pol0[L][A], pol1[L][A], u[L][3];
-#pragma unroll
-        for (int l = 0; l < L; ++l) {
-            u[l][0] = u[l][1] = u[l][2] = 0.0f;
-#pragma unroll
-            for (int a = 0; a < A; ++a) pol0[l][a] = pol1[l][a] = 0.0f;
-        }
-        if (__ballot(draws) != 0ull) {  // (wave-uniform: a wave whose lanes all replay skips the rows and the generator)
-#pragma unroll
-            for (int l = 0; l < L; ++l) {
-                load_policy_row<A>(policy_tab, state[l], tab_stride, vec4 != 0, pol0[l]);
-                if (two) load_policy_row<A>(policy_tab, S + state[l], tab_stride, vec4 != 0, pol1[l]);
-            }
-#pragma unroll
-            for (int l = 0; l < L; ++l) rnad_decision_uniforms(seed, lane[l], (uint32_t)t, u[l]);  // computed while the rows travel
-        }
-        const int sh0 = t < kPackedSteps ? 6 * t : 0, sh1 = t + 1 < kPackedSteps ? 6 * (t + 1) : 0;
-        int a0[L];
-#pragma unroll
-        for (int l = 0; l < L; ++l) {
-            const int drawn = pick<A>(pol0[l], u[l][0]);
-            a0[l] = draw0[l] ? drawn : (go[l] ? (int)(packed[l] >> sh0) & 7 : 0);
-            acts[l] |= (unsigned long long)a0[l] << (3 * t);
-        }
-        if (!two) continue;
-#pragma unroll
-        for (int l = 0; l < L; ++l) {
-            const int bits1 = (int)(packed[l] >> sh1) & 63;
-            const int drawn = pick<A>(pol1[l], u[l][1]);
-            const int a1 = draw1[l] ? drawn : (go[l] ? bits1 & 7 : 0);
-            acts[l] |= (unsigned long long)a1 << (3 * (t + 1));
-            const Trans *e = trans + (((int64_t)state[l] * A + a0[l]) * A + a1) * C;
-            int which = 0;
-            if (C > 1) {
-                if (draw1[l]) {
-                    float ch[RNAD_MAX_TRANSITIONS];
-#pragma unroll
-                    for (int k = 0; k < RNAD_MAX_TRANSITIONS; ++k) ch[k] = k < C ? e[k].chance : 0.0f;
-                    which = pick_n<RNAD_MAX_TRANSITIONS>(C, ch, u[l][2]);
-                } else if (go[l]) {
-                    which = bits1 >> 3;
-                }
-            }
-            const Trans best = e[which];
-            if (go[l]) {
-                if (best.next == 0) reward_final[l] = best.value;  // rewards *= (indices == 0): only the step into state 0 pays
-                state[l] = best.next;
-            }
-        }
-    }
-    int alive_end = 0;
-#pragma unroll
-    for (int l = 0; l < L; ++l) {
-        const int64_t j = j0 + (int64_t)l * kThreads;
-        if (active[l]) {
-            acts_out[j] = acts[l];
-            reward_out[j] = reward_final[l];
-            indices[(int64_t)T_cap * B + j] = state[l];
-        }
-        alive_end += (int)__popcll(__ballot(state[l] != 0));
-    }
-    if ((threadIdx.x & 63) == 0) cnt[wave][T_cap] = alive_end;
-    __syncthreads();
-    if ((int)threadIdx.x <= T_cap) {  // alive_part has a row per kThreads lanes: this block's sums in its first row, zeros in the others
-        int32_t sum = 0;
-#pragma unroll
-        for (int w = 0; w < kThreads / 64; ++w) sum += cnt[w][threadIdx.x];
-        const int64_t rows = (B + kThreads - 1) / kThreads;
-#pragma unroll
-        for (int l = 0; l < L; ++l) {
-            const int64_t row = (int64_t)blockIdx.x * L + l;
-            if (row < rows) alive_part[row * (T_cap + 1) + threadIdx.x] = l == 0 ? sum : 0;
-        }
-    }
-}
-
-// The compact rollout, one workgroup per work item (the learner's list: <= chunk lanes of one bucket).  Every lane of a bucket that
-// is ONE subtree took the same path to its root (ids are DFS pre-order: a state has exactly one parent entry), so the steps above
-// the cut are played once per workgroup from the first lane's decision word -- uniform values, scalar loads -- instead of a random
-// 8-byte gather (128 B of fabric traffic) and a replay per lane; below the cut every lane draws for itself as in
-// k_bucket_rollout_compact.  Same draws, same arithmetic, same outputs.  Workgroups beyond the item count leave zero alive counts.
+// The COMPACT rollout: the trajectory as 32 bytes per lane instead of 25 per slot.  A lane of bucket b sits in path_states[b][t] at
+// every step t < n_shared(b) -- above its group, and at the root of a group that is one subtree -- so nothing is stored for those
+// steps; below, a state is bucket_lo[b] + (0 .. rows - 1): one byte (REL = uint8_t while the cut's tables have <= 255 rows, else
+// uint16_t), `state - bucket_lo + 1`, 0 = absorbed.  states [T_cap + 1, B] of REL (rows t < n_shared of a column are never written nor
+// read), the lane's actions packed 3 bits per step (acts_out) and the one non-zero reward of the episode (rewards *= (indices == 0),
+// episode.py:120-121: only the transition into state 0 pays; reward_out).  Everything else of a slot is a function of (t & 1, state)
+// and the actor's table (k_bucket_indices / k_bucket_expand write the dense buffers on demand).
+//
+// One workgroup per work item (the learner's list: <= chunk lanes of one bucket).  Every lane of a bucket that is ONE subtree took the
+// same path to its root (ids are DFS pre-order: a state has exactly one parent entry), so the steps above the cut are played once per
+// workgroup from the first lane's decision word -- uniform values, scalar loads -- instead of a random 8-byte gather (128 B of fabric
+// traffic) and a replay per lane; below the cut every lane draws for itself.  One TRANSITION (the row player's step and the column
+// player's step in the same state) per iteration: both policy rows of the state are requested together and the transition's uniforms
+// are computed while they travel, so a transition costs two dependent memory latencies (policy rows, transition record) instead of
+// three.  Same draws (keyed by lane and step), same episodes as k_bucket_rollout.  An absorbed lane stops: no draws, no table reads.
+// Workgroups beyond the item count leave zero alive counts.
 // (Staging the group's transition records and policy rows in LDS for the drawn steps was measured: 42.0 us against 36.3 without --
 // 12.7 KB of copies per 256 lanes cost more than the gathers they replace.)
-template <int A>
+// base + a 32-bit BYTE offset: the form the compiler turns into `global_load ... v_off, s[base:base+1]` (no 64-bit VALU address
+// arithmetic); every table of the pipeline is smaller than 4 GB
+template <typename T>
+__device__ __forceinline__ const T *at_bytes(const void *base, uint32_t byte_offset) {
+    return reinterpret_cast<const T *>(reinterpret_cast<const char *>(base) + byte_offset);
+}
+template <typename T>
+__device__ __forceinline__ T *at_bytes(void *base, uint32_t byte_offset) {
+    return reinterpret_cast<T *>(reinterpret_cast<char *>(base) + byte_offset);
+}
+
+template <typename REL>
+__device__ __forceinline__ REL rel_of(int state, int lo) {
+    return (REL)(state == 0 ? 0 : state - lo + 1);
+}
+
+template <int A, typename REL>
 __global__ __launch_bounds__(kThreads) void k_bucket_rollout_items(const Trans *__restrict__ trans, int C, int64_t S, int64_t B, int T_cap,
                                                                    const float *__restrict__ policy_tab, int64_t tab_stride, int vec4,
                                                                    uint64_t seed, const rnad_step_params_t *__restrict__ sp, int64_t lane0,
                                                                    const int32_t *__restrict__ lane_ids,
                                                                    const unsigned long long *__restrict__ decisions,
                                                                    const Item *__restrict__ items, const int32_t *__restrict__ n_items,
-                                                                   const int32_t *__restrict__ bucket_path, int n_groups,
-                                                                   int32_t *__restrict__ indices, int32_t *__restrict__ alive_part,
+                                                                   const int32_t *__restrict__ bucket_path, const int32_t *__restrict__ bucket_lo,
+                                                                   const int32_t *__restrict__ path_states, int path_stride, int n_groups,
+                                                                   REL *__restrict__ states, int32_t *__restrict__ alive_part,
                                                                    unsigned long long *__restrict__ acts_out,
                                                                    float *__restrict__ reward_out, int32_t *__restrict__ visited) {
     __shared__ int32_t cnt[kThreads / 64][kMaxSteps + 1];
@@ -1065,95 +999,158 @@ __global__ __launch_bounds__(kThreads) void k_bucket_rollout_items(const Trans *
     }
     const Item item = items[blockIdx.x];
     if (sp) seed = sp->seed;
-    const bool active = (int)threadIdx.x < item.count;
-    const int64_t j = (int64_t)item.begin + threadIdx.x;
-    const int32_t lane_local = active ? lane_ids[j] : 0;
-    const uint64_t lane = (uint64_t)(lane0 + lane_local);
     const int wave = threadIdx.x >> 6;
-    const bool shared = item.bucket < n_groups && (bucket_path[item.bucket] & kSharedRoot) != 0;
-    unsigned long long packed;  // the first decisions, drawn by k_bucket_keys: of the bucket (shared) or of this lane
-    if (shared) {
-        const unsigned long long first = decisions[lane_ids[item.begin]];
-        packed = ((unsigned long long)(unsigned int)__builtin_amdgcn_readfirstlane((int)(first >> 32)) << 32) |
-                 (unsigned int)__builtin_amdgcn_readfirstlane((int)first);
-    } else {
-        packed = active ? decisions[lane_local] : 0ull;
-    }
-    const int n_packed = (int)(packed >> 60);
-    int state = active ? 1 : 0, t_from = 0;
-    unsigned long long acts = 0ull;
-    float reward_final = 0.0f;
-    if (shared) {  // the transitions above the cut, once for the workgroup
-        const int n_pre = min(n_packed, T_cap) & ~1;
-        const int32_t live_now = (int32_t)__popcll(__ballot(active));
-        int at = 1;
-        for (int t = 0; t < n_pre; t += 2) {
-            if ((threadIdx.x & 63) == 0) cnt[wave][t] = cnt[wave][t + 1] = live_now;
-            const int bits0 = (int)(packed >> (6 * t)) & 63, bits1 = (int)(packed >> (6 * (t + 1))) & 63;
-            if (active) {
-                const int64_t i = (int64_t)t * B + j;
-                indices[i] = at;
-                indices[i + B] = at;
+    const int path_word = bucket_path[item.bucket];
+    const bool shared = item.bucket < n_groups && (path_word & kSharedRoot) != 0;
+    const int n_shared = (path_word & (kSharedRoot - 1)) + (shared ? 2 : 0);  // steps whose state is the bucket's, not the lane's
+    const int lo = bucket_lo[item.bucket];
+    const int32_t *my_path = path_states + (int64_t)item.bucket * path_stride;
+    const uint32_t B32 = (uint32_t)B;
+    if ((threadIdx.x & 63) == 0)
+        for (int t = 0; t <= T_cap; ++t) cnt[wave][t] = 0;
+    for (int base = 0; base < item.count; base += kThreads) {  // (one pass: an item holds <= chunk = kThreads lanes unless RNAD_BUCKET_CHUNK says otherwise)
+        const bool active = base + (int)threadIdx.x < item.count;
+        const uint32_t j = (uint32_t)(item.begin + base) + threadIdx.x;
+        const int32_t lane_local = active ? lane_ids[j] : 0;
+        const uint64_t lane = (uint64_t)(lane0 + lane_local);
+        unsigned long long packed;  // the first decisions, drawn by k_bucket_keys: of the bucket (shared) or of this lane
+        if (shared) {
+            const unsigned long long first = decisions[lane_ids[item.begin]];
+            packed = ((unsigned long long)(unsigned int)__builtin_amdgcn_readfirstlane((int)(first >> 32)) << 32) |
+                     (unsigned int)__builtin_amdgcn_readfirstlane((int)first);
+        } else {
+            packed = active ? decisions[lane_local] : 0ull;
+        }
+        const int n_packed = (int)(packed >> 60);
+        int state = active ? 1 : 0, t_from = 0;
+        unsigned long long acts = 0ull;
+        float reward_final = 0.0f;
+        if (shared) {  // the transitions above the cut, once for the workgroup: the states are the bucket's path, the actions the first lane's
+            const int n_pre = min(min(n_packed, T_cap) & ~1, n_shared - 2);
+            const int32_t live_now = (int32_t)__popcll(__ballot(active));
+            for (int t = 0; t < n_pre; t += 2) {
+                if ((threadIdx.x & 63) == 0) {
+                    cnt[wave][t] += live_now;
+                    cnt[wave][t + 1] += live_now;
+                }
+                const int bits0 = (int)(packed >> (6 * t)) & 63, bits1 = (int)(packed >> (6 * (t + 1))) & 63;
+                if (visited && threadIdx.x == 0 && base == 0) {
+                    const int at = my_path[t];
+                    visited[at] = visited[S + at] = 1;
+                }
+                acts |= (unsigned long long)(bits0 & 7) << (3 * t) | (unsigned long long)(bits1 & 7) << (3 * (t + 1));
             }
-            if (visited && threadIdx.x == 0) visited[at] = visited[S + at] = 1;
-            acts |= (unsigned long long)(bits0 & 7) << (3 * t) | (unsigned long long)(bits1 & 7) << (3 * (t + 1));
-            at = trans[(((int64_t)at * A + (bits0 & 7)) * A + (bits1 & 7)) * C + (bits1 >> 3)].next;  // (never 0: it leads to the group)
+            t_from = n_pre;
+            state = active ? my_path[n_pre] : 0;  // (n_pre <= n_path: an upper state of the path, or the group's root)
         }
-        t_from = n_pre;
-        state = active ? at : 0;
-    }
-    for (int t = t_from; t < T_cap; t += 2) {
-        const bool two = t + 1 < T_cap;  // (an odd T_cap ends with a row step alone)
+        for (int t = t_from; t < T_cap; t += 2) {
+            const bool two = t + 1 < T_cap;  // (an odd T_cap ends with a row step alone)
+            const uint64_t live = __ballot(state != 0);
+            if ((threadIdx.x & 63) == 0) {
+                cnt[wave][t] += (int32_t)__popcll(live);
+                if (two) cnt[wave][t + 1] += (int32_t)__popcll(live);  // the row player's step leaves the state as it is
+            }
+            if (!active) continue;
+            if (t >= n_shared) {  // (n_shared is even: both steps of the transition, or neither)
+                const REL r = rel_of<REL>(state, lo);
+                *at_bytes<REL>(states, ((uint32_t)t * B32 + j) * (uint32_t)sizeof(REL)) = r;
+                if (two) *at_bytes<REL>(states, ((uint32_t)(t + 1) * B32 + j) * (uint32_t)sizeof(REL)) = r;
+            }
+            if (state == 0) continue;
+            const bool replay0 = t < n_packed, replay1 = t + 1 < n_packed;
+            const int64_t row0 = state, row1 = S + state;
+            if (visited) {
+                visited[row0] = 1;  // (every writer stores the same value)
+                if (two) visited[row1] = 1;
+            }
+            float pol0[A], pol1[A], u[3];
+            if (!replay0) load_policy_row<A>(policy_tab, row0, tab_stride, vec4 != 0, pol0);
+            if (two && !replay1) load_policy_row<A>(policy_tab, row1, tab_stride, vec4 != 0, pol1);
+            if (!replay0 || (two && !replay1)) rnad_decision_uniforms(seed, lane, (uint32_t)t, u);  // computed while the rows travel
+            const int bits0 = replay0 ? (int)(packed >> (6 * t)) & 63 : 0, bits1 = replay1 ? (int)(packed >> (6 * (t + 1))) & 63 : 0;
+            const int a0 = replay0 ? (bits0 & 7) : pick<A>(pol0, u[0]);
+            acts |= (unsigned long long)a0 << (3 * t);
+            if (!two) continue;
+            const int a1 = replay1 ? (bits1 & 7) : pick<A>(pol1, u[1]);
+            acts |= (unsigned long long)a1 << (3 * (t + 1));
+            int next;
+            float rew;
+            if (replay1)
+                transition_apply<A>(trans, C, state, a0, a1, bits1 >> 3, next, rew);
+            else
+                transition_lane<A>(trans, C, state, a0, a1, nullptr, u[2], next, rew);
+            if (next == 0) reward_final = rew;
+            state = next;
+        }
+        if (active) {
+            acts_out[j] = acts;
+            reward_out[j] = reward_final;
+            if (T_cap >= n_shared) *at_bytes<REL>(states, ((uint32_t)T_cap * B32 + j) * (uint32_t)sizeof(REL)) = rel_of<REL>(state, lo);
+        }
         const uint64_t live = __ballot(state != 0);
-        if ((threadIdx.x & 63) == 0) {
-            cnt[wave][t] = (int32_t)__popcll(live);
-            if (two) cnt[wave][t + 1] = (int32_t)__popcll(live);  // the row player's step leaves the state as it is
-        }
-        if (!active) continue;
-        const int64_t i = (int64_t)t * B + j;
-        // (non-temporal stores here were measured: the rollout 48.0 -> 46.8 us, but the learner, which reads these columns next, 73.4 ->
-        // 75.2: the L2 / MALL copy they leave behind is worth more than the write-allocate they cost)
-        indices[i] = state;
-        if (two) indices[i + B] = state;
-        if (state == 0) continue;
-        const bool replay0 = t < n_packed, replay1 = t + 1 < n_packed;
-        const int64_t row0 = state, row1 = S + state;
-        if (visited) {
-            visited[row0] = 1;  // (every writer stores the same value)
-            if (two) visited[row1] = 1;
-        }
-        float pol0[A], pol1[A], u[3];
-        if (!replay0) load_policy_row<A>(policy_tab, row0, tab_stride, vec4 != 0, pol0);
-        if (two && !replay1) load_policy_row<A>(policy_tab, row1, tab_stride, vec4 != 0, pol1);
-        if (!replay0 || (two && !replay1)) rnad_decision_uniforms(seed, lane, (uint32_t)t, u);  // computed while the rows travel
-        const int bits0 = replay0 ? (int)(packed >> (6 * t)) & 63 : 0, bits1 = replay1 ? (int)(packed >> (6 * (t + 1))) & 63 : 0;
-        const int a0 = replay0 ? (bits0 & 7) : pick<A>(pol0, u[0]);
-        acts |= (unsigned long long)a0 << (3 * t);
-        if (!two) continue;
-        const int a1 = replay1 ? (bits1 & 7) : pick<A>(pol1, u[1]);
-        acts |= (unsigned long long)a1 << (3 * (t + 1));
-        int next;
-        float rew;
-        if (replay1)
-            transition_apply<A>(trans, C, state, a0, a1, bits1 >> 3, next, rew);
-        else
-            transition_lane<A>(trans, C, state, a0, a1, nullptr, u[2], next, rew);
-        if (next == 0) reward_final = rew;
-        state = next;
+        if ((threadIdx.x & 63) == 0) cnt[wave][T_cap] += (int32_t)__popcll(live);
     }
-    if (active) {
-        acts_out[j] = acts;
-        reward_out[j] = reward_final;
-        indices[(int64_t)T_cap * B + j] = state;
-    }
-    const uint64_t live = __ballot(state != 0);
-    if ((threadIdx.x & 63) == 0) cnt[wave][T_cap] = (int32_t)__popcll(live);
     __syncthreads();
     if ((int)threadIdx.x <= T_cap) {
         int32_t sum = 0;
 #pragma unroll
         for (int w = 0; w < kThreads / 64; ++w) sum += cnt[w][threadIdx.x];
         my_alive[threadIdx.x] = sum;
+    }
+}
+
+// states (relative, bucket-ordered) <-> indices int32 [T1, B]: one workgroup per work item.
+//   k_bucket_indices: what Episodes.indices / rnad_bucket_expand read of a compact trajectory;
+//   k_bucket_pack: a recorded (or dense) bucket-ordered trajectory into the compact layout.
+template <typename REL>
+__global__ __launch_bounds__(kThreads) void k_bucket_indices(int T1, int64_t B, const Item *__restrict__ items, const int32_t *__restrict__ n_items,
+                                                             const int32_t *__restrict__ bucket_path, const int32_t *__restrict__ bucket_lo,
+                                                             const int32_t *__restrict__ path_states, int path_stride, int n_groups,
+                                                             const REL *__restrict__ states, int32_t *__restrict__ indices) {
+    if ((int)blockIdx.x >= *n_items) return;
+    const Item item = items[blockIdx.x];
+    const int path_word = bucket_path[item.bucket];
+    const int n_shared = (path_word & (kSharedRoot - 1)) + ((item.bucket < n_groups && (path_word & kSharedRoot)) ? 2 : 0);
+    const int lo = bucket_lo[item.bucket];
+    const int32_t *my_path = path_states + (int64_t)item.bucket * path_stride;
+    for (int k = threadIdx.x; k < item.count; k += kThreads) {
+        const int64_t j = (int64_t)item.begin + k;
+        for (int t = 0; t < T1; ++t) {
+            int state;
+            if (t < n_shared) {
+                state = my_path[t];
+            } else {
+                const int r = (int)states[(int64_t)t * B + j];
+                state = r == 0 ? 0 : lo + r - 1;
+            }
+            indices[(int64_t)t * B + j] = state;
+        }
+    }
+}
+
+template <typename REL>
+__global__ __launch_bounds__(kThreads) void k_bucket_pack(int T1, int64_t B, int rows, const Item *__restrict__ items, const int32_t *__restrict__ n_items,
+                                                          const int32_t *__restrict__ bucket_path, const int32_t *__restrict__ bucket_lo,
+                                                          const int32_t *__restrict__ path_states, int path_stride, int n_groups,
+                                                          const int32_t *__restrict__ indices, REL *__restrict__ states,
+                                                          int32_t *__restrict__ bad) {
+    if ((int)blockIdx.x >= *n_items) return;
+    const Item item = items[blockIdx.x];
+    const int path_word = bucket_path[item.bucket];
+    const int n_shared = (path_word & (kSharedRoot - 1)) + ((item.bucket < n_groups && (path_word & kSharedRoot)) ? 2 : 0);
+    const int lo = bucket_lo[item.bucket];
+    const int32_t *my_path = path_states + (int64_t)item.bucket * path_stride;
+    for (int k = threadIdx.x; k < item.count; k += kThreads) {
+        const int64_t j = (int64_t)item.begin + k;
+        for (int t = 0; t < T1; ++t) {
+            const int state = indices[(int64_t)t * B + j];
+            if (t < n_shared) {
+                if (state != my_path[t]) *bad = 1;  // (this column is not a lane of this bucket)
+            } else {
+                if (state != 0 && (state < lo || state - lo >= rows)) *bad = 1;
+                states[(int64_t)t * B + j] = rel_of<REL>(state, lo);
+            }
+        }
     }
 }
 
@@ -1288,171 +1285,28 @@ __device__ __forceinline__ void fast_slot(const float *__restrict__ f, const flo
 // same states down to the bucket state -- with the per-slot gradients added up per (player, state) row instead of being written:
 //   rows at steps t < n_path (above the bucket): one row per step for the whole workgroup -> kPathSlots LDS copies of it, lane l adds
 //   into copy l & 15;
-//   rows below: LDS table indexed by (state - bucket state), both players.
+//   rows below: LDS table indexed by (state - bucket state), both players, kTabStride<A> words apart (odd: the rows of 16 lanes fall
+//   into distinct banks -- with 4-word rows 61 % of the LDS cycles of this kernel were bank conflicts, profiles/r04_pmc_lds.txt).
 // Addends are the UN-normalised gradients  G_l[a] = -(w - legal * sum(w) / A)  and  G_v = 2 (v - v_target)  in 64-bit fixed
 // point; k_bucket_finish applies w_n / N_P and w_v / N_P (the reference scales every slot by them: vtrace.py:374,389 and
 // rnad.py:424; summing first changes the rounding of the last bit only).  losses_raw[4] += sum d^2 (P = 0, 1), sum -nerd (P = 0, 1).
 //
-// COMPACT: the trajectory of k_bucket_rollout<A, true> -- indices [T + 1, B], the lane's packed actions and its one reward -- played
-// with the pi columns of the records as the actor (on-policy: mu == pi, the very floats the rollout sampled from).  rec_ then
-// points at the FAST records (k_row_records): whatever of vtrace_step / nerd_row has row-only operands arrives precomputed, and a
-// slot is left with the carries, the value target, q, the advantage and one division -- the same operations on the same operands as
-// the dense variant, hence the same sums.  LOSSES (COMPACT only; the dense variant always adds them up): loss_v / loss_nerd sums
-// for a logging step, which need the logits of the dense record (logit_).
-template <int A, bool COMPACT, bool LOSSES>
-__global__ __launch_bounds__(kThreads) void k_bucket_learn(int T, int64_t B, int64_t S, int sub_rows, int path_words, int n_groups, int up_stride,
-                                                           const Item *__restrict__ items, const int32_t *__restrict__ n_items,
-                                                           const int32_t *__restrict__ bucket_of, const int32_t *__restrict__ bucket_lo,
-                                                           const int32_t *__restrict__ bucket_path, const int32_t *__restrict__ indices,
-                                                           const int32_t *__restrict__ actions, const float *__restrict__ rewards,
-                                                           const float *__restrict__ mu_, const float *__restrict__ rec_,
-                                                           const unsigned long long *__restrict__ acts_,
-                                                           const float *__restrict__ reward_, const float *__restrict__ logit_,
-                                                           rnad_learn_params_t hp, FixedPoint fx, unsigned long long *__restrict__ acc,
-                                                           unsigned long long *__restrict__ rep, double *__restrict__ losses_raw,
-                                                           int32_t *__restrict__ overflow, const int32_t *__restrict__ alive_part,
-                                                           int alive_blocks, int T1, int32_t *__restrict__ alive,
-                                                           double *__restrict__ norm_out) {
-    // [kMaxPath path rows][kPathSlots copies][(A + 1) | 1]  |  [sub_rows rows of player 0 | sub_rows rows of player 1][A + 1]
-    extern __shared__ unsigned long long tab[];
-    constexpr int PS = (A + 1) | 1;
-    const int kPathWords = path_words;  // u64 words of the path region: max_path rows of the cut x kPathSlots copies
-    __shared__ int32_t path_state[kMaxPath];
-    __shared__ double loss_part[kThreads / 64][4];
-    // The rollout left its per-workgroup alive counts un-summed (rnad_rollout_bucketed_compact with alive == NULL): workgroup t < T1
-    // adds up column t first -- k_bucket_alive's work without its launch; the normalisers are read by k_bucket_finish, after this kernel.
-    if (alive_part && (int)blockIdx.x < T1) alive_column(alive_blocks, T1, blockIdx.x, alive_part, alive, norm_out);
-    if ((int)blockIdx.x >= *n_items) return;
-    const Item item = items[blockIdx.x];
-    const int s_b = bucket_lo[item.bucket];        // first state id of the group (terminal buckets: the upper state; no rows below)
-    const int n_path = bucket_path[item.bucket] & (kSharedRoot - 1);  // env steps above the group: upper states shared by every lane of the bucket
-    // ... and, when the group is a single subtree, the two steps at its root: all lanes of the item add into the same two rows
-    // (64-way same-address LDS atomics otherwise), so those take copies in the path region too and are folded into the table at the end
-    const int n_shared = n_path + ((bucket_path[item.bucket] & kSharedRoot) ? 2 : 0);
-    constexpr int RS = kRowStride<A>;
-    const int n_tab = item.bucket < n_groups ? kPathWords + 2 * sub_rows * (A + 1) : n_path * kPathSlots * PS;
-    for (int i = threadIdx.x; i < n_tab; i += kThreads) tab[i] = 0ull;
-    __syncthreads();
-    const VtHp vh{-hp.eta, hp.lambda_, hp.c, hp.rho, hp.gamma};
-    double part[4] = {0.0, 0.0, 0.0, 0.0};
-    bool ovf = false;
-    for (int base = 0; base < item.count; base += kThreads) {
-        const bool active = base + (int)threadIdx.x < item.count;
-        const int64_t j = (int64_t)item.begin + base + threadIdx.x;
-        Carry cy[2];
-        // Software pipeline over the time loop: the states of step t - 2 and the slot's inputs of step t - 1 (action, acting policy,
-        // reward, the row record -- whose address needs that step's state) are requested before the arithmetic of step t, so the
-        // two dependent memory latencies of a step (state -> record) overlap the V-trace / NeuRD arithmetic of its successors.
-        constexpr int kFetch = COMPACT ? kFastStride<A> : kRowLearn<A>;  // floats of a record this variant reads
-        constexpr int kRecStride_ = COMPACT ? kFastStride<A> : RS;
-        struct Slot {
-            int act;
-            float rew;
-            float mu[A];
-            float rec[kFetch];
-            float lg[A];  // LOSSES: the row's logits
-        };
-        auto fetch = [&](int t, int state, Slot &o) {
-            if (state == 0) return;
-            const int64_t i = (int64_t)t * B + j;
-            const int64_t row = (int64_t)(t & 1) * S + state;
-            const float4 *rp = reinterpret_cast<const float4 *>(rec_ + row * kRecStride_);
-#pragma unroll
-            for (int u = 0; u < kFetch / 4; ++u) {
-                const float4 r4 = rp[u];
-                o.rec[4 * u] = r4.x; o.rec[4 * u + 1] = r4.y; o.rec[4 * u + 2] = r4.z; o.rec[4 * u + 3] = r4.w;
-            }
-            if (COMPACT && LOSSES) {
-#pragma unroll
-                for (int a = 0; a < A; ++a) o.lg[a] = logit_[row * RS + a];
-            }
-            if (!COMPACT) {
-                o.act = actions[i];
-#pragma unroll
-                for (int a = 0; a < A; ++a) o.mu[a] = mu_[i * A + a];
-                o.rew = (t & 1) ? rewards[i] : 0.0f;  // row turns carry torch.zeros (episode.py:101)
-            }
-        };
-        const unsigned long long acts = (COMPACT && active) ? acts_[j] : 0ull;
-        const float reward_final = (COMPACT && active) ? reward_[j] : 0.0f;
-        int s_after = (COMPACT && active) ? indices[(int64_t)T * B + j] : 0;  // the state the slot's step led to
-        int s_next = active ? indices[(int64_t)(T - 1) * B + j] : 0;
-        int s_next2 = (active && T >= 2) ? indices[(int64_t)(T - 2) * B + j] : 0;
-        Slot nxt;
-        fetch(T - 1, s_next, nxt);
-        for (int t = T - 1; t >= 0; --t) {
-            const int state = s_next;
-            const Slot cur = nxt;
-            s_next = s_next2;
-            if (t >= 1) fetch(t - 1, s_next, nxt);
-            s_next2 = (active && t >= 2) ? indices[(int64_t)(t - 2) * B + j] : 0;
-            const bool valid = state != 0;  // rnad.py:369
-            const int P = t & 1;            // turns[t, :] (episode.py:96-98)
-            long long q[A + 1];
-#pragma unroll
-            for (int a = 0; a <= A; ++a) q[a] = 0;
-            if (valid) {
-                if constexpr (COMPACT) {
-                    const int act = (int)(acts >> (3 * t)) & 7;
-                    if (t & 1)  // uniform: the mover is a template parameter of the slot arithmetic
-                        fast_slot<A, LOSSES, 1>(cur.rec, cur.lg, act, s_after == 0 ? reward_final : 0.0f,  // rewards *= (indices == 0), episode.py:120-121
-                                                vh, hp, fx, cy, q, part, ovf);
-                    else
-                        fast_slot<A, LOSSES, 0>(cur.rec, cur.lg, act, 0.0f, vh, hp, fx, cy, q, part, ovf);  // row turns: torch.zeros (episode.py:101)
-                } else {
-                    const int act = cur.act;
-                    const float *rec = cur.rec;  // this row's record (k_row_records)
-                    const uint32_t bits = __float_as_uint(rec[3 * A + 2]);
-                    float mu[A], lg[A], pip[A], lpol[A], legal[A], oh[A];
-#pragma unroll
-                    for (int a = 0; a < A; ++a) {
-                        mu[a] = cur.mu[a];
-                        lg[a] = rec[a];
-                        pip[a] = rec[A + 2 + a];    // process_policy(pi) of the learner (rnad.py:374)
-                        lpol[a] = rec[2 * A + 2 + a];  // log_policy_reg (rnad.py:382)
-                        legal[a] = (float)((bits >> a) & 1);
-                        oh[a] = act == a ? 1.0f : 0.0f;
-                    }
-                    const float rew = cur.rew;
-                    const float vtn = rec[A + 1];
-                    float vt[2], qv[2][A];
-                    vtrace_step<A>(cy[0], vh, true, P == 0, 1.0f, vtn, rew, mu, pip, lpol, oh, vt[0], qv[0]);   // player 0 (rnad.py:384-406)
-                    vtrace_step<A>(cy[1], vh, true, P == 1, 1.0f, vtn, -rew, mu, pip, lpol, oh, vt[1], qv[1]);  // player 1: rewards = -r (:368)
-                    const float d = rec[A] - (P ? vt[1] : vt[0]);
-                    float qp[A], g[A];
-#pragma unroll
-                    for (int a = 0; a < A; ++a) qp[a] = P ? qv[1][a] : qv[0][a];
-                    const float nerd = nerd_row<A>(lg, pip, qp, legal, hp.clip, hp.threshold, g);
-                    part[P] += (double)(d * d);
-                    part[2 + P] += -(double)nerd;
-                    const float gv = 2.0f * d;
-                    ovf |= !(fabsf(gv) < fx.limit_v);
-                    q[A] = round_to_ll((double)gv * fx.scale_v);
-#pragma unroll
-                    for (int a = 0; a < A; ++a) {
-                        ovf |= !(fabsf(g[a]) < fx.limit_l);
-                        q[a] = round_to_ll((double)(-g[a]) * fx.scale_l);
-                    }
-                }
-            } else {
-                cy[0] = Carry{};  // reset_carry (vtrace.py:320)
-                cy[1] = Carry{};
-            }
-            s_after = state;
-            if (t < n_shared) {  // a step above the bucket state (or at a shared root): one row for the whole workgroup, kPathSlots copies of it in LDS
-                if (threadIdx.x == 0 && base == 0) path_state[t] = state;
-                if (valid) {
-                    unsigned long long *dst = tab + (t * kPathSlots + (threadIdx.x & (kPathSlots - 1))) * PS;
-#pragma unroll
-                    for (int a = 0; a <= A; ++a) atomicAdd(dst + a, (unsigned long long)q[a]);
-                }
-            } else if (valid) {
-                unsigned long long *dst = tab + kPathWords + ((int64_t)(P * sub_rows + (state - s_b))) * (A + 1);
-#pragma unroll
-                for (int a = 0; a <= A; ++a) atomicAdd(dst + a, (unsigned long long)q[a]);
-            }
-        }
-    }
+// Two kernels share the layout and the epilogue (learn_epilogue):
+//   k_bucket_learn<A>            the DENSE trajectory (indices, actions, rewards, acting policy per slot; off-policy batches too)
+//   k_bucket_learn_c<A, REL, L>  the COMPACT trajectory of k_bucket_rollout_items, on-policy (below)
+template <int A>
+constexpr int kTabStride = (A + 1) | 1;
+
+// What both learner kernels do once the time loops are over: loss sums, overflow flag, path rows -> a replica of the upper-row table,
+// shared root rows -> the table, the table -> acc (plain stores for a bucket's only item, atomics otherwise).
+template <int A>
+__device__ __forceinline__ void learn_epilogue(unsigned long long *__restrict__ tab, const int32_t *__restrict__ path_state, const Item &item,
+                                               int s_b, int n_path, int n_shared, int kPathWords, int sub_rows, int64_t S, int n_groups,
+                                               int up_stride, const int32_t *__restrict__ bucket_of, const double (&part)[4], bool ovf,
+                                               double (*loss_part)[4], unsigned long long *__restrict__ acc,
+                                               unsigned long long *__restrict__ rep, double *__restrict__ losses_raw,
+                                               int32_t *__restrict__ overflow) {
+    constexpr int PS = (A + 1) | 1, TS = kTabStride<A>;
     // losses (logging): four fp64 partial sums per block
     if (losses_raw) {
 #pragma unroll
@@ -1489,21 +1343,291 @@ __global__ __launch_bounds__(kThreads) void k_bucket_learn(int T, int64_t B, int
         unsigned long long x = 0ull;
 #pragma unroll
         for (int c = 0; c < kPathSlots; ++c) x += tab[(t * kPathSlots + c) * PS + a];
-        tab[kPathWords + ((int64_t)((t & 1) * sub_rows + (path_state[t] - s_b))) * (A + 1) + a] += x;
+        tab[kPathWords + ((t & 1) * sub_rows + (path_state[t] - s_b)) * TS + a] += x;
     }
     __syncthreads();
-    const int64_t end = S - s_b < sub_rows ? S - s_b : sub_rows;
+    const int end = (int)(S - s_b < sub_rows ? S - s_b : sub_rows);
     for (int e = threadIdx.x; e < 2 * sub_rows * (A + 1); e += kThreads) {
-        const unsigned long long x = tab[kPathWords + e];
-        if (x != 0ull) {
-            const int P = e / (sub_rows * (A + 1)), r = e % (sub_rows * (A + 1));
-            if (r / (A + 1) < end) {
-                unsigned long long *dst = acc + ((int64_t)P * S + s_b) * (A + 1) + r;
-                if (item.single) *dst = x;
-                else atomicAdd(dst, x);
+        const int P = e / (sub_rows * (A + 1)), r = e % (sub_rows * (A + 1)), row = r / (A + 1), a = r % (A + 1);
+        const unsigned long long x = tab[kPathWords + (P * sub_rows + row) * TS + a];
+        if (x != 0ull && row < end) {
+            unsigned long long *dst = acc + ((int64_t)P * S + s_b) * (A + 1) + r;
+            if (item.single) *dst = x;
+            else atomicAdd(dst, x);
+        }
+    }
+}
+
+template <int A>
+__global__ __launch_bounds__(kThreads) void k_bucket_learn(int T, int64_t B, int64_t S, int sub_rows, int path_words, int n_groups, int up_stride,
+                                                           const Item *__restrict__ items, const int32_t *__restrict__ n_items,
+                                                           const int32_t *__restrict__ bucket_of, const int32_t *__restrict__ bucket_lo,
+                                                           const int32_t *__restrict__ bucket_path, const int32_t *__restrict__ indices,
+                                                           const int32_t *__restrict__ actions, const float *__restrict__ rewards,
+                                                           const float *__restrict__ mu_, const float *__restrict__ rec_,
+                                                           rnad_learn_params_t hp, FixedPoint fx, unsigned long long *__restrict__ acc,
+                                                           unsigned long long *__restrict__ rep, double *__restrict__ losses_raw,
+                                                           int32_t *__restrict__ overflow) {
+    // [max_path path rows][kPathSlots copies][(A + 1) | 1]  |  [sub_rows rows of player 0 | sub_rows rows of player 1][kTabStride<A>]
+    extern __shared__ unsigned long long tab[];
+    constexpr int PS = (A + 1) | 1, TS = kTabStride<A>;
+    const int kPathWords = path_words;  // u64 words of the path region: max_path rows of the cut x kPathSlots copies
+    __shared__ int32_t path_state[kMaxPath];
+    __shared__ double loss_part[kThreads / 64][4];
+    if ((int)blockIdx.x >= *n_items) return;
+    const Item item = items[blockIdx.x];
+    const int s_b = bucket_lo[item.bucket];        // first state id of the group (terminal buckets: the upper state; no rows below)
+    const int n_path = bucket_path[item.bucket] & (kSharedRoot - 1);  // env steps above the group: upper states shared by every lane of the bucket
+    // ... and, when the group is a single subtree, the two steps at its root: all lanes of the item add into the same two rows
+    // (64-way same-address LDS atomics otherwise), so those take copies in the path region too and are folded into the table at the end
+    const int n_shared = n_path + ((bucket_path[item.bucket] & kSharedRoot) ? 2 : 0);
+    constexpr int RS = kRowStride<A>;
+    const int n_tab = item.bucket < n_groups ? kPathWords + 2 * sub_rows * TS : n_path * kPathSlots * PS;
+    for (int i = threadIdx.x; i < n_tab; i += kThreads) tab[i] = 0ull;
+    __syncthreads();
+    const VtHp vh{-hp.eta, hp.lambda_, hp.c, hp.rho, hp.gamma};
+    double part[4] = {0.0, 0.0, 0.0, 0.0};
+    bool ovf = false;
+    for (int base = 0; base < item.count; base += kThreads) {
+        const bool active = base + (int)threadIdx.x < item.count;
+        const int64_t j = (int64_t)item.begin + base + threadIdx.x;
+        Carry cy[2];
+        // Software pipeline over the time loop: the states of step t - 2 and the slot's inputs of step t - 1 (action, acting policy,
+        // reward, the row record -- whose address needs that step's state) are requested before the arithmetic of step t, so the
+        // two dependent memory latencies of a step (state -> record) overlap the V-trace / NeuRD arithmetic of its successors.
+        constexpr int kFetch = kRowLearn<A>;  // floats of a record this kernel reads
+        struct Slot {
+            int act;
+            float rew;
+            float mu[A];
+            float rec[kFetch];
+        };
+        auto fetch = [&](int t, int state, Slot &o) {
+            if (state == 0) return;
+            const int64_t i = (int64_t)t * B + j;
+            const int64_t row = (int64_t)(t & 1) * S + state;
+            const float4 *rp = reinterpret_cast<const float4 *>(rec_ + row * RS);
+#pragma unroll
+            for (int u = 0; u < kFetch / 4; ++u) {
+                const float4 r4 = rp[u];
+                o.rec[4 * u] = r4.x; o.rec[4 * u + 1] = r4.y; o.rec[4 * u + 2] = r4.z; o.rec[4 * u + 3] = r4.w;
+            }
+            o.act = actions[i];
+#pragma unroll
+            for (int a = 0; a < A; ++a) o.mu[a] = mu_[i * A + a];
+            o.rew = (t & 1) ? rewards[i] : 0.0f;  // row turns carry torch.zeros (episode.py:101)
+        };
+        int s_next = active ? indices[(int64_t)(T - 1) * B + j] : 0;
+        int s_next2 = (active && T >= 2) ? indices[(int64_t)(T - 2) * B + j] : 0;
+        Slot nxt;
+        fetch(T - 1, s_next, nxt);
+        for (int t = T - 1; t >= 0; --t) {
+            const int state = s_next;
+            const Slot cur = nxt;
+            s_next = s_next2;
+            if (t >= 1) fetch(t - 1, s_next, nxt);
+            s_next2 = (active && t >= 2) ? indices[(int64_t)(t - 2) * B + j] : 0;
+            const bool valid = state != 0;  // rnad.py:369
+            const int P = t & 1;            // turns[t, :] (episode.py:96-98)
+            long long q[A + 1];
+#pragma unroll
+            for (int a = 0; a <= A; ++a) q[a] = 0;
+            if (valid) {
+                const int act = cur.act;
+                const float *rec = cur.rec;  // this row's record (k_row_records)
+                const uint32_t bits = __float_as_uint(rec[3 * A + 2]);
+                float mu[A], lg[A], pip[A], lpol[A], legal[A], oh[A];
+#pragma unroll
+                for (int a = 0; a < A; ++a) {
+                    mu[a] = cur.mu[a];
+                    lg[a] = rec[a];
+                    pip[a] = rec[A + 2 + a];    // process_policy(pi) of the learner (rnad.py:374)
+                    lpol[a] = rec[2 * A + 2 + a];  // log_policy_reg (rnad.py:382)
+                    legal[a] = (float)((bits >> a) & 1);
+                    oh[a] = act == a ? 1.0f : 0.0f;
+                }
+                const float rew = cur.rew;
+                const float vtn = rec[A + 1];
+                float vt[2], qv[2][A];
+                vtrace_step<A>(cy[0], vh, true, P == 0, 1.0f, vtn, rew, mu, pip, lpol, oh, vt[0], qv[0]);   // player 0 (rnad.py:384-406)
+                vtrace_step<A>(cy[1], vh, true, P == 1, 1.0f, vtn, -rew, mu, pip, lpol, oh, vt[1], qv[1]);  // player 1: rewards = -r (:368)
+                const float d = rec[A] - (P ? vt[1] : vt[0]);
+                float qp[A], g[A];
+#pragma unroll
+                for (int a = 0; a < A; ++a) qp[a] = P ? qv[1][a] : qv[0][a];
+                const float nerd = nerd_row<A>(lg, pip, qp, legal, hp.clip, hp.threshold, g);
+                part[P] += (double)(d * d);
+                part[2 + P] += -(double)nerd;
+                const float gv = 2.0f * d;
+                ovf |= !(fabsf(gv) < fx.limit_v);
+                q[A] = round_to_ll((double)gv * fx.scale_v);
+#pragma unroll
+                for (int a = 0; a < A; ++a) {
+                    ovf |= !(fabsf(g[a]) < fx.limit_l);
+                    q[a] = round_to_ll((double)(-g[a]) * fx.scale_l);
+                }
+            } else {
+                cy[0] = Carry{};  // reset_carry (vtrace.py:320)
+                cy[1] = Carry{};
+            }
+            if (t < n_shared) {  // a step above the bucket state (or at a shared root): one row for the whole workgroup, kPathSlots copies of it in LDS
+                if (threadIdx.x == 0 && base == 0) path_state[t] = state;
+                if (valid) {
+                    unsigned long long *dst = tab + (t * kPathSlots + (threadIdx.x & (kPathSlots - 1))) * PS;
+#pragma unroll
+                    for (int a = 0; a <= A; ++a) atomicAdd(dst + a, (unsigned long long)q[a]);
+                }
+            } else if (valid) {
+                unsigned long long *dst = tab + kPathWords + (P * sub_rows + (state - s_b)) * TS;
+#pragma unroll
+                for (int a = 0; a <= A; ++a) atomicAdd(dst + a, (unsigned long long)q[a]);
             }
         }
     }
+    learn_epilogue<A>(tab, path_state, item, s_b, n_path, n_shared, kPathWords, sub_rows, S, n_groups, up_stride, bucket_of, part, ovf,
+                      loss_part, acc, rep, losses_raw, overflow);
+}
+
+// The on-policy learner of the default step: the compact trajectory of k_bucket_rollout_items -- relative states below the cut, the
+// lane's packed actions and its one reward -- played with the pi columns of the records as the actor (mu == pi, the very floats the
+// rollout sampled from).  rec_ points at the FAST records (k_row_records): whatever of vtrace_step / nerd_row has row-only operands
+// arrives precomputed, and a slot is left with the carries, the value target, q, the advantage and one division -- the same operations
+// on the same operands as the dense kernel, hence the same sums, bit for bit (test_compact_trajectory_is_the_dense_one).
+// LOSSES: loss_v / loss_nerd sums for a logging step, which need the logits of the dense record (logit_).
+//
+// The time loop runs backwards in two phases (r04; 70 -> see DESIGN.md section 5.1):
+//   1. t >= n_shared: every lane is in a state of its own -- one byte of `states`, a 64-byte record gathered through the vector
+//      memory path, software-pipelined (the state of step t - 2 and the record of step t - 1 in flight during the arithmetic of step t),
+//      ds_add_u64 into the row of the LDS table.  4 of the 12 steps on configs[1].
+//   2. t < n_shared: the whole workgroup is in path_states[bucket][t].  Nothing is read per lane; the record arrives through the SCALAR
+//      cache into SGPRs (one s_load_dwordx16 per step and wave instead of 4 x 64 lanes of vector loads: the L1's tag rate, 64 % busy in
+//      the r03 kernel, is out of the picture), the gate bits are scalar, and only the carries, the action selects and the addends are
+//      vector work.  Every active lane is valid here (it reached the group).
+// All offsets are 32-bit off scalar bases (tables < 4 GB: the 64-bit address arithmetic was ~10 % of the r03 kernel's VALU work).
+template <int A, typename REL, bool LOSSES>
+__global__ __launch_bounds__(kThreads) void k_bucket_learn_c(int T, int64_t B, int64_t S, int sub_rows, int path_words, int n_groups, int up_stride,
+                                                             const Item *__restrict__ items, const int32_t *__restrict__ n_items,
+                                                             const int32_t *__restrict__ bucket_of, const int32_t *__restrict__ bucket_lo,
+                                                             const int32_t *__restrict__ bucket_path, const int32_t *__restrict__ path_states,
+                                                             int path_stride, const REL *__restrict__ states, const float *__restrict__ rec_,
+                                                             const unsigned long long *__restrict__ acts_,
+                                                             const float *__restrict__ reward_, const float *__restrict__ logit_,
+                                                             rnad_learn_params_t hp, FixedPoint fx, unsigned long long *__restrict__ acc,
+                                                             unsigned long long *__restrict__ rep, double *__restrict__ losses_raw,
+                                                             int32_t *__restrict__ overflow, const int32_t *__restrict__ alive_part,
+                                                             int alive_blocks, int T1, int32_t *__restrict__ alive,
+                                                             double *__restrict__ norm_out) {
+    extern __shared__ unsigned long long tab[];
+    constexpr int PS = (A + 1) | 1, TS = kTabStride<A>, FS = kFastStride<A>, RS = kRowStride<A>;
+    const int kPathWords = path_words;
+    __shared__ int32_t path_state[kMaxPath];
+    __shared__ double loss_part[kThreads / 64][4];
+    // The rollout left its per-workgroup alive counts un-summed (rnad_rollout_bucketed_compact with alive == NULL): workgroup t < T1
+    // adds up column t first -- k_bucket_alive's work without its launch; the normalisers are read by k_bucket_finish, after this kernel.
+    if (alive_part && (int)blockIdx.x < T1) alive_column(alive_blocks, T1, blockIdx.x, alive_part, alive, norm_out);
+    if ((int)blockIdx.x >= *n_items) return;
+    const Item item = items[blockIdx.x];
+    const int s_b = bucket_lo[item.bucket];
+    const int path_word = bucket_path[item.bucket];
+    const int n_path = path_word & (kSharedRoot - 1);
+    const int n_shared = n_path + ((item.bucket < n_groups && (path_word & kSharedRoot)) ? 2 : 0);
+    const int32_t *my_path = path_states + (uint32_t)item.bucket * (uint32_t)path_stride;
+    const int n_tab = item.bucket < n_groups ? kPathWords + 2 * sub_rows * TS : n_path * kPathSlots * PS;
+    for (int i = threadIdx.x; i < n_tab; i += kThreads) tab[i] = 0ull;
+    if ((int)threadIdx.x < n_shared) path_state[threadIdx.x] = my_path[threadIdx.x];
+    __syncthreads();
+    const VtHp vh{-hp.eta, hp.lambda_, hp.c, hp.rho, hp.gamma};
+    const uint32_t B32 = (uint32_t)B, S32 = (uint32_t)S;
+    const int t_low = min(T, n_shared);  // phase 2 covers [0, t_low), phase 1 [t_low, T)
+    double part[4] = {0.0, 0.0, 0.0, 0.0};
+    bool ovf = false;
+    for (int base = 0; base < item.count; base += kThreads) {
+        const bool active = base + (int)threadIdx.x < item.count;
+        const uint32_t j = (uint32_t)(item.begin + base) + threadIdx.x;
+        Carry cy[2];
+        const unsigned long long acts = active ? acts_[j] : 0ull;
+        const float reward_final = active ? reward_[j] : 0.0f;
+        // the state the last step of the window led to (rewards *= (indices == 0), episode.py:120-121: the step into state 0 pays)
+        auto state_at = [&](int t) { return (int)*at_bytes<REL>(states, ((uint32_t)t * B32 + j) * (uint32_t)sizeof(REL)); };
+        bool after_zero = active && (T < n_shared ? false : state_at(T) == 0);
+        // ------------------------------------------------------------------ phase 1: per-lane states below the cut
+        if (t_low < T) {
+            struct Slot {
+                float rec[FS];
+                float lg[A];  // LOSSES: the row's logits
+            };
+            auto fetch = [&](int t, int rel, Slot &o) {
+                if (rel == 0) return;
+                const uint32_t row = (uint32_t)(t & 1) * S32 + (uint32_t)(s_b + rel - 1);
+                const float4 *rp = at_bytes<float4>(rec_, row * (uint32_t)(FS * sizeof(float)));
+#pragma unroll
+                for (int u = 0; u < FS / 4; ++u) {
+                    const float4 r4 = rp[u];
+                    o.rec[4 * u] = r4.x; o.rec[4 * u + 1] = r4.y; o.rec[4 * u + 2] = r4.z; o.rec[4 * u + 3] = r4.w;
+                }
+                if (LOSSES) {
+                    const float *lp = at_bytes<float>(logit_, row * (uint32_t)(RS * sizeof(float)));
+#pragma unroll
+                    for (int a = 0; a < A; ++a) o.lg[a] = lp[a];
+                }
+            };
+            int r_next = active ? state_at(T - 1) : 0;
+            int r_next2 = (active && T - 2 >= t_low) ? state_at(T - 2) : 0;
+            Slot nxt;
+            fetch(T - 1, r_next, nxt);
+            for (int t = T - 1; t >= t_low; --t) {
+                const int rel = r_next;
+                const Slot cur = nxt;
+                r_next = r_next2;
+                if (t - 1 >= t_low) fetch(t - 1, r_next, nxt);
+                r_next2 = (active && t - 2 >= t_low) ? state_at(t - 2) : 0;
+                const bool valid = rel != 0;  // rnad.py:369
+                long long q[A + 1];
+#pragma unroll
+                for (int a = 0; a <= A; ++a) q[a] = 0;
+                if (valid) {
+                    const int act = (int)(acts >> (3 * t)) & 7;
+                    if (t & 1)  // uniform: the mover is a template parameter of the slot arithmetic
+                        fast_slot<A, LOSSES, 1>(cur.rec, cur.lg, act, after_zero ? reward_final : 0.0f, vh, hp, fx, cy, q, part, ovf);
+                    else
+                        fast_slot<A, LOSSES, 0>(cur.rec, cur.lg, act, 0.0f, vh, hp, fx, cy, q, part, ovf);  // row turns: torch.zeros (episode.py:101)
+                    unsigned long long *dst = tab + kPathWords + ((t & 1) * sub_rows + (rel - 1)) * TS;
+#pragma unroll
+                    for (int a = 0; a <= A; ++a) atomicAdd(dst + a, (unsigned long long)q[a]);
+                } else {
+                    cy[0] = Carry{};  // reset_carry (vtrace.py:320)
+                    cy[1] = Carry{};
+                }
+                after_zero = !valid;
+            }
+        }
+        // ------------------------------------------------------------------ phase 2: the bucket's own states, records through the scalar cache
+        if (active) {
+            for (int t = t_low - 1; t >= 0; --t) {
+                const uint32_t row = (uint32_t)(t & 1) * S32 + (uint32_t)__builtin_amdgcn_readfirstlane(my_path[t]);
+                const float *rp = rec_ + row * (uint32_t)FS;
+                float f[FS], lg[A];
+#pragma unroll
+                for (int u = 0; u < FS; ++u) f[u] = rp[u];
+                if (LOSSES) {
+#pragma unroll
+                    for (int a = 0; a < A; ++a) lg[a] = logit_[row * (uint32_t)RS + a];
+                }
+                const int act = (int)(acts >> (3 * t)) & 7;
+                long long q[A + 1];
+                if (t & 1)
+                    fast_slot<A, LOSSES, 1>(f, lg, act, after_zero ? reward_final : 0.0f, vh, hp, fx, cy, q, part, ovf);
+                else
+                    fast_slot<A, LOSSES, 0>(f, lg, act, 0.0f, vh, hp, fx, cy, q, part, ovf);
+                after_zero = false;
+                unsigned long long *dst = tab + (t * kPathSlots + (threadIdx.x & (kPathSlots - 1))) * PS;
+#pragma unroll
+                for (int a = 0; a <= A; ++a) atomicAdd(dst + a, (unsigned long long)q[a]);
+            }
+        }
+    }
+    learn_epilogue<A>(tab, path_state, item, s_b, n_path, n_shared, kPathWords, sub_rows, S, n_groups, up_stride, bucket_of, part, ovf,
+                      loss_part, acc, rep, losses_raw, overflow);
 }
 
 // acc -> fp32 tables, normalised: dlogit_tab[P * S + s] = w_n * (G_l / N_P), dv_tab likewise with w_v (learn/vtrace.py:374,389;
@@ -1645,6 +1769,7 @@ extern "C" int rnad_bucket_plan(const rnad_tree_t *tree, int64_t B, int64_t *out
     // losses_raw [4] f64 | overflow [1] i32
     out[6] = 8 * (2 * tree->S * A1 + (int64_t)kReplicas * 2 * std::max(nu, 1) * A1 + 4) + 16;
     out[7] = p.lds;
+    out[8] = p.rel_bytes;
     return 0;
 }
 
@@ -1658,15 +1783,19 @@ extern "C" int rnad_bucket_map(const rnad_tree_t *tree, int64_t B, int32_t *buck
 }
 
 namespace {
-// The compact rollout runs one workgroup per work item (k_bucket_rollout_items) unless RNAD_ROLLOUT_GLOBAL asks for the
-// lane-tiled kernel (k_bucket_rollout_compact: kThreads * kPlay columns per workgroup).  Either leaves one row of alive counts per workgroup.
-bool rollout_by_items(const rnad_tree_t *, const Plan &p) {
-    const bool off = getenv("RNAD_ROLLOUT_GLOBAL") && atoi(getenv("RNAD_ROLLOUT_GLOBAL")) != 0;
-    return !off && p.chunk <= kThreads;  // (a thread per lane of the item: RNAD_BUCKET_CHUNK beyond a workgroup takes the lane-tiled kernel)
-}
-int64_t alive_rows(const rnad_tree_t *tree, int64_t B, const Plan &p, bool compact) {
-    return compact && rollout_by_items(tree, p) ? p.max_items : (int64_t)blocks_for(B);
-}
+// The compact rollout runs one workgroup per work item (k_bucket_rollout_items), the dense one a workgroup per kThreads columns: either
+// leaves one row of alive counts per workgroup.
+int64_t alive_rows(const rnad_tree_t *, int64_t B, const Plan &p, bool compact) { return compact ? p.max_items : (int64_t)blocks_for(B); }
+
+// REL = the type of a relative state under plan p
+#define RNAD_DISPATCH_REL(p_, ...)        \
+    if ((p_).rel_bytes == 1) {            \
+        using REL = uint8_t;              \
+        __VA_ARGS__;                      \
+    } else {                              \
+        using REL = uint16_t;             \
+        __VA_ARGS__;                      \
+    }
 int64_t alive_rows_max(int64_t B, const Plan &p) { return std::max<int64_t>(p.max_items, (int64_t)blocks_for(B)); }
 
 struct Scratch {
@@ -1738,7 +1867,7 @@ __global__ __launch_bounds__(kThreads) void k_clear_visited(int64_t rows, int64_
 struct RolloutBuffers {  // the dense trajectory (rnad_traj_t) or the compact one
     int T_cap;
     int64_t B;
-    int32_t *indices;
+    void *indices;  // dense: int32 [T_cap + 1, B]; compact: the relative states, REL [T_cap + 1, B]
     uint8_t *mask_bits;
     float *policy;
     int32_t *actions;
@@ -1833,26 +1962,21 @@ int rollout_bucketed_impl(const rnad_tree_t *tree, const RolloutBuffers &tr, boo
 #define RNAD_BUCKET_ROLLOUT()                                                                                                            \
     hipLaunchKernelGGL((k_bucket_rollout<kA>), dim3(grid), dim3(kThreads), 0, stream, tree->trans, tree->C, S, B, tr.T_cap, policy_tab,     \
                        policy_stride, value_table, value_stride, (const uint8_t *)tree->mask_tab, seed, device_params, lane0,               \
-                       (const int32_t *)lane_ids, (const unsigned long long *)s.decisions, tr.indices, tr.mask_bits, tr.policy, tr.actions, \
+                       (const int32_t *)lane_ids, (const unsigned long long *)s.decisions, (int32_t *)tr.indices, tr.mask_bits, tr.policy, tr.actions, \
                        tr.rewards, tr.values, s.alive_part)
-#define RNAD_BUCKET_ROLLOUT_COMPACT()                                                                                                    \
-    hipLaunchKernelGGL((k_bucket_rollout_compact<kA, kPlay>), dim3(blocks_for(B, kThreads * kPlay)), dim3(kThreads), 0, stream, tree->trans, tree->C, S, B, tr.T_cap,         \
-                       policy_tab, policy_stride, vec4, seed, device_params, lane0, (const int32_t *)lane_ids,                              \
-                       (const unsigned long long *)s.decisions, tr.indices, s.alive_part, tr.acts, tr.final_reward, tr.visited)
-        if (compact && rollout_by_items(tree, p)) {
+        if (compact) {
             RNAD_REQUIRE(items && n_items, "rnad_rollout_bucketed_compact: the work list of the sort is needed to play");
             alive_n = (int)p.max_items;
-            RNAD_DISPATCH_A(tree->A, hipLaunchKernelGGL((k_bucket_rollout_items<kA>), dim3((unsigned)p.max_items), dim3(kThreads), 0, stream,
-                                                        tree->trans, tree->C, S, B, tr.T_cap, policy_tab, policy_stride, vec4, seed,
-                                                        device_params, lane0, (const int32_t *)lane_ids, (const unsigned long long *)s.decisions,
-                                                        (const Item *)items, (const int32_t *)n_items, (const int32_t *)p.cut->bucket_path,
-                                                        p.cut->n_groups, tr.indices, s.alive_part, tr.acts, tr.final_reward, tr.visited));
-        } else if (compact) {
-            RNAD_DISPATCH_A(tree->A, RNAD_BUCKET_ROLLOUT_COMPACT());
+            RNAD_DISPATCH_REL(p, RNAD_DISPATCH_A(tree->A, hipLaunchKernelGGL(
+                                     (k_bucket_rollout_items<kA, REL>), dim3((unsigned)p.max_items), dim3(kThreads), 0, stream, tree->trans, tree->C,
+                                     S, B, tr.T_cap, policy_tab, policy_stride, vec4, seed, device_params, lane0, (const int32_t *)lane_ids,
+                                     (const unsigned long long *)s.decisions, (const Item *)items, (const int32_t *)n_items,
+                                     (const int32_t *)p.cut->bucket_path, (const int32_t *)p.cut->bucket_lo, (const int32_t *)p.cut->path_states,
+                                     std::max(p.cut->max_path, 1), p.cut->n_groups, (REL *)tr.indices, s.alive_part, tr.acts, tr.final_reward,
+                                     tr.visited)));
         } else {
             RNAD_DISPATCH_A(tree->A, RNAD_BUCKET_ROLLOUT());
         }
-#undef RNAD_BUCKET_ROLLOUT_COMPACT
 #undef RNAD_BUCKET_ROLLOUT
     }
     if (tr.alive)  // (NULL: the caller lets rnad_learn_bucketed_compact add the counts up, or calls rnad_bucket_alive)
@@ -1877,8 +2001,9 @@ extern "C" int rnad_bucket_sort(const rnad_tree_t *tree, int T_cap, int64_t B, c
 extern "C" int rnad_bucket_play(const rnad_tree_t *tree, int T_cap, int64_t B, const float *table, int64_t table_stride, int table_is_policy,
                                 const int32_t *rows, const int64_t *n_rows, uint64_t seed, int64_t lane0,
                                 const rnad_step_params_t *device_params, void *scratch, const int32_t *lane_ids, const int32_t *items,
-                                const int32_t *n_items, double *norm, int32_t *indices, int32_t *alive, uint64_t *acts, float *final_reward,
+                                const int32_t *n_items, double *norm, void *states, int32_t *alive, uint64_t *acts, float *final_reward,
                                 int32_t *visited, void *stream) {
+    void *indices = states;
     RNAD_REQUIRE(tree && table && scratch && lane_ids && items && n_items && indices && acts && final_reward, "rnad_bucket_play: null argument");
     RNAD_REQUIRE(T_cap >= 1 && T_cap <= kCompactSteps && B >= 1, "rnad_bucket_play: 1 <= T_cap <= %d, got %d", kCompactSteps, T_cap);
     RNAD_REQUIRE(table_stride >= tree->A && (!rows == !n_rows), "rnad_bucket_play: bad table stride / row list");
@@ -1920,8 +2045,9 @@ extern "C" int rnad_rollout_bucketed(const rnad_tree_t *tree, const rnad_traj_t 
 extern "C" int rnad_rollout_bucketed_compact(const rnad_tree_t *tree, int T_cap, int64_t B, const float *table, int64_t table_stride,
                                              int table_is_policy, uint64_t seed, int64_t lane0, const rnad_step_params_t *device_params,
                                              void *scratch, int32_t *lane_ids, int32_t *items, int32_t *n_items, double *norm,
-                                             int32_t *indices, int32_t *alive, uint64_t *acts, float *final_reward, int32_t *visited,
+                                             void *states, int32_t *alive, uint64_t *acts, float *final_reward, int32_t *visited,
                                              void *stream) {
+    void *indices = states;
     RNAD_REQUIRE(tree && table && scratch && lane_ids && items && n_items && indices && acts && final_reward,
                  "rnad_rollout_bucketed_compact: null argument");
     RNAD_REQUIRE(alive || norm, "rnad_rollout_bucketed_compact: deferred alive counts (alive == NULL) need `norm` (it is cleared here)");
@@ -2013,12 +2139,12 @@ int finish_impl(const rnad_tree_t *tree, const Plan &p, const double *norm, cons
     return 0;
 }
 
-int learn_bucketed_impl(const rnad_tree_t *tree, int T, int64_t B, const int32_t *indices, const int32_t *actions, const float *rewards,
+int learn_bucketed_impl(const rnad_tree_t *tree, int T, int64_t B, const void *indices, const int32_t *actions, const float *rewards,
                         const float *mu, const unsigned long long *acts, const float *final_reward, const float *records,
                         const float *fast, const int32_t *items, const int32_t *n_items, const double *norm, const rnad_learn_params_t *hp,
                         void *accumulators, double *losses, float *dlogit_tab, float *dv_tab, const int32_t *rows, const int64_t *n_rows,
                         const void *rollout_scratch, int rollout_T_cap, int32_t *alive_out, double *norm_out, hipStream_t stream) {
-    const bool compact = acts != nullptr;
+    const bool compact = acts != nullptr;  // (indices: the relative states then)
     Plan p;
     RNAD_REQUIRE(make_plan(tree, B, p), "rnad_learn_bucketed: this tree / batch cannot be bucketed (see rnad_bucket_plan)");
     const int64_t S = tree->S, A1 = tree->A + 1;
@@ -2036,33 +2162,68 @@ int learn_bucketed_impl(const rnad_tree_t *tree, int T, int64_t B, const int32_t
     // the memset node of a captured graph was seen to write garbage after ~57 replays on ROCm 7.2,
     // tests/test_hip_graph.py::test_many_replays_stay_finite)
     ProfScope prof(PROF_LEARN, stream);
-#define RNAD_BUCKET_LEARN(COMPACT, LOSSES)                                                                                            \
+#define RNAD_BUCKET_LEARN_C(LOSSES)                                                                                                   \
     do {                                                                                                                              \
-        auto kern = k_bucket_learn<kA, COMPACT, LOSSES>;                                                                              \
+        auto kern = k_bucket_learn_c<kA, REL, LOSSES>;                                                                                \
         if (p.lds > 48 * 1024) RNAD_HIP_OK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, p.lds)); \
         hipLaunchKernelGGL(kern, dim3(learn_grid), dim3(kThreads), (size_t)p.lds, stream, T, B, S, p.cut->rows, p.path_words,         \
                            p.cut->n_groups, std::max(nu, 1), (const Item *)items, n_items, (const int32_t *)p.cut->bucket_of,         \
-                           (const int32_t *)p.cut->bucket_lo, (const int32_t *)p.cut->bucket_path, indices, actions, rewards, mu,     \
-                           compact ? fast : records, acts, final_reward, records, *hp, fx, acc, rep,                                  \
-                           losses ? losses_raw : (double *)nullptr, overflow, alive_part, (int)alive_rows(tree, B, p, true), T1, alive_out, norm_out); \
+                           (const int32_t *)p.cut->bucket_lo, (const int32_t *)p.cut->bucket_path, (const int32_t *)p.cut->path_states, \
+                           std::max(p.cut->max_path, 1), (const REL *)indices, fast, acts, final_reward, records, *hp, fx, acc, rep,  \
+                           losses ? losses_raw : (double *)nullptr, overflow, alive_part, (int)alive_rows(tree, B, p, true), T1,      \
+                           alive_out, norm_out);                                                                                      \
     } while (0)
     {
         ProfScope one(PROF_BUCKET_LEARN, stream);
         if (compact && (losses || fx.check_l)) {  // (the LOSSES instantiation also range-checks the dL/dlogit addends of a clip >= 2^29)
             RNAD_REQUIRE(records, "rnad_learn_bucketed_compact: a NeuRD clip of 2^29 or more needs the dense records too");
-            RNAD_DISPATCH_A(tree->A, RNAD_BUCKET_LEARN(true, true));
+            RNAD_DISPATCH_REL(p, RNAD_DISPATCH_A(tree->A, RNAD_BUCKET_LEARN_C(true)));
         } else if (compact) {
-            RNAD_DISPATCH_A(tree->A, RNAD_BUCKET_LEARN(true, false));
+            RNAD_DISPATCH_REL(p, RNAD_DISPATCH_A(tree->A, RNAD_BUCKET_LEARN_C(false)));
         } else {
-            RNAD_DISPATCH_A(tree->A, RNAD_BUCKET_LEARN(false, false));
+            if (p.lds > 48 * 1024)
+                RNAD_DISPATCH_A(tree->A, RNAD_HIP_OK(hipFuncSetAttribute((const void *)k_bucket_learn<kA>, hipFuncAttributeMaxDynamicSharedMemorySize, p.lds)));
+            RNAD_DISPATCH_A(tree->A, hipLaunchKernelGGL((k_bucket_learn<kA>), dim3((unsigned)p.max_items), dim3(kThreads), (size_t)p.lds, stream, T, B, S,
+                                                        p.cut->rows, p.path_words, p.cut->n_groups, std::max(nu, 1), (const Item *)items, n_items,
+                                                        (const int32_t *)p.cut->bucket_of, (const int32_t *)p.cut->bucket_lo,
+                                                        (const int32_t *)p.cut->bucket_path, (const int32_t *)indices, actions, rewards, mu, records,
+                                                        *hp, fx, acc, rep, losses ? losses_raw : (double *)nullptr, overflow));
         }
     }
-#undef RNAD_BUCKET_LEARN
+#undef RNAD_BUCKET_LEARN_C
     RNAD_HIP_OK(hipGetLastError());
     if (!norm) return 0;  // the caller completes the update with rnad_bucket_finish once the normalisers are known
     return finish_impl(tree, p, norm, hp, accumulators, losses, dlogit_tab, dv_tab, rows, n_rows, stream);
 }
 }  // namespace
+
+extern "C" int rnad_bucket_indices(const rnad_tree_t *tree, int T1, int64_t B, const void *states, const int32_t *items, const int32_t *n_items,
+                                   int32_t *indices, void *stream) {
+    RNAD_REQUIRE(tree && states && items && n_items && indices, "rnad_bucket_indices: null argument");
+    RNAD_REQUIRE(T1 >= 1 && T1 <= kCompactSteps + 1 && B >= 1, "rnad_bucket_indices: bad shape");
+    Plan p;
+    RNAD_REQUIRE(make_plan(tree, B, p), "rnad_bucket_indices: this tree / batch cannot be bucketed (see rnad_bucket_plan)");
+    RNAD_DISPATCH_REL(p, hipLaunchKernelGGL((k_bucket_indices<REL>), dim3((unsigned)p.max_items), dim3(kThreads), 0, (hipStream_t)stream, T1, B,
+                                            (const Item *)items, n_items, (const int32_t *)p.cut->bucket_path, (const int32_t *)p.cut->bucket_lo,
+                                            (const int32_t *)p.cut->path_states, std::max(p.cut->max_path, 1), p.cut->n_groups, (const REL *)states,
+                                            indices));
+    RNAD_HIP_OK(hipGetLastError());
+    return 0;
+}
+
+extern "C" int rnad_bucket_pack_states(const rnad_tree_t *tree, int T1, int64_t B, const int32_t *indices, const int32_t *items,
+                                       const int32_t *n_items, void *states, int32_t *mismatch, void *stream) {
+    RNAD_REQUIRE(tree && states && items && n_items && indices && mismatch, "rnad_bucket_pack_states: null argument");
+    RNAD_REQUIRE(T1 >= 1 && T1 <= kCompactSteps + 1 && B >= 1, "rnad_bucket_pack_states: bad shape");
+    Plan p;
+    RNAD_REQUIRE(make_plan(tree, B, p), "rnad_bucket_pack_states: this tree / batch cannot be bucketed (see rnad_bucket_plan)");
+    RNAD_DISPATCH_REL(p, hipLaunchKernelGGL((k_bucket_pack<REL>), dim3((unsigned)p.max_items), dim3(kThreads), 0, (hipStream_t)stream, T1, B, p.cut->rows,
+                                            (const Item *)items, n_items, (const int32_t *)p.cut->bucket_path, (const int32_t *)p.cut->bucket_lo,
+                                            (const int32_t *)p.cut->path_states, std::max(p.cut->max_path, 1), p.cut->n_groups, indices,
+                                            (REL *)states, mismatch));
+    RNAD_HIP_OK(hipGetLastError());
+    return 0;
+}
 
 extern "C" int rnad_bucket_finish(const rnad_tree_t *tree, int64_t B, const double *norm, const rnad_learn_params_t *hp, void *accumulators,
                                   double *losses, float *dlogit_tab, float *dv_tab, const int32_t *rows, const int64_t *n_rows, void *stream) {
@@ -2084,7 +2245,7 @@ extern "C" int rnad_learn_bucketed(const rnad_tree_t *tree, int T, int64_t B, co
                                accumulators, losses, dlogit_tab, dv_tab, nullptr, nullptr, nullptr, 0, nullptr, nullptr, (hipStream_t)stream);
 }
 
-extern "C" int rnad_learn_bucketed_compact(const rnad_tree_t *tree, int T, int64_t B, const int32_t *indices, const uint64_t *acts,
+extern "C" int rnad_learn_bucketed_compact(const rnad_tree_t *tree, int T, int64_t B, const void *states, const uint64_t *acts,
                                            const float *final_reward, const float *fast_records, const float *records,
                                            const int32_t *items, const int32_t *n_items, const double *norm, const rnad_learn_params_t *hp,
                                            void *accumulators, double *losses, float *dlogit_tab, float *dv_tab, const int32_t *rows,
@@ -2093,6 +2254,7 @@ extern "C" int rnad_learn_bucketed_compact(const rnad_tree_t *tree, int T, int64
     RNAD_REQUIRE(!rows == !n_rows, "rnad_learn_bucketed_compact: rows and n_rows go together");
     RNAD_REQUIRE(!rollout_scratch || (alive && rollout_T_cap >= T && rollout_T_cap <= kCompactSteps),
                  "rnad_learn_bucketed_compact: completing the rollout's alive counts needs `alive` and the rollout's T_cap");
+    const void *indices = states;
     RNAD_REQUIRE(tree && indices && acts && final_reward && fast_records && items && n_items && hp && accumulators && dlogit_tab && dv_tab,
                  "rnad_learn_bucketed_compact: null argument");
     RNAD_REQUIRE(!losses || records, "rnad_learn_bucketed_compact: the losses need the dense records (logits)");

@@ -88,6 +88,8 @@ struct BucketCut {
     int32_t *bucket_of = nullptr;    // device [S]: bucket of a state (group for every state of a group's id range, n_groups + slot for upper states, -1 else)
     int32_t *bucket_lo = nullptr;    // device [n_buckets]: first state id of the group / the upper state itself
     int32_t *bucket_path = nullptr;  // device [n_buckets]: env steps a lane of the bucket spends above the group (terminal buckets: all of them)
+    int32_t *path_states = nullptr;  // device [n_buckets][max(max_path, 1)]: the state every lane of the bucket sits in at env step t, for the steps
+                                     // it shares with the whole bucket (above the group; and at the root of a group that is one subtree)
     int32_t *upper_list = nullptr;   // device [max(n_upper, 1)]: the upper states in slot order
     void *upper_walk = nullptr;      // device [n_upper][A][A][C] {next state, its bucket, chance}: the transition table of the upper states,
                                      // compact, for k_bucket_keys to stage in LDS
@@ -119,6 +121,7 @@ struct rnad_tree {
     std::vector<int64_t> child_offsets;  // host CSR of the live children (index != 0, chance > 0) of every state, ascending ids
     std::vector<int32_t> children;
     mutable std::map<int, BucketCut> cuts;  // by rows; handles are used from one host thread (include/rnad_hip.h)
+    mutable std::map<std::pair<int64_t, int>, int> plan_rows;  // (lanes, forced rows or 0) -> rows of the cut the planner chose (0: none fits)
     size_t bytes = 0;
 };
 

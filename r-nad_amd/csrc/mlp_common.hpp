@@ -17,11 +17,11 @@ constexpr int kThreads = 256;
 #define RNAD_MLP_FWD_THREADS 256
 #endif
 constexpr int kFwdThreads = RNAD_MLP_FWD_THREADS;  // forward block size: waves of one block share one LDS weight image
-constexpr int kTile = 32;
+constexpr int kTile = 32;  // samples per wave-tile and hidden units per MFMA tile
 // Floats per hidden unit of dW0aug in a backward partial: the K inputs and the bias column, rounded up to a 16-byte multiple (the
 // partial rows are what k_mlp_reduce streams: a 32-float stride left 2/3 of every cache line of a K = 10 row unused).
 // (Wider inputs keep whole 32-float tiles: hipcc 7.2 crashes in its AGPR-copy rewrite on the A = 8 instantiation otherwise.)
-constexpr int bwd_feature_stride(int K) { return K + 1 <= kTile ? ((K + 1 + 3) & ~3) : ((K + 1 + kTile - 1) / kTile) * kTile; }  // samples per wave-tile and hidden units per MFMA tile
+constexpr int bwd_feature_stride(int K) { return K + 1 <= kTile ? ((K + 1 + 3) & ~3) : ((K + 1 + kTile - 1) / kTile) * kTile; }
 constexpr int kB1Pad = 12;  // floats reserved for the 1 + A output biases at the end of the packed image (multiple of 4)
 
 // Packed weight image (floats), copied verbatim into LDS by every block:

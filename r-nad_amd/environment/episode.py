@@ -56,7 +56,11 @@ class States:
     def indices(self):
         """[B] int32 state ids, all at the root (1) to start with (episode.py:22)."""
         if self._indices is None:
-            self._indices = torch.ones((self.batch_size,), dtype=torch.int32, device=self.tree.device)
+            final = getattr(self, "_final_of", None)
+            if final is not None:  # the states a compact rollout ended in: row T of its (lazily rebuilt) indices
+                self._indices = final[0].indices[final[1]]
+            else:
+                self._indices = torch.ones((self.batch_size,), dtype=torch.int32, device=self.tree.device)
         return self._indices
 
     @indices.setter
@@ -119,7 +123,7 @@ class Episodes:
 
     _PRIMARY = ("indices", "observations", "mask_bits", "policy", "action_idx", "rewards", "values")
     _DENSE = {"mask_bits": "mask_bits", "policy": "policy", "action_idx": "actions", "rewards": "rewards"}  # attribute -> Trajectory buffer
-    _observations = _values = _alive = None  # class-level defaults: objects assembled without __init__ (tests, collate) behave the same
+    _observations = _values = _alive = _indices = None  # class-level defaults: objects assembled without __init__ (tests, collate) behave the same
     lane_ids = buckets = None
     _compact = None  # (rnad_hip.Trajectory(compact=True), records) of a compact bucketed rollout: dense fields expand on first access
 
@@ -149,6 +153,20 @@ class Episodes:
         if key not in self._lazy:
             self._lazy[key] = make()
         return self._lazy[key]
+
+    @property
+    def indices(self):
+        """int32 [T, B] (episode.py:218: int64 there).  A compact bucketed rollout keeps one byte per slot below the cut of the tree and
+        nothing above it: the reference's tensor is rebuilt on first access (rnad_bucket_indices)."""
+        value = self.__dict__.get("_indices")
+        if value is None and self.__dict__.get("_compact") is not None and self.t_eff >= 0:
+            value = self._compact[0].indices[: self.t_eff + 1]
+            self.__dict__["_indices"] = value
+        return value
+
+    @indices.setter
+    def indices(self, value):
+        self.__dict__["_indices"] = value
 
     @property
     def observations(self):
@@ -199,8 +217,9 @@ class Episodes:
             self._observations = None
             self._values = None
         if self._compact is not None:
-            traj = self._compact[0]
-            traj.mask_bits = traj.policy = traj.actions = traj.rewards = None
+            self._compact[0].invalidate()
+            self.__dict__["_indices"] = None
+            self.states.indices = None
             for name in self._DENSE:
                 self.__dict__["_" + name] = None
 
@@ -411,7 +430,7 @@ class Episodes:
         self.generation_time = time_end - time_start
         self._traj = traj
         self.t_eff = T - 1
-        self.indices = traj.indices[:T]
+        self.indices = None if compact else traj.indices[:T]  # (compact: rebuilt from the relative states on first access)
         self.observations = traj.observations[:T] if traj.observations is not None else None
         for name, src in self._DENSE.items():
             setattr(self, name, None if compact else getattr(traj, src)[:T])
@@ -420,7 +439,8 @@ class Episodes:
         if self.actor_logits is not None:
             self.actor_logits = self.actor_logits[:T]
         self._lazy = {}
-        self.states.indices = traj.indices[T]
+        self.states.indices = None if compact else traj.indices[T]
+        self.states._final_of = (traj, T) if compact else None  # (compact: States.indices reads row T of the rebuilt tensor on first access)
         self.states.terminal = True  # by construction after 2 * depth steps
         self.finished = True
         net.train()
@@ -451,7 +471,7 @@ class Episodes:
         a device permutation seeded from python's `random`."""
         assert self.finished
         batch_size = min(batch_size, self.batch_size)
-        dev = self.indices.device
+        dev = torch.device(self.tree.device)  # (not self.indices.device: a compact batch would rebuild its indices for it)
         drawn = selected is None
         if selected is not None:
             selected = torch.as_tensor(selected, dtype=torch.long, device=dev)

@@ -393,7 +393,7 @@ class RNaD:
             with torch.no_grad():
                 outs = rnad_hip.mlp_forward_multi(rnad_hip.mlp_pack_many([self.net_reg._weights(), self.net_reg_._weights()], A, fold=fold),
                                                   self.net.width, table, A,
-                                                  [(True, False), (True, False)], fold=fold)
+                                                  [(True, False), (True, False)], fold=self.tree.handle() if fold else False)
             for name, out in (("logit_reg", outs[0][0]), ("logit_reg_", outs[1][0])):
                 if cache[name] is None:
                     cache[name] = out
@@ -403,11 +403,15 @@ class RNaD:
         return cache["logit_reg"], cache["logit_reg_"]
 
     def invalidate_tables(self):
-        """Force the next _reg_tables() call to re-evaluate the regularisation nets -- IN PLACE: the buffers keep their addresses,
-        which a captured graph of the step has baked in (a fresh allocation would leave the replays reading the old ones)."""
+        """The hook for weight edits torch's version counters do not see (`.data` writes, dist.broadcast(t.data), raw-pointer kernels), on
+        ANY of the four nets: the next step re-evaluates the regularisation tables (net_reg, net_reg_) and re-packs the weight images of
+        net and net_target -- all IN PLACE: the buffers keep their addresses, which a captured graph of the step has baked in (a fresh
+        allocation would leave the replays reading the old ones)."""
         cache = getattr(self, "_reg_table_cache", None)
         if cache is not None:
             cache["key"] = None
+        for entry in self.__dict__.get("_packed_cache", {}).get("layouts", {}).values():
+            entry["key"] = None
 
     def _fold(self):
         """The table evaluations of the per-row mode use the FOLD kernels: asked for, and the tree's observation table allows it."""
@@ -451,7 +455,7 @@ class RNaD:
             # then the rows of the groups the batch descends into); rows no lane can reach stay uninitialised and are never read
             logit = torch.empty((table.shape[0], A), dtype=torch.float32, device=table.device)
 
-            def staged_actor(rows, packed=packed, logit=logit, table=table, width=self.net.width):
+            def staged_actor(rows, packed=packed, logit=logit, table=table, width=self.net.width, fold=self.tree.handle() if fold else False):
                 with torch.no_grad():
                     rnad_hip.mlp_forward(packed, width, table, A, live=rows, out=(logit, None), fold=fold)
 
@@ -462,7 +466,7 @@ class RNaD:
             # (one launch entry per (net, head) -- three equal work units per 64-row span -- was measured: 45.5 instead of 43.4 us, every
             # workgroup loads its net's 43 KB weight image first)
             outs = rnad_hip.mlp_forward_multi([packed, packed_target], self.net.width, table, A,
-                                              [(True, True), (want_target_logits, True)], fold=fold)
+                                              [(True, True), (want_target_logits, True)], fold=self.tree.handle() if fold else False)
         logit_reg, logit_reg_ = self._reg_tables(table, fold)
         return dict(table=table, logit=outs[0][0], v=outs[0][1], logit_target=outs[1][0], v_target=outs[1][1], logit_reg=logit_reg,
                     logit_reg_=logit_reg_, packed_net=packed, fold=fold)
@@ -474,7 +478,7 @@ class RNaD:
         rows = rnad_hip.compact_valid(visited)
         with torch.no_grad():
             # (the rows that are not listed are never read: records, gradient tables and the backward all go by the same list)
-            fold = tables.get("fold", False)
+            fold = handle if tables.get("fold", False) else False
             tables["v"] = rnad_hip.mlp_forward(tables["packed_net"], self.net.width, tables["table"], A, want_logits=False, live=rows, zero_rest=False,
                                                fold=fold)[1]
             tables["v_target"] = rnad_hip.mlp_forward(tables["packed_target"], self.net.width, tables["table"], A, want_logits=False, live=rows,
@@ -639,7 +643,8 @@ class RNaD:
                 packed, fold = self.net.pack(), False
             else:
                 packed = tables["packed_net"] if tables is not None and "packed_net" in tables else self.net.pack()  # same weights as the forward
-            rnad_hip.mlp_backward(packed, weights, backward_obs, A, dlogit.view(-1, A), dv.view(-1, 1), live=live, out=views, fold=fold)
+            rnad_hip.mlp_backward(packed, weights, backward_obs, A, dlogit.view(-1, A), dv.view(-1, 1), live=live, out=views,
+                                  fold=self.tree.handle() if fold else False)
             if all(p_.grad is None for p_ in weights):
                 for p_, g_ in zip(weights, views):
                     p_.grad = g_

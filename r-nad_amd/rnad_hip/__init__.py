@@ -168,6 +168,11 @@ class TreeHandle:
             setattr(self, key, tab.half() if half else tab)
         return getattr(self, key)
 
+    def is_foldable_table(self, obs):
+        """True for this tree's own observation table (fp32 or fp16) when its legal planes allow the FOLD kernels: the only inputs the
+        binding hands to them -- they read legal[0][1] of a row and assume the rest of the plane."""
+        return self.legal_foldable and any(obs is getattr(self, k, None) for k in ("_obs_table", "_obs_table_half"))
+
     @property
     def legal_foldable(self):
         """True when every (player, state) row of the observation table carries an all-ones legal plane, or -- the absorbing state -- e0 =
@@ -306,12 +311,25 @@ class RowList:
         self.count = torch.tensor([self.rows.numel()], dtype=torch.int64, device=device)
 
 
+def _fold_checked(fold, obs, who):
+    """fold: False, or the TreeHandle whose observation table `obs` is (the FOLD kernels silently assume every row's legal plane is all
+    ones or e0: that is a property of a tree's table, checked once by TreeHandle.legal_foldable, not of arbitrary observations)."""
+    if not fold:
+        return False
+    if not isinstance(fold, TreeHandle) or not fold.is_foldable_table(obs):
+        raise RnadHipError(f"{who}: fold= takes the TreeHandle whose observations_table() is `obs`, and that table must be legal_foldable "
+                           "(the FOLD kernels read legal[0][1] of a row only)")
+    return True
+
+
 def mlp_forward(packed, W, obs, A, want_logits=True, want_value=True, live=None, out=None, zero_rest=True, fold=False):
     """packed: mlp_pack(weights, A); obs [N, 2, A, A] fp32/fp16 -> logits [N, A], value [N, 1].
+    fold: False, or the TreeHandle whose observation table `obs` is (FOLD kernels; packed = mlp_pack_many(..., fold=True)).
     A head that is not wanted is not computed (returns None for it).
     live: a LiveRows / RowList over the N samples -- only those rows are evaluated; the others come back as zeros (zero_rest=False:
     uninitialised -- for callers that never read them).  out = (logits, value): existing tables to write into (their other rows
     are left alone)."""
+    fold = _fold_checked(fold, obs, "mlp_forward")
     N = obs.numel() // (2 * A * A)
     half = obs.dtype == F16
     alloc = torch.zeros if (live is not None and zero_rest) else torch.empty
@@ -344,6 +362,7 @@ def mlp_forward(packed, W, obs, A, want_logits=True, want_value=True, live=None,
 def mlp_forward_multi(packed_list, W, obs, A, wants, fold=False):
     """Several nets of one shape on the same inputs in ONE launch (rnad_mlp_forward_multi).  packed_list: their weight images;
     wants: per net (want_logits, want_value).  Returns a list of (logits [N, A] or None, value [N, 1] or None)."""
+    fold = _fold_checked(fold, obs, "mlp_forward_multi")
     n = len(packed_list)
     assert 1 <= n <= 4 and len(wants) == n
     N = obs.numel() // (2 * A * A)
@@ -368,7 +387,9 @@ def mlp_backward_supported(A, W):
 def mlp_backward(packed, weights, obs, A, dlogits, dvalue, live=None, out=None, fold=False):
     """Gradients of the 8 Linear tensors (MLP_KEYS order) for dL/dlogits [N, A], dL/dvalue [N(,1)].
     live: a LiveRows -- only those rows contribute (the caller guarantees the others carry zero gradients).
-    out: eight preallocated tensors shaped like the weights (e.g. views of one flat all-reduce bucket) to write into."""
+    out: eight preallocated tensors shaped like the weights (e.g. views of one flat all-reduce bucket) to write into.
+    fold: False, or the TreeHandle whose observation table `obs` is (as mlp_forward)."""
+    fold = _fold_checked(fold, obs, "mlp_backward")
     N = obs.numel() // (2 * A * A)
     W = weights[0].shape[0]
     half = obs.dtype == F16
@@ -429,19 +450,28 @@ class Trajectory:
     def __init__(self, tree, B, T_cap, device, half=False, with_observations=True, with_values=True, compact=False):
         """with_observations / with_values = False: those buffers are not allocated (bucketed rollout: observations are a function
         of (t & 1, indices) and are materialised on demand; the actor's values are only stored when asked for).
-        compact=True (rollout_bucketed_compact): only indices, alive, `acts` (int64 [B], 3 bits per step) and `final_reward` [B]
-        exist; mask_bits / policy / actions / rewards are None until bucket_expand fills them."""
+        compact=True (rollout_bucketed_compact): only `states` (the relative states below the cut, uint8 / int16 [T_cap + 1, B]: include/rnad_hip.h
+        "Compact trajectory"), alive, `acts` (int64 [B], 3 bits per step) and `final_reward` [B] exist; `indices` (int32 [T_cap + 1, B], the
+        reference's) is rebuilt by bucket_indices on first access, mask_bits / policy / actions / rewards are None until bucket_expand
+        fills them."""
         A = tree.A
         self.T_cap, self.B, self.A, self.half = T_cap, B, A, half
         self.compact = bool(compact)
-        self.indices = torch.empty((T_cap + 1, B), dtype=I32, device=device)
+        self.device = torch.device(device)
+        self._indices = None
+        self._owner = None  # compact: (tree handle, Buckets) of the rollout that filled `states`
         if compact:
+            plan = bucket_plan(tree, B)
+            if plan is None:
+                raise RnadHipError(lib().rnad_last_error().decode())
+            self.states = torch.empty((T_cap + 1, B), dtype=U8 if plan.rel_bytes == 1 else torch.int16, device=device)
             self.observations = self.mask_bits = self.policy = self.actions = self.rewards = self.values = None
             self.acts = torch.empty((B,), dtype=torch.int64, device=device)
             self.final_reward = torch.empty((B,), dtype=F32, device=device)
             self.alive = torch.empty((T_cap + 1,), dtype=I32, device=device)
             self.c = None
             return
+        self._indices = torch.empty((T_cap + 1, B), dtype=I32, device=device)
         self.observations = torch.empty((T_cap, B, 2, A, A), dtype=F16 if half else F32, device=device) if with_observations else None
         self.mask_bits = torch.empty((T_cap, B), dtype=U8, device=device)
         self.policy = torch.empty((T_cap, B, A), dtype=F32, device=device)
@@ -450,9 +480,25 @@ class Trajectory:
         self.values = torch.empty((T_cap, B), dtype=F32, device=device) if with_values else None
         self.alive = torch.empty((T_cap + 1,), dtype=I32, device=device)
         ptr = lambda t: t.data_ptr() if t is not None else None  # noqa: E731
-        self.c = Traj(T_cap, int(half), B, self.indices.data_ptr(), ptr(self.observations), self.mask_bits.data_ptr(),
+        self.c = Traj(T_cap, int(half), B, self._indices.data_ptr(), ptr(self.observations), self.mask_bits.data_ptr(),
                       self.policy.data_ptr(), self.actions.data_ptr(), self.rewards.data_ptr(), ptr(self.values),
                       self.alive.data_ptr())
+
+    @property
+    def indices(self):
+        """int32 [T_cap + 1, B] (episode.py:218).  A compact trajectory rebuilds it from its relative states on first access
+        (rnad_bucket_indices) and keeps it until invalidate() says the buffers were rewritten."""
+        if self._indices is None and self.compact:
+            if self._owner is None:
+                raise RnadHipError("this compact trajectory has not been played yet")
+            self._indices = bucket_indices(self._owner[0], self._owner[1], self)
+        return self._indices
+
+    def invalidate(self):
+        """The rollout buffers were rewritten in place (a replayed hipGraph of the step): forget what was derived from them."""
+        if self.compact:
+            self._indices = None
+            self.mask_bits = self.policy = self.actions = self.rewards = None
 
 
 def rollout_begin(tree, traj):
@@ -647,7 +693,8 @@ class BucketPlan:
 
     def __init__(self, tree, B, out):
         self.B = B
-        self.rows, self.n_buckets, self.n_upper, self.n_groups, self.max_items, self.scratch_bytes, self.acc_bytes, self.lds = (int(x) for x in out)
+        (self.rows, self.n_buckets, self.n_upper, self.n_groups, self.max_items, self.scratch_bytes, self.acc_bytes, self.lds,
+         self.rel_bytes) = (int(x) for x in out)
         dev = tree.device
         self.scratch = torch.empty((self.scratch_bytes // 4 + 1,), dtype=I32, device=dev)
         self.accumulators = torch.zeros((self.acc_bytes // 8 + 1,), dtype=torch.int64, device=dev)
@@ -658,7 +705,7 @@ def bucket_plan(tree, B):
     cache = tree.__dict__.setdefault("_bucket_plans", {})
     key = (B, os.environ.get("RNAD_BUCKET_ROWS"), os.environ.get("RNAD_BUCKET_CHUNK"))  # the tuning overrides of csrc/bucket.hip
     if key not in cache:
-        out = (C.c_int64 * 8)()
+        out = (C.c_int64 * 9)()
         rc = lib().rnad_bucket_plan(tree.ptr, B, out)
         cache[key] = BucketPlan(tree, B, list(out)) if rc == 0 else None
     return cache[key]
@@ -692,7 +739,7 @@ def rollout_bucketed(tree, traj, table, value_table=None, seed=0, lane0=0, table
     if plan is None:
         raise RnadHipError(lib().rnad_last_error().decode())
     assert table.shape[0] == 2 * tree.S and table.shape[1] >= column + tree.A
-    buckets = Buckets(plan, traj.indices.device)
+    buckets = Buckets(plan, traj.device)
     base = _dp(table, F32, "table")
     _check(lib().rnad_rollout_bucketed(tree.ptr, C.byref(traj.c), C.c_void_p(base.value + 4 * column), table.shape[1], int(table_is_policy),
                                        _dp(value_table, F32, "value_table", True), 1, seed, lane0,
@@ -725,17 +772,19 @@ def rollout_bucketed_compact(tree, traj, table, seed=0, lane0=0, step_params=Non
         column = policy_column(tree.A) if table_is_policy else 0
     assert table.shape[0] == 2 * tree.S and table.shape[1] >= column + tree.A
     assert visited is None or visited.numel() == 2 * tree.S
-    buckets = Buckets(plan, traj.indices.device)
+    buckets = Buckets(plan, traj.device)
     base = _dp(table, F32, "table")
     _check(lib().rnad_rollout_bucketed_compact(tree.ptr, traj.T_cap, traj.B, C.c_void_p(base.value + 4 * column), table.shape[1],
                                                int(table_is_policy), seed, lane0, _dp(step_params, torch.int64, "step_params", True),
                                                _dp(plan.scratch, I32, "scratch"), _dp(buckets.lane_ids, I32, "lane_ids"),
                                                _dp(buckets.items, I32, "items"), _dp(buckets.n_items, I32, "n_items"),
-                                               _dp(buckets.norm, F64, "norm"), _dp(traj.indices, I32, "indices"),
+                                               _dp(buckets.norm, F64, "norm"), _dp(traj.states, traj.states.dtype, "states"),
                                                None if defer_alive else _dp(traj.alive, I32, "alive"),
                                                _dp(traj.acts, torch.int64, "acts"), _dp(traj.final_reward, F32, "final_reward"),
                                                _dp(visited, I32, "visited", True), _stream()))
     buckets.alive_pending = traj if defer_alive else None
+    traj._owner = (tree, buckets)
+    traj.invalidate()
     return buckets
 
 
@@ -760,8 +809,8 @@ def bucket_sort(tree, traj, table, seed=0, lane0=0, step_params=None, table_is_p
     if plan is None:
         raise RnadHipError(lib().rnad_last_error().decode())
     assert table.shape[0] == 2 * tree.S and table.shape[1] >= column + tree.A
-    buckets = Buckets(plan, traj.indices.device)
-    flags = torch.empty((2 * tree.S,), dtype=I32, device=traj.indices.device) if want_flags else None
+    buckets = Buckets(plan, traj.device)
+    flags = torch.empty((2 * tree.S,), dtype=I32, device=traj.device) if want_flags else None
     base = _dp(table, F32, "table")
     _check(lib().rnad_bucket_sort(tree.ptr, traj.T_cap, traj.B, C.c_void_p(base.value + 4 * column), table.shape[1], int(table_is_policy), seed,
                                   lane0, _dp(step_params, torch.int64, "step_params", True), _dp(plan.scratch, I32, "scratch"),
@@ -780,10 +829,12 @@ def bucket_play(tree, traj, buckets, table, rows=None, seed=0, lane0=0, step_par
                                   *_row_list(rows), seed, lane0, _dp(step_params, torch.int64, "step_params", True),
                                   _dp(buckets.plan.scratch, I32, "scratch"), _dp(buckets.lane_ids, I32, "lane_ids"),
                                   _dp(buckets.items, I32, "items"), _dp(buckets.n_items, I32, "n_items"),
-                                  _dp(buckets.norm, F64, "norm"), _dp(traj.indices, I32, "indices"),
+                                  _dp(buckets.norm, F64, "norm"), _dp(traj.states, traj.states.dtype, "states"),
                                   None if defer_alive else _dp(traj.alive, I32, "alive"), _dp(traj.acts, torch.int64, "acts"),
                                   _dp(traj.final_reward, F32, "final_reward"), _dp(visited, I32, "visited", True), _stream()))
     buckets.alive_pending = traj if defer_alive else None
+    traj._owner = (tree, buckets)
+    traj.invalidate()
 
 
 def bucket_alive(tree, buckets):
@@ -796,9 +847,32 @@ def bucket_alive(tree, buckets):
     buckets.alive_pending = None
 
 
+def bucket_indices(tree, buckets, traj):
+    """rnad_bucket_indices: the reference's indices (int32 [T_cap + 1, B], episode.py:218) of a compact trajectory -- the bucket's own
+    path states above the cut, bucket_lo + relative state below."""
+    out = torch.empty((traj.T_cap + 1, traj.B), dtype=I32, device=traj.device)
+    _check(lib().rnad_bucket_indices(tree.ptr, traj.T_cap + 1, traj.B, _dp(traj.states, traj.states.dtype, "states"),
+                                     _dp(buckets.items, I32, "items"), _dp(buckets.n_items, I32, "n_items"), _dp(out, I32, "indices"), _stream()))
+    return out
+
+
+def bucket_pack_states(tree, buckets, traj, indices):
+    """rnad_bucket_pack_states: a bucket-ordered int32 [T_cap + 1, B] trajectory (column j = lane buckets.lane_ids[j]) into the relative
+    states of the compact Trajectory `traj`.  Raises if a column does not belong to its work item's bucket."""
+    assert traj.compact and tuple(indices.shape) == (traj.T_cap + 1, traj.B)
+    bad = torch.zeros((1,), dtype=I32, device=traj.device)
+    _check(lib().rnad_bucket_pack_states(tree.ptr, traj.T_cap + 1, traj.B, _dp(indices.contiguous(), I32, "indices"), _dp(buckets.items, I32, "items"),
+                                         _dp(buckets.n_items, I32, "n_items"), _dp(traj.states, traj.states.dtype, "states"),
+                                         _dp(bad, I32, "mismatch"), _stream()))
+    if int(bad.item()):
+        raise RnadHipError("bucket_pack_states: a column of `indices` is not a lane of its work item's bucket")
+    traj._owner = (tree, buckets)
+    traj.invalidate()
+
+
 def bucket_expand(tree, traj, records):
     """rnad_bucket_expand: the dense mask_bits / policy / actions / rewards [T_cap, B] buffers of a compact trajectory."""
-    dev, T, B, A = traj.indices.device, traj.T_cap, traj.B, tree.A
+    dev, T, B, A = traj.device, traj.T_cap, traj.B, tree.A
     traj.mask_bits = torch.empty((T, B), dtype=U8, device=dev)
     traj.policy = torch.empty((T, B, A), dtype=F32, device=dev)
     traj.actions = torch.empty((T, B), dtype=I32, device=dev)
@@ -816,7 +890,7 @@ def learn_bucketed_compact(tree, buckets, traj, T, records, fast_records, norm, 
     B, A = traj.B, tree.A
     assert buckets.plan.B == B and traj.compact and 1 <= T <= traj.T_cap
     assert rows is None or rows.N == 2 * tree.S
-    dev = traj.indices.device
+    dev = traj.device
     dlogit = torch.empty((2 * tree.S, A), dtype=F32, device=dev)
     dv = torch.empty((2 * tree.S, 1), dtype=F32, device=dev)
     losses = torch.empty((2,), dtype=F64, device=dev) if want_losses else None
@@ -824,7 +898,7 @@ def learn_bucketed_compact(tree, buckets, traj, T, records, fast_records, norm, 
     pending = (None, 0, None, None)
     if getattr(buckets, "alive_pending", None) is traj:
         pending = (_dp(buckets.plan.scratch, I32, "scratch"), traj.T_cap, _dp(traj.alive, I32, "alive"), _dp(buckets.norm, F64, "norm"))
-    _check(lib().rnad_learn_bucketed_compact(tree.ptr, T, B, _dp(traj.indices, I32, "indices"), _dp(traj.acts, torch.int64, "acts"),
+    _check(lib().rnad_learn_bucketed_compact(tree.ptr, T, B, _dp(traj.states, traj.states.dtype, "states"), _dp(traj.acts, torch.int64, "acts"),
                                              _dp(traj.final_reward, F32, "final_reward"), _dp(fast_records, F32, "fast_records"),
                                              _dp(records, F32, "records"), _dp(buckets.items, I32, "items"),
                                              _dp(buckets.n_items, I32, "n_items"), _dp(norm, F64, "norm", True), C.byref(hp),

@@ -172,7 +172,6 @@ def compact_episodes_from_recorded(tree, indices, actions, rewards):
     assert (others == 0).all(), "more than one non-zero reward in an episode"
     assert (t_last[live.any(0)] % 2 == 1).all(), "episodes end on a column step"
     traj = rnad_hip.Trajectory(tree.handle(), B, T, DEV, compact=True)
-    traj.indices.copy_(gpu(np.concatenate([idx, np.zeros((1, B), np.int64)], 0), torch.int32))
     traj.acts.copy_(gpu(acts.view(np.int64)))
     traj.final_reward.copy_(gpu(final))
     alive = np.zeros(T + 1, np.int32)
@@ -181,12 +180,16 @@ def compact_episodes_from_recorded(tree, indices, actions, rewards):
     ep = Episodes(tree, B, seed=0)
     ep.t_eff, ep.finished = T - 1, True
     ep._traj = traj
-    ep.indices = traj.indices[:T]
     ep.alive = traj.alive
     for name in ep._DENSE:
         setattr(ep, name, None)
     norm = [alive[0:T:2].sum(), alive[1:T:2].sum()]
     ep.buckets = buckets_of(tree, B, perm, items, norm)
     ep.lane_ids = ep.buckets.lane_ids
+    # the states: one byte (two on wide cuts) per slot below the cut, nothing above it (rnad_bucket_pack_states checks that every column
+    # is a lane of its work item's bucket); Episodes.indices rebuilds the recorded tensor from them
+    full = gpu(np.concatenate([idx, np.zeros((1, B), np.int64)], 0), torch.int32)
+    rnad_hip.bucket_pack_states(tree.handle(), ep.buckets, traj, full)
     ep._compact = (traj, None)
+    assert torch.equal(ep.indices, full[:T]), "pack -> indices must be the identity"
     return ep, perm

@@ -201,9 +201,9 @@ def test_bucketed_update_gives_the_reference_parameter_gradients(name, level, mo
     for k, p in rn.net.named_parameters():
         want = g["g_net_" + k.replace(".", "_")]
         scale = np.abs(want).max() + 1e-12
-        np.testing.assert_allclose(G.cpu(p.grad), want, rtol=1e-3, atol=2e-5 * scale, err_msg=k)
-    np.testing.assert_allclose(log["loss_v"], g["loss_v"], rtol=1e-4)
-    np.testing.assert_allclose(log["loss_nerd"], g["loss_nerd"], rtol=1e-3, atol=1e-6)
+        np.testing.assert_allclose(G.cpu(p.grad), want, rtol=1e-4, atol=2e-6 * scale, err_msg=k)
+    np.testing.assert_allclose(log["loss_v"], g["loss_v"], rtol=2e-5)
+    np.testing.assert_allclose(log["loss_nerd"], g["loss_nerd"], rtol=1e-4, atol=1e-6)
 
 
 @pytest.mark.parametrize("name", ("ternary4", "pruned", "a5c4"))
@@ -236,7 +236,7 @@ def test_train_step_modes_agree(name, tmp_path, monkeypatch):
         assert torch.equal(a, b)
     for a, b in zip(grads[False], grads[True]):
         scale = a.abs().max().item() + 1e-12
-        np.testing.assert_allclose(b.cpu().numpy(), a.cpu().numpy(), rtol=1e-4, atol=1e-5 * scale)
+        np.testing.assert_allclose(b.cpu().numpy(), a.cpu().numpy(), rtol=3e-5, atol=3e-6 * scale)
 
 
 @pytest.mark.parametrize("name", sorted(TREES))
@@ -290,10 +290,11 @@ def test_compact_trajectory_is_the_dense_one(name, B):
 @pytest.mark.parametrize("rows", (None, 40, 8, 2))
 @pytest.mark.parametrize("name", sorted(TREES))
 def test_walk_kernel_variants_play_the_same_batch(name, rows, monkeypatch):
-    """The keys pass in LDS with its histogram (k_bucket_keys_lds) and the rollout by work item with the steps above the cut played
-    once per workgroup (k_bucket_rollout_items) against the global-table walk + k_bucket_hist and the lane-tiled rollout with a
-    per-lane replay (RNAD_KEYS_GLOBAL / RNAD_ROLLOUT_GLOBAL): same keys, same permutation, same work list, same trajectory, same alive
-    counts -- at the planner's cut and at forced ones (upper states, runs of several sibling subtrees per group, terminal buckets)."""
+    """The keys pass in LDS with its histogram (k_bucket_keys_lds) against the global-table walk + k_bucket_hist (RNAD_KEYS_GLOBAL): same
+    keys, same permutation, same work list, same trajectory, same alive counts -- at the planner's cut and at forced ones (upper states,
+    runs of several sibling subtrees per group, terminal buckets).  And the compact rollout by work item (relative states, the steps above
+    the cut played once per workgroup) against the DENSE bucketed rollout (k_bucket_rollout: every lane replays from the root): the
+    rebuilt indices are the dense kernel's, at every one of those cuts."""
     import rnad_hip
     from environment.episode import Episodes
 
@@ -311,9 +312,8 @@ def test_walk_kernel_variants_play_the_same_batch(name, rows, monkeypatch):
     rec, fast = rnad_hip.bucket_records(h, logit, v, vt, lr, lr_, hp, fast=True)
     actor = (rec, rnad_hip.policy_column(A))
     out = {}
-    for variant, env in (("default", {}), ("fallback", {"RNAD_KEYS_GLOBAL": "1", "RNAD_ROLLOUT_GLOBAL": "1"}),
-                         ("keys only", {"RNAD_KEYS_GLOBAL": "1"}), ("rollout only", {"RNAD_ROLLOUT_GLOBAL": "1"})):
-        for k in ("RNAD_KEYS_GLOBAL", "RNAD_ROLLOUT_GLOBAL"):
+    for variant, env in (("default", {}), ("keys only", {"RNAD_KEYS_GLOBAL": "1"})):
+        for k in ("RNAD_KEYS_GLOBAL",):
             monkeypatch.delenv(k, raising=False)
         for k, val in env.items():
             monkeypatch.setenv(k, val)
@@ -324,18 +324,23 @@ def test_walk_kernel_variants_play_the_same_batch(name, rows, monkeypatch):
         got = rnad_hip.learn_bucketed_compact(h, ep.buckets, traj, ep.t_eff + 1, rec, fast, ep.valid_counts, hp)
         out[variant] = (ep.lane_ids.clone(), ep.indices.clone(), traj.acts.clone(), traj.final_reward.clone(), ep.alive.clone(),
                         ep.valid_counts.clone(), ep.buckets.items[:n_items].clone(), got[0].clone(), got[1].clone())
-    for variant in ("fallback", "keys only", "rollout only"):
+    for variant in ("keys only",):
         for a, b, what in zip(out["default"], out[variant], ("lane_ids", "indices", "acts", "final_reward", "alive", "valid_counts", "items",
                                                              "dlogit", "dv")):
             assert torch.equal(a, b), f"{variant}: {what}"
     assert float(out["default"][7].abs().sum()) > 0
+    monkeypatch.delenv("RNAD_KEYS_GLOBAL", raising=False)
+    dense = Episodes(tree, B, seed=21, lane_offset=77)
+    dense.generate(nets[0], tabular=True, bucketed=True, trim=False, store_values=False, policy_table=actor)
+    assert dense._compact is None and torch.equal(dense.lane_ids, out["default"][0]) and torch.equal(dense.indices, out["default"][1])
+    assert torch.equal(dense.states.indices, ep.states.indices) and torch.equal(dense.alive, out["default"][4])
 
 
 @pytest.mark.timeout(120)
 @pytest.mark.parametrize("chunk", (64, 512))
 def test_work_items_of_another_size_give_the_same_update(chunk, monkeypatch):
     """RNAD_BUCKET_CHUNK (lanes per work item; 256 by default): the trajectory and the per-row sums do not depend on how a bucket's
-    lanes are cut into items.  Items larger than a workgroup take the lane-tiled rollout kernel and several passes of the learner."""
+    lanes are cut into items.  Items larger than a workgroup take several passes of the rollout and of the learner."""
     import rnad_hip
     from environment.episode import Episodes
 
@@ -484,7 +489,7 @@ def test_lazy_rows_train_like_all_rows(name, use_graph, tmp_path, monkeypatch):
     assert torch.equal(out[True][1], out[False][1]) or True  # (the nets drift apart by rounding: later episodes may differ)
     for a, b in zip(out[False][0], out[True][0]):
         scale = a.abs().max().item() + 1e-12
-        np.testing.assert_allclose(b.cpu().numpy(), a.cpu().numpy(), rtol=2e-3, atol=2e-5 * scale)
+        np.testing.assert_allclose(b.cpu().numpy(), a.cpu().numpy(), rtol=2e-4, atol=2e-6 * scale)
 
 
 def test_lazy_rows_first_step_is_exact_where_it_can_be(tmp_path, monkeypatch):

@@ -57,7 +57,7 @@ def test_two_ranks_equal_one_process(tmp_path):
     r0, r1 = (np.load(tmp_path / f"dp_{r}.npz") for r in range(2))
     for k, want in single.items():
         np.testing.assert_array_equal(r0[k], r1[k])  # ranks stay in lock step
-        np.testing.assert_allclose(r0[k], want, rtol=2e-4, atol=2e-6, err_msg=k)  # Adam normalises: compare loosely
+        np.testing.assert_allclose(r0[k], want, rtol=2e-5, atol=2e-7, err_msg=k)  # Adam normalises: compare loosely
     np.testing.assert_allclose(r0["loss_v"], log["loss_v"], rtol=1e-5)
     np.testing.assert_allclose(r0["loss_nerd"], log["loss_nerd"], rtol=1e-4, atol=1e-7)
 

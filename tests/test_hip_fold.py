@@ -33,7 +33,7 @@ def test_folded_forward_is_the_plain_forward(name, half):
     plain = hip.mlp_forward(net.pack(), W, table, A)
     packed = hip.mlp_pack_many([net._weights()], A, fold=True)[0]
     assert packed.numel() == hip.mlp_packed_size(A, W, fold=True)
-    got = hip.mlp_forward(packed, W, table, A, fold=True)
+    got = hip.mlp_forward(packed, W, table, A, fold=h)
     for a, b in zip(got, plain):
         np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=1e-5, atol=2e-6)
     # the two rows of the absorbing state are the ones whose legal plane differs (e0): they go through the indicator feature
@@ -45,15 +45,20 @@ def test_folded_forward_is_the_plain_forward(name, half):
     # several nets in one launch, and a row list
     other = type(net)(A, W, device=DEV)
     packs = hip.mlp_pack_many([net._weights(), other._weights()], A, fold=True)
-    multi = hip.mlp_forward_multi(packs, W, table, A, [(True, True), (False, True)], fold=True)
+    multi = hip.mlp_forward_multi(packs, W, table, A, [(True, True), (False, True)], fold=h)
     assert torch.equal(multi[0][0], got[0]) and torch.equal(multi[0][1], got[1]) and multi[1][0] is None
     np.testing.assert_allclose(multi[1][1].cpu().numpy(), hip.mlp_forward(other.pack(), W, table, A)[1].cpu().numpy(), rtol=1e-5, atol=2e-6)
     flags = torch.zeros((2 * S,), dtype=torch.int32, device=DEV)
     flags[::3] = 1
     rows = hip.compact_valid(flags)
-    part = hip.mlp_forward(packed, W, table, A, live=rows, fold=True)
+    part = hip.mlp_forward(packed, W, table, A, live=rows, fold=h)
     sel = flags.bool()
     assert torch.equal(part[0][sel], got[0][sel]) and torch.equal(part[1][sel], got[1][sel]) and (part[0][~sel] == 0).all()
+    # the premise is a property of the TREE's table: any other observations are refused, loudly
+    with pytest.raises(hip.RnadHipError, match="legal_foldable"):
+        hip.mlp_forward(packed, W, table.clone(), A, fold=h)
+    with pytest.raises(hip.RnadHipError, match="legal_foldable"):
+        hip.mlp_forward(packed, W, table, A, fold=True)
 
 
 @pytest.mark.parametrize("name", FOLDABLE)
@@ -68,10 +73,10 @@ def test_folded_backward_gives_the_gradients_of_the_original_tensors(name):
     weights = net._weights()
     want = hip.mlp_backward(net.pack(), weights, table, A, dl, dv)
     packed = hip.mlp_pack_many([weights], A, fold=True)[0]
-    got = hip.mlp_backward(packed, weights, table, A, dl, dv, fold=True)
+    got = hip.mlp_backward(packed, weights, table, A, dl, dv, fold=h)
     for name_, a, b in zip(hip.MLP_KEYS, got, want):
         scale = b.abs().max().item() + 1e-12
-        np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=1e-4, atol=1e-5 * scale, err_msg=name_)
+        np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=2e-5, atol=2e-6 * scale, err_msg=name_)
     # against autograd through the reference formulation of the net (float64)
     x = table.reshape(2 * S, -1).double()
     ws = [w.detach().double().requires_grad_(True) for w in weights]
@@ -80,17 +85,17 @@ def test_folded_backward_gives_the_gradients_of_the_original_tensors(name):
     ((value * dv.double()).sum() + (logits * dl.double()).sum()).backward()
     for name_, a, w in zip(hip.MLP_KEYS, got, ws):
         scale = w.grad.abs().max().item() + 1e-12
-        np.testing.assert_allclose(a.cpu().numpy(), w.grad.float().cpu().numpy(), rtol=1e-4, atol=1e-5 * scale, err_msg=name_)
+        np.testing.assert_allclose(a.cpu().numpy(), w.grad.float().cpu().numpy(), rtol=2e-5, atol=2e-6 * scale, err_msg=name_)
     # a row list
     flags = torch.zeros((2 * S,), dtype=torch.int32, device=DEV)
     flags[1::2] = 1
     rows = hip.compact_valid(flags)
     masked = (dl * flags.view(-1, 1), dv * flags.view(-1, 1))
-    a = hip.mlp_backward(packed, weights, table, A, dl, dv, live=rows, fold=True)
-    b = hip.mlp_backward(packed, weights, table, A, masked[0].contiguous(), masked[1].contiguous(), fold=True)
+    a = hip.mlp_backward(packed, weights, table, A, dl, dv, live=rows, fold=h)
+    b = hip.mlp_backward(packed, weights, table, A, masked[0].contiguous(), masked[1].contiguous(), fold=h)
     for x_, y_ in zip(a, b):
         scale = y_.abs().max().item() + 1e-12
-        np.testing.assert_allclose(x_.cpu().numpy(), y_.cpu().numpy(), rtol=1e-4, atol=1e-5 * scale)
+        np.testing.assert_allclose(x_.cpu().numpy(), y_.cpu().numpy(), rtol=2e-5, atol=2e-6 * scale)
 
 
 def test_a_tree_with_ragged_legality_is_not_folded(tmp_path, monkeypatch):
@@ -147,4 +152,4 @@ def test_training_with_and_without_the_fold(name, tmp_path, monkeypatch):
         out[fold] = [p.detach().clone() for n in (rn.net, rn.net_target) for p in n.parameters()]
     for a, b in zip(out[False], out[True]):
         scale = a.abs().max().item() + 1e-12
-        np.testing.assert_allclose(b.cpu().numpy(), a.cpu().numpy(), rtol=2e-3, atol=2e-5 * scale)
+        np.testing.assert_allclose(b.cpu().numpy(), a.cpu().numpy(), rtol=2e-4, atol=2e-6 * scale)

@@ -135,8 +135,8 @@ def test_c2_learner_is_lane_independent_and_matches_oracle_on_a_subset(c2):
     for p in range(2):
         rew = n(sub2(ep.rewards)) * (1 if p == 0 else -1)
         vt_p, _, q_p = oracle.vtrace(n(sub2(vt))[..., None], valid, turns, n(sub(ep.policy)), pip, lpol, a_oh, rew, p, 0.2, 1.0, 1.0, 1.0, 1.0)
-        np.testing.assert_allclose(n(part[4][p]), vt_p[..., 0], rtol=1e-4, atol=2e-5)
-        np.testing.assert_allclose(n(part[5][p]), q_p, rtol=1e-4, atol=2e-5)
+        np.testing.assert_allclose(n(part[4][p]), vt_p[..., 0], rtol=1e-5, atol=5e-6)
+        np.testing.assert_allclose(n(part[5][p]), q_p, rtol=1e-5, atol=5e-6)
 
 
 def test_c2_update_step_runs_and_is_finite(c2):
@@ -402,8 +402,8 @@ def test_c4_full_size_learner_is_lane_independent(c4):
     for p in range(2):
         rew = c(sub2(ep.rewards)) * (1 if p == 0 else -1)
         vt_p, _, q_p = oracle.vtrace(c(sub2(vt))[..., None], valid, turns, c(sub(ep.policy)), pip, lpol, a_oh, rew, p, 0.2, 1.0, 1.0, 1.0, 1.0)
-        np.testing.assert_allclose(c(part[4][p]), vt_p[..., 0], rtol=1e-4, atol=2e-5)
-        np.testing.assert_allclose(c(part[5][p]), q_p, rtol=1e-4, atol=2e-5)
+        np.testing.assert_allclose(c(part[4][p]), vt_p[..., 0], rtol=1e-5, atol=5e-6)
+        np.testing.assert_allclose(c(part[5][p]), q_p, rtol=1e-5, atol=5e-6)
 
 
 def test_c4_full_size_update_modes_agree(c4, tmp_path):

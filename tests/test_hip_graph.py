@@ -169,7 +169,8 @@ def test_fused_optimizer_tail_is_clip_adam_ema(tmp_path):
 
 
 def test_invalidate_tables_refreshes_the_captured_buffers_in_place(tmp_path):
-    """invalidate_tables() after an edit autograd's version counters do not see: the regularisation tables a captured step reads
+    """invalidate_tables() after an edit autograd's version counters do not see -- of a regularisation net AND of the learner net
+    (`.data` writes, as _sync_from_rank0's broadcast does): the regularisation tables and the packed weight images a captured step reads
     must be refreshed at the addresses the graph has baked in -- replays then equal eager steps from the same edit."""
     from test_hip_bucket import TREES, _native_tree
 
@@ -179,9 +180,18 @@ def test_invalidate_tables_refreshes_the_captured_buffers_in_place(tmp_path):
         rn, _, _ = _run(tree, tmp_path, use_graph, 5, tag="inval")
         buf = _BUFFERS[id(rn)]
         ptrs = [t.data_ptr() for t in rn._reg_tables(tree.handle().observations_table())]
+        images = [t.data_ptr() for t in rn._packed_images()]
         for p in rn.net_reg.parameters():
             p.data = p.data * 1.05  # a new tensor behind the same Parameter: no version bump on the old storage
+        before = [p.detach().clone() for p in rn.net.parameters()]
+        with torch.no_grad():
+            for p in list(rn.net.parameters()) + list(rn.net_target.parameters()):
+                p.data.mul_(0.97)  # in place through .data: same storage, same version counter -- invisible to _packed_images' key
+        key = rn._packed_cache["layouts"][bool(rn._packed_cache["maintained"])]["key"]
+        assert key == tuple((id(w), w.data_ptr(), w._version) for group in (rn.net._weights(), rn.net_target._weights()) for w in group)
         rn.invalidate_tables()
+        assert [t.data_ptr() for t in rn._packed_images()] == images, "the weight images must be re-packed in place"
+        assert all(not torch.equal(a, b) for a, b in zip(before, rn.net.parameters()))
         for i in range(3):
             rn.train_step(buf, alpha=0.5)
             rn.total_steps += 1

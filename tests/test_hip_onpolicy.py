@@ -116,10 +116,10 @@ def test_compact_default_path_gives_the_reference_gradients_on_its_own_on_policy
     for k, p in rn.net.named_parameters():
         want = g["g_net_" + k.replace(".", "_")]
         scale = np.abs(want).max() + 1e-12
-        np.testing.assert_allclose(G.cpu(p.grad), want, rtol=1e-3, atol=2e-5 * scale, err_msg=k)
+        np.testing.assert_allclose(G.cpu(p.grad), want, rtol=1e-4, atol=2e-6 * scale, err_msg=k)
     if logged:
-        np.testing.assert_allclose(log["loss_v"], g["loss_v"], rtol=1e-4)
-        np.testing.assert_allclose(log["loss_nerd"], g["loss_nerd"], rtol=1e-3, atol=1e-6)
+        np.testing.assert_allclose(log["loss_v"], g["loss_v"], rtol=2e-5)
+        np.testing.assert_allclose(log["loss_nerd"], g["loss_nerd"], rtol=1e-4, atol=1e-6)
         # the dense fields rnad_bucket_expand derives from the compact batch are the recorded ones
         sel = torch.as_tensor(perm, device=G.DEV)
         live_t = torch.as_tensor(live, device=G.DEV)[:, sel]
@@ -155,4 +155,4 @@ def test_compact_default_path_on_every_step_of_the_reference_run(step, fold):
         pad = got[16:] if k.endswith("fc0.weight") or k.endswith("fc0.bias") else (got[:, 16:] if k.endswith("fc1.weight") else got[:0])
         assert (pad == 0).all(), f"{k}: the padded hidden units must receive exactly zero gradients"
         scale = np.abs(want).max() + 1e-12
-        np.testing.assert_allclose(real, want, rtol=1e-3, atol=2e-5 * scale, err_msg=k)
+        np.testing.assert_allclose(real, want, rtol=1e-4, atol=2e-6 * scale, err_msg=k)

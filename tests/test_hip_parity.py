@@ -107,6 +107,23 @@ def test_seeded_draws_match_oracle_bit_for_bit(G, hip):
             np.testing.assert_array_equal(G.cpu(got), want)
 
 
+def test_seeded_draws_are_the_numpy_definition_on_adversarial_weights(G, hip):
+    """rnad_sample(seed=...) on the device against the contract written out in numpy (tests/_numpy_rng.py: philox4x32-10, the slot's
+    uniform, the fp32 inverse CDF) -- NOT through include/rnad_rng.h, which kernels and oracle share.  Zeros anywhere, weights of 1e-30
+    and 1e30, exact ties, all mass on the last category; 64-bit seeds and lane offsets; every category count the kernels are built for."""
+    from tests import _numpy_rng as nprng
+
+    rng = np.random.default_rng(21)
+    for n in (1, 2, 3, 4, 5, 8):
+        B = 65_537
+        p = nprng.adversarial_weights(rng, B, n)
+        for seed, lane0, step, stream in ((1, 0, 0, 0), (2**40 + 17, 2**33, 11, 1), (99, 123456, 31, 0), (2**63 + 5, 2**40, 6, 0), (7, 1, 1, 1)):
+            got = G.cpu(hip.sample(G.gpu(p), seed=seed, lane0=lane0, step=step, stream_id=stream))
+            want = nprng.pick(p, nprng.slot_uniform(B, seed, lane0, step, stream))
+            np.testing.assert_array_equal(got, want, err_msg=f"n={n} seed={seed} lane0={lane0} step={step} stream={stream}")
+            assert (p[np.arange(B), got] > 0).all()  # a category of weight zero is never drawn
+
+
 def test_seeded_draws_follow_the_policy_on_the_device(G, hip):
     """torch.multinomial's contract: the drawn categories are distributed as the weights.  2^20 seeded draws per decision slot (row
     player's action, column player's action, chance) against a fixed policy: chi-square, and no draw of a zero weight."""
@@ -493,11 +510,11 @@ def test_fused_learner_kernel_vs_reference_learn(G, hip, name):
         logit_reg_=G.gpu(lr_), norm=norm, hp=params, want_aux=True, **ep_args)
     np.testing.assert_allclose(G.cpu(pi), g["pi"], rtol=TOL, atol=1e-7)
     for p in range(2):
-        np.testing.assert_allclose(G.cpu(vt[p]), g[f"v_target_p{p}"][..., 0], rtol=1e-4, atol=2e-5)
-        np.testing.assert_allclose(G.cpu(q[p]), g[f"q_p{p}"], rtol=1e-4, atol=2e-5)
-    np.testing.assert_allclose(G.cpu(losses), [g["loss_v"], g["loss_nerd"]], rtol=1e-4, atol=1e-6)
-    np.testing.assert_allclose(G.cpu(dv), g["dv"][..., 0], rtol=1e-4, atol=1e-7)
-    np.testing.assert_allclose(G.cpu(dlogit), g["dlogit"], rtol=1e-4, atol=1e-7)
+        np.testing.assert_allclose(G.cpu(vt[p]), g[f"v_target_p{p}"][..., 0], rtol=1e-5, atol=5e-6)
+        np.testing.assert_allclose(G.cpu(q[p]), g[f"q_p{p}"], rtol=1e-5, atol=5e-6)
+    np.testing.assert_allclose(G.cpu(losses), [g["loss_v"], g["loss_nerd"]], rtol=2e-5, atol=1e-6)
+    np.testing.assert_allclose(G.cpu(dv), g["dv"][..., 0], rtol=2e-5, atol=1e-7)
+    np.testing.assert_allclose(G.cpu(dlogit), g["dlogit"], rtol=2e-5, atol=1e-7)
 
 
 @pytest.mark.parametrize("name", ("small_eta0.2", "ragged_eta0.5"))
@@ -564,9 +581,9 @@ def test_rnad_learn_step_parameter_gradients(G, name):
     for k, p in rn.net.named_parameters():
         want = g["g_net_" + k.replace(".", "_")]
         scale = np.abs(want).max() + 1e-12
-        np.testing.assert_allclose(G.cpu(p.grad), want, rtol=1e-3, atol=2e-5 * scale, err_msg=k)
-    np.testing.assert_allclose(log["loss_v"], g["loss_v"], rtol=1e-4)
-    np.testing.assert_allclose(log["loss_nerd"], g["loss_nerd"], rtol=1e-3, atol=1e-6)
+        np.testing.assert_allclose(G.cpu(p.grad), want, rtol=1e-4, atol=2e-6 * scale, err_msg=k)
+    np.testing.assert_allclose(log["loss_v"], g["loss_v"], rtol=2e-5)
+    np.testing.assert_allclose(log["loss_nerd"], g["loss_nerd"], rtol=1e-4, atol=1e-6)
 
 
 # ------------------------------------------------------------------------------------------------ NashConv

@@ -93,6 +93,6 @@ def test_learn_on_the_collated_batch_gives_the_reference_gradients(mode):
     for k, p in rn.net.named_parameters():
         want = g["g_net_" + k.replace(".", "_")]
         scale = np.abs(want).max() + 1e-12
-        np.testing.assert_allclose(G.cpu(p.grad), want, rtol=1e-3, atol=2e-5 * scale, err_msg=k)
-    np.testing.assert_allclose(log["loss_v"], g["loss_v"], rtol=1e-4)
-    np.testing.assert_allclose(log["loss_nerd"], g["loss_nerd"], rtol=1e-3, atol=1e-6)
+        np.testing.assert_allclose(G.cpu(p.grad), want, rtol=1e-4, atol=2e-6 * scale, err_msg=k)
+    np.testing.assert_allclose(log["loss_v"], g["loss_v"], rtol=2e-5)
+    np.testing.assert_allclose(log["loss_nerd"], g["loss_nerd"], rtol=1e-4, atol=1e-6)

@@ -2,6 +2,7 @@
 import numpy as np
 
 from oracle import oracle
+from tests import _numpy_rng as nprng
 
 # Random123 kat_vectors for philox4x32-10: (counter, key) -> output
 KAT = [
@@ -62,18 +63,26 @@ def test_decision_uniforms_are_the_documented_philox_words():
     assert abs(np.corrcoef(u[:, 0], u[:, 1])[0, 1]) < 0.01 and abs(np.corrcoef(u[:, 1], u[:, 2])[0, 1]) < 0.01
 
 
-def _pick_reference(p, u):
-    """The definition in plain numpy fp32: the number of running sums (index order) that are <= u * total."""
-    c = np.zeros(len(p), np.float32)
-    k = np.zeros(len(p), np.int64)
-    s = np.zeros(len(p), np.float32)
-    for a in range(p.shape[1]):
-        s = (s + p[:, a]).astype(np.float32)
-    target = (u * s).astype(np.float32)
-    for a in range(p.shape[1] - 1):
-        c = (c + p[:, a]).astype(np.float32)
-        k += c <= target
-    return k
+_pick_reference = nprng.pick  # the definition in plain numpy fp32 (tests/_numpy_rng.py)
+
+
+def test_numpy_restatement_of_the_contract_is_pinned():
+    """tests/_numpy_rng.py (what the device draws are compared with, independent of include/rnad_rng.h): philox known answers, and the
+    uniforms / picks of the header through the oracle build."""
+    for ctr, key, want in KAT:
+        got = nprng.philox4x32_10([np.array([c], np.uint64) for c in ctr], key)
+        assert tuple(int(x[0]) for x in got) == want
+    for seed, lane0, t in ((1, 0, 0), (2**40 + 17, 2**33 + 5, 7), (99, 123456, 31)):
+        np.testing.assert_array_equal(nprng.decision_uniforms(1000, seed, lane0, t), oracle.uniforms(1000, seed, lane0, t))
+        np.testing.assert_array_equal(nprng.slot_uniform(1000, seed, lane0, t, 0), oracle.action_uniform(1000, seed, lane0, t))
+        np.testing.assert_array_equal(nprng.slot_uniform(1000, seed, lane0, t, 1), oracle.chance_uniform(1000, seed, lane0, t))
+    rng = np.random.default_rng(11)
+    for n in (1, 2, 3, 5, 8):
+        p = nprng.adversarial_weights(rng, 40_000, n)
+        u = nprng.slot_uniform(len(p), 5, 0, 2, 0)
+        got = oracle.pick(p, u)
+        np.testing.assert_array_equal(got, nprng.pick(p, u))
+        assert (p[np.arange(len(p)), got] > 0).all()
 
 
 def test_pick_is_the_inverse_cdf_and_never_draws_a_zero_weight():

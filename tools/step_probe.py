@@ -30,6 +30,7 @@ def main():
     ap.add_argument("--prune", type=int, nargs=2, default=(0, 0))
     ap.add_argument("--threshold", type=float, default=None)
     ap.add_argument("--width", type=int, default=256)
+    ap.add_argument("--freeze", action="store_true", help="restore the nets' weights before every step (ablated kernels write garbage gradients)")
     ap.add_argument("--no-graph", action="store_true", help="enqueue every step eagerly (one dispatch per kernel launch for the counter passes)")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
@@ -53,9 +54,17 @@ def main():
         rn.train_step(buf, 0.3)
         rn.total_steps += 1
     torch.cuda.synchronize()
+    frozen = None
+    if args.freeze:
+        rn.fused_optimizer = False  # (its kernel would also keep the packed weight images current with the garbage)
+        frozen = [(p, p.detach().clone()) for m in (rn.net, rn.net_target) for p in m.parameters()]
     host = 0.0
     t0 = time.perf_counter()
     for i in range(args.steps):
+        if frozen is not None:
+            with torch.no_grad():
+                for p, keep in frozen:
+                    p.copy_(keep)
         h0 = time.perf_counter()
         rn.train_step(buf, 0.3)
         rn.total_steps += 1
