@@ -1347,13 +1347,16 @@ __device__ __forceinline__ void learn_epilogue(unsigned long long *__restrict__ 
     }
     __syncthreads();
     const int end = (int)(S - s_b < sub_rows ? S - s_b : sub_rows);
-    for (int e = threadIdx.x; e < 2 * sub_rows * (A + 1); e += kThreads) {
-        const int P = e / (sub_rows * (A + 1)), r = e % (sub_rows * (A + 1)), row = r / (A + 1), a = r % (A + 1);
-        const unsigned long long x = tab[kPathWords + (P * sub_rows + row) * TS + a];
-        if (x != 0ull && row < end) {
-            unsigned long long *dst = acc + ((int64_t)P * S + s_b) * (A + 1) + r;
-            if (item.single) *dst = x;
-            else atomicAdd(dst, x);
+#pragma unroll
+    for (int P = 0; P < 2; ++P) {
+        unsigned long long *dst0 = acc + ((int64_t)P * S + s_b) * (A + 1);
+        for (int r = threadIdx.x; r < end * (A + 1); r += kThreads) {
+            const int row = r / (A + 1), a = r % (A + 1);  // (constant divisor)
+            const unsigned long long x = tab[kPathWords + (P * sub_rows + row) * TS + a];
+            if (x != 0ull) {
+                if (item.single) dst0[r] = x;
+                else atomicAdd(dst0 + r, x);
+            }
         }
     }
 }
@@ -1504,8 +1507,16 @@ __global__ __launch_bounds__(kThreads) void k_bucket_learn(int T, int64_t B, int
 //      the r03 kernel, is out of the picture), the gate bits are scalar, and only the carries, the action selects and the addends are
 //      vector work.  Every active lane is valid here (it reached the group).
 // All offsets are 32-bit off scalar bases (tables < 4 GB: the 64-bit address arithmetic was ~10 % of the r03 kernel's VALU work).
+#ifndef RNAD_PHASE2_VMEM
+#define RNAD_PHASE2_VMEM 0
+#endif
+#ifdef RNAD_LEARN_WAVES
+#define RNAD_LEARN_ATTR __attribute__((amdgpu_waves_per_eu(RNAD_LEARN_WAVES, RNAD_LEARN_WAVES)))
+#else
+#define RNAD_LEARN_ATTR
+#endif
 template <int A, typename REL, bool LOSSES>
-__global__ __launch_bounds__(kThreads) void k_bucket_learn_c(int T, int64_t B, int64_t S, int sub_rows, int path_words, int n_groups, int up_stride,
+__global__ __launch_bounds__(kThreads) RNAD_LEARN_ATTR void k_bucket_learn_c(int T, int64_t B, int64_t S, int sub_rows, int path_words, int n_groups, int up_stride,
                                                              const Item *__restrict__ items, const int32_t *__restrict__ n_items,
                                                              const int32_t *__restrict__ bucket_of, const int32_t *__restrict__ bucket_lo,
                                                              const int32_t *__restrict__ bucket_path, const int32_t *__restrict__ path_states,
@@ -1551,7 +1562,7 @@ __global__ __launch_bounds__(kThreads) void k_bucket_learn_c(int T, int64_t B, i
         auto state_at = [&](int t) { return (int)*at_bytes<REL>(states, ((uint32_t)t * B32 + j) * (uint32_t)sizeof(REL)); };
         bool after_zero = active && (T < n_shared ? false : state_at(T) == 0);
         // ------------------------------------------------------------------ phase 1: per-lane states below the cut
-        if (t_low < T) {
+        if (t_low < T && !(RNAD_ABLATE & 8)) {
             struct Slot {
                 float rec[FS];
                 float lg[A];  // LOSSES: the row's logits
@@ -1591,9 +1602,13 @@ __global__ __launch_bounds__(kThreads) void k_bucket_learn_c(int T, int64_t B, i
                         fast_slot<A, LOSSES, 1>(cur.rec, cur.lg, act, after_zero ? reward_final : 0.0f, vh, hp, fx, cy, q, part, ovf);
                     else
                         fast_slot<A, LOSSES, 0>(cur.rec, cur.lg, act, 0.0f, vh, hp, fx, cy, q, part, ovf);  // row turns: torch.zeros (episode.py:101)
+#if RNAD_ABLATE & 1
+                    ovf |= (q[0] ^ q[1] ^ q[A]) == 0x123456789ll;
+#else
                     unsigned long long *dst = tab + kPathWords + ((t & 1) * sub_rows + (rel - 1)) * TS;
 #pragma unroll
                     for (int a = 0; a <= A; ++a) atomicAdd(dst + a, (unsigned long long)q[a]);
+#endif
                 } else {
                     cy[0] = Carry{};  // reset_carry (vtrace.py:320)
                     cy[1] = Carry{};
@@ -1602,17 +1617,31 @@ __global__ __launch_bounds__(kThreads) void k_bucket_learn_c(int T, int64_t B, i
             }
         }
         // ------------------------------------------------------------------ phase 2: the bucket's own states, records through the scalar cache
-        if (active) {
-            for (int t = t_low - 1; t >= 0; --t) {
-                const uint32_t row = (uint32_t)(t & 1) * S32 + (uint32_t)__builtin_amdgcn_readfirstlane(my_path[t]);
-                const float *rp = rec_ + row * (uint32_t)FS;
-                float f[FS], lg[A];
+        // (software-pipelined like phase 1: the path state of step t - 2 and the record of step t - 1 are requested before the
+        // arithmetic of step t; a scalar load that is waited for on the spot costs its whole latency twice per step)
+        if (active && t_low > 0 && !(RNAD_ABLATE & 16)) {
+            auto row_of = [&](int t, int state) { return (uint32_t)(t & 1) * S32 + (uint32_t)state; };
+            auto load_rec = [&](uint32_t row, float (&f)[FS], float (&lg)[A]) {
+#if RNAD_PHASE2_VMEM  // experiment: the same record through the vector path (every lane the same address)
+                asm volatile("" : "+v"(row));
+                const float4 *r4p = at_bytes<float4>(rec_, row * (uint32_t)(FS * sizeof(float)));
+#pragma unroll
+                for (int u = 0; u < FS / 4; ++u) {
+                    const float4 r4 = r4p[u];
+                    f[4 * u] = r4.x; f[4 * u + 1] = r4.y; f[4 * u + 2] = r4.z; f[4 * u + 3] = r4.w;
+                }
+#else
+                const float *rp = at_bytes<float>(rec_, row * (uint32_t)(FS * sizeof(float)));
 #pragma unroll
                 for (int u = 0; u < FS; ++u) f[u] = rp[u];
+#endif
                 if (LOSSES) {
+                    const float *lp = at_bytes<float>(logit_, row * (uint32_t)(RS * sizeof(float)));
 #pragma unroll
-                    for (int a = 0; a < A; ++a) lg[a] = logit_[row * (uint32_t)RS + a];
+                    for (int a = 0; a < A; ++a) lg[a] = lp[a];
                 }
+            };
+            auto slot = [&](int t, const float (&f)[FS], const float (&lg)[A]) {
                 const int act = (int)(acts >> (3 * t)) & 7;
                 long long q[A + 1];
                 if (t & 1)
@@ -1620,9 +1649,29 @@ __global__ __launch_bounds__(kThreads) void k_bucket_learn_c(int T, int64_t B, i
                 else
                     fast_slot<A, LOSSES, 0>(f, lg, act, 0.0f, vh, hp, fx, cy, q, part, ovf);
                 after_zero = false;
+#if RNAD_ABLATE & 1
+                ovf |= (q[0] ^ q[1] ^ q[A]) == 0x123456789ll;
+#else
                 unsigned long long *dst = tab + (t * kPathSlots + (threadIdx.x & (kPathSlots - 1))) * PS;
 #pragma unroll
                 for (int a = 0; a <= A; ++a) atomicAdd(dst + a, (unsigned long long)q[a]);
+#endif
+            };
+            // two record buffers that swap roles (no copies): the time loop is unrolled by two, and t_low is even whenever it is a path
+            // length (n_shared); an odd window (T < n_shared, T odd) plays its first step on its own
+            float fa[FS], la[A], fb[FS], lb[A];
+            int t = t_low - 1;
+            load_rec(row_of(t, __builtin_amdgcn_readfirstlane(my_path[t])), fa, la);
+            if (!(t & 1)) {  // (t even: a lone row step first)
+                slot(t, fa, la);
+                --t;
+                if (t >= 0) load_rec(row_of(t, __builtin_amdgcn_readfirstlane(my_path[t])), fa, la);
+            }
+            for (; t >= 1; t -= 2) {  // t odd: the column step in fa, then the row step of the same state in fb
+                load_rec(row_of(t - 1, __builtin_amdgcn_readfirstlane(my_path[t - 1])), fb, lb);
+                slot(t, fa, la);
+                if (t >= 2) load_rec(row_of(t - 2, __builtin_amdgcn_readfirstlane(my_path[t - 2])), fa, la);
+                slot(t - 1, fb, lb);
             }
         }
     }
