@@ -47,25 +47,50 @@ import torch.distributed as dist  # noqa: E402
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 CLOCK_HZ = 2.4e9       # max shader clock (same guide)
 SIMDS = 256 * 4        # 256 CUs x 4 SIMDs
-# VALU issue roof: wave-instructions per second if every SIMD issued one wave64 VALU instruction every 4 cycles -- what this path's
-# instruction mix costs (SQ_ACTIVE_INST_VALU x 4 cycles / SQ_INSTS_VALU = 4.0 in profiles/*_pmc_sq.csv: 64-bit integer and fp64
-# conversions, divisions and transcendental steps next to the 2-cycle fp32 ops)
-VALU_PEAK_GINST = SIMDS * CLOCK_HZ / 4 / 1e9
-PMC_FILE = os.path.join(ROOT, "profiles", "r03_pmc.json")
+# The rooflines of the integer / gather kernels of this path (keys, rollout, learner), all three always in the line:
+#   hbm    algorithmic bytes per launch / launch duration / 8 TB/s
+#   issue  VALU issue-port time / (SIMDs x launch duration x 2.4 GHz).  Issue-port time = SQ_INSTS_VALU (dynamic wave-instructions per
+#          launch, rocprofv3 counter pass: profiles/r04_pmc.json) x the kernel's mean cycles per instruction = sum over instruction
+#          classes of [share of the class in the kernel's loops (tools/isa_hist.py on `hipcc -S`: profiles/r04_isa_mix.json)] x [cycles a
+#          SIMD's issue port is busy per wave64 instruction of the class (tools/micro/valu_issue.hip on this hardware:
+#          profiles/r04_valu_issue.json: 1.8 - 1.9 for plain fp32 / integer / move, 2.8 - 3.0 for min / max / med3 / compare / select /
+#          64-bit / fp64 / packed, 3.1 - 3.4 for v_cvt_f64_f32 / v_mad_u64_u32, 5.3 transcendental)]
+#   wait   SQ_WAIT_ANY / SQ_WAVE_CYCLES (share of a resident wave's time parked on s_waitcnt) and SQ_WAIT_INST_ANY / SQ_WAVE_CYCLES
+#          (issue stalls) from the same counter pass
+# (r03 priced the issue roof at 4 cycles per instruction from SQ_ACTIVE_INST_VALU, which counts instructions, not cycles.)
+PMC_FILE = os.path.join(ROOT, "profiles", "r04_pmc.json")
+ISA_MIX_FILE = os.path.join(ROOT, "profiles", "r04_isa_mix.json")
+ISSUE_FILE = os.path.join(ROOT, "profiles", "r04_valu_issue.json")
+
+
+def _load(path):
+    try:
+        with open(path) as f:
+            return json.load(f)
+    except (OSError, ValueError):
+        return {}
 
 
 def pmc_counters():
-    """Counter evidence of the step's kernels from the separate rocprofv3 --pmc passes (tools/round_artifacts.sh -> tools/pmc_json.py),
-    or {} when the file was measured on another build (its source hash is not this tree's): stale counters are not reported."""
-    if not os.path.exists(PMC_FILE):
-        return {}
+    """(kernels, matches): counter evidence of the step's kernels from the separate rocprofv3 --pmc passes (tools/round_artifacts.sh ->
+    tools/pmc_json.py) and whether the file was measured on THIS build (its source hash is this tree's).  Counters of another build
+    are still reported -- instruction counts move little between builds -- but flagged."""
     import rnad_hip
 
-    with open(PMC_FILE) as f:
-        pmc = json.load(f)
-    if pmc.get("source_hash") != rnad_hip.source_hash():
-        return {}
-    return pmc.get("kernels", {})
+    pmc = _load(PMC_FILE)
+    return pmc.get("kernels", {}), pmc.get("source_hash") == rnad_hip.source_hash()
+
+
+def issue_cycles_per_instruction(kernel):
+    """Mean issue-port cycles per VALU wave-instruction of `kernel`: its static class mix x the measured class costs; None if either
+    file is missing.  Returns (cycles, detail)."""
+    mix = _load(ISA_MIX_FILE).get("kernels", {}).get(kernel)
+    cost = _load(ISSUE_FILE).get("class_cycles")
+    if not mix or not cost:
+        return None, None
+    cyc = sum(share * cost.get(cls, cost["slow32"]) for cls, share in mix["share"].items())
+    return cyc, {"class_share": mix["share"], "class_cycles": {c: cost.get(c) for c in mix["share"]}, "static_valu_in_loops": mix["valu"],
+                 "vgprs": mix.get("resources", {}).get("num_vgpr")}
 
 
 def main():
@@ -96,7 +121,8 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="RNaD.use_graph = False: enqueue every step eagerly")
     ap.add_argument("--obs-half", action="store_true", help="fp16 observations (BASELINE configs[4])")
     ap.add_argument("--other-steps", type=int, default=20, help="timed steps of each entry of other_modes and of the eager kernel-timing leg")
-    ap.add_argument("--cpu-lanes-log2", type=int, default=15, help="episodes in the CPU-baseline sample")
+    ap.add_argument("--cpu-lanes-log2", type=int, default=18, help="episodes per step of the CPU-baseline sample (C port)")
+    ap.add_argument("--cpu-torch-lanes-log2", type=int, default=16, help="episodes per step of the CPU-baseline sample (plain PyTorch-CPU leg)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -235,6 +261,10 @@ def main():
     replayed = bool(graph_state and graph_state.get("graph") is not None)
     T = rn.last_episodes.t_eff + 1
     args.compact_in_effect = getattr(rn.last_episodes, "_compact", None) is not None
+    args.rel_bytes = args.stored_slots = 0
+    if args.compact_in_effect:
+        args.rel_bytes = rn.last_episodes.buckets.plan.rel_bytes
+        args.stored_slots = rnad_hip.stored_state_slots(handle, rn.last_episodes.buckets, T)
     lazy_now = rn._use_lazy_rows(handle, local_batch, T, None, buffer) and mode_now_is_true(rn, T, local_batch)
     args.visited_rows = int(rn.last_rows.count.item()) if (lazy_now and rn.last_rows is not None) else 0
     staged = getattr(rn.last_episodes, "staged_rows", None) if lazy_now else None
@@ -295,19 +325,22 @@ def main():
     # materialised on demand); timed on its own over the T steps of the last rollout
     k1 = None
     if rank == 0:
-        obs = torch.empty((local_batch, 2, A, A), dtype=torch.float16 if args.obs_half else torch.float32, device=device)
-        bits = torch.empty((local_batch,), dtype=torch.uint8, device=device)
+        # every launch writes its own [B, 2, A, A] slice of a [T, B, 2, A, A] buffer (906 MB at T = 12, fp32: beyond the 256 MiB Infinity Cache)
+        obs = torch.empty((T, local_batch, 2, A, A), dtype=torch.float16 if args.obs_half else torch.float32, device=device)
+        bits = torch.empty((T, local_batch), dtype=torch.uint8, device=device)
+        idx_all = ep.indices
         for t in range(T):
-            rnad_hip.observe(handle, ep.indices[t], t & 1, obs=obs, half=args.obs_half, mask_bits=bits)
+            rnad_hip.observe(handle, idx_all[t], t & 1, obs=obs[t], half=args.obs_half, mask_bits=bits[t])
         fence_local = torch.cuda.synchronize
         fence_local()
         rnad_hip.prof_enable([rnad_hip.PROF_OBSERVE])
         for _ in range(3):
             for t in range(T):
-                rnad_hip.observe(handle, ep.indices[t], t & 1, obs=obs, half=args.obs_half, mask_bits=bits)
+                rnad_hip.observe(handle, idx_all[t], t & 1, obs=obs[t], half=args.obs_half, mask_bits=bits[t])
         n_obs, obs_ms = rnad_hip.prof_read(rnad_hip.PROF_OBSERVE)
         rnad_hip.prof_enable(False)
         k1 = (n_obs, obs_ms)
+        del obs, bits
     if world > 1:
         t = torch.tensor([rollout_s, host_s], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -477,13 +510,16 @@ def kernel_report(prof, A, C, args, B, T, live_slots, tree, mode_now):
     compact = bool(args.compact_in_effect)
     fast = (4 + 4 * A) * 4  # bytes of a fast row record (rnad_bucket_fast_record_stride)
     if compact:
-        rollout_model = (4 * B + slots * 4 + 4 * B + 8 * B + 4 * B,
-                         "per lane: lane id 4 (read; the decisions above the cut are one word per work item); per slot: state 4 (written); "
-                         "per lane: final state 4, packed actions 8, reward 4 (written).  Policy rows and transition records are gathered "
-                         "from the L2-resident tables")
-        learn_model = (live_slots * 4 + B * (4 + 8 + 4) + S2 * fast,
-                       "per live slot: state 4; per lane: final state 4, packed actions 8, reward 4; the 2S fast records (64 B at A = 3) once "
-                       "each -- they are gathered per slot, from L2 / MALL after the first touch; sums stay in LDS")
+        rb, stored = args.rel_bytes, args.stored_slots  # relative states: below the cut of the tree only (include/rnad_hip.h "Compact trajectory")
+        rollout_model = (4 * B + stored * rb + 8 * B + 4 * B,
+                         f"per lane: lane id 4 (read; the decisions above the cut are one word per work item); per slot BELOW the cut (and the "
+                         f"final state): relative state {rb} (written; {stored} of the {slots + B} slots of this batch: the steps a lane shares with its "
+                         "bucket are not stored); per lane: packed actions 8, reward 4 (written).  Policy rows and transition records are "
+                         "gathered from the L2-resident tables")
+        learn_model = (stored * rb + B * (8 + 4) + S2 * fast,
+                       f"per stored slot: relative state {rb}; per lane: packed actions 8, reward 4; the 2S fast records (64 B at A = 3) once "
+                       "each -- gathered per slot below the cut from L2 / MALL after the first touch, read through the scalar cache for the "
+                       "steps a workgroup shares; sums stay in LDS")
     else:
         rollout_model = (4 * B + slots * (4 + 1 + 4 * A + 4 + 4) + 4 * B,
                          "lane_ids 4 B/lane + per slot: state 4, legal bits 1, policy 4A, action 4, reward 4 (+ final state 4 B/lane)")
@@ -498,11 +534,15 @@ def kernel_report(prof, A, C, args, B, T, live_slots, tree, mode_now):
         rh.PROF_OBSERVE: ("hbm", B * (4 + 8 * A * A + 2 * A * A * (2 if args.obs_half else 4) + 4 * A), "SURVEY 8d"),
     }
     out = {}
-    pmc = pmc_counters() if (A, C, args.depth, tuple(args.prune), B, args.width, args.obs_half) == (3, 1, 6, (0, 0), 1 << 20, 256, False) else {}
-    # (the kernel a scope ran depends on the tree: LDS walk / global-table walk, by work item / by lane tile -- the counter file has one of each pair)
+    default_shape = (A, C, args.depth, tuple(args.prune), B, args.width, args.obs_half) == (3, 1, 6, (0, 0), 1 << 20, 256, False)
+    pmc, pmc_matches = pmc_counters() if default_shape else ({}, False)
+    rel = "unsigned char" if rh.bucket_plan(tree.handle(), B) is not None and rh.bucket_plan(tree.handle(), B).rel_bytes == 1 else "unsigned short"
+    # (the kernel a scope ran depends on the tree: LDS walk / global-table walk; compact / dense trajectory)
     pmc_name = {rh.PROF_BUCKET_KEYS: "k_bucket_keys_lds" if "k_bucket_keys_lds" in pmc else "k_bucket_keys",
-                rh.PROF_BUCKET_ROLLOUT: ("k_bucket_rollout_items" if "k_bucket_rollout_items" in pmc else "k_bucket_rollout_compact") if compact else "k_bucket_rollout",
-                rh.PROF_BUCKET_LEARN: "k_bucket_learn", rh.PROF_OBSERVE: "k_observe"}
+                rh.PROF_BUCKET_ROLLOUT: "k_bucket_rollout_items" if compact else "k_bucket_rollout",
+                rh.PROF_BUCKET_LEARN: "k_bucket_learn_c" if compact else "k_bucket_learn", rh.PROF_OBSERVE: "k_observe"}
+    mix_name = {rh.PROF_BUCKET_KEYS: f"k_bucket_keys_lds<{A}, 2>", rh.PROF_BUCKET_ROLLOUT: f"k_bucket_rollout_items<{A}, {rel}>",
+                rh.PROF_BUCKET_LEARN: f"k_bucket_learn_c<{A}, {rel}, false>"}
     units = {rh.PROF_BUCKET_KEYS: (B, "lane"), rh.PROF_BUCKET_ROLLOUT: (slots, "slot"), rh.PROF_BUCKET_LEARN: (max(live_slots, 1), "live slot")}
     for k, p in prof.items():
         e = dict(p)
@@ -511,24 +551,25 @@ def kernel_report(prof, A, C, args, B, T, live_slots, tree, mode_now):
             bound, nbytes, how = model[k]
             sec = p["avg_launch_us"] * 1e-6
             gbs = nbytes / sec / 1e9
-            hbm = dict(bound="hbm", algorithmic_bytes_per_launch=nbytes, achieved=gbs, peak=HBM_PEAK_GBS, unit="GB/s", frac=gbs / HBM_PEAK_GBS, bytes_model=how)
             c = pmc.get(pmc_name.get(k, ""), {})
-            hbm["traffic"] = c.get("traffic_bytes_per_launch")
-            if k in units and c.get("SQ_INSTS_VALU"):
-                # these kernels are bound by VALU issue, not by bandwidth: the roof that binds is the one reported,
-                # the HBM figure stays beside it.  Instructions per launch are the counters' (a property of the build and the workload,
-                # the file carries the build's source hash); the duration is this run's.
-                n_inst = c["SQ_INSTS_VALU"]
-                ginst = n_inst / sec / 1e9
-                e.update(bound="valu", achieved=ginst, peak=VALU_PEAK_GINST, unit="Gwave-inst/s", frac=ginst / VALU_PEAK_GINST,
-                         valu_wave_instructions_per_launch=n_inst,
-                         valu_instructions_per_unit={"per": units[k][1], "value": n_inst * 64 / units[k][0]},
-                         valu_busy_frac_from_SQ_ACTIVE_INST_VALU=(c["SQ_ACTIVE_INST_VALU"] * 4 / (SIMDS * sec * CLOCK_HZ) if c.get("SQ_ACTIVE_INST_VALU") else None),
-                         lds_wave_instructions_per_launch=c.get("SQ_INSTS_LDS"),
-                         roof_model=f"{SIMDS} SIMDs x {CLOCK_HZ / 1e9:g} GHz / 4 cycles per wave64 VALU instruction of this mix",
-                         traffic=hbm["traffic"], hbm=hbm, algorithmic_bytes_per_launch=nbytes, bytes_model=how)
-            else:
-                e.update(hbm)
+            e.update(bound="hbm", algorithmic_bytes_per_launch=nbytes, achieved=gbs, peak=HBM_PEAK_GBS, unit="GB/s", frac=gbs / HBM_PEAK_GBS,
+                     bytes_model=how, traffic=c.get("traffic_bytes_per_launch"))
+            if k in units:
+                issue = {"frac": None, "model": "SQ_INSTS_VALU x sum_class(share x cycles) / (1024 SIMDs x duration x 2.4 GHz)"}
+                cpi, detail = issue_cycles_per_instruction(mix_name[k]) if compact or k == rh.PROF_BUCKET_KEYS else (None, None)
+                n_inst = c.get("SQ_INSTS_VALU")
+                if n_inst and cpi:
+                    issue.update(frac=n_inst * cpi / (SIMDS * sec * CLOCK_HZ), valu_wave_instructions_per_launch=n_inst,
+                                 cycles_per_instruction=cpi, valu_instructions_per_unit={"per": units[k][1], "value": n_inst * 64 / units[k][0]},
+                                 lds_wave_instructions_per_launch=c.get("SQ_INSTS_LDS"), **detail)
+                wait = None
+                if c.get("SQ_WAVE_CYCLES"):
+                    wait = {"parked_on_waitcnt": c.get("SQ_WAIT_ANY", 0.0) / c["SQ_WAVE_CYCLES"] if c.get("SQ_WAIT_ANY") else None,
+                            "issue_stalled": c.get("SQ_WAIT_INST_ANY", 0.0) / c["SQ_WAVE_CYCLES"] if c.get("SQ_WAIT_INST_ANY") else None,
+                            "what": "SQ_WAIT_ANY / SQ_WAVE_CYCLES and SQ_WAIT_INST_ANY / SQ_WAVE_CYCLES of the counter pass"}
+                e.update(issue=issue, wait=wait, counters_from_this_build=pmc_matches if c else None,
+                         counters_source="profiles/r04_pmc.json (separate rocprofv3 --pmc passes: FETCH_SIZE | WRITE_SIZE | SQ_*; traffic = 2 x "
+                                         "FETCH_SIZE + WRITE_SIZE), profiles/r04_isa_mix.json, profiles/r04_valu_issue.json" if c else None)
         out[p["name"]] = e
     # the fused MLP kernels: flops the matrix cores execute per sample (first layer of a head: 2 K W; relu + second layer run on the
     # VALU; backward: recompute of both heads + dW0 over the augmented input padded to its MFMA tiles)
@@ -565,13 +606,9 @@ def roofline_of(k):
          "bytes_per_launch": k.get("algorithmic_bytes_per_launch"), "bytes_model": k.get("bytes_model"),
          "share_of_step_us": k["us_per_step"],
          "measured": "hipEvents around each launch, eager leg of the same steps after the timed region (the timed steps replay a graph)"}
-    for extra in ("valu_wave_instructions_per_launch", "valu_instructions_per_unit", "valu_busy_frac_from_SQ_ACTIVE_INST_VALU",
-                  "lds_wave_instructions_per_launch", "roof_model", "hbm", "flops_model", "samples_per_step"):
+    for extra in ("issue", "wait", "counters_from_this_build", "counters_source", "flops_model", "samples_per_step", "matrix_pipe"):
         if k.get(extra) is not None:
             r[extra] = k[extra]
-    if r["traffic"] is not None or k.get("bound") == "valu":
-        r["counters_source"] = ("profiles/r03_pmc.json: separate rocprofv3 --pmc passes (FETCH_SIZE | WRITE_SIZE | SQ_*), traffic = 2 x FETCH_SIZE + "
-                                "WRITE_SIZE; used because its source_hash is this build's")
     return r
 
 
@@ -587,8 +624,9 @@ def k1_report(k1, A, args, B):
     traffic = k1_traffic(A, args)
     if traffic:
         out.update(counter_bytes_per_launch=traffic, frac_of_hbm_peak_from_counter_bytes=traffic / (us * 1e-6) / 1e9 / HBM_PEAK_GBS,
-                   note="counter bytes = 2 x FETCH_SIZE + WRITE_SIZE of a separate rocprofv3 --pmc pass (profiles/r03_pmc.json); the "
-                        "SURVEY model over-counts (node rows are L2 hits, the mask travels as 1 byte), so the fraction is taken from the counters")
+                   note="counter bytes = 2 x FETCH_SIZE + WRITE_SIZE of a separate rocprofv3 --pmc pass (profiles/r04_pmc.json) over launches that "
+                        "each write their own slice of a [T, B, 2, A, A] buffer (906 MB: beyond the Infinity Cache); the SURVEY model over-counts "
+                        "(node rows are L2 hits, the mask travels as 1 byte), so the fraction is taken from the counters")
     return out
 
 
@@ -597,12 +635,16 @@ def k1_traffic(A, args):
     correction + WRITE_SIZE), valid for the default workload and for the build the counters were taken on; None otherwise."""
     if A != 3 or args.batch_log2 != 20 or args.gpus != 1 or args.obs_half:
         return None
-    return pmc_counters().get("k_observe", {}).get("traffic_bytes_per_launch")
+    return pmc_counters()[0].get("k_observe", {}).get("traffic_bytes_per_launch")
 
 
 def cpu_baseline(tree, args, T):
-    """The same step on the host cores: C oracle + PyTorch-CPU MLP (oracle/port.py), bounded sample."""
+    """The same step on the host cores, two ways, on bounded samples of the same workload:
+      port       the C oracle (OpenMP) + PyTorch-CPU MLP (oracle/port.py) -- `value`
+      torch_cpu  the reference's op sequence in plain PyTorch on the CPU (oracle/torch_port.py, pinned against the reference's own
+                 gradients by tests/test_oracle_golden.py) -- what the reference is on this box without a GPU"""
     from oracle.port import CpuTrainer
+    from oracle.torch_port import TorchCpuTrainer
 
     arrs = dict(index=tree.index_tensor.cpu().numpy(), value=tree.value_tensor.cpu().numpy(), chance=tree.chance_tensor.cpu().numpy(),
                 expected_value=tree.expected_value_tensor.cpu().numpy(), legal=tree.legal_tensor.cpu().numpy(),
@@ -614,18 +656,37 @@ def cpu_baseline(tree, args, T):
     ct.step(min(lanes, 4096), seed=0)  # warm-up (thread pools, page faults)
     t0 = time.perf_counter()
     n, roll, upd = 0, 0.0, 0.0
-    while n < 2 or (time.perf_counter() - t0 < 12 and n < 6):
+    while n < 1 or (time.perf_counter() - t0 < 12 and n < 6):
         Tc, r, u = ct.step(lanes, seed=1 + n)
         roll += r
         upd += u
         n += 1
     dt = time.perf_counter() - t0
-    return {
+    out = {
         "value": lanes * Tc * n / dt, "unit": "env-steps/s", "cores": cores, "kind": "port",
-        "sample": f"{n} full steps (rollout + update) of 2^{args.cpu_lanes_log2} episodes x T={Tc} on the same tree; "
+        "sample": f"{n} full step(s) (rollout + update) of 2^{args.cpu_lanes_log2} episodes x T={Tc} on the same tree; "
                   f"C oracle (OpenMP) + PyTorch-CPU MLP, {cores} threads",
         "rollout_env_steps_per_sec": lanes * Tc * n / roll, "updates_per_sec_at_sample_batch": n / dt,
+        "host": {"nproc": os.cpu_count(), "torch_num_threads": torch.get_num_threads()},
     }
+    try:
+        tt = TorchCpuTrainer(arrs, width=args.width)
+        tl = 1 << args.cpu_torch_lanes_log2
+        tt.step(min(tl, 4096), seed=0)
+        t0 = time.perf_counter()
+        m, roll_t = 0, 0.0
+        while m < 1 or (time.perf_counter() - t0 < 10 and m < 6):
+            Tt, r, _ = tt.step(tl, seed=1 + m)
+            roll_t += r
+            m += 1
+        dt_t = time.perf_counter() - t0
+        out["torch_cpu"] = {"value": tl * Tt * m / dt_t, "unit": "env-steps/s", "cores": torch.get_num_threads(), "kind": "port",
+                            "sample": f"{m} full step(s) of 2^{args.cpu_torch_lanes_log2} episodes x T={Tt}: the reference's op sequence "
+                                      "(episode.py:194-212, rnad.py:365-425, vtrace.py) in plain PyTorch on the CPU",
+                            "rollout_env_steps_per_sec": tl * Tt * m / roll_t, "updates_per_sec_at_sample_batch": m / dt_t}
+    except Exception as err:  # the second leg must not cost the run its line
+        out["torch_cpu"] = {"error": str(err)[:300]}
+    return out
 
 
 if __name__ == "__main__":

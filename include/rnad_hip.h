@@ -433,6 +433,9 @@ typedef struct rnad_step_params {
 int rnad_step_params_set(rnad_step_params_t *device_params, uint64_t seed, float alpha, float one_minus_alpha, void *stream);
 int rnad_bucket_plan(const rnad_tree_t *tree, int64_t B, int64_t *out);
 int rnad_bucket_map(const rnad_tree_t *tree, int64_t B, int32_t *bucket_of, int32_t *n_groups);
+/* n_shared[b] (host int32 [out[1] buckets]): the env steps a lane of bucket b shares with the whole bucket (above its group, plus the two
+ * at the root of a group that is one subtree) -- the rows of a column of the compact trajectory's `states` that are neither written nor read. */
+int rnad_bucket_shared_steps(const rnad_tree_t *tree, int64_t B, int32_t *n_shared);
 int rnad_rollout_bucketed(const rnad_tree_t *tree, const rnad_traj_t *traj, const float *table, int64_t table_stride,
                           int table_is_policy, const float *value_table, int64_t value_stride, uint64_t seed, int64_t lane0,
                           const rnad_step_params_t *device_params, void *scratch, int32_t *lane_ids, int32_t *items, int32_t *n_items,
@@ -504,7 +507,6 @@ typedef struct rnad_adam_params {
 int rnad_optimizer_step(int n_tensors, const int64_t *sizes, float *const *param, float *grads, float *const *exp_avg,
                         float *const *exp_avg_sq, float *const *step, float *const *target, const rnad_adam_params_t *hp,
                         float *total_norm, int mlp_A, int mlp_W, int mlp_fold, float *packed_param, float *packed_target, void *stream);
-
 /* ------------------------------------------------------------------------------------------------
  * NashConv  --  util/metric.py:93-175 (NashConvData.get_nashconv), level-batched on the GPU
  * instead of one Python frame per state.  joint_policy f32 [S,2A] (device) for every state below

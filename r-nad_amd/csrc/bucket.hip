@@ -1831,6 +1831,18 @@ extern "C" int rnad_bucket_map(const rnad_tree_t *tree, int64_t B, int32_t *buck
     return 0;
 }
 
+extern "C" int rnad_bucket_shared_steps(const rnad_tree_t *tree, int64_t B, int32_t *n_shared) {
+    RNAD_REQUIRE(tree && n_shared, "rnad_bucket_shared_steps: null argument");
+    Plan p;
+    RNAD_REQUIRE(make_plan(tree, B, p), "rnad_bucket_shared_steps: this tree / batch cannot be bucketed (see rnad_bucket_plan)");
+    std::vector<int32_t> path((size_t)p.cut->n_buckets);
+    DeviceGuard guard(tree->device);
+    RNAD_HIP_OK(hipMemcpy(path.data(), p.cut->bucket_path, path.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
+    for (int b = 0; b < p.cut->n_buckets; ++b)
+        n_shared[b] = (path[(size_t)b] & (kSharedRoot - 1)) + ((b < p.cut->n_groups && (path[(size_t)b] & kSharedRoot)) ? 2 : 0);
+    return 0;
+}
+
 namespace {
 // The compact rollout runs one workgroup per work item (k_bucket_rollout_items), the dense one a workgroup per kThreads columns: either
 // leaves one row of alive counts per workgroup.

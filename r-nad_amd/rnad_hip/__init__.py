@@ -719,6 +719,23 @@ def bucket_map(tree, B):
     return out, n_groups.value
 
 
+def bucket_shared_steps(tree, B):
+    """int32 [n_buckets] CPU tensor: the env steps a lane of each bucket shares with its whole bucket (rnad_bucket_shared_steps)."""
+    plan = bucket_plan(tree, B)
+    out = torch.empty((plan.n_buckets,), dtype=I32)
+    _check(lib().rnad_bucket_shared_steps(tree.ptr, B, C.c_void_p(out.data_ptr())))
+    return out
+
+
+def stored_state_slots(tree, buckets, T):
+    """Slots of a compact trajectory that hold a relative state: per column the rows n_shared(bucket) .. T (what the rollout writes and
+    the learner reads; bench.py's algorithmic bytes)."""
+    n = int(buckets.n_items.item())
+    items = buckets.items[:n].cpu().long()
+    shared = bucket_shared_steps(tree, buckets.plan.B).long()[items[:, 2]]
+    return int((items[:, 1] * (T + 1 - shared).clamp(min=0)).sum().item())
+
+
 class Buckets:
     """Lane permutation and learner work list of one bucket-ordered batch (outputs of rnad_rollout_bucketed)."""
 

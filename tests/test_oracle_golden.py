@@ -220,3 +220,48 @@ def test_on_policy_step_losses(name):
     ln, _ = oracle.loss_nerd(out["net"][0], pip, q[0], q[1], valid, turns, masks, float(g.get("hp_neurd_clip", 1e3)), float(g.get("hp_beta", 2.0)))
     np.testing.assert_allclose(lv, g["loss_v"], rtol=1e-4)
     np.testing.assert_allclose(ln, g["loss_nerd"], rtol=1e-3, atol=1e-6)
+
+
+@pytest.mark.parametrize("name", TREES)
+def test_torch_transcription_gives_the_reference_gradients(name):
+    """oracle/torch_port.py (bench.py's cpu_baseline.torch_cpu leg: the reference's op sequence in plain torch on the host cores) on the
+    on-policy fixtures: the reference's own losses and parameter gradients; its rollout plays legal episodes of the tree."""
+    import torch
+
+    from oracle import torch_port as tp
+
+    tree, g = load_tree(name), load("onpolicy_" + name)
+    A = tree["index"].shape[-1]
+    W = int(g["width"])
+    nets = []
+    for tag in ("net", "target", "reg", "reg_"):
+        n = tp.TorchMLP(A, W)
+        n.load_state_dict({k: torch.as_tensor(g[f"w_{tag}_" + k.replace(".", "_")]) for k in n.state_dict()})
+        nets.append(n)
+    tt = {k: torch.as_tensor(tree[k]) for k in ("index", "value", "chance", "expected_value", "legal")}
+    tt["index"] = tt["index"].long()
+    idx = torch.as_tensor(g["indices"]).long()
+    T, B = idx.shape
+    ep = dict(indices=idx, observations=torch.stack([tp.observe(tt, idx[t], t & 1) for t in range(T)]), policy=torch.as_tensor(g["policy"]),
+              actions=torch.nn.functional.one_hot(torch.as_tensor(g["actions"]).long(), A).float(), rewards=torch.as_tensor(g["rewards"]),
+              masks=torch.as_tensor(g["masks"]))
+    assert torch.equal(ep["observations"][:, :, 1, :, 0], ep["masks"])
+    hp = dict(tp.HP, eta=float(g["eta"]), c=float(g.get("hp_c_bar", 1.0)), rho=float(g.get("hp_roh_bar", 1.0)), gamma=float(g.get("hp_vtrace_gamma", 1.0)),
+              clip=float(g.get("hp_neurd_clip", tp.HP["clip"])), threshold=float(g.get("hp_beta", 2.0)))
+    loss, lv, ln = tp.learn_losses(nets, ep, float(g["alpha"]), hp)
+    loss.backward()
+    np.testing.assert_allclose(float(lv.detach()), g["loss_v"], rtol=2e-5)
+    np.testing.assert_allclose(float(ln.detach()), g["loss_nerd"], rtol=1e-4, atol=1e-6)
+    for k, p in nets[0].named_parameters():
+        want = g["g_net_" + k.replace(".", "_")]
+        np.testing.assert_allclose(p.grad.numpy(), want, rtol=1e-4, atol=2e-6 * np.abs(want).max(), err_msg=k)
+    # the rollout leg: every transition it plays is one of the tree's, rewards only on the step into state 0
+    torch.manual_seed(0)
+    played = tp.play(tt, nets[0], 64, 2 * int(tree["depth_bound"]) if "depth_bound" in tree else 16)
+    st, rew = played["indices"], played["rewards"]
+    assert (st[0] == 1).all() and ((rew != 0).sum(0) <= 1).all()
+    for t in range(1, st.shape[0]):
+        moved = st[t] != st[t - 1]
+        assert not moved[(t & 1) == 1].any() if (t & 1) == 1 else True  # the row player's step leaves the state as it is
+        kids = tt["index"][st[t - 1]].reshape(st.shape[1], -1)
+        assert ((kids == st[t].unsqueeze(-1)).any(-1) | ~moved).all()

@@ -24,19 +24,25 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-fvisibility=hidden",
          "-I" + os.path.join(ROOT, "include"), "-Wno-unused-function", "-S", "--cuda-device-only"]
 
-# issue classes, first match wins
+# issue classes, first match wins (the class labels of tools/micro/valu_issue.hip, which measures their cost)
+FAST32 = ("v_fma_f32", "v_add_f32", "v_sub_f32", "v_subrev_f32", "v_mul_f32", "v_and_b32", "v_or_b32", "v_xor_b32", "v_not_b32", "v_lshrrev_b32",
+          "v_add_u32", "v_sub_u32", "v_subrev_u32")
 CLASSES = [
     ("trans32", re.compile(r"^v_(exp|log|rcp|rsq|sqrt|sin|cos)_(f32|f16|legacy_f32|iflag_f32)")),
-    ("f64", re.compile(r"^v_\w+_f64|^v_cvt_f64|^v_cvt_\w+_f64")),
+    ("cvt64", re.compile(r"^v_cvt_f64_|^v_cvt_\w+_f64")),
+    ("f64", re.compile(r"^v_\w+_f64")),
     ("mad_u64", re.compile(r"^v_mad_[ui]64_[ui]32")),
     ("int64", re.compile(r"^v_(lshl_add_u64|lshlrev_b64|lshrrev_b64|ashrrev_i64|add_u64|sub_u64|add_i64)")),
     ("mov64", re.compile(r"^v_mov_b64")),
-    ("pk32", re.compile(r"^v_pk_(fma|mul|add)_f32|^v_pk_mov_b32")),
+    ("pk32", re.compile(r"^v_pk_")),
     ("mul32", re.compile(r"^v_mul_(lo|hi)_[ui]32")),
     ("mfma", re.compile(r"^v_mfma|^v_smfmac")),
     ("dpp_move", re.compile(r"^v_(readlane|readfirstlane|writelane|permlane|swap)")),
     ("mov32", re.compile(r"^v_(mov_b32|accvgpr)")),
-    ("valu32", re.compile(r"^v_")),
+    ("fmac", re.compile(r"^v_fmac_f32")),
+    ("cndmask", re.compile(r"^v_cndmask_b32")),
+    ("fast32", re.compile(r"^(" + "|".join(FAST32) + r")(_e32|_e64|_sdwa|_dpp)?$")),
+    ("slow32", re.compile(r"^v_")),
     ("lds", re.compile(r"^ds_")),
     ("vmem", re.compile(r"^(global|buffer|flat|scratch)_")),
     ("smem", re.compile(r"^s_(load|buffer_load|store|atomic)")),
@@ -44,7 +50,7 @@ CLASSES = [
     ("branch", re.compile(r"^s_(branch|cbranch|setpc|swappc|endpgm)")),
     ("salu", re.compile(r"^s_")),
 ]
-VALU_CLASSES = ("trans32", "f64", "mad_u64", "int64", "mov64", "pk32", "mul32", "dpp_move", "mov32", "valu32")
+VALU_CLASSES = ("trans32", "cvt64", "f64", "mad_u64", "int64", "mov64", "pk32", "mul32", "dpp_move", "mov32", "fmac", "cndmask", "fast32", "slow32")
 
 
 def classify(op):
@@ -81,9 +87,10 @@ def kernels_of(asm_path):
             bodies[cur] = []
             continue
         if cur is not None:
-            bodies[cur].append(ln)
-            if ln.strip().startswith("s_endpgm"):
+            if ln.startswith(".Lfunc_end"):  # (not the first s_endpgm: a kernel with an early return has several)
                 cur = None
+            else:
+                bodies[cur].append(ln)
     meta = {}
     blob = "\n".join(text)
     # resource usage: the `.set <symbol>.num_vgpr, N` lines that follow each kernel
@@ -154,7 +161,7 @@ def kernel_mix(source, pattern, loops_only=True, defines=()):
     body, meta = kernels[name]
     hist, ops = histogram(body, loops_only)
     valu = sum(hist[c] for c in VALU_CLASSES)
-    return {"kernel": name.split("(")[0], "loops_only": loops_only, "classes": dict(hist), "valu": valu,
+    return {"kernel": name.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0], "loops_only": loops_only, "classes": dict(hist), "valu": valu,
             "share": {c: hist[c] / valu for c in VALU_CLASSES if hist[c]} if valu else {}, "resources": meta,
             "top_ops": ops.most_common(25)}
 

@@ -21,8 +21,10 @@ tree.generate_native(seed=0)
 ep = Episodes(tree, B, seed=1)
 ep.generate(MLP(3, 256, device=dev))
 T = ep.t_eff + 1
-obs = torch.empty((B, 2, 3, 3), device=dev)
-bits = torch.empty((B,), dtype=torch.uint8, device=dev)
+# every launch writes its own [B, 2, A, A] slice of a [T, B, 2, A, A] buffer (906 MB at T = 12: larger than the 256 MiB Infinity Cache, so the
+# fabric counters cannot be served from it -- one 75 MB buffer rewritten 36 times could be)
+obs_all = torch.empty((T, B, 2, 3, 3), device=dev)
+bits_all = torch.empty((T, B), dtype=torch.uint8, device=dev)
 torch.cuda.synchronize()
 # calibration: a 160 MiB float4 streaming copy = 167 772 160 B read + 167 772 160 B written (same bytes as one K1 launch's model)
 src = torch.randn((B * 40,), device=dev)
@@ -32,6 +34,6 @@ for _ in range(3):
 torch.cuda.synchronize()
 for rep in range(3):
     for t in range(T):
-        rnad_hip.observe(tree.handle(), ep.indices[t], t & 1, obs=obs, mask_bits=bits)
+        rnad_hip.observe(tree.handle(), ep.indices[t], t & 1, obs=obs_all[t], mask_bits=bits_all[t])
 torch.cuda.synchronize()
 print("done", T)

@@ -78,6 +78,20 @@ KERNEL32(v_add3_u32, "v_add3_u32 %0, %0, %1, %1", uint32_t, 77u)
 KERNEL32(v_sub_co_u32, "v_sub_co_u32 %0, vcc, %0, %1", uint32_t, 77u)
 KERNEL32(v_cvt_f32_i32, "v_cvt_f32_i32 %0, %0", uint32_t, 77u)
 KERNEL32(v_ldexp_f32, "v_ldexp_f32 %0, %0, 1", float, 1.0f)
+KERNEL32(v_or_b32, "v_or_b32 %0, %0, %1", uint32_t, 77u)
+KERNEL32(v_sub_u32, "v_sub_u32 %0, %0, %1", uint32_t, 77u)
+KERNEL32(v_subrev_f32, "v_subrev_f32 %0, %0, %1", float, 1.0f)
+KERNEL32(v_ashrrev_i32, "v_ashrrev_i32 %0, 3, %0", uint32_t, 77u)
+KERNEL32(v_not_b32, "v_not_b32 %0, %0", uint32_t, 77u)
+KERNEL32(v_mul_u32_u24, "v_mul_u32_u24 %0, %0, %1", uint32_t, 77u)
+KERNEL32(v_lshl_or_b32, "v_lshl_or_b32 %0, %0, 3, %1", uint32_t, 77u)
+KERNEL32(v_cmp_eq_u32, "v_cmp_eq_u32 vcc, %0, %1", uint32_t, 77u)
+KERNEL32(v_cmp_ne_u32_sgpr, "v_cmp_ne_u32 s[20:21], %0, %1", uint32_t, 77u)
+KERNEL32(v_cvt_u32_f32, "v_cvt_u32_f32 %0, %0", float, 1.0f)
+KERNEL32(v_trunc_f32, "v_trunc_f32 %0, %0", float, 1.0f)
+KERNEL32(v_alignbit_b32, "v_alignbit_b32 %0, %0, %1, 7", uint32_t, 77u)
+KERNEL32(v_fma_f32_sgpr, "v_fma_f32 %0, %0, s20, %0", float, 1.0f)
+KERNEL32(v_add_f32_sgpr, "v_add_f32 %0, s20, %0", float, 1.0f)
 KERNEL32(v_cmp_lt_f32, "v_cmp_lt_f32 vcc, %0, %1", float, 1.0f)
 KERNEL32(v_cmp_sgpr, "v_cmp_lt_f32 s[20:21], %0, %1", float, 1.0f)
 KERNEL32(v_and_b32, "v_and_b32 %0, %0, %1", uint32_t, 77u)
@@ -258,18 +272,24 @@ int main(int argc, char **argv) {
         int per_iter;
     };
 #define E(NAME, CLS) {#NAME, CLS, k_##NAME, 32}
+    // class labels: tools/isa_hist.py sorts a kernel's instructions into the same classes (fast32 = the opcodes that measure ~1.8 cycles;
+    // every other 32-bit VALU opcode is priced as slow32)
     const Entry entries[] = {
-        E(v_fma_f32, "valu32"), E(v_add_f32, "valu32"), E(v_sub_f32, "valu32"), E(v_mul_f32, "valu32"), E(v_fmac_f32, "valu32"),
-        E(v_min_f32, "valu32"), E(v_max_f32, "valu32"), E(v_med3_f32, "valu32"), E(v_mov_b32, "mov32"), E(v_cndmask_b32, "cndmask"),
-        E(v_cndmask_e64, "cndmask"), E(v_cndmask_0_e64, "cndmask"), {"v_cmp + v_cndmask (pair)", "cndmask", k_cmp_then_cndmask, 32},
-        E(v_cmp_lt_f32, "valu32"), E(v_cmp_sgpr, "valu32"), E(v_and_b32, "valu32"), E(v_xor_b32, "valu32"), E(v_bfe_i32, "valu32"),
-        E(v_bfe_u32, "valu32"), E(v_and_or_b32, "valu32"), E(v_bfi_b32, "valu32"), E(v_lshlrev_b32, "valu32"), E(v_lshrrev_b32, "valu32"),
-        E(v_add_u32, "valu32"), E(v_add3_u32, "valu32"), E(v_lshl_add_u32, "valu32"), E(v_add_co_u32, "valu32"), E(v_sub_co_u32, "valu32"),
-        E(v_addc_co_u32, "valu32"), E(v_mul_lo_u32, "mul32"), E(v_mul_hi_u32, "mul32"), E(v_mad_u32_u24, "valu32"), E(v_cvt_f32_u32, "valu32"),
-        E(v_cvt_f32_i32, "valu32"), E(v_cvt_i32_f32, "valu32"), E(v_rndne_f32, "valu32"), E(v_ldexp_f32, "valu32"), E(v_rcp_f32, "trans32"),
-        E(v_exp_f32, "trans32"), E(v_log_f32, "trans32"), E(v_readfirstlane, "dpp_move"), E(v_mov_dpp, "valu32"), E(v_mov_b64, "mov64"),
-        E(v_lshl_add_u64, "int64"), E(v_lshlrev_b64, "int64"), E(v_add_f64, "f64"), E(v_fma_f64, "f64"), E(v_cvt_f64_f32, "f64"),
-        E(v_mad_u64_u32, "mad_u64"), E(v_pk_fma_f32, "pk32"), E(v_pk_mul_f32, "pk32"), E(v_pk_add_f32, "pk32"),
+        E(v_fma_f32, "fast32"), E(v_add_f32, "fast32"), E(v_sub_f32, "fast32"), E(v_subrev_f32, "fast32"), E(v_mul_f32, "fast32"),
+        E(v_fma_f32_sgpr, "fast32"), E(v_add_f32_sgpr, "fast32"), E(v_and_b32, "fast32"), E(v_or_b32, "fast32"), E(v_xor_b32, "fast32"),
+        E(v_not_b32, "fast32"), E(v_lshrrev_b32, "fast32"), E(v_add_u32, "fast32"), E(v_sub_u32, "fast32"), E(v_mov_b32, "mov32"),
+        E(v_fmac_f32, "fmac"), E(v_min_f32, "slow32"), E(v_max_f32, "slow32"), E(v_med3_f32, "slow32"), E(v_cndmask_e64, "cndmask"),
+        E(v_cndmask_0_e64, "cndmask"), {"v_cmp + v_cndmask (pair, vcc)", "pair", k_cmp_then_cndmask, 32},
+        {"v_cndmask_b32 vcc, back to back", "other", k_v_cndmask_b32, 32}, E(v_cmp_lt_f32, "slow32"), E(v_cmp_sgpr, "slow32"),
+        E(v_cmp_eq_u32, "slow32"), E(v_cmp_ne_u32_sgpr, "slow32"), E(v_bfe_i32, "slow32"), E(v_bfe_u32, "slow32"), E(v_and_or_b32, "slow32"),
+        E(v_bfi_b32, "slow32"), E(v_lshlrev_b32, "slow32"), E(v_ashrrev_i32, "slow32"), E(v_lshl_or_b32, "slow32"), E(v_alignbit_b32, "slow32"),
+        E(v_add3_u32, "slow32"), E(v_lshl_add_u32, "slow32"), E(v_add_co_u32, "slow32"), E(v_sub_co_u32, "slow32"), E(v_addc_co_u32, "slow32"),
+        E(v_mul_u32_u24, "slow32"), E(v_mad_u32_u24, "slow32"), E(v_cvt_f32_u32, "slow32"), E(v_cvt_f32_i32, "slow32"), E(v_cvt_i32_f32, "slow32"),
+        E(v_cvt_u32_f32, "slow32"), E(v_rndne_f32, "slow32"), E(v_trunc_f32, "slow32"), E(v_ldexp_f32, "slow32"), E(v_mov_dpp, "slow32"),
+        E(v_mul_lo_u32, "mul32"), E(v_mul_hi_u32, "mul32"), E(v_rcp_f32, "trans32"), E(v_exp_f32, "trans32"), E(v_log_f32, "trans32"),
+        E(v_readfirstlane, "dpp_move"), E(v_mov_b64, "mov64"), E(v_lshl_add_u64, "int64"), E(v_lshlrev_b64, "int64"), E(v_add_f64, "f64"),
+        E(v_fma_f64, "f64"), E(v_cvt_f64_f32, "cvt64"), E(v_mad_u64_u32, "mad_u64"), E(v_pk_fma_f32, "pk32"), E(v_pk_mul_f32, "pk32"),
+        E(v_pk_add_f32, "pk32"),
         {"ds_add_u64 distinct, stride 1", "lds", k_ds_add_u64<1, 1>, 32}, {"ds_add_u64 distinct, stride 4", "lds", k_ds_add_u64<1, 4>, 32},
         {"ds_add_u64 distinct, stride 5", "lds", k_ds_add_u64<1, 5>, 32}, {"ds_add_u64 4 lanes/address", "lds", k_ds_add_u64<4, 5>, 32},
         {"ds_add_u64 8 lanes/address", "lds", k_ds_add_u64<8, 5>, 32}, {"ds_add_u64 64 lanes/address", "lds", k_ds_add_u64<64, 5>, 32},

@@ -2,11 +2,11 @@
 """One JSON with the counter evidence bench.py's roofline reads, from the per-kernel summaries of separate rocprofv3 passes
 (tools/pmc_run.sh: FETCH_SIZE, WRITE_SIZE, SQ issue counters -- each in its own run with --kernel-trace only):
 
-    tools/pmc_json.py <fetch.csv> <write.csv> <sq.csv> <out.json> [<k1_fetch.csv> <k1_write.csv>]
+    tools/pmc_json.py <fetch.csv> <write.csv> <sq.csv> <out.json> [<k1_fetch.csv> <k1_write.csv> [<mfma.csv>]]
 
 Per kernel: HBM traffic = 2 x FETCH_SIZE + WRITE_SIZE (KiB counters; FETCH_SIZE doubled as /opt/skills/guides/MI355X_MICROARCH.md
-prescribes for gfx950), SQ_INSTS_VALU (wave-instructions), SQ_ACTIVE_INST_VALU (quad-cycles the VALU was busy), SQ_INSTS_LDS, the
-durations of the passes.  `source_hash` names the build (rnad_hip.source_hash()): bench.py uses the file only while it matches."""
+prescribes for gfx950), SQ_INSTS_VALU (wave-instructions), SQ_WAVE_CYCLES / SQ_WAIT_ANY / SQ_WAIT_INST_ANY (quad-cycles: resident, parked on
+s_waitcnt, issue-stalled), SQ_INSTS_LDS, the durations of the passes.  `source_hash` names the build (rnad_hip.source_hash()): bench.py uses the file only while it matches."""
 import csv
 import json
 import os
@@ -49,10 +49,17 @@ def main():
         if k in sq:
             r = sq[k]
             e.update(duration_us_sq_pass=float(r["mean_duration_us"]), launches=int(r["launches"]))
-            for c in ("SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_INSTS_LDS", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY"):
+            for c in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY"):
                 if r.get(c + "_mean"):
                     e[c] = float(r[c + "_mean"])
         out["kernels"][k] = e
+    if len(sys.argv) > 7:  # matrix-pipe busy cycles of the MLP kernels (their own pass)
+        for k, r in load(sys.argv[7]).items():
+            e = out["kernels"].setdefault(k, {})
+            for c in ("SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CYCLES", "SQ_INSTS_VALU"):
+                if r.get(c + "_mean"):
+                    e[c + "_mfma_pass"] = float(r[c + "_mean"])
+            e["duration_us_mfma_pass"] = float(r["mean_duration_us"])
     with open(sys.argv[4], "w") as f:
         json.dump(out, f, indent=1)
     print(json.dumps({k: {"traffic": v.get("traffic_bytes_per_launch"), "valu": v.get("SQ_INSTS_VALU")} for k, v in out["kernels"].items()}))
