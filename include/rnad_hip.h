@@ -147,6 +147,11 @@ int64_t rnad_mlp_fold_packed_size(int A, int W);
 int rnad_mlp_pack_fold_multi(int n_nets, int A, int W, const float *const *weights, float *const *packed, void *stream);
 int rnad_mlp_forward_fold(int n_nets, int64_t N, const int32_t *rows, const int64_t *n_rows, int A, int W, const float *const *packed,
                           const void *obs, int obs_half, float *const *logits, float *const *value, void *stream);
+/* A tabular ACTOR on (a row list of) the tree's 2S observations: the policy head of one net -> logits [2S, A] and, from the kernel's
+ * epilogue, its policy rows [2S, rnad_bucket_policy_row_stride(A)] (net.py:45-46 under the mover's legal bits): the table
+ * rnad_bucket_sort / rnad_bucket_play gather from (table_is_policy = 1) without a policy-head launch of their own.  fold: FOLD image. */
+int rnad_mlp_forward_actor(const rnad_tree_t *tree, const int32_t *rows, const int64_t *n_rows, int W, int fold, const float *packed,
+                           const void *obs, int obs_half, float *logits, float *policy_rows, void *stream);
 int rnad_mlp_backward_fold(int64_t N, const int32_t *rows, const int64_t *n_rows, int A, int W, const float *packed, const void *obs,
                            int obs_half, const float *dlogits, const float *dvalue, float *g_vw0, float *g_vb0, float *g_vw1, float *g_vb1,
                            float *g_pw0, float *g_pb0, float *g_pw1, float *g_pb1, float *workspace, void *stream);
@@ -472,16 +477,21 @@ int rnad_bucket_alive(const rnad_tree_t *tree, int T_cap, int64_t B, const void 
  * rnad_bucket_sort = the keys pass + the sort; it reads the actor's rows of the UPPER states of the cut and of the absorbing state
  * only (rnad_bucket_plan / rnad_bucket_map say which).  group_flags (int32 [2S], optional): 1 for both rows of every state inside a
  * group some lane descends into, 0 elsewhere -- after rnad_compact_valid, the rows the actor still has to be evaluated on.
+ * staged_rows (int32 [2S] capacity) / n_staged (device int64), optional: the same rows as an ascending LIST with its length, written by the
+ * sort's last kernel (no flags, no compaction: what a caller hands to rnad_mlp_forward_rows and to rnad_bucket_play as rows / n_rows).
+ * visited (int32 [2S], optional): cleared here for the rollout (then pass visited_is_clear = 1 to rnad_bucket_play, which otherwise clears it
+ * with a launch of its own).
  * rnad_bucket_play = the rollout itself (+ the alive counts), same scratch, same seed / lane0 / device_params, the lane_ids and
  * the work list (items / n_items) of the sort; with a logits table (table_is_policy == 0) `rows` / `n_rows` name the rows that were evaluated since (their policy head is
  * taken here), NULL = all. */
 int rnad_bucket_sort(const rnad_tree_t *tree, int T_cap, int64_t B, const float *table, int64_t table_stride, int table_is_policy,
                      uint64_t seed, int64_t lane0, const rnad_step_params_t *device_params, void *scratch, int32_t *lane_ids,
-                     int32_t *items, int32_t *n_items, double *norm, int32_t *group_flags, void *stream);
+                     int32_t *items, int32_t *n_items, double *norm, int32_t *group_flags, int32_t *staged_rows, int64_t *n_staged,
+                     int32_t *visited, void *stream);
 int rnad_bucket_play(const rnad_tree_t *tree, int T_cap, int64_t B, const float *table, int64_t table_stride, int table_is_policy,
                      const int32_t *rows, const int64_t *n_rows, uint64_t seed, int64_t lane0, const rnad_step_params_t *device_params,
                      void *scratch, const int32_t *lane_ids, const int32_t *items, const int32_t *n_items, double *norm, void *states,
-                     int32_t *alive, uint64_t *acts, float *final_reward, int32_t *visited, void *stream);
+                     int32_t *alive, uint64_t *acts, float *final_reward, int32_t *visited, int visited_is_clear, void *stream);
 int rnad_bucket_finish(const rnad_tree_t *tree, int64_t B, const double *norm, const rnad_learn_params_t *hp, void *accumulators,
                        double *losses, float *dlogit_tab, float *dv_tab, const int32_t *rows, const int64_t *n_rows, void *stream);
 

@@ -86,20 +86,22 @@ __global__ __launch_bounds__(kThreads) void k_upper_walk(int n, int AAC, const i
 // The cut of `tree` for tables of `rows` rows, on the host (O(S)).
 struct HostCut {
     int rows = 0, n_groups = 0, n_upper = 0, n_buckets = 0, max_path = 0;
-    std::vector<int32_t> bucket_of, lo, path, upper_list, path_states;  // path_states: [n_buckets][max(max_path, 1)]
+    std::vector<int32_t> bucket_of, lo, span, path, upper_list, path_states;  // path_states: [n_buckets][max(max_path, 1)]
+    std::vector<int32_t> group_by_lo;  // the groups sorted by lo (group ids follow the upper states they hang below, not the state ids)
 };
 
 HostCut build_cut(const rnad_tree_t *tree, int rows) {
     HostCut h;
     h.rows = rows;
     const int64_t S = tree->S;
-    std::vector<int32_t> &bucket_of = h.bucket_of, &lo = h.lo, &path = h.path, &upper_list = h.upper_list;
+    std::vector<int32_t> &bucket_of = h.bucket_of, &lo = h.lo, &span = h.span, &path = h.path, &upper_list = h.upper_list;
     bucket_of.assign((size_t)S, -1);
     std::vector<int32_t> parent_upper((size_t)S, 0);  // upper state -> the upper state above it (0: the root)
     std::vector<int32_t> group_parent;                // bucket -> the upper state it hangs below (0: none)
     auto is_upper = [&](int64_t s) { return tree->subtree_size[(size_t)s] > rows; };
     if (!is_upper(1)) {  // the whole tree fits one table: a single group, nothing above it
         lo.push_back(1);
+        span.push_back((int32_t)tree->subtree_size[1]);
         path.push_back(kSharedRoot);  // (every lane starts in state 1)
         group_parent.push_back(0);
         for (int64_t s = 1; s < S; ++s)
@@ -115,6 +117,7 @@ HostCut build_cut(const rnad_tree_t *tree, int rows) {
                 if (g_lo < 0) return;
                 const int32_t gid = (int32_t)lo.size();
                 lo.push_back((int32_t)g_lo);
+                span.push_back((int32_t)(g_hi - g_lo));
                 // a group of ONE subtree: every lane of the bucket also shares the group's root for two more steps (kSharedRoot)
                 path.push_back(2 * (level + 1) | (g_subtrees == 1 ? kSharedRoot : 0));
                 group_parent.push_back((int32_t)u);
@@ -149,6 +152,7 @@ HostCut build_cut(const rnad_tree_t *tree, int rows) {
         const int32_t u = upper_list[(size_t)i];
         bucket_of[(size_t)u] = h.n_groups + i;
         lo.push_back(u);
+        span.push_back(0);
         path.push_back(2 * tree->level_of[(size_t)u] + 2);
         group_parent.push_back(u);
     }
@@ -173,6 +177,9 @@ HostCut build_cut(const rnad_tree_t *tree, int rows) {
         }
     }
     if (upper_list.empty()) upper_list.push_back(0);
+    h.group_by_lo.resize((size_t)h.n_groups);
+    for (int g = 0; g < h.n_groups; ++g) h.group_by_lo[(size_t)g] = g;
+    std::sort(h.group_by_lo.begin(), h.group_by_lo.end(), [&](int32_t a, int32_t b) { return lo[(size_t)a] < lo[(size_t)b]; });
     return h;
 }
 
@@ -197,8 +204,9 @@ const BucketCut *get_cut(const rnad_tree_t *tree, int rows) {
         return src.empty() || hipMemcpy(*dst, src.data(), src.size() * sizeof(int32_t), hipMemcpyHostToDevice) == hipSuccess;
     };
     if (!guard.ok || !up(&cut.bucket_of, h.bucket_of) || !up(&cut.bucket_lo, h.lo) || !up(&cut.bucket_path, h.path) ||
-        !up(&cut.upper_list, h.upper_list) || !up(&cut.path_states, h.path_states)) {
-        for (int32_t *ptr : {cut.bucket_of, cut.bucket_lo, cut.bucket_path, cut.upper_list, cut.path_states})
+        !up(&cut.upper_list, h.upper_list) || !up(&cut.path_states, h.path_states) || !up(&cut.bucket_span, h.span) ||
+        !up(&cut.group_by_lo, h.group_by_lo)) {
+        for (int32_t *ptr : {cut.bucket_of, cut.bucket_lo, cut.bucket_path, cut.upper_list, cut.path_states, cut.bucket_span, cut.group_by_lo})
             if (ptr) (void)hipFree(ptr);
         return nullptr;
     }
@@ -804,15 +812,25 @@ __global__ __launch_bounds__(kSortThreads) void k_bucket_scan(int n_blocks, int 
 }
 
 // lane_ids[bucket_start[key] + (lanes of earlier blocks with that key) + (earlier lanes of this block with that key)] = lane.
-// The waves of a workgroup take turns (each owns 256 consecutive lanes) and a wave's rows are issued in order, so the rank a lane
-// draws from the LDS counter does not depend on wave scheduling; within one LDS atomic instruction the lanes that hit the same
-// counter are served in lane order.  The permutation is therefore the stable counting sort, the same on every run.
+// The 16 waves of a workgroup each own 256 consecutive lanes.  They rank their lanes against `wave_rows` counter rows in LDS (16, 8, 4, 2
+// or 1: as many as fit beside the bucket prefixes -- 16 up to ~1 300 buckets, 8 up to ~3 600): row r serves the waves 16 r / R .. 16 (r + 1)
+// / R - 1, which take turns in wave order; within one LDS atomic instruction the lanes that hit the same counter are served in lane
+// order, and a wave's instructions are issued in order.  The rows are then turned into their starting offsets -- row r starts where rows
+// 0 .. r - 1 end -- and the ranks become positions: the stable counting sort, the same permutation on every run.
 // bucket_start (the exclusive prefix of the column totals) is taken by every workgroup for itself; workgroup 0 also writes the
 // learner's work list (items_phase).
+// Staged actors (trees that are large next to the batch; rnad_bucket_sort): staged_rows receives, ascending, both players' rows of every
+// state inside a group some lane descends into (totals[group] > 0) -- what the actor still has to be evaluated on before the rollout --
+// and *n_staged their number: every workgroup takes the exclusive prefix of the non-empty groups' spans for itself and writes the
+// groups blockIdx.x, blockIdx.x + gridDim.x, ...  (Before r04: k_group_flags + a three-launch compaction of 2S flags.)  visited (int32
+// [2S], optional) is cleared here for the rollout that follows (the two rows of the absorbing state are set: absorbed slots show them).
 __global__ __launch_bounds__(kSortThreads) void k_bucket_scatter(int64_t B, int n_buckets, const int32_t *__restrict__ keys,
                                                                  const int32_t *__restrict__ hist, const int32_t *__restrict__ totals, int chunk,
                                                                  Item *__restrict__ items, int32_t *__restrict__ n_items,
-                                                                 int32_t *__restrict__ lane_ids, int wave_counts) {
+                                                                 int32_t *__restrict__ lane_ids, int wave_rows, int64_t S, int n_groups,
+                                                                 const int32_t *__restrict__ bucket_lo, const int32_t *__restrict__ bucket_span,
+                                                                 const int32_t *__restrict__ group_by_lo, int32_t *__restrict__ staged_rows,
+                                                                 int64_t *__restrict__ n_staged, int32_t *__restrict__ visited) {
     extern __shared__ int32_t cnt[];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int64_t base = (int64_t)blockIdx.x * kSortLanes + (int64_t)wave * (kSortLanes / 16);
@@ -822,50 +840,79 @@ __global__ __launch_bounds__(kSortThreads) void k_bucket_scatter(int64_t B, int 
         const int64_t b = base + r * 64 + lane;
         key[r] = b < B ? keys[b] : -1;
     }
+    if (visited) {
+        for (int64_t r = (int64_t)blockIdx.x * kSortThreads + threadIdx.x; r < 2 * S; r += (int64_t)gridDim.x * kSortThreads)
+            visited[r] = (r == 0 || r == S) ? 1 : 0;
+    }
+    if (staged_rows) {
+        // exclusive prefix over the groups of (non-empty ? span : 0), in the LDS words the sort uses afterwards
+        __shared__ int32_t wave_s[16];
+        __shared__ int32_t carry_s;
+        int32_t *pre = cnt;  // [n_groups + 1]
+        if (threadIdx.x == 0) carry_s = 0;
+        __syncthreads();
+        for (int k0 = 0; k0 < n_groups; k0 += kSortThreads) {  // k: position in ascending order of the groups' first state
+            const int k = k0 + threadIdx.x;
+            const int g = k < n_groups ? group_by_lo[k] : 0;
+            const int32_t n = (k < n_groups && totals[g] > 0) ? bucket_span[g] : 0;
+            int32_t incl = n;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const int32_t o = __shfl_up(incl, off, 64);
+                if (lane >= off) incl += o;
+            }
+            if (lane == 63) wave_s[wave] = incl;
+            __syncthreads();
+            int32_t before = carry_s;
+            for (int w = 0; w < wave; ++w) before += wave_s[w];
+            if (k < n_groups) pre[k] = before + incl - n;
+            __syncthreads();
+            if (threadIdx.x == kSortThreads - 1) carry_s = before + incl;
+            __syncthreads();
+        }
+        const int32_t total = carry_s;
+        if (blockIdx.x == 0 && threadIdx.x == 0) *n_staged = 2 * (int64_t)total;
+        for (int k = blockIdx.x * 16 + wave; k < n_groups; k += gridDim.x * 16) {  // a wave per group
+            const int g = group_by_lo[k];
+            if (totals[g] <= 0) continue;
+            const int32_t lo = bucket_lo[g], n = bucket_span[g], at = pre[k];
+            for (int j = lane; j < n; j += 64) {
+                staged_rows[at + j] = lo + j;
+                staged_rows[total + at + j] = (int32_t)S + lo + j;
+            }
+        }
+        __syncthreads();
+    }
     items_phase(n_buckets, chunk, totals, cnt, cnt + n_buckets, blockIdx.x == 0, items, n_items);  // cnt = bucket_start
     __syncthreads();
     const int32_t *row = hist + (int64_t)blockIdx.x * n_buckets;
     for (int i = threadIdx.x; i < n_buckets; i += kSortThreads) cnt[i] += row[i];
     __syncthreads();
-    if (wave_counts) {
-        // Every wave ranks its own lanes against a counter row of its own (all 16 at once), the rows are then turned into the waves'
-        // starting offsets -- wave w starts where waves 0 .. w - 1 end -- and the ranks become positions.  Same permutation as the
-        // turn-taking loop below: a lane's position is the bucket's start + the tile's offset + the lanes of earlier waves + its rank
-        // among its wave's (rows in order, lanes of one atomic instruction in lane order).
-        int32_t *wcnt = cnt + 2 * n_buckets + 1;  // [16][n_buckets]
-        for (int i = threadIdx.x; i < 16 * n_buckets; i += kSortThreads) wcnt[i] = 0;
-        __syncthreads();
-        int32_t rank[kSortLanes / kSortThreads];
+    // a lane's position = the bucket's start + the tile's offset (cnt) + the lanes of the tile's earlier counter rows + its rank in its row
+    const int R = wave_rows, G = 16 / R, my_row = wave / G;
+    int32_t *wcnt = cnt + 2 * n_buckets + 1;  // [R][n_buckets]
+    for (int i = threadIdx.x; i < R * n_buckets; i += kSortThreads) wcnt[i] = 0;
+    __syncthreads();
+    int32_t rank[kSortLanes / kSortThreads];
+    for (int turn = 0; turn < G; ++turn) {  // the waves of a row, in wave order
+        if (wave % G == turn) {
 #pragma unroll
-        for (int r = 0; r < kSortLanes / kSortThreads; ++r)
-            rank[r] = key[r] >= 0 ? atomicAdd(&wcnt[wave * n_buckets + key[r]], 1) : 0;
-        __syncthreads();
-        for (int i = threadIdx.x; i < n_buckets; i += kSortThreads) {
-            int32_t at = cnt[i];
-            for (int w = 0; w < 16; ++w) {
-                const int32_t n = wcnt[w * n_buckets + i];
-                wcnt[w * n_buckets + i] = at;
-                at += n;
-            }
-        }
-        __syncthreads();
-#pragma unroll
-        for (int r = 0; r < kSortLanes / kSortThreads; ++r)
-            if (key[r] >= 0) lane_ids[wcnt[wave * n_buckets + key[r]] + rank[r]] = (int32_t)(base + r * 64 + lane);
-        return;
-    }
-    for (int turn = 0; turn < 16; ++turn) {
-        if (turn == wave) {
-#pragma unroll
-            for (int r = 0; r < kSortLanes / kSortThreads; ++r) {
-                if (key[r] >= 0) {
-                    const int32_t pos = atomicAdd(&cnt[key[r]], 1);
-                    lane_ids[pos] = (int32_t)(base + r * 64 + lane);
-                }
-            }
+            for (int r = 0; r < kSortLanes / kSortThreads; ++r) rank[r] = key[r] >= 0 ? atomicAdd(&wcnt[my_row * n_buckets + key[r]], 1) : 0;
         }
         __syncthreads();
     }
+    for (int i = threadIdx.x; i < n_buckets; i += kSortThreads) {
+        int32_t at = cnt[i];
+        for (int w = 0; w < R; ++w) {
+            const int32_t n = wcnt[w * n_buckets + i];
+            wcnt[w * n_buckets + i] = at;
+            at += n;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < kSortLanes / kSortThreads; ++r)
+        if (key[r] >= 0) lane_ids[wcnt[my_row * n_buckets + key[r]] + rank[r]] = (int32_t)(base + r * 64 + lane);
 }
 
 // ---------------------------------------------------------------------------------------- 3. rollout in bucket order
@@ -1947,7 +1994,8 @@ int rollout_bucketed_impl(const rnad_tree_t *tree, const RolloutBuffers &tr, boo
                           int table_is_policy, const float *value_table, int64_t value_stride, uint64_t seed, int64_t lane0,
                           const rnad_step_params_t *device_params, void *scratch, int32_t *lane_ids, int32_t *items, int32_t *n_items,
                           double *norm, hipStream_t stream, int phases = 3, int32_t *group_flags = nullptr,
-                          const int32_t *play_rows = nullptr, const int64_t *n_play_rows = nullptr) {
+                          const int32_t *play_rows = nullptr, const int64_t *n_play_rows = nullptr, int32_t *staged_rows = nullptr,
+                          int64_t *n_staged = nullptr, bool visited_is_clear = false) {
     Plan p;
     RNAD_REQUIRE(make_plan(tree, tr.B, p), "rnad_rollout_bucketed: this tree / batch cannot be bucketed (see rnad_bucket_plan)");
     const int64_t B = tr.B, S = tree->S;
@@ -1955,7 +2003,9 @@ int rollout_bucketed_impl(const rnad_tree_t *tree, const RolloutBuffers &tr, boo
     const int n_steps = std::min(p.cut->max_path, tr.T_cap), nb = p.cut->n_buckets;
     ProfScope prof(PROF_ACT, stream);
     const bool sort_phase = (phases & 1) != 0, play_phase = (phases & 2) != 0;
-    if (tr.visited && play_phase)  // cleared by a kernel (memset nodes of captured graphs are not to be trusted, see learn_bucketed_impl)
+    // `visited` is cleared by a kernel (memset nodes of captured graphs are not to be trusted, see learn_bucketed_impl): by the sort's last
+    // kernel when this call (or the rnad_bucket_sort before it, visited_is_clear) runs one, by a launch of its own otherwise
+    if (tr.visited && play_phase && !sort_phase && !visited_is_clear)
         hipLaunchKernelGGL(k_clear_visited, dim3(blocks_for(2 * S, kThreads * 4)), dim3(kThreads), 0, stream, 2 * S, S, tr.visited);
     const float *policy_tab = table;
     int64_t policy_stride = table_stride;
@@ -2003,13 +2053,18 @@ int rollout_bucketed_impl(const rnad_tree_t *tree, const RolloutBuffers &tr, boo
         ProfScope sort_passes(PROF_BUCKET_SORT, stream);
         if (!keys_with_hist) hipLaunchKernelGGL(k_bucket_hist, dim3(p.sort_blocks), dim3(kSortThreads), lds, stream, B, nb, (const int32_t *)s.keys, s.hist);
         hipLaunchKernelGGL(k_bucket_scan, dim3((nb + kScanCols - 1) / kScanCols), dim3(kSortThreads), 0, stream, p.sort_blocks, nb, s.hist, s.totals);
-        // bucket_start -> rank counters | first item of every bucket | a counter row per wave when that fits (else the waves take turns)
-        const bool wave_counts = (18 * (size_t)nb + 1) * sizeof(int32_t) <= 96 * 1024;
-        const size_t scatter_lds = ((wave_counts ? 18 : 2) * (size_t)nb + 1) * sizeof(int32_t);
+        // bucket_start | first item of every bucket | as many counter rows as fit the LDS (16 waves share them in turns)
+        int wave_rows = 16;
+        while (wave_rows > 1 && ((2 + wave_rows) * (size_t)nb + 1) * sizeof(int32_t) > kKeysLds) wave_rows >>= 1;
+        if (const char *force = getenv("RNAD_SCATTER_ROWS")) wave_rows = std::max(1, std::min(wave_rows, atoi(force)));  // tuning knob
+        const size_t scatter_lds = ((2 + wave_rows) * (size_t)nb + 1) * sizeof(int32_t);
+        RNAD_REQUIRE(scatter_lds <= 160 * 1024, "rnad_bucket_sort: %d buckets do not fit the sort's LDS", nb);
         if (scatter_lds > 48 * 1024)
             RNAD_HIP_OK(hipFuncSetAttribute((const void *)k_bucket_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, (int)scatter_lds));
         hipLaunchKernelGGL(k_bucket_scatter, dim3(p.sort_blocks), dim3(kSortThreads), scatter_lds, stream, B, nb, (const int32_t *)s.keys,
-                           (const int32_t *)s.hist, (const int32_t *)s.totals, p.chunk, (Item *)items, n_items, lane_ids, wave_counts ? 1 : 0);
+                           (const int32_t *)s.hist, (const int32_t *)s.totals, p.chunk, (Item *)items, n_items, lane_ids, wave_rows, S,
+                           p.cut->n_groups, (const int32_t *)p.cut->bucket_lo, (const int32_t *)p.cut->bucket_span,
+                           (const int32_t *)p.cut->group_by_lo, staged_rows, n_staged, tr.visited);
         if (group_flags)
             hipLaunchKernelGGL(k_group_flags, dim3(blocks_for(S)), dim3(kThreads), 0, stream, S, (const int32_t *)p.cut->bucket_of,
                                p.cut->n_groups, (const int32_t *)s.totals, group_flags);
@@ -2050,20 +2105,22 @@ int rollout_bucketed_impl(const rnad_tree_t *tree, const RolloutBuffers &tr, boo
 
 extern "C" int rnad_bucket_sort(const rnad_tree_t *tree, int T_cap, int64_t B, const float *table, int64_t table_stride, int table_is_policy,
                                 uint64_t seed, int64_t lane0, const rnad_step_params_t *device_params, void *scratch, int32_t *lane_ids,
-                                int32_t *items, int32_t *n_items, double *norm, int32_t *group_flags, void *stream) {
+                                int32_t *items, int32_t *n_items, double *norm, int32_t *group_flags, int32_t *staged_rows, int64_t *n_staged,
+                                int32_t *visited, void *stream) {
     RNAD_REQUIRE(tree && table && scratch && lane_ids && items && n_items, "rnad_bucket_sort: null argument");
+    RNAD_REQUIRE(!staged_rows == !n_staged, "rnad_bucket_sort: staged_rows and n_staged go together");
     RNAD_REQUIRE(T_cap >= 1 && T_cap <= kCompactSteps && B >= 1, "rnad_bucket_sort: 1 <= T_cap <= %d, got %d", kCompactSteps, T_cap);
     RNAD_REQUIRE(table_stride >= tree->A, "rnad_bucket_sort: bad table stride");
-    const RolloutBuffers out{T_cap, B, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    const RolloutBuffers out{T_cap, B, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, visited};
     return rollout_bucketed_impl(tree, out, true, table, table_stride, table_is_policy, nullptr, 1, seed, lane0, device_params, scratch,
-                                 lane_ids, items, n_items, norm, (hipStream_t)stream, 1, group_flags);
+                                 lane_ids, items, n_items, norm, (hipStream_t)stream, 1, group_flags, nullptr, nullptr, staged_rows, n_staged);
 }
 
 extern "C" int rnad_bucket_play(const rnad_tree_t *tree, int T_cap, int64_t B, const float *table, int64_t table_stride, int table_is_policy,
                                 const int32_t *rows, const int64_t *n_rows, uint64_t seed, int64_t lane0,
                                 const rnad_step_params_t *device_params, void *scratch, const int32_t *lane_ids, const int32_t *items,
                                 const int32_t *n_items, double *norm, void *states, int32_t *alive, uint64_t *acts, float *final_reward,
-                                int32_t *visited, void *stream) {
+                                int32_t *visited, int visited_is_clear, void *stream) {
     void *indices = states;
     RNAD_REQUIRE(tree && table && scratch && lane_ids && items && n_items && indices && acts && final_reward, "rnad_bucket_play: null argument");
     RNAD_REQUIRE(T_cap >= 1 && T_cap <= kCompactSteps && B >= 1, "rnad_bucket_play: 1 <= T_cap <= %d, got %d", kCompactSteps, T_cap);
@@ -2072,7 +2129,7 @@ extern "C" int rnad_bucket_play(const rnad_tree_t *tree, int T_cap, int64_t B, c
                              visited};
     return rollout_bucketed_impl(tree, out, true, table, table_stride, table_is_policy, nullptr, 1, seed, lane0, device_params, scratch,
                                  const_cast<int32_t *>(lane_ids), const_cast<int32_t *>(items), const_cast<int32_t *>(n_items), norm,
-                                 (hipStream_t)stream, 2, nullptr, rows, n_rows);
+                                 (hipStream_t)stream, 2, nullptr, rows, n_rows, nullptr, nullptr, visited_is_clear != 0);
 }
 
 extern "C" int rnad_bucket_alive(const rnad_tree_t *tree, int T_cap, int64_t B, const void *scratch, int32_t *alive, double *norm, void *stream) {

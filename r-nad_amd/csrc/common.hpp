@@ -88,6 +88,8 @@ struct BucketCut {
     int32_t *bucket_of = nullptr;    // device [S]: bucket of a state (group for every state of a group's id range, n_groups + slot for upper states, -1 else)
     int32_t *bucket_lo = nullptr;    // device [n_buckets]: first state id of the group / the upper state itself
     int32_t *bucket_path = nullptr;  // device [n_buckets]: env steps a lane of the bucket spends above the group (terminal buckets: all of them)
+    int32_t *group_by_lo = nullptr;  // device [n_groups]: the groups in ascending order of their first state id
+    int32_t *bucket_span = nullptr;  // device [n_buckets]: state ids a group spans (bucket_lo .. bucket_lo + span - 1); 0 for terminal buckets
     int32_t *path_states = nullptr;  // device [n_buckets][max(max_path, 1)]: the state every lane of the bucket sits in at env step t, for the steps
                                      // it shares with the whole bucket (above the group; and at the root of a group that is one subtree)
     int32_t *upper_list = nullptr;   // device [max(n_upper, 1)]: the upper states in slot order

@@ -27,6 +27,7 @@
 // removed in turn (two sample tiles per weight read, software-pipelined operand reads, prefetched inputs) without moving the
 // wall time: the kernel is ALU- and power-bound, not memory- or latency-bound.
 #include "mlp_common.hpp"
+#include "rollout_math.hpp"
 
 using namespace rnad;
 using namespace rnad_mlp;
@@ -99,6 +100,10 @@ struct NetSet {
     float *logits[4];
     float *value[4];
     int first_block[5];  // workgroups [first_block[i], first_block[i + 1]) serve net i
+    // rnad_mlp_forward_actor: net 0 is a tabular ACTOR -- besides its logits, the policy head of every row (net.py:45-46 under the mover's
+    // legal bits mask_tab[row]) goes out as a padded policy row, the table the bucketed rollout kernels gather from
+    float *policy_rows;
+    const uint8_t *mask_tab;
 };
 
 template <int A, typename ObsT, int HEADS, bool FOLD>
@@ -200,8 +205,19 @@ __global__ __launch_bounds__(kFwdThreads) void k_mlp_forward(int64_t N, int W, N
                 const int64_t row = rows ? (int64_t)rows[sample] : sample;
                 if ((HEADS & 1) && value) value[row] = out_v + bv;
                 if ((HEADS & 2) && logits) {
+                    float lg[A];
 #pragma unroll
-                    for (int a = 0; a < A; ++a) logits[row * A + a] = out_p[a] + bp[a];
+                    for (int a = 0; a < A; ++a) logits[row * A + a] = lg[a] = out_p[a] + bp[a];
+                    if (nets.policy_rows && net == 0) {  // (uniform) the same function of the same logits as k_policy_rows / k_row_records
+                        constexpr int PS = (A + 3) & ~3;
+                        float pol[PS];
+                        rnad::dev::policy_head_ptr<A>(lg, nets.mask_tab[row], pol, nullptr);
+#pragma unroll
+                        for (int a = A; a < PS; ++a) pol[a] = 0.0f;
+                        float4 *p4 = reinterpret_cast<float4 *>(nets.policy_rows + row * PS);
+#pragma unroll
+                        for (int u = 0; u < PS / 4; ++u) p4[u] = float4{pol[4 * u], pol[4 * u + 1], pol[4 * u + 2], pol[4 * u + 3]};
+                    }
                 }
             }
         }
@@ -388,4 +404,20 @@ extern "C" int rnad_mlp_forward_fold(int n_nets, int64_t N, const int32_t *rows,
         nets.packed[i] = packed[i]; nets.logits[i] = logits[i]; nets.value[i] = value[i];
     }
     return mlp_forward_launch(N, rows, n_rows, A, W, n_nets, nets, obs, obs_half, stream, true);
+}
+
+// A tabular ACTOR on (a row list of) the tree's 2S observations: the policy head of one net -> its logits [2S, A] AND its policy rows
+// [2S, rnad_bucket_policy_row_stride(A)] (the masked exp-normalise of net.py:45-46 under the mover's legal bits, in the kernel's
+// epilogue: what rnad_bucket_sort / rnad_bucket_play otherwise take from the logits with a launch of their own per call).  fold != 0:
+// `packed` is the FOLD image.  rows / n_rows: NULL = all 2S rows.
+extern "C" int rnad_mlp_forward_actor(const rnad_tree_t *tree, const int32_t *rows, const int64_t *n_rows, int W, int fold, const float *packed,
+                                      const void *obs, int obs_half, float *logits, float *policy_rows, void *stream) {
+    RNAD_REQUIRE(tree && packed && obs && logits && policy_rows, "rnad_mlp_forward_actor: null argument");
+    RNAD_REQUIRE(!rows == !n_rows, "rnad_mlp_forward_actor: rows and n_rows go together");
+    RNAD_REQUIRE(((uintptr_t)policy_rows & 15) == 0, "rnad_mlp_forward_actor: policy_rows must be 16-byte aligned");
+    NetSet nets{};
+    nets.packed[0] = packed; nets.logits[0] = logits; nets.value[0] = nullptr;
+    nets.policy_rows = policy_rows;
+    nets.mask_tab = tree->mask_tab;
+    return mlp_forward_launch(2 * tree->S, rows, n_rows, tree->A, W, 1, nets, obs, obs_half, stream, fold != 0);
 }

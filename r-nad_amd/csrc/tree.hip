@@ -294,6 +294,8 @@ extern "C" void rnad_tree_destroy(rnad_tree_t *tree) {
         if (c.bucket_lo) (void)hipFree(c.bucket_lo);
         if (c.bucket_path) (void)hipFree(c.bucket_path);
         if (c.path_states) (void)hipFree(c.path_states);
+        if (c.bucket_span) (void)hipFree(c.bucket_span);
+        if (c.group_by_lo) (void)hipFree(c.group_by_lo);
         if (c.upper_list) (void)hipFree(c.upper_list);
         if (c.upper_walk) (void)hipFree(c.upper_walk);
     }

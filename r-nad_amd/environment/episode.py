@@ -371,12 +371,17 @@ class Episodes:
             elif compact and staged_actor is not None:
                 upper = rnad_hip.bucket_upper_rows(handle, B)
                 staged_actor(upper)
-                self.buckets, flags = rnad_hip.bucket_sort(handle, traj, table, seed=self.seed, lane0=self.lane_offset, step_params=step_params)
-                rows = rnad_hip.compact_valid(flags)
+                # an actor that also leaves its POLICY rows (rnad_hip.mlp_forward_actor: logits_table._policy_rows) spares the two
+                # policy-head launches the sort and the rollout would otherwise take from the logits
+                pol = getattr(table, "_policy_rows", None)
+                actor = dict(table=pol, table_is_policy=True) if pol is not None else dict(table=table)
+                # (the sort's last kernel writes the list of rows still to evaluate and clears `visited`: no flags, no compaction)
+                self.buckets, rows, _ = rnad_hip.bucket_sort(handle, traj, seed=self.seed, lane0=self.lane_offset, step_params=step_params,
+                                                             visited=visited, **actor)
                 staged_actor(rows)
                 self.staged_rows = (upper, rows)  # (bench.py reads how many rows the actor was evaluated on)
-                rnad_hip.bucket_play(handle, traj, self.buckets, table, rows=rows, seed=self.seed, lane0=self.lane_offset,
-                                     step_params=step_params, visited=visited, defer_alive=defer_alive)
+                rnad_hip.bucket_play(handle, traj, self.buckets, rows=None if pol is not None else rows, seed=self.seed, lane0=self.lane_offset,
+                                     step_params=step_params, visited=visited, defer_alive=defer_alive, visited_is_clear=visited is not None, **actor)
                 self.lane_ids = self.buckets.lane_ids
                 self._compact = (traj, None)  # the caller attaches the records once they exist (learn/rnad.py, lazy rows)
             elif compact:

@@ -454,10 +454,13 @@ class RNaD:
             # lazy rows: the learner's policy head is evaluated in stages by the rollout (staged_actor below: the upper rows of the cut,
             # then the rows of the groups the batch descends into); rows no lane can reach stay uninitialised and are never read
             logit = torch.empty((table.shape[0], A), dtype=torch.float32, device=table.device)
+            # the actor's policy rows come out of the same launch as its logits (rnad_mlp_forward_actor): the rollout kernels gather from them
+            logit._policy_rows = torch.empty((table.shape[0], int(rnad_hip.lib().rnad_bucket_policy_row_stride(A))), dtype=torch.float32,
+                                             device=table.device)
 
             def staged_actor(rows, packed=packed, logit=logit, table=table, width=self.net.width, fold=self.tree.handle() if fold else False):
                 with torch.no_grad():
-                    rnad_hip.mlp_forward(packed, width, table, A, live=rows, out=(logit, None), fold=fold)
+                    rnad_hip.mlp_forward_actor(self.tree.handle(), packed, width, table, logit, logit._policy_rows, rows=rows, fold=fold)
 
             logit_reg, logit_reg_ = self._reg_tables(table, fold)
             return dict(table=table, logit=logit, v=None, logit_target=None, v_target=None, logit_reg=logit_reg, logit_reg_=logit_reg_,
@@ -479,10 +482,15 @@ class RNaD:
         with torch.no_grad():
             # (the rows that are not listed are never read: records, gradient tables and the backward all go by the same list)
             fold = handle if tables.get("fold", False) else False
-            tables["v"] = rnad_hip.mlp_forward(tables["packed_net"], self.net.width, tables["table"], A, want_logits=False, live=rows, zero_rest=False,
-                                               fold=fold)[1]
-            tables["v_target"] = rnad_hip.mlp_forward(tables["packed_target"], self.net.width, tables["table"], A, want_logits=False, live=rows,
-                                                      zero_rest=False, fold=fold)[1]
+            if fold:  # both value heads in one launch
+                outs = rnad_hip.mlp_forward_multi([tables["packed_net"], tables["packed_target"]], self.net.width, tables["table"], A,
+                                                  [(False, True), (False, True)], fold=fold, live=rows, zero_rest=False)
+                tables["v"], tables["v_target"] = outs[0][1], outs[1][1]
+            else:
+                tables["v"] = rnad_hip.mlp_forward(tables["packed_net"], self.net.width, tables["table"], A, want_logits=False, live=rows,
+                                                   zero_rest=False)[1]
+                tables["v_target"] = rnad_hip.mlp_forward(tables["packed_target"], self.net.width, tables["table"], A, want_logits=False, live=rows,
+                                                          zero_rest=False)[1]
         tables["records"], tables["fast_records"] = rnad_hip.bucket_records(
             handle, tables["logit"], tables["v"], tables["v_target"], tables["logit_reg"], tables["logit_reg_"], self._learn_params(alpha),
             step_params=step_params, fast=True, rows=rows)

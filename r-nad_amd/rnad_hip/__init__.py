@@ -359,22 +359,37 @@ def mlp_forward(packed, W, obs, A, want_logits=True, want_value=True, live=None,
     return logits, value
 
 
-def mlp_forward_multi(packed_list, W, obs, A, wants, fold=False):
+def mlp_forward_actor(tree, packed, W, obs, logits, policy_rows, rows=None, fold=False):
+    """rnad_mlp_forward_actor: the policy head of one net on (the listed rows of) the tree's observation table -> `logits` [2S, A] and, from
+    the kernel's epilogue, `policy_rows` [2S, policy row stride] -- the actor table of bucket_sort / bucket_play(table_is_policy=True)."""
+    fold = _fold_checked(fold, obs, "mlp_forward_actor")
+    half = obs.dtype == F16
+    assert logits.shape == (2 * tree.S, tree.A) and policy_rows.shape[0] == 2 * tree.S
+    assert rows is None or rows.N == 2 * tree.S
+    _check(lib().rnad_mlp_forward_actor(tree.ptr, *_row_list(rows), W, int(fold), _dp(packed, F32, "packed"), _dp(obs, F16 if half else F32, "obs"),
+                                        int(half), _dp(logits, F32, "logits"), _dp(policy_rows, F32, "policy_rows"), _stream()))
+
+
+def mlp_forward_multi(packed_list, W, obs, A, wants, fold=False, live=None, zero_rest=True):
     """Several nets of one shape on the same inputs in ONE launch (rnad_mlp_forward_multi).  packed_list: their weight images;
-    wants: per net (want_logits, want_value).  Returns a list of (logits [N, A] or None, value [N, 1] or None)."""
+    wants: per net (want_logits, want_value).  Returns a list of (logits [N, A] or None, value [N, 1] or None).
+    live (FOLD kernels only): a row list -- only those rows are evaluated (the others: zeros, or uninitialised with zero_rest=False)."""
     fold = _fold_checked(fold, obs, "mlp_forward_multi")
     n = len(packed_list)
     assert 1 <= n <= 4 and len(wants) == n
     N = obs.numel() // (2 * A * A)
     half = obs.dtype == F16
-    outs = [(torch.empty((N, A), dtype=F32, device=obs.device) if wl else None,
-             torch.empty((N, 1), dtype=F32, device=obs.device) if wv else None) for wl, wv in wants]
+    assert live is None or (fold and live.N == N), "a row list goes with the FOLD kernels"
+    alloc = torch.zeros if (live is not None and zero_rest) else torch.empty
+    outs = [(alloc((N, A), dtype=F32, device=obs.device) if wl else None,
+             alloc((N, 1), dtype=F32, device=obs.device) if wv else None) for wl, wv in wants]
     ptr = lambda t: t.data_ptr() if t is not None else None  # noqa: E731
     P = (C.c_void_p * n)(*[_dp(p, F32, "packed").value for p in packed_list])
     L = (C.c_void_p * n)(*[ptr(o[0]) for o in outs])
     V = (C.c_void_p * n)(*[ptr(o[1]) for o in outs])
     if fold:
-        _check(lib().rnad_mlp_forward_fold(n, C.c_int64(N), None, None, A, W, P, _dp(obs, F16 if half else F32, "obs"), int(half), L, V, _stream()))
+        _check(lib().rnad_mlp_forward_fold(n, C.c_int64(N), *_row_list(live), A, W, P, _dp(obs, F16 if half else F32, "obs"), int(half), L, V,
+                                           _stream()))
     else:
         _check(lib().rnad_mlp_forward_multi(n, C.c_int64(N), A, W, P, _dp(obs, F16 if half else F32, "obs"), int(half), L, V, _stream()))
     return outs
@@ -817,10 +832,12 @@ def bucket_upper_rows(tree, B):
     return plan.upper_rows
 
 
-def bucket_sort(tree, traj, table, seed=0, lane0=0, step_params=None, table_is_policy=False, column=0, want_flags=True):
+def bucket_sort(tree, traj, table, seed=0, lane0=0, step_params=None, table_is_policy=False, column=0, want_flags=False, want_rows=True,
+                visited=None):
     """rnad_bucket_sort: the first half of rollout_bucketed_compact (keys + sort) for an actor evaluated in stages; `table` needs the
-    rows of bucket_upper_rows() only.  Returns (buckets, flags): flags int32 [2S] marks the rows of the groups the batch descends into
-    -- evaluate the actor on compact_valid(flags), then call bucket_play."""
+    rows of bucket_upper_rows() only.  Returns (buckets, rows, flags): rows = a RowList of both players' rows of every state inside a
+    group the batch descends into (written by the sort's last kernel: evaluate the actor on it, then call bucket_play); flags (want_flags)
+    the same set as int32 [2S] marks.  visited (int32 [2S]): cleared here for bucket_play(visited_is_clear=True)."""
     assert traj.compact and traj.T_cap <= COMPACT_MAX_STEPS
     plan = bucket_plan(tree, traj.B)
     if plan is None:
@@ -828,18 +845,27 @@ def bucket_sort(tree, traj, table, seed=0, lane0=0, step_params=None, table_is_p
     assert table.shape[0] == 2 * tree.S and table.shape[1] >= column + tree.A
     buckets = Buckets(plan, traj.device)
     flags = torch.empty((2 * tree.S,), dtype=I32, device=traj.device) if want_flags else None
+    rows = None
+    if want_rows:
+        rows = RowList.__new__(RowList)
+        rows.N = 2 * tree.S
+        rows.rows = torch.empty((2 * tree.S,), dtype=I32, device=traj.device)
+        rows.count = torch.empty((1,), dtype=torch.int64, device=traj.device)
     base = _dp(table, F32, "table")
     _check(lib().rnad_bucket_sort(tree.ptr, traj.T_cap, traj.B, C.c_void_p(base.value + 4 * column), table.shape[1], int(table_is_policy), seed,
                                   lane0, _dp(step_params, torch.int64, "step_params", True), _dp(plan.scratch, I32, "scratch"),
                                   _dp(buckets.lane_ids, I32, "lane_ids"), _dp(buckets.items, I32, "items"), _dp(buckets.n_items, I32, "n_items"),
-                                  _dp(buckets.norm, F64, "norm"), _dp(flags, I32, "group_flags", True), _stream()))
-    return buckets, flags
+                                  _dp(buckets.norm, F64, "norm"), _dp(flags, I32, "group_flags", True),
+                                  _dp(rows.rows, I32, "staged_rows") if rows is not None else None,
+                                  C.c_void_p(rows.count.data_ptr()) if rows is not None else None, _dp(visited, I32, "visited", True), _stream()))
+    return buckets, rows, flags
 
 
 def bucket_play(tree, traj, buckets, table, rows=None, seed=0, lane0=0, step_params=None, table_is_policy=False, column=0, visited=None,
-                defer_alive=False):
+                defer_alive=False, visited_is_clear=False):
     """rnad_bucket_play: the second half (the rollout in bucket order + alive counts); same seed / lane0 / step_params as bucket_sort.
-    rows: the LiveRows the actor was evaluated on since the sort (a logits table: their policy head is taken here)."""
+    rows: the LiveRows the actor was evaluated on since the sort (a logits table: their policy head is taken here).
+    visited_is_clear: bucket_sort(visited=...) cleared the flags already (no launch for it here)."""
     assert table.shape[0] == 2 * tree.S and table.shape[1] >= column + tree.A
     base = _dp(table, F32, "table")
     _check(lib().rnad_bucket_play(tree.ptr, traj.T_cap, traj.B, C.c_void_p(base.value + 4 * column), table.shape[1], int(table_is_policy),
@@ -848,7 +874,8 @@ def bucket_play(tree, traj, buckets, table, rows=None, seed=0, lane0=0, step_par
                                   _dp(buckets.items, I32, "items"), _dp(buckets.n_items, I32, "n_items"),
                                   _dp(buckets.norm, F64, "norm"), _dp(traj.states, traj.states.dtype, "states"),
                                   None if defer_alive else _dp(traj.alive, I32, "alive"), _dp(traj.acts, torch.int64, "acts"),
-                                  _dp(traj.final_reward, F32, "final_reward"), _dp(visited, I32, "visited", True), _stream()))
+                                  _dp(traj.final_reward, F32, "final_reward"), _dp(visited, I32, "visited", True), int(bool(visited_is_clear)),
+                                  _stream()))
     buckets.alive_pending = traj if defer_alive else None
     traj._owner = (tree, buckets)
     traj.invalidate()

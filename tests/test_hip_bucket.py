@@ -619,6 +619,16 @@ def test_staged_actor_plays_the_same_batch(name, rows, monkeypatch):
     seen = vis.bool()
     assert torch.isfinite(staged_logit[seen]).all(), "every visited row must have been evaluated"
     assert torch.equal(staged_logit[seen], full_logit[seen])
+    # the row list the sort's last kernel writes is the compaction of the group flags (k_group_flags), ascending; `visited` comes back cleared
+    traj = rnad_hip.Trajectory(h, B, staged._compact[0].T_cap, DEV, compact=True)
+    dirty = torch.full((2 * S,), 7, dtype=torch.int32, device=DEV)
+    _, listed, flags = rnad_hip.bucket_sort(h, traj, full_logit, seed=17, lane0=3, want_flags=True, visited=dirty)
+    want = rnad_hip.compact_valid(flags)
+    n = int(listed.count.item())
+    assert n == int(want.count.item()) == calls[1] and torch.equal(listed.rows[:n], want.rows[:n])
+    expect = torch.zeros((2 * S,), dtype=torch.int32, device=DEV)
+    expect[0] = expect[S] = 1
+    assert torch.equal(dirty, expect)
 
 
 @pytest.mark.parametrize("name", ("pruned", "ternary4"))
