@@ -269,7 +269,7 @@ def main():
     lazy_now = rn._use_lazy_rows(handle, local_batch, T, None, buffer) and mode_now_is_true(rn, T, local_batch)
     args.visited_rows = int(rn.last_rows.count.item()) if (lazy_now and rn.last_rows is not None) else 0
     staged = getattr(rn.last_episodes, "staged_rows", None) if lazy_now else None
-    args.policy_rows = int(staged[0].count.item() + staged[1].count.item()) if staged else 0  # rows the staged policy head was evaluated on
+    args.policy_rows = int(sum(r.count.item() for r in staged)) if staged else 0  # rows the staged policy head was evaluated on
     args.fold = bool(rn._fold() and mode_now_is_true(rn, T, local_batch))
     default_mode = rn.tabular
     mode_now = rn._tabular_mode(T, local_batch)

@@ -463,6 +463,20 @@ int rnad_bucket_records(const rnad_tree_t *tree, const float *logit_tab, const f
                         const float *logit_reg_tab, const float *logit_reg_tab_, const rnad_learn_params_t *hp,
                         const rnad_step_params_t *device_params, float *records, float *fast_records, float *policy_rows,
                         const int32_t *rows, const int64_t *n_rows, void *stream);
+/* rnad_mlp_rows_records (csrc/mlp_rows.hip): the table evaluations of a tabular update AND rnad_bucket_records in one launch -- replaces
+ * learn/rnad.py:373,378 on the 2S rows (the learner net's two heads, the target net's value head; nn/net.py:40-43) followed by the
+ * row-only arithmetic of :374,382 and learn/vtrace.py (see rnad_bucket_records).  packed_net / packed_target: weight images of
+ * rnad_mlp_pack(_fold)_multi (fold != 0: the FOLD images; `obs` is then the tree's own observation table); logit_tab [2S, A], v_tab [2S],
+ * v_target_tab [2S] are OUTPUTS (the same tables rnad_mlp_forward_multi would give, up to the order of the second-layer sums);
+ * records (optional) / fast_records / policy_rows (optional) exactly as rnad_bucket_records writes them from those tables (same function,
+ * same bits).  policy_from_table != 0: logit_tab is an INPUT (a staged actor wrote it) and only the two value heads are evaluated --
+ * with rows / n_rows (device memory, both NULL = all 2S rows) the lazy-rows step of learn/rnad.py.  Width: a multiple of 32 up to 256;
+ * A <= 3 with the policy head, A <= 5 (fold) / 4 without (rnad_mlp_rows_records_supported: other shapes take the two launches). */
+int rnad_mlp_rows_records_supported(int A, int W, int fold, int policy_from_table);
+int rnad_mlp_rows_records(const rnad_tree_t *tree, int W, int fold, const float *packed_net, const float *packed_target, const void *obs,
+                          int obs_half, const int32_t *rows, const int64_t *n_rows, int policy_from_table, float *logit_tab, float *v_tab,
+                          float *v_target_tab, const float *logit_reg_tab, const float *logit_reg_tab_, const rnad_learn_params_t *hp,
+                          const rnad_step_params_t *device_params, float *records, float *fast_records, float *policy_rows, void *stream);
 int rnad_learn_bucketed(const rnad_tree_t *tree, int T, int64_t B, const int32_t *indices, const int32_t *actions,
                         const float *rewards, const float *mu, const float *records, const int32_t *items, const int32_t *n_items,
                         const double *norm, const rnad_learn_params_t *hp, void *accumulators, double *losses, float *dlogit_tab,
@@ -487,7 +501,22 @@ int rnad_bucket_alive(const rnad_tree_t *tree, int T_cap, int64_t B, const void 
 int rnad_bucket_sort(const rnad_tree_t *tree, int T_cap, int64_t B, const float *table, int64_t table_stride, int table_is_policy,
                      uint64_t seed, int64_t lane0, const rnad_step_params_t *device_params, void *scratch, int32_t *lane_ids,
                      int32_t *items, int32_t *n_items, double *norm, int32_t *group_flags, int32_t *staged_rows, int64_t *n_staged,
-                     int32_t *visited, void *stream);
+                     int32_t *visited, void *stage, void *stream);
+/* Second staging level of a tabular actor on a tree that is large next to the batch (configs[3]: the non-empty groups hold 807 k rows, the
+ * batch visits 103 k).  rnad_bucket_sort with `stage` (rnad_bucket_stage_bytes(tree, B) bytes, zeroed once; its first two int64 are the
+ * lengths of the two row lists below) also records, per lane, the root of the group subtree it enters.  Then, on the same stream:
+ *   rnad_bucket_stage_rows(level 0) -> rows = both players' rows of those roots;  evaluate the actor on them;
+ *   rnad_bucket_stage_walk          -> draws every lane's transition at its root exactly as the rollout will (environment/episode.py:96-125
+ *                                      with the seeded draws of rnad_rng.h: same counters, same rows, same outcome);
+ *   rnad_bucket_stage_rows(level 1) -> rows = the rows of every subtree hanging below a state some lane was just drawn into;  evaluate the
+ *                                      actor on them;  rnad_bucket_play then only reads rows that were evaluated.
+ * configs[3]: 176 k rows instead of 807 k.  The lists are unordered (one launch each, a reservation per workgroup); `rows` holds up to 2S
+ * entries; seed / device_params as in rnad_bucket_sort (they stamp the marks: nothing is cleared between steps). */
+int64_t rnad_bucket_stage_bytes(const rnad_tree_t *tree, int64_t B);
+int rnad_bucket_stage_rows(const rnad_tree_t *tree, int64_t B, int level, uint64_t seed, const rnad_step_params_t *device_params, void *stage,
+                           int32_t *rows, void *stream);
+int rnad_bucket_stage_walk(const rnad_tree_t *tree, int T_cap, int64_t B, const float *policy_rows, int64_t stride, uint64_t seed, int64_t lane0,
+                           const rnad_step_params_t *device_params, const void *scratch, const int32_t *lane_ids, void *stage, void *stream);
 int rnad_bucket_play(const rnad_tree_t *tree, int T_cap, int64_t B, const float *table, int64_t table_stride, int table_is_policy,
                      const int32_t *rows, const int64_t *n_rows, uint64_t seed, int64_t lane0, const rnad_step_params_t *device_params,
                      void *scratch, const int32_t *lane_ids, const int32_t *items, const int32_t *n_items, double *norm, void *states,

@@ -26,6 +26,7 @@
 //   k_policy_rows / k_row_records   everything that depends on the (player, state) row alone, once per row instead of per slot
 //   k_bucket_finish    fixed point -> fp32 tables dL/dlogit [2S, A], dL/dv [2S], normalised by the batch-global N_P
 #include "learn_math.hpp"
+#include "row_records.hpp"
 #include "rollout_math.hpp"
 
 #include <algorithm>
@@ -88,6 +89,7 @@ struct HostCut {
     int rows = 0, n_groups = 0, n_upper = 0, n_buckets = 0, max_path = 0;
     std::vector<int32_t> bucket_of, lo, span, path, upper_list, path_states;  // path_states: [n_buckets][max(max_path, 1)]
     std::vector<int32_t> group_by_lo;  // the groups sorted by lo (group ids follow the upper states they hang below, not the state ids)
+    std::vector<int32_t> anchor1;      // [S] BucketCut::anchor1
 };
 
 HostCut build_cut(const rnad_tree_t *tree, int rows) {
@@ -96,6 +98,14 @@ HostCut build_cut(const rnad_tree_t *tree, int rows) {
     const int64_t S = tree->S;
     std::vector<int32_t> &bucket_of = h.bucket_of, &lo = h.lo, &span = h.span, &path = h.path, &upper_list = h.upper_list;
     bucket_of.assign((size_t)S, -1);
+    h.anchor1.assign((size_t)S, 0);
+    // the subtree of a group's root c, one level down: every state below a child d of c is anchored at d
+    auto anchor_below = [&](int64_t c) {
+        for (int64_t i = tree->child_offsets[(size_t)c]; i < tree->child_offsets[(size_t)c + 1]; ++i) {
+            const int64_t d = tree->children[(size_t)i], d_hi = d + tree->subtree_size[(size_t)d];
+            for (int64_t x = d; x < d_hi; ++x) h.anchor1[(size_t)x] = (int32_t)d;
+        }
+    };
     std::vector<int32_t> parent_upper((size_t)S, 0);  // upper state -> the upper state above it (0: the root)
     std::vector<int32_t> group_parent;                // bucket -> the upper state it hangs below (0: none)
     auto is_upper = [&](int64_t s) { return tree->subtree_size[(size_t)s] > rows; };
@@ -104,6 +114,7 @@ HostCut build_cut(const rnad_tree_t *tree, int rows) {
         span.push_back((int32_t)tree->subtree_size[1]);
         path.push_back(kSharedRoot);  // (every lane starts in state 1)
         group_parent.push_back(0);
+        anchor_below(1);
         for (int64_t s = 1; s < S; ++s)
             if (tree->level_of[(size_t)s] >= 0) bucket_of[(size_t)s] = 0;
     } else {
@@ -132,6 +143,7 @@ HostCut build_cut(const rnad_tree_t *tree, int rows) {
                     continue;
                 }
                 const int64_t c_hi = c + tree->subtree_size[(size_t)c];
+                anchor_below(c);
                 if (g_lo >= 0 && c == g_hi && c_hi - g_lo <= rows) {
                     g_hi = c_hi;
                     ++g_subtrees;
@@ -205,8 +217,8 @@ const BucketCut *get_cut(const rnad_tree_t *tree, int rows) {
     };
     if (!guard.ok || !up(&cut.bucket_of, h.bucket_of) || !up(&cut.bucket_lo, h.lo) || !up(&cut.bucket_path, h.path) ||
         !up(&cut.upper_list, h.upper_list) || !up(&cut.path_states, h.path_states) || !up(&cut.bucket_span, h.span) ||
-        !up(&cut.group_by_lo, h.group_by_lo)) {
-        for (int32_t *ptr : {cut.bucket_of, cut.bucket_lo, cut.bucket_path, cut.upper_list, cut.path_states, cut.bucket_span, cut.group_by_lo})
+        !up(&cut.group_by_lo, h.group_by_lo) || !up(&cut.anchor1, h.anchor1)) {
+        for (int32_t *ptr : {cut.bucket_of, cut.bucket_lo, cut.bucket_path, cut.upper_list, cut.path_states, cut.bucket_span, cut.group_by_lo, cut.anchor1})
             if (ptr) (void)hipFree(ptr);
         return nullptr;
     }
@@ -348,31 +360,7 @@ __global__ __launch_bounds__(kThreads) void k_group_flags(int64_t S, const int32
     flags[S + s] = on;
 }
 
-// Row record of the bucketed update, kRowStride<A> floats:  logit[A] | v | v_target | pi_processed[A] | log_policy_reg[A] |
-// legal bits | pi[A] | pad   (64 bytes at A = 3; the learner reads the first kRowLearn<A> floats = 48 bytes, the rollout pi).  From the five net-output tables: pi / log_pi = policy head of the learner (rnad.py:373,
-// net.py:74-77), pi_processed = process_policy (rnad.py:374), log_policy_reg = log_pi - (alpha log_pi_reg + (1 - alpha) log_pi_reg_)
-// (rnad.py:382) -- the per-slot arithmetic of k_learn_fused that does not depend on the slot.
-template <int A>
-constexpr int kRowStride = (4 * A + 3 + 3) & ~3;
-template <int A>
-constexpr int kRowLearn = (3 * A + 3 + 3) & ~3;  // what k_bucket_learn fetches of a record
-
-// "Fast" record of the on-policy learner (k_bucket_learn<A, true, .>), kFastStride<A> floats = 64 bytes at A = 3:
-//   v | v_target | e0 | bits | pi_processed[A] | elp[A] | cs[A] | inv_mu[A]
-// Everything of a slot's V-trace / NeuRD arithmetic whose operands are the row's alone, computed with the operations (and in the
-// order) learn_math.hpp's vtrace_step / nerd_row use per slot, once per row instead:
-//   e0 = -eta * sum_a pi_processed[a] * log_policy_reg[a]   eta_reg_entropy up to the sign of _player_others (vtrace.py:234-238)
-//   elp[a] = -eta * log_policy_reg[a]                        eta_log_policy of the mover (:239)
-//   cs[a] = pi_processed[a] / pi[a], inv_mu[a] = 1 / pi[a]   _policy_ratio with the actor's own pi as mu, had action a been taken (:199-204)
-//   bits = legal | (legal & logit - mean > -threshold) << 8 | (legal & logit - mean < threshold) << 16    the gates of
-//          apply_force_with_threshold (:362-366), closed for illegal actions (whose force :424-428 multiplies by legal == 0)
-template <int A>
-constexpr int kFastStride = 4 + 4 * A;
-// The actor's policy rows as a table of their own (16 bytes per row at A <= 4): the whole configs[1] table is 2 MB and stays in an
-// XCD's L2, where the 64-byte row records -- 8.5 MB, of which the rollout wants 12 bytes per row -- do not.
-template <int A>
-constexpr int kPolStride = (A + 3) & ~3;
-
+// (record layouts -- kRowStride / kRowLearn / kFastStride / kPolStride -- and the function that fills them: row_records.hpp)
 template <int A>
 __device__ __forceinline__ void load_policy_row(const float *__restrict__ tab, int64_t row, int64_t stride, bool vec4, float (&out)[A]) {
     if (vec4) {  // rows of a multiple of 4 floats, 16-byte aligned (k_row_records' policy rows)
@@ -406,74 +394,14 @@ __global__ __launch_bounds__(kThreads) void k_row_records(int64_t rows, const fl
         hp.one_minus_alpha = sp->one_minus_alpha;
     }
     const uint32_t bits = mask_tab[r];
-    float lg[A], lr[A], lr2[A], legal[A], pi[A], lp[A], lpr[A], lpr2[A], pip[A];
+    float lg[A], lr[A], lr2[A];
 #pragma unroll
     for (int a = 0; a < A; ++a) {
         lg[a] = logit[r * A + a];
         lr[a] = lr_[r * A + a];
         lr2[a] = lr2_[r * A + a];
-        legal[a] = (float)((bits >> a) & 1);
     }
-    policy_head<A>(lg, bits, pi, lp);
-    log_policy_only<A>(lr, bits, lpr);
-    log_policy_only<A>(lr2, bits, lpr2);
-    process_policy_row<A>(pi, legal, hp.n_disc, hp.eps_threshold, pip);
-    // both records are assembled in registers and leave as 16-byte stores (a store instruction per float would touch 64 different
-    // 64-byte segments each)
-    const float vr = v[r], vtr = vt[r];
-    float o[kRowStride<A>];
-#pragma unroll
-    for (int a = 0; a < A; ++a) {
-        o[a] = lg[a];
-        o[A + 2 + a] = pip[a];
-        o[2 * A + 2 + a] = lp[a] - (hp.alpha * lpr[a] + hp.one_minus_alpha * lpr2[a]);
-        o[3 * A + 3 + a] = pi[a];
-    }
-    o[A] = vr;
-    o[A + 1] = vtr;
-    o[3 * A + 2] = __uint_as_float(bits);
-#pragma unroll
-    for (int u = 4 * A + 3; u < kRowStride<A>; ++u) o[u] = 0.0f;
-    float4 *o4 = reinterpret_cast<float4 *>(rec + r * kRowStride<A>);
-#pragma unroll
-    for (int u = 0; u < kRowStride<A> / 4; ++u) o4[u] = float4{o[4 * u], o[4 * u + 1], o[4 * u + 2], o[4 * u + 3]};
-    if (pol_rows) {  // the actor's policy rows on their own, kPolStride<A> floats apart: the table the rollout kernels gather from
-        float4 *p4 = reinterpret_cast<float4 *>(pol_rows + r * kPolStride<A>);
-#pragma unroll
-        for (int u = 0; u < kPolStride<A> / 4; ++u)
-            p4[u] = float4{4 * u < A ? pi[4 * u] : 0.0f, 4 * u + 1 < A ? pi[4 * u + 1] : 0.0f, 4 * u + 2 < A ? pi[4 * u + 2] : 0.0f,
-                           4 * u + 3 < A ? pi[4 * u + 3] : 0.0f};
-    }
-    if (!fast) return;
-    float f[kFastStride<A>];
-    const float neg_eta = -hp.eta;
-    float ent = 0.0f, mean = 0.0f;
-#pragma unroll
-    for (int a = 0; a < A; ++a) {
-        const float lpol = lp[a] - (hp.alpha * lpr[a] + hp.one_minus_alpha * lpr2[a]);
-        ent += pip[a] * lpol;
-        mean += lg[a] * legal[a];
-        f[4 + a] = pip[a];
-        f[4 + A + a] = neg_eta * lpol;
-        f[4 + 2 * A + a] = pip[a] / pi[a];
-        f[4 + 3 * A + a] = 1.0f / pi[a];
-    }
-    mean = mean / (float)A;
-    uint32_t gates = bits & 0xffu;
-#pragma unroll
-    for (int a = 0; a < A; ++a) {
-        const float l = lg[a] - mean;
-        // (an illegal action's force is multiplied by legal == 0 further down, vtrace.py:424-428: its gates are left closed instead)
-        gates |= ((l > -hp.threshold ? 1u : 0u) & (bits >> a)) << (8 + a);
-        gates |= ((l < hp.threshold ? 1u : 0u) & (bits >> a)) << (16 + a);
-    }
-    f[0] = vr;
-    f[1] = vtr;
-    f[2] = neg_eta * ent;
-    f[3] = __uint_as_float(gates);
-    float4 *f4 = reinterpret_cast<float4 *>(fast + r * kFastStride<A>);
-#pragma unroll
-    for (int u = 0; u < kFastStride<A> / 4; ++u) f4[u] = float4{f[4 * u], f[4 * u + 1], f[4 * u + 2], f[4 * u + 3]};
+    write_row_records<A>(r, lg, v[r], vt[r], lr, lr2, bits, hp, rec, fast, pol_rows);
 }
 
 // ---------------------------------------------------------------------------------------- 1. keys
@@ -482,6 +410,32 @@ __global__ __launch_bounds__(kThreads) void k_row_records(int64_t rows, const fl
 // kPlay lanes per thread, in lock step: the walk is a chain of dependent gathers (policy rows -> transition record -> next state) with
 // little arithmetic between them since the draws became one uniform each, so a thread keeps several independent chains in flight.
 // A lane that has stopped keeps walking state 0 (its loads hit one line, its results are dropped), which keeps the code branch-free.
+// Second staging level of a tabular actor (rnad_bucket_stage_*; trees that are large next to the batch).  The keys pass knows, for every
+// lane that descends into a group, the subtree root it enters there: with `root` set it leaves that state per lane and stamps it in
+// `mark0`; k_stage_rows<0> turns the stamped states into a row list, the caller evaluates its actor on it, k_stage_walk draws the
+// transition at the root exactly as the rollout will (same counters, same rows: same outcome) and stamps the state it leads to in
+// `mark1`, and k_stage_rows<1> lists the rows of the subtrees below the stamped states (BucketCut::anchor1).  A stamp is a function of the
+// step's seed: nothing is cleared between steps, and a stale stamp that happens to match only lists rows nobody needed.
+struct StageOut {
+    unsigned long long *counts = nullptr;  // [2]: the lengths of the two row lists (cleared by the keys pass)
+    uint32_t *root = nullptr;              // [B] lane order: the group subtree root a lane enters (0: it leaves the tree above the cut) in the
+                                           // low kStageRootBits bits, the env steps it spent above the cut in the bits above
+    uint32_t *sorted = nullptr;            // [B] the same words in bucket order (k_bucket_scatter), what k_stage_walk reads
+    uint32_t *mark0 = nullptr, *mark1 = nullptr;  // [S] stamps
+};
+constexpr int kStageRootBits = 26;  // S <= 2^26 states; kMaxPath = 32 steps fit the 6 bits above
+__host__ __device__ inline uint32_t stage_stamp(uint64_t seed) { return ((uint32_t)seed ^ (uint32_t)(seed >> 32)) | 1u; }
+StageOut carve_stage(void *stage, int64_t B, int64_t S) {
+    StageOut st;
+    if (!stage) return st;
+    st.counts = (unsigned long long *)stage;
+    st.root = (uint32_t *)(st.counts + 2);
+    st.sorted = st.root + B;
+    st.mark0 = st.sorted + B;
+    st.mark1 = st.mark0 + S;
+    return st;
+}
+
 #ifndef RNAD_PLAY
 #define RNAD_PLAY 2
 #endif
@@ -493,9 +447,10 @@ __global__ __launch_bounds__(kThreads) void k_bucket_keys(const Trans *__restric
                                                           const int32_t *__restrict__ bucket_of, int n_groups, uint64_t seed,
                                                           const rnad_step_params_t *__restrict__ sp, int64_t lane0,
                                                           int32_t *__restrict__ keys, unsigned long long *__restrict__ decisions,
-                                                          double *__restrict__ norm) {
+                                                          double *__restrict__ norm, StageOut stage) {
     const int64_t b0 = (int64_t)blockIdx.x * (kThreads * L) + threadIdx.x;  // this thread's lanes: b0 + l * kThreads
     if (b0 == 0 && norm) norm[0] = norm[1] = 0.0;  // summed up by k_bucket_alive at the end of this rollout
+    if (b0 == 0 && stage.counts) stage.counts[0] = stage.counts[1] = 0ull;
     if (sp) seed = sp->seed;  // per-step scalars in device memory: a captured graph of the step replays with new values
     const int key_root = bucket_of[1];
     // decisions: what a lane drew at its first kPackedSteps env steps -- 3 bits of action and 3 bits of chance outcome per step,
@@ -558,6 +513,11 @@ __global__ __launch_bounds__(kThreads) void k_bucket_keys(const Trans *__restric
         if (b < B) {
             keys[b] = key[l];
             decisions[b] = packed[l] | ((unsigned long long)min(steps[l], kPackedSteps) << 60);
+            if (stage.root) {  // (state: where the walk stopped -- the root of a group subtree when the key is a group)
+                const int root = key[l] < n_groups ? state[l] : 0;
+                stage.root[b] = (uint32_t)root | ((uint32_t)steps[l] << kStageRootBits);
+                if (root) stage.mark0[root] = stage_stamp(seed);
+            }
         }
     }
 }
@@ -582,7 +542,7 @@ __global__ __launch_bounds__(kSortThreads) void k_bucket_keys_lds(const UpperWal
                                                                   int n_groups, uint64_t seed, const rnad_step_params_t *__restrict__ sp,
                                                                   int64_t lane0, int32_t *__restrict__ keys,
                                                                   unsigned long long *__restrict__ decisions, int32_t *__restrict__ hist,
-                                                                  double *__restrict__ norm) {
+                                                                  double *__restrict__ norm, StageOut stage) {
     extern __shared__ __attribute__((aligned(16))) unsigned char keys_smem[];
     constexpr int PS = kPolStride<A>;
     const int AAC = A * A * C;
@@ -596,16 +556,18 @@ __global__ __launch_bounds__(kSortThreads) void k_bucket_keys_lds(const UpperWal
     }
     for (int i = threadIdx.x; i < n_buckets; i += kSortThreads) cnt[i] = 0;
     if (blockIdx.x == 0 && threadIdx.x == 0 && norm) norm[0] = norm[1] = 0.0;  // summed up by k_bucket_alive at the end of this rollout
+    if (blockIdx.x == 0 && threadIdx.x == 0 && stage.counts) stage.counts[0] = stage.counts[1] = 0ull;
     if (sp) seed = sp->seed;
     __syncthreads();
     static_assert(kSortLanes % (kSortThreads * L) == 0, "a sort tile is a whole number of passes");
     for (int pass = 0; pass < kSortLanes / (kSortThreads * L); ++pass) {
         const int64_t b0 = (int64_t)blockIdx.x * kSortLanes + (int64_t)pass * (kSortThreads * L) + threadIdx.x;  // lanes b0 + l * kSortThreads
-        int slot[L], key[L], steps[L];
+        int slot[L], key[L], steps[L], root[L];
         unsigned long long packed[L];
         bool on[L];
 #pragma unroll
         for (int l = 0; l < L; ++l) {
+            root[l] = key_root < n_groups ? 1 : 0;  // (a tree that is one group: every lane enters it at state 1)
             slot[l] = key_root - n_groups;
             key[l] = key_root;
             steps[l] = 0;
@@ -654,6 +616,7 @@ __global__ __launch_bounds__(kSortThreads) void k_bucket_keys_lds(const UpperWal
                     if (hit.next != 0) key[l] = hit.key;  // (a lane that leaves the tree from an upper state keeps that state's bucket)
                     on[l] = hit.next != 0 && hit.key >= n_groups;
                     slot[l] = on[l] ? hit.key - n_groups : 0;
+                    if (hit.next != 0 && hit.key < n_groups) root[l] = hit.next;
                 }
             }
         }
@@ -664,6 +627,10 @@ __global__ __launch_bounds__(kSortThreads) void k_bucket_keys_lds(const UpperWal
                 keys[b] = key[l];
                 decisions[b] = packed[l] | ((unsigned long long)min(steps[l], kPackedSteps) << 60);
                 atomicAdd(&cnt[key[l]], 1);
+                if (stage.root) {
+                    stage.root[b] = (uint32_t)root[l] | ((uint32_t)steps[l] << kStageRootBits);
+                    if (root[l]) stage.mark0[root[l]] = stage_stamp(seed);
+                }
             }
         }
     }
@@ -688,6 +655,91 @@ __global__ __launch_bounds__(kSortThreads) void k_bucket_hist(int64_t B, int n_b
     __syncthreads();
     int32_t *row = hist + (int64_t)blockIdx.x * n_buckets;
     for (int i = threadIdx.x; i < n_buckets; i += kSortThreads) row[i] = cnt[i];
+}
+
+// The row list of staging level LEVEL: both players' rows of every state whose stamp (LEVEL 0: its own in mark0; LEVEL 1: its anchor's
+// in mark1) is this step's.  One launch: a workgroup counts its states, reserves a range of the list with ONE atomic on the list's
+// length and writes its rows there -- the list is unordered across workgroups, which no consumer minds (an actor's forward writes
+// logits[row]; the same rows get the same values in any order).  *count was cleared by the keys pass.
+constexpr int kStagePer = 4;  // states per thread of k_stage_rows: 4096 per workgroup, i.e. a few hundred reservations per list
+template <int LEVEL>
+__global__ __launch_bounds__(kSortThreads) void k_stage_rows(int64_t S, const uint32_t *__restrict__ mark, const int32_t *__restrict__ anchor1,
+                                                             uint64_t seed, const rnad_step_params_t *__restrict__ sp,
+                                                             int32_t *__restrict__ rows, unsigned long long *__restrict__ count) {
+    __shared__ int32_t wave_n[kSortThreads / 64];
+    __shared__ unsigned long long base_s;
+    if (sp) seed = sp->seed;
+    const uint32_t stamp = stage_stamp(seed);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // a wave takes kStagePer * 64 consecutive states, 64 at a time (coalesced loads of the stamps)
+    const int64_t s0 = ((int64_t)blockIdx.x * (kSortThreads / 64) + wave) * (kStagePer * 64) + lane;
+    uint64_t votes[kStagePer];
+    int32_t mine = 0;
+#pragma unroll
+    for (int r = 0; r < kStagePer; ++r) {
+        const int64_t s = s0 + r * 64;
+        bool hit = false;
+        if (s > 0 && s < S) {
+            if (LEVEL == 0) {
+                hit = mark[s] == stamp;
+            } else {
+                const int32_t a = anchor1[s];
+                hit = a != 0 && mark[a] == stamp;
+            }
+        }
+        votes[r] = __ballot(hit);
+        mine += (int32_t)__popcll(votes[r]);
+    }
+    if (lane == 0) wave_n[wave] = mine;
+    __syncthreads();
+    int32_t before = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < kSortThreads / 64; ++w) {
+        if (w < wave) before += wave_n[w];
+        total += wave_n[w];
+    }
+    if (threadIdx.x == 0) base_s = total ? atomicAdd(count, 2ull * (unsigned long long)total) : 0ull;
+    __syncthreads();
+    unsigned long long at = base_s + 2ull * (unsigned long long)before;
+#pragma unroll
+    for (int r = 0; r < kStagePer; ++r) {
+        if ((votes[r] >> lane) & 1ull) {
+            const unsigned long long mine_at = at + 2ull * (unsigned long long)__popcll(votes[r] & ((1ull << lane) - 1ull));
+            rows[mine_at] = (int32_t)(s0 + r * 64);
+            rows[mine_at + 1] = (int32_t)(S + s0 + r * 64);
+        }
+        at += 2ull * (unsigned long long)__popcll(votes[r]);
+    }
+}
+
+// The transition every lane draws at the root of the group subtree it enters (env steps t, t + 1 with t = the steps it spent above the
+// cut): both players' actions from the root's policy rows, the chance outcome -- the draws k_bucket_rollout_items makes there (same
+// seed, lane, step -> same uniforms; same rows) -- and a stamp on the state it leads to.  After the sort (it reads lane_ids).
+template <int A>
+__global__ __launch_bounds__(kThreads) void k_stage_walk(const Trans *__restrict__ trans, int C, int64_t S, int64_t B, int T_cap,
+                                                         const float *__restrict__ policy_tab, int64_t tab_stride, int vec4,
+                                                         const uint32_t *__restrict__ sorted, const int32_t *__restrict__ lane_ids,
+                                                         uint64_t seed, const rnad_step_params_t *__restrict__ sp, int64_t lane0,
+                                                         uint32_t *__restrict__ mark1) {
+    const int64_t j = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    if (j >= B) return;
+    // in BUCKET order (thread j takes lane lane_ids[j], its root word travelled with it through the sort): the lanes of a wave sit in a few
+    // roots of one group, and the rows, the transition records and the stamps they touch share cache lines (in lane order every gather of
+    // a wave touched 64 lines: 46 us on configs[3])
+    const uint32_t word = sorted[j];
+    const int root = (int)(word & ((1u << kStageRootBits) - 1u)), t = (int)(word >> kStageRootBits);  // t: env steps above the group
+    if (root == 0 || t + 1 >= T_cap) return;
+    if (sp) seed = sp->seed;
+    const int64_t b = lane_ids[j];
+    float pol0[A], pol1[A], u[3];
+    load_policy_row<A>(policy_tab, root, tab_stride, vec4 != 0, pol0);
+    load_policy_row<A>(policy_tab, S + root, tab_stride, vec4 != 0, pol1);
+    rnad_decision_uniforms(seed, (uint64_t)(lane0 + b), (uint32_t)t, u);
+    const int a0 = pick<A>(pol0, u[0]), a1 = pick<A>(pol1, u[1]);
+    int next;
+    float rew;
+    transition_lane<A>(trans, C, root, a0, a1, nullptr, u[2], next, rew);
+    if (next != 0) mark1[next] = stage_stamp(seed);
 }
 
 // Column-wise exclusive prefix of hist over the blocks (in place) and the column totals.  A workgroup takes kScanCols buckets; its
@@ -830,15 +882,18 @@ __global__ __launch_bounds__(kSortThreads) void k_bucket_scatter(int64_t B, int 
                                                                  int32_t *__restrict__ lane_ids, int wave_rows, int64_t S, int n_groups,
                                                                  const int32_t *__restrict__ bucket_lo, const int32_t *__restrict__ bucket_span,
                                                                  const int32_t *__restrict__ group_by_lo, int32_t *__restrict__ staged_rows,
-                                                                 int64_t *__restrict__ n_staged, int32_t *__restrict__ visited) {
+                                                                 int64_t *__restrict__ n_staged, int32_t *__restrict__ visited,
+                                                                 const uint32_t *__restrict__ stage_root, uint32_t *__restrict__ stage_sorted) {
     extern __shared__ int32_t cnt[];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int64_t base = (int64_t)blockIdx.x * kSortLanes + (int64_t)wave * (kSortLanes / 16);
     int32_t key[kSortLanes / kSortThreads];
+    uint32_t root_word[kSortLanes / kSortThreads];  // (second staging level: the lanes' root words go through the same permutation)
 #pragma unroll
     for (int r = 0; r < kSortLanes / kSortThreads; ++r) {
         const int64_t b = base + r * 64 + lane;
         key[r] = b < B ? keys[b] : -1;
+        root_word[r] = (stage_root && b < B) ? stage_root[b] : 0u;
     }
     if (visited) {
         for (int64_t r = (int64_t)blockIdx.x * kSortThreads + threadIdx.x; r < 2 * S; r += (int64_t)gridDim.x * kSortThreads)
@@ -912,7 +967,11 @@ __global__ __launch_bounds__(kSortThreads) void k_bucket_scatter(int64_t B, int 
     __syncthreads();
 #pragma unroll
     for (int r = 0; r < kSortLanes / kSortThreads; ++r)
-        if (key[r] >= 0) lane_ids[wcnt[my_row * n_buckets + key[r]] + rank[r]] = (int32_t)(base + r * 64 + lane);
+        if (key[r] >= 0) {
+            const int32_t at = wcnt[my_row * n_buckets + key[r]] + rank[r];
+            lane_ids[at] = (int32_t)(base + r * 64 + lane);
+            if (stage_sorted) stage_sorted[at] = root_word[r];
+        }
 }
 
 // ---------------------------------------------------------------------------------------- 3. rollout in bucket order
@@ -1995,11 +2054,12 @@ int rollout_bucketed_impl(const rnad_tree_t *tree, const RolloutBuffers &tr, boo
                           const rnad_step_params_t *device_params, void *scratch, int32_t *lane_ids, int32_t *items, int32_t *n_items,
                           double *norm, hipStream_t stream, int phases = 3, int32_t *group_flags = nullptr,
                           const int32_t *play_rows = nullptr, const int64_t *n_play_rows = nullptr, int32_t *staged_rows = nullptr,
-                          int64_t *n_staged = nullptr, bool visited_is_clear = false) {
+                          int64_t *n_staged = nullptr, bool visited_is_clear = false, void *stage_buf = nullptr) {
     Plan p;
     RNAD_REQUIRE(make_plan(tree, tr.B, p), "rnad_rollout_bucketed: this tree / batch cannot be bucketed (see rnad_bucket_plan)");
     const int64_t B = tr.B, S = tree->S;
     const Scratch s = carve_scratch(scratch, B, p);
+    const StageOut stage = carve_stage(stage_buf, B, S);
     const int n_steps = std::min(p.cut->max_path, tr.T_cap), nb = p.cut->n_buckets;
     ProfScope prof(PROF_ACT, stream);
     const bool sort_phase = (phases & 1) != 0, play_phase = (phases & 2) != 0;
@@ -2041,11 +2101,11 @@ int rollout_bucketed_impl(const rnad_tree_t *tree, const RolloutBuffers &tr, boo
             RNAD_DISPATCH_A(tree->A, hipLaunchKernelGGL((k_bucket_keys_lds<kA, kPlay>), dim3(p.sort_blocks), dim3(kSortThreads), keys_lds, stream,
                                                         (const UpperWalk *)p.cut->upper_walk, (const int32_t *)p.cut->upper_list, p.cut->n_upper, nb,
                                                         tree->C, S, B, n_steps, policy_tab, policy_stride, (int)p.cut->host_bucket_of[1],
-                                                        p.cut->n_groups, seed, device_params, lane0, s.keys, s.decisions, s.hist, norm));
+                                                        p.cut->n_groups, seed, device_params, lane0, s.keys, s.decisions, s.hist, norm, stage));
         } else {
             RNAD_DISPATCH_A(tree->A, hipLaunchKernelGGL((k_bucket_keys<kA, kPlay>), dim3(blocks_for(B, kThreads * kPlay)), dim3(kThreads), 0, stream, tree->trans, tree->C,
                                                         S, B, n_steps, policy_tab, policy_stride, vec4, (const int32_t *)p.cut->bucket_of,
-                                                        p.cut->n_groups, seed, device_params, lane0, s.keys, s.decisions, norm));
+                                                        p.cut->n_groups, seed, device_params, lane0, s.keys, s.decisions, norm, stage));
         }
     }
     const size_t lds = (size_t)nb * sizeof(int32_t);
@@ -2064,7 +2124,7 @@ int rollout_bucketed_impl(const rnad_tree_t *tree, const RolloutBuffers &tr, boo
         hipLaunchKernelGGL(k_bucket_scatter, dim3(p.sort_blocks), dim3(kSortThreads), scatter_lds, stream, B, nb, (const int32_t *)s.keys,
                            (const int32_t *)s.hist, (const int32_t *)s.totals, p.chunk, (Item *)items, n_items, lane_ids, wave_rows, S,
                            p.cut->n_groups, (const int32_t *)p.cut->bucket_lo, (const int32_t *)p.cut->bucket_span,
-                           (const int32_t *)p.cut->group_by_lo, staged_rows, n_staged, tr.visited);
+                           (const int32_t *)p.cut->group_by_lo, staged_rows, n_staged, tr.visited, (const uint32_t *)stage.root, stage.sorted);
         if (group_flags)
             hipLaunchKernelGGL(k_group_flags, dim3(blocks_for(S)), dim3(kThreads), 0, stream, S, (const int32_t *)p.cut->bucket_of,
                                p.cut->n_groups, (const int32_t *)s.totals, group_flags);
@@ -2106,14 +2166,53 @@ int rollout_bucketed_impl(const rnad_tree_t *tree, const RolloutBuffers &tr, boo
 extern "C" int rnad_bucket_sort(const rnad_tree_t *tree, int T_cap, int64_t B, const float *table, int64_t table_stride, int table_is_policy,
                                 uint64_t seed, int64_t lane0, const rnad_step_params_t *device_params, void *scratch, int32_t *lane_ids,
                                 int32_t *items, int32_t *n_items, double *norm, int32_t *group_flags, int32_t *staged_rows, int64_t *n_staged,
-                                int32_t *visited, void *stream) {
+                                int32_t *visited, void *stage, void *stream) {
     RNAD_REQUIRE(tree && table && scratch && lane_ids && items && n_items, "rnad_bucket_sort: null argument");
     RNAD_REQUIRE(!staged_rows == !n_staged, "rnad_bucket_sort: staged_rows and n_staged go together");
     RNAD_REQUIRE(T_cap >= 1 && T_cap <= kCompactSteps && B >= 1, "rnad_bucket_sort: 1 <= T_cap <= %d, got %d", kCompactSteps, T_cap);
     RNAD_REQUIRE(table_stride >= tree->A, "rnad_bucket_sort: bad table stride");
     const RolloutBuffers out{T_cap, B, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, visited};
     return rollout_bucketed_impl(tree, out, true, table, table_stride, table_is_policy, nullptr, 1, seed, lane0, device_params, scratch,
-                                 lane_ids, items, n_items, norm, (hipStream_t)stream, 1, group_flags, nullptr, nullptr, staged_rows, n_staged);
+                                 lane_ids, items, n_items, norm, (hipStream_t)stream, 1, group_flags, nullptr, nullptr, staged_rows, n_staged,
+                                 false, stage);
+}
+
+extern "C" int64_t rnad_bucket_stage_bytes(const rnad_tree_t *tree, int64_t B) {
+    if (!tree || B < 1) return -1;
+    if (tree->S > ((int64_t)1 << kStageRootBits)) return -1;  // (a root word holds the state in 26 bits)
+    return (int64_t)(2 * sizeof(unsigned long long) + 2 * (size_t)B * sizeof(uint32_t) + 2 * (size_t)tree->S * sizeof(uint32_t));
+}
+
+extern "C" int rnad_bucket_stage_rows(const rnad_tree_t *tree, int64_t B, int level, uint64_t seed, const rnad_step_params_t *device_params,
+                                      void *stage, int32_t *rows, void *stream) {
+    RNAD_REQUIRE(tree && stage && rows && (level == 0 || level == 1), "rnad_bucket_stage_rows: null argument / level must be 0 or 1");
+    Plan p;
+    RNAD_REQUIRE(make_plan(tree, B, p), "rnad_bucket_stage_rows: this tree / batch cannot be bucketed (see rnad_bucket_plan)");
+    const StageOut st = carve_stage(stage, B, tree->S);
+    if (level == 0)
+        hipLaunchKernelGGL(k_stage_rows<0>, dim3(blocks_for(tree->S, kSortThreads * kStagePer)), dim3(kSortThreads), 0, (hipStream_t)stream, tree->S, (const uint32_t *)st.mark0,
+                           (const int32_t *)p.cut->anchor1, seed, device_params, rows, st.counts);
+    else
+        hipLaunchKernelGGL(k_stage_rows<1>, dim3(blocks_for(tree->S, kSortThreads * kStagePer)), dim3(kSortThreads), 0, (hipStream_t)stream, tree->S, (const uint32_t *)st.mark1,
+                           (const int32_t *)p.cut->anchor1, seed, device_params, rows, st.counts + 1);
+    RNAD_HIP_OK(hipGetLastError());
+    return 0;
+}
+
+extern "C" int rnad_bucket_stage_walk(const rnad_tree_t *tree, int T_cap, int64_t B, const float *policy_rows, int64_t stride, uint64_t seed,
+                                      int64_t lane0, const rnad_step_params_t *device_params, const void *scratch, const int32_t *lane_ids,
+                                      void *stage, void *stream) {
+    RNAD_REQUIRE(tree && policy_rows && scratch && stage && lane_ids, "rnad_bucket_stage_walk: null argument");
+    RNAD_REQUIRE(stride >= tree->A && T_cap >= 1, "rnad_bucket_stage_walk: bad table stride / T_cap");
+    Plan p;
+    RNAD_REQUIRE(make_plan(tree, B, p), "rnad_bucket_stage_walk: this tree / batch cannot be bucketed (see rnad_bucket_plan)");
+    const StageOut st = carve_stage(stage, B, tree->S);
+    const int vec4 = (stride % 4 == 0 && ((uintptr_t)policy_rows & 15) == 0) ? 1 : 0;
+    RNAD_DISPATCH_A(tree->A, hipLaunchKernelGGL((k_stage_walk<kA>), dim3(blocks_for(B)), dim3(kThreads), 0, (hipStream_t)stream, tree->trans, tree->C,
+                                                tree->S, B, T_cap, policy_rows, stride, vec4, (const uint32_t *)st.sorted, lane_ids, seed,
+                                                device_params, lane0, st.mark1));
+    RNAD_HIP_OK(hipGetLastError());
+    return 0;
 }
 
 extern "C" int rnad_bucket_play(const rnad_tree_t *tree, int T_cap, int64_t B, const float *table, int64_t table_stride, int table_is_policy,

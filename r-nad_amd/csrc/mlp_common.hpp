@@ -137,6 +137,32 @@ __device__ __forceinline__ f32x16 mfma_chain(const float *__restrict__ lds, int 
 
 __device__ __forceinline__ f32x2 relu2(float a, float b) { return f32x2{fmaxf(a, 0.0f), fmaxf(b, 0.0f)}; }
 
+// Second layer for one 32x32 hidden tile, written on float pairs so that it compiles to v_pk_fma_f32 without register
+// shuffles (fp32 MFMA and VALU work do not overlap on gfx950: every VALU instruction here is kernel time).  The summation
+// order is this kernel's own; nothing in the reference fixes it.
+__device__ __forceinline__ void epilogue_value(const f32x16 &c, const float *__restrict__ w1, f32x2 (&acc)[2]) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const float4 w = *reinterpret_cast<const float4 *>(w1 + 8 * g);
+        acc[0] = __builtin_elementwise_fma(f32x2{w.x, w.y}, relu2(c[4 * g + 0], c[4 * g + 1]), acc[0]);
+        acc[1] = __builtin_elementwise_fma(f32x2{w.z, w.w}, relu2(c[4 * g + 2], c[4 * g + 3]), acc[1]);
+    }
+}
+
+template <int A>
+__device__ __forceinline__ void epilogue_policy(const f32x16 &c, const float *__restrict__ w1, int W, f32x2 (&acc)[A][2]) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const f32x2 h01 = relu2(c[4 * g + 0], c[4 * g + 1]), h23 = relu2(c[4 * g + 2], c[4 * g + 3]);
+#pragma unroll
+        for (int a = 0; a < A; ++a) {
+            const float4 w = *reinterpret_cast<const float4 *>(w1 + a * W + 8 * g);
+            acc[a][0] = __builtin_elementwise_fma(f32x2{w.x, w.y}, h01, acc[a][0]);
+            acc[a][1] = __builtin_elementwise_fma(f32x2{w.z, w.w}, h23, acc[a][1]);
+        }
+    }
+}
+
 // floats per sample row of the backward's LDS stage: the augmented input (x | 1) padded with zeros to whole MFMA feature tiles
 // (16-wide tiles, plus one 4-wide tile when at most 4 features are left over), made odd
 __host__ __device__ constexpr int bwd_stage_stride(int K) {

@@ -1,0 +1,334 @@
+// mlp_rows.hip -- the nets of a tabular update on the (player, state) rows of the tree AND the row records, in one launch (gfx950).
+//
+// The default step evaluates the learner net (both heads) and the target net (value head) on the 2S observations of the tree
+// (learn/rnad.py:373,378 on every distinct input) and then turns the five net-output tables into the row records of the bucketed
+// update (rnad_bucket_records: policy heads, process_policy, log_policy_reg, the fast records, the actor's policy rows).  At
+// 2S = 132 862 rows both are mostly latency: k_mlp_forward gives every 4-wave workgroup a 45 KB weight image for ONE 64-row span per
+// wave, and k_row_records is a launch of ~550 dependent instructions per row that waits for its loads and stores.  Here:
+//   * one persistent workgroup per CU: W / 32 COMPUTE waves, one per hidden tile -- wave w owns hidden tile w of the learner's value
+//     head, of the target's value head and of the learner's policy head; its first-layer weights (the A operands of its MFMA chains)
+//     stay in REGISTERS for the whole launch: there is no weight image in LDS, only the folded first-layer biases and the second-layer
+//     rows -- and 4 RECORD waves;
+//   * a workgroup takes a contiguous run of 32-row tiles (their count differs by at most one between workgroups) in steps of 64 rows
+//     (an odd last tile is a half step), 4 steps to a chunk.  Phase 1 (compute waves): the partial second-layer sums of the wave's tiles
+//     for the rows of the chunk, parked in LDS.  Phase 2 (record waves, one step each, WHILE the compute waves are in phase 1 of the
+//     next chunk: the matrix pipe never waits for the latency-bound record arithmetic): the W / 32 partial sums added up in wave order
+//     (+ the output bias) complete logits / v / v_target; then the row's records with the very function k_row_records uses
+//     (row_records.hpp) -- same bits for the same logits.  One barrier per chunk, two buffers of partial sums.
+// POLICY = false is the lazy-rows variant (learn/rnad.py: _value_tables): the learner's logits already exist (the staged actor wrote
+// them), only the two value heads are evaluated, on a listed subset of the rows.
+// Summation order of the second layer (this kernel's own, as k_mlp_forward's is its own; nothing in the reference fixes it): per lane
+// and hidden tile as epilogue_value / epilogue_policy, the two half-waves, then the tiles in ascending order, then the bias.
+#include "mlp_common.hpp"
+#include "row_records.hpp"
+
+using namespace rnad;
+using namespace rnad::dev;
+using namespace rnad_mlp;
+
+namespace {
+
+constexpr int kRowsMaxWaves = 8;  // compute waves: W <= 256
+constexpr int kRecWaves = 4;      // record waves
+constexpr int kChunkSteps = 4;    // 64-row steps per chunk: one per record wave
+// A/B switch for tools/ (what the kernel's time is made of): 1 = no records in phase 2, 2 = no MFMA chains / epilogues in phase 1
+#ifndef RNAD_ROWS_ABLATE
+#define RNAD_ROWS_ABLATE 0
+#endif
+
+struct RowsArgs {
+    const float *packed_net, *packed_target;  // weight images (rnad_mlp_pack / _pack_fold)
+    float *logit, *v, *v_target;              // tables [2S, A], [2S], [2S]: written (logit: read when the policy head is not evaluated here)
+    const float *logit_reg, *logit_reg_;      // [2S, A] logits of the two regularisation nets
+    const uint8_t *mask_tab;
+    float *rec, *fast, *pol_rows;             // record tables (rec / pol_rows may be NULL)
+    const rnad_step_params_t *sp;
+    const int32_t *rows;                      // optional row list (count in device memory)
+    const int64_t *n_rows;
+};
+
+// First layer of one hidden tile for two (TWO) or one 32-row tiles: A operands from registers, the (folded) bias tile from LDS as the
+// C operand of each chain's first MFMA.
+template <int KS, bool TWO>
+__device__ __forceinline__ void chain_reg(const float (&a)[KS], const float *__restrict__ brow, const float (&x0)[KS], const float (&x1)[KS],
+                                          f32x16 &c0, f32x16 &c1) {
+    f32x16 bias;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const float4 b = *reinterpret_cast<const float4 *>(brow + 8 * g);
+        bias[4 * g + 0] = b.x; bias[4 * g + 1] = b.y; bias[4 * g + 2] = b.z; bias[4 * g + 3] = b.w;
+    }
+    c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0], x0[0], bias, 0, 0, 0);
+    if constexpr (TWO) c1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0], x1[0], bias, 0, 0, 0);
+#pragma unroll
+    for (int ks = 1; ks < KS; ++ks) {
+        c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ks], x0[ks], c0, 0, 0, 0);
+        if constexpr (TWO) c1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ks], x1[ks], c1, 0, 0, 0);
+    }
+}
+
+__device__ __forceinline__ float lane_sum(const f32x2 (&acc)[2]) { return (acc[0].x + acc[0].y) + (acc[1].x + acc[1].y); }
+
+template <bool B>
+struct Flag { static constexpr bool value = B; };
+
+template <int A, typename ObsT, bool FOLD, bool POLICY>
+__global__ __launch_bounds__(64 * (kRowsMaxWaves + kRecWaves)) void k_rows_forward_records(int64_t N, int W, RowsArgs g, const ObsT *__restrict__ obs,
+                                                                                           rnad_learn_params_t hp) {
+    if (g.n_rows) N = *g.n_rows;
+    if (g.sp) {
+        hp.alpha = g.sp->alpha;
+        hp.one_minus_alpha = g.sp->one_minus_alpha;
+    }
+    constexpr int K = MlpShape<A, FOLD>::K, KS = K / 2, OBS = MlpShape<A, FOLD>::OBS;
+    constexpr int NOUT = POLICY ? 2 + A : 2;  // partial sums per row: learner value | target value | learner logits
+    constexpr int U = POLICY ? 3 : 2;         // hidden tiles per compute wave: learner value, target value, learner policy
+    const int T = W / kTile;                  // hidden tiles per head = compute waves of this workgroup
+    const int nthreads = 64 * (T + kRecWaves);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, col = lane & 31, half = lane >> 5;
+    const bool computes = wave < T;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float *b0f = lds;                // [3][W] first-layer biases (FOLD: with the legal columns folded in)
+    float *w1 = lds + 3 * W;         // [2 + A][W] second-layer rows: learner value | target value | learner policy [A]
+    float *part = w1 + (2 + A) * W;  // [2][kChunkSteps][T][NOUT][64] partial sums; before the first step: the indicator weights [U][W]
+    const int part_buf = kChunkSteps * T * NOUT * 64;
+
+    float a[U][KS];  // a compute wave's A operands: W0[hidden = 32 tile + col][k = 2 ks + half]
+    if (computes) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const float *img = u == 1 ? g.packed_target : g.packed_net;
+            const int tile = u == 2 ? T + wave : wave;
+            const float *wa = img + tile * (KS * 64) + half * 32 + col;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) a[u][ks] = wa[ks * 64];
+        }
+    }
+    for (int i = threadIdx.x; i < U * W; i += nthreads) {
+        const int u = i / W, h = i % W;
+        const float *img = u == 1 ? g.packed_target : g.packed_net;
+        const int hs = u == 2 ? W + h : h;  // row of the stacked [2W] first layer
+        float b = img[img_b0(K, W) + hs], wi = 0.0f;
+        if constexpr (FOLD) {
+            const float *lc = img + img_legal(K, W, A) + hs;
+            fold_hidden_unit<A>([&](int k) { return lc[k * 2 * W]; }, b, b, wi);
+        }
+        b0f[i] = b;
+        part[i] = wi;
+    }
+    for (int i = threadIdx.x; i < (POLICY ? 2 + A : 2) * W; i += nthreads) {
+        float x;
+        if (i < W) x = g.packed_net[img_w1v(K, W) + i];
+        else if (i < 2 * W) x = g.packed_target[img_w1v(K, W) + i - W];
+        else x = g.packed_net[img_w1p(K, W) + i - 2 * W];
+        w1[i] = x;
+    }
+    __syncthreads();
+    if constexpr (FOLD) {
+        constexpr int kk = A * A;  // the indicator's input slot
+        if (computes && half == (kk & 1)) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) a[u][kk / 2] = part[u * W + wave * kTile + col];
+        }
+    }
+    __syncthreads();  // the scratch in `part` is free
+
+    // this workgroup's rows: a contiguous run of 32-row tiles
+    const int64_t n_tiles = (N + kTile - 1) / kTile;
+    const int64_t base = n_tiles / gridDim.x, rem = n_tiles % gridDim.x;
+    const int64_t tile0 = (int64_t)blockIdx.x * base + ((int64_t)blockIdx.x < rem ? (int64_t)blockIdx.x : rem);
+    const int64_t my_tiles = base + ((int64_t)blockIdx.x < rem ? 1 : 0);
+    const int64_t s_begin = tile0 * kTile, s_end_ = (tile0 + my_tiles) * kTile, s_end = s_end_ < N ? s_end_ : N;
+    const int n_steps = (int)((my_tiles + 1) / 2);
+    const int n_chunks = (n_steps + kChunkSteps - 1) / kChunkSteps;
+
+    float xn[2][KS];  // B operands of the next step (x[row = 32 s + col][2 ks + half]), in flight during the current one
+    auto fetch = [&](int step) {
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const int64_t sample = s_begin + (int64_t)step * (2 * kTile) + s * kTile + col;
+            const bool in = sample < s_end;
+            const int64_t row = (in && g.rows) ? (int64_t)g.rows[sample] : sample;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) xn[s][ks] = in ? obs_feature<A, FOLD, ObsT>(obs + row * OBS, 2 * ks + half) : 0.0f;
+        }
+    };
+    const float *bias_u = b0f + wave * kTile + 4 * half;
+    const float *w1_u = w1 + wave * kTile + 4 * half;
+    // phase 1 of one step: this wave's hidden tiles on the step's 64 (TWO) or 32 rows -> partial sums into `dst`
+    auto p1_step = [&](int step, float *dst, auto two_) {
+        constexpr bool TWO = decltype(two_)::value;
+        float x0[KS], x1[KS];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) { x0[ks] = xn[0][ks]; x1[ks] = xn[1][ks]; }
+        if (step + 1 < n_steps) fetch(step + 1);
+        float out[NOUT][2];  // [output][row tile]
+#if RNAD_ROWS_ABLATE & 2
+#pragma unroll
+        for (int o = 0; o < NOUT; ++o) out[o][0] = out[o][1] = x0[0] + x1[1];
+#else
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {  // learner value, target value
+            f32x16 c0_, c1_;
+            f32x2 acc0[2] = {f32x2{0.f, 0.f}, f32x2{0.f, 0.f}}, acc1[2] = {f32x2{0.f, 0.f}, f32x2{0.f, 0.f}};
+            chain_reg<KS, TWO>(a[u], bias_u + u * W, x0, x1, c0_, c1_);
+            epilogue_value(c0_, w1_u + u * W, acc0);
+            if constexpr (TWO) epilogue_value(c1_, w1_u + u * W, acc1);
+            out[u][0] = lane_sum(acc0);
+            out[u][1] = lane_sum(acc1);
+        }
+        if constexpr (POLICY) {
+            f32x16 c0_, c1_;
+            f32x2 acc0[A][2], acc1[A][2];
+#pragma unroll
+            for (int a_ = 0; a_ < A; ++a_) acc0[a_][0] = acc0[a_][1] = acc1[a_][0] = acc1[a_][1] = f32x2{0.f, 0.f};
+            chain_reg<KS, TWO>(a[U - 1], bias_u + 2 * W, x0, x1, c0_, c1_);
+            epilogue_policy<A>(c0_, w1_u + 2 * W, W, acc0);
+            if constexpr (TWO) epilogue_policy<A>(c1_, w1_u + 2 * W, W, acc1);
+#pragma unroll
+            for (int a_ = 0; a_ < A; ++a_) {
+                out[2 + a_][0] = lane_sum(acc0[a_]);
+                out[2 + a_][1] = lane_sum(acc1[a_]);
+            }
+        }
+#endif
+        // the two half-waves hold complementary hidden rows of the same 32 + 32 rows: half h keeps row tile h and gets the other
+        // half's share of it -- lane l ends up with the tile's sums for row 64 step + l
+#pragma unroll
+        for (int o = 0; o < NOUT; ++o) {
+            const float keep = half ? out[o][1] : out[o][0], send = half ? out[o][0] : out[o][1];
+            dst[o * 64] = keep + __shfl_xor(send, 32, 64);
+        }
+    };
+    // phase 2 of one step: complete the sums of its 64 rows, then their records
+    auto p2_step = [&](int step, const float *src) {
+        const int64_t sample = s_begin + (int64_t)step * (2 * kTile) + lane;
+        if (sample >= s_end) return;
+        const int64_t row = g.rows ? (int64_t)g.rows[sample] : sample;
+        const uint32_t bits = g.mask_tab[row];
+        float lr[A], lr2[A], lg[A];
+#pragma unroll
+        for (int a_ = 0; a_ < A; ++a_) {
+            lr[a_] = g.logit_reg[row * A + a_];
+            lr2[a_] = g.logit_reg_[row * A + a_];
+            if (!POLICY) lg[a_] = g.logit[row * A + a_];
+        }
+        float sum[NOUT];
+#pragma unroll
+        for (int o = 0; o < NOUT; ++o) sum[o] = src[o * 64];
+        for (int w = 1; w < T; ++w) {
+#pragma unroll
+            for (int o = 0; o < NOUT; ++o) sum[o] += src[(w * NOUT + o) * 64];
+        }
+        const float *b1n = g.packed_net + img_b1(K, W, A), *b1t = g.packed_target + img_b1(K, W, A);  // [1 + A]: value bias, policy biases
+        const float vr = sum[0] + b1n[0], vtr = sum[1] + b1t[0];
+        if constexpr (POLICY) {
+#pragma unroll
+            for (int a_ = 0; a_ < A; ++a_) g.logit[row * A + a_] = lg[a_] = sum[2 + a_] + b1n[1 + a_];
+        }
+        g.v[row] = vr;
+        g.v_target[row] = vtr;
+#if RNAD_ROWS_ABLATE & 1
+        if (bits == 0x12345u) g.fast[row] = lr[0] + lr2[0] + lg[0];
+#else
+        write_row_records<A>(row, lg, vr, vtr, lr, lr2, bits, hp, g.rec, g.fast, g.pol_rows);
+#endif
+    };
+
+    if (computes && n_steps > 0) fetch(0);
+    // iteration c: the compute waves are in phase 1 of chunk c, the record waves in phase 2 of chunk c - 1 (the other buffer)
+    for (int c = 0; c <= n_chunks; ++c) {
+        if (computes) {
+            if (c < n_chunks) {
+                float *buf = part + (c & 1) * part_buf + (int64_t)wave * NOUT * 64 + lane;
+                const int first = c * kChunkSteps, last = first + kChunkSteps < n_steps ? first + kChunkSteps : n_steps;
+                for (int step = first; step < last; ++step) {
+                    float *dst = buf + (int64_t)(step - first) * T * NOUT * 64;
+                    if (2 * step + 1 < my_tiles) p1_step(step, dst, Flag<true>{});
+                    else p1_step(step, dst, Flag<false>{});
+                }
+            }
+        } else if (c > 0) {
+            const int step = (c - 1) * kChunkSteps + (wave - T);
+            if (step < n_steps) p2_step(step, part + ((c - 1) & 1) * part_buf + (int64_t)(wave - T) * T * NOUT * 64 + lane);
+        }
+        __syncthreads();
+    }
+}
+
+size_t rows_lds_bytes(int A, int W, bool policy) {
+    const int T = W / kTile, nout = policy ? 2 + A : 2;
+    return ((size_t)3 * W + (size_t)(2 + A) * W + (size_t)2 * kChunkSteps * T * nout * 64) * sizeof(float);
+}
+
+}  // namespace
+
+// Shapes whose instantiation keeps everything in registers under the 12-wave budget (168 VGPRs; hipcc 7.2 spills beyond): with the
+// policy head A <= 3, without it A <= 5 (FOLD) / 4.  Other shapes take the two launches this one replaces.
+extern "C" int rnad_mlp_rows_records_supported(int A, int W, int fold, int policy_from_table) {
+    if (A < 1 || A > RNAD_MAX_ACTIONS || W < kTile || W % kTile != 0 || W / kTile > kRowsMaxWaves) return 0;
+    if (fold && A < 2) return 0;
+    if (rows_lds_bytes(A, W, !policy_from_table) > 150 * 1024) return 0;
+    return policy_from_table ? A <= (fold ? 5 : 4) : A <= 3;
+}
+
+extern "C" int rnad_mlp_rows_records(const rnad_tree_t *tree, int W, int fold, const float *packed_net, const float *packed_target,
+                                     const void *obs, int obs_half, const int32_t *rows, const int64_t *n_rows, int policy_from_table,
+                                     float *logit_tab, float *v_tab, float *v_target_tab, const float *logit_reg_tab,
+                                     const float *logit_reg_tab_, const rnad_learn_params_t *hp, const rnad_step_params_t *device_params,
+                                     float *records, float *fast_records, float *policy_rows, void *stream_) {
+    RNAD_REQUIRE(tree && packed_net && packed_target && obs && logit_tab && v_tab && v_target_tab && logit_reg_tab && logit_reg_tab_ && hp && fast_records,
+                 "rnad_mlp_rows_records: null argument");
+    RNAD_REQUIRE(!rows == !n_rows, "rnad_mlp_rows_records: rows and n_rows go together");
+    const int A = tree->A;
+    RNAD_REQUIRE(rnad_mlp_rows_records_supported(A, W, fold, policy_from_table),
+                 "rnad_mlp_rows_records: shape not supported (A=%d, width=%d, fold=%d, policy_from_table=%d): see rnad_mlp_rows_records_supported", A, W,
+                 fold, policy_from_table);
+    RNAD_REQUIRE((((uintptr_t)records | (uintptr_t)fast_records | (uintptr_t)policy_rows) & 15) == 0, "rnad_mlp_rows_records: record tables must be 16-byte aligned");
+    hipStream_t stream = (hipStream_t)stream_;
+    const bool policy = !policy_from_table;
+    const int64_t N = 2 * tree->S;
+    int dev = 0, cus = 256;
+    RNAD_HIP_OK(hipGetDevice(&dev));
+    RNAD_HIP_OK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    const int T = W / kTile;
+    const int64_t n_tiles = (N + kTile - 1) / kTile;
+    const int64_t grid = std::max<int64_t>(1, std::min<int64_t>((n_tiles + 1) / 2, cus));  // one persistent workgroup per CU
+    const size_t lds_bytes = rows_lds_bytes(A, W, policy);
+    RowsArgs g{};
+    g.packed_net = packed_net; g.packed_target = packed_target;
+    g.logit = logit_tab; g.v = v_tab; g.v_target = v_target_tab;
+    g.logit_reg = logit_reg_tab; g.logit_reg_ = logit_reg_tab_;
+    g.mask_tab = tree->mask_tab;
+    g.rec = records; g.fast = fast_records; g.pol_rows = policy_rows;
+    g.sp = device_params; g.rows = rows; g.n_rows = n_rows;
+    ProfScope prof(PROF_MLP, stream);
+#define RNAD_ROWS_LAUNCH3(T_, F_, P_)                                                                                                  \
+    do {                                                                                                                               \
+        auto kern = k_rows_forward_records<kA, T_, F_, P_>;                                                                            \
+        if (lds_bytes > 64 * 1024)                                                                                                     \
+            RNAD_HIP_OK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));          \
+        hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64 * (T + kRecWaves)), lds_bytes, stream, N, W, g, (const T_ *)obs, *hp);          \
+    } while (0)
+#define RNAD_ROWS_LAUNCH2(T_, F_)                      \
+    do {                                               \
+        if (policy) RNAD_ROWS_LAUNCH3(T_, F_, true);   \
+        else RNAD_ROWS_LAUNCH3(T_, F_, false);         \
+    } while (0)
+#define RNAD_ROWS_LAUNCH(T_)                           \
+    do {                                               \
+        if (fold) RNAD_ROWS_LAUNCH2(T_, true);         \
+        else RNAD_ROWS_LAUNCH2(T_, false);             \
+    } while (0)
+    RNAD_DISPATCH_A(A, {
+        if (obs_half)
+            RNAD_ROWS_LAUNCH(__half);
+        else
+            RNAD_ROWS_LAUNCH(float);
+    });
+#undef RNAD_ROWS_LAUNCH3
+#undef RNAD_ROWS_LAUNCH2
+#undef RNAD_ROWS_LAUNCH
+    RNAD_HIP_OK(hipGetLastError());
+    return 0;
+}

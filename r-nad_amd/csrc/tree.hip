@@ -298,6 +298,7 @@ extern "C" void rnad_tree_destroy(rnad_tree_t *tree) {
         if (c.group_by_lo) (void)hipFree(c.group_by_lo);
         if (c.upper_list) (void)hipFree(c.upper_list);
         if (c.upper_walk) (void)hipFree(c.upper_walk);
+        if (c.anchor1) (void)hipFree(c.anchor1);
     }
     delete tree;
 }

@@ -21,6 +21,7 @@ What differs from the reference (all documented in INTEGRATION.md):
     `torch.manual_seed` still makes runs repeatable.
 """
 import random
+import os
 import time
 from collections import deque
 
@@ -375,11 +376,26 @@ class Episodes:
                 # policy-head launches the sort and the rollout would otherwise take from the logits
                 pol = getattr(table, "_policy_rows", None)
                 actor = dict(table=pol, table_is_policy=True) if pol is not None else dict(table=table)
-                # (the sort's last kernel writes the list of rows still to evaluate and clears `visited`: no flags, no compaction)
-                self.buckets, rows, _ = rnad_hip.bucket_sort(handle, traj, seed=self.seed, lane0=self.lane_offset, step_params=step_params,
-                                                             visited=visited, **actor)
-                staged_actor(rows)
-                self.staged_rows = (upper, rows)  # (bench.py reads how many rows the actor was evaluated on)
+                stage = rnad_hip.bucket_stage(handle, B) if (pol is not None and os.environ.get("RNAD_STAGE_LEVELS", "2") != "1") else None
+                if stage is not None:
+                    # two more stages below the cut (rnad_bucket_stage_*): the roots of the group subtrees the lanes enter, then -- one drawn
+                    # transition later -- the subtrees below the states they land in (configs[3]: 176 k rows instead of the 807 k of
+                    # every non-empty group)
+                    self.buckets, _, _ = rnad_hip.bucket_sort(handle, traj, seed=self.seed, lane0=self.lane_offset, step_params=step_params,
+                                                              visited=visited, want_rows=False, stage=stage, **actor)
+                    roots = rnad_hip.bucket_stage_rows(handle, B, stage, 0, seed=self.seed, step_params=step_params)
+                    staged_actor(roots)
+                    rnad_hip.bucket_stage_walk(handle, traj, self.buckets, stage, pol, seed=self.seed, lane0=self.lane_offset,
+                                               step_params=step_params)
+                    rows = rnad_hip.bucket_stage_rows(handle, B, stage, 1, seed=self.seed, step_params=step_params)
+                    staged_actor(rows)
+                    self.staged_rows = (upper, roots, rows)  # (bench.py reads how many rows the actor was evaluated on)
+                else:
+                    # (the sort's last kernel writes the list of rows still to evaluate and clears `visited`: no flags, no compaction)
+                    self.buckets, rows, _ = rnad_hip.bucket_sort(handle, traj, seed=self.seed, lane0=self.lane_offset, step_params=step_params,
+                                                                 visited=visited, **actor)
+                    staged_actor(rows)
+                    self.staged_rows = (upper, rows)  # (bench.py reads how many rows the actor was evaluated on)
                 rnad_hip.bucket_play(handle, traj, self.buckets, rows=None if pol is not None else rows, seed=self.seed, lane0=self.lane_offset,
                                      step_params=step_params, visited=visited, defer_alive=defer_alive, visited_is_clear=visited is not None, **actor)
                 self.lane_ids = self.buckets.lane_ids

@@ -441,7 +441,8 @@ class RNaD:
             entry["key"] = key
         return entry["images"]
 
-    def _table_outputs(self, alpha, obs_half=False, want_target_logits=False, policy_only=False, fold=False):
+    def _table_outputs(self, alpha, obs_half=False, want_target_logits=False, policy_only=False, fold=False, records_hp=None,
+                       step_params=None):
         """learner / target / regularisation nets on the 2S observations of the tree (rnad.py:373-380 on every distinct input):
         learner and target in ONE launch per step, the two regularisation nets from _reg_tables.  Both regularisation tables are
         always there: a term of log_policy_reg (:382) whose weight is exactly 0 adds exactly 0.
@@ -465,20 +466,45 @@ class RNaD:
             logit_reg, logit_reg_ = self._reg_tables(table, fold)
             return dict(table=table, logit=logit, v=None, logit_target=None, v_target=None, logit_reg=logit_reg, logit_reg_=logit_reg_,
                         packed_net=packed, packed_target=packed_target, staged_actor=staged_actor, fold=fold)
+        if records_hp is not None and not want_target_logits and rnad_hip.mlp_rows_records_supported(A, self.net.width, fold):
+            # records_hp: the caller wants the row records of this step too (rnad_hip.bucket_records(fast=True)) -- forwards and records
+            # come out of ONE launch (csrc/mlp_rows.hip: a persistent workgroup per CU, a wave per hidden tile, weights in registers)
+            logit_reg, logit_reg_ = self._reg_tables(table, fold)
+            with torch.no_grad():
+                out = rnad_hip.mlp_rows_records(self.tree.handle(), packed, packed_target, self.net.width, table, logit_reg, logit_reg_,
+                                                records_hp, step_params=step_params, fold=self.tree.handle() if fold else False)
+            return dict(table=table, logit=out["logit"], v=out["v"], logit_target=None, v_target=out["v_target"], logit_reg=logit_reg,
+                        logit_reg_=logit_reg_, packed_net=packed, fold=fold, records=out["records"], fast_records=out["fast_records"])
         with torch.no_grad():
             # (one launch entry per (net, head) -- three equal work units per 64-row span -- was measured: 45.5 instead of 43.4 us, every
             # workgroup loads its net's 43 KB weight image first)
             outs = rnad_hip.mlp_forward_multi([packed, packed_target], self.net.width, table, A,
                                               [(True, True), (want_target_logits, True)], fold=self.tree.handle() if fold else False)
         logit_reg, logit_reg_ = self._reg_tables(table, fold)
-        return dict(table=table, logit=outs[0][0], v=outs[0][1], logit_target=outs[1][0], v_target=outs[1][1], logit_reg=logit_reg,
-                    logit_reg_=logit_reg_, packed_net=packed, fold=fold)
+        tables = dict(table=table, logit=outs[0][0], v=outs[0][1], logit_target=outs[1][0], v_target=outs[1][1], logit_reg=logit_reg,
+                      logit_reg_=logit_reg_, packed_net=packed, fold=fold)
+        if records_hp is not None:
+            tables["records"], tables["fast_records"] = rnad_hip.bucket_records(
+                self.tree.handle(), tables["logit"], tables["v"], tables["v_target"], logit_reg, logit_reg_, records_hp,
+                step_params=step_params, fast=True)
+        return tables
 
     def _value_tables(self, tables, visited, alpha, step_params=None):
         """Lazy rows, after the rollout: the learner's and the target's value heads, the row records and (in __learn) the gradient
         tables and the backward on the rows the batch visited -- `visited` int32 [2S] from the rollout, compacted on the stream."""
         handle, A = self.tree.handle(), self.tree.max_actions
         rows = rnad_hip.compact_valid(visited)
+        if rnad_hip.mlp_rows_records_supported(A, self.net.width, tables.get("fold", False), True):
+            # both value heads on the listed rows and their records in one launch (csrc/mlp_rows.hip, the variant that reads the logits)
+            with torch.no_grad():
+                out = rnad_hip.mlp_rows_records(handle, tables["packed_net"], tables["packed_target"], self.net.width, tables["table"],
+                                                tables["logit_reg"], tables["logit_reg_"], self._learn_params(alpha), step_params=step_params,
+                                                fold=handle if tables.get("fold", False) else False, rows=rows, logit_tab=tables["logit"])
+            tables["v"], tables["v_target"] = out["v"], out["v_target"]
+            tables["records"], tables["fast_records"] = out["records"], out["fast_records"]
+            tables["rows"] = rows
+            self.last_rows = rows
+            return tables
         with torch.no_grad():
             # (the rows that are not listed are never read: records, gradient tables and the backward all go by the same list)
             fold = handle if tables.get("fold", False) else False
@@ -747,10 +773,8 @@ class RNaD:
         elif mode is True:
             # the nets do not change between this step's rollout and its update: one evaluation of the 2S observations serves the
             # actor (= the learner net, rnad.py:503-505) and all four nets of __learn
-            tables = self._table_outputs(alpha, getattr(self, "obs_half", False), want_target_logits=log is not None, fold=fold)
-            tables["records"], tables["fast_records"] = rnad_hip.bucket_records(
-                handle, tables["logit"], tables["v"], tables["v_target"], tables["logit_reg"], tables["logit_reg_"], self._learn_params(alpha),
-                step_params=step_params, fast=True)
+            tables = self._table_outputs(alpha, getattr(self, "obs_half", False), want_target_logits=log is not None, fold=fold,
+                                         records_hp=self._learn_params(alpha), step_params=step_params)
         if self.total_steps % self.buffer_mod == 0:
             episodes = episode.Episodes(self.tree, local_batch, seed=self._new_seed(), lane_offset=rank * local_batch,
                                         obs_half=getattr(self, "obs_half", False))

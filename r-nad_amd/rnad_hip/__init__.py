@@ -832,12 +832,57 @@ def bucket_upper_rows(tree, B):
     return plan.upper_rows
 
 
+class Stage:
+    """Workspace of a staged actor's second level (rnad_bucket_stage_*): per lane the group subtree root it enters, two stamp tables over
+    the states, and the two row lists (LiveRows-shaped: rows int32 [2S], count = a view of the workspace's first two int64)."""
+
+    def __init__(self, tree, B, device):
+        n = int(lib().rnad_bucket_stage_bytes(tree.ptr, B))
+        self.buf = torch.zeros(((n + 7) // 8,), dtype=torch.int64, device=device)
+        self.lists = []
+        for level in range(2):
+            rows = RowList.__new__(RowList)
+            rows.N = 2 * tree.S
+            rows.rows = torch.empty((2 * tree.S,), dtype=I32, device=device)
+            rows.count = self.buf[level: level + 1]
+            self.lists.append(rows)
+
+
+def bucket_stage(tree, B):
+    """The Stage of (tree, B), cached on the plan (its buffers keep their addresses: a captured graph of the step holds them)."""
+    plan = bucket_plan(tree, B)
+    if getattr(plan, "stage", None) is None:
+        if int(lib().rnad_bucket_stage_bytes(tree.ptr, B)) < 0:
+            return None  # (more than 2^26 states: one staging level)
+        plan.stage = Stage(tree, B, tree.device)
+    return plan.stage
+
+
+def bucket_stage_rows(tree, B, stage, level, seed=0, step_params=None):
+    """rnad_bucket_stage_rows: the row list of staging level 0 (the group subtree roots the lanes enter; after bucket_sort(stage=...)) or 1
+    (the subtrees below the states the lanes were drawn into; after bucket_stage_walk).  Same seed / step_params as the sort."""
+    rows = stage.lists[level]
+    _check(lib().rnad_bucket_stage_rows(tree.ptr, B, level, seed, _dp(step_params, torch.int64, "step_params", True),
+                                        _dp(stage.buf, torch.int64, "stage"), _dp(rows.rows, I32, "rows"), _stream()))
+    return rows
+
+
+def bucket_stage_walk(tree, traj, buckets, stage, policy_rows, seed=0, lane0=0, step_params=None):
+    """rnad_bucket_stage_walk: every lane's transition at the root of the group subtree it enters, drawn as bucket_play will draw it from
+    `policy_rows` (the actor's policy rows [2S, stride], evaluated on bucket_stage_rows(level 0)); stamps the states the lanes land in."""
+    assert policy_rows.shape[0] == 2 * tree.S
+    _check(lib().rnad_bucket_stage_walk(tree.ptr, traj.T_cap, traj.B, _dp(policy_rows, F32, "policy_rows"), policy_rows.shape[1], seed, lane0,
+                                        _dp(step_params, torch.int64, "step_params", True), _dp(buckets.plan.scratch, I32, "scratch"),
+                                        _dp(buckets.lane_ids, I32, "lane_ids"), _dp(stage.buf, torch.int64, "stage"), _stream()))
+
+
 def bucket_sort(tree, traj, table, seed=0, lane0=0, step_params=None, table_is_policy=False, column=0, want_flags=False, want_rows=True,
-                visited=None):
+                visited=None, stage=None):
     """rnad_bucket_sort: the first half of rollout_bucketed_compact (keys + sort) for an actor evaluated in stages; `table` needs the
     rows of bucket_upper_rows() only.  Returns (buckets, rows, flags): rows = a RowList of both players' rows of every state inside a
     group the batch descends into (written by the sort's last kernel: evaluate the actor on it, then call bucket_play); flags (want_flags)
-    the same set as int32 [2S] marks.  visited (int32 [2S]): cleared here for bucket_play(visited_is_clear=True)."""
+    the same set as int32 [2S] marks.  visited (int32 [2S]): cleared here for bucket_play(visited_is_clear=True).
+    stage (bucket_stage()): the keys pass also records what the second staging level needs (bucket_stage_rows / bucket_stage_walk)."""
     assert traj.compact and traj.T_cap <= COMPACT_MAX_STEPS
     plan = bucket_plan(tree, traj.B)
     if plan is None:
@@ -857,7 +902,8 @@ def bucket_sort(tree, traj, table, seed=0, lane0=0, step_params=None, table_is_p
                                   _dp(buckets.lane_ids, I32, "lane_ids"), _dp(buckets.items, I32, "items"), _dp(buckets.n_items, I32, "n_items"),
                                   _dp(buckets.norm, F64, "norm"), _dp(flags, I32, "group_flags", True),
                                   _dp(rows.rows, I32, "staged_rows") if rows is not None else None,
-                                  C.c_void_p(rows.count.data_ptr()) if rows is not None else None, _dp(visited, I32, "visited", True), _stream()))
+                                  C.c_void_p(rows.count.data_ptr()) if rows is not None else None, _dp(visited, I32, "visited", True),
+                                  _dp(stage.buf, torch.int64, "stage") if stage is not None else None, _stream()))
     return buckets, rows, flags
 
 
@@ -991,6 +1037,42 @@ def bucket_records(tree, logit_tab, v_tab, v_target_tab, logit_reg_tab, logit_re
     if pol is not None:
         rec._policy_rows = pol  # travels with the records: rollout_bucketed_compact(table=records) gathers from it
     return (rec, quick) if fast else rec
+
+
+def mlp_rows_records_supported(A, W, fold=False, from_table=False):
+    return os.environ.get("RNAD_FUSED_ROWS", "1") == "1" and bool(lib().rnad_mlp_rows_records_supported(A, W, int(bool(fold)), int(bool(from_table))))
+
+
+def mlp_rows_records(tree, packed_net, packed_target, W, obs, logit_reg_tab, logit_reg_tab_, hp, step_params=None, fold=False, rows=None,
+                     logit_tab=None, want_records=True, want_policy_rows=True):
+    """rnad_mlp_rows_records: learner (both heads) and target (value head) on the tree's observation table `obs` AND the row records of
+    bucket_records(fast=True), in one launch.  Returns dict(logit [2S, A], v [2S, 1], v_target [2S, 1], records, fast_records); the
+    actor's policy rows travel as records._policy_rows, as with bucket_records.
+    logit_tab: the learner's logits already exist (a staged actor wrote them) -- only the value heads are evaluated; rows: a LiveRows
+    over the 2S rows -- only those rows are evaluated and written (policy rows are then not produced: only a full table can be an actor)."""
+    fold = _fold_checked(fold, obs, "mlp_rows_records")
+    A, N = tree.A, 2 * tree.S
+    assert obs.numel() == N * 2 * A * A, "mlp_rows_records: obs must be the tree's observation table"
+    half = obs.dtype == F16
+    dev = obs.device
+    assert rows is None or rows.N == N
+    from_table = logit_tab is not None
+    logit = logit_tab if from_table else torch.empty((N, A), dtype=F32, device=dev)
+    v = torch.empty((N, 1), dtype=F32, device=dev)
+    vt = torch.empty((N, 1), dtype=F32, device=dev)
+    rec = torch.empty((N, int(lib().rnad_bucket_record_stride(A))), dtype=F32, device=dev) if want_records else None
+    quick = torch.empty((N, int(lib().rnad_bucket_fast_record_stride(A))), dtype=F32, device=dev)
+    pol = (torch.empty((N, int(lib().rnad_bucket_policy_row_stride(A))), dtype=F32, device=dev)
+           if (want_policy_rows and rows is None and not from_table and os.environ.get("RNAD_POLICY_ROWS", "1") == "1") else None)
+    _check(lib().rnad_mlp_rows_records(tree.ptr, W, int(fold), _dp(packed_net, F32, "packed_net"), _dp(packed_target, F32, "packed_target"),
+                                       _dp(obs, F16 if half else F32, "obs"), int(half), *_row_list(rows), int(from_table),
+                                       _dp(logit, F32, "logit_tab"), _dp(v, F32, "v_tab"), _dp(vt, F32, "v_target_tab"),
+                                       _dp(logit_reg_tab, F32, "logit_reg_tab"), _dp(logit_reg_tab_, F32, "logit_reg_tab_"), C.byref(hp),
+                                       _dp(step_params, torch.int64, "step_params", True), _dp(rec, F32, "records", True),
+                                       _dp(quick, F32, "fast_records"), _dp(pol, F32, "policy_rows", True), _stream()))
+    if pol is not None and rec is not None:
+        rec._policy_rows = pol
+    return dict(logit=logit, v=v, v_target=vt, records=rec, fast_records=quick, policy_rows=pol)
 
 
 def learn_bucketed(tree, buckets, indices, actions, rewards, mu, records, norm, hp, want_losses=False):

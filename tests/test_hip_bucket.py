@@ -631,6 +631,66 @@ def test_staged_actor_plays_the_same_batch(name, rows, monkeypatch):
     assert torch.equal(dirty, expect)
 
 
+@pytest.mark.parametrize("name,rows", (("pruned", None), ("pruned", 12), ("a5c4", None), ("a5c4", 40), ("ternary4", None), ("ternary4", 20), ("binary", None)))
+@pytest.mark.parametrize("keys_global", ("0", "1"))
+def test_second_staging_level_plays_the_same_batch(name, rows, keys_global, monkeypatch):
+    """An actor that leaves policy rows (rnad_mlp_forward_actor) is staged two levels deeper (rnad_bucket_stage_*): the upper rows, the roots
+    of the group subtrees the lanes enter, the subtrees below the states the lanes are drawn into next.  Same batch bit for bit as the fully
+    evaluated table gives, every visited row evaluated, and never more rows than the one-level staging (all rows of the non-empty groups)."""
+    import rnad_hip
+    from environment.episode import Episodes
+
+    tree = _native_tree(**TREES[name])
+    h = tree.handle()
+    A, S, B = tree.max_actions, h.S, 4096
+    monkeypatch.setenv("RNAD_KEYS_GLOBAL", keys_global)
+    if rows is not None:
+        monkeypatch.setenv("RNAD_BUCKET_ROWS", str(rows))
+        if rnad_hip.bucket_plan(h, B) is None:
+            pytest.skip(f"a table of {rows} rows does not fit this tree")
+    nets = _four_nets(A, 64, seed=12)
+    table = h.observations_table()
+    packed = nets[0].pack()
+    stride = int(rnad_hip.lib().rnad_bucket_policy_row_stride(A))
+
+    def tables(fill):
+        logit = torch.full((2 * S, A), fill, device=DEV)
+        logit._policy_rows = torch.full((2 * S, stride), fill, device=DEV)
+        return logit
+
+    full_logit = tables(0.0)
+    rnad_hip.mlp_forward_actor(h, packed, 64, table, full_logit, full_logit._policy_rows)
+    full = Episodes(tree, B, seed=23, lane_offset=5)
+    vis_full = torch.empty((2 * S,), dtype=torch.int32, device=DEV)
+    full.generate(nets[0], tabular=True, bucketed=True, trim=False, store_values=False, logits_table=full_logit, compact=True, visited=vis_full)
+
+    def play(levels):
+        monkeypatch.setenv("RNAD_STAGE_LEVELS", levels)
+        logit = tables(float("nan"))  # a row that was not evaluated would poison the rollout
+        calls = []
+
+        def actor(row_list):
+            calls.append(int(row_list.count.item()))
+            rnad_hip.mlp_forward_actor(h, packed, 64, table, logit, logit._policy_rows, rows=row_list)
+
+        ep = Episodes(tree, B, seed=23, lane_offset=5)
+        vis = torch.empty((2 * S,), dtype=torch.int32, device=DEV)
+        ep.generate(nets[0], tabular=True, bucketed=True, trim=False, store_values=False, logits_table=logit, compact=True, visited=vis,
+                    staged_actor=actor)
+        assert torch.equal(ep.lane_ids, full.lane_ids) and torch.equal(ep.indices, full.indices)
+        assert torch.equal(ep._compact[0].acts, full._compact[0].acts) and torch.equal(ep._compact[0].final_reward, full._compact[0].final_reward)
+        assert torch.equal(ep.alive, full.alive) and torch.equal(vis, vis_full)
+        seen = vis.bool()
+        assert torch.isfinite(logit._policy_rows[seen]).all(), "every visited row must have been evaluated"
+        assert torch.equal(logit._policy_rows[seen], full_logit._policy_rows[seen])
+        return calls
+
+    two = play("2")
+    one = play("1")
+    assert len(two) == 3 and len(one) == 2 and two[0] == one[0]
+    assert two[1] + two[2] <= one[1], (two, one)
+
+
 @pytest.mark.parametrize("name", ("pruned", "ternary4"))
 def test_deferred_alive_counts_are_completed_by_the_learner_or_on_first_read(name):
     """Episodes.generate(defer_alive=True) leaves the per-step alive counts and the loss normalisers un-summed (one launch less per

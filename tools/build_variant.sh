@@ -9,7 +9,7 @@ mkdir -p _variants/_obj_$name
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -fvisibility=hidden -I../../include -Wall -Wno-unused-function"
 EXTRA=""
 case $src in
-  mlp_fwd.hip|mlp_bwd_t.hip) EXTRA="-mllvm -amdgpu-mfma-vgpr-form -fno-honor-nans";;
+  mlp_fwd.hip|mlp_bwd_t.hip|mlp_rows.hip) EXTRA="-mllvm -amdgpu-mfma-vgpr-form -fno-honor-nans";;
   mlp_bwd.hip) EXTRA="-fno-honor-nans";;
 esac
 /opt/rocm/bin/hipcc $FLAGS $EXTRA "$@" -c $src -o _variants/_obj_$name/${src%.*}.o
