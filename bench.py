@@ -120,6 +120,9 @@ def main():
                     help="RNaD.tabular for the timed `value`: dense = False, forward = 'forward', tabular = True (RNaD's default); "
                          "the other modes are reported under other_modes either way")
     ap.add_argument("--no-graph", action="store_true", help="RNaD.use_graph = False: enqueue every step eagerly")
+    ap.add_argument("--shard-rows", action="store_true",
+                    help="N > 1: RNaD.shard_rows -- the table forwards / records / backward on a rank's 1/N of the 2S rows (all-gather of the "
+                         "record tables, all-reduce of the 64-bit per-row sums); default: every rank evaluates all rows")
     ap.add_argument("--obs-half", action="store_true", help="fp16 observations (BASELINE configs[4])")
     ap.add_argument("--other-steps", type=int, default=20, help="timed steps of each entry of other_modes and of the eager kernel-timing leg")
     ap.add_argument("--cpu-lanes-log2", type=int, default=18, help="episodes per step of the CPU-baseline sample (C port)")
@@ -184,6 +187,7 @@ def main():
         t.initialize()
         t.obs_half = args.obs_half
         t.use_graph = not args.no_graph
+        t.shard_rows = bool(args.shard_rows and data_parallel)
         if args.net_mode != "default":
             t.tabular = {"dense": False, "forward": "forward", "tabular": True}[args.net_mode]
         with torch.no_grad():
@@ -444,7 +448,16 @@ def main():
         if world > 1:
             out["legs_ms_per_step"] = {k: v / args.steps * 1e3 for k, v in legs.items()}
             out["collectives"] = {"backend": dist.get_backend(), "rccl_ranks": dist.get_world_size() if dist.get_backend() == "nccl" else None,
-                                  "ranks": dist.get_world_size(), "per_step": "all_reduce(2 x f64 normalisers) + all_reduce(43 KB fp32 gradient bucket)"}
+                                  "ranks": dist.get_world_size(), "per_step": "all_reduce(2 x f64 normalisers) + all_reduce(43 KB fp32 gradient bucket)",
+                                  "shard_rows": bool(args.shard_rows)}
+            if args.shard_rows:
+                A1, nu = A + 1, rn.last_episodes.buckets.plan.n_upper
+                per = (2 * handle.S + world - 1) // world
+                out["collectives"]["per_step"] += (" + all_gather(policy rows, fast records, records: %d B received per rank) + all_reduce(int64 per-row sums, %d B)"
+                                                   % (4 * per * (world - 1) * (int(rnad_hip.lib().rnad_bucket_policy_row_stride(A))
+                                                                               + int(rnad_hip.lib().rnad_bucket_fast_record_stride(A))
+                                                                               + int(rnad_hip.lib().rnad_bucket_record_stride(A))),
+                                                      8 * (2 * handle.S * A1 + rnad_hip.BUCKET_REPLICAS * 2 * max(nu, 1) * A1)))
             if base is not None:
                 out["strong_scaling"] = {"base": base}
                 if base.get("ms_per_step"):

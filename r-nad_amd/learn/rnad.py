@@ -153,6 +153,13 @@ class RNaD:
         self.lazy_rows = None
         self.last_rows = None  # rnad_hip.LiveRows of the last lazy step
         self.fused_optimizer = True  # clip + Adam + EMA target of the MLP in one launch (csrc/optim.hip) instead of ~8 torch launches
+        # Data parallel, per-row mode: what a rank does on the 2S rows of the tree (table forwards + records, backward) does not shrink
+        # with its share of the batch.  shard_rows = True also shards THAT: rank r evaluates rows [r * 2S / N, (r + 1) * 2S / N), the
+        # record tables are all-gathered, the learner's 64-bit per-row sums are all-reduced (exact: every rank then holds the sums of
+        # the GLOBAL batch, bit for bit those of a one-process step), and a rank finishes and back-propagates its own rows only; the
+        # 43 KB weight-gradient all-reduce closes the step as before.  Default off: three more collectives per step, to be set against the
+        # row work they remove on real xGMI (DESIGN.md section 7 has the byte counts and the prediction).
+        self.shard_rows = False
         # The legal fold (include/rnad_hip.h): on a tree whose observation rows all carry the same legal plane (all ones; e0 in the
         # absorbing state) the table evaluations of the per-row mode run the MLP with A^2 + 1 input features instead of 2 A^2 -- the
         # same function of the same weights in another summation order, ~45 % fewer matrix instructions in the first layer.
@@ -175,6 +182,34 @@ class RNaD:
     @property
     def _world(self):
         return dist.get_world_size() if self._dp() else 1
+
+    def _shard_now(self, handle, local_batch, log, lazy):
+        """Row sharding applies: asked for, more than one rank, the default per-row step with the fused table launch, not a logging step."""
+        A = self.tree.max_actions
+        return bool(getattr(self, "shard_rows", False) and self._dp() and self._world > 1 and log is None and not lazy
+                    and rnad_hip.mlp_rows_records_supported(A, self.net.width, self._fold())
+                    and rnad_hip.bucket_plan(handle, local_batch) is not None)
+
+    def _row_shard(self, handle):
+        """(RowList of this rank's rows, rows per rank): rank r owns rows [r * per, min((r + 1) * per, 2S)) of the (player, state) tables."""
+        world, rank = self._world, self._rank
+        key = (id(handle), world, rank)
+        cached = self.__dict__.get("_row_shard_cache")
+        if cached is None or cached[0] != key:
+            N = 2 * handle.S
+            per = (N + world - 1) // world
+            r0, r1 = min(N, rank * per), min(N, (rank + 1) * per)
+            cached = self._row_shard_cache = (key, rnad_hip.RowList(torch.arange(r0, r1, dtype=torch.int32), N, self.device), per)
+        return cached[1], cached[2]
+
+    def _gather_rows(self, t, per):
+        """t [world * per, k]: every rank wrote its own `per` rows; afterwards every rank holds them all."""
+        rank, world = self._rank, self._world
+        mine = t[rank * per: (rank + 1) * per]
+        if dist.get_backend() == "nccl":
+            dist.all_gather_into_tensor(t, mine)  # in place: the input is this rank's slice of the output
+        else:
+            dist.all_gather([t[i * per: (i + 1) * per] for i in range(world)], mine.clone())
 
     def _sync_from_rank0(self, module):
         if self._dp():
@@ -442,7 +477,7 @@ class RNaD:
         return entry["images"]
 
     def _table_outputs(self, alpha, obs_half=False, want_target_logits=False, policy_only=False, fold=False, records_hp=None,
-                       step_params=None):
+                       step_params=None, shard=False):
         """learner / target / regularisation nets on the 2S observations of the tree (rnad.py:373-380 on every distinct input):
         learner and target in ONE launch per step, the two regularisation nets from _reg_tables.  Both regularisation tables are
         always there: a term of log_policy_reg (:382) whose weight is exactly 0 adds exactly 0.
@@ -470,11 +505,25 @@ class RNaD:
             # records_hp: the caller wants the row records of this step too (rnad_hip.bucket_records(fast=True)) -- forwards and records
             # come out of ONE launch (csrc/mlp_rows.hip: a persistent workgroup per CU, a wave per hidden tile, weights in registers)
             logit_reg, logit_reg_ = self._reg_tables(table, fold)
+            rows, per = self._row_shard(self.tree.handle()) if shard else (None, 0)
             with torch.no_grad():
                 out = rnad_hip.mlp_rows_records(self.tree.handle(), packed, packed_target, self.net.width, table, logit_reg, logit_reg_,
-                                                records_hp, step_params=step_params, fold=self.tree.handle() if fold else False)
-            return dict(table=table, logit=out["logit"], v=out["v"], logit_target=None, v_target=out["v_target"], logit_reg=logit_reg,
-                        logit_reg_=logit_reg_, packed_net=packed, fold=fold, records=out["records"], fast_records=out["fast_records"])
+                                                records_hp, step_params=step_params, fold=self.tree.handle() if fold else False, rows=rows,
+                                                alloc_rows=per * self._world if shard else None)
+            tables = dict(table=table, logit=out["logit"], v=out["v"], logit_target=None, v_target=out["v_target"], logit_reg=logit_reg,
+                          logit_reg_=logit_reg_, packed_net=packed, fold=fold, records=out["records"], fast_records=out["fast_records"])
+            if shard:
+                # this rank evaluated its rows only: the actor's policy rows first (the rollout needs them), then the learner's operands
+                self._gather_rows(out["policy_rows"], per)
+                self._gather_rows(out["fast_records"], per)
+                self._gather_rows(out["records"], per)  # (only read by logging / Episodes' dense views: DESIGN.md section 7)
+                N = table.shape[0]  # (the shares are padded to equal size: the tables proper are the first 2S rows)
+                tables["records"], tables["fast_records"] = out["records"][:N], out["fast_records"][:N]
+                tables["records"]._policy_rows = out["policy_rows"][:N]
+                for name in ("logit", "v", "v_target"):
+                    tables[name] = tables[name][:N]
+                tables["shard_rows"] = rows
+            return tables
         with torch.no_grad():
             # (one launch entry per (net, head) -- three equal work units per 64-row span -- was measured: 45.5 instead of 43.4 us, every
             # workgroup loads its net's 43 KB weight image first)
@@ -649,9 +698,22 @@ class RNaD:
                 dlogit, dv, losses = rnad_hip.learn_bucketed(self.tree.handle(), episodes.buckets, episodes.indices[:T], episodes.action_idx[:T],
                                                              episodes.rewards[:T], episodes.policy[:T], records,
                                                              None if late_norm else norm, hp, want_losses=log is not None)
+            shard = tables.get("shard_rows") if late_norm else None
+            if shard is not None:
+                # row sharding: the 64-bit per-row sums of every rank's lanes -> the sums of the global batch on every rank (integer
+                # addition: exact, the same bits whatever the order); this rank finishes and back-propagates its own rows
+                plan, A1 = episodes.buckets.plan, A + 1
+                S_ = self.tree.handle().S
+                dist.all_reduce(plan.accumulators[: 2 * S_ * A1 + rnad_hip.BUCKET_REPLICAS * 2 * max(plan.n_upper, 1) * A1])
             if late_norm:
                 norm_work.wait()
-                rnad_hip.bucket_finish(self.tree.handle(), episodes.buckets, norm, hp, dlogit, dv, losses, rows=tables.get("rows"))
+                rnad_hip.bucket_finish(self.tree.handle(), episodes.buckets, norm, hp, dlogit, dv, losses,
+                                       rows=shard if shard is not None else tables.get("rows"))
+            if shard is not None:
+                plan.accumulators[: 2 * S_ * A1].zero_()  # (finish cleared the rows it read; the other ranks' rows still hold their sums)
+                live = shard
+            if getattr(self, "keep_last_tables", False):  # (tests: the per-row gradient tables of this step)
+                self.last_tables = (dlogit, dv, shard)
             pi = None
             backward_obs = table
         elif table is not None:
@@ -774,7 +836,8 @@ class RNaD:
             # the nets do not change between this step's rollout and its update: one evaluation of the 2S observations serves the
             # actor (= the learner net, rnad.py:503-505) and all four nets of __learn
             tables = self._table_outputs(alpha, getattr(self, "obs_half", False), want_target_logits=log is not None, fold=fold,
-                                         records_hp=self._learn_params(alpha), step_params=step_params)
+                                         records_hp=self._learn_params(alpha), step_params=step_params,
+                                         shard=self._shard_now(handle, local_batch, log, lazy))
         if self.total_steps % self.buffer_mod == 0:
             episodes = episode.Episodes(self.tree, local_batch, seed=self._new_seed(), lane_offset=rank * local_batch,
                                         obs_half=getattr(self, "obs_half", False))

@@ -782,6 +782,7 @@ def rollout_bucketed(tree, traj, table, value_table=None, seed=0, lane0=0, table
 
 
 COMPACT_MAX_STEPS = 21  # 3 bits of action per step in one 64-bit word (csrc/bucket.hip kCompactSteps)
+BUCKET_REPLICAS = 64  # copies of the upper rows' accumulators (csrc/bucket.hip kReplicas; rnad_bucket_plan out[6] counts them)
 BUCKET_MAX_LANES = 1 << 22  # lanes per call of the bucketed pipeline (csrc/bucket.hip kLaneBits: fixed-point headroom of the row sums)
 
 
@@ -1044,7 +1045,7 @@ def mlp_rows_records_supported(A, W, fold=False, from_table=False):
 
 
 def mlp_rows_records(tree, packed_net, packed_target, W, obs, logit_reg_tab, logit_reg_tab_, hp, step_params=None, fold=False, rows=None,
-                     logit_tab=None, want_records=True, want_policy_rows=True):
+                     logit_tab=None, want_records=True, want_policy_rows=True, alloc_rows=None):
     """rnad_mlp_rows_records: learner (both heads) and target (value head) on the tree's observation table `obs` AND the row records of
     bucket_records(fast=True), in one launch.  Returns dict(logit [2S, A], v [2S, 1], v_target [2S, 1], records, fast_records); the
     actor's policy rows travel as records._policy_rows, as with bucket_records.
@@ -1057,13 +1058,18 @@ def mlp_rows_records(tree, packed_net, packed_target, W, obs, logit_reg_tab, log
     dev = obs.device
     assert rows is None or rows.N == N
     from_table = logit_tab is not None
-    logit = logit_tab if from_table else torch.empty((N, A), dtype=F32, device=dev)
-    v = torch.empty((N, 1), dtype=F32, device=dev)
-    vt = torch.empty((N, 1), dtype=F32, device=dev)
-    rec = torch.empty((N, int(lib().rnad_bucket_record_stride(A))), dtype=F32, device=dev) if want_records else None
-    quick = torch.empty((N, int(lib().rnad_bucket_fast_record_stride(A))), dtype=F32, device=dev)
-    pol = (torch.empty((N, int(lib().rnad_bucket_policy_row_stride(A))), dtype=F32, device=dev)
-           if (want_policy_rows and rows is None and not from_table and os.environ.get("RNAD_POLICY_ROWS", "1") == "1") else None)
+    # alloc_rows (>= 2S): rows of the output tables -- a caller that all-gathers row shards of equal size pads them (rows beyond 2S are
+    # never written); with it the policy rows are produced for a row list too
+    M = N if alloc_rows is None else int(alloc_rows)
+    assert M >= N
+    logit = logit_tab if from_table else torch.empty((M, A), dtype=F32, device=dev)
+    v = torch.empty((M, 1), dtype=F32, device=dev)
+    vt = torch.empty((M, 1), dtype=F32, device=dev)
+    rec = torch.empty((M, int(lib().rnad_bucket_record_stride(A))), dtype=F32, device=dev) if want_records else None
+    quick = torch.empty((M, int(lib().rnad_bucket_fast_record_stride(A))), dtype=F32, device=dev)
+    pol = (torch.empty((M, int(lib().rnad_bucket_policy_row_stride(A))), dtype=F32, device=dev)
+           if (want_policy_rows and (rows is None or alloc_rows is not None) and not from_table and os.environ.get("RNAD_POLICY_ROWS", "1") == "1")
+           else None)
     _check(lib().rnad_mlp_rows_records(tree.ptr, W, int(fold), _dp(packed_net, F32, "packed_net"), _dp(packed_target, F32, "packed_target"),
                                        _dp(obs, F16 if half else F32, "obs"), int(half), *_row_list(rows), int(from_table),
                                        _dp(logit, F32, "logit_tab"), _dp(v, F32, "v_tab"), _dp(vt, F32, "v_target_tab"),

@@ -84,3 +84,21 @@ def test_eight_ranks_with_no_other_flags_run_configs_2():
     assert base["global_batch"] == 1 << 22 and base["net_mode_in_effect"] == "True" and base["step_replayed_from_hipGraph"] is True
     assert base["ms_per_step"] > 0 and j["value"] > 0
     assert abs(j["value"] - cfg["global_batch"] * cfg["T"] / (j["ms_per_step"] * 1e-3)) < 1e-6 * j["value"]
+
+
+@pytest.mark.timeout(1500)
+def test_eight_ranks_with_row_sharding():
+    """The same rehearsal with `--shard-rows`: every rank evaluates 1/8 of the 2S rows, all-gathers the record tables and all-reduces the
+    per-row sums (gloo here; the RCCL path differs only in the in-place all_gather_into_tensor)."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, RNAD_BENCH_REHEARSAL="1", HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="2")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "10", "--warmup", "2", "--other-steps", "2",
+           "--shard-rows", "--no-base-leg"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=1400, env=env)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    j = _json_line(r.stdout)
+    assert j["n_gpus"] == 8 and j["collectives"]["shard_rows"] is True and "all_gather" in j["collectives"]["per_step"]
+    assert j["net_evaluation"]["in_effect"] == "True" and j["value"] > 0

@@ -153,3 +153,68 @@ def test_graph_replay_with_rccl_collectives_inside(tmp_path):
     assert bool(got["captured"]), "the step with RCCL collectives inside must have been captured"
     for i in range(8):
         np.testing.assert_array_equal(got[f"e{i}"], got[f"g{i}"])
+
+
+def _sharded_step(tmp, tag, shard):
+    from environment.episode import Buffer
+    from environment.tree import Tree
+    from learn.rnad import RNaD
+
+    dev = torch.device("cuda:0")
+    os.environ["RNAD_SAVE_DIR"] = os.path.join(tmp, tag)
+    tree = Tree(device=dev, max_actions=3, max_transitions=1, depth_bound=4)
+    tree.generate_native(seed=0)
+    torch.manual_seed(SEED)
+    rn = RNaD(tree=tree, device=dev, directory_name="sh", batch_size=3 << 12,  # (lanes divisible by 2 and by 3 ranks)
+              eta=0.2, b1_adam=0.0, lr=1e-3,
+              net_params={"type": "MLP", "max_actions": 3, "width": 64})
+    rn.initialize()
+    rn.shard_rows = shard
+    rn.keep_last_tables = True
+    rn.use_graph = False
+    rn.train_step(Buffer(1), alpha=0.4)
+    torch.cuda.synchronize()
+    dlogit, dv, rows = rn.last_tables
+    out = {k: v.detach().cpu().numpy() for k, v in rn.net.state_dict().items()}
+    out["dlogit"], out["dv"] = dlogit.cpu().numpy(), dv.cpu().numpy()
+    out["rows"] = rows.rows.cpu().numpy() if rows is not None else np.zeros(0, np.int32)
+    return out
+
+
+def _shard_worker(rank, world, port, tmp):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        for shard in (True, False):
+            np.savez(os.path.join(tmp, f"sh_{int(shard)}_{rank}.npz"), **_sharded_step(tmp, f"rank{rank}_{int(shard)}", shard))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("world", (2, 3))
+def test_row_sharding_gives_the_one_process_row_sums(tmp_path, world):
+    """RNaD.shard_rows: rank r evaluates the nets on its share of the 2S rows (all-gather of the record tables), the learner's 64-bit
+    per-row sums are all-reduced, and the rank finishes and back-propagates its own rows.  The per-row gradient tables a rank ends up with
+    are those of the ONE-process step on the whole batch bit for bit (integer sums; same rows, same records), the ranks' shares cover all
+    rows (3 ranks: the shares are padded), and the update equals the replicated data-parallel one up to the order of the fp32 weight-gradient sums."""
+    single = _sharded_step(str(tmp_path), "single", False)
+    mp.spawn(_shard_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    seen = np.zeros(single["dlogit"].shape[0], bool)
+    for r in range(world):
+        got = np.load(tmp_path / f"sh_1_{r}.npz")
+        rows = got["rows"]
+        assert rows.size > 0 and not seen[rows].any()
+        seen[rows] = True
+        n = single["dlogit"].shape[0]
+        assert np.array_equal(got["dlogit"][:n][rows].view(np.uint32), single["dlogit"][rows].view(np.uint32)), f"dL/dlogit rows of rank {r}"
+        assert np.array_equal(got["dv"][:n][rows].view(np.uint32), single["dv"][rows].view(np.uint32)), f"dL/dv rows of rank {r}"
+        repl = np.load(tmp_path / f"sh_0_{r}.npz")
+        for k in single:
+            if k in ("dlogit", "dv", "rows"):
+                continue
+            np.testing.assert_array_equal(got[k], np.load(tmp_path / f"sh_1_0.npz")[k])  # the ranks stay in lock step
+            np.testing.assert_allclose(got[k], repl[k], rtol=2e-5, atol=2e-7, err_msg=k)
+            np.testing.assert_allclose(got[k], single[k], rtol=2e-5, atol=2e-7, err_msg=k)
+    assert seen.all()
