@@ -289,8 +289,11 @@ def main():
     for _ in range(EP):
         one_step()
     fence()
+    # (the default step's table launch also writes the row records: csrc/mlp_rows.hip; the lazy-rows step runs it for the value heads)
+    fused_rows = mode_now_is_true(rn, T, local_batch) and rnad_hip.mlp_rows_records_supported(A, args.width, rn._fold(), lazy_now)
+    fwd_name = "k_rows_forward_records (table forwards + row records)" + (" + k_mlp_forward (staged actor)" if lazy_now else "") if fused_rows else "k_mlp_forward"
     names = {rnad_hip.PROF_OBSERVE: "k_observe", rnad_hip.PROF_ACT: "rollout (all kernels of Episodes.generate)",
-             rnad_hip.PROF_LEARN: "learner (all kernels between the forwards and the backward)", rnad_hip.PROF_MLP: "k_mlp_forward",
+             rnad_hip.PROF_LEARN: "learner (all kernels between the forwards and the backward)", rnad_hip.PROF_MLP: fwd_name,
              rnad_hip.PROF_MLP_BWD: "k_mlp_backward", rnad_hip.PROF_BUCKET_KEYS: "k_bucket_keys (with the sort tile's histogram)",
              rnad_hip.PROF_BUCKET_SORT: "k_bucket_scan+scatter (+hist on the global-table fallback)", rnad_hip.PROF_BUCKET_ROLLOUT: "k_bucket_rollout",
              rnad_hip.PROF_BUCKET_LEARN: "k_bucket_learn", rnad_hip.PROF_BUCKET_FINISH: "k_bucket_finish"}
@@ -590,6 +593,26 @@ def kernel_report(prof, A, C, args, B, T, live_slots, tree, mode_now):
     uniform = tree.handle().uniform_length
     visited = args.visited_rows  # lazy rows: the value heads and the backward run on the rows the batch visited
     bwd_samples = (visited or S2) if mode_now is True else (live_slots if not uniform else slots)
+    def mlp_counters(entry, name):
+        """Counter evidence of an MLP kernel (profiles/r04_pmc.json): HBM traffic, the matrix pipe's busy share of the launch's SIMD cycles,
+        VALU wave-instructions, wait shares."""
+        c = pmc.get(name, {})
+        if not c:
+            return
+        entry["traffic"] = c.get("traffic_bytes_per_launch")
+        entry["counters_from_this_build"] = pmc_matches
+        dur = c.get("duration_us_mfma_pass")
+        if c.get("SQ_VALU_MFMA_BUSY_CYCLES_mfma_pass") and dur:
+            entry["matrix_pipe"] = {"busy_cycles_per_launch": c["SQ_VALU_MFMA_BUSY_CYCLES_mfma_pass"],
+                                    "busy_frac_of_simd_cycles": c["SQ_VALU_MFMA_BUSY_CYCLES_mfma_pass"] / (SIMDS * dur * 1e-6 * CLOCK_HZ),
+                                    "valu_wave_instructions_per_launch": c.get("SQ_INSTS_VALU"),
+                                    "what": "SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x launch duration x 2.4 GHz), its own rocprofv3 --pmc pass; fp32 "
+                                            "MFMA and VALU share the ALUs on gfx950, so the VALU instructions of the epilogues add to it"}
+        if c.get("SQ_WAVE_CYCLES"):
+            entry["wait"] = {"parked_on_waitcnt": c.get("SQ_WAIT_ANY", 0.0) / c["SQ_WAVE_CYCLES"],
+                             "issue_stalled": c.get("SQ_WAIT_INST_ANY", 0.0) / c["SQ_WAVE_CYCLES"],
+                             "what": "SQ_WAIT_ANY / SQ_WAVE_CYCLES and SQ_WAIT_INST_ANY / SQ_WAVE_CYCLES of the counter pass"}
+
     if rh.PROF_MLP_BWD in prof:
         p = prof[rh.PROF_MLP_BWD]
         flops = (2.0 * K * 2 * W + 2.0 * feat * 2 * W) * bwd_samples
@@ -597,6 +620,7 @@ def kernel_report(prof, A, C, args, B, T, live_slots, tree, mode_now):
         out[p["name"]].update(bound="mfma", achieved=tf, peak=FP32_PEAK_TFLOPS, unit="TFLOP/s", frac=tf / FP32_PEAK_TFLOPS,
                               samples_per_step=bwd_samples,
                               flops_model=f"per sample 2*K*2W (recompute) + 2*feat*2W (dW0 tiles), K = {K}" + (" (legal fold)" if getattr(args, "fold", False) else ""))
+        mlp_counters(out[p["name"]], "rnad_mlp::k_mlp_backward_t")
     if rh.PROF_MLP in prof and mode_now is True:
         p = prof[rh.PROF_MLP]
         # learner: both heads, target: value head, on the 2S rows (regularisation tables are cached); lazy rows: the two value heads
@@ -609,6 +633,7 @@ def kernel_report(prof, A, C, args, B, T, live_slots, tree, mode_now):
                                           + ": learner 2 heads + target value head"
                                           + (f"; lazy rows: policy head on {policy_rows} rows (upper states + the groups the batch descends into), "
                                              f"the two value heads on the {visited} visited rows" if visited else ""))
+        mlp_counters(out[p["name"]], "k_rows_forward_records" if "k_rows_forward_records" in pmc else "k_mlp_forward")
     return out
 
 

@@ -233,6 +233,31 @@ const BucketCut *get_cut(const rnad_tree_t *tree, int rows) {
             }
         }
     }
+    if (cut.upper_walk && cut.n_upper > 0) {
+        // hybrid keys walk: whole levels of upper states, top down, while their tables fit the LDS budget (next to the slot map)
+        const int AAC = tree->A * tree->A * tree->C;
+        const size_t per_state = (size_t)AAC * sizeof(UpperWalk) + 2 * (size_t)((tree->A + 3) & ~3) * sizeof(float);
+        size_t budget = kKeysLds;
+        if (const char *e = getenv("RNAD_KEYS_STAGE_BYTES")) budget = (size_t)std::max(0, atoi(e));  // (tests: partial staging on small trees)
+        const size_t fixed = (size_t)cut.n_upper * sizeof(int32_t) + 16;
+        std::vector<std::vector<int32_t>> by_level;
+        for (int i = 0; i < cut.n_upper; ++i) {
+            const int l = tree->level_of[(size_t)h.upper_list[(size_t)i]];
+            if (l < 0) continue;
+            if ((int)by_level.size() <= l) by_level.resize((size_t)l + 1);
+            by_level[(size_t)l].push_back(i);
+        }
+        std::vector<int32_t> hot_list, hot_of((size_t)cut.n_upper, -1);
+        for (const auto &lv : by_level) {
+            if (fixed + (hot_list.size() + lv.size()) * per_state > budget) break;
+            for (int32_t slot : lv) {
+                hot_of[(size_t)slot] = (int32_t)hot_list.size();
+                hot_list.push_back(slot);
+            }
+        }
+        cut.n_hot = (int)hot_list.size();
+        if (cut.n_hot > 0 && (!up(&cut.hot_list, hot_list) || !up(&cut.hot_of, hot_of))) cut.n_hot = 0;
+    }
     cut.host_bucket_of = std::move(h.bucket_of);
     return &tree->cuts.emplace(rows, std::move(cut)).first->second;
 }
@@ -637,6 +662,129 @@ __global__ __launch_bounds__(kSortThreads) void k_bucket_keys_lds(const UpperWal
     __syncthreads();
     int32_t *row = hist + (int64_t)blockIdx.x * n_buckets;
     for (int i = threadIdx.x; i < n_buckets; i += kSortThreads) row[i] = cnt[i];
+}
+
+// Hybrid walk for trees whose upper tables exceed the LDS (configs[3]: 2 616 upper states, 3.1 MB of walk table): the upper states of the
+// TOP levels that fit (BucketCut::hot_list: whole levels, root first; configs[3]: the root and its 100 children, 128 KB) are staged as in
+// k_bucket_keys_lds -- every lane passes through them, in lane order, i.e. with no locality a cache could use beyond one line per lane --
+// and a lane that walks on into an upper state below them continues on the global tables as k_bucket_keys does.  Same draws, same
+// arithmetic, same keys and decisions as both.  (The tile's histogram does not fit next to the tables: k_bucket_hist follows.)
+inline size_t keys_hybrid_lds_bytes(int n_hot, int n_upper, int A, int C) {
+    return (((size_t)n_hot * A * A * C * sizeof(UpperWalk) + 15) & ~(size_t)15) + (size_t)n_hot * 2 * ((A + 3) & ~3) * sizeof(float) +
+           (size_t)n_upper * sizeof(int32_t);
+}
+
+template <int A, int L>
+__global__ __launch_bounds__(kSortThreads) void k_bucket_keys_hybrid(const UpperWalk *__restrict__ walk, const int32_t *__restrict__ upper_list,
+                                                                     const int32_t *__restrict__ hot_list, const int32_t *__restrict__ hot_of_g,
+                                                                     int n_hot, int n_upper, const Trans *__restrict__ trans,
+                                                                     const int32_t *__restrict__ bucket_of, int C, int64_t S, int64_t B,
+                                                                     int n_steps, const float *__restrict__ policy_tab, int64_t tab_stride, int vec4,
+                                                                     int key_root, int n_groups, uint64_t seed,
+                                                                     const rnad_step_params_t *__restrict__ sp, int64_t lane0,
+                                                                     int32_t *__restrict__ keys, unsigned long long *__restrict__ decisions,
+                                                                     double *__restrict__ norm, StageOut stage) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char keys_smem[];
+    constexpr int PS = kPolStride<A>;
+    const int AAC = A * A * C;
+    UpperWalk *w = reinterpret_cast<UpperWalk *>(keys_smem);                                                           // [n_hot][A][A][C]
+    float *pol = reinterpret_cast<float *>(keys_smem + (((size_t)n_hot * AAC * sizeof(UpperWalk) + 15) & ~(size_t)15));  // [n_hot][2][PS]
+    int32_t *hot_of = reinterpret_cast<int32_t *>(pol + (size_t)n_hot * 2 * PS);                                         // [n_upper]
+    for (int i = threadIdx.x; i < n_hot * AAC; i += kSortThreads) w[i] = walk[(int64_t)hot_list[i / AAC] * AAC + i % AAC];
+    for (int i = threadIdx.x; i < n_hot * 2 * PS; i += kSortThreads) {
+        const int h = i / (2 * PS), player = (i / PS) & 1, a = i % PS;
+        pol[i] = a < A ? policy_tab[((int64_t)player * S + upper_list[hot_list[h]]) * tab_stride + a] : 0.0f;
+    }
+    for (int i = threadIdx.x; i < n_upper; i += kSortThreads) hot_of[i] = hot_of_g[i];
+    if (blockIdx.x == 0 && threadIdx.x == 0 && norm) norm[0] = norm[1] = 0.0;  // summed up by k_bucket_alive at the end of this rollout
+    if (blockIdx.x == 0 && threadIdx.x == 0 && stage.counts) stage.counts[0] = stage.counts[1] = 0ull;
+    if (sp) seed = sp->seed;
+    __syncthreads();
+    for (int pass = 0; pass < kSortLanes / (kSortThreads * L); ++pass) {
+        const int64_t b0 = (int64_t)blockIdx.x * kSortLanes + (int64_t)pass * (kSortThreads * L) + threadIdx.x;  // lanes b0 + l * kSortThreads
+        int state[L], hot[L], key[L], steps[L];  // hot: position of the lane's upper state in the staged tables, or -1
+        unsigned long long packed[L];
+        bool on[L];
+#pragma unroll
+        for (int l = 0; l < L; ++l) {
+            state[l] = 1;
+            key[l] = key_root;
+            steps[l] = 0;
+            packed[l] = 0ull;
+            on[l] = b0 + (int64_t)l * kSortThreads < B && key_root >= n_groups;
+            hot[l] = on[l] ? hot_of[key_root - n_groups] : 0;
+        }
+        for (int t = 0; t < n_steps; t += 2) {
+            bool any = false;
+#pragma unroll
+            for (int l = 0; l < L; ++l) any |= on[l];
+            if (!any) break;
+            const bool two = t + 1 < n_steps;
+            float u[L][3];
+            int a0[L];
+#pragma unroll
+            for (int l = 0; l < L; ++l) rnad_decision_uniforms(seed, (uint64_t)(lane0 + b0 + (int64_t)l * kSortThreads), (uint32_t)t, u[l]);
+#pragma unroll
+            for (int l = 0; l < L; ++l) {
+                float p0[A];
+                if (!on[l] || hot[l] >= 0) load_policy_row<A>(pol, (int64_t)(on[l] ? hot[l] : 0) * 2, PS, true, p0);
+                else load_policy_row<A>(policy_tab, state[l], tab_stride, vec4 != 0, p0);
+                a0[l] = pick<A>(p0, u[l][0]);
+                if (on[l]) {
+                    if (t < kPackedSteps) packed[l] |= (unsigned long long)a0[l] << (6 * t);
+                    steps[l] = t + 1;
+                }
+            }
+            if (!two) break;
+#pragma unroll
+            for (int l = 0; l < L; ++l) {
+                int next, key_next, chosen = 0, a1;
+                if (!on[l] || hot[l] >= 0) {
+                    const int sl = on[l] ? hot[l] : 0;
+                    float p1[A];
+                    load_policy_row<A>(pol, (int64_t)sl * 2 + 1, PS, true, p1);
+                    a1 = pick<A>(p1, u[l][1]);
+                    const UpperWalk *e = w + ((sl * A + a0[l]) * A + a1) * C;
+                    if (C > 1) {
+                        float ch[RNAD_MAX_TRANSITIONS];
+#pragma unroll
+                        for (int k = 0; k < RNAD_MAX_TRANSITIONS; ++k) ch[k] = k < C ? e[k].chance : 0.0f;
+                        chosen = pick_n<RNAD_MAX_TRANSITIONS>(C, ch, u[l][2]);
+                    }
+                    const UpperWalk hit = e[chosen];
+                    next = hit.next;
+                    key_next = hit.key;
+                } else {
+                    float p1[A], rew;
+                    load_policy_row<A>(policy_tab, S + state[l], tab_stride, vec4 != 0, p1);
+                    a1 = pick<A>(p1, u[l][1]);
+                    transition_lane<A>(trans, C, state[l], a0[l], a1, nullptr, u[l][2], next, rew, &chosen);
+                    key_next = bucket_of[next];
+                }
+                if (on[l]) {
+                    if (t + 1 < kPackedSteps) packed[l] |= (unsigned long long)(a1 | (chosen << 3)) << (6 * (t + 1));
+                    steps[l] = t + 2;
+                    state[l] = next;
+                    if (next != 0) key[l] = key_next;  // (a lane that leaves the tree from an upper state keeps that state's bucket)
+                    on[l] = next != 0 && key_next >= n_groups;
+                    hot[l] = on[l] ? hot_of[key_next - n_groups] : 0;
+                }
+            }
+        }
+#pragma unroll
+        for (int l = 0; l < L; ++l) {
+            const int64_t b = b0 + (int64_t)l * kSortThreads;
+            if (b < B) {
+                keys[b] = key[l];
+                decisions[b] = packed[l] | ((unsigned long long)min(steps[l], kPackedSteps) << 60);
+                if (stage.root) {
+                    const int root = key[l] < n_groups ? state[l] : 0;
+                    stage.root[b] = (uint32_t)root | ((uint32_t)steps[l] << kStageRootBits);
+                    if (root) stage.mark0[root] = stage_stamp(seed);
+                }
+            }
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------- 2. stable counting sort by key
@@ -1439,7 +1587,8 @@ __device__ __forceinline__ void learn_epilogue(unsigned long long *__restrict__ 
         for (int c = 0; c < kPathSlots; ++c) x += tab[(t * kPathSlots + c) * PS + a];
         if (x != 0ull) {
             const int64_t slot = bucket_of[path_state[t]] - n_groups;  // path states are upper states
-            atomicAdd(rep + (((int64_t)(blockIdx.x & (kReplicas - 1)) * 2 + (t & 1)) * up_stride + slot) * (A + 1) + a, x);
+            // (row-major: the kReplicas copies of a row are contiguous, which is how k_bucket_finish reads them -- a wave per row)
+            atomicAdd(rep + ((((int64_t)(t & 1) * up_stride + slot) * kReplicas) + (blockIdx.x & (kReplicas - 1))) * (A + 1) + a, x);
         }
     }
     // rows of the bucket's own subtree: this workgroup owns them unless the bucket was split over several items
@@ -1849,7 +1998,7 @@ __global__ __launch_bounds__(kThreads) void k_bucket_finish(int64_t S, int row_b
         const int u = ((int)blockIdx.x - row_blocks) * (kThreads / 64) + (threadIdx.x >> 6), c = threadIdx.x & 63;
         if (u < 2 * n_upper) {
             const int P = u / n_upper, pos = u % n_upper;
-            unsigned long long *src = rep + (((int64_t)c * 2 + P) * n_upper + pos) * (A + 1);
+            unsigned long long *src = rep + (((int64_t)P * n_upper + pos) * kReplicas + c) * (A + 1);
             const int64_t r = (int64_t)P * S + upper_list[pos];
             long long x[A + 1];
 #pragma unroll
@@ -2093,7 +2242,8 @@ int rollout_bucketed_impl(const rnad_tree_t *tree, const RolloutBuffers &tr, boo
         ProfScope one(PROF_BUCKET_KEYS, stream);
         const size_t keys_lds = keys_lds_bytes(p.cut->n_upper, nb, tree->A, tree->C);
         const bool walk_global = getenv("RNAD_KEYS_GLOBAL") && atoi(getenv("RNAD_KEYS_GLOBAL")) != 0;  // (tests: the fallback on any tree)
-        if (p.cut->upper_walk && keys_lds <= kKeysLds && !walk_global) {  // the upper states' tables fit the LDS: walk there, one sort tile per workgroup
+        const bool no_full_lds = getenv("RNAD_KEYS_LDS") && atoi(getenv("RNAD_KEYS_LDS")) == 0;  // (tests: the hybrid walk on small trees)
+        if (p.cut->upper_walk && keys_lds <= kKeysLds && !walk_global && !no_full_lds) {  // the upper states' tables fit the LDS: walk there, one sort tile per workgroup
             keys_with_hist = true;
             if (keys_lds > 48 * 1024)
                 RNAD_DISPATCH_A(tree->A, RNAD_HIP_OK(hipFuncSetAttribute((const void *)k_bucket_keys_lds<kA, kPlay>,
@@ -2102,6 +2252,19 @@ int rollout_bucketed_impl(const rnad_tree_t *tree, const RolloutBuffers &tr, boo
                                                         (const UpperWalk *)p.cut->upper_walk, (const int32_t *)p.cut->upper_list, p.cut->n_upper, nb,
                                                         tree->C, S, B, n_steps, policy_tab, policy_stride, (int)p.cut->host_bucket_of[1],
                                                         p.cut->n_groups, seed, device_params, lane0, s.keys, s.decisions, s.hist, norm, stage));
+        } else if (p.cut->upper_walk && p.cut->n_hot > 0 && p.cut->n_hot < p.cut->n_upper && !walk_global &&
+                   !(getenv("RNAD_KEYS_HYBRID") && atoi(getenv("RNAD_KEYS_HYBRID")) == 0)) {
+            // the top levels of the upper states in LDS, the rest from the global tables
+            const size_t hyb_lds = keys_hybrid_lds_bytes(p.cut->n_hot, p.cut->n_upper, tree->A, tree->C);
+            if (hyb_lds > 48 * 1024)
+                RNAD_DISPATCH_A(tree->A, RNAD_HIP_OK(hipFuncSetAttribute((const void *)k_bucket_keys_hybrid<kA, kPlay>,
+                                                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)hyb_lds)));
+            RNAD_DISPATCH_A(tree->A, hipLaunchKernelGGL((k_bucket_keys_hybrid<kA, kPlay>), dim3(p.sort_blocks), dim3(kSortThreads), hyb_lds, stream,
+                                                        (const UpperWalk *)p.cut->upper_walk, (const int32_t *)p.cut->upper_list,
+                                                        (const int32_t *)p.cut->hot_list, (const int32_t *)p.cut->hot_of, p.cut->n_hot, p.cut->n_upper,
+                                                        tree->trans, (const int32_t *)p.cut->bucket_of, tree->C, S, B, n_steps, policy_tab, policy_stride,
+                                                        vec4, (int)p.cut->host_bucket_of[1], p.cut->n_groups, seed, device_params, lane0, s.keys,
+                                                        s.decisions, norm, stage));
         } else {
             RNAD_DISPATCH_A(tree->A, hipLaunchKernelGGL((k_bucket_keys<kA, kPlay>), dim3(blocks_for(B, kThreads * kPlay)), dim3(kThreads), 0, stream, tree->trans, tree->C,
                                                         S, B, n_steps, policy_tab, policy_stride, vec4, (const int32_t *)p.cut->bucket_of,

@@ -95,6 +95,10 @@ struct BucketCut {
     int32_t *upper_list = nullptr;   // device [max(n_upper, 1)]: the upper states in slot order
     void *upper_walk = nullptr;      // device [n_upper][A][A][C] {next state, its bucket, chance}: the transition table of the upper states,
                                      // compact, for k_bucket_keys to stage in LDS
+    // hybrid keys walk (trees whose upper tables exceed the LDS, configs[3]): the upper states of the top levels that fit are staged
+    int n_hot = 0;                   // upper slots staged in LDS by k_bucket_keys_hybrid (the first n_hot entries of hot_list)
+    int32_t *hot_list = nullptr;     // device [max(n_hot, 1)]: upper slots (indices into upper_list), top levels first
+    int32_t *hot_of = nullptr;       // device [max(n_upper, 1)]: position in hot_list, or -1
     int32_t *anchor1 = nullptr;      // device [S]: for a state strictly below the root of a group subtree, its ancestor one level below that
                                      // root (itself for the root's children); 0 elsewhere.  A staged actor's second level (rnad_bucket_stage_*)
     std::vector<int32_t> host_bucket_of;  // the same map on the host (rnad_bucket_map: tests and tools)

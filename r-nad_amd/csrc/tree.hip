@@ -299,6 +299,8 @@ extern "C" void rnad_tree_destroy(rnad_tree_t *tree) {
         if (c.upper_list) (void)hipFree(c.upper_list);
         if (c.upper_walk) (void)hipFree(c.upper_walk);
         if (c.anchor1) (void)hipFree(c.anchor1);
+        if (c.hot_list) (void)hipFree(c.hot_list);
+        if (c.hot_of) (void)hipFree(c.hot_of);
     }
     delete tree;
 }

@@ -631,6 +631,41 @@ def test_staged_actor_plays_the_same_batch(name, rows, monkeypatch):
     assert torch.equal(dirty, expect)
 
 
+@pytest.mark.parametrize("stage_bytes", (700, 4000, 20000))
+@pytest.mark.parametrize("name,rows", (("pruned", 12), ("a5c4", 40), ("ternary4", 20), ("ternary4", None)))
+def test_hybrid_keys_walk_plays_the_same_batch(name, rows, stage_bytes, monkeypatch):
+    """k_bucket_keys_hybrid (the upper states of the top levels in LDS, the deeper ones from the global tables: what configs[3] takes)
+    against the global-table walk: same keys, same decisions -> the same bucket order and the same episodes, bit for bit.  The LDS budget
+    is forced small so that the small test trees are staged partially (root only / a level or two / everything that fits)."""
+    import rnad_hip
+    from environment.episode import Episodes
+
+    if rows is not None:
+        monkeypatch.setenv("RNAD_BUCKET_ROWS", str(rows))
+    B = 4096
+    nets = _four_nets(TREES[name]["A"], 64, seed=3)
+
+    def play(env):
+        for k in ("RNAD_KEYS_GLOBAL", "RNAD_KEYS_LDS", "RNAD_KEYS_STAGE_BYTES"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        tree = _native_tree(**TREES[name])  # (a fresh handle: the staged levels are chosen when the cut is built)
+        h = tree.handle()
+        if rnad_hip.bucket_plan(h, B) is None:
+            pytest.skip("this table size does not fit the tree")
+        logit = rnad_hip.mlp_forward(nets[0].pack(), 64, h.observations_table(), tree.max_actions, want_value=False)[0]
+        ep = Episodes(tree, B, seed=31, lane_offset=9)
+        ep.generate(nets[0], tabular=True, bucketed=True, trim=False, store_values=False, logits_table=logit, compact=True)
+        return ep
+
+    want = play({"RNAD_KEYS_GLOBAL": "1"})
+    got = play({"RNAD_KEYS_LDS": "0", "RNAD_KEYS_STAGE_BYTES": str(stage_bytes)})
+    assert torch.equal(got.lane_ids, want.lane_ids) and torch.equal(got.indices, want.indices)
+    assert torch.equal(got._compact[0].acts, want._compact[0].acts) and torch.equal(got._compact[0].final_reward, want._compact[0].final_reward)
+    assert torch.equal(got.alive, want.alive)
+
+
 @pytest.mark.parametrize("name,rows", (("pruned", None), ("pruned", 12), ("a5c4", None), ("a5c4", 40), ("ternary4", None), ("ternary4", 20), ("binary", None)))
 @pytest.mark.parametrize("keys_global", ("0", "1"))
 def test_second_staging_level_plays_the_same_batch(name, rows, keys_global, monkeypatch):
