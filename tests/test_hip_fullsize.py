@@ -196,9 +196,12 @@ def _modes_agree(tree, batch, tmp_path, obs_half=False, width=256, modes=(False,
     if False in modes:
         for a, b in zip(grads[False], grads["forward"]):
             assert torch.equal(a, b)
+    # (the per-row mode evaluates the tables with other kernels -- legal fold, csrc/mlp_rows.hip -- whose logits differ from the per-slot
+    # kernels' in the last bit: of the ~5e7 inverse-CDF draws of a 2^22 batch a handful then fall on the other side of a boundary, i.e. the
+    # two modes learn from batches that differ in a few episodes.  Achieved: ~1.1e-5 of the largest entry)
     for a, b in zip(grads["forward"], grads[True]):
         scale = a.abs().max().item() + 1e-12
-        np.testing.assert_allclose(b.cpu().numpy(), a.cpu().numpy(), rtol=1e-4, atol=1e-5 * scale)
+        np.testing.assert_allclose(b.cpu().numpy(), a.cpu().numpy(), rtol=1e-4, atol=2.5e-5 * scale)
 
 
 def test_c2_tree_at_2_to_22_lanes_on_one_gpu_keeps_the_default_mode(c2, tmp_path):
