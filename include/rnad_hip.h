@@ -473,6 +473,11 @@ int rnad_bucket_records(const rnad_tree_t *tree, const float *logit_tab, const f
  * with rows / n_rows (device memory, both NULL = all 2S rows) the lazy-rows step of learn/rnad.py.  Width: a multiple of 32 up to 256;
  * A <= 3 with the policy head, A <= 5 (fold) / 4 without (rnad_mlp_rows_records_supported: other shapes take the two launches). */
 int rnad_mlp_rows_records_supported(int A, int W, int fold, int policy_from_table);
+/* rnad_mlp_rows_actor: rnad_mlp_forward_actor with the mapping of csrc/mlp_rows.hip (weights in registers, a wave per hidden tile) -- the
+ * three staging launches of a large tree's actor, each on a short row list.  Same outputs up to the order of the second-layer sums. */
+int rnad_mlp_rows_actor_supported(int A, int W, int fold);
+int rnad_mlp_rows_actor(const rnad_tree_t *tree, const int32_t *rows, const int64_t *n_rows, int W, int fold, const float *packed, const void *obs,
+                        int obs_half, float *logits, float *policy_rows, void *stream);
 int rnad_mlp_rows_records(const rnad_tree_t *tree, int W, int fold, const float *packed_net, const float *packed_target, const void *obs,
                           int obs_half, const int32_t *rows, const int64_t *n_rows, int policy_from_table, float *logit_tab, float *v_tab,
                           float *v_target_tab, const float *logit_reg_tab, const float *logit_reg_tab_, const rnad_learn_params_t *hp,

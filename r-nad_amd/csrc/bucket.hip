@@ -58,6 +58,7 @@ constexpr int kPackedSteps = 10;      // env steps whose decisions k_bucket_keys
 constexpr int kCompactSteps = 21;     // env steps of a compact trajectory: 3 bits of action per step in one 64-bit word
 constexpr int kSharedRoot = 256;      // flag in bucket_path: the group is one subtree (its root row is shared by the bucket's lanes)
 constexpr int kFinishRows = 4;        // rows per thread of k_bucket_finish
+constexpr int kTicketGroups = 64;     // first-level tickets of k_bucket_finish's last-workgroup election
 constexpr int kTargetLanes = 1024;   // finest cut whose groups still hold this many lanes on average (configs[1]: full work items win)
 
 inline unsigned blocks_for(int64_t n, int per = kThreads) { return (unsigned)((n + per - 1) / per); }
@@ -2019,12 +2020,20 @@ __global__ __launch_bounds__(kThreads) void k_bucket_finish(int64_t S, int row_b
     if (threadIdx.x == 0) {
         // (no __threadfence: a device-scope release writes the XCD's L2 back -- 22 us here -- and nothing this workgroup wrote is read
         // by the clearing one)
-        int32_t *ticket = overflow + 1;
-        if (atomicAdd(ticket, 1) == (int)gridDim.x - 1) {
-            *ticket = 0;
-            *overflow = 0;
+        // the LAST workgroup clears the flag and the loss sums.  Tickets in two levels -- kTicketGroups counters, then one: atomics on ONE
+        // address retire at ~10 ns each on this part, i.e. 18 us for the 1 820 workgroups of a configs[3] launch (5 of the 8 us on
+        // configs[1]) when every workgroup took the same ticket
+        int32_t *ticket = overflow + 1, *sub = overflow + 2;
+        const int per = ((int)gridDim.x + kTicketGroups - 1) / kTicketGroups, g = (int)blockIdx.x / per;
+        const int members = min(per, (int)gridDim.x - g * per), groups = ((int)gridDim.x + per - 1) / per;
+        if (atomicAdd(sub + g, 1) == members - 1) {
+            sub[g] = 0;
+            if (atomicAdd(ticket, 1) == groups - 1) {
+                *ticket = 0;
+                *overflow = 0;
 #pragma unroll
-            for (int u = 0; u < 4; ++u) losses_raw[u] = 0.0;
+                for (int u = 0; u < 4; ++u) losses_raw[u] = 0.0;
+            }
         }
     }
 }
@@ -2071,7 +2080,7 @@ extern "C" int rnad_bucket_plan(const rnad_tree_t *tree, int64_t B, int64_t *out
                   2 * tree->S * ((tree->A + 3) & ~3)) + 256;
     // accumulators of the learner (bytes, must be zero before the first update): acc [2S][A+1] u64 | rep [64][2][n_upper][A+1] u64 |
     // losses_raw [4] f64 | overflow [1] i32
-    out[6] = 8 * (2 * tree->S * A1 + (int64_t)kReplicas * 2 * std::max(nu, 1) * A1 + 4) + 16;
+    out[6] = 8 * (2 * tree->S * A1 + (int64_t)kReplicas * 2 * std::max(nu, 1) * A1 + 4) + 16 + 4 * kTicketGroups;  // sums | loss sums | flag, ticket | group tickets
     out[7] = p.lds;
     out[8] = p.rel_bytes;
     return 0;

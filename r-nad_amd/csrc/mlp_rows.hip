@@ -15,11 +15,15 @@
 //     next chunk: the matrix pipe never waits for the latency-bound record arithmetic): the W / 32 partial sums added up in wave order
 //     (+ the output bias) complete logits / v / v_target; then the row's records with the very function k_row_records uses
 //     (row_records.hpp) -- same bits for the same logits.  One barrier per chunk, two buffers of partial sums.
-// POLICY = false is the lazy-rows variant (learn/rnad.py: _value_tables): the learner's logits already exist (the staged actor wrote
-// them), only the two value heads are evaluated, on a listed subset of the rows.
+// MODE 1 is the lazy-rows variant (learn/rnad.py: _value_tables): the learner's logits already exist (the staged actor wrote them), only
+// the two value heads are evaluated, on a listed subset of the rows.  MODE 2 is that staged ACTOR (rnad_mlp_rows_actor): the policy
+// head of one net on a row list, its logits and -- from phase 2 -- its policy rows (net.py:45-46 under the mover's legal bits), no
+// records: on configs[3] k_mlp_forward gives every workgroup a 112 KB weight image (one workgroup per CU) for each of the three
+// staging launches.
 // Summation order of the second layer (this kernel's own, as k_mlp_forward's is its own; nothing in the reference fixes it): per lane
 // and hidden tile as epilogue_value / epilogue_policy, the two half-waves, then the tiles in ascending order, then the bias.
 #include "mlp_common.hpp"
+#include "rollout_math.hpp"
 #include "row_records.hpp"
 
 using namespace rnad;
@@ -72,7 +76,9 @@ __device__ __forceinline__ float lane_sum(const f32x2 (&acc)[2]) { return (acc[0
 template <bool B>
 struct Flag { static constexpr bool value = B; };
 
-template <int A, typename ObsT, bool FOLD, bool POLICY>
+// MODE 0: learner (both heads) + target (value head) -> tables + records;  1: the two value heads (logits from the table) -> tables +
+// records;  2: the learner's policy head -> logits + policy rows
+template <int A, typename ObsT, bool FOLD, int MODE>
 __global__ __launch_bounds__(64 * (kRowsMaxWaves + kRecWaves)) void k_rows_forward_records(int64_t N, int W, RowsArgs g, const ObsT *__restrict__ obs,
                                                                                            rnad_learn_params_t hp) {
     if (g.n_rows) N = *g.n_rows;
@@ -81,8 +87,11 @@ __global__ __launch_bounds__(64 * (kRowsMaxWaves + kRecWaves)) void k_rows_forwa
         hp.one_minus_alpha = g.sp->one_minus_alpha;
     }
     constexpr int K = MlpShape<A, FOLD>::K, KS = K / 2, OBS = MlpShape<A, FOLD>::OBS;
-    constexpr int NOUT = POLICY ? 2 + A : 2;  // partial sums per row: learner value | target value | learner logits
-    constexpr int U = POLICY ? 3 : 2;         // hidden tiles per compute wave: learner value, target value, learner policy
+    constexpr bool POLICY = MODE != 1, VALUES = MODE != 2;
+    constexpr int NV = VALUES ? 2 : 0;                 // value heads: learner, target
+    constexpr int NOUT = NV + (POLICY ? A : 0);        // partial sums per row: learner value | target value | learner logits
+    constexpr int U = NV + (POLICY ? 1 : 0);           // hidden tiles per compute wave
+    constexpr int U0 = VALUES ? 0 : 2;                 // first of them in the order learner value (0), target value (1), learner policy (2)
     const int T = W / kTile;                  // hidden tiles per head = compute waves of this workgroup
     const int nthreads = 64 * (T + kRecWaves);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, col = lane & 31, half = lane >> 5;
@@ -96,15 +105,16 @@ __global__ __launch_bounds__(64 * (kRowsMaxWaves + kRecWaves)) void k_rows_forwa
     float a[U][KS];  // a compute wave's A operands: W0[hidden = 32 tile + col][k = 2 ks + half]
     if (computes) {
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
+        for (int v = 0; v < U; ++v) {
+            const int u = U0 + v;
             const float *img = u == 1 ? g.packed_target : g.packed_net;
             const int tile = u == 2 ? T + wave : wave;
             const float *wa = img + tile * (KS * 64) + half * 32 + col;
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks) a[u][ks] = wa[ks * 64];
+            for (int ks = 0; ks < KS; ++ks) a[v][ks] = wa[ks * 64];
         }
     }
-    for (int i = threadIdx.x; i < U * W; i += nthreads) {
+    for (int i = threadIdx.x + U0 * W; i < (U0 + U) * W; i += nthreads) {
         const int u = i / W, h = i % W;
         const float *img = u == 1 ? g.packed_target : g.packed_net;
         const int hs = u == 2 ? W + h : h;  // row of the stacked [2W] first layer
@@ -116,7 +126,7 @@ __global__ __launch_bounds__(64 * (kRowsMaxWaves + kRecWaves)) void k_rows_forwa
         b0f[i] = b;
         part[i] = wi;
     }
-    for (int i = threadIdx.x; i < (POLICY ? 2 + A : 2) * W; i += nthreads) {
+    for (int i = threadIdx.x + (VALUES ? 0 : 2 * W); i < (POLICY ? 2 + A : 2) * W; i += nthreads) {
         float x;
         if (i < W) x = g.packed_net[img_w1v(K, W) + i];
         else if (i < 2 * W) x = g.packed_target[img_w1v(K, W) + i - W];
@@ -128,7 +138,7 @@ __global__ __launch_bounds__(64 * (kRowsMaxWaves + kRecWaves)) void k_rows_forwa
         constexpr int kk = A * A;  // the indicator's input slot
         if (computes && half == (kk & 1)) {
 #pragma unroll
-            for (int u = 0; u < U; ++u) a[u][kk / 2] = part[u * W + wave * kTile + col];
+            for (int v = 0; v < U; ++v) a[v][kk / 2] = part[(U0 + v) * W + wave * kTile + col];
         }
     }
     __syncthreads();  // the scratch in `part` is free
@@ -168,7 +178,7 @@ __global__ __launch_bounds__(64 * (kRowsMaxWaves + kRecWaves)) void k_rows_forwa
         for (int o = 0; o < NOUT; ++o) out[o][0] = out[o][1] = x0[0] + x1[1];
 #else
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {  // learner value, target value
+        for (int u = 0; u < NV; ++u) {  // learner value, target value
             f32x16 c0_, c1_;
             f32x2 acc0[2] = {f32x2{0.f, 0.f}, f32x2{0.f, 0.f}}, acc1[2] = {f32x2{0.f, 0.f}, f32x2{0.f, 0.f}};
             chain_reg<KS, TWO>(a[u], bias_u + u * W, x0, x1, c0_, c1_);
@@ -187,8 +197,8 @@ __global__ __launch_bounds__(64 * (kRowsMaxWaves + kRecWaves)) void k_rows_forwa
             if constexpr (TWO) epilogue_policy<A>(c1_, w1_u + 2 * W, W, acc1);
 #pragma unroll
             for (int a_ = 0; a_ < A; ++a_) {
-                out[2 + a_][0] = lane_sum(acc0[a_]);
-                out[2 + a_][1] = lane_sum(acc1[a_]);
+                out[NV + a_][0] = lane_sum(acc0[a_]);
+                out[NV + a_][1] = lane_sum(acc1[a_]);
             }
         }
 #endif
@@ -200,18 +210,20 @@ __global__ __launch_bounds__(64 * (kRowsMaxWaves + kRecWaves)) void k_rows_forwa
             dst[o * 64] = keep + __shfl_xor(send, 32, 64);
         }
     };
-    // phase 2 of one step: complete the sums of its 64 rows, then their records
+    // phase 2 of one step: complete the sums of its 64 rows, then their records (MODE 2: their policy rows)
     auto p2_step = [&](int step, const float *src) {
         const int64_t sample = s_begin + (int64_t)step * (2 * kTile) + lane;
         if (sample >= s_end) return;
         const int64_t row = g.rows ? (int64_t)g.rows[sample] : sample;
         const uint32_t bits = g.mask_tab[row];
         float lr[A], lr2[A], lg[A];
+        if constexpr (VALUES) {
 #pragma unroll
-        for (int a_ = 0; a_ < A; ++a_) {
-            lr[a_] = g.logit_reg[row * A + a_];
-            lr2[a_] = g.logit_reg_[row * A + a_];
-            if (!POLICY) lg[a_] = g.logit[row * A + a_];
+            for (int a_ = 0; a_ < A; ++a_) {
+                lr[a_] = g.logit_reg[row * A + a_];
+                lr2[a_] = g.logit_reg_[row * A + a_];
+                if (!POLICY) lg[a_] = g.logit[row * A + a_];
+            }
         }
         float sum[NOUT];
 #pragma unroll
@@ -220,19 +232,31 @@ __global__ __launch_bounds__(64 * (kRowsMaxWaves + kRecWaves)) void k_rows_forwa
 #pragma unroll
             for (int o = 0; o < NOUT; ++o) sum[o] += src[(w * NOUT + o) * 64];
         }
-        const float *b1n = g.packed_net + img_b1(K, W, A), *b1t = g.packed_target + img_b1(K, W, A);  // [1 + A]: value bias, policy biases
-        const float vr = sum[0] + b1n[0], vtr = sum[1] + b1t[0];
+        const float *b1n = g.packed_net + img_b1(K, W, A);  // [1 + A]: value bias, policy biases
         if constexpr (POLICY) {
 #pragma unroll
-            for (int a_ = 0; a_ < A; ++a_) g.logit[row * A + a_] = lg[a_] = sum[2 + a_] + b1n[1 + a_];
+            for (int a_ = 0; a_ < A; ++a_) g.logit[row * A + a_] = lg[a_] = sum[NV + a_] + b1n[1 + a_];
         }
-        g.v[row] = vr;
-        g.v_target[row] = vtr;
+        if constexpr (VALUES) {
+            const float *b1t = g.packed_target + img_b1(K, W, A);
+            const float vr = sum[0] + b1n[0], vtr = sum[1] + b1t[0];
+            g.v[row] = vr;
+            g.v_target[row] = vtr;
 #if RNAD_ROWS_ABLATE & 1
-        if (bits == 0x12345u) g.fast[row] = lr[0] + lr2[0] + lg[0];
+            if (bits == 0x12345u) g.fast[row] = lr[0] + lr2[0] + lg[0];
 #else
-        write_row_records<A>(row, lg, vr, vtr, lr, lr2, bits, hp, g.rec, g.fast, g.pol_rows);
+            write_row_records<A>(row, lg, vr, vtr, lr, lr2, bits, hp, g.rec, g.fast, g.pol_rows);
 #endif
+        } else {  // the same function of the same logits as k_policy_rows / k_row_records
+            constexpr int PSTR = (A + 3) & ~3;
+            float pol[PSTR];
+            rnad::dev::policy_head_ptr<A>(lg, bits, pol, nullptr);
+#pragma unroll
+            for (int a_ = A; a_ < PSTR; ++a_) pol[a_] = 0.0f;
+            float4 *p4 = reinterpret_cast<float4 *>(g.pol_rows + row * PSTR);
+#pragma unroll
+            for (int u = 0; u < PSTR / 4; ++u) p4[u] = float4{pol[4 * u], pol[4 * u + 1], pol[4 * u + 2], pol[4 * u + 3]};
+        }
     };
 
     if (computes && n_steps > 0) fetch(0);
@@ -256,8 +280,8 @@ __global__ __launch_bounds__(64 * (kRowsMaxWaves + kRecWaves)) void k_rows_forwa
     }
 }
 
-size_t rows_lds_bytes(int A, int W, bool policy) {
-    const int T = W / kTile, nout = policy ? 2 + A : 2;
+size_t rows_lds_bytes(int A, int W, int mode) {
+    const int T = W / kTile, nout = (mode != 2 ? 2 : 0) + (mode != 1 ? A : 0);
     return ((size_t)3 * W + (size_t)(2 + A) * W + (size_t)2 * kChunkSteps * T * nout * 64) * sizeof(float);
 }
 
@@ -268,25 +292,20 @@ size_t rows_lds_bytes(int A, int W, bool policy) {
 extern "C" int rnad_mlp_rows_records_supported(int A, int W, int fold, int policy_from_table) {
     if (A < 1 || A > RNAD_MAX_ACTIONS || W < kTile || W % kTile != 0 || W / kTile > kRowsMaxWaves) return 0;
     if (fold && A < 2) return 0;
-    if (rows_lds_bytes(A, W, !policy_from_table) > 150 * 1024) return 0;
+    if (rows_lds_bytes(A, W, policy_from_table ? 1 : 0) > 150 * 1024) return 0;
     return policy_from_table ? A <= (fold ? 5 : 4) : A <= 3;
 }
 
-extern "C" int rnad_mlp_rows_records(const rnad_tree_t *tree, int W, int fold, const float *packed_net, const float *packed_target,
-                                     const void *obs, int obs_half, const int32_t *rows, const int64_t *n_rows, int policy_from_table,
-                                     float *logit_tab, float *v_tab, float *v_target_tab, const float *logit_reg_tab,
-                                     const float *logit_reg_tab_, const rnad_learn_params_t *hp, const rnad_step_params_t *device_params,
-                                     float *records, float *fast_records, float *policy_rows, void *stream_) {
-    RNAD_REQUIRE(tree && packed_net && packed_target && obs && logit_tab && v_tab && v_target_tab && logit_reg_tab && logit_reg_tab_ && hp && fast_records,
-                 "rnad_mlp_rows_records: null argument");
-    RNAD_REQUIRE(!rows == !n_rows, "rnad_mlp_rows_records: rows and n_rows go together");
+// the staged actor's launch (MODE 2): A <= 5 with the fold, A <= 3 without (registers, as above)
+extern "C" int rnad_mlp_rows_actor_supported(int A, int W, int fold) {
+    if (A < 1 || A > RNAD_MAX_ACTIONS || W < kTile || W % kTile != 0 || W / kTile > kRowsMaxWaves) return 0;
+    if (fold && A < 2) return 0;
+    return A <= (fold ? 5 : 3);
+}
+
+static int rows_launch(const rnad_tree_t *tree, int W, int fold, const void *obs, int obs_half, int mode, const RowsArgs &g,
+                       const rnad_learn_params_t &hp, hipStream_t stream) {
     const int A = tree->A;
-    RNAD_REQUIRE(rnad_mlp_rows_records_supported(A, W, fold, policy_from_table),
-                 "rnad_mlp_rows_records: shape not supported (A=%d, width=%d, fold=%d, policy_from_table=%d): see rnad_mlp_rows_records_supported", A, W,
-                 fold, policy_from_table);
-    RNAD_REQUIRE((((uintptr_t)records | (uintptr_t)fast_records | (uintptr_t)policy_rows) & 15) == 0, "rnad_mlp_rows_records: record tables must be 16-byte aligned");
-    hipStream_t stream = (hipStream_t)stream_;
-    const bool policy = !policy_from_table;
     const int64_t N = 2 * tree->S;
     int dev = 0, cus = 256;
     RNAD_HIP_OK(hipGetDevice(&dev));
@@ -294,26 +313,20 @@ extern "C" int rnad_mlp_rows_records(const rnad_tree_t *tree, int W, int fold, c
     const int T = W / kTile;
     const int64_t n_tiles = (N + kTile - 1) / kTile;
     const int64_t grid = std::max<int64_t>(1, std::min<int64_t>((n_tiles + 1) / 2, cus));  // one persistent workgroup per CU
-    const size_t lds_bytes = rows_lds_bytes(A, W, policy);
-    RowsArgs g{};
-    g.packed_net = packed_net; g.packed_target = packed_target;
-    g.logit = logit_tab; g.v = v_tab; g.v_target = v_target_tab;
-    g.logit_reg = logit_reg_tab; g.logit_reg_ = logit_reg_tab_;
-    g.mask_tab = tree->mask_tab;
-    g.rec = records; g.fast = fast_records; g.pol_rows = policy_rows;
-    g.sp = device_params; g.rows = rows; g.n_rows = n_rows;
+    const size_t lds_bytes = rows_lds_bytes(A, W, mode);
     ProfScope prof(PROF_MLP, stream);
-#define RNAD_ROWS_LAUNCH3(T_, F_, P_)                                                                                                  \
+#define RNAD_ROWS_LAUNCH3(T_, F_, M_)                                                                                                  \
     do {                                                                                                                               \
-        auto kern = k_rows_forward_records<kA, T_, F_, P_>;                                                                            \
+        auto kern = k_rows_forward_records<kA, T_, F_, M_>;                                                                            \
         if (lds_bytes > 64 * 1024)                                                                                                     \
             RNAD_HIP_OK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));          \
-        hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64 * (T + kRecWaves)), lds_bytes, stream, N, W, g, (const T_ *)obs, *hp);          \
+        hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64 * (T + kRecWaves)), lds_bytes, stream, N, W, g, (const T_ *)obs, hp);   \
     } while (0)
-#define RNAD_ROWS_LAUNCH2(T_, F_)                      \
-    do {                                               \
-        if (policy) RNAD_ROWS_LAUNCH3(T_, F_, true);   \
-        else RNAD_ROWS_LAUNCH3(T_, F_, false);         \
+#define RNAD_ROWS_LAUNCH2(T_, F_)                           \
+    do {                                                    \
+        if (mode == 0) RNAD_ROWS_LAUNCH3(T_, F_, 0);        \
+        else if (mode == 1) RNAD_ROWS_LAUNCH3(T_, F_, 1);   \
+        else RNAD_ROWS_LAUNCH3(T_, F_, 2);                  \
     } while (0)
 #define RNAD_ROWS_LAUNCH(T_)                           \
     do {                                               \
@@ -331,4 +344,44 @@ extern "C" int rnad_mlp_rows_records(const rnad_tree_t *tree, int W, int fold, c
 #undef RNAD_ROWS_LAUNCH
     RNAD_HIP_OK(hipGetLastError());
     return 0;
+}
+
+extern "C" int rnad_mlp_rows_records(const rnad_tree_t *tree, int W, int fold, const float *packed_net, const float *packed_target,
+                                     const void *obs, int obs_half, const int32_t *rows, const int64_t *n_rows, int policy_from_table,
+                                     float *logit_tab, float *v_tab, float *v_target_tab, const float *logit_reg_tab,
+                                     const float *logit_reg_tab_, const rnad_learn_params_t *hp, const rnad_step_params_t *device_params,
+                                     float *records, float *fast_records, float *policy_rows, void *stream_) {
+    RNAD_REQUIRE(tree && packed_net && packed_target && obs && logit_tab && v_tab && v_target_tab && logit_reg_tab && logit_reg_tab_ && hp && fast_records,
+                 "rnad_mlp_rows_records: null argument");
+    RNAD_REQUIRE(!rows == !n_rows, "rnad_mlp_rows_records: rows and n_rows go together");
+    RNAD_REQUIRE(rnad_mlp_rows_records_supported(tree->A, W, fold, policy_from_table),
+                 "rnad_mlp_rows_records: shape not supported (A=%d, width=%d, fold=%d, policy_from_table=%d): see rnad_mlp_rows_records_supported",
+                 tree->A, W, fold, policy_from_table);
+    RNAD_REQUIRE((((uintptr_t)records | (uintptr_t)fast_records | (uintptr_t)policy_rows) & 15) == 0, "rnad_mlp_rows_records: record tables must be 16-byte aligned");
+    RowsArgs g{};
+    g.packed_net = packed_net; g.packed_target = packed_target;
+    g.logit = logit_tab; g.v = v_tab; g.v_target = v_target_tab;
+    g.logit_reg = logit_reg_tab; g.logit_reg_ = logit_reg_tab_;
+    g.mask_tab = tree->mask_tab;
+    g.rec = records; g.fast = fast_records; g.pol_rows = policy_rows;
+    g.sp = device_params; g.rows = rows; g.n_rows = n_rows;
+    return rows_launch(tree, W, fold, obs, obs_half, policy_from_table ? 1 : 0, g, *hp, (hipStream_t)stream_);
+}
+
+// The staged actor of a tree that is large next to the batch (rnad_mlp_forward_actor's job with this file's mapping): the policy head of one
+// net on the listed rows of the tree's observation table -> logits [2S, A] and policy rows [2S, rnad_bucket_policy_row_stride(A)].
+extern "C" int rnad_mlp_rows_actor(const rnad_tree_t *tree, const int32_t *rows, const int64_t *n_rows, int W, int fold, const float *packed,
+                                   const void *obs, int obs_half, float *logits, float *policy_rows, void *stream_) {
+    RNAD_REQUIRE(tree && packed && obs && logits && policy_rows, "rnad_mlp_rows_actor: null argument");
+    RNAD_REQUIRE(!rows == !n_rows, "rnad_mlp_rows_actor: rows and n_rows go together");
+    RNAD_REQUIRE(rnad_mlp_rows_actor_supported(tree->A, W, fold), "rnad_mlp_rows_actor: shape not supported (A=%d, width=%d, fold=%d)", tree->A, W, fold);
+    RNAD_REQUIRE(((uintptr_t)policy_rows & 15) == 0, "rnad_mlp_rows_actor: policy_rows must be 16-byte aligned");
+    RowsArgs g{};
+    g.packed_net = packed; g.packed_target = packed;
+    g.logit = logits;
+    g.mask_tab = tree->mask_tab;
+    g.pol_rows = policy_rows;
+    g.rows = rows; g.n_rows = n_rows;
+    rnad_learn_params_t hp{};
+    return rows_launch(tree, W, fold, obs, obs_half, 2, g, hp, (hipStream_t)stream_);
 }

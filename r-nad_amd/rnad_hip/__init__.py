@@ -366,6 +366,12 @@ def mlp_forward_actor(tree, packed, W, obs, logits, policy_rows, rows=None, fold
     half = obs.dtype == F16
     assert logits.shape == (2 * tree.S, tree.A) and policy_rows.shape[0] == 2 * tree.S
     assert rows is None or rows.N == 2 * tree.S
+    if os.environ.get("RNAD_ROWS_ACTOR", "0") == "1" and lib().rnad_mlp_rows_actor_supported(tree.A, W, int(fold)):
+        # (csrc/mlp_rows.hip's mapping for the staged actor: no 112 KB weight image per workgroup at A = 5.  Measured on configs[3]: 3
+        # launches 86.9 us against 80.5 for k_mlp_forward -- both spend the same fp32 ALU time -- so it is opt-in)
+        _check(lib().rnad_mlp_rows_actor(tree.ptr, *_row_list(rows), W, int(fold), _dp(packed, F32, "packed"), _dp(obs, F16 if half else F32, "obs"),
+                                         int(half), _dp(logits, F32, "logits"), _dp(policy_rows, F32, "policy_rows"), _stream()))
+        return
     _check(lib().rnad_mlp_forward_actor(tree.ptr, *_row_list(rows), W, int(fold), _dp(packed, F32, "packed"), _dp(obs, F16 if half else F32, "obs"),
                                         int(half), _dp(logits, F32, "logits"), _dp(policy_rows, F32, "policy_rows"), _stream()))
 
@@ -806,6 +812,7 @@ def rollout_bucketed_compact(tree, traj, table, seed=0, lane0=0, step_params=Non
     assert table.shape[0] == 2 * tree.S and table.shape[1] >= column + tree.A
     assert visited is None or visited.numel() == 2 * tree.S
     buckets = Buckets(plan, traj.device)
+    _complete_pending(tree, plan)
     base = _dp(table, F32, "table")
     _check(lib().rnad_rollout_bucketed_compact(tree.ptr, traj.T_cap, traj.B, C.c_void_p(base.value + 4 * column), table.shape[1],
                                                int(table_is_policy), seed, lane0, _dp(step_params, torch.int64, "step_params", True),
@@ -816,9 +823,20 @@ def rollout_bucketed_compact(tree, traj, table, seed=0, lane0=0, step_params=Non
                                                _dp(traj.acts, torch.int64, "acts"), _dp(traj.final_reward, F32, "final_reward"),
                                                _dp(visited, I32, "visited", True), _stream()))
     buckets.alive_pending = traj if defer_alive else None
+    plan._pending = buckets if defer_alive else None
     traj._owner = (tree, buckets)
     traj.invalidate()
     return buckets
+
+
+def _complete_pending(tree, plan, buckets=None):
+    """The un-summed alive partials of a rollout with defer_alive=True live in plan.scratch, which every Buckets of the plan shares: before
+    another rollout of the same (tree, B) overwrites them, the counts of the batch that still waits for them are added up (a launch; RNaD's
+    own flow never gets here -- its learner completes the batch within the step)."""
+    prev = getattr(plan, "_pending", None)
+    if prev is not None and prev is not buckets and prev.alive_pending is not None:
+        bucket_alive(tree, prev)
+    plan._pending = None
 
 
 def bucket_upper_rows(tree, B):
@@ -914,6 +932,7 @@ def bucket_play(tree, traj, buckets, table, rows=None, seed=0, lane0=0, step_par
     rows: the LiveRows the actor was evaluated on since the sort (a logits table: their policy head is taken here).
     visited_is_clear: bucket_sort(visited=...) cleared the flags already (no launch for it here)."""
     assert table.shape[0] == 2 * tree.S and table.shape[1] >= column + tree.A
+    _complete_pending(tree, buckets.plan, buckets)
     base = _dp(table, F32, "table")
     _check(lib().rnad_bucket_play(tree.ptr, traj.T_cap, traj.B, C.c_void_p(base.value + 4 * column), table.shape[1], int(table_is_policy),
                                   *_row_list(rows), seed, lane0, _dp(step_params, torch.int64, "step_params", True),
@@ -924,6 +943,7 @@ def bucket_play(tree, traj, buckets, table, rows=None, seed=0, lane0=0, step_par
                                   _dp(traj.final_reward, F32, "final_reward"), _dp(visited, I32, "visited", True), int(bool(visited_is_clear)),
                                   _stream()))
     buckets.alive_pending = traj if defer_alive else None
+    buckets.plan._pending = buckets if defer_alive else None
     traj._owner = (tree, buckets)
     traj.invalidate()
 

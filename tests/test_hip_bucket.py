@@ -765,3 +765,14 @@ def test_deferred_alive_counts_are_completed_by_the_learner_or_on_first_read(nam
     trimmed = Episodes(tree, B, seed=4)
     trimmed.generate(nets[0], defer_alive=True, **dict(kw, trim=True))
     assert trimmed.buckets.alive_pending is None and torch.equal(trimmed.alive, want_alive[: trimmed.t_eff + 2])
+    # (d) two deferred rollouts of the same (tree, B) back to back: the partial counts live in the plan's scratch, which both share --
+    # the second rollout first completes the batch that still waits for them
+    first = Episodes(tree, B, seed=4)
+    first.generate(nets[0], defer_alive=True, **kw)
+    second = Episodes(tree, B, seed=5)
+    second.generate(nets[0], defer_alive=True, **kw)
+    assert first.buckets.alive_pending is None and second.buckets.alive_pending is second._compact[0]
+    assert torch.equal(first.alive, want_alive) and torch.equal(first.valid_counts, want_norm)
+    other = Episodes(tree, B, seed=5)
+    other.generate(nets[0], **kw)
+    assert torch.equal(second.alive, other.alive) and torch.equal(second.valid_counts, other.valid_counts)

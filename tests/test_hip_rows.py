@@ -169,3 +169,46 @@ def test_default_step_uses_the_fused_launch_and_trains_like_the_two_launches(mon
     for a, b in zip(grads["1"], grads["0"]):
         scale = b.abs().max().item() + 1e-12
         np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=0, atol=2e-2 * scale)
+
+
+@pytest.mark.parametrize("fold", (True, False))
+@pytest.mark.parametrize("width", (64, 256))
+@pytest.mark.parametrize("name", ("ternary4", "a5c4", "binary", "pruned"))
+def test_rows_actor_is_the_forward_actor(name, width, fold, monkeypatch):
+    """rnad_mlp_rows_actor (the staged actor's launch with the mapping of csrc/mlp_rows.hip) against rnad_mlp_forward_actor: logits to
+    rounding, the policy rows the policy head of its OWN logits bit for bit (rnad_policy_head: the same function), with a row list (only
+    the listed rows are written) and on all rows."""
+    import rnad_hip as hip
+    from test_hip_bucket import TREES, _native_tree
+
+    tree = _native_tree(**TREES[name])
+    h = tree.handle()
+    A, S = h.A, h.S
+    if fold and not h.legal_foldable:
+        pytest.skip("not foldable")
+    if not hip.lib().rnad_mlp_rows_actor_supported(A, width, int(fold)):
+        pytest.skip("shape takes rnad_mlp_forward_actor")
+    net = _nets(A, width, 21)[0]
+    table = h.observations_table()
+    packed = hip.mlp_pack_many([net._weights()], A, fold=fold)[0]
+    stride = int(hip.lib().rnad_bucket_policy_row_stride(A))
+    flags = torch.zeros((2 * S,), dtype=torch.int32, device=DEV)
+    flags[::5] = 1
+    flags[3] = 1
+    for rows in (None, hip.compact_valid(flags)):
+        out = {}
+        for fused in ("1", "0"):
+            monkeypatch.setenv("RNAD_ROWS_ACTOR", fused)
+            logit = torch.full((2 * S, A), 7.0, device=DEV)
+            pol = torch.full((2 * S, stride), 7.0, device=DEV)
+            hip.mlp_forward_actor(h, packed, width, table, logit, pol, rows=rows, fold=h if fold else False)
+            out[fused] = (logit, pol)
+        sel = flags.bool() if rows is not None else torch.ones((2 * S,), dtype=torch.bool, device=DEV)
+        np.testing.assert_allclose(out["1"][0][sel].cpu().numpy(), out["0"][0][sel].cpu().numpy(), rtol=1e-5, atol=3e-6)
+        np.testing.assert_allclose(out["1"][1][sel].cpu().numpy(), out["0"][1][sel].cpu().numpy(), rtol=1e-5, atol=3e-6)
+        assert (out["1"][0][~sel] == 7.0).all() and (out["1"][1][~sel] == 7.0).all(), "rows that are not listed must not be written"
+        mask = table[:, 1, :, 0].float().contiguous()  # the mover's legal actions: legal[a][0] of its view of the state
+        want = hip.policy_head(out["1"][0].contiguous(), mask=mask)
+        got = out["1"][1][:, :A]
+        assert torch.equal(got[sel], want[sel]), "policy rows must be the policy head of the kernel's own logits"
+        assert (out["1"][1][sel][:, A:] == 0).all()
