@@ -973,6 +973,10 @@ class RNaD:
             graph = torch.cuda.CUDAGraph()
             self._seed_override = seed  # the captured body (and an eager retry) must use THIS step's seed, not draw another
             ok = False
+            import gc
+
+            gc_was_on = gc.isenabled()
+            gc.disable()  # (a collection in the middle of the capture may run finalisers that free device memory: hipFree invalidates it)
             try:
                 with torch.cuda.graph(graph):
                     self._step_body(buffer, alpha, None, step_params=g["dev"])
@@ -981,6 +985,9 @@ class RNaD:
                 why = "the rollout of this step is not the native bucketed one"
             except Exception as err:  # capture is an optimisation: fall back to eager steps, loudly
                 why = str(err)
+            finally:
+                if gc_was_on:
+                    gc.enable()
             if self._dp():  # every rank replays, or none does (a rank replaying collectives the others enqueue eagerly would hang)
                 flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=self.device)
                 dist.all_reduce(flag, op=dist.ReduceOp.MIN)

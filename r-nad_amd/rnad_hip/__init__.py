@@ -146,6 +146,7 @@ class TreeHandle:
         self.S, self.C, self.A = S, Cc, A
         self.device = dev
         self._h = C.c_void_p()
+        _destroy_deferred()
         idx = dev.index if dev.index is not None else torch.cuda.current_device()
         _check(lib().rnad_tree_create(C.byref(self._h), C.c_int64(S), Cc, A, C.c_void_p(index.data_ptr()),
                                       C.c_void_p(value.data_ptr()), C.c_void_p(chance.data_ptr()),
@@ -189,12 +190,30 @@ class TreeHandle:
         return self._legal_foldable
 
     def __del__(self):
+        # rnad_tree_destroy is a series of hipFree calls, and a hipFree while ANY stream of the process is capturing (torch.cuda.graph
+        # captures in the global mode) invalidates that capture -- which is what happens when the garbage collector gets to the tree of an
+        # earlier trainer in the middle of RNaD's capture of a step.  Handles that die during a capture are parked and destroyed at the
+        # next safe point (the next handle's construction or destruction outside a capture).
         try:
             if self._h:
-                lib().rnad_tree_destroy(self._h)
-                self._h = C.c_void_p()
+                h, self._h = self._h, C.c_void_p()
+                _deferred_destroy.append(h)
+                _destroy_deferred()
         except Exception:
             pass
+
+
+_deferred_destroy = []
+
+
+def _destroy_deferred():
+    try:
+        if torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
+            return
+    except Exception:
+        return
+    while _deferred_destroy:
+        lib().rnad_tree_destroy(_deferred_destroy.pop())
 
 
 def observe(tree, idx, player, obs=None, half=False, mask_bits=None, mask=None):
