@@ -84,21 +84,9 @@ __global__ __launch_bounds__(kOptThreads) void k_optimizer_step(OptTensors ts, c
             bc2s_s[k] = (float)sqrt(1.0 - pow((double)hp.beta2, (double)step));
         }
     }
-    __syncthreads();  // (the pointer table)
-    // this thread's own element -- gradient, moments, weight, target weight --: requested before the norm so that their latency hides
-    // behind it (after it they were a second round trip: 9.8 -> see DESIGN.md section 6)
+    // this thread's own element: requested before the norm so that its latency hides behind it
     const int64_t i = (int64_t)blockIdx.x * kOptThreads + threadIdx.x;
     const float g_own = i < n ? grads[i] : 0.0f;
-    int k = 0;
-#pragma unroll
-    for (int q = 1; q < kMaxTensors; ++q) k += i >= off_s[q] ? 1 : 0;
-    const int32_t e = (int32_t)(i - off_s[k]);
-    float *pp = nullptr, *pm = nullptr, *pv = nullptr, *pt = nullptr;
-    float m = 0.0f, v = 0.0f, p = 0.0f, tg = 0.0f;
-    if (i < n) {
-        pp = ptr_s[0][k] + e; pm = ptr_s[1][k] + e; pv = ptr_s[2][k] + e; pt = ptr_s[3][k] ? ptr_s[3][k] + e : nullptr;
-        m = *pm; v = *pv; p = *pp; tg = pt ? *pt : 0.0f;
-    }
     double s = 0.0;
     for (int64_t base = threadIdx.x; base < n; base += (int64_t)kOptThreads * kNormBatch) {
         float g[kNormBatch];
@@ -131,6 +119,12 @@ __global__ __launch_bounds__(kOptThreads) void k_optimizer_step(OptTensors ts, c
         }
     }
     if (i >= n) return;
+    int k = 0;
+#pragma unroll
+    for (int q = 1; q < kMaxTensors; ++q) k += i >= off_s[q] ? 1 : 0;
+    const int32_t e = (int32_t)(i - off_s[k]);
+    float *pp = ptr_s[0][k] + e, *pm = ptr_s[1][k] + e, *pv = ptr_s[2][k] + e, *pt = ptr_s[3][k] ? ptr_s[3][k] + e : nullptr;
+    const float m = *pm, v = *pv, p = *pp, tg = pt ? *pt : 0.0f;
     const float grad = g_own * coef_s, w = 1.0f - hp.beta1;
     const float m_new = w < 0.5f ? m + w * (grad - m) : grad - (grad - m) * (1.0f - w);  // at::lerp
     const float v_new = hp.beta2 * v + (1.0f - hp.beta2) * grad * grad;
