@@ -978,7 +978,10 @@ class RNaD:
             gc_was_on = gc.isenabled()
             gc.disable()  # (a collection in the middle of the capture may run finalisers that free device memory: hipFree invalidates it)
             try:
-                with torch.cuda.graph(graph):
+                # (data parallel: torch's NCCL watchdog thread polls the events of the eager steps' collectives; under the default GLOBAL
+                # capture mode such a query from another thread while this one captures is an error -- seen once in a full test run as a
+                # crash of the watchdog.  thread_local: only this thread's calls are checked)
+                with torch.cuda.graph(graph, capture_error_mode="thread_local" if self._dp() else "global"):
                     self._step_body(buffer, alpha, None, step_params=g["dev"])
                 # only the native bucketed rollout takes its seed from device memory: anything else would replay stale noise
                 ok = getattr(self.last_episodes, "buckets", None) is not None
