@@ -43,7 +43,10 @@ namespace {
 
 constexpr int kThreads = 256;
 constexpr int kMaxPath = 32;         // env steps above a group (path rows of the LDS table)
-constexpr int kPathSlots = 16;       // copies of a path row in LDS: lane l adds into copy l & 15 (4-way instead of 64-way same-address adds)
+#ifndef RNAD_PATH_SLOTS
+#define RNAD_PATH_SLOTS 16
+#endif
+constexpr int kPathSlots = RNAD_PATH_SLOTS;  // copies of a path row in LDS: lane l adds into copy l & 15 (4-way instead of 64-way same-address adds)
 constexpr int kMaxBuckets = 12288;   // LDS histogram of the sort passes: 48 KiB of int32
 constexpr int kMaxUpper = 8192;      // upper states (64 replicas of their rows are kept)
 constexpr int kSortThreads = 1024;   // threads per block of the sort passes
