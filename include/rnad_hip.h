@@ -506,11 +506,12 @@ int rnad_bucket_alive(const rnad_tree_t *tree, int T_cap, int64_t B, const void 
 int rnad_bucket_sort(const rnad_tree_t *tree, int T_cap, int64_t B, const float *table, int64_t table_stride, int table_is_policy,
                      uint64_t seed, int64_t lane0, const rnad_step_params_t *device_params, void *scratch, int32_t *lane_ids,
                      int32_t *items, int32_t *n_items, double *norm, int32_t *group_flags, int32_t *staged_rows, int64_t *n_staged,
-                     int32_t *visited, void *stage, void *stream);
+                     int32_t *visited, void *stage, int32_t *stage_rows0, void *stream);
 /* Second staging level of a tabular actor on a tree that is large next to the batch (configs[3]: the non-empty groups hold 807 k rows, the
  * batch visits 103 k).  rnad_bucket_sort with `stage` (rnad_bucket_stage_bytes(tree, B) bytes, zeroed once; its first two int64 are the
  * lengths of the two row lists below) also records, per lane, the root of the group subtree it enters.  Then, on the same stream:
- *   rnad_bucket_stage_rows(level 0) -> rows = both players' rows of those roots;  evaluate the actor on them;
+ *   rnad_bucket_stage_rows(level 0) -> rows = both players' rows of those roots (or hand rnad_bucket_sort `stage_rows0`: its last kernel
+ *                                      then writes this list itself, one launch less);  evaluate the actor on them;
  *   rnad_bucket_stage_walk          -> draws every lane's transition at its root exactly as the rollout will (environment/episode.py:96-125
  *                                      with the seeded draws of rnad_rng.h: same counters, same rows, same outcome);
  *   rnad_bucket_stage_rows(level 1) -> rows = the rows of every subtree hanging below a state some lane was just drawn into;  evaluate the

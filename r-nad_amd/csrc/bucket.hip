@@ -813,18 +813,16 @@ __global__ __launch_bounds__(kSortThreads) void k_bucket_hist(int64_t B, int n_b
 // in mark1) is this step's.  One launch: a workgroup counts its states, reserves a range of the list with ONE atomic on the list's
 // length and writes its rows there -- the list is unordered across workgroups, which no consumer minds (an actor's forward writes
 // logits[row]; the same rows get the same values in any order).  *count was cleared by the keys pass.
-constexpr int kStagePer = 4;  // states per thread of k_stage_rows: 4096 per workgroup, i.e. a few hundred reservations per list
+constexpr int kStagePer = 4;  // states per thread of a chunk: 4096 per workgroup pass, i.e. a few hundred reservations per list
+// one chunk (kSortThreads * kStagePer consecutive states) of the list of level LEVEL, by one workgroup of kSortThreads threads
 template <int LEVEL>
-__global__ __launch_bounds__(kSortThreads) void k_stage_rows(int64_t S, const uint32_t *__restrict__ mark, const int32_t *__restrict__ anchor1,
-                                                             uint64_t seed, const rnad_step_params_t *__restrict__ sp,
-                                                             int32_t *__restrict__ rows, unsigned long long *__restrict__ count) {
+__device__ __forceinline__ void stage_rows_chunk(int64_t chunk, int64_t S, const uint32_t *__restrict__ mark, const int32_t *__restrict__ anchor1,
+                                                 uint32_t stamp, int32_t *__restrict__ rows, unsigned long long *__restrict__ count) {
     __shared__ int32_t wave_n[kSortThreads / 64];
     __shared__ unsigned long long base_s;
-    if (sp) seed = sp->seed;
-    const uint32_t stamp = stage_stamp(seed);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     // a wave takes kStagePer * 64 consecutive states, 64 at a time (coalesced loads of the stamps)
-    const int64_t s0 = ((int64_t)blockIdx.x * (kSortThreads / 64) + wave) * (kStagePer * 64) + lane;
+    const int64_t s0 = (chunk * (kSortThreads / 64) + wave) * (kStagePer * 64) + lane;
     uint64_t votes[kStagePer];
     int32_t mine = 0;
 #pragma unroll
@@ -862,6 +860,15 @@ __global__ __launch_bounds__(kSortThreads) void k_stage_rows(int64_t S, const ui
         }
         at += 2ull * (unsigned long long)__popcll(votes[r]);
     }
+    __syncthreads();  // (wave_n / base_s are reused by the caller's next chunk)
+}
+
+template <int LEVEL>
+__global__ __launch_bounds__(kSortThreads) void k_stage_rows(int64_t S, const uint32_t *__restrict__ mark, const int32_t *__restrict__ anchor1,
+                                                             uint64_t seed, const rnad_step_params_t *__restrict__ sp,
+                                                             int32_t *__restrict__ rows, unsigned long long *__restrict__ count) {
+    if (sp) seed = sp->seed;
+    stage_rows_chunk<LEVEL>(blockIdx.x, S, mark, anchor1, stage_stamp(seed), rows, count);
 }
 
 // The transition every lane draws at the root of the group subtree it enters (env steps t, t + 1 with t = the steps it spent above the
@@ -1062,7 +1069,10 @@ __global__ __launch_bounds__(kSortThreads) void k_bucket_scatter(int64_t B, int 
                                                                  const int32_t *__restrict__ bucket_lo, const int32_t *__restrict__ bucket_span,
                                                                  const int32_t *__restrict__ group_by_lo, int32_t *__restrict__ staged_rows,
                                                                  int64_t *__restrict__ n_staged, int32_t *__restrict__ visited,
-                                                                 const uint32_t *__restrict__ stage_root, uint32_t *__restrict__ stage_sorted) {
+                                                                 const uint32_t *__restrict__ stage_root, uint32_t *__restrict__ stage_sorted,
+                                                                 const uint32_t *__restrict__ stage_mark0, int32_t *__restrict__ stage_rows0,
+                                                                 unsigned long long *__restrict__ stage_count0, uint64_t seed,
+                                                                 const rnad_step_params_t *__restrict__ sp) {
     extern __shared__ int32_t cnt[];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int64_t base = (int64_t)blockIdx.x * kSortLanes + (int64_t)wave * (kSortLanes / 16);
@@ -1077,6 +1087,12 @@ __global__ __launch_bounds__(kSortThreads) void k_bucket_scatter(int64_t B, int 
     if (visited) {
         for (int64_t r = (int64_t)blockIdx.x * kSortThreads + threadIdx.x; r < 2 * S; r += (int64_t)gridDim.x * kSortThreads)
             visited[r] = (r == 0 || r == S) ? 1 : 0;
+    }
+    if (stage_rows0) {  // second staging level: the row list of the roots the keys pass stamped (k_stage_rows<0>'s work without its launch)
+        if (sp) seed = sp->seed;
+        const int64_t n_chunks = (S + kSortThreads * kStagePer - 1) / (kSortThreads * kStagePer);
+        for (int64_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x)
+            stage_rows_chunk<0>(chunk, S, stage_mark0, nullptr, stage_stamp(seed), stage_rows0, stage_count0);
     }
     if (staged_rows) {
         // exclusive prefix over the groups of (non-empty ? span : 0), in the LDS words the sort uses afterwards
@@ -2242,7 +2258,7 @@ int rollout_bucketed_impl(const rnad_tree_t *tree, const RolloutBuffers &tr, boo
                           const rnad_step_params_t *device_params, void *scratch, int32_t *lane_ids, int32_t *items, int32_t *n_items,
                           double *norm, hipStream_t stream, int phases = 3, int32_t *group_flags = nullptr,
                           const int32_t *play_rows = nullptr, const int64_t *n_play_rows = nullptr, int32_t *staged_rows = nullptr,
-                          int64_t *n_staged = nullptr, bool visited_is_clear = false, void *stage_buf = nullptr) {
+                          int64_t *n_staged = nullptr, bool visited_is_clear = false, void *stage_buf = nullptr, int32_t *stage_rows0 = nullptr) {
     Plan p;
     RNAD_REQUIRE(make_plan(tree, tr.B, p), "rnad_rollout_bucketed: this tree / batch cannot be bucketed (see rnad_bucket_plan)");
     const int64_t B = tr.B, S = tree->S;
@@ -2326,7 +2342,8 @@ int rollout_bucketed_impl(const rnad_tree_t *tree, const RolloutBuffers &tr, boo
         hipLaunchKernelGGL(k_bucket_scatter, dim3(p.sort_blocks), dim3(kSortThreads), scatter_lds, stream, B, nb, (const int32_t *)s.keys,
                            (const int32_t *)s.hist, (const int32_t *)s.totals, p.chunk, (Item *)items, n_items, lane_ids, wave_rows, S,
                            p.cut->n_groups, (const int32_t *)p.cut->bucket_lo, (const int32_t *)p.cut->bucket_span,
-                           (const int32_t *)p.cut->group_by_lo, staged_rows, n_staged, tr.visited, (const uint32_t *)stage.root, stage.sorted);
+                           (const int32_t *)p.cut->group_by_lo, staged_rows, n_staged, tr.visited, (const uint32_t *)stage.root, stage.sorted,
+                           (const uint32_t *)stage.mark0, stage.root ? stage_rows0 : nullptr, stage.counts, seed, device_params);
         if (group_flags)
             hipLaunchKernelGGL(k_group_flags, dim3(blocks_for(S)), dim3(kThreads), 0, stream, S, (const int32_t *)p.cut->bucket_of,
                                p.cut->n_groups, (const int32_t *)s.totals, group_flags);
@@ -2368,15 +2385,16 @@ int rollout_bucketed_impl(const rnad_tree_t *tree, const RolloutBuffers &tr, boo
 extern "C" int rnad_bucket_sort(const rnad_tree_t *tree, int T_cap, int64_t B, const float *table, int64_t table_stride, int table_is_policy,
                                 uint64_t seed, int64_t lane0, const rnad_step_params_t *device_params, void *scratch, int32_t *lane_ids,
                                 int32_t *items, int32_t *n_items, double *norm, int32_t *group_flags, int32_t *staged_rows, int64_t *n_staged,
-                                int32_t *visited, void *stage, void *stream) {
+                                int32_t *visited, void *stage, int32_t *stage_rows0, void *stream) {
     RNAD_REQUIRE(tree && table && scratch && lane_ids && items && n_items, "rnad_bucket_sort: null argument");
+    RNAD_REQUIRE(!stage_rows0 || stage, "rnad_bucket_sort: stage_rows0 goes with stage");
     RNAD_REQUIRE(!staged_rows == !n_staged, "rnad_bucket_sort: staged_rows and n_staged go together");
     RNAD_REQUIRE(T_cap >= 1 && T_cap <= kCompactSteps && B >= 1, "rnad_bucket_sort: 1 <= T_cap <= %d, got %d", kCompactSteps, T_cap);
     RNAD_REQUIRE(table_stride >= tree->A, "rnad_bucket_sort: bad table stride");
     const RolloutBuffers out{T_cap, B, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, visited};
     return rollout_bucketed_impl(tree, out, true, table, table_stride, table_is_policy, nullptr, 1, seed, lane0, device_params, scratch,
                                  lane_ids, items, n_items, norm, (hipStream_t)stream, 1, group_flags, nullptr, nullptr, staged_rows, n_staged,
-                                 false, stage);
+                                 false, stage, stage_rows0);
 }
 
 extern "C" int64_t rnad_bucket_stage_bytes(const rnad_tree_t *tree, int64_t B) {

@@ -900,6 +900,8 @@ def bucket_stage_rows(tree, B, stage, level, seed=0, step_params=None):
     """rnad_bucket_stage_rows: the row list of staging level 0 (the group subtree roots the lanes enter; after bucket_sort(stage=...)) or 1
     (the subtrees below the states the lanes were drawn into; after bucket_stage_walk).  Same seed / step_params as the sort."""
     rows = stage.lists[level]
+    if level == 0:
+        return rows  # (bucket_sort(stage=...) had its last kernel write this list: no launch here)
     _check(lib().rnad_bucket_stage_rows(tree.ptr, B, level, seed, _dp(step_params, torch.int64, "step_params", True),
                                         _dp(stage.buf, torch.int64, "stage"), _dp(rows.rows, I32, "rows"), _stream()))
     return rows
@@ -941,7 +943,8 @@ def bucket_sort(tree, traj, table, seed=0, lane0=0, step_params=None, table_is_p
                                   _dp(buckets.norm, F64, "norm"), _dp(flags, I32, "group_flags", True),
                                   _dp(rows.rows, I32, "staged_rows") if rows is not None else None,
                                   C.c_void_p(rows.count.data_ptr()) if rows is not None else None, _dp(visited, I32, "visited", True),
-                                  _dp(stage.buf, torch.int64, "stage") if stage is not None else None, _stream()))
+                                  _dp(stage.buf, torch.int64, "stage") if stage is not None else None,
+                                  _dp(stage.lists[0].rows, I32, "stage_rows0") if stage is not None else None, _stream()))
     return buckets, rows, flags
 
 
