@@ -318,7 +318,7 @@ bool make_plan(const rnad_tree_t *tree, int64_t B, Plan &p) {
     p.rel_bytes = chosen->rows <= 255 ? 1 : 2;
     p.sort_blocks = (int)((B + kSortLanes - 1) / kSortLanes);
     if (const char *c = getenv("RNAD_BUCKET_CHUNK")) p.chunk = std::max(64, atoi(c));  // tuning knob
-    p.max_items = (int64_t)chosen->n_buckets + B / p.chunk + 1;
+    p.max_items = (int64_t)chosen->n_buckets + B / p.chunk + 1 + 7;  // (+ 7: the XCD-aware item mapping needs 8 * ceil(n / 8) workgroups)
     return true;
 }
 
@@ -809,6 +809,25 @@ __global__ __launch_bounds__(kSortThreads) void k_bucket_hist(int64_t B, int n_b
     for (int i = threadIdx.x; i < n_buckets; i += kSortThreads) row[i] = cnt[i];
 }
 
+// Workgroup -> work item, XCD-aware.  The dispatcher places workgroup b on XCD b % 8 (observed, not contractual: a wrong guess is
+// slower, not wrong), each XCD has its own 4 MB L2, and the work items are in bucket order, i.e. in the order of the tree's state ids:
+// with item = workgroup, every XCD pulls ALL of the tables the lanes gather from (policy rows, transition records, fast records: 8 x 9 MB
+// of fabric traffic per rollout launch on configs[1], 8 x 8.5 MB per learner launch).  Here XCD x takes the x-th CONTIGUOUS eighth of the
+// items, so its L2 only sees its eighth of the tree.  Bijective for any item count n (the grid holds n + 7 workgroups at least).
+// Returns -1 for a workgroup without an item.
+#ifndef RNAD_XCD_ITEMS
+#define RNAD_XCD_ITEMS 1
+#endif
+__device__ __forceinline__ int xcd_item(int n) {
+#if RNAD_XCD_ITEMS
+    const int q = n >> 3, r = n & 7, xcd = (int)blockIdx.x & 7, k = (int)blockIdx.x >> 3;
+    const int cnt = q + (xcd < r ? 1 : 0), start = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return k < cnt ? start + k : -1;
+#else
+    return (int)blockIdx.x < n ? (int)blockIdx.x : -1;
+#endif
+}
+
 // The row list of staging level LEVEL: both players' rows of every state whose stamp (LEVEL 0: its own in mark0; LEVEL 1: its anchor's
 // in mark1) is this step's.  One launch: a workgroup counts its states, reserves a range of the list with ONE atomic on the list's
 // length and writes its rows there -- the list is unordered across workgroups, which no consumer minds (an actor's forward writes
@@ -880,7 +899,11 @@ __global__ __launch_bounds__(kThreads) void k_stage_walk(const Trans *__restrict
                                                          const uint32_t *__restrict__ sorted, const int32_t *__restrict__ lane_ids,
                                                          uint64_t seed, const rnad_step_params_t *__restrict__ sp, int64_t lane0,
                                                          uint32_t *__restrict__ mark1) {
-    const int64_t j = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    // (XCD-aware as xcd_item: XCD x walks the x-th contiguous eighth of the bucket-ordered lanes)
+    const int nb = (int)gridDim.x, xq = nb >> 3, xr = nb & 7, xcd = (int)blockIdx.x & 7, xk = (int)blockIdx.x >> 3;
+    const int64_t blk = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + xk;
+    if (xk >= xq + (xcd < xr ? 1 : 0)) return;  // (cannot happen: the map is a bijection of [0, nb))
+    const int64_t j = blk * kThreads + threadIdx.x;
     if (j >= B) return;
     // in BUCKET order (thread j takes lane lane_ids[j], its root word travelled with it through the sort): the lanes of a wave sit in a few
     // roots of one group, and the rows, the transition records and the stamps they touch share cache lines (in lane order every gather of
@@ -1293,12 +1316,13 @@ __global__ __launch_bounds__(kThreads) void k_bucket_rollout_items(const Trans *
                                                                    unsigned long long *__restrict__ acts_out,
                                                                    float *__restrict__ reward_out, int32_t *__restrict__ visited) {
     __shared__ int32_t cnt[kThreads / 64][kMaxSteps + 1];
-    int32_t *my_alive = alive_part + (int64_t)blockIdx.x * (T_cap + 1);
-    if ((int)blockIdx.x >= *n_items) {
+    int32_t *my_alive = alive_part + (int64_t)blockIdx.x * (T_cap + 1);  // (a row per WORKGROUP: the sum over the rows does not care which item it held)
+    const int my_item = xcd_item(*n_items);
+    if (my_item < 0) {
         if ((int)threadIdx.x <= T_cap) my_alive[threadIdx.x] = 0;
         return;
     }
-    const Item item = items[blockIdx.x];
+    const Item item = items[my_item];
     if (sp) seed = sp->seed;
     const int wave = threadIdx.x >> 6;
     const int path_word = bucket_path[item.bucket];
@@ -1838,8 +1862,9 @@ __global__ __launch_bounds__(kThreads) RNAD_LEARN_ATTR void k_bucket_learn_c(int
     // The rollout left its per-workgroup alive counts un-summed (rnad_rollout_bucketed_compact with alive == NULL): workgroup t < T1
     // adds up column t first -- k_bucket_alive's work without its launch; the normalisers are read by k_bucket_finish, after this kernel.
     if (alive_part && (int)blockIdx.x < T1) alive_column(alive_blocks, T1, blockIdx.x, alive_part, alive, norm_out);
-    if ((int)blockIdx.x >= *n_items) return;
-    const Item item = items[blockIdx.x];
+    const int my_item = xcd_item(*n_items);
+    if (my_item < 0) return;
+    const Item item = items[my_item];
     const int s_b = bucket_lo[item.bucket];
     const int path_word = bucket_path[item.bucket];
     const int n_path = path_word & (kSharedRoot - 1);
