@@ -1303,8 +1303,17 @@ __device__ __forceinline__ REL rel_of(int state, int lo) {
     return (REL)(state == 0 ? 0 : state - lo + 1);
 }
 
-template <int A, typename REL>
-__global__ __launch_bounds__(kThreads) void k_bucket_rollout_items(const Trans *__restrict__ trans, int C, int64_t S, int64_t B, int T_cap,
+// L lanes per thread (workgroups of kThreads / L threads, lanes l * NT + thread of the item's pass; build switch).  The kernel spends 59 %
+// of a resident wave's time on s_waitcnt with the SIMDs' wave slots full (41 VGPRs), so more independent chains per thread looked like
+// the lever -- measured on configs[1] / configs[3]: L = 1 27.0 / 61.8 us, L = 2 28.2 / 62.4, L = 4 36.8 / 80.3.  It is not the number of
+// lanes in flight that bounds it.
+#ifndef RNAD_ROLLOUT_LANES
+#define RNAD_ROLLOUT_LANES 1
+#endif
+constexpr int kRolloutLanes = RNAD_ROLLOUT_LANES;
+
+template <int A, typename REL, int L>
+__global__ __launch_bounds__(kThreads / L) void k_bucket_rollout_items(const Trans *__restrict__ trans, int C, int64_t S, int64_t B, int T_cap,
                                                                    const float *__restrict__ policy_tab, int64_t tab_stride, int vec4,
                                                                    uint64_t seed, const rnad_step_params_t *__restrict__ sp, int64_t lane0,
                                                                    const int32_t *__restrict__ lane_ids,
@@ -1315,7 +1324,9 @@ __global__ __launch_bounds__(kThreads) void k_bucket_rollout_items(const Trans *
                                                                    REL *__restrict__ states, int32_t *__restrict__ alive_part,
                                                                    unsigned long long *__restrict__ acts_out,
                                                                    float *__restrict__ reward_out, int32_t *__restrict__ visited) {
-    __shared__ int32_t cnt[kThreads / 64][kMaxSteps + 1];
+    constexpr int NT = kThreads / L, NW = NT / 64;
+    static_assert(NT >= 64 && NT > kCompactSteps, "a wave at least, and a thread per alive counter");
+    __shared__ int32_t cnt[NW][kMaxSteps + 1];
     int32_t *my_alive = alive_part + (int64_t)blockIdx.x * (T_cap + 1);  // (a row per WORKGROUP: the sum over the rows does not care which item it held)
     const int my_item = xcd_item(*n_items);
     if (my_item < 0) {
@@ -1334,92 +1345,143 @@ __global__ __launch_bounds__(kThreads) void k_bucket_rollout_items(const Trans *
     if ((threadIdx.x & 63) == 0)
         for (int t = 0; t <= T_cap; ++t) cnt[wave][t] = 0;
     for (int base = 0; base < item.count; base += kThreads) {  // (one pass: an item holds <= chunk = kThreads lanes unless RNAD_BUCKET_CHUNK says otherwise)
-        const bool active = base + (int)threadIdx.x < item.count;
-        const uint32_t j = (uint32_t)(item.begin + base) + threadIdx.x;
-        const int32_t lane_local = active ? lane_ids[j] : 0;
-        const uint64_t lane = (uint64_t)(lane0 + lane_local);
-        unsigned long long packed;  // the first decisions, drawn by k_bucket_keys: of the bucket (shared) or of this lane
+        bool active[L];
+        uint32_t j[L];
+        int32_t lane_local[L];
+        uint64_t lane[L];
+        unsigned long long packed[L];  // the first decisions, drawn by k_bucket_keys: of the bucket (shared) or of this lane
+#pragma unroll
+        for (int l = 0; l < L; ++l) {
+            const int k = base + l * NT + (int)threadIdx.x;
+            active[l] = k < item.count;
+            j[l] = (uint32_t)(item.begin + k);
+            lane_local[l] = active[l] ? lane_ids[j[l]] : 0;
+            lane[l] = (uint64_t)(lane0 + lane_local[l]);
+        }
         if (shared) {
             const unsigned long long first = decisions[lane_ids[item.begin]];
-            packed = ((unsigned long long)(unsigned int)__builtin_amdgcn_readfirstlane((int)(first >> 32)) << 32) |
-                     (unsigned int)__builtin_amdgcn_readfirstlane((int)first);
+            const unsigned long long uni = ((unsigned long long)(unsigned int)__builtin_amdgcn_readfirstlane((int)(first >> 32)) << 32) |
+                                           (unsigned int)__builtin_amdgcn_readfirstlane((int)first);
+#pragma unroll
+            for (int l = 0; l < L; ++l) packed[l] = uni;
         } else {
-            packed = active ? decisions[lane_local] : 0ull;
+#pragma unroll
+            for (int l = 0; l < L; ++l) packed[l] = active[l] ? decisions[lane_local[l]] : 0ull;
         }
-        const int n_packed = (int)(packed >> 60);
-        int state = active ? 1 : 0, t_from = 0;
-        unsigned long long acts = 0ull;
-        float reward_final = 0.0f;
+        int state[L], n_packed[L], t_from = 0;
+        unsigned long long acts[L];
+        float reward_final[L];
+#pragma unroll
+        for (int l = 0; l < L; ++l) {
+            n_packed[l] = (int)(packed[l] >> 60);
+            state[l] = active[l] ? 1 : 0;
+            acts[l] = 0ull;
+            reward_final[l] = 0.0f;
+        }
         if (shared) {  // the transitions above the cut, once for the workgroup: the states are the bucket's path, the actions the first lane's
-            const int n_pre = min(min(n_packed, T_cap) & ~1, n_shared - 2);
-            const int32_t live_now = (int32_t)__popcll(__ballot(active));
+            const int n_pre = min(min(n_packed[0], T_cap) & ~1, n_shared - 2);
+            int32_t live_now = 0;
+#pragma unroll
+            for (int l = 0; l < L; ++l) live_now += (int32_t)__popcll(__ballot(active[l]));
             for (int t = 0; t < n_pre; t += 2) {
                 if ((threadIdx.x & 63) == 0) {
                     cnt[wave][t] += live_now;
                     cnt[wave][t + 1] += live_now;
                 }
-                const int bits0 = (int)(packed >> (6 * t)) & 63, bits1 = (int)(packed >> (6 * (t + 1))) & 63;
+                const int bits0 = (int)(packed[0] >> (6 * t)) & 63, bits1 = (int)(packed[0] >> (6 * (t + 1))) & 63;
                 if (visited && threadIdx.x == 0 && base == 0) {
                     const int at = my_path[t];
                     visited[at] = visited[S + at] = 1;
                 }
-                acts |= (unsigned long long)(bits0 & 7) << (3 * t) | (unsigned long long)(bits1 & 7) << (3 * (t + 1));
+#pragma unroll
+                for (int l = 0; l < L; ++l)
+                    acts[l] |= (unsigned long long)(bits0 & 7) << (3 * t) | (unsigned long long)(bits1 & 7) << (3 * (t + 1));
             }
             t_from = n_pre;
-            state = active ? my_path[n_pre] : 0;  // (n_pre <= n_path: an upper state of the path, or the group's root)
+#pragma unroll
+            for (int l = 0; l < L; ++l) state[l] = active[l] ? my_path[n_pre] : 0;  // (n_pre <= n_path: an upper state of the path, or the group's root)
         }
         for (int t = t_from; t < T_cap; t += 2) {
             const bool two = t + 1 < T_cap;  // (an odd T_cap ends with a row step alone)
-            const uint64_t live = __ballot(state != 0);
+            int32_t live = 0;
+#pragma unroll
+            for (int l = 0; l < L; ++l) live += (int32_t)__popcll(__ballot(state[l] != 0));
             if ((threadIdx.x & 63) == 0) {
-                cnt[wave][t] += (int32_t)__popcll(live);
-                if (two) cnt[wave][t + 1] += (int32_t)__popcll(live);  // the row player's step leaves the state as it is
+                cnt[wave][t] += live;
+                if (two) cnt[wave][t + 1] += live;  // the row player's step leaves the state as it is
             }
-            if (!active) continue;
-            if (t >= n_shared) {  // (n_shared is even: both steps of the transition, or neither)
-                const REL r = rel_of<REL>(state, lo);
-                *at_bytes<REL>(states, ((uint32_t)t * B32 + j) * (uint32_t)sizeof(REL)) = r;
-                if (two) *at_bytes<REL>(states, ((uint32_t)(t + 1) * B32 + j) * (uint32_t)sizeof(REL)) = r;
+            bool go[L], replay0[L], replay1[L];
+            float pol0[L][A], pol1[L][A], u[L][3];
+            // every lane's stores and table requests first, then the draws: the L chains overlap their two dependent latencies
+#pragma unroll
+            for (int l = 0; l < L; ++l) {
+                go[l] = active[l];
+                if (go[l] && t >= n_shared) {  // (n_shared is even: both steps of the transition, or neither)
+                    const REL r = rel_of<REL>(state[l], lo);
+                    *at_bytes<REL>(states, ((uint32_t)t * B32 + j[l]) * (uint32_t)sizeof(REL)) = r;
+                    if (two) *at_bytes<REL>(states, ((uint32_t)(t + 1) * B32 + j[l]) * (uint32_t)sizeof(REL)) = r;
+                }
+                go[l] = go[l] && state[l] != 0;
+                replay0[l] = t < n_packed[l];
+                replay1[l] = t + 1 < n_packed[l];
+                if (go[l]) {
+                    const int64_t row0 = state[l], row1 = S + state[l];
+                    if (visited) {
+                        visited[row0] = 1;  // (every writer stores the same value)
+                        if (two) visited[row1] = 1;
+                    }
+                    if (!replay0[l]) load_policy_row<A>(policy_tab, row0, tab_stride, vec4 != 0, pol0[l]);
+                    if (two && !replay1[l]) load_policy_row<A>(policy_tab, row1, tab_stride, vec4 != 0, pol1[l]);
+                }
             }
-            if (state == 0) continue;
-            const bool replay0 = t < n_packed, replay1 = t + 1 < n_packed;
-            const int64_t row0 = state, row1 = S + state;
-            if (visited) {
-                visited[row0] = 1;  // (every writer stores the same value)
-                if (two) visited[row1] = 1;
+#pragma unroll
+            for (int l = 0; l < L; ++l)
+                if (go[l] && (!replay0[l] || (two && !replay1[l]))) rnad_decision_uniforms(seed, lane[l], (uint32_t)t, u[l]);  // computed while the rows travel
+            int a0[L], a1[L], bits1[L];
+#pragma unroll
+            for (int l = 0; l < L; ++l) {
+                if (!go[l]) continue;
+                const int bits0 = replay0[l] ? (int)(packed[l] >> (6 * t)) & 63 : 0;
+                bits1[l] = replay1[l] ? (int)(packed[l] >> (6 * (t + 1))) & 63 : 0;
+                a0[l] = replay0[l] ? (bits0 & 7) : pick<A>(pol0[l], u[l][0]);
+                acts[l] |= (unsigned long long)a0[l] << (3 * t);
+                if (two) {
+                    a1[l] = replay1[l] ? (bits1[l] & 7) : pick<A>(pol1[l], u[l][1]);
+                    acts[l] |= (unsigned long long)a1[l] << (3 * (t + 1));
+                }
             }
-            float pol0[A], pol1[A], u[3];
-            if (!replay0) load_policy_row<A>(policy_tab, row0, tab_stride, vec4 != 0, pol0);
-            if (two && !replay1) load_policy_row<A>(policy_tab, row1, tab_stride, vec4 != 0, pol1);
-            if (!replay0 || (two && !replay1)) rnad_decision_uniforms(seed, lane, (uint32_t)t, u);  // computed while the rows travel
-            const int bits0 = replay0 ? (int)(packed >> (6 * t)) & 63 : 0, bits1 = replay1 ? (int)(packed >> (6 * (t + 1))) & 63 : 0;
-            const int a0 = replay0 ? (bits0 & 7) : pick<A>(pol0, u[0]);
-            acts |= (unsigned long long)a0 << (3 * t);
-            if (!two) continue;
-            const int a1 = replay1 ? (bits1 & 7) : pick<A>(pol1, u[1]);
-            acts |= (unsigned long long)a1 << (3 * (t + 1));
-            int next;
-            float rew;
-            if (replay1)
-                transition_apply<A>(trans, C, state, a0, a1, bits1 >> 3, next, rew);
-            else
-                transition_lane<A>(trans, C, state, a0, a1, nullptr, u[2], next, rew);
-            if (next == 0) reward_final = rew;
-            state = next;
+            if (two) {
+#pragma unroll
+                for (int l = 0; l < L; ++l) {
+                    if (!go[l]) continue;
+                    int next;
+                    float rew;
+                    if (replay1[l])
+                        transition_apply<A>(trans, C, state[l], a0[l], a1[l], bits1[l] >> 3, next, rew);
+                    else
+                        transition_lane<A>(trans, C, state[l], a0[l], a1[l], nullptr, u[l][2], next, rew);
+                    if (next == 0) reward_final[l] = rew;
+                    state[l] = next;
+                }
+            }
         }
-        if (active) {
-            acts_out[j] = acts;
-            reward_out[j] = reward_final;
-            if (T_cap >= n_shared) *at_bytes<REL>(states, ((uint32_t)T_cap * B32 + j) * (uint32_t)sizeof(REL)) = rel_of<REL>(state, lo);
+        int32_t live = 0;
+#pragma unroll
+        for (int l = 0; l < L; ++l) {
+            if (active[l]) {
+                acts_out[j[l]] = acts[l];
+                reward_out[j[l]] = reward_final[l];
+                if (T_cap >= n_shared) *at_bytes<REL>(states, ((uint32_t)T_cap * B32 + j[l]) * (uint32_t)sizeof(REL)) = rel_of<REL>(state[l], lo);
+            }
+            live += (int32_t)__popcll(__ballot(state[l] != 0));
         }
-        const uint64_t live = __ballot(state != 0);
-        if ((threadIdx.x & 63) == 0) cnt[wave][T_cap] += (int32_t)__popcll(live);
+        if ((threadIdx.x & 63) == 0) cnt[wave][T_cap] += live;
     }
     __syncthreads();
     if ((int)threadIdx.x <= T_cap) {
         int32_t sum = 0;
 #pragma unroll
-        for (int w = 0; w < kThreads / 64; ++w) sum += cnt[w][threadIdx.x];
+        for (int w = 0; w < NW; ++w) sum += cnt[w][threadIdx.x];
         my_alive[threadIdx.x] = sum;
     }
 }
@@ -2388,7 +2450,7 @@ int rollout_bucketed_impl(const rnad_tree_t *tree, const RolloutBuffers &tr, boo
             RNAD_REQUIRE(items && n_items, "rnad_rollout_bucketed_compact: the work list of the sort is needed to play");
             alive_n = (int)p.max_items;
             RNAD_DISPATCH_REL(p, RNAD_DISPATCH_A(tree->A, hipLaunchKernelGGL(
-                                     (k_bucket_rollout_items<kA, REL>), dim3((unsigned)p.max_items), dim3(kThreads), 0, stream, tree->trans, tree->C,
+                                     (k_bucket_rollout_items<kA, REL, kRolloutLanes>), dim3((unsigned)p.max_items), dim3(kThreads / kRolloutLanes), 0, stream, tree->trans, tree->C,
                                      S, B, tr.T_cap, policy_tab, policy_stride, vec4, seed, device_params, lane0, (const int32_t *)lane_ids,
                                      (const unsigned long long *)s.decisions, (const Item *)items, (const int32_t *)n_items,
                                      (const int32_t *)p.cut->bucket_path, (const int32_t *)p.cut->bucket_lo, (const int32_t *)p.cut->path_states,
