@@ -469,6 +469,12 @@ StageOut carve_stage(void *stage, int64_t B, int64_t S) {
 #define RNAD_PLAY 2
 #endif
 constexpr int kPlay = RNAD_PLAY;
+// ... of the walks with tables in LDS (k_bucket_keys_lds, k_bucket_keys_hybrid).  r04: one lane per thread -- 18.9 -> 17.7 us on
+// configs[1], 42.9 -> 37.8 on configs[3]'s hybrid walk (two: what the global-table walk above keeps; four: 18.3 / 46.1)
+#ifndef RNAD_PLAY_LDS
+#define RNAD_PLAY_LDS 1
+#endif
+constexpr int kPlayLds = RNAD_PLAY_LDS;
 
 template <int A, int L>
 __global__ __launch_bounds__(kThreads) void k_bucket_keys(const Trans *__restrict__ trans, int C, int64_t S, int64_t B, int n_steps,
@@ -2388,9 +2394,9 @@ int rollout_bucketed_impl(const rnad_tree_t *tree, const RolloutBuffers &tr, boo
         if (p.cut->upper_walk && keys_lds <= kKeysLds && !walk_global && !no_full_lds) {  // the upper states' tables fit the LDS: walk there, one sort tile per workgroup
             keys_with_hist = true;
             if (keys_lds > 48 * 1024)
-                RNAD_DISPATCH_A(tree->A, RNAD_HIP_OK(hipFuncSetAttribute((const void *)k_bucket_keys_lds<kA, kPlay>,
+                RNAD_DISPATCH_A(tree->A, RNAD_HIP_OK(hipFuncSetAttribute((const void *)k_bucket_keys_lds<kA, kPlayLds>,
                                                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)keys_lds)));
-            RNAD_DISPATCH_A(tree->A, hipLaunchKernelGGL((k_bucket_keys_lds<kA, kPlay>), dim3(p.sort_blocks), dim3(kSortThreads), keys_lds, stream,
+            RNAD_DISPATCH_A(tree->A, hipLaunchKernelGGL((k_bucket_keys_lds<kA, kPlayLds>), dim3(p.sort_blocks), dim3(kSortThreads), keys_lds, stream,
                                                         (const UpperWalk *)p.cut->upper_walk, (const int32_t *)p.cut->upper_list, p.cut->n_upper, nb,
                                                         tree->C, S, B, n_steps, policy_tab, policy_stride, (int)p.cut->host_bucket_of[1],
                                                         p.cut->n_groups, seed, device_params, lane0, s.keys, s.decisions, s.hist, norm, stage));
@@ -2399,9 +2405,9 @@ int rollout_bucketed_impl(const rnad_tree_t *tree, const RolloutBuffers &tr, boo
             // the top levels of the upper states in LDS, the rest from the global tables
             const size_t hyb_lds = keys_hybrid_lds_bytes(p.cut->n_hot, p.cut->n_upper, tree->A, tree->C);
             if (hyb_lds > 48 * 1024)
-                RNAD_DISPATCH_A(tree->A, RNAD_HIP_OK(hipFuncSetAttribute((const void *)k_bucket_keys_hybrid<kA, kPlay>,
+                RNAD_DISPATCH_A(tree->A, RNAD_HIP_OK(hipFuncSetAttribute((const void *)k_bucket_keys_hybrid<kA, kPlayLds>,
                                                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)hyb_lds)));
-            RNAD_DISPATCH_A(tree->A, hipLaunchKernelGGL((k_bucket_keys_hybrid<kA, kPlay>), dim3(p.sort_blocks), dim3(kSortThreads), hyb_lds, stream,
+            RNAD_DISPATCH_A(tree->A, hipLaunchKernelGGL((k_bucket_keys_hybrid<kA, kPlayLds>), dim3(p.sort_blocks), dim3(kSortThreads), hyb_lds, stream,
                                                         (const UpperWalk *)p.cut->upper_walk, (const int32_t *)p.cut->upper_list,
                                                         (const int32_t *)p.cut->hot_list, (const int32_t *)p.cut->hot_of, p.cut->n_hot, p.cut->n_upper,
                                                         tree->trans, (const int32_t *)p.cut->bucket_of, tree->C, S, B, n_steps, policy_tab, policy_stride,
