@@ -463,6 +463,18 @@ int rnad_bucket_records(const rnad_tree_t *tree, const float *logit_tab, const f
                         const float *logit_reg_tab, const float *logit_reg_tab_, const rnad_learn_params_t *hp,
                         const rnad_step_params_t *device_params, float *records, float *fast_records, float *policy_rows,
                         const int32_t *rows, const int64_t *n_rows, void *stream);
+/* Distinct observations (csrc/rows_dedup.hip).  What a net contributes to a (player, state) row is a function of the row's observation
+ * alone (nn/net.py:37-51), so rows with the same observation share their net outputs and records, and their gradients dL/dout can be
+ * added up before the backward.  The caller groups the rows by the bits of their observation (rnad_hip.TreeHandle.obs_dedup) and
+ *   rnad_rows_expand      after a table launch on one representative row per group: tables[k][r] = tables[k][rep_of[r]] for every row r
+ *                         (rep_of: int32 [rows], the representative of r's group, itself for a representative; tables: up to 4 device
+ *                         tables of floats_per_row[k] floats per row, multiples of 4, 16-byte aligned);
+ *   rnad_rows_segment_sum after rnad_bucket_finish: for every group g with more than one row -- rows order[start[g] .. start[g + 1]),
+ *                         ascending, the first its representative -- dlogit_tab / dv_tab of the representative <- the sums over the group
+ *                         (one wave per group, a fixed reduction tree); the backward then runs on the representatives alone. */
+int rnad_rows_expand(int64_t rows, const int32_t *rep_of, int n_tables, float *const *tables, const int32_t *floats_per_row, void *stream);
+int rnad_rows_segment_sum(int n_groups, const int32_t *start, const int32_t *order, int A, float *dlogit_tab, float *dv_tab, void *stream);
+
 /* rnad_mlp_rows_records (csrc/mlp_rows.hip): the table evaluations of a tabular update AND rnad_bucket_records in one launch -- replaces
  * learn/rnad.py:373,378 on the 2S rows (the learner net's two heads, the target net's value head; nn/net.py:40-43) followed by the
  * row-only arithmetic of :374,382 and learn/vtrace.py (see rnad_bucket_records).  packed_net / packed_target: weight images of

@@ -160,6 +160,12 @@ class RNaD:
         # 43 KB weight-gradient all-reduce closes the step as before.  Default off: three more collectives per step, to be set against the
         # row work they remove on real xGMI (DESIGN.md section 7 has the byte counts and the prediction).
         self.shard_rows = False
+        # Distinct observations (csrc/rows_dedup.hip): rows of the tree with the same observation share their net outputs and records, and
+        # their gradients are added up before the backward -- the table launch and the backward then run on one representative row per
+        # observation (BASELINE configs[1]: 132 862 rows, ~15 k distinct observations, because the deepest level's payoff matrices are
+        # +-1).  Exact for the forward (same bits per row); the weight gradient is the same sum in another fp32 order.  Applied when it
+        # removes at least a fifth of the rows; never on logging steps, lazy rows or row sharding.
+        self.dedup_rows = True
         # The legal fold (include/rnad_hip.h): on a tree whose observation rows all carry the same legal plane (all ones; e0 in the
         # absorbing state) the table evaluations of the per-row mode run the MLP with A^2 + 1 input features instead of 2 A^2 -- the
         # same function of the same weights in another summation order, ~45 % fewer matrix instructions in the first layer.
@@ -189,6 +195,15 @@ class RNaD:
         return bool(getattr(self, "shard_rows", False) and self._dp() and self._world > 1 and log is None and not lazy
                     and rnad_hip.mlp_rows_records_supported(A, self.net.width, self._fold())
                     and rnad_hip.bucket_plan(handle, local_batch) is not None)
+
+    def _dedup_now(self, handle, log, lazy, shard, fold):
+        """TreeHandle.obs_dedup() when the step should evaluate the nets on distinct observations only, else None."""
+        if not getattr(self, "dedup_rows", True) or log is not None or lazy or shard:
+            return None
+        if not rnad_hip.mlp_rows_records_supported(self.tree.max_actions, self.net.width, fold):
+            return None
+        d = handle.obs_dedup(getattr(self, "obs_half", False))
+        return d if 5 * d.n_unique <= 4 * d.n_rows else None
 
     def _row_shard(self, handle):
         """(RowList of this rank's rows, rows per rank): rank r owns rows [r * per, min((r + 1) * per, 2S)) of the (player, state) tables."""
@@ -477,7 +492,7 @@ class RNaD:
         return entry["images"]
 
     def _table_outputs(self, alpha, obs_half=False, want_target_logits=False, policy_only=False, fold=False, records_hp=None,
-                       step_params=None, shard=False):
+                       step_params=None, shard=False, dedup=None):
         """learner / target / regularisation nets on the 2S observations of the tree (rnad.py:373-380 on every distinct input):
         learner and target in ONE launch per step, the two regularisation nets from _reg_tables.  Both regularisation tables are
         always there: a term of log_policy_reg (:382) whose weight is exactly 0 adds exactly 0.
@@ -506,12 +521,17 @@ class RNaD:
             # come out of ONE launch (csrc/mlp_rows.hip: a persistent workgroup per CU, a wave per hidden tile, weights in registers)
             logit_reg, logit_reg_ = self._reg_tables(table, fold)
             rows, per = self._row_shard(self.tree.handle()) if shard else (None, 0)
+            if dedup is not None:
+                rows = dedup.uniq  # one representative row per distinct observation
             with torch.no_grad():
                 out = rnad_hip.mlp_rows_records(self.tree.handle(), packed, packed_target, self.net.width, table, logit_reg, logit_reg_,
                                                 records_hp, step_params=step_params, fold=self.tree.handle() if fold else False, rows=rows,
-                                                alloc_rows=per * self._world if shard else None)
+                                                alloc_rows=per * self._world if shard else (table.shape[0] if dedup is not None else None))
+                if dedup is not None:  # every other row: a copy of its representative's records (the same bits the launch on all rows writes)
+                    rnad_hip.rows_expand(dedup, [out["fast_records"], out["policy_rows"], out["records"]])
             tables = dict(table=table, logit=out["logit"], v=out["v"], logit_target=None, v_target=out["v_target"], logit_reg=logit_reg,
-                          logit_reg_=logit_reg_, packed_net=packed, fold=fold, records=out["records"], fast_records=out["fast_records"])
+                          logit_reg_=logit_reg_, packed_net=packed, fold=fold, records=out["records"], fast_records=out["fast_records"],
+                          dedup=dedup)
             if shard:
                 # this rank evaluated its rows only: the actor's policy rows first (the rollout needs them), then the learner's operands
                 self._gather_rows(out["policy_rows"], per)
@@ -637,7 +657,7 @@ class RNaD:
             per_row_backward = False  # a batch that is not bucket-ordered (a replay sample) beyond the atomics kernel's 2^21 lanes: per-slot backward
         if not bucketed and getattr(episodes, "buckets", None) is not None:
             rnad_hip.bucket_alive(self.tree.handle(), episodes.buckets)  # (a no-op unless the rollout left its alive counts to the compact learner)
-        live = None
+        live, capacity = None, None
         if (not per_row_backward and getattr(self, "skip_absorbed", True) and log is None and fused_mlp
                 and not self.tree.handle().uniform_length):
             live = rnad_hip.compact_valid(episodes.indices[:T])
@@ -713,7 +733,12 @@ class RNaD:
                 plan.accumulators[: 2 * S_ * A1].zero_()  # (finish cleared the rows it read; the other ranks' rows still hold their sums)
                 live = shard
             if getattr(self, "keep_last_tables", False):  # (tests: the per-row gradient tables of this step)
-                self.last_tables = (dlogit, dv, shard)
+                self.last_tables = (dlogit.clone(), dv.clone(), shard)
+            dedup = tables.get("dedup") if shard is None else None
+            if dedup is not None:
+                # rows with the same observation: their dL/dlogit, dL/dv added up into the representative row; the backward on those
+                rnad_hip.rows_segment_sum(dedup, A, dlogit, dv)
+                live, capacity = dedup.uniq, dedup.n_unique
             pi = None
             backward_obs = table
         elif table is not None:
@@ -740,7 +765,7 @@ class RNaD:
             else:
                 packed = tables["packed_net"] if tables is not None and "packed_net" in tables else self.net.pack()  # same weights as the forward
             rnad_hip.mlp_backward(packed, weights, backward_obs, A, dlogit.view(-1, A), dv.view(-1, 1), live=live, out=views,
-                                  fold=self.tree.handle() if fold else False)
+                                  fold=self.tree.handle() if fold else False, capacity=capacity)
             if all(p_.grad is None for p_ in weights):
                 for p_, g_ in zip(weights, views):
                     p_.grad = g_
@@ -835,9 +860,10 @@ class RNaD:
         elif mode is True:
             # the nets do not change between this step's rollout and its update: one evaluation of the 2S observations serves the
             # actor (= the learner net, rnad.py:503-505) and all four nets of __learn
+            shard = self._shard_now(handle, local_batch, log, lazy)
             tables = self._table_outputs(alpha, getattr(self, "obs_half", False), want_target_logits=log is not None, fold=fold,
-                                         records_hp=self._learn_params(alpha), step_params=step_params,
-                                         shard=self._shard_now(handle, local_batch, log, lazy))
+                                         records_hp=self._learn_params(alpha), step_params=step_params, shard=shard,
+                                         dedup=self._dedup_now(handle, log, lazy, shard, fold))
         if self.total_steps % self.buffer_mod == 0:
             episodes = episode.Episodes(self.tree, local_batch, seed=self._new_seed(), lane_offset=rank * local_batch,
                                         obs_half=getattr(self, "obs_half", False))

@@ -189,6 +189,42 @@ class TreeHandle:
             self._legal_foldable = ok
         return self._legal_foldable
 
+    def obs_dedup(self, half=False):
+        """The rows of the observation table grouped by the BITS of their observation (csrc/rows_dedup.hip).  Returns an object with
+        n_rows (2S), n_unique, uniq (RowList of one representative row per group, ascending: the first row of the group), rep_of (int32
+        [2S]: the representative of every row), multi_start / multi_order (int32 CSR of the groups with more than one row, rows ascending,
+        the representative first) and n_multi.  Computed once per table and kept."""
+        key = "_obs_dedup_half" if half else "_obs_dedup"
+        got = getattr(self, key, None)
+        if got is None:
+            table = self.observations_table(half)
+            N = table.shape[0]
+            flat = table.reshape(N, -1)
+            bits = flat.view(torch.int16 if half else torch.int32).to(torch.int64)
+            _, inverse = torch.unique(bits, dim=0, return_inverse=True)
+            n_unique = int(inverse.max().item()) + 1
+            rows = torch.arange(N, device=table.device, dtype=torch.int64)
+            first = torch.full((n_unique,), N, dtype=torch.int64, device=table.device).scatter_reduce(0, inverse, rows, reduce="amin")
+            rep_of = first[inverse]
+            uniq_rows = torch.sort(first).values
+            # groups with more than one row: their rows, ascending, group after group in the order of their representatives
+            size = torch.bincount(inverse, minlength=n_unique)
+            in_multi = size[inverse] > 1
+            m_rows = rows[in_multi]
+            order = m_rows[torch.argsort(rep_of[in_multi] * N + m_rows)]
+            reps_multi = torch.sort(first[size > 1]).values
+            counts = size[inverse[reps_multi]]
+            start = torch.zeros((reps_multi.numel() + 1,), dtype=torch.int64, device=table.device)
+            start[1:] = torch.cumsum(counts, 0)
+            got = type("ObsDedup", (), {})()
+            got.n_rows, got.n_unique, got.n_multi = N, n_unique, int(reps_multi.numel())
+            got.uniq = RowList(uniq_rows.to(I32), N, table.device)
+            got.rep_of = rep_of.to(I32).contiguous()
+            got.multi_start = start.to(I32).contiguous()
+            got.multi_order = order.to(I32).contiguous()
+            setattr(self, key, got)
+        return got
+
     def __del__(self):
         # rnad_tree_destroy is a series of hipFree calls, and a hipFree while ANY stream of the process is capturing (torch.cuda.graph
         # captures in the global mode) invalidates that capture -- which is what happens when the garbage collector gets to the tree of an
@@ -424,7 +460,7 @@ def mlp_backward_supported(A, W):
     return W % 32 == 0 and lib().rnad_mlp_backward_workspace(C.c_int64(32), A, W) > 0
 
 
-def mlp_backward(packed, weights, obs, A, dlogits, dvalue, live=None, out=None, fold=False):
+def mlp_backward(packed, weights, obs, A, dlogits, dvalue, live=None, out=None, fold=False, capacity=None):
     """Gradients of the 8 Linear tensors (MLP_KEYS order) for dL/dlogits [N, A], dL/dvalue [N(,1)].
     live: a LiveRows -- only those rows contribute (the caller guarantees the others carry zero gradients).
     out: eight preallocated tensors shaped like the weights (e.g. views of one flat all-reduce bucket) to write into.
@@ -440,7 +476,10 @@ def mlp_backward(packed, weights, obs, A, dlogits, dvalue, live=None, out=None, 
               _dp(dvalue, F32, "dvalue"), *[_dp(g, F32, "grad") for g in grads], _dp(ws, F32, "workspace"), _stream())
     if fold:  # (packed: the fold image; gradients of the eight original tensors)
         assert live is None or live.N == N, "live-row list built for a different batch"
-        _check(lib().rnad_mlp_backward_fold(C.c_int64(N), *_row_list(live), *common))
+        # capacity: the length of a FIXED row list (the representatives of TreeHandle.obs_dedup): the launch -- workgroups, partial rows of
+        # the reduction -- is then sized for it instead of for all N rows
+        cap = N if (capacity is None or live is None) else int(capacity)
+        _check(lib().rnad_mlp_backward_fold(C.c_int64(cap), *_row_list(live), *common))
     elif live is None:
         _check(lib().rnad_mlp_backward(C.c_int64(N), *common))
     else:
@@ -1080,6 +1119,22 @@ def bucket_records(tree, logit_tab, v_tab, v_target_tab, logit_reg_tab, logit_re
     if pol is not None:
         rec._policy_rows = pol  # travels with the records: rollout_bucketed_compact(table=records) gathers from it
     return (rec, quick) if fast else rec
+
+
+def rows_expand(dedup, tables):
+    """rnad_rows_expand: every table (float32 [2S, k], k a multiple of 4) gets, in the rows that are not representatives, the row of their
+    representative (dedup: TreeHandle.obs_dedup())."""
+    tables = [t for t in tables if t is not None]
+    assert 1 <= len(tables) <= 4 and all(t.shape[0] >= dedup.n_rows and t.dtype == F32 for t in tables)
+    ptrs = (C.c_void_p * len(tables))(*[_dp(t, F32, "table").value for t in tables])
+    widths = (C.c_int32 * len(tables))(*[int(t.shape[1]) for t in tables])
+    _check(lib().rnad_rows_expand(C.c_int64(dedup.n_rows), _dp(dedup.rep_of, I32, "rep_of"), len(tables), ptrs, widths, _stream()))
+
+
+def rows_segment_sum(dedup, A, dlogit_tab, dv_tab):
+    """rnad_rows_segment_sum: the representatives' rows of dlogit_tab [2S, A] / dv_tab [2S, 1] receive the sums over their groups."""
+    _check(lib().rnad_rows_segment_sum(dedup.n_multi, _dp(dedup.multi_start, I32, "start"), _dp(dedup.multi_order, I32, "order"), A,
+                                       _dp(dlogit_tab, F32, "dlogit_tab"), _dp(dv_tab, F32, "dv_tab"), _stream()))
 
 
 def mlp_rows_records_supported(A, W, fold=False, from_table=False):
