@@ -275,6 +275,9 @@ def main():
     staged = getattr(rn.last_episodes, "staged_rows", None) if lazy_now else None
     args.policy_rows = int(sum(r.count.item() for r in staged)) if staged else 0  # rows the staged policy head was evaluated on
     args.fold = bool(rn._fold() and mode_now_is_true(rn, T, local_batch))
+    # distinct observations (RNaD.dedup_rows): the table launch and the backward run on one representative row per observation
+    dd = rn._dedup_now(handle, None, lazy_now, None, rn._fold()) if mode_now_is_true(rn, T, local_batch) else None
+    args.unique_rows = int(dd.n_unique) if dd is not None else 0
     default_mode = rn.tabular
     mode_now = rn._tabular_mode(T, local_batch)
 
@@ -435,6 +438,7 @@ def main():
                                "in_effect": repr(mode_now), "what": what[mode_now],
                                "step_replayed_from_hipGraph": replayed, "compact_trajectory": bool(args.compact_in_effect),
                                "lazy_rows_visited": args.visited_rows or None, "staged_policy_rows": args.policy_rows or None,
+                               "rows_after_dedup": args.unique_rows or None,  # (RNaD.dedup_rows: rows with distinct observation bits)
                                "legal_fold": args.fold,
                                "distinct_observations": 2 * handle.S, "slots": T * local_batch},
             "other_modes": {name: {"env_steps_per_sec": global_batch * T_ref * E / sec, "updates_per_sec": E / sec,
@@ -584,7 +588,13 @@ def kernel_report(prof, A, C, args, B, T, live_slots, tree, mode_now):
                     wait = {"parked_on_waitcnt": c.get("SQ_WAIT_ANY", 0.0) / c["SQ_WAVE_CYCLES"] if c.get("SQ_WAIT_ANY") else None,
                             "issue_stalled": c.get("SQ_WAIT_INST_ANY", 0.0) / c["SQ_WAVE_CYCLES"] if c.get("SQ_WAIT_INST_ANY") else None,
                             "what": "SQ_WAIT_ANY / SQ_WAVE_CYCLES and SQ_WAIT_INST_ANY / SQ_WAVE_CYCLES of the counter pass"}
-                e.update(issue=issue, wait=wait, counters_from_this_build=pmc_matches if c else None,
+                l1 = None
+                if c.get("TCP_TOTAL_CACHE_ACCESSES_sum") and c.get("duration_us_tcp_pass"):
+                    l1 = {"cache_accesses_per_launch": c["TCP_TOTAL_CACHE_ACCESSES_sum"],
+                          "tcp_clock_enabled_frac": c.get("TCP_GATE_EN1_sum", 0.0) / (256 * c["duration_us_tcp_pass"] * 1e-6 * CLOCK_HZ),
+                          "what": "TCP_TOTAL_CACHE_ACCESSES_sum and TCP_GATE_EN1_sum / (256 CUs x launch duration x 2.4 GHz) of their own counter "
+                                  "pass: the vector L1s' access count and busy share -- what holds the gather kernels"}
+                e.update(issue=issue, wait=wait, l1=l1, counters_from_this_build=pmc_matches if c else None,
                          counters_source="profiles/r04_pmc.json (separate rocprofv3 --pmc passes: FETCH_SIZE | WRITE_SIZE | SQ_*; traffic = 2 x "
                                          "FETCH_SIZE + WRITE_SIZE), profiles/r04_isa_mix.json, profiles/r04_valu_issue.json" if c else None)
         out[p["name"]] = e
@@ -592,7 +602,8 @@ def kernel_report(prof, A, C, args, B, T, live_slots, tree, mode_now):
     # VALU; backward: recompute of both heads + dW0 over the augmented input padded to its MFMA tiles)
     uniform = tree.handle().uniform_length
     visited = args.visited_rows  # lazy rows: the value heads and the backward run on the rows the batch visited
-    bwd_samples = (visited or S2) if mode_now is True else (live_slots if not uniform else slots)
+    uniq = getattr(args, "unique_rows", 0)  # (0: every row evaluated)
+    bwd_samples = (visited or uniq or S2) if mode_now is True else (live_slots if not uniform else slots)
     def mlp_counters(entry, name):
         """Counter evidence of an MLP kernel (profiles/r04_pmc.json): HBM traffic, the matrix pipe's busy share of the launch's SIMD cycles,
         VALU wave-instructions, wait shares."""
@@ -626,11 +637,12 @@ def kernel_report(prof, A, C, args, B, T, live_slots, tree, mode_now):
         # learner: both heads, target: value head, on the 2S rows (regularisation tables are cached); lazy rows: the two value heads
         # on the visited rows only
         policy_rows = (getattr(args, "policy_rows", 0) or S2) if visited else S2
-        flops = 2.0 * K * W * (3 * S2 if not visited else policy_rows + 2 * visited)
+        flops = 2.0 * K * W * (3 * (uniq or S2) if not visited else policy_rows + 2 * visited)
         tf = flops / (p["us_per_step"] * 1e-6) / 1e12
-        out[p["name"]].update(bound="mfma", achieved=tf, peak=FP32_PEAK_TFLOPS, unit="TFLOP/s", frac=tf / FP32_PEAK_TFLOPS, samples_per_step=S2,
+        out[p["name"]].update(bound="mfma", achieved=tf, peak=FP32_PEAK_TFLOPS, unit="TFLOP/s", frac=tf / FP32_PEAK_TFLOPS, samples_per_step=uniq or S2,
                               flops_model=f"2*K*W per head and row, K = {K} input features" + (" (legal fold)" if getattr(args, "fold", False) else "")
                                           + ": learner 2 heads + target value head"
+                                          + (f"; on the {uniq} distinct observations of the tree's {S2} rows (RNaD.dedup_rows)" if uniq and not visited else "")
                                           + (f"; lazy rows: policy head on {policy_rows} rows (upper states + the groups the batch descends into), "
                                              f"the two value heads on the {visited} visited rows" if visited else ""))
         mlp_counters(out[p["name"]], "k_rows_forward_records" if "k_rows_forward_records" in pmc else "k_mlp_forward")
@@ -645,7 +657,7 @@ def roofline_of(k):
          "bytes_per_launch": k.get("algorithmic_bytes_per_launch"), "bytes_model": k.get("bytes_model"),
          "share_of_step_us": k["us_per_step"],
          "measured": "hipEvents around each launch, eager leg of the same steps after the timed region (the timed steps replay a graph)"}
-    for extra in ("issue", "wait", "counters_from_this_build", "counters_source", "flops_model", "samples_per_step", "matrix_pipe"):
+    for extra in ("issue", "wait", "l1", "counters_from_this_build", "counters_source", "flops_model", "samples_per_step", "matrix_pipe"):
         if k.get(extra) is not None:
             r[extra] = k[extra]
     return r

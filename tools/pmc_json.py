@@ -53,6 +53,13 @@ def main():
                 if r.get(c + "_mean"):
                     e[c] = float(r[c + "_mean"])
         out["kernels"][k] = e
+    if len(sys.argv) > 8:  # vector-L1 (TCP) counters of the bucket kernels (their own pass)
+        for k, r in load(sys.argv[8]).items():
+            e = out["kernels"].setdefault(k, {})
+            for c in ("TCP_TOTAL_CACHE_ACCESSES_sum", "TCP_GATE_EN1_sum", "TCP_TCC_READ_REQ_sum", "TCP_PENDING_STALL_CYCLES_sum"):
+                if r.get(c + "_mean"):
+                    e[c] = float(r[c + "_mean"])
+            e["duration_us_tcp_pass"] = float(r["mean_duration_us"])
     if len(sys.argv) > 7:  # matrix-pipe busy cycles of the MLP kernels (their own pass)
         for k, r in load(sys.argv[7]).items():
             e = out["kernels"].setdefault(k, {})

@@ -9,7 +9,7 @@ mkdir -p $O
 # 0. issue cost of the instruction classes on this hardware (the constants of bench.py's issue roof)
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 tools/micro/valu_issue.hip -o /tmp/valu_issue && /tmp/valu_issue --json $O/${tag}_valu_issue.json > $O/${tag}_valu_issue.txt 2>&1
 # 3. HBM counters of the step's kernels (default mode, eager so that every launch is its own dispatch) and of K1
-K="k_bucket_learn|k_bucket_rollout|k_bucket_keys|k_bucket_scatter|k_bucket_finish|k_mlp|k_rows_forward|k_row_records|k_optimizer"
+K="k_bucket_learn|k_bucket_rollout|k_bucket_keys|k_bucket_scatter|k_bucket_finish|k_mlp|k_rows_|k_row_records|k_optimizer"
 RNAD_NO_GRAPH=1 tools/pmc_run.sh ${tag}_fetch "FETCH_SIZE" "$K" -- python tools/step_probe.py --steps 20 --no-graph > /dev/null
 RNAD_NO_GRAPH=1 tools/pmc_run.sh ${tag}_write "WRITE_SIZE" "$K" -- python tools/step_probe.py --steps 20 --no-graph > /dev/null
 # 3b. what the learner / rollout / keys kernels are bound by: SQ issue / wait counters (their own pass)
@@ -23,7 +23,7 @@ head -5 $O/pmc_${tag}_k1_fetch.csv $O/pmc_${tag}_k1_write.csv
 RNAD_NO_GRAPH=1 tools/pmc_run.sh ${tag}_mfma "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU" "k_mlp|k_rows_forward" -- python tools/step_probe.py --steps 20 --no-graph > /dev/null
 # 3c. the counter file bench.py's roofline reads (it carries the source hash of this build): written into profiles/ ON THE BOX so that the
 # bench lines below already use it, and into gpurun_out/ for the way back; the static instruction mix and the class costs beside it
-python tools/pmc_json.py $O/pmc_${tag}_fetch.csv $O/pmc_${tag}_write.csv $O/pmc_${tag}_sq.csv $O/${tag}_pmc.json $O/pmc_${tag}_k1_fetch.csv $O/pmc_${tag}_k1_write.csv $O/pmc_${tag}_mfma.csv
+python tools/pmc_json.py $O/pmc_${tag}_fetch.csv $O/pmc_${tag}_write.csv $O/pmc_${tag}_sq.csv $O/${tag}_pmc.json $O/pmc_${tag}_k1_fetch.csv $O/pmc_${tag}_k1_write.csv $O/pmc_${tag}_mfma.csv $O/pmc_${tag}_tcp.csv
 cp $O/${tag}_pmc.json profiles/${tag}_pmc.json
 python tools/isa_mix.py --issue $O/${tag}_valu_issue.json > $O/${tag}_isa_mix.log 2>&1
 cp profiles/${tag}_isa_mix.json profiles/${tag}_valu_issue.json $O/
