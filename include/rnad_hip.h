@@ -449,6 +449,14 @@ int rnad_rollout_bucketed_compact(const rnad_tree_t *tree, int T_cap, int64_t B,
                                   int table_is_policy, uint64_t seed, int64_t lane0, const rnad_step_params_t *device_params,
                                   void *scratch, int32_t *lane_ids, int32_t *items, int32_t *n_items, double *norm, void *states,
                                   int32_t *alive, uint64_t *acts, float *final_reward, int32_t *visited, void *stream);
+/* rnad_rollout_bucketed_compact + rnad_rows_expand in its keys pass (distinct observations, csrc/rows_dedup.hip: `tables` were evaluated
+ * on one representative row per observation; rep_of: int32 [2S]).  The copies ride in the launch that walks the upper states; walks that
+ * cannot carry them (global / hybrid tables) get a launch of rnad_rows_expand in front. */
+int rnad_rollout_bucketed_compact_expand(const rnad_tree_t *tree, int T_cap, int64_t B, const float *table, int64_t table_stride,
+                                         int table_is_policy, uint64_t seed, int64_t lane0, const rnad_step_params_t *device_params,
+                                         void *scratch, int32_t *lane_ids, int32_t *items, int32_t *n_items, double *norm, void *states,
+                                         int32_t *alive, uint64_t *acts, float *final_reward, int32_t *visited, const int32_t *rep_of,
+                                         int n_tables, float *const *tables, const int32_t *floats_per_row, void *stream);
 int rnad_bucket_indices(const rnad_tree_t *tree, int T1, int64_t B, const void *states, const int32_t *items, const int32_t *n_items,
                         int32_t *indices, void *stream);
 int rnad_bucket_pack_states(const rnad_tree_t *tree, int T1, int64_t B, const int32_t *indices, const int32_t *items,

@@ -565,6 +565,32 @@ __global__ __launch_bounds__(kThreads) void k_bucket_keys(const Trans *__restric
 // Same draws, same arithmetic, same keys and decisions as k_bucket_keys.
 // One workgroup per sort tile (kSortLanes consecutive lanes, kSortThreads threads): it also counts its lanes per bucket in LDS and
 // writes the tile's histogram row -- k_bucket_hist's work without its launch and without reading the keys back.
+// Distinct observations (csrc/rows_dedup.hip): the copies of the representatives' records into the other rows of their groups, carried by
+// the keys pass instead of a launch of their own (rnad_rows_expand: 7.4 us on configs[1]) -- the walk waits on LDS and arithmetic, the
+// copies are 19 MB of independent loads and stores that fill those waits.  The walk itself reads the actor's policy rows of the UPPER
+// states through rep_of (a representative's row is never written here: no race with the copies of other workgroups).
+struct KeysExpand {
+    const int32_t *rep_of = nullptr;  // [rows]: the representative of every row; NULL: nothing to copy
+    int64_t rows = 0;
+    int n = 0, max_quads = 0;
+    float4 *tab[4] = {nullptr, nullptr, nullptr, nullptr};
+    int quads[4] = {0, 0, 0, 0};
+};
+__device__ __forceinline__ void keys_expand_share(const KeysExpand &ex, int n_threads) {
+    // workgroup b copies the rows [b * per, (b + 1) * per); a thread per (row, 16-byte chunk of the widest table)
+    const int64_t per = (ex.rows + gridDim.x - 1) / gridDim.x, r0 = (int64_t)blockIdx.x * per;
+    const int64_t r1 = r0 + per < ex.rows ? r0 + per : ex.rows;
+    for (int64_t i = r0 * ex.max_quads + threadIdx.x; i < r1 * ex.max_quads; i += n_threads) {
+        const int64_t r = i / ex.max_quads;
+        const int q = (int)(i % ex.max_quads);
+        const int64_t rp = ex.rep_of[r];
+        if (rp == r) continue;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (k < ex.n && q < ex.quads[k]) ex.tab[k][r * ex.quads[k] + q] = ex.tab[k][rp * ex.quads[k] + q];
+    }
+}
+
 inline size_t keys_lds_bytes(int n_upper, int n_buckets, int A, int C) {
     return (((size_t)n_upper * A * A * C * sizeof(UpperWalk) + 15) & ~(size_t)15) + (size_t)n_upper * 2 * ((A + 3) & ~3) * sizeof(float) +
            (size_t)n_buckets * sizeof(int32_t);
@@ -577,7 +603,7 @@ __global__ __launch_bounds__(kSortThreads) void k_bucket_keys_lds(const UpperWal
                                                                   int n_groups, uint64_t seed, const rnad_step_params_t *__restrict__ sp,
                                                                   int64_t lane0, int32_t *__restrict__ keys,
                                                                   unsigned long long *__restrict__ decisions, int32_t *__restrict__ hist,
-                                                                  double *__restrict__ norm, StageOut stage) {
+                                                                  double *__restrict__ norm, StageOut stage, KeysExpand ex) {
     extern __shared__ __attribute__((aligned(16))) unsigned char keys_smem[];
     constexpr int PS = kPolStride<A>;
     const int AAC = A * A * C;
@@ -587,8 +613,11 @@ __global__ __launch_bounds__(kSortThreads) void k_bucket_keys_lds(const UpperWal
     for (int i = threadIdx.x; i < n_upper * AAC; i += kSortThreads) w[i] = walk[i];
     for (int i = threadIdx.x; i < n_upper * 2 * PS; i += kSortThreads) {
         const int slot = i / (2 * PS), player = (i / PS) & 1, a = i % PS;
-        pol[i] = a < A ? policy_tab[((int64_t)player * S + upper_list[slot]) * tab_stride + a] : 0.0f;
+        int64_t row = (int64_t)player * S + upper_list[slot];
+        if (ex.rep_of) row = ex.rep_of[row];  // (the row's own copy may not have been written yet)
+        pol[i] = a < A ? policy_tab[row * tab_stride + a] : 0.0f;
     }
+    if (ex.rep_of) keys_expand_share(ex, kSortThreads);  // (its stores are in flight during the walk)
     for (int i = threadIdx.x; i < n_buckets; i += kSortThreads) cnt[i] = 0;
     if (blockIdx.x == 0 && threadIdx.x == 0 && norm) norm[0] = norm[1] = 0.0;  // summed up by k_bucket_alive at the end of this rollout
     if (blockIdx.x == 0 && threadIdx.x == 0 && stage.counts) stage.counts[0] = stage.counts[1] = 0ull;
@@ -2351,7 +2380,8 @@ int rollout_bucketed_impl(const rnad_tree_t *tree, const RolloutBuffers &tr, boo
                           const rnad_step_params_t *device_params, void *scratch, int32_t *lane_ids, int32_t *items, int32_t *n_items,
                           double *norm, hipStream_t stream, int phases = 3, int32_t *group_flags = nullptr,
                           const int32_t *play_rows = nullptr, const int64_t *n_play_rows = nullptr, int32_t *staged_rows = nullptr,
-                          int64_t *n_staged = nullptr, bool visited_is_clear = false, void *stage_buf = nullptr, int32_t *stage_rows0 = nullptr) {
+                          int64_t *n_staged = nullptr, bool visited_is_clear = false, void *stage_buf = nullptr, int32_t *stage_rows0 = nullptr,
+                          const KeysExpand *expand = nullptr) {
     Plan p;
     RNAD_REQUIRE(make_plan(tree, tr.B, p), "rnad_rollout_bucketed: this tree / batch cannot be bucketed (see rnad_bucket_plan)");
     const int64_t B = tr.B, S = tree->S;
@@ -2391,7 +2421,18 @@ int rollout_bucketed_impl(const rnad_tree_t *tree, const RolloutBuffers &tr, boo
         const size_t keys_lds = keys_lds_bytes(p.cut->n_upper, nb, tree->A, tree->C);
         const bool walk_global = getenv("RNAD_KEYS_GLOBAL") && atoi(getenv("RNAD_KEYS_GLOBAL")) != 0;  // (tests: the fallback on any tree)
         const bool no_full_lds = getenv("RNAD_KEYS_LDS") && atoi(getenv("RNAD_KEYS_LDS")) == 0;  // (tests: the hybrid walk on small trees)
-        if (p.cut->upper_walk && keys_lds <= kKeysLds && !walk_global && !no_full_lds) {  // the upper states' tables fit the LDS: walk there, one sort tile per workgroup
+        const bool use_lds = p.cut->upper_walk && keys_lds <= kKeysLds && !walk_global && !no_full_lds;
+        if (expand && !use_lds) {  // (only k_bucket_keys_lds carries the copies: a launch of their own in front of the other walks)
+            float *tabs[4];
+            int32_t widths[4];
+            for (int k = 0; k < expand->n; ++k) {
+                tabs[k] = reinterpret_cast<float *>(expand->tab[k]);
+                widths[k] = 4 * expand->quads[k];
+            }
+            if (int rc = rnad_rows_expand(expand->rows, expand->rep_of, expand->n, tabs, widths, stream)) return rc;
+            expand = nullptr;
+        }
+        if (use_lds) {  // the upper states' tables fit the LDS: walk there, one sort tile per workgroup
             keys_with_hist = true;
             if (keys_lds > 48 * 1024)
                 RNAD_DISPATCH_A(tree->A, RNAD_HIP_OK(hipFuncSetAttribute((const void *)k_bucket_keys_lds<kA, kPlayLds>,
@@ -2399,7 +2440,9 @@ int rollout_bucketed_impl(const rnad_tree_t *tree, const RolloutBuffers &tr, boo
             RNAD_DISPATCH_A(tree->A, hipLaunchKernelGGL((k_bucket_keys_lds<kA, kPlayLds>), dim3(p.sort_blocks), dim3(kSortThreads), keys_lds, stream,
                                                         (const UpperWalk *)p.cut->upper_walk, (const int32_t *)p.cut->upper_list, p.cut->n_upper, nb,
                                                         tree->C, S, B, n_steps, policy_tab, policy_stride, (int)p.cut->host_bucket_of[1],
-                                                        p.cut->n_groups, seed, device_params, lane0, s.keys, s.decisions, s.hist, norm, stage));
+                                                        p.cut->n_groups, seed, device_params, lane0, s.keys, s.decisions, s.hist, norm, stage,
+                                                        expand ? *expand : KeysExpand{}));
+            expand = nullptr;  // (done)
         } else if (p.cut->upper_walk && p.cut->n_hot > 0 && p.cut->n_hot < p.cut->n_upper && !walk_global &&
                    !(getenv("RNAD_KEYS_HYBRID") && atoi(getenv("RNAD_KEYS_HYBRID")) == 0)) {
             // the top levels of the upper states in LDS, the rest from the global tables
@@ -2589,6 +2632,40 @@ extern "C" int rnad_rollout_bucketed_compact(const rnad_tree_t *tree, int T_cap,
                              visited};
     return rollout_bucketed_impl(tree, out, true, table, table_stride, table_is_policy, nullptr, 1, seed, lane0, device_params, scratch,
                                  lane_ids, items, n_items, norm, (hipStream_t)stream);
+}
+
+// rnad_rollout_bucketed_compact with the copies of rnad_rows_expand carried by its keys pass (distinct observations: the actor's table and
+// the learner's records were evaluated on one representative row per observation; `table` must be one of the tables being expanded, or
+// already complete).
+extern "C" int rnad_rollout_bucketed_compact_expand(const rnad_tree_t *tree, int T_cap, int64_t B, const float *table, int64_t table_stride,
+                                                    int table_is_policy, uint64_t seed, int64_t lane0,
+                                                    const rnad_step_params_t *device_params, void *scratch, int32_t *lane_ids, int32_t *items,
+                                                    int32_t *n_items, double *norm, void *states, int32_t *alive, uint64_t *acts,
+                                                    float *final_reward, int32_t *visited, const int32_t *rep_of, int n_tables,
+                                                    float *const *tables, const int32_t *floats_per_row, void *stream) {
+    void *indices = states;
+    RNAD_REQUIRE(tree && table && scratch && lane_ids && items && n_items && indices && acts && final_reward && rep_of && tables && floats_per_row,
+                 "rnad_rollout_bucketed_compact_expand: null argument");
+    RNAD_REQUIRE(alive || norm, "rnad_rollout_bucketed_compact_expand: deferred alive counts (alive == NULL) need `norm` (it is cleared here)");
+    RNAD_REQUIRE(T_cap >= 1 && T_cap <= kCompactSteps && B >= 1, "rnad_rollout_bucketed_compact_expand: 1 <= T_cap <= %d, got %d", kCompactSteps, T_cap);
+    RNAD_REQUIRE(table_stride >= tree->A && table_is_policy, "rnad_rollout_bucketed_compact_expand: the actor must be a table of policy rows");
+    RNAD_REQUIRE(n_tables >= 1 && n_tables <= 4, "rnad_rollout_bucketed_compact_expand: 1..4 tables");
+    KeysExpand ex;
+    ex.rep_of = rep_of;
+    ex.rows = 2 * tree->S;
+    ex.n = n_tables;
+    for (int k = 0; k < n_tables; ++k) {
+        RNAD_REQUIRE(tables[k] && floats_per_row[k] > 0 && floats_per_row[k] % 4 == 0 && ((uintptr_t)tables[k] & 15) == 0,
+                     "rnad_rollout_bucketed_compact_expand: table %d must be 16-byte aligned with a row of a multiple of 4 floats", k);
+        ex.tab[k] = reinterpret_cast<float4 *>(tables[k]);
+        ex.quads[k] = floats_per_row[k] / 4;
+        ex.max_quads = std::max(ex.max_quads, ex.quads[k]);
+    }
+    const RolloutBuffers out{T_cap, B, indices, nullptr, nullptr, nullptr, nullptr, nullptr, alive, (unsigned long long *)acts, final_reward,
+                             visited};
+    return rollout_bucketed_impl(tree, out, true, table, table_stride, table_is_policy, nullptr, 1, seed, lane0, device_params, scratch,
+                                 lane_ids, items, n_items, norm, (hipStream_t)stream, 3, nullptr, nullptr, nullptr, nullptr, nullptr, false, nullptr,
+                                 nullptr, &ex);
 }
 
 // The dense buffers of a compact trajectory: slot (t, j) from indices[t, j] (and indices[t + 1, j] for the reward) alone.

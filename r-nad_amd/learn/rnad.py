@@ -492,7 +492,7 @@ class RNaD:
         return entry["images"]
 
     def _table_outputs(self, alpha, obs_half=False, want_target_logits=False, policy_only=False, fold=False, records_hp=None,
-                       step_params=None, shard=False, dedup=None):
+                       step_params=None, shard=False, dedup=None, defer_expand=False):
         """learner / target / regularisation nets on the 2S observations of the tree (rnad.py:373-380 on every distinct input):
         learner and target in ONE launch per step, the two regularisation nets from _reg_tables.  Both regularisation tables are
         always there: a term of log_policy_reg (:382) whose weight is exactly 0 adds exactly 0.
@@ -527,8 +527,14 @@ class RNaD:
                 out = rnad_hip.mlp_rows_records(self.tree.handle(), packed, packed_target, self.net.width, table, logit_reg, logit_reg_,
                                                 records_hp, step_params=step_params, fold=self.tree.handle() if fold else False, rows=rows,
                                                 alloc_rows=per * self._world if shard else (table.shape[0] if dedup is not None else None))
-                if dedup is not None:  # every other row: a copy of its representative's records (the same bits the launch on all rows writes)
-                    rnad_hip.rows_expand(dedup, [out["fast_records"], out["policy_rows"], out["records"]])
+                if dedup is not None:
+                    # every other row: a copy of its representative's records (the same bits the launch on all rows writes) -- made by the
+                    # keys pass of the rollout that follows (rnad_rollout_bucketed_compact_expand), or right here when none does
+                    job = (dedup, [out["fast_records"], out["policy_rows"], out["records"]])
+                    if defer_expand and out["policy_rows"] is not None:
+                        out["records"]._expand = job
+                    else:
+                        rnad_hip.rows_expand(*job)
             tables = dict(table=table, logit=out["logit"], v=out["v"], logit_target=None, v_target=out["v_target"], logit_reg=logit_reg,
                           logit_reg_=logit_reg_, packed_net=packed, fold=fold, records=out["records"], fast_records=out["fast_records"],
                           dedup=dedup)
@@ -863,7 +869,12 @@ class RNaD:
             shard = self._shard_now(handle, local_batch, log, lazy)
             tables = self._table_outputs(alpha, getattr(self, "obs_half", False), want_target_logits=log is not None, fold=fold,
                                          records_hp=self._learn_params(alpha), step_params=step_params, shard=shard,
-                                         dedup=self._dedup_now(handle, log, lazy, shard, fold))
+                                         dedup=self._dedup_now(handle, log, lazy, shard, fold),
+                                         # (the compact rollout's keys pass carries the copies; any other rollout needs them made first)
+                                         defer_expand=(self.total_steps % self.buffer_mod == 0 and getattr(self, "compact_trajectory", True)
+                                                       and T_cap <= rnad_hip.COMPACT_MAX_STEPS and not self.reuse_actor_outputs
+                                                       and not getattr(self, "store_actor_values", False)
+                                                       and rnad_hip.bucket_plan(handle, local_batch) is not None))
         if self.total_steps % self.buffer_mod == 0:
             episodes = episode.Episodes(self.tree, local_batch, seed=self._new_seed(), lane_offset=rank * local_batch,
                                         obs_half=getattr(self, "obs_half", False))
@@ -881,6 +892,10 @@ class RNaD:
                               # normalisers are all-reduced beside the learner kernel, so they are needed before it
                               defer_alive=mode is True and log is None and not self._dp(),
                               staged_actor=tables.get("staged_actor") if (tables is not None and lazy) else None)
+            if tables is not None and getattr(tables.get("records"), "_expand", None) is not None:
+                # (the rollout took a path that does not carry the copies of the distinct-observation tables: make them now)
+                rnad_hip.rows_expand(*tables["records"]._expand)
+                tables["records"]._expand = None
             if lazy:
                 # the rows this batch went through are known now: value heads, records, gradient tables, backward on those only
                 assert episodes._compact is not None, "lazy rows need the compact bucketed rollout"

@@ -862,6 +862,7 @@ def rollout_bucketed_compact(tree, traj, table, seed=0, lane0=0, step_params=Non
     plan = bucket_plan(tree, traj.B)
     if plan is None:
         raise RnadHipError(lib().rnad_last_error().decode())
+    given = table  # (a records tensor may carry a pending rows_expand job: see below)
     pol_rows = getattr(table, "_policy_rows", None)
     if table_is_policy and column is None and pol_rows is not None:
         table, column = pol_rows, 0  # the same floats as the pi columns of the records, 16 bytes per row
@@ -872,6 +873,31 @@ def rollout_bucketed_compact(tree, traj, table, seed=0, lane0=0, step_params=Non
     buckets = Buckets(plan, traj.device)
     _complete_pending(tree, plan)
     base = _dp(table, F32, "table")
+    pending = getattr(given, "_expand", None) if table_is_policy else None
+    if pending is not None:
+        # distinct observations: the tables hold their representatives' rows only -- the copies to the other rows ride in the keys pass
+        dedup, tabs = pending
+        tabs = [t for t in tabs if t is not None]
+        ptrs = (C.c_void_p * len(tabs))(*[_dp(t, F32, "table").value for t in tabs])
+        widths = (C.c_int32 * len(tabs))(*[int(t.shape[1]) for t in tabs])
+        _check(lib().rnad_rollout_bucketed_compact_expand(
+            tree.ptr, traj.T_cap, traj.B, C.c_void_p(base.value + 4 * column), table.shape[1], int(table_is_policy), seed, lane0,
+            _dp(step_params, torch.int64, "step_params", True), _dp(plan.scratch, I32, "scratch"), _dp(buckets.lane_ids, I32, "lane_ids"),
+            _dp(buckets.items, I32, "items"), _dp(buckets.n_items, I32, "n_items"), _dp(buckets.norm, F64, "norm"),
+            _dp(traj.states, traj.states.dtype, "states"), None if defer_alive else _dp(traj.alive, I32, "alive"),
+            _dp(traj.acts, torch.int64, "acts"), _dp(traj.final_reward, F32, "final_reward"), _dp(visited, I32, "visited", True),
+            _dp(dedup.rep_of, I32, "rep_of"), len(tabs), ptrs, widths, _stream()))
+        given._expand = None
+    else:
+        _rollout_compact_plain(tree, traj, table, base, column, table_is_policy, seed, lane0, step_params, plan, buckets, defer_alive, visited)
+    buckets.alive_pending = traj if defer_alive else None
+    plan._pending = buckets if defer_alive else None
+    traj._owner = (tree, buckets)
+    traj.invalidate()
+    return buckets
+
+
+def _rollout_compact_plain(tree, traj, table, base, column, table_is_policy, seed, lane0, step_params, plan, buckets, defer_alive, visited):
     _check(lib().rnad_rollout_bucketed_compact(tree.ptr, traj.T_cap, traj.B, C.c_void_p(base.value + 4 * column), table.shape[1],
                                                int(table_is_policy), seed, lane0, _dp(step_params, torch.int64, "step_params", True),
                                                _dp(plan.scratch, I32, "scratch"), _dp(buckets.lane_ids, I32, "lane_ids"),
@@ -880,11 +906,6 @@ def rollout_bucketed_compact(tree, traj, table, seed=0, lane0=0, step_params=Non
                                                None if defer_alive else _dp(traj.alive, I32, "alive"),
                                                _dp(traj.acts, torch.int64, "acts"), _dp(traj.final_reward, F32, "final_reward"),
                                                _dp(visited, I32, "visited", True), _stream()))
-    buckets.alive_pending = traj if defer_alive else None
-    plan._pending = buckets if defer_alive else None
-    traj._owner = (tree, buckets)
-    traj.invalidate()
-    return buckets
 
 
 def _complete_pending(tree, plan, buckets=None):
