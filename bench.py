@@ -199,7 +199,8 @@ def main():
 
         def step():
             i = count["i"]
-            alpha = 1 if i > delta_m / 2 else i * 2 / delta_m
+            alpha = t.alpha_of(i, delta_m)  # rnad.py:497
+            t.alpha_ahead = lambda k: t.alpha_of(i + k, delta_m)  # (as RNaD.run does: the scalars of the coming steps are queued on the device)
             t.train_step(buf, alpha)
             t.total_steps += 1
             count["i"] = i + 1

@@ -432,10 +432,30 @@ typedef struct rnad_step_params {
     uint64_t seed;                  /* noise seed of the rollout (replaces the `seed` argument) */
     float alpha, one_minus_alpha;   /* rnad.py:497 (replace the fields of rnad_learn_params_t) */
 } rnad_step_params_t;
+/* Groups of (player, state) rows with the same observation, those of more than one row (csrc/rows_dedup.hip; rnad_hip.TreeHandle.obs_dedup):
+ * the rows of group g are order[start[g] .. start[g + 1]), ascending, the first of them its representative. */
+typedef struct rnad_row_groups {
+    int32_t n_groups;
+    const int32_t *start;   /* device int32 [n_groups + 1] */
+    const int32_t *order;   /* device int32 [start[n_groups]] */
+} rnad_row_groups_t;
 
 /* *device_params = {seed, alpha, one_minus_alpha}, enqueued on `stream` (the values travel as kernel arguments: safe to call again
  * before the GPU has consumed the previous values). */
 int rnad_step_params_set(rnad_step_params_t *device_params, uint64_t seed, float alpha, float one_minus_alpha, void *stream);
+/* The scalars of the NEXT steps, in device memory: a replayed step then needs no launch before it.  `live` is what the kernels of a
+ * step read (a rnad_step_queue_t* is passed wherever a rnad_step_params_t* device_params is expected); rnad_step_queue_set writes n
+ * entries (1 <= n <= RNAD_STEP_QUEUE, HOST array, copied at the call: they travel as kernel arguments), live = entries[0], cursor = 0;
+ * rnad_optimizer_step(..., advance = the queue) -- the last launch of a step -- moves on: cursor += 1, live = ahead[cursor] while
+ * cursor < n.  The caller keeps count: once it has replayed n steps, or when a step's scalars are not the ones it queued (a logging
+ * step in between took a seed; alpha left the schedule), it sets the queue again. */
+#define RNAD_STEP_QUEUE 32
+typedef struct rnad_step_queue {
+    rnad_step_params_t live;
+    int64_t cursor, n;
+    rnad_step_params_t ahead[RNAD_STEP_QUEUE];
+} rnad_step_queue_t;
+int rnad_step_queue_set(rnad_step_queue_t *device_queue, int n, const rnad_step_params_t *entries, void *stream);
 int rnad_bucket_plan(const rnad_tree_t *tree, int64_t B, int64_t *out);
 int rnad_bucket_map(const rnad_tree_t *tree, int64_t B, int32_t *bucket_of, int32_t *n_groups);
 /* n_shared[b] (host int32 [out[1] buckets]): the env steps a lane of bucket b shares with the whole bucket (above its group, plus the two
@@ -479,7 +499,13 @@ int rnad_bucket_records(const rnad_tree_t *tree, const float *logit_tab, const f
  *                         tables of floats_per_row[k] floats per row, multiples of 4, 16-byte aligned);
  *   rnad_rows_segment_sum after rnad_bucket_finish: for every group g with more than one row -- rows order[start[g] .. start[g + 1]),
  *                         ascending, the first its representative -- dlogit_tab / dv_tab of the representative <- the sums over the group
- *                         (one wave per group, a fixed reduction tree); the backward then runs on the representatives alone. */
+ *                         (one wave per group, a fixed reduction tree); the backward then runs on the representatives alone;
+ *   `groups` of rnad_bucket_finish / rnad_learn_bucketed_compact (optional) does the same inside k_bucket_finish: rows / n_rows then list the
+ *                         rows OUTSIDE the groups (the groups of one row), a wave per group converts and adds up its rows' int64 sums
+ *                         into dlogit_tab / dv_tab of the representative -- the bits of finish on all rows + rnad_rows_segment_sum -- and
+ *                         the table rows of the groups' other rows are not written.  The caller's promise: no row above the buckets
+ *                         (rnad_bucket_map: bucket_of >= n_groups) is in a group of more than one row (those rows' sums live in the
+ *                         replicas; rnad_hip.ObsDedup.groups_below_cut checks). */
 int rnad_rows_expand(int64_t rows, const int32_t *rep_of, int n_tables, float *const *tables, const int32_t *floats_per_row, void *stream);
 int rnad_rows_segment_sum(int n_groups, const int32_t *start, const int32_t *order, int A, float *dlogit_tab, float *dv_tab, void *stream);
 
@@ -510,7 +536,8 @@ int rnad_learn_bucketed_compact(const rnad_tree_t *tree, int T, int64_t B, const
                                 const float *final_reward, const float *fast_records, const float *records, const int32_t *items,
                                 const int32_t *n_items, const double *norm, const rnad_learn_params_t *hp, void *accumulators,
                                 double *losses, float *dlogit_tab, float *dv_tab, const int32_t *rows, const int64_t *n_rows,
-                                const void *rollout_scratch, int rollout_T_cap, int32_t *alive, double *norm_out, void *stream);
+                                const void *rollout_scratch, int rollout_T_cap, int32_t *alive, double *norm_out,
+                                const rnad_row_groups_t *groups, void *stream);
 int rnad_bucket_alive(const rnad_tree_t *tree, int T_cap, int64_t B, const void *scratch, int32_t *alive, double *norm, void *stream);
 /* rnad_rollout_bucketed_compact in two calls, for an actor that is evaluated in stages (trees that are large next to the batch):
  * rnad_bucket_sort = the keys pass + the sort; it reads the actor's rows of the UPPER states of the cut and of the absorbing state
@@ -548,7 +575,8 @@ int rnad_bucket_play(const rnad_tree_t *tree, int T_cap, int64_t B, const float 
                      void *scratch, const int32_t *lane_ids, const int32_t *items, const int32_t *n_items, double *norm, void *states,
                      int32_t *alive, uint64_t *acts, float *final_reward, int32_t *visited, int visited_is_clear, void *stream);
 int rnad_bucket_finish(const rnad_tree_t *tree, int64_t B, const double *norm, const rnad_learn_params_t *hp, void *accumulators,
-                       double *losses, float *dlogit_tab, float *dv_tab, const int32_t *rows, const int64_t *n_rows, void *stream);
+                       double *losses, float *dlogit_tab, float *dv_tab, const int32_t *rows, const int64_t *n_rows,
+                       const rnad_row_groups_t *groups, void *stream);
 
 /* torch.nn.utils.clip_grad_norm_(parameters, max_norm) of learn/rnad.py:456 over one flat fp32 gradient bucket (all of a net's
  * .grad tensors back to back): g *= min(max_norm / (||g||_2 + 1e-6), 1), in place, one launch.  total_norm: optional device
@@ -563,7 +591,8 @@ int rnad_clip_grad_norm(int64_t n, float *grads, float max_norm, float *total_no
  * mlp_A > 0 (with mlp_W, packed_param, packed_target; either image may be NULL): the 8 tensors are the fused MLP's Linear tensors in
  * the order rnad_mlp_pack takes them, and every new weight / new target weight is ALSO written into its slot of that net's packed
  * image (rnad_mlp_pack's layout; mlp_fold != 0: rnad_mlp_pack_fold_multi's) -- the images stay current without a pack launch per
- * step.  mlp_A == 0: none of this. */
+ * step.  mlp_A == 0: none of this.  advance (optional, device memory): see rnad_step_queue_t -- the workgroup that finishes last moves the
+ * queue of per-step scalars on. */
 typedef struct rnad_adam_params {
     float lr, beta1, beta2, eps;  /* rnad.py:232-237 */
     float max_norm;               /* grad_clip, rnad.py:456 */
@@ -571,7 +600,7 @@ typedef struct rnad_adam_params {
 } rnad_adam_params_t;
 int rnad_optimizer_step(int n_tensors, const int64_t *sizes, float *const *param, float *grads, float *const *exp_avg,
                         float *const *exp_avg_sq, float *const *step, float *const *target, const rnad_adam_params_t *hp,
-                        float *total_norm, int mlp_A, int mlp_W, int mlp_fold, float *packed_param, float *packed_target, void *stream);
+                        float *total_norm, int mlp_A, int mlp_W, int mlp_fold, float *packed_param, float *packed_target, rnad_step_queue_t *advance, void *stream);
 /* ------------------------------------------------------------------------------------------------
  * NashConv  --  util/metric.py:93-175 (NashConvData.get_nashconv), level-batched on the GPU
  * instead of one Python frame per state.  joint_policy f32 [S,2A] (device) for every state below

@@ -2118,7 +2118,9 @@ __global__ __launch_bounds__(kThreads) void k_bucket_finish(int64_t S, int row_b
                                                             const double *__restrict__ norm, float w_v, float w_n, FixedPoint fx,
                                                             int32_t *__restrict__ overflow, double *__restrict__ losses_raw,
                                                             double *__restrict__ losses, float *__restrict__ dlogit_tab,
-                                                            float *__restrict__ dv_tab) {
+                                                            float *__restrict__ dv_tab, int upper_blocks, int n_multi,
+                                                            const int32_t *__restrict__ multi_start,
+                                                            const int32_t *__restrict__ multi_order) {
     static_assert(kReplicas == 64, "one replica per lane");
     const float nf0 = norm_of(norm), nf1 = norm_of(norm + 1);
     const bool bad = *overflow != 0;
@@ -2161,6 +2163,49 @@ __global__ __launch_bounds__(kThreads) void k_bucket_finish(int64_t S, int row_b
 #pragma unroll
                 for (int a = 0; a < A; ++a) dlogit_tab[r[k] * A + a] = bad ? nan : w_n * ((float)((double)x[k][a] / fx.scale_l) / nf);
                 dv_tab[r[k]] = bad ? nan : w_v * ((float)((double)x[k][A] / fx.scale_v) / nf);
+            }
+        }
+    } else if ((int)blockIdx.x >= row_blocks + upper_blocks) {
+        // Rows with the same observation (csrc/rows_dedup.hip), groups of more than one row: a wave per group converts its rows like the
+        // threads above and adds them up into the table row of the group's representative -- lane l the rows l, l + 64, ... in that order,
+        // then one butterfly: operation for operation k_rows_segment_sum on the tables of a finish over all rows, without the tables.
+        const int g = ((int)blockIdx.x - row_blocks - upper_blocks) * (kThreads / 64) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+        if (g < n_multi) {
+            const int lo = multi_start[g], hi = multi_start[g + 1];
+            float sum[A + 1];
+#pragma unroll
+            for (int a = 0; a <= A; ++a) sum[a] = 0.0f;
+            for (int i0 = lo + lane; i0 < hi; i0 += 64 * kFinishRows) {  // kFinishRows rows per lane in flight, added in ascending order
+                int64_t r[kFinishRows];
+                long long x[kFinishRows][A + 1];
+#pragma unroll
+                for (int k = 0; k < kFinishRows; ++k) r[k] = i0 + 64 * k < hi ? (int64_t)multi_order[i0 + 64 * k] : -1;
+#pragma unroll
+                for (int k = 0; k < kFinishRows; ++k)
+#pragma unroll
+                    for (int a = 0; a <= A; ++a) x[k][a] = r[k] >= 0 ? (long long)acc[r[k] * (A + 1) + a] : 0ll;
+#pragma unroll
+                for (int k = 0; k < kFinishRows; ++k) {
+                    if (r[k] < 0) continue;
+#pragma unroll
+                    for (int a = 0; a <= A; ++a)
+                        if (x[k][a] != 0) acc[r[k] * (A + 1) + a] = 0ull;
+                    const float nf = r[k] >= S ? nf1 : nf0;
+#pragma unroll
+                    for (int a = 0; a < A; ++a) sum[a] += bad ? nan : w_n * ((float)((double)x[k][a] / fx.scale_l) / nf);
+                    sum[A] += bad ? nan : w_v * ((float)((double)x[k][A] / fx.scale_v) / nf);
+                }
+            }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+#pragma unroll
+                for (int a = 0; a <= A; ++a) sum[a] += __shfl_xor(sum[a], off, 64);
+            }
+            if (lane == 0) {
+                const int64_t r = multi_order[lo];
+#pragma unroll
+                for (int a = 0; a < A; ++a) dlogit_tab[r * A + a] = sum[a];
+                dv_tab[r] = sum[A];
             }
         }
     } else {
@@ -2315,7 +2360,29 @@ __global__ void k_step_params_set(rnad_step_params_t *dst, uint64_t seed, float 
     dst->alpha = alpha;
     dst->one_minus_alpha = one_minus_alpha;
 }
+
+struct QueueEntries {
+    rnad_step_params_t e[RNAD_STEP_QUEUE];
+};
+__global__ void k_step_queue_set(rnad_step_queue_t *q, int n, QueueEntries entries) {
+    const int k = threadIdx.x;
+    if (k < n) q->ahead[k] = entries.e[k];
+    if (k == 0) {
+        q->live = entries.e[0];
+        q->cursor = 0;
+        q->n = n;
+    }
+}
 }  // namespace
+
+extern "C" int rnad_step_queue_set(rnad_step_queue_t *device_queue, int n, const rnad_step_params_t *entries, void *stream) {
+    RNAD_REQUIRE(device_queue && entries && n >= 1 && n <= RNAD_STEP_QUEUE, "rnad_step_queue_set: 1..%d entries", RNAD_STEP_QUEUE);
+    QueueEntries q{};
+    for (int k = 0; k < n; ++k) q.e[k] = entries[k];
+    hipLaunchKernelGGL(k_step_queue_set, dim3(1), dim3(64), 0, (hipStream_t)stream, device_queue, n, q);
+    RNAD_HIP_OK(hipGetLastError());
+    return 0;
+}
 
 // The values travel as kernel arguments (copied at launch), so the host may call this again before the GPU has consumed the
 // previous step's values -- unlike an asynchronous copy from a host buffer that is about to be overwritten.
@@ -2728,7 +2795,8 @@ extern "C" int rnad_bucket_expand(const rnad_tree_t *tree, int T, int64_t B, con
 namespace {
 // upper rows out of their replicas, then sums -> normalised fp32 tables (and the two logged losses)
 int finish_impl(const rnad_tree_t *tree, const Plan &p, const double *norm, const rnad_learn_params_t *hp, void *accumulators, double *losses,
-                float *dlogit_tab, float *dv_tab, const int32_t *rows, const int64_t *n_rows, hipStream_t stream) {
+                float *dlogit_tab, float *dv_tab, const int32_t *rows, const int64_t *n_rows, const rnad_row_groups_t *groups,
+                hipStream_t stream) {
     const int64_t S = tree->S, A1 = tree->A + 1;
     unsigned long long *acc = (unsigned long long *)accumulators;
     unsigned long long *rep = acc + 2 * S * A1;
@@ -2736,12 +2804,18 @@ int finish_impl(const rnad_tree_t *tree, const Plan &p, const double *norm, cons
     double *losses_raw = (double *)(rep + (int64_t)kReplicas * 2 * std::max(nu, 1) * A1);
     int32_t *overflow = (int32_t *)(losses_raw + 4);
     const FixedPoint fx = fixed_point_for(*hp);
+    const int n_multi = groups ? groups->n_groups : 0;
+    RNAD_REQUIRE(n_multi >= 0 && (n_multi == 0 || (groups->start && groups->order && rows)),
+                 "rnad_bucket_finish: row groups come with their start / order arrays and with the list of the rows outside them");
     ProfScope fin(PROF_BUCKET_FINISH, stream);
     const unsigned row_blocks = std::min(blocks_for(2 * S, kThreads * kFinishRows), 512u), upper_blocks = nu > 0 ? blocks_for(2 * (int64_t)nu, kThreads / 64) : 0;
-    RNAD_DISPATCH_A(tree->A, hipLaunchKernelGGL((k_bucket_finish<kA>), dim3(row_blocks + upper_blocks), dim3(kThreads), 0, stream, S,
+    const unsigned group_blocks = n_multi > 0 ? blocks_for(n_multi, kThreads / 64) : 0;
+    RNAD_DISPATCH_A(tree->A, hipLaunchKernelGGL((k_bucket_finish<kA>), dim3(row_blocks + upper_blocks + group_blocks), dim3(kThreads), 0, stream, S,
                                                 (int)row_blocks, rows, n_rows, nu, p.cut->n_groups, (const int32_t *)p.cut->upper_list,
                                                 (const int32_t *)p.cut->bucket_of, acc, rep, norm, hp->w_v, hp->w_n, fx, overflow,
-                                                losses_raw, losses, dlogit_tab, dv_tab));
+                                                losses_raw, losses, dlogit_tab, dv_tab, (int)upper_blocks, n_multi,
+                                                n_multi ? groups->start : (const int32_t *)nullptr,
+                                                n_multi ? groups->order : (const int32_t *)nullptr));
     RNAD_HIP_OK(hipGetLastError());
     return 0;
 }
@@ -2750,7 +2824,8 @@ int learn_bucketed_impl(const rnad_tree_t *tree, int T, int64_t B, const void *i
                         const float *mu, const unsigned long long *acts, const float *final_reward, const float *records,
                         const float *fast, const int32_t *items, const int32_t *n_items, const double *norm, const rnad_learn_params_t *hp,
                         void *accumulators, double *losses, float *dlogit_tab, float *dv_tab, const int32_t *rows, const int64_t *n_rows,
-                        const void *rollout_scratch, int rollout_T_cap, int32_t *alive_out, double *norm_out, hipStream_t stream) {
+                        const void *rollout_scratch, int rollout_T_cap, int32_t *alive_out, double *norm_out, const rnad_row_groups_t *groups,
+                        hipStream_t stream) {
     const bool compact = acts != nullptr;  // (indices: the relative states then)
     Plan p;
     RNAD_REQUIRE(make_plan(tree, B, p), "rnad_learn_bucketed: this tree / batch cannot be bucketed (see rnad_bucket_plan)");
@@ -2800,7 +2875,7 @@ int learn_bucketed_impl(const rnad_tree_t *tree, int T, int64_t B, const void *i
 #undef RNAD_BUCKET_LEARN_C
     RNAD_HIP_OK(hipGetLastError());
     if (!norm) return 0;  // the caller completes the update with rnad_bucket_finish once the normalisers are known
-    return finish_impl(tree, p, norm, hp, accumulators, losses, dlogit_tab, dv_tab, rows, n_rows, stream);
+    return finish_impl(tree, p, norm, hp, accumulators, losses, dlogit_tab, dv_tab, rows, n_rows, groups, stream);
 }
 }  // namespace
 
@@ -2833,12 +2908,13 @@ extern "C" int rnad_bucket_pack_states(const rnad_tree_t *tree, int T1, int64_t 
 }
 
 extern "C" int rnad_bucket_finish(const rnad_tree_t *tree, int64_t B, const double *norm, const rnad_learn_params_t *hp, void *accumulators,
-                                  double *losses, float *dlogit_tab, float *dv_tab, const int32_t *rows, const int64_t *n_rows, void *stream) {
+                                  double *losses, float *dlogit_tab, float *dv_tab, const int32_t *rows, const int64_t *n_rows,
+                                  const rnad_row_groups_t *groups, void *stream) {
     RNAD_REQUIRE(tree && norm && hp && accumulators && dlogit_tab && dv_tab, "rnad_bucket_finish: null argument");
     RNAD_REQUIRE(!rows == !n_rows, "rnad_bucket_finish: rows and n_rows go together");
     Plan p;
     RNAD_REQUIRE(make_plan(tree, B, p), "rnad_bucket_finish: this tree / batch cannot be bucketed (see rnad_bucket_plan)");
-    return finish_impl(tree, p, norm, hp, accumulators, losses, dlogit_tab, dv_tab, rows, n_rows, (hipStream_t)stream);
+    return finish_impl(tree, p, norm, hp, accumulators, losses, dlogit_tab, dv_tab, rows, n_rows, groups, (hipStream_t)stream);
 }
 
 extern "C" int rnad_learn_bucketed(const rnad_tree_t *tree, int T, int64_t B, const int32_t *indices, const int32_t *actions,
@@ -2849,7 +2925,8 @@ extern "C" int rnad_learn_bucketed(const rnad_tree_t *tree, int T, int64_t B, co
                  "rnad_learn_bucketed: null argument");
     RNAD_REQUIRE(T >= 1 && B >= 1, "rnad_learn_bucketed: bad shape");
     return learn_bucketed_impl(tree, T, B, indices, actions, rewards, mu, nullptr, nullptr, records, nullptr, items, n_items, norm, hp,
-                               accumulators, losses, dlogit_tab, dv_tab, nullptr, nullptr, nullptr, 0, nullptr, nullptr, (hipStream_t)stream);
+                               accumulators, losses, dlogit_tab, dv_tab, nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr,
+                               (hipStream_t)stream);
 }
 
 extern "C" int rnad_learn_bucketed_compact(const rnad_tree_t *tree, int T, int64_t B, const void *states, const uint64_t *acts,
@@ -2857,7 +2934,7 @@ extern "C" int rnad_learn_bucketed_compact(const rnad_tree_t *tree, int T, int64
                                            const int32_t *items, const int32_t *n_items, const double *norm, const rnad_learn_params_t *hp,
                                            void *accumulators, double *losses, float *dlogit_tab, float *dv_tab, const int32_t *rows,
                                            const int64_t *n_rows, const void *rollout_scratch, int rollout_T_cap, int32_t *alive,
-                                           double *norm_out, void *stream) {
+                                           double *norm_out, const rnad_row_groups_t *groups, void *stream) {
     RNAD_REQUIRE(!rows == !n_rows, "rnad_learn_bucketed_compact: rows and n_rows go together");
     RNAD_REQUIRE(!rollout_scratch || (alive && rollout_T_cap >= T && rollout_T_cap <= kCompactSteps),
                  "rnad_learn_bucketed_compact: completing the rollout's alive counts needs `alive` and the rollout's T_cap");
@@ -2869,5 +2946,5 @@ extern "C" int rnad_learn_bucketed_compact(const rnad_tree_t *tree, int T, int64
     RNAD_REQUIRE(T >= 1 && T <= kCompactSteps && B >= 1, "rnad_learn_bucketed_compact: bad shape");
     return learn_bucketed_impl(tree, T, B, indices, nullptr, nullptr, nullptr, (const unsigned long long *)acts, final_reward, records,
                                fast_records, items, n_items, norm, hp, accumulators, losses, dlogit_tab, dv_tab, rows, n_rows,
-                               rollout_scratch, rollout_T_cap, alive, norm_out, (hipStream_t)stream);
+                               rollout_scratch, rollout_T_cap, alive, norm_out, groups, (hipStream_t)stream);
 }

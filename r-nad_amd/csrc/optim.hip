@@ -62,7 +62,8 @@ __device__ __forceinline__ int image_index(int k, int e, int A, int W, bool fold
 // backward kernels read, kept current here instead of by a k_mlp_pack launch per step.
 __global__ __launch_bounds__(kOptThreads) void k_optimizer_step(OptTensors ts, const float *__restrict__ grads, rnad_adam_params_t hp,
                                                                 float *__restrict__ total_norm, int mlp_A, int mlp_W, int mlp_fold,
-                                                                float *__restrict__ packed_param, float *__restrict__ packed_target) {
+                                                                float *__restrict__ packed_param, float *__restrict__ packed_target,
+                                                                rnad_step_queue_t *__restrict__ advance) {
     __shared__ double part[kOptThreads / 64];
     __shared__ float coef_s, step_size_s[kMaxTensors], bc2s_s[kMaxTensors];
     __shared__ float *ptr_s[4][kMaxTensors];
@@ -116,6 +117,11 @@ __global__ __launch_bounds__(kOptThreads) void k_optimizer_step(OptTensors ts, c
         if (atomicAdd(&g_ticket, 1u) == gridDim.x - 1) {
             g_ticket = 0;
             for (int t = 0; t < ts.n; ++t) *ts.step[t] += 1.0f;
+            if (advance) {  // the step is over: the scalars of the next one (every reader of `live` ran in an earlier launch)
+                const int64_t c = advance->cursor + 1;
+                advance->cursor = c;
+                if (c < advance->n) advance->live = advance->ahead[c];
+            }
         }
     }
     if (i >= n) return;
@@ -147,7 +153,7 @@ __global__ __launch_bounds__(kOptThreads) void k_optimizer_step(OptTensors ts, c
 extern "C" int rnad_optimizer_step(int n_tensors, const int64_t *sizes, float *const *param, float *grads, float *const *exp_avg,
                                    float *const *exp_avg_sq, float *const *step, float *const *target, const rnad_adam_params_t *hp,
                                    float *total_norm, int mlp_A, int mlp_W, int mlp_fold, float *packed_param, float *packed_target,
-                                   void *stream) {
+                                   rnad_step_queue_t *advance, void *stream) {
     RNAD_REQUIRE(sizes && param && grads && exp_avg && exp_avg_sq && step && hp, "rnad_optimizer_step: null argument");
     if (mlp_A > 0) {
         RNAD_REQUIRE(n_tensors == 8 && mlp_A <= RNAD_MAX_ACTIONS && mlp_W >= rnad_mlp::kTile && mlp_W % rnad_mlp::kTile == 0,
@@ -170,7 +176,7 @@ extern "C" int rnad_optimizer_step(int n_tensors, const int64_t *sizes, float *c
     const unsigned grid = (unsigned)std::max<int64_t>(1, (ts.offset[n_tensors] + kOptThreads - 1) / kOptThreads);
     RNAD_REQUIRE(!mlp_fold || mlp_A >= 2, "rnad_optimizer_step: the legal fold needs at least two actions");
     hipLaunchKernelGGL(k_optimizer_step, dim3(grid), dim3(kOptThreads), 0, (hipStream_t)stream, ts, (const float *)grads, *hp, total_norm, mlp_A,
-                       mlp_W, mlp_fold, mlp_A > 0 ? packed_param : nullptr, mlp_A > 0 ? packed_target : nullptr);
+                       mlp_W, mlp_fold, mlp_A > 0 ? packed_param : nullptr, mlp_A > 0 ? packed_target : nullptr, advance);
     RNAD_HIP_OK(hipGetLastError());
     return 0;
 }

@@ -166,6 +166,12 @@ class RNaD:
         # +-1).  Exact for the forward (same bits per row); the weight gradient is the same sum in another fp32 order.  Applied when it
         # removes at least a fifth of the rows; never on logging steps, lazy rows or row sharding.
         self.dedup_rows = True
+        # alpha_ahead(k): the alpha the caller will pass k steps from now (run() sets it from rnad.py:497's schedule); None: "as now".
+        # Only a prediction -- a replayed step whose scalars were not the queued ones sets them itself (_graph_step).
+        self.alpha_ahead = None
+        # ... added up by k_bucket_finish itself (the `groups` of rnad_bucket_finish) when no row above the cut shares its observation;
+        # False: always rnad_rows_segment_sum on the tables of a finish over all rows (the same bits, one launch more).
+        self.group_sums_in_finish = True
         # The legal fold (include/rnad_hip.h): on a tree whose observation rows all carry the same legal plane (all ones; e0 in the
         # absorbing state) the table evaluations of the per-row mode run the MLP with A^2 + 1 input features instead of 2 A^2 -- the
         # same function of the same weights in another summation order, ~45 % fewer matrix instructions in the first layer.
@@ -245,7 +251,16 @@ class RNaD:
             self._seed_base, self._seed_count = int(s.item()), 0
             return self._seed_base
         self._seed_count += 1
-        z = (self._seed_base + self._seed_count * 0x9E3779B97F4A7C15) & 0xFFFFFFFFFFFFFFFF  # splitmix64
+        return self._seed_at(self._seed_count)
+
+    @staticmethod
+    def alpha_of(n, delta_m):
+        """alpha of step n of an outer iteration of delta_m steps (rnad.py:497)."""
+        return 1 if n > delta_m / 2 else n * 2 / delta_m
+
+    def _seed_at(self, count):
+        """The count-th seed after the first (count >= 1): what _new_seed returns on its (count + 1)-th call."""
+        z = (self._seed_base + count * 0x9E3779B97F4A7C15) & 0xFFFFFFFFFFFFFFFF  # splitmix64
         z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & 0xFFFFFFFFFFFFFFFF
         z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & 0xFFFFFFFFFFFFFFFF
         return (z ^ (z >> 31)) & (2**62 - 1)
@@ -712,13 +727,19 @@ class RNaD:
             records = tables.get("records")
             if records is None:
                 records = rnad_hip.bucket_records(self.tree.handle(), logit, v, v_target, logit_reg, logit_reg_, hp)
+            dedup, grouped, rows_now = tables.get("dedup"), None, tables.get("rows")
             compact = getattr(episodes, "_compact", None)
             if compact is not None and compact[1] is records and tables.get("fast_records") is not None:
                 # the batch was played this very step with the pi columns of these records as the actor: 64 bytes per lane
+                if (dedup is not None and getattr(self, "group_sums_in_finish", True)
+                        and dedup.groups_below_cut(self.tree.handle(), episodes.buckets.plan)):
+                    # distinct observations: k_bucket_finish adds the rows of a group up into its representative's row -- no pass over
+                    # the gradient tables between finish and the backward
+                    grouped, rows_now = dedup, dedup.singles
                 dlogit, dv, losses = rnad_hip.learn_bucketed_compact(self.tree.handle(), episodes.buckets, compact[0], T, records,
                                                                      tables["fast_records"], None if late_norm else norm, hp,
-                                                                     want_losses=log is not None, rows=tables.get("rows"))
-                live = tables.get("rows")  # lazy rows: the backward runs on the visited rows only
+                                                                     want_losses=log is not None, rows=rows_now, groups=grouped)
+                live = rows_now  # lazy rows: the backward runs on the visited rows only
             else:
                 rnad_hip.bucket_alive(self.tree.handle(), episodes.buckets)  # (a no-op unless the rollout left its counts to a compact learner)
                 dlogit, dv, losses = rnad_hip.learn_bucketed(self.tree.handle(), episodes.buckets, episodes.indices[:T], episodes.action_idx[:T],
@@ -734,16 +755,16 @@ class RNaD:
             if late_norm:
                 norm_work.wait()
                 rnad_hip.bucket_finish(self.tree.handle(), episodes.buckets, norm, hp, dlogit, dv, losses,
-                                       rows=shard if shard is not None else tables.get("rows"))
+                                       rows=shard if shard is not None else rows_now, groups=grouped)
             if shard is not None:
                 plan.accumulators[: 2 * S_ * A1].zero_()  # (finish cleared the rows it read; the other ranks' rows still hold their sums)
                 live = shard
             if getattr(self, "keep_last_tables", False):  # (tests: the per-row gradient tables of this step)
                 self.last_tables = (dlogit.clone(), dv.clone(), shard)
-            dedup = tables.get("dedup") if shard is None else None
-            if dedup is not None:
+            if dedup is not None and shard is None:
                 # rows with the same observation: their dL/dlogit, dL/dv added up into the representative row; the backward on those
-                rnad_hip.rows_segment_sum(dedup, A, dlogit, dv)
+                if grouped is None:
+                    rnad_hip.rows_segment_sum(dedup, A, dlogit, dv)
                 live, capacity = dedup.uniq, dedup.n_unique
             pi = None
             backward_obs = table
@@ -908,7 +929,9 @@ class RNaD:
         fused_tail = self._fused_tail()
         self.__learn(episodes_sample, alpha, log=log, tables=tables, defer_clip=fused_tail is not None)
         if fused_tail is not None and self._pending_flat is not None:
-            fused_tail(self._pending_flat)  # clip + Adam + EMA target in one launch (csrc/optim.hip)
+            # clip + Adam + EMA target in one launch (csrc/optim.hip); a captured step also moves its queue of per-step scalars on
+            fused_tail(self._pending_flat, advance=step_params)
+            self._tail_advances = step_params is not None
             self._pending_flat = None
             self.optimizer.zero_grad()
             return
@@ -1005,14 +1028,28 @@ class RNaD:
             return self._step_body(buffer, alpha, None)
         seed = self._new_seed()
         if g["graph"] is None:
-            g["dev"] = torch.zeros((2,), dtype=torch.int64, device=self.device)
-        rnad_hip.step_params_set(g["dev"], seed, alpha)
+            g["dev"] = torch.zeros((rnad_hip.STEP_QUEUE_WORDS,), dtype=torch.int64, device=self.device)
+            g["ahead"], g["pos"], g["advances"], g["queue_sets"] = None, 0, False, 0
+        # The step's scalars (noise seed, alpha) are in device memory.  The captured optimiser launch moves a queue of them on at the end
+        # of every step (rnad_hip.step_queue_set), so a replay needs no launch of its own as long as this step's scalars are the ones
+        # queued for it: the seeds are a counter hash, the alphas come from the caller's schedule (alpha_ahead; else "as now").  Anything
+        # else -- a logging step in between took a seed, alpha left the prediction, the queue ran out -- sets the queue again.
+        entry = rnad_hip.step_entry(seed, alpha)
+        if not (g["ahead"] is not None and g["pos"] < len(g["ahead"]) and g["ahead"][g["pos"]] == entry):
+            ahead = getattr(self, "alpha_ahead", None)
+            n = rnad_hip.STEP_QUEUE if (g["advances"] or g["graph"] is None) else 1
+            g["ahead"] = [entry] + [rnad_hip.step_entry(self._seed_at(self._seed_count + k), alpha if ahead is None else ahead(k))
+                                    for k in range(1, n)]
+            g["pos"] = 0
+            g["queue_sets"] += 1
+            rnad_hip.step_queue_set(g["dev"], g["ahead"])
         # the regularisation nets are constant inside a captured step: refresh their tables (in place) when their weights changed
         self._reg_tables(self.tree.handle().observations_table(getattr(self, "obs_half", False)), self._fold())
         self._packed_images()  # (re-packed here, in place, if somebody edited net / net_target since the last step: no pack inside the graph)
         if g["graph"] is None:
             graph = torch.cuda.CUDAGraph()
             self._seed_override = seed  # the captured body (and an eager retry) must use THIS step's seed, not draw another
+            self._tail_advances = False
             ok = False
             import gc
 
@@ -1049,7 +1086,12 @@ class RNaD:
             self._seed_override = None
             g["graph"] = graph
             g["episodes"] = self.last_episodes
+            g["advances"] = self._tail_advances  # (the captured step ends in the fused optimiser launch)
         g["graph"].replay()
+        if g["advances"]:
+            g["pos"] += 1
+        else:
+            g["ahead"] = None
         # the replay rewrote the CAPTURED batch in place: an eager (logging) step in between left another Episodes object in
         # last_episodes and in the buffer
         ep = g["episodes"]
@@ -1087,7 +1129,8 @@ class RNaD:
                     dist.barrier()
 
             while self.n < delta_m:
-                alpha = 1 if self.n > delta_m / 2 else self.n * 2 / delta_m  # rnad.py:497
+                alpha = self.alpha_of(self.n, delta_m)
+                self.alpha_ahead = lambda k, n=self.n, d=delta_m: self.alpha_of(n + k, d)  # (what the next steps will ask for: _graph_step)
                 if self.n % checkpoint_mod == 0:
                     self.__save_checkpoint()
                 # the reference logs only with wandb on (rnad.py:509); keep_last_log asks for the same scalars in RNaD.last_log

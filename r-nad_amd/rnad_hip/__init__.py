@@ -216,12 +216,15 @@ class TreeHandle:
             counts = size[inverse[reps_multi]]
             start = torch.zeros((reps_multi.numel() + 1,), dtype=torch.int64, device=table.device)
             start[1:] = torch.cumsum(counts, 0)
-            got = type("ObsDedup", (), {})()
+            got = ObsDedup()
             got.n_rows, got.n_unique, got.n_multi = N, n_unique, int(reps_multi.numel())
+            got.singles = RowList(rows[~in_multi].to(I32), N, table.device)  # the rows that are groups of their own, ascending
+            got._in_multi = in_multi
             got.uniq = RowList(uniq_rows.to(I32), N, table.device)
             got.rep_of = rep_of.to(I32).contiguous()
             got.multi_start = start.to(I32).contiguous()
             got.multi_order = order.to(I32).contiguous()
+            got.c_groups = RowGroups(got.n_multi, got.multi_start.data_ptr(), got.multi_order.data_ptr())
             setattr(self, key, got)
         return got
 
@@ -237,6 +240,26 @@ class TreeHandle:
                 _destroy_deferred()
         except Exception:
             pass
+
+
+class RowGroups(C.Structure):
+    """struct rnad_row_groups (include/rnad_hip.h)."""
+
+    _fields_ = [("n_groups", C.c_int32), ("start", C.c_void_p), ("order", C.c_void_p)]
+
+
+class ObsDedup:
+    """TreeHandle.obs_dedup's result (fields there)."""
+
+    def groups_below_cut(self, tree, plan):
+        """May k_bucket_finish add the groups up (the `groups` of bucket_finish / learn_bucketed_compact)?  The sums of the rows above the
+        buckets travel through the replicas, so each of those rows must be a group of its own.  Checked once per batch size."""
+        known = self.__dict__.setdefault("_below_cut", {})
+        if plan.B not in known:
+            bucket_of, n_groups = bucket_map(tree, plan.B)
+            upper = torch.nonzero(bucket_of >= n_groups).reshape(-1).to(self._in_multi.device)
+            known[plan.B] = not bool(self._in_multi[torch.cat([upper, upper + tree.S])].any().item())
+        return known[plan.B]
 
 
 _deferred_destroy = []
@@ -1076,12 +1099,13 @@ def bucket_expand(tree, traj, records):
                                     _dp(traj.rewards, F32, "rewards"), _stream()))
 
 
-def learn_bucketed_compact(tree, buckets, traj, T, records, fast_records, norm, hp, want_losses=False, rows=None):
+def learn_bucketed_compact(tree, buckets, traj, T, records, fast_records, norm, hp, want_losses=False, rows=None, groups=None):
     """rnad_learn_bucketed_compact on the first T steps of a compact trajectory played with the pi columns of `records`;
     (records, fast_records) = bucket_records(..., fast=True).  rows: a LiveRows over the 2S rows -- only those rows of the gradient
-    tables are written (the batch visited no others)."""
+    tables are written (the batch visited no others).  groups: see bucket_finish."""
     B, A = traj.B, tree.A
     assert buckets.plan.B == B and traj.compact and 1 <= T <= traj.T_cap
+    rows, groups = _rows_and_groups(tree, buckets, rows, groups)
     assert rows is None or rows.N == 2 * tree.S
     dev = traj.device
     dlogit = torch.empty((2 * tree.S, A), dtype=F32, device=dev)
@@ -1097,7 +1121,7 @@ def learn_bucketed_compact(tree, buckets, traj, T, records, fast_records, norm, 
                                              _dp(buckets.n_items, I32, "n_items"), _dp(norm, F64, "norm", True), C.byref(hp),
                                              _dp(buckets.plan.accumulators, torch.int64, "accumulators"),
                                              _dp(losses, F64, "losses", True), _dp(dlogit, F32, "dlogit_tab"), _dp(dv, F32, "dv_tab"),
-                                             *_row_list(rows), *pending, _stream()))
+                                             *_row_list(rows), *pending, groups, _stream()))
     buckets.alive_pending = None
     return dlogit, dv, losses
 
@@ -1113,6 +1137,32 @@ def step_params_set(step_params, seed, alpha):
     """step_params (device int64 [2] = struct rnad_step_params) <- seed, alpha, 1 - alpha; enqueued on the current stream."""
     _check(lib().rnad_step_params_set(_dp(step_params, torch.int64, "step_params"), int(seed) & 0xFFFFFFFFFFFFFFFF, float(alpha),
                                       1.0 - float(alpha), _stream()))
+
+
+STEP_QUEUE = 32  # RNAD_STEP_QUEUE
+STEP_QUEUE_WORDS = 2 + 2 + 2 * STEP_QUEUE  # int64 words of a struct rnad_step_queue
+
+
+class StepParams(C.Structure):
+    """struct rnad_step_params (include/rnad_hip.h)."""
+
+    _fields_ = [("seed", C.c_uint64), ("alpha", C.c_float), ("one_minus_alpha", C.c_float)]
+
+
+def step_entry(seed, alpha):
+    """(seed, alpha, 1 - alpha) as the device will hold them: the two floats rounded to fp32 the way step_params_set passes them."""
+    e = StepParams(int(seed) & 0xFFFFFFFFFFFFFFFF, float(alpha), 1.0 - float(alpha))
+    return (e.seed, e.alpha, e.one_minus_alpha)
+
+
+def step_queue_set(queue, entries):
+    """queue (device int64 [STEP_QUEUE_WORDS] = struct rnad_step_queue) <- the scalars of the next len(entries) steps, entries =
+    [step_entry(seed, alpha), ...]; its first 16 bytes are the struct rnad_step_params the kernels read (pass `queue` as step_params),
+    and OptimizerStep(..., advance=queue) moves on to the next entry at the end of every step."""
+    n = len(entries)
+    assert 1 <= n <= STEP_QUEUE and queue.numel() >= STEP_QUEUE_WORDS
+    arr = (StepParams * n)(*[StepParams(*e) for e in entries])
+    _check(lib().rnad_step_queue_set(_dp(queue, torch.int64, "step_queue"), n, arr, _stream()))
 
 
 def policy_column(A):
@@ -1215,11 +1265,22 @@ def learn_bucketed(tree, buckets, indices, actions, rewards, mu, records, norm, 
     return dlogit, dv, losses
 
 
-def bucket_finish(tree, buckets, norm, hp, dlogit, dv, losses=None, rows=None):
-    """rnad_bucket_finish: completes a learn_bucketed / learn_bucketed_compact call that was made with norm=None."""
+def bucket_finish(tree, buckets, norm, hp, dlogit, dv, losses=None, rows=None, groups=None):
+    """rnad_bucket_finish: completes a learn_bucketed / learn_bucketed_compact call that was made with norm=None.  groups: an ObsDedup
+    with groups_below_cut(tree, buckets.plan) -- rows is then its `singles`, and the groups' sums end up in their representatives' rows."""
+    rows, groups = _rows_and_groups(tree, buckets, rows, groups)
     _check(lib().rnad_bucket_finish(tree.ptr, buckets.plan.B, _dp(norm, F64, "norm"), C.byref(hp),
                                     _dp(buckets.plan.accumulators, torch.int64, "accumulators"), _dp(losses, F64, "losses", True),
-                                    _dp(dlogit, F32, "dlogit_tab"), _dp(dv, F32, "dv_tab"), *_row_list(rows), _stream()))
+                                    _dp(dlogit, F32, "dlogit_tab"), _dp(dv, F32, "dv_tab"), *_row_list(rows), groups, _stream()))
+
+
+def _rows_and_groups(tree, buckets, rows, groups):
+    """(rows, pointer to the rnad_row_groups_t) of a finish that adds the groups of an ObsDedup up."""
+    if groups is None:
+        return rows, None
+    assert rows is None or rows is groups.singles, "with groups, the row list is the rows outside them"
+    assert groups.n_rows == 2 * tree.S and groups.groups_below_cut(tree, buckets.plan)
+    return groups.singles, C.byref(groups.c_groups)
 
 
 def clip_grad_norm(flat, max_norm):
@@ -1253,12 +1314,13 @@ class OptimizerStep:
         self.target = arr(targets, "target") if targets is not None else None
         self.hp = AdamParams(float(lr), float(beta1), float(beta2), float(eps), float(max_norm), float(ema))
 
-    def __call__(self, flat):
-        assert flat.numel() == self.numel
+    def __call__(self, flat, advance=None):
+        """advance: a step queue (step_queue_set) to move on once the step is over."""
+        assert flat.numel() == self.numel and (advance is None or advance.numel() >= STEP_QUEUE_WORDS)
         img = self.packed or (None, None)
         _check(lib().rnad_optimizer_step(self.n, self.sizes, self.param, _dp(flat, F32, "grads"), self.m, self.v, self.step, self.target,
                                          C.byref(self.hp), None, self.A, self.W, self.fold, _dp(img[0], F32, "packed_param", True),
-                                         _dp(img[1], F32, "packed_target", True), _stream()))
+                                         _dp(img[1], F32, "packed_target", True), _dp(advance, torch.int64, "advance", True), _stream()))
 
 
 def make_learn_params(alpha, eta, lambda_=1.0, c=1.0, rho=1.0, gamma=1.0, clip=1e3, threshold=2.0, w_v=1.0, w_n=1.0,

@@ -94,7 +94,7 @@ def test_segment_sum_adds_the_groups_up_reproducibly():
     assert torch.equal(outs[0][0][others], dl[others]), "rows that are not representatives are left alone"
 
 
-def _step(tree, dedup, use_graph=False, steps=1, want_grads=True):
+def _step(tree, dedup, use_graph=False, steps=1, want_grads=True, in_finish=True):
     from environment.episode import Buffer
     from learn.rnad import RNaD
 
@@ -103,7 +103,7 @@ def _step(tree, dedup, use_graph=False, steps=1, want_grads=True):
     rn = RNaD(tree=tree, device=DEV, directory_name="d", batch_size=1 << 14, eta=0.2, b1_adam=0.0, lr=1e-3,
               net_params={"type": "MLP", "max_actions": tree.max_actions, "width": 64})
     rn.initialize()
-    rn.dedup_rows, rn.use_graph, rn.keep_last_tables = dedup, use_graph, True
+    rn.dedup_rows, rn.use_graph, rn.keep_last_tables, rn.group_sums_in_finish = dedup, use_graph, True, in_finish
     grads = []
     if want_grads and not use_graph:
         rn.fused_optimizer = False
@@ -118,16 +118,30 @@ def _step(tree, dedup, use_graph=False, steps=1, want_grads=True):
 
 
 def test_default_step_with_and_without_dedup():
-    """Same episodes (the actor's policy rows are the same bits), the same per-row gradient tables bit for bit, the weight gradients equal
-    up to the order of the fp32 sums."""
+    """Same episodes (the actor's policy rows are the same bits).  The groups added up by rnad_rows_segment_sum after a finish over all
+    rows: the same per-row gradient tables bit for bit; added up inside k_bucket_finish: the same bits in the representatives' rows (the
+    only rows the backward reads).  The weight gradients are equal up to the order of the fp32 sums."""
     tree = _tree()
-    on, g_on = _step(tree, True)
     off, g_off = _step(tree, False)
-    assert on.last_episodes is not None and torch.equal(on.last_episodes.indices, off.last_episodes.indices)
-    assert torch.equal(on.last_tables[0], off.last_tables[0]) and torch.equal(on.last_tables[1], off.last_tables[1])
-    for a, b in zip(g_on[0], g_off[0]):
-        scale = b.abs().max().item() + 1e-12
-        np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=1e-4, atol=2e-6 * scale)
+    d = tree.handle().obs_dedup()
+    uniq = d.uniq.rows.long()
+    sums = [t.clone() for t in off.last_tables[:2]]
+    import rnad_hip as hip
+
+    hip.rows_segment_sum(d, tree.handle().A, *sums)
+    for in_finish in (False, True):
+        on, g_on = _step(tree, True, in_finish=in_finish)
+        assert on.last_episodes is not None and torch.equal(on.last_episodes.indices, off.last_episodes.indices)
+        if in_finish:
+            assert d.groups_below_cut(tree.handle(), on.last_episodes.buckets.plan), "this tree and batch let finish add the groups up"
+            assert torch.equal(on.last_tables[0][uniq], sums[0][uniq]) and torch.equal(on.last_tables[1][uniq], sums[1][uniq])
+        else:
+            assert torch.equal(on.last_tables[0], off.last_tables[0]) and torch.equal(on.last_tables[1], off.last_tables[1])
+        for a, b in zip(g_on[0], g_off[0]):
+            scale = b.abs().max().item() + 1e-12
+            np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=1e-4, atol=2e-6 * scale)
+        acc = on.last_episodes.buckets.plan.accumulators[: 2 * tree.handle().S * (tree.handle().A + 1)]
+        assert not acc.any(), "finish cleared every accumulator it read: zero again for the next update"
 
 
 def test_dedup_inside_the_captured_step_and_off_where_it_does_not_pay():

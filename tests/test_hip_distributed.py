@@ -171,6 +171,7 @@ def _sharded_step(tmp, tag, shard):
     rn.initialize()
     rn.shard_rows = shard
     rn.keep_last_tables = True
+    rn.group_sums_in_finish = False  # (the one-process step keeps its per-row tables: what the shards are compared with)
     rn.use_graph = False
     rn.train_step(Buffer(1), alpha=0.4)
     torch.cuda.synchronize()

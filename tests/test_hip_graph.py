@@ -10,7 +10,7 @@ DEV = torch.device("cuda:0")
 _BUFFERS = {}  # the replay buffer of each _run (the captured graph is bound to it)
 
 
-def _run(tree, tmp_path, use_graph, steps, rotate_at=None, tag=""):
+def _run(tree, tmp_path, use_graph, steps, rotate_at=None, tag="", schedule=None, log_at=()):
     import os
 
     from environment.episode import Buffer
@@ -32,7 +32,9 @@ def _run(tree, tmp_path, use_graph, steps, rotate_at=None, tag=""):
         if i == rotate_at:  # what __resume does between two regularisation updates (rnad.py:528-531)
             rn.net_reg_.load_state_dict(rn.net_reg.state_dict())
             rn.net_reg.load_state_dict(rn.net_target.state_dict())
-        rn.train_step(buf, alpha=min(1.0, 0.15 * i))
+        if schedule is not None:  # the caller announces its alphas, as RNaD.run does
+            rn.alpha_ahead = lambda k, i=i: schedule(i + k)
+        rn.train_step(buf, alpha=min(1.0, 0.15 * i) if schedule is None else schedule(i), log={} if i in log_at else None)
         rn.total_steps += 1
         seeds.append(rn.last_episodes.seed)
     torch.cuda.synchronize()
@@ -56,6 +58,30 @@ def test_graph_replay_equals_eager_steps(name, tmp_path):
     ep_e, ep_g = eager.last_episodes, graph.last_episodes
     assert torch.equal(ep_e.indices, ep_g.indices) and torch.equal(ep_e.policy, ep_g.policy) and torch.equal(ep_e.lane_ids, ep_g.lane_ids)
     assert np.isfinite(sum(float(p.abs().sum()) for p in nets_g))
+
+
+def test_replayed_steps_take_their_scalars_from_the_queue(tmp_path):
+    """The optimiser launch of a captured step moves a queue of (seed, alpha) on, so that a replay needs no launch before it -- as long as
+    the step's scalars are the queued ones.  Announced schedule: one queue per RNAD_STEP_QUEUE steps; a logging (eager) step in between
+    takes a seed of its own and the queue is set again; an alpha that was not announced: set again, every step.  Always the eager steps."""
+    import rnad_hip as hip
+    from test_hip_bucket import TREES, _native_tree
+
+    tree = _native_tree(**TREES["ternary4"])
+    steps = hip.STEP_QUEUE + 12
+    schedule = lambda i: 1 if i > 15 else i * 2 / 30  # noqa: E731  (rnad.py:497 with delta_m = 30)
+    eager, nets_e, seeds_e = _run(tree, tmp_path, False, steps, tag="q", schedule=schedule, log_at=(20,))
+    graph, nets_g, seeds_g = _run(tree, tmp_path, True, steps, tag="q", schedule=schedule, log_at=(20,))
+    g = graph._graph
+    assert g["graph"] is not None and not g["failed"] and g["advances"]
+    assert seeds_e == seeds_g
+    for a, b in zip(nets_e, nets_g):
+        assert torch.equal(a, b)
+    replays = steps - graph._GRAPH_WARMUP - 1  # (the logging step ran eagerly)
+    assert g["queue_sets"] == 2 + (replays - (20 - graph._GRAPH_WARMUP)) // hip.STEP_QUEUE, "at the capture, after the logging step, when it ran out"
+    # no announcement and a moving alpha: every replay sets its own scalars -- still the eager steps (test_graph_replay_equals_eager_steps)
+    moving, _, _ = _run(tree, tmp_path, True, 8, tag="m")
+    assert moving._graph["queue_sets"] == 8 - moving._GRAPH_WARMUP
 
 
 def test_many_replays_stay_finite(tmp_path):
