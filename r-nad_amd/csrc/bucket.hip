@@ -707,7 +707,8 @@ __global__ __launch_bounds__(kSortThreads) void k_bucket_keys_lds(const UpperWal
 // TOP levels that fit (BucketCut::hot_list: whole levels, root first; configs[3]: the root and its 100 children, 128 KB) are staged as in
 // k_bucket_keys_lds -- every lane passes through them, in lane order, i.e. with no locality a cache could use beyond one line per lane --
 // and a lane that walks on into an upper state below them continues on the global tables as k_bucket_keys does.  Same draws, same
-// arithmetic, same keys and decisions as both.  (The tile's histogram does not fit next to the tables: k_bucket_hist follows.)
+// arithmetic, same keys and decisions as both.  The tile's histogram does not fit NEXT to the tables, so it is built in their place once
+// the walk is over (every thread keeps the keys of its lanes): k_bucket_hist's work without its launch.
 inline size_t keys_hybrid_lds_bytes(int n_hot, int n_upper, int A, int C) {
     return (((size_t)n_hot * A * A * C * sizeof(UpperWalk) + 15) & ~(size_t)15) + (size_t)n_hot * 2 * ((A + 3) & ~3) * sizeof(float) +
            (size_t)n_upper * sizeof(int32_t);
@@ -722,9 +723,12 @@ __global__ __launch_bounds__(kSortThreads) void k_bucket_keys_hybrid(const Upper
                                                                      int key_root, int n_groups, uint64_t seed,
                                                                      const rnad_step_params_t *__restrict__ sp, int64_t lane0,
                                                                      int32_t *__restrict__ keys, unsigned long long *__restrict__ decisions,
-                                                                     double *__restrict__ norm, StageOut stage) {
+                                                                     double *__restrict__ norm, StageOut stage, int n_buckets,
+                                                                     int32_t *__restrict__ hist) {
     extern __shared__ __attribute__((aligned(16))) unsigned char keys_smem[];
     constexpr int PS = kPolStride<A>;
+    constexpr int kPasses = kSortLanes / (kSortThreads * L);
+    int my_keys[kPasses][L];
     const int AAC = A * A * C;
     UpperWalk *w = reinterpret_cast<UpperWalk *>(keys_smem);                                                           // [n_hot][A][A][C]
     float *pol = reinterpret_cast<float *>(keys_smem + (((size_t)n_hot * AAC * sizeof(UpperWalk) + 15) & ~(size_t)15));  // [n_hot][2][PS]
@@ -739,7 +743,8 @@ __global__ __launch_bounds__(kSortThreads) void k_bucket_keys_hybrid(const Upper
     if (blockIdx.x == 0 && threadIdx.x == 0 && stage.counts) stage.counts[0] = stage.counts[1] = 0ull;
     if (sp) seed = sp->seed;
     __syncthreads();
-    for (int pass = 0; pass < kSortLanes / (kSortThreads * L); ++pass) {
+#pragma unroll
+    for (int pass = 0; pass < kPasses; ++pass) {
         const int64_t b0 = (int64_t)blockIdx.x * kSortLanes + (int64_t)pass * (kSortThreads * L) + threadIdx.x;  // lanes b0 + l * kSortThreads
         int state[L], hot[L], key[L], steps[L];  // hot: position of the lane's upper state in the staged tables, or -1
         unsigned long long packed[L];
@@ -813,6 +818,7 @@ __global__ __launch_bounds__(kSortThreads) void k_bucket_keys_hybrid(const Upper
 #pragma unroll
         for (int l = 0; l < L; ++l) {
             const int64_t b = b0 + (int64_t)l * kSortThreads;
+            my_keys[pass][l] = b < B ? key[l] : -1;
             if (b < B) {
                 keys[b] = key[l];
                 decisions[b] = packed[l] | ((unsigned long long)min(steps[l], kPackedSteps) << 60);
@@ -824,6 +830,19 @@ __global__ __launch_bounds__(kSortThreads) void k_bucket_keys_hybrid(const Upper
             }
         }
     }
+    // the tile's histogram row, in the LDS the tables occupied
+    __syncthreads();
+    int32_t *cnt = reinterpret_cast<int32_t *>(keys_smem);
+    for (int i = threadIdx.x; i < n_buckets; i += kSortThreads) cnt[i] = 0;
+    __syncthreads();
+#pragma unroll
+    for (int pass = 0; pass < kPasses; ++pass)
+#pragma unroll
+        for (int l = 0; l < L; ++l)
+            if (my_keys[pass][l] >= 0) atomicAdd(&cnt[my_keys[pass][l]], 1);
+    __syncthreads();
+    int32_t *row = hist + (int64_t)blockIdx.x * n_buckets;
+    for (int i = threadIdx.x; i < n_buckets; i += kSortThreads) row[i] = cnt[i];
 }
 
 // ---------------------------------------------------------------------------------------- 2. stable counting sort by key
@@ -2513,7 +2532,8 @@ int rollout_bucketed_impl(const rnad_tree_t *tree, const RolloutBuffers &tr, boo
         } else if (p.cut->upper_walk && p.cut->n_hot > 0 && p.cut->n_hot < p.cut->n_upper && !walk_global &&
                    !(getenv("RNAD_KEYS_HYBRID") && atoi(getenv("RNAD_KEYS_HYBRID")) == 0)) {
             // the top levels of the upper states in LDS, the rest from the global tables
-            const size_t hyb_lds = keys_hybrid_lds_bytes(p.cut->n_hot, p.cut->n_upper, tree->A, tree->C);
+            const size_t hyb_lds = std::max(keys_hybrid_lds_bytes(p.cut->n_hot, p.cut->n_upper, tree->A, tree->C), (size_t)nb * sizeof(int32_t));
+            keys_with_hist = true;
             if (hyb_lds > 48 * 1024)
                 RNAD_DISPATCH_A(tree->A, RNAD_HIP_OK(hipFuncSetAttribute((const void *)k_bucket_keys_hybrid<kA, kPlayLds>,
                                                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)hyb_lds)));
@@ -2522,7 +2542,7 @@ int rollout_bucketed_impl(const rnad_tree_t *tree, const RolloutBuffers &tr, boo
                                                         (const int32_t *)p.cut->hot_list, (const int32_t *)p.cut->hot_of, p.cut->n_hot, p.cut->n_upper,
                                                         tree->trans, (const int32_t *)p.cut->bucket_of, tree->C, S, B, n_steps, policy_tab, policy_stride,
                                                         vec4, (int)p.cut->host_bucket_of[1], p.cut->n_groups, seed, device_params, lane0, s.keys,
-                                                        s.decisions, norm, stage));
+                                                        s.decisions, norm, stage, nb, s.hist));
         } else {
             RNAD_DISPATCH_A(tree->A, hipLaunchKernelGGL((k_bucket_keys<kA, kPlay>), dim3(blocks_for(B, kThreads * kPlay)), dim3(kThreads), 0, stream, tree->trans, tree->C,
                                                         S, B, n_steps, policy_tab, policy_stride, vec4, (const int32_t *)p.cut->bucket_of,

@@ -165,8 +165,8 @@ __global__ __launch_bounds__(kThreads) void k_count_alive(int64_t B, const int32
 
 // ---------------------------------------------------------------------------------------- live-row lists
 // rows[] = the positions r with indices[r] != 0, in increasing order, and their count -- so that the MLP kernels can skip the
-// (t, b) slots of absorbed episodes (ragged trees: rnad_mlp_forward_rows / rnad_mlp_backward_rows).  Three small launches:
-// per-chunk counts, one-block exclusive scan of the counts, ordered write.  The order is fixed (not an atomic append), which
+// (t, b) slots of absorbed episodes (ragged trees: rnad_mlp_forward_rows / rnad_mlp_backward_rows).  Small launches: per-chunk counts,
+// [beyond kCompactOwnPrefix chunks: a one-block exclusive scan of the counts,] ordered write.  The order is fixed (not an atomic append), which
 // keeps the weight-gradient sums of the backward pass reproducible.
 constexpr int kCompactRows = 8;                           // rows of kThreads elements per block
 constexpr int kCompactChunk = kCompactRows * kThreads;    // 2048 positions per block
@@ -225,9 +225,23 @@ __global__ __launch_bounds__(1024) void k_compact_scan(int nb, int32_t *__restri
     if (threadIdx.x == 0) *n_rows = carry_s;
 }
 
+// OWN_PREFIX: `offsets` still holds the per-chunk COUNTS and every workgroup adds up the counts of the chunks before its own (a few
+// loads per thread while there are at most kCompactOwnPrefix chunks) -- k_compact_scan's work without its launch; the last workgroup
+// writes the total.
+constexpr int kCompactOwnPrefix = 2048;
+template <bool OWN_PREFIX>
 __global__ __launch_bounds__(kThreads) void k_compact_write(int64_t N, const int32_t *__restrict__ indices,
-                                                            const int32_t *__restrict__ offsets, int32_t *__restrict__ rows) {
+                                                            const int32_t *__restrict__ offsets, int32_t *__restrict__ rows,
+                                                            int64_t *__restrict__ n_rows) {
     __shared__ int totals[kCompactRows][kThreads / 64];
+    __shared__ int prefix_s[kThreads / 64];
+    if (OWN_PREFIX) {
+        int sum = 0;
+        for (int b = threadIdx.x; b < (int)blockIdx.x; b += kThreads) sum += offsets[b];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) sum += __shfl_down(sum, off, 64);
+        if ((threadIdx.x & 63) == 0) prefix_s[threadIdx.x >> 6] = sum;
+    }
     const int64_t base = (int64_t)blockIdx.x * kCompactChunk;
     bool flag[kCompactRows];
     int rank[kCompactRows];
@@ -240,7 +254,14 @@ __global__ __launch_bounds__(kThreads) void k_compact_write(int64_t N, const int
         if ((threadIdx.x & 63) == 0) totals[j][threadIdx.x >> 6] = tot;
     }
     __syncthreads();
-    int before = offsets[blockIdx.x];
+    int before;
+    if (OWN_PREFIX) {
+        before = 0;
+#pragma unroll
+        for (int w = 0; w < kThreads / 64; ++w) before += prefix_s[w];
+    } else {
+        before = offsets[blockIdx.x];
+    }
 #pragma unroll
     for (int j = 0; j < kCompactRows; ++j) {
 #pragma unroll
@@ -249,6 +270,7 @@ __global__ __launch_bounds__(kThreads) void k_compact_write(int64_t N, const int
             before += totals[j][w];
         }
     }
+    if (OWN_PREFIX && blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) *n_rows = before;
 }
 
 __global__ void k_fill_i32(int64_t n, int32_t *p, int32_t v) {
@@ -410,8 +432,12 @@ extern "C" int rnad_compact_valid(int64_t N, const int32_t *indices, int32_t *ro
     }
     const int nb = (int)((N + kCompactChunk - 1) / kCompactChunk);
     hipLaunchKernelGGL(k_compact_count, dim3(nb), dim3(kThreads), 0, stream, N, indices, block_counts);
-    hipLaunchKernelGGL(k_compact_scan, dim3(1), dim3(1024), 0, stream, nb, block_counts, n_rows);
-    hipLaunchKernelGGL(k_compact_write, dim3(nb), dim3(kThreads), 0, stream, N, indices, block_counts, rows);
+    if (nb <= kCompactOwnPrefix) {
+        hipLaunchKernelGGL(k_compact_write<true>, dim3(nb), dim3(kThreads), 0, stream, N, indices, block_counts, rows, n_rows);
+    } else {
+        hipLaunchKernelGGL(k_compact_scan, dim3(1), dim3(1024), 0, stream, nb, block_counts, n_rows);
+        hipLaunchKernelGGL(k_compact_write<false>, dim3(nb), dim3(kThreads), 0, stream, N, indices, block_counts, rows, n_rows);
+    }
     RNAD_HIP_OK(hipGetLastError());
     return 0;
 }

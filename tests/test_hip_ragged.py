@@ -16,7 +16,8 @@ DEV = torch.device("cuda:0")
 
 
 @pytest.mark.parametrize("N,p", [(0, 0.5), (1, 1.0), (1, 0.0), (63, 0.5), (2047, 0.3), (2048, 0.9), (2049, 0.5), (5000, 0.0), (5000, 1.0),
-                                 (1_000_003, 0.4), (3 * 2048 * 1024 + 17, 0.05)])
+                                 (1_000_003, 0.4), (2048 * 2048, 0.2), (2048 * 2048 + 1, 0.2), (3 * 2048 * 1024 + 17, 0.05)])
+# (up to 2048 chunks of 2048 positions the ordered write adds up the chunk counts before its own itself; beyond, a scan launch does)
 def test_compact_valid_is_the_ascending_nonzero_list(N, p):
     import rnad_hip
 
