@@ -1367,7 +1367,7 @@ __device__ __forceinline__ REL rel_of(int state, int lo) {
 constexpr int kRolloutLanes = RNAD_ROLLOUT_LANES;
 
 template <int A, typename REL, int L>
-__global__ __launch_bounds__(kThreads / L) void k_bucket_rollout_items(const Trans *__restrict__ trans, int C, int64_t S, int64_t B, int T_cap,
+__device__ __forceinline__ void rollout_items_body(const Trans *__restrict__ trans, int C, int64_t S, int64_t B, int T_cap,
                                                                    const float *__restrict__ policy_tab, int64_t tab_stride, int vec4,
                                                                    uint64_t seed, const rnad_step_params_t *__restrict__ sp, int64_t lane0,
                                                                    const int32_t *__restrict__ lane_ids,
@@ -1377,14 +1377,17 @@ __global__ __launch_bounds__(kThreads / L) void k_bucket_rollout_items(const Tra
                                                                    const int32_t *__restrict__ path_states, int path_stride, int n_groups,
                                                                    REL *__restrict__ states, int32_t *__restrict__ alive_part,
                                                                    unsigned long long *__restrict__ acts_out,
-                                                                   float *__restrict__ reward_out, int32_t *__restrict__ visited) {
+                                                                   float *__restrict__ reward_out, int32_t *__restrict__ visited,
+                                                                   double *__restrict__ norm_rep = nullptr) {
     constexpr int NT = kThreads / L, NW = NT / 64;
     static_assert(NT >= 64 && NT > kCompactSteps, "a wave at least, and a thread per alive counter");
     __shared__ int32_t cnt[NW][kMaxSteps + 1];
-    int32_t *my_alive = alive_part + (int64_t)blockIdx.x * (T_cap + 1);  // (a row per WORKGROUP: the sum over the rows does not care which item it held)
+    // a row per WORKGROUP (the sum over the rows does not care which item it held) -- or, norm_rep given (k_bucket_play_learn: no launch
+    // between the rollout and the finish to add the rows up in), atomics into one of kReplicas rows of counts, which k_bucket_finish sums
+    int32_t *my_alive = alive_part + (norm_rep ? (int64_t)(blockIdx.x & (kReplicas - 1)) : (int64_t)blockIdx.x) * (T_cap + 1);
     const int my_item = xcd_item(*n_items);
     if (my_item < 0) {
-        if ((int)threadIdx.x <= T_cap) my_alive[threadIdx.x] = 0;
+        if (!norm_rep && (int)threadIdx.x <= T_cap) my_alive[threadIdx.x] = 0;
         return;
     }
     const Item item = items[my_item];
@@ -1536,8 +1539,34 @@ __global__ __launch_bounds__(kThreads / L) void k_bucket_rollout_items(const Tra
         int32_t sum = 0;
 #pragma unroll
         for (int w = 0; w < NW; ++w) sum += cnt[w][threadIdx.x];
-        my_alive[threadIdx.x] = sum;
+        if (!norm_rep) my_alive[threadIdx.x] = sum;
+        else if (sum != 0) atomicAdd(my_alive + threadIdx.x, sum);
+        if (norm_rep) cnt[0][threadIdx.x] = sum;  // (every wave's count of this step has been read: by this very thread)
     }
+    if (norm_rep) {  // N_P of the workgroup's lanes: the live slots of parity P (alive[T_cap]: after the last step, not a slot)
+        __syncthreads();
+        if (threadIdx.x < 2) {
+            int32_t n = 0;
+            for (int t = threadIdx.x; t < T_cap; t += 2) n += cnt[0][t];
+            if (n != 0) atomicAdd(norm_rep + 2 * (blockIdx.x & (kReplicas - 1)) + threadIdx.x, (double)n);
+        }
+    }
+}
+
+template <int A, typename REL, int L>
+__global__ __launch_bounds__(kThreads / L) void k_bucket_rollout_items(const Trans *__restrict__ trans, int C, int64_t S, int64_t B, int T_cap,
+                                                                   const float *__restrict__ policy_tab, int64_t tab_stride, int vec4,
+                                                                   uint64_t seed, const rnad_step_params_t *__restrict__ sp, int64_t lane0,
+                                                                   const int32_t *__restrict__ lane_ids,
+                                                                   const unsigned long long *__restrict__ decisions,
+                                                                   const Item *__restrict__ items, const int32_t *__restrict__ n_items,
+                                                                   const int32_t *__restrict__ bucket_path, const int32_t *__restrict__ bucket_lo,
+                                                                   const int32_t *__restrict__ path_states, int path_stride, int n_groups,
+                                                                   REL *__restrict__ states, int32_t *__restrict__ alive_part,
+                                                                   unsigned long long *__restrict__ acts_out,
+                                                                   float *__restrict__ reward_out, int32_t *__restrict__ visited) {
+    rollout_items_body<A, REL, L>(trans, C, S, B, T_cap, policy_tab, tab_stride, vec4, seed, sp, lane0, lane_ids, decisions, items, n_items,
+                                  bucket_path, bucket_lo, path_states, path_stride, n_groups, states, alive_part, acts_out, reward_out, visited);
 }
 
 // states (relative, bucket-ordered) <-> indices int32 [T1, B]: one workgroup per work item.
@@ -1618,6 +1647,28 @@ __device__ __forceinline__ void alive_column(int n_blocks, int T1, int t, const 
 __global__ __launch_bounds__(kThreads) void k_bucket_alive(int n_blocks, int T1, const int32_t *__restrict__ alive_part,
                                                            int32_t *__restrict__ alive, double *__restrict__ norm) {
     alive_column(n_blocks, T1, blockIdx.x, alive_part, alive, norm);
+}
+
+// The counts k_bucket_play_learn left in kReplicas rows: alive[t], norm[P] (integers: the same bits in any order); clears the rows.
+__device__ __forceinline__ void alive_from_replicas(int T1, int32_t *__restrict__ alive_rep, double *__restrict__ norm_rep,
+                                                    int32_t *__restrict__ alive, double *__restrict__ norm) {
+    if ((int)threadIdx.x < T1) {
+        int32_t x = 0;
+        for (int c = 0; c < kReplicas; ++c) x += alive_rep[c * T1 + threadIdx.x];
+        alive[threadIdx.x] = x;
+    }
+    if (threadIdx.x >= 64 && threadIdx.x < 66) {
+        double x = 0.0;
+        for (int c = 0; c < kReplicas; ++c) x += norm_rep[2 * c + (threadIdx.x - 64)];
+        norm[threadIdx.x - 64] = x;
+    }
+}
+__global__ __launch_bounds__(kThreads) void k_bucket_alive_rep(int T1, int32_t *__restrict__ alive_rep, double *__restrict__ norm_rep,
+                                                               int32_t *__restrict__ alive, double *__restrict__ norm) {
+    alive_from_replicas(T1, alive_rep, norm_rep, alive, norm);
+    __syncthreads();
+    for (int i = threadIdx.x; i < kReplicas * T1; i += kThreads) alive_rep[i] = 0;
+    if (threadIdx.x < 2 * kReplicas) norm_rep[threadIdx.x] = 0.0;
 }
 
 // ---------------------------------------------------------------------------------------- 4. learner
@@ -1958,7 +2009,7 @@ __global__ __launch_bounds__(kThreads) void k_bucket_learn(int T, int64_t B, int
 #define RNAD_LEARN_ATTR
 #endif
 template <int A, typename REL, bool LOSSES>
-__global__ __launch_bounds__(kThreads) RNAD_LEARN_ATTR void k_bucket_learn_c(int T, int64_t B, int64_t S, int sub_rows, int path_words, int n_groups, int up_stride,
+__device__ __forceinline__ void learn_c_body(int T, int64_t B, int64_t S, int sub_rows, int path_words, int n_groups, int up_stride,
                                                              const Item *__restrict__ items, const int32_t *__restrict__ n_items,
                                                              const int32_t *__restrict__ bucket_of, const int32_t *__restrict__ bucket_lo,
                                                              const int32_t *__restrict__ bucket_path, const int32_t *__restrict__ path_states,
@@ -2122,6 +2173,48 @@ __global__ __launch_bounds__(kThreads) RNAD_LEARN_ATTR void k_bucket_learn_c(int
                       loss_part, acc, rep, losses_raw, overflow);
 }
 
+template <int A, typename REL, bool LOSSES>
+__global__ __launch_bounds__(kThreads) RNAD_LEARN_ATTR void k_bucket_learn_c(int T, int64_t B, int64_t S, int sub_rows, int path_words, int n_groups, int up_stride,
+                                                             const Item *__restrict__ items, const int32_t *__restrict__ n_items,
+                                                             const int32_t *__restrict__ bucket_of, const int32_t *__restrict__ bucket_lo,
+                                                             const int32_t *__restrict__ bucket_path, const int32_t *__restrict__ path_states,
+                                                             int path_stride, const REL *__restrict__ states, const float *__restrict__ rec_,
+                                                             const unsigned long long *__restrict__ acts_,
+                                                             const float *__restrict__ reward_, const float *__restrict__ logit_,
+                                                             rnad_learn_params_t hp, FixedPoint fx, unsigned long long *__restrict__ acc,
+                                                             unsigned long long *__restrict__ rep, double *__restrict__ losses_raw,
+                                                             int32_t *__restrict__ overflow, const int32_t *__restrict__ alive_part,
+                                                             int alive_blocks, int T1, int32_t *__restrict__ alive,
+                                                             double *__restrict__ norm_out) {
+    learn_c_body<A, REL, LOSSES>(T, B, S, sub_rows, path_words, n_groups, up_stride, items, n_items, bucket_of, bucket_lo, bucket_path, path_states,
+                                 path_stride, states, rec_, acts_, reward_, logit_, hp, fx, acc, rep, losses_raw, overflow, alive_part,
+                                 alive_blocks, T1, alive, norm_out);
+}
+
+// Rollout and learner of a work item in ONE launch (r04): the workgroup that played the item's lanes runs their update right away --
+// thread k reads back what it wrote itself (states, packed actions, reward of lane item.begin + k: program order, no fence), so the
+// trajectory is the one k_bucket_rollout_items leaves and the sums are the ones k_bucket_learn_c adds up, bit for bit.  What it buys is
+// a launch floor and the overlap of the rollout's gather latency with the learner's arithmetic across the workgroups of a CU
+// (tools/micro/overlap_probe.py: the two kernels side by side on two streams take 80 us where back to back they take 95).
+// The alive counts and the normalisers go, with atomics, into one of kReplicas rows each (alive_rep, norm_rep: behind the learner's
+// accumulators, zero between updates); k_bucket_finish -- or k_bucket_alive_rep, when the finish is the caller's -- adds the rows up,
+// hands alive[] / norm[] out and clears them.
+template <int A, typename REL>
+__global__ __launch_bounds__(kThreads) RNAD_LEARN_ATTR void k_bucket_play_learn(
+    const Trans *__restrict__ trans, int C, int64_t S, int64_t B, int T_cap, const float *__restrict__ policy_tab, int64_t tab_stride, int vec4,
+    uint64_t seed, const rnad_step_params_t *__restrict__ sp, int64_t lane0, const int32_t *__restrict__ lane_ids,
+    const unsigned long long *__restrict__ decisions, const Item *__restrict__ items, const int32_t *__restrict__ n_items,
+    const int32_t *__restrict__ bucket_path, const int32_t *__restrict__ bucket_lo, const int32_t *__restrict__ path_states, int path_stride,
+    int n_groups, REL *states, int32_t *__restrict__ alive_rep, double *__restrict__ norm_rep, unsigned long long *acts, float *reward,
+    int sub_rows, int path_words, int up_stride, const int32_t *__restrict__ bucket_of, const float *__restrict__ rec_, rnad_learn_params_t hp,
+    FixedPoint fx, unsigned long long *__restrict__ acc, unsigned long long *__restrict__ rep, int32_t *__restrict__ overflow) {
+    rollout_items_body<A, REL, 1>(trans, C, S, B, T_cap, policy_tab, tab_stride, vec4, seed, sp, lane0, lane_ids, decisions, items, n_items,
+                                  bucket_path, bucket_lo, path_states, path_stride, n_groups, states, alive_rep, acts, reward, nullptr, norm_rep);
+    learn_c_body<A, REL, false>(T_cap, B, S, sub_rows, path_words, n_groups, up_stride, items, n_items, bucket_of, bucket_lo, bucket_path,
+                                path_states, path_stride, states, rec_, acts, reward, nullptr, hp, fx, acc, rep, nullptr, overflow, nullptr, 0,
+                                T_cap + 1, nullptr, nullptr);
+}
+
 // acc -> fp32 tables, normalised: dlogit_tab[P * S + s] = w_n * (G_l / N_P), dv_tab likewise with w_v (learn/vtrace.py:374,389;
 // rnad.py:424).  Clears what it read, so that the accumulators are zero again for the next update.  An addend beyond the
 // fixed-point range poisons the tables with NaN instead of passing silently.
@@ -2139,9 +2232,27 @@ __global__ __launch_bounds__(kThreads) void k_bucket_finish(int64_t S, int row_b
                                                             double *__restrict__ losses, float *__restrict__ dlogit_tab,
                                                             float *__restrict__ dv_tab, int upper_blocks, int n_multi,
                                                             const int32_t *__restrict__ multi_start,
-                                                            const int32_t *__restrict__ multi_order) {
+                                                            const int32_t *__restrict__ multi_order, int32_t *__restrict__ alive_rep,
+                                                            double *__restrict__ norm_rep, int T1, int32_t *__restrict__ alive_out,
+                                                            double *__restrict__ norm_out) {
     static_assert(kReplicas == 64, "one replica per lane");
-    const float nf0 = norm_of(norm), nf1 = norm_of(norm + 1);
+    // norm_rep given (after k_bucket_play_learn): the normalisers are still spread over kReplicas rows -- lane c reads row c, the wave adds
+    // them up (integers below 2^53: exact in any order, the bits of k_bucket_alive's sums); workgroup 0 also hands alive[] / norm[] out
+    float nf0, nf1;
+    if (norm_rep) {
+        double n0 = norm_rep[2 * (threadIdx.x & 63)], n1 = norm_rep[2 * (threadIdx.x & 63) + 1];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            n0 += __shfl_xor(n0, off, 64);
+            n1 += __shfl_xor(n1, off, 64);
+        }
+        nf0 = norm_of(&n0);
+        nf1 = norm_of(&n1);
+        if (blockIdx.x == 0) alive_from_replicas(T1, alive_rep, norm_rep, alive_out, norm_out);
+    } else {
+        nf0 = norm_of(norm);
+        nf1 = norm_of(norm + 1);
+    }
     const bool bad = *overflow != 0;
     const float nan = __uint_as_float(0x7fc00000u);
     if (blockIdx.x == 0 && threadIdx.x == 0 && losses) {
@@ -2248,6 +2359,8 @@ __global__ __launch_bounds__(kThreads) void k_bucket_finish(int64_t S, int row_b
             }
         }
     }
+    __shared__ int last_s;
+    if (threadIdx.x == 0) last_s = 0;
     __syncthreads();  // this workgroup's reads of the flag and the loss sums are complete
     if (threadIdx.x == 0) {
         // (no __threadfence: a device-scope release writes the XCD's L2 back -- 22 us here -- and nothing this workgroup wrote is read
@@ -2265,7 +2378,15 @@ __global__ __launch_bounds__(kThreads) void k_bucket_finish(int64_t S, int row_b
                 *overflow = 0;
 #pragma unroll
                 for (int u = 0; u < 4; ++u) losses_raw[u] = 0.0;
+                last_s = 1;
             }
+        }
+    }
+    if (norm_rep) {  // the rows of counts are zero again for the next update (every workgroup has read them: it took its ticket afterwards)
+        __syncthreads();
+        if (last_s) {
+            for (int i = threadIdx.x; i < kReplicas * T1; i += kThreads) alive_rep[i] = 0;
+            if (threadIdx.x < 2 * kReplicas) norm_rep[threadIdx.x] = 0.0;
         }
     }
 }
@@ -2312,7 +2433,9 @@ extern "C" int rnad_bucket_plan(const rnad_tree_t *tree, int64_t B, int64_t *out
                   2 * tree->S * ((tree->A + 3) & ~3)) + 256;
     // accumulators of the learner (bytes, must be zero before the first update): acc [2S][A+1] u64 | rep [64][2][n_upper][A+1] u64 |
     // losses_raw [4] f64 | overflow [1] i32
-    out[6] = 8 * (2 * tree->S * A1 + (int64_t)kReplicas * 2 * std::max(nu, 1) * A1 + 4) + 16 + 4 * kTicketGroups;  // sums | loss sums | flag, ticket | group tickets
+    // | norm_rep [64][2] f64 | alive_rep [64][kCompactSteps + 1] i32 (the counts of rnad_rollout_learn_bucketed_compact)
+    out[6] = 8 * (2 * tree->S * A1 + (int64_t)kReplicas * 2 * std::max(nu, 1) * A1 + 4) + 16 + 4 * kTicketGroups +  // sums | loss sums | flag, ticket | group tickets
+             8 * 2 * kReplicas + 4 * kReplicas * (kCompactSteps + 1);
     out[7] = p.lds;
     out[8] = p.rel_bytes;
     return 0;
@@ -2461,13 +2584,43 @@ struct RolloutBuffers {  // the dense trajectory (rnad_traj_t) or the compact on
 // non-empty group), 3 = both.  A caller that splits them (rnad_bucket_sort / rnad_bucket_play) evaluates its actor in stages:
 // the upper rows, then -- once the sort has shown which groups the batch descends into (group_flags) -- the rows of those groups.
 // play_rows / n_play_rows (phase 2 of a split call with a logits table): the rows that were evaluated for it.
+struct CountReps {  // where k_bucket_play_learn leaves the alive counts and the normalisers (behind the tickets of the accumulators)
+    double *norm_rep = nullptr;
+    int32_t *alive_rep = nullptr;
+    int T1 = 0;
+    int32_t *alive_out = nullptr;
+    double *norm_out = nullptr;
+};
+struct FusedLearn {  // the learner of the batch in the rollout's launch (k_bucket_play_learn): what k_bucket_learn_c needs beyond the rollout's arguments
+    const float *fast;
+    const rnad_learn_params_t *hp;
+    void *accumulators;
+};
+CountReps count_reps(const rnad_tree_t *tree, const Plan &p, void *accumulators, int T1, int32_t *alive_out, double *norm_out) {
+    const int64_t A1 = tree->A + 1;
+    unsigned long long *rep = (unsigned long long *)accumulators + 2 * tree->S * A1;
+    double *losses_raw = (double *)(rep + (int64_t)kReplicas * 2 * std::max(p.cut->n_upper, 1) * A1);
+    int32_t *overflow = (int32_t *)(losses_raw + 4);
+    CountReps c;
+    c.norm_rep = (double *)(overflow + 2 + kTicketGroups);  // (8-byte aligned: kTicketGroups is even)
+    c.alive_rep = (int32_t *)(c.norm_rep + 2 * kReplicas);
+    c.T1 = T1;
+    c.alive_out = alive_out;
+    c.norm_out = norm_out;
+    return c;
+}
+
+int finish_impl(const rnad_tree_t *tree, const Plan &p, const double *norm, const rnad_learn_params_t *hp, void *accumulators, double *losses,
+                float *dlogit_tab, float *dv_tab, const int32_t *rows, const int64_t *n_rows, const rnad_row_groups_t *groups,
+                hipStream_t stream, const CountReps *counts = nullptr);
+
 int rollout_bucketed_impl(const rnad_tree_t *tree, const RolloutBuffers &tr, bool compact, const float *table, int64_t table_stride,
                           int table_is_policy, const float *value_table, int64_t value_stride, uint64_t seed, int64_t lane0,
                           const rnad_step_params_t *device_params, void *scratch, int32_t *lane_ids, int32_t *items, int32_t *n_items,
                           double *norm, hipStream_t stream, int phases = 3, int32_t *group_flags = nullptr,
                           const int32_t *play_rows = nullptr, const int64_t *n_play_rows = nullptr, int32_t *staged_rows = nullptr,
                           int64_t *n_staged = nullptr, bool visited_is_clear = false, void *stage_buf = nullptr, int32_t *stage_rows0 = nullptr,
-                          const KeysExpand *expand = nullptr) {
+                          const KeysExpand *expand = nullptr, const FusedLearn *fused = nullptr) {
     Plan p;
     RNAD_REQUIRE(make_plan(tree, tr.B, p), "rnad_rollout_bucketed: this tree / batch cannot be bucketed (see rnad_bucket_plan)");
     const int64_t B = tr.B, S = tree->S;
@@ -2585,6 +2738,32 @@ int rollout_bucketed_impl(const rnad_tree_t *tree, const RolloutBuffers &tr, boo
         if (compact) {
             RNAD_REQUIRE(items && n_items, "rnad_rollout_bucketed_compact: the work list of the sort is needed to play");
             alive_n = (int)p.max_items;
+            if (fused) {
+                const int64_t A1 = tree->A + 1;
+                unsigned long long *acc = (unsigned long long *)fused->accumulators;
+                unsigned long long *rep = acc + 2 * S * A1;
+                const int nu = p.cut->n_upper;
+                double *losses_raw = (double *)(rep + (int64_t)kReplicas * 2 * std::max(nu, 1) * A1);
+                int32_t *overflow = (int32_t *)(losses_raw + 4);
+                const FixedPoint fx = fixed_point_for(*fused->hp);
+                const CountReps cr = count_reps(tree, p, fused->accumulators, tr.T_cap + 1, nullptr, nullptr);
+                RNAD_REQUIRE(!fx.check_l, "rnad_rollout_learn_bucketed_compact: a NeuRD clip of 2^29 or more takes the two-launch path");
+                RNAD_REQUIRE(!tr.visited, "rnad_rollout_learn_bucketed_compact: no visited flags (lazy rows evaluate their records after the rollout)");
+#define RNAD_PLAY_LEARN()                                                                                                              \
+    do {                                                                                                                               \
+        auto kern = k_bucket_play_learn<kA, REL>;                                                                                      \
+        if (p.lds > 48 * 1024) RNAD_HIP_OK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, p.lds)); \
+        hipLaunchKernelGGL(kern, dim3((unsigned)p.max_items), dim3(kThreads), (size_t)p.lds, stream, tree->trans, tree->C, S, B, tr.T_cap, \
+                           policy_tab, policy_stride, vec4, seed, device_params, lane0, (const int32_t *)lane_ids,                     \
+                           (const unsigned long long *)s.decisions, (const Item *)items, (const int32_t *)n_items,                     \
+                           (const int32_t *)p.cut->bucket_path, (const int32_t *)p.cut->bucket_lo, (const int32_t *)p.cut->path_states, \
+                           std::max(p.cut->max_path, 1), p.cut->n_groups, (REL *)tr.indices, cr.alive_rep, cr.norm_rep, tr.acts,       \
+                           tr.final_reward, p.cut->rows, p.path_words, std::max(nu, 1), (const int32_t *)p.cut->bucket_of, fused->fast, *fused->hp, fx, \
+                           acc, rep, overflow);                                                                                        \
+    } while (0)
+                RNAD_DISPATCH_REL(p, RNAD_DISPATCH_A(tree->A, RNAD_PLAY_LEARN()));
+#undef RNAD_PLAY_LEARN
+            } else
             RNAD_DISPATCH_REL(p, RNAD_DISPATCH_A(tree->A, hipLaunchKernelGGL(
                                      (k_bucket_rollout_items<kA, REL, kRolloutLanes>), dim3((unsigned)p.max_items), dim3(kThreads / kRolloutLanes), 0, stream, tree->trans, tree->C,
                                      S, B, tr.T_cap, policy_tab, policy_stride, vec4, seed, device_params, lane0, (const int32_t *)lane_ids,
@@ -2597,7 +2776,7 @@ int rollout_bucketed_impl(const rnad_tree_t *tree, const RolloutBuffers &tr, boo
         }
 #undef RNAD_BUCKET_ROLLOUT
     }
-    if (tr.alive)  // (NULL: the caller lets rnad_learn_bucketed_compact add the counts up, or calls rnad_bucket_alive)
+    if (tr.alive && !fused)  // (NULL: the caller lets rnad_learn_bucketed_compact add the counts up, or calls rnad_bucket_alive)
         hipLaunchKernelGGL(k_bucket_alive, dim3(tr.T_cap + 1), dim3(kThreads), 0, stream, alive_n, tr.T_cap + 1, (const int32_t *)s.alive_part,
                            tr.alive, norm);
     RNAD_HIP_OK(hipGetLastError());
@@ -2755,6 +2934,58 @@ extern "C" int rnad_rollout_bucketed_compact_expand(const rnad_tree_t *tree, int
                                  nullptr, &ex);
 }
 
+// rnad_rollout_bucketed_compact(_expand) and rnad_learn_bucketed_compact of the batch it plays, T = T_cap, in one call: keys, sort, then
+// ONE launch in which every work item's workgroup plays its lanes and adds up their update (k_bucket_play_learn), then the alive
+// counts and -- finish != 0 -- rnad_bucket_finish with the batch's own normalisers (a data-parallel caller passes finish = 0, all-reduces
+// `norm` and calls rnad_bucket_finish itself).  The trajectory, the counts and the gradient tables are those of the two calls, bit for bit.
+extern "C" int rnad_rollout_learn_bucketed_compact(const rnad_tree_t *tree, int T_cap, int64_t B, const float *table, int64_t table_stride,
+                                                   uint64_t seed, int64_t lane0, const rnad_step_params_t *device_params, void *scratch,
+                                                   int32_t *lane_ids, int32_t *items, int32_t *n_items, double *norm, void *states,
+                                                   int32_t *alive, uint64_t *acts, float *final_reward, const int32_t *rep_of, int n_tables,
+                                                   float *const *tables, const int32_t *floats_per_row, const float *fast_records,
+                                                   const rnad_learn_params_t *hp, void *accumulators, int finish, float *dlogit_tab,
+                                                   float *dv_tab, const int32_t *rows, const int64_t *n_rows, const rnad_row_groups_t *groups,
+                                                   void *stream) {
+    RNAD_REQUIRE(tree && table && scratch && lane_ids && items && n_items && norm && states && alive && acts && final_reward && fast_records &&
+                     hp && accumulators,
+                 "rnad_rollout_learn_bucketed_compact: null argument");
+    RNAD_REQUIRE(T_cap >= 1 && T_cap <= kCompactSteps && B >= 1, "rnad_rollout_learn_bucketed_compact: 1 <= T_cap <= %d, got %d", kCompactSteps, T_cap);
+    RNAD_REQUIRE(table_stride >= tree->A, "rnad_rollout_learn_bucketed_compact: bad table stride");
+    RNAD_REQUIRE(((uintptr_t)fast_records & 15) == 0, "rnad_rollout_learn_bucketed_compact: fast_records must be 16-byte aligned");
+    RNAD_REQUIRE(!finish || (dlogit_tab && dv_tab), "rnad_rollout_learn_bucketed_compact: finish needs the gradient tables");
+    RNAD_REQUIRE(!rows == !n_rows, "rnad_rollout_learn_bucketed_compact: rows and n_rows go together");
+    RNAD_REQUIRE(n_tables >= 0 && n_tables <= 4 && (n_tables == 0 || (rep_of && tables && floats_per_row)),
+                 "rnad_rollout_learn_bucketed_compact: 0..4 tables to expand, with rep_of");
+    KeysExpand ex;
+    if (n_tables > 0) {
+        ex.rep_of = rep_of;
+        ex.rows = 2 * tree->S;
+        ex.n = n_tables;
+        for (int k = 0; k < n_tables; ++k) {
+            RNAD_REQUIRE(tables[k] && floats_per_row[k] > 0 && floats_per_row[k] % 4 == 0 && ((uintptr_t)tables[k] & 15) == 0,
+                         "rnad_rollout_learn_bucketed_compact: table %d must be 16-byte aligned with a row of a multiple of 4 floats", k);
+            ex.tab[k] = reinterpret_cast<float4 *>(tables[k]);
+            ex.quads[k] = floats_per_row[k] / 4;
+            ex.max_quads = std::max(ex.max_quads, ex.quads[k]);
+        }
+    }
+    const FusedLearn fused{fast_records, hp, accumulators};
+    const RolloutBuffers out{T_cap, B, states, nullptr, nullptr, nullptr, nullptr, nullptr, alive, (unsigned long long *)acts, final_reward, nullptr};
+    if (int rc = rollout_bucketed_impl(tree, out, true, table, table_stride, 1, nullptr, 1, seed, lane0, device_params, scratch, lane_ids, items,
+                                       n_items, norm, (hipStream_t)stream, 3, nullptr, nullptr, nullptr, nullptr, nullptr, false, nullptr, nullptr,
+                                       n_tables > 0 ? &ex : nullptr, &fused))
+        return rc;
+    Plan p;
+    RNAD_REQUIRE(make_plan(tree, B, p), "rnad_rollout_learn_bucketed_compact: this tree / batch cannot be bucketed (see rnad_bucket_plan)");
+    const CountReps cr = count_reps(tree, p, accumulators, T_cap + 1, alive, norm);
+    if (!finish) {  // the counts on their own: the caller all-reduces `norm` before its rnad_bucket_finish
+        hipLaunchKernelGGL(k_bucket_alive_rep, dim3(1), dim3(kThreads), 0, (hipStream_t)stream, cr.T1, cr.alive_rep, cr.norm_rep, alive, norm);
+        RNAD_HIP_OK(hipGetLastError());
+        return 0;
+    }
+    return finish_impl(tree, p, nullptr, hp, accumulators, nullptr, dlogit_tab, dv_tab, rows, n_rows, groups, (hipStream_t)stream, &cr);
+}
+
 // The dense buffers of a compact trajectory: slot (t, j) from indices[t, j] (and indices[t + 1, j] for the reward) alone.
 namespace {
 template <int A>
@@ -2816,7 +3047,7 @@ namespace {
 // upper rows out of their replicas, then sums -> normalised fp32 tables (and the two logged losses)
 int finish_impl(const rnad_tree_t *tree, const Plan &p, const double *norm, const rnad_learn_params_t *hp, void *accumulators, double *losses,
                 float *dlogit_tab, float *dv_tab, const int32_t *rows, const int64_t *n_rows, const rnad_row_groups_t *groups,
-                hipStream_t stream) {
+                hipStream_t stream, const CountReps *counts) {
     const int64_t S = tree->S, A1 = tree->A + 1;
     unsigned long long *acc = (unsigned long long *)accumulators;
     unsigned long long *rep = acc + 2 * S * A1;
@@ -2835,7 +3066,9 @@ int finish_impl(const rnad_tree_t *tree, const Plan &p, const double *norm, cons
                                                 (const int32_t *)p.cut->bucket_of, acc, rep, norm, hp->w_v, hp->w_n, fx, overflow,
                                                 losses_raw, losses, dlogit_tab, dv_tab, (int)upper_blocks, n_multi,
                                                 n_multi ? groups->start : (const int32_t *)nullptr,
-                                                n_multi ? groups->order : (const int32_t *)nullptr));
+                                                n_multi ? groups->order : (const int32_t *)nullptr, counts ? counts->alive_rep : (int32_t *)nullptr,
+                                                counts ? counts->norm_rep : (double *)nullptr, counts ? counts->T1 : 0,
+                                                counts ? counts->alive_out : (int32_t *)nullptr, counts ? counts->norm_out : (double *)nullptr));
     RNAD_HIP_OK(hipGetLastError());
     return 0;
 }

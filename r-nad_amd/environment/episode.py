@@ -283,7 +283,7 @@ class Episodes:
     # ---------------------------------------------------------------- episode.py:175-230
     def generate(self, net: torch.nn.Module, noise_action=None, noise_chance=None, max_steps=None, trim=True, keep_logits=False,
                  skip_absorbed=False, store_values=True, tabular=None, bucketed=False, logits_table=None, value_table=None, policy_table=None, step_params=None,
-                 compact=False, visited=None, defer_alive=False, staged_actor=None):
+                 compact=False, visited=None, defer_alive=False, staged_actor=None, learn=None):
         """Play the batch to the end with `net` as the actor.
 
         Nets exposing `forward_logits(obs) -> (logits [B,A], value [B,1])` (the MLP here) take the fast path: policy head,
@@ -324,7 +324,9 @@ class Episodes:
         the policy head of those logits and the caller attaches the records later.  visited (int32 [2S], compact only): receives a
         1 for every (player, state) row a live slot of the batch sits in.  defer_alive (compact, trim=False): the per-step alive
         counters and the loss normalisers are added up by the learner's launch (rnad_hip.learn_bucketed_compact) instead of by a
-        kernel of their own; reading `alive` or `valid_counts` before that completes them on the spot.  staged_actor (compact with
+        kernel of their own; reading `alive` or `valid_counts` before that completes them on the spot.  learn (compact with policy_table,
+        trim=False; a dict: fast_records, hp, norm_is_global, rows, groups): the batch's on-policy update is added up by the very launch
+        that plays it (rnad_hip.rollout_learn_bucketed_compact) and `_learned` carries its per-row gradient tables.  staged_actor (compact with
         logits_table; trees that are large next to the batch): a callable `f(rows)` that evaluates the actor's logits INTO
         logits_table on the given rnad_hip.LiveRows / RowList -- called twice: with the rows of the cut's upper states before the keys
         pass and the sort, then with the rows of the groups the batch turned out to descend into, before the rollout itself
@@ -364,7 +366,17 @@ class Episodes:
                 table, vtable = rnad_hip.mlp_forward(packed, net.width, handle.observations_table(self.obs_half), tree.max_actions,
                                                      want_value=store_values)
             defer_alive = bool(defer_alive) and compact and not trim
-            if compact and policy_table is not None:
+            self.__dict__.pop("_learned", None)
+            if compact and policy_table is not None and learn is not None and visited is None and not trim:
+                # rollout AND the on-policy update of the batch in one launch (rnad_rollout_learn_bucketed_compact): RNaD.__learn picks
+                # the per-row gradient tables up from `_learned` instead of launching the learner
+                self.buckets, dlogit, dv = rnad_hip.rollout_learn_bucketed_compact(
+                    handle, traj, policy_table[0], learn["fast_records"], learn["hp"], seed=self.seed, lane0=self.lane_offset,
+                    step_params=step_params, norm_is_global=learn.get("norm_is_global", True), rows=learn.get("rows"), groups=learn.get("groups"))
+                self._learned = dict(records=policy_table[0], dlogit=dlogit, dv=dv)
+                self.lane_ids = self.buckets.lane_ids
+                self._compact = (traj, policy_table[0])
+            elif compact and policy_table is not None:
                 self.buckets = rnad_hip.rollout_bucketed_compact(handle, traj, policy_table[0], seed=self.seed, lane0=self.lane_offset,
                                                                  step_params=step_params, visited=visited, defer_alive=defer_alive)
                 self.lane_ids = self.buckets.lane_ids

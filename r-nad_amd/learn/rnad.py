@@ -436,6 +436,10 @@ class RNaD:
             return "forward"
         return mode
 
+    def _fuse_now(self):
+        """RNaD.fuse_rollout_learner (default on; RNAD_FUSE_PLAY_LEARN=0 turns the default off): rollout and learner of the step in one launch."""
+        return bool(getattr(self, "fuse_rollout_learner", os.environ.get("RNAD_FUSE_PLAY_LEARN", "1") != "0"))
+
     def _learn_params(self, alpha):
         return rnad_hip.make_learn_params(
             alpha=alpha, eta=self.eta, lambda_=1.0, c=self.c_bar, rho=self.roh_bar, gamma=self.vtrace_gamma,
@@ -736,9 +740,20 @@ class RNaD:
                     # distinct observations: k_bucket_finish adds the rows of a group up into its representative's row -- no pass over
                     # the gradient tables between finish and the backward
                     grouped, rows_now = dedup, dedup.singles
-                dlogit, dv, losses = rnad_hip.learn_bucketed_compact(self.tree.handle(), episodes.buckets, compact[0], T, records,
-                                                                     tables["fast_records"], None if late_norm else norm, hp,
-                                                                     want_losses=log is not None, rows=rows_now, groups=grouped)
+                learned = episodes.__dict__.pop("_learned", None)
+                if learned is not None and learned["records"] is records and log is None and T == compact[0].T_cap:
+                    # the rollout's own launch added this batch's update up (Episodes.generate(learn=...), k_bucket_play_learn) and,
+                    # single process, finished it; data parallel: the finish below, once the normalisers are all-reduced
+                    dlogit, dv, losses = learned["dlogit"], learned["dv"], None
+                    if dlogit is None:
+                        S2 = 2 * self.tree.handle().S
+                        dlogit = torch.empty((S2, A), dtype=torch.float32, device=records.device)
+                        dv = torch.empty((S2, 1), dtype=torch.float32, device=records.device)
+                else:
+                    assert learned is None, "a batch whose update rode in its rollout can only be learned from as it was played"
+                    dlogit, dv, losses = rnad_hip.learn_bucketed_compact(self.tree.handle(), episodes.buckets, compact[0], T, records,
+                                                                         tables["fast_records"], None if late_norm else norm, hp,
+                                                                         want_losses=log is not None, rows=rows_now, groups=grouped)
                 live = rows_now  # lazy rows: the backward runs on the visited rows only
             else:
                 rnad_hip.bucket_alive(self.tree.handle(), episodes.buckets)  # (a no-op unless the rollout left its counts to a compact learner)
@@ -901,6 +916,19 @@ class RNaD:
                                         obs_half=getattr(self, "obs_half", False))
             # no host sync: trailing all-absorbed steps are masked by `valid`
             store_values = self.reuse_actor_outputs or getattr(self, "store_actor_values", False)
+            # rollout and learner in one launch (r04, RNaD.fuse_rollout_learner): the batch played here is the batch learned from -- a
+            # one-batch buffer refilled every step --, its records exist before the rollout (no lazy rows) and nothing is logged
+            learn_now = None
+            if (mode is True and not lazy and log is None and self._fuse_now() and self.buffer_mod == 1
+                    and getattr(buffer, "max_size", None) == 1 and tables.get("fast_records") is not None and not store_values
+                    and getattr(self, "compact_trajectory", True) and float(self.neurd_clip) < 2.0 ** 28):
+                plan = rnad_hip.bucket_plan(handle, local_batch)
+                dedup = tables.get("dedup")
+                grouped = (dedup if (dedup is not None and plan is not None and getattr(self, "group_sums_in_finish", True)
+                                     and dedup.groups_below_cut(handle, plan)) else None)
+                if plan is not None:
+                    learn_now = dict(fast_records=tables["fast_records"], hp=self._learn_params(alpha), norm_is_global=not self._dp(),
+                                     rows=grouped.singles if grouped is not None else tables.get("rows"), groups=grouped)
             episodes.generate(self.net, trim=False, keep_logits=self.reuse_actor_outputs,
                               skip_absorbed=getattr(self, "skip_absorbed", True) and not self.reuse_actor_outputs,
                               store_values=store_values, tabular=bool(mode), bucketed=mode is True,
@@ -912,7 +940,7 @@ class RNaD:
                               # single process: the learner's launch adds up the alive counts (one kernel less); data parallel: the
                               # normalisers are all-reduced beside the learner kernel, so they are needed before it
                               defer_alive=mode is True and log is None and not self._dp(),
-                              staged_actor=tables.get("staged_actor") if (tables is not None and lazy) else None)
+                              staged_actor=tables.get("staged_actor") if (tables is not None and lazy) else None, learn=learn_now)
             if tables is not None and getattr(tables.get("records"), "_expand", None) is not None:
                 # (the rollout took a path that does not carry the copies of the distinct-observation tables: make them now)
                 rnad_hip.rows_expand(*tables["records"]._expand)
@@ -1016,7 +1044,7 @@ class RNaD:
                 self.c_bar, self.roh_bar, self.vtrace_gamma, self.value_weight, self.neurd_weight, self.epsilon_threshold, self.n_discrete,
                 self.gamma_averaging, getattr(self, "obs_half", False), getattr(self, "store_actor_values", False), getattr(self, "fused_optimizer", True),
                 getattr(self, "compact_trajectory", True), getattr(self, "lazy_rows", None), os.environ.get("RNAD_BUCKET_ROWS"), os.environ.get("RNAD_BUCKET_CHUNK"),
-                getattr(self, "fold_legal", True))
+                getattr(self, "fold_legal", True), self._fuse_now())
 
     def _graph_step(self, buffer, alpha):
         g = getattr(self, "_graph", None)

@@ -920,6 +920,55 @@ def rollout_bucketed_compact(tree, traj, table, seed=0, lane0=0, step_params=Non
     return buckets
 
 
+def rollout_learn_bucketed_compact(tree, traj, records, fast_records, hp, seed=0, lane0=0, step_params=None, norm_is_global=True, rows=None,
+                                   groups=None):
+    """rnad_rollout_learn_bucketed_compact: rollout_bucketed_compact(records) and learn_bucketed_compact of the batch it plays (T = T_cap)
+    with ONE launch for rollout + learner -- the trajectory, traj.alive, buckets.norm and the per-row gradient tables of the two calls, bit
+    for bit.  records: bucket_records(..., fast=True)[0] (its policy rows are the actor; a pending rows_expand job rides in the keys pass).
+    norm_is_global=False (data parallel): stops before k_bucket_finish -- all-reduce buckets.norm, then bucket_finish(...).
+    Returns (buckets, dlogit, dv); the tables are None when the finish is left to the caller."""
+    assert traj.compact and traj.T_cap <= COMPACT_MAX_STEPS
+    plan = bucket_plan(tree, traj.B)
+    if plan is None:
+        raise RnadHipError(lib().rnad_last_error().decode())
+    table = getattr(records, "_policy_rows", None)
+    column = 0
+    if table is None:
+        table, column = records, policy_column(tree.A)
+    assert table.shape[0] == 2 * tree.S and table.shape[1] >= column + tree.A
+    buckets = Buckets(plan, traj.device)
+    _complete_pending(tree, plan)
+    rows, groups = _rows_and_groups(tree, buckets, rows, groups)
+    base = _dp(table, F32, "table")
+    pending = getattr(records, "_expand", None)
+    n_tabs, ptrs, widths, rep_of = 0, None, None, None
+    if pending is not None:
+        dedup, tabs = pending
+        tabs = [t for t in tabs if t is not None]
+        n_tabs = len(tabs)
+        ptrs = (C.c_void_p * n_tabs)(*[_dp(t, F32, "table").value for t in tabs])
+        widths = (C.c_int32 * n_tabs)(*[int(t.shape[1]) for t in tabs])
+        rep_of = _dp(dedup.rep_of, I32, "rep_of")
+    dev, A = traj.device, tree.A
+    dlogit = torch.empty((2 * tree.S, A), dtype=F32, device=dev) if norm_is_global else None
+    dv = torch.empty((2 * tree.S, 1), dtype=F32, device=dev) if norm_is_global else None
+    _check(lib().rnad_rollout_learn_bucketed_compact(
+        tree.ptr, traj.T_cap, traj.B, C.c_void_p(base.value + 4 * column), table.shape[1], seed, lane0,
+        _dp(step_params, torch.int64, "step_params", True), _dp(plan.scratch, I32, "scratch"), _dp(buckets.lane_ids, I32, "lane_ids"),
+        _dp(buckets.items, I32, "items"), _dp(buckets.n_items, I32, "n_items"), _dp(buckets.norm, F64, "norm"),
+        _dp(traj.states, traj.states.dtype, "states"), _dp(traj.alive, I32, "alive"), _dp(traj.acts, torch.int64, "acts"),
+        _dp(traj.final_reward, F32, "final_reward"), rep_of, n_tabs, ptrs, widths, _dp(fast_records, F32, "fast_records"), C.byref(hp),
+        _dp(plan.accumulators, torch.int64, "accumulators"), int(bool(norm_is_global)), _dp(dlogit, F32, "dlogit_tab", True),
+        _dp(dv, F32, "dv_tab", True), *_row_list(rows), groups, _stream()))
+    if pending is not None:
+        records._expand = None
+    buckets.alive_pending = None
+    plan._pending = None
+    traj._owner = (tree, buckets)
+    traj.invalidate()
+    return buckets, dlogit, dv
+
+
 def _rollout_compact_plain(tree, traj, table, base, column, table_is_policy, seed, lane0, step_params, plan, buckets, defer_alive, visited):
     _check(lib().rnad_rollout_bucketed_compact(tree.ptr, traj.T_cap, traj.B, C.c_void_p(base.value + 4 * column), table.shape[1],
                                                int(table_is_policy), seed, lane0, _dp(step_params, torch.int64, "step_params", True),

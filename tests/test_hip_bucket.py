@@ -776,3 +776,51 @@ def test_deferred_alive_counts_are_completed_by_the_learner_or_on_first_read(nam
     other = Episodes(tree, B, seed=5)
     other.generate(nets[0], **kw)
     assert torch.equal(second.alive, other.alive) and torch.equal(second.valid_counts, other.valid_counts)
+
+
+@pytest.mark.parametrize("rows", (None, 40, 8))
+@pytest.mark.parametrize("name", sorted(TREES))
+@pytest.mark.parametrize("B", (8192, 3000))
+def test_rollout_and_learner_in_one_launch(name, B, rows, monkeypatch):
+    """rnad_rollout_learn_bucketed_compact (k_bucket_play_learn: the workgroup of a work item plays its lanes and adds up their update)
+    against rnad_rollout_bucketed_compact + rnad_learn_bucketed_compact: the same trajectory, alive counts, normalisers and per-row
+    gradient tables, bit for bit -- at the planner's cut and at forced ones; also with the finish left to the caller (data parallel)."""
+    import rnad_hip
+
+    tree = _native_tree(**TREES[name])
+    h = tree.handle()
+    A = tree.max_actions
+    if rows is not None:
+        monkeypatch.setenv("RNAD_BUCKET_ROWS", str(rows))
+        if rnad_hip.bucket_plan(h, B) is None:
+            pytest.skip(f"a table of {rows} rows does not fit this tree")
+    nets = _four_nets(A, 64, seed=6)
+    logit, v, vt, lr, lr_ = _tables(tree, nets, A)
+    hp = rnad_hip.make_learn_params(alpha=0.3, eta=0.2, w_v=0.7, w_n=1.3)
+    rec, fast = rnad_hip.bucket_records(h, logit, v, vt, lr, lr_, hp, fast=True)
+    T_cap = 2 * h.max_depth
+
+    def traj():
+        return rnad_hip.Trajectory(h, B, T_cap, DEV, with_observations=False, with_values=False, compact=True)
+
+    two = traj()
+    bk2 = rnad_hip.rollout_bucketed_compact(h, two, rec, seed=21, lane0=77)
+    want = rnad_hip.learn_bucketed_compact(h, bk2, two, T_cap, rec, fast, bk2.norm, hp)
+    one = traj()
+    bk1, dlogit, dv = rnad_hip.rollout_learn_bucketed_compact(h, one, rec, fast, hp, seed=21, lane0=77)
+    assert torch.equal(bk1.lane_ids, bk2.lane_ids) and torch.equal(bk1.n_items, bk2.n_items)
+    n = int(bk1.n_items.item())
+    assert torch.equal(bk1.items[:n], bk2.items[:n])
+    assert torch.equal(one.alive, two.alive) and torch.equal(bk1.norm, bk2.norm)
+    assert torch.equal(one.acts, two.acts) and torch.equal(one.final_reward.view(torch.int32), two.final_reward.view(torch.int32))
+    assert torch.equal(one.indices, two.indices), "the states a lane went through (rebuilt from the relative states)"
+    assert torch.equal(dlogit, want[0]) and torch.equal(dv, want[1])
+    assert torch.isfinite(dlogit).all() and float(dlogit.abs().sum()) > 0
+    # the finish left to the caller
+    late = traj()
+    bk3, none_l, none_v = rnad_hip.rollout_learn_bucketed_compact(h, late, rec, fast, hp, seed=21, lane0=77, norm_is_global=False)
+    assert none_l is None and none_v is None
+    dl3 = torch.empty_like(dlogit)
+    dv3 = torch.empty_like(dv)
+    rnad_hip.bucket_finish(h, bk3, bk3.norm, hp, dl3, dv3)
+    assert torch.equal(dl3, want[0]) and torch.equal(dv3, want[1])
