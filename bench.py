@@ -308,6 +308,10 @@ def main():
             prof[k] = dict(name=nm, launches_per_step=n / EP, avg_launch_us=ms * 1e3 / n, us_per_step=ms * 1e3 / EP)
     rnad_hip.prof_enable(False)
     rn.use_graph = not args.no_graph
+    # rollout and learner in one launch (RNaD.fuse_rollout_learner, k_bucket_play_learn): booked under the learner's id, nothing under the rollout's
+    args.fused_play_learn = (mode_now is True and rnad_hip.PROF_BUCKET_LEARN in prof and rnad_hip.PROF_BUCKET_ROLLOUT not in prof)
+    if args.fused_play_learn:
+        prof[rnad_hip.PROF_BUCKET_LEARN]["name"] = "k_bucket_play_learn (rollout + learner of a work item in one launch)"
 
     # ---- the same step in the other net-evaluation modes of RNaD (reported separately, NOT `value`), eager
     variants = {}
@@ -438,6 +442,7 @@ def main():
             "net_evaluation": {"mode": f"RNaD.tabular = {default_mode!r}" + (" (default)" if args.net_mode == "default" else ""),
                                "in_effect": repr(mode_now), "what": what[mode_now],
                                "step_replayed_from_hipGraph": replayed, "compact_trajectory": bool(args.compact_in_effect),
+                               "rollout_and_learner_in_one_launch": bool(getattr(args, "fused_play_learn", False)),
                                "lazy_rows_visited": args.visited_rows or None, "staged_policy_rows": args.policy_rows or None,
                                "rows_after_dedup": args.unique_rows or None,  # (RNaD.dedup_rows: rows with distinct observation bits)
                                "legal_fold": args.fold,
@@ -547,6 +552,13 @@ def kernel_report(prof, A, C, args, B, T, live_slots, tree, mode_now):
                          "lane_ids 4 B/lane + per slot: state 4, legal bits 1, policy 4A, action 4, reward 4 (+ final state 4 B/lane)")
         learn_model = (live_slots * (4 + 4 + 4 * A) + (live_slots // 2) * 4,
                        "per live slot: state 4, action 4, acting policy 4A; reward 4 on column steps; sums stay in LDS")
+    fused = bool(getattr(args, "fused_play_learn", False)) and compact
+    if fused:
+        learn_model = (4 * B + stored * rb + B * (8 + 4) + S2 * fast,
+                       f"per lane: lane id 4 (read); per slot below the cut (and the final state): relative state {rb} (written: the trajectory "
+                       "the API hands out; read back by the thread that wrote it, from L2); per lane: packed actions 8, reward 4 (written); the 2S "
+                       "fast records (64 B at A = 3) once each -- gathered per slot below the cut from L2 / MALL, through the scalar cache for "
+                       "the steps a workgroup shares; policy rows and transition records from the L2-resident tables; sums stay in LDS")
     model = {
         # bytes the kernel must move per launch (streams; the L2-resident tables it gathers from are not HBM traffic)
         rh.PROF_BUCKET_ROLLOUT: ("hbm",) + rollout_model,
@@ -562,9 +574,10 @@ def kernel_report(prof, A, C, args, B, T, live_slots, tree, mode_now):
     # (the kernel a scope ran depends on the tree: LDS walk / global-table walk; compact / dense trajectory)
     pmc_name = {rh.PROF_BUCKET_KEYS: "k_bucket_keys_lds" if "k_bucket_keys_lds" in pmc else "k_bucket_keys",
                 rh.PROF_BUCKET_ROLLOUT: "k_bucket_rollout_items" if compact else "k_bucket_rollout",
-                rh.PROF_BUCKET_LEARN: "k_bucket_learn_c" if compact else "k_bucket_learn", rh.PROF_OBSERVE: "k_observe"}
-    mix_name = {rh.PROF_BUCKET_KEYS: f"k_bucket_keys_lds<{A}, 2>", rh.PROF_BUCKET_ROLLOUT: f"k_bucket_rollout_items<{A}, {rel}>",
-                rh.PROF_BUCKET_LEARN: f"k_bucket_learn_c<{A}, {rel}, false>"}
+                rh.PROF_BUCKET_LEARN: "k_bucket_play_learn" if fused else "k_bucket_learn_c" if compact else "k_bucket_learn",
+                rh.PROF_OBSERVE: "k_observe"}
+    mix_name = {rh.PROF_BUCKET_KEYS: f"k_bucket_keys_lds<{A}, 1>", rh.PROF_BUCKET_ROLLOUT: f"k_bucket_rollout_items<{A}, {rel}, 1>",
+                rh.PROF_BUCKET_LEARN: f"k_bucket_play_learn<{A}, {rel}>" if fused else f"k_bucket_learn_c<{A}, {rel}, false>"}
     units = {rh.PROF_BUCKET_KEYS: (B, "lane"), rh.PROF_BUCKET_ROLLOUT: (slots, "slot"), rh.PROF_BUCKET_LEARN: (max(live_slots, 1), "live slot")}
     for k, p in prof.items():
         e = dict(p)

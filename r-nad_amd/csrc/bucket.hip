@@ -1366,7 +1366,32 @@ __device__ __forceinline__ REL rel_of(int state, int lo) {
 #endif
 constexpr int kRolloutLanes = RNAD_ROLLOUT_LANES;
 
-template <int A, typename REL, int L>
+// What a thread of k_bucket_play_learn hands from its rollout to its update in registers (single-pass items: lane item.begin + thread):
+// the packed actions, the reward, the relative state of the last four stored transitions (16 bits each, the latest in the low bits) and
+// the state the episode ended in -- the values the update would otherwise read back from the trajectory it has just written.
+struct Hand {
+    unsigned long long acts, relq;
+    float reward;
+    int final_rel;
+};
+constexpr int kHandPairs = 4;
+
+// Distinct trajectories of a work item (k_bucket_play_learn).  A state has exactly one parent entry (ids are DFS pre-order), so the state a
+// lane was last alive in, together with the outcome it drew there -- (row action, column action, chance) into the absorbing state, or
+// "still in the tree after T_cap steps" -- fixes its whole trajectory: states, actions, reward.  Lanes of an item with the same key
+// therefore add the SAME addends to the same rows, and the update of the item is  sum over its distinct keys of  count x addends  -- in
+// 64-bit integers: the bits of the sum over the lanes.  The rollout counts the lanes per key in LDS and lists, for every key it sees
+// first, one lane that has it; the learner runs on the list.
+struct Distinct {  // (passed by value: a pointer to it would keep the struct in scratch memory)
+    int32_t *count = nullptr;   // LDS [rows of the group][A * A * C + 1]: lanes of the item per key (zero before the rollout); NULL: off
+    int32_t *n = nullptr;       // LDS: keys listed so far
+    int32_t *key = nullptr;     // LDS [capacity]: the listed keys ...
+    int32_t *column = nullptr;  // ... and the trajectory column (bucket order) of the lane that listed each
+    int codes = 0;              // A * A * C + 1
+    int keys = 0;               // counters; count[keys] stays 1: the weight of a lane listed on its own (a key outside the table: not expected)
+};
+
+template <int A, typename REL, int L, bool DISTINCT = false>
 __device__ __forceinline__ void rollout_items_body(const Trans *__restrict__ trans, int C, int64_t S, int64_t B, int T_cap,
                                                                    const float *__restrict__ policy_tab, int64_t tab_stride, int vec4,
                                                                    uint64_t seed, const rnad_step_params_t *__restrict__ sp, int64_t lane0,
@@ -1378,7 +1403,8 @@ __device__ __forceinline__ void rollout_items_body(const Trans *__restrict__ tra
                                                                    REL *__restrict__ states, int32_t *__restrict__ alive_part,
                                                                    unsigned long long *__restrict__ acts_out,
                                                                    float *__restrict__ reward_out, int32_t *__restrict__ visited,
-                                                                   double *__restrict__ norm_rep = nullptr) {
+                                                                   double *__restrict__ norm_rep = nullptr, Hand *hand = nullptr,
+                                                                   const Distinct distinct = Distinct{}) {
     constexpr int NT = kThreads / L, NW = NT / 64;
     static_assert(NT >= 64 && NT > kCompactSteps, "a wave at least, and a thread per alive counter");
     __shared__ int32_t cnt[NW][kMaxSteps + 1];
@@ -1426,11 +1452,14 @@ __device__ __forceinline__ void rollout_items_body(const Trans *__restrict__ tra
             for (int l = 0; l < L; ++l) packed[l] = active[l] ? decisions[lane_local[l]] : 0ull;
         }
         int state[L], n_packed[L], t_from = 0;
+        unsigned long long relq = 0ull;  // (hand: lane 0 of the thread)
+        int last_key[L];                 // (distinct: the key of the lane's trajectory, -1 while it is in the tree)
         unsigned long long acts[L];
         float reward_final[L];
 #pragma unroll
         for (int l = 0; l < L; ++l) {
             n_packed[l] = (int)(packed[l] >> 60);
+            last_key[l] = -1;
             state[l] = active[l] ? 1 : 0;
             acts[l] = 0ull;
             reward_final[l] = 0.0f;
@@ -1475,6 +1504,7 @@ __device__ __forceinline__ void rollout_items_body(const Trans *__restrict__ tra
                 go[l] = active[l];
                 if (go[l] && t >= n_shared) {  // (n_shared is even: both steps of the transition, or neither)
                     const REL r = rel_of<REL>(state[l], lo);
+                    if (hand && l == 0) relq = (relq << 16) | (unsigned long long)r;
                     *at_bytes<REL>(states, ((uint32_t)t * B32 + j[l]) * (uint32_t)sizeof(REL)) = r;
                     if (two) *at_bytes<REL>(states, ((uint32_t)(t + 1) * B32 + j[l]) * (uint32_t)sizeof(REL)) = r;
                 }
@@ -1511,13 +1541,18 @@ __device__ __forceinline__ void rollout_items_body(const Trans *__restrict__ tra
 #pragma unroll
                 for (int l = 0; l < L; ++l) {
                     if (!go[l]) continue;
-                    int next;
+                    int next, outcome;
                     float rew;
-                    if (replay1[l])
-                        transition_apply<A>(trans, C, state[l], a0[l], a1[l], bits1[l] >> 3, next, rew);
-                    else
-                        transition_lane<A>(trans, C, state[l], a0[l], a1[l], nullptr, u[l][2], next, rew);
-                    if (next == 0) reward_final[l] = rew;
+                    if (replay1[l]) {
+                        outcome = bits1[l] >> 3;
+                        transition_apply<A>(trans, C, state[l], a0[l], a1[l], outcome, next, rew);
+                    } else {
+                        transition_lane<A>(trans, C, state[l], a0[l], a1[l], nullptr, u[l][2], next, rew, &outcome);
+                    }
+                    if (next == 0) {
+                        reward_final[l] = rew;
+                        if (DISTINCT) last_key[l] = (state[l] - lo) * distinct.codes + (a0[l] * A + a1[l]) * C + outcome;
+                    }
                     state[l] = next;
                 }
             }
@@ -1533,6 +1568,20 @@ __device__ __forceinline__ void rollout_items_body(const Trans *__restrict__ tra
             live += (int32_t)__popcll(__ballot(state[l] != 0));
         }
         if ((threadIdx.x & 63) == 0) cnt[wave][T_cap] += live;
+        if (DISTINCT) {
+#pragma unroll
+            for (int l = 0; l < L; ++l) {
+                if (!active[l]) continue;
+                const int key = state[l] != 0 ? (state[l] - lo) * distinct.codes + distinct.codes - 1 : last_key[l];
+                const bool in_table = key >= 0 && key < distinct.keys;
+                if (!in_table || atomicAdd(distinct.count + key, 1) == 0) {  // the first lane with this trajectory lists it
+                    const int at = atomicAdd(distinct.n, 1);
+                    distinct.key[at] = in_table ? key : distinct.keys;
+                    distinct.column[at] = (int32_t)j[l];
+                }
+            }
+        }
+        if (hand) *hand = Hand{acts[0], relq, reward_final[0], active[0] ? (int)rel_of<REL>(state[0], lo) : 0};
     }
     __syncthreads();
     if ((int)threadIdx.x <= T_cap) {
@@ -2008,7 +2057,7 @@ __global__ __launch_bounds__(kThreads) void k_bucket_learn(int T, int64_t B, int
 #else
 #define RNAD_LEARN_ATTR
 #endif
-template <int A, typename REL, bool LOSSES>
+template <int A, typename REL, bool LOSSES, bool DISTINCT = false>
 __device__ __forceinline__ void learn_c_body(int T, int64_t B, int64_t S, int sub_rows, int path_words, int n_groups, int up_stride,
                                                              const Item *__restrict__ items, const int32_t *__restrict__ n_items,
                                                              const int32_t *__restrict__ bucket_of, const int32_t *__restrict__ bucket_lo,
@@ -2020,7 +2069,8 @@ __device__ __forceinline__ void learn_c_body(int T, int64_t B, int64_t S, int su
                                                              unsigned long long *__restrict__ rep, double *__restrict__ losses_raw,
                                                              int32_t *__restrict__ overflow, const int32_t *__restrict__ alive_part,
                                                              int alive_blocks, int T1, int32_t *__restrict__ alive,
-                                                             double *__restrict__ norm_out) {
+                                                             double *__restrict__ norm_out, const Hand *hand = nullptr,
+                                                             const Distinct distinct = Distinct{}) {
     extern __shared__ unsigned long long tab[];
     constexpr int PS = (A + 1) | 1, TS = kTabStride<A>, FS = kFastStride<A>, RS = kRowStride<A>;
     const int kPathWords = path_words;
@@ -2046,14 +2096,28 @@ __device__ __forceinline__ void learn_c_body(int T, int64_t B, int64_t S, int su
     const int t_low = min(T, n_shared);  // phase 2 covers [0, t_low), phase 1 [t_low, T)
     double part[4] = {0.0, 0.0, 0.0, 0.0};
     bool ovf = false;
-    for (int base = 0; base < item.count; base += kThreads) {
-        const bool active = base + (int)threadIdx.x < item.count;
-        const uint32_t j = (uint32_t)(item.begin + base) + threadIdx.x;
+    // distinct: one pass per kThreads listed trajectories, each weighted with the number of lanes that took it
+    constexpr bool by_trajectory = DISTINCT;
+    const int n_work = by_trajectory ? *distinct.n : item.count;
+    for (int base = 0; base < n_work; base += kThreads) {
+        const bool active = base + (int)threadIdx.x < n_work;
+        const uint32_t j = by_trajectory ? (uint32_t)(active ? distinct.column[base + threadIdx.x] : item.begin) : (uint32_t)(item.begin + base) + threadIdx.x;
+        const long long weight = by_trajectory ? (long long)(active ? distinct.count[distinct.key[base + threadIdx.x]] : 0) : 1ll;
         Carry cy[2];
-        const unsigned long long acts = active ? acts_[j] : 0ull;
-        const float reward_final = active ? reward_[j] : 0.0f;
+        // (k_bucket_play_learn, an item played in one pass: this thread's own values arrive in registers)
+        const bool handed = hand != nullptr && item.count <= kThreads;
+        const unsigned long long acts = handed ? hand->acts : active ? acts_[j] : 0ull;
+        const float reward_final = handed ? hand->reward : active ? reward_[j] : 0.0f;
+        const int last_pair = (T - 1) >> 1;
         // the state the last step of the window led to (rewards *= (indices == 0), episode.py:120-121: the step into state 0 pays)
-        auto state_at = [&](int t) { return (int)*at_bytes<REL>(states, ((uint32_t)t * B32 + j) * (uint32_t)sizeof(REL)); };
+        auto state_at = [&](int t) {
+            if (handed) {
+                if (t == T) return hand->final_rel;
+                const int k = last_pair - (t >> 1);
+                if (k < kHandPairs) return (int)((hand->relq >> (16 * k)) & 0xffffull);
+            }
+            return (int)*at_bytes<REL>(states, ((uint32_t)t * B32 + j) * (uint32_t)sizeof(REL));
+        };
         bool after_zero = active && (T < n_shared ? false : state_at(T) == 0);
         // ------------------------------------------------------------------ phase 1: per-lane states below the cut
         if (t_low < T && !(RNAD_ABLATE & 8)) {
@@ -2101,7 +2165,7 @@ __device__ __forceinline__ void learn_c_body(int T, int64_t B, int64_t S, int su
 #else
                     unsigned long long *dst = tab + kPathWords + ((t & 1) * sub_rows + (rel - 1)) * TS;
 #pragma unroll
-                    for (int a = 0; a <= A; ++a) atomicAdd(dst + a, (unsigned long long)q[a]);
+                    for (int a = 0; a <= A; ++a) atomicAdd(dst + a, (unsigned long long)(by_trajectory ? q[a] * weight : q[a]));
 #endif
                 } else {
                     cy[0] = Carry{};  // reset_carry (vtrace.py:320)
@@ -2148,7 +2212,7 @@ __device__ __forceinline__ void learn_c_body(int T, int64_t B, int64_t S, int su
 #else
                 unsigned long long *dst = tab + (t * kPathSlots + (threadIdx.x & (kPathSlots - 1))) * PS;
 #pragma unroll
-                for (int a = 0; a <= A; ++a) atomicAdd(dst + a, (unsigned long long)q[a]);
+                for (int a = 0; a <= A; ++a) atomicAdd(dst + a, (unsigned long long)(by_trajectory ? q[a] * weight : q[a]));
 #endif
             };
             // two record buffers that swap roles (no copies): the time loop is unrolled by two, and t_low is even whenever it is a path
@@ -2192,27 +2256,58 @@ __global__ __launch_bounds__(kThreads) RNAD_LEARN_ATTR void k_bucket_learn_c(int
 }
 
 // Rollout and learner of a work item in ONE launch (r04): the workgroup that played the item's lanes runs their update right away --
-// thread k reads back what it wrote itself (states, packed actions, reward of lane item.begin + k: program order, no fence), so the
-// trajectory is the one k_bucket_rollout_items leaves and the sums are the ones k_bucket_learn_c adds up, bit for bit.  What it buys is
+// thread k takes over, in registers (struct Hand), what it played itself (packed actions, reward, the last stored states of lane
+// item.begin + k; older states and the items of a chunk beyond one pass are read back from the trajectory it wrote: program order, no
+// fence), so the trajectory is the one k_bucket_rollout_items leaves and the sums are the ones k_bucket_learn_c adds up, bit for bit.  What it buys is
 // a launch floor and the overlap of the rollout's gather latency with the learner's arithmetic across the workgroups of a CU
 // (tools/micro/overlap_probe.py: the two kernels side by side on two streams take 80 us where back to back they take 95).
 // The alive counts and the normalisers go, with atomics, into one of kReplicas rows each (alive_rep, norm_rep: behind the learner's
 // accumulators, zero between updates); k_bucket_finish -- or k_bucket_alive_rep, when the finish is the caller's -- adds the rows up,
 // hands alive[] / norm[] out and clears them.
-template <int A, typename REL>
-__global__ __launch_bounds__(kThreads) RNAD_LEARN_ATTR void k_bucket_play_learn(
+#ifndef RNAD_HANDOVER
+#define RNAD_HANDOVER 0
+#endif
+// (build switch: waves per SIMD the compiler must leave room for.  On its own it takes 77 VGPRs -- six waves; the variants that need
+// more, RNAD_HANDOVER and the DISTINCT instantiation at 83 - 85, run at five and lose 7 %: 73.8 -> 79.1 us)
+#ifndef RNAD_PLAY_LEARN_WAVES
+#define RNAD_PLAY_LEARN_WAVES 0
+#endif
+#if RNAD_PLAY_LEARN_WAVES > 0
+#define RNAD_PLAY_LEARN_ATTR __attribute__((amdgpu_waves_per_eu(RNAD_PLAY_LEARN_WAVES, RNAD_PLAY_LEARN_WAVES)))
+#else
+#define RNAD_PLAY_LEARN_ATTR
+#endif
+template <int A, typename REL, bool DISTINCT>
+__global__ __launch_bounds__(kThreads) RNAD_PLAY_LEARN_ATTR void k_bucket_play_learn(
     const Trans *__restrict__ trans, int C, int64_t S, int64_t B, int T_cap, const float *__restrict__ policy_tab, int64_t tab_stride, int vec4,
     uint64_t seed, const rnad_step_params_t *__restrict__ sp, int64_t lane0, const int32_t *__restrict__ lane_ids,
     const unsigned long long *__restrict__ decisions, const Item *__restrict__ items, const int32_t *__restrict__ n_items,
     const int32_t *__restrict__ bucket_path, const int32_t *__restrict__ bucket_lo, const int32_t *__restrict__ path_states, int path_stride,
     int n_groups, REL *states, int32_t *__restrict__ alive_rep, double *__restrict__ norm_rep, unsigned long long *acts, float *reward,
     int sub_rows, int path_words, int up_stride, const int32_t *__restrict__ bucket_of, const float *__restrict__ rec_, rnad_learn_params_t hp,
-    FixedPoint fx, unsigned long long *__restrict__ acc, unsigned long long *__restrict__ rep, int32_t *__restrict__ overflow) {
-    rollout_items_body<A, REL, 1>(trans, C, S, B, T_cap, policy_tab, tab_stride, vec4, seed, sp, lane0, lane_ids, decisions, items, n_items,
-                                  bucket_path, bucket_lo, path_states, path_stride, n_groups, states, alive_rep, acts, reward, nullptr, norm_rep);
-    learn_c_body<A, REL, false>(T_cap, B, S, sub_rows, path_words, n_groups, up_stride, items, n_items, bucket_of, bucket_lo, bucket_path,
+    FixedPoint fx, unsigned long long *__restrict__ acc, unsigned long long *__restrict__ rep, int32_t *__restrict__ overflow,
+    int distinct_words, int distinct_keys, int distinct_capacity) {
+    // distinct_keys > 0: the learner runs once per distinct trajectory of the item (struct Distinct); its arrays sit behind the
+    // learner's table in the dynamic LDS
+    extern __shared__ unsigned long long lds_all[];
+    Distinct dd;
+    dd.count = reinterpret_cast<int32_t *>(lds_all + distinct_words);  // [distinct_keys] | a counter that stays 1 | the list length
+    dd.n = dd.count + distinct_keys + 1;
+    dd.key = dd.n + 1;
+    dd.column = dd.key + distinct_capacity;
+    dd.codes = A * A * C + 1;
+    dd.keys = distinct_keys;
+    if (DISTINCT) {
+        for (int i = threadIdx.x; i < distinct_keys + 2; i += kThreads) dd.count[i] = i == distinct_keys ? 1 : 0;
+        __syncthreads();
+    }
+    Hand hand{0ull, 0ull, 0.0f, 0};
+    rollout_items_body<A, REL, 1, DISTINCT>(trans, C, S, B, T_cap, policy_tab, tab_stride, vec4, seed, sp, lane0, lane_ids, decisions, items, n_items,
+                                  bucket_path, bucket_lo, path_states, path_stride, n_groups, states, alive_rep, acts, reward, nullptr, norm_rep,
+                                  RNAD_HANDOVER ? &hand : nullptr, dd);
+    learn_c_body<A, REL, false, DISTINCT>(T_cap, B, S, sub_rows, path_words, n_groups, up_stride, items, n_items, bucket_of, bucket_lo, bucket_path,
                                 path_states, path_stride, states, rec_, acts, reward, nullptr, hp, fx, acc, rep, nullptr, overflow, nullptr, 0,
-                                T_cap + 1, nullptr, nullptr);
+                                T_cap + 1, nullptr, nullptr, RNAD_HANDOVER ? &hand : nullptr, dd);
 }
 
 // acc -> fp32 tables, normalised: dlogit_tab[P * S + s] = w_n * (G_l / N_P), dv_tab likewise with w_v (learn/vtrace.py:374,389;
@@ -2596,6 +2691,25 @@ struct FusedLearn {  // the learner of the batch in the rollout's launch (k_buck
     const rnad_learn_params_t *hp;
     void *accumulators;
 };
+// k_bucket_play_learn on the distinct trajectories of a work item (struct Distinct): larger items -- more lanes share a trajectory --
+// while the counters (a key per state of the group and outcome) and the list fit the LDS beside the learner's table.
+constexpr int kFusedChunkDefault = 512;      // (measured on configs[1]: 256 / 512 / 768 / 2048 lanes per item -> 0.181 / 0.171 / 0.171 / 0.177 ms per step)
+constexpr int kFusedLdsBudget = 26 * 1024;  // bytes of LDS per workgroup, the learner's table included: six workgroups to a CU
+int fused_distinct_keys(const rnad_tree_t *tree, const Plan &p) {
+    // opt-in (RNAD_FUSED_DISTINCT=1): the same sums bit for bit (tests/test_hip_bucket.py); what it buys depends on how many lanes share a
+    // trajectory -- configs[1]: 4 % slower under the uniform policies of fresh nets, 6.5 % faster 5 000 updates later
+    const char *e = getenv("RNAD_FUSED_DISTINCT");
+    if (!e || atoi(e) == 0) return 0;
+    return p.cut->rows * (tree->A * tree->A * tree->C + 1);
+}
+int fused_chunk(const rnad_tree_t *tree, const Plan &p) {
+    int chunk = kFusedChunkDefault;
+    if (const char *e = getenv("RNAD_FUSED_CHUNK")) chunk = std::max(64, atoi(e));
+    chunk = std::max(chunk, p.chunk);
+    const int keys = fused_distinct_keys(tree, p);
+    if (keys == 0 || (size_t)p.lds + ((size_t)keys + 2 + 2 * (size_t)chunk) * 4 > (size_t)kFusedLdsBudget) return p.chunk;  // (per lane, as played)
+    return chunk;
+}
 CountReps count_reps(const rnad_tree_t *tree, const Plan &p, void *accumulators, int T1, int32_t *alive_out, double *norm_out) {
     const int64_t A1 = tree->A + 1;
     unsigned long long *rep = (unsigned long long *)accumulators + 2 * tree->S * A1;
@@ -2716,7 +2830,7 @@ int rollout_bucketed_impl(const rnad_tree_t *tree, const RolloutBuffers &tr, boo
         if (scatter_lds > 48 * 1024)
             RNAD_HIP_OK(hipFuncSetAttribute((const void *)k_bucket_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, (int)scatter_lds));
         hipLaunchKernelGGL(k_bucket_scatter, dim3(p.sort_blocks), dim3(kSortThreads), scatter_lds, stream, B, nb, (const int32_t *)s.keys,
-                           (const int32_t *)s.hist, (const int32_t *)s.totals, p.chunk, (Item *)items, n_items, lane_ids, wave_rows, S,
+                           (const int32_t *)s.hist, (const int32_t *)s.totals, fused ? fused_chunk(tree, p) : p.chunk, (Item *)items, n_items, lane_ids, wave_rows, S,
                            p.cut->n_groups, (const int32_t *)p.cut->bucket_lo, (const int32_t *)p.cut->bucket_span,
                            (const int32_t *)p.cut->group_by_lo, staged_rows, n_staged, tr.visited, (const uint32_t *)stage.root, stage.sorted,
                            (const uint32_t *)stage.mark0, stage.root ? stage_rows0 : nullptr, stage.counts, seed, device_params);
@@ -2729,7 +2843,7 @@ int rollout_bucketed_impl(const rnad_tree_t *tree, const RolloutBuffers &tr, boo
     const unsigned grid = blocks_for(B);
     int alive_n = (int)grid;  // rows of alive_part the rollout kernel leaves
     {
-        ProfScope one(PROF_BUCKET_ROLLOUT, stream);
+        ProfScope one(fused ? PROF_BUCKET_LEARN : PROF_BUCKET_ROLLOUT, stream);  // (k_bucket_play_learn is booked as the learner: the larger share)
 #define RNAD_BUCKET_ROLLOUT()                                                                                                            \
     hipLaunchKernelGGL((k_bucket_rollout<kA>), dim3(grid), dim3(kThreads), 0, stream, tree->trans, tree->C, S, B, tr.T_cap, policy_tab,     \
                        policy_stride, value_table, value_stride, (const uint8_t *)tree->mask_tab, seed, device_params, lane0,               \
@@ -2749,17 +2863,21 @@ int rollout_bucketed_impl(const rnad_tree_t *tree, const RolloutBuffers &tr, boo
                 const CountReps cr = count_reps(tree, p, fused->accumulators, tr.T_cap + 1, nullptr, nullptr);
                 RNAD_REQUIRE(!fx.check_l, "rnad_rollout_learn_bucketed_compact: a NeuRD clip of 2^29 or more takes the two-launch path");
                 RNAD_REQUIRE(!tr.visited, "rnad_rollout_learn_bucketed_compact: no visited flags (lazy rows evaluate their records after the rollout)");
+                const int f_chunk = fused_chunk(tree, p);
+                const int d_keys = f_chunk > p.chunk || getenv("RNAD_FUSED_CHUNK") ? fused_distinct_keys(tree, p) : 0;
+                const int d_keys_fit = (size_t)p.lds + ((size_t)d_keys + 2 + 2 * (size_t)f_chunk) * 4 <= (size_t)kFusedLdsBudget ? d_keys : 0;
+                const size_t f_lds = (size_t)p.lds + (d_keys_fit ? ((size_t)d_keys_fit + 2 + 2 * (size_t)f_chunk) * 4 : 0);
 #define RNAD_PLAY_LEARN()                                                                                                              \
     do {                                                                                                                               \
-        auto kern = k_bucket_play_learn<kA, REL>;                                                                                      \
-        if (p.lds > 48 * 1024) RNAD_HIP_OK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, p.lds)); \
-        hipLaunchKernelGGL(kern, dim3((unsigned)p.max_items), dim3(kThreads), (size_t)p.lds, stream, tree->trans, tree->C, S, B, tr.T_cap, \
+        auto kern = d_keys_fit > 0 ? k_bucket_play_learn<kA, REL, true> : k_bucket_play_learn<kA, REL, false>;                         \
+        if (f_lds > 48 * 1024) RNAD_HIP_OK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)f_lds)); \
+        hipLaunchKernelGGL(kern, dim3((unsigned)p.max_items), dim3(kThreads), f_lds, stream, tree->trans, tree->C, S, B, tr.T_cap,     \
                            policy_tab, policy_stride, vec4, seed, device_params, lane0, (const int32_t *)lane_ids,                     \
                            (const unsigned long long *)s.decisions, (const Item *)items, (const int32_t *)n_items,                     \
                            (const int32_t *)p.cut->bucket_path, (const int32_t *)p.cut->bucket_lo, (const int32_t *)p.cut->path_states, \
                            std::max(p.cut->max_path, 1), p.cut->n_groups, (REL *)tr.indices, cr.alive_rep, cr.norm_rep, tr.acts,       \
                            tr.final_reward, p.cut->rows, p.path_words, std::max(nu, 1), (const int32_t *)p.cut->bucket_of, fused->fast, *fused->hp, fx, \
-                           acc, rep, overflow);                                                                                        \
+                           acc, rep, overflow, p.lds / 8, d_keys_fit, f_chunk);                                                        \
     } while (0)
                 RNAD_DISPATCH_REL(p, RNAD_DISPATCH_A(tree->A, RNAD_PLAY_LEARN()));
 #undef RNAD_PLAY_LEARN

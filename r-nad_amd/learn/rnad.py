@@ -1044,7 +1044,7 @@ class RNaD:
                 self.c_bar, self.roh_bar, self.vtrace_gamma, self.value_weight, self.neurd_weight, self.epsilon_threshold, self.n_discrete,
                 self.gamma_averaging, getattr(self, "obs_half", False), getattr(self, "store_actor_values", False), getattr(self, "fused_optimizer", True),
                 getattr(self, "compact_trajectory", True), getattr(self, "lazy_rows", None), os.environ.get("RNAD_BUCKET_ROWS"), os.environ.get("RNAD_BUCKET_CHUNK"),
-                getattr(self, "fold_legal", True), self._fuse_now())
+                getattr(self, "fold_legal", True), self._fuse_now(), os.environ.get("RNAD_FUSED_DISTINCT"), os.environ.get("RNAD_FUSED_CHUNK"))
 
     def _graph_step(self, buffer, alpha):
         g = getattr(self, "_graph", None)

@@ -781,11 +781,18 @@ def test_deferred_alive_counts_are_completed_by_the_learner_or_on_first_read(nam
 @pytest.mark.parametrize("rows", (None, 40, 8))
 @pytest.mark.parametrize("name", sorted(TREES))
 @pytest.mark.parametrize("B", (8192, 3000))
-def test_rollout_and_learner_in_one_launch(name, B, rows, monkeypatch):
+@pytest.mark.parametrize("distinct", (False, True))
+def test_rollout_and_learner_in_one_launch(name, B, rows, distinct, monkeypatch):
     """rnad_rollout_learn_bucketed_compact (k_bucket_play_learn: the workgroup of a work item plays its lanes and adds up their update)
     against rnad_rollout_bucketed_compact + rnad_learn_bucketed_compact: the same trajectory, alive counts, normalisers and per-row
-    gradient tables, bit for bit -- at the planner's cut and at forced ones; also with the finish left to the caller (data parallel)."""
+    gradient tables, bit for bit -- at the planner's cut and at forced ones; also with the finish left to the caller (data parallel).
+    distinct (RNAD_FUSED_DISTINCT=1, opt-in): larger work items, the learner once per distinct trajectory of an item weighted with the
+    number of lanes that took it -- integer sums: the same bits."""
     import rnad_hip
+
+    if distinct:
+        monkeypatch.setenv("RNAD_FUSED_DISTINCT", "1")
+        monkeypatch.setenv("RNAD_FUSED_CHUNK", "512" if B == 3000 else "1024")
 
     tree = _native_tree(**TREES[name])
     h = tree.handle()
@@ -808,9 +815,12 @@ def test_rollout_and_learner_in_one_launch(name, B, rows, monkeypatch):
     want = rnad_hip.learn_bucketed_compact(h, bk2, two, T_cap, rec, fast, bk2.norm, hp)
     one = traj()
     bk1, dlogit, dv = rnad_hip.rollout_learn_bucketed_compact(h, one, rec, fast, hp, seed=21, lane0=77)
-    assert torch.equal(bk1.lane_ids, bk2.lane_ids) and torch.equal(bk1.n_items, bk2.n_items)
-    n = int(bk1.n_items.item())
-    assert torch.equal(bk1.items[:n], bk2.items[:n])
+    assert torch.equal(bk1.lane_ids, bk2.lane_ids)
+    # (the work items may be larger -- the one launch runs its learner on the distinct trajectories of an item --: the same lanes, bucket by bucket)
+    n1, n2 = int(bk1.n_items.item()), int(bk2.n_items.item())
+    it1, it2 = bk1.items[:n1].cpu().numpy(), bk2.items[:n2].cpu().numpy()
+    assert n1 <= n2 and it1[:, 1].sum() == it2[:, 1].sum() == B
+    assert np.array_equal(np.bincount(it1[:, 2], weights=it1[:, 1]), np.bincount(it2[:, 2], weights=it2[:, 1]))
     assert torch.equal(one.alive, two.alive) and torch.equal(bk1.norm, bk2.norm)
     assert torch.equal(one.acts, two.acts) and torch.equal(one.final_reward.view(torch.int32), two.final_reward.view(torch.int32))
     assert torch.equal(one.indices, two.indices), "the states a lane went through (rebuilt from the relative states)"
