@@ -438,7 +438,10 @@ class RNaD:
 
     def _fuse_now(self):
         """RNaD.fuse_rollout_learner (default on; RNAD_FUSE_PLAY_LEARN=0 turns the default off): rollout and learner of the step in one launch."""
-        return bool(getattr(self, "fuse_rollout_learner", os.environ.get("RNAD_FUSE_PLAY_LEARN", "1") != "0"))
+        # (data parallel: off unless asked for -- with two launches the all-reduce of the normalisers runs beside the learner; behind the
+        # one launch it would sit, exposed, between it and the finish: a collective's latency for the 6 us the fusion saves)
+        default = os.environ.get("RNAD_FUSE_PLAY_LEARN", "1") != "0" and not self._dp()
+        return bool(getattr(self, "fuse_rollout_learner", default))
 
     def _learn_params(self, alpha):
         return rnad_hip.make_learn_params(
