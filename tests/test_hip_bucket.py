@@ -793,6 +793,8 @@ def test_rollout_and_learner_in_one_launch(name, B, rows, distinct, monkeypatch)
     if distinct:
         monkeypatch.setenv("RNAD_FUSED_DISTINCT", "1")
         monkeypatch.setenv("RNAD_FUSED_CHUNK", "512" if B == 3000 else "1024")
+    elif rows == 40:
+        monkeypatch.setenv("RNAD_BUCKET_CHUNK", "600")  # items of several passes: a thread reads back the lanes it played, pass by pass
 
     tree = _native_tree(**TREES[name])
     h = tree.handle()

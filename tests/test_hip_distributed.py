@@ -122,24 +122,29 @@ def _nccl_graph(rank, port, tmp):
         dev = torch.device("cuda:0")
         tree = Tree(device=dev, max_actions=3, max_transitions=1, depth_bound=4)
         tree.generate_native(seed=0)
-        out = {}
-        for use_graph in (False, True):
+        out = {"captured": True}
+        # fuse: rollout and learner of the step in one launch (a data-parallel rank keeps two unless asked: RNaD._fuse_now) -- the counts
+        # then come from k_bucket_alive_rep and the finish is the caller's, after the all-reduce of the normalisers
+        for use_graph, fuse in ((False, False), (True, False), (False, True), (True, True)):
             torch.manual_seed(SEED)
-            rn = RNaD(tree=tree, device=dev, directory_name=f"g{int(use_graph)}", batch_size=1 << 14, eta=0.2, b1_adam=0.0, lr=1e-3,
+            rn = RNaD(tree=tree, device=dev, directory_name=f"g{int(use_graph)}{int(fuse)}", batch_size=1 << 14, eta=0.2, b1_adam=0.0, lr=1e-3,
                       net_params={"type": "MLP", "max_actions": 3, "width": 64})
             rn.initialize()
             rn.use_graph = use_graph
+            rn.fuse_rollout_learner = fuse
             buf = Buffer(1)
             for i in range(8):
                 rn.train_step(buf, alpha=0.1 * i)
                 rn.total_steps += 1
             torch.cuda.synchronize()
-            out[use_graph] = [p.detach().cpu().numpy() for p in rn.net.parameters()]
+            assert (getattr(rn.last_episodes, "_compact", None) is not None), "the compact bucketed rollout must apply"
+            out[(use_graph, fuse)] = [p.detach().cpu().numpy() for p in rn.net.parameters()]
             if use_graph:
                 g = getattr(rn, "_graph", None)
-                out["captured"] = bool(g and g.get("graph") is not None and not g.get("failed"))
-        np.savez(os.path.join(tmp, "nccl_graph.npz"), captured=out["captured"], **{f"e{i}": a for i, a in enumerate(out[False])},
-                 **{f"g{i}": a for i, a in enumerate(out[True])})
+                out["captured"] = out["captured"] and bool(g and g.get("graph") is not None and not g.get("failed"))
+        np.savez(os.path.join(tmp, "nccl_graph.npz"), captured=out["captured"], **{f"e{i}": a for i, a in enumerate(out[(False, False)])},
+                 **{f"g{i}": a for i, a in enumerate(out[(True, False)])}, **{f"ef{i}": a for i, a in enumerate(out[(False, True)])},
+                 **{f"gf{i}": a for i, a in enumerate(out[(True, True)])})
     finally:
         dist.destroy_process_group()
 
@@ -153,6 +158,9 @@ def test_graph_replay_with_rccl_collectives_inside(tmp_path):
     assert bool(got["captured"]), "the step with RCCL collectives inside must have been captured"
     for i in range(8):
         np.testing.assert_array_equal(got[f"e{i}"], got[f"g{i}"])
+        # rollout + learner in one launch: the same per-row sums bit for bit, hence the same parameters
+        np.testing.assert_array_equal(got[f"e{i}"], got[f"ef{i}"])
+        np.testing.assert_array_equal(got[f"e{i}"], got[f"gf{i}"])
 
 
 def _sharded_step(tmp, tag, shard):
