@@ -480,15 +480,21 @@ int rnad_rollout_bucketed_compact_expand(const rnad_tree_t *tree, int T_cap, int
 /* Rollout AND learner of the batch in one call (r04): rnad_rollout_bucketed_compact(_expand) (a table of policy rows; n_tables == 0: no
  * copies to carry) followed by rnad_learn_bucketed_compact of the batch it plays with T = T_cap (learn/rnad.py:503-505 + :365-425 on the
  * on-policy batch) -- keys, sort, then ONE launch in which the workgroup of a work item plays its lanes and adds up their update right
- * away, then the alive counts (`alive`, `norm`: required) and, finish != 0, rnad_bucket_finish with the batch's own normalisers (a
- * data-parallel caller passes finish = 0, all-reduces `norm` and calls rnad_bucket_finish itself).  Trajectory, counts, accumulators and
- * gradient tables are those of the two calls, bit for bit.  No loss sums (a logging step takes the two calls), no visited flags. */
+ * away, then the alive counts (`alive`, `norm`: required) and, flags & RNAD_PLAY_LEARN_FINISH, rnad_bucket_finish with the batch's own
+ * normalisers (a data-parallel caller leaves the flag out, all-reduces `norm` and calls rnad_bucket_finish itself).  Trajectory, counts,
+ * accumulators and gradient tables are those of the two calls, bit for bit.  No loss sums (a logging step takes the two calls), no
+ * visited flags.  RNAD_PLAY_LEARN_DISTINCT: larger work items, and the learner half runs once per DISTINCT trajectory of an item -- a
+ * state has one parent entry, so the state a lane was last alive in and the outcome it drew there fix its trajectory -- weighted with
+ * the number of lanes that took it: 64-bit integer sums, the same bits.  Pays once the policy has sharpened (fewer distinct
+ * trajectories per item), costs ~4 % under uniform policies; the environment variable RNAD_FUSED_DISTINCT=0/1 overrides the flag. */
+#define RNAD_PLAY_LEARN_FINISH 1
+#define RNAD_PLAY_LEARN_DISTINCT 2
 int rnad_rollout_learn_bucketed_compact(const rnad_tree_t *tree, int T_cap, int64_t B, const float *table, int64_t table_stride,
                                         uint64_t seed, int64_t lane0, const rnad_step_params_t *device_params, void *scratch,
                                         int32_t *lane_ids, int32_t *items, int32_t *n_items, double *norm, void *states, int32_t *alive,
                                         uint64_t *acts, float *final_reward, const int32_t *rep_of, int n_tables, float *const *tables,
                                         const int32_t *floats_per_row, const float *fast_records, const rnad_learn_params_t *hp,
-                                        void *accumulators, int finish, float *dlogit_tab, float *dv_tab, const int32_t *rows,
+                                        void *accumulators, int flags, float *dlogit_tab, float *dv_tab, const int32_t *rows,
                                         const int64_t *n_rows, const rnad_row_groups_t *groups, void *stream);
 int rnad_bucket_indices(const rnad_tree_t *tree, int T1, int64_t B, const void *states, const int32_t *items, const int32_t *n_items,
                         int32_t *indices, void *stream);

@@ -2690,23 +2690,25 @@ struct FusedLearn {  // the learner of the batch in the rollout's launch (k_buck
     const float *fast;
     const rnad_learn_params_t *hp;
     void *accumulators;
+    bool distinct;  // the learner once per distinct trajectory of a work item (struct Distinct)
 };
 // k_bucket_play_learn on the distinct trajectories of a work item (struct Distinct): larger items -- more lanes share a trajectory --
 // while the counters (a key per state of the group and outcome) and the list fit the LDS beside the learner's table.
 constexpr int kFusedChunkDefault = 512;      // (measured on configs[1]: 256 / 512 / 768 / 2048 lanes per item -> 0.181 / 0.171 / 0.171 / 0.177 ms per step)
 constexpr int kFusedLdsBudget = 26 * 1024;  // bytes of LDS per workgroup, the learner's table included: six workgroups to a CU
-int fused_distinct_keys(const rnad_tree_t *tree, const Plan &p) {
-    // opt-in (RNAD_FUSED_DISTINCT=1): the same sums bit for bit (tests/test_hip_bucket.py); what it buys depends on how many lanes share a
-    // trajectory -- configs[1]: 4 % slower under the uniform policies of fresh nets, 6.5 % faster 5 000 updates later
-    const char *e = getenv("RNAD_FUSED_DISTINCT");
-    if (!e || atoi(e) == 0) return 0;
+int fused_distinct_keys(const rnad_tree_t *tree, const Plan &p, bool asked) {
+    // opt-in (the caller's flag; RNAD_FUSED_DISTINCT=0 / 1 overrides it): the same sums bit for bit (tests/test_hip_bucket.py); what it buys
+    // depends on how many lanes share a trajectory -- configs[1]: 4 % slower under the uniform policies of fresh nets, 6.5 % faster 5 000
+    // updates later, 14 % after 30 000
+    if (const char *e = getenv("RNAD_FUSED_DISTINCT")) asked = atoi(e) != 0;
+    if (!asked) return 0;
     return p.cut->rows * (tree->A * tree->A * tree->C + 1);
 }
-int fused_chunk(const rnad_tree_t *tree, const Plan &p) {
+int fused_chunk(const rnad_tree_t *tree, const Plan &p, bool asked) {
     int chunk = kFusedChunkDefault;
     if (const char *e = getenv("RNAD_FUSED_CHUNK")) chunk = std::max(64, atoi(e));
     chunk = std::max(chunk, p.chunk);
-    const int keys = fused_distinct_keys(tree, p);
+    const int keys = fused_distinct_keys(tree, p, asked);
     if (keys == 0 || (size_t)p.lds + ((size_t)keys + 2 + 2 * (size_t)chunk) * 4 > (size_t)kFusedLdsBudget) return p.chunk;  // (per lane, as played)
     return chunk;
 }
@@ -2830,7 +2832,7 @@ int rollout_bucketed_impl(const rnad_tree_t *tree, const RolloutBuffers &tr, boo
         if (scatter_lds > 48 * 1024)
             RNAD_HIP_OK(hipFuncSetAttribute((const void *)k_bucket_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, (int)scatter_lds));
         hipLaunchKernelGGL(k_bucket_scatter, dim3(p.sort_blocks), dim3(kSortThreads), scatter_lds, stream, B, nb, (const int32_t *)s.keys,
-                           (const int32_t *)s.hist, (const int32_t *)s.totals, fused ? fused_chunk(tree, p) : p.chunk, (Item *)items, n_items, lane_ids, wave_rows, S,
+                           (const int32_t *)s.hist, (const int32_t *)s.totals, fused ? fused_chunk(tree, p, fused->distinct) : p.chunk, (Item *)items, n_items, lane_ids, wave_rows, S,
                            p.cut->n_groups, (const int32_t *)p.cut->bucket_lo, (const int32_t *)p.cut->bucket_span,
                            (const int32_t *)p.cut->group_by_lo, staged_rows, n_staged, tr.visited, (const uint32_t *)stage.root, stage.sorted,
                            (const uint32_t *)stage.mark0, stage.root ? stage_rows0 : nullptr, stage.counts, seed, device_params);
@@ -2863,8 +2865,8 @@ int rollout_bucketed_impl(const rnad_tree_t *tree, const RolloutBuffers &tr, boo
                 const CountReps cr = count_reps(tree, p, fused->accumulators, tr.T_cap + 1, nullptr, nullptr);
                 RNAD_REQUIRE(!fx.check_l, "rnad_rollout_learn_bucketed_compact: a NeuRD clip of 2^29 or more takes the two-launch path");
                 RNAD_REQUIRE(!tr.visited, "rnad_rollout_learn_bucketed_compact: no visited flags (lazy rows evaluate their records after the rollout)");
-                const int f_chunk = fused_chunk(tree, p);
-                const int d_keys = f_chunk > p.chunk || getenv("RNAD_FUSED_CHUNK") ? fused_distinct_keys(tree, p) : 0;
+                const int f_chunk = fused_chunk(tree, p, fused->distinct);
+                const int d_keys = f_chunk > p.chunk || getenv("RNAD_FUSED_CHUNK") ? fused_distinct_keys(tree, p, fused->distinct) : 0;
                 const int d_keys_fit = (size_t)p.lds + ((size_t)d_keys + 2 + 2 * (size_t)f_chunk) * 4 <= (size_t)kFusedLdsBudget ? d_keys : 0;
                 const size_t f_lds = (size_t)p.lds + (d_keys_fit ? ((size_t)d_keys_fit + 2 + 2 * (size_t)f_chunk) * 4 : 0);
 #define RNAD_PLAY_LEARN()                                                                                                              \
@@ -3054,14 +3056,15 @@ extern "C" int rnad_rollout_bucketed_compact_expand(const rnad_tree_t *tree, int
 
 // rnad_rollout_bucketed_compact(_expand) and rnad_learn_bucketed_compact of the batch it plays, T = T_cap, in one call: keys, sort, then
 // ONE launch in which every work item's workgroup plays its lanes and adds up their update (k_bucket_play_learn), then the alive
-// counts and -- finish != 0 -- rnad_bucket_finish with the batch's own normalisers (a data-parallel caller passes finish = 0, all-reduces
-// `norm` and calls rnad_bucket_finish itself).  The trajectory, the counts and the gradient tables are those of the two calls, bit for bit.
+// counts and -- RNAD_PLAY_LEARN_FINISH -- rnad_bucket_finish with the batch's own normalisers (a data-parallel caller leaves the flag out,
+// all-reduces `norm` and calls rnad_bucket_finish itself).  RNAD_PLAY_LEARN_DISTINCT: the learner half once per distinct trajectory of a
+// work item (struct Distinct).  The trajectory, the counts and the gradient tables are those of the two calls, bit for bit.
 extern "C" int rnad_rollout_learn_bucketed_compact(const rnad_tree_t *tree, int T_cap, int64_t B, const float *table, int64_t table_stride,
                                                    uint64_t seed, int64_t lane0, const rnad_step_params_t *device_params, void *scratch,
                                                    int32_t *lane_ids, int32_t *items, int32_t *n_items, double *norm, void *states,
                                                    int32_t *alive, uint64_t *acts, float *final_reward, const int32_t *rep_of, int n_tables,
                                                    float *const *tables, const int32_t *floats_per_row, const float *fast_records,
-                                                   const rnad_learn_params_t *hp, void *accumulators, int finish, float *dlogit_tab,
+                                                   const rnad_learn_params_t *hp, void *accumulators, int flags, float *dlogit_tab,
                                                    float *dv_tab, const int32_t *rows, const int64_t *n_rows, const rnad_row_groups_t *groups,
                                                    void *stream) {
     RNAD_REQUIRE(tree && table && scratch && lane_ids && items && n_items && norm && states && alive && acts && final_reward && fast_records &&
@@ -3070,6 +3073,7 @@ extern "C" int rnad_rollout_learn_bucketed_compact(const rnad_tree_t *tree, int 
     RNAD_REQUIRE(T_cap >= 1 && T_cap <= kCompactSteps && B >= 1, "rnad_rollout_learn_bucketed_compact: 1 <= T_cap <= %d, got %d", kCompactSteps, T_cap);
     RNAD_REQUIRE(table_stride >= tree->A, "rnad_rollout_learn_bucketed_compact: bad table stride");
     RNAD_REQUIRE(((uintptr_t)fast_records & 15) == 0, "rnad_rollout_learn_bucketed_compact: fast_records must be 16-byte aligned");
+    const bool finish = (flags & RNAD_PLAY_LEARN_FINISH) != 0;
     RNAD_REQUIRE(!finish || (dlogit_tab && dv_tab), "rnad_rollout_learn_bucketed_compact: finish needs the gradient tables");
     RNAD_REQUIRE(!rows == !n_rows, "rnad_rollout_learn_bucketed_compact: rows and n_rows go together");
     RNAD_REQUIRE(n_tables >= 0 && n_tables <= 4 && (n_tables == 0 || (rep_of && tables && floats_per_row)),
@@ -3087,7 +3091,7 @@ extern "C" int rnad_rollout_learn_bucketed_compact(const rnad_tree_t *tree, int 
             ex.max_quads = std::max(ex.max_quads, ex.quads[k]);
         }
     }
-    const FusedLearn fused{fast_records, hp, accumulators};
+    const FusedLearn fused{fast_records, hp, accumulators, (flags & RNAD_PLAY_LEARN_DISTINCT) != 0};
     const RolloutBuffers out{T_cap, B, states, nullptr, nullptr, nullptr, nullptr, nullptr, alive, (unsigned long long *)acts, final_reward, nullptr};
     if (int rc = rollout_bucketed_impl(tree, out, true, table, table_stride, 1, nullptr, 1, seed, lane0, device_params, scratch, lane_ids, items,
                                        n_items, norm, (hipStream_t)stream, 3, nullptr, nullptr, nullptr, nullptr, nullptr, false, nullptr, nullptr,

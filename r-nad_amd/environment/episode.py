@@ -372,7 +372,8 @@ class Episodes:
                 # the per-row gradient tables up from `_learned` instead of launching the learner
                 self.buckets, dlogit, dv = rnad_hip.rollout_learn_bucketed_compact(
                     handle, traj, policy_table[0], learn["fast_records"], learn["hp"], seed=self.seed, lane0=self.lane_offset,
-                    step_params=step_params, norm_is_global=learn.get("norm_is_global", True), rows=learn.get("rows"), groups=learn.get("groups"))
+                    step_params=step_params, norm_is_global=learn.get("norm_is_global", True), rows=learn.get("rows"), groups=learn.get("groups"),
+                    distinct=bool(learn.get("distinct", False)))
                 self._learned = dict(records=policy_table[0], dlogit=dlogit, dv=dv)
                 self.lane_ids = self.buckets.lane_ids
                 self._compact = (traj, policy_table[0])

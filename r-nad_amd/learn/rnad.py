@@ -443,6 +443,16 @@ class RNaD:
         default = os.environ.get("RNAD_FUSE_PLAY_LEARN", "1") != "0" and not self._dp()
         return bool(getattr(self, "fuse_rollout_learner", default))
 
+    DISTINCT_AFTER = 4096  # updates after which `distinct_trajectories = None` switches the learner to the distinct trajectories of a work item
+
+    def _distinct_now(self):
+        """RNaD.distinct_trajectories: the learner half of the one-launch rollout + learner runs once per distinct trajectory of a work item
+        (rnad_hip.rollout_learn_bucketed_compact(distinct=True): the same per-row sums bit for bit).  It pays once lanes pile up on few
+        trajectories -- a trained policy -- and costs ~4 % under the near-uniform policies of fresh nets: None
+        (default) turns it on after DISTINCT_AFTER updates of this trainer; True / False force it."""
+        want = getattr(self, "distinct_trajectories", None)
+        return bool(want) if want is not None else self.total_steps >= self.DISTINCT_AFTER
+
     def _learn_params(self, alpha):
         return rnad_hip.make_learn_params(
             alpha=alpha, eta=self.eta, lambda_=1.0, c=self.c_bar, rho=self.roh_bar, gamma=self.vtrace_gamma,
@@ -931,6 +941,7 @@ class RNaD:
                                      and dedup.groups_below_cut(handle, plan)) else None)
                 if plan is not None:
                     learn_now = dict(fast_records=tables["fast_records"], hp=self._learn_params(alpha), norm_is_global=not self._dp(),
+                                     distinct=self._distinct_now(),
                                      rows=grouped.singles if grouped is not None else tables.get("rows"), groups=grouped)
             episodes.generate(self.net, trim=False, keep_logits=self.reuse_actor_outputs,
                               skip_absorbed=getattr(self, "skip_absorbed", True) and not self.reuse_actor_outputs,
@@ -1047,7 +1058,7 @@ class RNaD:
                 self.c_bar, self.roh_bar, self.vtrace_gamma, self.value_weight, self.neurd_weight, self.epsilon_threshold, self.n_discrete,
                 self.gamma_averaging, getattr(self, "obs_half", False), getattr(self, "store_actor_values", False), getattr(self, "fused_optimizer", True),
                 getattr(self, "compact_trajectory", True), getattr(self, "lazy_rows", None), os.environ.get("RNAD_BUCKET_ROWS"), os.environ.get("RNAD_BUCKET_CHUNK"),
-                getattr(self, "fold_legal", True), self._fuse_now(), os.environ.get("RNAD_FUSED_DISTINCT"), os.environ.get("RNAD_FUSED_CHUNK"))
+                getattr(self, "fold_legal", True), self._fuse_now(), self._fuse_now() and self._distinct_now(), os.environ.get("RNAD_FUSED_DISTINCT"), os.environ.get("RNAD_FUSED_CHUNK"))
 
     def _graph_step(self, buffer, alpha):
         g = getattr(self, "_graph", None)

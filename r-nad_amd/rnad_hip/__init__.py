@@ -920,12 +920,16 @@ def rollout_bucketed_compact(tree, traj, table, seed=0, lane0=0, step_params=Non
     return buckets
 
 
+PLAY_LEARN_FINISH, PLAY_LEARN_DISTINCT = 1, 2  # include/rnad_hip.h
+
+
 def rollout_learn_bucketed_compact(tree, traj, records, fast_records, hp, seed=0, lane0=0, step_params=None, norm_is_global=True, rows=None,
-                                   groups=None):
+                                   groups=None, distinct=False):
     """rnad_rollout_learn_bucketed_compact: rollout_bucketed_compact(records) and learn_bucketed_compact of the batch it plays (T = T_cap)
     with ONE launch for rollout + learner -- the trajectory, traj.alive, buckets.norm and the per-row gradient tables of the two calls, bit
     for bit.  records: bucket_records(..., fast=True)[0] (its policy rows are the actor; a pending rows_expand job rides in the keys pass).
     norm_is_global=False (data parallel): stops before k_bucket_finish -- all-reduce buckets.norm, then bucket_finish(...).
+    distinct: the learner half once per distinct trajectory of a (larger) work item, weighted with its lanes (RNAD_PLAY_LEARN_DISTINCT).
     Returns (buckets, dlogit, dv); the tables are None when the finish is left to the caller."""
     assert traj.compact and traj.T_cap <= COMPACT_MAX_STEPS
     plan = bucket_plan(tree, traj.B)
@@ -958,7 +962,8 @@ def rollout_learn_bucketed_compact(tree, traj, records, fast_records, hp, seed=0
         _dp(buckets.items, I32, "items"), _dp(buckets.n_items, I32, "n_items"), _dp(buckets.norm, F64, "norm"),
         _dp(traj.states, traj.states.dtype, "states"), _dp(traj.alive, I32, "alive"), _dp(traj.acts, torch.int64, "acts"),
         _dp(traj.final_reward, F32, "final_reward"), rep_of, n_tabs, ptrs, widths, _dp(fast_records, F32, "fast_records"), C.byref(hp),
-        _dp(plan.accumulators, torch.int64, "accumulators"), int(bool(norm_is_global)), _dp(dlogit, F32, "dlogit_tab", True),
+        _dp(plan.accumulators, torch.int64, "accumulators"),
+        (PLAY_LEARN_FINISH if norm_is_global else 0) | (PLAY_LEARN_DISTINCT if distinct else 0), _dp(dlogit, F32, "dlogit_tab", True),
         _dp(dv, F32, "dv_tab", True), *_row_list(rows), groups, _stream()))
     if pending is not None:
         records._expand = None

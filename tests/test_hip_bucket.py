@@ -786,12 +786,11 @@ def test_rollout_and_learner_in_one_launch(name, B, rows, distinct, monkeypatch)
     """rnad_rollout_learn_bucketed_compact (k_bucket_play_learn: the workgroup of a work item plays its lanes and adds up their update)
     against rnad_rollout_bucketed_compact + rnad_learn_bucketed_compact: the same trajectory, alive counts, normalisers and per-row
     gradient tables, bit for bit -- at the planner's cut and at forced ones; also with the finish left to the caller (data parallel).
-    distinct (RNAD_FUSED_DISTINCT=1, opt-in): larger work items, the learner once per distinct trajectory of an item weighted with the
+    distinct (RNAD_PLAY_LEARN_DISTINCT): larger work items, the learner once per distinct trajectory of an item weighted with the
     number of lanes that took it -- integer sums: the same bits."""
     import rnad_hip
 
     if distinct:
-        monkeypatch.setenv("RNAD_FUSED_DISTINCT", "1")
         monkeypatch.setenv("RNAD_FUSED_CHUNK", "512" if B == 3000 else "1024")
     elif rows == 40:
         monkeypatch.setenv("RNAD_BUCKET_CHUNK", "600")  # items of several passes: a thread reads back the lanes it played, pass by pass
@@ -816,7 +815,7 @@ def test_rollout_and_learner_in_one_launch(name, B, rows, distinct, monkeypatch)
     bk2 = rnad_hip.rollout_bucketed_compact(h, two, rec, seed=21, lane0=77)
     want = rnad_hip.learn_bucketed_compact(h, bk2, two, T_cap, rec, fast, bk2.norm, hp)
     one = traj()
-    bk1, dlogit, dv = rnad_hip.rollout_learn_bucketed_compact(h, one, rec, fast, hp, seed=21, lane0=77)
+    bk1, dlogit, dv = rnad_hip.rollout_learn_bucketed_compact(h, one, rec, fast, hp, seed=21, lane0=77, distinct=distinct)
     assert torch.equal(bk1.lane_ids, bk2.lane_ids)
     # (the work items may be larger -- the one launch runs its learner on the distinct trajectories of an item --: the same lanes, bucket by bucket)
     n1, n2 = int(bk1.n_items.item()), int(bk2.n_items.item())
@@ -830,7 +829,7 @@ def test_rollout_and_learner_in_one_launch(name, B, rows, distinct, monkeypatch)
     assert torch.isfinite(dlogit).all() and float(dlogit.abs().sum()) > 0
     # the finish left to the caller
     late = traj()
-    bk3, none_l, none_v = rnad_hip.rollout_learn_bucketed_compact(h, late, rec, fast, hp, seed=21, lane0=77, norm_is_global=False)
+    bk3, none_l, none_v = rnad_hip.rollout_learn_bucketed_compact(h, late, rec, fast, hp, seed=21, lane0=77, norm_is_global=False, distinct=distinct)
     assert none_l is None and none_v is None
     dl3 = torch.empty_like(dlogit)
     dv3 = torch.empty_like(dv)

@@ -349,3 +349,27 @@ def test_packed_weight_images_follow_the_optimiser(use_graph, tmp_path):
     assert [t.data_ptr() for t in rn._packed_cache["layouts"][fold]["images"]] == ptrs, "the images are re-packed in place (a captured step reads them)"
     if use_graph:
         assert rn._graph["graph"] is not None and not rn._graph["failed"]
+
+
+def test_the_learner_on_distinct_trajectories_trains_like_the_per_lane_learner(tmp_path, monkeypatch):
+    """RNaD.distinct_trajectories (rollout + learner in one launch, the learner half once per distinct trajectory of a work item): the
+    per-row sums are integer sums of the same addends, so the trainer ends up with the same parameters bit for bit -- forced on from the
+    first step, and switched on by itself after DISTINCT_AFTER updates (a new graph is captured at the switch)."""
+    from learn.rnad import RNaD
+    from test_hip_bucket import TREES, _native_tree
+
+    tree = _native_tree(**TREES["ternary4"])
+    monkeypatch.setattr(RNaD, "distinct_trajectories", False, raising=False)
+    off, nets_off, seeds_off = _run(tree, tmp_path, True, 12, tag="d0")
+    assert off._fuse_now() and not off._distinct_now()
+    assert getattr(off.last_episodes, "_compact", None) is not None and off._graph["graph"] is not None
+    monkeypatch.setattr(RNaD, "distinct_trajectories", True, raising=False)
+    on, nets_on, seeds_on = _run(tree, tmp_path, True, 12, tag="d1")
+    assert on._distinct_now() and on._graph["graph"] is not None and not on._graph["failed"]
+    monkeypatch.setattr(RNaD, "distinct_trajectories", None, raising=False)
+    monkeypatch.setattr(RNaD, "DISTINCT_AFTER", 6)
+    auto, nets_auto, seeds_auto = _run(tree, tmp_path, True, 12, tag="d2")
+    assert auto._distinct_now() and auto._graph["graph"] is not None and not auto._graph["failed"]
+    assert seeds_off == seeds_on == seeds_auto
+    for a, b, c in zip(nets_off, nets_on, nets_auto):
+        assert torch.equal(a, b) and torch.equal(a, c)
