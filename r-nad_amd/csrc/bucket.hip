@@ -2256,9 +2256,9 @@ __global__ __launch_bounds__(kThreads) RNAD_LEARN_ATTR void k_bucket_learn_c(int
 }
 
 // Rollout and learner of a work item in ONE launch (r04): the workgroup that played the item's lanes runs their update right away --
-// thread k takes over, in registers (struct Hand), what it played itself (packed actions, reward, the last stored states of lane
-// item.begin + k; older states and the items of a chunk beyond one pass are read back from the trajectory it wrote: program order, no
-// fence), so the trajectory is the one k_bucket_rollout_items leaves and the sums are the ones k_bucket_learn_c adds up, bit for bit.  What it buys is
+// thread k reads back what it played itself (packed actions, reward, states of lane item.begin + k: its own stores, program order, no
+// fence; RNAD_HANDOVER=1 keeps them in registers instead -- struct Hand --, which costs the sixth wave per SIMD and more than it saves),
+// so the trajectory is the one k_bucket_rollout_items leaves and the sums are the ones k_bucket_learn_c adds up, bit for bit.  What it buys is
 // a launch floor and the overlap of the rollout's gather latency with the learner's arithmetic across the workgroups of a CU
 // (tools/micro/overlap_probe.py: the two kernels side by side on two streams take 80 us where back to back they take 95).
 // The alive counts and the normalisers go, with atomics, into one of kReplicas rows each (alive_rep, norm_rep: behind the learner's
@@ -2267,8 +2267,8 @@ __global__ __launch_bounds__(kThreads) RNAD_LEARN_ATTR void k_bucket_learn_c(int
 #ifndef RNAD_HANDOVER
 #define RNAD_HANDOVER 0
 #endif
-// (build switch: waves per SIMD the compiler must leave room for.  On its own it takes 77 VGPRs -- six waves; the variants that need
-// more, RNAD_HANDOVER and the DISTINCT instantiation at 83 - 85, run at five and lose 7 %: 73.8 -> 79.1 us)
+// (build switch: waves per SIMD the compiler must leave room for.  On its own it takes 77 VGPRs (DISTINCT: 79) -- six waves; with
+// RNAD_HANDOVER it takes 85, runs at five and loses 7 %: 73.8 -> 79.1 us)
 #ifndef RNAD_PLAY_LEARN_WAVES
 #define RNAD_PLAY_LEARN_WAVES 0
 #endif

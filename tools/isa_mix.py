@@ -19,7 +19,7 @@ import isa_hist  # noqa: E402
 KERNELS = [
     ("bucket.hip", "k_bucket_learn_c<3, unsigned char, false>"),
     ("bucket.hip", "k_bucket_learn_c<5, unsigned short, false>"),
-    ("bucket.hip", "k_bucket_play_learn<3, unsigned char>"),
+    ("bucket.hip", "k_bucket_play_learn<3, unsigned char, false>"),
     ("bucket.hip", "k_bucket_rollout_items<3, unsigned char, 1>"),
     ("bucket.hip", "k_bucket_rollout_items<5, unsigned short, 1>"),
     ("bucket.hip", "k_bucket_keys_lds<3, 1>"),
