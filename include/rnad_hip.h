@@ -487,6 +487,9 @@ int rnad_rollout_bucketed_compact_expand(const rnad_tree_t *tree, int T_cap, int
  * state has one parent entry, so the state a lane was last alive in and the outcome it drew there fix its trajectory -- weighted with
  * the number of lanes that took it: 64-bit integer sums, the same bits.  Pays once the policy has sharpened (fewer distinct
  * trajectories per item), costs ~4 % under uniform policies; the environment variable RNAD_FUSED_DISTINCT=0/1 overrides the flag. */
+/* norm_global (device f64 [2], optional, with RNAD_PLAY_LEARN_FINISH): the finish divides by THESE normalisers instead of the batch's
+ * own -- the N_P of a global batch whose other lanes other ranks play.  On a tree whose episodes all last 2 * max_depth env steps
+ * (rnad_tree_info(tree, 6)) they are known without a collective: N_0 = N_1 = global lanes * T_cap / 2. */
 #define RNAD_PLAY_LEARN_FINISH 1
 #define RNAD_PLAY_LEARN_DISTINCT 2
 int rnad_rollout_learn_bucketed_compact(const rnad_tree_t *tree, int T_cap, int64_t B, const float *table, int64_t table_stride,
@@ -494,8 +497,8 @@ int rnad_rollout_learn_bucketed_compact(const rnad_tree_t *tree, int T_cap, int6
                                         int32_t *lane_ids, int32_t *items, int32_t *n_items, double *norm, void *states, int32_t *alive,
                                         uint64_t *acts, float *final_reward, const int32_t *rep_of, int n_tables, float *const *tables,
                                         const int32_t *floats_per_row, const float *fast_records, const rnad_learn_params_t *hp,
-                                        void *accumulators, int flags, float *dlogit_tab, float *dv_tab, const int32_t *rows,
-                                        const int64_t *n_rows, const rnad_row_groups_t *groups, void *stream);
+                                        void *accumulators, int flags, const double *norm_global, float *dlogit_tab, float *dv_tab,
+                                        const int32_t *rows, const int64_t *n_rows, const rnad_row_groups_t *groups, void *stream);
 int rnad_bucket_indices(const rnad_tree_t *tree, int T1, int64_t B, const void *states, const int32_t *items, const int32_t *n_items,
                         int32_t *indices, void *stream);
 int rnad_bucket_pack_states(const rnad_tree_t *tree, int T1, int64_t B, const int32_t *indices, const int32_t *items,

@@ -2341,8 +2341,9 @@ __global__ __launch_bounds__(kThreads) void k_bucket_finish(int64_t S, int row_b
             n0 += __shfl_xor(n0, off, 64);
             n1 += __shfl_xor(n1, off, 64);
         }
-        nf0 = norm_of(&n0);
-        nf1 = norm_of(&n1);
+        // (`norm` given as well: the caller's normalisers -- those of a global batch -- divide; the rows are still handed out and cleared)
+        nf0 = norm ? norm_of(norm) : norm_of(&n0);
+        nf1 = norm ? norm_of(norm + 1) : norm_of(&n1);
         if (blockIdx.x == 0) alive_from_replicas(T1, alive_rep, norm_rep, alive_out, norm_out);
     } else {
         nf0 = norm_of(norm);
@@ -3057,16 +3058,17 @@ extern "C" int rnad_rollout_bucketed_compact_expand(const rnad_tree_t *tree, int
 // rnad_rollout_bucketed_compact(_expand) and rnad_learn_bucketed_compact of the batch it plays, T = T_cap, in one call: keys, sort, then
 // ONE launch in which every work item's workgroup plays its lanes and adds up their update (k_bucket_play_learn), then the alive
 // counts and -- RNAD_PLAY_LEARN_FINISH -- rnad_bucket_finish with the batch's own normalisers (a data-parallel caller leaves the flag out,
-// all-reduces `norm` and calls rnad_bucket_finish itself).  RNAD_PLAY_LEARN_DISTINCT: the learner half once per distinct trajectory of a
+// all-reduces `norm` and calls rnad_bucket_finish itself; or it hands in norm_global -- the normalisers of the GLOBAL batch, known without
+// a collective on a tree whose episodes all have the same length -- and the finish divides by those).  RNAD_PLAY_LEARN_DISTINCT: the learner half once per distinct trajectory of a
 // work item (struct Distinct).  The trajectory, the counts and the gradient tables are those of the two calls, bit for bit.
 extern "C" int rnad_rollout_learn_bucketed_compact(const rnad_tree_t *tree, int T_cap, int64_t B, const float *table, int64_t table_stride,
                                                    uint64_t seed, int64_t lane0, const rnad_step_params_t *device_params, void *scratch,
                                                    int32_t *lane_ids, int32_t *items, int32_t *n_items, double *norm, void *states,
                                                    int32_t *alive, uint64_t *acts, float *final_reward, const int32_t *rep_of, int n_tables,
                                                    float *const *tables, const int32_t *floats_per_row, const float *fast_records,
-                                                   const rnad_learn_params_t *hp, void *accumulators, int flags, float *dlogit_tab,
-                                                   float *dv_tab, const int32_t *rows, const int64_t *n_rows, const rnad_row_groups_t *groups,
-                                                   void *stream) {
+                                                   const rnad_learn_params_t *hp, void *accumulators, int flags, const double *norm_global,
+                                                   float *dlogit_tab, float *dv_tab, const int32_t *rows, const int64_t *n_rows,
+                                                   const rnad_row_groups_t *groups, void *stream) {
     RNAD_REQUIRE(tree && table && scratch && lane_ids && items && n_items && norm && states && alive && acts && final_reward && fast_records &&
                      hp && accumulators,
                  "rnad_rollout_learn_bucketed_compact: null argument");
@@ -3105,7 +3107,8 @@ extern "C" int rnad_rollout_learn_bucketed_compact(const rnad_tree_t *tree, int 
         RNAD_HIP_OK(hipGetLastError());
         return 0;
     }
-    return finish_impl(tree, p, nullptr, hp, accumulators, nullptr, dlogit_tab, dv_tab, rows, n_rows, groups, (hipStream_t)stream, &cr);
+    RNAD_REQUIRE(norm_global != norm, "rnad_rollout_learn_bucketed_compact: norm_global must not be the `norm` output");
+    return finish_impl(tree, p, norm_global, hp, accumulators, nullptr, dlogit_tab, dv_tab, rows, n_rows, groups, (hipStream_t)stream, &cr);
 }
 
 // The dense buffers of a compact trajectory: slot (t, j) from indices[t, j] (and indices[t + 1, j] for the reward) alone.

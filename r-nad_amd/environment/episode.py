@@ -373,7 +373,7 @@ class Episodes:
                 self.buckets, dlogit, dv = rnad_hip.rollout_learn_bucketed_compact(
                     handle, traj, policy_table[0], learn["fast_records"], learn["hp"], seed=self.seed, lane0=self.lane_offset,
                     step_params=step_params, norm_is_global=learn.get("norm_is_global", True), rows=learn.get("rows"), groups=learn.get("groups"),
-                    distinct=bool(learn.get("distinct", False)))
+                    distinct=bool(learn.get("distinct", False)), norm_global=learn.get("norm_global"))
                 self._learned = dict(records=policy_table[0], dlogit=dlogit, dv=dv)
                 self.lane_ids = self.buckets.lane_ids
                 self._compact = (traj, policy_table[0])

@@ -436,11 +436,28 @@ class RNaD:
             return "forward"
         return mode
 
+    def _known_norm(self, T):
+        """N_P of the GLOBAL batch without a collective (f64 [2] on the device), or None.  On a tree whose episodes all last 2 * max_depth
+        env steps (TreeHandle.uniform_length) every lane is alive at every step of the window: N_0 = N_1 = batch_size * T / 2, whatever the
+        ranks played -- the all-reduce of the normalisers (vtrace.py:373,388 are sums over the whole batch) has nothing to add.
+        RNaD.analytic_norm = False keeps the collective."""
+        handle = self.tree.handle()
+        if not (self._dp() and getattr(self, "analytic_norm", True) and handle.uniform_length and T == 2 * handle.max_depth):
+            return None
+        key = (self.batch_size, T)
+        cached = self.__dict__.get("_known_norm_cache")
+        if cached is None or cached[0] != key:
+            n = float(self.batch_size // self._world * self._world) * T / 2
+            cached = self._known_norm_cache = (key, torch.tensor([n, n], dtype=torch.float64, device=self.device))
+        return cached[1]
+
     def _fuse_now(self):
         """RNaD.fuse_rollout_learner (default on; RNAD_FUSE_PLAY_LEARN=0 turns the default off): rollout and learner of the step in one launch."""
         # (data parallel: off unless asked for -- with two launches the all-reduce of the normalisers runs beside the learner; behind the
-        # one launch it would sit, exposed, between it and the finish: a collective's latency for the 6 us the fusion saves)
-        default = os.environ.get("RNAD_FUSE_PLAY_LEARN", "1") != "0" and not self._dp()
+        # one launch it would sit, exposed, between it and the finish: a collective's latency for the 6 us the fusion saves -- except on
+        # trees whose normalisers need no collective, _known_norm)
+        default = os.environ.get("RNAD_FUSE_PLAY_LEARN", "1") != "0" and (
+            not self._dp() or self._known_norm(2 * self.tree.handle().max_depth) is not None)
         return bool(getattr(self, "fuse_rollout_learner", default))
 
     DISTINCT_AFTER = 4096  # updates after which `distinct_trajectories = None` switches the learner to the distinct trajectories of a work item
@@ -666,7 +683,11 @@ class RNaD:
         # issued first and overlaps the MLP forwards below (RCCL runs it on its own stream).
         norm = episodes.norm_for_learner() if hasattr(episodes, "norm_for_learner") else episodes.valid_counts
         norm_work = None
-        if self._dp():
+        known = (self._known_norm(T) if (self._dp() and getattr(episodes, "buckets", None) is not None
+                                        and B == getattr(self, "batch_size", -1) // self._world) else None)
+        if known is not None:
+            norm = known  # (a uniform-length tree: the global counts are a constant)
+        elif self._dp():
             norm = norm.clone()  # the all-reduce is in place, and the episodes keep their own count
             norm_work = dist.all_reduce(norm, async_op=True)
 
@@ -735,7 +756,8 @@ class RNaD:
                         logit_reg_, _ = self._logits_of(self.net_reg_, episodes, want_value=False, live=fwd_live)  # :380
 
         # the bucketed learner needs the normalisers only in its last kernel: their all-reduce runs beside k_bucket_learn
-        late_norm = bucketed and norm_work is not None
+        # (row sharding finishes late as well: the ranks' per-row sums are all-reduced between the learner and the finish)
+        late_norm = bucketed and (norm_work is not None or (tables is not None and tables.get("shard_rows") is not None))
         if norm_work is not None and not late_norm:
             norm_work.wait()
         hp = self._learn_params(alpha)
@@ -762,6 +784,7 @@ class RNaD:
                         S2 = 2 * self.tree.handle().S
                         dlogit = torch.empty((S2, A), dtype=torch.float32, device=records.device)
                         dv = torch.empty((S2, 1), dtype=torch.float32, device=records.device)
+                        late_norm = True  # (the finish below; nothing to wait for when the normalisers are known)
                 else:
                     assert learned is None, "a batch whose update rode in its rollout can only be learned from as it was played"
                     dlogit, dv, losses = rnad_hip.learn_bucketed_compact(self.tree.handle(), episodes.buckets, compact[0], T, records,
@@ -781,7 +804,8 @@ class RNaD:
                 S_ = self.tree.handle().S
                 dist.all_reduce(plan.accumulators[: 2 * S_ * A1 + rnad_hip.BUCKET_REPLICAS * 2 * max(plan.n_upper, 1) * A1])
             if late_norm:
-                norm_work.wait()
+                if norm_work is not None:
+                    norm_work.wait()
                 rnad_hip.bucket_finish(self.tree.handle(), episodes.buckets, norm, hp, dlogit, dv, losses,
                                        rows=shard if shard is not None else rows_now, groups=grouped)
             if shard is not None:
@@ -940,7 +964,11 @@ class RNaD:
                 grouped = (dedup if (dedup is not None and plan is not None and getattr(self, "group_sums_in_finish", True)
                                      and dedup.groups_below_cut(handle, plan)) else None)
                 if plan is not None:
+                    # (data parallel: the finish is __learn's, after the all-reduce of the normalisers -- or, on a tree whose normalisers
+                    # are known without one, the call's own; row sharding: after an all-reduce of the sums in any case)
+                    known = self._known_norm(T_cap) if not shard else None
                     learn_now = dict(fast_records=tables["fast_records"], hp=self._learn_params(alpha), norm_is_global=not self._dp(),
+                                     norm_global=known,
                                      distinct=self._distinct_now(),
                                      rows=grouped.singles if grouped is not None else tables.get("rows"), groups=grouped)
             episodes.generate(self.net, trim=False, keep_logits=self.reuse_actor_outputs,
@@ -1058,7 +1086,7 @@ class RNaD:
                 self.c_bar, self.roh_bar, self.vtrace_gamma, self.value_weight, self.neurd_weight, self.epsilon_threshold, self.n_discrete,
                 self.gamma_averaging, getattr(self, "obs_half", False), getattr(self, "store_actor_values", False), getattr(self, "fused_optimizer", True),
                 getattr(self, "compact_trajectory", True), getattr(self, "lazy_rows", None), os.environ.get("RNAD_BUCKET_ROWS"), os.environ.get("RNAD_BUCKET_CHUNK"),
-                getattr(self, "fold_legal", True), self._fuse_now(), self._fuse_now() and self._distinct_now(), os.environ.get("RNAD_FUSED_DISTINCT"), os.environ.get("RNAD_FUSED_CHUNK"))
+                getattr(self, "fold_legal", True), self._fuse_now(), self._fuse_now() and self._distinct_now(), getattr(self, "analytic_norm", True), os.environ.get("RNAD_FUSED_DISTINCT"), os.environ.get("RNAD_FUSED_CHUNK"))
 
     def _graph_step(self, buffer, alpha):
         g = getattr(self, "_graph", None)

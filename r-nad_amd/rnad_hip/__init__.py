@@ -924,12 +924,14 @@ PLAY_LEARN_FINISH, PLAY_LEARN_DISTINCT = 1, 2  # include/rnad_hip.h
 
 
 def rollout_learn_bucketed_compact(tree, traj, records, fast_records, hp, seed=0, lane0=0, step_params=None, norm_is_global=True, rows=None,
-                                   groups=None, distinct=False):
+                                   groups=None, distinct=False, norm_global=None):
     """rnad_rollout_learn_bucketed_compact: rollout_bucketed_compact(records) and learn_bucketed_compact of the batch it plays (T = T_cap)
     with ONE launch for rollout + learner -- the trajectory, traj.alive, buckets.norm and the per-row gradient tables of the two calls, bit
     for bit.  records: bucket_records(..., fast=True)[0] (its policy rows are the actor; a pending rows_expand job rides in the keys pass).
     norm_is_global=False (data parallel): stops before k_bucket_finish -- all-reduce buckets.norm, then bucket_finish(...).
     distinct: the learner half once per distinct trajectory of a (larger) work item, weighted with its lanes (RNAD_PLAY_LEARN_DISTINCT).
+    norm_global (f64 [2], device): the finish divides by these normalisers -- those of a global batch -- instead of the batch's own
+    (buckets.norm still receives the batch's own counts); implies the finish.
     Returns (buckets, dlogit, dv); the tables are None when the finish is left to the caller."""
     assert traj.compact and traj.T_cap <= COMPACT_MAX_STEPS
     plan = bucket_plan(tree, traj.B)
@@ -954,6 +956,7 @@ def rollout_learn_bucketed_compact(tree, traj, records, fast_records, hp, seed=0
         widths = (C.c_int32 * n_tabs)(*[int(t.shape[1]) for t in tabs])
         rep_of = _dp(dedup.rep_of, I32, "rep_of")
     dev, A = traj.device, tree.A
+    norm_is_global = bool(norm_is_global) or norm_global is not None
     dlogit = torch.empty((2 * tree.S, A), dtype=F32, device=dev) if norm_is_global else None
     dv = torch.empty((2 * tree.S, 1), dtype=F32, device=dev) if norm_is_global else None
     _check(lib().rnad_rollout_learn_bucketed_compact(
@@ -963,7 +966,8 @@ def rollout_learn_bucketed_compact(tree, traj, records, fast_records, hp, seed=0
         _dp(traj.states, traj.states.dtype, "states"), _dp(traj.alive, I32, "alive"), _dp(traj.acts, torch.int64, "acts"),
         _dp(traj.final_reward, F32, "final_reward"), rep_of, n_tabs, ptrs, widths, _dp(fast_records, F32, "fast_records"), C.byref(hp),
         _dp(plan.accumulators, torch.int64, "accumulators"),
-        (PLAY_LEARN_FINISH if norm_is_global else 0) | (PLAY_LEARN_DISTINCT if distinct else 0), _dp(dlogit, F32, "dlogit_tab", True),
+        (PLAY_LEARN_FINISH if norm_is_global else 0) | (PLAY_LEARN_DISTINCT if distinct else 0), _dp(norm_global, F64, "norm_global", True),
+        _dp(dlogit, F32, "dlogit_tab", True),
         _dp(dv, F32, "dv_tab", True), *_row_list(rows), groups, _stream()))
     if pending is not None:
         records._expand = None

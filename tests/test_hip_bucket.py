@@ -835,3 +835,13 @@ def test_rollout_and_learner_in_one_launch(name, B, rows, distinct, monkeypatch)
     dv3 = torch.empty_like(dv)
     rnad_hip.bucket_finish(h, bk3, bk3.norm, hp, dl3, dv3)
     assert torch.equal(dl3, want[0]) and torch.equal(dv3, want[1])
+    # the normalisers of a global batch handed in (norm_global): the finish divides by those, the batch's own counts are still handed out
+    g = (bk2.norm * 3).clone()
+    part = traj()
+    bk4, _, _ = rnad_hip.rollout_learn_bucketed_compact(h, part, rec, fast, hp, seed=21, lane0=77, norm_is_global=False, distinct=distinct)
+    dl4, dv4 = torch.empty_like(dlogit), torch.empty_like(dv)
+    rnad_hip.bucket_finish(h, bk4, g, hp, dl4, dv4)
+    glob = traj()
+    bk5, dl5, dv5 = rnad_hip.rollout_learn_bucketed_compact(h, glob, rec, fast, hp, seed=21, lane0=77, norm_global=g, distinct=distinct)
+    assert torch.equal(bk5.norm, bk2.norm) and torch.equal(glob.alive, two.alive)
+    assert torch.equal(dl5, dl4) and torch.equal(dv5, dv4)

@@ -227,3 +227,64 @@ def test_row_sharding_gives_the_one_process_row_sums(tmp_path, world):
             np.testing.assert_allclose(got[k], repl[k], rtol=2e-5, atol=2e-7, err_msg=k)
             np.testing.assert_allclose(got[k], single[k], rtol=2e-5, atol=2e-7, err_msg=k)
     assert seen.all()
+
+
+def _uniform_steps(tmp, tag, count=None):
+    from environment.episode import Buffer
+    from environment.tree import Tree
+    from learn.rnad import RNaD
+
+    dev = torch.device("cuda:0")
+    os.environ["RNAD_SAVE_DIR"] = os.path.join(tmp, tag)
+    tree = Tree(device=dev, max_actions=3, max_transitions=1, depth_bound=4)
+    tree.generate_native(seed=0)
+    assert tree.handle().uniform_length
+    torch.manual_seed(SEED)
+    rn = RNaD(tree=tree, device=dev, directory_name="un", batch_size=1 << 13, eta=0.2, b1_adam=0.0, lr=1e-3,
+              net_params={"type": "MLP", "max_actions": 3, "width": 64})
+    rn.initialize()
+    rn.use_graph = False
+    buf = Buffer(1)
+    if count is not None:
+        count["all_reduce"] = 0
+    for i in range(3):
+        rn.train_step(buf, alpha=0.2 * i)
+        rn.total_steps += 1
+    torch.cuda.synchronize()
+    fused = getattr(rn.last_episodes, "_compact", None) is not None and rn._fuse_now()
+    return {k: v.detach().cpu().numpy() for k, v in rn.net.state_dict().items()}, fused
+
+
+def _uniform_worker(rank, world, port, tmp):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    count = {"all_reduce": 0}
+    real = dist.all_reduce
+
+    def counting(t, *a, **kw):
+        count["all_reduce"] += 1
+        return real(t, *a, **kw)
+
+    dist.all_reduce = counting
+    try:
+        params, fused = _uniform_steps(tmp, f"u{rank}", count)
+        np.savez(os.path.join(tmp, f"un_{rank}.npz"), n_all_reduce=count["all_reduce"], fused=fused, **params)
+    finally:
+        dist.all_reduce = real
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_two_ranks_on_a_uniform_tree_need_no_collective_for_the_normalisers(tmp_path):
+    """Every episode of an unpruned tree lasts 2 * depth env steps, so the loss normalisers of the GLOBAL batch are batch_size * T / 2
+    whatever the ranks played (RNaD._known_norm): the step all-reduces its 43 KB of gradients and nothing else, rollout and learner share
+    one launch on every rank, and two ranks still train like one process."""
+    single, _ = _uniform_steps(str(tmp_path), "single")
+    mp.spawn(_uniform_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = (np.load(tmp_path / f"un_{r}.npz") for r in range(2))
+    assert int(r0["n_all_reduce"]) == 3 and int(r1["n_all_reduce"]) == 3, "one all-reduce per step: the gradient bucket"
+    assert bool(r0["fused"]) and bool(r1["fused"])
+    for k, want in single.items():
+        np.testing.assert_array_equal(r0[k], r1[k])
+        np.testing.assert_allclose(r0[k], want, rtol=2e-5, atol=2e-7, err_msg=k)  # (the ranks' gradient sums meet in another fp32 order)
