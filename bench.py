@@ -435,7 +435,9 @@ def main():
                             + f" x T={T_ref} env steps, MLP width {args.width}" + which,
                 "global_batch": global_batch, "per_gpu_batch": local_batch, "T": T_ref, "T_buffer": T,
                 "valid_env_steps_per_step": live_slots * world,
-                "parallelism": f"dp{world} (episodes sharded, RCCL all-reduce of 2 normalisers + 43 KB grads)",
+                "parallelism": f"dp{world} (episodes sharded, RCCL all-reduce of 43 KB grads"
+                               + ("; the normalisers of this tree need no collective: every episode has the same length)"
+                                  if tree.handle().uniform_length else " + 2 normalisers)"),
             },
             "updates_per_sec": args.steps / elapsed,
             "host_enqueue_ms_per_step": host_s / host_n * 1e3,
