@@ -445,6 +445,8 @@ def main():
                                "in_effect": repr(mode_now), "what": what[mode_now],
                                "step_replayed_from_hipGraph": replayed, "compact_trajectory": bool(args.compact_in_effect),
                                "rollout_and_learner_in_one_launch": bool(getattr(args, "fused_play_learn", False)),
+                               # (RNaD.distinct_trajectories: by itself only after RNaD.DISTINCT_AFTER = 4096 updates -- not within a default run)
+                               "learner_on_distinct_trajectories_at_the_end": bool(rn._fuse_now() and rn._distinct_now()),
                                "lazy_rows_visited": args.visited_rows or None, "staged_policy_rows": args.policy_rows or None,
                                "rows_after_dedup": args.unique_rows or None,  # (RNaD.dedup_rows: rows with distinct observation bits)
                                "legal_fold": args.fold,
