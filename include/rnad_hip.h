@@ -23,10 +23,12 @@
  *   - fp32 arithmetic follows the reference's operation order and is compiled with
  *     -ffp-contract=off; integer results are bit-exact, fp32 results within 1e-5 (exp/log use the
  *     device libm).
- *   - one host thread per GPU; handles are not thread-safe.  ONE trainer per (tree handle, batch size) and device at a time:
- *     the `scratch` / `accumulators` workspaces of the bucketed pipeline are shared by every call made with them, and
- *     rnad_optimizer_step keeps one device-global ticket counter -- two updates in flight on different streams of one device
- *     would race on both (one process per GPU with one training stream, the arrangement of learn/rnad.py, never does).
+ *   - one host thread per GPU; handles are not thread-safe.  The library keeps NO mutable device state of its own: the tree
+ *     handle's tables are read-only after rnad_tree_create / the first rnad_bucket_plan of a cut, and everything a call writes is a
+ *     caller-owned buffer -- the `scratch` / `accumulators` workspaces of the bucketed pipeline, the ticket word of
+ *     rnad_optimizer_step.  Two trainers on one device (the `for eta in ...` loop of main.py:55-81 run side by side, an evaluation
+ *     beside a training run) are safe on different streams as long as each brings its OWN workspaces; calls that share a workspace
+ *     must be ordered by a stream (r-nad_amd/rnad_hip gives every RNaD object its own: rnad_hip.workspace_owner).
  */
 #ifndef RNAD_HIP_H
 #define RNAD_HIP_H
@@ -614,7 +616,9 @@ int rnad_clip_grad_norm(int64_t n, float *grads, float max_norm, float *total_no
  * the order rnad_mlp_pack takes them, and every new weight / new target weight is ALSO written into its slot of that net's packed
  * image (rnad_mlp_pack's layout; mlp_fold != 0: rnad_mlp_pack_fold_multi's) -- the images stay current without a pack launch per
  * step.  mlp_A == 0: none of this.  advance (optional, device memory): see rnad_step_queue_t -- the workgroup that finishes last moves the
- * queue of per-step scalars on. */
+ * queue of per-step scalars on.  ticket (device, one uint32 the caller zero-initialises ONCE and then leaves alone): the kernel's
+ * workgroups count themselves in it and the last one resets it -- one word per optimiser, so that two trainers stepping on two streams
+ * of one device do not share a counter. */
 typedef struct rnad_adam_params {
     float lr, beta1, beta2, eps;  /* rnad.py:232-237 */
     float max_norm;               /* grad_clip, rnad.py:456 */
@@ -622,7 +626,8 @@ typedef struct rnad_adam_params {
 } rnad_adam_params_t;
 int rnad_optimizer_step(int n_tensors, const int64_t *sizes, float *const *param, float *grads, float *const *exp_avg,
                         float *const *exp_avg_sq, float *const *step, float *const *target, const rnad_adam_params_t *hp,
-                        float *total_norm, int mlp_A, int mlp_W, int mlp_fold, float *packed_param, float *packed_target, rnad_step_queue_t *advance, void *stream);
+                        float *total_norm, int mlp_A, int mlp_W, int mlp_fold, float *packed_param, float *packed_target, rnad_step_queue_t *advance,
+                        uint32_t *ticket, void *stream);
 /* ------------------------------------------------------------------------------------------------
  * NashConv  --  util/metric.py:93-175 (NashConvData.get_nashconv), level-batched on the GPU
  * instead of one Python frame per state.  joint_policy f32 [S,2A] (device) for every state below

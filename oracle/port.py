@@ -31,7 +31,12 @@ class CpuMLP(torch.nn.Module):
 
 
 class CpuTrainer:
-    def __init__(self, tree_arrays, width=256, lr=5e-5, eta=0.2, gamma_averaging=0.001, seed=0):
+    """The hyper-parameters are the reference's defaults (rnad.py:40-64); `state_dicts` (net, net_target, net_reg, net_reg_: the four
+    state_dicts of a trainer, reference key names) starts from given weights instead of fresh ones -- how tests/test_hip_e2e.py runs this
+    port in lock step with the GPU trainer.  keep=True: the last step's rollout and gradients stay in self.last."""
+
+    def __init__(self, tree_arrays, width=256, lr=5e-5, eta=0.2, gamma_averaging=0.001, seed=0, state_dicts=None, n_discrete=32,
+                 epsilon_threshold=0.03, neurd_clip=1e3, logit_clip=2.0, grad_clip=1e3, betas=(0.0, 0.999), eps=1e-8, keep=False):
         torch.manual_seed(seed)
         self.tree = tree_arrays
         self.A = tree_arrays["index"].shape[-1]
@@ -39,15 +44,21 @@ class CpuTrainer:
         self.net_target, self.net_reg, self.net_reg_ = (CpuMLP(self.A, width) for _ in range(3))
         for n in (self.net_target, self.net_reg, self.net_reg_):
             n.load_state_dict(self.net.state_dict())
-        self.opt = torch.optim.Adam(self.net.parameters(), lr=lr, betas=(0.0, 0.999), eps=1e-8)
+        if state_dicts is not None:
+            for n, sd in zip((self.net, self.net_target, self.net_reg, self.net_reg_), state_dicts):
+                n.load_state_dict({k: v.detach().to("cpu", torch.float32).clone() for k, v in sd.items()})
+        self.opt = torch.optim.Adam(self.net.parameters(), lr=lr, betas=(float(betas[0]), float(betas[1])), eps=eps)
         self.eta, self.gamma_averaging = eta, gamma_averaging
+        self.n_discrete, self.epsilon_threshold = int(n_discrete), float(epsilon_threshold)
+        self.neurd_clip, self.logit_clip, self.grad_clip = float(neurd_clip), float(logit_clip), float(grad_clip)
         self.T_cap = 2 * int(tree_arrays["depth_bound"])
+        self.keep, self.last = bool(keep), None
 
-    def step(self, B, seed, alpha=0.5):
+    def step(self, B, seed, alpha=0.5, lane0=0):
         """One iteration; returns (T, rollout seconds, update seconds)."""
         A = self.A
         t0 = time.perf_counter()
-        ro = oracle.rollout(self.tree, self.net.weights(), B, self.T_cap, seed)  # episode.py:175-230
+        ro = oracle.rollout(self.tree, self.net.weights(), B, self.T_cap, seed, lane0=lane0)  # episode.py:175-230
         t1 = time.perf_counter()
         T = ro["T"]
         obs = torch.from_numpy(ro["observations"].reshape(T * B, 2 * A * A))
@@ -60,7 +71,7 @@ class CpuTrainer:
         pi, log_pi = oracle.policy_head(logit.detach().numpy(), masks)
         _, log_r = oracle.policy_head(lr.numpy(), masks)
         _, log_r_ = oracle.policy_head(lr_.numpy(), masks)
-        pip = oracle.process_policy(pi, masks, 32, 0.03)  # rnad.py:374
+        pip = oracle.process_policy(pi, masks, self.n_discrete, self.epsilon_threshold)  # rnad.py:374
         lpol = (log_pi - (np.float32(alpha) * log_r + np.float32(1 - alpha) * log_r_)).reshape(T, B, A)  # :382
         valid = (ro["indices"] != 0).astype(np.float32)
         turns = np.broadcast_to((np.arange(T) % 2)[:, None], (T, B)).astype(np.int64)
@@ -72,9 +83,11 @@ class CpuTrainer:
                                       p, self.eta, 1.0, 1.0, 1.0, 1.0)
             vts.append(vt); hps.append(hp); qs.append(q)  # noqa: E702
         _, dv = oracle.loss_v(v.detach().numpy(), vts[0], vts[1], hps[0], hps[1])  # rnad.py:407
-        _, dl = oracle.loss_nerd(logit.detach().numpy(), pip, qs[0], qs[1], valid, turns, masks, 1e3, 2.0)  # :412-422
+        _, dl = oracle.loss_nerd(logit.detach().numpy(), pip, qs[0], qs[1], valid, turns, masks, self.neurd_clip, self.logit_clip)  # :412-422
         torch.autograd.backward([logit, v], [torch.from_numpy(dl).view_as(logit), torch.from_numpy(dv).view_as(v)])  # :425
-        torch.nn.utils.clip_grad_norm_(self.net.parameters(), 1e3)
+        torch.nn.utils.clip_grad_norm_(self.net.parameters(), self.grad_clip)  # :456
+        if self.keep:
+            self.last = dict(rollout=ro, grads={k: p.grad.detach().clone() for k, p in self.net.named_parameters()})
         self.opt.step()
         self.opt.zero_grad()
         with torch.no_grad():  # EMA target, rnad.py:516-523

@@ -63,6 +63,7 @@ constexpr int kSharedRoot = 256;      // flag in bucket_path: the group is one s
 constexpr int kFinishRows = 4;        // rows per thread of k_bucket_finish
 constexpr int kTicketGroups = 64;     // first-level tickets of k_bucket_finish's last-workgroup election
 constexpr int kTargetLanes = 1024;   // finest cut whose groups still hold this many lanes on average (configs[1]: full work items win)
+constexpr int kMinLanesLevelCut = 128;  // a level cut (one group per subtree) is taken while its groups hold this many lanes on average
 
 inline unsigned blocks_for(int64_t n, int per = kThreads) { return (unsigned)((n + per - 1) / per); }
 
@@ -285,6 +286,24 @@ int choose_rows(const rnad_tree_t *tree, int64_t B, int forced, int rows_max) {
             chosen = rows;
         }
     } else {
+        // r05, measured (tools/cut_sweep.sh, profiles/r05_cut_sweep.txt: the configs[1] tree at 2^18 .. 2^22 lanes, tables of 35 .. 563
+        // rows): what k_bucket_play_learn pays for is not the number of steps below the cut but (1) groups that are runs of SEVERAL
+        // sibling subtrees -- their lanes keep decision words of their own and replay the steps above the cut per lane -- and (2) two-byte
+        // relative states; the cut "one level of the tree = one group per subtree" at one byte per state won at every batch size (2^19:
+        // 142.7 us per step against 156.2 for the runs of three the halving below arrives at; 2^22: 420.9 against 507.0 for its 6 561
+        // groups of ten states, whose keys pass walks a level more in lane order).  So: the COARSEST level cut -- a table the size of the
+        // largest subtree of a level -- whose groups are all single subtrees with one-byte states, as long as a group still receives a
+        // few wavefronts of lanes on average; trees without such a level (ragged subtrees packed into runs) fall through to the halving.
+        for (int l = 0; l < tree->n_levels && !chosen; ++l) {
+            const int64_t rows = tree->level_max_subtree[(size_t)l];
+            if (rows < 1 || rows > rows_max || rows > 255) continue;
+            const HostCut c = build_cut(tree, (int)rows);
+            if (!cut_fits(c) || c.n_groups < 1 || B / c.n_groups < kMinLanesLevelCut) break;  // (deeper levels only have more groups)
+            bool single = true;
+            for (int g = 0; g < c.n_groups && single; ++g) single = (c.path[(size_t)g] & kSharedRoot) != 0;
+            if (single) chosen = (int)rows;
+        }
+        if (chosen) return chosen;
         for (int rows = rows_max; rows >= 4; rows /= 2) {
             const HostCut c = build_cut(tree, rows);
             if (!cut_fits(c)) {
@@ -576,9 +595,9 @@ struct KeysExpand {
     float4 *tab[4] = {nullptr, nullptr, nullptr, nullptr};
     int quads[4] = {0, 0, 0, 0};
 };
-__device__ __forceinline__ void keys_expand_share(const KeysExpand &ex, int n_threads) {
-    // workgroup b copies the rows [b * per, (b + 1) * per); a thread per (row, 16-byte chunk of the widest table)
-    const int64_t per = (ex.rows + gridDim.x - 1) / gridDim.x, r0 = (int64_t)blockIdx.x * per;
+__device__ __forceinline__ void keys_expand_share(const KeysExpand &ex, int n_threads, int block, int n_blocks) {
+    // workgroup b of n_blocks copies the rows [b * per, (b + 1) * per); a thread per (row, 16-byte chunk of the widest table)
+    const int64_t per = (ex.rows + n_blocks - 1) / n_blocks, r0 = (int64_t)block * per;
     const int64_t r1 = r0 + per < ex.rows ? r0 + per : ex.rows;
     for (int64_t i = r0 * ex.max_quads + threadIdx.x; i < r1 * ex.max_quads; i += n_threads) {
         const int64_t r = i / ex.max_quads;
@@ -617,7 +636,8 @@ __global__ __launch_bounds__(kSortThreads) void k_bucket_keys_lds(const UpperWal
         if (ex.rep_of) row = ex.rep_of[row];  // (the row's own copy may not have been written yet)
         pol[i] = a < A ? policy_tab[row * tab_stride + a] : 0.0f;
     }
-    if (ex.rep_of) keys_expand_share(ex, kSortThreads);  // (its stores are in flight during the walk)
+    // (r04 made the copies here, "in flight during the walk": 19 MB through the B / 4096 workgroups of this launch -- 64 of them at 2^18
+    // lanes, 27 us where the walk alone takes 9.  r05: extra workgroups of the scan launch that follows, k_bucket_scan)
     for (int i = threadIdx.x; i < n_buckets; i += kSortThreads) cnt[i] = 0;
     if (blockIdx.x == 0 && threadIdx.x == 0 && norm) norm[0] = norm[1] = 0.0;  // summed up by k_bucket_alive at the end of this rollout
     if (blockIdx.x == 0 && threadIdx.x == 0 && stage.counts) stage.counts[0] = stage.counts[1] = 0ull;
@@ -1074,8 +1094,15 @@ __device__ __forceinline__ void items_phase(int n_buckets, int chunk, const int3
 // (The items were tried in this kernel's last workgroup, elected by a ticket: the device-scope release / acquire fences that the
 // election needs -- the workgroups sit on different XCDs -- write back whatever the previous kernels left dirty in the L2s:
 // 14.5 us against 5.2 + 5.6 for two launches.  They ride in k_bucket_scatter instead.)
+// r05: the launch also carries the copies of the distinct observations' records (KeysExpand: nothing between the table launch and the
+// rollout reads the rows of non-representatives -- the keys pass reads the upper rows through rep_of) in workgroups of its own behind the
+// scan's: the scan is a launch floor with a handful of workgroups, the copies fill the rest of the chip at memory speed.
 __global__ __launch_bounds__(kSortThreads) void k_bucket_scan(int n_blocks, int n_buckets, int32_t *__restrict__ hist,
-                                                              int32_t *__restrict__ totals) {
+                                                              int32_t *__restrict__ totals, int scan_blocks, KeysExpand ex) {
+    if ((int)blockIdx.x >= scan_blocks) {
+        keys_expand_share(ex, kSortThreads, (int)blockIdx.x - scan_blocks, (int)gridDim.x - scan_blocks);
+        return;
+    }
     __shared__ int32_t part[kScanParts][kScanCols + 1];
     const int col = threadIdx.x & (kScanCols - 1), g = threadIdx.x / kScanCols;
     const int c = blockIdx.x * kScanCols + col;
@@ -2798,7 +2825,7 @@ int rollout_bucketed_impl(const rnad_tree_t *tree, const RolloutBuffers &tr, boo
                                                         tree->C, S, B, n_steps, policy_tab, policy_stride, (int)p.cut->host_bucket_of[1],
                                                         p.cut->n_groups, seed, device_params, lane0, s.keys, s.decisions, s.hist, norm, stage,
                                                         expand ? *expand : KeysExpand{}));
-            expand = nullptr;  // (done)
+            // (the copies themselves: workgroups of the scan launch below)
         } else if (p.cut->upper_walk && p.cut->n_hot > 0 && p.cut->n_hot < p.cut->n_upper && !walk_global &&
                    !(getenv("RNAD_KEYS_HYBRID") && atoi(getenv("RNAD_KEYS_HYBRID")) == 0)) {
             // the top levels of the upper states in LDS, the rest from the global tables
@@ -2823,7 +2850,17 @@ int rollout_bucketed_impl(const rnad_tree_t *tree, const RolloutBuffers &tr, boo
     if (sort_phase) {
         ProfScope sort_passes(PROF_BUCKET_SORT, stream);
         if (!keys_with_hist) hipLaunchKernelGGL(k_bucket_hist, dim3(p.sort_blocks), dim3(kSortThreads), lds, stream, B, nb, (const int32_t *)s.keys, s.hist);
-        hipLaunchKernelGGL(k_bucket_scan, dim3((nb + kScanCols - 1) / kScanCols), dim3(kSortThreads), 0, stream, p.sort_blocks, nb, s.hist, s.totals);
+        {
+            const int scan_blocks = (nb + kScanCols - 1) / kScanCols;
+            int copy_blocks = 0;
+            if (expand) {  // a thread per (row, 16-byte chunk) and pass; two passes per thread keep the launch at a few hundred workgroups
+                copy_blocks = (int)std::min<int64_t>(1024, std::max<int64_t>(1, (expand->rows * expand->max_quads + 2 * kSortThreads - 1) / (2 * kSortThreads)));
+                if (const char *e = getenv("RNAD_EXPAND_BLOCKS")) copy_blocks = std::max(1, atoi(e));  // tuning knob
+            }
+            hipLaunchKernelGGL(k_bucket_scan, dim3(scan_blocks + copy_blocks), dim3(kSortThreads), 0, stream, p.sort_blocks, nb, s.hist, s.totals,
+                               scan_blocks, expand ? *expand : KeysExpand{});
+            expand = nullptr;  // (done)
+        }
         // bucket_start | first item of every bucket | as many counter rows as fit the LDS (16 waves share them in turns)
         int wave_rows = 16;
         while (wave_rows > 1 && ((2 + wave_rows) * (size_t)nb + 1) * sizeof(int32_t) > kKeysLds) wave_rows >>= 1;

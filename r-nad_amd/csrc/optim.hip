@@ -31,8 +31,9 @@ struct OptTensors {
 // go straight into Adam; nothing reads .grad between clip_grad_norm_ and zero_grad in learn/rnad.py:456-514), so a workgroup may
 // still be summing while another one updates.  The per-tensor pointers and Adam scalars sit in LDS (indexed per lane without
 // waterfall loops).  The step counters are advanced by whichever workgroup takes the last ticket: by then all have read them.
+// The ticket counter is the CALLER's (one zero-initialised word per optimiser: two trainers stepping on two streams of one device
+// each count their own workgroups).
 constexpr int kNormBatch = 8;
-__device__ unsigned int g_ticket = 0;  // one optimiser step at a time per device (one process per GPU, one training stream)
 
 // Where element e of Linear tensor k (MLP_KEYS order: value_fc0.weight, .bias, value_fc1.weight, .bias, policy_fc0.weight, ...) sits in
 // the packed LDS image the MLP kernels read (mlp_common.hpp; k_mlp_pack is the forward map).
@@ -63,7 +64,7 @@ __device__ __forceinline__ int image_index(int k, int e, int A, int W, bool fold
 __global__ __launch_bounds__(kOptThreads) void k_optimizer_step(OptTensors ts, const float *__restrict__ grads, rnad_adam_params_t hp,
                                                                 float *__restrict__ total_norm, int mlp_A, int mlp_W, int mlp_fold,
                                                                 float *__restrict__ packed_param, float *__restrict__ packed_target,
-                                                                rnad_step_queue_t *__restrict__ advance) {
+                                                                rnad_step_queue_t *__restrict__ advance, unsigned int *__restrict__ ticket) {
     __shared__ double part[kOptThreads / 64];
     __shared__ float coef_s, step_size_s[kMaxTensors], bc2s_s[kMaxTensors];
     __shared__ float *ptr_s[4][kMaxTensors];
@@ -114,8 +115,8 @@ __global__ __launch_bounds__(kOptThreads) void k_optimizer_step(OptTensors ts, c
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-        if (atomicAdd(&g_ticket, 1u) == gridDim.x - 1) {
-            g_ticket = 0;
+        if (atomicAdd(ticket, 1u) == gridDim.x - 1) {
+            *ticket = 0;
             for (int t = 0; t < ts.n; ++t) *ts.step[t] += 1.0f;
             if (advance) {  // the step is over: the scalars of the next one (every reader of `live` ran in an earlier launch)
                 const int64_t c = advance->cursor + 1;
@@ -153,8 +154,8 @@ __global__ __launch_bounds__(kOptThreads) void k_optimizer_step(OptTensors ts, c
 extern "C" int rnad_optimizer_step(int n_tensors, const int64_t *sizes, float *const *param, float *grads, float *const *exp_avg,
                                    float *const *exp_avg_sq, float *const *step, float *const *target, const rnad_adam_params_t *hp,
                                    float *total_norm, int mlp_A, int mlp_W, int mlp_fold, float *packed_param, float *packed_target,
-                                   rnad_step_queue_t *advance, void *stream) {
-    RNAD_REQUIRE(sizes && param && grads && exp_avg && exp_avg_sq && step && hp, "rnad_optimizer_step: null argument");
+                                   rnad_step_queue_t *advance, uint32_t *ticket, void *stream) {
+    RNAD_REQUIRE(sizes && param && grads && exp_avg && exp_avg_sq && step && hp && ticket, "rnad_optimizer_step: null argument");
     if (mlp_A > 0) {
         RNAD_REQUIRE(n_tensors == 8 && mlp_A <= RNAD_MAX_ACTIONS && mlp_W >= rnad_mlp::kTile && mlp_W % rnad_mlp::kTile == 0,
                      "rnad_optimizer_step: packed images go with the 8 Linear tensors of the fused MLP (A=%d, width=%d)", mlp_A, mlp_W);
@@ -176,7 +177,7 @@ extern "C" int rnad_optimizer_step(int n_tensors, const int64_t *sizes, float *c
     const unsigned grid = (unsigned)std::max<int64_t>(1, (ts.offset[n_tensors] + kOptThreads - 1) / kOptThreads);
     RNAD_REQUIRE(!mlp_fold || mlp_A >= 2, "rnad_optimizer_step: the legal fold needs at least two actions");
     hipLaunchKernelGGL(k_optimizer_step, dim3(grid), dim3(kOptThreads), 0, (hipStream_t)stream, ts, (const float *)grads, *hp, total_norm, mlp_A,
-                       mlp_W, mlp_fold, mlp_A > 0 ? packed_param : nullptr, mlp_A > 0 ? packed_target : nullptr, advance);
+                       mlp_W, mlp_fold, mlp_A > 0 ? packed_param : nullptr, mlp_A > 0 ? packed_target : nullptr, advance, (unsigned int *)ticket);
     RNAD_HIP_OK(hipGetLastError());
     return 0;
 }

@@ -195,16 +195,32 @@ class RNaD:
     def _world(self):
         return dist.get_world_size() if self._dp() else 1
 
-    def _shard_now(self, handle, local_batch, log, lazy):
-        """Row sharding applies: asked for, more than one rank, the default per-row step with the fused table launch, not a logging step."""
+    def _plays_what_it_learns(self, handle, local_batch, T_cap, buffer):
+        """This step plays its batch with the compact bucketed rollout and learns from exactly that batch, in bucket order: a one-batch
+        buffer refilled every step (Buffer.sample then hands the batch back in place, buckets and all).  ONE predicate for everything
+        that relies on it -- the record tables written for a subset of the rows only (distinct observations, row sharding: their logit /
+        v / v_target tables are valid in the listed rows alone, which only the bucketed learner never reads), the copies of the distinct
+        observations' records carried by the rollout's keys pass, lazy rows, the one-launch rollout + learner.  Episodes.generate's own
+        `compact` condition is the same list (environment/episode.py)."""
+        return bool(self.buffer_mod == 1 and getattr(buffer, "max_size", None) == 1 and getattr(self, "compact_trajectory", True)
+                    and T_cap <= rnad_hip.COMPACT_MAX_STEPS and not self.reuse_actor_outputs
+                    and not getattr(self, "store_actor_values", False) and rnad_hip.bucket_plan(handle, local_batch) is not None)
+
+    def _shard_now(self, handle, local_batch, log, lazy, on_policy=True):
+        """Row sharding applies: asked for, more than one rank, the default per-row step with the fused table launch, not a logging step,
+        the batch learned from in bucket order (_plays_what_it_learns), and the GLOBAL batch within the headroom of the 64-bit per-row sums
+        (csrc/bucket.hip kLaneBits: one addend per lane of up to 2^22 lanes -- the all-reduce adds every rank's lanes into one sum)."""
         A = self.tree.max_actions
-        return bool(getattr(self, "shard_rows", False) and self._dp() and self._world > 1 and log is None and not lazy
+        return bool(getattr(self, "shard_rows", False) and self._dp() and self._world > 1 and log is None and not lazy and on_policy
+                    and self.batch_size <= rnad_hip.BUCKET_MAX_LANES
                     and rnad_hip.mlp_rows_records_supported(A, self.net.width, self._fold())
                     and rnad_hip.bucket_plan(handle, local_batch) is not None)
 
-    def _dedup_now(self, handle, log, lazy, shard, fold):
-        """TreeHandle.obs_dedup() when the step should evaluate the nets on distinct observations only, else None."""
-        if not getattr(self, "dedup_rows", True) or log is not None or lazy or shard:
+    def _dedup_now(self, handle, log, lazy, shard, fold, on_policy=True):
+        """TreeHandle.obs_dedup() when the step should evaluate the nets on distinct observations only, else None.  on_policy:
+        _plays_what_it_learns -- any other step (a replay buffer of several batches, stored actor values) reads the per-row logit / value
+        tables, which the launch on the representatives leaves unwritten in every other row."""
+        if not getattr(self, "dedup_rows", True) or log is not None or lazy or shard or not on_policy:
             return None
         if not rnad_hip.mlp_rows_records_supported(self.tree.max_actions, self.net.width, fold):
             return None
@@ -716,6 +732,11 @@ class RNaD:
             per_row_backward = False  # a batch that is not bucket-ordered (a replay sample) beyond the atomics kernel's 2^21 lanes: per-slot backward
         if not bucketed and getattr(episodes, "buckets", None) is not None:
             rnad_hip.bucket_alive(self.tree.handle(), episodes.buckets)  # (a no-op unless the rollout left its alive counts to the compact learner)
+        if table is not None and not bucketed and (tables.get("dedup") is not None or tables.get("shard_rows") is not None):
+            # (_plays_what_it_learns keeps _step_body from getting here; a caller who hands such tables in with another batch is told)
+            raise RuntimeError("these tables hold the nets' outputs for the representatives of the distinct observations (or for one rank's "
+                               "rows) only: a batch that is not bucket-ordered gathers logit / v / v_target from EVERY row -- evaluate "
+                               "the tables on all rows for it (_table_outputs without dedup / shard)")
         live, capacity = None, None
         if (not per_row_backward and getattr(self, "skip_absorbed", True) and log is None and fused_mlp
                 and not self.tree.handle().uniform_length):
@@ -919,9 +940,18 @@ class RNaD:
         then only rewrites the 16 bytes of per-step scalars (noise seed, alpha: struct rnad_step_params in device memory) and
         launches the graph -- ~30 launches and their Python bookkeeping become one call.  Same kernels, same inputs: the replayed
         steps are bit-identical to the eager ones (tests/test_hip_graph.py)."""
-        if self._graph_eligible(buffer, log):
-            return self._graph_step(buffer, alpha)
-        return self._step_body(buffer, alpha, log)
+        # this trainer's own workspaces of the bucketed pipeline (sort scratch, the learner's 64-bit accumulators, staging buffers): a
+        # second trainer over the same tree and batch size -- main.py:55-81 builds several -- may step on another stream meanwhile
+        with rnad_hip.workspace_owner(self._workspace_token()):
+            if self._graph_eligible(buffer, log):
+                return self._graph_step(buffer, alpha)
+            return self._step_body(buffer, alpha, log)
+
+    def _workspace_token(self):
+        token = self.__dict__.get("_ws_token")
+        if token is None:
+            token = self._ws_token = rnad_hip.WorkspaceToken()
+        return token
 
     def _step_body(self, buffer, alpha, log=None, step_params=None):
         world, rank = self._world, self._rank
@@ -939,15 +969,13 @@ class RNaD:
         elif mode is True:
             # the nets do not change between this step's rollout and its update: one evaluation of the 2S observations serves the
             # actor (= the learner net, rnad.py:503-505) and all four nets of __learn
-            shard = self._shard_now(handle, local_batch, log, lazy)
+            on_policy = self._plays_what_it_learns(handle, local_batch, T_cap, buffer)
+            shard = self._shard_now(handle, local_batch, log, lazy, on_policy)
             tables = self._table_outputs(alpha, getattr(self, "obs_half", False), want_target_logits=log is not None, fold=fold,
                                          records_hp=self._learn_params(alpha), step_params=step_params, shard=shard,
-                                         dedup=self._dedup_now(handle, log, lazy, shard, fold),
+                                         dedup=self._dedup_now(handle, log, lazy, shard, fold, on_policy),
                                          # (the compact rollout's keys pass carries the copies; any other rollout needs them made first)
-                                         defer_expand=(self.total_steps % self.buffer_mod == 0 and getattr(self, "compact_trajectory", True)
-                                                       and T_cap <= rnad_hip.COMPACT_MAX_STEPS and not self.reuse_actor_outputs
-                                                       and not getattr(self, "store_actor_values", False)
-                                                       and rnad_hip.bucket_plan(handle, local_batch) is not None))
+                                         defer_expand=on_policy)
         if self.total_steps % self.buffer_mod == 0:
             episodes = episode.Episodes(self.tree, local_batch, seed=self._new_seed(), lane_offset=rank * local_batch,
                                         obs_half=getattr(self, "obs_half", False))
@@ -1158,6 +1186,7 @@ class RNaD:
             g["episodes"] = self.last_episodes
             g["advances"] = self._tail_advances  # (the captured step ends in the fused optimiser launch)
         g["graph"].replay()
+        rnad_hip.destroy_deferred()  # (tree handles that died while the capture was open: freed here, outside any capture)
         if g["advances"]:
             g["pos"] += 1
         else:

@@ -6,6 +6,8 @@ CPU fallback: if the library is missing or a tensor is not on a GPU the call fai
 """
 import ctypes as C
 import os
+import threading
+import weakref
 
 import torch
 
@@ -167,6 +169,8 @@ class TreeHandle:
             row, col = observe_all(self, self.device)
             tab = torch.cat([row, col], dim=0)
             setattr(self, key, tab.half() if half else tab)
+            if tab.is_cuda:  # a cache shared by every user of the handle, possibly on other streams: complete before anyone else sees it
+                torch.cuda.current_stream(tab.device).synchronize()
         return getattr(self, key)
 
     def is_foldable_table(self, obs):
@@ -273,6 +277,13 @@ def _destroy_deferred():
         return
     while _deferred_destroy:
         lib().rnad_tree_destroy(_deferred_destroy.pop())
+
+
+def destroy_deferred():
+    """Free the tables of tree handles that died while a stream capture was open (a hipFree would have invalidated the capture, so they
+    were parked).  Called at safe points: handle construction / destruction, bucket_plan, after RNaD's graph replays."""
+    if _deferred_destroy:
+        _destroy_deferred()
 
 
 def observe(tree, idx, player, obs=None, half=False, mask_bits=None, mask=None):
@@ -802,9 +813,44 @@ class BucketPlan:
         self.accumulators = torch.zeros((self.acc_bytes // 8 + 1,), dtype=torch.int64, device=dev)
 
 
+_owner = threading.local()
+
+
+class WorkspaceToken:
+    """Identity of one owner of bucketed-pipeline workspaces (see workspace_owner); the workspaces live as long as the token."""
+
+    __slots__ = ("__weakref__",)
+
+
+class workspace_owner:
+    """`with workspace_owner(token):` -- the BucketPlans made or looked up inside belong to `token` (a WorkspaceToken; every RNaD object
+    holds one): their device workspaces (`scratch` of the sort and the rollout, the learner's `accumulators`, the staging buffers) are that
+    owner's alone.  Calls outside any such block share the default set, as every call did before r05 -- fine for one trainer per
+    (tree, batch size), and for several whose calls are ordered by one stream; two trainers stepping on two streams of one device
+    (reference main.py:55-81 runs several over one tree) each need their own, or they add into each other's sums."""
+
+    def __init__(self, token):
+        self.token, self.prev = token, None
+
+    def __enter__(self):
+        self.prev = getattr(_owner, "token", None)
+        _owner.token = self.token
+        return self
+
+    def __exit__(self, *exc):
+        _owner.token = self.prev
+        return False
+
+
 def bucket_plan(tree, B):
-    """The BucketPlan of (tree, B) (cached on the tree handle), or None when this tree / batch cannot be bucketed."""
-    cache = tree.__dict__.setdefault("_bucket_plans", {})
+    """The BucketPlan of (tree, B) for the current workspace_owner (cached on the tree handle), or None when this tree / batch cannot be
+    bucketed."""
+    destroy_deferred()
+    token = getattr(_owner, "token", None)
+    if token is None:
+        cache = tree.__dict__.setdefault("_bucket_plans", {})
+    else:  # (weakly keyed: a trainer's workspaces go when the trainer does)
+        cache = tree.__dict__.setdefault("_owner_plans", weakref.WeakKeyDictionary()).setdefault(token, {})
     key = (B, os.environ.get("RNAD_BUCKET_ROWS"), os.environ.get("RNAD_BUCKET_CHUNK"))  # the tuning overrides of csrc/bucket.hip
     if key not in cache:
         out = (C.c_int64 * 9)()
@@ -1371,6 +1417,8 @@ class OptimizerStep:
         self.param, self.m, self.v, self.step = arr(params, "param"), arr(exp_avg, "exp_avg"), arr(exp_avg_sq, "exp_avg_sq"), arr(steps, "step")
         self.target = arr(targets, "target") if targets is not None else None
         self.hp = AdamParams(float(lr), float(beta1), float(beta2), float(eps), float(max_norm), float(ema))
+        # the kernel's workgroups count themselves here (and the last one resets it): this optimiser's own word, not a device global
+        self.ticket = torch.zeros((1,), dtype=I32, device=params[0].device)
 
     def __call__(self, flat, advance=None):
         """advance: a step queue (step_queue_set) to move on once the step is over."""
@@ -1378,7 +1426,8 @@ class OptimizerStep:
         img = self.packed or (None, None)
         _check(lib().rnad_optimizer_step(self.n, self.sizes, self.param, _dp(flat, F32, "grads"), self.m, self.v, self.step, self.target,
                                          C.byref(self.hp), None, self.A, self.W, self.fold, _dp(img[0], F32, "packed_param", True),
-                                         _dp(img[1], F32, "packed_target", True), _dp(advance, torch.int64, "advance", True), _stream()))
+                                         _dp(img[1], F32, "packed_target", True), _dp(advance, torch.int64, "advance", True),
+                                         _dp(self.ticket, I32, "ticket"), _stream()))
 
 
 def make_learn_params(alpha, eta, lambda_=1.0, c=1.0, rho=1.0, gamma=1.0, clip=1e3, threshold=2.0, w_v=1.0, w_n=1.0,

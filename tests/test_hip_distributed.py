@@ -288,3 +288,72 @@ def test_two_ranks_on_a_uniform_tree_need_no_collective_for_the_normalisers(tmp_
     for k, want in single.items():
         np.testing.assert_array_equal(r0[k], r1[k])
         np.testing.assert_allclose(r0[k], want, rtol=2e-5, atol=2e-7, err_msg=k)  # (the ranks' gradient sums meet in another fp32 order)
+
+
+# ------------------------------------------------------------------------------------------------ RCCL with more than one rank
+def _rccl_ranks(rank, world, port, tmp, steps):
+    """One process per GPU over `nccl` (= RCCL over xGMI): `steps` default steps on configs[1]'s shape two levels shallower, the first
+    three enqueued eagerly, then captured with the collectives inside and replayed."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0", RNAD_SAVE_DIR=os.path.join(tmp, f"r{rank}"),
+                      NCCL_DEBUG="INFO", NCCL_DEBUG_SUBSYS="INIT,COLL", NCCL_DEBUG_FILE=os.path.join(tmp, "rccl2_%p.log"))
+    torch.cuda.set_device(rank)
+    dev = torch.device("cuda", rank)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    try:
+        from environment.episode import Buffer
+        from environment.tree import Tree
+        from learn.rnad import RNaD
+
+        tree = Tree(device=dev, max_actions=3, max_transitions=1, depth_bound=4)
+        tree.generate_native(seed=0)
+        torch.manual_seed(SEED)
+        rn = RNaD(tree=tree, device=dev, directory_name="rccl2", batch_size=1 << 14, eta=0.2, b1_adam=0.0, lr=1e-3,
+                  net_params={"type": "MLP", "max_actions": 3, "width": 64})
+        rn.initialize()
+        rn.tabular_gate = 0
+        buf = Buffer(1)
+        for _ in range(steps):
+            rn.train_step(buf, alpha=0.3)
+            rn.total_steps += 1
+        torch.cuda.synchronize()
+        g = rn.__dict__.get("_graph") or {}
+        np.savez(os.path.join(tmp, f"rccl2_{rank}.npz"), replayed=int(g.get("graph") is not None), world=dist.get_world_size(),
+                 **{k: v.detach().cpu().numpy() for k, v in rn.net.state_dict().items()})
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="RCCL with more than one rank needs at least two GPUs (the build loop's box has one)")
+def test_two_rccl_ranks_train_like_one_process(tmp_path):
+    """The first multi-GPU run's gate (BASELINE.json configs[2], [4]): 2 ranks over RCCL, eager steps then the captured step with the
+    collectives inside, against the one-process step on the same global batch -- the bounds of the gloo test above (Adam normalises)."""
+    from environment.episode import Buffer
+    from environment.tree import Tree
+    from learn.rnad import RNaD
+
+    steps = 8
+    dev = torch.device("cuda:0")
+    os.environ["RNAD_SAVE_DIR"] = str(tmp_path / "single")
+    tree = Tree(device=dev, max_actions=3, max_transitions=1, depth_bound=4)
+    tree.generate_native(seed=0)
+    torch.manual_seed(SEED)
+    rn = RNaD(tree=tree, device=dev, directory_name="rccl2", batch_size=1 << 14, eta=0.2, b1_adam=0.0, lr=1e-3,
+              net_params={"type": "MLP", "max_actions": 3, "width": 64})
+    rn.initialize()
+    rn.tabular_gate = 0
+    buf = Buffer(1)
+    for _ in range(steps):
+        rn.train_step(buf, alpha=0.3)
+        rn.total_steps += 1
+    torch.cuda.synchronize()
+    single = {k: v.detach().cpu().numpy() for k, v in rn.net.state_dict().items()}
+    mp.spawn(_rccl_ranks, args=(2, _free_port(), str(tmp_path), steps), nprocs=2, join=True)
+    r0, r1 = (np.load(tmp_path / f"rccl2_{r}.npz") for r in range(2))
+    assert int(r0["world"]) == 2 and int(r0["replayed"]) == 1 and int(r1["replayed"]) == 1
+    for k, want in single.items():
+        np.testing.assert_array_equal(r0[k], r1[k])  # ranks stay in lock step
+        np.testing.assert_allclose(r0[k], want, rtol=2e-4, atol=2e-6, err_msg=k)
+    text = "".join(p.read_text(errors="replace") for p in tmp_path.glob("rccl2_*.log"))
+    assert "nranks 2" in text or "nRanks 2" in text, "RCCL's own log must show a 2-rank communicator"
+    assert sum(1 for ln in text.splitlines() if "AllReduce" in ln and "opCount" in ln) >= steps, "one gradient all-reduce per step and rank"
