@@ -50,17 +50,17 @@ SIMDS = 256 * 4        # 256 CUs x 4 SIMDs
 # The rooflines of the integer / gather kernels of this path (keys, rollout, learner), all three always in the line:
 #   hbm    algorithmic bytes per launch / launch duration / 8 TB/s
 #   issue  VALU issue-port time / (SIMDs x launch duration x 2.4 GHz).  Issue-port time = SQ_INSTS_VALU (dynamic wave-instructions per
-#          launch, rocprofv3 counter pass: profiles/r04_pmc.json) x the kernel's mean cycles per instruction = sum over instruction
-#          classes of [share of the class in the kernel's loops (tools/isa_hist.py on `hipcc -S`: profiles/r04_isa_mix.json)] x [cycles a
+#          launch, rocprofv3 counter pass: profiles/r05_pmc.json) x the kernel's mean cycles per instruction = sum over instruction
+#          classes of [share of the class in the kernel's loops (tools/isa_hist.py on `hipcc -S`: profiles/r05_isa_mix.json)] x [cycles a
 #          SIMD's issue port is busy per wave64 instruction of the class (tools/micro/valu_issue.hip on this hardware:
-#          profiles/r04_valu_issue.json: 1.8 - 1.9 for plain fp32 / integer / move, 2.8 - 3.0 for min / max / med3 / compare / select /
+#          profiles/r05_valu_issue.json: 1.8 - 1.9 for plain fp32 / integer / move, 2.8 - 3.0 for min / max / med3 / compare / select /
 #          64-bit / fp64 / packed, 3.1 - 3.4 for v_cvt_f64_f32 / v_mad_u64_u32, 5.3 transcendental)]
 #   wait   SQ_WAIT_ANY / SQ_WAVE_CYCLES (share of a resident wave's time parked on s_waitcnt) and SQ_WAIT_INST_ANY / SQ_WAVE_CYCLES
 #          (issue stalls) from the same counter pass
 # (r03 priced the issue roof at 4 cycles per instruction from SQ_ACTIVE_INST_VALU, which counts instructions, not cycles.)
-PMC_FILE = os.path.join(ROOT, "profiles", "r04_pmc.json")
-ISA_MIX_FILE = os.path.join(ROOT, "profiles", "r04_isa_mix.json")
-ISSUE_FILE = os.path.join(ROOT, "profiles", "r04_valu_issue.json")
+PMC_FILE = os.path.join(ROOT, "profiles", "r05_pmc.json")
+ISA_MIX_FILE = os.path.join(ROOT, "profiles", "r05_isa_mix.json")
+ISSUE_FILE = os.path.join(ROOT, "profiles", "r05_valu_issue.json")
 
 
 def _load(path):
@@ -128,6 +128,9 @@ def main():
     ap.add_argument("--cpu-lanes-log2", type=int, default=18, help="episodes per step of the CPU-baseline sample (C port)")
     ap.add_argument("--cpu-torch-lanes-log2", type=int, default=16, help="episodes per step of the CPU-baseline sample (plain PyTorch-CPU leg)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-side-legs", action="store_true",
+                    help="skip the legs the default one-GPU line carries beside `value`: configs[3], dedup off, a sharp policy, 2^19 / 2^22 lanes")
+    ap.add_argument("--side-steps", type=int, default=200, help="timed replays of each side leg")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -179,10 +182,10 @@ def main():
     os.environ["RNAD_SAVE_DIR"] = tempfile.mkdtemp(prefix="rnad_bench_")
     delta_m = 10_000
 
-    def make_trainer(batch, name, data_parallel=True):
+    def make_trainer(batch, name, data_parallel=True, tree=tree):
         torch.manual_seed(0)
         t = RNaD(tree=tree, device=device, directory_name=name, batch_size=batch, eta=0.2, b1_adam=0.0,
-                 net_params={"type": "MLP", "max_actions": A, "width": args.width})
+                 net_params={"type": "MLP", "max_actions": tree.max_actions, "width": args.width})
         t.data_parallel = data_parallel
         t.initialize()
         t.obs_half = args.obs_half
@@ -390,6 +393,13 @@ def main():
                 base = {"error": str(err)[:300]}
         dist.barrier()
 
+    # ---- side legs (one GPU, the default workload only; outside the timed region, each its own trainer, replayed graphs)
+    side = {}
+    default_line = (world == 1 and (A, C, depth, tuple(args.prune), args.width, args.batch_log2) == (3, 1, 6, (0, 0), 256, 20)
+                    and args.net_mode == "default" and not args.no_graph and not args.obs_half and not args.no_side_legs)
+    if default_line:
+        side = side_legs(make_trainer, tree, args, device)
+
     def emit(elapsed, replayed, note=None):
         if rank != 0:
             return
@@ -435,7 +445,8 @@ def main():
                             + f" x T={T_ref} env steps, MLP width {args.width}" + which,
                 "global_batch": global_batch, "per_gpu_batch": local_batch, "T": T_ref, "T_buffer": T,
                 "valid_env_steps_per_step": live_slots * world,
-                "parallelism": f"dp{world} (episodes sharded, RCCL all-reduce of 43 KB grads"
+                "parallelism": "single GPU (no collectives)" if world == 1 else
+                               f"dp{world} (episodes sharded, RCCL all-reduce of 43 KB grads"
                                + ("; the normalisers of this tree need no collective: every episode has the same length)"
                                   if tree.handle().uniform_length else " + 2 normalisers)"),
             },
@@ -450,7 +461,8 @@ def main():
                                "lazy_rows_visited": args.visited_rows or None, "staged_policy_rows": args.policy_rows or None,
                                "rows_after_dedup": args.unique_rows or None,  # (RNaD.dedup_rows: rows with distinct observation bits)
                                "legal_fold": args.fold,
-                               "distinct_observations": 2 * handle.S, "slots": T * local_batch},
+                               "table_rows": 2 * handle.S,  # (player, state) rows of the tree: what the nets are evaluated on without dedup
+                               "slots": T * local_batch},
             "other_modes": {name: {"env_steps_per_sec": global_batch * T_ref * E / sec, "updates_per_sec": E / sec,
                                    "ms_per_step": sec / E * 1e3, "steps": E,
                                    "what": what[{"dense_nets": False, "forward": "forward", "tabular_nets": True}[name]]}
@@ -464,6 +476,8 @@ def main():
         }
         if world > 1:
             out["legs_ms_per_step"] = {k: v / args.steps * 1e3 for k, v in legs.items()}
+            if not rehearsal:
+                assert dist.get_backend() == "nccl" and dist.get_world_size() == args.gpus, "bench.py --gpus N is one RCCL rank per GPU"
             out["collectives"] = {"backend": dist.get_backend(), "rccl_ranks": dist.get_world_size() if dist.get_backend() == "nccl" else None,
                                   "ranks": dist.get_world_size(), "per_step": "all_reduce(2 x f64 normalisers) + all_reduce(43 KB fp32 gradient bucket)",
                                   "shard_rows": bool(args.shard_rows)}
@@ -481,6 +495,7 @@ def main():
                     out["strong_scaling"]["speedup_vs_one_gpu_same_batch"] = base["ms_per_step"] / (elapsed / args.steps * 1e3)
             if note:
                 out["note"] = note
+        out.update(side)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(tree, args, T)
         print(json.dumps(out), flush=True)
@@ -519,6 +534,105 @@ def main():
 
 
 FP32_PEAK_TFLOPS = 157.3  # fp32 MFMA == fp32 vector peak (/opt/skills/guides/MI355X_MICROARCH.md)
+ALLREDUCE_US_ASSUMED = 15.0  # one 43 KB all-reduce over xGMI, exposed between backward and optimiser (latency-bound)
+
+
+def side_legs(make_trainer, tree, args, device):
+    """What the default line carries beside `value`, each measured like `value` -- its own trainer, primed, the
+    step replayed from its captured graph, `--side-steps` replays between two fences:
+      other_configs.c4          BASELINE.json configs[3]: depth-8 5x5 tree, chance branching 4, pruned to ~1 M states, batch 2^20
+      dedup_off_ms_per_step     the default workload with RNaD.dedup_rows = False: nets and backward on all 2S rows (what a tree without
+                                repeated observations pays)
+      trained_policy_ms_per_step  the default workload with a SHARP actor (the policy head's output layer scaled: lanes pile up on few
+                                trajectories, as after training) and the learner on the distinct trajectories of a work item, which is what
+                                RNaD switches to after DISTINCT_AFTER updates
+      strong_scaling.predicted  configs[2] without the 8 GPUs: the one-GPU time of the 2^22 batch over (a rank's 2^19-lane step + one
+                                exposed 43 KB all-reduce, assumed ALLREDUCE_US_ASSUMED us)."""
+    from environment.tree import Tree
+
+    n = max(1, args.side_steps)
+
+    def run(trainer_step, steps=n, prime=60):
+        t, _, step = trainer_step
+        for _ in range(prime):
+            step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / steps * 1e3
+        g = getattr(t, "_graph", None)
+        return ms, bool(g and g.get("graph") is not None), t
+
+    out = {}
+    try:
+        ms, rep, t = run(_with(make_trainer(1 << 20, "side-nodedup"), dedup_rows=False))
+        out["dedup_off_ms_per_step"] = {"ms_per_step": ms, "step_replayed_from_hipGraph": rep,
+                                        "what": "RNaD.dedup_rows = False: table launch and backward on all 2S rows of the tree"}
+        del t
+    except Exception as err:
+        out["dedup_off_ms_per_step"] = {"error": str(err)[:300]}
+    try:
+        tr = _with(make_trainer(1 << 20, "side-sharp"), distinct_trajectories=True)
+        with torch.no_grad():
+            for name, p_ in tr[0].net.named_parameters():
+                if name.startswith("policy_fc1"):
+                    p_.mul_(40.0)
+        tr[0].invalidate_tables()
+        ms, rep, t = run(tr)
+        ep = t.last_episodes
+        per_bucket = torch.bincount(ep.buckets.items[: int(ep.buckets.n_items.item()), 2].long(),
+                                    weights=ep.buckets.items[: int(ep.buckets.n_items.item()), 1].double())
+        out["trained_policy_ms_per_step"] = {"ms_per_step": ms, "step_replayed_from_hipGraph": rep,
+                                             "largest_bucket_share_of_lanes": float(per_bucket.max().item()) / (1 << 20),
+                                             "what": "a sharp actor (policy_fc1 x 40: near-deterministic, lanes concentrate as after training) with "
+                                                     "RNaD.distinct_trajectories = True (what RNaD switches to after DISTINCT_AFTER = 4096 updates)"}
+        del t, tr
+    except Exception as err:
+        out["trained_policy_ms_per_step"] = {"error": str(err)[:300]}
+    torch.cuda.empty_cache()
+    try:
+        ms19, rep19, t = run(make_trainer(1 << 19, "side-b19"))
+        del t
+        ms22, rep22, t = run(make_trainer(1 << 22, "side-b22"), steps=max(1, n // 2), prime=20)
+        del t
+        out["strong_scaling"] = {"predicted": {
+            "one_gpu_2p22_ms_per_step": ms22, "rank_share_2p19_ms_per_step": ms19, "assumed_exposed_allreduce_us": ALLREDUCE_US_ASSUMED,
+            "speedup_8_gpus": ms22 / (ms19 + ALLREDUCE_US_ASSUMED * 1e-3), "replayed": bool(rep19 and rep22),
+            "what": "BASELINE.json configs[2] predicted from one GPU: the 2^22 batch on one GPU over (a rank's 2^19 lanes + one exposed 43 KB "
+                    "all-reduce); both legs measured here, the collective's latency assumed (no multi-GPU node in the build loop)"}}
+    except Exception as err:
+        out["strong_scaling"] = {"predicted": {"error": str(err)[:300]}}
+    torch.cuda.empty_cache()
+    try:
+        t0 = time.perf_counter()
+        c4 = Tree(device=device, max_actions=5, max_transitions=4, depth_bound=8, transition_threshold=0.1)
+        c4.generate_native(seed=0, prune=(7, 8))
+        gen_s = time.perf_counter() - t0
+        ms, rep, t = run(make_trainer(1 << 20, "side-c4", tree=c4), prime=40)
+        ep = t.last_episodes
+        alive = ep.alive.cpu().numpy()
+        T_ref = int((alive[: ep.t_eff + 1] > 0).sum())
+        staged = getattr(ep, "staged_rows", None)
+        out["other_configs"] = {"c4": {
+            "workload": f"BASELINE.json configs[3]: depth-8 5x5 tree, chance branching 4, threshold 0.1, pruned 7/8, S={c4.index_tensor.shape[0]}, "
+                        f"batch 2^20 x T={T_ref}", "ms_per_step": ms, "env_steps_per_sec": (1 << 20) * T_ref / (ms * 1e-3),
+            "valid_env_steps_per_step": int(alive[: ep.t_eff + 1].sum()), "updates_per_sec": 1e3 / ms, "step_replayed_from_hipGraph": rep,
+            "lazy_rows_visited": int(t.last_rows.count.item()) if t.last_rows is not None else None,
+            "staged_policy_rows": int(sum(r.count.item() for r in staged)) if staged else None,
+            "table_rows": 2 * c4.handle().S, "tree_generate_and_upload_s": gen_s, "steps": n}}
+        del t, c4
+    except Exception as err:
+        out["other_configs"] = {"c4": {"error": str(err)[:300]}}
+    torch.cuda.empty_cache()
+    return out
+
+
+def _with(trainer_step, **attrs):
+    for k, v in attrs.items():
+        setattr(trainer_step[0], k, v)
+    return trainer_step
 
 
 def mode_now_is_true(rn, T, local_batch):
@@ -580,7 +694,7 @@ def kernel_report(prof, A, C, args, B, T, live_slots, tree, mode_now):
                 rh.PROF_BUCKET_ROLLOUT: "k_bucket_rollout_items" if compact else "k_bucket_rollout",
                 rh.PROF_BUCKET_LEARN: "k_bucket_play_learn" if fused else "k_bucket_learn_c" if compact else "k_bucket_learn",
                 rh.PROF_OBSERVE: "k_observe"}
-    mix_name = {rh.PROF_BUCKET_KEYS: f"k_bucket_keys_lds<{A}, 1>", rh.PROF_BUCKET_ROLLOUT: f"k_bucket_rollout_items<{A}, {rel}, 1>",
+    mix_name = {rh.PROF_BUCKET_KEYS: f"k_bucket_keys_lds<{A}, 1, 4096>", rh.PROF_BUCKET_ROLLOUT: f"k_bucket_rollout_items<{A}, {rel}, 1>",
                 rh.PROF_BUCKET_LEARN: f"k_bucket_play_learn<{A}, {rel}, false>" if fused else f"k_bucket_learn_c<{A}, {rel}, false>"}
     units = {rh.PROF_BUCKET_KEYS: (B, "lane"), rh.PROF_BUCKET_ROLLOUT: (slots, "slot"), rh.PROF_BUCKET_LEARN: (max(live_slots, 1), "live slot")}
     for k, p in prof.items():
@@ -613,8 +727,8 @@ def kernel_report(prof, A, C, args, B, T, live_slots, tree, mode_now):
                           "what": "TCP_TOTAL_CACHE_ACCESSES_sum and TCP_GATE_EN1_sum / (256 CUs x launch duration x 2.4 GHz) of their own counter "
                                   "pass: the vector L1s' access count and busy share -- what holds the gather kernels"}
                 e.update(issue=issue, wait=wait, l1=l1, counters_from_this_build=pmc_matches if c else None,
-                         counters_source="profiles/r04_pmc.json (separate rocprofv3 --pmc passes: FETCH_SIZE | WRITE_SIZE | SQ_*; traffic = 2 x "
-                                         "FETCH_SIZE + WRITE_SIZE), profiles/r04_isa_mix.json, profiles/r04_valu_issue.json" if c else None)
+                         counters_source="profiles/r05_pmc.json (separate rocprofv3 --pmc passes: FETCH_SIZE | WRITE_SIZE | SQ_*; traffic = 2 x "
+                                         "FETCH_SIZE + WRITE_SIZE), profiles/r05_isa_mix.json, profiles/r05_valu_issue.json" if c else None)
         out[p["name"]] = e
     # the fused MLP kernels: flops the matrix cores execute per sample (first layer of a head: 2 K W; relu + second layer run on the
     # VALU; backward: recompute of both heads + dW0 over the augmented input padded to its MFMA tiles)
@@ -623,7 +737,7 @@ def kernel_report(prof, A, C, args, B, T, live_slots, tree, mode_now):
     uniq = getattr(args, "unique_rows", 0)  # (0: every row evaluated)
     bwd_samples = (visited or uniq or S2) if mode_now is True else (live_slots if not uniform else slots)
     def mlp_counters(entry, name):
-        """Counter evidence of an MLP kernel (profiles/r04_pmc.json): HBM traffic, the matrix pipe's busy share of the launch's SIMD cycles,
+        """Counter evidence of an MLP kernel (profiles/r05_pmc.json): HBM traffic, the matrix pipe's busy share of the launch's SIMD cycles,
         VALU wave-instructions, wait shares."""
         c = pmc.get(name, {})
         if not c:
@@ -670,7 +784,13 @@ def kernel_report(prof, A, C, args, B, T, live_slots, tree, mode_now):
 def roofline_of(k):
     if k is None:
         return None
-    r = {"kernel": k["name"], "bound": k.get("bound"), "achieved": k.get("achieved"), "peak": k.get("peak"), "unit": k.get("unit"),
+    binds = None
+    if k.get("bound") == "hbm" and (k.get("issue") or k.get("wait")):
+        # the contract's `bound` names the roof the bytes are priced against; what actually holds a gather kernel of this path is below
+        iss, wt = (k.get("issue") or {}).get("frac"), (k.get("wait") or {}).get("parked_on_waitcnt")
+        binds = ("dependent-gather latency and the vector L1's access rate, not HBM: VALU issue %s of its roof, %s of a resident wave's time "
+                 "parked on s_waitcnt" % ("%.2f" % iss if iss else "n/a", "%.2f" % wt if wt else "n/a"))
+    r = {"kernel": k["name"], "bound": k.get("bound"), "binds": binds, "achieved": k.get("achieved"), "peak": k.get("peak"), "unit": k.get("unit"),
          "frac": k.get("frac"), "traffic": k.get("traffic"), "avg_launch_us": k["avg_launch_us"], "launches_per_step": k["launches_per_step"],
          "bytes_per_launch": k.get("algorithmic_bytes_per_launch"), "bytes_model": k.get("bytes_model"),
          "share_of_step_us": k["us_per_step"],
@@ -689,11 +809,15 @@ def k1_report(k1, A, args, B):
     algo = B * (4 + 8 * A * A + 2 * A * A * (2 if args.obs_half else 4) + 4 * A)
     out = {"kernel": "k_observe (K1, States.observations: the API's episode-gather kernel; not in the default step any more)",
            "avg_launch_us": us, "launches": n, "algorithmic_bytes_per_launch_survey_8d": algo,
-           "algorithmic_GBps": algo / (us * 1e-6) / 1e9}
+           "algorithmic_GBps": algo / (us * 1e-6) / 1e9,
+           # SURVEY 8(d) prices an env step at idx 4 + two gathered 4 A^2-byte rows + the observation + a 4 A-byte mask; the kernel reads ONE
+           # 48-byte node row per lane, which comes from L2 (the tables are 3 MB), and writes the mask as one byte: by that model the launch
+           # would exceed the HBM peak -- the model counts bytes that never travel, so the fraction that counts is the counters' below
+           "frac_of_hbm_peak_by_survey_8d_model": algo / (us * 1e-6) / 1e9 / HBM_PEAK_GBS}
     traffic = k1_traffic(A, args)
     if traffic:
         out.update(counter_bytes_per_launch=traffic, frac_of_hbm_peak_from_counter_bytes=traffic / (us * 1e-6) / 1e9 / HBM_PEAK_GBS,
-                   note="counter bytes = 2 x FETCH_SIZE + WRITE_SIZE of a separate rocprofv3 --pmc pass (profiles/r04_pmc.json) over launches that "
+                   note="counter bytes = 2 x FETCH_SIZE + WRITE_SIZE of a separate rocprofv3 --pmc pass (profiles/r05_pmc.json) over launches that "
                         "each write their own slice of a [T, B, 2, A, A] buffer (906 MB: beyond the Infinity Cache); the SURVEY model over-counts "
                         "(node rows are L2 hits, the mask travels as 1 byte), so the fraction is taken from the counters")
     return out
@@ -731,8 +855,11 @@ def cpu_baseline(tree, args, T):
         upd += u
         n += 1
     dt = time.perf_counter() - t0
+    full = (1 << args.batch_log2) * Tc / (lanes * Tc * n / dt)
     out = {
         "value": lanes * Tc * n / dt, "unit": "env-steps/s", "cores": cores, "kind": "port",
+        # (one step of the full 2^batch-log2 batch at this rate: beyond the minute the default run may spend here, hence the sample)
+        "full_batch_step_estimate_s": full,
         "sample": f"{n} full step(s) (rollout + update) of 2^{args.cpu_lanes_log2} episodes x T={Tc} on the same tree; "
                   f"C oracle (OpenMP) + PyTorch-CPU MLP, {cores} threads",
         "rollout_env_steps_per_sec": lanes * Tc * n / roll, "updates_per_sec_at_sample_batch": n / dt,

@@ -65,11 +65,27 @@ constexpr int kTicketGroups = 64;     // first-level tickets of k_bucket_finish'
 constexpr int kTargetLanes = 1024;   // finest cut whose groups still hold this many lanes on average (configs[1]: full work items win)
 constexpr int kMinLanesLevelCut = 128;  // a level cut (one group per subtree) is taken while its groups hold this many lanes on average
 
+// lanes per thread of the walks with tables in LDS (k_bucket_keys_lds, k_bucket_keys_hybrid).  r04: one lane per thread -- 18.9 -> 17.7 us on
+// configs[1], 42.9 -> 37.8 on configs[3]'s hybrid walk (two: what the global-table walk above keeps; four: 18.3 / 46.1)
+#ifndef RNAD_PLAY_LDS
+#define RNAD_PLAY_LDS 1
+#endif
+constexpr int kPlayLds = RNAD_PLAY_LDS;
+constexpr int kMinSortTile = kSortThreads * kPlayLds > 1024 ? kSortThreads * kPlayLds : 1024;  // a tile is a whole number of passes of the LDS walks
+// `kTile` = the plan's sort tile as a constant (tiles below kMinSortTile are never planned)
+#define RNAD_DISPATCH_TILE(p_, ...)                                                          \
+    switch ((p_).tile) {                                                                     \
+        case 1024: { constexpr int kTile = kMinSortTile > 1024 ? kMinSortTile : 1024; __VA_ARGS__; } break; \
+        case 2048: { constexpr int kTile = kMinSortTile > 2048 ? kMinSortTile : 2048; __VA_ARGS__; } break; \
+        default: { constexpr int kTile = kSortLanes; __VA_ARGS__; } break;                    \
+    }
+
 inline unsigned blocks_for(int64_t n, int per = kThreads) { return (unsigned)((n + per - 1) / per); }
 
 struct Plan {
     const BucketCut *cut = nullptr;
     int lds = 0, path_words = 0, sort_blocks = 0, chunk = kChunkDefault;
+    int tile = kSortLanes;  // lanes per workgroup of the sort passes (keys walk, histogram, scatter): kSortLanes, or a fraction of it on small batches
     int rel_bytes = 1;  // width of a relative state of the compact trajectory: states of a group are bucket_lo + (0 .. rows - 1)
     int64_t max_items = 0;
 };
@@ -335,7 +351,20 @@ bool make_plan(const rnad_tree_t *tree, int64_t B, Plan &p) {
     p.path_words = std::min(kMaxPath, std::max(chosen->max_path, 1)) * kPathSlots * ((tree->A + 1) | 1);
     p.lds = (p.path_words + 2 * chosen->rows * ((tree->A + 1) | 1)) * 8;
     p.rel_bytes = chosen->rows <= 255 ? 1 : 2;
-    p.sort_blocks = (int)((B + kSortLanes - 1) / kSortLanes);
+    // Sort tile.  A workgroup of the keys pass / the scatter works through its tile in tile / 1024 passes, one after the other, and below
+    // 2^20 lanes there are fewer tiles of 4096 than CUs: the launch then lasts as long as ONE workgroup's four passes whatever the batch
+    // (r05, measured at 2^18 / 2^19 lanes: keys 15.0 / 15.5 us, scatter 9.4 / 10.6).  Smaller tiles while they still fill the chip at one
+    // workgroup per CU -- not beyond: every workgroup stages the upper tables and takes the prefix of all bucket totals for itself
+    // (2048-lane tiles at 2^20 lanes: keys 21.0 -> 23.3 us, scatter 13.1 -> 17.3, r04) -- and not on cuts with thousands of buckets
+    // (configs[3]: the scatter's per-workgroup walk over the counters is what its time is).
+    p.tile = kSortLanes;
+    if (chosen->n_buckets <= 2048)
+        while (p.tile > kMinSortTile && (B + p.tile - 1) / p.tile < 256) p.tile /= 2;
+    if (const char *t = getenv("RNAD_SORT_TILE")) {  // tuning knob / tests
+        const int v = atoi(t);
+        if ((v == 1024 || v == 2048 || v == 4096) && v >= kMinSortTile) p.tile = v;
+    }
+    p.sort_blocks = (int)((B + p.tile - 1) / p.tile);
     if (const char *c = getenv("RNAD_BUCKET_CHUNK")) p.chunk = std::max(64, atoi(c));  // tuning knob
     p.max_items = (int64_t)chosen->n_buckets + B / p.chunk + 1 + 7;  // (+ 7: the XCD-aware item mapping needs 8 * ceil(n / 8) workgroups)
     return true;
@@ -488,12 +517,6 @@ StageOut carve_stage(void *stage, int64_t B, int64_t S) {
 #define RNAD_PLAY 2
 #endif
 constexpr int kPlay = RNAD_PLAY;
-// ... of the walks with tables in LDS (k_bucket_keys_lds, k_bucket_keys_hybrid).  r04: one lane per thread -- 18.9 -> 17.7 us on
-// configs[1], 42.9 -> 37.8 on configs[3]'s hybrid walk (two: what the global-table walk above keeps; four: 18.3 / 46.1)
-#ifndef RNAD_PLAY_LDS
-#define RNAD_PLAY_LDS 1
-#endif
-constexpr int kPlayLds = RNAD_PLAY_LDS;
 
 template <int A, int L>
 __global__ __launch_bounds__(kThreads) void k_bucket_keys(const Trans *__restrict__ trans, int C, int64_t S, int64_t B, int n_steps,
@@ -615,7 +638,7 @@ inline size_t keys_lds_bytes(int n_upper, int n_buckets, int A, int C) {
            (size_t)n_buckets * sizeof(int32_t);
 }
 
-template <int A, int L>
+template <int A, int L, int TILE>
 __global__ __launch_bounds__(kSortThreads) void k_bucket_keys_lds(const UpperWalk *__restrict__ walk, const int32_t *__restrict__ upper_list,
                                                                   int n_upper, int n_buckets, int C, int64_t S, int64_t B, int n_steps,
                                                                   const float *__restrict__ policy_tab, int64_t tab_stride, int key_root,
@@ -643,9 +666,9 @@ __global__ __launch_bounds__(kSortThreads) void k_bucket_keys_lds(const UpperWal
     if (blockIdx.x == 0 && threadIdx.x == 0 && stage.counts) stage.counts[0] = stage.counts[1] = 0ull;
     if (sp) seed = sp->seed;
     __syncthreads();
-    static_assert(kSortLanes % (kSortThreads * L) == 0, "a sort tile is a whole number of passes");
-    for (int pass = 0; pass < kSortLanes / (kSortThreads * L); ++pass) {
-        const int64_t b0 = (int64_t)blockIdx.x * kSortLanes + (int64_t)pass * (kSortThreads * L) + threadIdx.x;  // lanes b0 + l * kSortThreads
+    static_assert(TILE % (kSortThreads * L) == 0, "a sort tile is a whole number of passes");
+    for (int pass = 0; pass < TILE / (kSortThreads * L); ++pass) {
+        const int64_t b0 = (int64_t)blockIdx.x * TILE + (int64_t)pass * (kSortThreads * L) + threadIdx.x;  // lanes b0 + l * kSortThreads
         int slot[L], key[L], steps[L], root[L];
         unsigned long long packed[L];
         bool on[L];
@@ -734,7 +757,7 @@ inline size_t keys_hybrid_lds_bytes(int n_hot, int n_upper, int A, int C) {
            (size_t)n_upper * sizeof(int32_t);
 }
 
-template <int A, int L>
+template <int A, int L, int TILE>
 __global__ __launch_bounds__(kSortThreads) void k_bucket_keys_hybrid(const UpperWalk *__restrict__ walk, const int32_t *__restrict__ upper_list,
                                                                      const int32_t *__restrict__ hot_list, const int32_t *__restrict__ hot_of_g,
                                                                      int n_hot, int n_upper, const Trans *__restrict__ trans,
@@ -747,7 +770,7 @@ __global__ __launch_bounds__(kSortThreads) void k_bucket_keys_hybrid(const Upper
                                                                      int32_t *__restrict__ hist) {
     extern __shared__ __attribute__((aligned(16))) unsigned char keys_smem[];
     constexpr int PS = kPolStride<A>;
-    constexpr int kPasses = kSortLanes / (kSortThreads * L);
+    constexpr int kPasses = TILE / (kSortThreads * L);
     int my_keys[kPasses][L];
     const int AAC = A * A * C;
     UpperWalk *w = reinterpret_cast<UpperWalk *>(keys_smem);                                                           // [n_hot][A][A][C]
@@ -765,7 +788,7 @@ __global__ __launch_bounds__(kSortThreads) void k_bucket_keys_hybrid(const Upper
     __syncthreads();
 #pragma unroll
     for (int pass = 0; pass < kPasses; ++pass) {
-        const int64_t b0 = (int64_t)blockIdx.x * kSortLanes + (int64_t)pass * (kSortThreads * L) + threadIdx.x;  // lanes b0 + l * kSortThreads
+        const int64_t b0 = (int64_t)blockIdx.x * TILE + (int64_t)pass * (kSortThreads * L) + threadIdx.x;  // lanes b0 + l * kSortThreads
         int state[L], hot[L], key[L], steps[L];  // hot: position of the lane's upper state in the staged tables, or -1
         unsigned long long packed[L];
         bool on[L];
@@ -867,14 +890,15 @@ __global__ __launch_bounds__(kSortThreads) void k_bucket_keys_hybrid(const Upper
 
 // ---------------------------------------------------------------------------------------- 2. stable counting sort by key
 // hist[blk][bucket] = #lanes of block blk (kSortLanes consecutive lanes) with that key.
+template <int TILE>
 __global__ __launch_bounds__(kSortThreads) void k_bucket_hist(int64_t B, int n_buckets, const int32_t *__restrict__ keys,
                                                               int32_t *__restrict__ hist) {
     extern __shared__ int32_t cnt[];
     for (int i = threadIdx.x; i < n_buckets; i += kSortThreads) cnt[i] = 0;
     __syncthreads();
-    const int64_t base = (int64_t)blockIdx.x * kSortLanes;
+    const int64_t base = (int64_t)blockIdx.x * TILE;
 #pragma unroll
-    for (int r = 0; r < kSortLanes / kSortThreads; ++r) {
+    for (int r = 0; r < TILE / kSortThreads; ++r) {
         const int64_t b = base + (int64_t)r * kSortThreads + threadIdx.x;
         if (b < B) atomicAdd(&cnt[keys[b]], 1);
     }
@@ -1166,6 +1190,7 @@ __global__ __launch_bounds__(kSortThreads) void k_bucket_scan(int n_blocks, int 
 // and *n_staged their number: every workgroup takes the exclusive prefix of the non-empty groups' spans for itself and writes the
 // groups blockIdx.x, blockIdx.x + gridDim.x, ...  (Before r04: k_group_flags + a three-launch compaction of 2S flags.)  visited (int32
 // [2S], optional) is cleared here for the rollout that follows (the two rows of the absorbing state are set: absorbed slots show them).
+template <int TILE>
 __global__ __launch_bounds__(kSortThreads) void k_bucket_scatter(int64_t B, int n_buckets, const int32_t *__restrict__ keys,
                                                                  const int32_t *__restrict__ hist, const int32_t *__restrict__ totals, int chunk,
                                                                  Item *__restrict__ items, int32_t *__restrict__ n_items,
@@ -1179,11 +1204,11 @@ __global__ __launch_bounds__(kSortThreads) void k_bucket_scatter(int64_t B, int 
                                                                  const rnad_step_params_t *__restrict__ sp) {
     extern __shared__ int32_t cnt[];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int64_t base = (int64_t)blockIdx.x * kSortLanes + (int64_t)wave * (kSortLanes / 16);
-    int32_t key[kSortLanes / kSortThreads];
-    uint32_t root_word[kSortLanes / kSortThreads];  // (second staging level: the lanes' root words go through the same permutation)
+    const int64_t base = (int64_t)blockIdx.x * TILE + (int64_t)wave * (TILE / 16);
+    int32_t key[TILE / kSortThreads];
+    uint32_t root_word[TILE / kSortThreads];  // (second staging level: the lanes' root words go through the same permutation)
 #pragma unroll
-    for (int r = 0; r < kSortLanes / kSortThreads; ++r) {
+    for (int r = 0; r < TILE / kSortThreads; ++r) {
         const int64_t b = base + r * 64 + lane;
         key[r] = b < B ? keys[b] : -1;
         root_word[r] = (stage_root && b < B) ? stage_root[b] : 0u;
@@ -1247,11 +1272,11 @@ __global__ __launch_bounds__(kSortThreads) void k_bucket_scatter(int64_t B, int 
     int32_t *wcnt = cnt + 2 * n_buckets + 1;  // [R][n_buckets]
     for (int i = threadIdx.x; i < R * n_buckets; i += kSortThreads) wcnt[i] = 0;
     __syncthreads();
-    int32_t rank[kSortLanes / kSortThreads];
+    int32_t rank[TILE / kSortThreads];
     for (int turn = 0; turn < G; ++turn) {  // the waves of a row, in wave order
         if (wave % G == turn) {
 #pragma unroll
-            for (int r = 0; r < kSortLanes / kSortThreads; ++r) rank[r] = key[r] >= 0 ? atomicAdd(&wcnt[my_row * n_buckets + key[r]], 1) : 0;
+            for (int r = 0; r < TILE / kSortThreads; ++r) rank[r] = key[r] >= 0 ? atomicAdd(&wcnt[my_row * n_buckets + key[r]], 1) : 0;
         }
         __syncthreads();
     }
@@ -1265,7 +1290,7 @@ __global__ __launch_bounds__(kSortThreads) void k_bucket_scatter(int64_t B, int 
     }
     __syncthreads();
 #pragma unroll
-    for (int r = 0; r < kSortLanes / kSortThreads; ++r)
+    for (int r = 0; r < TILE / kSortThreads; ++r)
         if (key[r] >= 0) {
             const int32_t at = wcnt[my_row * n_buckets + key[r]] + rank[r];
             lane_ids[at] = (int32_t)(base + r * 64 + lane);
@@ -2818,13 +2843,13 @@ int rollout_bucketed_impl(const rnad_tree_t *tree, const RolloutBuffers &tr, boo
         if (use_lds) {  // the upper states' tables fit the LDS: walk there, one sort tile per workgroup
             keys_with_hist = true;
             if (keys_lds > 48 * 1024)
-                RNAD_DISPATCH_A(tree->A, RNAD_HIP_OK(hipFuncSetAttribute((const void *)k_bucket_keys_lds<kA, kPlayLds>,
-                                                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)keys_lds)));
-            RNAD_DISPATCH_A(tree->A, hipLaunchKernelGGL((k_bucket_keys_lds<kA, kPlayLds>), dim3(p.sort_blocks), dim3(kSortThreads), keys_lds, stream,
+                RNAD_DISPATCH_TILE(p, RNAD_DISPATCH_A(tree->A, RNAD_HIP_OK(hipFuncSetAttribute((const void *)k_bucket_keys_lds<kA, kPlayLds, kTile>,
+                                                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)keys_lds))));
+            RNAD_DISPATCH_TILE(p, RNAD_DISPATCH_A(tree->A, hipLaunchKernelGGL((k_bucket_keys_lds<kA, kPlayLds, kTile>), dim3(p.sort_blocks), dim3(kSortThreads), keys_lds, stream,
                                                         (const UpperWalk *)p.cut->upper_walk, (const int32_t *)p.cut->upper_list, p.cut->n_upper, nb,
                                                         tree->C, S, B, n_steps, policy_tab, policy_stride, (int)p.cut->host_bucket_of[1],
                                                         p.cut->n_groups, seed, device_params, lane0, s.keys, s.decisions, s.hist, norm, stage,
-                                                        expand ? *expand : KeysExpand{}));
+                                                        expand ? *expand : KeysExpand{})));
             // (the copies themselves: workgroups of the scan launch below)
         } else if (p.cut->upper_walk && p.cut->n_hot > 0 && p.cut->n_hot < p.cut->n_upper && !walk_global &&
                    !(getenv("RNAD_KEYS_HYBRID") && atoi(getenv("RNAD_KEYS_HYBRID")) == 0)) {
@@ -2832,14 +2857,14 @@ int rollout_bucketed_impl(const rnad_tree_t *tree, const RolloutBuffers &tr, boo
             const size_t hyb_lds = std::max(keys_hybrid_lds_bytes(p.cut->n_hot, p.cut->n_upper, tree->A, tree->C), (size_t)nb * sizeof(int32_t));
             keys_with_hist = true;
             if (hyb_lds > 48 * 1024)
-                RNAD_DISPATCH_A(tree->A, RNAD_HIP_OK(hipFuncSetAttribute((const void *)k_bucket_keys_hybrid<kA, kPlayLds>,
-                                                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)hyb_lds)));
-            RNAD_DISPATCH_A(tree->A, hipLaunchKernelGGL((k_bucket_keys_hybrid<kA, kPlayLds>), dim3(p.sort_blocks), dim3(kSortThreads), hyb_lds, stream,
+                RNAD_DISPATCH_TILE(p, RNAD_DISPATCH_A(tree->A, RNAD_HIP_OK(hipFuncSetAttribute((const void *)k_bucket_keys_hybrid<kA, kPlayLds, kTile>,
+                                                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)hyb_lds))));
+            RNAD_DISPATCH_TILE(p, RNAD_DISPATCH_A(tree->A, hipLaunchKernelGGL((k_bucket_keys_hybrid<kA, kPlayLds, kTile>), dim3(p.sort_blocks), dim3(kSortThreads), hyb_lds, stream,
                                                         (const UpperWalk *)p.cut->upper_walk, (const int32_t *)p.cut->upper_list,
                                                         (const int32_t *)p.cut->hot_list, (const int32_t *)p.cut->hot_of, p.cut->n_hot, p.cut->n_upper,
                                                         tree->trans, (const int32_t *)p.cut->bucket_of, tree->C, S, B, n_steps, policy_tab, policy_stride,
                                                         vec4, (int)p.cut->host_bucket_of[1], p.cut->n_groups, seed, device_params, lane0, s.keys,
-                                                        s.decisions, norm, stage, nb, s.hist));
+                                                        s.decisions, norm, stage, nb, s.hist)));
         } else {
             RNAD_DISPATCH_A(tree->A, hipLaunchKernelGGL((k_bucket_keys<kA, kPlay>), dim3(blocks_for(B, kThreads * kPlay)), dim3(kThreads), 0, stream, tree->trans, tree->C,
                                                         S, B, n_steps, policy_tab, policy_stride, vec4, (const int32_t *)p.cut->bucket_of,
@@ -2849,7 +2874,8 @@ int rollout_bucketed_impl(const rnad_tree_t *tree, const RolloutBuffers &tr, boo
     const size_t lds = (size_t)nb * sizeof(int32_t);
     if (sort_phase) {
         ProfScope sort_passes(PROF_BUCKET_SORT, stream);
-        if (!keys_with_hist) hipLaunchKernelGGL(k_bucket_hist, dim3(p.sort_blocks), dim3(kSortThreads), lds, stream, B, nb, (const int32_t *)s.keys, s.hist);
+        if (!keys_with_hist)
+            RNAD_DISPATCH_TILE(p, hipLaunchKernelGGL(k_bucket_hist<kTile>, dim3(p.sort_blocks), dim3(kSortThreads), lds, stream, B, nb, (const int32_t *)s.keys, s.hist));
         {
             const int scan_blocks = (nb + kScanCols - 1) / kScanCols;
             int copy_blocks = 0;
@@ -2868,12 +2894,12 @@ int rollout_bucketed_impl(const rnad_tree_t *tree, const RolloutBuffers &tr, boo
         const size_t scatter_lds = ((2 + wave_rows) * (size_t)nb + 1) * sizeof(int32_t);
         RNAD_REQUIRE(scatter_lds <= 160 * 1024, "rnad_bucket_sort: %d buckets do not fit the sort's LDS", nb);
         if (scatter_lds > 48 * 1024)
-            RNAD_HIP_OK(hipFuncSetAttribute((const void *)k_bucket_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, (int)scatter_lds));
-        hipLaunchKernelGGL(k_bucket_scatter, dim3(p.sort_blocks), dim3(kSortThreads), scatter_lds, stream, B, nb, (const int32_t *)s.keys,
+            RNAD_DISPATCH_TILE(p, RNAD_HIP_OK(hipFuncSetAttribute((const void *)k_bucket_scatter<kTile>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)scatter_lds)));
+        RNAD_DISPATCH_TILE(p, hipLaunchKernelGGL(k_bucket_scatter<kTile>, dim3(p.sort_blocks), dim3(kSortThreads), scatter_lds, stream, B, nb, (const int32_t *)s.keys,
                            (const int32_t *)s.hist, (const int32_t *)s.totals, fused ? fused_chunk(tree, p, fused->distinct) : p.chunk, (Item *)items, n_items, lane_ids, wave_rows, S,
                            p.cut->n_groups, (const int32_t *)p.cut->bucket_lo, (const int32_t *)p.cut->bucket_span,
                            (const int32_t *)p.cut->group_by_lo, staged_rows, n_staged, tr.visited, (const uint32_t *)stage.root, stage.sorted,
-                           (const uint32_t *)stage.mark0, stage.root ? stage_rows0 : nullptr, stage.counts, seed, device_params);
+                           (const uint32_t *)stage.mark0, stage.root ? stage_rows0 : nullptr, stage.counts, seed, device_params));
         if (group_flags)
             hipLaunchKernelGGL(k_group_flags, dim3(blocks_for(S)), dim3(kThreads), 0, stream, S, (const int32_t *)p.cut->bucket_of,
                                p.cut->n_groups, (const int32_t *)s.totals, group_flags);

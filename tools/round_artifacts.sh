@@ -1,7 +1,7 @@
 #!/bin/bash
 # Everything the round's measurement row is judged on, from the CURRENT build, on the GPU box:  tools/round_artifacts.sh <tag>
 # Writes under gpurun_out/ (copy what should be kept into profiles/).
-tag=${1:-r04}
+tag=${1:-r05}
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd $R
 O=gpurun_out
