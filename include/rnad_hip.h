@@ -494,13 +494,44 @@ int rnad_rollout_bucketed_compact_expand(const rnad_tree_t *tree, int T_cap, int
  * (rnad_tree_info(tree, 6)) they are known without a collective: N_0 = N_1 = global lanes * T_cap / 2. */
 #define RNAD_PLAY_LEARN_FINISH 1
 #define RNAD_PLAY_LEARN_DISTINCT 2
+/* The learner on the tree's LEAF PATHS (r05; `leaf` of rnad_rollout_learn_bucketed_compact, NULL: the learner per lane).  A state has
+ * exactly one parent entry (tree.py:311-330: ids are DFS pre-order), so the transition a lane leaves the tree by -- (state, row action,
+ * column action, outcome) with index == 0 -- fixes its whole trajectory: states, actions, reward (episode.py:96-125).  The on-policy
+ * update of learn/rnad.py:365-425 is a sum over the lanes of addends that depend on the trajectory alone, i.e.  sum over the tree's
+ * terminal transitions of  (lanes that took it) x (the addends of that trajectory)  -- in the learner's 64-bit fixed point: the same
+ * bits.  The caller builds, ONCE per tree and cut, the batch of those trajectories in the compact layout (one column per terminal
+ * transition, sorted by bucket, with its work items: what rnad_rollout_bucketed_compact would leave had every trajectory been played
+ * once; rnad_leaf_paths_pack writes the relative states); per step the rollout's launch leaves, per lane, the column of the transition it
+ * left the tree by (col_of: terminal transition -> column; in `scratch`), and the learner runs on the n_cols columns -- a work item counts,
+ * in LDS, the lanes of its bucket that fall into its columns (items of at most 256 columns) and skips the columns nobody played.
+ * Its cost no longer grows with the batch, and lanes that share a trajectory are learned from once (configs[1]: 531 441 columns for
+ * 2^20 .. 2^22 lanes).  Rollout and learner are two launches then.  Needs T_cap == 2 * depth (every lane has left the tree by the end
+ * of the window). */
+typedef struct rnad_leaf_paths {
+    int64_t n_cols;            /* columns: one per terminal transition of a reachable state */
+    int32_t rows, T_cap;       /* the cut (rnad_bucket_plan out[0]) and window the columns were packed for */
+    const void *states;        /* relative states [T_cap + 1, n_cols], 1 or 2 bytes each (rnad_leaf_paths_pack) */
+    const uint64_t *acts;      /* [n_cols] 3 bits of action per env step */
+    const float *final_reward; /* [n_cols] value of the terminal transition */
+    const int32_t *items;      /* [max_items][4] work items over the columns: begin, count (<= 256), bucket, single */
+    const int32_t *n_items;    /* device int32: their number */
+    int32_t max_items;
+    const int32_t *col_of;     /* [S * A * A * C]: column of transition ((s * A + a0) * A + a1) * C + c, -1 if it is not terminal */
+} rnad_leaf_paths_t;
+/* relative states of the columns from their dense states (int32 [T1, n_cols], bucket order, 0 once the episode is over) under the cut
+ * rnad_bucket_plan chooses for batches of plan_B lanes; mismatch (device int32, caller-zeroed): set if a column does not lie in its
+ * item's bucket; rows_out / rel_bytes_out (host): the cut's table rows and the width of a relative state. */
+int rnad_leaf_paths_pack(const rnad_tree_t *tree, int64_t plan_B, int T1, int64_t n_cols, const int32_t *indices, const int32_t *items,
+                         const int32_t *n_items, int32_t max_items, void *states, int32_t *mismatch, int32_t *rows_out, int32_t *rel_bytes_out,
+                         void *stream);
 int rnad_rollout_learn_bucketed_compact(const rnad_tree_t *tree, int T_cap, int64_t B, const float *table, int64_t table_stride,
                                         uint64_t seed, int64_t lane0, const rnad_step_params_t *device_params, void *scratch,
                                         int32_t *lane_ids, int32_t *items, int32_t *n_items, double *norm, void *states, int32_t *alive,
                                         uint64_t *acts, float *final_reward, const int32_t *rep_of, int n_tables, float *const *tables,
                                         const int32_t *floats_per_row, const float *fast_records, const rnad_learn_params_t *hp,
                                         void *accumulators, int flags, const double *norm_global, float *dlogit_tab, float *dv_tab,
-                                        const int32_t *rows, const int64_t *n_rows, const rnad_row_groups_t *groups, void *stream);
+                                        const int32_t *rows, const int64_t *n_rows, const rnad_row_groups_t *groups,
+                                        const rnad_leaf_paths_t *leaf, void *stream);
 int rnad_bucket_indices(const rnad_tree_t *tree, int T1, int64_t B, const void *states, const int32_t *items, const int32_t *n_items,
                         int32_t *indices, void *stream);
 int rnad_bucket_pack_states(const rnad_tree_t *tree, int T1, int64_t B, const int32_t *indices, const int32_t *items,

@@ -1043,7 +1043,7 @@ constexpr int kItemsInline = 16;
 // first_s (LDS, [n_buckets + 1]): scratch, the first item of every bucket (exclusive prefix of the item counts).
 __device__ __forceinline__ void items_phase(int n_buckets, int chunk, const int32_t *__restrict__ totals, int32_t *__restrict__ start_s,
                                             int32_t *__restrict__ first_s, bool write_items, Item *__restrict__ items,
-                                            int32_t *__restrict__ n_items) {
+                                            int32_t *__restrict__ n_items, int32_t *__restrict__ bucket_start_out = nullptr) {
     __shared__ int32_t wave_l[16], wave_i[16];
     __shared__ int32_t total_s, most;
     if (threadIdx.x == 0) most = 0;
@@ -1085,6 +1085,7 @@ __device__ __forceinline__ void items_phase(int n_buckets, int chunk, const int3
         const int32_t n = totals[i], ni = (n + chunk - 1) / chunk;
         start_s[i] = run_l;
         first_s[i] = run_i;
+        if (write_items && bucket_start_out) bucket_start_out[i] = run_l;  // (global copy: the leaf-path learner finds a bucket's lanes by it)
         run_l += n;
         run_i += ni;
     }
@@ -1201,7 +1202,7 @@ __global__ __launch_bounds__(kSortThreads) void k_bucket_scatter(int64_t B, int 
                                                                  const uint32_t *__restrict__ stage_root, uint32_t *__restrict__ stage_sorted,
                                                                  const uint32_t *__restrict__ stage_mark0, int32_t *__restrict__ stage_rows0,
                                                                  unsigned long long *__restrict__ stage_count0, uint64_t seed,
-                                                                 const rnad_step_params_t *__restrict__ sp) {
+                                                                 const rnad_step_params_t *__restrict__ sp, int32_t *__restrict__ bucket_start_out) {
     extern __shared__ int32_t cnt[];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int64_t base = (int64_t)blockIdx.x * TILE + (int64_t)wave * (TILE / 16);
@@ -1262,7 +1263,7 @@ __global__ __launch_bounds__(kSortThreads) void k_bucket_scatter(int64_t B, int 
         }
         __syncthreads();
     }
-    items_phase(n_buckets, chunk, totals, cnt, cnt + n_buckets, blockIdx.x == 0, items, n_items);  // cnt = bucket_start
+    items_phase(n_buckets, chunk, totals, cnt, cnt + n_buckets, blockIdx.x == 0, items, n_items, bucket_start_out);  // cnt = bucket_start
     __syncthreads();
     const int32_t *row = hist + (int64_t)blockIdx.x * n_buckets;
     for (int i = threadIdx.x; i < n_buckets; i += kSortThreads) cnt[i] += row[i];
@@ -1456,7 +1457,9 @@ __device__ __forceinline__ void rollout_items_body(const Trans *__restrict__ tra
                                                                    unsigned long long *__restrict__ acts_out,
                                                                    float *__restrict__ reward_out, int32_t *__restrict__ visited,
                                                                    double *__restrict__ norm_rep = nullptr, Hand *hand = nullptr,
-                                                                   const Distinct distinct = Distinct{}) {
+                                                                   const Distinct distinct = Distinct{},
+                                                                   const int32_t *__restrict__ col_of = nullptr,
+                                                                   int32_t *__restrict__ leaf_col = nullptr) {
     constexpr int NT = kThreads / L, NW = NT / 64;
     static_assert(NT >= 64 && NT > kCompactSteps, "a wave at least, and a thread per alive counter");
     __shared__ int32_t cnt[NW][kMaxSteps + 1];
@@ -1604,6 +1607,12 @@ __device__ __forceinline__ void rollout_items_body(const Trans *__restrict__ tra
                     if (next == 0) {
                         reward_final[l] = rew;
                         if (DISTINCT) last_key[l] = (state[l] - lo) * distinct.codes + (a0[l] * A + a1[l]) * C + outcome;
+                        if (leaf_col)
+                            // leaf paths (rnad_leaf_paths_t): the transition a lane leaves the tree by fixes its whole trajectory (a state has one
+                            // parent entry) -- the column of that trajectory, per lane in bucket order; the learner's workgroups count the lanes
+                            // of their columns in LDS (a global counter per column took a device-scope atomic per lane: 15 us per 2^20 lanes)
+                            leaf_col[j[l]] = col_of[(((uint32_t)state[l] * A + a0[l]) * A + a1[l]) * C + outcome];
+
                     }
                     state[l] = next;
                 }
@@ -2109,7 +2118,7 @@ __global__ __launch_bounds__(kThreads) void k_bucket_learn(int T, int64_t B, int
 #else
 #define RNAD_LEARN_ATTR
 #endif
-template <int A, typename REL, bool LOSSES, bool DISTINCT = false>
+template <int A, typename REL, bool LOSSES, bool DISTINCT = false, bool WEIGHTED = false>
 __device__ __forceinline__ void learn_c_body(int T, int64_t B, int64_t S, int sub_rows, int path_words, int n_groups, int up_stride,
                                                              const Item *__restrict__ items, const int32_t *__restrict__ n_items,
                                                              const int32_t *__restrict__ bucket_of, const int32_t *__restrict__ bucket_lo,
@@ -2122,7 +2131,9 @@ __device__ __forceinline__ void learn_c_body(int T, int64_t B, int64_t S, int su
                                                              int32_t *__restrict__ overflow, const int32_t *__restrict__ alive_part,
                                                              int alive_blocks, int T1, int32_t *__restrict__ alive,
                                                              double *__restrict__ norm_out, const Hand *hand = nullptr,
-                                                             const Distinct distinct = Distinct{}) {
+                                                             const Distinct distinct = Distinct{}, const int32_t *__restrict__ leaf_col = nullptr,
+                                                             const int32_t *__restrict__ lane_start = nullptr,
+                                                             const int32_t *__restrict__ lane_total = nullptr) {
     extern __shared__ unsigned long long tab[];
     constexpr int PS = (A + 1) | 1, TS = kTabStride<A>, FS = kFastStride<A>, RS = kRowStride<A>;
     const int kPathWords = path_words;
@@ -2149,12 +2160,34 @@ __device__ __forceinline__ void learn_c_body(int T, int64_t B, int64_t S, int su
     double part[4] = {0.0, 0.0, 0.0, 0.0};
     bool ovf = false;
     // distinct: one pass per kThreads listed trajectories, each weighted with the number of lanes that took it
-    constexpr bool by_trajectory = DISTINCT;
-    const int n_work = by_trajectory ? *distinct.n : item.count;
+    // WEIGHTED (leaf paths, rnad_leaf_paths_t): column j is a trajectory of the TREE and its weight the number of lanes of the batch that
+    // played it; a column nobody played is skipped.  64-bit integer sums: weight x addend is what the per-lane learner adds up over those
+    // lanes, bit for bit.  The weights of this item's columns: the lanes of the item's BUCKET are lane_total[bucket] consecutive entries of
+    // leaf_col (bucket order) from lane_start[bucket] on -- every workgroup of the bucket reads them all and counts, in LDS, those that
+    // fall into its own columns (<= kThreads of them).
+    constexpr bool by_trajectory = DISTINCT || WEIGHTED;
+    __shared__ int32_t w_lds[WEIGHTED ? kThreads : 1];
+    if (WEIGHTED) {
+        w_lds[threadIdx.x] = 0;
+        __syncthreads();
+        const int32_t l0 = lane_start[item.bucket], ln = lane_total[item.bucket];
+        for (int i = threadIdx.x; i < ln; i += kThreads) {
+            const uint32_t c = (uint32_t)(leaf_col[l0 + i] - item.begin);
+            if (c < (uint32_t)item.count) atomicAdd(&w_lds[c], 1);
+        }
+        __syncthreads();
+    }
+    const int n_work = DISTINCT ? *distinct.n : item.count;
     for (int base = 0; base < n_work; base += kThreads) {
-        const bool active = base + (int)threadIdx.x < n_work;
-        const uint32_t j = by_trajectory ? (uint32_t)(active ? distinct.column[base + threadIdx.x] : item.begin) : (uint32_t)(item.begin + base) + threadIdx.x;
-        const long long weight = by_trajectory ? (long long)(active ? distinct.count[distinct.key[base + threadIdx.x]] : 0) : 1ll;
+        bool active = base + (int)threadIdx.x < n_work;
+        const uint32_t j = DISTINCT ? (uint32_t)(active ? distinct.column[base + threadIdx.x] : item.begin) : (uint32_t)(item.begin + base) + threadIdx.x;
+        long long weight = DISTINCT ? (long long)(active ? distinct.count[distinct.key[base + threadIdx.x]] : 0) : 1ll;
+        if (WEIGHTED) {
+            const int32_t w = active ? w_lds[threadIdx.x] : 0;  // (one pass: a leaf-path item holds <= kThreads columns)
+            weight = w;
+            active = w != 0;
+            if (__ballot(active) == 0ull) continue;  // (a wave whose columns are all empty: nothing to add, no barrier inside the loop)
+        }
         Carry cy[2];
         // (k_bucket_play_learn, an item played in one pass: this thread's own values arrive in registers)
         const bool handed = hand != nullptr && item.count <= kThreads;
@@ -2289,7 +2322,7 @@ __device__ __forceinline__ void learn_c_body(int T, int64_t B, int64_t S, int su
                       loss_part, acc, rep, losses_raw, overflow);
 }
 
-template <int A, typename REL, bool LOSSES>
+template <int A, typename REL, bool LOSSES, bool WEIGHTED = false>
 __global__ __launch_bounds__(kThreads) RNAD_LEARN_ATTR void k_bucket_learn_c(int T, int64_t B, int64_t S, int sub_rows, int path_words, int n_groups, int up_stride,
                                                              const Item *__restrict__ items, const int32_t *__restrict__ n_items,
                                                              const int32_t *__restrict__ bucket_of, const int32_t *__restrict__ bucket_lo,
@@ -2301,10 +2334,31 @@ __global__ __launch_bounds__(kThreads) RNAD_LEARN_ATTR void k_bucket_learn_c(int
                                                              unsigned long long *__restrict__ rep, double *__restrict__ losses_raw,
                                                              int32_t *__restrict__ overflow, const int32_t *__restrict__ alive_part,
                                                              int alive_blocks, int T1, int32_t *__restrict__ alive,
-                                                             double *__restrict__ norm_out) {
-    learn_c_body<A, REL, LOSSES>(T, B, S, sub_rows, path_words, n_groups, up_stride, items, n_items, bucket_of, bucket_lo, bucket_path, path_states,
-                                 path_stride, states, rec_, acts_, reward_, logit_, hp, fx, acc, rep, losses_raw, overflow, alive_part,
-                                 alive_blocks, T1, alive, norm_out);
+                                                             double *__restrict__ norm_out, const int32_t *__restrict__ leaf_col,
+                                                             const int32_t *__restrict__ lane_start, const int32_t *__restrict__ lane_total) {
+    learn_c_body<A, REL, LOSSES, false, WEIGHTED>(T, B, S, sub_rows, path_words, n_groups, up_stride, items, n_items, bucket_of, bucket_lo, bucket_path,
+                                                  path_states, path_stride, states, rec_, acts_, reward_, logit_, hp, fx, acc, rep, losses_raw, overflow,
+                                                  alive_part, alive_blocks, T1, alive, norm_out, nullptr, Distinct{}, leaf_col, lane_start, lane_total);
+}
+
+// The rollout half of the leaf-path step (rnad_leaf_paths_t): k_bucket_rollout_items with the alive counts and normalisers left in the
+// replica rows (as k_bucket_play_learn leaves them: k_bucket_finish adds them up) and, per lane, the column of the transition it leaves the
+// tree by (leaf_col, bucket order: the scratch words that held the sort keys).
+template <int A, typename REL>
+__global__ __launch_bounds__(kThreads) void k_bucket_play_count(const Trans *__restrict__ trans, int C, int64_t S, int64_t B, int T_cap,
+                                                                const float *__restrict__ policy_tab, int64_t tab_stride, int vec4, uint64_t seed,
+                                                                const rnad_step_params_t *__restrict__ sp, int64_t lane0,
+                                                                const int32_t *__restrict__ lane_ids,
+                                                                const unsigned long long *__restrict__ decisions, const Item *__restrict__ items,
+                                                                const int32_t *__restrict__ n_items, const int32_t *__restrict__ bucket_path,
+                                                                const int32_t *__restrict__ bucket_lo, const int32_t *__restrict__ path_states,
+                                                                int path_stride, int n_groups, REL *__restrict__ states,
+                                                                int32_t *__restrict__ alive_rep, double *__restrict__ norm_rep,
+                                                                unsigned long long *__restrict__ acts_out, float *__restrict__ reward_out,
+                                                                const int32_t *__restrict__ col_of, int32_t *__restrict__ leaf_col) {
+    rollout_items_body<A, REL, 1>(trans, C, S, B, T_cap, policy_tab, tab_stride, vec4, seed, sp, lane0, lane_ids, decisions, items, n_items,
+                                  bucket_path, bucket_lo, path_states, path_stride, n_groups, states, alive_rep, acts_out, reward_out, nullptr,
+                                  norm_rep, nullptr, Distinct{}, col_of, leaf_col);
 }
 
 // Rollout and learner of a work item in ONE launch (r04): the workgroup that played the item's lanes runs their update right away --
@@ -2744,6 +2798,7 @@ struct FusedLearn {  // the learner of the batch in the rollout's launch (k_buck
     const rnad_learn_params_t *hp;
     void *accumulators;
     bool distinct;  // the learner once per distinct trajectory of a work item (struct Distinct)
+    const rnad_leaf_paths_t *leaf = nullptr;  // the learner on the tree's leaf paths, weighted with the lanes the rollout counted (two launches)
 };
 // k_bucket_play_learn on the distinct trajectories of a work item (struct Distinct): larger items -- more lanes share a trajectory --
 // while the counters (a key per state of the group and outcome) and the list fit the LDS beside the learner's table.
@@ -2899,7 +2954,7 @@ int rollout_bucketed_impl(const rnad_tree_t *tree, const RolloutBuffers &tr, boo
                            (const int32_t *)s.hist, (const int32_t *)s.totals, fused ? fused_chunk(tree, p, fused->distinct) : p.chunk, (Item *)items, n_items, lane_ids, wave_rows, S,
                            p.cut->n_groups, (const int32_t *)p.cut->bucket_lo, (const int32_t *)p.cut->bucket_span,
                            (const int32_t *)p.cut->group_by_lo, staged_rows, n_staged, tr.visited, (const uint32_t *)stage.root, stage.sorted,
-                           (const uint32_t *)stage.mark0, stage.root ? stage_rows0 : nullptr, stage.counts, seed, device_params));
+                           (const uint32_t *)stage.mark0, stage.root ? stage_rows0 : nullptr, stage.counts, seed, device_params, s.bucket_start));
         if (group_flags)
             hipLaunchKernelGGL(k_group_flags, dim3(blocks_for(S)), dim3(kThreads), 0, stream, S, (const int32_t *)p.cut->bucket_of,
                                p.cut->n_groups, (const int32_t *)s.totals, group_flags);
@@ -2945,6 +3000,36 @@ int rollout_bucketed_impl(const rnad_tree_t *tree, const RolloutBuffers &tr, boo
                            tr.final_reward, p.cut->rows, p.path_words, std::max(nu, 1), (const int32_t *)p.cut->bucket_of, fused->fast, *fused->hp, fx, \
                            acc, rep, overflow, p.lds / 8, d_keys_fit, f_chunk);                                                        \
     } while (0)
+                if (fused->leaf) {
+                    // rollout (lanes counted per terminal transition), then the learner on the leaf paths of the tree: n_cols columns whatever
+                    // the batch -- and none of the per-lane learner's work for lanes that share a trajectory
+                    const rnad_leaf_paths_t &lf = *fused->leaf;
+                    RNAD_REQUIRE(lf.n_cols >= 1 && lf.states && lf.acts && lf.final_reward && lf.items && lf.n_items && lf.col_of && lf.max_items >= 1,
+                                 "rnad_rollout_learn_bucketed_compact: incomplete rnad_leaf_paths_t");
+                    RNAD_REQUIRE(lf.rows == p.cut->rows && lf.T_cap == tr.T_cap && tr.T_cap == 2 * tree->max_depth,
+                                 "rnad_rollout_learn_bucketed_compact: the leaf paths were built for another cut / window (rows %d vs %d, T_cap %d vs %d, "
+                                 "2 * depth %d)", lf.rows, p.cut->rows, lf.T_cap, tr.T_cap, 2 * tree->max_depth);
+#define RNAD_PLAY_COUNT()                                                                                                              \
+    do {                                                                                                                               \
+        hipLaunchKernelGGL((k_bucket_play_count<kA, REL>), dim3((unsigned)p.max_items), dim3(kThreads), 0, stream, tree->trans, tree->C, S, B,   \
+                           tr.T_cap, policy_tab, policy_stride, vec4, seed, device_params, lane0, (const int32_t *)lane_ids,          \
+                           (const unsigned long long *)s.decisions, (const Item *)items, (const int32_t *)n_items,                     \
+                           (const int32_t *)p.cut->bucket_path, (const int32_t *)p.cut->bucket_lo, (const int32_t *)p.cut->path_states, \
+                           std::max(p.cut->max_path, 1), p.cut->n_groups, (REL *)tr.indices, cr.alive_rep, cr.norm_rep, tr.acts,       \
+                           tr.final_reward, lf.col_of, s.keys);                                                                        \
+        auto kern = k_bucket_learn_c<kA, REL, false, true>;                                                                           \
+        if (p.lds > 48 * 1024) RNAD_HIP_OK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, p.lds)); \
+        hipLaunchKernelGGL(kern, dim3((unsigned)lf.max_items + 7), dim3(kThreads), (size_t)p.lds, stream, tr.T_cap, lf.n_cols, S, p.cut->rows,  \
+                           p.path_words, p.cut->n_groups, std::max(nu, 1), (const Item *)lf.items, lf.n_items,                        \
+                           (const int32_t *)p.cut->bucket_of, (const int32_t *)p.cut->bucket_lo, (const int32_t *)p.cut->bucket_path,  \
+                           (const int32_t *)p.cut->path_states, std::max(p.cut->max_path, 1), (const REL *)lf.states, fused->fast,     \
+                           (const unsigned long long *)lf.acts, lf.final_reward, (const float *)nullptr, *fused->hp, fx, acc, rep,     \
+                           (double *)nullptr, overflow, (const int32_t *)nullptr, 0, tr.T_cap + 1, (int32_t *)nullptr, (double *)nullptr, \
+                           (const int32_t *)s.keys, (const int32_t *)s.bucket_start, (const int32_t *)s.totals);                       \
+    } while (0)
+                    RNAD_DISPATCH_REL(p, RNAD_DISPATCH_A(tree->A, RNAD_PLAY_COUNT()));
+#undef RNAD_PLAY_COUNT
+                } else
                 RNAD_DISPATCH_REL(p, RNAD_DISPATCH_A(tree->A, RNAD_PLAY_LEARN()));
 #undef RNAD_PLAY_LEARN
             } else
@@ -3131,10 +3216,11 @@ extern "C" int rnad_rollout_learn_bucketed_compact(const rnad_tree_t *tree, int 
                                                    float *const *tables, const int32_t *floats_per_row, const float *fast_records,
                                                    const rnad_learn_params_t *hp, void *accumulators, int flags, const double *norm_global,
                                                    float *dlogit_tab, float *dv_tab, const int32_t *rows, const int64_t *n_rows,
-                                                   const rnad_row_groups_t *groups, void *stream) {
+                                                   const rnad_row_groups_t *groups, const rnad_leaf_paths_t *leaf, void *stream) {
     RNAD_REQUIRE(tree && table && scratch && lane_ids && items && n_items && norm && states && alive && acts && final_reward && fast_records &&
                      hp && accumulators,
                  "rnad_rollout_learn_bucketed_compact: null argument");
+    RNAD_REQUIRE(!leaf || !(flags & RNAD_PLAY_LEARN_DISTINCT), "rnad_rollout_learn_bucketed_compact: leaf paths or distinct trajectories, not both");
     RNAD_REQUIRE(T_cap >= 1 && T_cap <= kCompactSteps && B >= 1, "rnad_rollout_learn_bucketed_compact: 1 <= T_cap <= %d, got %d", kCompactSteps, T_cap);
     RNAD_REQUIRE(table_stride >= tree->A, "rnad_rollout_learn_bucketed_compact: bad table stride");
     RNAD_REQUIRE(((uintptr_t)fast_records & 15) == 0, "rnad_rollout_learn_bucketed_compact: fast_records must be 16-byte aligned");
@@ -3156,7 +3242,7 @@ extern "C" int rnad_rollout_learn_bucketed_compact(const rnad_tree_t *tree, int 
             ex.max_quads = std::max(ex.max_quads, ex.quads[k]);
         }
     }
-    const FusedLearn fused{fast_records, hp, accumulators, (flags & RNAD_PLAY_LEARN_DISTINCT) != 0};
+    const FusedLearn fused{fast_records, hp, accumulators, (flags & RNAD_PLAY_LEARN_DISTINCT) != 0, leaf};
     const RolloutBuffers out{T_cap, B, states, nullptr, nullptr, nullptr, nullptr, nullptr, alive, (unsigned long long *)acts, final_reward, nullptr};
     if (int rc = rollout_bucketed_impl(tree, out, true, table, table_stride, 1, nullptr, 1, seed, lane0, device_params, scratch, lane_ids, items,
                                        n_items, norm, (hipStream_t)stream, 3, nullptr, nullptr, nullptr, nullptr, nullptr, false, nullptr, nullptr,
@@ -3294,7 +3380,7 @@ int learn_bucketed_impl(const rnad_tree_t *tree, int T, int64_t B, const void *i
                            (const int32_t *)p.cut->bucket_lo, (const int32_t *)p.cut->bucket_path, (const int32_t *)p.cut->path_states, \
                            std::max(p.cut->max_path, 1), (const REL *)indices, fast, acts, final_reward, records, *hp, fx, acc, rep,  \
                            losses ? losses_raw : (double *)nullptr, overflow, alive_part, (int)alive_rows(tree, B, p, true), T1,      \
-                           alive_out, norm_out);                                                                                      \
+                           alive_out, norm_out, (const int32_t *)nullptr, (const int32_t *)nullptr, (const int32_t *)nullptr);        \
     } while (0)
     {
         ProfScope one(PROF_BUCKET_LEARN, stream);
@@ -3341,6 +3427,23 @@ extern "C" int rnad_bucket_pack_states(const rnad_tree_t *tree, int T1, int64_t 
     Plan p;
     RNAD_REQUIRE(make_plan(tree, B, p), "rnad_bucket_pack_states: this tree / batch cannot be bucketed (see rnad_bucket_plan)");
     RNAD_DISPATCH_REL(p, hipLaunchKernelGGL((k_bucket_pack<REL>), dim3((unsigned)p.max_items), dim3(kThreads), 0, (hipStream_t)stream, T1, B, p.cut->rows,
+                                            (const Item *)items, n_items, (const int32_t *)p.cut->bucket_path, (const int32_t *)p.cut->bucket_lo,
+                                            (const int32_t *)p.cut->path_states, std::max(p.cut->max_path, 1), p.cut->n_groups, indices,
+                                            (REL *)states, mismatch));
+    RNAD_HIP_OK(hipGetLastError());
+    return 0;
+}
+
+extern "C" int rnad_leaf_paths_pack(const rnad_tree_t *tree, int64_t plan_B, int T1, int64_t n_cols, const int32_t *indices, const int32_t *items,
+                                    const int32_t *n_items, int32_t max_items, void *states, int32_t *mismatch, int32_t *rows_out,
+                                    int32_t *rel_bytes_out, void *stream) {
+    RNAD_REQUIRE(tree && states && items && n_items && indices && mismatch && rows_out && rel_bytes_out, "rnad_leaf_paths_pack: null argument");
+    RNAD_REQUIRE(T1 >= 1 && T1 <= kCompactSteps + 1 && n_cols >= 1 && max_items >= 1, "rnad_leaf_paths_pack: bad shape");
+    Plan p;
+    RNAD_REQUIRE(make_plan(tree, plan_B, p), "rnad_leaf_paths_pack: this tree / batch cannot be bucketed (see rnad_bucket_plan)");
+    *rows_out = p.cut->rows;
+    *rel_bytes_out = p.rel_bytes;
+    RNAD_DISPATCH_REL(p, hipLaunchKernelGGL((k_bucket_pack<REL>), dim3((unsigned)max_items), dim3(kThreads), 0, (hipStream_t)stream, T1, n_cols, p.cut->rows,
                                             (const Item *)items, n_items, (const int32_t *)p.cut->bucket_path, (const int32_t *)p.cut->bucket_lo,
                                             (const int32_t *)p.cut->path_states, std::max(p.cut->max_path, 1), p.cut->n_groups, indices,
                                             (REL *)states, mismatch));

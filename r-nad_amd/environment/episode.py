@@ -325,7 +325,7 @@ class Episodes:
         1 for every (player, state) row a live slot of the batch sits in.  defer_alive (compact, trim=False): the per-step alive
         counters and the loss normalisers are added up by the learner's launch (rnad_hip.learn_bucketed_compact) instead of by a
         kernel of their own; reading `alive` or `valid_counts` before that completes them on the spot.  learn (compact with policy_table,
-        trim=False; a dict: fast_records, hp, norm_is_global, rows, groups): the batch's on-policy update is added up by the very launch
+        trim=False; a dict: fast_records, hp, norm_is_global, rows, groups, leaf): the batch's on-policy update is added up by the very launch
         that plays it (rnad_hip.rollout_learn_bucketed_compact) and `_learned` carries its per-row gradient tables.  staged_actor (compact with
         logits_table; trees that are large next to the batch): a callable `f(rows)` that evaluates the actor's logits INTO
         logits_table on the given rnad_hip.LiveRows / RowList -- called twice: with the rows of the cut's upper states before the keys
@@ -373,7 +373,7 @@ class Episodes:
                 self.buckets, dlogit, dv = rnad_hip.rollout_learn_bucketed_compact(
                     handle, traj, policy_table[0], learn["fast_records"], learn["hp"], seed=self.seed, lane0=self.lane_offset,
                     step_params=step_params, norm_is_global=learn.get("norm_is_global", True), rows=learn.get("rows"), groups=learn.get("groups"),
-                    distinct=bool(learn.get("distinct", False)), norm_global=learn.get("norm_global"))
+                    distinct=bool(learn.get("distinct", False)), norm_global=learn.get("norm_global"), leaf=learn.get("leaf"))
                 self._learned = dict(records=policy_table[0], dlogit=dlogit, dv=dv)
                 self.lane_ids = self.buckets.lane_ids
                 self._compact = (traj, policy_table[0])

@@ -166,6 +166,9 @@ class RNaD:
         # +-1).  Exact for the forward (same bits per row); the weight gradient is the same sum in another fp32 order.  Applied when it
         # removes at least a fifth of the rows; never on logging steps, lazy rows or row sharding.
         self.dedup_rows = True
+        # Leaf paths (_leaf_now): the learner of the one-call rollout + learner on the tree's terminal transitions, weighted with the lanes
+        # that left the tree by them, instead of once per lane.  None: automatic (uniform-length trees with no more leaf paths than lanes).
+        self.leaf_paths = None
         # alpha_ahead(k): the alpha the caller will pass k steps from now (run() sets it from rnad.py:497's schedule); None: "as now".
         # Only a prediction -- a replayed step whose scalars were not the queued ones sets them itself (_graph_step).
         self.alpha_ahead = None
@@ -485,6 +488,31 @@ class RNaD:
         (default) turns it on after DISTINCT_AFTER updates of this trainer; True / False force it."""
         want = getattr(self, "distinct_trajectories", None)
         return bool(want) if want is not None else self.total_steps >= self.DISTINCT_AFTER
+
+    def _leaf_now(self, handle, local_batch, T_cap):
+        """RNaD.leaf_paths (None: automatic; True / False force it; RNAD_LEAF_PATHS=0 / 1 overrides): the learner of the one-call rollout +
+        learner runs on the tree's LEAF PATHS (rnad_hip.LeafPaths: one column per terminal transition, weighted with the lanes the rollout
+        counted on it) instead of once per lane -- the same per-row sums bit for bit (integer sums), as two launches.  Its cost is the
+        tree's, not the batch's.  Automatic when every episode has the tree's full length (so that every lane leaves the tree inside the
+        window), the rank plays at least two lanes per leaf path (measured on configs[1]'s 531 441 paths, uniform policies: a tie with the
+        one-launch rollout + learner at 2^20 lanes, 250 -> 220 us per step at 2^21, 403 -> 311 at 2^22) and the trainer is young: a
+        work item of the leaf learner counts the lanes of its bucket, so a bucket that a sharpened policy fills with a third of the batch
+        makes three workgroups read a third of the batch each (a x40 policy head at 2^20 lanes: 0.241 ms per step against 0.195 per lane
+        and 0.163 on the distinct trajectories of a work item) -- from DISTINCT_AFTER updates on, distinct_trajectories takes over."""
+        want = getattr(self, "leaf_paths", None)
+        env = os.environ.get("RNAD_LEAF_PATHS")
+        if env is not None:
+            want = env != "0"
+        if want is False or not handle.uniform_length or T_cap != 2 * handle.max_depth or T_cap > rnad_hip.COMPACT_MAX_STEPS:
+            return None
+        if want is None:
+            n = handle.__dict__.get("_n_terminal")
+            if n is None:
+                live = (self.tree.index_tensor == 0) & (self.tree.chance_tensor > 0)
+                n = handle._n_terminal = int(live[1:].sum().item())
+            if 2 * n > local_batch or self.total_steps >= self.DISTINCT_AFTER:
+                return None
+        return rnad_hip.leaf_paths(handle, local_batch, self.tree.index_tensor, self.tree.chance_tensor, self.tree.value_tensor)
 
     def _learn_params(self, alpha):
         return rnad_hip.make_learn_params(
@@ -995,9 +1023,10 @@ class RNaD:
                     # (data parallel: the finish is __learn's, after the all-reduce of the normalisers -- or, on a tree whose normalisers
                     # are known without one, the call's own; row sharding: after an all-reduce of the sums in any case)
                     known = self._known_norm(T_cap) if not shard else None
+                    leaf = self._leaf_now(handle, local_batch, T_cap)
                     learn_now = dict(fast_records=tables["fast_records"], hp=self._learn_params(alpha), norm_is_global=not self._dp(),
-                                     norm_global=known,
-                                     distinct=self._distinct_now(),
+                                     norm_global=known, leaf=leaf,
+                                     distinct=self._distinct_now() and leaf is None,
                                      rows=grouped.singles if grouped is not None else tables.get("rows"), groups=grouped)
             episodes.generate(self.net, trim=False, keep_logits=self.reuse_actor_outputs,
                               skip_absorbed=getattr(self, "skip_absorbed", True) and not self.reuse_actor_outputs,
@@ -1114,7 +1143,8 @@ class RNaD:
                 self.c_bar, self.roh_bar, self.vtrace_gamma, self.value_weight, self.neurd_weight, self.epsilon_threshold, self.n_discrete,
                 self.gamma_averaging, getattr(self, "obs_half", False), getattr(self, "store_actor_values", False), getattr(self, "fused_optimizer", True),
                 getattr(self, "compact_trajectory", True), getattr(self, "lazy_rows", None), os.environ.get("RNAD_BUCKET_ROWS"), os.environ.get("RNAD_BUCKET_CHUNK"),
-                getattr(self, "fold_legal", True), self._fuse_now(), self._fuse_now() and self._distinct_now(), getattr(self, "analytic_norm", True), os.environ.get("RNAD_FUSED_DISTINCT"), os.environ.get("RNAD_FUSED_CHUNK"))
+                getattr(self, "fold_legal", True), self._fuse_now(), self._fuse_now() and self._distinct_now(), getattr(self, "analytic_norm", True), os.environ.get("RNAD_FUSED_DISTINCT"), os.environ.get("RNAD_FUSED_CHUNK"),
+                getattr(self, "leaf_paths", None), os.environ.get("RNAD_LEAF_PATHS"), self.total_steps >= self.DISTINCT_AFTER)
 
     def _graph_step(self, buffer, alpha):
         g = getattr(self, "_graph", None)

@@ -969,8 +969,115 @@ def rollout_bucketed_compact(tree, traj, table, seed=0, lane0=0, step_params=Non
 PLAY_LEARN_FINISH, PLAY_LEARN_DISTINCT = 1, 2  # include/rnad_hip.h
 
 
+class _LeafPathsC(C.Structure):
+    """struct rnad_leaf_paths (include/rnad_hip.h)."""
+
+    _fields_ = [("n_cols", C.c_int64), ("rows", C.c_int32), ("T_cap", C.c_int32), ("states", C.c_void_p), ("acts", C.c_void_p),
+                ("final_reward", C.c_void_p), ("items", C.c_void_p), ("n_items", C.c_void_p), ("max_items", C.c_int32),
+                ("col_of", C.c_void_p)]
+
+
+class LeafPaths:
+    """The tree's leaf paths as a batch in the compact layout (struct rnad_leaf_paths): one column per terminal transition (state, row
+    action, column action, outcome) of a reachable state, sorted by the bucket of the cut that batches of `plan_B` lanes get -- the
+    trajectory every lane that leaves the tree by that transition has played (tree.py:311-330: a state has one parent entry) --, its work
+    items (<= 256 columns of one bucket) and `col_of` (transition -> column).  Built once per (tree, cut) from the tree's tensors in the reference layout (index int64 [S, C, A, A], chance, value f32 [S, C, A, A]); see leaf_paths()."""
+
+    def __init__(self, tree, plan_B, index, chance, value):
+        dev = tree.device
+        S, Cc, A = tree.S, tree.C, tree.A
+        T_cap = 2 * tree.max_depth
+        assert T_cap <= COMPACT_MAX_STEPS
+        index = index.to(dev).long()
+        live = chance.to(dev) > 0
+        bucket_of, n_groups = bucket_map(tree, plan_B)
+        bucket_of = bucket_of.to(dev).long()
+        # parent entry of every state but the root: the (only) transition that leads to it
+        s_, c_, a0_, a1_ = torch.nonzero((index != 0) & live, as_tuple=True)
+        child = index[s_, c_, a0_, a1_]
+        parent = torch.zeros((S,), dtype=torch.long, device=dev)
+        pa0, pa1 = torch.zeros_like(parent), torch.zeros_like(parent)
+        parent[child], pa0[child], pa1[child] = s_, a0_, a1_
+        # terminal transitions of reachable states (state 0 is the absorbing state: not a state of the tree)
+        ts, tc, ta0, ta1 = torch.nonzero((index == 0) & live, as_tuple=True)
+        keep = (ts != 0) & (bucket_of[ts] >= 0)
+        ts, tc, ta0, ta1 = ts[keep], tc[keep], ta0[keep], ta1[keep]
+        code = (ta0 * A + ta1) * Cc + tc
+        order = torch.argsort((bucket_of[ts] * S + ts) * (A * A * Cc) + code)  # by bucket, then state, then outcome (all distinct)
+        ts, tc, ta0, ta1, code = ts[order], tc[order], ta0[order], ta1[order], code[order]
+        n = int(ts.numel())
+        assert n >= 1, "a tree without terminal transitions"
+        self.n_cols, self.T_cap, self.plan_B = n, T_cap, plan_B
+        # depth of the last state of every column, then its path up to the root
+        depth = torch.zeros((n,), dtype=torch.long, device=dev)
+        cur = ts.clone()
+        for _ in range(tree.max_depth):
+            up = cur != 1
+            depth += up.long()
+            cur = torch.where(up, parent[cur], cur)
+        assert bool((cur == 1).all()), "every reachable state descends from state 1"
+        indices = torch.zeros((T_cap + 1, n), dtype=torch.int32, device=dev)
+        acts = torch.zeros((n,), dtype=torch.int64, device=dev)
+        cols = torch.arange(n, device=dev)
+        cur, a0, a1 = ts.clone(), ta0.clone(), ta1.clone()
+        for _ in range(tree.max_depth):
+            on = depth >= 0
+            d = depth.clamp(min=0)
+            st = torch.where(on, cur, torch.zeros_like(cur)).to(torch.int32)
+            indices[2 * d[on], cols[on]] = st[on]
+            indices[2 * d[on] + 1, cols[on]] = st[on]
+            acts += torch.where(on, (a0 << (6 * d)) | (a1 << (6 * d + 3)), torch.zeros_like(a0))  # 3 bits per env step: row step 2d, column step 2d + 1
+            a0, a1 = torch.where(on, pa0[cur], a0), torch.where(on, pa1[cur], a1)
+            cur = torch.where(on, parent[cur], cur)
+            depth = depth - 1
+        self.acts = acts.contiguous()
+        self.final_reward = value.to(dev)[ts, tc, ta0, ta1].to(F32).contiguous()
+        # work items: <= 256 consecutive columns of one bucket
+        b = bucket_of[ts]
+        uniq, counts = torch.unique_consecutive(b, return_counts=True)
+        starts = torch.cumsum(counts, 0) - counts
+        items = []
+        chunk = max(64, min(256, int(os.environ.get("RNAD_LEAF_CHUNK", "256"))))  # (tuning knob: columns per work item; one pass of a 256-thread workgroup at most)
+        for bk, st0, cnt in zip(uniq.tolist(), starts.tolist(), counts.tolist()):
+            chunks = (cnt + chunk - 1) // chunk
+            per = (cnt + chunks - 1) // chunks  # (equal shares: 729 columns are 3 x 243, not 256 + 256 + 217)
+            for k in range(chunks):
+                items.append((st0 + per * k, min(per, cnt - per * k), bk, int(chunks == 1)))
+        self.max_items = len(items)
+        self.items = torch.tensor(items, dtype=I32, device=dev).contiguous()
+        self.n_items = torch.tensor([len(items)], dtype=I32, device=dev)
+        self.col_of = torch.full((S * A * A * Cc,), -1, dtype=I32, device=dev)
+        self.col_of[ts * (A * A * Cc) + code] = cols.to(I32)
+        # relative states under that cut (1 or 2 bytes per slot)
+        bad = torch.zeros((1,), dtype=I32, device=dev)
+        rows, rel = C.c_int32(), C.c_int32()
+        states8 = torch.empty((T_cap + 1, n), dtype=torch.int16, device=dev)  # (room for the two-byte case)
+        _check(lib().rnad_leaf_paths_pack(tree.ptr, C.c_int64(plan_B), T_cap + 1, C.c_int64(n), _dp(indices, I32, "indices"),
+                                          _dp(self.items, I32, "items"), _dp(self.n_items, I32, "n_items"), self.max_items,
+                                          C.c_void_p(states8.data_ptr()), _dp(bad, I32, "mismatch"), C.byref(rows), C.byref(rel), _stream()))
+        if int(bad.item()) != 0:
+            raise RnadHipError("leaf paths: a column does not lie in its work item's bucket")
+        self.rows, self.rel_bytes = rows.value, rel.value
+        self.states = states8
+        self.indices = indices  # (tests: the dense states of the columns)
+        self.c = _LeafPathsC(n, self.rows, T_cap, states8.data_ptr(), self.acts.data_ptr(), self.final_reward.data_ptr(), self.items.data_ptr(),
+                             self.n_items.data_ptr(), self.max_items, self.col_of.data_ptr())
+
+
+def leaf_paths(tree, plan_B, index, chance, value):
+    """The LeafPaths of (tree, the cut of batches of plan_B lanes), cached on the BucketPlan.  index / chance / value: the tree's tensors in
+    the reference layout."""
+    plan = bucket_plan(tree, plan_B)
+    if plan is None:
+        return None
+    got = getattr(plan, "leaf", None)
+    if got is None:
+        got = plan.leaf = LeafPaths(tree, plan_B, index, chance, value)
+    return got
+
+
 def rollout_learn_bucketed_compact(tree, traj, records, fast_records, hp, seed=0, lane0=0, step_params=None, norm_is_global=True, rows=None,
-                                   groups=None, distinct=False, norm_global=None):
+                                   groups=None, distinct=False, norm_global=None, leaf=None):
     """rnad_rollout_learn_bucketed_compact: rollout_bucketed_compact(records) and learn_bucketed_compact of the batch it plays (T = T_cap)
     with ONE launch for rollout + learner -- the trajectory, traj.alive, buckets.norm and the per-row gradient tables of the two calls, bit
     for bit.  records: bucket_records(..., fast=True)[0] (its policy rows are the actor; a pending rows_expand job rides in the keys pass).
@@ -978,8 +1085,11 @@ def rollout_learn_bucketed_compact(tree, traj, records, fast_records, hp, seed=0
     distinct: the learner half once per distinct trajectory of a (larger) work item, weighted with its lanes (RNAD_PLAY_LEARN_DISTINCT).
     norm_global (f64 [2], device): the finish divides by these normalisers -- those of a global batch -- instead of the batch's own
     (buckets.norm still receives the batch's own counts); implies the finish.
+    leaf (LeafPaths of this tree and batch size): rollout and learner as two launches, the learner on the tree's leaf paths weighted with
+    the lanes that played them -- the same per-row sums bit for bit, at a cost that does not grow with the batch.
     Returns (buckets, dlogit, dv); the tables are None when the finish is left to the caller."""
     assert traj.compact and traj.T_cap <= COMPACT_MAX_STEPS
+    assert leaf is None or (leaf.plan_B == traj.B and leaf.T_cap == traj.T_cap and not distinct)
     plan = bucket_plan(tree, traj.B)
     if plan is None:
         raise RnadHipError(lib().rnad_last_error().decode())
@@ -1014,7 +1124,7 @@ def rollout_learn_bucketed_compact(tree, traj, records, fast_records, hp, seed=0
         _dp(plan.accumulators, torch.int64, "accumulators"),
         (PLAY_LEARN_FINISH if norm_is_global else 0) | (PLAY_LEARN_DISTINCT if distinct else 0), _dp(norm_global, F64, "norm_global", True),
         _dp(dlogit, F32, "dlogit_tab", True),
-        _dp(dv, F32, "dv_tab", True), *_row_list(rows), groups, _stream()))
+        _dp(dv, F32, "dv_tab", True), *_row_list(rows), groups, C.byref(leaf.c) if leaf is not None else None, _stream()))
     if pending is not None:
         records._expand = None
     buckets.alive_pending = None

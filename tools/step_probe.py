@@ -32,6 +32,8 @@ def main():
     ap.add_argument("--width", type=int, default=256)
     ap.add_argument("--freeze", action="store_true", help="restore the nets' weights before every step (ablated kernels write garbage gradients)")
     ap.add_argument("--no-graph", action="store_true", help="enqueue every step eagerly (one dispatch per kernel launch for the counter passes)")
+    ap.add_argument("--sharp", type=float, default=0.0, help="scale the learner's policy output layer by this factor first (a near-deterministic actor, as after training)")
+    ap.add_argument("--distinct", action="store_true", help="RNaD.distinct_trajectories = True")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     torch.cuda.set_device(0)
@@ -49,6 +51,12 @@ def main():
     with torch.no_grad():
         for p in rn.net_reg_.parameters():
             p.mul_(1.001)
+        if args.sharp:
+            for name, p in rn.net.named_parameters():
+                if name.startswith("policy_fc1"):
+                    p.mul_(args.sharp)
+    if args.distinct:
+        rn.distinct_trajectories = True
     buf = Buffer(1)
     for i in range(5):
         rn.train_step(buf, 0.3)
