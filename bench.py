@@ -695,7 +695,7 @@ def kernel_report(prof, A, C, args, B, T, live_slots, tree, mode_now):
                 rh.PROF_BUCKET_LEARN: "k_bucket_play_learn" if fused else "k_bucket_learn_c" if compact else "k_bucket_learn",
                 rh.PROF_OBSERVE: "k_observe"}
     mix_name = {rh.PROF_BUCKET_KEYS: f"k_bucket_keys_lds<{A}, 1, 4096>", rh.PROF_BUCKET_ROLLOUT: f"k_bucket_rollout_items<{A}, {rel}, 1>",
-                rh.PROF_BUCKET_LEARN: f"k_bucket_play_learn<{A}, {rel}, false>" if fused else f"k_bucket_learn_c<{A}, {rel}, false>"}
+                rh.PROF_BUCKET_LEARN: f"k_bucket_play_learn<{A}, {rel}, false>" if fused else f"k_bucket_learn_c<{A}, {rel}, false, false>"}
     units = {rh.PROF_BUCKET_KEYS: (B, "lane"), rh.PROF_BUCKET_ROLLOUT: (slots, "slot"), rh.PROF_BUCKET_LEARN: (max(live_slots, 1), "live slot")}
     for k, p in prof.items():
         e = dict(p)

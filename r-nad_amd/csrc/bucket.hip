@@ -1263,10 +1263,14 @@ __global__ __launch_bounds__(kSortThreads) void k_bucket_scatter(int64_t B, int 
         }
         __syncthreads();
     }
+    // (this tile's row of the prefixed histogram, requested before the prefix of the totals instead of after it: one round trip to
+    // memory less on the workgroup's critical path)
+    const int32_t *row = hist + (int64_t)blockIdx.x * n_buckets;
+    const int32_t row_first = (int)threadIdx.x < n_buckets ? row[threadIdx.x] : 0;
     items_phase(n_buckets, chunk, totals, cnt, cnt + n_buckets, blockIdx.x == 0, items, n_items, bucket_start_out);  // cnt = bucket_start
     __syncthreads();
-    const int32_t *row = hist + (int64_t)blockIdx.x * n_buckets;
-    for (int i = threadIdx.x; i < n_buckets; i += kSortThreads) cnt[i] += row[i];
+    if ((int)threadIdx.x < n_buckets) cnt[threadIdx.x] += row_first;
+    for (int i = threadIdx.x + kSortThreads; i < n_buckets; i += kSortThreads) cnt[i] += row[i];
     __syncthreads();
     // a lane's position = the bucket's start + the tile's offset (cnt) + the lanes of the tile's earlier counter rows + its rank in its row
     const int R = wave_rows, G = 16 / R, my_row = wave / G;
@@ -2461,7 +2465,11 @@ __global__ __launch_bounds__(kThreads) void k_bucket_finish(int64_t S, int row_b
         losses[0] = losses_raw[0] / (double)nf0 + losses_raw[1] / (double)nf1;
         losses[1] = losses_raw[2] / (double)nf0 + losses_raw[3] / (double)nf1;
     }
+#ifndef RNAD_FINISH_ABLATE
+#define RNAD_FINISH_ABLATE 0  // (timing experiments, tools/build_variant.sh: 1 = no row threads, 2 = no groups, 4 = no upper rows, 8 = no tickets)
+#endif
     if ((int)blockIdx.x < row_blocks) {
+        if (RNAD_FINISH_ABLATE & 1) return;
         // (few, fat workgroups: every one of them takes a ticket below)
         const int64_t limit = row_list ? *n_rows : 2 * S;
         const int64_t stride = (int64_t)row_blocks * kThreads;
@@ -2502,6 +2510,7 @@ __global__ __launch_bounds__(kThreads) void k_bucket_finish(int64_t S, int row_b
         // threads above and adds them up into the table row of the group's representative -- lane l the rows l, l + 64, ... in that order,
         // then one butterfly: operation for operation k_rows_segment_sum on the tables of a finish over all rows, without the tables.
         const int g = ((int)blockIdx.x - row_blocks - upper_blocks) * (kThreads / 64) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+        if (RNAD_FINISH_ABLATE & 2) return;
         if (g < n_multi) {
             const int lo = multi_start[g], hi = multi_start[g + 1];
             float sum[A + 1];
@@ -2542,6 +2551,7 @@ __global__ __launch_bounds__(kThreads) void k_bucket_finish(int64_t S, int row_b
         }
     } else {
         const int u = ((int)blockIdx.x - row_blocks) * (kThreads / 64) + (threadIdx.x >> 6), c = threadIdx.x & 63;
+        if (RNAD_FINISH_ABLATE & 4) return;
         if (u < 2 * n_upper) {
             const int P = u / n_upper, pos = u % n_upper;
             unsigned long long *src = rep + (((int64_t)P * n_upper + pos) * kReplicas + c) * (A + 1);
@@ -2564,6 +2574,7 @@ __global__ __launch_bounds__(kThreads) void k_bucket_finish(int64_t S, int row_b
     __shared__ int last_s;
     if (threadIdx.x == 0) last_s = 0;
     __syncthreads();  // this workgroup's reads of the flag and the loss sums are complete
+    if (RNAD_FINISH_ABLATE & 8) return;
     if (threadIdx.x == 0) {
         // (no __threadfence: a device-scope release writes the XCD's L2 back -- 22 us here -- and nothing this workgroup wrote is read
         // by the clearing one)

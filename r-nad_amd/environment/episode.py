@@ -203,6 +203,7 @@ class Episodes:
         if records is None:
             raise RuntimeError("this compact batch has no row records attached yet (Episodes.generate(compact=True, logits_table=...))")
         if traj.policy is None:
+            rnad_hip.complete_records(records)  # (distinct observations: the records of the other rows of a group are copied when first read)
             rnad_hip.bucket_expand(self.tree.handle(), traj, records)
         T = self.t_eff + 1
         for name, src in self._DENSE.items():
@@ -219,6 +220,8 @@ class Episodes:
             self._values = None
         if self._compact is not None:
             self._compact[0].invalidate()
+            if self._compact[1] is not None and getattr(self._compact[1], "_expand_job", None) is not None:
+                self._compact[1]._expand_stale = True  # (the replay rewrote the representatives' records: the copies are the last step's)
             self.__dict__["_indices"] = None
             self.states.indices = None
             for name in self._DENSE:

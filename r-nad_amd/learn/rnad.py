@@ -623,11 +623,14 @@ class RNaD:
                 if dedup is not None:
                     # every other row: a copy of its representative's records (the same bits the launch on all rows writes) -- made by the
                     # keys pass of the rollout that follows (rnad_rollout_bucketed_compact_expand), or right here when none does
-                    job = (dedup, [out["fast_records"], out["policy_rows"], out["records"]])
+                    # r05: of the three tables only the fast records and the policy rows travel with the step (11.6 of the 19 MB: the
+                    # rollout and the learner gather those); the 64-byte row records of the other rows are copied when somebody reads
+                    # them (rnad_hip.complete_records: the dense views of the batch, a logging step)
                     if defer_expand and out["policy_rows"] is not None:
-                        out["records"]._expand = job
+                        out["records"]._expand = (dedup, [out["fast_records"], out["policy_rows"]])
+                        out["records"]._expand_job, out["records"]._expand_stale = (dedup, [out["records"]]), True
                     else:
-                        rnad_hip.rows_expand(*job)
+                        rnad_hip.rows_expand(dedup, [out["fast_records"], out["policy_rows"], out["records"]])
             tables = dict(table=table, logit=out["logit"], v=out["v"], logit_target=None, v_target=out["v_target"], logit_reg=logit_reg,
                           logit_reg_=logit_reg_, packed_net=packed, fold=fold, records=out["records"], fast_records=out["fast_records"],
                           dedup=dedup)
@@ -842,6 +845,7 @@ class RNaD:
                 live = rows_now  # lazy rows: the backward runs on the visited rows only
             else:
                 rnad_hip.bucket_alive(self.tree.handle(), episodes.buckets)  # (a no-op unless the rollout left its counts to a compact learner)
+                rnad_hip.complete_records(records)
                 dlogit, dv, losses = rnad_hip.learn_bucketed(self.tree.handle(), episodes.buckets, episodes.indices[:T], episodes.action_idx[:T],
                                                              episodes.rewards[:T], episodes.policy[:T], records,
                                                              None if late_norm else norm, hp, want_losses=log is not None)
@@ -1044,6 +1048,7 @@ class RNaD:
                 # (the rollout took a path that does not carry the copies of the distinct-observation tables: make them now)
                 rnad_hip.rows_expand(*tables["records"]._expand)
                 tables["records"]._expand = None
+                rnad_hip.complete_records(tables["records"])
             if lazy:
                 # the rows this batch went through are known now: value heads, records, gradient tables, backward on those only
                 assert episodes._compact is not None, "lazy rows need the compact bucketed rollout"

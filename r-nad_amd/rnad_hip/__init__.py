@@ -1406,6 +1406,17 @@ def bucket_records(tree, logit_tab, v_tab, v_target_tab, logit_reg_tab, logit_re
     return (rec, quick) if fast else rec
 
 
+def complete_records(records):
+    """Distinct observations: the default step copies a representative's fast record and policy row to the other rows of its group (the
+    rollout and the learner gather those per row) but leaves the 64-byte ROW records of the other rows to whoever reads them -- the dense
+    views of a compact batch (bucket_expand), the dense-trajectory learner.  This makes the copies if they are still owed (`_expand_job` /
+    `_expand_stale`, set where the records are written: learn/rnad.py _table_outputs, Episodes.invalidate_derived after a graph replay)."""
+    job = getattr(records, "_expand_job", None)
+    if job is not None and getattr(records, "_expand_stale", False):
+        rows_expand(*job)
+        records._expand_stale = False
+
+
 def rows_expand(dedup, tables):
     """rnad_rows_expand: every table (float32 [2S, k], k a multiple of 4) gets, in the rows that are not representatives, the row of their
     representative (dedup: TreeHandle.obs_dedup())."""

@@ -17,8 +17,8 @@ sys.path.insert(0, os.path.join(ROOT, "r-nad_amd"))
 import isa_hist  # noqa: E402
 
 KERNELS = [
-    ("bucket.hip", "k_bucket_learn_c<3, unsigned char, false>"),
-    ("bucket.hip", "k_bucket_learn_c<5, unsigned short, false>"),
+    ("bucket.hip", "k_bucket_learn_c<3, unsigned char, false, false>"),
+    ("bucket.hip", "k_bucket_learn_c<5, unsigned short, false, false>"),
     ("bucket.hip", "k_bucket_play_learn<3, unsigned char, false>"),
     ("bucket.hip", "k_bucket_rollout_items<3, unsigned char, 1>"),
     ("bucket.hip", "k_bucket_rollout_items<5, unsigned short, 1>"),

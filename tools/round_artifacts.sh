@@ -9,7 +9,7 @@ mkdir -p $O
 # 0. issue cost of the instruction classes on this hardware (the constants of bench.py's issue roof)
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 tools/micro/valu_issue.hip -o /tmp/valu_issue && /tmp/valu_issue --json $O/${tag}_valu_issue.json > $O/${tag}_valu_issue.txt 2>&1
 # 3. HBM counters of the step's kernels (default mode, eager so that every launch is its own dispatch) and of K1
-K="k_bucket_play_learn|k_bucket_learn|k_bucket_rollout|k_bucket_keys|k_bucket_scatter|k_bucket_finish|k_mlp|k_rows_|k_row_records|k_optimizer"
+K="k_bucket_play_learn|k_bucket_play_count|k_bucket_learn|k_bucket_rollout|k_bucket_keys|k_bucket_scan|k_bucket_scatter|k_bucket_finish|k_mlp|k_rows_|k_row_records|k_optimizer"
 RNAD_NO_GRAPH=1 tools/pmc_run.sh ${tag}_fetch "FETCH_SIZE" "$K" -- python tools/step_probe.py --steps 20 --no-graph > /dev/null
 RNAD_NO_GRAPH=1 tools/pmc_run.sh ${tag}_write "WRITE_SIZE" "$K" -- python tools/step_probe.py --steps 20 --no-graph > /dev/null
 # 3b. what the learner / rollout / keys kernels are bound by: SQ issue / wait counters (their own pass)
