@@ -53,14 +53,18 @@ def _trainer(tree, B, width, lazy):
     return rn
 
 
+# depth: the configs[1] tree (A = 3, C = 1, terminal values +-1) at that depth; a name: a tree of tests/test_hip_bucket.py::TREES -- "pruned"
+# (A = 3, C = 2, ragged episode lengths) and "a5c4" (the configs[3] shape: A = 5, C = 4, pruned) take RNaD's lazy-rows step with the staged
+# actor, the default on trees that are large next to the batch
 @pytest.mark.parametrize("depth,log2_B,width,lazy", ((4, 14, 64, False), (4, 16, 256, False), (6, 16, 256, False), (6, 18, 256, False),
-                                                     (6, 16, 256, None)))
+                                                     (6, 16, 256, None), ("pruned", 14, 64, True), ("a5c4", 14, 64, True), ("pruned", 14, 64, False)))
 def test_default_step_trains_like_the_cpu_port(depth, log2_B, width, lazy):
     from environment.episode import Buffer
     from oracle.port import CpuTrainer
-    from test_hip_bucket import _native_tree
+    from test_hip_bucket import TREES, _native_tree
 
-    tree = _native_tree(A=3, C=1, depth=depth, seed=0)  # terminal values +-1: the configs[1] tree at depth 6
+    regular = not isinstance(depth, str)
+    tree = _native_tree(A=3, C=1, depth=depth, seed=0) if regular else _native_tree(**TREES[depth])
     B = 1 << log2_B
     rn = _trainer(tree, B, width, lazy)
     h = tree.handle()
@@ -83,17 +87,20 @@ def test_default_step_trains_like_the_cpu_port(depth, log2_B, width, lazy):
         seed = int(ep.seed)
         cpu.step(B, seed, alpha=alpha)
         ro = cpu.last["rollout"]
-        assert ro["T"] == T
+        Tc = ro["T"]  # (the port stops once every lane is absorbed, episode.py:194; the GPU step plays the whole window and masks)
+        assert Tc == T if regular else Tc <= T
         # ---- the batch the GPU played against the batch the port played: same lanes, same seed, (nearly) the same policy bits
         lanes = ep.lane_ids.long().cpu().numpy()
         assert np.array_equal(np.sort(lanes), np.arange(B))
-        idx = ep.indices.cpu().numpy().astype(np.int64)  # [T, B] in bucket order: column j is lane lanes[j]
+        idx_all = ep.indices.cpu().numpy().astype(np.int64)  # [T, B] in bucket order: column j is lane lanes[j]
+        assert not idx_all[Tc:].any() or flipped_total, "beyond the port's last step every lane is absorbed"
+        idx = idx_all[:Tc]
         want_idx = ro["indices"][:, lanes]
         same = (idx == want_idx).all(0)
-        act = ep.action_idx.cpu().numpy().astype(np.int64)
+        act = ep.action_idx.cpu().numpy().astype(np.int64)[:Tc]
         live = want_idx != 0
         same &= ((act == ro["actions"][:, lanes]) | ~live).all(0)
-        rew = ep.rewards.cpu().numpy()
+        rew = ep.rewards.cpu().numpy()[:Tc]
         same &= (rew.view(np.uint32) == ro["rewards"][:, lanes].view(np.uint32)).all(0)
         flipped = int((~same).sum())
         flipped_total += flipped
@@ -101,16 +108,17 @@ def test_default_step_trains_like_the_cpu_port(depth, log2_B, width, lazy):
         # ~1e-7 per decision: a handful per million lanes at most
         assert flipped <= max(2, B * T // 250_000), f"step {step}: {flipped} of {B} lanes played another episode than the port"
         if flipped == 0:
-            np.testing.assert_array_equal(ep.alive.cpu().numpy()[:T], live.sum(1))
-        if lazy is False:
-            assert getattr(ep, "_learned", None) is None and ep._compact is not None, "the compact one-launch path ran"
+            np.testing.assert_array_equal(ep.alive.cpu().numpy()[:Tc], live.sum(1))
+        assert ep._compact is not None, "the compact bucketed rollout ran"
         rn.total_steps += 1
     torch.cuda.synchronize()
     assert modes[:3] == ["eager"] * 3 and modes[-1] == "replay", modes
     g = rn._graph
     assert g["graph"] is not None and not g["failed"], "the step was captured and replayed"
-    if lazy is False:
+    if lazy is False and regular:
         assert rn._dedup_now(h, None, False, False, rn._fold()) is not None, "distinct observations are on for this tree"
+    if lazy is not False and not regular:
+        assert rn.last_rows is not None and getattr(rn.last_episodes, "staged_rows", None) is not None, "lazy rows with the staged actor ran"
     # ---- parameters and EMA target after K updates
     outliers, n, worst = 0, 0, 0.0
     for name, got_module, want_module in (("net", rn.net, cpu.net), ("target", rn.net_target, cpu.net_target)):
