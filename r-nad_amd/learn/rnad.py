@@ -212,7 +212,10 @@ class RNaD:
     def _shard_now(self, handle, local_batch, log, lazy, on_policy=True):
         """Row sharding applies: asked for, more than one rank, the default per-row step with the fused table launch, not a logging step,
         the batch learned from in bucket order (_plays_what_it_learns), and the GLOBAL batch within the headroom of the 64-bit per-row sums
-        (csrc/bucket.hip kLaneBits: one addend per lane of up to 2^22 lanes -- the all-reduce adds every rank's lanes into one sum)."""
+        (csrc/bucket.hip kLaneBits: one addend per lane of up to 2^22 lanes -- the all-reduce adds every rank's lanes into one sum, so
+        with this bound the reduced sums cannot wrap).  The per-addend overflow flag stays per rank and is not reduced: a rank that saw an
+        addend beyond the fixed-point range poisons ITS gradient tables with NaN (k_bucket_finish), its weight gradients are NaN, and the
+        43 KB gradient all-reduce that closes the step hands the NaN to every rank -- the failure is loud everywhere one collective later."""
         A = self.tree.max_actions
         return bool(getattr(self, "shard_rows", False) and self._dp() and self._world > 1 and log is None and not lazy and on_policy
                     and self.batch_size <= rnad_hip.BUCKET_MAX_LANES
