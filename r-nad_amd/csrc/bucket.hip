@@ -77,6 +77,7 @@ constexpr int kMinSortTile = kSortThreads * kPlayLds > 1024 ? kSortThreads * kPl
     switch ((p_).tile) {                                                                     \
         case 1024: { constexpr int kTile = kMinSortTile > 1024 ? kMinSortTile : 1024; __VA_ARGS__; } break; \
         case 2048: { constexpr int kTile = kMinSortTile > 2048 ? kMinSortTile : 2048; __VA_ARGS__; } break; \
+        case 8192: { constexpr int kTile = 8192; __VA_ARGS__; } break;                        \
         default: { constexpr int kTile = kSortLanes; __VA_ARGS__; } break;                    \
     }
 
@@ -358,11 +359,15 @@ bool make_plan(const rnad_tree_t *tree, int64_t B, Plan &p) {
     // (2048-lane tiles at 2^20 lanes: keys 21.0 -> 23.3 us, scatter 13.1 -> 17.3, r04) -- and not on cuts with thousands of buckets
     // (configs[3]: the scatter's per-workgroup walk over the counters is what its time is).
     p.tile = kSortLanes;
-    if (chosen->n_buckets <= 2048)
+    if (chosen->n_buckets <= 2048) {
         while (p.tile > kMinSortTile && (B + p.tile - 1) / p.tile < 256) p.tile /= 2;
+        // ... and larger ones once every CU would get more than two of 4096: a workgroup's fixed part (the upper tables staged, the prefix
+        // of all bucket totals: ~9 us of the scatter whatever the tile) is then paid half as often
+        if ((B + p.tile - 1) / p.tile > 512) p.tile = 8192;
+    }
     if (const char *t = getenv("RNAD_SORT_TILE")) {  // tuning knob / tests
         const int v = atoi(t);
-        if ((v == 1024 || v == 2048 || v == 4096) && v >= kMinSortTile) p.tile = v;
+        if ((v == 1024 || v == 2048 || v == 4096 || v == 8192) && v >= kMinSortTile) p.tile = v;
     }
     p.sort_blocks = (int)((B + p.tile - 1) / p.tile);
     if (const char *c = getenv("RNAD_BUCKET_CHUNK")) p.chunk = std::max(64, atoi(c));  // tuning knob
