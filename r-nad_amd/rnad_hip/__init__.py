@@ -988,66 +988,17 @@ class LeafPaths:
         S, Cc, A = tree.S, tree.C, tree.A
         T_cap = 2 * tree.max_depth
         assert T_cap <= COMPACT_MAX_STEPS
-        index = index.to(dev).long()
-        live = chance.to(dev) > 0
         bucket_of, n_groups = bucket_map(tree, plan_B)
-        bucket_of = bucket_of.to(dev).long()
-        # parent entry of every state but the root: the (only) transition that leads to it
-        s_, c_, a0_, a1_ = torch.nonzero((index != 0) & live, as_tuple=True)
-        child = index[s_, c_, a0_, a1_]
-        parent = torch.zeros((S,), dtype=torch.long, device=dev)
-        pa0, pa1 = torch.zeros_like(parent), torch.zeros_like(parent)
-        parent[child], pa0[child], pa1[child] = s_, a0_, a1_
-        # terminal transitions of reachable states (state 0 is the absorbing state: not a state of the tree)
-        ts, tc, ta0, ta1 = torch.nonzero((index == 0) & live, as_tuple=True)
-        keep = (ts != 0) & (bucket_of[ts] >= 0)
-        ts, tc, ta0, ta1 = ts[keep], tc[keep], ta0[keep], ta1[keep]
-        code = (ta0 * A + ta1) * Cc + tc
-        order = torch.argsort((bucket_of[ts] * S + ts) * (A * A * Cc) + code)  # by bucket, then state, then outcome (all distinct)
-        ts, tc, ta0, ta1, code = ts[order], tc[order], ta0[order], ta1[order], code[order]
-        n = int(ts.numel())
-        assert n >= 1, "a tree without terminal transitions"
+        cols = leaf_columns(index.to(dev), chance.to(dev), value.to(dev), bucket_of.to(dev), tree.max_depth)
+        n = cols["n_cols"]
         self.n_cols, self.T_cap, self.plan_B = n, T_cap, plan_B
-        # depth of the last state of every column, then its path up to the root
-        depth = torch.zeros((n,), dtype=torch.long, device=dev)
-        cur = ts.clone()
-        for _ in range(tree.max_depth):
-            up = cur != 1
-            depth += up.long()
-            cur = torch.where(up, parent[cur], cur)
-        assert bool((cur == 1).all()), "every reachable state descends from state 1"
-        indices = torch.zeros((T_cap + 1, n), dtype=torch.int32, device=dev)
-        acts = torch.zeros((n,), dtype=torch.int64, device=dev)
-        cols = torch.arange(n, device=dev)
-        cur, a0, a1 = ts.clone(), ta0.clone(), ta1.clone()
-        for _ in range(tree.max_depth):
-            on = depth >= 0
-            d = depth.clamp(min=0)
-            st = torch.where(on, cur, torch.zeros_like(cur)).to(torch.int32)
-            indices[2 * d[on], cols[on]] = st[on]
-            indices[2 * d[on] + 1, cols[on]] = st[on]
-            acts += torch.where(on, (a0 << (6 * d)) | (a1 << (6 * d + 3)), torch.zeros_like(a0))  # 3 bits per env step: row step 2d, column step 2d + 1
-            a0, a1 = torch.where(on, pa0[cur], a0), torch.where(on, pa1[cur], a1)
-            cur = torch.where(on, parent[cur], cur)
-            depth = depth - 1
-        self.acts = acts.contiguous()
-        self.final_reward = value.to(dev)[ts, tc, ta0, ta1].to(F32).contiguous()
+        indices = cols["indices"]
+        self.acts, self.final_reward, self.col_of = cols["acts"], cols["final_reward"], cols["col_of"]
         # work items: <= 256 consecutive columns of one bucket
-        b = bucket_of[ts]
-        uniq, counts = torch.unique_consecutive(b, return_counts=True)
-        starts = torch.cumsum(counts, 0) - counts
-        items = []
-        chunk = max(64, min(256, int(os.environ.get("RNAD_LEAF_CHUNK", "256"))))  # (tuning knob: columns per work item; one pass of a 256-thread workgroup at most)
-        for bk, st0, cnt in zip(uniq.tolist(), starts.tolist(), counts.tolist()):
-            chunks = (cnt + chunk - 1) // chunk
-            per = (cnt + chunks - 1) // chunks  # (equal shares: 729 columns are 3 x 243, not 256 + 256 + 217)
-            for k in range(chunks):
-                items.append((st0 + per * k, min(per, cnt - per * k), bk, int(chunks == 1)))
+        items = leaf_items(cols["bucket"], max(64, min(256, int(os.environ.get("RNAD_LEAF_CHUNK", "256")))))  # (tuning knob: columns per work item)
         self.max_items = len(items)
         self.items = torch.tensor(items, dtype=I32, device=dev).contiguous()
         self.n_items = torch.tensor([len(items)], dtype=I32, device=dev)
-        self.col_of = torch.full((S * A * A * Cc,), -1, dtype=I32, device=dev)
-        self.col_of[ts * (A * A * Cc) + code] = cols.to(I32)
         # relative states under that cut (1 or 2 bytes per slot)
         bad = torch.zeros((1,), dtype=I32, device=dev)
         rows, rel = C.c_int32(), C.c_int32()
@@ -1062,6 +1013,77 @@ class LeafPaths:
         self.indices = indices  # (tests: the dense states of the columns)
         self.c = _LeafPathsC(n, self.rows, T_cap, states8.data_ptr(), self.acts.data_ptr(), self.final_reward.data_ptr(), self.items.data_ptr(),
                              self.n_items.data_ptr(), self.max_items, self.col_of.data_ptr())
+
+
+def leaf_columns(index, chance, value, bucket_of, max_depth):
+    """The tree's terminal transitions as trajectories (pure tensor code: any device; tests/test_leaf_columns.py runs it on the CPU against
+    the oracle's rollouts).  index int64 / chance / value f32 [S, C, A, A] in the reference layout (tree.py:115-146), bucket_of int [S]
+    (< 0: unreachable).  One column per (state s >= 1, outcome c, row action a0, column action a1) with index == 0 and chance > 0, sorted
+    by (bucket, state, code) with code = (a0 * A + a1) * C + c.  Returns n_cols, bucket [n] (the column's bucket), indices int32
+    [2 * max_depth + 1, n] (the states of its env steps, 0 once the episode is over: episode.py:96-125), acts int64 [n] (3 bits per env
+    step), final_reward f32 [n] (the transition's value: rewards *= (indices == 0), episode.py:120-121) and col_of int32 [S * A * A * C]
+    (transition ((s * A + a0) * A + a1) * C + c -> column, -1 if it is not terminal)."""
+    S, Cc, A, _ = index.shape
+    dev = index.device
+    index = index.long()
+    live = chance > 0
+    bucket_of = bucket_of.long()
+    T_cap = 2 * max_depth
+    # parent entry of every state but the root: the (only) transition that leads to it (ids are DFS pre-order, tree.py:311-330)
+    s_, c_, a0_, a1_ = torch.nonzero((index != 0) & live, as_tuple=True)
+    child = index[s_, c_, a0_, a1_]
+    parent = torch.zeros((S,), dtype=torch.long, device=dev)
+    pa0, pa1 = torch.zeros_like(parent), torch.zeros_like(parent)
+    parent[child], pa0[child], pa1[child] = s_, a0_, a1_
+    # terminal transitions of reachable states (state 0 is the absorbing state: not a state of the tree)
+    ts, tc, ta0, ta1 = torch.nonzero((index == 0) & live, as_tuple=True)
+    keep = (ts != 0) & (bucket_of[ts] >= 0)
+    ts, tc, ta0, ta1 = ts[keep], tc[keep], ta0[keep], ta1[keep]
+    code = (ta0 * A + ta1) * Cc + tc
+    order = torch.argsort((bucket_of[ts] * S + ts) * (A * A * Cc) + code)  # by bucket, then state, then outcome (all distinct)
+    ts, tc, ta0, ta1, code = ts[order], tc[order], ta0[order], ta1[order], code[order]
+    n = int(ts.numel())
+    assert n >= 1, "a tree without terminal transitions"
+    # depth of the last state of every column, then its path up to the root
+    depth = torch.zeros((n,), dtype=torch.long, device=dev)
+    cur = ts.clone()
+    for _ in range(max_depth):
+        up = cur != 1
+        depth += up.long()
+        cur = torch.where(up, parent[cur], cur)
+    assert bool((cur == 1).all()), "every reachable state descends from state 1"
+    indices = torch.zeros((T_cap + 1, n), dtype=torch.int32, device=dev)
+    acts = torch.zeros((n,), dtype=torch.int64, device=dev)
+    cols = torch.arange(n, device=dev)
+    cur, a0, a1 = ts.clone(), ta0.clone(), ta1.clone()
+    for _ in range(max_depth):
+        on = depth >= 0
+        d = depth.clamp(min=0)
+        st = torch.where(on, cur, torch.zeros_like(cur)).to(torch.int32)
+        indices[2 * d[on], cols[on]] = st[on]
+        indices[2 * d[on] + 1, cols[on]] = st[on]
+        acts += torch.where(on, (a0 << (6 * d)) | (a1 << (6 * d + 3)), torch.zeros_like(a0))  # 3 bits per env step: row step 2d, column step 2d + 1
+        a0, a1 = torch.where(on, pa0[cur], a0), torch.where(on, pa1[cur], a1)
+        cur = torch.where(on, parent[cur], cur)
+        depth = depth - 1
+    col_of = torch.full((S * A * A * Cc,), -1, dtype=torch.int32, device=dev)
+    col_of[ts * (A * A * Cc) + code] = cols.to(torch.int32)
+    return dict(n_cols=n, bucket=bucket_of[ts], indices=indices, acts=acts.contiguous(),
+                final_reward=value[ts, tc, ta0, ta1].to(torch.float32).contiguous(), col_of=col_of)
+
+
+def leaf_items(bucket, chunk=256):
+    """Work items over columns sorted by bucket: (begin, count, bucket, single) with at most `chunk` columns of ONE bucket each, a bucket's
+    columns in equal shares (729 columns are 3 x 243, not 256 + 256 + 217)."""
+    uniq, counts = torch.unique_consecutive(bucket, return_counts=True)
+    starts = torch.cumsum(counts, 0) - counts
+    items = []
+    for bk, st0, cnt in zip(uniq.tolist(), starts.tolist(), counts.tolist()):
+        chunks = (cnt + chunk - 1) // chunk
+        per = (cnt + chunks - 1) // chunks
+        for k in range(chunks):
+            items.append((st0 + per * k, min(per, cnt - per * k), bk, int(chunks == 1)))
+    return items
 
 
 def leaf_paths(tree, plan_B, index, chance, value):
