@@ -313,7 +313,12 @@ def main():
     rn.use_graph = not args.no_graph
     # rollout and learner in one launch (RNaD.fuse_rollout_learner, k_bucket_play_learn): booked under the learner's id, nothing under the rollout's
     args.fused_play_learn = (mode_now is True and rnad_hip.PROF_BUCKET_LEARN in prof and rnad_hip.PROF_BUCKET_ROLLOUT not in prof)
-    if args.fused_play_learn:
+    # (the learner on the tree's leaf paths, DESIGN.md section 5.6: rollout and learner are two launches inside the same scope)
+    args.leaf_paths = bool(args.fused_play_learn and rn._fuse_now() and rn._leaf_now(handle, local_batch, T) is not None)
+    if args.leaf_paths:
+        args.fused_play_learn = False
+        prof[rnad_hip.PROF_BUCKET_LEARN]["name"] = "k_bucket_play_count + k_bucket_learn_c<WEIGHTED> (rollout, then the learner on the tree's leaf paths)"
+    elif args.fused_play_learn:
         prof[rnad_hip.PROF_BUCKET_LEARN]["name"] = "k_bucket_play_learn (rollout + learner of a work item in one launch)"
 
     # ---- the same step in the other net-evaluation modes of RNaD (reported separately, NOT `value`), eager
@@ -456,6 +461,7 @@ def main():
                                "in_effect": repr(mode_now), "what": what[mode_now],
                                "step_replayed_from_hipGraph": replayed, "compact_trajectory": bool(args.compact_in_effect),
                                "rollout_and_learner_in_one_launch": bool(getattr(args, "fused_play_learn", False)),
+                               "learner_on_leaf_paths": bool(getattr(args, "leaf_paths", False)),
                                # (RNaD.distinct_trajectories: by itself only after RNaD.DISTINCT_AFTER = 4096 updates -- not within a default run)
                                "learner_on_distinct_trajectories_at_the_end": bool(rn._fuse_now() and rn._distinct_now()),
                                "lazy_rows_visited": args.visited_rows or None, "staged_policy_rows": args.policy_rows or None,
@@ -699,7 +705,8 @@ def kernel_report(prof, A, C, args, B, T, live_slots, tree, mode_now):
     units = {rh.PROF_BUCKET_KEYS: (B, "lane"), rh.PROF_BUCKET_ROLLOUT: (slots, "slot"), rh.PROF_BUCKET_LEARN: (max(live_slots, 1), "live slot")}
     for k, p in prof.items():
         e = dict(p)
-        e["single_kernel"] = k in (rh.PROF_BUCKET_KEYS, rh.PROF_BUCKET_ROLLOUT, rh.PROF_BUCKET_LEARN, rh.PROF_OBSERVE, rh.PROF_MLP, rh.PROF_MLP_BWD)
+        e["single_kernel"] = (k in (rh.PROF_BUCKET_KEYS, rh.PROF_BUCKET_ROLLOUT, rh.PROF_BUCKET_LEARN, rh.PROF_OBSERVE, rh.PROF_MLP, rh.PROF_MLP_BWD)
+                              and not (k == rh.PROF_BUCKET_LEARN and getattr(args, "leaf_paths", False)))
         if k in model:
             bound, nbytes, how = model[k]
             sec = p["avg_launch_us"] * 1e-6
