@@ -1016,8 +1016,7 @@ class LeafPaths:
 
 
 def leaf_columns(index, chance, value, bucket_of, max_depth):
-    """The tree's terminal transitions as trajectories (pure tensor code: any device; tests/test_leaf_columns.py runs it on the CPU against
-    the oracle's rollouts).  index int64 / chance / value f32 [S, C, A, A] in the reference layout (tree.py:115-146), bucket_of int [S]
+    """The tree's terminal transitions as trajectories (pure tensor code: any device; tests/test_leaf_columns.py runs it on the CPU).  index int64 / chance / value f32 [S, C, A, A] in the reference layout (tree.py:115-146), bucket_of int [S]
     (< 0: unreachable).  One column per (state s >= 1, outcome c, row action a0, column action a1) with index == 0 and chance > 0, sorted
     by (bucket, state, code) with code = (a0 * A + a1) * C + c.  Returns n_cols, bucket [n] (the column's bucket), indices int32
     [2 * max_depth + 1, n] (the states of its env steps, 0 once the episode is over: episode.py:96-125), acts int64 [n] (3 bits per env
