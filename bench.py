@@ -363,7 +363,26 @@ def main():
                 rnad_hip.observe(handle, idx_all[t], t & 1, obs=obs[t], half=args.obs_half, mask_bits=bits[t])
         n_obs, obs_ms = rnad_hip.prof_read(rnad_hip.PROF_OBSERVE)
         rnad_hip.prof_enable(False)
-        k1 = (n_obs, obs_ms)
+        # what plain streams reach on this GPU over the same buffer (the practical ceiling K1's fraction of the 8 TB/s spec peak is to be
+        # read against): torch.fill_ (stores only) and torch.copy_ (a read and a write stream)
+        practical = {}
+        try:
+            flat = obs.view(-1)
+            half_n = flat.numel() // 2
+            for name, fn, moved in (("fill", lambda: flat.fill_(0.0), flat.numel() * flat.element_size()),
+                                    ("copy", lambda: flat[:half_n].copy_(flat[half_n: 2 * half_n]), 2 * half_n * flat.element_size())):
+                for _ in range(2):
+                    fn()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(10):
+                    fn()
+                e1.record()
+                torch.cuda.synchronize()
+                practical[name + "_TBps"] = moved / (e0.elapsed_time(e1) * 1e-3 / 10) / 1e12
+        except Exception as err:
+            practical = {"error": str(err)[:200]}
+        k1 = (n_obs, obs_ms, practical)
         del obs, bits
     if world > 1:
         t = torch.tensor([rollout_s, host_s], device=device, dtype=torch.float64)
@@ -811,7 +830,8 @@ def roofline_of(k):
 def k1_report(k1, A, args, B):
     if not k1 or not k1[0]:
         return None
-    n, ms = k1
+    n, ms = k1[0], k1[1]
+    practical = k1[2] if len(k1) > 2 else None
     us = ms * 1e3 / n
     algo = B * (4 + 8 * A * A + 2 * A * A * (2 if args.obs_half else 4) + 4 * A)
     out = {"kernel": "k_observe (K1, States.observations: the API's episode-gather kernel; not in the default step any more)",
@@ -821,6 +841,10 @@ def k1_report(k1, A, args, B):
            # 48-byte node row per lane, which comes from L2 (the tables are 3 MB), and writes the mask as one byte: by that model the launch
            # would exceed the HBM peak -- the model counts bytes that never travel, so the fraction that counts is the counters' below
            "frac_of_hbm_peak_by_survey_8d_model": algo / (us * 1e-6) / 1e9 / HBM_PEAK_GBS}
+    if practical:
+        out["plain_streams_on_this_gpu"] = dict(practical, what="torch.fill_ (stores only) and torch.copy_ (read + write) over the same buffer, TB/s: the "
+                                                "practical ceilings of a write stream and of a mixed stream -- K1 reads a state id and a node row and writes "
+                                                "the observation, i.e. it is a mixed stream")
     traffic = k1_traffic(A, args)
     if traffic:
         out.update(counter_bytes_per_launch=traffic, frac_of_hbm_peak_from_counter_bytes=traffic / (us * 1e-6) / 1e9 / HBM_PEAK_GBS,
