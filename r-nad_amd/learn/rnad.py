@@ -498,10 +498,13 @@ class RNaD:
         counted on it) instead of once per lane -- the same per-row sums bit for bit (integer sums), as two launches.  Its cost is the
         tree's, not the batch's.  Automatic when every episode has the tree's full length (so that every lane leaves the tree inside the
         window), the rank plays at least two lanes per leaf path (measured on configs[1]'s 531 441 paths, uniform policies: a tie with the
-        one-launch rollout + learner at 2^20 lanes, 250 -> 220 us per step at 2^21, 403 -> 311 at 2^22) and the trainer is young: a
-        work item of the leaf learner counts the lanes of its bucket, so a bucket that a sharpened policy fills with a third of the batch
-        makes three workgroups read a third of the batch each (a x40 policy head at 2^20 lanes: 0.241 ms per step against 0.195 per lane
-        and 0.163 on the distinct trajectories of a work item) -- from DISTINCT_AFTER updates on, distinct_trajectories takes over."""
+        one-launch rollout + learner at 2^20 lanes, 250 -> 220 us per step at 2^21, 403 -> 311 at 2^22) and no bucket is CROWDED: a
+        work item of the leaf learner counts the lanes of its bucket, so a bucket that a sharpened policy fills with a large share of the
+        batch makes its three workgroups read that share each, and count it with LDS atomics on a few addresses (a x40 policy head at 2^20
+        lanes, the largest bucket at ten times its even share: 0.241 ms per step against 0.195 per lane and 0.163 on the distinct
+        trajectories of a work item).  _leaf_watch looks at the batch's bucket sizes every LEAF_CHECK_EVERY steps and switches the leaf
+        learner off for good once a bucket holds more than LEAF_CROWDED times its even share: the per-lane learner -- from DISTINCT_AFTER
+        updates on, the distinct trajectories of a work item -- takes over (a new graph is captured)."""
         want = getattr(self, "leaf_paths", None)
         env = os.environ.get("RNAD_LEAF_PATHS")
         if env is not None:
@@ -513,9 +516,37 @@ class RNaD:
             if n is None:
                 live = (self.tree.index_tensor == 0) & (self.tree.chance_tensor > 0)
                 n = handle._n_terminal = int(live[1:].sum().item())
-            if 2 * n > local_batch or self.total_steps >= self.DISTINCT_AFTER:
+            if 2 * n > local_batch or self.__dict__.get("_leaf_crowded", False):
                 return None
         return rnad_hip.leaf_paths(handle, local_batch, self.tree.index_tensor, self.tree.chance_tensor, self.tree.value_tensor)
+
+    LEAF_CHECK_EVERY = 256  # steps between two looks at the bucket sizes (one small device -> host copy)
+    LEAF_CROWDED = 4.0      # a bucket with more than this many times its even share of the lanes ends the automatic leaf learner
+
+    def _leaf_watch(self):
+        """The automatic leaf learner's guard against crowded buckets (see _leaf_now): every LEAF_CHECK_EVERY steps the work list of
+        the last batch is read back -- lanes per bucket -- and compared with the even share.  Sticky: policies sharpen, they do not
+        flatten again."""
+        if getattr(self, "leaf_paths", None) is not None or self.__dict__.get("_leaf_crowded", False):
+            return
+        if self.total_steps % self.LEAF_CHECK_EVERY != self.LEAF_CHECK_EVERY - 1:
+            return
+        ep = self.__dict__.get("last_episodes")
+        buckets = getattr(ep, "buckets", None) if ep is not None else None
+        if buckets is None or getattr(buckets.plan, "leaf", None) is None:
+            return  # (the leaf learner is not what runs)
+        n = int(buckets.n_items.item())
+        items = buckets.items[:n]
+        per_bucket = torch.zeros((buckets.plan.n_buckets,), dtype=torch.int64, device=items.device).index_add_(0, items[:, 2].long(), items[:, 1].long())
+        share = float(per_bucket.max().item()) * max(buckets.plan.n_groups, 1) / max(ep.batch_size, 1)
+        if self._dp():  # every rank decides alike (they capture, or drop, the same graph)
+            t = torch.tensor([share], dtype=torch.float64, device=self.device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            share = float(t.item())
+        self._leaf_share = share
+        if share > self.LEAF_CROWDED:
+            logging.info("leaf-path learner off: a bucket holds %.1f times its even share of the lanes", share)
+            self._leaf_crowded = True
 
     def _learn_params(self, alpha):
         return rnad_hip.make_learn_params(
@@ -978,6 +1009,7 @@ class RNaD:
         # this trainer's own workspaces of the bucketed pipeline (sort scratch, the learner's 64-bit accumulators, staging buffers): a
         # second trainer over the same tree and batch size -- main.py:55-81 builds several -- may step on another stream meanwhile
         with rnad_hip.workspace_owner(self._workspace_token()):
+            self._leaf_watch()  # (looks at the PREVIOUS step's batch, before this step's graph key is taken)
             if self._graph_eligible(buffer, log):
                 return self._graph_step(buffer, alpha)
             return self._step_body(buffer, alpha, log)
@@ -1152,7 +1184,7 @@ class RNaD:
                 self.gamma_averaging, getattr(self, "obs_half", False), getattr(self, "store_actor_values", False), getattr(self, "fused_optimizer", True),
                 getattr(self, "compact_trajectory", True), getattr(self, "lazy_rows", None), os.environ.get("RNAD_BUCKET_ROWS"), os.environ.get("RNAD_BUCKET_CHUNK"),
                 getattr(self, "fold_legal", True), self._fuse_now(), self._fuse_now() and self._distinct_now(), getattr(self, "analytic_norm", True), os.environ.get("RNAD_FUSED_DISTINCT"), os.environ.get("RNAD_FUSED_CHUNK"),
-                getattr(self, "leaf_paths", None), os.environ.get("RNAD_LEAF_PATHS"), self.total_steps >= self.DISTINCT_AFTER)
+                getattr(self, "leaf_paths", None), os.environ.get("RNAD_LEAF_PATHS"), self.__dict__.get("_leaf_crowded", False))
 
     def _graph_step(self, buffer, alpha):
         g = getattr(self, "_graph", None)

@@ -129,8 +129,9 @@ def test_training_on_leaf_paths_is_training_per_lane(graph):
     assert on_paths._leaf_now(h, 1 << 14, 2 * h.max_depth) is not None and per_lane._leaf_now(h, 1 << 14, 2 * h.max_depth) is None
     assert auto._leaf_now(h, 1 << 14, 2 * h.max_depth) is not None, "6 561 leaf paths for 16 384 lanes (two lanes per path at least): automatic"
     assert auto._leaf_now(h, 1 << 13, 2 * h.max_depth) is None
-    auto.total_steps = auto.DISTINCT_AFTER
-    assert auto._leaf_now(h, 1 << 14, 2 * h.max_depth) is None, "an older trainer's policy may have sharpened: distinct trajectories take over"
+    assert not auto.__dict__.get("_leaf_crowded", False)
+    auto._leaf_crowded = True
+    assert auto._leaf_now(h, 1 << 14, 2 * h.max_depth) is None, "a crowded bucket ends the automatic leaf learner"
     if graph:
         assert on_paths._graph["graph"] is not None and not on_paths._graph["failed"]
     for (k, a), b, c in zip(on_paths.net.named_parameters(), per_lane.net.parameters(), auto.net.parameters()):
@@ -140,3 +141,63 @@ def test_training_on_leaf_paths_is_training_per_lane(graph):
     ragged = _native_tree(**TREES["pruned"])
     probe = _train(ragged, None, False, steps=1, B=4096)
     assert probe._leaf_now(ragged.handle(), 4096, 2 * ragged.handle().max_depth) is None
+
+
+def test_a_crowded_bucket_switches_the_leaf_learner_off(monkeypatch):
+    """The guard of the automatic mode: with a sharp actor lanes pile up in one bucket, whose lanes every leaf work item of that bucket
+    has to count -- RNaD._leaf_watch sees it in the work list and goes back to the per-lane learner (a new graph), training on unchanged."""
+    from environment.episode import Buffer
+    from learn.rnad import RNaD
+    from test_hip_bucket import TREES, _native_tree
+
+    monkeypatch.setattr(RNaD, "LEAF_CHECK_EVERY", 4)
+    tree = _native_tree(**TREES["ternary4"])
+    h = tree.handle()
+    B = 1 << 14
+
+    def run(sharp):
+        os.environ["RNAD_SAVE_DIR"] = tempfile.mkdtemp(prefix="rnad_leafwatch_")
+        torch.manual_seed(3)
+        rn = RNaD(tree=tree, device=DEV, directory_name="w", batch_size=B, eta=0.2, b1_adam=0.0, lr=1e-3,
+                  net_params={"type": "MLP", "max_actions": tree.max_actions, "width": 64})
+        rn.initialize()
+        rn.tabular_gate = 0
+        rn._seed_base, rn._seed_count = 5, 0
+        if sharp:
+            with torch.no_grad():
+                for name, p in rn.net.named_parameters():
+                    if name.startswith("policy_fc1"):
+                        p.mul_(60.0)
+        buf = Buffer(1)
+        used = []
+        for _ in range(12):
+            rn.train_step(buf, alpha=0.3)
+            used.append(getattr(rn.last_episodes.buckets.plan, "leaf", None) is not None and rn._leaf_now(h, B, 2 * h.max_depth) is not None)
+            rn.total_steps += 1
+        torch.cuda.synchronize()
+        return rn, used
+
+    flat, used_flat = run(False)
+    assert all(used_flat) and not flat.__dict__.get("_leaf_crowded", False) and flat._leaf_share < RNaD.LEAF_CROWDED
+    sharp, used = run(True)
+    assert used[0] and not used[-1] and sharp._leaf_crowded and sharp._leaf_share > RNaD.LEAF_CROWDED, (used, sharp._leaf_share)
+    assert all(torch.isfinite(p).all() for p in sharp.net.parameters())
+    # the same run with the leaf learner forced off from the start: the same parameters bit for bit (both learners add up the same sums)
+    os.environ["RNAD_SAVE_DIR"] = tempfile.mkdtemp(prefix="rnad_leafwatch_")
+    torch.manual_seed(3)
+    ref = RNaD(tree=tree, device=DEV, directory_name="w", batch_size=B, eta=0.2, b1_adam=0.0, lr=1e-3,
+               net_params={"type": "MLP", "max_actions": tree.max_actions, "width": 64})
+    ref.initialize()
+    ref.tabular_gate, ref.leaf_paths = 0, False
+    ref._seed_base, ref._seed_count = 5, 0
+    with torch.no_grad():
+        for name, p in ref.net.named_parameters():
+            if name.startswith("policy_fc1"):
+                p.mul_(60.0)
+    buf = Buffer(1)
+    for _ in range(12):
+        ref.train_step(buf, alpha=0.3)
+        ref.total_steps += 1
+    torch.cuda.synchronize()
+    for (k, a), b in zip(sharp.net.named_parameters(), ref.net.parameters()):
+        assert torch.equal(a, b), k
