@@ -82,6 +82,14 @@ def main():
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     # host-only enqueue cost: the same steps with the GPU kept idle-waiting is not possible; report both numbers
+    share = None
+    bk = getattr(rn.last_episodes, "buckets", None)
+    if bk is not None:
+        n = int(bk.n_items.item())
+        it = bk.items[:n]
+        per = torch.zeros((bk.plan.n_buckets,), dtype=torch.int64, device=it.device).index_add_(0, it[:, 2].long(), it[:, 1].long())
+        share = float(per.max().item()) * max(bk.plan.n_groups, 1) / rn.batch_size
+    print(f"largest_bucket_share={share}")
     print(f"mode={args.mode} S={tree.handle().S} B=2^{args.batch_log2} ms_per_step={dt / args.steps * 1e3:.4f} "
           f"host_enqueue_ms_per_step={host / args.steps * 1e3:.4f}")
 
