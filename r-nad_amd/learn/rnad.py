@@ -490,7 +490,10 @@ class RNaD:
         trajectories -- a trained policy -- and costs ~4 % under the near-uniform policies of fresh nets: None
         (default) turns it on after DISTINCT_AFTER updates of this trainer; True / False force it."""
         want = getattr(self, "distinct_trajectories", None)
-        return bool(want) if want is not None else self.total_steps >= self.DISTINCT_AFTER
+        if want is not None:
+            return bool(want)
+        # (r05: or earlier, once the watch over the bucket sizes has seen the lanes pile up -- sticky, like its other verdict)
+        return self.total_steps >= self.DISTINCT_AFTER or self.__dict__.get("_distinct_crowded", False)
 
     def _leaf_now(self, handle, local_batch, T_cap):
         """RNaD.leaf_paths (None: automatic; True / False force it; RNAD_LEAF_PATHS=0 / 1 overrides): the learner of the one-call rollout +
@@ -520,33 +523,47 @@ class RNaD:
                 return None
         return rnad_hip.leaf_paths(handle, local_batch, self.tree.index_tensor, self.tree.chance_tensor, self.tree.value_tensor)
 
-    LEAF_CHECK_EVERY = 256  # steps between two looks at the bucket sizes (one small device -> host copy)
-    LEAF_CROWDED = 4.0      # a bucket with more than this many times its even share of the lanes ends the automatic leaf learner
+    LEAF_CHECK_EVERY = 1024  # steps between two looks at the bucket sizes (a sync and a small device -> host copy: ~0.3 ms)
+    LEAF_CROWDED = 4.0       # a bucket with more than this many times its even share of the lanes ends the automatic leaf learner
+    DISTINCT_CROWDED = 4.0   # ... and turns the automatic learner on distinct trajectories on before DISTINCT_AFTER
+    # (profiles/r05_leaf.md, 2^21 lanes: at a share of 3.4 the leaf learner is still ahead of the per-lane one, 0.233 against 0.262 ms per
+    # step, at 6.1 behind it, 0.275 against 0.266; the distinct trajectories of a work item take 0.259 / 0.239 / 0.223 / 0.214 at shares
+    # of 2.06 (fresh nets) / 3.1 / 3.4 / 6.1.  With the reference's lr = 5e-5 the share drifts between 2 and 3.5 over the first 6 000
+    # updates -- tools/micro/share_probe.py --, so neither switch falls into a benchmark of fresh nets)
 
     def _leaf_watch(self):
-        """The automatic leaf learner's guard against crowded buckets (see _leaf_now): every LEAF_CHECK_EVERY steps the work list of
-        the last batch is read back -- lanes per bucket -- and compared with the even share.  Sticky: policies sharpen, they do not
-        flatten again."""
-        if getattr(self, "leaf_paths", None) is not None or self.__dict__.get("_leaf_crowded", False):
+        """The automatic learners' look at the batch (see _leaf_now, _distinct_now): every LEAF_CHECK_EVERY steps the work list of the last
+        batch is read back -- lanes per bucket -- and compared with the even share: above LEAF_CROWDED the leaf-path learner goes, above
+        DISTINCT_CROWDED the learner on the distinct trajectories of a work item comes (before DISTINCT_AFTER).  Sticky: policies sharpen,
+        they do not flatten again."""
+        leaf_settled = getattr(self, "leaf_paths", None) is not None or self.__dict__.get("_leaf_crowded", False)
+        distinct_settled = (getattr(self, "distinct_trajectories", None) is not None or self.__dict__.get("_distinct_crowded", False)
+                            or self.total_steps >= self.DISTINCT_AFTER)
+        if leaf_settled and distinct_settled:
             return
         if self.total_steps % self.LEAF_CHECK_EVERY != self.LEAF_CHECK_EVERY - 1:
             return
         ep = self.__dict__.get("last_episodes")
         buckets = getattr(ep, "buckets", None) if ep is not None else None
-        if buckets is None or getattr(buckets.plan, "leaf", None) is None:
-            return  # (the leaf learner is not what runs)
+        if buckets is None or getattr(ep, "_compact", None) is None or not self.tree.handle().uniform_length:
+            # (not the compact bucketed step: neither learner is what runs; or a ragged tree, whose buckets differ in size by construction:
+            # "times the even share" says nothing there -- the leaf learner never runs on it and the distinct one keeps its DISTINCT_AFTER)
+            return
         n = int(buckets.n_items.item())
-        items = buckets.items[:n]
-        per_bucket = torch.zeros((buckets.plan.n_buckets,), dtype=torch.int64, device=items.device).index_add_(0, items[:, 2].long(), items[:, 1].long())
+        items = buckets.items[:n].cpu()  # (a few thousand work items: counted on the host -- no kernel of torch's that the step has not loaded yet)
+        per_bucket = torch.bincount(items[:, 2].long(), weights=items[:, 1].double(), minlength=buckets.plan.n_buckets)
         share = float(per_bucket.max().item()) * max(buckets.plan.n_groups, 1) / max(ep.batch_size, 1)
         if self._dp():  # every rank decides alike (they capture, or drop, the same graph)
             t = torch.tensor([share], dtype=torch.float64, device=self.device)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             share = float(t.item())
         self._leaf_share = share
-        if share > self.LEAF_CROWDED:
+        if share > self.LEAF_CROWDED and not self.__dict__.get("_leaf_crowded", False):
             logging.info("leaf-path learner off: a bucket holds %.1f times its even share of the lanes", share)
             self._leaf_crowded = True
+        if share > self.DISTINCT_CROWDED and not self.__dict__.get("_distinct_crowded", False):
+            logging.info("learner on distinct trajectories on: a bucket holds %.1f times its even share of the lanes", share)
+            self._distinct_crowded = True
 
     def _learn_params(self, alpha):
         return rnad_hip.make_learn_params(

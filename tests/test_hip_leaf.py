@@ -181,6 +181,9 @@ def test_a_crowded_bucket_switches_the_leaf_learner_off(monkeypatch):
     assert all(used_flat) and not flat.__dict__.get("_leaf_crowded", False) and flat._leaf_share < RNaD.LEAF_CROWDED
     sharp, used = run(True)
     assert used[0] and not used[-1] and sharp._leaf_crowded and sharp._leaf_share > RNaD.LEAF_CROWDED, (used, sharp._leaf_share)
+    # ... and the learner on the distinct trajectories of a work item comes on long before DISTINCT_AFTER updates
+    assert sharp._distinct_crowded and sharp._distinct_now() and sharp.total_steps < RNaD.DISTINCT_AFTER
+    assert not flat.__dict__.get("_distinct_crowded", False) and not flat._distinct_now()
     assert all(torch.isfinite(p).all() for p in sharp.net.parameters())
     # the same run with the leaf learner forced off from the start: the same parameters bit for bit (both learners add up the same sums)
     os.environ["RNAD_SAVE_DIR"] = tempfile.mkdtemp(prefix="rnad_leafwatch_")
