@@ -471,8 +471,10 @@ int rnad_rollout_bucketed_compact(const rnad_tree_t *tree, int T_cap, int64_t B,
                                   int table_is_policy, uint64_t seed, int64_t lane0, const rnad_step_params_t *device_params,
                                   void *scratch, int32_t *lane_ids, int32_t *items, int32_t *n_items, double *norm, void *states,
                                   int32_t *alive, uint64_t *acts, float *final_reward, int32_t *visited, void *stream);
-/* rnad_rollout_bucketed_compact + rnad_rows_expand in its keys pass (distinct observations, csrc/rows_dedup.hip: `tables` were evaluated
- * on one representative row per observation; rep_of: int32 [2S]).  The copies ride in the launch that walks the upper states; walks that
+/* rnad_rollout_bucketed_compact + rnad_rows_expand inside its own launches (distinct observations, csrc/rows_dedup.hip: `tables` were
+ * evaluated on one representative row per observation; rep_of: int32 [2S]).  The keys pass reads the upper states' policy rows through
+ * rep_of and the copies are made by extra workgroups of the sort's scan launch (r05; r04: by the keys pass itself), i.e. they are
+ * complete before the rollout launch, which is the first to read the other rows; walks that
  * cannot carry them (global / hybrid tables) get a launch of rnad_rows_expand in front. */
 int rnad_rollout_bucketed_compact_expand(const rnad_tree_t *tree, int T_cap, int64_t B, const float *table, int64_t table_stride,
                                          int table_is_policy, uint64_t seed, int64_t lane0, const rnad_step_params_t *device_params,
