@@ -362,7 +362,9 @@ int rnad_learn_fused_gather(const rnad_tree_t *tree, int T, int64_t B, const int
  * [2] = number of upper states, [3] = number of groups, [4] = capacity of the work-item list (items: int32 [out[4]][4] = first lane,
  * lanes, bucket, 1 if the bucket's only item), [5] = bytes of `scratch` for rnad_rollout_bucketed, [6] = bytes of `accumulators` for
  * rnad_learn_bucketed (zero them once; every update leaves them zero), [7] = LDS bytes of a learner workgroup, [8] = bytes of a relative
- * state of the compact trajectory (1 or 2; out must hold 9 values).  Non-zero return: this
+ * state of the compact trajectory (1 or 2), [9] = lanes per workgroup of the sort passes, [10] = lanes per work item (out must hold 11
+ * values).  The last two follow the tuning knobs RNAD_SORT_TILE / RNAD_BUCKET_CHUNK, which size out[5] / out[4]: the entry points that
+ * write `scratch` fail (status 1) when the knobs differ from every combination rnad_bucket_plan was asked the sizes of.  Non-zero return: this
  * tree / batch cannot be bucketed (use the entry points above).  rnad_bucket_map: the bucket of every state (host int32 [S]; < *n_groups:
  * a group, else n_groups + upper slot; -1: state 0 / unreachable) -- what tests and tools need to reproduce the lane order.
  *
@@ -440,6 +442,9 @@ typedef struct rnad_row_groups {
     int32_t n_groups;
     const int32_t *start;   /* device int32 [n_groups + 1] */
     const int32_t *order;   /* device int32 [start[n_groups]] */
+    const int32_t *first;   /* optional (NULL: not given), device int32 [n_groups][4][64]: the group's first 256 rows once more, padded --
+                             * first[g][k][l] = order[start[g] + 64 k + l] while that is a row of group g, else -1 -- so that k_bucket_finish
+                             * requests a group's accumulators without walking start -> order first (r06) */
 } rnad_row_groups_t;
 
 /* *device_params = {seed, alpha, one_minus_alpha}, enqueued on `stream` (the values travel as kernel arguments: safe to call again

@@ -36,7 +36,7 @@ class CpuTrainer:
     port in lock step with the GPU trainer.  keep=True: the last step's rollout and gradients stay in self.last."""
 
     def __init__(self, tree_arrays, width=256, lr=5e-5, eta=0.2, gamma_averaging=0.001, seed=0, state_dicts=None, n_discrete=32,
-                 epsilon_threshold=0.03, neurd_clip=1e3, logit_clip=2.0, grad_clip=1e3, betas=(0.0, 0.999), eps=1e-8, keep=False):
+                 epsilon_threshold=0.03, neurd_clip=1e3, logit_clip=2.0, grad_clip=1e3, betas=(0.0, 0.999), eps=1e-8, keep=False, chunk_rows=None):
         torch.manual_seed(seed)
         self.tree = tree_arrays
         self.A = tree_arrays["index"].shape[-1]
@@ -53,6 +53,9 @@ class CpuTrainer:
         self.neurd_clip, self.logit_clip, self.grad_clip = float(neurd_clip), float(logit_clip), float(grad_clip)
         self.T_cap = 2 * int(tree_arrays["depth_bound"])
         self.keep, self.last = bool(keep), None
+        # chunk_rows: evaluate / differentiate the MLPs on this many (t, b) rows at a time (a 2^20-lane batch is 12.6 M rows: 13 GB per
+        # hidden activation otherwise).  Same per-row outputs; the weight gradient is accumulated chunk by chunk (another fp32 order).
+        self.chunk_rows = chunk_rows
 
     def step(self, B, seed, alpha=0.5, lane0=0):
         """One iteration; returns (T, rollout seconds, update seconds)."""
@@ -62,11 +65,25 @@ class CpuTrainer:
         t1 = time.perf_counter()
         T = ro["T"]
         obs = torch.from_numpy(ro["observations"].reshape(T * B, 2 * A * A))
-        logit, v = self.net.logits(obs)  # rnad.py:373
-        with torch.no_grad():
-            _, v_t = self.net_target.logits(obs)
-            lr, _ = self.net_reg.logits(obs)
-            lr_, _ = self.net_reg_.logits(obs)
+        chunks = None
+        if self.chunk_rows and T * B > self.chunk_rows:
+            chunks = [(i, min(i + self.chunk_rows, T * B)) for i in range(0, T * B, self.chunk_rows)]
+
+            def whole(net):
+                with torch.no_grad():
+                    parts = [net.logits(obs[i:j]) for i, j in chunks]
+                return torch.cat([p[0] for p in parts]), torch.cat([p[1] for p in parts])
+
+            logit, v = whole(self.net)  # rnad.py:373 (values now; the graph for the backward is rebuilt per chunk below)
+            _, v_t = whole(self.net_target)
+            lr, _ = whole(self.net_reg)
+            lr_, _ = whole(self.net_reg_)
+        else:
+            logit, v = self.net.logits(obs)  # rnad.py:373
+            with torch.no_grad():
+                _, v_t = self.net_target.logits(obs)
+                lr, _ = self.net_reg.logits(obs)
+                lr_, _ = self.net_reg_.logits(obs)
         masks = ro["masks"].reshape(T * B, A)
         pi, log_pi = oracle.policy_head(logit.detach().numpy(), masks)
         _, log_r = oracle.policy_head(lr.numpy(), masks)
@@ -84,7 +101,13 @@ class CpuTrainer:
             vts.append(vt); hps.append(hp); qs.append(q)  # noqa: E702
         _, dv = oracle.loss_v(v.detach().numpy(), vts[0], vts[1], hps[0], hps[1])  # rnad.py:407
         _, dl = oracle.loss_nerd(logit.detach().numpy(), pip, qs[0], qs[1], valid, turns, masks, self.neurd_clip, self.logit_clip)  # :412-422
-        torch.autograd.backward([logit, v], [torch.from_numpy(dl).view_as(logit), torch.from_numpy(dv).view_as(v)])  # :425
+        if chunks is not None:
+            dl_t, dv_t = torch.from_numpy(dl).view_as(logit), torch.from_numpy(dv).view_as(v)
+            for i, j in chunks:  # :425, chunk by chunk (parameter .grad accumulates)
+                lg_c, v_c = self.net.logits(obs[i:j])
+                torch.autograd.backward([lg_c, v_c], [dl_t[i:j], dv_t[i:j]])
+        else:
+            torch.autograd.backward([logit, v], [torch.from_numpy(dl).view_as(logit), torch.from_numpy(dv).view_as(v)])  # :425
         torch.nn.utils.clip_grad_norm_(self.net.parameters(), self.grad_clip)  # :456
         if self.keep:
             self.last = dict(rollout=ro, grads={k: p.grad.detach().clone() for k, p in self.net.named_parameters()})

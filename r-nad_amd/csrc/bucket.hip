@@ -88,6 +88,7 @@ struct Plan {
     int lds = 0, path_words = 0, sort_blocks = 0, chunk = kChunkDefault;
     int tile = kSortLanes;  // lanes per workgroup of the sort passes (keys walk, histogram, scatter): kSortLanes, or a fraction of it on small batches
     int rel_bytes = 1;  // width of a relative state of the compact trajectory: states of a group are bucket_lo + (0 .. rows - 1)
+    int forced = 0;     // RNAD_BUCKET_ROWS at the time of the call (0: the planner's choice)
     int64_t max_items = 0;
 };
 
@@ -372,8 +373,21 @@ bool make_plan(const rnad_tree_t *tree, int64_t B, Plan &p) {
     p.sort_blocks = (int)((B + p.tile - 1) / p.tile);
     if (const char *c = getenv("RNAD_BUCKET_CHUNK")) p.chunk = std::max(64, atoi(c));  // tuning knob
     p.max_items = (int64_t)chosen->n_buckets + B / p.chunk + 1 + 7;  // (+ 7: the XCD-aware item mapping needs 8 * ceil(n / 8) workgroups)
+    p.forced = forced;
     return true;
 }
+
+// The sort tile and the chunk are read from the environment on every call (tuning knobs), and the caller's scratch buffer was sized by
+// rnad_bucket_plan as hist[sort_blocks][n_buckets] + items: a knob that changed in between would make carve_scratch lay out more than was
+// allocated (r05 advisor: a silent out-of-bounds write).  rnad_bucket_plan notes every (tile, chunk) it handed sizes out for; the entry
+// points that write the scratch refuse a combination nobody asked the sizes of.
+void note_sized(const rnad_tree_t *tree, int64_t B, const Plan &p) { tree->plan_sized.insert(std::make_tuple(B, p.forced, p.tile, p.chunk)); }
+bool sized_for(const rnad_tree_t *tree, int64_t B, const Plan &p) {
+    return tree->plan_sized.count(std::make_tuple(B, p.forced, p.tile, p.chunk)) != 0;
+}
+#define RNAD_REQUIRE_SIZED(tree_, B_, p_)                                                                                                  \
+    RNAD_REQUIRE(sized_for(tree_, B_, p_), "RNAD_SORT_TILE / RNAD_BUCKET_CHUNK / RNAD_BUCKET_ROWS differ from what rnad_bucket_plan sized " \
+                                            "this batch's scratch buffers for (tile %d, chunk %d): call rnad_bucket_plan again and reallocate", (p_).tile, (p_).chunk)
 
 // Sum over the 64 lanes of a wave in integer arithmetic on the VALU's data-parallel primitives (no LDS traffic): an inclusive
 // scan within each row of 16 lanes (row_shr 1, 2, 4, 8), then row 15 -> next row (row_bcast15) and lane 31 -> rows 2, 3
@@ -1722,9 +1736,10 @@ __global__ __launch_bounds__(kThreads) void k_bucket_pack(int T1, int64_t B, int
                                                           const int32_t *__restrict__ bucket_path, const int32_t *__restrict__ bucket_lo,
                                                           const int32_t *__restrict__ path_states, int path_stride, int n_groups,
                                                           const int32_t *__restrict__ indices, REL *__restrict__ states,
-                                                          int32_t *__restrict__ bad) {
+                                                          int32_t *__restrict__ bad, int max_count) {
     if ((int)blockIdx.x >= *n_items) return;
     const Item item = items[blockIdx.x];
+    if (item.count > max_count && threadIdx.x == 0) *bad = 1;  // (leaf paths: the weighted learner counts an item's columns in ONE pass of kThreads)
     const int path_word = bucket_path[item.bucket];
     const int n_shared = (path_word & (kSharedRoot - 1)) + ((item.bucket < n_groups && (path_word & kSharedRoot)) ? 2 : 0);
     const int lo = bucket_lo[item.bucket];
@@ -2442,7 +2457,8 @@ __global__ __launch_bounds__(kThreads) void k_bucket_finish(int64_t S, int row_b
                                                             double *__restrict__ losses, float *__restrict__ dlogit_tab,
                                                             float *__restrict__ dv_tab, int upper_blocks, int n_multi,
                                                             const int32_t *__restrict__ multi_start,
-                                                            const int32_t *__restrict__ multi_order, int32_t *__restrict__ alive_rep,
+                                                            const int32_t *__restrict__ multi_order,
+                                                            const int32_t *__restrict__ multi_first, int32_t *__restrict__ alive_rep,
                                                             double *__restrict__ norm_rep, int T1, int32_t *__restrict__ alive_out,
                                                             double *__restrict__ norm_out) {
     static_assert(kReplicas == 64, "one replica per lane");
@@ -2517,15 +2533,12 @@ __global__ __launch_bounds__(kThreads) void k_bucket_finish(int64_t S, int row_b
         const int g = ((int)blockIdx.x - row_blocks - upper_blocks) * (kThreads / 64) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
         if (RNAD_FINISH_ABLATE & 2) return;
         if (g < n_multi) {
-            const int lo = multi_start[g], hi = multi_start[g + 1];
             float sum[A + 1];
 #pragma unroll
             for (int a = 0; a <= A; ++a) sum[a] = 0.0f;
-            for (int i0 = lo + lane; i0 < hi; i0 += 64 * kFinishRows) {  // kFinishRows rows per lane in flight, added in ascending order
-                int64_t r[kFinishRows];
+            // kFinishRows rows per lane in flight, added in ascending order
+            auto add_rows = [&](const int64_t (&r)[kFinishRows]) {
                 long long x[kFinishRows][A + 1];
-#pragma unroll
-                for (int k = 0; k < kFinishRows; ++k) r[k] = i0 + 64 * k < hi ? (int64_t)multi_order[i0 + 64 * k] : -1;
 #pragma unroll
                 for (int k = 0; k < kFinishRows; ++k)
 #pragma unroll
@@ -2541,6 +2554,32 @@ __global__ __launch_bounds__(kThreads) void k_bucket_finish(int64_t S, int row_b
                     for (int a = 0; a < A; ++a) sum[a] += bad ? nan : w_n * ((float)((double)x[k][a] / fx.scale_l) / nf);
                     sum[A] += bad ? nan : w_v * ((float)((double)x[k][A] / fx.scale_v) / nf);
                 }
+            };
+            int64_t rep_row;
+            if (multi_first) {
+                // r06: the group's first 64 * kFinishRows rows from a table padded per group (lane-major as the loop below takes them, -1
+                // beyond the group): their accumulators are requested one round trip after the launch starts instead of two (group ->
+                // multi_start -> multi_order -> acc was 10 of this kernel's 16 us on configs[1]'s 1 682 groups)
+                int64_t r[kFinishRows];
+#pragma unroll
+                for (int k = 0; k < kFinishRows; ++k) r[k] = (int64_t)multi_first[((int64_t)g * kFinishRows + k) * 64 + lane];
+                const int lo = multi_start[g], hi = multi_start[g + 1];  // (in flight beside them: only groups beyond the table need them)
+                rep_row = __shfl(r[0], 0, 64);
+                add_rows(r);
+                for (int i0 = lo + 64 * kFinishRows + lane; i0 < hi; i0 += 64 * kFinishRows) {
+#pragma unroll
+                    for (int k = 0; k < kFinishRows; ++k) r[k] = i0 + 64 * k < hi ? (int64_t)multi_order[i0 + 64 * k] : -1;
+                    add_rows(r);
+                }
+            } else {
+                const int lo = multi_start[g], hi = multi_start[g + 1];
+                for (int i0 = lo + lane; i0 < hi; i0 += 64 * kFinishRows) {
+                    int64_t r[kFinishRows];
+#pragma unroll
+                    for (int k = 0; k < kFinishRows; ++k) r[k] = i0 + 64 * k < hi ? (int64_t)multi_order[i0 + 64 * k] : -1;
+                    add_rows(r);
+                }
+                rep_row = multi_order[lo];
             }
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1) {
@@ -2548,7 +2587,7 @@ __global__ __launch_bounds__(kThreads) void k_bucket_finish(int64_t S, int row_b
                 for (int a = 0; a <= A; ++a) sum[a] += __shfl_xor(sum[a], off, 64);
             }
             if (lane == 0) {
-                const int64_t r = multi_order[lo];
+                const int64_t r = rep_row;
 #pragma unroll
                 for (int a = 0; a < A; ++a) dlogit_tab[r * A + a] = sum[a];
                 dv_tab[r] = sum[A];
@@ -2656,6 +2695,9 @@ extern "C" int rnad_bucket_plan(const rnad_tree_t *tree, int64_t B, int64_t *out
              8 * 2 * kReplicas + 4 * kReplicas * (kCompactSteps + 1);
     out[7] = p.lds;
     out[8] = p.rel_bytes;
+    out[9] = p.tile;
+    out[10] = p.chunk;
+    note_sized(tree, B, p);
     return 0;
 }
 
@@ -2863,6 +2905,7 @@ int rollout_bucketed_impl(const rnad_tree_t *tree, const RolloutBuffers &tr, boo
                           const KeysExpand *expand = nullptr, const FusedLearn *fused = nullptr) {
     Plan p;
     RNAD_REQUIRE(make_plan(tree, tr.B, p), "rnad_rollout_bucketed: this tree / batch cannot be bucketed (see rnad_bucket_plan)");
+    RNAD_REQUIRE_SIZED(tree, tr.B, p);
     const int64_t B = tr.B, S = tree->S;
     const Scratch s = carve_scratch(scratch, B, p);
     const StageOut stage = carve_stage(stage_buf, B, S);
@@ -3095,6 +3138,7 @@ extern "C" int rnad_bucket_stage_rows(const rnad_tree_t *tree, int64_t B, int le
     RNAD_REQUIRE(tree && stage && rows && (level == 0 || level == 1), "rnad_bucket_stage_rows: null argument / level must be 0 or 1");
     Plan p;
     RNAD_REQUIRE(make_plan(tree, B, p), "rnad_bucket_stage_rows: this tree / batch cannot be bucketed (see rnad_bucket_plan)");
+    RNAD_REQUIRE_SIZED(tree, B, p);
     const StageOut st = carve_stage(stage, B, tree->S);
     if (level == 0)
         hipLaunchKernelGGL(k_stage_rows<0>, dim3(blocks_for(tree->S, kSortThreads * kStagePer)), dim3(kSortThreads), 0, (hipStream_t)stream, tree->S, (const uint32_t *)st.mark0,
@@ -3113,6 +3157,7 @@ extern "C" int rnad_bucket_stage_walk(const rnad_tree_t *tree, int T_cap, int64_
     RNAD_REQUIRE(stride >= tree->A && T_cap >= 1, "rnad_bucket_stage_walk: bad table stride / T_cap");
     Plan p;
     RNAD_REQUIRE(make_plan(tree, B, p), "rnad_bucket_stage_walk: this tree / batch cannot be bucketed (see rnad_bucket_plan)");
+    RNAD_REQUIRE_SIZED(tree, B, p);
     const StageOut st = carve_stage(stage, B, tree->S);
     const int vec4 = (stride % 4 == 0 && ((uintptr_t)policy_rows & 15) == 0) ? 1 : 0;
     RNAD_DISPATCH_A(tree->A, hipLaunchKernelGGL((k_stage_walk<kA>), dim3(blocks_for(B)), dim3(kThreads), 0, (hipStream_t)stream, tree->trans, tree->C,
@@ -3143,6 +3188,7 @@ extern "C" int rnad_bucket_alive(const rnad_tree_t *tree, int T_cap, int64_t B, 
     RNAD_REQUIRE(T_cap >= 1 && T_cap <= kMaxSteps && B >= 1, "rnad_bucket_alive: bad shape");
     Plan p;
     RNAD_REQUIRE(make_plan(tree, B, p), "rnad_bucket_alive: this tree / batch cannot be bucketed (see rnad_bucket_plan)");
+    RNAD_REQUIRE_SIZED(tree, B, p);
     const Scratch s = carve_scratch(const_cast<void *>(scratch), B, p);
     hipLaunchKernelGGL(k_bucket_alive, dim3(T_cap + 1), dim3(kThreads), 0, (hipStream_t)stream, (int)alive_rows(tree, B, p, true), T_cap + 1,
                        (const int32_t *)s.alive_part, alive, norm);
@@ -3356,7 +3402,8 @@ int finish_impl(const rnad_tree_t *tree, const Plan &p, const double *norm, cons
                                                 (const int32_t *)p.cut->bucket_of, acc, rep, norm, hp->w_v, hp->w_n, fx, overflow,
                                                 losses_raw, losses, dlogit_tab, dv_tab, (int)upper_blocks, n_multi,
                                                 n_multi ? groups->start : (const int32_t *)nullptr,
-                                                n_multi ? groups->order : (const int32_t *)nullptr, counts ? counts->alive_rep : (int32_t *)nullptr,
+                                                n_multi ? groups->order : (const int32_t *)nullptr,
+                                                n_multi ? groups->first : (const int32_t *)nullptr, counts ? counts->alive_rep : (int32_t *)nullptr,
                                                 counts ? counts->norm_rep : (double *)nullptr, counts ? counts->T1 : 0,
                                                 counts ? counts->alive_out : (int32_t *)nullptr, counts ? counts->norm_out : (double *)nullptr));
     RNAD_HIP_OK(hipGetLastError());
@@ -3445,7 +3492,7 @@ extern "C" int rnad_bucket_pack_states(const rnad_tree_t *tree, int T1, int64_t 
     RNAD_DISPATCH_REL(p, hipLaunchKernelGGL((k_bucket_pack<REL>), dim3((unsigned)p.max_items), dim3(kThreads), 0, (hipStream_t)stream, T1, B, p.cut->rows,
                                             (const Item *)items, n_items, (const int32_t *)p.cut->bucket_path, (const int32_t *)p.cut->bucket_lo,
                                             (const int32_t *)p.cut->path_states, std::max(p.cut->max_path, 1), p.cut->n_groups, indices,
-                                            (REL *)states, mismatch));
+                                            (REL *)states, mismatch, INT32_MAX));
     RNAD_HIP_OK(hipGetLastError());
     return 0;
 }
@@ -3457,12 +3504,15 @@ extern "C" int rnad_leaf_paths_pack(const rnad_tree_t *tree, int64_t plan_B, int
     RNAD_REQUIRE(T1 >= 1 && T1 <= kCompactSteps + 1 && n_cols >= 1 && max_items >= 1, "rnad_leaf_paths_pack: bad shape");
     Plan p;
     RNAD_REQUIRE(make_plan(tree, plan_B, p), "rnad_leaf_paths_pack: this tree / batch cannot be bucketed (see rnad_bucket_plan)");
+    // a lane's bucket and its leaf column's bucket only pair up when every episode leaves the tree inside the window (learn/rnad.py guards
+    // the same; a C caller gets the check here)
+    RNAD_REQUIRE(tree->uniform_length && T1 - 1 == 2 * tree->max_depth, "rnad_leaf_paths_pack: leaf paths need a tree whose episodes all have full length, T1 = 2 * depth + 1");
     *rows_out = p.cut->rows;
     *rel_bytes_out = p.rel_bytes;
     RNAD_DISPATCH_REL(p, hipLaunchKernelGGL((k_bucket_pack<REL>), dim3((unsigned)max_items), dim3(kThreads), 0, (hipStream_t)stream, T1, n_cols, p.cut->rows,
                                             (const Item *)items, n_items, (const int32_t *)p.cut->bucket_path, (const int32_t *)p.cut->bucket_lo,
                                             (const int32_t *)p.cut->path_states, std::max(p.cut->max_path, 1), p.cut->n_groups, indices,
-                                            (REL *)states, mismatch));
+                                            (REL *)states, mismatch, kThreads));
     RNAD_HIP_OK(hipGetLastError());
     return 0;
 }

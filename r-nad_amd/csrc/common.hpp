@@ -8,7 +8,9 @@
 #include <cstdint>
 #include <cstdio>
 #include <map>
+#include <set>
 #include <string>
+#include <tuple>
 #include <vector>
 
 #include "rnad_hip.h"
@@ -130,6 +132,7 @@ struct rnad_tree {
     std::vector<int32_t> children;
     mutable std::map<int, BucketCut> cuts;  // by rows; handles are used from one host thread (include/rnad_hip.h)
     mutable std::map<std::pair<int64_t, int>, int> plan_rows;  // (lanes, forced rows or 0) -> rows of the cut the planner chose (0: none fits)
+    mutable std::set<std::tuple<int64_t, int, int, int>> plan_sized;  // (lanes, forced rows, sort tile, chunk) rnad_bucket_plan handed buffer sizes out for
     size_t bytes = 0;
 };
 

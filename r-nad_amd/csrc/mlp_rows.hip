@@ -71,6 +71,69 @@ __device__ __forceinline__ void chain_reg(const float (&a)[KS], const float *__r
     }
 }
 
+// ---------------------------------------------------------------------------------------------- r06: split-precision first layer
+// fp32 MFMA runs at 1/16 of the bf16 rate on gfx950 (64 against 1024 FLOP per clock and SIMD) and shares the ALUs with the VALU work of
+// the epilogues.  SPLIT: every fp32 operand as the exact sum of three bf16 numbers, x = x_h + x_m + x_l (round to nearest each time:
+// x_h = bf16(x), x_m = bf16(x - x_h), x_l = bf16(x - x_h - x_m); the differences are exact, 3 x 9 significant bits cover the 24 of a
+// float), and W x as SIX v_mfma_f32_32x32x16_bf16 products per 16 input features -- W_l x_h, W_h x_l, W_m x_m, W_m x_h, W_h x_m, W_h x_h,
+// small terms first -- accumulated in fp32 by the matrix core.  Every bf16 x bf16 product is exact in fp32; what is dropped (W_m x_l,
+// W_l x_m, W_l x_l) is below 2^-24 |W| |x| in total, i.e. below the rounding of the fp32 chain it replaces: the same function to fp32
+// accuracy in another summation order (tests/test_hip_rows.py: 1e-5 / 3e-6 against k_mlp_forward as before).  6 x 32 cycles per 16
+// features against 8 x 64 (A = 3 with the fold: 5 x 64), and the bf16 matrix pipe leaves the VALU free for the epilogues.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+struct Split8 {
+    bf16x8 h, m, l;
+};
+__device__ __forceinline__ Split8 split8(const float (&v)[8]) {
+    Split8 o;
+#pragma unroll
+    for (int i = 0; i < 8; i += 2) {
+        const bf16x2 h = __builtin_convertvector(f32x2{v[i], v[i + 1]}, bf16x2);
+        const float r0 = v[i] - (float)h[0], r1 = v[i + 1] - (float)h[1];  // exact
+        const bf16x2 m = __builtin_convertvector(f32x2{r0, r1}, bf16x2);
+        const float q0 = r0 - (float)m[0], q1 = r1 - (float)m[1];  // exact
+        const bf16x2 l = __builtin_convertvector(f32x2{q0, q1}, bf16x2);
+        o.h[i] = h[0]; o.h[i + 1] = h[1];
+        o.m[i] = m[0]; o.m[i + 1] = m[1];
+        o.l[i] = l[0]; o.l[i + 1] = l[1];
+    }
+    return o;
+}
+
+// chain_reg on split operands: KB blocks of 16 input features
+template <int KB, bool TWO>
+__device__ __forceinline__ void chain_split(const Split8 (&a)[KB], const float *__restrict__ brow, const Split8 (&x0)[KB], const Split8 (&x1)[KB],
+                                            f32x16 &c0, f32x16 &c1) {
+    f32x16 bias;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const float4 b = *reinterpret_cast<const float4 *>(brow + 8 * g);
+        bias[4 * g + 0] = b.x; bias[4 * g + 1] = b.y; bias[4 * g + 2] = b.z; bias[4 * g + 3] = b.w;
+    }
+    c0 = bias;
+    if constexpr (TWO) c1 = bias;
+#define RNAD_SPLIT_MFMA(wa_, xb_)                                                                      \
+    c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[kb].wa_, x0[kb].xb_, c0, 0, 0, 0);                  \
+    if constexpr (TWO) c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[kb].wa_, x1[kb].xb_, c1, 0, 0, 0)
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) {
+        RNAD_SPLIT_MFMA(l, h);
+        RNAD_SPLIT_MFMA(h, l);
+        RNAD_SPLIT_MFMA(m, m);
+    }
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) {
+        RNAD_SPLIT_MFMA(m, h);
+        RNAD_SPLIT_MFMA(h, m);
+    }
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) {
+        RNAD_SPLIT_MFMA(h, h);
+    }
+#undef RNAD_SPLIT_MFMA
+}
+
 __device__ __forceinline__ float lane_sum(const f32x2 (&acc)[2]) { return (acc[0].x + acc[0].y) + (acc[1].x + acc[1].y); }
 
 template <bool B>
@@ -78,8 +141,15 @@ struct Flag { static constexpr bool value = B; };
 
 // MODE 0: learner (both heads) + target (value head) -> tables + records;  1: the two value heads (logits from the table) -> tables +
 // records;  2: the learner's policy head -> logits + policy rows
-template <int A, typename ObsT, bool FOLD, int MODE>
-__global__ __launch_bounds__(64 * (kRowsMaxWaves + kRecWaves)) void k_rows_forward_records(int64_t N, int W, RowsArgs g, const ObsT *__restrict__ obs,
+// WIDE (SPLIT with more than one block of 16 input features: A >= 4, and A = 3 without the fold): no dedicated record waves -- the first
+// kChunkSteps compute waves write the records of the previous chunk after their own phase 1 (r04 measured that arrangement 3 % behind
+// dedicated record waves) -- so that a workgroup is 8 waves, two per SIMD, and a wave may hold 256 registers: split weights (12 per hidden
+// tile and block) and split inputs of two row tiles do not fit the 168 of a 12-wave workgroup.
+template <int A, bool FOLD, bool SPLIT>
+constexpr bool rows_wide() { return SPLIT && (MlpShape<A, FOLD>::K + 15) / 16 > 1; }
+
+template <int A, typename ObsT, bool FOLD, int MODE, bool SPLIT = false>
+__global__ __launch_bounds__(64 * (kRowsMaxWaves + (rows_wide<A, FOLD, SPLIT>() ? 0 : kRecWaves))) void k_rows_forward_records(int64_t N, int W, RowsArgs g, const ObsT *__restrict__ obs,
                                                                                            rnad_learn_params_t hp) {
     if (g.n_rows) N = *g.n_rows;
     if (g.sp) {
@@ -93,7 +163,8 @@ __global__ __launch_bounds__(64 * (kRowsMaxWaves + kRecWaves)) void k_rows_forwa
     constexpr int U = NV + (POLICY ? 1 : 0);           // hidden tiles per compute wave
     constexpr int U0 = VALUES ? 0 : 2;                 // first of them in the order learner value (0), target value (1), learner policy (2)
     const int T = W / kTile;                  // hidden tiles per head = compute waves of this workgroup
-    const int nthreads = 64 * (T + kRecWaves);
+    constexpr bool WIDE = rows_wide<A, FOLD, SPLIT>();
+    const int nthreads = 64 * (T + (WIDE ? 0 : kRecWaves));
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, col = lane & 31, half = lane >> 5;
     const bool computes = wave < T;
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -102,8 +173,11 @@ __global__ __launch_bounds__(64 * (kRowsMaxWaves + kRecWaves)) void k_rows_forwa
     float *part = w1 + (2 + A) * W;  // [2][kChunkSteps][T][NOUT][64] partial sums; before the first step: the indicator weights [U][W]
     const int part_buf = kChunkSteps * T * NOUT * 64;
 
-    float a[U][KS];  // a compute wave's A operands: W0[hidden = 32 tile + col][k = 2 ks + half]
-    if (computes) {
+    constexpr int KB = (K + 15) / 16;          // SPLIT: blocks of 16 input features (zero beyond K)
+    constexpr int KSr = SPLIT ? 1 : KS, KBs = SPLIT ? KB : 1;
+    Split8 aw[U][KBs];  // SPLIT: a compute wave's A operands, W0[hidden = 32 tile + col][k = 16 kb + 8 half + j] as three bf16 each
+    float a[U][KSr];  // a compute wave's A operands: W0[hidden = 32 tile + col][k = 2 ks + half]
+    if (computes && !SPLIT) {
 #pragma unroll
         for (int v = 0; v < U; ++v) {
             const int u = U0 + v;
@@ -134,11 +208,39 @@ __global__ __launch_bounds__(64 * (kRowsMaxWaves + kRecWaves)) void k_rows_forwa
         w1[i] = x;
     }
     __syncthreads();
-    if constexpr (FOLD) {
+    if constexpr (FOLD && !SPLIT) {
         constexpr int kk = A * A;  // the indicator's input slot
         if (computes && half == (kk & 1)) {
 #pragma unroll
             for (int v = 0; v < U; ++v) a[v][kk / 2] = part[(U0 + v) * W + wave * kTile + col];
+        }
+    }
+    if constexpr (SPLIT) {
+        if (computes) {
+#pragma unroll
+            for (int v = 0; v < U; ++v) {
+                const int u = U0 + v;
+                const float *img = u == 1 ? g.packed_target : g.packed_net;
+                const int tile = u == 2 ? T + wave : wave;
+                const float *wa = img + tile * (KS * 64) + col;
+#pragma unroll
+                for (int kb = 0; kb < KB; ++kb) {
+                    float w8[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        // (k depends on the lane's half: both candidates are compile-time slots of the image)
+                        const int k0 = 16 * kb + j, k1 = k0 + 8;
+                        auto slot = [&](int k) -> float {
+                            if (FOLD && k == A * A) return part[(U0 + v) * W + wave * kTile + col];  // the indicator's weight
+                            if (k >= (FOLD ? A * A : K)) return 0.0f;
+                            return wa[(k / 2) * 64 + (k % 2) * 32];
+                        };
+                        const float lo_half = slot(k0), hi_half = slot(k1);
+                        w8[j] = half ? hi_half : lo_half;
+                    }
+                    aw[v][kb] = split8(w8);
+                }
+            }
         }
     }
     __syncthreads();  // the scratch in `part` is free
@@ -152,56 +254,125 @@ __global__ __launch_bounds__(64 * (kRowsMaxWaves + kRecWaves)) void k_rows_forwa
     const int n_steps = (int)((my_tiles + 1) / 2);
     const int n_chunks = (n_steps + kChunkSteps - 1) / kChunkSteps;
 
-    float xn[2][KS];  // B operands of the next step (x[row = 32 s + col][2 ks + half]), in flight during the current one
+    // B operands of the next step, in flight during the current one: x[row = 32 s + col][2 ks + half]; SPLIT: [16 kb + 8 half + j]
+    constexpr int XN = SPLIT ? 8 * KB : KS;
+    float xn[2][XN];
     auto fetch = [&](int step) {
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             const int64_t sample = s_begin + (int64_t)step * (2 * kTile) + s * kTile + col;
             const bool in = sample < s_end;
             const int64_t row = (in && g.rows) ? (int64_t)g.rows[sample] : sample;
+            if constexpr (SPLIT) {
+                const ObsT *rp = obs + row * OBS;
+                constexpr int EV = FOLD ? A * A : K;  // features read from the row as they are
+                float ind = 0.0f;                     // FOLD: the indicator feature (obs_feature)
+                if constexpr (FOLD) ind = in ? 1.0f - load_obs<ObsT>(rp + A * A + (A > 1 ? 1 : 0)) : 0.0f;
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks) xn[s][ks] = in ? obs_feature<A, FOLD, ObsT>(obs + row * OBS, 2 * ks + half) : 0.0f;
+                for (int i = 0; i < XN; ++i) {
+                    const int k0 = 16 * (i / 8) + (i % 8), k1 = k0 + 8;  // the two half-waves' features of this slot
+                    if (k0 >= K && k1 >= K) {
+                        xn[s][i] = 0.0f;  // (beyond K for both: a constant)
+                        continue;
+                    }
+                    const int k = half ? k1 : k0;
+                    float v = (in && k < EV) ? load_obs<ObsT>(rp + k) : 0.0f;
+                    if constexpr (FOLD) v = k == A * A ? ind : v;
+                    xn[s][i] = v;
+                }
+            } else {
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) xn[s][ks] = in ? obs_feature<A, FOLD, ObsT>(obs + row * OBS, 2 * ks + half) : 0.0f;
+            }
         }
     };
     const float *bias_u = b0f + wave * kTile + 4 * half;
     const float *w1_u = w1 + wave * kTile + 4 * half;
     // phase 1 of one step: this wave's hidden tiles on the step's 64 (TWO) or 32 rows -> partial sums into `dst`
-    auto p1_step = [&](int step, float *dst, auto two_) {
-        constexpr bool TWO = decltype(two_)::value;
-        float x0[KS], x1[KS];
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) { x0[ks] = xn[0][ks]; x1[ks] = xn[1][ks]; }
-        if (step + 1 < n_steps) fetch(step + 1);
-        float out[NOUT][2];  // [output][row tile]
-#if RNAD_ROWS_ABLATE & 2
-#pragma unroll
-        for (int o = 0; o < NOUT; ++o) out[o][0] = out[o][1] = x0[0] + x1[1];
-#else
+    // the heads of this wave's hidden tiles on one (PAIR = false: x0 / xs0, into out[.][o0]) or two row tiles (into out[.][0], out[.][1])
+    auto heads = [&](const float (&x0)[KSr], const float (&x1)[KSr], const Split8 (&xs0)[KBs], const Split8 (&xs1)[KBs], float (&out)[NOUT][2],
+                     auto pair_, int o0) {
+        constexpr bool PAIR = decltype(pair_)::value;
 #pragma unroll
         for (int u = 0; u < NV; ++u) {  // learner value, target value
             f32x16 c0_, c1_;
             f32x2 acc0[2] = {f32x2{0.f, 0.f}, f32x2{0.f, 0.f}}, acc1[2] = {f32x2{0.f, 0.f}, f32x2{0.f, 0.f}};
-            chain_reg<KS, TWO>(a[u], bias_u + u * W, x0, x1, c0_, c1_);
+            if constexpr (SPLIT) chain_split<KBs, PAIR>(aw[u], bias_u + u * W, xs0, xs1, c0_, c1_);
+            else chain_reg<KSr, PAIR>(a[u], bias_u + u * W, x0, x1, c0_, c1_);
             epilogue_value(c0_, w1_u + u * W, acc0);
-            if constexpr (TWO) epilogue_value(c1_, w1_u + u * W, acc1);
-            out[u][0] = lane_sum(acc0);
-            out[u][1] = lane_sum(acc1);
+            if constexpr (PAIR) epilogue_value(c1_, w1_u + u * W, acc1);
+            out[u][o0] = lane_sum(acc0);
+            if constexpr (PAIR) out[u][1] = lane_sum(acc1);
         }
         if constexpr (POLICY) {
             f32x16 c0_, c1_;
             f32x2 acc0[A][2], acc1[A][2];
 #pragma unroll
             for (int a_ = 0; a_ < A; ++a_) acc0[a_][0] = acc0[a_][1] = acc1[a_][0] = acc1[a_][1] = f32x2{0.f, 0.f};
-            chain_reg<KS, TWO>(a[U - 1], bias_u + 2 * W, x0, x1, c0_, c1_);
+            if constexpr (SPLIT) chain_split<KBs, PAIR>(aw[U - 1], bias_u + 2 * W, xs0, xs1, c0_, c1_);
+            else chain_reg<KSr, PAIR>(a[U - 1], bias_u + 2 * W, x0, x1, c0_, c1_);
             epilogue_policy<A>(c0_, w1_u + 2 * W, W, acc0);
-            if constexpr (TWO) epilogue_policy<A>(c1_, w1_u + 2 * W, W, acc1);
+            if constexpr (PAIR) epilogue_policy<A>(c1_, w1_u + 2 * W, W, acc1);
 #pragma unroll
             for (int a_ = 0; a_ < A; ++a_) {
-                out[NV + a_][0] = lane_sum(acc0[a_]);
-                out[NV + a_][1] = lane_sum(acc1[a_]);
+                out[NV + a_][o0] = lane_sum(acc0[a_]);
+                if constexpr (PAIR) out[NV + a_][1] = lane_sum(acc1[a_]);
             }
         }
+    };
+    // SPLIT with more than one block of 16 features (A >= 4; A = 3 without the fold): the two row tiles of a step one after the other --
+    // both tiles' split operands beside the split weights do not fit the 168 registers of a 12-wave workgroup
+    constexpr bool kSerialTiles = false;  // (r06: tried for the 12-wave workgroup -- it spilled more, not less; WIDE workgroups replaced it)
+    auto p1_step = [&](int step, float *dst, auto two_) {
+        constexpr bool TWO = decltype(two_)::value;
+        float out[NOUT][2];  // [output][row tile]
+#pragma unroll
+        for (int o = 0; o < NOUT; ++o) out[o][0] = out[o][1] = 0.0f;
+        float x0[KSr], x1[KSr];
+        Split8 xs0[KBs], xs1[KBs];
+        if constexpr (kSerialTiles) {
+            float t1[XN];  // the second tile's raw features: kept while the next step's loads go out
+#pragma unroll
+            for (int kb = 0; kb < KB; ++kb) {
+                float t0[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { t0[j] = xn[0][8 * kb + j]; t1[8 * kb + j] = xn[1][8 * kb + j]; }
+                xs0[kb] = split8(t0);
+            }
+            if (step + 1 < n_steps) fetch(step + 1);
+            heads(x0, x1, xs0, xs1, out, Flag<false>{}, 0);
+            if constexpr (TWO) {
+#pragma unroll
+                for (int kb = 0; kb < KB; ++kb) {
+                    float t0[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) t0[j] = t1[8 * kb + j];
+                    xs0[kb] = split8(t0);
+                }
+                heads(x0, x1, xs0, xs1, out, Flag<false>{}, 1);
+            }
+        } else {
+            if constexpr (SPLIT) {
+#pragma unroll
+                for (int kb = 0; kb < KB; ++kb) {
+                    float t0[8], t1[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) { t0[j] = xn[0][8 * kb + j]; t1[j] = xn[1][8 * kb + j]; }
+                    xs0[kb] = split8(t0);
+                    if constexpr (TWO) xs1[kb] = split8(t1);
+                }
+            } else {
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) { x0[ks] = xn[0][ks]; x1[ks] = xn[1][ks]; }
+            }
+            if (step + 1 < n_steps) fetch(step + 1);
+#if RNAD_ROWS_ABLATE & 2
+#pragma unroll
+            for (int o = 0; o < NOUT; ++o) out[o][0] = out[o][1] = (SPLIT ? (float)xs0[0].h[0] + (float)xs1[0].l[1] : x0[0] + x1[0]);
+#else
+            heads(x0, x1, xs0, xs1, out, two_, 0);
 #endif
+        }
         // the two half-waves hold complementary hidden rows of the same 32 + 32 rows: half h keeps row tile h and gets the other
         // half's share of it -- lane l ends up with the tile's sums for row 64 step + l
 #pragma unroll
@@ -276,6 +447,12 @@ __global__ __launch_bounds__(64 * (kRowsMaxWaves + kRecWaves)) void k_rows_forwa
             const int step = (c - 1) * kChunkSteps + (wave - T);
             if (step < n_steps) p2_step(step, part + ((c - 1) & 1) * part_buf + (int64_t)(wave - T) * T * NOUT * 64 + lane);
         }
+        if constexpr (WIDE) {  // (the buffer of chunk c - 1 is written again in iteration c + 1, behind the barrier below)
+            if (c > 0 && wave < kChunkSteps) {
+                const int step = (c - 1) * kChunkSteps + wave;
+                if (step < n_steps) p2_step(step, part + ((c - 1) & 1) * part_buf + (int64_t)wave * T * NOUT * 64 + lane);
+            }
+        }
         __syncthreads();
     }
 }
@@ -305,22 +482,39 @@ extern "C" int rnad_mlp_rows_actor_supported(int A, int W, int fold) {
 
 static int rows_launch(const rnad_tree_t *tree, int W, int fold, const void *obs, int obs_half, int mode, const RowsArgs &g,
                        const rnad_learn_params_t &hp, hipStream_t stream) {
-    const int A = tree->A;
+    const int A = tree->A, T = W / kTile;
     const int64_t N = 2 * tree->S;
     int dev = 0, cus = 256;
     RNAD_HIP_OK(hipGetDevice(&dev));
     RNAD_HIP_OK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-    const int T = W / kTile;
     const int64_t n_tiles = (N + kTile - 1) / kTile;
     const int64_t grid = std::max<int64_t>(1, std::min<int64_t>((n_tiles + 1) / 2, cus));  // one persistent workgroup per CU
     const size_t lds_bytes = rows_lds_bytes(A, W, mode);
     ProfScope prof(PROF_MLP, stream);
-#define RNAD_ROWS_LAUNCH3(T_, F_, M_)                                                                                                  \
+    // r06: the split-precision first layer (bf16 matrix rate, see chain_split) for the action counts of BASELINE.json's configurations;
+    // RNAD_MLP_SPLIT=0 restores the fp32 MFMA chains (A/B runs, tests)
+    const char *split_e = getenv("RNAD_MLP_SPLIT");
+    const bool split_env = !(split_e && atoi(split_e) == 0);
+    const int K_in = fold ? ((A * A + 2) & ~1) : 2 * A * A;
+    const bool wide_shape = (K_in + 15) / 16 > 1;
+    const bool split = split_env && A >= 2 && A <= 5 && (fold || A <= 4) && (!wide_shape || T >= kChunkSteps);  // (WIDE workgroups: kChunkSteps compute waves write the records)  // (A = 5 without the fold: 4 blocks of 16 features spill)
+#define RNAD_ROWS_LAUNCH4(T_, F_, M_, S_)                                                                                              \
     do {                                                                                                                               \
-        auto kern = k_rows_forward_records<kA, T_, F_, M_>;                                                                            \
+        auto kern = k_rows_forward_records<kA, T_, F_, M_, S_>;                                                                        \
         if (lds_bytes > 64 * 1024)                                                                                                     \
             RNAD_HIP_OK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));          \
-        hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64 * (T + kRecWaves)), lds_bytes, stream, N, W, g, (const T_ *)obs, hp);   \
+        constexpr bool wide_ = rows_wide<kA, F_, S_>();                                                                                \
+        RNAD_REQUIRE(!wide_ || T >= kChunkSteps, "rnad_mlp_rows: the split first layer of this shape needs a width of at least %d", kChunkSteps * kTile); \
+        hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64 * (T + (wide_ ? 0 : kRecWaves))), lds_bytes, stream, N, W, g, (const T_ *)obs, hp); \
+    } while (0)
+#define RNAD_ROWS_LAUNCH3(T_, F_, M_)                                                   \
+    do {                                                                                \
+        if constexpr (kA >= 2 && kA <= 5) {                                             \
+            if (split) RNAD_ROWS_LAUNCH4(T_, F_, M_, true);                             \
+            else RNAD_ROWS_LAUNCH4(T_, F_, M_, false);                                  \
+        } else {                                                                        \
+            RNAD_ROWS_LAUNCH4(T_, F_, M_, false);                                       \
+        }                                                                               \
     } while (0)
 #define RNAD_ROWS_LAUNCH2(T_, F_)                           \
     do {                                                    \
@@ -339,6 +533,7 @@ static int rows_launch(const rnad_tree_t *tree, int W, int fold, const void *obs
         else
             RNAD_ROWS_LAUNCH(float);
     });
+#undef RNAD_ROWS_LAUNCH4
 #undef RNAD_ROWS_LAUNCH3
 #undef RNAD_ROWS_LAUNCH2
 #undef RNAD_ROWS_LAUNCH

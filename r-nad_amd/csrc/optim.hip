@@ -70,6 +70,8 @@ __global__ __launch_bounds__(kOptThreads) void k_optimizer_step(OptTensors ts, c
     __shared__ float *ptr_s[4][kMaxTensors];
     __shared__ int64_t off_s[kMaxTensors + 1];
     const int64_t n = ts.offset[ts.n];
+    // every tensor has its own step counter in torch's state (they move together): requested first, used after the norm
+    float step_now = 0.0f;
     if ((int)threadIdx.x < kMaxTensors) {
         const int k = threadIdx.x;
         const bool on = k < ts.n;
@@ -79,12 +81,7 @@ __global__ __launch_bounds__(kOptThreads) void k_optimizer_step(OptTensors ts, c
         ptr_s[3][k] = on ? ts.target[k] : nullptr;
         off_s[k] = on ? ts.offset[k] : n;
         if (k == 0) off_s[kMaxTensors] = n;
-        if (on) {  // every tensor has its own step counter in torch's state; they move together
-            const float step = *ts.step[k] + 1.0f;
-            const double bc1 = 1.0 - pow((double)hp.beta1, (double)step);
-            step_size_s[k] = (float)((double)hp.lr / bc1);
-            bc2s_s[k] = (float)sqrt(1.0 - pow((double)hp.beta2, (double)step));
-        }
+        if (on) step_now = *ts.step[k];
     }
     // this thread's own element: requested before the norm so that its latency hides behind it
     const int64_t i = (int64_t)blockIdx.x * kOptThreads + threadIdx.x;
@@ -104,6 +101,21 @@ __global__ __launch_bounds__(kOptThreads) void k_optimizer_step(OptTensors ts, c
     for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
     if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
     __syncthreads();
+    if ((int)threadIdx.x < ts.n) {
+        // bias corrections in double from the step counter.  r06: beta^step by squaring (the counter is an integer below 2^24: at most 24
+        // squarings and 24 products, a few ulps of a DOUBLE from libm's pow -- invisible once rounded to the floats below) instead of two
+        // calls of pow, ~600 fp64 instructions on the launch's critical path (wave 0 also finishes the norm)
+        const float step = step_now + 1.0f;
+        unsigned e = (unsigned)step;
+        double p1 = 1.0, p2 = 1.0, b1 = (double)hp.beta1, b2 = (double)hp.beta2;
+        for (; e; e >>= 1) {
+            if (e & 1u) { p1 *= b1; p2 *= b2; }
+            b1 *= b1;
+            b2 *= b2;
+        }
+        step_size_s[threadIdx.x] = (float)((double)hp.lr / (1.0 - p1));
+        bc2s_s[threadIdx.x] = (float)sqrt(1.0 - p2);
+    }
     if (threadIdx.x == 0) {
         double t = 0.0;
 #pragma unroll

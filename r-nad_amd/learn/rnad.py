@@ -1199,7 +1199,7 @@ class RNaD:
                 self.batch_size, self.tabular, getattr(self, "tabular_gate", 8), self.eta, self.beta, self.neurd_clip, self.grad_clip,
                 self.c_bar, self.roh_bar, self.vtrace_gamma, self.value_weight, self.neurd_weight, self.epsilon_threshold, self.n_discrete,
                 self.gamma_averaging, getattr(self, "obs_half", False), getattr(self, "store_actor_values", False), getattr(self, "fused_optimizer", True),
-                getattr(self, "compact_trajectory", True), getattr(self, "lazy_rows", None), os.environ.get("RNAD_BUCKET_ROWS"), os.environ.get("RNAD_BUCKET_CHUNK"),
+                getattr(self, "compact_trajectory", True), getattr(self, "lazy_rows", None), rnad_hip.plan_knobs(), os.environ.get("RNAD_LEAF_CHUNK"),
                 getattr(self, "fold_legal", True), self._fuse_now(), self._fuse_now() and self._distinct_now(), getattr(self, "analytic_norm", True), os.environ.get("RNAD_FUSED_DISTINCT"), os.environ.get("RNAD_FUSED_CHUNK"),
                 getattr(self, "leaf_paths", None), os.environ.get("RNAD_LEAF_PATHS"), self.__dict__.get("_leaf_crowded", False))
 

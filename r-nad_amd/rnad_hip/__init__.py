@@ -228,7 +228,11 @@ class TreeHandle:
             got.rep_of = rep_of.to(I32).contiguous()
             got.multi_start = start.to(I32).contiguous()
             got.multi_order = order.to(I32).contiguous()
-            got.c_groups = RowGroups(got.n_multi, got.multi_start.data_ptr(), got.multi_order.data_ptr())
+            # the groups' first 256 rows once more, padded per group ([n_multi][4][64], -1 beyond the group): rnad_row_groups_t.first
+            pos = start[:-1, None] + torch.arange(256, device=table.device, dtype=torch.int64)[None, :]
+            inside = pos < start[1:, None]
+            got.multi_first = torch.where(inside, order[pos.clamp(max=max(order.numel() - 1, 0))] if order.numel() else pos, -torch.ones_like(pos)).to(I32).contiguous()
+            got.c_groups = RowGroups(got.n_multi, got.multi_start.data_ptr(), got.multi_order.data_ptr(), got.multi_first.data_ptr())
             setattr(self, key, got)
         return got
 
@@ -249,7 +253,7 @@ class TreeHandle:
 class RowGroups(C.Structure):
     """struct rnad_row_groups (include/rnad_hip.h)."""
 
-    _fields_ = [("n_groups", C.c_int32), ("start", C.c_void_p), ("order", C.c_void_p)]
+    _fields_ = [("n_groups", C.c_int32), ("start", C.c_void_p), ("order", C.c_void_p), ("first", C.c_void_p)]
 
 
 class ObsDedup:
@@ -807,7 +811,7 @@ class BucketPlan:
     def __init__(self, tree, B, out):
         self.B = B
         (self.rows, self.n_buckets, self.n_upper, self.n_groups, self.max_items, self.scratch_bytes, self.acc_bytes, self.lds,
-         self.rel_bytes) = (int(x) for x in out)
+         self.rel_bytes, self.sort_tile, self.chunk) = (int(x) for x in out)
         dev = tree.device
         self.scratch = torch.empty((self.scratch_bytes // 4 + 1,), dtype=I32, device=dev)
         self.accumulators = torch.zeros((self.acc_bytes // 8 + 1,), dtype=torch.int64, device=dev)
@@ -842,6 +846,12 @@ class workspace_owner:
         return False
 
 
+def plan_knobs():
+    """The tuning overrides csrc/bucket.hip's make_plan reads from the environment on every call: they size the plan's workspaces, so they
+    key every cache of plans (and RNaD's captured graphs)."""
+    return tuple(os.environ.get(k) for k in ("RNAD_BUCKET_ROWS", "RNAD_BUCKET_CHUNK", "RNAD_SORT_TILE"))
+
+
 def bucket_plan(tree, B):
     """The BucketPlan of (tree, B) for the current workspace_owner (cached on the tree handle), or None when this tree / batch cannot be
     bucketed."""
@@ -851,9 +861,9 @@ def bucket_plan(tree, B):
         cache = tree.__dict__.setdefault("_bucket_plans", {})
     else:  # (weakly keyed: a trainer's workspaces go when the trainer does)
         cache = tree.__dict__.setdefault("_owner_plans", weakref.WeakKeyDictionary()).setdefault(token, {})
-    key = (B, os.environ.get("RNAD_BUCKET_ROWS"), os.environ.get("RNAD_BUCKET_CHUNK"))  # the tuning overrides of csrc/bucket.hip
+    key = (B,) + plan_knobs()
     if key not in cache:
-        out = (C.c_int64 * 9)()
+        out = (C.c_int64 * 11)()
         rc = lib().rnad_bucket_plan(tree.ptr, B, out)
         cache[key] = BucketPlan(tree, B, list(out)) if rc == 0 else None
     return cache[key]
@@ -1091,9 +1101,12 @@ def leaf_paths(tree, plan_B, index, chance, value):
     plan = bucket_plan(tree, plan_B)
     if plan is None:
         return None
-    got = getattr(plan, "leaf", None)
+    cache = plan.__dict__.setdefault("leaf_by_chunk", {})
+    key = os.environ.get("RNAD_LEAF_CHUNK")  # (tuning knob: columns per work item -- part of what a LeafPaths is)
+    got = cache.get(key)
     if got is None:
-        got = plan.leaf = LeafPaths(tree, plan_B, index, chance, value)
+        got = cache[key] = LeafPaths(tree, plan_B, index, chance, value)
+    plan.leaf = got
     return got
 
 

@@ -12,10 +12,13 @@ for p in (ROOT, PKG, os.path.dirname(os.path.realpath(__file__))):
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "last: long full-size cases, moved to the end of the run")
 
 
 def pytest_collection_modifyitems(config, items):
     import torch
+
+    items.sort(key=lambda item: 1 if "last" in item.keywords else 0)  # (stable: everything else keeps its order)
 
     if torch.cuda.is_available():
         return

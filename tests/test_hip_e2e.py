@@ -23,7 +23,6 @@ import torch
 pytestmark = pytest.mark.gpu
 
 DEV = torch.device("cuda:0")
-K = 8
 LR = 5e-5  # the reference's default (rnad.py:45)
 
 
@@ -33,7 +32,7 @@ def _arrays(tree):
                 depth_bound=tree.depth_bound)
 
 
-def _trainer(tree, B, width, lazy):
+def _trainer(tree, B, width, lazy, leaf=None):
     from learn.rnad import RNaD
 
     os.environ["RNAD_SAVE_DIR"] = tempfile.mkdtemp(prefix="rnad_e2e_")
@@ -42,6 +41,7 @@ def _trainer(tree, B, width, lazy):
               net_params={"type": "MLP", "max_actions": tree.max_actions, "width": width})
     rn.initialize()
     rn.lazy_rows = lazy
+    rn.leaf_paths = leaf
     rn.tabular_gate = 0  # the per-row mode whatever the ratio of tree to batch (the test's batches are small next to configs[1]'s)
     # four different nets, as in the middle of a run (rnad.py:528-531 rotates them): every term of log_policy_reg (:382) is live
     g = torch.Generator(device="cpu")
@@ -56,9 +56,16 @@ def _trainer(tree, B, width, lazy):
 # depth: the configs[1] tree (A = 3, C = 1, terminal values +-1) at that depth; a name: a tree of tests/test_hip_bucket.py::TREES -- "pruned"
 # (A = 3, C = 2, ragged episode lengths) and "a5c4" (the configs[3] shape: A = 5, C = 4, pruned) take RNaD's lazy-rows step with the staged
 # actor, the default on trees that are large next to the batch
-@pytest.mark.parametrize("depth,log2_B,width,lazy", ((4, 14, 64, False), (4, 16, 256, False), (6, 16, 256, False), (6, 18, 256, False),
-                                                     (6, 16, 256, None), ("pruned", 14, 64, True), ("a5c4", 14, 64, True), ("pruned", 14, 64, False)))
-def test_default_step_trains_like_the_cpu_port(depth, log2_B, width, lazy):
+# r06, the last two: the BENCHMARKED size -- configs[1]'s tree at 2^20 lanes, the very cut, sort tile and kernel instantiations bench.py
+# times (3 eager steps, the capture, one more replay) -- and an 8-GPU rank's 2^19 lanes with the leaf-path learner forced (the learner that
+# carries the N = 1 point of configs[2]).  They run last (the CPU port takes ~20 s per step at that size, its MLP
+# in row chunks so that the host's memory stays bounded).
+@pytest.mark.parametrize("depth,log2_B,width,lazy,K,leaf",
+                         ((4, 14, 64, False, 8, None), (4, 16, 256, False, 8, None), (6, 16, 256, False, 8, None), (6, 18, 256, False, 8, None),
+                          (6, 16, 256, None, 8, None), ("pruned", 14, 64, True, 8, None), ("a5c4", 14, 64, True, 8, None),
+                          ("pruned", 14, 64, False, 8, None), pytest.param(6, 19, 256, False, 5, True, marks=pytest.mark.last),
+                          pytest.param(6, 20, 256, False, 5, None, marks=pytest.mark.last)))
+def test_default_step_trains_like_the_cpu_port(depth, log2_B, width, lazy, K, leaf):
     from environment.episode import Buffer
     from oracle.port import CpuTrainer
     from test_hip_bucket import TREES, _native_tree
@@ -66,13 +73,14 @@ def test_default_step_trains_like_the_cpu_port(depth, log2_B, width, lazy):
     regular = not isinstance(depth, str)
     tree = _native_tree(A=3, C=1, depth=depth, seed=0) if regular else _native_tree(**TREES[depth])
     B = 1 << log2_B
-    rn = _trainer(tree, B, width, lazy)
+    rn = _trainer(tree, B, width, lazy, leaf)
     h = tree.handle()
     T = 2 * h.max_depth
     cpu = CpuTrainer(_arrays(tree), width=width, lr=LR, eta=rn.eta, gamma_averaging=rn.gamma_averaging, n_discrete=rn.n_discrete,
                      epsilon_threshold=rn.epsilon_threshold, neurd_clip=rn.neurd_clip, logit_clip=rn.beta, grad_clip=rn.grad_clip,
-                     state_dicts=[m.state_dict() for m in (rn.net, rn.net_target, rn.net_reg, rn.net_reg_)], keep=True)
-    torch.set_num_threads(8)
+                     state_dicts=[m.state_dict() for m in (rn.net, rn.net_target, rn.net_reg, rn.net_reg_)], keep=True,
+                     chunk_rows=1 << 20 if log2_B >= 19 else None)
+    torch.set_num_threads(min(64, os.cpu_count() or 8) if log2_B >= 19 else 8)
     buf = Buffer(1)
     delta_m = 64
     rn.alpha_ahead = lambda k: rn.alpha_of(rn.total_steps + k, delta_m)
@@ -115,6 +123,8 @@ def test_default_step_trains_like_the_cpu_port(depth, log2_B, width, lazy):
     assert modes[:3] == ["eager"] * 3 and modes[-1] == "replay", modes
     g = rn._graph
     assert g["graph"] is not None and not g["failed"], "the step was captured and replayed"
+    if leaf:
+        assert getattr(rn.last_episodes, "_learned", None) is not None and rn._leaf_now(h, B, T) is not None, "the leaf-path learner ran"
     if lazy is False and regular:
         assert rn._dedup_now(h, None, False, False, rn._fold()) is not None, "distinct observations are on for this tree"
     if lazy is not False and not regular:
@@ -136,7 +146,8 @@ def test_default_step_trains_like_the_cpu_port(depth, log2_B, width, lazy):
                 np.testing.assert_allclose(a[~bad], b[~bad], rtol=1e-4, atol=2e-6, err_msg=f"{name}.{k}")
             else:  # the EMA target has moved by gamma_averaging of the net's steps: everything within the tolerance
                 np.testing.assert_allclose(a, b, rtol=1e-4, atol=2e-6, err_msg=f"{name}.{k}")
-    stats = dict(depth=depth, log2_B=log2_B, width=width, lazy=lazy, steps=K, flipped_lanes=flipped_total, decisions=decisions,
+    torch.set_num_threads(8)
+    stats = dict(depth=depth, log2_B=log2_B, width=width, lazy=lazy, leaf=leaf, steps=K, flipped_lanes=flipped_total, decisions=decisions,
                  flipped_per_1e7_decisions=flipped_total * 1e7 / max(decisions, 1), parameters=n, parameters_outside_tolerance=outliers,
                  largest_parameter_error=worst, modes=modes)
     print("e2e", stats)

@@ -8,6 +8,6 @@ tag=$1; counters=$2; regex=$3; shift 3
 [ "$1" == "--" ] && shift
 out=$R/gpurun_out/pmc_$tag
 rm -rf $out; mkdir -p $out
-( cd $R && rocprofv3 --kernel-trace --pmc $counters --output-format csv -d $out -o $tag -- "$@" ) > $out/run.log 2>&1
+( cd $R && timeout -k 10 ${PMC_TIMEOUT:-420} rocprofv3 --kernel-trace --pmc $counters --output-format csv -d $out -o $tag -- "$@" ) > $out/run.log 2>&1
 python $R/tools/pmc_summary.py $out "$regex" > $R/gpurun_out/pmc_$tag.csv
 cat $R/gpurun_out/pmc_$tag.csv | cut -c1-220

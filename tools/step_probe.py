@@ -34,6 +34,7 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="enqueue every step eagerly (one dispatch per kernel launch for the counter passes)")
     ap.add_argument("--sharp", type=float, default=0.0, help="scale the learner's policy output layer by this factor first (a near-deterministic actor, as after training)")
     ap.add_argument("--distinct", action="store_true", help="RNaD.distinct_trajectories = True")
+    ap.add_argument("--no-dedup", action="store_true", help="RNaD.dedup_rows = False: nets and backward on all 2S rows (kernel quality of the MLP launches)")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     torch.cuda.set_device(0)
@@ -57,6 +58,8 @@ def main():
                     p.mul_(args.sharp)
     if args.distinct:
         rn.distinct_trajectories = True
+    if args.no_dedup:
+        rn.dedup_rows = False
     buf = Buffer(1)
     for i in range(5):
         rn.train_step(buf, 0.3)
