@@ -3504,9 +3504,9 @@ extern "C" int rnad_leaf_paths_pack(const rnad_tree_t *tree, int64_t plan_B, int
     RNAD_REQUIRE(T1 >= 1 && T1 <= kCompactSteps + 1 && n_cols >= 1 && max_items >= 1, "rnad_leaf_paths_pack: bad shape");
     Plan p;
     RNAD_REQUIRE(make_plan(tree, plan_B, p), "rnad_leaf_paths_pack: this tree / batch cannot be bucketed (see rnad_bucket_plan)");
-    // a lane's bucket and its leaf column's bucket only pair up when every episode leaves the tree inside the window (learn/rnad.py guards
-    // the same; a C caller gets the check here)
-    RNAD_REQUIRE(tree->uniform_length && T1 - 1 == 2 * tree->max_depth, "rnad_leaf_paths_pack: leaf paths need a tree whose episodes all have full length, T1 = 2 * depth + 1");
+    // (a lane's bucket and its leaf column's bucket pair up because every episode leaves the tree inside the window: T1 - 1 = 2 * depth steps
+    // are enough on any tree, ragged episode lengths included -- tests/test_hip_leaf.py plays those)
+    RNAD_REQUIRE(T1 - 1 == 2 * tree->max_depth, "rnad_leaf_paths_pack: leaf paths span the whole window, T1 = 2 * depth + 1");
     *rows_out = p.cut->rows;
     *rel_bytes_out = p.rel_bytes;
     RNAD_DISPATCH_REL(p, hipLaunchKernelGGL((k_bucket_pack<REL>), dim3((unsigned)max_items), dim3(kThreads), 0, (hipStream_t)stream, T1, n_cols, p.cut->rows,

@@ -23,6 +23,7 @@
 // Summation order of the second layer (this kernel's own, as k_mlp_forward's is its own; nothing in the reference fixes it): per lane
 // and hidden tile as epilogue_value / epilogue_policy, the two half-waves, then the tiles in ascending order, then the bias.
 #include "mlp_common.hpp"
+#include <type_traits>
 #include "rollout_math.hpp"
 #include "row_records.hpp"
 
@@ -113,6 +114,10 @@ __device__ __forceinline__ void chain_split(const Split8 (&a)[KB], const float *
     }
     c0 = bias;
     if constexpr (TWO) c1 = bias;
+#if RNAD_ROWS_ABLATE & 4
+    c0[0] += (float)x0[0].h[0]; if constexpr (TWO) c1[0] += (float)x1[0].h[0];
+    return;
+#endif
 #define RNAD_SPLIT_MFMA(wa_, xb_)                                                                      \
     c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[kb].wa_, x0[kb].xb_, c0, 0, 0, 0);                  \
     if constexpr (TWO) c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[kb].wa_, x1[kb].xb_, c1, 0, 0, 0)
@@ -144,7 +149,8 @@ struct Flag { static constexpr bool value = B; };
 // WIDE (SPLIT with more than one block of 16 input features: A >= 4, and A = 3 without the fold): no dedicated record waves -- the first
 // kChunkSteps compute waves write the records of the previous chunk after their own phase 1 (r04 measured that arrangement 3 % behind
 // dedicated record waves) -- so that a workgroup is 8 waves, two per SIMD, and a wave may hold 256 registers: split weights (12 per hidden
-// tile and block) and split inputs of two row tiles do not fit the 168 of a 12-wave workgroup.
+// tile and block), split inputs of two row tiles and the accumulators of TWO heads in flight (the next head's matrix products are issued
+// before the current head's epilogue: the bf16 matrix pipe runs beside the VALU) do not fit the 168 of a 12-wave workgroup.
 template <int A, bool FOLD, bool SPLIT>
 constexpr bool rows_wide() { return SPLIT && (MlpShape<A, FOLD>::K + 15) / 16 > 1; }
 
@@ -164,6 +170,7 @@ __global__ __launch_bounds__(64 * (kRowsMaxWaves + (rows_wide<A, FOLD, SPLIT>() 
     constexpr int U0 = VALUES ? 0 : 2;                 // first of them in the order learner value (0), target value (1), learner policy (2)
     const int T = W / kTile;                  // hidden tiles per head = compute waves of this workgroup
     constexpr bool WIDE = rows_wide<A, FOLD, SPLIT>();
+    constexpr bool STAGED = SPLIT;  // the chunk's observation rows go through LDS, loaded once per workgroup (below)
     const int nthreads = 64 * (T + (WIDE ? 0 : kRecWaves));
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, col = lane & 31, half = lane >> 5;
     const bool computes = wave < T;
@@ -172,6 +179,13 @@ __global__ __launch_bounds__(64 * (kRowsMaxWaves + (rows_wide<A, FOLD, SPLIT>() 
     float *w1 = lds + 3 * W;         // [2 + A][W] second-layer rows: learner value | target value | learner policy [A]
     float *part = w1 + (2 + A) * W;  // [2][kChunkSteps][T][NOUT][64] partial sums; before the first step: the indicator weights [U][W]
     const int part_buf = kChunkSteps * T * NOUT * 64;
+    // WIDE: the observation rows of a chunk, staged ONCE per workgroup -- [2 buffers][kChunkRows][XS] floats behind the partial sums.  r06,
+    // measured: every compute wave fetching its own copy of the rows (8 waves x 10 scattered 4-byte loads per step) kept the CU's vector L1
+    // busy 0.87 of the launch (TCP_TOTAL_CACHE_ACCESSES 23.8 M per configs[3] launch, the most of any kernel of the step) and was what
+    // the launch waited for: the split first layer alone changed nothing (profiles/r06_rows_ablate.md).
+    constexpr int kChunkRows = kChunkSteps * 2 * kTile;
+    constexpr int KBx = (K + 15) / 16, XS = 16 * KBx + 4;  // floats per staged row: the features padded to whole blocks of 16, + 4 (bank spread of the 32-byte reads)
+    float *xl = part + 2 * part_buf;
 
     constexpr int KB = (K + 15) / 16;          // SPLIT: blocks of 16 input features (zero beyond K)
     constexpr int KSr = SPLIT ? 1 : KS, KBs = SPLIT ? KB : 1;
@@ -254,6 +268,45 @@ __global__ __launch_bounds__(64 * (kRowsMaxWaves + (rows_wide<A, FOLD, SPLIT>() 
     const int n_steps = (int)((my_tiles + 1) / 2);
     const int n_chunks = (n_steps + kChunkSteps - 1) / kChunkSteps;
 
+    // WIDE: chunk c's rows -> registers (stage_load, at the start of the iteration before: the loads travel while the chunk before is
+    // computed) -> LDS buffer c & 1 (stage_store, at the end of that iteration, in front of its barrier).  Thread i takes the elements
+    // i, i + nthreads, ... of the chunk's [kChunkRows][K] feature matrix: consecutive threads read consecutive floats of a row.
+    constexpr int kStageThreads = 64 * (kRowsMaxWaves + (WIDE ? 0 : kRecWaves));  // (staged workgroups have kRowsMaxWaves compute waves: width 256)
+    constexpr int kStageMax = STAGED ? (kChunkRows * K + kStageThreads - 1) / kStageThreads : 1;
+    float xst[kStageMax];
+    auto stage_load = [&](int c) {
+        const int64_t first = s_begin + (int64_t)c * kChunkRows;
+#pragma unroll
+        for (int e = 0; e < kStageMax; ++e) {
+            const int i = threadIdx.x + e * nthreads;
+            const int r = i / K, k = i % K;
+            const int64_t sample = first + r;
+            float v = 0.0f;
+            if (i < kChunkRows * K && sample < s_end) {
+                const int64_t row = g.rows ? (int64_t)g.rows[sample] : sample;
+                v = obs_feature<A, FOLD, ObsT>(obs + row * OBS, k);
+            }
+            xst[e] = v;
+        }
+    };
+    auto stage_store = [&](int c) {
+        float *dst = xl + (c & 1) * (kChunkRows * XS);
+#pragma unroll
+        for (int e = 0; e < kStageMax; ++e) {
+            const int i = threadIdx.x + e * nthreads;
+            if (i < kChunkRows * K) dst[(i / K) * XS + (i % K)] = xst[e];
+        }
+    };
+    if constexpr (STAGED) {
+        for (int i = threadIdx.x; i < 2 * kChunkRows * XS; i += nthreads) xl[i] = 0.0f;  // (the features beyond K stay zero)
+        __syncthreads();
+        if (n_chunks > 0) {
+            stage_load(0);
+            stage_store(0);
+        }
+        __syncthreads();
+    }
+
     // B operands of the next step, in flight during the current one: x[row = 32 s + col][2 ks + half]; SPLIT: [16 kb + 8 half + j]
     constexpr int XN = SPLIT ? 8 * KB : KS;
     float xn[2][XN];
@@ -262,8 +315,20 @@ __global__ __launch_bounds__(64 * (kRowsMaxWaves + (rows_wide<A, FOLD, SPLIT>() 
         for (int s = 0; s < 2; ++s) {
             const int64_t sample = s_begin + (int64_t)step * (2 * kTile) + s * kTile + col;
             const bool in = sample < s_end;
-            const int64_t row = (in && g.rows) ? (int64_t)g.rows[sample] : sample;
-            if constexpr (SPLIT) {
+            int64_t row = sample;
+            if constexpr (!STAGED) row = (in && g.rows) ? (int64_t)g.rows[sample] : sample;
+            if constexpr (STAGED) {
+                // (the staged rows: 32 contiguous bytes per lane and block of 16 features)
+                const int local = (step % kChunkSteps) * (2 * kTile) + s * kTile + col;
+                const float *rp = xl + ((step / kChunkSteps) & 1) * (kChunkRows * XS) + local * XS + 8 * half;
+#pragma unroll
+                for (int kb = 0; kb < KB; ++kb) {
+                    const float4 lo4 = *reinterpret_cast<const float4 *>(rp + 16 * kb), hi4 = *reinterpret_cast<const float4 *>(rp + 16 * kb + 4);
+                    xn[s][8 * kb + 0] = lo4.x; xn[s][8 * kb + 1] = lo4.y; xn[s][8 * kb + 2] = lo4.z; xn[s][8 * kb + 3] = lo4.w;
+                    xn[s][8 * kb + 4] = hi4.x; xn[s][8 * kb + 5] = hi4.y; xn[s][8 * kb + 6] = hi4.z; xn[s][8 * kb + 7] = hi4.w;
+                }
+                (void)in; (void)row;
+            } else if constexpr (SPLIT) {
                 const ObsT *rp = obs + row * OBS;
                 constexpr int EV = FOLD ? A * A : K;  // features read from the row as they are
                 float ind = 0.0f;                     // FOLD: the indicator feature (obs_feature)
@@ -320,6 +385,50 @@ __global__ __launch_bounds__(64 * (kRowsMaxWaves + (rows_wide<A, FOLD, SPLIT>() 
             }
         }
     };
+    // SPLIT: the same heads, software-pipelined -- head u + 1's matrix products are in flight while head u's epilogue runs on the VALU
+    auto heads_split = [&](const Split8 (&xs0)[KBs], const Split8 (&xs1)[KBs], float (&out)[NOUT][2], auto pair_) {
+        constexpr bool PAIR = decltype(pair_)::value;
+        f32x16 c[2][2];
+        auto issue = [&](auto u_, f32x16 (&cc)[2]) {
+            constexpr int u = decltype(u_)::value;  // position in this wave's list of hidden tiles
+            constexpr int net_row = (POLICY && u == U - 1) ? 2 : u;  // row of bias_u / w1_u: learner value, target value, learner policy
+            chain_split<KBs, PAIR>(aw[u], bias_u + net_row * W, xs0, xs1, cc[0], cc[1]);
+        };
+        auto finish = [&](auto u_, f32x16 (&cc)[2]) {
+            constexpr int u = decltype(u_)::value;
+#if RNAD_ROWS_ABLATE & 8
+            if constexpr (POLICY && u == U - 1) {
+#pragma unroll
+                for (int a_ = 0; a_ < A; ++a_) { out[NV + a_][0] = cc[0][a_]; if constexpr (PAIR) out[NV + a_][1] = cc[1][a_]; }
+            } else { out[u][0] = cc[0][5]; if constexpr (PAIR) out[u][1] = cc[1][5]; }
+            return;
+#endif
+            if constexpr (POLICY && u == U - 1) {
+                f32x2 acc0[A][2], acc1[A][2];
+#pragma unroll
+                for (int a_ = 0; a_ < A; ++a_) acc0[a_][0] = acc0[a_][1] = acc1[a_][0] = acc1[a_][1] = f32x2{0.f, 0.f};
+                epilogue_policy<A>(cc[0], w1_u + 2 * W, W, acc0);
+                if constexpr (PAIR) epilogue_policy<A>(cc[1], w1_u + 2 * W, W, acc1);
+#pragma unroll
+                for (int a_ = 0; a_ < A; ++a_) {
+                    out[NV + a_][0] = lane_sum(acc0[a_]);
+                    if constexpr (PAIR) out[NV + a_][1] = lane_sum(acc1[a_]);
+                }
+            } else {
+                f32x2 acc0[2] = {f32x2{0.f, 0.f}, f32x2{0.f, 0.f}}, acc1[2] = {f32x2{0.f, 0.f}, f32x2{0.f, 0.f}};
+                epilogue_value(cc[0], w1_u + u * W, acc0);
+                if constexpr (PAIR) epilogue_value(cc[1], w1_u + u * W, acc1);
+                out[u][0] = lane_sum(acc0);
+                if constexpr (PAIR) out[u][1] = lane_sum(acc1);
+            }
+        };
+        issue(std::integral_constant<int, 0>{}, c[0]);
+        if constexpr (U > 1) issue(std::integral_constant<int, 1>{}, c[1]);
+        finish(std::integral_constant<int, 0>{}, c[0]);
+        if constexpr (U > 2) issue(std::integral_constant<int, 2>{}, c[0]);
+        if constexpr (U > 1) finish(std::integral_constant<int, 1>{}, c[1]);
+        if constexpr (U > 2) finish(std::integral_constant<int, 2>{}, c[0]);
+    };
     // SPLIT with more than one block of 16 features (A >= 4; A = 3 without the fold): the two row tiles of a step one after the other --
     // both tiles' split operands beside the split weights do not fit the 168 registers of a 12-wave workgroup
     constexpr bool kSerialTiles = false;  // (r06: tried for the 12-wave workgroup -- it spilled more, not less; WIDE workgroups replaced it)
@@ -330,6 +439,7 @@ __global__ __launch_bounds__(64 * (kRowsMaxWaves + (rows_wide<A, FOLD, SPLIT>() 
         for (int o = 0; o < NOUT; ++o) out[o][0] = out[o][1] = 0.0f;
         float x0[KSr], x1[KSr];
         Split8 xs0[KBs], xs1[KBs];
+        if constexpr (STAGED) fetch(step);  // (from the staged rows in LDS: no prefetch across steps)
         if constexpr (kSerialTiles) {
             float t1[XN];  // the second tile's raw features: kept while the next step's loads go out
 #pragma unroll
@@ -365,12 +475,14 @@ __global__ __launch_bounds__(64 * (kRowsMaxWaves + (rows_wide<A, FOLD, SPLIT>() 
 #pragma unroll
                 for (int ks = 0; ks < KS; ++ks) { x0[ks] = xn[0][ks]; x1[ks] = xn[1][ks]; }
             }
-            if (step + 1 < n_steps) fetch(step + 1);
+            if constexpr (!STAGED)
+                if (step + 1 < n_steps) fetch(step + 1);
 #if RNAD_ROWS_ABLATE & 2
 #pragma unroll
             for (int o = 0; o < NOUT; ++o) out[o][0] = out[o][1] = (SPLIT ? (float)xs0[0].h[0] + (float)xs1[0].l[1] : x0[0] + x1[0]);
 #else
-            heads(x0, x1, xs0, xs1, out, two_, 0);
+            if constexpr (SPLIT) heads_split(xs0, xs1, out, two_);
+            else heads(x0, x1, xs0, xs1, out, two_, 0);
 #endif
         }
         // the two half-waves hold complementary hidden rows of the same 32 + 32 rows: half h keeps row tile h and gets the other
@@ -430,9 +542,11 @@ __global__ __launch_bounds__(64 * (kRowsMaxWaves + (rows_wide<A, FOLD, SPLIT>() 
         }
     };
 
-    if (computes && n_steps > 0) fetch(0);
+    if (!STAGED && computes && n_steps > 0) fetch(0);
     // iteration c: the compute waves are in phase 1 of chunk c, the record waves in phase 2 of chunk c - 1 (the other buffer)
     for (int c = 0; c <= n_chunks; ++c) {
+        if constexpr (STAGED)
+            if (c + 1 < n_chunks) stage_load(c + 1);
         if (computes) {
             if (c < n_chunks) {
                 float *buf = part + (c & 1) * part_buf + (int64_t)wave * NOUT * 64 + lane;
@@ -453,13 +567,17 @@ __global__ __launch_bounds__(64 * (kRowsMaxWaves + (rows_wide<A, FOLD, SPLIT>() 
                 if (step < n_steps) p2_step(step, part + ((c - 1) & 1) * part_buf + (int64_t)wave * T * NOUT * 64 + lane);
             }
         }
+        if constexpr (STAGED)
+            if (c + 1 < n_chunks) stage_store(c + 1);
         __syncthreads();
     }
 }
 
-size_t rows_lds_bytes(int A, int W, int mode) {
+size_t rows_lds_bytes(int A, int W, int mode, int fold = 0, bool split = false) {
     const int T = W / kTile, nout = (mode != 2 ? 2 : 0) + (mode != 1 ? A : 0);
-    return ((size_t)3 * W + (size_t)(2 + A) * W + (size_t)2 * kChunkSteps * T * nout * 64) * sizeof(float);
+    const int K = fold ? ((A * A + 2) & ~1) : 2 * A * A;
+    const size_t staged = split ? (size_t)2 * (kChunkSteps * 2 * kTile) * (16 * ((K + 15) / 16) + 4) : 0;  // (WIDE: two chunks of staged rows)
+    return ((size_t)3 * W + (size_t)(2 + A) * W + (size_t)2 * kChunkSteps * T * nout * 64 + staged) * sizeof(float);
 }
 
 }  // namespace
@@ -489,22 +607,23 @@ static int rows_launch(const rnad_tree_t *tree, int W, int fold, const void *obs
     RNAD_HIP_OK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
     const int64_t n_tiles = (N + kTile - 1) / kTile;
     const int64_t grid = std::max<int64_t>(1, std::min<int64_t>((n_tiles + 1) / 2, cus));  // one persistent workgroup per CU
-    const size_t lds_bytes = rows_lds_bytes(A, W, mode);
     ProfScope prof(PROF_MLP, stream);
     // r06: the split-precision first layer (bf16 matrix rate, see chain_split) for the action counts of BASELINE.json's configurations;
     // RNAD_MLP_SPLIT=0 restores the fp32 MFMA chains (A/B runs, tests)
     const char *split_e = getenv("RNAD_MLP_SPLIT");
     const bool split_env = !(split_e && atoi(split_e) == 0);
     const int K_in = fold ? ((A * A + 2) & ~1) : 2 * A * A;
-    const bool wide_shape = (K_in + 15) / 16 > 1;
-    const bool split = split_env && A >= 2 && A <= 5 && (fold || A <= 4) && (!wide_shape || T >= kChunkSteps);  // (WIDE workgroups: kChunkSteps compute waves write the records)  // (A = 5 without the fold: 4 blocks of 16 features spill)
+    (void)K_in;
+    const bool split = split_env && A >= 2 && A <= 5 && (fold || A <= 3) && T == kRowsMaxWaves &&
+                       rows_lds_bytes(A, W, mode, fold, true) <= 160 * 1024;
+    const size_t lds_bytes = rows_lds_bytes(A, W, mode, fold, split);  // (WIDE workgroups: kChunkSteps compute waves write the records)  // (A = 5 without the fold: 4 blocks of 16 features spill)
 #define RNAD_ROWS_LAUNCH4(T_, F_, M_, S_)                                                                                              \
     do {                                                                                                                               \
         auto kern = k_rows_forward_records<kA, T_, F_, M_, S_>;                                                                        \
         if (lds_bytes > 64 * 1024)                                                                                                     \
             RNAD_HIP_OK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));          \
         constexpr bool wide_ = rows_wide<kA, F_, S_>();                                                                                \
-        RNAD_REQUIRE(!wide_ || T >= kChunkSteps, "rnad_mlp_rows: the split first layer of this shape needs a width of at least %d", kChunkSteps * kTile); \
+        RNAD_REQUIRE(!S_ || T == kRowsMaxWaves, "rnad_mlp_rows: the split first layer needs a width of %d", kRowsMaxWaves * kTile); \
         hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64 * (T + (wide_ ? 0 : kRecWaves))), lds_bytes, stream, N, W, g, (const T_ *)obs, hp); \
     } while (0)
 #define RNAD_ROWS_LAUNCH3(T_, F_, M_)                                                   \
