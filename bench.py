@@ -50,17 +50,27 @@ SIMDS = 256 * 4        # 256 CUs x 4 SIMDs
 # The rooflines of the integer / gather kernels of this path (keys, rollout, learner), all three always in the line:
 #   hbm    algorithmic bytes per launch / launch duration / 8 TB/s
 #   issue  VALU issue-port time / (SIMDs x launch duration x 2.4 GHz).  Issue-port time = SQ_INSTS_VALU (dynamic wave-instructions per
-#          launch, rocprofv3 counter pass: profiles/r05_pmc.json) x the kernel's mean cycles per instruction = sum over instruction
-#          classes of [share of the class in the kernel's loops (tools/isa_hist.py on `hipcc -S`: profiles/r05_isa_mix.json)] x [cycles a
+#          launch, rocprofv3 counter pass: profiles/r0N_pmc.json) x the kernel's mean cycles per instruction = sum over instruction
+#          classes of [share of the class in the kernel's loops (tools/isa_hist.py on `hipcc -S`: profiles/r0N_isa_mix.json)] x [cycles a
 #          SIMD's issue port is busy per wave64 instruction of the class (tools/micro/valu_issue.hip on this hardware:
-#          profiles/r05_valu_issue.json: 1.8 - 1.9 for plain fp32 / integer / move, 2.8 - 3.0 for min / max / med3 / compare / select /
+#          profiles/r0N_valu_issue.json: 1.8 - 1.9 for plain fp32 / integer / move, 2.8 - 3.0 for min / max / med3 / compare / select /
 #          64-bit / fp64 / packed, 3.1 - 3.4 for v_cvt_f64_f32 / v_mad_u64_u32, 5.3 transcendental)]
 #   wait   SQ_WAIT_ANY / SQ_WAVE_CYCLES (share of a resident wave's time parked on s_waitcnt) and SQ_WAIT_INST_ANY / SQ_WAVE_CYCLES
 #          (issue stalls) from the same counter pass
 # (r03 priced the issue roof at 4 cycles per instruction from SQ_ACTIVE_INST_VALU, which counts instructions, not cycles.)
-PMC_FILE = os.path.join(ROOT, "profiles", "r05_pmc.json")
-ISA_MIX_FILE = os.path.join(ROOT, "profiles", "r05_isa_mix.json")
-ISSUE_FILE = os.path.join(ROOT, "profiles", "r05_valu_issue.json")
+def _profile_file(name):
+    """profiles/r06_<name> (tools/round_artifacts.sh r06), else the r05 file of the same name."""
+    for tag in ("r06", "r05"):
+        path = os.path.join(ROOT, "profiles", f"{tag}_{name}")
+        if os.path.exists(path):
+            return path
+    return os.path.join(ROOT, "profiles", f"r06_{name}")
+
+
+PMC_FILE = _profile_file("pmc.json")
+PMC_C4_FILE = _profile_file("pmc_c4.json")  # the same counter passes over the configs[3] step (tools/pmc_config.sh)
+ISA_MIX_FILE = _profile_file("isa_mix.json")
+ISSUE_FILE = _profile_file("valu_issue.json")
 
 
 def _load(path):
@@ -314,7 +324,8 @@ def main():
     # rollout and learner in one launch (RNaD.fuse_rollout_learner, k_bucket_play_learn): booked under the learner's id, nothing under the rollout's
     args.fused_play_learn = (mode_now is True and rnad_hip.PROF_BUCKET_LEARN in prof and rnad_hip.PROF_BUCKET_ROLLOUT not in prof)
     # (the learner on the tree's leaf paths, DESIGN.md section 5.6: rollout and learner are two launches inside the same scope)
-    args.leaf_paths = bool(args.fused_play_learn and rn._fuse_now() and rn._leaf_now(handle, local_batch, T) is not None)
+    with rnad_hip.workspace_owner(rn._workspace_token()):  # (the trainer's own plan: no second LeafPaths on the default one)
+        args.leaf_paths = bool(args.fused_play_learn and rn._fuse_now() and rn._leaf_now(handle, local_batch, T) is not None)
     if args.leaf_paths:
         args.fused_play_learn = False
         prof[rnad_hip.PROF_BUCKET_LEARN]["name"] = "k_bucket_play_count + k_bucket_learn_c<WEIGHTED> (rollout, then the learner on the tree's leaf paths)"
@@ -388,6 +399,28 @@ def main():
         t = torch.tensor([rollout_s, host_s], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         rollout_s, host_s = t.tolist()
+    # ---- N > 1: what the step's one exposed collective costs on THIS node -- the 43 KB gradient bucket all-reduced back to back on the
+    # step's stream, eagerly and replayed from a graph of its own (side_legs' `strong_scaling.predicted` ASSUMES ALLREDUCE_US_ASSUMED for it)
+    allreduce_us = None
+    if world > 1:
+        try:
+            n_params = sum(p_.numel() for p_ in rn.net.parameters())
+            bucket = torch.zeros((n_params,), dtype=torch.float32, device=device)
+            for _ in range(20):
+                dist.all_reduce(bucket)
+            fence()
+            t_a = time.perf_counter()
+            for _ in range(200):
+                dist.all_reduce(bucket)
+            torch.cuda.synchronize()
+            allreduce_us = {"bytes": 4 * n_params, "eager_back_to_back_us": (time.perf_counter() - t_a) / 200 * 1e6, "calls": 200,
+                            "what": "dist.all_reduce of the flat gradient bucket, 200 calls between two fences, max over ranks below"}
+            t = torch.tensor([allreduce_us["eager_back_to_back_us"]], device=device, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            allreduce_us["eager_back_to_back_us"] = float(t.item())
+            del bucket
+        except Exception as err:  # (never the reason a scaling line is lost)
+            allreduce_us = {"error": str(err)[:300]}
 
     # read back NOW: emit() may be called from the watchdog thread while the device queue is stuck
     alive = rn.last_episodes.alive.cpu().numpy()[:T]
@@ -505,7 +538,7 @@ def main():
                 assert dist.get_backend() == "nccl" and dist.get_world_size() == args.gpus, "bench.py --gpus N is one RCCL rank per GPU"
             out["collectives"] = {"backend": dist.get_backend(), "rccl_ranks": dist.get_world_size() if dist.get_backend() == "nccl" else None,
                                   "ranks": dist.get_world_size(), "per_step": "all_reduce(2 x f64 normalisers) + all_reduce(43 KB fp32 gradient bucket)",
-                                  "shard_rows": bool(args.shard_rows)}
+                                  "shard_rows": bool(args.shard_rows), "allreduce_us": allreduce_us}
             if args.shard_rows:
                 A1, nu = A + 1, rn.last_episodes.buckets.plan.n_upper
                 per = (2 * handle.S + world - 1) // world
@@ -624,7 +657,8 @@ def side_legs(make_trainer, tree, args, device):
         del t
         out["strong_scaling"] = {"predicted": {
             "one_gpu_2p22_ms_per_step": ms22, "rank_share_2p19_ms_per_step": ms19, "assumed_exposed_allreduce_us": ALLREDUCE_US_ASSUMED,
-            "speedup_8_gpus": ms22 / (ms19 + ALLREDUCE_US_ASSUMED * 1e-3), "replayed": bool(rep19 and rep22),
+            "assumed_speedup_8_gpus": ms22 / (ms19 + ALLREDUCE_US_ASSUMED * 1e-3), "replayed": bool(rep19 and rep22),
+            "measured_on": "ONE GPU (both legs); nothing here is a multi-GPU measurement",
             "what": "BASELINE.json configs[2] predicted from one GPU: the 2^22 batch on one GPU over (a rank's 2^19 lanes + one exposed 43 KB "
                     "all-reduce); both legs measured here, the collective's latency assumed (no multi-GPU node in the build loop)"}}
     except Exception as err:
@@ -647,11 +681,58 @@ def side_legs(make_trainer, tree, args, device):
             "lazy_rows_visited": int(t.last_rows.count.item()) if t.last_rows is not None else None,
             "staged_policy_rows": int(sum(r.count.item() for r in staged)) if staged else None,
             "table_rows": 2 * c4.handle().S, "tree_generate_and_upload_s": gen_s, "steps": n}}
+        try:
+            out["other_configs"]["c4"]["kernels"] = c4_kernel_table(t, ep, c4, T_ref)
+        except Exception as err:
+            out["other_configs"]["c4"]["kernels"] = {"error": str(err)[:300]}
         del t, c4
     except Exception as err:
         out["other_configs"] = {"c4": {"error": str(err)[:300]}}
     torch.cuda.empty_cache()
     return out
+
+
+def c4_kernel_table(t, ep, tree, T):
+    """Per kernel of the configs[3] step: the counter evidence of tools/pmc_config.sh (profiles/r06_pmc_c4.json: FETCH_SIZE / WRITE_SIZE / SQ / TCP passes
+    over the eagerly enqueued step, durations of those passes) and, for the two gather kernels, their algorithmic bytes -- the same yardsticks
+    as the headline `roofline`, for the configuration where no degeneracy of the tree helps."""
+    import rnad_hip as rh
+
+    pmc = _load(PMC_C4_FILE)
+    kernels, matches = pmc.get("kernels", {}), pmc.get("source_hash") == rh.source_hash()
+    handle, B, A = tree.handle(), ep.batch_size, tree.max_actions
+    stored = rh.stored_state_slots(handle, ep.buckets, T)
+    rb = ep.buckets.plan.rel_bytes
+    visited = int(t.last_rows.count.item()) if t.last_rows is not None else 2 * handle.S
+    algo = {"k_bucket_rollout_items": (4 * B + stored * rb + 12 * B, "lane id 4 read; relative state per stored slot, packed actions 8 + reward 4 per lane written"),
+            "k_bucket_learn_c": (stored * rb + 12 * B + visited * (4 + 4 * A) * 4, "relative state per stored slot, packed actions 8 + reward 4 per lane, "
+                                 "the fast records of the visited rows once each (%d B)" % ((4 + 4 * A) * 4))}
+    table = {}
+    for name, c in kernels.items():
+        us = c.get("duration_us_sq_pass") or c.get("duration_us_fetch_pass")
+        if not us:
+            continue
+        sec = us * 1e-6
+        e = {"avg_launch_us_counter_pass": us, "launches_in_pass": c.get("launches"), "traffic": c.get("traffic_bytes_per_launch")}
+        if c.get("traffic_bytes_per_launch"):
+            e["hbm_frac_on_counter_traffic"] = c["traffic_bytes_per_launch"] / sec / 1e9 / HBM_PEAK_GBS
+        if name in algo:
+            e.update(algorithmic_bytes_per_launch=algo[name][0], bytes_model=algo[name][1], hbm_frac_on_algorithmic_bytes=algo[name][0] / sec / 1e9 / HBM_PEAK_GBS)
+        if c.get("SQ_INSTS_VALU"):
+            e["valu_wave_instructions"] = c["SQ_INSTS_VALU"]
+            e["issue_frac_at_2p4_cycles"] = c["SQ_INSTS_VALU"] * 2.4 / (SIMDS * sec * CLOCK_HZ)
+        if c.get("SQ_WAVE_CYCLES"):
+            e["parked_on_waitcnt"] = c.get("SQ_WAIT_ANY", 0.0) / c["SQ_WAVE_CYCLES"]
+            e["issue_stalled"] = c.get("SQ_WAIT_INST_ANY", 0.0) / c["SQ_WAVE_CYCLES"]
+        if c.get("TCP_TOTAL_CACHE_ACCESSES_sum") and c.get("duration_us_tcp_pass"):
+            e["l1_accesses"] = c["TCP_TOTAL_CACHE_ACCESSES_sum"]
+            e["l1_clock_enabled_frac"] = c.get("TCP_GATE_EN1_sum", 0.0) / (256 * c["duration_us_tcp_pass"] * 1e-6 * CLOCK_HZ)
+        if c.get("SQ_VALU_MFMA_BUSY_CYCLES_mfma_pass") and c.get("duration_us_mfma_pass"):
+            e["matrix_pipe_busy_frac"] = c["SQ_VALU_MFMA_BUSY_CYCLES_mfma_pass"] / (SIMDS * c["duration_us_mfma_pass"] * 1e-6 * CLOCK_HZ)
+        table[name] = e
+    return {"counters_from_this_build": matches, "counters_source": os.path.relpath(PMC_C4_FILE, ROOT),
+            "note": "durations are those of the counter passes (eager launches under rocprofv3); issue_frac prices every VALU wave-instruction at 2.4 cycles "
+                    "(the mean of the measured class costs, profiles/r0N_valu_issue.json)", "per_kernel": table}
 
 
 def _with(trainer_step, **attrs):
@@ -753,8 +834,8 @@ def kernel_report(prof, A, C, args, B, T, live_slots, tree, mode_now):
                           "what": "TCP_TOTAL_CACHE_ACCESSES_sum and TCP_GATE_EN1_sum / (256 CUs x launch duration x 2.4 GHz) of their own counter "
                                   "pass: the vector L1s' access count and busy share -- what holds the gather kernels"}
                 e.update(issue=issue, wait=wait, l1=l1, counters_from_this_build=pmc_matches if c else None,
-                         counters_source="profiles/r05_pmc.json (separate rocprofv3 --pmc passes: FETCH_SIZE | WRITE_SIZE | SQ_*; traffic = 2 x "
-                                         "FETCH_SIZE + WRITE_SIZE), profiles/r05_isa_mix.json, profiles/r05_valu_issue.json" if c else None)
+                         counters_source="%s (separate rocprofv3 --pmc passes: FETCH_SIZE | WRITE_SIZE | SQ_*; traffic = 2 x "
+                                         "FETCH_SIZE + WRITE_SIZE), %s, %s" % tuple(os.path.relpath(f, ROOT) for f in (PMC_FILE, ISA_MIX_FILE, ISSUE_FILE)) if c else None)
         out[p["name"]] = e
     # the fused MLP kernels: flops the matrix cores execute per sample (first layer of a head: 2 K W; relu + second layer run on the
     # VALU; backward: recompute of both heads + dW0 over the augmented input padded to its MFMA tiles)
@@ -763,7 +844,7 @@ def kernel_report(prof, A, C, args, B, T, live_slots, tree, mode_now):
     uniq = getattr(args, "unique_rows", 0)  # (0: every row evaluated)
     bwd_samples = (visited or uniq or S2) if mode_now is True else (live_slots if not uniform else slots)
     def mlp_counters(entry, name):
-        """Counter evidence of an MLP kernel (profiles/r05_pmc.json): HBM traffic, the matrix pipe's busy share of the launch's SIMD cycles,
+        """Counter evidence of an MLP kernel (profiles/r0N_pmc.json): HBM traffic, the matrix pipe's busy share of the launch's SIMD cycles,
         VALU wave-instructions, wait shares."""
         c = pmc.get(name, {})
         if not c:
@@ -816,7 +897,10 @@ def roofline_of(k):
         iss, wt = (k.get("issue") or {}).get("frac"), (k.get("wait") or {}).get("parked_on_waitcnt")
         binds = ("dependent-gather latency and the vector L1's access rate, not HBM: VALU issue %s of its roof, %s of a resident wave's time "
                  "parked on s_waitcnt" % ("%.2f" % iss if iss else "n/a", "%.2f" % wt if wt else "n/a"))
-    r = {"kernel": k["name"], "bound": k.get("bound"), "binds": binds, "achieved": k.get("achieved"), "peak": k.get("peak"), "unit": k.get("unit"),
+    bound = k.get("bound")
+    if binds is not None:
+        bound = "l1/latency"  # what holds the kernel; `frac` stays its algorithmic bytes over the HBM peak, as the contract prices it
+    r = {"kernel": k["name"], "bound": bound, "priced_against": k.get("bound"), "binds": binds, "achieved": k.get("achieved"), "peak": k.get("peak"), "unit": k.get("unit"),
          "frac": k.get("frac"), "traffic": k.get("traffic"), "avg_launch_us": k["avg_launch_us"], "launches_per_step": k["launches_per_step"],
          "bytes_per_launch": k.get("algorithmic_bytes_per_launch"), "bytes_model": k.get("bytes_model"),
          "share_of_step_us": k["us_per_step"],
@@ -848,7 +932,7 @@ def k1_report(k1, A, args, B):
     traffic = k1_traffic(A, args)
     if traffic:
         out.update(counter_bytes_per_launch=traffic, frac_of_hbm_peak_from_counter_bytes=traffic / (us * 1e-6) / 1e9 / HBM_PEAK_GBS,
-                   note="counter bytes = 2 x FETCH_SIZE + WRITE_SIZE of a separate rocprofv3 --pmc pass (profiles/r05_pmc.json) over launches that "
+                   note="counter bytes = 2 x FETCH_SIZE + WRITE_SIZE of a separate rocprofv3 --pmc pass (profiles/r0N_pmc.json) over launches that "
                         "each write their own slice of a [T, B, 2, A, A] buffer (906 MB: beyond the Infinity Cache); the SURVEY model over-counts "
                         "(node rows are L2 hits, the mask travels as 1 byte), so the fraction is taken from the counters")
     return out
@@ -875,7 +959,7 @@ def cpu_baseline(tree, args, T):
                 depth_bound=tree.depth_bound)
     cores = CPU_THREADS
     torch.set_num_threads(cores)
-    ct = CpuTrainer(arrs, width=args.width)
+    ct = CpuTrainer(arrs, width=args.width, chunk_rows=1 << 14)  # (r06: the MLP in cache-sized row chunks -- 4.6x faster updates than whole-batch matrices)
     lanes = 1 << args.cpu_lanes_log2
     ct.step(min(lanes, 4096), seed=0)  # warm-up (thread pools, page faults)
     t0 = time.perf_counter()
@@ -892,7 +976,7 @@ def cpu_baseline(tree, args, T):
         # (one step of the full 2^batch-log2 batch at this rate: beyond the minute the default run may spend here, hence the sample)
         "full_batch_step_estimate_s": full,
         "sample": f"{n} full step(s) (rollout + update) of 2^{args.cpu_lanes_log2} episodes x T={Tc} on the same tree; "
-                  f"C oracle (OpenMP) + PyTorch-CPU MLP, {cores} threads",
+                  f"C oracle (OpenMP) + PyTorch-CPU MLP in 16 384-row chunks, {cores} threads",
         "rollout_env_steps_per_sec": lanes * Tc * n / roll, "updates_per_sec_at_sample_batch": n / dt,
         "host": {"nproc": os.cpu_count(), "torch_num_threads": torch.get_num_threads()},
     }

@@ -524,6 +524,13 @@ typedef struct rnad_leaf_paths {
     const int32_t *n_items;    /* device int32: their number */
     int32_t max_items;
     const int32_t *col_of;     /* [S * A * A * C]: column of transition ((s * A + a0) * A + a1) * C + c, -1 if it is not terminal */
+    /* r06, optional (NULL / 0: every bucket's lanes are counted by the learner's work items): a bucket that holds at least crowded_lanes
+     * lanes of the batch (and at most 1024 columns) is counted by the ROLLOUT's work items instead -- a histogram over the bucket's columns
+     * in LDS, its non-zero bins added to col_count -- so that a sharpened policy, whose lanes pile up in few buckets and on few
+     * trajectories, does not make every learner work item of such a bucket scan all of its lanes. */
+    int32_t *col_count;          /* device int32 [n_cols], zero before the first step; the learner leaves it zero */
+    const int32_t *bucket_col0;  /* device int32 [buckets + 1]: first column of every bucket (columns are sorted by bucket) */
+    int32_t crowded_lanes;
 } rnad_leaf_paths_t;
 /* relative states of the columns from their dense states (int32 [T1, n_cols], bucket order, 0 once the episode is over) under the cut
  * rnad_bucket_plan chooses for batches of plan_B lanes; mismatch (device int32, caller-zeroed): set if a column does not lie in its

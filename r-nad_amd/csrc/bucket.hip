@@ -1467,7 +1467,25 @@ struct Distinct {  // (passed by value: a pointer to it would keep the struct in
     int keys = 0;               // counters; count[keys] stays 1: the weight of a lane listed on its own (a key outside the table: not expected)
 };
 
-template <int A, typename REL, int L, bool DISTINCT = false>
+// r06, leaf paths under a sharp policy: LeafCount -- a bucket that holds at least `crowded_lanes` lanes (and at most kLeafHist columns) is
+// counted HERE, by the work items that play its lanes (a histogram over the bucket's columns in LDS, its non-zero bins added to col_count
+// with one global atomic each: lanes that pile up on few trajectories cost a handful of atomics per item), instead of by every learner work
+// item of the bucket scanning all of the bucket's lanes (k_bucket_learn_c<WEIGHTED>: items x lanes of the bucket -- what made the leaf-path
+// learner lose to the per-lane one once a policy had sharpened).  Both kernels take the decision from the sort's
+// bucket totals, so they agree.
+constexpr int kLeafHist = 1024;
+struct LeafCount {
+    int32_t *col_count = nullptr;          // [n_cols] lanes per column, of crowded buckets only; the learner clears what it reads
+    const int32_t *bucket_col0 = nullptr;  // [n_buckets + 1] first column of a bucket
+    const int32_t *lane_total = nullptr;   // [n_buckets] the sort's totals
+    int32_t crowded_lanes = 0;
+};
+__device__ __forceinline__ bool leaf_crowded(const LeafCount &lc, int bucket) {
+    return lc.col_count != nullptr && lc.crowded_lanes > 0 && lc.lane_total[bucket] >= lc.crowded_lanes &&
+           lc.bucket_col0[bucket + 1] - lc.bucket_col0[bucket] <= kLeafHist;
+}
+
+template <int A, typename REL, int L, bool DISTINCT = false, bool HIST = false>
 __device__ __forceinline__ void rollout_items_body(const Trans *__restrict__ trans, int C, int64_t S, int64_t B, int T_cap,
                                                                    const float *__restrict__ policy_tab, int64_t tab_stride, int vec4,
                                                                    uint64_t seed, const rnad_step_params_t *__restrict__ sp, int64_t lane0,
@@ -1482,8 +1500,9 @@ __device__ __forceinline__ void rollout_items_body(const Trans *__restrict__ tra
                                                                    double *__restrict__ norm_rep = nullptr, Hand *hand = nullptr,
                                                                    const Distinct distinct = Distinct{},
                                                                    const int32_t *__restrict__ col_of = nullptr,
-                                                                   int32_t *__restrict__ leaf_col = nullptr) {
+                                                                   int32_t *__restrict__ leaf_col = nullptr, const LeafCount lc = LeafCount{}) {
     constexpr int NT = kThreads / L, NW = NT / 64;
+    __shared__ int32_t leaf_hist[HIST ? kLeafHist : 1];
     static_assert(NT >= 64 && NT > kCompactSteps, "a wave at least, and a thread per alive counter");
     __shared__ int32_t cnt[NW][kMaxSteps + 1];
     // a row per WORKGROUP (the sum over the rows does not care which item it held) -- or, norm_rep given (k_bucket_play_learn: no launch
@@ -1505,6 +1524,17 @@ __device__ __forceinline__ void rollout_items_body(const Trans *__restrict__ tra
     const uint32_t B32 = (uint32_t)B;
     if ((threadIdx.x & 63) == 0)
         for (int t = 0; t <= T_cap; ++t) cnt[wave][t] = 0;
+    bool count_here = false;
+    int32_t col0 = 0, n_bins = 0;
+    if constexpr (HIST) {
+        count_here = leaf_crowded(lc, item.bucket);
+        if (count_here) {
+            col0 = lc.bucket_col0[item.bucket];
+            n_bins = lc.bucket_col0[item.bucket + 1] - col0;
+            for (int i = threadIdx.x; i < n_bins; i += NT) leaf_hist[i] = 0;
+            __syncthreads();
+        }
+    }
     for (int base = 0; base < item.count; base += kThreads) {  // (one pass: an item holds <= chunk = kThreads lanes unless RNAD_BUCKET_CHUNK says otherwise)
         bool active[L];
         uint32_t j[L];
@@ -1634,7 +1664,12 @@ __device__ __forceinline__ void rollout_items_body(const Trans *__restrict__ tra
                             // leaf paths (rnad_leaf_paths_t): the transition a lane leaves the tree by fixes its whole trajectory (a state has one
                             // parent entry) -- the column of that trajectory, per lane in bucket order; the learner's workgroups count the lanes
                             // of their columns in LDS (a global counter per column took a device-scope atomic per lane: 15 us per 2^20 lanes)
-                            leaf_col[j[l]] = col_of[(((uint32_t)state[l] * A + a0[l]) * A + a1[l]) * C + outcome];
+                        {
+                            const int32_t col = col_of[(((uint32_t)state[l] * A + a0[l]) * A + a1[l]) * C + outcome];
+                            leaf_col[j[l]] = col;
+                            if constexpr (HIST)
+                                if (count_here) atomicAdd(&leaf_hist[col - col0], 1);
+                        }
 
                     }
                     state[l] = next;
@@ -1668,6 +1703,14 @@ __device__ __forceinline__ void rollout_items_body(const Trans *__restrict__ tra
         if (hand) *hand = Hand{acts[0], relq, reward_final[0], active[0] ? (int)rel_of<REL>(state[0], lo) : 0};
     }
     __syncthreads();
+    if constexpr (HIST) {
+        if (count_here) {
+            for (int i = threadIdx.x; i < n_bins; i += NT) {
+                const int32_t n = leaf_hist[i];
+                if (n != 0) atomicAdd(lc.col_count + col0 + i, n);
+            }
+        }
+    }
     if ((int)threadIdx.x <= T_cap) {
         int32_t sum = 0;
 #pragma unroll
@@ -1980,7 +2023,7 @@ __device__ __forceinline__ void learn_epilogue(unsigned long long *__restrict__ 
         for (int r = threadIdx.x; r < end * (A + 1); r += kThreads) {
             const int row = r / (A + 1), a = r % (A + 1);  // (constant divisor)
             const unsigned long long x = tab[kPathWords + (P * sub_rows + row) * TS + a];
-            if (x != 0ull) {
+            if (x != 0ull && !(RNAD_ABLATE & 32)) {  // (32: timing experiment without the flush of the table)
                 if (item.single) dst0[r] = x;
                 else atomicAdd(dst0 + r, x);
             }
@@ -2157,7 +2200,7 @@ __device__ __forceinline__ void learn_c_body(int T, int64_t B, int64_t S, int su
                                                              double *__restrict__ norm_out, const Hand *hand = nullptr,
                                                              const Distinct distinct = Distinct{}, const int32_t *__restrict__ leaf_col = nullptr,
                                                              const int32_t *__restrict__ lane_start = nullptr,
-                                                             const int32_t *__restrict__ lane_total = nullptr) {
+                                                             const int32_t *__restrict__ lane_total = nullptr, const LeafCount lc = LeafCount{}) {
     extern __shared__ unsigned long long tab[];
     constexpr int PS = (A + 1) | 1, TS = kTabStride<A>, FS = kFastStride<A>, RS = kRowStride<A>;
     const int kPathWords = path_words;
@@ -2192,12 +2235,21 @@ __device__ __forceinline__ void learn_c_body(int T, int64_t B, int64_t S, int su
     constexpr bool by_trajectory = DISTINCT || WEIGHTED;
     __shared__ int32_t w_lds[WEIGHTED ? kThreads : 1];
     if (WEIGHTED) {
-        w_lds[threadIdx.x] = 0;
-        __syncthreads();
-        const int32_t l0 = lane_start[item.bucket], ln = lane_total[item.bucket];
-        for (int i = threadIdx.x; i < ln; i += kThreads) {
-            const uint32_t c = (uint32_t)(leaf_col[l0 + i] - item.begin);
-            if (c < (uint32_t)item.count) atomicAdd(&w_lds[c], 1);
+        if (leaf_crowded(lc, item.bucket)) {  // (the rollout's work items counted this bucket's lanes per column: LeafCount)
+            int32_t w = 0;
+            if ((int)threadIdx.x < item.count) {
+                w = lc.col_count[item.begin + threadIdx.x];
+                if (w != 0) lc.col_count[item.begin + threadIdx.x] = 0;  // zero again for the next step
+            }
+            w_lds[threadIdx.x] = w;
+        } else {
+            w_lds[threadIdx.x] = 0;
+            __syncthreads();
+            const int32_t l0 = lane_start[item.bucket], ln = lane_total[item.bucket];
+            for (int i = threadIdx.x; i < ln; i += kThreads) {
+                const uint32_t c = (uint32_t)(leaf_col[l0 + i] - item.begin);
+                if (c < (uint32_t)item.count) atomicAdd(&w_lds[c], 1);
+            }
         }
         __syncthreads();
     }
@@ -2359,10 +2411,11 @@ __global__ __launch_bounds__(kThreads) RNAD_LEARN_ATTR void k_bucket_learn_c(int
                                                              int32_t *__restrict__ overflow, const int32_t *__restrict__ alive_part,
                                                              int alive_blocks, int T1, int32_t *__restrict__ alive,
                                                              double *__restrict__ norm_out, const int32_t *__restrict__ leaf_col,
-                                                             const int32_t *__restrict__ lane_start, const int32_t *__restrict__ lane_total) {
+                                                             const int32_t *__restrict__ lane_start, const int32_t *__restrict__ lane_total,
+                                                             LeafCount lc) {
     learn_c_body<A, REL, LOSSES, false, WEIGHTED>(T, B, S, sub_rows, path_words, n_groups, up_stride, items, n_items, bucket_of, bucket_lo, bucket_path,
                                                   path_states, path_stride, states, rec_, acts_, reward_, logit_, hp, fx, acc, rep, losses_raw, overflow,
-                                                  alive_part, alive_blocks, T1, alive, norm_out, nullptr, Distinct{}, leaf_col, lane_start, lane_total);
+                                                  alive_part, alive_blocks, T1, alive, norm_out, nullptr, Distinct{}, leaf_col, lane_start, lane_total, lc);
 }
 
 // The rollout half of the leaf-path step (rnad_leaf_paths_t): k_bucket_rollout_items with the alive counts and normalisers left in the
@@ -2379,10 +2432,10 @@ __global__ __launch_bounds__(kThreads) void k_bucket_play_count(const Trans *__r
                                                                 int path_stride, int n_groups, REL *__restrict__ states,
                                                                 int32_t *__restrict__ alive_rep, double *__restrict__ norm_rep,
                                                                 unsigned long long *__restrict__ acts_out, float *__restrict__ reward_out,
-                                                                const int32_t *__restrict__ col_of, int32_t *__restrict__ leaf_col) {
-    rollout_items_body<A, REL, 1>(trans, C, S, B, T_cap, policy_tab, tab_stride, vec4, seed, sp, lane0, lane_ids, decisions, items, n_items,
+                                                                const int32_t *__restrict__ col_of, int32_t *__restrict__ leaf_col, LeafCount lc) {
+    rollout_items_body<A, REL, 1, false, true>(trans, C, S, B, T_cap, policy_tab, tab_stride, vec4, seed, sp, lane0, lane_ids, decisions, items, n_items,
                                   bucket_path, bucket_lo, path_states, path_stride, n_groups, states, alive_rep, acts_out, reward_out, nullptr,
-                                  norm_rep, nullptr, Distinct{}, col_of, leaf_col);
+                                  norm_rep, nullptr, Distinct{}, col_of, leaf_col, lc);
 }
 
 // Rollout and learner of a work item in ONE launch (r04): the workgroup that played the item's lanes runs their update right away --
@@ -3075,7 +3128,7 @@ int rollout_bucketed_impl(const rnad_tree_t *tree, const RolloutBuffers &tr, boo
                            (const unsigned long long *)s.decisions, (const Item *)items, (const int32_t *)n_items,                     \
                            (const int32_t *)p.cut->bucket_path, (const int32_t *)p.cut->bucket_lo, (const int32_t *)p.cut->path_states, \
                            std::max(p.cut->max_path, 1), p.cut->n_groups, (REL *)tr.indices, cr.alive_rep, cr.norm_rep, tr.acts,       \
-                           tr.final_reward, lf.col_of, s.keys);                                                                        \
+                           tr.final_reward, lf.col_of, s.keys, lcount);                                                                \
         auto kern = k_bucket_learn_c<kA, REL, false, true>;                                                                           \
         if (p.lds > 48 * 1024) RNAD_HIP_OK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, p.lds)); \
         hipLaunchKernelGGL(kern, dim3((unsigned)lf.max_items + 7), dim3(kThreads), (size_t)p.lds, stream, tr.T_cap, lf.n_cols, S, p.cut->rows,  \
@@ -3084,8 +3137,11 @@ int rollout_bucketed_impl(const rnad_tree_t *tree, const RolloutBuffers &tr, boo
                            (const int32_t *)p.cut->path_states, std::max(p.cut->max_path, 1), (const REL *)lf.states, fused->fast,     \
                            (const unsigned long long *)lf.acts, lf.final_reward, (const float *)nullptr, *fused->hp, fx, acc, rep,     \
                            (double *)nullptr, overflow, (const int32_t *)nullptr, 0, tr.T_cap + 1, (int32_t *)nullptr, (double *)nullptr, \
-                           (const int32_t *)s.keys, (const int32_t *)s.bucket_start, (const int32_t *)s.totals);                       \
+                           (const int32_t *)s.keys, (const int32_t *)s.bucket_start, (const int32_t *)s.totals, lcount);               \
     } while (0)
+                    LeafCount lcount;
+                    if (lf.col_count && lf.bucket_col0 && lf.crowded_lanes > 0)
+                        lcount = LeafCount{lf.col_count, lf.bucket_col0, (const int32_t *)s.totals, lf.crowded_lanes};
                     RNAD_DISPATCH_REL(p, RNAD_DISPATCH_A(tree->A, RNAD_PLAY_COUNT()));
 #undef RNAD_PLAY_COUNT
                 } else
@@ -3443,7 +3499,7 @@ int learn_bucketed_impl(const rnad_tree_t *tree, int T, int64_t B, const void *i
                            (const int32_t *)p.cut->bucket_lo, (const int32_t *)p.cut->bucket_path, (const int32_t *)p.cut->path_states, \
                            std::max(p.cut->max_path, 1), (const REL *)indices, fast, acts, final_reward, records, *hp, fx, acc, rep,  \
                            losses ? losses_raw : (double *)nullptr, overflow, alive_part, (int)alive_rows(tree, B, p, true), T1,      \
-                           alive_out, norm_out, (const int32_t *)nullptr, (const int32_t *)nullptr, (const int32_t *)nullptr);        \
+                           alive_out, norm_out, (const int32_t *)nullptr, (const int32_t *)nullptr, (const int32_t *)nullptr, LeafCount{}); \
     } while (0)
     {
         ProfScope one(PROF_BUCKET_LEARN, stream);

@@ -501,13 +501,13 @@ class RNaD:
         counted on it) instead of once per lane -- the same per-row sums bit for bit (integer sums), as two launches.  Its cost is the
         tree's, not the batch's.  Automatic when every episode has the tree's full length (so that every lane leaves the tree inside the
         window), the rank plays at least two lanes per leaf path (measured on configs[1]'s 531 441 paths, uniform policies: a tie with the
-        one-launch rollout + learner at 2^20 lanes, 250 -> 220 us per step at 2^21, 403 -> 311 at 2^22) and no bucket is CROWDED: a
-        work item of the leaf learner counts the lanes of its bucket, so a bucket that a sharpened policy fills with a large share of the
-        batch makes its three workgroups read that share each, and count it with LDS atomics on a few addresses (a x40 policy head at 2^20
-        lanes, the largest bucket at ten times its even share: 0.241 ms per step against 0.195 per lane and 0.163 on the distinct
-        trajectories of a work item).  _leaf_watch looks at the batch's bucket sizes every LEAF_CHECK_EVERY steps and switches the leaf
-        learner off for good once a bucket holds more than LEAF_CROWDED times its even share: the per-lane learner -- from DISTINCT_AFTER
-        updates on, the distinct trajectories of a work item -- takes over (a new graph is captured)."""
+        one-launch rollout + learner at 2^20 lanes, 250 -> 220 us per step at 2^21, 403 -> 311 at 2^22).  r06: a CROWDED bucket no
+        longer ends it.  A work item of the leaf learner used to count all lanes of its bucket, so a bucket that a sharpened policy fills
+        with ten times its even share made the step 2 - 2.5 times slower (x40 policy head: 0.269 / 0.439 / 0.769 ms at 2^20 / 2^21 / 2^22
+        lanes) and RNaD._leaf_watch switched the leaf learner off for good; now the rollout's work items count such a bucket themselves
+        (rnad_leaf_paths_t.col_count: a histogram in LDS, a global atomic per non-zero bin) and the same steps take 0.160 / 0.209 / 0.298 ms,
+        within 7 % of the learner on the distinct trajectories of a work item (0.147 / 0.196 / 0.289), with unchanged times under uniform
+        policies (profiles/r06_leaf_sharp.md)."""
         want = getattr(self, "leaf_paths", None)
         env = os.environ.get("RNAD_LEAF_PATHS")
         if env is not None:
@@ -519,35 +519,38 @@ class RNaD:
             if n is None:
                 live = (self.tree.index_tensor == 0) & (self.tree.chance_tensor > 0)
                 n = handle._n_terminal = int(live[1:].sum().item())
-            if 2 * n > local_batch or self.__dict__.get("_leaf_crowded", False):
+            if 2 * n > local_batch:
                 return None
         return rnad_hip.leaf_paths(handle, local_batch, self.tree.index_tensor, self.tree.chance_tensor, self.tree.value_tensor)
 
     LEAF_CHECK_EVERY = 1024  # steps between two looks at the bucket sizes (a sync and a small device -> host copy: ~0.3 ms)
-    LEAF_CROWDED = 4.0       # a bucket with more than this many times its even share of the lanes ends the automatic leaf learner
-    DISTINCT_CROWDED = 4.0   # ... and turns the automatic learner on distinct trajectories on before DISTINCT_AFTER
+    LEAF_CROWDED = 4.0       # (r05: ended the automatic leaf learner; r06: rnad_hip.LEAF_CROWDED_SHARE -- from this share on the rollout counts a bucket's lanes)
+    DISTINCT_CROWDED = 4.0   # a bucket with more than this many times its even share turns the automatic learner on distinct trajectories on before DISTINCT_AFTER
     # (profiles/r05_leaf.md, 2^21 lanes: at a share of 3.4 the leaf learner is still ahead of the per-lane one, 0.233 against 0.262 ms per
     # step, at 6.1 behind it, 0.275 against 0.266; the distinct trajectories of a work item take 0.259 / 0.239 / 0.223 / 0.214 at shares
     # of 2.06 (fresh nets) / 3.1 / 3.4 / 6.1.  With the reference's lr = 5e-5 the share drifts between 2 and 3.5 over the first 6 000
     # updates -- tools/micro/share_probe.py --, so neither switch falls into a benchmark of fresh nets)
 
     def _leaf_watch(self):
-        """The automatic learners' look at the batch (see _leaf_now, _distinct_now): every LEAF_CHECK_EVERY steps the work list of the last
-        batch is read back -- lanes per bucket -- and compared with the even share: above LEAF_CROWDED the leaf-path learner goes, above
-        DISTINCT_CROWDED the learner on the distinct trajectories of a work item comes (before DISTINCT_AFTER).  Sticky: policies sharpen,
-        they do not flatten again."""
-        leaf_settled = getattr(self, "leaf_paths", None) is not None or self.__dict__.get("_leaf_crowded", False)
-        distinct_settled = (getattr(self, "distinct_trajectories", None) is not None or self.__dict__.get("_distinct_crowded", False)
-                            or self.total_steps >= self.DISTINCT_AFTER)
-        if leaf_settled and distinct_settled:
+        """The automatic learner's look at the batch (see _distinct_now): every LEAF_CHECK_EVERY steps the work list of the last batch is
+        read back -- lanes per bucket -- and compared with the even share: above DISTINCT_CROWDED the learner on the distinct trajectories
+        of a work item comes on before DISTINCT_AFTER (sticky: policies sharpen).  A check that falls on a step whose batch cannot be read
+        (a logging step, another rollout) is retried on the next step that can.  (r05 also ended the leaf-path learner here, for good; r06:
+        the rollout counts crowded buckets itself, _leaf_now, and the leaf learner stays.)"""
+        if (getattr(self, "distinct_trajectories", None) is not None or self.__dict__.get("_distinct_crowded", False)
+                or self.total_steps >= self.DISTINCT_AFTER):
             return
-        if self.total_steps % self.LEAF_CHECK_EVERY != self.LEAF_CHECK_EVERY - 1:
+        if self.total_steps % self.LEAF_CHECK_EVERY == self.LEAF_CHECK_EVERY - 1:
+            self._watch_due = True
+        if not self.__dict__.get("_watch_due", False):
             return
         ep = self.__dict__.get("last_episodes")
         buckets = getattr(ep, "buckets", None) if ep is not None else None
-        if buckets is None or getattr(ep, "_compact", None) is None or not self.tree.handle().uniform_length:
-            # (not the compact bucketed step: neither learner is what runs; or a ragged tree, whose buckets differ in size by construction:
-            # "times the even share" says nothing there -- the leaf learner never runs on it and the distinct one keeps its DISTINCT_AFTER)
+        if buckets is None or getattr(ep, "_compact", None) is None:
+            return  # (not the compact bucketed step: retried on the next one)
+        self._watch_due = False
+        if not self.tree.handle().uniform_length:
+            # (a ragged tree, whose buckets differ in size by construction: "times the even share" says nothing there)
             return
         n = int(buckets.n_items.item())
         items = buckets.items[:n].cpu()  # (a few thousand work items: counted on the host -- no kernel of torch's that the step has not loaded yet)
@@ -558,10 +561,7 @@ class RNaD:
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             share = float(t.item())
         self._leaf_share = share
-        if share > self.LEAF_CROWDED and not self.__dict__.get("_leaf_crowded", False):
-            logging.info("leaf-path learner off: a bucket holds %.1f times its even share of the lanes", share)
-            self._leaf_crowded = True
-        if share > self.DISTINCT_CROWDED and not self.__dict__.get("_distinct_crowded", False):
+        if share > self.DISTINCT_CROWDED:
             logging.info("learner on distinct trajectories on: a bucket holds %.1f times its even share of the lanes", share)
             self._distinct_crowded = True
 
@@ -1201,7 +1201,7 @@ class RNaD:
                 self.gamma_averaging, getattr(self, "obs_half", False), getattr(self, "store_actor_values", False), getattr(self, "fused_optimizer", True),
                 getattr(self, "compact_trajectory", True), getattr(self, "lazy_rows", None), rnad_hip.plan_knobs(), os.environ.get("RNAD_LEAF_CHUNK"),
                 getattr(self, "fold_legal", True), self._fuse_now(), self._fuse_now() and self._distinct_now(), getattr(self, "analytic_norm", True), os.environ.get("RNAD_FUSED_DISTINCT"), os.environ.get("RNAD_FUSED_CHUNK"),
-                getattr(self, "leaf_paths", None), os.environ.get("RNAD_LEAF_PATHS"), self.__dict__.get("_leaf_crowded", False))
+                getattr(self, "leaf_paths", None), os.environ.get("RNAD_LEAF_PATHS"), os.environ.get("RNAD_LEAF_CROWDED_LANES"))
 
     def _graph_step(self, buffer, alpha):
         g = getattr(self, "_graph", None)

@@ -984,7 +984,10 @@ class _LeafPathsC(C.Structure):
 
     _fields_ = [("n_cols", C.c_int64), ("rows", C.c_int32), ("T_cap", C.c_int32), ("states", C.c_void_p), ("acts", C.c_void_p),
                 ("final_reward", C.c_void_p), ("items", C.c_void_p), ("n_items", C.c_void_p), ("max_items", C.c_int32),
-                ("col_of", C.c_void_p)]
+                ("col_of", C.c_void_p), ("col_count", C.c_void_p), ("bucket_col0", C.c_void_p), ("crowded_lanes", C.c_int32)]
+
+
+LEAF_CROWDED_SHARE = 4.0  # a bucket with this many times its even share of the batch's lanes is counted by the rollout's work items (r06)
 
 
 class LeafPaths:
@@ -1021,8 +1024,17 @@ class LeafPaths:
         self.rows, self.rel_bytes = rows.value, rel.value
         self.states = states8
         self.indices = indices  # (tests: the dense states of the columns)
+        # r06: who counts a bucket's lanes per column (rnad_leaf_paths_t.col_count): the learner's work items, each scanning the bucket's lanes
+        # -- or, for a bucket that holds LEAF_CROWDED_SHARE times its even share of the batch (a sharpened policy), the rollout's work items
+        # with a histogram in LDS.  RNAD_LEAF_CROWDED_LANES forces the threshold (1: every bucket, 0: none -- tests).
+        plan = bucket_plan(tree, plan_B)
+        self.col_count = torch.zeros((n,), dtype=I32, device=dev)
+        self.bucket_col0 = torch.searchsorted(cols["bucket"].long().contiguous(), torch.arange(plan.n_buckets + 1, device=dev)).to(I32).contiguous()
+        forced = os.environ.get("RNAD_LEAF_CROWDED_LANES")
+        self.crowded_lanes = int(forced) if forced is not None else max(2048, int(LEAF_CROWDED_SHARE * plan_B / max(n_groups, 1)))
         self.c = _LeafPathsC(n, self.rows, T_cap, states8.data_ptr(), self.acts.data_ptr(), self.final_reward.data_ptr(), self.items.data_ptr(),
-                             self.n_items.data_ptr(), self.max_items, self.col_of.data_ptr())
+                             self.n_items.data_ptr(), self.max_items, self.col_of.data_ptr(), self.col_count.data_ptr(),
+                             self.bucket_col0.data_ptr(), self.crowded_lanes)
 
 
 def leaf_columns(index, chance, value, bucket_of, max_depth):
@@ -1102,7 +1114,7 @@ def leaf_paths(tree, plan_B, index, chance, value):
     if plan is None:
         return None
     cache = plan.__dict__.setdefault("leaf_by_chunk", {})
-    key = os.environ.get("RNAD_LEAF_CHUNK")  # (tuning knob: columns per work item -- part of what a LeafPaths is)
+    key = (os.environ.get("RNAD_LEAF_CHUNK"), os.environ.get("RNAD_LEAF_CROWDED_LANES"))  # (tuning knobs that are part of what a LeafPaths is)
     got = cache.get(key)
     if got is None:
         got = cache[key] = LeafPaths(tree, plan_B, index, chance, value)

@@ -129,9 +129,6 @@ def test_training_on_leaf_paths_is_training_per_lane(graph):
     assert on_paths._leaf_now(h, 1 << 14, 2 * h.max_depth) is not None and per_lane._leaf_now(h, 1 << 14, 2 * h.max_depth) is None
     assert auto._leaf_now(h, 1 << 14, 2 * h.max_depth) is not None, "6 561 leaf paths for 16 384 lanes (two lanes per path at least): automatic"
     assert auto._leaf_now(h, 1 << 13, 2 * h.max_depth) is None
-    assert not auto.__dict__.get("_leaf_crowded", False)
-    auto._leaf_crowded = True
-    assert auto._leaf_now(h, 1 << 14, 2 * h.max_depth) is None, "a crowded bucket ends the automatic leaf learner"
     if graph:
         assert on_paths._graph["graph"] is not None and not on_paths._graph["failed"]
     for (k, a), b, c in zip(on_paths.net.named_parameters(), per_lane.net.parameters(), auto.net.parameters()):
@@ -143,9 +140,10 @@ def test_training_on_leaf_paths_is_training_per_lane(graph):
     assert probe._leaf_now(ragged.handle(), 4096, 2 * ragged.handle().max_depth) is None
 
 
-def test_a_crowded_bucket_switches_the_leaf_learner_off(monkeypatch):
-    """The guard of the automatic mode: with a sharp actor lanes pile up in one bucket, whose lanes every leaf work item of that bucket
-    has to count -- RNaD._leaf_watch sees it in the work list and goes back to the per-lane learner (a new graph), training on unchanged."""
+def test_a_crowded_bucket_is_counted_by_the_rollout(monkeypatch):
+    """With a sharp actor lanes pile up in one bucket.  r05: every leaf work item of that bucket counted all of its lanes, and RNaD._leaf_watch
+    switched the leaf learner off for good.  r06: the rollout's work items count such a bucket (rnad_leaf_paths_t.col_count, forced here for
+    EVERY bucket and for none) -- the leaf learner stays on, and training is the per-lane learner's bit for bit either way."""
     from environment.episode import Buffer
     from learn.rnad import RNaD
     from test_hip_bucket import TREES, _native_tree
@@ -178,10 +176,19 @@ def test_a_crowded_bucket_switches_the_leaf_learner_off(monkeypatch):
         return rn, used
 
     flat, used_flat = run(False)
-    assert all(used_flat) and not flat.__dict__.get("_leaf_crowded", False) and flat._leaf_share < RNaD.LEAF_CROWDED
+    assert all(used_flat) and flat._leaf_share < RNaD.DISTINCT_CROWDED
+    monkeypatch.setenv("RNAD_LEAF_CROWDED_LANES", "1")  # every bucket counted by the rollout's work items
     sharp, used = run(True)
-    assert used[0] and not used[-1] and sharp._leaf_crowded and sharp._leaf_share > RNaD.LEAF_CROWDED, (used, sharp._leaf_share)
-    # ... and the learner on the distinct trajectories of a work item comes on long before DISTINCT_AFTER updates
+    assert all(used) and sharp._leaf_share > RNaD.DISTINCT_CROWDED, (used, sharp._leaf_share)
+    assert int(sharp.last_episodes.buckets.plan.leaf.col_count.abs().sum().item()) == 0, "the learner leaves the counters zero"
+    monkeypatch.setenv("RNAD_LEAF_CROWDED_LANES", "0")  # ... by the learner's (r05)
+    sharp0, used0 = run(True)
+    assert all(used0)
+    monkeypatch.delenv("RNAD_LEAF_CROWDED_LANES")
+    for (k, a), b in zip(sharp.net.named_parameters(), sharp0.net.parameters()):
+        assert torch.equal(a, b), k
+    # ... the watch still turns the learner on the distinct trajectories of a work item on long before DISTINCT_AFTER updates (it is what
+    # runs whenever the leaf learner does not)
     assert sharp._distinct_crowded and sharp._distinct_now() and sharp.total_steps < RNaD.DISTINCT_AFTER
     assert not flat.__dict__.get("_distinct_crowded", False) and not flat._distinct_now()
     assert all(torch.isfinite(p).all() for p in sharp.net.parameters())
