@@ -650,6 +650,28 @@ def side_legs(make_trainer, tree, args, device):
     except Exception as err:
         out["trained_policy_ms_per_step"] = {"error": str(err)[:300]}
     torch.cuda.empty_cache()
+    # the same sharp actor at 2^21 and 2^22 lanes with the learner RNaD picks there on its own -- the leaf paths of the tree (DESIGN.md
+    # section 5.6; r06: crowded buckets are counted by the rollout's work items, so a sharpened policy no longer ends it)
+    out["trained_policy_large_batches"] = {}
+    for log2 in (21, 22):
+        try:
+            tr = make_trainer(1 << log2, f"side-sharp{log2}")
+            with torch.no_grad():
+                for name, p_ in tr[0].net.named_parameters():
+                    if name.startswith("policy_fc1"):
+                        p_.mul_(40.0)
+            tr[0].invalidate_tables()
+            ms, rep, t = run(tr, steps=max(1, n // 2), prime=30)
+            ep = t.last_episodes
+            items = ep.buckets.items[: int(ep.buckets.n_items.item())]
+            per_bucket = torch.bincount(items[:, 2].long(), weights=items[:, 1].double())
+            out["trained_policy_large_batches"][f"2^{log2}"] = {
+                "ms_per_step": ms, "step_replayed_from_hipGraph": rep, "leaf_path_learner": getattr(ep.buckets.plan, "leaf", None) is not None,
+                "largest_bucket_share_of_lanes": float(per_bucket.max().item()) / (1 << log2)}
+            del t, tr
+        except Exception as err:
+            out["trained_policy_large_batches"][f"2^{log2}"] = {"error": str(err)[:300]}
+        torch.cuda.empty_cache()
     try:
         ms19, rep19, t = run(make_trainer(1 << 19, "side-b19"))
         del t

@@ -169,8 +169,7 @@ class TreeHandle:
             row, col = observe_all(self, self.device)
             tab = torch.cat([row, col], dim=0)
             setattr(self, key, tab.half() if half else tab)
-            if tab.is_cuda:  # a cache shared by every user of the handle, possibly on other streams: complete before anyone else sees it
-                torch.cuda.current_stream(tab.device).synchronize()
+            _publish_shared(tab.device)
         return getattr(self, key)
 
     def is_foldable_table(self, obs):
@@ -233,6 +232,7 @@ class TreeHandle:
             inside = pos < start[1:, None]
             got.multi_first = torch.where(inside, order[pos.clamp(max=max(order.numel() - 1, 0))] if order.numel() else pos, -torch.ones_like(pos)).to(I32).contiguous()
             got.c_groups = RowGroups(got.n_multi, got.multi_start.data_ptr(), got.multi_order.data_ptr(), got.multi_first.data_ptr())
+            _publish_shared(table.device)
             setattr(self, key, got)
         return got
 
@@ -248,6 +248,17 @@ class TreeHandle:
                 _destroy_deferred()
         except Exception:
             pass
+
+
+def _publish_shared(device):
+    """A cache kept on a tree handle is read by every user of the handle, possibly on other streams (two trainers of one tree on two
+    streams): whatever built it on the current stream is complete before anyone else can see it.  Not during a stream capture (a
+    synchronize would invalidate it; a captured step only ever meets caches its eager warm-up steps have built)."""
+    if device is None or torch.device(device).type != "cuda":
+        return
+    if torch.cuda.is_current_stream_capturing():
+        return
+    torch.cuda.current_stream(device).synchronize()
 
 
 class RowGroups(C.Structure):

@@ -118,15 +118,17 @@ def _steps(rn, buf, n, stream=None):
         rn.total_steps += 1
 
 
-@pytest.mark.parametrize("graph", (False, True))
-def test_two_trainers_on_two_streams_of_one_device(graph):
+# fresh: the two-stream trainers are the FIRST users of a tree handle of their own (r05 advisor: the solo runs used to warm every cache
+# kept on the shared handle -- observation table, distinct observations -- before the two streams met them)
+@pytest.mark.parametrize("graph,fresh", ((False, False), (True, False), (False, True)))
+def test_two_trainers_on_two_streams_of_one_device(graph, fresh):
     from environment.episode import Buffer
 
     tree = _tree()
     n = 12
     solo = []
     for seed in (7, 8):
-        rn = _rnad(tree, seed=seed, name=f"solo{seed}")
+        rn = _rnad(_tree() if fresh else tree, seed=seed, name=f"solo{seed}")
         rn.use_graph = graph
         _steps(rn, Buffer(1), n)
         torch.cuda.synchronize()

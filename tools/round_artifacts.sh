@@ -1,7 +1,7 @@
 #!/bin/bash
 # Everything the round's measurement row is judged on, from the CURRENT build, on the GPU box:  tools/round_artifacts.sh <tag>
 # Writes under gpurun_out/ (copy what should be kept into profiles/).
-tag=${1:-r05}
+tag=${1:-r06}
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd $R
 O=gpurun_out
@@ -25,6 +25,11 @@ RNAD_NO_GRAPH=1 tools/pmc_run.sh ${tag}_mfma "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_C
 # bench lines below already use it, and into gpurun_out/ for the way back; the static instruction mix and the class costs beside it
 python tools/pmc_json.py $O/pmc_${tag}_fetch.csv $O/pmc_${tag}_write.csv $O/pmc_${tag}_sq.csv $O/${tag}_pmc.json $O/pmc_${tag}_k1_fetch.csv $O/pmc_${tag}_k1_write.csv $O/pmc_${tag}_mfma.csv $O/pmc_${tag}_tcp.csv
 cp $O/${tag}_pmc.json profiles/${tag}_pmc.json
+# 3e. the same passes over the configs[3] step and over the 2^22-lane step (leaf-path pair: k_bucket_play_count + k_bucket_learn_c<WEIGHTED>)
+C4="--actions 5 --transitions 4 --depth 8 --prune 7 8 --threshold 0.1"
+tools/pmc_config.sh ${tag} c4 $C4 > $O/${tag}_pmc_c4.stdout 2>&1
+tools/pmc_config.sh ${tag} b22 --batch-log2 22 > $O/${tag}_pmc_b22.stdout 2>&1
+cp $O/${tag}_pmc_c4.json $O/${tag}_pmc_b22.json profiles/
 python tools/isa_mix.py --issue $O/${tag}_valu_issue.json > $O/${tag}_isa_mix.log 2>&1
 cp profiles/${tag}_isa_mix.json profiles/${tag}_valu_issue.json $O/
 # 1. headline bench (default flags) + the per-GPU share of an 8-GPU run + configs[3] + fp16 observations
@@ -38,6 +43,9 @@ bash tools/profile_bench.sh ${tag} --steps 300 > $O/${tag}_profile.log 2>&1
 tools/step_kernels.sh > $O/${tag}_step_kernels.txt 2>&1
 tools/step_kernels.sh --actions 5 --transitions 4 --depth 8 --prune 7 8 --threshold 0.1 > $O/${tag}_step_kernels_c4.txt 2>&1
 tools/step_kernels.sh --batch-log2 19 > $O/${tag}_step_kernels_b19.txt 2>&1
+tools/step_kernels.sh --batch-log2 22 > $O/${tag}_step_kernels_b22.txt 2>&1
+tools/step_kernels.sh --no-dedup > $O/${tag}a_step_kernels_nodedup.txt 2>&1
+RNAD_MLP_SPLIT=0 tools/step_kernels.sh --no-dedup > $O/${tag}a_step_kernels_nodedup_fp32.txt 2>&1
 python - <<PY
 import json
 for n in ("", "_b19", "_b22", "_c4", "_half"):
