@@ -146,16 +146,17 @@ struct Flag { static constexpr bool value = B; };
 
 // MODE 0: learner (both heads) + target (value head) -> tables + records;  1: the two value heads (logits from the table) -> tables +
 // records;  2: the learner's policy head -> logits + policy rows
-// WIDE (SPLIT with more than one block of 16 input features: A >= 4, and A = 3 without the fold): no dedicated record waves -- the first
+// WIDE (SPLIT with more than one block of 16 input features -- A >= 4, and A = 3 without the fold -- or with all three heads, MODE 0: the
+// 12-wave build of that one needs scratch): no dedicated record waves -- the first
 // kChunkSteps compute waves write the records of the previous chunk after their own phase 1 (r04 measured that arrangement 3 % behind
 // dedicated record waves) -- so that a workgroup is 8 waves, two per SIMD, and a wave may hold 256 registers: split weights (12 per hidden
 // tile and block), split inputs of two row tiles and the accumulators of TWO heads in flight (the next head's matrix products are issued
 // before the current head's epilogue: the bf16 matrix pipe runs beside the VALU) do not fit the 168 of a 12-wave workgroup.
-template <int A, bool FOLD, bool SPLIT>
-constexpr bool rows_wide() { return SPLIT && (MlpShape<A, FOLD>::K + 15) / 16 > 1; }
+template <int A, bool FOLD, bool SPLIT, int MODE>
+constexpr bool rows_wide() { return SPLIT && ((MlpShape<A, FOLD>::K + 15) / 16 > 1 || MODE == 0); }
 
 template <int A, typename ObsT, bool FOLD, int MODE, bool SPLIT = false>
-__global__ __launch_bounds__(64 * (kRowsMaxWaves + (rows_wide<A, FOLD, SPLIT>() ? 0 : kRecWaves))) void k_rows_forward_records(int64_t N, int W, RowsArgs g, const ObsT *__restrict__ obs,
+__global__ __launch_bounds__(64 * (kRowsMaxWaves + (rows_wide<A, FOLD, SPLIT, MODE>() ? 0 : kRecWaves))) void k_rows_forward_records(int64_t N, int W, RowsArgs g, const ObsT *__restrict__ obs,
                                                                                            rnad_learn_params_t hp) {
     if (g.n_rows) N = *g.n_rows;
     if (g.sp) {
@@ -169,7 +170,7 @@ __global__ __launch_bounds__(64 * (kRowsMaxWaves + (rows_wide<A, FOLD, SPLIT>() 
     constexpr int U = NV + (POLICY ? 1 : 0);           // hidden tiles per compute wave
     constexpr int U0 = VALUES ? 0 : 2;                 // first of them in the order learner value (0), target value (1), learner policy (2)
     const int T = W / kTile;                  // hidden tiles per head = compute waves of this workgroup
-    constexpr bool WIDE = rows_wide<A, FOLD, SPLIT>();
+    constexpr bool WIDE = rows_wide<A, FOLD, SPLIT, MODE>();
     constexpr bool STAGED = SPLIT;  // the chunk's observation rows go through LDS, loaded once per workgroup (below)
     const int nthreads = 64 * (T + (WIDE ? 0 : kRecWaves));
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, col = lane & 31, half = lane >> 5;
@@ -272,13 +273,15 @@ __global__ __launch_bounds__(64 * (kRowsMaxWaves + (rows_wide<A, FOLD, SPLIT>() 
     // computed) -> LDS buffer c & 1 (stage_store, at the end of that iteration, in front of its barrier).  Thread i takes the elements
     // i, i + nthreads, ... of the chunk's [kChunkRows][K] feature matrix: consecutive threads read consecutive floats of a row.
     constexpr int kStageThreads = 64 * (kRowsMaxWaves + (WIDE ? 0 : kRecWaves));  // (staged workgroups have kRowsMaxWaves compute waves: width 256)
+    const bool stages = true;
+    const int stage_tid = (int)threadIdx.x;
     constexpr int kStageMax = STAGED ? (kChunkRows * K + kStageThreads - 1) / kStageThreads : 1;
     float xst[kStageMax];
     auto stage_load = [&](int c) {
         const int64_t first = s_begin + (int64_t)c * kChunkRows;
 #pragma unroll
         for (int e = 0; e < kStageMax; ++e) {
-            const int i = threadIdx.x + e * nthreads;
+            const int i = stage_tid + e * kStageThreads;
             const int r = i / K, k = i % K;
             const int64_t sample = first + r;
             float v = 0.0f;
@@ -293,14 +296,14 @@ __global__ __launch_bounds__(64 * (kRowsMaxWaves + (rows_wide<A, FOLD, SPLIT>() 
         float *dst = xl + (c & 1) * (kChunkRows * XS);
 #pragma unroll
         for (int e = 0; e < kStageMax; ++e) {
-            const int i = threadIdx.x + e * nthreads;
+            const int i = stage_tid + e * kStageThreads;
             if (i < kChunkRows * K) dst[(i / K) * XS + (i % K)] = xst[e];
         }
     };
     if constexpr (STAGED) {
         for (int i = threadIdx.x; i < 2 * kChunkRows * XS; i += nthreads) xl[i] = 0.0f;  // (the features beyond K stay zero)
         __syncthreads();
-        if (n_chunks > 0) {
+        if (n_chunks > 0 && stages) {
             stage_load(0);
             stage_store(0);
         }
@@ -385,53 +388,9 @@ __global__ __launch_bounds__(64 * (kRowsMaxWaves + (rows_wide<A, FOLD, SPLIT>() 
             }
         }
     };
-    // SPLIT: the same heads, software-pipelined -- head u + 1's matrix products are in flight while head u's epilogue runs on the VALU
-    auto heads_split = [&](const Split8 (&xs0)[KBs], const Split8 (&xs1)[KBs], float (&out)[NOUT][2], auto pair_) {
-        constexpr bool PAIR = decltype(pair_)::value;
-        f32x16 c[2][2];
-        auto issue = [&](auto u_, f32x16 (&cc)[2]) {
-            constexpr int u = decltype(u_)::value;  // position in this wave's list of hidden tiles
-            constexpr int net_row = (POLICY && u == U - 1) ? 2 : u;  // row of bias_u / w1_u: learner value, target value, learner policy
-            chain_split<KBs, PAIR>(aw[u], bias_u + net_row * W, xs0, xs1, cc[0], cc[1]);
-        };
-        auto finish = [&](auto u_, f32x16 (&cc)[2]) {
-            constexpr int u = decltype(u_)::value;
-#if RNAD_ROWS_ABLATE & 8
-            if constexpr (POLICY && u == U - 1) {
-#pragma unroll
-                for (int a_ = 0; a_ < A; ++a_) { out[NV + a_][0] = cc[0][a_]; if constexpr (PAIR) out[NV + a_][1] = cc[1][a_]; }
-            } else { out[u][0] = cc[0][5]; if constexpr (PAIR) out[u][1] = cc[1][5]; }
-            return;
-#endif
-            if constexpr (POLICY && u == U - 1) {
-                f32x2 acc0[A][2], acc1[A][2];
-#pragma unroll
-                for (int a_ = 0; a_ < A; ++a_) acc0[a_][0] = acc0[a_][1] = acc1[a_][0] = acc1[a_][1] = f32x2{0.f, 0.f};
-                epilogue_policy<A>(cc[0], w1_u + 2 * W, W, acc0);
-                if constexpr (PAIR) epilogue_policy<A>(cc[1], w1_u + 2 * W, W, acc1);
-#pragma unroll
-                for (int a_ = 0; a_ < A; ++a_) {
-                    out[NV + a_][0] = lane_sum(acc0[a_]);
-                    if constexpr (PAIR) out[NV + a_][1] = lane_sum(acc1[a_]);
-                }
-            } else {
-                f32x2 acc0[2] = {f32x2{0.f, 0.f}, f32x2{0.f, 0.f}}, acc1[2] = {f32x2{0.f, 0.f}, f32x2{0.f, 0.f}};
-                epilogue_value(cc[0], w1_u + u * W, acc0);
-                if constexpr (PAIR) epilogue_value(cc[1], w1_u + u * W, acc1);
-                out[u][0] = lane_sum(acc0);
-                if constexpr (PAIR) out[u][1] = lane_sum(acc1);
-            }
-        };
-        issue(std::integral_constant<int, 0>{}, c[0]);
-        if constexpr (U > 1) issue(std::integral_constant<int, 1>{}, c[1]);
-        finish(std::integral_constant<int, 0>{}, c[0]);
-        if constexpr (U > 2) issue(std::integral_constant<int, 2>{}, c[0]);
-        if constexpr (U > 1) finish(std::integral_constant<int, 1>{}, c[1]);
-        if constexpr (U > 2) finish(std::integral_constant<int, 2>{}, c[0]);
-    };
     // SPLIT with more than one block of 16 features (A >= 4; A = 3 without the fold): the two row tiles of a step one after the other --
     // both tiles' split operands beside the split weights do not fit the 168 registers of a 12-wave workgroup
-    constexpr bool kSerialTiles = false;  // (r06: tried for the 12-wave workgroup -- it spilled more, not less; WIDE workgroups replaced it)
+    constexpr bool kSerialTiles = false;  // (r06: tried for the 12-wave workgroups -- the compiler overlapped the two passes and spilled more)
     auto p1_step = [&](int step, float *dst, auto two_) {
         constexpr bool TWO = decltype(two_)::value;
         float out[NOUT][2];  // [output][row tile]
@@ -449,7 +408,8 @@ __global__ __launch_bounds__(64 * (kRowsMaxWaves + (rows_wide<A, FOLD, SPLIT>() 
                 for (int j = 0; j < 8; ++j) { t0[j] = xn[0][8 * kb + j]; t1[8 * kb + j] = xn[1][8 * kb + j]; }
                 xs0[kb] = split8(t0);
             }
-            if (step + 1 < n_steps) fetch(step + 1);
+            if constexpr (!STAGED)
+                if (step + 1 < n_steps) fetch(step + 1);
             heads(x0, x1, xs0, xs1, out, Flag<false>{}, 0);
             if constexpr (TWO) {
 #pragma unroll
@@ -481,8 +441,8 @@ __global__ __launch_bounds__(64 * (kRowsMaxWaves + (rows_wide<A, FOLD, SPLIT>() 
 #pragma unroll
             for (int o = 0; o < NOUT; ++o) out[o][0] = out[o][1] = (SPLIT ? (float)xs0[0].h[0] + (float)xs1[0].l[1] : x0[0] + x1[0]);
 #else
-            if constexpr (SPLIT) heads_split(xs0, xs1, out, two_);
-            else heads(x0, x1, xs0, xs1, out, two_, 0);
+            // (r06: issuing the next head's products ahead of this head's epilogue -- two more accumulators -- measured no gain and spilled)
+            heads(x0, x1, xs0, xs1, out, two_, 0);
 #endif
         }
         // the two half-waves hold complementary hidden rows of the same 32 + 32 rows: half h keeps row tile h and gets the other
@@ -546,7 +506,7 @@ __global__ __launch_bounds__(64 * (kRowsMaxWaves + (rows_wide<A, FOLD, SPLIT>() 
     // iteration c: the compute waves are in phase 1 of chunk c, the record waves in phase 2 of chunk c - 1 (the other buffer)
     for (int c = 0; c <= n_chunks; ++c) {
         if constexpr (STAGED)
-            if (c + 1 < n_chunks) stage_load(c + 1);
+            if (c + 1 < n_chunks && stages) stage_load(c + 1);
         if (computes) {
             if (c < n_chunks) {
                 float *buf = part + (c & 1) * part_buf + (int64_t)wave * NOUT * 64 + lane;
@@ -568,7 +528,7 @@ __global__ __launch_bounds__(64 * (kRowsMaxWaves + (rows_wide<A, FOLD, SPLIT>() 
             }
         }
         if constexpr (STAGED)
-            if (c + 1 < n_chunks) stage_store(c + 1);
+            if (c + 1 < n_chunks && stages) stage_store(c + 1);
         __syncthreads();
     }
 }
@@ -614,7 +574,7 @@ static int rows_launch(const rnad_tree_t *tree, int W, int fold, const void *obs
     const bool split_env = !(split_e && atoi(split_e) == 0);
     const int K_in = fold ? ((A * A + 2) & ~1) : 2 * A * A;
     (void)K_in;
-    const bool split = split_env && A >= 2 && A <= 5 && (fold || A <= 3) && T == kRowsMaxWaves &&
+    const bool split = split_env && A >= 2 && A <= 5 && fold && T == kRowsMaxWaves &&
                        rows_lds_bytes(A, W, mode, fold, true) <= 160 * 1024;
     const size_t lds_bytes = rows_lds_bytes(A, W, mode, fold, split);  // (WIDE workgroups: kChunkSteps compute waves write the records)  // (A = 5 without the fold: 4 blocks of 16 features spill)
 #define RNAD_ROWS_LAUNCH4(T_, F_, M_, S_)                                                                                              \
@@ -622,7 +582,7 @@ static int rows_launch(const rnad_tree_t *tree, int W, int fold, const void *obs
         auto kern = k_rows_forward_records<kA, T_, F_, M_, S_>;                                                                        \
         if (lds_bytes > 64 * 1024)                                                                                                     \
             RNAD_HIP_OK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));          \
-        constexpr bool wide_ = rows_wide<kA, F_, S_>();                                                                                \
+        constexpr bool wide_ = rows_wide<kA, F_, S_, M_>();                                                                                \
         RNAD_REQUIRE(!S_ || T == kRowsMaxWaves, "rnad_mlp_rows: the split first layer needs a width of %d", kRowsMaxWaves * kTile); \
         hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64 * (T + (wide_ ? 0 : kRecWaves))), lds_bytes, stream, N, W, g, (const T_ *)obs, hp); \
     } while (0)
