@@ -570,11 +570,14 @@ static int rows_launch(const rnad_tree_t *tree, int W, int fold, const void *obs
     ProfScope prof(PROF_MLP, stream);
     // r06: the split-precision first layer (bf16 matrix rate, see chain_split) for the action counts of BASELINE.json's configurations;
     // RNAD_MLP_SPLIT=0 restores the fp32 MFMA chains (A/B runs, tests)
+    // RNAD_MLP_SPLIT: 0 = the fp32 MFMA chains everywhere, 1 = the split first layer wherever an instantiation without scratch exists; unset:
+    // where it pays -- first layers of more than 16 input features (A >= 4 with the fold: configs[3]'s value heads 61.6 -> 53.9 us).  At
+    // A = 3 it is a tie on all 132 862 rows of configs[1] (44.7 against 45.4 us) and a loss on the 13 676 distinct ones (13.7 against 11.8:
+    // one step per workgroup, all prologue), so the default step of configs[1] keeps the r05 kernel.
     const char *split_e = getenv("RNAD_MLP_SPLIT");
-    const bool split_env = !(split_e && atoi(split_e) == 0);
     const int K_in = fold ? ((A * A + 2) & ~1) : 2 * A * A;
-    (void)K_in;
-    const bool split = split_env && A >= 2 && A <= 5 && fold && T == kRowsMaxWaves &&
+    const bool split_wanted = split_e ? atoi(split_e) != 0 : (K_in + 15) / 16 > 1;
+    const bool split = split_wanted && A >= 2 && A <= 5 && fold && T == kRowsMaxWaves &&
                        rows_lds_bytes(A, W, mode, fold, true) <= 160 * 1024;
     const size_t lds_bytes = rows_lds_bytes(A, W, mode, fold, split);  // (WIDE workgroups: kChunkSteps compute waves write the records)  // (A = 5 without the fold: 4 blocks of 16 features spill)
 #define RNAD_ROWS_LAUNCH4(T_, F_, M_, S_)                                                                                              \

@@ -80,10 +80,16 @@ def test_fused_rows_fp16_observations_and_step_params():
     assert torch.equal(got["records"].view(torch.int32), out["records"].view(torch.int32))
 
 
+# split: RNAD_MLP_SPLIT -- None: the library's choice (r06: the split-precision first layer on rows staged in LDS where the first layer has
+# more than 16 input features, i.e. on "a5c4"; the fp32 chains at A = 3), "1" / "0": forced on (wherever a build without scratch exists) / off
+@pytest.mark.parametrize("split", (None, "1", "0"))
 @pytest.mark.parametrize("name", ("ternary4", "a5c4"))
-def test_fused_rows_with_a_row_list_and_the_logits_from_a_table(name):
+def test_fused_rows_with_a_row_list_and_the_logits_from_a_table(name, split, monkeypatch):
     """The lazy-rows variant: a staged actor wrote the learner's logits; the two value heads and the records on the listed rows only."""
     import rnad_hip as hip
+
+    if split is not None:
+        monkeypatch.setenv("RNAD_MLP_SPLIT", split)
     from test_hip_bucket import TREES, _native_tree
 
     tree = _native_tree(**TREES[name])
@@ -115,10 +121,14 @@ def test_fused_rows_with_a_row_list_and_the_logits_from_a_table(name):
     assert torch.equal(part["fast_records"].view(torch.int32), full["fast_records"].view(torch.int32))
 
 
-@pytest.mark.parametrize("depth,fold", ((6, True), (7, True), (6, False)))
-def test_fused_rows_full_size(depth, fold):
-    """configs[1] (2S = 132 862 rows: every workgroup's rows in one chunk) and a depth-7 tree (1.2 M rows: many chunks per workgroup)."""
+@pytest.mark.parametrize("depth,fold,split", ((6, True, None), (7, True, None), (6, False, None), (6, True, "1"), (7, True, "1")))
+def test_fused_rows_full_size(depth, fold, split, monkeypatch):
+    """configs[1] (2S = 132 862 rows: every workgroup's rows in one chunk) and a depth-7 tree (1.2 M rows: many chunks per workgroup);
+    split "1": the split-precision first layer forced on at A = 3 (8-wave workgroups, rows staged in LDS)."""
     import rnad_hip as hip
+
+    if split is not None:
+        monkeypatch.setenv("RNAD_MLP_SPLIT", split)
     from test_hip_bucket import _native_tree
 
     tree = _native_tree(A=3, C=1, depth=depth, seed=0)
