@@ -445,6 +445,9 @@ typedef struct rnad_row_groups {
     const int32_t *first;   /* optional (NULL: not given), device int32 [n_groups][4][64]: the group's first 256 rows once more, padded --
                              * first[g][k][l] = order[start[g] + 64 k + l] while that is a row of group g, else -1 -- so that k_bucket_finish
                              * requests a group's accumulators without walking start -> order first (r06) */
+    int32_t rows_below_cut; /* non-zero: the caller's `rows` list holds no row above the buckets (those are converted by the wave-per-row
+                             * workgroups whatever the list says), so the row threads skip the lookup of each row's bucket -- one dependent
+                             * load less on their path (r06) */
 } rnad_row_groups_t;
 
 /* *device_params = {seed, alpha, one_minus_alpha}, enqueued on `stream` (the values travel as kernel arguments: safe to call again

@@ -1858,6 +1858,7 @@ __device__ __forceinline__ long long round_to_ll(double d) {
 
 struct FixedPoint {
     double scale_l, scale_v;  // 2^f: units per 1.0 of an addend of dL/dlogit / dL/dv
+    double inv_l, inv_v;      // 2^-f: k_bucket_finish multiplies (exact: powers of two -- the bits of the division it replaces, without its ~30 fp64 instructions)
     float limit_l, limit_v;   // |addend| must stay below this (2^(62 - kLaneBits) units)
     float scale_l32, scale_v32;  // the same scales as floats (exact: powers of two)
     int check_l;                 // 2 * clip does not fit below limit_l (neurd_clip >= 2^29, e.g. "no clipping"): range-check every dL/dlogit addend
@@ -2511,7 +2512,8 @@ __global__ __launch_bounds__(kThreads) void k_bucket_finish(int64_t S, int row_b
                                                             float *__restrict__ dv_tab, int upper_blocks, int n_multi,
                                                             const int32_t *__restrict__ multi_start,
                                                             const int32_t *__restrict__ multi_order,
-                                                            const int32_t *__restrict__ multi_first, int32_t *__restrict__ alive_rep,
+                                                            const int32_t *__restrict__ multi_first, int rows_below_cut,
+                                                            int32_t *__restrict__ alive_rep,
                                                             double *__restrict__ norm_rep, int T1, int32_t *__restrict__ alive_out,
                                                             double *__restrict__ norm_out) {
     static_assert(kReplicas == 64, "one replica per lane");
@@ -2561,7 +2563,7 @@ __global__ __launch_bounds__(kThreads) void k_bucket_finish(int64_t S, int row_b
 #pragma unroll
             for (int k = 0; k < kFinishRows; ++k) {
                 const int64_t s = r[k] >= S ? r[k] - S : r[k];
-                on[k] = on[k] && !(n_upper > 0 && bucket_of[s] >= n_groups);  // (rows above the cut: the wave-per-row workgroups)
+                if (!rows_below_cut) on[k] = on[k] && !(n_upper > 0 && bucket_of[s] >= n_groups);  // (rows above the cut: the wave-per-row workgroups)
             }
 #pragma unroll
             for (int k = 0; k < kFinishRows; ++k)
@@ -2575,8 +2577,8 @@ __global__ __launch_bounds__(kThreads) void k_bucket_finish(int64_t S, int row_b
                     if (x[k][a] != 0) acc[r[k] * (A + 1) + a] = 0ull;
                 const float nf = r[k] >= S ? nf1 : nf0;
 #pragma unroll
-                for (int a = 0; a < A; ++a) dlogit_tab[r[k] * A + a] = bad ? nan : w_n * ((float)((double)x[k][a] / fx.scale_l) / nf);
-                dv_tab[r[k]] = bad ? nan : w_v * ((float)((double)x[k][A] / fx.scale_v) / nf);
+                for (int a = 0; a < A; ++a) dlogit_tab[r[k] * A + a] = bad ? nan : w_n * ((float)((double)x[k][a] * fx.inv_l) / nf);
+                dv_tab[r[k]] = bad ? nan : w_v * ((float)((double)x[k][A] * fx.inv_v) / nf);
             }
         }
     } else if ((int)blockIdx.x >= row_blocks + upper_blocks) {
@@ -2604,8 +2606,8 @@ __global__ __launch_bounds__(kThreads) void k_bucket_finish(int64_t S, int row_b
                         if (x[k][a] != 0) acc[r[k] * (A + 1) + a] = 0ull;
                     const float nf = r[k] >= S ? nf1 : nf0;
 #pragma unroll
-                    for (int a = 0; a < A; ++a) sum[a] += bad ? nan : w_n * ((float)((double)x[k][a] / fx.scale_l) / nf);
-                    sum[A] += bad ? nan : w_v * ((float)((double)x[k][A] / fx.scale_v) / nf);
+                    for (int a = 0; a < A; ++a) sum[a] += bad ? nan : w_n * ((float)((double)x[k][a] * fx.inv_l) / nf);
+                    sum[A] += bad ? nan : w_v * ((float)((double)x[k][A] * fx.inv_v) / nf);
                 }
             };
             int64_t rep_row;
@@ -2663,8 +2665,8 @@ __global__ __launch_bounds__(kThreads) void k_bucket_finish(int64_t S, int row_b
             if (c == 63) {
                 const float nf = P ? nf1 : nf0;
 #pragma unroll
-                for (int a = 0; a < A; ++a) dlogit_tab[r * A + a] = bad ? nan : w_n * ((float)((double)x[a] / fx.scale_l) / nf);
-                dv_tab[r] = bad ? nan : w_v * ((float)((double)x[A] / fx.scale_v) / nf);
+                for (int a = 0; a < A; ++a) dlogit_tab[r * A + a] = bad ? nan : w_n * ((float)((double)x[a] * fx.inv_l) / nf);
+                dv_tab[r] = bad ? nan : w_v * ((float)((double)x[A] * fx.inv_v) / nf);
             }
         }
     }
@@ -2711,6 +2713,8 @@ FixedPoint fixed_point_for(const rnad_learn_params_t &hp) {
     FixedPoint fx;
     fx.scale_l = std::ldexp(1.0, budget - e_l);
     fx.scale_v = std::ldexp(1.0, budget - e_v);
+    fx.inv_l = std::ldexp(1.0, -(budget - e_l));
+    fx.inv_v = std::ldexp(1.0, -(budget - e_v));
     fx.limit_l = (float)std::ldexp(1.0, e_l);
     fx.limit_v = (float)std::ldexp(1.0, e_v);
     fx.scale_l32 = (float)fx.scale_l;
@@ -3459,7 +3463,7 @@ int finish_impl(const rnad_tree_t *tree, const Plan &p, const double *norm, cons
                                                 losses_raw, losses, dlogit_tab, dv_tab, (int)upper_blocks, n_multi,
                                                 n_multi ? groups->start : (const int32_t *)nullptr,
                                                 n_multi ? groups->order : (const int32_t *)nullptr,
-                                                n_multi ? groups->first : (const int32_t *)nullptr, counts ? counts->alive_rep : (int32_t *)nullptr,
+                                                n_multi ? groups->first : (const int32_t *)nullptr, (groups && rows) ? groups->rows_below_cut : 0, counts ? counts->alive_rep : (int32_t *)nullptr,
                                                 counts ? counts->norm_rep : (double *)nullptr, counts ? counts->T1 : 0,
                                                 counts ? counts->alive_out : (int32_t *)nullptr, counts ? counts->norm_out : (double *)nullptr));
     RNAD_HIP_OK(hipGetLastError());

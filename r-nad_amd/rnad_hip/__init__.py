@@ -264,7 +264,7 @@ def _publish_shared(device):
 class RowGroups(C.Structure):
     """struct rnad_row_groups (include/rnad_hip.h)."""
 
-    _fields_ = [("n_groups", C.c_int32), ("start", C.c_void_p), ("order", C.c_void_p), ("first", C.c_void_p)]
+    _fields_ = [("n_groups", C.c_int32), ("start", C.c_void_p), ("order", C.c_void_p), ("first", C.c_void_p), ("rows_below_cut", C.c_int32)]
 
 
 class ObsDedup:
@@ -1562,7 +1562,21 @@ def _rows_and_groups(tree, buckets, rows, groups):
         return rows, None
     assert rows is None or rows is groups.singles, "with groups, the row list is the rows outside them"
     assert groups.n_rows == 2 * tree.S and groups.groups_below_cut(tree, buckets.plan)
-    return groups.singles, C.byref(groups.c_groups)
+    # r06: the singles BELOW the cut of this plan (the rows above it are converted by the finish's wave-per-row workgroups whatever the list
+    # says): with them listed apart the row threads need no per-row lookup of the row's bucket.  Cached per batch size.
+    below = groups.__dict__.setdefault("_singles_below", {})
+    if buckets.plan.B not in below:
+        bucket_of, n_groups = bucket_map(tree, buckets.plan.B)
+        dev = groups.singles.rows.device
+        upper = (bucket_of >= n_groups).to(dev)
+        r = groups.singles.rows[: int(groups.singles.count.item())].long()
+        keep = ~upper[torch.where(r >= tree.S, r - tree.S, r)]
+        lst = RowList(r[keep].to(I32), 2 * tree.S, dev)
+        c = RowGroups(groups.c_groups.n_groups, groups.c_groups.start, groups.c_groups.order, groups.c_groups.first, 1)
+        _publish_shared(dev)
+        below[buckets.plan.B] = (lst, c)
+    lst, c = below[buckets.plan.B]
+    return lst, C.byref(c)
 
 
 def clip_grad_norm(flat, max_norm):
