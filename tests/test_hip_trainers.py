@@ -169,3 +169,37 @@ def test_workspaces_go_with_their_trainer():
     del rn
     gc.collect()
     assert len(owners) == 0
+
+
+def test_a_sort_tile_the_scratch_was_not_sized_for_is_refused(monkeypatch):
+    """r05 advisor: csrc/bucket.hip reads RNAD_SORT_TILE on every call while the scratch buffer was sized by rnad_bucket_plan once -- a knob
+    that changed in between laid a larger histogram over the buffer.  Now the plan caches (C and Python) are keyed by the knobs, and the
+    entry points that write the scratch refuse a combination nobody asked the sizes of."""
+    import rnad_hip as hip
+    from environment.episode import Episodes
+    from nn.net import MLP
+
+    tree = _tree()
+    h = tree.handle()
+    B, T = 1 << 13, 2 * h.max_depth
+    monkeypatch.delenv("RNAD_SORT_TILE", raising=False)
+    plan = hip.bucket_plan(h, B)
+    torch.manual_seed(0)
+    net = MLP(3, 64, device=DEV)
+    ep = Episodes(tree, B, seed=5)
+    ep.generate(net, bucketed=True)
+    want = ep.indices[:, torch.argsort(ep.lane_ids.long())].clone()
+    other = 2048 if plan.sort_tile != 2048 else 4096
+    monkeypatch.setenv("RNAD_SORT_TILE", str(other))
+    # the C entry point with the OLD plan's scratch: refused, loudly
+    alive = torch.zeros((T + 1,), dtype=torch.int32, device=DEV)
+    norm = torch.zeros((2,), dtype=torch.float64, device=DEV)
+    with pytest.raises(hip.RnadHipError, match="rnad_bucket_plan"):
+        hip._check(hip.lib().rnad_bucket_alive(h.ptr, T, B, hip._dp(plan.scratch, torch.int32, "scratch"), hip._dp(alive, torch.int32, "alive"),
+                                               hip._dp(norm, torch.float64, "norm"), hip._stream()))
+    # through the binding: a plan of its own for the new knob, sized for it -- and the same episodes
+    again = hip.bucket_plan(h, B)
+    assert again is not plan and again.sort_tile == other and plan.sort_tile != other
+    ep2 = Episodes(tree, B, seed=5)
+    ep2.generate(net, bucketed=True)
+    assert torch.equal(ep2.indices[:, torch.argsort(ep2.lane_ids.long())], want)
