@@ -377,6 +377,9 @@ class RNaD:
         self.optimizer = self.__new_optimizer()
         self.optimizer.load_state_dict(saved["optimizer"])
         self._adopt_optimizer_state()
+        # (the checkpoint keeps the reference's keys, so the watch's verdict is not in it: _leaf_watch looks at the first batch it can read
+        # instead of waiting for the next multiple of LEAF_CHECK_EVERY -- a resumed run with a sharp policy has its learner within a step)
+        self._watch_due = True
         logging.info("resumed at m=%d n=%d (step %d)", m, n, self.total_steps)
 
     def _adopt_optimizer_state(self):
