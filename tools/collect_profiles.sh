@@ -18,7 +18,7 @@ done
 for n in "" _c4 _b19 _b22; do
   [ -f $O/${tag}_step_kernels$n.txt ] && grep -v "rocprofv3\|simple_timer\|amdgpu.ids" $O/${tag}_step_kernels$n.txt > $P/${tag}_step_kernels$n.txt
 done
-for n in nodedup nodedup_fp32; do
+for n in nodedup nodedup_split; do
   [ -f $O/${tag}a_step_kernels_$n.txt ] && grep -v "rocprofv3\|simple_timer\|amdgpu.ids" $O/${tag}a_step_kernels_$n.txt > $P/${tag}a_step_kernels_$n.txt
 done
 [ -f $O/parity_errors.json ] && cp $O/parity_errors.json $P/${tag}_parity_errors.json

@@ -44,8 +44,9 @@ tools/step_kernels.sh > $O/${tag}_step_kernels.txt 2>&1
 tools/step_kernels.sh --actions 5 --transitions 4 --depth 8 --prune 7 8 --threshold 0.1 > $O/${tag}_step_kernels_c4.txt 2>&1
 tools/step_kernels.sh --batch-log2 19 > $O/${tag}_step_kernels_b19.txt 2>&1
 tools/step_kernels.sh --batch-log2 22 > $O/${tag}_step_kernels_b22.txt 2>&1
+# (the MLP launches on all 2S rows: the fp32 first layer -- the default at A = 3 -- and the split-precision one forced on)
 tools/step_kernels.sh --no-dedup > $O/${tag}a_step_kernels_nodedup.txt 2>&1
-RNAD_MLP_SPLIT=0 tools/step_kernels.sh --no-dedup > $O/${tag}a_step_kernels_nodedup_fp32.txt 2>&1
+RNAD_MLP_SPLIT=1 tools/step_kernels.sh --no-dedup > $O/${tag}a_step_kernels_nodedup_split.txt 2>&1
 python - <<PY
 import json
 for n in ("", "_b19", "_b22", "_c4", "_half"):
