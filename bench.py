@@ -135,7 +135,9 @@ def main():
                          "record tables, all-reduce of the 64-bit per-row sums); default: every rank evaluates all rows")
     ap.add_argument("--obs-half", action="store_true", help="fp16 observations (BASELINE configs[4])")
     ap.add_argument("--other-steps", type=int, default=20, help="timed steps of each entry of other_modes and of the eager kernel-timing leg")
-    ap.add_argument("--cpu-lanes-log2", type=int, default=18, help="episodes per step of the CPU-baseline sample (C port)")
+    ap.add_argument("--cpu-lanes-log2", type=int, default=None,
+                    help="episodes per step of the CPU-baseline sample (C port); default: the benchmarked batch itself up to 2^20 (r06: one full "
+                         "2^20-lane step of the port takes ~25 s on 16 host threads -- r05: 65 s, hence its 2^18-lane sample)")
     ap.add_argument("--cpu-torch-lanes-log2", type=int, default=16, help="episodes per step of the CPU-baseline sample (plain PyTorch-CPU leg)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-side-legs", action="store_true",
@@ -982,6 +984,8 @@ def cpu_baseline(tree, args, T):
     cores = CPU_THREADS
     torch.set_num_threads(cores)
     ct = CpuTrainer(arrs, width=args.width, chunk_rows=1 << 14)  # (r06: the MLP in cache-sized row chunks -- 4.6x faster updates than whole-batch matrices)
+    if args.cpu_lanes_log2 is None:
+        args.cpu_lanes_log2 = min(args.batch_log2, 20)
     lanes = 1 << args.cpu_lanes_log2
     ct.step(min(lanes, 4096), seed=0)  # warm-up (thread pools, page faults)
     t0 = time.perf_counter()

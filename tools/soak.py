@@ -55,7 +55,7 @@ def main():
             ok = all(bool(torch.isfinite(p).all()) for net in (rn.net, rn.net_target) for p in net.parameters())
             print(f"step {i + 1}: finite={ok} {1e3 * (time.perf_counter() - t0) / (i + 1):.4f} ms/step "
                   f"graph={rn._graph is not None and rn._graph.get('graph') is not None} "
-                  f"leaf={getattr(rn.last_episodes.buckets.plan, 'leaf', None) is not None and not rn.__dict__.get('_leaf_crowded', False)} "
+                  f"leaf={getattr(rn.last_episodes.buckets.plan, 'leaf', None) is not None } "
                   f"largest_bucket_share={rn.__dict__.get('_leaf_share')}", flush=True)
             if not ok:
                 raise SystemExit("parameters are not finite")
