@@ -87,6 +87,26 @@ __global__ __launch_bounds__(kOptThreads) void k_optimizer_step(OptTensors ts, c
     const int64_t i = (int64_t)blockIdx.x * kOptThreads + threadIdx.x;
     const float g_own = i < n ? grads[i] : 0.0f;
     double s = 0.0;
+    // r06: 16-byte loads where the bucket allows (one round trip for buckets of up to 32 K floats -- configs[3]'s 27 653 took four batches of
+    // 4-byte loads); the squares are added in the order of the elements a thread holds either way, so a run is reproducible, and the
+    // per-thread partition is part of the kernel's own (documented) summation order
+    if ((reinterpret_cast<uintptr_t>(grads) & 15) == 0) {
+        const int64_t n4 = n / 4;
+        const float4 *g4 = reinterpret_cast<const float4 *>(grads);
+        for (int64_t base = threadIdx.x; base < n4; base += (int64_t)kOptThreads * kNormBatch) {
+            float4 g[kNormBatch];
+#pragma unroll
+            for (int u = 0; u < kNormBatch; ++u) {
+                const int64_t e = base + (int64_t)u * kOptThreads;
+                g[u] = e < n4 ? g4[e] : float4{0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int u = 0; u < kNormBatch; ++u)
+                s += ((double)g[u].x * (double)g[u].x + (double)g[u].y * (double)g[u].y) + ((double)g[u].z * (double)g[u].z + (double)g[u].w * (double)g[u].w);
+        }
+        const int64_t e = 4 * n4 + threadIdx.x;  // (the last n % 4 elements)
+        if (e < n) s += (double)grads[e] * (double)grads[e];
+    } else
     for (int64_t base = threadIdx.x; base < n; base += (int64_t)kOptThreads * kNormBatch) {
         float g[kNormBatch];
 #pragma unroll
