@@ -146,12 +146,11 @@ struct Flag { static constexpr bool value = B; };
 
 // MODE 0: learner (both heads) + target (value head) -> tables + records;  1: the two value heads (logits from the table) -> tables +
 // records;  2: the learner's policy head -> logits + policy rows
-// WIDE (SPLIT with more than one block of 16 input features -- A >= 4, and A = 3 without the fold -- or with all three heads, MODE 0: the
-// 12-wave build of that one needs scratch): no dedicated record waves -- the first
-// kChunkSteps compute waves write the records of the previous chunk after their own phase 1 (r04 measured that arrangement 3 % behind
-// dedicated record waves) -- so that a workgroup is 8 waves, two per SIMD, and a wave may hold 256 registers: split weights (12 per hidden
-// tile and block), split inputs of two row tiles and the accumulators of TWO heads in flight (the next head's matrix products are issued
-// before the current head's epilogue: the bf16 matrix pipe runs beside the VALU) do not fit the 168 of a 12-wave workgroup.
+// WIDE (SPLIT with more than one block of 16 input features -- A >= 4 -- or with all three heads, MODE 0, whose 12-wave build needs scratch:
+// a build with scratch wrote wrong records): no dedicated record waves -- the first kChunkSteps compute waves write the
+// records of the previous chunk after their own phase 1 (r04 measured that arrangement 3 % behind dedicated record waves) -- so that a
+// workgroup is 8 waves, two per SIMD, and a wave may hold 256 registers: split weights (12 per hidden tile and block) and the split inputs of
+// two row tiles do not fit the 168 of a 12-wave workgroup.
 template <int A, bool FOLD, bool SPLIT, int MODE>
 constexpr bool rows_wide() { return SPLIT && ((MlpShape<A, FOLD>::K + 15) / 16 > 1 || MODE == 0); }
 
@@ -180,10 +179,10 @@ __global__ __launch_bounds__(64 * (kRowsMaxWaves + (rows_wide<A, FOLD, SPLIT, MO
     float *w1 = lds + 3 * W;         // [2 + A][W] second-layer rows: learner value | target value | learner policy [A]
     float *part = w1 + (2 + A) * W;  // [2][kChunkSteps][T][NOUT][64] partial sums; before the first step: the indicator weights [U][W]
     const int part_buf = kChunkSteps * T * NOUT * 64;
-    // WIDE: the observation rows of a chunk, staged ONCE per workgroup -- [2 buffers][kChunkRows][XS] floats behind the partial sums.  r06,
+    // STAGED: the observation rows of a chunk, staged ONCE per workgroup -- [2 buffers][kChunkRows][XS] floats behind the partial sums.  r06,
     // measured: every compute wave fetching its own copy of the rows (8 waves x 10 scattered 4-byte loads per step) kept the CU's vector L1
     // busy 0.87 of the launch (TCP_TOTAL_CACHE_ACCESSES 23.8 M per configs[3] launch, the most of any kernel of the step) and was what
-    // the launch waited for: the split first layer alone changed nothing (profiles/r06_rows_ablate.md).
+    // the launch waited for: the split first layer alone changed nothing (profiles/r06_experiments.md).
     constexpr int kChunkRows = kChunkSteps * 2 * kTile;
     constexpr int KBx = (K + 15) / 16, XS = 16 * KBx + 4;  // floats per staged row: the features padded to whole blocks of 16, + 4 (bank spread of the 32-byte reads)
     float *xl = part + 2 * part_buf;
@@ -269,7 +268,7 @@ __global__ __launch_bounds__(64 * (kRowsMaxWaves + (rows_wide<A, FOLD, SPLIT, MO
     const int n_steps = (int)((my_tiles + 1) / 2);
     const int n_chunks = (n_steps + kChunkSteps - 1) / kChunkSteps;
 
-    // WIDE: chunk c's rows -> registers (stage_load, at the start of the iteration before: the loads travel while the chunk before is
+    // STAGED: chunk c's rows -> registers (stage_load, at the start of the iteration before: the loads travel while the chunk before is
     // computed) -> LDS buffer c & 1 (stage_store, at the end of that iteration, in front of its barrier).  Thread i takes the elements
     // i, i + nthreads, ... of the chunk's [kChunkRows][K] feature matrix: consecutive threads read consecutive floats of a row.
     constexpr int kStageThreads = 64 * (kRowsMaxWaves + (WIDE ? 0 : kRecWaves));  // (staged workgroups have kRowsMaxWaves compute waves: width 256)
@@ -388,9 +387,6 @@ __global__ __launch_bounds__(64 * (kRowsMaxWaves + (rows_wide<A, FOLD, SPLIT, MO
             }
         }
     };
-    // SPLIT with more than one block of 16 features (A >= 4; A = 3 without the fold): the two row tiles of a step one after the other --
-    // both tiles' split operands beside the split weights do not fit the 168 registers of a 12-wave workgroup
-    constexpr bool kSerialTiles = false;  // (r06: tried for the 12-wave workgroups -- the compiler overlapped the two passes and spilled more)
     auto p1_step = [&](int step, float *dst, auto two_) {
         constexpr bool TWO = decltype(two_)::value;
         float out[NOUT][2];  // [output][row tile]
@@ -399,29 +395,7 @@ __global__ __launch_bounds__(64 * (kRowsMaxWaves + (rows_wide<A, FOLD, SPLIT, MO
         float x0[KSr], x1[KSr];
         Split8 xs0[KBs], xs1[KBs];
         if constexpr (STAGED) fetch(step);  // (from the staged rows in LDS: no prefetch across steps)
-        if constexpr (kSerialTiles) {
-            float t1[XN];  // the second tile's raw features: kept while the next step's loads go out
-#pragma unroll
-            for (int kb = 0; kb < KB; ++kb) {
-                float t0[8];
-#pragma unroll
-                for (int j = 0; j < 8; ++j) { t0[j] = xn[0][8 * kb + j]; t1[8 * kb + j] = xn[1][8 * kb + j]; }
-                xs0[kb] = split8(t0);
-            }
-            if constexpr (!STAGED)
-                if (step + 1 < n_steps) fetch(step + 1);
-            heads(x0, x1, xs0, xs1, out, Flag<false>{}, 0);
-            if constexpr (TWO) {
-#pragma unroll
-                for (int kb = 0; kb < KB; ++kb) {
-                    float t0[8];
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) t0[j] = t1[8 * kb + j];
-                    xs0[kb] = split8(t0);
-                }
-                heads(x0, x1, xs0, xs1, out, Flag<false>{}, 1);
-            }
-        } else {
+        {
             if constexpr (SPLIT) {
 #pragma unroll
                 for (int kb = 0; kb < KB; ++kb) {
@@ -536,7 +510,7 @@ __global__ __launch_bounds__(64 * (kRowsMaxWaves + (rows_wide<A, FOLD, SPLIT, MO
 size_t rows_lds_bytes(int A, int W, int mode, int fold = 0, bool split = false) {
     const int T = W / kTile, nout = (mode != 2 ? 2 : 0) + (mode != 1 ? A : 0);
     const int K = fold ? ((A * A + 2) & ~1) : 2 * A * A;
-    const size_t staged = split ? (size_t)2 * (kChunkSteps * 2 * kTile) * (16 * ((K + 15) / 16) + 4) : 0;  // (WIDE: two chunks of staged rows)
+    const size_t staged = split ? (size_t)2 * (kChunkSteps * 2 * kTile) * (16 * ((K + 15) / 16) + 4) : 0;  // (two chunks of staged rows)
     return ((size_t)3 * W + (size_t)(2 + A) * W + (size_t)2 * kChunkSteps * T * nout * 64 + staged) * sizeof(float);
 }
 
@@ -568,8 +542,7 @@ static int rows_launch(const rnad_tree_t *tree, int W, int fold, const void *obs
     const int64_t n_tiles = (N + kTile - 1) / kTile;
     const int64_t grid = std::max<int64_t>(1, std::min<int64_t>((n_tiles + 1) / 2, cus));  // one persistent workgroup per CU
     ProfScope prof(PROF_MLP, stream);
-    // r06: the split-precision first layer (bf16 matrix rate, see chain_split) for the action counts of BASELINE.json's configurations;
-    // RNAD_MLP_SPLIT=0 restores the fp32 MFMA chains (A/B runs, tests)
+    // r06: the split-precision first layer on rows staged in LDS (chain_split, STAGED).
     // RNAD_MLP_SPLIT: 0 = the fp32 MFMA chains everywhere, 1 = the split first layer wherever an instantiation without scratch exists; unset:
     // where it pays -- first layers of more than 16 input features (A >= 4 with the fold: configs[3]'s value heads 61.6 -> 53.9 us).  At
     // A = 3 it is a tie on all 132 862 rows of configs[1] (44.7 against 45.4 us) and a loss on the 13 676 distinct ones (13.7 against 11.8:
@@ -579,7 +552,7 @@ static int rows_launch(const rnad_tree_t *tree, int W, int fold, const void *obs
     const bool split_wanted = split_e ? atoi(split_e) != 0 : (K_in + 15) / 16 > 1;
     const bool split = split_wanted && A >= 2 && A <= 5 && fold && T == kRowsMaxWaves &&
                        rows_lds_bytes(A, W, mode, fold, true) <= 160 * 1024;
-    const size_t lds_bytes = rows_lds_bytes(A, W, mode, fold, split);  // (WIDE workgroups: kChunkSteps compute waves write the records)  // (A = 5 without the fold: 4 blocks of 16 features spill)
+    const size_t lds_bytes = rows_lds_bytes(A, W, mode, fold, split);
 #define RNAD_ROWS_LAUNCH4(T_, F_, M_, S_)                                                                                              \
     do {                                                                                                                               \
         auto kern = k_rows_forward_records<kA, T_, F_, M_, S_>;                                                                        \
