@@ -63,7 +63,8 @@ def _trainer(tree, B, width, lazy, leaf=None):
 @pytest.mark.parametrize("depth,log2_B,width,lazy,K,leaf",
                          ((4, 14, 64, False, 8, None), (4, 16, 256, False, 8, None), (6, 16, 256, False, 8, None), (6, 18, 256, False, 8, None),
                           (6, 16, 256, None, 8, None), ("pruned", 14, 64, True, 8, None), ("a5c4", 14, 64, True, 8, None),
-                          ("pruned", 14, 64, False, 8, None), pytest.param(6, 19, 256, False, 4, True, marks=pytest.mark.last),
+                          ("pruned", 14, 64, False, 8, None), ("a5c4", 14, 256, True, 8, None),  # (width 256: the split-precision value heads of configs[3])
+                          pytest.param(6, 19, 256, False, 4, True, marks=pytest.mark.last),
                           pytest.param(6, 20, 256, False, 4, None, marks=pytest.mark.last)))
 def test_default_step_trains_like_the_cpu_port(depth, log2_B, width, lazy, K, leaf):
     from environment.episode import Buffer
