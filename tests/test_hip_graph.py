@@ -373,3 +373,60 @@ def test_the_learner_on_distinct_trajectories_trains_like_the_per_lane_learner(t
     assert seeds_off == seeds_on == seeds_auto
     for a, b, c in zip(nets_off, nets_on, nets_auto):
         assert torch.equal(a, b) and torch.equal(a, c)
+
+
+def test_every_automatic_switch_in_one_run_trains_like_the_plain_learner(tmp_path, monkeypatch):
+    """The step picks its learner by itself -- the tree's leaf paths, the one launch per lane, the one launch on the distinct trajectories of a
+    work item after DISTINCT_AFTER updates -- and leaves the captured graph for logging steps.  Each pair of modes is tested on its own; here
+    they all switch inside ONE run (leaf paths -> a logging step -> replays -> leaf paths forced off: per lane -> a rotation of the
+    regularisation nets -> distinct trajectories, a re-capture -> another logging step -> replays), against a trainer that takes the per-lane
+    learner eagerly throughout.  Integer per-row sums in every learner, the same nets on the same distinct observations in both runs: the
+    same parameters, bit for bit."""
+    import os
+
+    from environment.episode import Buffer
+    from learn.rnad import RNaD
+    from test_hip_bucket import TREES, _native_tree
+
+    tree = _native_tree(**TREES["ternary4"])
+    h = tree.handle()
+    B, steps = 1 << 14, 18
+    monkeypatch.setattr(RNaD, "DISTINCT_AFTER", 11)
+
+    def run(switching, tag):
+        os.environ["RNAD_SAVE_DIR"] = str(tmp_path)
+        torch.manual_seed(7)
+        rn = RNaD(tree=tree, device=DEV, directory_name=f"soup{tag}", batch_size=B, eta=0.2, b1_adam=0.0, lr=1e-3,
+                  net_params={"type": "MLP", "max_actions": tree.max_actions, "width": 64})
+        rn.initialize()
+        rn.tabular_gate = 0
+        rn.use_graph = switching
+        if not switching:
+            rn.leaf_paths, rn.distinct_trajectories = False, False
+        with torch.no_grad():
+            for p in rn.net_reg_.parameters():
+                p.mul_(1.01)
+        buf = Buffer(1)
+        seen = []
+        for i in range(steps):
+            if i == 8:  # rnad.py:528-531
+                rn.net_reg_.load_state_dict(rn.net_reg.state_dict())
+                rn.net_reg.load_state_dict(rn.net_target.state_dict())
+            if switching and i == 6:
+                rn.leaf_paths = False
+            log = {} if i in (4, 13) else None
+            rn.train_step(buf, alpha=min(1.0, 0.1 * i), log=log)
+            g = rn.__dict__.get("_graph") or {}
+            seen.append((rn._leaf_now(h, B, 2 * h.max_depth) is not None, bool(rn._distinct_now()), g.get("graph") is not None and log is None))
+            rn.total_steps += 1
+        torch.cuda.synchronize()
+        return rn, [p.detach().clone() for n in (rn.net, rn.net_target) for p in n.parameters()], seen
+
+    auto, nets_auto, seen = run(True, "a")
+    plain, nets_plain, _ = run(False, "p")
+    leaf, distinct, replayed = zip(*seen)
+    assert all(leaf[:6]) and not any(leaf[6:]), leaf                      # the leaf-path learner, then the one launch per lane
+    assert not any(distinct[:10]) and all(distinct[11:]), distinct        # ... then the distinct trajectories of a work item
+    assert replayed[3] and not replayed[4] and replayed[9] and replayed[-1], replayed  # replays around the eager logging steps and the re-captures
+    for a, b in zip(nets_auto, nets_plain):
+        assert torch.equal(a, b)
