@@ -83,10 +83,12 @@ class _LossV(torch.autograd.Function):
 
 def get_loss_v(v_list: Sequence[torch.Tensor], v_target_list: Sequence[torch.Tensor], mask_list: Sequence[torch.Tensor]) -> torch.Tensor:
     """Critic loss sum_k sum(mask_k (v_k - target_k)^2) / max(sum(mask_k), 1).  reference learn/vtrace.py:377-393.
-    Differentiable w.r.t. `v` (closed-form gradient).  As at the reference's call site (learn/rnad.py:407) every entry
-    of v_list must be the same tensor."""
-    assert all(v is v_list[0] for v in v_list), "get_loss_v: the kernel path expects v_list == [v] * n"
-    return _LossV.apply(v_list[0], list(v_target_list), list(mask_list))
+    Differentiable w.r.t. every entry of `v_list` (closed-form gradient).  At the reference's call site (learn/rnad.py:407) every entry
+    is the same tensor: one pass of the kernel per player over it, one gradient buffer; distinct tensors (r06: the full signature) take
+    one call per entry and the losses are added as the reference adds them (:393)."""
+    if all(v is v_list[0] for v in v_list):
+        return _LossV.apply(v_list[0], list(v_target_list), list(mask_list))
+    return sum(_LossV.apply(v, [vt], [m]) for v, vt, m in zip(v_list, v_target_list, mask_list))
 
 
 class _LossNerd(torch.autograd.Function):
@@ -122,10 +124,17 @@ def get_loss_nerd(
     threshold: float = 2,
 ) -> torch.Tensor:
     """NeuRD loss.  reference learn/vtrace.py:396-431.  Differentiable w.r.t. `logit` (the force is detached there too).
-    The per-row importance weights multiply the advantage before clipping; since adv is linear in q they are folded
-    into q (`is_c * q`), which is exact for the all-ones weights the reference passes (learn/rnad.py:409-410)."""
+    The importance weights multiply the advantage before clipping (:416); a weight per ROW (a scalar, or a last dimension of 1, as the
+    reference passes: learn/rnad.py:409-410) commutes with the advantage -- adv is linear in q -- and is folded into q (`is_c * q`); a
+    weight per ACTION does not commute and is refused.  At the reference's call site every entry of logit_list is the same tensor: one
+    kernel pass per player over it; distinct tensors (r06: the full signature) take one call per entry, the losses added as at :431."""
     assert isinstance(importance_sampling_correction, list)
-    assert all(l is logit_list[0] for l in logit_list), "get_loss_nerd: the kernel path expects logit_list == [logit] * n"
+    for is_c in importance_sampling_correction:
+        assert not torch.is_tensor(is_c) or is_c.dim() == 0 or is_c.shape[-1] == 1, \
+            "get_loss_nerd: importance weights per action are not supported (one weight per row, shape [..., 1], or a scalar)"
     qs = [q * is_c for q, is_c in zip(q_vr_list, importance_sampling_correction)]
     masks = [valid * (player_ids == k) for k in range(len(logit_list))]
-    return _LossNerd.apply(logit_list[0], list(policy_list), qs, masks, legal_actions, float(clip), float(threshold))
+    if all(l is logit_list[0] for l in logit_list):
+        return _LossNerd.apply(logit_list[0], list(policy_list), qs, masks, legal_actions, float(clip), float(threshold))
+    return sum(_LossNerd.apply(lg, [pi], [q], [m], legal_actions, float(clip), float(threshold))
+               for lg, pi, q, m in zip(logit_list, policy_list, qs, masks))

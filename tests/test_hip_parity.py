@@ -640,3 +640,59 @@ def test_reference_test_nashconv_semantics(G, A):
     assert (data.row_best[1] + data.col_best[1]).item() == 0
     # the reference asserts == 2 exactly; mixed solutions such as (1/3, 1/3, 1/3) sum to 2 only up to fp32 rounding
     assert abs(torch.sum(data.reach_probability).item() - 2) < 1e-6
+
+
+def test_loss_wrappers_take_the_full_signature(G):
+    """get_loss_v / get_loss_nerd with a DIFFERENT tensor per list entry and non-trivial per-row importance weights (the reference's only call
+    site passes the same tensor twice and weights of one, learn/rnad.py:407-422; r05 asserted exactly that) against the formulas of
+    learn/vtrace.py:352-431 evaluated with torch's autograd on the same device, in float64."""
+    import learn.vtrace as vtrace
+
+    torch.manual_seed(3)
+    T, B, A = 5, 257, 3
+    dev = G.DEV
+    valid = (torch.rand((T, B), device=dev) > 0.2).float()
+    pid = torch.randint(0, 2, (T, B), device=dev)
+    legal = (torch.rand((T, B, A), device=dev) > 0.25).float()
+    legal[..., 0] = 1.0
+    vs = [torch.randn((T, B, 1), device=dev, requires_grad=True) for _ in range(2)]
+    vts = [torch.randn((T, B, 1), device=dev) for _ in range(2)]
+    hps = [(torch.rand((T, B), device=dev) > 0.5).float() for _ in range(2)]
+    logits = [torch.randn((T, B, A), device=dev, requires_grad=True) for _ in range(2)]
+    pis = [torch.softmax(torch.randn((T, B, A), device=dev), -1) for _ in range(2)]
+    qs = [torch.randn((T, B, A), device=dev) for _ in range(2)]
+    isc = [0.5 + torch.rand((T, B, 1), device=dev) for _ in range(2)]
+    clip, thr = 0.7, 0.9
+
+    def reference(vs, logits):
+        d = torch.float64
+        loss = 0.0
+        for v, vt, m in zip(vs, vts, hps):
+            n = m.to(d).sum()
+            loss = loss + (m.to(d).unsqueeze(-1) * (v.to(d) - vt.to(d)) ** 2).sum() / (n + (n == 0))
+        loss_n = 0.0
+        for k, (lg, pi, q, c) in enumerate(zip(logits, pis, qs, isc)):
+            q, pi, lg64, lgl = q.to(d), pi.to(d), lg.to(d), legal.to(d)
+            adv = (c.to(d) * (q - (pi * q).sum(-1, keepdim=True))).clamp(-clip, clip).detach()
+            z = lg64 - (lg64 * lgl).mean(-1, keepdim=True)
+            force = ((z > -thr) * adv.clamp(max=0.0) + (z < thr) * adv.clamp(min=0.0)).detach()
+            row = (lgl * z * force).sum(-1)
+            m = (valid * (pid == k)).to(d)
+            n = m.sum()
+            loss_n = loss_n - (row * m).sum() / (n + (n == 0))
+        return loss, loss_n
+
+    got_v = vtrace.get_loss_v(vs, vts, hps)
+    got_n = vtrace.get_loss_nerd(logits, pis, qs, valid, pid, legal, isc, clip=clip, threshold=thr)
+    (got_v + got_n).backward()
+    got_grads = [x.grad.clone() for x in vs + logits]
+    for x in vs + logits:
+        x.grad = None
+    want_v, want_n = reference(vs, logits)
+    (want_v + want_n).backward()
+    np.testing.assert_allclose(got_v.item(), want_v.item(), rtol=TOL)
+    np.testing.assert_allclose(got_n.item(), want_n.item(), rtol=TOL, atol=1e-7)
+    for got, x in zip(got_grads, vs + logits):
+        np.testing.assert_allclose(G.cpu(got), G.cpu(x.grad), rtol=TOL, atol=1e-8)
+    with pytest.raises(AssertionError, match="per action"):
+        vtrace.get_loss_nerd(logits, pis, qs, valid, pid, legal, [torch.ones((T, B, A), device=dev)] * 2, clip=clip, threshold=thr)
